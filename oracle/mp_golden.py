@@ -1,0 +1,369 @@
+"""Generate tests/golden/mp_*.json: 50-digit mpmath evaluation of the hot-path formulas.
+
+TEST INFRASTRUCTURE.  This is an *independent* scalar-loop restatement (no NumPy
+broadcasting, no code shared with oracle/vbmc_ref.py) of the reference formulas,
+evaluated with mpmath at 50 significant digits on tiny shapes.  Its outputs are the
+committed golden vectors that pin the NumPy/C oracles and the HIP path to ~1e-12.
+
+Formulas follow (reference paths, acerbilab/vbmc v1.0.12):
+  entmc    ent/entmc_vbmc.m:49-125
+  entlb    ent/entlb_vbmc.m:66-141
+  logjoint misc/gplogjoint.m:97-413 (negquad mean, meanfun id 4; also 0 and 1)
+  gp_post  gplite/private/gplite_core.m:33-102,278-291
+  gp_pred  gplite/gplite_pred.m:52-165
+
+Run:  python oracle/mp_golden.py   (writes tests/golden/mp_case*.json)
+The inputs are drawn with numpy default_rng(seed) and stored in the JSON next to
+the expected outputs, so the fixtures are self-contained data.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+
+mp.mp.dps = 50
+
+
+def M(x):
+    return mp.mpf(float(x))
+
+
+def softmax_jac(eta):
+    K = len(eta)
+    e = [mp.e ** t for t in eta]
+    ssum = mp.fsum(e)
+    J = [[-(e[a] * e[b]) / ssum**2 + (e[a] / ssum if a == b else 0) for b in range(K)] for a in range(K)]
+    return J
+
+
+def matvec(J, v):
+    return [mp.fsum(J[a][b] * v[b] for b in range(len(v))) for a in range(len(J))]
+
+
+# ------------------------------------------------------------------ entmc
+def mp_entmc(mu, sigma, lam, w, eta, eps):
+    """mu[d][k], sigma[k], lam[d], w[k], eta[k], eps[j][i][d] (i < M/2)."""
+    D, K = len(mu), len(sigma)
+    Mh = len(eps[0])
+    Ns = 2 * Mh
+    nf = 1 / (2 * mp.pi) ** (mp.mpf(D) / 2) / mp.fprod(lam)
+    H = mp.mpf(0)
+    mu_g = [[mp.mpf(0)] * K for _ in range(D)]
+    sg_g = [mp.mpf(0)] * K
+    lam_g = [mp.mpf(0)] * D
+    w_g = [mp.mpf(0)] * K
+    for j in range(K):
+        samples = [eps[j][i] for i in range(Mh)] + [[-e for e in eps[j][i]] for i in range(Mh)]
+        for e in samples:
+            x = [e[d] * lam[d] * sigma[j] + mu[d][j] for d in range(D)]
+            norm = []
+            for k in range(K):
+                d2 = mp.fsum(((x[d] - mu[d][k]) / (sigma[k] * lam[d])) ** 2 for d in range(D))
+                norm.append(nf / sigma[k] ** D * mp.e ** (-d2 / 2))
+            q = mp.fsum(w[k] * norm[k] for k in range(K))
+            H -= w[j] * mp.log(q) / Ns
+            lsum = [mp.fsum((x[d] - mu[d][k]) / (sigma[k] * lam[d]) ** 2 * norm[k] * w[k] for k in range(K)) for d in range(D)]
+            for d in range(D):
+                mu_g[d][j] += w[j] * lsum[d] / q / Ns
+                lam_g[d] += lsum[d] * w[j] * sigma[j] * e[d] / q / Ns
+            sg_g[j] += w[j] * mp.fsum(lsum[d] * e[d] * lam[d] for d in range(D)) / q / Ns
+            w_g[j] -= mp.log(q) / Ns
+            for l in range(K):
+                w_g[l] -= w[j] * norm[l] / q / Ns
+    lam_g = [lam_g[d] * lam[d] for d in range(D)]
+    sg_g = [sg_g[k] * sigma[k] for k in range(K)]
+    w_g = matvec(softmax_jac(eta), w_g)
+    dH = [mu_g[d][k] for k in range(K) for d in range(D)] + sg_g + lam_g + w_g
+    return H, dH
+
+
+# ------------------------------------------------------------------ entlb
+def mp_entlb(mu, sigma, lam, w, eta):
+    D, K = len(mu), len(sigma)
+    nconst = 1 / (2 * mp.pi) ** (mp.mpf(D) / 2) / mp.fprod(lam)
+
+    def Hfun(mu, sigma, lam, w):
+        nconst = 1 / (2 * mp.pi) ** (mp.mpf(D) / 2) / mp.fprod(lam)
+        H = mp.mpf(0)
+        for n in range(K):
+            gs = mp.mpf(0)
+            for k in range(K):
+                ss2 = sigma[n] ** 2 + sigma[k] ** 2
+                d2 = mp.fsum((mu[d][n] - mu[d][k]) ** 2 / (ss2 * lam[d] ** 2) for d in range(D))
+                gs += w[k] * nconst * ss2 ** (-mp.mpf(D) / 2) * mp.e ** (-d2 / 2)
+            H -= w[n] * mp.log(gs)
+        return H
+
+    H = Hfun(mu, sigma, lam, w)
+
+    # Gradient by high-precision differentiation of H in the *transformed* parameters
+    # (valid: the entlb gradient in the reference is the exact derivative of the bound).
+    def Htheta(th):
+        mu_ = [[th[k * D + d] for k in range(K)] for d in range(D)]
+        sg_ = [mp.e ** th[D * K + k] for k in range(K)]
+        lm_ = [mp.e ** th[D * K + K + d] for d in range(D)]
+        et_ = th[D * K + K + D :]
+        ee = [mp.e ** t for t in et_]
+        sm = mp.fsum(ee)
+        w_ = [t / sm for t in ee]
+        return Hfun(mu_, sg_, lm_, w_)
+
+    th0 = [mu[d][k] for k in range(K) for d in range(D)] + [mp.log(s) for s in sigma] + [mp.log(l) for l in lam] + list(eta)
+    dH = []
+    for i in range(len(th0)):
+        dH.append(mp.diff(lambda t: Htheta(th0[:i] + [t] + th0[i + 1 :]), th0[i]))
+    return H, dH
+
+
+# ------------------------------------------------------------------ GP pieces
+def mp_chol_upper(A):
+    n = len(A)
+    R = [[mp.mpf(0)] * n for _ in range(n)]
+    for j in range(n):
+        s = A[j][j] - mp.fsum(R[i][j] ** 2 for i in range(j))
+        R[j][j] = mp.sqrt(s)
+        for c in range(j + 1, n):
+            R[j][c] = (A[j][c] - mp.fsum(R[i][j] * R[i][c] for i in range(j))) / R[j][j]
+    return R
+
+
+def mp_solve_ut_t(R, b):  # R' \ b
+    n = len(b)
+    x = [mp.mpf(0)] * n
+    for i in range(n):
+        x[i] = (b[i] - mp.fsum(R[r][i] * x[r] for r in range(i))) / R[i][i]
+    return x
+
+
+def mp_solve_ut(R, b):  # R \ b
+    n = len(b)
+    x = [mp.mpf(0)] * n
+    for i in reversed(range(n)):
+        x[i] = (b[i] - mp.fsum(R[i][c] * x[c] for c in range(i + 1, n))) / R[i][i]
+    return x
+
+
+def mp_meanfun(hyp_mean, x, meanfun, D):
+    if meanfun == 0:
+        return mp.mpf(0)
+    if meanfun == 1:
+        return hyp_mean[0]
+    m0 = hyp_mean[0]
+    xm = hyp_mean[1 : D + 1]
+    om = [mp.e ** t for t in hyp_mean[D + 1 : 2 * D + 1]]
+    return m0 - mp.fsum(((x[d] - xm[d]) / om[d]) ** 2 for d in range(D)) / 2
+
+
+def mp_gp_post(hyp, X, y, meanfun):
+    """One hyper-sample; const noise (noisefun [1 0 0]); returns alpha, L (upper), sn2."""
+    N, D = len(X), len(X[0])
+    ell = [mp.e ** hyp[d] for d in range(D)]
+    sf2 = mp.e ** (2 * hyp[D])
+    sn2 = mp.e ** (2 * hyp[D + 1])
+    hyp_mean = hyp[D + 2 :]
+    Kmat = [[sf2 * mp.e ** (-mp.fsum(((X[a][d] - X[b][d]) / ell[d]) ** 2 for d in range(D)) / 2) for b in range(N)] for a in range(N)]
+    A = [[Kmat[a][b] / sn2 + (1 if a == b else 0) for b in range(N)] for a in range(N)]
+    L = mp_chol_upper(A)
+    r = [y[n] - mp_meanfun(hyp_mean, X[n], meanfun, D) for n in range(N)]
+    alpha = [t / sn2 for t in mp_solve_ut(L, mp_solve_ut_t(L, r))]
+    return alpha, L, sn2
+
+
+def mp_gp_pred(hyp, X, alpha, L, sn2, Xs, meanfun):
+    N, D = len(X), len(X[0])
+    ell = [mp.e ** hyp[d] for d in range(D)]
+    sf2 = mp.e ** (2 * hyp[D])
+    hyp_mean = hyp[D + 2 :]
+    fmu, fs2 = [], []
+    for xs in Xs:
+        ks = [sf2 * mp.e ** (-mp.fsum(((X[n][d] - xs[d]) / ell[d]) ** 2 for d in range(D)) / 2) for n in range(N)]
+        fmu.append(mp_meanfun(hyp_mean, xs, meanfun, D) + mp.fsum(ks[n] * alpha[n] for n in range(N)))
+        v = mp_solve_ut_t(L, [k / mp.sqrt(sn2) for k in ks])
+        fs2.append(max(sf2 - mp.fsum(t * t for t in v), mp.mpf(0)))
+    return fmu, fs2
+
+
+# ------------------------------------------------------------------ gplogjoint
+def mp_logjoint(mu, sigma, lam, w, eta, X, posts, meanfun, compute_var):
+    """posts: list of dict(hyp, alpha, L, sn2).  Returns per-sample F[s], dF[s][t],
+    I_sk, J_sjk (full), varF[s] for compute_var in {1,2}; averaging done by caller tests."""
+    D, K, N = len(mu), len(sigma), len(X)
+    S = len(posts)
+    eps = mp.mpf(2) ** -52
+    Fs, dFs, I_sk, J_all, varFs = [], [], [], [], []
+    Jw = softmax_jac(eta)
+    for s in range(S):
+        hyp = posts[s]["hyp"]
+        alpha = posts[s]["alpha"]
+        L = posts[s]["L"]
+        sn2 = posts[s]["sn2"]
+        ell = [mp.e ** hyp[d] for d in range(D)]
+        ln_sf2 = 2 * hyp[D]
+        sum_lnell = mp.fsum(hyp[:D])
+        hm = hyp[D + 2 :]
+        m0 = hm[0] if meanfun > 0 else mp.mpf(0)
+        if meanfun == 4:
+            xm = hm[1 : D + 1]
+            om = [mp.e ** t for t in hm[D + 1 : 2 * D + 1]]
+        F = mp.mpf(0)
+        mu_g = [[mp.mpf(0)] * K for _ in range(D)]
+        sg_g = [mp.mpf(0)] * K
+        lam_g = [mp.mpf(0)] * D
+        w_g = [mp.mpf(0)] * K
+        Ik = []
+        zs = []
+        for k in range(K):
+            tau = [mp.sqrt(sigma[k] ** 2 * lam[d] ** 2 + ell[d] ** 2) for d in range(D)]
+            lnnf = ln_sf2 + sum_lnell - mp.fsum(mp.log(t) for t in tau)
+            delt = [[(mu[d][k] - X[n][d]) / tau[d] for n in range(N)] for d in range(D)]
+            z = [mp.e ** (lnnf - mp.fsum(delt[d][n] ** 2 for d in range(D)) / 2) for n in range(N)]
+            zs.append(z)
+            I = mp.fsum(z[n] * alpha[n] for n in range(N)) + m0
+            if meanfun == 4:
+                I += -mp.fsum((mu[d][k] ** 2 + sigma[k] ** 2 * lam[d] ** 2 - 2 * mu[d][k] * xm[d] + xm[d] ** 2) / om[d] ** 2 for d in range(D)) / 2
+            Ik.append(I)
+            F += w[k] * I
+            for d in range(D):
+                mu_g[d][k] = w[k] * mp.fsum(-delt[d][n] / tau[d] * z[n] * alpha[n] for n in range(N))
+                if meanfun == 4:
+                    mu_g[d][k] -= w[k] / om[d] ** 2 * (mu[d][k] - xm[d])
+            sg_g[k] = w[k] * mp.fsum(
+                mp.fsum((lam[d] / tau[d]) ** 2 * (delt[d][n] ** 2 - 1) for d in range(D)) * sigma[k] * z[n] * alpha[n] for n in range(N)
+            )
+            if meanfun == 4:
+                sg_g[k] -= w[k] * sigma[k] * mp.fsum(lam[d] ** 2 / om[d] ** 2 for d in range(D))
+            for d in range(D):
+                lam_g[d] += w[k] * mp.fsum((sigma[k] / tau[d]) ** 2 * (delt[d][n] ** 2 - 1) * lam[d] * z[n] * alpha[n] for n in range(N))
+                if meanfun == 4:
+                    lam_g[d] -= w[k] * sigma[k] ** 2 / om[d] ** 2 * lam[d]
+            w_g[k] = I
+        sg_g = [sg_g[k] * sigma[k] for k in range(K)]
+        lam_g = [lam_g[d] * lam[d] for d in range(D)]
+        w_g = matvec(Jw, w_g)
+        Fs.append(F)
+        dFs.append([mu_g[d][k] for k in range(K) for d in range(D)] + sg_g + lam_g + w_g)
+        I_sk.append(Ik)
+        if compute_var:
+            # K^{-1} z_j  (Lchol branch: (L\(L'\z))/sn2_eff)
+            Kinvz = [[t / sn2 for t in mp_solve_ut(L, mp_solve_ut_t(L, zs[j]))] for j in range(K)]
+            J = [[mp.mpf(0)] * K for _ in range(K)]
+            for k in range(K):
+                for j in range(K):
+                    tau_jk = [mp.sqrt((sigma[j] ** 2 + sigma[k] ** 2) * lam[d] ** 2 + ell[d] ** 2) for d in range(D)]
+                    lnnf_jk = ln_sf2 + sum_lnell - mp.fsum(mp.log(t) for t in tau_jk)
+                    d_jk = mp.fsum(((mu[d][j] - mu[d][k]) / tau_jk[d]) ** 2 for d in range(D))
+                    J[j][k] = mp.e ** (lnnf_jk - d_jk / 2) - mp.fsum(zs[k][n] * Kinvz[j][n] for n in range(N))
+            J_all.append(J)
+            if compute_var == 2:
+                v = mp.fsum(w[k] ** 2 * max(eps, J[k][k]) for k in range(K))
+            else:
+                v = mp.fsum(w[k] ** 2 * max(eps, J[k][k]) for k in range(K)) + mp.fsum(
+                    2 * w[j] * w[k] * J[j][k] for k in range(K) for j in range(k)
+                )
+            varFs.append(max(v, eps))
+    return Fs, dFs, I_sk, J_all, varFs
+
+
+# ------------------------------------------------------------------ driver
+def tolist(a):
+    return np.asarray(a, dtype=np.float64).tolist()
+
+
+def fl(x):
+    if isinstance(x, (list, tuple)):
+        return [fl(t) for t in x]
+    return float(x)
+
+
+def make_case(seed, D, K, N, S, Mh, meanfun):
+    rng = np.random.default_rng(seed)
+    X = 1.5 * rng.standard_normal((N, D))
+    y = -0.5 * np.sum((X / 1.3) ** 2, axis=1) + 0.3 * np.sin(X[:, 0]) + 0.05 * rng.standard_normal(N)
+    nmean = {0: 0, 1: 1, 4: 2 * D + 1}[meanfun]
+    hyp = np.zeros((D + 2 + nmean, S))
+    for s in range(S):
+        hyp[:D, s] = np.log(0.8) + 0.2 * rng.standard_normal(D)
+        hyp[D, s] = np.log(np.std(y)) + 0.1 * rng.standard_normal()
+        hyp[D + 1, s] = np.log(3e-2) + 0.1 * rng.standard_normal()
+        if meanfun >= 1:
+            hyp[D + 2, s] = np.max(y) + 0.1 * rng.standard_normal()
+        if meanfun == 4:
+            hyp[D + 3 : D + 3 + D, s] = 0.2 * rng.standard_normal(D)
+            hyp[D + 3 + D :, s] = np.log(2.0) + 0.1 * rng.standard_normal(D)
+    mu = X[rng.permutation(N)[:K]].T + 0.1 * rng.standard_normal((D, K))
+    sigma = 0.4 * np.exp(0.3 * rng.standard_normal(K))
+    lam = np.exp(0.2 * rng.standard_normal(D))
+    lam = lam / np.sqrt(np.sum(lam**2) / D)
+    eta = 0.5 * rng.standard_normal(K)
+    w = np.exp(eta) / np.sum(np.exp(eta))
+    eps = rng.standard_normal((K, Mh, D))
+    Xstar = 1.5 * rng.standard_normal((5, D))
+    return dict(seed=seed, D=D, K=K, N=N, S=S, Mh=Mh, meanfun=meanfun, X=X, y=y, hyp=hyp, mu=mu, sigma=sigma,
+                lam=lam, eta=eta, w=w, eps=eps, Xstar=Xstar)
+
+
+def run_case(c):
+    D, K, N, S = c["D"], c["K"], c["N"], c["S"]
+    mu = [[M(c["mu"][d, k]) for k in range(K)] for d in range(D)]
+    sigma = [M(t) for t in c["sigma"]]
+    lam = [M(t) for t in c["lam"]]
+    eta = [M(t) for t in c["eta"]]
+    # weights exactly as negelcbo_vbmc.m:45-47 forms them from eta
+    ee = [mp.e ** t for t in eta]
+    w = [t / mp.fsum(ee) for t in ee]
+    eps = [[[M(c["eps"][j, i, d]) for d in range(D)] for i in range(c["Mh"])] for j in range(K)]
+    X = [[M(c["X"][n, d]) for d in range(D)] for n in range(N)]
+    y = [M(t) for t in c["y"]]
+    out = {}
+    H, dH = mp_entmc(mu, sigma, lam, w, eta, eps)
+    out["entmc_H"], out["entmc_dH"] = fl(H), fl(dH)
+    Hl, dHl = mp_entlb(mu, sigma, lam, w, eta)
+    out["entlb_H"], out["entlb_dH"] = fl(Hl), fl(dHl)
+    posts = []
+    out["alpha"], out["L"], out["pred_fmu"], out["pred_fs2"] = [], [], [], []
+    Xs = [[M(c["Xstar"][i, d]) for d in range(D)] for i in range(c["Xstar"].shape[0])]
+    for s in range(S):
+        hyp = [M(t) for t in c["hyp"][:, s]]
+        alpha, L, sn2 = mp_gp_post(hyp, X, y, c["meanfun"])
+        posts.append(dict(hyp=hyp, alpha=alpha, L=L, sn2=sn2))
+        out["alpha"].append(fl(alpha))
+        out["L"].append(fl(L))
+        fmu, fs2 = mp_gp_pred(hyp, X, alpha, L, sn2, Xs, c["meanfun"])
+        out["pred_fmu"].append(fl(fmu))
+        out["pred_fs2"].append(fl(fs2))
+    Fs, dFs, I_sk, J, varF1 = mp_logjoint(mu, sigma, lam, w, eta, X, posts, c["meanfun"], 1)
+    _, _, _, _, varF2 = mp_logjoint(mu, sigma, lam, w, eta, X, posts, c["meanfun"], 2)
+    out["G_s"], out["dG_s"], out["I_sk"], out["J_sjk"] = fl(Fs), fl(dFs), fl(I_sk), fl(J)
+    out["varG_s_full"], out["varG_s_diag"] = fl(varF1), fl(varF2)
+    return out
+
+
+CASES = [
+    dict(seed=11, D=2, K=2, N=6, S=1, Mh=8, meanfun=4),
+    dict(seed=12, D=3, K=4, N=12, S=3, Mh=6, meanfun=4),
+    dict(seed=13, D=1, K=3, N=8, S=2, Mh=10, meanfun=1),
+    dict(seed=14, D=4, K=3, N=10, S=2, Mh=4, meanfun=0),
+]
+
+
+def main():
+    outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for i, spec in enumerate(CASES):
+        c = make_case(**spec)
+        out = run_case(c)
+        rec = {"generator": "oracle/mp_golden.py (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps),
+               "inputs": {k: (tolist(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()},
+               "expected": out}
+        path = os.path.join(outdir, "mp_case%d.json" % i)
+        with open(path, "w") as f:
+            json.dump(rec, f)
+        print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

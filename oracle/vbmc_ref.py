@@ -1,0 +1,1227 @@
+"""CPU oracle (NumPy) for the VBMC ELBO inner loop -- TEST INFRASTRUCTURE ONLY.
+
+This module is a line-by-line NumPy restatement of the MATLAB reference
+(acerbilab/vbmc v1.0.12) for the hot path named in BASELINE.json.  It is the
+*checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import it.  The product path (``vbmc_amd``) never does.
+
+PARITY UNPINNED (by the reference): the reference is pure MATLAB, it holds no
+function-level golden vectors for this path and neither
+MATLAB nor Octave exists in the build container, so the reference cannot be run
+to generate vectors.  What pins this restatement instead is committed under
+``tests/golden/`` and exercised by ``tests/test_oracle_*.py``:
+  * 50-digit mpmath re-evaluation of the same formulas (``oracle/mp_golden.py``),
+  * closed forms (K=1 entropy, alpha=0 log-joint, identical-component bounds),
+  * finite differences where the reference's gradient is an exact derivative
+    (all of gplogjoint, entlb; the eta block of entmc),
+  * linear-algebra identities for gplite_post / gplite_pred, rank-1 == full.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  MATLAB shapes are kept: ``mu`` is D x K, ``sigma`` (K,),
+``lambda_`` (D,), ``w`` (K,), ``eta`` (K,); ``gp['X']`` is N x D.  All fp64.
+
+The implicit ``randn`` stream of ``entmc_vbmc`` is an explicit input here:
+``eps`` has shape (K, M/2, D) in C order, which is byte-identical to K
+consecutive MATLAB ``randn(D,1,M/2)`` blocks (d fastest, then sample, then j).
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+
+EPS = np.finfo(np.float64).eps  # MATLAB `eps`
+REALMIN = np.finfo(np.float64).tiny
+
+# --------------------------------------------------------------------------
+# small containers
+# --------------------------------------------------------------------------
+
+
+def make_vp(mu, sigma, lambda_, w=None, eta=None, optimize=(True, True, True, True), delta=None):
+    """Variational posterior struct (misc/setupvars_vbmc.m:78-99)."""
+    mu = np.array(mu, dtype=np.float64)
+    D, K = mu.shape
+    vp = {
+        "D": D,
+        "K": K,
+        "mu": mu,
+        "sigma": np.array(sigma, dtype=np.float64).reshape(K),
+        "lambda": np.array(lambda_, dtype=np.float64).reshape(D),
+        "w": (np.full(K, 1.0 / K) if w is None else np.array(w, dtype=np.float64).reshape(K)),
+        "optimize_mu": bool(optimize[0]),
+        "optimize_sigma": bool(optimize[1]),
+        "optimize_lambda": bool(optimize[2]),
+        "optimize_weights": bool(optimize[3]),
+        "delta": delta,
+        "bounds": None,
+        "stats": None,
+    }
+    if eta is not None:
+        vp["eta"] = np.array(eta, dtype=np.float64).reshape(K)
+    return vp
+
+
+def copy_vp(vp):
+    return copy.deepcopy(vp)
+
+
+# --------------------------------------------------------------------------
+# sq_dist  (utils/sq_dist.m:14-50, identical copy in gplite/private/sq_dist.m)
+# --------------------------------------------------------------------------
+
+
+def sq_dist(a, b=None):
+    """Pairwise squared distances between columns of a (D x n) and b (D x m)."""
+    a = np.asarray(a, dtype=np.float64)
+    D, n = a.shape
+    if b is None:
+        mu = a.mean(axis=1, keepdims=True)  # sq_dist.m:26
+        a = a - mu
+        b = a
+        m = n
+    else:
+        b = np.asarray(b, dtype=np.float64)
+        d, m = b.shape
+        if d != D:
+            raise ValueError("Error: column lengths must agree.")
+        mu = (m / (n + m)) * b.mean(axis=1, keepdims=True) + (n / (n + m)) * a.mean(axis=1, keepdims=True)  # :36
+        a = a - mu
+        b = b - mu
+    C = np.sum(a * a, axis=0)[:, None] + (np.sum(b * b, axis=0)[None, :] - 2.0 * (a.T @ b))  # :45
+    return np.maximum(C, 0.0)  # :49
+
+
+# --------------------------------------------------------------------------
+# GP mean / noise function tables (only what VBMC's defaults reach)
+# --------------------------------------------------------------------------
+
+
+def gplite_meanfun(hyp_mean, X, meanfun):
+    """gplite/gplite_meanfun.m:398-436, ids 0 (zero), 1 (const), 4 (negquad)."""
+    X = np.asarray(X, dtype=np.float64)
+    N, D = X.shape
+    if meanfun == 0:
+        return np.zeros(N)
+    if meanfun == 1:
+        return hyp_mean[0] * np.ones(N)
+    if meanfun == 4:
+        m0 = hyp_mean[0]
+        xm = hyp_mean[1 : D + 1]
+        omega = np.exp(hyp_mean[D + 1 : 2 * D + 1])
+        z2 = ((X - xm[None, :]) / omega[None, :]) ** 2  # :430
+        return m0 - 0.5 * np.sum(z2, axis=1)  # :431
+    raise NotImplementedError("meanfun %r outside the hot path" % (meanfun,))
+
+
+def meanfun_nhyp(meanfun, D):
+    return {0: 0, 1: 1, 4: 2 * D + 1}[meanfun]
+
+
+def gplite_noisefun(hyp_noise, X, noisefun, y=None, s2=None):
+    """gplite/gplite_noisefun.m:176-210."""
+    idx = 0
+    if noisefun[0] == 0:
+        sn2 = EPS
+    else:
+        sn2 = math.exp(2.0 * hyp_noise[idx])  # :181
+        idx += 1
+    if noisefun[1] == 1:
+        sn2 = sn2 + np.asarray(s2, dtype=np.float64)  # :188
+    elif noisefun[1] == 2:
+        sn2 = sn2 + math.exp(hyp_noise[idx]) * np.asarray(s2, dtype=np.float64)  # :190
+        idx += 1
+    if len(noisefun) > 2 and noisefun[2] == 1:
+        if y is not None and np.size(y) > 0:
+            ythresh = hyp_noise[idx]
+            w2 = math.exp(2.0 * hyp_noise[idx + 1])
+            zz = np.maximum(0.0, ythresh - np.asarray(y, dtype=np.float64))
+            sn2 = sn2 + w2 * zz**2  # :202
+        idx += 2
+    return sn2
+
+
+def noisefun_nhyp(noisefun):
+    n = 0
+    if noisefun[0] == 1:
+        n += 1
+    if noisefun[1] == 2:
+        n += 1
+    if len(noisefun) > 2 and noisefun[2] == 1:
+        n += 2
+    return n
+
+
+# --------------------------------------------------------------------------
+# dense helpers standing in for MATLAB built-ins (chol, \ on triangular)
+# --------------------------------------------------------------------------
+
+
+def chol_upper(A):
+    """MATLAB ``[R,p] = chol(A)``: upper R with R'R = A; p>0 on failure."""
+    A = np.array(A, dtype=np.float64)
+    n = A.shape[0]
+    R = np.zeros_like(A)
+    for j in range(n):
+        s = A[j, j] - np.dot(R[:j, j], R[:j, j])
+        if not (s > 0.0) or not np.isfinite(s):
+            return R, j + 1
+        R[j, j] = math.sqrt(s)
+        if j + 1 < n:
+            R[j, j + 1 :] = (A[j, j + 1 :] - R[:j, j] @ R[:j, j + 1 :]) / R[j, j]
+    return R, 0
+
+
+def solve_upper(R, B):
+    """R \\ B with R upper triangular (back substitution)."""
+    from scipy.linalg import solve_triangular
+
+    return solve_triangular(R, B, lower=False, trans="N", check_finite=False)
+
+
+def solve_upper_t(R, B):
+    """R' \\ B with R upper triangular (forward substitution on R')."""
+    from scipy.linalg import solve_triangular
+
+    return solve_triangular(R, B, lower=False, trans="T", check_finite=False)
+
+
+# --------------------------------------------------------------------------
+# gplite_core (no-nlZ branch) and gplite_post
+# --------------------------------------------------------------------------
+
+
+def gplite_core_post(hyp, gp):
+    """gplite/private/gplite_core.m:1-102,278-291 with compute_nlZ = 0.
+
+    Returns the ``post`` struct {hyp, alpha, sW, L, sn2_mult, Lchol}.
+    Only covfun 1 (SE-ARD), no output warping, no integrated mean.
+    """
+    X = gp["X"]
+    y = gp["y"]
+    N, D = X.shape
+    Ncov, Nnoise, Nmean = gp["Ncov"], gp["Nnoise"], gp["Nmean"]
+    hyp = np.asarray(hyp, dtype=np.float64)
+    hyp_noise = hyp[Ncov : Ncov + Nnoise]
+    sn2 = gplite_noisefun(hyp_noise, X, gp["noisefun"], y, gp.get("s2"))  # :38
+    sn2_mult = 1.0  # :40
+    hyp_mean = hyp[Ncov + Nnoise : Ncov + Nnoise + Nmean]
+    m = gplite_meanfun(hyp_mean, X, gp["meanfun"])  # :46
+
+    ell = np.exp(hyp[0:D])  # :53
+    sf2 = math.exp(2.0 * hyp[D])  # :54
+    K_mat = sq_dist(X.T / ell[:, None])  # :55
+    K_mat = sf2 * np.exp(-K_mat / 2.0)  # :56
+
+    Lchol = bool(np.min(sn2) >= 1e-6)  # :67
+    if Lchol:
+        if np.isscalar(sn2) or np.ndim(sn2) == 0:
+            sn2div = float(sn2)
+            sn2_mat = np.eye(N)
+        else:
+            sn2div = float(np.min(sn2))
+            sn2_mat = np.diag(sn2 / sn2div)
+        for _ in range(10):  # :77-80
+            L, p = chol_upper(K_mat / (sn2div * sn2_mult) + sn2_mat)
+            if p > 0:
+                sn2_mult *= 10.0
+            else:
+                break
+        sl = sn2div * sn2_mult
+        pL = L
+    else:
+        if np.isscalar(sn2) or np.ndim(sn2) == 0:
+            sn2_mat = float(sn2) * np.eye(N)
+        else:
+            sn2_mat = np.diag(sn2)
+        for _ in range(10):  # :91-94
+            L, p = chol_upper(K_mat + sn2_mult * sn2_mat)
+            if p > 0:
+                sn2_mult *= 10.0
+            else:
+                break
+        sl = 1.0
+        pL = -solve_upper(L, solve_upper_t(L, np.eye(N)))  # :98
+    alpha = solve_upper(L, solve_upper_t(L, y - m)) / sl  # :102
+    post = {
+        "hyp": hyp.copy(),
+        "alpha": alpha,
+        "sW": np.ones(N) / math.sqrt(float(np.min(sn2)) * sn2_mult),  # :281
+        "L": pL,
+        "sn2_mult": sn2_mult,
+        "Lchol": Lchol,
+    }
+    return post
+
+
+def gplite_post(hyp, X, y, meanfun=4, noisefun=(1, 0, 0), s2=None):
+    """gplite/gplite_post.m:94-172 (fresh GP struct + full posterior per sample).
+
+    ``hyp`` is Nhyp x S (columns are hyper-parameter samples).
+    """
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    N, D = X.shape
+    hyp = np.asarray(hyp, dtype=np.float64)
+    if hyp.ndim == 1:
+        hyp = hyp[:, None]
+    gp = {
+        "X": X,
+        "y": y,
+        "s2": None if s2 is None else np.asarray(s2, dtype=np.float64).reshape(-1),
+        "covfun": 1,
+        "Ncov": D + 1,
+        "noisefun": tuple(noisefun),
+        "Nnoise": noisefun_nhyp(noisefun),
+        "meanfun": meanfun,
+        "Nmean": meanfun_nhyp(meanfun, D),
+        "meanfun_extras": None,
+        "intmeanfun": 0,
+    }
+    if hyp.shape[0] != gp["Ncov"] + gp["Nnoise"] + gp["Nmean"]:
+        raise ValueError("gplite_post:dimmismatch")  # :152-155
+    gp["post"] = [gplite_core_post(hyp[:, s], gp) for s in range(hyp.shape[1])]  # :167-172
+    return gp
+
+
+def gplite_post_rank1(gp, xstar, ystar):
+    """gplite/gplite_post.m:173-251: rank-1 append of one training point."""
+    gp = copy.deepcopy(gp)
+    xstar = np.asarray(xstar, dtype=np.float64).reshape(1, -1)
+    ystar = float(ystar)
+    if gp.get("s2") is not None:
+        raise NotImplementedError("rank-1 with s2 falls back to full update (:76-79)")
+    N, D = gp["X"].shape
+    Ncov, Nnoise = gp["Ncov"], gp["Nnoise"]
+    mstar, vstar, _, _ = gplite_pred(gp, xstar, np.array([ystar]), None, ssflag=True)  # :189
+    for s, post in enumerate(gp["post"]):
+        hyp = post["hyp"]
+        hyp_noise = hyp[Ncov : Ncov + Nnoise]
+        sn2 = gplite_noisefun(hyp_noise, xstar, gp["noisefun"], np.array([ystar]), None)
+        sn2 = float(np.min(sn2)) if np.ndim(sn2) else float(sn2)
+        sn2_eff = sn2 * post["sn2_mult"]  # :207
+        ell = np.exp(hyp[0:D])
+        sf2 = math.exp(2.0 * hyp[D])
+        Kss = sf2  # :213
+        Ks_mat = sq_dist(gp["X"].T / ell[:, None], xstar.T / ell[:, None])  # :214
+        Ks_mat = sf2 * np.exp(-Ks_mat / 2.0)
+        L = post["L"]
+        if post["Lchol"]:
+            alpha_update = solve_upper(L, solve_upper_t(L, Ks_mat)) / sn2_eff  # :227
+            new_col = solve_upper_t(L, Ks_mat) / sn2_eff  # :228-229
+            newL = np.zeros((N + 1, N + 1))
+            newL[:N, :N] = L
+            newL[:N, N:] = new_col
+            newL[N, N] = math.sqrt(1.0 + Kss / sn2_eff - float((new_col.T @ new_col)[0, 0]))  # :232
+        else:
+            alpha_update = -L @ Ks_mat  # :234
+            v = -alpha_update / vstar[0, s]
+            newL = np.zeros((N + 1, N + 1))
+            newL[:N, :N] = L + v @ alpha_update.T
+            newL[:N, N:] = -v
+            newL[N:, :N] = -v.T
+            newL[N, N] = -1.0 / vstar[0, s]  # :236
+        post["L"] = newL
+        post["sW"] = np.concatenate([post["sW"], [1.0 / math.sqrt(sn2_eff)]])  # :239
+        upd = np.concatenate([alpha_update[:, 0], [-1.0]])
+        post["alpha"] = np.concatenate([post["alpha"], [0.0]]) + (mstar[0, s] - ystar) / vstar[0, s] * upd  # :242-244
+    gp["X"] = np.vstack([gp["X"], xstar])
+    gp["y"] = np.concatenate([gp["y"], [ystar]])
+    return gp
+
+
+# --------------------------------------------------------------------------
+# gplite_pred
+# --------------------------------------------------------------------------
+
+
+def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False):
+    """gplite/gplite_pred.m:1-165 -> (ymu, ys2, fmu, fs2); Nstar x S if ssflag
+    else Nstar x 1 vectors (returned as (Nstar,S) / (Nstar,) arrays)."""
+    X = gp["X"]
+    N, D = X.shape
+    S = len(gp["post"])
+    Xstar = np.asarray(Xstar, dtype=np.float64)
+    Nstar = Xstar.shape[0]
+    Ncov, Nnoise, Nmean = gp["Ncov"], gp["Nnoise"], gp["Nmean"]
+    fmu = np.zeros((Nstar, S))
+    ymu = np.zeros((Nstar, S))
+    fs2 = np.zeros((Nstar, S))
+    ys2 = np.zeros((Nstar, S))
+    for s, post in enumerate(gp["post"]):
+        hyp = post["hyp"]
+        alpha, L, Lchol, sW, sn2_mult = post["alpha"], post["L"], post["Lchol"], post["sW"], post["sn2_mult"]
+        hyp_noise = hyp[Ncov : Ncov + Nnoise]
+        sn2_star = gplite_noisefun(hyp_noise, Xstar, gp["noisefun"], ystar, s2star)  # :63
+        hyp_mean = hyp[Ncov + Nnoise : Ncov + Nnoise + Nmean]
+        mstar = gplite_meanfun(hyp_mean, Xstar, gp["meanfun"])  # :67
+        ell = np.exp(hyp[0:D])
+        sf2 = math.exp(2.0 * hyp[D])
+        Ks_mat = sq_dist(X.T / ell[:, None], Xstar.T / ell[:, None])  # :73
+        Ks_mat = sf2 * np.exp(-Ks_mat / 2.0)
+        kss = sf2 * np.ones(Nstar)  # :75
+        fmu[:, s] = mstar + Ks_mat.T @ alpha  # :83
+        ymu[:, s] = fmu[:, s]
+        if Lchol:
+            V = solve_upper_t(L, sW[:, None] * Ks_mat)  # :99
+            fs2[:, s] = kss - np.sum(V * V, axis=0)  # :100
+        else:
+            LKs = L @ Ks_mat
+            fs2[:, s] = kss + np.sum(Ks_mat * LKs, axis=0)  # :103
+        fs2[:, s] = np.maximum(fs2[:, s], 0.0)  # :120
+        ys2[:, s] = fs2[:, s] + sn2_star * sn2_mult  # :121
+    if S > 1 and not ssflag:  # :154-165
+        fbar = np.sum(fmu, axis=1) / S
+        ybar = np.sum(ymu, axis=1) / S
+        vf = np.sum((fmu - fbar[:, None]) ** 2, axis=1) / (S - 1)
+        fs2 = np.sum(fs2, axis=1) / S + vf
+        vy = np.sum((ymu - ybar[:, None]) ** 2, axis=1) / (S - 1)
+        ys2 = np.sum(ys2, axis=1) / S + vy
+        return ybar, ys2, fbar, fs2
+    if not ssflag:
+        return ymu[:, 0], ys2[:, 0], fmu[:, 0], fs2[:, 0]
+    return ymu, ys2, fmu, fs2
+
+
+# --------------------------------------------------------------------------
+# softmax Jacobian used by gplogjoint / entmc / entlb / negelcbo
+# --------------------------------------------------------------------------
+
+
+def softmax_jacobian(eta):
+    """J_w = -exp(eta)' * exp(eta)/sum^2 + diag(exp(eta)/sum)
+    (misc/gplogjoint.m:366-368, ent/entmc_vbmc.m:121-123)."""
+    e = np.exp(np.asarray(eta, dtype=np.float64))
+    eta_sum = np.sum(e)
+    return -np.outer(e, e / eta_sum**2) + np.diag(e / eta_sum)
+
+
+# --------------------------------------------------------------------------
+# gplogjoint
+# --------------------------------------------------------------------------
+
+
+def _unpack_hyp(gp, hyp, D):
+    """misc/gplogjoint.m:99-121 for meanfun in {0,1,4}."""
+    Ncov, Nnoise = gp["Ncov"], gp["Nnoise"]
+    ell = np.exp(hyp[0:D])
+    ln_sf2 = 2.0 * hyp[D]
+    sum_lnell = np.sum(hyp[0:D])
+    meanfun = gp["meanfun"]
+    m0 = hyp[Ncov + Nnoise] if meanfun > 0 else 0.0  # :107-111
+    xm = omega = None
+    if meanfun == 4:  # :112-121 (quadratic_meanfun, not fixed)
+        xm = hyp[Ncov + Nnoise + 1 : Ncov + Nnoise + 1 + D]
+        omega = np.exp(hyp[Ncov + Nnoise + D + 1 : Ncov + Nnoise + 2 * D + 1])
+    return ell, ln_sf2, sum_lnell, m0, xm, omega
+
+
+def gplogjoint(vp, gp, grad_flags=(0, 0, 0, 0), avg_flag=True, jacobian_flag=True, compute_var=0,
+               separate_K=False, compute_vargrad=None):
+    """misc/gplogjoint.m:1-415 -> dict(F, dF, varF, dvarF, varss, I_sk, J_sjk).
+
+    compute_var: 0 none, 1 full K x K (pair loop :306-337), 2 diagonal (:273-304).
+    ``compute_vargrad`` mirrors ``nargout > 3 && compute_var && any(grad_flags)``
+    (:27); pass True to request dvarF (requires compute_var == 2).
+    """
+    if gp["meanfun"] not in (0, 1, 4):
+        raise NotImplementedError("gplogjoint:UnsupportedMeanFun (only 0,1,4 restated)")
+    grad_flags = tuple(bool(g) for g in (grad_flags if np.ndim(grad_flags) else (grad_flags,) * 4))
+    anygrad = any(grad_flags)
+    if compute_vargrad is None:
+        compute_vargrad = False
+    compute_vargrad = bool(compute_vargrad and compute_var and anygrad)
+    if compute_vargrad and compute_var != 2:
+        raise ValueError("gplogjoint:FullVarianceGradient")  # :29-32
+
+    D, K = vp["D"], vp["K"]
+    X = gp["X"]
+    N = X.shape[0]
+    mu, sigma, lam, w = vp["mu"], vp["sigma"], vp["lambda"], vp["w"]
+    S = len(gp["post"])
+    quadratic = gp["meanfun"] == 4
+
+    F = np.zeros(S)
+    mu_grad = np.zeros((D, K, S)) if grad_flags[0] else None
+    sigma_grad = np.zeros((K, S)) if grad_flags[1] else None
+    lambda_grad = np.zeros((D, S)) if grad_flags[2] else None
+    w_grad = np.zeros((K, S)) if grad_flags[3] else None
+    varF = np.zeros(S) if compute_var else None
+    if compute_vargrad:
+        mu_vargrad = np.zeros((D, K, S)) if grad_flags[0] else None
+        sigma_vargrad = np.zeros((K, S)) if grad_flags[1] else None
+        lambda_vargrad = np.zeros((D, S)) if grad_flags[2] else None
+        w_vargrad = np.zeros((K, S)) if grad_flags[3] else None
+    I_sk = np.zeros((S, K)) if separate_K else None
+    J_sjk = np.zeros((S, K, K)) if (separate_K and compute_var) else None
+
+    delta = vp.get("delta")
+    if delta is None or np.size(delta) == 0:
+        delta = 0.0  # :85-89
+    delta = np.asarray(delta, dtype=np.float64).reshape(-1) if np.ndim(delta) else float(delta)
+
+    Xt = mu.T[:, :, None] - X.T[None, :, :]  # Xt[k] = mu(:,k) - X'  (D x N)  :92-95
+
+    for s in range(S):
+        post = gp["post"][s]
+        hyp = post["hyp"]
+        ell, ln_sf2, sum_lnell, m0, xm, omega = _unpack_hyp(gp, hyp, D)
+        alpha = post["alpha"]
+        L = post["L"]
+        Lchol = post["Lchol"]
+        sn2_eff = 1.0 / post["sW"][0] ** 2  # :160
+
+        for k in range(K):
+            tau_k = np.sqrt(sigma[k] ** 2 * lam**2 + ell**2 + delta**2)  # :164
+            lnnf_k = ln_sf2 + sum_lnell - np.sum(np.log(tau_k))  # :165
+            delta_k = Xt[k] / tau_k[:, None]  # :167
+            z_k = np.exp(lnnf_k - 0.5 * np.sum(delta_k**2, axis=0))  # :168
+            I_k = z_k @ alpha + m0  # :169
+            if quadratic:
+                nu_k = -0.5 * np.sum(
+                    1.0 / omega**2 * (mu[:, k] ** 2 + sigma[k] ** 2 * lam**2 - 2.0 * mu[:, k] * xm + xm**2 + delta**2)
+                )  # :172-173
+                I_k = I_k + nu_k
+            F[s] += w[k] * I_k  # :203
+            if separate_K:
+                I_sk[s, k] = I_k
+
+            if grad_flags[0]:
+                dz_dmu = -(delta_k / tau_k[:, None]) * z_k[None, :]  # :207
+                mu_grad[:, k, s] = w[k] * (dz_dmu @ alpha)  # :208
+                if quadratic:
+                    mu_grad[:, k, s] -= w[k] / omega**2 * (mu[:, k] - xm)  # :210
+            if grad_flags[1]:
+                dz_dsigma = np.sum((lam / tau_k)[:, None] ** 2 * (delta_k**2 - 1.0), axis=0) * (sigma[k] * z_k)  # :228
+                sigma_grad[k, s] = w[k] * (dz_dsigma @ alpha)  # :229
+                if quadratic:
+                    sigma_grad[k, s] -= w[k] * sigma[k] * np.sum(1.0 / omega**2 * lam**2)  # :231
+            if grad_flags[2]:
+                dz_dlambda = ((sigma[k] / tau_k) ** 2)[:, None] * (delta_k**2 - 1.0) * (lam[:, None] * z_k[None, :])  # :249
+                lambda_grad[:, s] += w[k] * (dz_dlambda @ alpha)  # :250
+                if quadratic:
+                    lambda_grad[:, s] -= w[k] * sigma[k] ** 2 / omega**2 * lam  # :252
+            if grad_flags[3]:
+                w_grad[k, s] = I_k  # :270
+
+            if compute_var == 2:  # :273-304
+                tau_kk = np.sqrt(2.0 * sigma[k] ** 2 * lam**2 + ell**2 + 2.0 * delta**2)
+                nf_kk = math.exp(ln_sf2 + sum_lnell - np.sum(np.log(tau_kk)))
+                if Lchol:
+                    invKzk = solve_upper(L, solve_upper_t(L, z_k)) / sn2_eff  # :277
+                else:
+                    invKzk = -L @ z_k  # :279
+                J_kk = nf_kk - z_k @ invKzk  # :281
+                varF[s] += w[k] ** 2 * max(EPS, J_kk)  # :283
+                if separate_K:
+                    J_sjk[s, k, k] = J_kk
+                if compute_vargrad:
+                    if grad_flags[0]:
+                        mu_vargrad[:, k, s] = -w[k] ** 2 * (2.0 * (dz_dmu @ invKzk))  # :289
+                    if grad_flags[1]:
+                        sigma_vargrad[k, s] = -2.0 * w[k] ** 2 * (
+                            sigma[k] * nf_kk * np.sum(lam**2 / tau_kk**2) + dz_dsigma @ invKzk
+                        )  # :293
+                    if grad_flags[2]:
+                        lambda_vargrad[:, s] -= 2.0 * w[k] ** 2 * (
+                            sigma[k] ** 2 * nf_kk * lam / tau_kk**2 + dz_dlambda @ invKzk
+                        )  # :297
+                    if grad_flags[3]:
+                        w_vargrad[k, s] = 2.0 * w[k] * max(EPS, J_kk)  # :301
+            elif compute_var:  # :306-337  full pair loop
+                for j in range(k + 1):
+                    tau_j = np.sqrt(sigma[j] ** 2 * lam**2 + ell**2 + delta**2)
+                    lnnf_j = ln_sf2 + sum_lnell - np.sum(np.log(tau_j))
+                    delta_j = (mu[:, j][:, None] - X.T) / tau_j[:, None]
+                    z_j = np.exp(lnnf_j - 0.5 * np.sum(delta_j**2, axis=0))
+                    tau_jk = np.sqrt((sigma[j] ** 2 + sigma[k] ** 2) * lam**2 + ell**2 + 2.0 * delta**2)
+                    lnnf_jk = ln_sf2 + sum_lnell - np.sum(np.log(tau_jk))
+                    delta_jk = (mu[:, j] - mu[:, k]) / tau_jk
+                    if Lchol:
+                        J_jk = math.exp(lnnf_jk - 0.5 * np.sum(delta_jk**2)) - z_k @ solve_upper(
+                            L, solve_upper_t(L, z_j)
+                        ) / sn2_eff  # :318-319
+                    else:
+                        J_jk = math.exp(lnnf_jk - 0.5 * np.sum(delta_jk**2)) + z_k @ (L @ z_j)  # :321-322
+                    if j == k:
+                        varF[s] += w[k] ** 2 * max(EPS, J_jk)  # :329
+                        if separate_K:
+                            J_sjk[s, k, k] = J_jk
+                    else:
+                        varF[s] += 2.0 * w[j] * w[k] * J_jk  # :332
+                        if separate_K:
+                            J_sjk[s, j, k] = J_jk
+                            J_sjk[s, k, j] = J_jk
+
+    if compute_var:
+        varF = np.maximum(varF, EPS)  # :350
+
+    dF = None
+    J_w = None
+    if anygrad:  # :352-373
+        blocks = []
+        if grad_flags[0]:
+            blocks.append(mu_grad.reshape(D * K, S, order="F"))
+        if grad_flags[1]:
+            if jacobian_flag:
+                sigma_grad = sigma_grad * sigma[:, None]
+            blocks.append(sigma_grad)
+        if grad_flags[2]:
+            if jacobian_flag:
+                lambda_grad = lambda_grad * lam[:, None]
+            blocks.append(lambda_grad)
+        if grad_flags[3]:
+            if jacobian_flag:
+                J_w = softmax_jacobian(vp["eta"])
+                w_grad = J_w @ w_grad
+            blocks.append(w_grad)
+        dF = np.vstack(blocks)
+
+    dvarF = None
+    if compute_vargrad:  # :375-395
+        blocks = []
+        if grad_flags[0]:
+            blocks.append(mu_vargrad.reshape(D * K, S, order="F"))
+        if grad_flags[1]:
+            if jacobian_flag:
+                sigma_vargrad = sigma_vargrad * sigma[:, None]
+            blocks.append(sigma_vargrad)
+        if grad_flags[2]:
+            if jacobian_flag:
+                lambda_vargrad = lambda_vargrad * lam[:, None]
+            blocks.append(lambda_vargrad)
+        if grad_flags[3]:
+            if jacobian_flag:
+                w_vargrad = J_w @ w_vargrad
+            blocks.append(w_vargrad)
+        dvarF = np.vstack(blocks)
+
+    varss = 0.0
+    if S > 1 and avg_flag:  # :399-413
+        Fbar = np.sum(F) / S
+        if compute_var:
+            varFss = np.sum((F - Fbar) ** 2) / (S - 1)
+            varss = varFss + np.std(varF, ddof=1)  # MATLAB std normalises by S-1
+            varF_out = np.sum(varF) / S + varFss
+        if compute_vargrad:
+            dvv = 2.0 * np.sum(F[None, :] * dF, axis=1) / (S - 1) - 2.0 * Fbar * np.sum(dF, axis=1) / (S - 1)
+            dvarF = np.sum(dvarF, axis=1) / S + dvv
+        if compute_var:
+            varF = varF_out
+        F = Fbar
+        if anygrad:
+            dF = np.sum(dF, axis=1) / S
+    else:
+        if S == 1:  # MATLAB 1x1 / Tx1 results
+            F = F[0]
+            if compute_var:
+                varF = varF[0]
+            if anygrad:
+                dF = dF[:, 0]
+            if compute_vargrad:
+                dvarF = dvarF[:, 0]
+    return {"F": F, "dF": dF, "varF": varF, "dvarF": dvarF, "varss": varss, "I_sk": I_sk, "J_sjk": J_sjk}
+
+
+def gplogjoint_weights(vp, grad_flag, avg_flag=True, jacobian_flag=True, compute_var=0, compute_vargrad=False):
+    """misc/gplogjoint_weights.m:1-104 (reuses cached vp.stats.I_sk / J_sjk)."""
+    K = vp["K"]
+    w = vp["w"]
+    I_sk = vp["stats"]["I_sk"]
+    J_sjk = vp["stats"]["J_sjk"]
+    S = I_sk.shape[0]
+    compute_vargrad = bool(compute_vargrad and compute_var and grad_flag)
+    if compute_vargrad and compute_var != 2:
+        raise ValueError("gplogjoint:FullVarianceGradient")
+    F = np.zeros(S)
+    w_grad = np.zeros((K, S)) if grad_flag else None
+    varF = np.zeros(S) if compute_var else None
+    w_vargrad = np.zeros((K, S)) if compute_vargrad else None
+    for s in range(S):
+        F[s] = np.sum(w * I_sk[s, :])  # :47
+        if grad_flag:
+            w_grad[:, s] = I_sk[s, :]
+        if compute_var == 2:
+            J_diag = np.diag(J_sjk[s])
+            varF[s] = np.sum(w**2 * np.maximum(EPS, J_diag))  # :52
+            if compute_vargrad:
+                w_vargrad[:, s] = 2.0 * w * np.maximum(EPS, J_diag)
+        elif compute_var:
+            varF[s] = np.sum(J_sjk[s] * np.outer(w, w))  # :58
+    if compute_var:
+        varF = np.maximum(varF, EPS)
+    dF = None
+    J_w = None
+    if grad_flag:
+        if jacobian_flag:
+            J_w = softmax_jacobian(vp["eta"])
+            w_grad = J_w @ w_grad
+        dF = w_grad
+    dvarF = None
+    if compute_vargrad:
+        if jacobian_flag:
+            w_vargrad = J_w @ w_vargrad
+        dvarF = w_vargrad
+    varss = 0.0
+    if S > 1 and avg_flag:
+        Fbar = np.sum(F) / S
+        if compute_var:
+            varFss = np.sum((F - Fbar) ** 2) / (S - 1)
+            varss = varFss + np.std(varF, ddof=1)
+            varF_out = np.sum(varF) / S + varFss
+        if compute_vargrad:
+            dvv = 2.0 * np.sum(F[None, :] * dF, axis=1) / (S - 1) - 2.0 * Fbar * np.sum(dF, axis=1) / (S - 1)
+            dvarF = np.sum(dvarF, axis=1) / S + dvv
+        if compute_var:
+            varF = varF_out
+        F = Fbar
+        if grad_flag:
+            dF = np.sum(dF, axis=1) / S
+    elif S == 1:
+        F = F[0]
+        if compute_var:
+            varF = varF[0]
+        if grad_flag:
+            dF = dF[:, 0]
+        if compute_vargrad:
+            dvarF = dvarF[:, 0]
+    return {"F": F, "dF": dF, "varF": varF, "dvarF": dvarF, "varss": varss, "I_sk": I_sk, "J_sjk": J_sjk}
+
+
+# --------------------------------------------------------------------------
+# entmc_vbmc
+# --------------------------------------------------------------------------
+
+
+def entmc_vbmc(vp, Ns, grad_flags=(0, 0, 0, 0), jacobian_flag=True, eps=None, rng=None):
+    """ent/entmc_vbmc.m:1-128 -> (H, dH).
+
+    ``eps``: (K, ceil(Ns/2), D) standard normals standing in for the K calls
+    ``randn(D,1,Ns/2)`` at :53; drawn from ``rng`` (np.random.Generator) if None.
+    """
+    grad_flags = tuple(bool(g) for g in (grad_flags if np.ndim(grad_flags) else (grad_flags,) * 4))
+    D, K = vp["D"], vp["K"]
+    mu, sigma, lam, w = vp["mu"], vp["sigma"], vp["lambda"], vp["w"]
+    mu_grad = np.zeros((D, K)) if grad_flags[0] else None
+    sigma_grad = np.zeros(K) if grad_flags[1] else None
+    lambda_grad = np.zeros(D) if grad_flags[2] else None
+    w_grad = np.zeros(K) if grad_flags[3] else None
+
+    sigmalambda = sigma[None, :] * lam[:, None]  # D x K   :34
+    nconst = 1.0 / (2.0 * math.pi) ** (D / 2.0) / np.prod(lam)  # :35
+    nf = nconst  # :40
+    H = 0.0
+    Ns = int(math.ceil(Ns / 2.0) * 2)  # :45
+    Mh = Ns // 2
+    if eps is None:
+        rng = np.random.default_rng() if rng is None else rng
+        eps = rng.standard_normal((K, Mh, D))
+    eps = np.asarray(eps, dtype=np.float64)
+    assert eps.shape == (K, Mh, D), (eps.shape, (K, Mh, D))
+
+    for j in range(K):
+        epsilon = np.concatenate([eps[j], -eps[j]], axis=0)  # Ns x D  :53-54 antithetic
+        xi = epsilon * lam[None, :] * sigma[j] + mu[:, j][None, :]  # Ns x D  :55
+        Xs = xi
+        ys = np.zeros(Ns)
+        for k in range(K):  # :60-65
+            d2 = np.sum(((Xs - mu[:, k][None, :]) / (sigma[k] * lam[None, :])) ** 2, axis=1)
+            nn = w[k] * nf / sigma[k] ** D * np.exp(-0.5 * d2)
+            ys = ys + nn
+        H = H - w[j] * np.sum(np.log(ys)) / Ns  # :67
+
+        if any(grad_flags):
+            diff = xi[:, :, None] - mu[None, :, :]  # Ns x D x K
+            norm_jl = (nconst / sigma**D)[None, :] * np.exp(-0.5 * np.sum((diff / sigmalambda[None, :, :]) ** 2, axis=1))  # Ns x K  :72
+            q_j = np.sum(w[None, :] * norm_jl, axis=1)  # Ns  :73
+            lsum = np.sum(diff / sigmalambda[None, :, :] ** 2 * (norm_jl * w[None, :])[:, None, :], axis=2)  # Ns x D :77-79
+            if grad_flags[0]:
+                mu_grad[:, j] = w[j] * np.sum(lsum / q_j[:, None], axis=0) / Ns  # :82
+            if grad_flags[1]:
+                isum = np.sum(lsum * (epsilon * lam[None, :]), axis=1)  # :87
+                sigma_grad[j] = w[j] * np.sum(isum / q_j) / Ns  # :88
+            if grad_flags[2]:
+                lambda_grad = lambda_grad + np.sum(lsum * (w[j] * sigma[j] * epsilon / q_j[:, None]), axis=0) / Ns  # :93
+            if grad_flags[3]:
+                w_grad[j] = w_grad[j] - np.sum(np.log(q_j)) / Ns  # :97
+                w_grad = w_grad - w[j] * np.sum(norm_jl / q_j[:, None], axis=0) / Ns  # :100
+
+    if grad_flags[2]:
+        lambda_grad = lambda_grad * lam  # :107
+    if jacobian_flag and grad_flags[1]:
+        sigma_grad = sigma_grad * sigma  # :113
+    if (not jacobian_flag) and grad_flags[2]:
+        lambda_grad = lambda_grad / lam  # :117
+    if jacobian_flag and grad_flags[3]:
+        w_grad = softmax_jacobian(vp["eta"]) @ w_grad  # :121-123
+    blocks = []
+    if grad_flags[0]:
+        blocks.append(mu_grad.reshape(-1, order="F"))
+    if grad_flags[1]:
+        blocks.append(sigma_grad)
+    if grad_flags[2]:
+        blocks.append(lambda_grad)
+    if grad_flags[3]:
+        blocks.append(w_grad)
+    dH = np.concatenate(blocks) if blocks else np.zeros(0)
+    return H, dH
+
+
+# --------------------------------------------------------------------------
+# entlb_vbmc
+# --------------------------------------------------------------------------
+
+
+def entlb_vbmc(vp, grad_flags=(0, 0, 0, 0), jacobian_flag=True):
+    """ent/entlb_vbmc.m:1-148 (Gershman et al. lower bound) -> (H, dH)."""
+    grad_flags = tuple(bool(g) for g in (grad_flags if np.ndim(grad_flags) else (grad_flags,) * 4))
+    D, K = vp["D"], vp["K"]
+    mu, sigma, lam, w = vp["mu"], vp["sigma"], vp["lambda"], vp["w"]
+    mu_grad = np.zeros((D, K)) if grad_flags[0] else None
+    sigma_grad = np.zeros(K) if grad_flags[1] else None
+    lambda_grad = np.zeros(D) if grad_flags[2] else None
+    w_grad = np.zeros(K) if grad_flags[3] else None
+
+    if K == 1:  # :32-47
+        H = 0.5 * D * (1.0 + math.log(2.0 * math.pi)) + D * np.sum(np.log(sigma)) + np.sum(np.log(lam))
+        if grad_flags[1]:
+            sigma_grad[:] = D / sigma
+        if grad_flags[2]:
+            lambda_grad[:] = 1.0
+        if grad_flags[3]:
+            w_grad = np.zeros(1)
+    else:  # :66-126
+        sumsigma2 = sigma[:, None] ** 2 + sigma[None, :] ** 2  # [j, k]
+        sumsigma = np.sqrt(sumsigma2)
+        nconst = 1.0 / (2.0 * math.pi) ** (D / 2.0) / np.prod(lam)
+        dmu_jk = mu[:, :, None] - mu[:, None, :]  # D x j x k : mu_j - mu_k
+        d2 = np.sum((dmu_jk / (sumsigma[None, :, :] * lam[:, None, None])) ** 2, axis=0)  # :74
+        gamma = nconst / sumsigma**D * np.exp(-0.5 * d2)  # [j,k]  :75
+        gammasum = np.sum(w[:, None] * gamma, axis=0)  # over j -> [k]  :76
+        H = -np.sum(w * np.log(gammasum))  # :78
+        if any(grad_flags):
+            gammafrac = gamma / gammasum[None, :]  # :83
+            wgammafrac = w[None, :] * gammafrac  # w_3 (3rd dim = k) :84
+            if grad_flags[0]:
+                dmu = (mu[:, None, :] - mu[:, :, None]) / (sumsigma2[None, :, :] * lam[:, None, None] ** 2)  # mu_k - mu_j  :87
+            if grad_flags[1]:
+                dsigma = -D / sumsigma2 + 1.0 / sumsigma2**2 * np.sum((dmu_jk / lam[:, None, None]) ** 2, axis=0)  # :90
+            for j in range(K):
+                if grad_flags[0]:
+                    m1 = np.sum(wgammafrac[j, :][None, :] * dmu[:, j, :], axis=1)  # :96
+                    m2 = np.sum(dmu[:, j, :] * (gamma[j, :] * w)[None, :], axis=1) / gammasum[j]  # :97
+                    mu_grad[:, j] = -w[j] * (m1 + m2)  # :98
+                if grad_flags[1]:
+                    s1 = np.sum(wgammafrac[j, :] * dsigma[j, :])  # :103
+                    s2 = np.sum(dsigma[j, :] * gamma[j, :] * w) / gammasum[j]  # :104
+                    sigma_grad[j] = -w[j] * sigma[j] * (s1 + s2)  # :105
+            if grad_flags[2]:
+                dmu2 = (mu[:, None, :] - mu[:, :, None]) ** 2 / (sumsigma2[None, :, :] * lam[:, None, None] ** 2)  # :110
+                inner = np.sum((dmu2 - 1.0) * (gamma * w[:, None])[None, :, :], axis=1)  # sum over j -> D x k :112
+                lambda_grad[:] = -np.sum(w[None, :] * inner / gammasum[None, :], axis=1)  # :111-113
+            if grad_flags[3]:
+                w_grad[:] = -np.log(gammasum) - np.sum(wgammafrac, axis=1)  # :118
+
+    if jacobian_flag and grad_flags[1]:
+        sigma_grad = sigma_grad * sigma  # :131
+    if (not jacobian_flag) and grad_flags[2]:
+        lambda_grad = lambda_grad / lam  # :135
+    if jacobian_flag and grad_flags[3]:
+        w_grad = softmax_jacobian(vp["eta"]) @ w_grad  # :139-141
+    blocks = []
+    if grad_flags[0]:
+        blocks.append(mu_grad.reshape(-1, order="F"))
+    if grad_flags[1]:
+        blocks.append(sigma_grad)
+    if grad_flags[2]:
+        blocks.append(lambda_grad)
+    if grad_flags[3]:
+        blocks.append(np.asarray(w_grad).reshape(-1))
+    dH = np.concatenate(blocks) if blocks else np.zeros(0)
+    return H, dH
+
+
+# --------------------------------------------------------------------------
+# soft bounds
+# --------------------------------------------------------------------------
+
+
+def softbndloss(x, slb, sub, TolCon=1e-3):
+    """utils/softbndloss.m:1-30 -> (y, dy)."""
+    x = np.asarray(x, dtype=np.float64)
+    ell = (sub - slb) * TolCon
+    y = 0.0
+    dy = np.zeros_like(x)
+    idx = x < slb
+    if np.any(idx):
+        y += 0.5 * np.sum(((slb[idx] - x[idx]) / ell[idx]) ** 2)
+        dy[idx] = (x[idx] - slb[idx]) / ell[idx] ** 2
+    idx = x > sub
+    if np.any(idx):
+        y += 0.5 * np.sum(((x[idx] - sub[idx]) / ell[idx]) ** 2)
+        dy[idx] = (x[idx] - sub[idx]) / ell[idx] ** 2
+    return y, dy
+
+
+def vpbounds(vp, gp, options, K=None):
+    """misc/vpbounds.m:1-55 -> (vp, thetabnd); accumulates into vp['bounds']."""
+    if K is None:
+        K = vp["K"]
+    D = vp["D"]
+    vp = copy_vp(vp)
+    b = vp.get("bounds")
+    if not b:
+        b = {
+            "mu_lb": np.full(D, np.inf),
+            "mu_ub": np.full(D, -np.inf),
+            "lnscale_lb": np.full(D, np.inf),
+            "lnscale_ub": np.full(D, -np.inf),
+        }
+    X = gp["X"]
+    b["mu_lb"] = np.minimum(X.min(axis=0), b["mu_lb"])  # :18
+    b["mu_ub"] = np.maximum(X.max(axis=0), b["mu_ub"])
+    lnrange = np.log(X.max(axis=0) - X.min(axis=0))  # :22
+    b["lnscale_lb"] = np.minimum(b["lnscale_lb"], lnrange + math.log(options["TolLength"]))
+    b["lnscale_ub"] = np.maximum(b["lnscale_ub"], lnrange)
+    if vp["optimize_weights"]:
+        b["eta_lb"] = math.log(0.5 * options["TolWeight"])  # :28
+        b["eta_ub"] = 0.0
+    vp["bounds"] = b
+    lb, ub = [], []
+    if vp["optimize_mu"]:
+        lb.append(np.tile(b["mu_lb"], K))
+        ub.append(np.tile(b["mu_ub"], K))
+    if vp["optimize_sigma"] or vp["optimize_lambda"]:
+        lb.append(np.tile(b["lnscale_lb"], K))
+        ub.append(np.tile(b["lnscale_ub"], K))
+    if vp["optimize_weights"]:
+        lb.append(np.full(K, b["eta_lb"]))
+        ub.append(np.full(K, b["eta_ub"]))
+    thetabnd = {
+        "lb": np.concatenate(lb) if lb else np.zeros(0),
+        "ub": np.concatenate(ub) if ub else np.zeros(0),
+        "TolCon": options["TolConLoss"],
+    }
+    if vp["optimize_weights"]:
+        thetabnd["WeightThreshold"] = max(1.0 / (4 * K), options["TolWeight"])  # :51
+        thetabnd["WeightPenalty"] = options["WeightPenalty"]
+    return vp, thetabnd
+
+
+def vpbndloss(theta, vp, thetabnd, TolCon, compute_grad=True):
+    """misc/vpbndloss.m:1-73 -> (L, dL)."""
+    theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    K, D = vp["K"], vp["D"]
+    if vp["optimize_mu"]:
+        mu = theta[0 : K * D]
+        idx_start = K * D
+    else:
+        mu = vp["mu"].reshape(-1, order="F")
+        idx_start = 0
+    if vp["optimize_sigma"]:
+        lnsigma = theta[idx_start : idx_start + K]
+        idx_start += K
+    else:
+        lnsigma = np.log(vp["sigma"])
+    if vp["optimize_lambda"]:
+        lnlambda = theta[idx_start : idx_start + D]
+    else:
+        lnlambda = np.log(vp["lambda"])
+    eta = theta[-K:] if vp["optimize_weights"] else None
+    lnscale = lnsigma[None, :] + lnlambda[:, None]  # D x K  :36
+    ext = []
+    if vp["optimize_mu"]:
+        ext.append(mu)
+    if vp["optimize_sigma"] or vp["optimize_lambda"]:
+        ext.append(lnscale.reshape(-1, order="F"))
+    if vp["optimize_weights"]:
+        ext.append(eta)
+    theta_ext = np.concatenate(ext)
+    L, dLext = softbndloss(theta_ext, thetabnd["lb"], thetabnd["ub"], TolCon)
+    if not compute_grad:
+        return L, None
+    out = []
+    if vp["optimize_mu"]:
+        out.append(dLext[0 : D * K])
+        idx_start = D * K
+    else:
+        idx_start = 0
+    if vp["optimize_sigma"] or vp["optimize_lambda"]:
+        dlnscale = dLext[idx_start : idx_start + D * K].reshape(D, K, order="F")
+        if vp["optimize_sigma"]:
+            out.append(np.sum(dlnscale, axis=0))
+        if vp["optimize_lambda"]:
+            out.append(np.sum(dlnscale, axis=1))
+    if vp["optimize_weights"]:
+        out.append(dLext[-K:])
+    return L, np.concatenate(out)
+
+
+# --------------------------------------------------------------------------
+# theta <-> vp
+# --------------------------------------------------------------------------
+
+
+def rescale_params(vp, theta=None):
+    """misc/rescale_params.m:1-40."""
+    vp = copy_vp(vp)
+    D = vp["D"]
+    if theta is not None and np.size(theta) > 0:
+        theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+        K = vp["K"]
+        if vp["optimize_mu"]:
+            vp["mu"] = theta[0 : D * K].reshape(D, K, order="F").copy()
+            idx_start = D * K
+        else:
+            idx_start = 0
+        if vp["optimize_sigma"]:
+            vp["sigma"] = np.exp(theta[idx_start : idx_start + K])
+            idx_start += K
+        if vp["optimize_lambda"]:
+            vp["lambda"] = np.exp(theta[idx_start : idx_start + D])
+        if vp["optimize_weights"]:
+            eta = theta[-K:]
+            eta = eta - np.max(eta)  # :23
+            vp["w"] = np.exp(eta)
+    nl = math.sqrt(np.sum(vp["lambda"] ** 2) / D)  # :28
+    vp["lambda"] = vp["lambda"] / nl
+    vp["sigma"] = vp["sigma"] * nl
+    if vp["optimize_weights"]:
+        vp["w"] = vp["w"] / np.sum(vp["w"])  # :34
+        vp.pop("eta", None)
+    vp.pop("mode", None)
+    return vp
+
+
+def get_vptheta(vp, optimize_mu=None, optimize_sigma=None, optimize_lambda=None, optimize_weights=None):
+    """misc/get_vptheta.m:1-22 -> (theta, vp)."""
+    if optimize_weights is None:
+        optimize_weights = vp["optimize_weights"]
+    if optimize_lambda is None:
+        optimize_lambda = vp["optimize_lambda"]
+    if optimize_sigma is None:
+        optimize_sigma = vp["optimize_sigma"]
+    if optimize_mu is None:
+        optimize_mu = vp["optimize_mu"]
+    vp = rescale_params(vp)
+    parts = []
+    if optimize_mu:
+        parts.append(vp["mu"].reshape(-1, order="F"))
+    if optimize_sigma:
+        parts.append(np.log(vp["sigma"]))
+    if optimize_lambda:
+        parts.append(np.log(vp["lambda"]))
+    if optimize_weights:
+        parts.append(np.log(vp["w"]))
+    theta = np.concatenate(parts) if parts else np.zeros(0)
+    return theta, vp
+
+
+# --------------------------------------------------------------------------
+# negelcbo_vbmc
+# --------------------------------------------------------------------------
+
+
+def negelcbo_vbmc(theta, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None,
+                  separate_K=False, eps=None, rng=None):
+    """misc/negelcbo_vbmc.m:1-165.
+
+    Returns dict(F, dF, G, H, varF, dH, varGss, varG, varH, I_sk, J_sjk).
+    ``separate_K`` mirrors ``nargout > 9`` (:17); ``compute_var`` default mirrors
+    ``beta ~= 0 || nargout > 4`` only in its first clause (callers pass it).
+    """
+    theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    if beta is None or not np.isfinite(beta):
+        beta = 0.0
+    if compute_var is None:
+        compute_var = 1 if beta != 0 else 0
+    compute_var = int(compute_var)
+    if compute_grad and beta != 0 and compute_var != 2:
+        raise ValueError("negelcbo_vbmc:vargrad")  # :21-24
+    vp = copy_vp(vp)
+    D, K = vp["D"], vp["K"]
+    # :33-48
+    if vp["optimize_mu"]:
+        vp["mu"] = theta[0 : D * K].reshape(D, K, order="F").copy()
+        idx_start = D * K
+    else:
+        idx_start = 0
+    if vp["optimize_sigma"]:
+        vp["sigma"] = np.exp(theta[idx_start : idx_start + K])
+        idx_start += K
+    if vp["optimize_lambda"]:
+        vp["lambda"] = np.exp(theta[idx_start : idx_start + D])
+    if vp["optimize_weights"]:
+        vp["eta"] = theta[-K:].copy()
+        vp["w"] = np.exp(vp["eta"])
+        vp["w"] = vp["w"] / np.sum(vp["w"])  # no max-shift (:45-47)
+
+    gf = (vp["optimize_mu"], vp["optimize_sigma"], vp["optimize_lambda"], vp["optimize_weights"])
+    grad_flags = tuple(bool(compute_grad) and bool(g) for g in gf)  # :51
+    onlyweights = vp["optimize_weights"] and not (vp["optimize_mu"] or vp["optimize_sigma"] or vp["optimize_lambda"])  # :54
+    if separate_K and compute_grad:
+        raise ValueError("gradient and per-component results requested together")  # :57-59
+
+    dvarG = None
+    if onlyweights:
+        r = gplogjoint_weights(vp, bool(compute_grad), True, True, compute_var,
+                               compute_vargrad=bool(compute_grad and compute_var))
+        varGss = float("nan")
+    else:
+        r = gplogjoint(vp, gp, grad_flags, True, True, compute_var, separate_K=separate_K,
+                       compute_vargrad=bool(compute_grad and compute_var))
+        varGss = r["varss"] if compute_var else 0.0
+    G = r["F"]
+    dG = r["dF"]
+    varG = r["varF"] if compute_var else 0.0
+    dvarG = r["dvarF"]
+    I_sk = r["I_sk"] if separate_K else None
+    J_sjk = r["J_sjk"] if (separate_K and compute_var) else None
+
+    if Ns > 0:
+        H, dH = entmc_vbmc(vp, Ns, grad_flags, True, eps=eps, rng=rng)  # :106
+    else:
+        H, dH = entlb_vbmc(vp, grad_flags, True)  # :109
+
+    F = -G - H  # :116
+    dF = (-dG - dH) if compute_grad else None
+    varH = 0.0
+    varF = (varG + varH) if compute_var else 0.0
+    if beta != 0:
+        F = F + beta * math.sqrt(varF)  # :127
+        if compute_grad:
+            dF = dF + 0.5 * beta * dvarG / math.sqrt(varF)  # :129
+
+    if thetabnd is not None:  # :136-164
+        L, dL = vpbndloss(theta, vp, thetabnd, thetabnd["TolCon"], compute_grad=bool(compute_grad))
+        if compute_grad:
+            dF = dF + dL
+        F = F + L
+        if vp["optimize_weights"]:
+            Thresh = thetabnd["WeightThreshold"]
+            w = vp["w"]
+            L = np.sum(w * (w < Thresh) + Thresh * (w >= Thresh)) * thetabnd["WeightPenalty"]  # :150
+            F = F + L
+            if compute_grad:
+                w_grad = thetabnd["WeightPenalty"] * (w < Thresh).astype(np.float64)  # :155
+                w_grad = softmax_jacobian(vp["eta"]) @ w_grad
+                dL = np.zeros_like(dF)
+                dL[-K:] = w_grad
+                dF = dF + dL
+    return {"F": F, "dF": dF, "G": G, "H": H, "varF": varF, "dH": dH if compute_grad else None,
+            "dG": dG if compute_grad else None,
+            "varGss": varGss, "varG": varG, "varH": varH, "I_sk": I_sk, "J_sjk": J_sjk}
+
+
+# --------------------------------------------------------------------------
+# fminadam
+# --------------------------------------------------------------------------
+
+
+def fminadam(fun, x0, TolFun=0.001, MaxIter=10000, master_stepsize=None, LB=None, UB=None):
+    """utils/fminadam.m:1-104 -> (x, f, xtab, ftab, iter)."""
+    ms = {"max": 0.1, "min": 0.001, "decay": 200.0}
+    if master_stepsize:
+        ms.update({k: v for k, v in master_stepsize.items() if v is not None})
+    fudge_factor = math.sqrt(EPS)
+    beta1, beta2 = 0.9, 0.999
+    batchsize = 20
+    TolX, TolX_max = 0.001, 0.1
+    TolFun_max = TolFun * 100.0
+    MinIter = batchsize * 2
+    x0 = np.asarray(x0, dtype=np.float64)
+    nvars = x0.size
+    LB = np.full(nvars, -np.inf) if LB is None else np.asarray(LB, dtype=np.float64).reshape(-1)
+    UB = np.full(nvars, np.inf) if UB is None else np.asarray(UB, dtype=np.float64).reshape(-1)
+    m = np.zeros(nvars)
+    v = np.zeros(nvars)
+    xtab = np.zeros((nvars, MaxIter))
+    x = x0.reshape(-1).copy()
+    ftab = np.full(MaxIter, np.nan)
+    it = 0
+    for it in range(1, MaxIter + 1):
+        isMinibatchEnd = (it % batchsize) == 0
+        f, grad = fun(x)  # :48
+        ftab[it - 1] = f
+        grad = np.asarray(grad, dtype=np.float64).reshape(-1)
+        m = beta1 * m + (1 - beta1) * grad
+        v = beta2 * v + (1 - beta2) * grad**2
+        mhat = m / (1 - beta1**it)
+        vhat = v / (1 - beta2**it)
+        stepsize = ms["min"] + (ms["max"] - ms["min"]) * math.exp(-it / ms["decay"])  # :56-57
+        x = x - stepsize * mhat / (np.sqrt(vhat) + fudge_factor)  # :59
+        x = np.minimum(np.maximum(x, LB), UB)
+        xtab[:, it - 1] = x
+        if isMinibatchEnd and it >= MinIter:  # :65-81
+            xxp = np.linspace(-(batchsize - 1) / 2.0, (batchsize - 1) / 2.0, batchsize)
+            yy = ftab[it - batchsize : it]
+            slope, slope_var = _polyfit1_slope(xxp, yy)
+            slope_err = math.sqrt(slope_var + TolFun**2)
+            slope_err_max = math.sqrt(slope_var + TolFun_max**2)
+            dx = math.sqrt(
+                np.sum(
+                    (np.mean(xtab[:, it - batchsize : it], axis=1) - np.mean(xtab[:, it - 2 * batchsize : it - batchsize], axis=1)) ** 2
+                    / batchsize
+                )
+            )
+            if (dx < TolX and abs(slope) < slope_err_max) or (abs(slope) < slope_err and dx < TolX_max):
+                break
+    x_out = np.mean(xtab[:, it - batchsize : it], axis=1)  # :96
+    f_out = float(np.mean(ftab[it - batchsize : it]))
+    return x_out.reshape(x0.shape), f_out, xtab[:, :it], ftab[:it], it
+
+
+def _polyfit1_slope(x, y):
+    """Slope of the degree-1 least-squares fit and A(1,1) of
+    ``Rinv = inv(S.R); A = (Rinv*Rinv')*S.normr^2/S.df`` (utils/fminadam.m:67-69):
+    the usual OLS variance of the slope, normr^2 / df / sum((x-mean x)^2)
+    (x is centred here, so the closed form is exact)."""
+    n = x.size
+    xm = np.mean(x)
+    sxx = np.sum((x - xm) ** 2)
+    slope = np.sum((x - xm) * (y - np.mean(y))) / sxx
+    icpt = np.mean(y) - slope * xm
+    r = y - (slope * x + icpt)
+    normr2 = float(np.sum(r * r))
+    df = n - 2
+    return float(slope), normr2 / df / sxx
+
+
+# --------------------------------------------------------------------------
+# sieve
+# --------------------------------------------------------------------------
+
+
+def gethpd_vbmc(X, y, HPDFrac=0.8):
+    """misc/gethpd_vbmc.m:9-14 (stable descending sort like MATLAB's)."""
+    N = X.shape[0]
+    order = matlab_sort_descend(y)
+    N_hpd = int(matlab_round(HPDFrac * N))
+    return X[order[:N_hpd], :], y[order[:N_hpd]]
+
+
+def matlab_round(x):
+    return math.floor(abs(x) + 0.5) * (1 if x >= 0 else -1)
+
+
+def matlab_sort_ascend(v):
+    """MATLAB sort(v,'ascend'): stable, NaN placed last (in original order)."""
+    v = np.asarray(v, dtype=np.float64)
+    nan = np.isnan(v)
+    good = np.nonzero(~nan)[0]
+    return np.concatenate([good[np.argsort(v[good], kind="stable")], np.nonzero(nan)[0]])
+
+
+def matlab_sort_descend(v):
+    """MATLAB sort(v,'descend'): stable among ties (original order kept), NaN first."""
+    v = np.asarray(v, dtype=np.float64)
+    nan = np.isnan(v)
+    idx = np.argsort(-np.where(nan, 0.0, v), kind="stable")
+    idx = idx[~nan[idx]]
+    return np.concatenate([np.nonzero(nan)[0], idx])
+
+
+def sieve_order(nelcbo_fill):
+    """misc/vpsieve_vbmc.m:81: ``[~,vp0_ord] = sort(nelcbo_fill,'ascend')``."""
+    return matlab_sort_ascend(nelcbo_fill)

@@ -1,0 +1,80 @@
+"""Shared helpers for the tests: load golden cases, build seeded synthetic problems."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from oracle import vbmc_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "mp_case*.json")))
+
+
+def load_golden(path):
+    with open(path) as f:
+        rec = json.load(f)
+    inp = {k: (np.array(v, dtype=np.float64) if isinstance(v, list) else v) for k, v in rec["inputs"].items()}
+    return inp, rec["expected"]
+
+
+def vp_from_inputs(inp):
+    vp = R.make_vp(inp["mu"], inp["sigma"], inp["lam"], eta=inp["eta"])
+    e = np.exp(inp["eta"])
+    vp["w"] = e / np.sum(e)  # negelcbo_vbmc.m:45-47
+    return vp
+
+
+def theta_from_inputs(inp):
+    return np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]), np.log(inp["lam"]), inp["eta"]])
+
+
+def synth_problem(seed, D, N, K, S, meanfun=4, noisy=False, target="lumpy"):
+    """Seeded synthetic GP + VP in the shape of SURVEY.md section 8(d)."""
+    rng = np.random.default_rng(seed)
+    X = 1.5 * rng.standard_normal((N, D))
+    if target == "lumpy":
+        nc = 12
+        mus = rng.uniform(-2, 2, size=(nc, D))
+        sig = rng.uniform(0.3, 1.0, size=nc)
+        wts = rng.dirichlet(np.ones(nc))
+        lp = np.stack([
+            np.log(wts[i]) - 0.5 * np.sum(((X - mus[i]) / sig[i]) ** 2, axis=1) - D * np.log(sig[i]) - 0.5 * D * np.log(2 * np.pi)
+            for i in range(nc)
+        ])
+        mx = lp.max(axis=0)
+        y = mx + np.log(np.sum(np.exp(lp - mx), axis=0))
+    else:  # multivariate Student-t, nu = 5, scale diag(1:D)/D
+        nu = 5.0
+        sc = np.arange(1, D + 1) / D
+        y = -0.5 * (nu + D) * np.log1p(np.sum((X / sc) ** 2, axis=1) / nu)
+    s2 = None
+    noisefun = (1, 0, 0)
+    if noisy:
+        y = y + rng.standard_normal(N)
+        s2 = np.ones(N)
+        noisefun = (1, 1, 0)
+    nmean = {0: 0, 1: 1, 4: 2 * D + 1}[meanfun]
+    hyp = np.zeros((D + 2 + nmean, S))
+    for s in range(S):
+        hyp[:D, s] = np.log(0.8) + 0.2 * rng.standard_normal(D)
+        hyp[D, s] = np.log(np.std(y)) + 0.1 * rng.standard_normal()
+        hyp[D + 1, s] = np.log(1e-3)
+        if meanfun >= 1:
+            hyp[D + 2, s] = np.max(y)
+        if meanfun == 4:
+            hyp[D + 3 : D + 3 + D, s] = 0.2 * rng.standard_normal(D)
+            hyp[D + 3 + D :, s] = np.log(2.0) + 0.1 * rng.standard_normal(D)
+    order = np.argsort(-y, kind="stable")
+    hpd = X[order[: int(round(0.8 * N))]]
+    mu = hpd[rng.permutation(hpd.shape[0])[np.arange(K) % hpd.shape[0]]].T.copy()
+    V = np.var(mu, axis=1, ddof=1) if K > 1 else np.var(hpd, axis=0, ddof=1)
+    sigma = np.sqrt(np.mean(V) / K) * np.exp(0.2 * rng.standard_normal(K))
+    lam = np.std(hpd, axis=0, ddof=1)
+    lam = lam * np.sqrt(D / np.sum(lam**2))
+    eta = 0.3 * rng.standard_normal(K)
+    return dict(D=D, N=N, K=K, S=S, X=X, y=y, s2=s2, hyp=hyp, meanfun=meanfun, noisefun=noisefun,
+                mu=mu, sigma=sigma, lam=lam, eta=eta, rng=rng)

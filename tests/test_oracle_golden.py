@@ -1,0 +1,87 @@
+"""The NumPy oracle against the committed 50-digit mpmath golden vectors (CPU only)."""
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._cases import golden_cases, load_golden, vp_from_inputs
+
+RTOL = 1e-11  # fp64 restatement vs 50-digit evaluation; sums of <= ~100 terms
+
+
+def close(a, b, rtol=RTOL, atol=1e-13):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(1.0, float(np.max(np.abs(b))))
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.max(np.abs(a - b)) if a.size else 0.0
+    assert err <= rtol * scale + atol, (err, scale)
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_entmc_matches_mpmath(path):
+    inp, exp = load_golden(path)
+    vp = vp_from_inputs(inp)
+    H, dH = R.entmc_vbmc(vp, 2 * inp["Mh"], (1, 1, 1, 1), True, eps=inp["eps"])
+    close(H, exp["entmc_H"])
+    close(dH, exp["entmc_dH"])
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_entlb_matches_mpmath(path):
+    inp, exp = load_golden(path)
+    vp = vp_from_inputs(inp)
+    H, dH = R.entlb_vbmc(vp, (1, 1, 1, 1), True)
+    close(H, exp["entlb_H"])
+    close(dH, exp["entlb_dH"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_gp_post_pred_match_mpmath(path):
+    inp, exp = load_golden(path)
+    gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"])
+    for s, post in enumerate(gp["post"]):
+        assert post["Lchol"] and post["sn2_mult"] == 1.0
+        close(post["alpha"], exp["alpha"][s], rtol=1e-9)  # cond(K) amplifies rounding
+        close(post["L"], exp["L"][s], rtol=1e-10)
+    _, _, fmu, fs2 = R.gplite_pred(gp, inp["Xstar"], ssflag=True)
+    close(fmu.T, exp["pred_fmu"], rtol=1e-9)
+    close(fs2.T, exp["pred_fs2"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_gplogjoint_matches_mpmath(path):
+    inp, exp = load_golden(path)
+    vp = vp_from_inputs(inp)
+    gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"])
+    # plug the 50-digit alpha/L so the comparison isolates gplogjoint itself
+    for s, post in enumerate(gp["post"]):
+        post["alpha"] = np.array(exp["alpha"][s])
+        post["L"] = np.array(exp["L"][s])
+    r = R.gplogjoint(vp, gp, (1, 1, 1, 1), avg_flag=False, jacobian_flag=True, compute_var=1, separate_K=True)
+    S = inp["S"]
+    close(np.atleast_1d(r["F"]), exp["G_s"])
+    close(np.asarray(r["dF"]).reshape(-1, S, order="F").T if S > 1 else np.asarray(r["dF"])[None, :], exp["dG_s"])
+    close(r["I_sk"], exp["I_sk"])
+    close(r["J_sjk"], exp["J_sjk"], rtol=1e-8)  # z' K^-1 z cancels against nf_jk
+    close(np.atleast_1d(r["varF"]), exp["varG_s_full"], rtol=1e-8)
+    r2 = R.gplogjoint(vp, gp, (0, 0, 0, 0), avg_flag=False, compute_var=2, separate_K=True)
+    close(np.atleast_1d(r2["varF"]), exp["varG_s_diag"], rtol=1e-8)
+
+
+def test_averaging_over_hyper_samples():
+    """misc/gplogjoint.m:399-413 against a direct evaluation from per-sample values."""
+    inp, exp = load_golden(golden_cases()[1])
+    vp = vp_from_inputs(inp)
+    gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"])
+    per = R.gplogjoint(vp, gp, (1, 1, 1, 1), avg_flag=False, compute_var=2, compute_vargrad=True)
+    avg = R.gplogjoint(vp, gp, (1, 1, 1, 1), avg_flag=True, compute_var=2, compute_vargrad=True)
+    S = inp["S"]
+    F, dF, vF, dvF = per["F"], per["dF"], per["varF"], per["dvarF"]
+    Fbar = F.sum() / S
+    varFss = ((F - Fbar) ** 2).sum() / (S - 1)
+    close(avg["F"], Fbar)
+    close(avg["dF"], dF.sum(axis=1) / S)
+    close(avg["varF"], vF.sum() / S + varFss)
+    close(avg["varss"], varFss + np.std(vF, ddof=1))
+    dvv = 2 * (F[None, :] * dF).sum(axis=1) / (S - 1) - 2 * Fbar * dF.sum(axis=1) / (S - 1)
+    close(avg["dvarF"], dvF.sum(axis=1) / S + dvv)
