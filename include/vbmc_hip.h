@@ -1,0 +1,138 @@
+/*
+ * vbmc_hip.h -- C ABI of libvbmc_hip.so: the MI355X (gfx950) implementation of the VBMC
+ * ELBO inner loop.  This is the drop-in boundary: the reference (acerbilab/vbmc v1.0.12)
+ * is pure MATLAB with no FFI seam, so these entry points are what a MEX
+ * gateway (matlab/vbmc_hip_mex.cpp) or a ctypes binding (vbmc_amd/_lib.py) binds, one per
+ * reference function on the path.  Each declaration cites the reference interface it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - all arrays are column-major IEEE fp64 exactly as MATLAB stores them, caller-owned,
+ *     non-aliasing; the library never keeps a host pointer after the call returns;
+ *   - every function returns a vbmc_status (0 = OK) and never throws across the ABI;
+ *     vbmc_last_error(ctx) gives the message of the last failure on that context;
+ *   - a context owns one HIP stream and all device scratch; calls on one context are
+ *     serialised by the caller (the MATLAB interpreter thread / one Python process per GPU);
+ *   - the library FAILS (VBMC_ERR_NO_DEVICE) when no gfx950 device is present: there is no
+ *     CPU fallback anywhere behind this ABI.
+ */
+#ifndef VBMC_HIP_H
+#define VBMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBMC_ABI_VERSION 1
+
+typedef int vbmc_status;
+enum {
+  VBMC_OK = 0,
+  VBMC_ERR_INVALID = 1,      /* bad argument (message says which)                         */
+  VBMC_ERR_NO_DEVICE = 2,    /* no HIP device / not gfx950                                */
+  VBMC_ERR_HIP = 3,          /* a HIP runtime call failed                                 */
+  VBMC_ERR_UNSUPPORTED = 4,  /* option outside the accelerated path: caller must fall     */
+                             /* through to the reference .m (e.g. meanfun not in {0,1,4}) */
+  VBMC_ERR_NOT_POSDEF = 5    /* Cholesky failed after the reference's 10 jitter retries   */
+};
+
+typedef struct vbmc_ctx vbmc_ctx; /* device context: stream + scratch                      */
+typedef struct vbmc_gp vbmc_gp;   /* device-resident gp.post(1..S) (gplite_post.m:94-157)  */
+
+/* ---- library / context ------------------------------------------------------------- */
+int vbmc_abi_version(void);
+/* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private one */
+vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out);
+void vbmc_ctx_destroy(vbmc_ctx* ctx);
+const char* vbmc_last_error(const vbmc_ctx* ctx);
+vbmc_status vbmc_ctx_synchronize(vbmc_ctx* ctx);
+/* When enabled, HIP events bracket the dominant kernel (entropy MC) of every elbo call on the
+ * context's stream; vbmc_ctx_last_kernel_ms returns its duration (bench.py roofline leg). */
+vbmc_status vbmc_ctx_set_profiling(vbmc_ctx* ctx, int enable);
+vbmc_status vbmc_ctx_last_kernel_ms(vbmc_ctx* ctx, double* ent_ms, double* logjoint_ms);
+
+/* ---- GP surrogate state -------------------------------------------------------------- */
+/*
+ * Upload gp.X and gp.post(s).{hyp,alpha,L,sW,Lchol} once per vpoptimize_vbmc call
+ * (misc/vpoptimize_vbmc.m:71 closes over a constant gp).  Replaces the reads at
+ * misc/gplogjoint.m:97-160.
+ *   X      N x D      training inputs
+ *   hyp    Nhyp x S   [log ell(D); log sf; noise(Nnoise); mean(Nmean)]
+ *   alpha  N x S
+ *   L      N x N x S  upper Cholesky factor (Lchol=1) or -inv(K+sn2 I) (Lchol=0); may be NULL
+ *                     when only value/gradient without variance will be requested
+ *   sW1    S          gp.post(s).sW(1)   (sn2_eff = 1/sW1^2, gplogjoint.m:160)
+ *   Lchol  S          uint8 flags
+ *   meanfun           gplite mean-function id; only 0 (zero), 1 (const), 4 (negquad) are
+ *                     accelerated -- others return VBMC_ERR_UNSUPPORTED
+ */
+vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Ncov, int Nnoise,
+                           int meanfun, const double* X, const double* hyp, const double* alpha,
+                           const double* L, const double* sW1, const uint8_t* Lchol,
+                           vbmc_gp** out);
+void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp);
+
+/* ---- the ELBO objective ---------------------------------------------------------------
+ * One call evaluates R independent negelcbo_vbmc(theta_r, beta, vp, gp, Ns, compute_grad,
+ * compute_var, ~, thetabnd) (misc/negelcbo_vbmc.m:1) -- R = 1 is the Adam-loop call
+ * (misc/vpoptimize_vbmc.m:71, utils/fminadam.m:48), R > 1 is the sieve batch
+ * (misc/vpsieve_vbmc.m:74-78).
+ */
+typedef struct vbmc_elbo_args {
+  uint32_t struct_size;      /* = sizeof(vbmc_elbo_args), for ABI versioning                */
+  int32_t D, K, R;
+  int32_t optimize[4];       /* vp.optimize_{mu,sigma,lambda,weights}                       */
+  const double* theta;       /* T x R, T = sum of optimised groups, negelcbo_vbmc.m:33-48   */
+  /* current vp fields; used for every group that is NOT optimised (may be NULL otherwise)  */
+  const double* vp_mu;       /* D x K */
+  const double* vp_sigma;    /* K     */
+  const double* vp_lambda;   /* D     */
+  const double* vp_w;        /* K     */
+  const double* vp_delta;    /* D or NULL (= 0), gplogjoint.m:85-89                         */
+  int32_t Ns;                /* MC samples per component; forced even (entmc_vbmc.m:45);    */
+                             /* 0 -> deterministic bound entlb_vbmc (negelcbo_vbmc.m:104-110) */
+  int32_t eps_mode;          /* 0 device Philox RNG; 1 eps on host; 2 eps already on device */
+  const double* eps;         /* D x Ns/2 x K (x R unless eps_shared): the K consecutive     */
+                             /* randn(D,1,Ns/2) blocks of entmc_vbmc.m:53                   */
+  int32_t eps_shared;        /* 1: one eps block reused for all R restarts                  */
+  uint64_t seed;             /* eps_mode 0: Philox key; stream position = (r, j, sample)    */
+  int32_t compute_grad;      /* negelcbo arg 6                                              */
+  int32_t compute_var;       /* 0 none, 1 full K x K, 2 diagonal (gplogjoint.m:273-337)     */
+  int32_t separate_K;        /* also return I_sk (and J_sjk when compute_var)               */
+  double beta;               /* ELCBO weight (negelcbo arg 2)                               */
+  /* soft bounds (misc/vpbounds.m, misc/vpbndloss.m); lb == NULL -> thetabnd = []           */
+  const double* bnd_lb;      /* length of theta_ext: [mu(:); lnscale(:) (D x K); eta]       */
+  const double* bnd_ub;
+  double TolCon, WeightThreshold, WeightPenalty;
+  /* outputs (any may be NULL) */
+  double* F;                 /* R      negative EL(C)BO incl. penalties                     */
+  double* dF;                /* T x R                                                       */
+  double* G;                 /* R      expected log joint                                   */
+  double* H;                 /* R      entropy                                              */
+  double* dG;                /* T x R                                                       */
+  double* dH;                /* T x R                                                       */
+  double* varG;              /* R                                                           */
+  double* varGss;            /* R                                                           */
+  double* I_sk;              /* S x K x R                                                   */
+  double* J_sjk;             /* S x K x K x R                                               */
+} vbmc_elbo_args;
+
+vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
+
+/* Writes the exact standard-normal block eps (D x Ns/2 x K x R) that eps_mode 0 consumes for
+ * `seed`, so that a host oracle can be fed the same draws (test hook; entmc_vbmc.m:53). */
+vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t seed, double* eps_host);
+
+/* Device-memory helpers for callers without their own allocator (MEX). */
+vbmc_status vbmc_device_alloc(vbmc_ctx* ctx, size_t bytes, void** dptr);
+vbmc_status vbmc_device_free(vbmc_ctx* ctx, void* dptr);
+vbmc_status vbmc_memcpy_h2d(vbmc_ctx* ctx, void* dst, const void* src, size_t bytes);
+vbmc_status vbmc_memcpy_d2h(vbmc_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBMC_HIP_H */

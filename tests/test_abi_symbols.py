@@ -1,0 +1,55 @@
+"""CPU: libvbmc_hip.so loads and exports every symbol include/vbmc_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if not fn.endswith(".h"):
+            continue
+        txt = open(os.path.join(ROOT, "include", fn)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        for m in re.finditer(r"\b(vbmc_[a-z0-9_]+)\s*\(", txt):
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+
+    g.build()
+    from vbmc_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.vbmc_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a gfx950 device the product path must fail loudly, never compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import vbmc_amd
+
+    with pytest.raises(vbmc_amd.VbmcHipError):
+        vbmc_amd.Context(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vbmc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.replace("no CPU fallback", ""), os.path.join(dirpath, fn)

@@ -1,0 +1,200 @@
+"""GPU parity: HIP negelcbo path (through the C ABI) vs the oracle on identical inputs.
+
+Tolerances: fp64 end to end.  ELBO pieces are compared at rel 1e-10 (north_star asks 1e-6); the
+looser 1e-9 on gradients covers summation-order differences over N / Ns terms.
+"""
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._cases import golden_cases, load_golden, synth_problem, theta_from_inputs, vp_from_inputs
+
+pytestmark = pytest.mark.gpu
+
+RT_VAL = 1e-10
+RT_GRAD = 1e-9
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+def problem(seed, D, N, K, S, **kw):
+    p = synth_problem(seed, D, N, K, S, **kw)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"], noisefun=p["noisefun"], s2=p["s2"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    return p, gp, vp, theta
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_golden_vectors(va, path):
+    """HIP path vs the committed 50-digit mpmath vectors (entmc, entlb, per-sample log joint)."""
+    inp, exp = load_golden(path)
+    vp = vp_from_inputs(inp)
+    gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"])
+    for s, post in enumerate(gp["post"]):
+        post["alpha"] = np.array(exp["alpha"][s])
+    theta = theta_from_inputs(inp)
+    S = inp["S"]
+    r = va.negelcbo_batch(theta, 0, vp, gp, 2 * inp["Mh"], True, 0, eps=inp["eps"])
+    assert relerr(r["H"][0], exp["entmc_H"]) < 1e-11
+    assert relerr(r["dH"][:, 0], exp["entmc_dH"]) < 1e-11
+    assert relerr(r["G"][0], np.mean(exp["G_s"])) < 1e-11
+    assert relerr(r["dG"][:, 0], np.mean(np.array(exp["dG_s"]), axis=0)) < 1e-11
+    r0 = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 0)
+    assert relerr(r0["H"][0], exp["entlb_H"]) < 1e-11
+    assert relerr(r0["dH"][:, 0], exp["entlb_dH"]) < 1e-10
+    rs = va.negelcbo_batch(theta, 0, vp, gp, 0, False, 0, separate_K=True)
+    assert relerr(rs["I_sk"][:, :, 0], np.array(exp["I_sk"])) < 1e-11
+    assert S == rs["I_sk"].shape[0]
+
+
+CONFIGS = [
+    # name, D, N, K, S, Ns, target
+    ("C1-rosenbrock-shape", 2, 30, 2, 1, 100, "lumpy"),
+    ("C2-student", 6, 200, 10, 8, 1000, "student"),
+    ("small-odd", 3, 17, 5, 2, 37, "lumpy"),
+    ("D10", 10, 120, 12, 4, 200, "lumpy"),
+    ("D13-pad", 13, 60, 6, 2, 64, "lumpy"),
+    ("D20", 20, 90, 7, 2, 64, "lumpy"),
+    ("K70", 4, 40, 70, 2, 66, "lumpy"),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_elbo_and_gradient_match_oracle(va, cfg):
+    _, D, N, K, S, Ns, target = cfg
+    p, gp, vp, theta = problem(1, D, N, K, S, target=target)
+    Mh = (Ns + 1) // 2
+    eps = np.random.default_rng(5).standard_normal((K, Mh, D))
+    ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+    F, dF, G, H, varF, dH = va.negelcbo_vbmc(theta, 0, vp, gp, Ns, 1, 0, nargout=6, eps=eps)
+    assert relerr(G, ref["G"]) < RT_VAL
+    assert relerr(H, ref["H"]) < RT_VAL
+    assert relerr(F, ref["F"]) < RT_VAL
+    assert relerr(dH, ref["dH"]) < RT_GRAD
+    assert relerr(dF, ref["dF"]) < RT_GRAD
+    # value-only call (the sieve's form) gives the same value
+    (F2,) = va.negelcbo_vbmc(theta, 0, vp, gp, Ns, 0, 0, nargout=1, eps=eps)
+    assert relerr(F2, ref["F"]) < RT_VAL
+
+
+def test_deterministic_entropy_branch(va):
+    """Ns == 0 -> entlb_vbmc (negelcbo_vbmc.m:104-110), the sieve's default."""
+    for K in (1, 2, 9):
+        p, gp, vp, theta = problem(2, 5, 50, K, 3)
+        ref = R.negelcbo_vbmc(theta, 0, vp, gp, 0, True, 0)
+        F, dF, G, H, _, dH = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 1, 0, nargout=6)
+        assert relerr(H, ref["H"]) < RT_VAL and relerr(G, ref["G"]) < RT_VAL
+        assert relerr(dH, ref["dH"]) < RT_GRAD and relerr(dF, ref["dF"]) < RT_GRAD
+
+
+@pytest.mark.parametrize("flags", [(1, 1, 1, 0), (1, 1, 0, 0), (0, 1, 1, 1), (1, 0, 0, 1), (0, 0, 0, 1)])
+def test_optimize_flag_subsets(va, flags):
+    """theta packing honours vp.optimize_* (negelcbo_vbmc.m:33-51); warm-up has no eta block."""
+    p, gp, vp, _ = problem(3, 4, 40, 6, 2)
+    for name, f in zip(("optimize_mu", "optimize_sigma", "optimize_lambda", "optimize_weights"), flags):
+        vp[name] = bool(f)
+    parts = []
+    if flags[0]:
+        parts.append(vp["mu"].reshape(-1, order="F") + 0.05)
+    if flags[1]:
+        parts.append(np.log(vp["sigma"]) - 0.1)
+    if flags[2]:
+        parts.append(np.log(vp["lambda"]) + 0.02)
+    if flags[3]:
+        parts.append(vp["eta"] + 0.1)
+    theta = np.concatenate(parts)
+    if flags == (0, 0, 0, 1):
+        pytest.skip("weights-only branch uses cached I_sk (gplogjoint_weights); host-side, covered elsewhere")
+    eps = np.random.default_rng(7).standard_normal((6, 20, 4))
+    ref = R.negelcbo_vbmc(theta, 0, vp, gp, 40, True, 0, eps=eps)
+    F, dF = va.negelcbo_vbmc(theta, 0, vp, gp, 40, 1, 0, eps=eps)
+    assert dF.shape == ref["dF"].shape
+    assert relerr(F, ref["F"]) < RT_VAL and relerr(dF, ref["dF"]) < RT_GRAD
+
+
+def test_soft_bounds_and_weight_penalty(va):
+    p, gp, vp, theta = problem(4, 3, 30, 5, 2)
+    opts = dict(TolLength=1e-6, TolWeight=1e-2, TolConLoss=0.01, WeightPenalty=0.1)
+    vpb, tb = R.vpbounds(vp, gp, opts)
+    th = theta.copy()
+    th[0] += 9.0
+    th[4] -= 7.0
+    th[3 * 5 + 1] = 3.0     # a log-sigma far above the scale bound
+    th[-1] = -9.0           # eta below its bound, weight below threshold
+    th[-2] = 1.0            # eta above its upper bound 0
+    eps = np.random.default_rng(8).standard_normal((5, 16, 3))
+    ref = R.negelcbo_vbmc(th, 0, vpb, gp, 32, True, 0, thetabnd=tb, eps=eps)
+    ref0 = R.negelcbo_vbmc(th, 0, vpb, gp, 32, True, 0, eps=eps)
+    assert ref["F"] - ref0["F"] > 1.0  # the penalties are actually active
+    F, dF = va.negelcbo_vbmc(th, 0, vpb, gp, 32, 1, 0, False, tb, eps=eps)
+    assert relerr(F, ref["F"]) < RT_VAL and relerr(dF, ref["dF"]) < RT_GRAD
+
+
+def test_batch_equals_singles_and_is_deterministic(va):
+    p, gp, vp, theta = problem(5, 6, 80, 8, 4)
+    R_ = 5
+    rng = np.random.default_rng(3)
+    thetas = theta[:, None] + 0.05 * rng.standard_normal((theta.size, R_))
+    eps = rng.standard_normal((R_, 8, 25, 6))
+    b1 = va.negelcbo_batch(thetas, 0, vp, gp, 50, True, 0, eps=eps)
+    b2 = va.negelcbo_batch(thetas, 0, vp, gp, 50, True, 0, eps=eps)
+    assert np.array_equal(b1["F"], b2["F"]) and np.array_equal(b1["dF"], b2["dF"])  # bit-identical reruns
+    for r in range(R_):
+        ref = R.negelcbo_vbmc(thetas[:, r], 0, vp, gp, 50, True, 0, eps=eps[r])
+        assert relerr(b1["F"][r], ref["F"]) < RT_VAL
+        assert relerr(b1["dF"][:, r], ref["dF"]) < RT_GRAD
+
+
+def test_device_rng_stream_is_reproducible_and_standard_normal(va):
+    """eps_mode 0: the Philox stream the kernel consumes can be dumped and fed to the oracle."""
+    p, gp, vp, theta = problem(6, 5, 40, 4, 2)
+    eng = va.default_engine()
+    Ns, seed = 96, 1234
+    eps = eng.ctx.rng_dump(5, 4, 2, Ns, seed)
+    assert eps.shape == (2, 4, 48, 5)
+    thetas = np.stack([theta, theta + 0.01], axis=1)
+    out = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=seed)
+    for r in range(2):
+        ref = R.negelcbo_vbmc(thetas[:, r], 0, vp, gp, Ns, True, 0, eps=eps[r])
+        assert relerr(out["H"][r], ref["H"]) < RT_VAL
+        assert relerr(out["dF"][:, r], ref["dF"]) < RT_GRAD
+    big = eng.ctx.rng_dump(8, 16, 4, 4096, 99).reshape(-1)
+    assert abs(big.mean()) < 5e-3 and abs(big.std() - 1.0) < 5e-3
+    assert abs(np.mean(big**3)) < 2e-2 and abs(np.mean(big**4) - 3.0) < 5e-2
+    out2 = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=seed + 1)
+    assert out2["H"][0] != out["H"][0]
+
+
+def test_entropy_mc_converges_to_closed_form(va):
+    """K = 1: entmc -> 0.5 D (1 + log 2 pi) + D log sigma + sum log lambda (entlb_vbmc.m:34)."""
+    p, gp, vp, theta = problem(7, 4, 30, 1, 1)
+    (F0, _, _, H0) = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 0, 0, nargout=4)
+    (F1, _, _, H1) = va.negelcbo_vbmc(theta, 0, vp, gp, 200000, 0, 0, nargout=4, seed=5)
+    assert abs(H1 - H0) < 0.02
+
+
+def test_error_ids_mirror_reference(va):
+    p, gp, vp, theta = problem(8, 3, 20, 3, 1)
+    with pytest.raises(va.VbmcHipError, match="negelcbo_vbmc:vargrad"):
+        va.negelcbo_vbmc(theta, 1.0, vp, gp, 10, 1, 1)
+    gp_bad = dict(gp)
+    gp_bad["meanfun"] = 6
+    with pytest.raises(va.VbmcUnsupported, match="UnsupportedMeanFun"):
+        va.negelcbo_vbmc(theta, 0, vp, gp_bad, 10, 1, 0)
+    with pytest.raises(va.VbmcHipError, match="non-finite"):
+        bad = theta.copy()
+        bad[0] = np.nan
+        va.negelcbo_vbmc(bad, 0, vp, gp, 10, 1, 0)

@@ -1,0 +1,197 @@
+"""ctypes binding of libvbmc_hip.so (include/vbmc_hip.h).
+
+The product path has NO CPU fallback: importing this module without the built
+library, or creating a Context without a gfx950 device, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvbmc_hip.so")
+
+VBMC_OK, VBMC_ERR_INVALID, VBMC_ERR_NO_DEVICE, VBMC_ERR_HIP, VBMC_ERR_UNSUPPORTED, VBMC_ERR_NOT_POSDEF = range(6)
+_STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "UNSUPPORTED", 5: "NOT_POSDEF"}
+
+
+class VbmcHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("libvbmc_hip: %s: %s" % (_STATUS_NAMES.get(status, status), msg))
+        self.status = status
+        self.message = msg
+
+
+class VbmcUnsupported(VbmcHipError):
+    """Option outside the accelerated path; the caller should fall through to the reference .m."""
+
+
+_dp = C.POINTER(C.c_double)
+
+
+class ElboArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("D", C.c_int32), ("K", C.c_int32), ("R", C.c_int32),
+        ("optimize", C.c_int32 * 4),
+        ("theta", _dp),
+        ("vp_mu", _dp), ("vp_sigma", _dp), ("vp_lambda", _dp), ("vp_w", _dp), ("vp_delta", _dp),
+        ("Ns", C.c_int32),
+        ("eps_mode", C.c_int32),
+        ("eps", C.c_void_p),
+        ("eps_shared", C.c_int32),
+        ("seed", C.c_uint64),
+        ("compute_grad", C.c_int32), ("compute_var", C.c_int32), ("separate_K", C.c_int32),
+        ("beta", C.c_double),
+        ("bnd_lb", _dp), ("bnd_ub", _dp),
+        ("TolCon", C.c_double), ("WeightThreshold", C.c_double), ("WeightPenalty", C.c_double),
+        ("F", _dp), ("dF", _dp), ("G", _dp), ("H", _dp), ("dG", _dp), ("dH", _dp),
+        ("varG", _dp), ("varGss", _dp), ("I_sk", _dp), ("J_sjk", _dp),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.vbmc_abi_version.restype = C.c_int
+    lib.vbmc_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.vbmc_ctx_destroy.argtypes = [vp]
+    lib.vbmc_ctx_destroy.restype = None
+    lib.vbmc_last_error.argtypes = [vp]
+    lib.vbmc_last_error.restype = C.c_char_p
+    lib.vbmc_ctx_synchronize.argtypes = [vp]
+    lib.vbmc_ctx_set_profiling.argtypes = [vp, C.c_int]
+    lib.vbmc_ctx_last_kernel_ms.argtypes = [vp, _dp, _dp]
+    lib.vbmc_gp_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_uint8), C.POINTER(vp)]
+    lib.vbmc_gp_free.argtypes = [vp, vp]
+    lib.vbmc_gp_free.restype = None
+    lib.vbmc_elbo_batch.argtypes = [vp, vp, C.POINTER(ElboArgs)]
+    lib.vbmc_rng_dump.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp]
+    lib.vbmc_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.vbmc_device_free.argtypes = [vp, vp]
+    lib.vbmc_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.vbmc_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    for name in DECLARED_OPTIONAL:
+        if hasattr(lib, name):
+            pass
+    if lib.vbmc_abi_version() != 1:
+        raise ImportError("libvbmc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+DECLARED_OPTIONAL = ()
+
+
+def f64(a, order="F"):
+    """Contiguous column-major fp64 copy/view (what MATLAB hands over)."""
+    return np.require(np.asarray(a, dtype=np.float64), dtype=np.float64, requirements=["F" if order == "F" else "C", "A"])
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Context:
+    """One HIP stream + device scratch on one GPU (vbmc_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = C.c_void_p()
+        st = self.lib.vbmc_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != VBMC_OK:
+            raise VbmcHipError(st, "vbmc_ctx_create(device=%d) failed: a gfx950 (MI355X) device is required; "
+                                   "there is no CPU fallback" % device)
+        self.h = h
+        self.device = device
+
+    def check(self, st):
+        if st == VBMC_OK:
+            return
+        msg = self.lib.vbmc_last_error(self.h).decode("utf-8", "replace")
+        if st == VBMC_ERR_UNSUPPORTED:
+            raise VbmcUnsupported(st, msg)
+        raise VbmcHipError(st, msg)
+
+    def synchronize(self):
+        self.check(self.lib.vbmc_ctx_synchronize(self.h))
+
+    def set_profiling(self, on=True):
+        self.check(self.lib.vbmc_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        a, b = C.c_double(), C.c_double()
+        self.check(self.lib.vbmc_ctx_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def rng_dump(self, D, K, R, Ns, seed):
+        """eps (R, K, Ns/2, D) that eps_mode 0 consumes for `seed` (test hook)."""
+        Mh = (Ns + 1) // 2
+        out = np.empty((R, K, Mh, D), dtype=np.float64)
+        self.check(self.lib.vbmc_rng_dump(self.h, D, K, R, Ns, C.c_uint64(seed), ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vbmc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceGP:
+    """Device-resident gp.post(1..S) (vbmc_gp)."""
+
+    def __init__(self, ctx, X, hyp, alpha, L, sW1, Lchol, meanfun, Ncov, Nnoise):
+        self.ctx = ctx
+        X = f64(X)
+        hyp = f64(hyp)
+        if hyp.ndim == 1:
+            hyp = hyp[:, None]
+        alpha = f64(alpha)
+        if alpha.ndim == 1:
+            alpha = alpha[:, None]
+        N, D = X.shape
+        Nhyp, S = hyp.shape
+        sW1 = f64(np.asarray(sW1).reshape(S))
+        lch = np.ascontiguousarray(np.asarray(Lchol, dtype=np.uint8).reshape(S))
+        Lp = None
+        if L is not None:
+            L = f64(L)  # (N, N, S) column-major == MATLAB N x N x S
+            assert L.shape == (N, N, S), L.shape
+            Lp = ptr(L)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.vbmc_gp_upload(ctx.h, N, D, S, Nhyp, int(Ncov), int(Nnoise), int(meanfun), ptr(X), ptr(hyp),
+                                         ptr(alpha), Lp, ptr(sW1), lch.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(h)))
+        self.h = h
+        self.N, self.D, self.S = N, D, S
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.vbmc_gp_free(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,452 @@
+// C-ABI entry points of libvbmc_hip.so for the ELBO objective (include/vbmc_hip.h).
+// Host side: argument validation, device scratch, launches, one packed D2H per call.
+#include <cmath>
+
+#include "elbo_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+extern "C" int vbmc_abi_version(void) { return VBMC_ABI_VERSION; }
+
+extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out) {
+  if (!out) return VBMC_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VBMC_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return VBMC_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VBMC_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VBMC_ERR_NO_DEVICE;  // gfx950 only, no fallback
+  vbmc_ctx* ctx = new vbmc_ctx();
+  ctx->device = device;
+  ctx->num_cu = prop.multiProcessorCount;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return VBMC_ERR_HIP; }
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VBMC_ERR_HIP; }
+    ctx->own_stream = true;
+  }
+  for (auto& e : ctx->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete ctx; return VBMC_ERR_HIP; }
+  *out = ctx;
+  return VBMC_OK;
+}
+
+extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  DevBuf* bufs[] = {&ctx->theta, &ctx->prep, &ctx->entp, &ctx->ljpart, &ctx->entpart, &ctx->out,
+                    &ctx->eps, &ctx->bnd, &ctx->vpfix, &ctx->misc, &ctx->varbuf, &ctx->zbuf};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* vbmc_last_error(const vbmc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" vbmc_status vbmc_ctx_synchronize(vbmc_ctx* ctx) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_ctx_set_profiling(vbmc_ctx* ctx, int enable) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  ctx->profiling = enable != 0;
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_ctx_last_kernel_ms(vbmc_ctx* ctx, double* ent_ms, double* logjoint_ms) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (ent_ms) *ent_ms = ctx->last_ent_ms;
+  if (logjoint_ms) *logjoint_ms = ctx->last_lj_ms;
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_device_alloc(vbmc_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return VBMC_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMalloc(dptr, bytes));
+  return VBMC_OK;
+}
+extern "C" vbmc_status vbmc_device_free(vbmc_ctx* ctx, void* dptr) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  HIP_TRY(ctx, hipFree(dptr));
+  return VBMC_OK;
+}
+extern "C" vbmc_status vbmc_memcpy_h2d(vbmc_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VBMC_OK;
+}
+extern "C" vbmc_status vbmc_memcpy_d2h(vbmc_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GP upload
+// ------------------------------------------------------------------------------------------
+extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Ncov, int Nnoise,
+                                      int meanfun, const double* X, const double* hyp, const double* alpha,
+                                      const double* L, const double* sW1, const uint8_t* Lchol,
+                                      vbmc_gp** out) {
+  if (!ctx || !out) return VBMC_ERR_INVALID;
+  *out = nullptr;
+  if (N <= 0 || D <= 0 || S <= 0 || !X || !hyp || !alpha || !sW1)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_upload: N, D, S must be positive and X/hyp/alpha/sW1 non-null");
+  if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_gp_upload: D = %d > 32 not accelerated", D);
+  if (!(meanfun == 0 || meanfun == 1 || meanfun == 4))
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "gplogjoint:UnsupportedMeanFun: meanfun %d not accelerated (0,1,4 are)", meanfun);
+  if (Ncov != D + 1) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "only the SE-ARD covariance (Ncov = D+1) is accelerated");
+  const int Nmean = meanfun == 0 ? 0 : (meanfun == 1 ? 1 : 2 * D + 1);
+  if (Nhyp < Ncov + Nnoise + Nmean)
+    return set_err(ctx, VBMC_ERR_INVALID, "gplite_post:dimmismatch: Nhyp = %d < Ncov+Nnoise+Nmean = %d", Nhyp, Ncov + Nnoise + Nmean);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  vbmc_gp* gp = new vbmc_gp();
+  gp->N = N; gp->D = D; gp->S = S; gp->Nhyp = Nhyp; gp->Ncov = Ncov; gp->Nnoise = Nnoise; gp->meanfun = meanfun;
+  gp->hyp_host.assign(hyp, hyp + (size_t)Nhyp * S);
+  gp->sn2_eff.resize(S);
+  gp->Lchol.resize(S);
+  for (int s = 0; s < S; ++s) {
+    gp->sn2_eff[s] = 1.0 / (sW1[s] * sW1[s]);  // gplogjoint.m:160
+    gp->Lchol[s] = Lchol ? Lchol[s] : 1;
+  }
+  // derived per-sample constants (gplogjoint.m:99-121)
+  std::vector<double> gpc((size_t)S * GPC_STRIDE(D));
+  for (int s = 0; s < S; ++s) {
+    const double* h = hyp + (size_t)s * Nhyp;
+    double* g = gpc.data() + (size_t)s * GPC_STRIDE(D);
+    double sum_lnell = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double ell = std::exp(h[d]);
+      g[d] = ell * ell;
+      sum_lnell += h[d];
+    }
+    const int mo = Ncov + Nnoise;
+    for (int d = 0; d < D; ++d) {
+      if (meanfun == 4) {
+        g[D + d] = h[mo + 1 + d];
+        double om = std::exp(h[mo + D + 1 + d]);
+        g[2 * D + d] = 1.0 / (om * om);
+      } else {
+        g[D + d] = 0.0;
+        g[2 * D + d] = 0.0;
+      }
+    }
+    g[3 * D] = 2.0 * h[D] + sum_lnell;
+    g[3 * D + 1] = meanfun > 0 ? h[mo] : 0.0;
+  }
+  auto up = [&](double** dst, const double* src, size_t n) -> hipError_t {
+    hipError_t e = hipMalloc((void**)dst, n * sizeof(double));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice);
+  };
+  hipError_t e = up(&gp->X, X, (size_t)N * D);
+  if (e == hipSuccess) e = up(&gp->alpha, alpha, (size_t)N * S);
+  if (e == hipSuccess) e = up(&gp->gpc, gpc.data(), gpc.size());
+  if (e == hipSuccess) e = up(&gp->hyp, hyp, (size_t)Nhyp * S);
+  if (e == hipSuccess && L) {
+    e = up(&gp->L, L, (size_t)N * N * S);
+    gp->hasL = true;
+  }
+  if (e != hipSuccess) {
+    vbmc_gp_free(ctx, gp);
+    return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_upload: %s", hipGetErrorString(e));
+  }
+  *out = gp;
+  return VBMC_OK;
+}
+
+extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
+  (void)ctx;
+  if (!gp) return;
+  if (gp->X) (void)hipFree(gp->X);
+  if (gp->alpha) (void)hipFree(gp->alpha);
+  if (gp->L) (void)hipFree(gp->L);
+  if (gp->gpc) (void)hipFree(gp->gpc);
+  if (gp->hyp) (void)hipFree(gp->hyp);
+  delete gp;
+}
+
+// ------------------------------------------------------------------------------------------
+// template dispatch on the padded dimension DT
+// ------------------------------------------------------------------------------------------
+static int pick_dt(int D) {
+  static const int dts[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 20, 24, 28, 32};
+  for (int t : dts)
+    if (t >= D) return t;
+  return -1;
+}
+
+#define DISPATCH_DT(DTV, ...)                                                                      \
+  switch (DTV) {                                                                                   \
+    case 1: { constexpr int DT = 1; __VA_ARGS__; } break;                                                 \
+    case 2: { constexpr int DT = 2; __VA_ARGS__; } break;                                                 \
+    case 3: { constexpr int DT = 3; __VA_ARGS__; } break;                                                 \
+    case 4: { constexpr int DT = 4; __VA_ARGS__; } break;                                                 \
+    case 5: { constexpr int DT = 5; __VA_ARGS__; } break;                                                 \
+    case 6: { constexpr int DT = 6; __VA_ARGS__; } break;                                                 \
+    case 7: { constexpr int DT = 7; __VA_ARGS__; } break;                                                 \
+    case 8: { constexpr int DT = 8; __VA_ARGS__; } break;                                                 \
+    case 9: { constexpr int DT = 9; __VA_ARGS__; } break;                                                 \
+    case 10: { constexpr int DT = 10; __VA_ARGS__; } break;                                               \
+    case 11: { constexpr int DT = 11; __VA_ARGS__; } break;                                               \
+    case 12: { constexpr int DT = 12; __VA_ARGS__; } break;                                               \
+    case 14: { constexpr int DT = 14; __VA_ARGS__; } break;                                               \
+    case 16: { constexpr int DT = 16; __VA_ARGS__; } break;                                               \
+    case 18: { constexpr int DT = 18; __VA_ARGS__; } break;                                               \
+    case 20: { constexpr int DT = 20; __VA_ARGS__; } break;                                               \
+    case 24: { constexpr int DT = 24; __VA_ARGS__; } break;                                               \
+    case 28: { constexpr int DT = 28; __VA_ARGS__; } break;                                               \
+    case 32: { constexpr int DT = 32; __VA_ARGS__; } break;                                               \
+    default: return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d not accelerated", dm.D);            \
+  }
+
+template <int DT>
+static void launch_entropy(bool grad, dim3 grid, size_t lds, hipStream_t st, const EntArgs& ea) {
+  if (grad) hipLaunchKernelGGL((k_entropy<DT, true>), grid, dim3(WAVE), lds, st, ea);
+  else hipLaunchKernelGGL((k_entropy<DT, false>), grid, dim3(WAVE), lds, st, ea);
+}
+
+template <int DT>
+static hipError_t set_entropy_lds(bool grad, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  if (grad) return hipFuncSetAttribute((const void*)k_entropy<DT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return hipFuncSetAttribute((const void*)k_entropy<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// vbmc_elbo_batch
+// ------------------------------------------------------------------------------------------
+extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
+  if (a->struct_size != sizeof(vbmc_elbo_args))
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(vbmc_elbo_args));
+  ElboDims dm{};
+  dm.D = a->D; dm.K = a->K; dm.R = a->R; dm.S = gp->S; dm.N = gp->N;
+  if (dm.D != gp->D) return set_err(ctx, VBMC_ERR_INVALID, "vp.D = %d but gp has D = %d", dm.D, gp->D);
+  if (dm.K <= 0 || dm.R <= 0) return set_err(ctx, VBMC_ERR_INVALID, "K and R must be positive");
+  if (dm.K > 256) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d > 256 not accelerated", dm.K);
+  const int D = dm.D, K = dm.K, R = dm.R, S = dm.S;
+  int T = 0;
+  for (int g = 0; g < 4; ++g) dm.opt[g] = a->optimize[g] ? 1 : 0;
+  dm.off_mu = dm.off_sigma = dm.off_lambda = dm.off_eta = -1;
+  if (dm.opt[0]) { dm.off_mu = T; T += D * K; }
+  if (dm.opt[1]) { dm.off_sigma = T; T += K; }
+  if (dm.opt[2]) { dm.off_lambda = T; T += D; }
+  if (dm.opt[3]) { dm.off_eta = T; T += K; }
+  dm.T = T;
+  if (T > 0 && !a->theta) return set_err(ctx, VBMC_ERR_INVALID, "theta is null");
+  if ((!dm.opt[0] && !a->vp_mu) || (!dm.opt[1] && !a->vp_sigma) || (!dm.opt[2] && !a->vp_lambda) || (!dm.opt[3] && !a->vp_w))
+    return set_err(ctx, VBMC_ERR_INVALID, "a vp field is required for every group that is not optimised");
+  const int compute_grad = a->compute_grad ? 1 : 0;
+  const int compute_var = a->compute_var;
+  if (compute_var < 0 || compute_var > 2) return set_err(ctx, VBMC_ERR_INVALID, "compute_var must be 0, 1 or 2");
+  // negelcbo_vbmc.m:21-24
+  if (compute_grad && a->beta != 0.0 && compute_var != 2)
+    return set_err(ctx, VBMC_ERR_INVALID, "negelcbo_vbmc:vargrad Computation of the gradient of ELBO with full variance not supported.");
+  // gplogjoint.m:29-32 (negelcbo requests dvarG whenever compute_var && compute_grad)
+  if (compute_grad && compute_var == 1)
+    return set_err(ctx, VBMC_ERR_INVALID, "gplogjoint:FullVarianceGradient gradient of the log joint variance needs compute_var == 2");
+  if (a->separate_K && compute_grad)  // negelcbo_vbmc.m:57-59
+    return set_err(ctx, VBMC_ERR_INVALID, "Computing the gradient of variational parameters and requesting per-component results at the same time.");
+  if (compute_var != 0)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "compute_var != 0 not yet on device");
+  if (a->beta != 0.0 && !std::isfinite(a->beta)) { /* negelcbo_vbmc.m:15: non-finite beta -> 0 */ }
+  const double beta = (std::isfinite(a->beta)) ? a->beta : 0.0;
+  // theta must be finite (device exp() clamps would swallow NaN)
+  for (size_t i = 0; i < (size_t)T * R; ++i)
+    if (!std::isfinite(a->theta[i])) return set_err(ctx, VBMC_ERR_INVALID, "theta contains a non-finite value at linear index %zu", i);
+
+  int M = a->Ns;
+  if (M < 0) return set_err(ctx, VBMC_ERR_INVALID, "Ns must be >= 0");
+  M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
+  const int Mh = M / 2;
+  const bool mc = M > 0;
+  if (!mc && K > 128) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "entlb with K > 128 not accelerated");
+  if (mc && a->eps_mode != 0 && !a->eps) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode %d needs eps", a->eps_mode);
+  const int dt = pick_dt(D);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  VpLayout VL{D, K};
+
+  // ---- uploads: theta, fixed vp, delta^2, bounds (one pinned staging buffer, one H2D)
+  const size_t n_theta = (size_t)T * R;
+  const size_t n_fix = (size_t)D * K + 2 * K + D;
+  const size_t n_delta = D;
+  const int next_mu = dm.opt[0] ? D * K : 0;
+  const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
+  const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
+  const bool has_bnd = a->bnd_lb != nullptr && a->bnd_ub != nullptr;
+  const size_t n_bnd = has_bnd ? 2 * (size_t)Text : 0;
+  const size_t n_up = n_theta + n_fix + n_delta + n_bnd;
+  { vbmc_status s_ = ensure_pin(ctx, (n_up + (size_t)R * (OUT_HDR + 3 * T) + (size_t)S * K * R) * sizeof(double)); if (s_) return s_; }
+  { vbmc_status s_ = ensure(ctx, ctx->theta, n_up * sizeof(double)); if (s_) return s_; }
+  double* hp = (double*)ctx->pin;
+  if (n_theta) memcpy(hp, a->theta, n_theta * sizeof(double));
+  double* hfix = hp + n_theta;
+  for (size_t i = 0; i < n_fix; ++i) hfix[i] = 1.0;
+  if (a->vp_mu) memcpy(hfix, a->vp_mu, (size_t)D * K * sizeof(double));
+  if (a->vp_sigma) memcpy(hfix + D * K, a->vp_sigma, K * sizeof(double));
+  if (a->vp_lambda) memcpy(hfix + D * K + K, a->vp_lambda, D * sizeof(double));
+  if (a->vp_w) memcpy(hfix + D * K + K + D, a->vp_w, K * sizeof(double));
+  double* hdel = hfix + n_fix;
+  for (int d = 0; d < D; ++d) hdel[d] = a->vp_delta ? a->vp_delta[d] * a->vp_delta[d] : 0.0;
+  if (has_bnd) {
+    memcpy(hdel + n_delta, a->bnd_lb, Text * sizeof(double));
+    memcpy(hdel + n_delta + Text, a->bnd_ub, Text * sizeof(double));
+  }
+  double* d_theta = (double*)ctx->theta.p;
+  double* d_fix = d_theta + n_theta;
+  double* d_delta2 = d_fix + n_fix;
+  double* d_bnd = d_delta2 + n_delta;
+  HIP_TRY(ctx, hipMemcpyAsync(d_theta, hp, n_up * sizeof(double), hipMemcpyHostToDevice, st));
+
+  // ---- scratch
+  { vbmc_status s_ = ensure(ctx, ctx->prep, (size_t)R * VL.stride() * sizeof(double)); if (s_) return s_; }
+  { vbmc_status s_ = ensure(ctx, ctx->entp, (size_t)R * K * (D + ENTP_EXTRA) * sizeof(double)); if (s_) return s_; }
+  const int LJS = 2 * D + 2;
+  { vbmc_status s_ = ensure(ctx, ctx->ljpart, (size_t)R * S * K * LJS * sizeof(double)); if (s_) return s_; }
+  const size_t out_n = (size_t)R * (OUT_HDR + 3 * T);
+  { vbmc_status s_ = ensure(ctx, ctx->out, out_n * sizeof(double)); if (s_) return s_; }
+  double* d_vpd = (double*)ctx->prep.p;
+  double* d_entp = (double*)ctx->entp.p;
+  double* d_lj = (double*)ctx->ljpart.p;
+  double* d_out = (double*)ctx->out.p;
+
+  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, d_theta, d_fix, d_vpd, d_entp);
+
+  // ---- expected log joint
+  if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+  DISPATCH_DT(dt, {
+    hipLaunchKernelGGL((k_logjoint<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, d_vpd, gp->X, gp->alpha, gp->gpc,
+                       d_delta2, d_lj, compute_grad);
+  });
+  if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+
+  // ---- entropy
+  FinArgs fa{};
+  fa.dm = dm;
+  if (mc) {
+    const int ntile = (Mh + 31) / 32;
+    // enough waves to fill the chip several times over, but >= 2 tiles per wave when possible
+    long long target = (long long)ctx->num_cu * 5 * 4;
+    int C = (int)((target + (long long)K * R - 1) / ((long long)K * R));
+    if (C < 1) C = 1;
+    if (C > ntile) C = ntile;
+    int tpc = (ntile + C - 1) / C;
+    C = (ntile + tpc - 1) / tpc;
+    const int ncol = compute_grad ? (2 + 2 * D + K) : 1;
+    { vbmc_status s_ = ensure(ctx, ctx->entpart, (size_t)R * K * C * ncol * sizeof(double)); if (s_) return s_; }
+    EntArgs ea{};
+    ea.entp = d_entp; ea.vpd = d_vpd; ea.part = (double*)ctx->entpart.p;
+    ea.D = D; ea.K = K; ea.Mh = Mh; ea.C = C; ea.tiles_per_chunk = tpc; ea.ncol = ncol; ea.seed = a->seed;
+    const size_t eps_block = (size_t)D * Mh * K;
+    if (a->eps_mode == 0) {
+      ea.eps = nullptr; ea.eps_stride_r = 0;
+    } else if (a->eps_mode == 1) {
+      const size_t n_eps = eps_block * (a->eps_shared ? 1 : (size_t)R);
+      { vbmc_status s_ = ensure(ctx, ctx->eps, n_eps * sizeof(double)); if (s_) return s_; }
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->eps.p, a->eps, n_eps * sizeof(double), hipMemcpyHostToDevice, st));
+      ea.eps = (const double*)ctx->eps.p; ea.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
+    } else if (a->eps_mode == 2) {
+      ea.eps = a->eps; ea.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
+    } else {
+      return set_err(ctx, VBMC_ERR_INVALID, "eps_mode must be 0, 1 or 2");
+    }
+    size_t lds = ((size_t)K * (dt + ENTP_EXTRA) + WAVE + (compute_grad ? (size_t)K * 65 : 0)) * sizeof(double);
+    if (lds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d needs %zu B of LDS (> 160 KiB)", K, D, lds);
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    DISPATCH_DT(dt, {
+      HIP_TRY(ctx, set_entropy_lds<DT>(compute_grad != 0, lds));
+      launch_entropy<DT>(compute_grad != 0, dim3(C, K, R), lds, st, ea);
+    });
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+    fa.entpart = ea.part; fa.entlb = nullptr; fa.M = Mh; fa.C = C; fa.ncol = ncol;
+  } else {
+    const size_t ebs = 1 + (size_t)D * K + 2 * K + D;
+    { vbmc_status s_ = ensure(ctx, ctx->entpart, (size_t)R * ebs * sizeof(double)); if (s_) return s_; }
+    size_t lds = ((size_t)K * K + K + 256) * sizeof(double);
+    if (lds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_entlb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, d_vpd, (double*)ctx->entpart.p, compute_grad);
+    fa.entpart = nullptr; fa.entlb = (const double*)ctx->entpart.p;
+  }
+
+  // ---- finalize
+  fa.vpd = d_vpd; fa.theta = d_theta; fa.lj = d_lj; fa.var = nullptr; fa.var_stride = 0;
+  fa.bnd = has_bnd ? d_bnd : nullptr; fa.has_bnd = has_bnd ? 1 : 0;
+  fa.TolCon = a->TolCon; fa.WeightThreshold = a->WeightThreshold; fa.WeightPenalty = a->WeightPenalty;
+  fa.beta = beta; fa.want_grad = compute_grad; fa.out = d_out;
+  {
+    size_t lds = (256 + 3 * (size_t)K + 3 * (size_t)T + 8) * sizeof(double);
+    if (lds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_finalize, dim3(R), dim3(256), lds, st, fa);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+
+  // ---- results: one packed D2H (+ I_sk when requested)
+  double* hout = hp + n_up;
+  HIP_TRY(ctx, hipMemcpyAsync(hout, d_out, out_n * sizeof(double), hipMemcpyDeviceToHost, st));
+  double* hisk = hout + out_n;
+  std::vector<double> ljh;
+  if (a->separate_K && a->I_sk) {
+    ljh.resize((size_t)R * S * K * LJS);
+    HIP_TRY(ctx, hipMemcpyAsync(ljh.data(), d_lj, ljh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  (void)hisk;
+  if (ctx->profiling) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_lj_ms = ms;
+    if (mc && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ent_ms = ms;
+  }
+  const size_t OS = OUT_HDR + 3 * (size_t)T;
+  for (int r = 0; r < R; ++r) {
+    const double* o = hout + (size_t)r * OS;
+    if (a->F) a->F[r] = o[0];
+    if (a->G) a->G[r] = o[1];
+    if (a->H) a->H[r] = o[2];
+    if (a->varG) a->varG[r] = o[3];
+    if (a->varGss) a->varGss[r] = o[4];
+    if (compute_grad) {
+      if (a->dF) memcpy(a->dF + (size_t)r * T, o + OUT_HDR, T * sizeof(double));
+      if (a->dG) memcpy(a->dG + (size_t)r * T, o + OUT_HDR + T, T * sizeof(double));
+      if (a->dH) memcpy(a->dH + (size_t)r * T, o + OUT_HDR + 2 * T, T * sizeof(double));
+    }
+  }
+  if (a->separate_K && a->I_sk) {
+    for (int r = 0; r < R; ++r)
+      for (int k = 0; k < K; ++k)
+        for (int s = 0; s < S; ++s) a->I_sk[s + (size_t)S * (k + (size_t)K * r)] = ljh[(((size_t)r * S + s) * K + k) * LJS];
+  }
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t seed, double* eps_host) {
+  if (!ctx || !eps_host || D <= 0 || K <= 0 || R <= 0 || Ns <= 0) return VBMC_ERR_INVALID;
+  const int Mh = (Ns + 1) / 2;
+  const size_t n = (size_t)D * Mh * K * R;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { vbmc_status s_ = ensure(ctx, ctx->eps, n * sizeof(double)); if (s_) return s_; }
+  const long long total = (long long)R * K * Mh;
+  hipLaunchKernelGGL(k_rng_dump, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, D, K, R, Mh,
+                     (unsigned long long)seed, (double*)ctx->eps.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(eps_host, ctx->eps.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VBMC_OK;
+}

@@ -1,0 +1,88 @@
+// Shared host-side plumbing for libvbmc_hip.so (context, device buffers, error reporting).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vbmc_hip.h"
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct vbmc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int num_cu = 256;
+  // grow-only scratch
+  DevBuf theta, prep, entp, ljpart, entpart, out, eps, bnd, vpfix, misc, varbuf, zbuf;
+  // pinned staging for small D2H/H2D
+  void* pin = nullptr;
+  size_t pin_cap = 0;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double last_ent_ms = 0.0, last_lj_ms = 0.0;
+};
+
+struct vbmc_gp {
+  int N = 0, D = 0, S = 0, Nhyp = 0, Ncov = 0, Nnoise = 0, meanfun = 0;
+  bool hasL = false;
+  double* X = nullptr;      // N x D col-major
+  double* alpha = nullptr;  // N x S
+  double* L = nullptr;      // N x N x S
+  double* gpc = nullptr;    // S x GPC_STRIDE derived per-sample constants (see elbo.hip)
+  double* hyp = nullptr;    // Nhyp x S
+  std::vector<double> sn2_eff;
+  std::vector<uint8_t> Lchol;
+  std::vector<double> hyp_host;
+};
+
+static inline vbmc_status set_err(vbmc_ctx* ctx, vbmc_status st, const char* fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return st;
+}
+
+#define HIP_TRY(ctx, call)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return set_err(ctx, VBMC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                    \
+  } while (0)
+
+static inline vbmc_status ensure(vbmc_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return VBMC_OK;
+  if (b.p) HIP_TRY(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  HIP_TRY(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return VBMC_OK;
+}
+
+static inline vbmc_status ensure_pin(vbmc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->pin_cap) return VBMC_OK;
+  if (ctx->pin) HIP_TRY(ctx, hipHostFree(ctx->pin));
+  ctx->pin = nullptr;
+  ctx->pin_cap = 0;
+  size_t want = bytes * 2 + 4096;
+  HIP_TRY(ctx, hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
+  ctx->pin_cap = want;
+  return VBMC_OK;
+}

@@ -1,0 +1,778 @@
+// ELBO inner loop on gfx950: negelcbo_vbmc -> gplogjoint + entmc_vbmc / entlb_vbmc.
+//
+// Reference (acerbilab/vbmc v1.0.12, MATLAB): misc/negelcbo_vbmc.m:1-165,
+// misc/gplogjoint.m:1-415, ent/entmc_vbmc.m:1-128, ent/entlb_vbmc.m:1-148,
+// misc/vpbndloss.m:1-73, utils/softbndloss.m:1-30.  Nothing here is translated from the
+// reference's vectorised bsxfun code: the kernels are organised around wave64 lanes that own
+// Monte-Carlo samples (entropy) or GP training points (log-joint), LDS-staged mixture
+// parameters, and fixed-order two-level reductions so that results are run-to-run identical.
+//
+// Kernel inventory (DESIGN.md has the data layout and rooflines):
+//   k_prep       theta -> vp fields + packed per-component parameters        (1 WG / restart)
+//   k_logjoint   closed-form BQ expected log joint + gradient partials       (1 wave / (k,s,r))
+//   k_entropy    antithetic MC entropy + reparameterisation-gradient partials (1 wave / chunk)
+//   k_entlb      Gershman lower bound on the entropy + gradient               (1 WG / restart)
+//   k_finalize   fixed-order reduction of the partials, Jacobians, penalties  (1 WG / restart)
+#include "common.h"
+#include "device_math.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------
+// vpd block per restart (doubles): mu[D*K] sigma[K] lambda[D] w[K] eta[K] lognf lnsigma[K] lnlambda[D]
+struct VpLayout {
+  int D, K;
+  __host__ __device__ int mu() const { return 0; }
+  __host__ __device__ int sigma() const { return D * K; }
+  __host__ __device__ int lambda() const { return D * K + K; }
+  __host__ __device__ int w() const { return D * K + K + D; }
+  __host__ __device__ int eta() const { return D * K + 2 * K + D; }
+  __host__ __device__ int lognf() const { return D * K + 3 * K + D; }
+  __host__ __device__ int lnsigma() const { return D * K + 3 * K + D + 1; }
+  __host__ __device__ int lnlambda() const { return D * K + 4 * K + D + 1; }
+  __host__ __device__ int stride() const { return D * K + 4 * K + 2 * D + 2; }
+};
+// packed per-component entropy parameters: [m_dk = mu_dk/lambda_d (D), h_k = -1/(2 sigma_k^2),
+// cK_k = -D log sigma_k, w_k, wi_k = w_k / sigma_k^2]
+#define ENTP_EXTRA 4
+// per-hyper-sample GP constants: ell2[D] xm[D] iom2[D] lnsf2_plus_sumlnell m0
+#define GPC_STRIDE(D) (3 * (D) + 2)
+// output block per restart: F G H varG varGss | dF[T] dG[T] dH[T]
+#define OUT_HDR 5
+
+struct ElboDims {
+  int D, K, R, S, N, T;
+  int opt[4];
+  int off_mu, off_sigma, off_lambda, off_eta;  // offsets into theta (or -1)
+};
+
+// ------------------------------------------------------------------------------------------
+// k_prep: unpack theta exactly as misc/negelcbo_vbmc.m:33-48 does
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_prep(ElboDims dm, const double* __restrict__ theta,
+                                              const double* __restrict__ vpfix,  // mu sigma lambda w (fixed vp) packed
+                                              double* __restrict__ vpd, double* __restrict__ entp) {
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int D = dm.D, K = dm.K;
+  VpLayout L{D, K};
+  const double* th = theta + (size_t)r * dm.T;
+  double* v = vpd + (size_t)r * L.stride();
+  const double* fmu = vpfix;
+  const double* fsig = vpfix + D * K;
+  const double* flam = fsig + K;
+  const double* fw = flam + D;
+  __shared__ double s_sum;
+  for (int i = tid; i < D * K; i += nt) v[L.mu() + i] = dm.opt[0] ? th[dm.off_mu + i] : fmu[i];
+  for (int k = tid; k < K; k += nt) {
+    double ls = dm.opt[1] ? th[dm.off_sigma + k] : log(fsig[k]);
+    v[L.lnsigma() + k] = ls;
+    v[L.sigma() + k] = dm.opt[1] ? exp(ls) : fsig[k];  // vp.sigma = exp(theta) (:40)
+  }
+  for (int d = tid; d < D; d += nt) {
+    double ll = dm.opt[2] ? th[dm.off_lambda + d] : log(flam[d]);
+    v[L.lnlambda() + d] = ll;
+    v[L.lambda() + d] = dm.opt[2] ? exp(ll) : flam[d];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // vp.w = exp(eta)/sum(exp(eta)), no max-shift (:45-47); serial sum = MATLAB's sum order
+    double ssum = 0.0;
+    if (dm.opt[3]) {
+      for (int k = 0; k < K; ++k) ssum += exp(th[dm.off_eta + k]);
+    }
+    s_sum = ssum;
+    double slog = 0.0;
+    for (int d = 0; d < D; ++d) slog += log(v[L.lambda() + d]);
+    v[L.lognf()] = -0.5 * D * 1.8378770664093454835606594728112 - slog;  // log((2pi)^(-D/2)/prod(lambda))
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += nt) {
+    double eta = dm.opt[3] ? th[dm.off_eta + k] : log(fw[k]);
+    v[L.eta() + k] = eta;
+    v[L.w() + k] = dm.opt[3] ? exp(eta) / s_sum : fw[k];
+  }
+  __syncthreads();
+  // packed entropy parameters
+  double* ep = entp + (size_t)r * K * (D + ENTP_EXTRA);
+  for (int i = tid; i < K * (D + ENTP_EXTRA); i += nt) {
+    int k = i / (D + ENTP_EXTRA), c = i % (D + ENTP_EXTRA);
+    double sg = v[L.sigma() + k];
+    double val;
+    if (c < D) val = v[L.mu() + c + D * k] / v[L.lambda() + c];
+    else if (c == D) val = -0.5 / (sg * sg);
+    else if (c == D + 1) val = -(double)D * v[L.lnsigma() + k];
+    else if (c == D + 2) val = v[L.w() + k];
+    else val = v[L.w() + k] / (sg * sg);
+    ep[i] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_logjoint: misc/gplogjoint.m:162-271 for one (k, s, r); lanes stride over training points
+// partial layout LJ[r][s][k][2D+2] = I_k, w_k*dmu[D], w_k*dsigma (no Jacobian), w_k*dlambda[D]
+// ------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __restrict__ vpd,
+                                                   const double* __restrict__ X,      // N x D col-major
+                                                   const double* __restrict__ alpha,  // N x S
+                                                   const double* __restrict__ gpc,    // S x GPC_STRIDE
+                                                   const double* __restrict__ delta2,  // D (delta.^2)
+                                                   double* __restrict__ lj, int want_grad) {
+  const int k = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
+  const double sig = v[L.sigma() + k];
+  const double wk = v[L.w() + k];
+  double mu[DT], itau[DT], lam[DT];
+  double sumlogtau = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    if (d < D) {
+      lam[d] = v[L.lambda() + d];
+      mu[d] = v[L.mu() + d + D * k];
+      double tau = sqrt(sig * sig * lam[d] * lam[d] + g[d] + delta2[d]);  // :164
+      sumlogtau += log(tau);
+      itau[d] = 1.0 / tau;
+    } else {
+      lam[d] = 0.0; mu[d] = 0.0; itau[d] = 0.0;
+    }
+  }
+  const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
+  double accI = 0.0, accS = 0.0;
+  double accM[DT], accL[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { accM[d] = 0.0; accL[d] = 0.0; }
+  const double* al = alpha + (size_t)s * N;
+  for (int n = lane; n < N; n += WAVE) {
+    double dl[DT];
+    double a2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      double x = (d < D) ? X[n + (size_t)N * d] : 0.0;
+      dl[d] = (mu[d] - x) * itau[d];  // delta_k :167
+      a2 = fma(dl[d], dl[d], a2);
+    }
+    double z = vb_exp(lnnf - 0.5 * a2);  // z_k :168
+    double za = z * al[n];
+    accI += za;
+    if (want_grad) {
+      double ssum = 0.0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        double li = lam[d] * itau[d];
+        double si = sig * itau[d];
+        double q = fma(dl[d], dl[d], -1.0);
+        accM[d] = fma(-dl[d] * itau[d], za, accM[d]);  // dz_dmu*alpha :207-208
+        ssum = fma(li * li, q, ssum);                   // :228
+        accL[d] = fma(si * si * q * lam[d], za, accL[d]);  // :249-250
+      }
+      accS = fma(ssum * sig, za, accS);
+    }
+  }
+  accI = wave_sum(accI);
+  if (want_grad) {
+    accS = wave_sum(accS);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { accM[d] = wave_sum(accM[d]); accL[d] = wave_sum(accL[d]); }
+  }
+  if (lane == 0) {
+    double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
+    // mean-function terms; iom2 = 0 and xm = 0 for meanfun 0/1 so they vanish  :169-174
+    double nu = 0.0, sl2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      if (d < D) {
+        double xm = g[D + d], iom2 = g[2 * D + d];
+        nu += iom2 * (mu[d] * mu[d] + sig * sig * lam[d] * lam[d] - 2.0 * mu[d] * xm + xm * xm + delta2[d]);
+        sl2 += iom2 * lam[d] * lam[d];
+      }
+    }
+    o[0] = accI + g[3 * D + 1] + (-0.5 * nu);
+    if (want_grad) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        if (d < D) {
+          double xm = g[D + d], iom2 = g[2 * D + d];
+          o[1 + d] = wk * accM[d] - wk * iom2 * (mu[d] - xm);                    // :208-210
+          o[2 + D + d] = wk * accL[d] - wk * sig * sig * iom2 * lam[d];          // :250-252
+        }
+      }
+      o[1 + D] = wk * accS - wk * sig * sl2;                                     // :229-231
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_entropy: ent/entmc_vbmc.m:49-104.  One wave per (chunk of samples, component j, restart r).
+// Lanes 0-31 own base samples with +eps, lanes 32-63 the antithetic -eps (:53-54).
+// partial layout PE[r][j][c][NCOL]: sum log q | G[D] | SG | LG[D] | W[K]   (NCOL = 1 if !GRAD)
+// ------------------------------------------------------------------------------------------
+struct EntArgs {
+  const double* entp;    // R x K x (D+4)
+  const double* vpd;     // R x VpLayout
+  const double* eps;     // D x Mh x K (x R) or null -> Philox
+  long long eps_stride_r;
+  double* part;
+  int D, K, Mh, C, tiles_per_chunk, ncol;
+  unsigned long long seed;
+};
+
+template <int DT, bool GRAD>
+__global__ void __launch_bounds__(WAVE) k_entropy(EntArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
+  const int D = a.D, K = a.K;
+  constexpr int PS = DT + ENTP_EXTRA;
+  double* P = lds;                 // K * PS  packed params, d padded to DT with zeros
+  double* rqb = P + K * PS;        // 64
+  double* Tn = rqb + WAVE;         // K * 65 (GRAD)
+  {
+    const double* gp = a.entp + (size_t)r * K * (D + ENTP_EXTRA);
+    for (int idx = lane; idx < K * PS; idx += WAVE) {
+      int k = idx / PS, cc = idx - k * PS;
+      double val;
+      if (cc < DT) val = (cc < D) ? gp[k * (D + ENTP_EXTRA) + cc] : 0.0;
+      else val = gp[k * (D + ENTP_EXTRA) + D + (cc - DT)];
+      P[idx] = val;
+    }
+  }
+  __syncthreads();
+  VpLayout L{D, K};
+  const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
+  double mj[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) mj[d] = P[j * PS + d];
+  const double cKj = P[j * PS + DT + 1];
+
+  double accH = 0.0, accSG = 0.0;
+  double accG[DT], accLG[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { accG[d] = 0.0; accLG[d] = 0.0; }
+  constexpr int KW = 4;  // K <= 256
+  double accW[KW] = {0.0, 0.0, 0.0, 0.0};
+
+  const int nt = (a.Mh + 31) / 32;
+  const int t0 = c * a.tiles_per_chunk;
+  const int t1 = min(t0 + a.tiles_per_chunk, nt);
+  const double sgn = (lane < 32) ? 1.0 : -1.0;
+  const double* epsr = a.eps ? a.eps + (size_t)r * a.eps_stride_r + (size_t)j * a.Mh * D : nullptr;
+
+  for (int tile = t0; tile < t1; ++tile) {
+    const int b = tile * 32 + (lane & 31);
+    const bool valid = b < a.Mh;
+    double e[DT], u[DT];
+    if (epsr) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) e[d] = (valid && d < D) ? sgn * epsr[(size_t)b * D + d] : 0.0;
+    } else {
+#pragma unroll
+      for (int q4 = 0; q4 < (DT + 3) / 4; ++q4) {
+        double z4[4];
+        vb_normal4(a.seed, (unsigned)b, (unsigned)j, (unsigned)r, (unsigned)q4, z4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          int d = q4 * 4 + t;
+          if (d < DT) e[d] = (valid && d < D) ? sgn * z4[t] : 0.0;
+        }
+      }
+    }
+    double e2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      u[d] = fma(e[d], sigj, mj[d]);  // x/lambda = eps*sigma_j + mu_j/lambda   (:55)
+      e2 = fma(e[d], e[d], e2);
+    }
+    const double shift = cKj - 0.5 * e2;  // exponent of the sample's own component
+    double qp = 0.0, Ap = 0.0;
+    double Bp[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) Bp[d] = 0.0;
+
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+      const double* Pk = P + k * PS;
+      double acc = 0.0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        double df = u[d] - Pk[d];
+        acc = fma(df, df, acc);
+      }
+      double ex = fma(acc, Pk[DT], Pk[DT + 1] - shift);  // -d2/2 - D log sigma_k - shift  (:61-63)
+      double n = vb_exp(ex);
+      qp = fma(Pk[DT + 2], n, qp);                       // q' += w_k n_k   (:64)
+      if (GRAD) {
+        double ta = n * Pk[DT + 3];                      // w_k n_k / sigma_k^2
+        Ap += ta;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) Bp[d] = fma(ta, Pk[d], Bp[d]);
+        Tn[k * 65 + lane] = n;
+      }
+    }
+    // log q = log nf + shift + log q'  (log nf added in k_finalize)
+    const double lq = valid ? (shift + log(qp)) : 0.0;
+    accH += lq;
+    if (GRAD) {
+      const double rq = valid ? 1.0 / qp : 0.0;
+      double sg = 0.0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        // lambda_d * lsum_d / q = u_d * A - B_d   (:77-79)
+        double gd = (u[d] * Ap - Bp[d]) * rq;
+        accG[d] += gd;                         // -> mu_grad (:82)
+        double eg = e[d] * gd;
+        sg += eg;                              // -> sigma_grad (:87-88)
+        accLG[d] += eg;                        // -> lambda_grad (:93)
+      }
+      accSG += sg;
+      rqb[lane] = rq;
+      __syncthreads();
+      // w_grad(l) -= w_j * sum_i N_l(x_i)/q(x_i)  (:100): lane l sweeps the 64 samples of the tile
+#pragma unroll
+      for (int kk = 0; kk < KW; ++kk) {
+        int l = lane + kk * WAVE;
+        if (l < K) {
+          double ws = 0.0;
+          const double* Tl = Tn + l * 65;
+#pragma unroll 8
+          for (int i = 0; i < WAVE; ++i) ws = fma(Tl[i], rqb[i], ws);
+          accW[kk] += ws;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // wave reduction, fixed order
+  double* o = a.part + (((size_t)r * K + j) * a.C + c) * a.ncol;
+  accH = wave_sum(accH);
+  if (GRAD) {
+    accSG = wave_sum(accSG);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { accG[d] = wave_sum(accG[d]); accLG[d] = wave_sum(accLG[d]); }
+  }
+  if (lane == 0) {
+    o[0] = accH;
+    if (GRAD) {
+      o[1 + D] = accSG;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        if (d < D) { o[1 + d] = accG[d]; o[2 + D + d] = accLG[d]; }
+    }
+  }
+  if (GRAD) {
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      int l = lane + kk * WAVE;
+      if (l < K) o[2 + 2 * D + l] = accW[kk];
+    }
+  }
+}
+
+// eps dump for the test hook (same generator, same counters as k_entropy)
+__global__ void k_rng_dump(int D, int K, int R, int Mh, unsigned long long seed, double* __restrict__ out) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)R * K * Mh;
+  if (idx >= total) return;
+  int b = (int)(idx % Mh);
+  int j = (int)((idx / Mh) % K);
+  int r = (int)(idx / ((long long)Mh * K));
+  double* o = out + idx * D;
+  for (int q4 = 0; q4 < (D + 3) / 4; ++q4) {
+    double z4[4];
+    vb_normal4(seed, (unsigned)b, (unsigned)j, (unsigned)r, (unsigned)q4, z4);
+    for (int t = 0; t < 4; ++t)
+      if (q4 * 4 + t < D) o[q4 * 4 + t] = z4[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_entlb: ent/entlb_vbmc.m:1-148 -- deterministic lower bound, O(K^2 D); one WG per restart.
+// Writes H and the *untransformed-to-theta-order* gradient pieces straight into the same
+// "entropy result" slots k_finalize reads: EB[r] = H | mu_grad[D*K] | sigma_grad[K] (Jacobian
+// applied) | lambda_grad[D] | w_grad_raw[K] (softmax Jacobian applied in k_finalize).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __restrict__ vpd,
+                                               double* __restrict__ eb, int want_grad) {
+  extern __shared__ double lds[];
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int D = dm.D, K = dm.K;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* mu = v + L.mu();
+  const double* sigma = v + L.sigma();
+  const double* lam = v + L.lambda();
+  const double* w = v + L.w();
+  double* o = eb + (size_t)r * (1 + D * K + 2 * K + D);
+  double* gamma = lds;              // K*K  gamma[j + K*k]
+  double* gammasum = gamma + K * K; // K
+  double* red = gammasum + K;       // nt
+  if (K == 1) {  // :32-47 exact entropy
+    if (tid == 0) {
+      double sl = 0.0;
+      for (int d = 0; d < D; ++d) sl += log(lam[d]);
+      o[0] = 0.5 * D * (1.0 + 1.8378770664093454835606594728112) + D * log(sigma[0]) + sl;
+      if (want_grad) {
+        for (int d = 0; d < D; ++d) o[1 + d] = 0.0;
+        o[1 + D] = D / sigma[0] * sigma[0];   // sigma_grad = D./sigma, then Jacobian *sigma (:36,131)
+        for (int d = 0; d < D; ++d) o[1 + D + 1 + d] = 1.0;  // :41
+        o[1 + D + 1 + D] = 0.0;
+      }
+    }
+    return;
+  }
+  const double lognf = v[L.lognf()];
+  for (int p = tid; p < K * K; p += nt) {
+    int j = p % K, k = p / K;
+    double ss2 = sigma[j] * sigma[j] + sigma[k] * sigma[k];
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double t = (mu[d + D * j] - mu[d + D * k]) / lam[d];
+      d2 = fma(t, t, d2);
+    }
+    d2 /= ss2;
+    gamma[p] = exp(lognf - 0.5 * D * log(ss2) - 0.5 * d2);  // :75
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += nt) {
+    double gs = 0.0;
+    for (int j = 0; j < K; ++j) gs += w[j] * gamma[j + K * k];  // :76
+    gammasum[k] = gs;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double H = 0.0;
+    for (int k = 0; k < K; ++k) H -= w[k] * log(gammasum[k]);  // :78
+    o[0] = H;
+  }
+  if (!want_grad) return;
+  // mu_grad(:,j) = -w_j * sum_k dmu_jk * (w_k gamma_jk/gammasum_k + gamma_jk w_k / gammasum_j)  (:96-98)
+  for (int p = tid; p < D * K; p += nt) {
+    int d = p % D, j = p / D;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double ss2 = sigma[j] * sigma[j] + sigma[k] * sigma[k];
+      double dmu = (mu[d + D * k] - mu[d + D * j]) / (ss2 * lam[d] * lam[d]);  // :87
+      double gj = gamma[j + K * k] * w[k];
+      acc += dmu * (gj / gammasum[k] + gj / gammasum[j]);
+    }
+    o[1 + p] = -w[j] * acc;
+  }
+  for (int j = tid; j < K; j += nt) {  // :103-105, Jacobian :131
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double ss2 = sigma[j] * sigma[j] + sigma[k] * sigma[k];
+      double m2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        double t = (mu[d + D * j] - mu[d + D * k]) / lam[d];
+        m2 = fma(t, t, m2);
+      }
+      double ds = -D / ss2 + m2 / (ss2 * ss2);  // :90
+      double gj = gamma[j + K * k] * w[k];
+      acc += ds * (gj / gammasum[k] + gj / gammasum[j]);
+    }
+    o[1 + D * K + j] = -w[j] * sigma[j] * acc * sigma[j];
+    // w_grad = -log(gammasum) - sum_k w_k gamma_jk / gammasum_k  (:118)
+    double ws = 0.0;
+    for (int k = 0; k < K; ++k) ws += w[k] * gamma[j + K * k] / gammasum[k];
+    o[1 + D * K + K + D + j] = -log(gammasum[j]) - ws;
+  }
+  for (int d = tid; d < D; d += nt) {  // :110-113
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double inner = 0.0;
+      for (int j = 0; j < K; ++j) {
+        double ss2 = sigma[j] * sigma[j] + sigma[k] * sigma[k];
+        double t = mu[d + D * k] - mu[d + D * j];
+        double dmu2 = t * t / (ss2 * lam[d] * lam[d]);
+        inner += (dmu2 - 1.0) * gamma[j + K * k] * w[j];
+      }
+      acc += w[k] * inner / gammasum[k];
+    }
+    o[1 + D * K + K + d] = -acc;
+  }
+  (void)red;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: reduce partials in a fixed order, apply Jacobians (gplogjoint.m:352-373,
+// entmc_vbmc.m:106-125), average over hyper-samples (gplogjoint.m:399-413), add the soft-bound
+// and weight penalties (negelcbo_vbmc.m:116-164), pack to theta order.
+// ------------------------------------------------------------------------------------------
+struct FinArgs {
+  ElboDims dm;
+  const double* vpd;
+  const double* theta;
+  const double* lj;       // R x S x K x (2D+2)
+  const double* entpart;  // MC partials or null
+  const double* entlb;    // entlb block or null
+  const double* var;      // R x 2 (varG, varGss) + optional dvarG[T] per restart, or null
+  const double* bnd;      // lb[Text] ub[Text] or null
+  double TolCon, WeightThreshold, WeightPenalty, beta;
+  int M, C, ncol, want_grad, has_bnd, var_stride;
+  double* out;            // R x (OUT_HDR + 3T)
+};
+
+__device__ inline double block_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
+  extern __shared__ double lds[];
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const ElboDims& dm = a.dm;
+  const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
+  VpLayout L{D, K};
+  const double* v = a.vpd + (size_t)r * L.stride();
+  const double* w = v + L.w();
+  const double* sigma = v + L.sigma();
+  const double* lam = v + L.lambda();
+  double* red = lds;           // nt
+  double* Ibar = red + nt;     // K   mean_s I_sk
+  double* Hj = Ibar + K;       // K   (1/M) sum_i log q' for component j
+  double* wraw = Hj + K;       // K   raw w-gradient of H
+  double* dG = wraw + K;       // T (packed)
+  double* dH = dG + T;         // T
+  double* dP = dH + T;         // T   penalty gradient
+  double* scal = dP + T;       // 8 scalars
+  double* o = a.out + (size_t)r * (OUT_HDR + 3 * T);
+  const int LJS = 2 * D + 2;
+  const double* lj = a.lj + (size_t)r * S * K * LJS;
+  const double invS = 1.0 / S;
+
+  for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
+  // ---- expected log joint: F(s) = sum_k w_k I_k ; G = sum_s F(s)/S
+  for (int k = tid; k < K; k += nt) {
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS];
+    Ibar[k] = acc * invS;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double G = 0.0;
+    for (int s = 0; s < S; ++s) {
+      double Fs = 0.0;
+      for (int k = 0; k < K; ++k) Fs += w[k] * lj[((size_t)s * K + k) * LJS];  // :203
+      G += Fs;
+    }
+    scal[0] = G * invS;  // Fbar (:400); equals F when S == 1
+  }
+  if (a.want_grad) {
+    if (dm.opt[0])
+      for (int p = tid; p < D * K; p += nt) {
+        int d = p % D, k = p / D;
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS + 1 + d];
+        dG[dm.off_mu + p] = acc * invS;
+      }
+    if (dm.opt[1])
+      for (int k = tid; k < K; k += nt) {
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS + 1 + D] * sigma[k];  // Jacobian :356
+        dG[dm.off_sigma + k] = acc * invS;
+      }
+    if (dm.opt[2])
+      for (int d = tid; d < D; d += nt) {
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) {
+          double ls = 0.0;
+          for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];  // :250
+          acc += ls * lam[d];                                                          // :362
+        }
+        dG[dm.off_lambda + d] = acc * invS;
+      }
+  }
+  __syncthreads();
+  if (a.want_grad && dm.opt[3]) {
+    // softmax Jacobian J_w = diag(w) - w w' (gplogjoint.m:366-368) applied to w_grad = I_k
+    double part = 0.0;
+    for (int k = tid; k < K; k += nt) part += w[k] * Ibar[k];
+    double dot = block_sum(part, red);
+    for (int k = tid; k < K; k += nt) dG[dm.off_eta + k] = w[k] * Ibar[k] - w[k] * dot;
+  }
+  __syncthreads();
+
+  // ---- entropy
+  const double lognf = v[L.lognf()];
+  if (a.entpart) {
+    const double invM = 1.0 / (2.0 * a.M);  // Ns = 2*Mh samples per component
+    const double* pe = a.entpart + (size_t)r * K * a.C * a.ncol;
+    for (int j = tid; j < K; j += nt) {
+      double acc = 0.0;
+      for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol];
+      Hj[j] = lognf + acc * invM;  // mean_i log q(x_i), x_i ~ component j
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double H = 0.0;
+      for (int j = 0; j < K; ++j) H -= w[j] * Hj[j];  // :67
+      scal[1] = H;
+    }
+    if (a.want_grad) {
+      if (dm.opt[0])
+        for (int p = tid; p < D * K; p += nt) {
+          int d = p % D, j = p / D;
+          double acc = 0.0;
+          for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol + 1 + d];
+          dH[dm.off_mu + p] = w[j] * acc * invM / lam[d];  // :82
+        }
+      if (dm.opt[1])
+        for (int j = tid; j < K; j += nt) {
+          double acc = 0.0;
+          for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol + 1 + D];
+          dH[dm.off_sigma + j] = w[j] * acc * invM * sigma[j];  // :88 and Jacobian :113
+        }
+      if (dm.opt[2])
+        for (int d = tid; d < D; d += nt) {
+          double acc = 0.0;
+          for (int j = 0; j < K; ++j) {
+            double aj = 0.0;
+            for (int c = 0; c < a.C; ++c) aj += pe[((size_t)j * a.C + c) * a.ncol + 2 + D + d];
+            acc += w[j] * sigma[j] * aj * invM;  // :93 (the /lambda of lsum cancels the *lambda of :107)
+          }
+          dH[dm.off_lambda + d] = acc;
+        }
+      if (dm.opt[3])
+        for (int l = tid; l < K; l += nt) {
+          double acc = 0.0;
+          for (int j = 0; j < K; ++j) {
+            double aj = 0.0;
+            for (int c = 0; c < a.C; ++c) aj += pe[((size_t)j * a.C + c) * a.ncol + 2 + 2 * D + l];
+            acc += w[j] * aj * invM;  // :100
+          }
+          wraw[l] = -Hj[l] - acc;  // :97
+        }
+    }
+  } else {
+    const double* eb = a.entlb + (size_t)r * (1 + D * K + 2 * K + D);
+    if (tid == 0) scal[1] = eb[0];
+    if (a.want_grad) {
+      if (dm.opt[0]) for (int p = tid; p < D * K; p += nt) dH[dm.off_mu + p] = eb[1 + p];
+      if (dm.opt[1]) for (int k = tid; k < K; k += nt) dH[dm.off_sigma + k] = eb[1 + D * K + k];
+      if (dm.opt[2]) for (int d = tid; d < D; d += nt) dH[dm.off_lambda + d] = eb[1 + D * K + K + d];
+      if (dm.opt[3]) for (int k = tid; k < K; k += nt) wraw[k] = eb[1 + D * K + K + D + k];
+    }
+  }
+  __syncthreads();
+  if (a.want_grad && dm.opt[3]) {
+    double part = 0.0;
+    for (int k = tid; k < K; k += nt) part += w[k] * wraw[k];
+    double dot = block_sum(part, red);
+    for (int k = tid; k < K; k += nt) dH[dm.off_eta + k] = w[k] * wraw[k] - w[k] * dot;  // :121-123
+  }
+  __syncthreads();
+
+  // ---- penalties (negelcbo_vbmc.m:136-164, vpbndloss.m, softbndloss.m)
+  double pen = 0.0;
+  if (a.has_bnd) {
+    const int next_mu = dm.opt[0] ? D * K : 0;
+    const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
+    const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
+    const double* lb = a.bnd;
+    const double* ub = a.bnd + Text;
+    double part = 0.0;
+    // mu block
+    if (dm.opt[0])
+      for (int p = tid; p < D * K; p += nt) {
+        double x = v[L.mu() + p], l = lb[p], u = ub[p], ell = (u - l) * a.TolCon;
+        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; dP[dm.off_mu + p] += (x - l) / (ell * ell); }
+        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; dP[dm.off_mu + p] += (x - u) / (ell * ell); }
+      }
+    pen += block_sum(part, red);
+    // lnscale block D x K : lnsigma_k + lnlambda_d (vpbndloss.m:36); gradient summed over d / k
+    if (has_sc) {
+      part = 0.0;
+      // pass 1: loss
+      for (int p = tid; p < D * K; p += nt) {
+        int d = p % D, k = p / D;
+        double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
+        double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
+        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; }
+        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; }
+      }
+      pen += block_sum(part, red);
+      if (a.want_grad) {
+        if (dm.opt[1])
+          for (int k = tid; k < K; k += nt) {
+            double acc = 0.0;
+            for (int d = 0; d < D; ++d) {
+              int p = d + D * k;
+              double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
+              double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
+              if (x < l) acc += (x - l) / (ell * ell);
+              if (x > u) acc += (x - u) / (ell * ell);
+            }
+            dP[dm.off_sigma + k] += acc;
+          }
+        if (dm.opt[2])
+          for (int d = tid; d < D; d += nt) {
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) {
+              int p = d + D * k;
+              double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
+              double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
+              if (x < l) acc += (x - l) / (ell * ell);
+              if (x > u) acc += (x - u) / (ell * ell);
+            }
+            dP[dm.off_lambda + d] += acc;
+          }
+      }
+    }
+    if (dm.opt[3]) {
+      part = 0.0;
+      const int o3 = next_mu + has_sc * D * K;
+      for (int k = tid; k < K; k += nt) {
+        double x = v[L.eta() + k], l = lb[o3 + k], u = ub[o3 + k], ell = (u - l) * a.TolCon;
+        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; dP[dm.off_eta + k] += (x - l) / (ell * ell); }
+        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; dP[dm.off_eta + k] += (x - u) / (ell * ell); }
+      }
+      pen += block_sum(part, red);
+      // weight-size penalty :146-162
+      part = 0.0;
+      for (int k = tid; k < K; k += nt) part += (w[k] < a.WeightThreshold) ? w[k] : a.WeightThreshold;
+      pen += block_sum(part, red) * a.WeightPenalty;
+      if (a.want_grad) {
+        double pd = 0.0;
+        for (int k = tid; k < K; k += nt) pd += (w[k] < a.WeightThreshold) ? w[k] * a.WeightPenalty : 0.0;
+        double dot = block_sum(pd, red);
+        for (int k = tid; k < K; k += nt) {
+          double gk = (w[k] < a.WeightThreshold) ? a.WeightPenalty : 0.0;
+          dP[dm.off_eta + k] += w[k] * gk - w[k] * dot;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- assemble
+  double varG = 0.0, varGss = 0.0;
+  const double* vr = a.var ? a.var + (size_t)r * a.var_stride : nullptr;
+  if (vr) { varG = vr[0]; varGss = vr[1]; }
+  if (tid == 0) {
+    double G = scal[0], H = scal[1];
+    double F = -G - H;                                  // :116
+    if (a.beta != 0.0) F += a.beta * sqrt(varG);        // :127 (varH = 0)
+    F += pen;
+    o[0] = F; o[1] = G; o[2] = H; o[3] = varG; o[4] = varGss;
+  }
+  if (a.want_grad) {
+    for (int i = tid; i < T; i += nt) {
+      double g = -dG[i] - dH[i];                        // :117
+      if (a.beta != 0.0 && vr) g += 0.5 * a.beta * vr[2 + i] / sqrt(varG);  // :129
+      o[OUT_HDR + i] = g + dP[i];
+      o[OUT_HDR + T + i] = dG[i];
+      o[OUT_HDR + 2 * T + i] = dH[i];
+    }
+  }
+}

@@ -1,0 +1,200 @@
+"""negelcbo_vbmc on the GPU: the reference's objective call surface over the C ABI.
+
+``negelcbo_vbmc(theta, beta, vp, gp, Ns, compute_grad, compute_var, altent_flag, thetabnd,
+entropy_alpha)`` keeps the reference's positional arguments (misc/negelcbo_vbmc.m:1) and
+returns the reference's 11 outputs as a tuple truncated to ``nargout``.  ``negelcbo_batch``
+evaluates R thetas in one launch (sieve batch / many Adam chains).
+
+``gp`` is a plain dict with the reference's field names: X, y, s2, covfun, meanfun, noisefun,
+Ncov, Nnoise, Nmean, post = [ {hyp, alpha, sW, L, sn2_mult, Lchol}, ... ] (gplite_post.m:94-157).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, DeviceGP, ElboArgs, f64, ptr
+
+_engines = {}
+
+
+class Engine:
+    """A device context plus a cache of uploaded GP posteriors."""
+
+    def __init__(self, device=0, stream=None):
+        self.ctx = Context(device, stream)
+        self._gp_cache = {}
+
+    def device_gp(self, gp, need_L=False):
+        key = id(gp)
+        ent = self._gp_cache.get(key)
+        if ent is not None and ent[0] is gp and (ent[2] or not need_L) and ent[3] == self._fingerprint(gp):
+            return ent[1]
+        post = gp["post"]
+        S = len(post)
+        X = np.asarray(gp["X"], dtype=np.float64)
+        N = X.shape[0]
+        hyp = np.stack([np.asarray(p["hyp"], dtype=np.float64).reshape(-1) for p in post], axis=1)
+        alpha = np.stack([np.asarray(p["alpha"], dtype=np.float64).reshape(-1) for p in post], axis=1)
+        L = None
+        if need_L:
+            L = np.stack([np.asarray(p["L"], dtype=np.float64) for p in post], axis=2)
+        sW1 = np.array([np.asarray(p["sW"]).reshape(-1)[0] for p in post])
+        lch = np.array([1 if p["Lchol"] else 0 for p in post], dtype=np.uint8)
+        dgp = DeviceGP(self.ctx, X, hyp, alpha, L, sW1, lch, gp["meanfun"], gp["Ncov"], gp["Nnoise"])
+        self._gp_cache = {key: (gp, dgp, need_L, self._fingerprint(gp))}  # one live GP per engine
+        return dgp
+
+    @staticmethod
+    def _fingerprint(gp):
+        p0 = gp["post"][0]
+        return (np.asarray(gp["X"]).shape, len(gp["post"]), float(np.asarray(p0["alpha"]).reshape(-1)[0]),
+                float(np.asarray(p0["hyp"]).reshape(-1)[0]))
+
+    def invalidate(self):
+        self._gp_cache = {}
+
+
+def default_engine(device=0):
+    eng = _engines.get(device)
+    if eng is None:
+        eng = Engine(device)
+        _engines[device] = eng
+    return eng
+
+
+def _flags(vp):
+    return (int(bool(vp["optimize_mu"])), int(bool(vp["optimize_sigma"])), int(bool(vp["optimize_lambda"])),
+            int(bool(vp["optimize_weights"])))
+
+
+def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
+                   separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
+                   want=("F", "dF", "G", "H", "dG", "dH")):
+    """R evaluations of negelcbo_vbmc in one device pass.
+
+    thetas: (T, R) column per restart (or (T,) for R = 1).  Returns a dict of arrays
+    F[R], dF[T,R], G[R], H[R], dG[T,R], dH[T,R], varG[R], varGss[R], I_sk[S,K,R], J_sjk[S,K,K,R].
+    eps: host array shaped (R, K, Ns/2, D) (or (K, Ns/2, D) with eps_shared) standing in for the
+    reference's randn stream (entmc_vbmc.m:53); None -> device Philox stream keyed by ``seed``.
+    """
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    D, K = int(vp["D"]), int(vp["K"])
+    thetas = f64(thetas)
+    if thetas.ndim == 1:
+        thetas = f64(thetas.reshape(-1, 1))
+    T, R = thetas.shape
+    if beta is None or not np.isfinite(beta):
+        beta = 0.0  # negelcbo_vbmc.m:15
+    if compute_var is None:
+        compute_var = 1 if beta != 0 else 0  # :16 (first clause; nargout clause handled by callers)
+    compute_var = int(compute_var)
+    dgp = engine.device_gp(gp, need_L=compute_var != 0)
+    S = dgp.S
+    a = ElboArgs()
+    a.struct_size = C.sizeof(ElboArgs)
+    a.D, a.K, a.R = D, K, R
+    fl = _flags(vp)
+    for i in range(4):
+        a.optimize[i] = fl[i]
+    keep = [thetas]
+    a.theta = ptr(thetas)
+
+    def hold(x):
+        x = f64(x)
+        keep.append(x)
+        return ptr(x)
+
+    a.vp_mu = hold(vp["mu"])
+    a.vp_sigma = hold(vp["sigma"])
+    a.vp_lambda = hold(vp["lambda"])
+    a.vp_w = hold(vp["w"])
+    delta = vp.get("delta")
+    if delta is not None and np.size(delta) > 0 and np.any(np.asarray(delta) != 0):
+        a.vp_delta = hold(np.broadcast_to(np.asarray(delta, dtype=np.float64).reshape(-1), (D,)).copy())
+    Ns = int(Ns)
+    a.Ns = Ns
+    a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    a.eps_shared = 1 if eps_shared else 0
+    if Ns > 0 and eps_device_ptr is not None:
+        a.eps_mode = 2
+        a.eps = C.c_void_p(int(eps_device_ptr))
+    elif Ns > 0 and eps is not None:
+        Mh = (Ns + 1) // 2
+        e = np.ascontiguousarray(np.asarray(eps, dtype=np.float64))
+        want_shape = (K, Mh, D) if eps_shared else (R, K, Mh, D)
+        if e.shape != want_shape and not (R == 1 and e.shape == (K, Mh, D)):
+            raise ValueError("eps has shape %r, expected %r" % (e.shape, want_shape))
+        keep.append(e)
+        a.eps_mode = 1
+        a.eps = C.c_void_p(e.ctypes.data)
+    else:
+        a.eps_mode = 0
+    a.compute_grad = 1 if compute_grad else 0
+    a.compute_var = compute_var
+    a.separate_K = 1 if separate_K else 0
+    a.beta = float(beta)
+    if thetabnd is not None:
+        a.bnd_lb = hold(thetabnd["lb"])
+        a.bnd_ub = hold(thetabnd["ub"])
+        a.TolCon = float(thetabnd["TolCon"])
+        a.WeightThreshold = float(thetabnd.get("WeightThreshold", 0.0))
+        a.WeightPenalty = float(thetabnd.get("WeightPenalty", 0.0))
+    out = {}
+
+    def outbuf(name, shape):
+        arr = np.zeros(shape, dtype=np.float64, order="F")
+        out[name] = arr
+        return ptr(arr)
+
+    a.F = outbuf("F", (R,))
+    a.G = outbuf("G", (R,))
+    a.H = outbuf("H", (R,))
+    if compute_grad:
+        a.dF = outbuf("dF", (T, R))
+        a.dG = outbuf("dG", (T, R))
+        a.dH = outbuf("dH", (T, R))
+    a.varG = outbuf("varG", (R,))
+    a.varGss = outbuf("varGss", (R,))
+    if separate_K:
+        a.I_sk = outbuf("I_sk", (S, K, R))
+        if compute_var:
+            a.J_sjk = outbuf("J_sjk", (S, K, K, R))
+    ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, dgp.h, C.byref(a)))
+    return out
+
+
+def negelcbo_vbmc(theta, beta, vp, gp, Ns=0, compute_grad=None, compute_var=None, altent_flag=False, thetabnd=None,
+                  entropy_alpha=0, nargout=2, *, eps=None, seed=0, engine=None):
+    """[F,dF,G,H,varF,dH,varGss,varG,varH,I_sk,J_sjk] = negelcbo_vbmc(...)  (misc/negelcbo_vbmc.m:1).
+
+    ``nargout`` plays MATLAB's role: compute_grad defaults to nargout > 1 (:10), compute_var to
+    beta ~= 0 || nargout > 4 (:16), separate_K = nargout > 9 (:17).  altent_flag and
+    entropy_alpha are accepted and ignored, as in the reference (:19).
+    """
+    if Ns is None:
+        Ns = 0
+    if compute_grad is None:
+        compute_grad = nargout > 1
+    if beta is None or not np.isfinite(beta):
+        beta = 0.0
+    if compute_var is None:
+        compute_var = (beta != 0) or nargout > 4
+    separate_K = nargout > 9
+    r = negelcbo_batch(np.asarray(theta, dtype=np.float64).reshape(-1), beta, vp, gp, Ns, bool(compute_grad),
+                       int(compute_var), thetabnd, separate_K=separate_K, eps=eps, seed=seed, engine=engine)
+    F = float(r["F"][0])
+    dF = r["dF"][:, 0].copy() if compute_grad else np.zeros(0)
+    G, H = float(r["G"][0]), float(r["H"][0])
+    varH = 0.0
+    varG = float(r["varG"][0]) if compute_var else 0.0
+    varF = varG + varH if compute_var else 0.0
+    dH = r["dH"][:, 0].copy() if compute_grad else np.zeros(0)
+    varGss = float(r["varGss"][0]) if compute_var else 0.0
+    I_sk = r["I_sk"][:, :, 0].copy() if separate_K else None
+    J_sjk = r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None
+    outs = (F, dF, G, H, varF, dH, varGss, varG, varH, I_sk, J_sjk)
+    return outs[: max(1, nargout)] if nargout < 11 else outs
