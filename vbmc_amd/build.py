@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SOURCES = ["abi_elbo.hip"]
-HEADERS = ["common.h", "device_math.h", "elbo_kernels.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
+HEADERS = ["common.h", "device_math.h", "elbo_kernels.h", "var_kernels.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
 
 
 def _newer(target, deps):

@@ -3,6 +3,7 @@
 #include <cmath>
 
 #include "elbo_kernels.h"
+#include "var_kernels.h"
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -160,6 +161,11 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
     e = up(&gp->L, L, (size_t)N * N * S);
     gp->hasL = true;
   }
+  if (e == hipSuccess) e = up(&gp->d_sn2, gp->sn2_eff.data(), (size_t)S);
+  if (e == hipSuccess) {
+    e = hipMalloc((void**)&gp->d_lchol, (size_t)S);
+    if (e == hipSuccess) e = hipMemcpy(gp->d_lchol, gp->Lchol.data(), (size_t)S, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     vbmc_gp_free(ctx, gp);
     return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_upload: %s", hipGetErrorString(e));
@@ -176,6 +182,8 @@ extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
   if (gp->L) (void)hipFree(gp->L);
   if (gp->gpc) (void)hipFree(gp->gpc);
   if (gp->hyp) (void)hipFree(gp->hyp);
+  if (gp->d_sn2) (void)hipFree(gp->d_sn2);
+  if (gp->d_lchol) (void)hipFree(gp->d_lchol);
   delete gp;
 }
 
@@ -262,8 +270,10 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     return set_err(ctx, VBMC_ERR_INVALID, "gplogjoint:FullVarianceGradient gradient of the log joint variance needs compute_var == 2");
   if (a->separate_K && compute_grad)  // negelcbo_vbmc.m:57-59
     return set_err(ctx, VBMC_ERR_INVALID, "Computing the gradient of variational parameters and requesting per-component results at the same time.");
-  if (compute_var != 0)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "compute_var != 0 not yet on device");
+  if (compute_var != 0 && !gp->hasL)
+    return set_err(ctx, VBMC_ERR_INVALID, "compute_var != 0 needs gp.post(s).L: upload the GP with L");
+  if (compute_var != 0 && ((size_t)dm.N * 16 + 256) * sizeof(double) > 160 * 1024)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1264 not accelerated", dm.N);
   if (a->beta != 0.0 && !std::isfinite(a->beta)) { /* negelcbo_vbmc.m:15: non-finite beta -> 0 */ }
   const double beta = (std::isfinite(a->beta)) ? a->beta : 0.0;
   // theta must be finite (device exp() clamps would swallow NaN)
@@ -385,8 +395,57 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     fa.entpart = nullptr; fa.entlb = (const double*)ctx->entpart.p;
   }
 
+  // ---- variance of the expected log joint (gplogjoint.m:273-337,375-413)
+  double* d_J = nullptr;
+  double* d_var = nullptr;
+  const int var_stride = 2 + T;
+  if (compute_var != 0) {
+    const int N = dm.N;
+    const bool vgrad = compute_grad && compute_var == 2;
+    bool any_nochol = false;
+    for (int s = 0; s < S; ++s) any_nochol |= (gp->Lchol[s] == 0);
+    const size_t nz = (size_t)R * S * K * N;
+    { vbmc_status s_ = ensure(ctx, ctx->zbuf, nz * sizeof(double)); if (s_) return s_; }
+    const size_t nJ = (size_t)R * S * K * K, nvg = (size_t)R * S * K * (2 * D + 1), nvo = (size_t)R * var_stride;
+    const bool needX = vgrad || any_nochol;
+    { vbmc_status s_ = ensure(ctx, ctx->varbuf, ((needX ? nz : 0) + nJ + nvg + nvo) * sizeof(double)); if (s_) return s_; }
+    double* d_Z = (double*)ctx->zbuf.p;
+    double* d_X = (double*)ctx->varbuf.p;
+    d_J = d_X + (needX ? nz : 0);
+    double* d_vg = d_J + nJ;
+    d_var = d_vg + nvg;
+    DISPATCH_DT(dt, {
+      hipLaunchKernelGGL((k_var_z<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, d_vpd, gp->X, gp->gpc, d_delta2, d_Z);
+    });
+    const size_t tlds = ((size_t)N * 16 + 256) * sizeof(double);
+    if (tlds > 64 * 1024) {
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    }
+    const dim3 tg((K + TR_CB - 1) / TR_CB, S, R);
+    if (any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, d_Z, d_X);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, d_Z);
+    hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, d_vpd, gp->gpc, d_delta2, gp->d_sn2, gp->d_lchol,
+                       d_Z, d_X, d_J, compute_var == 1 ? 1 : 0);
+    if (vgrad) {
+      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, d_Z, d_X);
+      DISPATCH_DT(dt, {
+        hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, d_vpd, gp->X, gp->gpc, d_delta2,
+                           gp->d_sn2, gp->d_lchol, d_X, d_vg);
+      });
+    }
+    VarFinArgs va{};
+    va.dm = dm; va.vpd = d_vpd; va.gpc = gp->gpc; va.delta2 = d_delta2; va.lj = d_lj; va.J = d_J;
+    va.vg = vgrad ? d_vg : nullptr; va.compute_var = compute_var; va.want_grad = compute_grad; va.stride = var_stride;
+    va.out = d_var;
+    const size_t vlds = (256 + 2 * (size_t)S + 7 * (size_t)T + K + 8) * sizeof(double);
+    if (vlds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
+    hipLaunchKernelGGL(k_var_final, dim3(R), dim3(256), vlds, st, va);
+  }
+
   // ---- finalize
-  fa.vpd = d_vpd; fa.theta = d_theta; fa.lj = d_lj; fa.var = nullptr; fa.var_stride = 0;
+  fa.vpd = d_vpd; fa.theta = d_theta; fa.lj = d_lj; fa.var = d_var; fa.var_stride = d_var ? var_stride : 0;
   fa.bnd = has_bnd ? d_bnd : nullptr; fa.has_bnd = has_bnd ? 1 : 0;
   fa.TolCon = a->TolCon; fa.WeightThreshold = a->WeightThreshold; fa.WeightPenalty = a->WeightPenalty;
   fa.beta = beta; fa.want_grad = compute_grad; fa.out = d_out;
@@ -406,6 +465,11 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   if (a->separate_K && a->I_sk) {
     ljh.resize((size_t)R * S * K * LJS);
     HIP_TRY(ctx, hipMemcpyAsync(ljh.data(), d_lj, ljh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  std::vector<double> Jh;
+  if (a->separate_K && a->J_sjk && d_J) {
+    Jh.resize((size_t)R * S * K * K);
+    HIP_TRY(ctx, hipMemcpyAsync(Jh.data(), d_J, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   (void)hisk;
@@ -432,6 +496,13 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     for (int r = 0; r < R; ++r)
       for (int k = 0; k < K; ++k)
         for (int s = 0; s < S; ++s) a->I_sk[s + (size_t)S * (k + (size_t)K * r)] = ljh[(((size_t)r * S + s) * K + k) * LJS];
+  }
+  if (!Jh.empty()) {
+    for (int r = 0; r < R; ++r)
+      for (int k = 0; k < K; ++k)
+        for (int j = 0; j < K; ++j)
+          for (int s = 0; s < S; ++s)
+            a->J_sjk[s + (size_t)S * (j + (size_t)K * (k + (size_t)K * r))] = Jh[(((size_t)r * S + s) * K + k) * K + j];
   }
   return VBMC_OK;
 }

@@ -40,6 +40,8 @@ struct vbmc_gp {
   double* L = nullptr;      // N x N x S
   double* gpc = nullptr;    // S x GPC_STRIDE derived per-sample constants (see elbo.hip)
   double* hyp = nullptr;    // Nhyp x S
+  double* d_sn2 = nullptr;  // S  sn2_eff
+  unsigned char* d_lchol = nullptr;  // S
   std::vector<double> sn2_eff;
   std::vector<uint8_t> Lchol;
   std::vector<double> hyp_host;

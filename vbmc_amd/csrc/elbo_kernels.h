@@ -13,6 +13,7 @@
 //   k_entropy    antithetic MC entropy + reparameterisation-gradient partials (1 wave / chunk)
 //   k_entlb      Gershman lower bound on the entropy + gradient               (1 WG / restart)
 //   k_finalize   fixed-order reduction of the partials, Jacobians, penalties  (1 WG / restart)
+#pragma once
 #include "common.h"
 #include "device_math.h"
 

@@ -1,0 +1,466 @@
+// Bayesian-quadrature variance of the expected log joint on gfx950.
+//
+// Reference: misc/gplogjoint.m:273-337 (diag and full K x K variance), :375-413 (gradient of the
+// diagonal variance, hyper-sample averaging).  The reference re-solves two N x N triangular systems
+// for every (j,k) pair -- O(S K^2 N^2).  Here every hyper-sample does ONE blocked triangular solve
+// V = L' \ Z for all K right-hand sides and then a K x K Gram matrix, O(S (N^2 K + K^2 N)); results
+// agree to summation order.
+//
+//   k_var_z       Z[r][s][k][:] = z_k  (gplogjoint.m:164-168)
+//   k_trsm_fwd    V = L' \ Z   (L upper, MATLAB chol convention), 16 columns per workgroup in LDS
+//   k_trsm_bwd    X = L \ V    (only for the variance gradient: invKzk = X / sn2_eff, :277)
+//   k_symm        U = L * Z    (Lchol == false: L = -inv(K + sn2 I), :279,:321)
+//   k_var_gram    J[r][s][j][k] (:281,:318-322) and the raw varF(s) terms
+//   k_vargrad     raw dots  dz_dtheta * invKzk  (:289-301)
+//   k_var_final   varF, varss, dvarF with Jacobians and averaging (:350,:375-413)
+#pragma once
+#include "common.h"
+#include "device_math.h"
+#include "elbo_kernels.h"
+
+#define TR_CB 16   // right-hand-side columns per workgroup
+#define TR_B 16    // row block
+
+// ------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(WAVE) k_var_z(ElboDims dm, const double* __restrict__ vpd,
+                                                const double* __restrict__ X, const double* __restrict__ gpc,
+                                                const double* __restrict__ delta2, double* __restrict__ Z) {
+  const int k = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
+  const double sig = v[L.sigma() + k];
+  double mu[DT], itau[DT];
+  double sumlogtau = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    if (d < D) {
+      double lam = v[L.lambda() + d];
+      mu[d] = v[L.mu() + d + D * k];
+      double tau = sqrt(sig * sig * lam * lam + g[d] + delta2[d]);
+      sumlogtau += log(tau);
+      itau[d] = 1.0 / tau;
+    } else { mu[d] = 0.0; itau[d] = 0.0; }
+  }
+  const double lnnf = g[3 * D] - sumlogtau;
+  double* z = Z + (((size_t)r * dm.S + s) * K + k) * N;
+  for (int n = lane; n < N; n += WAVE) {
+    double a2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      double x = (d < D) ? X[n + (size_t)N * d] : 0.0;
+      double dl = (mu[d] - x) * itau[d];
+      a2 = fma(dl, dl, a2);
+    }
+    z[n] = vb_exp(lnnf - 0.5 * a2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward substitution with R' (R upper triangular, column-major N x N): solve R' V = Z in place.
+// One workgroup = 256 threads = 16 row-lanes x 16 columns; the N x 16 slab of V lives in LDS.
+// v_i = (z_i - sum_{j<i} R[j][i] v_j) / R[i][i]; column i of R is contiguous.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_trsm_fwd(int N, int K, int S, const double* __restrict__ Lall,
+                                                  const unsigned char* __restrict__ lchol, double* __restrict__ Z) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+  if (!lchol[s]) return;
+  const int tid = threadIdx.x, c = tid & 15, ri = tid >> 4;
+  const int k0 = cb * TR_CB;
+  const int kc = k0 + c;
+  const bool cv = kc < K;
+  const double* Rm = Lall + (size_t)s * N * N;
+  double* Zs = Z + ((size_t)r * S + s) * (size_t)K * N;
+  double* V = lds;                    // N x 16 (row-major: V[i*16 + c])
+  double* Rd = V + (size_t)N * 16;    // 16 x 16 diagonal block, Rd[jj*16 + ii] = R[b0+jj][b0+ii]
+  for (int i = ri; i < N; i += 16) V[i * 16 + c] = cv ? Zs[(size_t)kc * N + i] : 0.0;
+  __syncthreads();
+  for (int b0 = 0; b0 < N; b0 += TR_B) {
+    const int nb = min(TR_B, N - b0);
+    // trailing update from all solved rows j < b0
+    double acc = 0.0;
+    if (ri < nb) {
+      const double* col = Rm + (size_t)(b0 + ri) * N;  // column b0+ri of R
+      int j = 0;
+      for (; j + 4 <= b0; j += 4) {
+        acc = fma(col[j], V[j * 16 + c], acc);
+        acc = fma(col[j + 1], V[(j + 1) * 16 + c], acc);
+        acc = fma(col[j + 2], V[(j + 2) * 16 + c], acc);
+        acc = fma(col[j + 3], V[(j + 3) * 16 + c], acc);
+      }
+      for (; j < b0; ++j) acc = fma(col[j], V[j * 16 + c], acc);
+    }
+    // diagonal block to LDS
+    {
+      int jj = tid >> 4, ii = tid & 15;
+      Rd[jj * 16 + ii] = (jj < nb && ii < nb) ? Rm[(size_t)(b0 + ii) * N + b0 + jj] : 0.0;
+    }
+    __syncthreads();
+    if (ri < nb) V[(b0 + ri) * 16 + c] -= acc;
+    __syncthreads();
+    // sequential solve inside the block: thread c (ri == 0) owns column c
+    if (ri == 0) {
+      for (int ii = 0; ii < nb; ++ii) {
+        double t = V[(b0 + ii) * 16 + c];
+        for (int jj = 0; jj < ii; ++jj) t = fma(-Rd[jj * 16 + ii], V[(b0 + jj) * 16 + c], t);
+        V[(b0 + ii) * 16 + c] = t / Rd[ii * 16 + ii];
+      }
+    }
+    __syncthreads();
+  }
+  if (cv)
+    for (int i = ri; i < N; i += 16) Zs[(size_t)kc * N + i] = V[i * 16 + c];
+}
+
+// Backward substitution with R: solve R Xo = V (V read, Xo written).  x_i = (v_i - sum_{j>i} R[i][j] x_j)/R[i][i]
+__global__ void __launch_bounds__(256) k_trsm_bwd(int N, int K, int S, const double* __restrict__ Lall,
+                                                  const unsigned char* __restrict__ lchol,
+                                                  const double* __restrict__ Vin, double* __restrict__ Xo) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+  if (!lchol[s]) return;
+  const int tid = threadIdx.x, c = tid & 15, ri = tid >> 4;
+  const int kc = cb * TR_CB + c;
+  const bool cv = kc < K;
+  const double* Rm = Lall + (size_t)s * N * N;
+  const double* Vs = Vin + ((size_t)r * S + s) * (size_t)K * N;
+  double* Xs = Xo + ((size_t)r * S + s) * (size_t)K * N;
+  double* V = lds;
+  double* Rd = V + (size_t)N * 16;
+  for (int i = ri; i < N; i += 16) V[i * 16 + c] = cv ? Vs[(size_t)kc * N + i] : 0.0;
+  __syncthreads();
+  const int nblk = (N + TR_B - 1) / TR_B;
+  for (int bi = nblk - 1; bi >= 0; --bi) {
+    const int b0 = bi * TR_B;
+    const int nb = min(TR_B, N - b0);
+    const int e0 = b0 + nb;  // rows >= e0 are solved
+    double acc = 0.0;
+    if (ri < nb) {
+      for (int j = e0; j < N; ++j) acc = fma(Rm[(size_t)j * N + b0 + ri], V[j * 16 + c], acc);  // R[b0+ri][j]
+    }
+    {
+      int jj = tid >> 4, ii = tid & 15;  // Rd[ii*16 + jj] = R[b0+ii][b0+jj]
+      Rd[ii * 16 + jj] = (jj < nb && ii < nb) ? Rm[(size_t)(b0 + jj) * N + b0 + ii] : 0.0;
+    }
+    __syncthreads();
+    if (ri < nb) V[(b0 + ri) * 16 + c] -= acc;
+    __syncthreads();
+    if (ri == 0) {
+      for (int ii = nb - 1; ii >= 0; --ii) {
+        double t = V[(b0 + ii) * 16 + c];
+        for (int jj = ii + 1; jj < nb; ++jj) t = fma(-Rd[ii * 16 + jj], V[(b0 + jj) * 16 + c], t);
+        V[(b0 + ii) * 16 + c] = t / Rd[ii * 16 + ii];
+      }
+    }
+    __syncthreads();
+  }
+  if (cv)
+    for (int i = ri; i < N; i += 16) Xs[(size_t)kc * N + i] = V[i * 16 + c];
+}
+
+// U = Lm * Z for hyper-samples with Lchol == false (Lm = -inv(K + sn2 I), full symmetric N x N)
+__global__ void __launch_bounds__(256) k_symm(int N, int K, int S, const double* __restrict__ Lall,
+                                              const unsigned char* __restrict__ lchol,
+                                              const double* __restrict__ Z, double* __restrict__ U) {
+  const int s = blockIdx.y, r = blockIdx.z;
+  if (lchol[s]) return;
+  const double* Lm = Lall + (size_t)s * N * N;
+  const double* Zs = Z + ((size_t)r * S + s) * (size_t)K * N;
+  double* Us = U + ((size_t)r * S + s) * (size_t)K * N;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * K; idx += gridDim.x * blockDim.x) {
+    int i = idx % N, k = idx / N;
+    double acc = 0.0;
+    for (int j = 0; j < N; ++j) acc = fma(Lm[(size_t)j * N + i], Zs[(size_t)k * N + j], acc);  // symmetric: L[i][j] = L[j][i]
+    Us[idx] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// J[r][s][j][k] for j <= k (mirrored), diag only if !full.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_var_gram(ElboDims dm, const double* __restrict__ vpd,
+                                                  const double* __restrict__ gpc, const double* __restrict__ delta2,
+                                                  const double* __restrict__ sn2_eff, const unsigned char* __restrict__ lchol,
+                                                  const double* __restrict__ ZV,   // L'\Z in place (Lchol) / raw z (!Lchol)
+                                                  const double* __restrict__ XU,   // L*Z for !Lchol samples (else unused)
+                                                  double* __restrict__ J, int full) {
+  const int s = blockIdx.y, r = blockIdx.z;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
+  const double* Zs = ZV + ((size_t)r * dm.S + s) * (size_t)K * N;
+  const bool lc = lchol[s] != 0;
+  const double* Vs = (lc ? ZV : XU) + ((size_t)r * dm.S + s) * (size_t)K * N;
+  double* Js = J + ((size_t)r * dm.S + s) * (size_t)K * K;
+  const int lane = threadIdx.x & 63, wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const int npair = full ? K * K : K;
+  for (int p = wv; p < npair; p += nw) {
+    int j, k;
+    if (full) { j = p % K; k = p / K; if (j > k) continue; } else { j = k = p; }
+    double dot = 0.0;
+    if (lc) {
+      for (int n = lane; n < N; n += 64) dot = fma(Vs[(size_t)j * N + n], Vs[(size_t)k * N + n], dot);
+    } else {
+      for (int n = lane; n < N; n += 64) dot = fma(Zs[(size_t)k * N + n], Vs[(size_t)j * N + n], dot);
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+      double sj = v[L.sigma() + j], sk = v[L.sigma() + k];
+      double slt = 0.0, d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        double lam = v[L.lambda() + d];
+        double t2 = (sj * sj + sk * sk) * lam * lam + g[d] + 2.0 * delta2[d];  // tau_jk^2 (:313), tau_kk (:274)
+        slt += log(sqrt(t2));
+        double dm_ = v[L.mu() + d + D * j] - v[L.mu() + d + D * k];
+        d2 += dm_ * dm_ / t2;
+      }
+      double nf = exp(g[3 * D] - slt - 0.5 * d2);
+      double val = lc ? nf - dot / sn2_eff[s] : nf + dot;  // :318-322
+      Js[j + (size_t)K * k] = val;
+      Js[k + (size_t)K * j] = val;
+    }
+  }
+}
+
+// raw dots of the variance gradient for compute_var == 2: one wave per (k, s, r)
+// VG[r][s][k][2D+1] = dz_dmu*x [D], dz_dsigma*x, dz_dlambda*x [D]   with x = invKzk
+template <int DT>
+__global__ void __launch_bounds__(WAVE) k_vargrad(ElboDims dm, const double* __restrict__ vpd,
+                                                  const double* __restrict__ X, const double* __restrict__ gpc,
+                                                  const double* __restrict__ delta2, const double* __restrict__ sn2_eff,
+                                                  const unsigned char* __restrict__ lchol,
+                                                  const double* __restrict__ Xsol,  // L\(L'\z) (Lchol) or L*z (!Lchol)
+                                                  double* __restrict__ vg) {
+  const int k = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
+  const double sig = v[L.sigma() + k];
+  const double xs = lchol[s] ? 1.0 / sn2_eff[s] : -1.0;  // invKzk = X/sn2_eff  or  -L z
+  double mu[DT], itau[DT], lam[DT];
+  double sumlogtau = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    if (d < D) {
+      lam[d] = v[L.lambda() + d];
+      mu[d] = v[L.mu() + d + D * k];
+      double tau = sqrt(sig * sig * lam[d] * lam[d] + g[d] + delta2[d]);
+      sumlogtau += log(tau);
+      itau[d] = 1.0 / tau;
+    } else { lam[d] = 0.0; mu[d] = 0.0; itau[d] = 0.0; }
+  }
+  const double lnnf = g[3 * D] - sumlogtau;
+  double accS = 0.0, accM[DT], accL[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { accM[d] = 0.0; accL[d] = 0.0; }
+  const double* xv = Xsol + (((size_t)r * dm.S + s) * K + k) * N;
+  for (int n = lane; n < N; n += WAVE) {
+    double dl[DT];
+    double a2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      double x = (d < D) ? X[n + (size_t)N * d] : 0.0;
+      dl[d] = (mu[d] - x) * itau[d];
+      a2 = fma(dl[d], dl[d], a2);
+    }
+    double za = vb_exp(lnnf - 0.5 * a2) * (xv[n] * xs);
+    double ssum = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      double li = lam[d] * itau[d], si = sig * itau[d];
+      double q = fma(dl[d], dl[d], -1.0);
+      accM[d] = fma(-dl[d] * itau[d], za, accM[d]);
+      ssum = fma(li * li, q, ssum);
+      accL[d] = fma(si * si * q * lam[d], za, accL[d]);
+    }
+    accS = fma(ssum * sig, za, accS);
+  }
+  accS = wave_sum(accS);
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { accM[d] = wave_sum(accM[d]); accL[d] = wave_sum(accL[d]); }
+  if (lane == 0) {
+    double* o = vg + (((size_t)r * dm.S + s) * K + k) * (2 * D + 1);
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      if (d < D) { o[d] = accM[d]; o[D + 1 + d] = accL[d]; }
+    o[D] = accS;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_var_final: one workgroup per restart.  out VR[r] = varG, varGss, dvarG[T]
+// ------------------------------------------------------------------------------------------
+struct VarFinArgs {
+  ElboDims dm;
+  const double* vpd;
+  const double* gpc;
+  const double* delta2;
+  const double* lj;   // R x S x K x (2D+2)  (per-sample I_k and gradient pieces)
+  const double* J;    // R x S x K x K
+  const double* vg;   // R x S x K x (2D+1) or null
+  int compute_var, want_grad, stride;
+  double* out;
+};
+
+__global__ void __launch_bounds__(256) k_var_final(VarFinArgs a) {
+  extern __shared__ double lds[];
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const ElboDims& dm = a.dm;
+  const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
+  const double EPS = 2.220446049250313e-16;
+  VpLayout L{D, K};
+  const double* v = a.vpd + (size_t)r * L.stride();
+  const double* w = v + L.w();
+  const double* sigma = v + L.sigma();
+  const double* lam = v + L.lambda();
+  double* red = lds;          // nt
+  double* Fs = red + nt;      // S
+  double* vFs = Fs + S;       // S
+  double* dFs = vFs + S;      // T  per-sample gradient (after Jacobians), reused per s
+  double* dvs = dFs + T;      // T  per-sample variance gradient
+  double* acc1 = dvs + T;     // T  sum_s dvarF(:,s)
+  double* acc2 = acc1 + T;    // T  sum_s F(s) dF(:,s)
+  double* acc3 = acc2 + T;    // T  sum_s dF(:,s)
+  double* tmpK = acc3 + T;    // K
+  const int LJS = 2 * D + 2;
+  const double* lj = a.lj + (size_t)r * S * K * LJS;
+  const double* Jr = a.J + (size_t)r * S * K * K;
+  double* o = a.out + (size_t)r * a.stride;
+  const bool vgrad = a.want_grad && a.compute_var == 2;
+  for (int i = tid; i < T; i += nt) { acc1[i] = 0.0; acc2[i] = 0.0; acc3[i] = 0.0; }
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const double* Js = Jr + (size_t)s * K * K;
+    // varF(s)  (:283, :329-332, :350)
+    double part = 0.0;
+    if (a.compute_var == 2) {
+      for (int k = tid; k < K; k += nt) part += w[k] * w[k] * fmax(EPS, Js[k + (size_t)K * k]);
+    } else {
+      for (int p = tid; p < K * K; p += nt) {
+        int j = p % K, k = p / K;
+        if (j == k) part += w[k] * w[k] * fmax(EPS, Js[p]);
+        else if (j < k) part += 2.0 * w[j] * w[k] * Js[p];
+      }
+    }
+    double vf = block_sum(part, red);
+    part = 0.0;
+    for (int k = tid; k < K; k += nt) part += w[k] * lj[((size_t)s * K + k) * LJS];
+    double fs = block_sum(part, red);
+    if (tid == 0) { vFs[s] = fmax(vf, EPS); Fs[s] = fs; }
+    if (vgrad) {
+      const double* g = a.gpc + (size_t)s * GPC_STRIDE(D);
+      const double* vg = a.vg + ((size_t)r * S + s) * (size_t)K * (2 * D + 1);
+      for (int i = tid; i < T; i += nt) { dFs[i] = 0.0; dvs[i] = 0.0; }
+      __syncthreads();
+      // per-sample value gradient dF(:,s) after Jacobians (:352-373)
+      if (dm.opt[0]) for (int p = tid; p < D * K; p += nt) dFs[dm.off_mu + p] = lj[((size_t)s * K + p / D) * LJS + 1 + p % D];
+      if (dm.opt[1]) for (int k = tid; k < K; k += nt) dFs[dm.off_sigma + k] = lj[((size_t)s * K + k) * LJS + 1 + D] * sigma[k];
+      if (dm.opt[2])
+        for (int d = tid; d < D; d += nt) {
+          double ls = 0.0;
+          for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
+          dFs[dm.off_lambda + d] = ls * lam[d];
+        }
+      // variance gradient pieces (:286-303)
+      if (dm.opt[0])
+        for (int p = tid; p < D * K; p += nt) {
+          int d = p % D, k = p / D;
+          dvs[dm.off_mu + p] = -w[k] * w[k] * (2.0 * vg[(size_t)k * (2 * D + 1) + d]);  // :289
+        }
+      if (dm.opt[1])
+        for (int k = tid; k < K; k += nt) {
+          double slt = 0.0, sl2 = 0.0;
+          for (int d = 0; d < D; ++d) {
+            double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
+            slt += log(sqrt(t2));
+            sl2 += lam[d] * lam[d] / t2;
+          }
+          double nfkk = exp(g[3 * D] - slt);
+          dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * nfkk * sl2 + vg[(size_t)k * (2 * D + 1) + D]) * sigma[k];  // :293, Jacobian :382
+        }
+      if (dm.opt[2])
+        for (int d = tid; d < D; d += nt) {
+          double accd = 0.0;
+          for (int k = 0; k < K; ++k) {
+            double slt = 0.0;
+            for (int dd = 0; dd < D; ++dd)
+              slt += log(sqrt(2.0 * sigma[k] * sigma[k] * lam[dd] * lam[dd] + g[dd] + 2.0 * a.delta2[dd]));
+            double nfkk = exp(g[3 * D] - slt);
+            double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
+            accd -= 2.0 * w[k] * w[k] * (sigma[k] * sigma[k] * nfkk * lam[d] / t2 + vg[(size_t)k * (2 * D + 1) + D + 1 + d]);  // :297
+          }
+          dvs[dm.off_lambda + d] = accd * lam[d];  // Jacobian :386
+        }
+      __syncthreads();
+      if (dm.opt[3]) {
+        // softmax Jacobian on w_grad = I_k and on w_vargrad = 2 w_k max(eps, J_kk)  (:301, :366-372, :390)
+        double p1 = 0.0, p2 = 0.0;
+        for (int k = tid; k < K; k += nt) {
+          double ik = lj[((size_t)s * K + k) * LJS];
+          double wv = 2.0 * w[k] * fmax(EPS, Js[k + (size_t)K * k]);
+          tmpK[k] = wv;
+          p1 += w[k] * ik;
+          p2 += w[k] * wv;
+        }
+        double d1 = block_sum(p1, red);
+        double d2 = block_sum(p2, red);
+        for (int k = tid; k < K; k += nt) {
+          double ik = lj[((size_t)s * K + k) * LJS];
+          dFs[dm.off_eta + k] = w[k] * ik - w[k] * d1;
+          dvs[dm.off_eta + k] = w[k] * tmpK[k] - w[k] * d2;
+        }
+      }
+      __syncthreads();
+      double fsv = Fs[s];
+      for (int i = tid; i < T; i += nt) {
+        acc1[i] += dvs[i];
+        acc2[i] += fsv * dFs[i];
+        acc3[i] += dFs[i];
+      }
+    }
+    __syncthreads();
+  }
+  // averaging (:399-413)
+  if (tid == 0) {
+    double varF, varss = 0.0;
+    if (S > 1) {
+      double Fbar = 0.0;
+      for (int s = 0; s < S; ++s) Fbar += Fs[s];
+      Fbar /= S;
+      double vss = 0.0, vm = 0.0;
+      for (int s = 0; s < S; ++s) { vss += (Fs[s] - Fbar) * (Fs[s] - Fbar); vm += vFs[s]; }
+      vss /= (S - 1);
+      double mean = vm / S, sd = 0.0;
+      for (int s = 0; s < S; ++s) sd += (vFs[s] - mean) * (vFs[s] - mean);
+      sd = sqrt(sd / (S - 1));        // MATLAB std()
+      varss = vss + sd;               // :404 (variance + std, as in the reference)
+      varF = vm / S + vss;            // :405
+      red[0] = Fbar;
+    } else {
+      varF = vFs[0];
+      red[0] = Fs[0];
+    }
+    o[0] = varF;
+    o[1] = varss;
+  }
+  __syncthreads();
+  if (vgrad) {
+    const double Fbar = red[0];
+    for (int i = tid; i < T; i += nt) {
+      double dv;
+      if (S > 1) {
+        double dvv = 2.0 * acc2[i] / (S - 1) - 2.0 * Fbar * acc3[i] / (S - 1);  // :408
+        dv = acc1[i] / S + dvv;                                                  // :409
+      } else {
+        dv = acc1[i];
+      }
+      o[2 + i] = dv;
+    }
+  }
+}
