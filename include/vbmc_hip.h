@@ -74,6 +74,35 @@ vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Nco
                            const double* L, const double* sW1, const uint8_t* Lchol,
                            vbmc_gp** out);
 void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp);
+/* Noise model needed by vbmc_gp_pred: gp.noisefun (3 ids, gplite_noisefun.m:176-210) and
+ * gp.post(s).sn2_mult (S). */
+vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32_t noisefun[3], const double* sn2_mult);
+
+/*
+ * gp = gplite_post(hyp, X, y, covfun=SE-ARD, meanfun, noisefun, s2)   (gplite/gplite_post.m:1,
+ * gplite/private/gplite_core.m:1-102,278-291; full posterior, no rank-1): per hyper-sample the
+ * ARD-SE kernel matrix via sq_dist, the jittered Cholesky with the reference's x10 noise
+ * inflation retry (<= 10 tries), alpha, and L (upper factor, or -inv(K+sn2 I) when
+ * min(sn2) < 1e-6).  Outputs (any may be NULL): alpha N x S, L N x N x S, sW N x S, sn2_mult S,
+ * Lchol S; *gp_out (optional) receives the device-resident posterior for vbmc_elbo_batch /
+ * vbmc_gp_pred without a second upload.
+ */
+vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
+                         const double* X, const double* y, const double* s2, const double* hyp,
+                         double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
+                         vbmc_gp** gp_out);
+
+/*
+ * [ymu,ys2,fmu,fs2] = gplite_pred(gp, Xstar, [], s2star, ssflag)   (gplite/gplite_pred.m:1-165).
+ * Xstar is Nstar x D.  ssflag = 0: outputs are Nstar vectors averaged over hyper-samples with
+ * the between-sample variance added (:154-165); ssflag = 1: Nstar x S per-sample outputs.
+ */
+vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
+                         int ssflag, double* ymu, double* ys2, double* fmu, double* fs2);
+
+/* C = sq_dist(a, b)   (utils/sq_dist.m:14-50): a is D x n, b is D x m (NULL -> b = a), C is n x m.
+ * The a'b contraction runs on v_mfma_f64_16x16x4_f64. */
+vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const double* a, const double* b, double* C);
 
 /* ---- the ELBO objective ---------------------------------------------------------------
  * One call evaluates R independent negelcbo_vbmc(theta_r, beta, vp, gp, Ns, compute_grad,

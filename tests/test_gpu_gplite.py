@@ -1,0 +1,120 @@
+"""GPU parity: gplite_post / gplite_pred / sq_dist through the C ABI vs the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._cases import golden_cases, load_golden, synth_problem
+from tests.test_gpu_elbo import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 5), (10, 400, 33), (1, 20, 20), (6, 17, 100), (13, 64, 48)])
+def test_sq_dist(va, shape):
+    D, n, m = shape
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((D, n)) + 50.0  # large common offset: exercises the mean-centring
+    b = rng.standard_normal((D, m)) + 50.0
+    assert relerr(va.sq_dist(a, b), R.sq_dist(a, b)) < 1e-12
+    assert relerr(va.sq_dist(a), R.sq_dist(a)) < 1e-12
+    direct = np.sum((a[:, :, None] - b[:, None, :]) ** 2, axis=0)
+    assert relerr(va.sq_dist(a, b), direct) < 1e-10
+    assert np.all(va.sq_dist(a) >= 0)
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_gp_post_pred_golden(va, path):
+    inp, exp = load_golden(path)
+    gp = va.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, inp["meanfun"])
+    for s, post in enumerate(gp["post"]):
+        assert post["Lchol"] and post["sn2_mult"] == 1.0
+        assert relerr(post["alpha"], exp["alpha"][s]) < 1e-9
+        assert relerr(post["L"], exp["L"][s]) < 1e-10
+    ymu, ys2, fmu, fs2 = va.gplite_pred(gp, inp["Xstar"], None, None, True)
+    assert relerr(np.atleast_2d(fmu.T) if fmu.ndim > 1 else fmu[None, :], np.array(exp["pred_fmu"])) < 1e-9
+    assert relerr(np.atleast_2d(fs2.T) if fs2.ndim > 1 else fs2[None, :], np.array(exp["pred_fs2"])) < 1e-9
+
+
+@pytest.mark.parametrize("cfg", [(6, 200, 8, 4, False), (10, 400, 3, 4, False), (3, 37, 2, 1, False), (5, 90, 3, 4, True), (2, 16, 2, 0, False)])
+def test_gp_post_matches_oracle(va, cfg):
+    D, N, S, meanfun, noisy = cfg
+    p = synth_problem(21, D, N, 3, S, meanfun=meanfun, noisy=noisy)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=meanfun, noisefun=p["noisefun"], s2=p["s2"])
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, meanfun, p["noisefun"], p["s2"])
+    for a, b in zip(gp["post"], ref["post"]):
+        assert a["Lchol"] == b["Lchol"] and a["sn2_mult"] == b["sn2_mult"]
+        assert relerr(a["sW"], b["sW"]) < 1e-14
+        assert relerr(a["L"], b["L"]) < 1e-9
+        assert np.allclose(np.tril(a["L"], -1), 0)
+        assert relerr(a["alpha"], b["alpha"]) < 1e-7  # cond(K/sn2 + I) ~ 1e7 at sn2 = 1e-6
+        # backward-error check that does not depend on the oracle: (K + sn2 I) alpha = y - m
+        hyp = a["hyp"]
+        ell = np.exp(hyp[:D])
+        Kmat = math.exp(2 * hyp[D]) * np.exp(-0.5 * R.sq_dist(p["X"].T / ell[:, None]))
+        sn2 = np.broadcast_to(R.gplite_noisefun(hyp[D + 1:D + 2], p["X"], p["noisefun"], p["y"], p["s2"]), (N,)) * a["sn2_mult"]
+        m = R.gplite_meanfun(hyp[D + 2:], p["X"], meanfun)
+        res = (Kmat + np.diag(sn2)) @ a["alpha"] - (p["y"] - m)
+        assert np.max(np.abs(res)) < 1e-6 * max(1.0, np.max(np.abs(p["y"] - m)))
+    Xs = 1.5 * np.random.default_rng(3).standard_normal((70, D))
+    s2s = np.full(70, 0.5) if noisy else None
+    for ss in (True, False):
+        o = va.gplite_pred(gp, Xs, None, s2s, ss)
+        r = R.gplite_pred(ref, Xs, None, s2s, ssflag=ss)
+        for x, z in zip(o, r):
+            assert x.shape == np.asarray(z).shape
+            assert relerr(x, z) < 1e-7
+    assert np.all(va.gplite_pred(gp, Xs, None, s2s, True)[3] >= 0)
+
+
+def test_cholesky_jitter_retry_matches_reference_semantics(va):
+    """Duplicate inputs + small noise: chol fails, sn2_mult is inflated x10 until it works."""
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((12, 2))
+    X = np.vstack([X, X, X])
+    y = rng.standard_normal(36)
+    hyp = np.array([0.0, 0.0, 4.0, math.log(1.05e-3), 0.0, 0.0, 0.0, 0.0, 0.0])[:, None]
+    ref = R.gplite_post(hyp, X, y, meanfun=4)
+    gp = va.gplite_post(hyp, X, y, 1, 4)
+    assert gp["post"][0]["sn2_mult"] == ref["post"][0]["sn2_mult"]
+    assert np.all(np.isfinite(gp["post"][0]["alpha"]))
+    assert relerr(gp["post"][0]["L"], ref["post"][0]["L"]) < 1e-6
+
+
+def test_low_noise_branch(va):
+    """min(sn2) < 1e-6 -> Lchol = false, L = -inv(K + sn2 I) (gplite_core.m:67,84-99)."""
+    p = synth_problem(22, 3, 30, 2, 2)
+    hyp = p["hyp"].copy()
+    hyp[3 + 1, :] = math.log(3e-4)  # sn2 = 9e-8
+    hyp[3, :] -= 1.0
+    ref = R.gplite_post(hyp, p["X"], p["y"], meanfun=4)
+    gp = va.gplite_post(hyp, p["X"], p["y"], 1, 4)
+    for a, b in zip(gp["post"], ref["post"]):
+        assert (not a["Lchol"]) and (not b["Lchol"])
+        assert relerr(a["L"], b["L"]) < 1e-6
+        assert relerr(a["alpha"], b["alpha"]) < 1e-6
+    Xs = p["X"][:9] + 0.05
+    o = va.gplite_pred(gp, Xs, None, None, False)
+    r = R.gplite_pred(ref, Xs)
+    assert relerr(o[2], r[2]) < 1e-6 and np.max(np.abs(o[3] - r[3])) < 1e-6
+
+
+def test_posterior_feeds_elbo_without_reupload(va):
+    """gplite_post's device handle is reused by negelcbo (no host round trip of L)."""
+    p = synth_problem(23, 4, 60, 5, 3)
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 4)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
+    vp = va.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    out = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 0, 1, nargout=11)
+    r = R.negelcbo_vbmc(theta, 0, vp, ref, 0, False, 1, separate_K=True)
+    assert relerr(out[2], r["G"]) < 1e-7 and relerr(out[7], r["varG"]) < 1e-5

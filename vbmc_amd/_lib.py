@@ -86,6 +86,13 @@ def load():
     lib.vbmc_device_free.argtypes = [vp, vp]
     lib.vbmc_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.vbmc_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    i32p = C.POINTER(C.c_int32)
+    u8p = C.POINTER(C.c_uint8)
+    lib.vbmc_gp_set_noise.argtypes = [vp, vp, i32p, _dp]
+    lib.vbmc_gp_post.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, _dp, _dp, _dp, _dp,
+                                 _dp, _dp, _dp, _dp, u8p, C.POINTER(vp)]
+    lib.vbmc_gp_pred.argtypes = [vp, vp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
+    lib.vbmc_sq_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     for name in DECLARED_OPTIONAL:
         if hasattr(lib, name):
             pass
@@ -184,6 +191,17 @@ class DeviceGP:
                                          ptr(alpha), Lp, ptr(sW1), lch.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(h)))
         self.h = h
         self.N, self.D, self.S = N, D, S
+
+    @classmethod
+    def from_handle(cls, ctx, h, N, D, S):
+        self = cls.__new__(cls)
+        self.ctx, self.h, self.N, self.D, self.S = ctx, h, N, D, S
+        return self
+
+    def set_noise(self, noisefun, sn2_mult):
+        nf = (C.c_int32 * 3)(*[int(x) for x in (list(noisefun) + [0, 0, 0])[:3]])
+        m = f64(np.asarray(sn2_mult, dtype=np.float64).reshape(self.S))
+        self.ctx.check(self.ctx.lib.vbmc_gp_set_noise(self.ctx.h, self.h, nf, ptr(m)))
 
     def close(self):
         if getattr(self, "h", None):

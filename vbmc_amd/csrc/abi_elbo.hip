@@ -163,6 +163,15 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
   }
   if (e == hipSuccess) e = up(&gp->d_sn2, gp->sn2_eff.data(), (size_t)S);
   if (e == hipSuccess) {
+    std::vector<double> mx(D);
+    for (int d = 0; d < D; ++d) {
+      double acc = 0.0;
+      for (int n = 0; n < N; ++n) acc += X[n + (size_t)N * d];
+      mx[d] = acc / N;
+    }
+    e = up(&gp->d_meanX, mx.data(), (size_t)D);
+  }
+  if (e == hipSuccess) {
     e = hipMalloc((void**)&gp->d_lchol, (size_t)S);
     if (e == hipSuccess) e = hipMemcpy(gp->d_lchol, gp->Lchol.data(), (size_t)S, hipMemcpyHostToDevice);
   }
@@ -184,6 +193,8 @@ extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
   if (gp->hyp) (void)hipFree(gp->hyp);
   if (gp->d_sn2) (void)hipFree(gp->d_sn2);
   if (gp->d_lchol) (void)hipFree(gp->d_lchol);
+  if (gp->d_mult) (void)hipFree(gp->d_mult);
+  if (gp->d_meanX) (void)hipFree(gp->d_meanX);
   delete gp;
 }
 

@@ -1,0 +1,307 @@
+// C-ABI entry points for the gplite GP surrogate: vbmc_sq_dist, vbmc_gp_post, vbmc_gp_pred
+// (include/vbmc_hip.h).  Host side: O(N) hyper-parameter transforms, the Cholesky jitter-retry
+// loop (gplite_core.m:77-80,91-94), launches, D2H of the posterior.
+#include <algorithm>
+#include <cmath>
+
+#include "gp_kernels.h"
+
+namespace {
+
+struct TmpBuf {
+  void* p = nullptr;
+  ~TmpBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+// gplite_noisefun.m:176-210 on the host (O(N)): returns per-point sn2 (length N)
+void noise_vector(const int32_t nf[3], const double* hn, int N, const double* y, const double* s2, std::vector<double>& sn2) {
+  int idx = 0;
+  double base;
+  if (nf[0] == 0) base = 2.220446049250313e-16;
+  else { base = std::exp(2.0 * hn[idx]); idx++; }
+  sn2.assign(N, base);
+  if (nf[1] == 1 && s2) { for (int n = 0; n < N; ++n) sn2[n] += s2[n]; }
+  else if (nf[1] == 2 && s2) { double c = std::exp(hn[idx]); for (int n = 0; n < N; ++n) sn2[n] += c * s2[n]; idx++; }
+  else if (nf[1] == 2) idx++;
+  if (nf[2] == 1) {
+    if (y) {
+      double ythr = hn[idx], w2 = std::exp(2.0 * hn[idx + 1]);
+      for (int n = 0; n < N; ++n) { double zz = std::max(0.0, ythr - y[n]); sn2[n] += w2 * zz * zz; }
+    }
+  }
+}
+
+int noise_nhyp(const int32_t nf[3]) { return (nf[0] == 1) + (nf[1] == 2) + 2 * (nf[2] == 1); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const double* a, const double* b, double* C) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (D <= 0 || n <= 0 || !a || !C) return set_err(ctx, VBMC_ERR_INVALID, "sq_dist: Wrong number of arguments.");
+  const bool self = (b == nullptr);
+  if (self) { b = a; m = n; }
+  if (m <= 0) return set_err(ctx, VBMC_ERR_INVALID, "sq_dist: empty b");
+  // mean used for stabilisation (sq_dist.m:26,36), computed in MATLAB's order on the host: O(D(n+m))
+  std::vector<double> mu(D);
+  for (int d = 0; d < D; ++d) {
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < n; ++i) sa += a[d + (size_t)D * i];
+    if (self) mu[d] = sa / n;
+    else {
+      for (int j = 0; j < m; ++j) sb += b[d + (size_t)D * j];
+      mu[d] = ((double)m / (n + m)) * (sb / m) + ((double)n / (n + m)) * (sa / n);
+    }
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  TmpBuf da, db, dmu, dC;
+  HIP_TRY(ctx, da.alloc((size_t)D * n * 8));
+  HIP_TRY(ctx, dmu.alloc((size_t)D * 8));
+  HIP_TRY(ctx, dC.alloc((size_t)n * m * 8));
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemcpyAsync(da.p, a, (size_t)D * n * 8, hipMemcpyHostToDevice, st));
+  const double* dbp = da.as<double>();
+  if (!self) {
+    HIP_TRY(ctx, db.alloc((size_t)D * m * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(db.p, b, (size_t)D * m * 8, hipMemcpyHostToDevice, st));
+    dbp = db.as<double>();
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(dmu.p, mu.data(), (size_t)D * 8, hipMemcpyHostToDevice, st));
+  dim3 grid(((n + 15) / 16 + 3) / 4, (m + 15) / 16);
+  hipLaunchKernelGGL(k_sq_dist_mfma, grid, dim3(256), 0, st, D, n, m, da.as<double>(), dbp, dmu.as<double>(), dC.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(C, dC.p, (size_t)n * m * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
+                                    const double* X, const double* y, const double* s2, const double* hyp,
+                                    double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
+                                    vbmc_gp** gp_out) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (gp_out) *gp_out = nullptr;
+  if (N <= 0 || D <= 0 || S <= 0 || !X || !y || !hyp || !noisefun)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_post: bad arguments");
+  if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
+  if (!(meanfun == 0 || meanfun == 1 || meanfun == 4))
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "gplite mean function %d not accelerated (0,1,4 are)", meanfun);
+  const int Ncov = D + 1, Nnoise = noise_nhyp(noisefun);
+  const int Nmean = meanfun == 0 ? 0 : (meanfun == 1 ? 1 : 2 * D + 1);
+  if (Nhyp != Ncov + Nnoise + Nmean)
+    return set_err(ctx, VBMC_ERR_INVALID, "gplite_post:dimmismatch Number of hyperparameters mismatched with GP model specification.");
+  if ((size_t)(16 * 17 + 16 * (size_t)N) * 8 > 160 * 1024)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 1260 not accelerated", N);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  // host: noise vectors, Lchol flags (gplite_core.m:33-40,67)
+  std::vector<double> sn2all((size_t)S * N), scal((size_t)S * 4), sn2min(S);
+  std::vector<unsigned char> lch(S), active(S, 1), ones(S, 1), needinv(S);
+  std::vector<double> tmp;
+  bool any_inv = false;
+  for (int s = 0; s < S; ++s) {
+    noise_vector(noisefun, hyp + (size_t)s * Nhyp + Ncov, N, y, s2, tmp);
+    std::copy(tmp.begin(), tmp.end(), sn2all.begin() + (size_t)s * N);
+    double mn = *std::min_element(tmp.begin(), tmp.end());
+    sn2min[s] = mn;
+    lch[s] = mn >= 1e-6 ? 1 : 0;
+    needinv[s] = lch[s] ? 0 : 1;
+    any_inv |= !lch[s];
+    scal[s * 4 + 0] = lch[s] ? mn : 1.0;  // sn2div
+    scal[s * 4 + 1] = 1.0;                // sn2_mult
+    scal[s * 4 + 2] = lch[s];
+    scal[s * 4 + 3] = 1.0;                // sl (set after the retry loop)
+  }
+  TmpBuf dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dones, dZ, dXi, dninv;
+  HIP_TRY(ctx, dX.alloc((size_t)N * D * 8));
+  HIP_TRY(ctx, dy.alloc((size_t)N * 8));
+  HIP_TRY(ctx, dhyp.alloc((size_t)Nhyp * S * 8));
+  HIP_TRY(ctx, dXc.alloc((size_t)S * N * D * 8));
+  HIP_TRY(ctx, daa.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dsn2.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dscal.alloc((size_t)S * 4 * 8));
+  HIP_TRY(ctx, dact.alloc(S));
+  HIP_TRY(ctx, dones.alloc(S));
+  HIP_TRY(ctx, dninv.alloc(S));
+  HIP_TRY(ctx, dA.alloc((size_t)S * N * N * 8));
+  HIP_TRY(ctx, dpf.alloc((size_t)S * sizeof(int)));
+  HIP_TRY(ctx, dr.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(dX.p, X, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dy.p, y, (size_t)N * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dhyp.p, hyp, (size_t)Nhyp * S * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dsn2.p, sn2all.data(), (size_t)S * N * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dones.p, ones.data(), S, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dninv.p, needinv.data(), S, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>());
+
+  // jittered Cholesky: up to 10 tries, noise multiplier x10 per failure (gplite_core.m:77-80,91-94)
+  const size_t chol_lds = (size_t)(16 * 17 + 16 * (size_t)N) * 8;
+  if (chol_lds > 64 * 1024)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
+  std::vector<int> pf(S);
+  bool pending = true;
+  for (int iter = 0; iter < 10 && pending; ++iter) {
+    HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dact.p, active.data(), S, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gp_build, dim3(64, S), dim3(256), 0, st, N, D, Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
+                       dsn2.as<double>(), dscal.as<double>(), dact.as<unsigned char>(), dA.as<double>());
+    hipLaunchKernelGGL(k_chol, dim3(S), dim3(256), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(pf.data(), dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    pending = false;
+    for (int s = 0; s < S; ++s) {
+      if (!active[s]) continue;
+      if (pf[s] > 0) { scal[s * 4 + 1] *= 10.0; pending = true; }  // sn2_mult = sn2_mult*10
+      else active[s] = 0;
+    }
+  }
+  if (pending) {
+    // MATLAB leaves the loop with the last multiplier even when chol still fails; we refuse instead.
+    return set_err(ctx, VBMC_ERR_NOT_POSDEF, "gplite_core: Cholesky failed after 10 noise-inflation retries");
+  }
+  for (int s = 0; s < S; ++s) scal[s * 4 + 3] = lch[s] ? scal[s * 4 + 0] * scal[s * 4 + 1] : 1.0;  // sl (:82,:96)
+  HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
+
+  // alpha = L\(L'\(y-m)) / sl  (:102)
+  const int moff = Ncov + Nnoise;
+  hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
+                     dhyp.as<double>(), dr.as<double>());
+  const size_t tlds = ((size_t)N * 16 + 256) * 8;
+  if (tlds > 64 * 1024) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+  }
+  TmpBuf dal;
+  HIP_TRY(ctx, dal.alloc((size_t)S * N * 8));
+  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, dA.as<double>(), dones.as<unsigned char>(), dr.as<double>());
+  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, dA.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
+  hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, st, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+
+  std::vector<double> Lh;
+  if (L || gp_out) Lh.resize((size_t)S * N * N);
+  std::vector<double> alh((size_t)S * N);
+  HIP_TRY(ctx, hipMemcpyAsync(alh.data(), dal.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
+  if (!Lh.empty()) {
+    if (any_inv) {
+      // pL = -L\(L'\eye(N)) for low-noise samples (:98)
+      HIP_TRY(ctx, dZ.alloc((size_t)S * N * N * 8));
+      HIP_TRY(ctx, dXi.alloc((size_t)S * N * N * 8));
+      hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, dZ.as<double>());
+      dim3 tg((N + TR_CB - 1) / TR_CB, S, 1);
+      hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(256), tlds, st, N, N, S, dA.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
+      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(256), tlds, st, N, N, S, dA.as<double>(), dninv.as<unsigned char>(), dZ.as<double>(), dXi.as<double>());
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      for (int s = 0; s < S; ++s) {
+        if (lch[s]) HIP_TRY(ctx, hipMemcpyAsync(Lh.data() + (size_t)s * N * N, dA.as<double>() + (size_t)s * N * N, (size_t)N * N * 8, hipMemcpyDeviceToHost, st));
+        else HIP_TRY(ctx, hipMemcpyAsync(Lh.data() + (size_t)s * N * N, dXi.as<double>() + (size_t)s * N * N, (size_t)N * N * 8, hipMemcpyDeviceToHost, st));
+      }
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(Lh.data(), dA.p, (size_t)S * N * N * 8, hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (any_inv && !Lh.empty())
+    for (int s = 0; s < S; ++s)
+      if (!lch[s]) for (size_t i = 0; i < (size_t)N * N; ++i) Lh[(size_t)s * N * N + i] = -Lh[(size_t)s * N * N + i];
+
+  std::vector<double> sW1(S), mult(S);
+  for (int s = 0; s < S; ++s) {
+    mult[s] = scal[s * 4 + 1];
+    sW1[s] = 1.0 / std::sqrt(sn2min[s] * mult[s]);  // post.sW = ones(N,1)./sqrt(min(sn2)*sn2_mult)  (:281)
+  }
+  if (alpha) memcpy(alpha, alh.data(), (size_t)S * N * 8);
+  if (L) memcpy(L, Lh.data(), (size_t)S * N * N * 8);
+  if (sW) for (int s = 0; s < S; ++s) for (int n = 0; n < N; ++n) sW[(size_t)s * N + n] = sW1[s];
+  if (sn2_mult) memcpy(sn2_mult, mult.data(), S * 8);
+  if (Lchol) memcpy(Lchol, lch.data(), S);
+  if (gp_out) {
+    vbmc_status st2 = vbmc_gp_upload(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alh.data(), Lh.data(), sW1.data(), lch.data(), gp_out);
+    if (st2 != VBMC_OK) return st2;
+    st2 = vbmc_gp_set_noise(ctx, *gp_out, noisefun, mult.data());
+    if (st2 != VBMC_OK) return st2;
+  }
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32_t noisefun[3], const double* sn2_mult) {
+  if (!ctx || !gp || !noisefun || !sn2_mult) return VBMC_ERR_INVALID;
+  for (int i = 0; i < 3; ++i) gp->noisefun[i] = noisefun[i];
+  if (!gp->d_mult) HIP_TRY(ctx, hipMalloc((void**)&gp->d_mult, (size_t)gp->S * 8));
+  HIP_TRY(ctx, hipMemcpy(gp->d_mult, sn2_mult, (size_t)gp->S * 8, hipMemcpyHostToDevice));
+  gp->has_noise = true;
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
+                                    int ssflag, double* ymu, double* ys2, double* fmu, double* fs2) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp || Nstar <= 0 || !Xstar) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_pred: bad arguments");
+  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_pred needs gp.post(s).L on the device");
+  if (!gp->has_noise) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_pred: call vbmc_gp_set_noise (noisefun, sn2_mult) first");
+  if (gp->noisefun[2] == 1)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "output-dependent noise (noisefun(3) = 1) at test points not accelerated");
+  if ((gp->noisefun[1] == 1 || gp->noisefun[1] == 2) && !s2star)
+    return set_err(ctx, VBMC_ERR_INVALID, "gplite_pred: S2STAR is required by the noise function");
+  const int N = gp->N, D = gp->D, S = gp->S;
+  const size_t plds = ((size_t)N * 16 + 256 + 256 + 16 * 32 + 64) * 8;
+  if (plds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // column means for sq_dist's centring (sq_dist.m:36), O((N + Nstar) D) on the host in MATLAB's order
+  std::vector<double> mb(D);
+  for (int d = 0; d < D; ++d) {
+    double sb = 0.0;
+    for (int j = 0; j < Nstar; ++j) sb += Xstar[j + (size_t)Nstar * d];
+    mb[d] = sb / Nstar;
+  }
+  TmpBuf dXs, ds2, dmb, dout, davg;
+  HIP_TRY(ctx, dXs.alloc((size_t)Nstar * D * 8));
+  HIP_TRY(ctx, dmb.alloc((size_t)D * 8));
+  HIP_TRY(ctx, dout.alloc((size_t)3 * Nstar * S * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(dXs.p, Xstar, (size_t)Nstar * D * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dmb.p, mb.data(), (size_t)D * 8, hipMemcpyHostToDevice, st));
+  if (s2star) {
+    HIP_TRY(ctx, ds2.alloc((size_t)Nstar * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ds2.p, s2star, (size_t)Nstar * 8, hipMemcpyHostToDevice, st));
+  }
+  PredArgs pa{};
+  pa.N = N; pa.D = D; pa.S = S; pa.Nhyp = gp->Nhyp; pa.Nstar = Nstar; pa.meanfun = gp->meanfun;
+  pa.moff = gp->Ncov + gp->Nnoise; pa.noff = gp->Ncov; pa.nf0 = gp->noisefun[0]; pa.nf1 = gp->noisefun[1];
+  pa.X = gp->X; pa.Xs = dXs.as<double>(); pa.s2s = s2star ? ds2.as<double>() : nullptr; pa.hyp = gp->hyp;
+  pa.alpha = gp->alpha; pa.L = gp->L; pa.sn2_eff = gp->d_sn2; pa.sn2_mult = gp->d_mult; pa.lchol = gp->d_lchol;
+  pa.mean_a = gp->d_meanX; pa.mean_b = dmb.as<double>();
+  pa.fmu = dout.as<double>(); pa.fs2 = pa.fmu + (size_t)Nstar * S; pa.ys2 = pa.fs2 + (size_t)Nstar * S;
+  if (plds > 64 * 1024)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+  hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(256), plds, st, pa);
+  HIP_TRY(ctx, hipGetLastError());
+  const size_t ns = (size_t)Nstar * S;
+  if (S > 1 && !ssflag) {
+    HIP_TRY(ctx, davg.alloc((size_t)4 * Nstar * 8));
+    hipLaunchKernelGGL(k_pred_avg, dim3((Nstar + 255) / 256), dim3(256), 0, st, Nstar, S, pa.fmu, pa.fs2, pa.ys2, davg.as<double>());
+    std::vector<double> h((size_t)4 * Nstar);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), davg.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ymu) memcpy(ymu, h.data(), (size_t)Nstar * 8);
+    if (ys2) memcpy(ys2, h.data() + Nstar, (size_t)Nstar * 8);
+    if (fmu) memcpy(fmu, h.data() + 2 * (size_t)Nstar, (size_t)Nstar * 8);
+    if (fs2) memcpy(fs2, h.data() + 3 * (size_t)Nstar, (size_t)Nstar * 8);
+  } else {
+    std::vector<double> h(3 * ns);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), dout.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (fmu) memcpy(fmu, h.data(), ns * 8);
+    if (ymu) memcpy(ymu, h.data(), ns * 8);
+    if (fs2) memcpy(fs2, h.data() + ns, ns * 8);
+    if (ys2) memcpy(ys2, h.data() + 2 * ns, ns * 8);
+  }
+  return VBMC_OK;
+}

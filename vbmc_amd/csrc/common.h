@@ -42,6 +42,10 @@ struct vbmc_gp {
   double* hyp = nullptr;    // Nhyp x S
   double* d_sn2 = nullptr;  // S  sn2_eff
   unsigned char* d_lchol = nullptr;  // S
+  double* d_mult = nullptr;   // S  sn2_mult (prediction)
+  double* d_meanX = nullptr;  // D  column means of X (sq_dist centring in gplite_pred)
+  int noisefun[3] = {1, 0, 0};
+  bool has_noise = false;
   std::vector<double> sn2_eff;
   std::vector<uint8_t> Lchol;
   std::vector<double> hyp_host;

@@ -1,0 +1,413 @@
+// gplite GP surrogate on gfx950: SE-ARD kernel matrix (sq_dist), jittered Cholesky posterior,
+// predictive mean / variance.
+//
+// Reference: utils/sq_dist.m:14-50, gplite/private/gplite_core.m:33-102,278-291,
+// gplite/gplite_post.m:167-251, gplite/gplite_pred.m:52-165, gplite/gplite_meanfun.m:400-436,
+// gplite/gplite_noisefun.m:176-210.
+//
+//   k_sq_dist_mfma  C = max(|a|^2 + |b|^2 - 2 a'b, 0), the a'b contraction on v_mfma_f64_16x16x4_f64
+//   k_gp_build      A_s = K/(sn2div*mult) + diag(sn2/sn2div)   (Lchol)   or  K + mult*diag(sn2)
+//   k_chol          in-place blocked (16) right-looking Cholesky, upper factor, one WG per sample,
+//                   reports MATLAB's p (> 0 = not positive definite) for the jitter retry
+//   k_gp_resid      r = y - m(X)
+//   k_gp_pred       fused: cross-kernel tile -> fmu = m* + Ks'alpha, V = L'\(sW.*Ks), fs2 = kss - |V|^2
+//   k_pred_avg      hyper-sample averaging with between-sample variance (gplite_pred.m:154-165)
+#pragma once
+#include "common.h"
+#include "device_math.h"
+#include "var_kernels.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// sq_dist on MFMA.  a: D x n, b: D x m (column-major, already mean-centred by the caller kernel
+// through `mu`), C: n x m.  One wave computes a 16(i) x 16(j) tile as the TRANSPOSED product
+// (rows = j from b, cols = i from a) so that the four accumulator registers of a lane are four
+// consecutive-j rows of ONE column i... stores of a fixed register are 16 consecutive i (128 B).
+// A operand: lane l holds b[d = 4q + (l>>4)][j0 + (l&15)];  B operand: a[d = 4q + (l>>4)][i0 + (l&15)].
+// C/D layout of v_mfma_f64_16x16x4_f64: col = l&15, row = (l>>4) + 4*reg.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sq_dist_mfma(int D, int n, int m, const double* __restrict__ a,
+                                                      const double* __restrict__ b, const double* __restrict__ mu,
+                                                      double* __restrict__ C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ti = blockIdx.x * 4 + wv;     // tile along i (a)
+  const int tj = blockIdx.y;              // tile along j (b)
+  const int i0 = ti * 16, j0 = tj * 16;
+  if (i0 >= n) return;
+  const int li = lane & 15, lq = lane >> 4;
+  const int ia = i0 + li, jb = j0 + li;
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double aa = 0.0, bb = 0.0;  // partial |a_i|^2 (for i = ia) and |b_j|^2 (j = jb) over this lane's d's
+  for (int q = 0; q < (D + 3) / 4; ++q) {
+    const int d = 4 * q + lq;
+    double av = 0.0, bv = 0.0;
+    if (d < D) {
+      if (ia < n) av = a[d + (size_t)D * ia] - mu[d];
+      if (jb < m) bv = b[d + (size_t)D * jb] - mu[d];
+    }
+    aa = fma(av, av, aa);
+    bb = fma(bv, bv, bb);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);
+  }
+  // complete the squared norms across the 4 lanes sharing (l&15)
+  aa += __shfl_xor(aa, 16, 64); aa += __shfl_xor(aa, 32, 64);
+  bb += __shfl_xor(bb, 16, 64); bb += __shfl_xor(bb, 32, 64);
+  // lane holds column i = ia, rows j = j0 + lq + 4*reg ; needs bb of those j (held by lanes with l&15 == lq+4reg)
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int jr = lq + 4 * reg;
+    const double bbj = __shfl(bb, jr, 64);
+    const int j = j0 + jr;
+    if (ia < n && j < m) {
+      double c = aa + (bbj - 2.0 * acc[reg]);   // sq_dist.m:45  sum(a.*a)' + (sum(b.*b) - 2*a'*b)
+      C[ia + (size_t)n * j] = fmax(c, 0.0);     // :49
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// device mean function (ids 0, 1, 4) at a point x (strided access), hyp_mean points at the block
+// ------------------------------------------------------------------------------------------
+__device__ inline double gp_meanfun(int meanfun, int D, const double* hm, const double* x, size_t stride) {
+  if (meanfun == 0) return 0.0;
+  if (meanfun == 1) return hm[0];
+  double z2 = 0.0;
+  for (int d = 0; d < D; ++d) {
+    double t = (x[d * stride] - hm[1 + d]) / exp(hm[D + 1 + d]);
+    z2 = fma(t, t, z2);
+  }
+  return hm[0] - 0.5 * z2;  // gplite_meanfun.m:425-431
+}
+
+// A_s for the Cholesky.  Xc[s] holds the scaled, mean-centred inputs a = (X' ./ ell) - mean  (D x N),
+// aa[s][n] = |a_n|^2.  K = sf2 * exp(-max(aa_i + aa_j - 2 a_i.a_j, 0)/2)   (gplite_core.m:52-56)
+__global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const double* __restrict__ X,
+                                                  const double* __restrict__ hyp, double* __restrict__ Xc,
+                                                  double* __restrict__ aa) {
+  const int s = blockIdx.y;
+  const double* h = hyp + (size_t)s * Nhyp;
+  __shared__ double mean[32];
+  const int tid = threadIdx.x;
+  if (tid < D) {
+    // mean over n of X(n,d)/ell_d in MATLAB's order: mean(a,2)
+    double ell = exp(h[tid]);
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) acc += X[n + (size_t)N * tid] / ell;
+    mean[tid] = acc / N;
+  }
+  __syncthreads();
+  for (int n = blockIdx.x * blockDim.x + tid; n < N; n += gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double v = X[n + (size_t)N * d] / exp(h[d]) - mean[d];
+      Xc[((size_t)s * N + n) * D + d] = v;
+      acc = fma(v, v, acc);
+    }
+    aa[(size_t)s * N + n] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const double* __restrict__ hyp,
+                                                  const double* __restrict__ Xc, const double* __restrict__ aa,
+                                                  const double* __restrict__ sn2,      // S x N  noise variance per point
+                                                  const double* __restrict__ scal,     // S x 4: sn2div, mult, lchol, _
+                                                  const unsigned char* __restrict__ active, double* __restrict__ A) {
+  const int s = blockIdx.y;
+  if (!active[s]) return;
+  const double* h = hyp + (size_t)s * Nhyp;
+  const double sf2 = exp(2.0 * h[D]);
+  const double sn2div = scal[s * 4 + 0], mult = scal[s * 4 + 1];
+  const bool lchol = scal[s * 4 + 2] != 0.0;
+  const double* xs = Xc + (size_t)s * N * D;
+  const double* as = aa + (size_t)s * N;
+  double* As = A + (size_t)s * N * N;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)N * N; idx += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(idx % N), j = (int)(idx / N);
+    double dot = 0.0;
+    for (int d = 0; d < D; ++d) dot = fma(xs[(size_t)i * D + d], xs[(size_t)j * D + d], dot);
+    double c = fmax(as[i] + (as[j] - 2.0 * dot), 0.0);
+    double k = sf2 * exp(-c / 2.0);
+    double v;
+    if (lchol) v = k / (sn2div * mult) + (i == j ? sn2[(size_t)s * N + i] / sn2div : 0.0);  // :78
+    else v = k + (i == j ? mult * sn2[(size_t)s * N + i] : 0.0);                            // :92
+    As[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky, upper factor R (R'R = A) in place, strict lower part zeroed.
+// pfail[s] = 0 on success, j+1 when the j-th pivot is not positive (MATLAB's [R,p] = chol(A)).
+// ------------------------------------------------------------------------------------------
+#define CH_NB 16
+__global__ void __launch_bounds__(256) k_chol(int N, double* __restrict__ Aall, int* __restrict__ pfail,
+                                              const unsigned char* __restrict__ active) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x;
+  if (!active[s]) return;
+  const int tid = threadIdx.x;
+  double* A = Aall + (size_t)s * N * N;
+  double* Dg = lds;                 // 16 x 17
+  double* P = Dg + 16 * 17;         // 16 x N  panel rows R[kb+t][*]
+  __shared__ int s_fail;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  const int ii = tid >> 4, jj = tid & 15;
+  for (int kb = 0; kb < N; kb += CH_NB) {
+    const int nb = min(CH_NB, N - kb);
+    Dg[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] : 0.0;
+    __syncthreads();
+    for (int t = 0; t < nb; ++t) {
+      if (tid == 0) {
+        double piv = Dg[t * 17 + t];
+        if (!(piv > 0.0) || !isfinite(piv)) { if (s_fail == 0) s_fail = kb + t + 1; Dg[t * 17 + t] = 1.0; }
+        else Dg[t * 17 + t] = sqrt(piv);
+      }
+      __syncthreads();
+      if (ii == t && jj > t && jj < nb) Dg[t * 17 + jj] /= Dg[t * 17 + t];
+      __syncthreads();
+      if (ii > t && jj >= ii && jj < nb) Dg[ii * 17 + jj] -= Dg[t * 17 + ii] * Dg[t * 17 + jj];
+      __syncthreads();
+    }
+    if (s_fail) break;  // uniform: s_fail read after a barrier
+    if (ii < nb && jj < nb) A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] = (ii <= jj) ? Dg[ii * 17 + jj] : 0.0;
+    const int t0 = kb + nb;       // first trailing column
+    const int ntr = N - t0;
+    // panel: R[kb..kb+nb, j] = Rkk'^{-1} A[kb..kb+nb, j]
+    for (int j = tid; j < ntr; j += 256) {
+      double r[CH_NB];
+#pragma unroll
+      for (int t = 0; t < CH_NB; ++t) {
+        if (t < nb) {
+          double v = A[(size_t)(kb + t) + (size_t)N * (t0 + j)];
+          for (int u = 0; u < t; ++u) v = fma(-Dg[u * 17 + t], r[u], v);
+          r[t] = v / Dg[t * 17 + t];
+          A[(size_t)(kb + t) + (size_t)N * (t0 + j)] = r[t];
+          P[(size_t)t * ntr + j] = r[t];
+        } else r[t] = 0.0;
+      }
+    }
+    __syncthreads();
+    // trailing update A[i][j] -= sum_t P[t][i] P[t][j]  for i <= j, 4 x 4 register tiles
+    const int ntile = (ntr + 3) / 4;
+    for (int tl = tid; tl < ntile * ntile; tl += 256) {
+      const int ti = tl % ntile, tj = tl / ntile;
+      if (ti > tj) continue;
+      const int i0 = ti * 4, j0 = tj * 4;
+      double c[4][4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
+      for (int t = 0; t < nb; ++t) {
+        double pi[4], pj[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          pi[x] = (i0 + x < ntr) ? P[(size_t)t * ntr + i0 + x] : 0.0;
+          pj[x] = (j0 + x < ntr) ? P[(size_t)t * ntr + j0 + x] : 0.0;
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) c[x][y] = fma(pi[x], pj[y], c[x][y]);
+      }
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int i = i0 + x, j = j0 + y;
+          if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] -= c[x][y];
+        }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) pfail[s] = s_fail;
+  if (s_fail) return;
+  // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
+  for (size_t idx = tid; idx < (size_t)N * N; idx += 256) {
+    int i = (int)(idx % N), j = (int)(idx / N);
+    if (i > j) A[idx] = 0.0;
+  }
+}
+
+// r = y - m(X)  per sample
+__global__ void __launch_bounds__(256) k_gp_resid(int N, int D, int Nhyp, int moff, int meanfun,
+                                                  const double* __restrict__ X, const double* __restrict__ y,
+                                                  const double* __restrict__ hyp, double* __restrict__ rout) {
+  const int s = blockIdx.y;
+  const double* hm = hyp + (size_t)s * Nhyp + moff;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
+    rout[(size_t)s * N + n] = y[n] - gp_meanfun(meanfun, D, hm, X + n, (size_t)N);
+}
+
+__global__ void k_scale_vec(size_t n, int per, const double* __restrict__ scal, int scol, double* __restrict__ v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = v[i] / scal[(i / per) * 4 + scol];
+}
+
+__global__ void k_set_identity(int N, int S, double* __restrict__ Z) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)S * N * N) {
+    size_t e = i % ((size_t)N * N);
+    Z[i] = (e % N == e / N) ? 1.0 : 0.0;
+  }
+}
+
+__global__ void k_negate_copy(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = -src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Prediction: one workgroup = 16 test points x one hyper-sample.
+// ------------------------------------------------------------------------------------------
+struct PredArgs {
+  int N, D, S, Nhyp, Nstar, meanfun, moff, noff, nf0, nf1;
+  const double* X;       // N x D
+  const double* Xs;      // Nstar x D (column-major)
+  const double* s2s;     // Nstar or null
+  const double* hyp;     // Nhyp x S
+  const double* alpha;   // N x S
+  const double* L;       // N x N x S
+  const double* sn2_eff; // S  (1/sW^2)
+  const double* sn2_mult;// S
+  const unsigned char* lchol;
+  const double* mean_a;  // D  column means of X
+  const double* mean_b;  // D  column means of Xstar
+  double* fmu;           // Nstar x S
+  double* fs2;
+  double* ys2;
+};
+
+__global__ void __launch_bounds__(256) k_gp_pred(PredArgs a) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y;
+  const int tid = threadIdx.x, c = tid & 15, ri = tid >> 4;
+  const int N = a.N, D = a.D;
+  const int jc = cb * 16 + c;
+  const bool cv = jc < a.Nstar;
+  const double* h = a.hyp + (size_t)s * a.Nhyp;
+  double* V = lds;                   // N x 16
+  double* Rd = V + (size_t)N * 16;   // 256
+  double* red = Rd + 256;            // 256
+  double* xs = red + 256;            // 16 x D scaled centred test points
+  double* muv = xs + 16 * 32;        // D
+  double* ellv = muv + 32;           // D
+  const double sf2 = exp(2.0 * h[D]);
+  if (tid < D) {
+    ellv[tid] = exp(h[tid]);
+    // sq_dist(a,b) centring: mu = (m/(n+m)) mean(b) + (n/(n+m)) mean(a), on the ell-scaled inputs (sq_dist.m:36)
+    double ell = exp(h[tid]);
+    double n = (double)N, m = (double)a.Nstar;
+    muv[tid] = (m / (n + m)) * (a.mean_b[tid] / ell) + (n / (n + m)) * (a.mean_a[tid] / ell);
+  }
+  __syncthreads();
+  if (ri == 0) {
+    for (int d = 0; d < D; ++d) xs[c * 32 + d] = cv ? a.Xs[jc + (size_t)a.Nstar * d] / ellv[d] - muv[d] : 0.0;
+  }
+  __syncthreads();
+  double bb = 0.0;
+  for (int d = 0; d < D; ++d) bb = fma(xs[c * 32 + d], xs[c * 32 + d], bb);
+  const double* al = a.alpha + (size_t)s * N;
+  double fm = 0.0;
+  for (int i = ri; i < N; i += 16) {
+    double aa = 0.0, dot = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double av = a.X[i + (size_t)N * d] / ellv[d] - muv[d];
+      aa = fma(av, av, aa);
+      dot = fma(av, xs[c * 32 + d], dot);
+    }
+    double cdist = fmax(aa + (bb - 2.0 * dot), 0.0);
+    double ks = sf2 * exp(-cdist / 2.0);   // gplite_pred.m:73-74
+    V[i * 16 + c] = ks;
+    fm = fma(ks, al[i], fm);
+  }
+  red[tid] = fm;
+  __syncthreads();
+  double fmu = 0.0;
+  if (ri == 0) {
+    for (int q = 0; q < 16; ++q) fmu += red[q * 16 + c];
+    const double* hm = h + a.moff;
+    double mstar = 0.0;
+    if (cv) mstar = gp_meanfun(a.meanfun, D, hm, a.Xs + jc, (size_t)a.Nstar);
+    fmu += mstar;  // :83
+  }
+  __syncthreads();
+  double fs2;
+  const double* Rm = a.L + (size_t)s * N * N;
+  if (a.lchol[s]) {
+    const double sW = 1.0 / sqrt(a.sn2_eff[s]);
+    for (int i = ri; i < N; i += 16) V[i * 16 + c] *= sW;  // sW .* Ks  (:99)
+    __syncthreads();
+    for (int b0 = 0; b0 < N; b0 += TR_B) {
+      const int nb = min(TR_B, N - b0);
+      double acc = 0.0;
+      if (ri < nb) {
+        const double* col = Rm + (size_t)(b0 + ri) * N;
+        for (int j = 0; j < b0; ++j) acc = fma(col[j], V[j * 16 + c], acc);
+      }
+      {
+        int jj = tid >> 4, ii = tid & 15;
+        Rd[jj * 16 + ii] = (jj < nb && ii < nb) ? Rm[(size_t)(b0 + ii) * N + b0 + jj] : 0.0;
+      }
+      __syncthreads();
+      if (ri < nb) V[(b0 + ri) * 16 + c] -= acc;
+      __syncthreads();
+      if (ri == 0) {
+        for (int ii = 0; ii < nb; ++ii) {
+          double t = V[(b0 + ii) * 16 + c];
+          for (int jj = 0; jj < ii; ++jj) t = fma(-Rd[jj * 16 + ii], V[(b0 + jj) * 16 + c], t);
+          V[(b0 + ii) * 16 + c] = t / Rd[ii * 16 + ii];
+        }
+      }
+      __syncthreads();
+    }
+    double part = 0.0;
+    for (int i = ri; i < N; i += 16) part = fma(V[i * 16 + c], V[i * 16 + c], part);
+    red[tid] = part;
+    __syncthreads();
+    double vv = 0.0;
+    if (ri == 0) for (int q = 0; q < 16; ++q) vv += red[q * 16 + c];
+    fs2 = sf2 - vv;  // kss - sum(V.*V)  (:100)
+  } else {
+    // fs2 = kss + sum(Ks .* (L*Ks))  (:103-104)
+    double part = 0.0;
+    for (int i = ri; i < N; i += 16) {
+      double lk = 0.0;
+      for (int j = 0; j < N; ++j) lk = fma(Rm[(size_t)j * N + i], V[j * 16 + c], lk);
+      part = fma(V[i * 16 + c], lk, part);
+    }
+    red[tid] = part;
+    __syncthreads();
+    double vv = 0.0;
+    if (ri == 0) for (int q = 0; q < 16; ++q) vv += red[q * 16 + c];
+    fs2 = sf2 + vv;
+  }
+  if (ri == 0 && cv) {
+    fs2 = fmax(fs2, 0.0);  // :120
+    // noise at the test points (gplite_noisefun.m:176-194; output-dependent term needs ystar: not here)
+    double sn2s = a.nf0 ? exp(2.0 * h[a.noff]) : 2.220446049250313e-16;
+    if (a.nf1 == 1 && a.s2s) sn2s += a.s2s[jc];
+    else if (a.nf1 == 2 && a.s2s) sn2s += exp(h[a.noff + (a.nf0 ? 1 : 0)]) * a.s2s[jc];
+    a.fmu[jc + (size_t)a.Nstar * s] = fmu;
+    a.fs2[jc + (size_t)a.Nstar * s] = fs2;
+    a.ys2[jc + (size_t)a.Nstar * s] = fs2 + sn2s * a.sn2_mult[s];  // :121
+  }
+}
+
+// gplite_pred.m:154-165 averaging over hyper-samples (in place into column 0 of the *_avg outputs)
+__global__ void k_pred_avg(int Nstar, int S, const double* __restrict__ fmu, const double* __restrict__ fs2,
+                           const double* __restrict__ ys2, double* __restrict__ out /* 4 x Nstar: ymu ys2 fmu fs2 */) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Nstar) return;
+  double fbar = 0.0, f2 = 0.0, y2 = 0.0;
+  for (int s = 0; s < S; ++s) { fbar += fmu[i + (size_t)Nstar * s]; f2 += fs2[i + (size_t)Nstar * s]; y2 += ys2[i + (size_t)Nstar * s]; }
+  fbar /= S;
+  double vf = 0.0;
+  for (int s = 0; s < S; ++s) { double d = fmu[i + (size_t)Nstar * s] - fbar; vf += d * d; }
+  vf /= (S - 1);
+  out[i] = fbar;                              // ymu = fmu without output warping
+  out[i + (size_t)Nstar] = y2 / S + vf;       // ys2
+  out[i + 2 * (size_t)Nstar] = fbar;          // fmu
+  out[i + 3 * (size_t)Nstar] = f2 / S + vf;   // fs2
+}

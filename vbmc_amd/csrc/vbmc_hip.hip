@@ -1,0 +1,3 @@
+// Single translation unit of libvbmc_hip.so: the kernels live in headers shared by both ABI files.
+#include "abi_elbo.hip"
+#include "abi_gp.hip"

@@ -1,0 +1,117 @@
+"""gplite GP surrogate on the GPU behind the reference's call surface.
+
+``gplite_post(hyp, X, y, covfun, meanfun, noisefun, s2)`` (gplite/gplite_post.m:1),
+``gplite_pred(gp, Xstar, ystar, s2star, ssflag)`` (gplite/gplite_pred.m:1) and
+``sq_dist(a, b)`` (utils/sq_dist.m:14) keep the reference's positional arguments.  ``gp`` is a
+dict with the reference's field names; its ``post`` list holds the per-hyper-sample
+{hyp, alpha, sW, L, sn2_mult, Lchol} exactly like ``gp.post(s)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import DeviceGP, f64, ptr
+from .elbo import default_engine
+
+
+def _nnoise(noisefun):
+    return int(noisefun[0] == 1) + int(noisefun[1] == 2) + 2 * int(len(noisefun) > 2 and noisefun[2] == 1)
+
+
+def _nmean(meanfun, D):
+    return {0: 0, 1: 1, 4: 2 * D + 1}.get(int(meanfun), -1)
+
+
+def sq_dist(a, b=None, *, engine=None):
+    """C = sq_dist(a, b): pairwise squared distances between the columns of a (D x n) and b (D x m)."""
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    a = f64(a)
+    D, n = a.shape
+    if b is None:
+        m, bp = n, None
+    else:
+        b = f64(b)
+        if b.shape[0] != D:
+            raise ValueError("Error: column lengths must agree.")  # sq_dist.m:35
+        m, bp = b.shape[1], ptr(b)
+    Cm = np.zeros((n, m), dtype=np.float64, order="F")
+    ctx.check(ctx.lib.vbmc_sq_dist(ctx.h, D, n, m, ptr(a), bp, ptr(Cm)))
+    return Cm
+
+
+def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engine=None):
+    """gp = gplite_post(hyp,X,y,covfun,meanfun,noisefun,s2): full posterior for every hyper-sample.
+
+    Only the VBMC configuration is accelerated: covfun 1 (SE-ARD), meanfun in {0, 1, 4}; anything
+    else raises VbmcUnsupported so a caller can fall through to the reference implementation.
+    """
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    X = f64(X)
+    N, D = X.shape
+    y = f64(np.asarray(y, dtype=np.float64).reshape(-1))
+    hyp = f64(np.asarray(hyp, dtype=np.float64))
+    if hyp.ndim == 1:
+        hyp = f64(hyp.reshape(-1, 1))
+    Nhyp, S = hyp.shape
+    if covfun is None:
+        covfun = 1
+    if np.ndim(covfun) and len(covfun):
+        covfun = covfun[0]
+    if int(covfun) != 1:
+        from ._lib import VBMC_ERR_UNSUPPORTED, VbmcUnsupported
+
+        raise VbmcUnsupported(VBMC_ERR_UNSUPPORTED, "only the SE-ARD covariance (covfun 1) is accelerated")
+    if meanfun is None:
+        meanfun = 1  # gplite_post.m:103
+    if noisefun is None:
+        noisefun = (1, 0, 0) if s2 is None else (1, 1, 0)  # :104-106
+    noisefun = tuple(int(v) for v in noisefun) + (0,) * (3 - len(noisefun))
+    s2a = None if s2 is None else f64(np.asarray(s2, dtype=np.float64).reshape(-1))
+    alpha = np.zeros((N, S), order="F")
+    L = np.zeros((N, N, S), order="F")
+    sW = np.zeros((N, S), order="F")
+    mult = np.zeros(S)
+    lch = np.zeros(S, dtype=np.uint8)
+    nf = (C.c_int32 * 3)(*noisefun)
+    h = C.c_void_p()
+    ctx.check(ctx.lib.vbmc_gp_post(ctx.h, N, D, S, Nhyp, int(meanfun), nf, ptr(X), ptr(y), ptr(s2a), ptr(hyp), ptr(alpha),
+                                   ptr(L), ptr(sW), ptr(mult), lch.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(h)))
+    gp = {
+        "X": X, "y": y, "s2": s2a, "covfun": 1, "meanfun": int(meanfun), "noisefun": noisefun,
+        "Ncov": D + 1, "Nnoise": _nnoise(noisefun), "Nmean": _nmean(meanfun, D), "meanfun_extras": None, "intmeanfun": 0,
+        "post": [{"hyp": hyp[:, s].copy(), "alpha": alpha[:, s].copy(), "sW": sW[:, s].copy(), "L": L[:, :, s].copy(),
+                  "sn2_mult": float(mult[s]), "Lchol": bool(lch[s])} for s in range(S)],
+    }
+    dgp = DeviceGP.from_handle(ctx, h, N, D, S)
+    engine._gp_cache = {id(gp): (gp, dgp, True, engine._fingerprint(gp))}
+    return gp
+
+
+def _device_gp_with_noise(engine, gp):
+    dgp = engine.device_gp(gp, need_L=True)
+    dgp.set_noise(gp["noisefun"], [p["sn2_mult"] for p in gp["post"]])
+    return dgp
+
+
+def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nowarpflag=False, nargout=4, *, engine=None):
+    """[ymu,ys2,fmu,fs2] = gplite_pred(gp,Xstar,ystar,s2star,ssflag)."""
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    Xs = f64(Xstar)
+    Nstar = Xs.shape[0]
+    if s2star is not None and np.size(s2star) and np.asarray(s2star).reshape(-1).shape[0] != Nstar:
+        raise ValueError("gplite_pred:s2dimmismatch S2STAR should be empty or a column vector of NSTAR estimated variances.")
+    s2s = None if s2star is None or np.size(s2star) == 0 else f64(np.asarray(s2star, dtype=np.float64).reshape(-1))
+    dgp = _device_gp_with_noise(engine, gp)
+    S = dgp.S
+    per = bool(ssflag) or S == 1
+    shape = (Nstar, S) if (per and S > 1) else (Nstar,)
+    outs = [np.zeros((Nstar, S) if per else (Nstar,), order="F") for _ in range(4)]
+    ctx.check(ctx.lib.vbmc_gp_pred(ctx.h, dgp.h, Nstar, ptr(Xs), ptr(s2s), 1 if per else 0, ptr(outs[0]), ptr(outs[1]),
+                                   ptr(outs[2]), ptr(outs[3])))
+    outs = [o.reshape(shape, order="F") if per else o for o in outs]
+    return tuple(outs[: max(1, nargout)])
