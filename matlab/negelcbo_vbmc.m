@@ -1,0 +1,49 @@
+function [F,dF,G,H,varF,dH,varGss,varG,varH,I_sk,J_sjk] = negelcbo_vbmc(theta,beta,vp,gp,Ns,compute_grad,compute_var,altent_flag,thetabnd,entropy_alpha)
+%NEGELCBO_VBMC Drop-in shim: negative ELCBO on an MI355X through vbmc_hip_mex.
+%
+% Same signature, nargin/nargout defaulting and error ids as the reference
+% (misc/negelcbo_vbmc.m:1-24).  Put this directory BEFORE the VBMC folders on the path.  Anything
+% outside the accelerated path (unsupported mean function, weights-only optimisation, K > 256,
+% ...) falls through to the reference implementation found further down the path.
+%
+% MC draws: with VBMC_HIP_PARITY=1 in the environment the K blocks randn(D,1,Ns/2) are drawn here, in
+% the reference's order (ent/entmc_vbmc.m:53), so MATLAB's global stream advances identically and the
+% result matches the reference to fp64 round-off; otherwise a device Philox stream is used.
+if nargin < 5 || isempty(Ns); Ns = 0; end
+if nargin < 6 || isempty(compute_grad); compute_grad = nargout > 1; end
+if nargin < 7; compute_var = []; end
+if nargin < 8 || isempty(altent_flag); altent_flag = false; end %#ok<NASGU>
+if nargin < 9; thetabnd = []; end
+if nargin < 10 || isempty(entropy_alpha); entropy_alpha = 0; end %#ok<NASGU>
+if isempty(beta) || ~isfinite(beta); beta = 0; end
+if isempty(compute_var); compute_var = beta ~= 0 || nargout > 4; end
+separate_K = nargout > 9;
+
+onlyweights = vp.optimize_weights && ~vp.optimize_mu && ~vp.optimize_sigma && ~vp.optimize_lambda;
+try
+    if onlyweights; error('vbmc_hip:unsupported','weights-only branch stays on the host'); end
+    h = vbmc_hip_gp_handle(gp);                 % cached upload, keyed on the gp struct (see INTEGRATION.md)
+    epsblk = [];
+    if Ns > 0 && strcmp(getenv('VBMC_HIP_PARITY'),'1')
+        Nse = ceil(Ns/2)*2;
+        epsblk = zeros(vp.D,Nse/2,vp.K);
+        for j = 1:vp.K; epsblk(:,:,j) = reshape(randn(vp.D,1,Nse/2),[vp.D,Nse/2]); end
+    end
+    seed = randi(2^31-1);
+    [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo',h,theta(:),vp,Ns,double(compute_grad), ...
+        double(compute_var),double(separate_K),beta,thetabnd,epsblk,seed,numel(gp.post));
+    varH = 0;
+    if compute_var; varF = varG + varH; else; varF = 0; varG = 0; varGss = 0; end
+catch err
+    if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+    ref = vbmc_hip_reference('negelcbo_vbmc');  % next negelcbo_vbmc on the path (which -all)
+    outs = cell(1,max(nargout,1));
+    [outs{:}] = ref(theta,beta,vp,gp,Ns,compute_grad,compute_var,false,thetabnd,0);
+    [F,dF,G,H,varF,dH,varGss,varG,varH,I_sk,J_sjk] = deal_padded(outs,11);
+end
+end
+
+function varargout = deal_padded(c,n)
+c(end+1:n) = {[]};
+varargout = c(1:n);
+end

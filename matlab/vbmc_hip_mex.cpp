@@ -1,0 +1,199 @@
+// vbmc_hip_mex.cpp -- MEX gateway from MATLAB to libvbmc_hip.so (include/vbmc_hip.h).
+//
+// Build (on a machine with MATLAB + ROCm; cannot be built in the development container, which has
+// neither MATLAB nor mex.h -- this file is deliberately free of numerics):
+//     mex -R2018a vbmc_hip_mex.cpp -I../include -L../vbmc_amd/lib -lvbmc_hip
+//
+// Usage from the .m shims in this directory:
+//     vbmc_hip_mex('open', device)                         -> (context kept in a persistent, mexLock'ed)
+//     h  = vbmc_hip_mex('gp_upload', gpstruct)             -> uint64 handle of a device-resident gp.post
+//          vbmc_hip_mex('gp_free', h)
+//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
+//                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty)
+//     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
+//     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
+//     C = vbmc_hip_mex('sq_dist', a, b)
+//
+// Errors are raised with mexErrMsgIdAndTxt AFTER all temporaries are released (it long-jumps);
+// VBMC_ERR_UNSUPPORTED becomes the id 'vbmc_hip:unsupported' which the shims catch to fall through
+// to the reference .m implementation (SURVEY.md 8b "Errors").
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mex.h"
+#include "vbmc_hip.h"
+
+static vbmc_ctx* g_ctx = nullptr;
+
+static void at_exit() {
+  if (g_ctx) { vbmc_ctx_destroy(g_ctx); g_ctx = nullptr; }
+}
+
+static void ensure_ctx(int device) {
+  if (g_ctx) return;
+  vbmc_status st = vbmc_ctx_create(device, nullptr, &g_ctx);
+  if (st != VBMC_OK) mexErrMsgIdAndTxt("vbmc_hip:nodevice", "libvbmc_hip: no gfx950 (MI355X) device available (status %d)", st);
+  mexLock();
+  mexAtExit(at_exit);
+}
+
+static void fail(vbmc_status st) {
+  std::string msg = vbmc_last_error(g_ctx);
+  if (st == VBMC_ERR_UNSUPPORTED) mexErrMsgIdAndTxt("vbmc_hip:unsupported", "%s", msg.c_str());
+  // messages of INVALID errors start with the reference's own error id where one exists
+  size_t sp = msg.find(' ');
+  if (st == VBMC_ERR_INVALID && sp != std::string::npos && msg.find(':') < sp)
+    mexErrMsgIdAndTxt(msg.substr(0, sp).c_str(), "%s", msg.c_str() + sp + 1);
+  mexErrMsgIdAndTxt("vbmc_hip:error", "%s", msg.c_str());
+}
+
+static const double* dbl(const mxArray* a) { return (a && !mxIsEmpty(a)) ? mxGetDoubles(a) : nullptr; }
+static const mxArray* field(const mxArray* s, const char* name) { return mxGetField(s, 0, name); }
+static double scalar_field(const mxArray* s, const char* name, double dflt) {
+  const mxArray* f = field(s, name);
+  return (f && !mxIsEmpty(f)) ? mxGetScalar(f) : dflt;
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("vbmc_hip:usage", "first argument must be a command string");
+  char cmd[32];
+  mxGetString(prhs[0], cmd, sizeof cmd);
+
+  if (!strcmp(cmd, "open")) { ensure_ctx(nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0); return; }
+  ensure_ctx(0);
+
+  if (!strcmp(cmd, "gp_upload")) {
+    const mxArray* gp = prhs[1];
+    const mxArray* X = field(gp, "X");
+    const mxArray* post = field(gp, "post");
+    const int N = (int)mxGetM(X), D = (int)mxGetN(X), S = (int)mxGetNumberOfElements(post);
+    const int Nhyp = (int)mxGetNumberOfElements(mxGetField(post, 0, "hyp"));
+    std::vector<double> hyp((size_t)Nhyp * S), alpha((size_t)N * S), L((size_t)N * N * S), sW1(S), mult(S);
+    std::vector<uint8_t> lch(S);
+    for (int s = 0; s < S; ++s) {
+      memcpy(&hyp[(size_t)s * Nhyp], mxGetDoubles(mxGetField(post, s, "hyp")), Nhyp * sizeof(double));
+      memcpy(&alpha[(size_t)s * N], mxGetDoubles(mxGetField(post, s, "alpha")), N * sizeof(double));
+      memcpy(&L[(size_t)s * N * N], mxGetDoubles(mxGetField(post, s, "L")), (size_t)N * N * sizeof(double));
+      sW1[s] = mxGetDoubles(mxGetField(post, s, "sW"))[0];
+      mult[s] = mxGetScalar(mxGetField(post, s, "sn2_mult"));
+      lch[s] = mxIsLogicalScalarTrue(mxGetField(post, s, "Lchol")) ? 1 : 0;
+    }
+    int32_t nf[3] = {1, 0, 0};
+    const mxArray* nfa = field(gp, "noisefun");
+    for (int i = 0; nfa && i < 3 && i < (int)mxGetNumberOfElements(nfa); ++i) nf[i] = (int32_t)mxGetDoubles(nfa)[i];
+    vbmc_gp* h = nullptr;
+    vbmc_status st = vbmc_gp_upload(g_ctx, N, D, S, Nhyp, (int)scalar_field(gp, "Ncov", D + 1), (int)scalar_field(gp, "Nnoise", 1),
+                                    (int)scalar_field(gp, "meanfun", 4), mxGetDoubles(X), hyp.data(), alpha.data(), L.data(),
+                                    sW1.data(), lch.data(), &h);
+    if (st == VBMC_OK) st = vbmc_gp_set_noise(g_ctx, h, nf, mult.data());
+    hyp = {}; alpha = {}; L = {};
+    if (st != VBMC_OK) fail(st);
+    plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+    *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+    return;
+  }
+  if (!strcmp(cmd, "gp_free")) { vbmc_gp_free(g_ctx, (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return; }
+
+  if (!strcmp(cmd, "elbo")) {
+    // (h, theta, vp, Ns, compute_grad, compute_var, separate_K, beta, thetabnd, eps)
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    const mxArray* theta = prhs[2];
+    const mxArray* vp = prhs[3];
+    vbmc_elbo_args a;
+    memset(&a, 0, sizeof a);
+    a.struct_size = sizeof a;
+    a.D = (int)scalar_field(vp, "D", 0); a.K = (int)scalar_field(vp, "K", 0); a.R = 1;
+    a.optimize[0] = scalar_field(vp, "optimize_mu", 1) != 0; a.optimize[1] = scalar_field(vp, "optimize_sigma", 1) != 0;
+    a.optimize[2] = scalar_field(vp, "optimize_lambda", 1) != 0; a.optimize[3] = scalar_field(vp, "optimize_weights", 0) != 0;
+    a.theta = mxGetDoubles(theta);
+    a.vp_mu = dbl(field(vp, "mu")); a.vp_sigma = dbl(field(vp, "sigma")); a.vp_lambda = dbl(field(vp, "lambda")); a.vp_w = dbl(field(vp, "w"));
+    std::vector<double> delta;
+    const mxArray* dl = field(vp, "delta");
+    if (dl && !mxIsEmpty(dl)) {  // scalar or D-vector (gplogjoint.m:85-89)
+      delta.assign(a.D, mxGetDoubles(dl)[0]);
+      if ((int)mxGetNumberOfElements(dl) == a.D) memcpy(delta.data(), mxGetDoubles(dl), a.D * sizeof(double));
+      a.vp_delta = delta.data();
+    }
+    a.Ns = (int)mxGetScalar(prhs[4]);
+    a.compute_grad = (int)mxGetScalar(prhs[5]); a.compute_var = (int)mxGetScalar(prhs[6]); a.separate_K = (int)mxGetScalar(prhs[7]);
+    a.beta = mxGetScalar(prhs[8]);
+    const mxArray* tb = nrhs > 9 ? prhs[9] : nullptr;
+    if (tb && !mxIsEmpty(tb)) {
+      a.bnd_lb = dbl(field(tb, "lb")); a.bnd_ub = dbl(field(tb, "ub")); a.TolCon = scalar_field(tb, "TolCon", 0.01);
+      a.WeightThreshold = scalar_field(tb, "WeightThreshold", 0); a.WeightPenalty = scalar_field(tb, "WeightPenalty", 0);
+    }
+    const mxArray* eps = nrhs > 10 ? prhs[10] : nullptr;  // D x Ns/2 x K block drawn by the shim with randn, or []
+    if (eps && !mxIsEmpty(eps)) { a.eps_mode = 1; a.eps = mxGetDoubles(eps); a.eps_shared = 1; }
+    else { a.eps_mode = 0; a.seed = (uint64_t)(nrhs > 11 ? mxGetScalar(prhs[11]) : 0); }
+    const size_t T = mxGetNumberOfElements(theta);
+    mxArray *F = mxCreateDoubleMatrix(1, 1, mxREAL), *dF = mxCreateDoubleMatrix(a.compute_grad ? T : 0, a.compute_grad ? 1 : 0, mxREAL);
+    mxArray *G = mxCreateDoubleMatrix(1, 1, mxREAL), *H = mxCreateDoubleMatrix(1, 1, mxREAL), *vG = mxCreateDoubleMatrix(1, 1, mxREAL);
+    mxArray *dH = mxCreateDoubleMatrix(a.compute_grad ? T : 0, a.compute_grad ? 1 : 0, mxREAL), *vss = mxCreateDoubleMatrix(1, 1, mxREAL);
+    a.F = mxGetDoubles(F); a.G = mxGetDoubles(G); a.H = mxGetDoubles(H); a.varG = mxGetDoubles(vG); a.varGss = mxGetDoubles(vss);
+    if (a.compute_grad) { a.dF = mxGetDoubles(dF); a.dH = mxGetDoubles(dH); }
+    mxArray *Isk = nullptr, *Jsjk = nullptr;
+    if (a.separate_K) {
+      // S is known to the library; query through a first call would cost a launch, so the shim passes numel(gp.post)
+      const int S = (int)mxGetScalar(prhs[12]);
+      Isk = mxCreateDoubleMatrix(S, a.K, mxREAL);
+      a.I_sk = mxGetDoubles(Isk);
+      if (a.compute_var) { mwSize dims[3] = {(mwSize)S, (mwSize)a.K, (mwSize)a.K}; Jsjk = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); a.J_sjk = mxGetDoubles(Jsjk); }
+    }
+    vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
+    if (st != VBMC_OK) fail(st);  // MATLAB frees the mxArrays created above on error
+    mxArray* outs[9] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk};
+    for (int i = 0; i < 9 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    return;
+  }
+
+  if (!strcmp(cmd, "gp_post")) {
+    // (hyp, X, y, s2, meanfun, noisefun) -> alpha, L, sW, sn2_mult, Lchol, handle
+    const mxArray *hyp = prhs[1], *X = prhs[2], *y = prhs[3], *s2 = prhs[4];
+    const int N = (int)mxGetM(X), D = (int)mxGetN(X), Nhyp = (int)mxGetM(hyp), S = (int)mxGetN(hyp);
+    int32_t nf[3] = {1, 0, 0};
+    for (int i = 0; i < 3 && i < (int)mxGetNumberOfElements(prhs[6]); ++i) nf[i] = (int32_t)mxGetDoubles(prhs[6])[i];
+    mwSize ld[3] = {(mwSize)N, (mwSize)N, (mwSize)S};
+    plhs[0] = mxCreateDoubleMatrix(N, S, mxREAL);
+    mxArray* L = mxCreateNumericArray(3, ld, mxDOUBLE_CLASS, mxREAL);
+    mxArray* sW = mxCreateDoubleMatrix(N, S, mxREAL);
+    mxArray* mult = mxCreateDoubleMatrix(S, 1, mxREAL);
+    mxArray* lch = mxCreateNumericMatrix(S, 1, mxUINT8_CLASS, mxREAL);
+    vbmc_gp* h = nullptr;
+    vbmc_status st = vbmc_gp_post(g_ctx, N, D, S, Nhyp, (int)mxGetScalar(prhs[5]), nf, mxGetDoubles(X), mxGetDoubles(y), dbl(s2),
+                                  mxGetDoubles(hyp), mxGetDoubles(plhs[0]), mxGetDoubles(L), mxGetDoubles(sW), mxGetDoubles(mult),
+                                  (uint8_t*)mxGetData(lch), &h);
+    if (st != VBMC_OK) fail(st);
+    if (nlhs > 1) plhs[1] = L;
+    if (nlhs > 2) plhs[2] = sW;
+    if (nlhs > 3) plhs[3] = mult;
+    if (nlhs > 4) plhs[4] = lch;
+    if (nlhs > 5) { plhs[5] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[5]) = (uint64_t)(uintptr_t)h; }
+    else vbmc_gp_free(g_ctx, h);
+    return;
+  }
+
+  if (!strcmp(cmd, "gp_pred")) {
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    const mxArray* Xs = prhs[2];
+    const int Nstar = (int)mxGetM(Xs), ss = (int)mxGetScalar(prhs[4]), S = (int)mxGetScalar(prhs[5]);
+    const int nc = (ss && S > 1) ? S : 1;
+    for (int i = 0; i < 4; ++i) plhs[i] = mxCreateDoubleMatrix(Nstar, nc, mxREAL);
+    vbmc_status st = vbmc_gp_pred(g_ctx, h, Nstar, mxGetDoubles(Xs), dbl(prhs[3]), ss || S == 1, mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]),
+                                  mxGetDoubles(plhs[2]), mxGetDoubles(plhs[3]));
+    if (st != VBMC_OK) fail(st);
+    return;
+  }
+
+  if (!strcmp(cmd, "sq_dist")) {
+    const mxArray* a = prhs[1];
+    const mxArray* b = (nrhs > 2 && !mxIsEmpty(prhs[2])) ? prhs[2] : nullptr;
+    const int D = (int)mxGetM(a), n = (int)mxGetN(a), m = b ? (int)mxGetN(b) : n;
+    if (b && (int)mxGetM(b) != D) mexErrMsgTxt("Error: column lengths must agree.");
+    plhs[0] = mxCreateDoubleMatrix(n, m, mxREAL);
+    vbmc_status st = vbmc_sq_dist(g_ctx, D, n, m, mxGetDoubles(a), b ? mxGetDoubles(b) : nullptr, mxGetDoubles(plhs[0]));
+    if (st != VBMC_OK) fail(st);
+    return;
+  }
+  mexErrMsgIdAndTxt("vbmc_hip:usage", "unknown command '%s'", cmd);
+}
