@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SOURCES = ["vbmc_hip.hip"]
-HEADERS = ["abi_elbo.hip", "abi_gp.hip", "common.h", "device_math.h", "elbo_kernels.h", "var_kernels.h", "gp_kernels.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
+HEADERS = ["abi_elbo.hip", "abi_gp.hip", "common.h", "device_math.h", "elbo_kernels.h", "var_kernels.h", "gp_kernels.h", "entropy_mfma.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
 
 
 def _newer(target, deps):

@@ -4,6 +4,8 @@
 
 #include "elbo_kernels.h"
 #include "var_kernels.h"
+#include "entropy_mfma.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -245,6 +247,39 @@ static hipError_t set_entropy_lds(bool grad, size_t lds) {
   return hipFuncSetAttribute((const void*)k_entropy<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+
+// ---- MFMA entropy kernel dispatch: QS = ceil((D+2)/4) in 1..9, KTM in {4, 8}
+template <int QS, int KTM>
+static void launch_entropy_mfma_k(bool grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
+  if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS, KTM, true>), grid, dim3(WAVE), 0, st, ea);
+  else hipLaunchKernelGGL((k_entropy_mfma<QS, KTM, false>), grid, dim3(WAVE), 0, st, ea);
+}
+template <int KTM>
+static bool launch_entropy_mfma(int qs, bool grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
+  switch (qs) {
+    case 1: launch_entropy_mfma_k<1, KTM>(grad, grid, st, ea); return true;
+    case 2: launch_entropy_mfma_k<2, KTM>(grad, grid, st, ea); return true;
+    case 3: launch_entropy_mfma_k<3, KTM>(grad, grid, st, ea); return true;
+    case 4: launch_entropy_mfma_k<4, KTM>(grad, grid, st, ea); return true;
+    case 5: launch_entropy_mfma_k<5, KTM>(grad, grid, st, ea); return true;
+    case 6: launch_entropy_mfma_k<6, KTM>(grad, grid, st, ea); return true;
+    case 7: launch_entropy_mfma_k<7, KTM>(grad, grid, st, ea); return true;
+    case 8: launch_entropy_mfma_k<8, KTM>(grad, grid, st, ea); return true;
+    case 9: launch_entropy_mfma_k<9, KTM>(grad, grid, st, ea); return true;
+    default: return false;
+  }
+}
+// register budget (doubles per lane) of k_entropy_mfma<QS,KTM,grad>; beyond ~215 it would spill
+static bool mfma_entropy_fits(int D, int K, int* qs_out, int* ktm_out) {
+  const int qs = (D + 2 + 3) / 4, kt = (K + 15) / 16;
+  if (qs < 1 || qs > 9 || kt > 8) return false;
+  const int ktm = kt <= 4 ? 4 : 8;
+  const int npv = (4 * qs + 15) / 16;
+  const int regs = ktm * qs + 4 * ktm * npv + 8 * ktm + 4 * npv + 2 * qs + 24;
+  *qs_out = qs; *ktm_out = ktm;
+  return regs <= 215;
+}
+
 // ------------------------------------------------------------------------------------------
 // vbmc_elbo_batch
 // ------------------------------------------------------------------------------------------
@@ -361,9 +396,14 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   FinArgs fa{};
   fa.dm = dm;
   if (mc) {
-    const int ntile = (Mh + 31) / 32;
-    // enough waves to fill the chip several times over, but >= 2 tiles per wave when possible
-    long long target = (long long)ctx->num_cu * 5 * 4;
+    int qs = 0, ktm = 0;
+    const char* force = getenv("VBMC_ENT_KERNEL");  // "valu" | "mfma" (A/B testing); default: mfma when it fits
+    bool use_mfma = mfma_entropy_fits(D, K, &qs, &ktm);
+    if (force && !strcmp(force, "valu")) use_mfma = false;
+    const int tile_sz = use_mfma ? 16 : 32;          // base samples per tile
+    const int ntile = (Mh + tile_sz - 1) / tile_sz;
+    // enough waves to fill the chip several times over
+    long long target = (long long)ctx->num_cu * (use_mfma ? 8 : 5) * 4;
     int C = (int)((target + (long long)K * R - 1) / ((long long)K * R));
     if (C < 1) C = 1;
     if (C > ntile) C = ntile;
@@ -387,14 +427,22 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     } else {
       return set_err(ctx, VBMC_ERR_INVALID, "eps_mode must be 0, 1 or 2");
     }
-    size_t lds = ((size_t)K * (dt + ENTP_EXTRA) + WAVE + (compute_grad ? (size_t)K * 65 : 0)) * sizeof(double);
-    if (lds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d needs %zu B of LDS (> 160 KiB)", K, D, lds);
-    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-    DISPATCH_DT(dt, {
-      HIP_TRY(ctx, set_entropy_lds<DT>(compute_grad != 0, lds));
-      launch_entropy<DT>(compute_grad != 0, dim3(C, K, R), lds, st, ea);
-    });
-    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+    if (use_mfma) {
+      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+      bool ok = ktm == 4 ? launch_entropy_mfma<4>(qs, compute_grad != 0, dim3(C, K, R), st, ea)
+                         : launch_entropy_mfma<8>(qs, compute_grad != 0, dim3(C, K, R), st, ea);
+      if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
+      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+    } else {
+      size_t lds = ((size_t)K * (dt + ENTP_EXTRA) + WAVE + (compute_grad ? (size_t)K * 65 : 0)) * sizeof(double);
+      if (lds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d needs %zu B of LDS (> 160 KiB)", K, D, lds);
+      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+      DISPATCH_DT(dt, {
+        HIP_TRY(ctx, set_entropy_lds<DT>(compute_grad != 0, lds));
+        launch_entropy<DT>(compute_grad != 0, dim3(C, K, R), lds, st, ea);
+      });
+      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+    }
     fa.entpart = ea.part; fa.entlb = nullptr; fa.M = Mh; fa.C = C; fa.ncol = ncol;
   } else {
     const size_t ebs = 1 + (size_t)D * K + 2 * K + D;
