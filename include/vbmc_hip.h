@@ -155,6 +155,9 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * `seed`, so that a host oracle can be fed the same draws (test hook; entmc_vbmc.m:53). */
 vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t seed, double* eps_host);
 
+/* Test hook: y = exp(x) evaluated by the hot-loop device implementations (0: polynomial, 1: table). */
+vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const double* x, double* y);
+
 /* Device-memory helpers for callers without their own allocator (MEX). */
 vbmc_status vbmc_device_alloc(vbmc_ctx* ctx, size_t bytes, void** dptr);
 vbmc_status vbmc_device_free(vbmc_ctx* ctx, void* dptr);

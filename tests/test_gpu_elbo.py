@@ -198,3 +198,18 @@ def test_error_ids_mirror_reference(va):
         bad = theta.copy()
         bad[0] = np.nan
         va.negelcbo_vbmc(bad, 0, vp, gp, 10, 1, 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_exp_accuracy(va, variant):
+    """The hot-loop exp implementations: <= 2 ulp over the working range, saturation at the ends."""
+    ctx = va.default_engine().ctx
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-40, 5, 20000), rng.uniform(-1e-3, 1e-3, 2000),
+                        np.array([0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -800.0, -1e300, -1e5])])
+    y = ctx.test_exp(x, variant)
+    ref = np.exp(np.maximum(x, -1e4))
+    ok = ref > 1e-300  # normal range
+    rel = np.abs(y[ok] - ref[ok]) / ref[ok]
+    assert rel.max() < 4.5e-16, rel.max()
+    assert np.all(y[x <= -800] == 0.0) and np.all(y[~ok] < 1e-299)

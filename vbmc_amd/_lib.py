@@ -92,6 +92,7 @@ def load():
     lib.vbmc_gp_post.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, _dp, _dp, _dp, _dp,
                                  _dp, _dp, _dp, _dp, u8p, C.POINTER(vp)]
     lib.vbmc_gp_pred.argtypes = [vp, vp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
+    lib.vbmc_test_exp.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
     lib.vbmc_sq_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     for name in DECLARED_OPTIONAL:
         if hasattr(lib, name):
@@ -152,6 +153,12 @@ class Context:
         out = np.empty((R, K, Mh, D), dtype=np.float64)
         self.check(self.lib.vbmc_rng_dump(self.h, D, K, R, Ns, C.c_uint64(seed), ptr(out)))
         return out
+
+    def test_exp(self, x, variant=0):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+        y = np.empty_like(x)
+        self.check(self.lib.vbmc_test_exp(self.h, x.size, int(variant), ptr(x), ptr(y)))
+        return y
 
     def close(self):
         if getattr(self, "h", None):

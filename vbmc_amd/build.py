@@ -1,16 +1,25 @@
-"""Build libvbmc_hip.so (and the microbenchmark) for gfx950 with hipcc, in-tree."""
+"""Build libvbmc_hip.so (and the microbenchmark) for gfx950 with hipcc, in-tree.
+
+Translation units are compiled in parallel: vbmc_hip.hip (ABI + all kernels but the MFMA entropy
+family) and ent_mfma_inst.hip once per QS = 1..9 (k_entropy_mfma<QS, KT, grad> for every KT).
+"""
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-SOURCES = ["vbmc_hip.hip"]
-HEADERS = ["abi_elbo.hip", "abi_gp.hip", "common.h", "device_math.h", "elbo_kernels.h", "var_kernels.h", "gp_kernels.h", "entropy_mfma.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
+OBJDIR = os.path.join(HERE, "lib", "obj")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+MAIN_DEPS = ["vbmc_hip.hip", "abi_elbo.hip", "abi_gp.hip", "common.h", "device_math.h", "elbo_types.h", "elbo_kernels.h",
+             "var_kernels.h", "gp_kernels.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
+MFMA_DEPS = ["ent_mfma_inst.hip", "entropy_mfma.h", "device_math.h", "elbo_types.h"]
+QS_RANGE = range(1, 10)
 
 
 def _newer(target, deps):
@@ -20,24 +29,36 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+
+
 def build(force=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    objs = []
+    main_o = os.path.join(OBJDIR, "vbmc_hip.o")
+    objs.append(main_o)
+    if force or _newer(main_o, [os.path.join(CSRC, d) for d in MAIN_DEPS]):
+        jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, "vbmc_hip.hip"), "-o", main_o])
+    for qs in QS_RANGE:
+        o = os.path.join(OBJDIR, "ent_mfma_qs%d.o" % qs)
+        objs.append(o)
+        if force or _newer(o, [os.path.join(CSRC, d) for d in MFMA_DEPS]):
+            jobs.append([hipcc] + FLAGS + ["-DQS_VALUE=%d" % qs, "-c", os.path.join(CSRC, "ent_mfma_inst.hip"), "-o", o])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(lambda c: _run(c, verbose), jobs))
     lib = os.path.join(LIBDIR, "libvbmc_hip.so")
-    if force or _newer(lib, deps):
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + srcs + ["-o", lib]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    if force or jobs or _newer(lib, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib], verbose)
     mb_src = os.path.join(ROOT, "tools", "microbench.hip")
     mb = os.path.join(LIBDIR, "microbench")
     if os.path.exists(mb_src) and (force or _newer(mb, [mb_src, os.path.join(CSRC, "device_math.h")])):
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", mb_src, "-o", mb]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        _run([hipcc] + FLAGS[:3] + ["-Wno-unused-value", mb_src, "-o", mb], verbose)
     return lib
 
 

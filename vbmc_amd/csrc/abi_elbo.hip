@@ -4,7 +4,6 @@
 
 #include "elbo_kernels.h"
 #include "var_kernels.h"
-#include "entropy_mfma.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
@@ -248,36 +247,32 @@ static hipError_t set_entropy_lds(bool grad, size_t lds) {
 }
 
 
-// ---- MFMA entropy kernel dispatch: QS = ceil((D+2)/4) in 1..9, KTM in {4, 8}
-template <int QS, int KTM>
-static void launch_entropy_mfma_k(bool grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
-  if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS, KTM, true>), grid, dim3(WAVE), 0, st, ea);
-  else hipLaunchKernelGGL((k_entropy_mfma<QS, KTM, false>), grid, dim3(WAVE), 0, st, ea);
+// ---- MFMA entropy kernel dispatch: QS = ceil((D+2)/4) in 1..9 (one translation unit each,
+// ent_mfma_inst.hip), KT = ceil(K/16) in 1..8 (1..4 for QS > 6: register budget)
+extern "C" {
+int vbmc_launch_ent_mfma_qs1(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs2(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs3(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs4(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs5(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs6(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs7(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs8(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs9(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 }
-template <int KTM>
-static bool launch_entropy_mfma(int qs, bool grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
-  switch (qs) {
-    case 1: launch_entropy_mfma_k<1, KTM>(grad, grid, st, ea); return true;
-    case 2: launch_entropy_mfma_k<2, KTM>(grad, grid, st, ea); return true;
-    case 3: launch_entropy_mfma_k<3, KTM>(grad, grid, st, ea); return true;
-    case 4: launch_entropy_mfma_k<4, KTM>(grad, grid, st, ea); return true;
-    case 5: launch_entropy_mfma_k<5, KTM>(grad, grid, st, ea); return true;
-    case 6: launch_entropy_mfma_k<6, KTM>(grad, grid, st, ea); return true;
-    case 7: launch_entropy_mfma_k<7, KTM>(grad, grid, st, ea); return true;
-    case 8: launch_entropy_mfma_k<8, KTM>(grad, grid, st, ea); return true;
-    case 9: launch_entropy_mfma_k<9, KTM>(grad, grid, st, ea); return true;
-    default: return false;
-  }
+static bool launch_entropy_mfma(int qs, int kt, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
+  typedef int (*fn_t)(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+  static const fn_t fns[9] = {vbmc_launch_ent_mfma_qs1, vbmc_launch_ent_mfma_qs2, vbmc_launch_ent_mfma_qs3,
+                              vbmc_launch_ent_mfma_qs4, vbmc_launch_ent_mfma_qs5, vbmc_launch_ent_mfma_qs6,
+                              vbmc_launch_ent_mfma_qs7, vbmc_launch_ent_mfma_qs8, vbmc_launch_ent_mfma_qs9};
+  if (qs < 1 || qs > 9) return false;
+  return fns[qs - 1](kt, grad ? 1 : 0, g.x, g.y, g.z, (void*)st, &ea) == 0;
 }
-// register budget (doubles per lane) of k_entropy_mfma<QS,KTM,grad>; beyond ~215 it would spill
-static bool mfma_entropy_fits(int D, int K, int* qs_out, int* ktm_out) {
+static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out) {
   const int qs = (D + 2 + 3) / 4, kt = (K + 15) / 16;
-  if (qs < 1 || qs > 9 || kt > 8) return false;
-  const int ktm = kt <= 4 ? 4 : 8;
-  const int npv = (4 * qs + 15) / 16;
-  const int regs = ktm * qs + 4 * ktm * npv + 8 * ktm + 4 * npv + 2 * qs + 24;
-  *qs_out = qs; *ktm_out = ktm;
-  return regs <= 215;
+  *qs_out = qs; *kt_out = kt;
+  if (qs < 1 || qs > 9 || kt < 1 || kt > 8) return false;
+  return qs <= 6 || kt <= 4;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -429,8 +424,7 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     }
     if (use_mfma) {
       if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-      bool ok = ktm == 4 ? launch_entropy_mfma<4>(qs, compute_grad != 0, dim3(C, K, R), st, ea)
-                         : launch_entropy_mfma<8>(qs, compute_grad != 0, dim3(C, K, R), st, ea);
+      bool ok = launch_entropy_mfma(qs, ktm, compute_grad != 0, dim3(C, K, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
       if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     } else {
@@ -563,6 +557,28 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
           for (int s = 0; s < S; ++s)
             a->J_sjk[s + (size_t)S * (j + (size_t)K * (k + (size_t)K * r))] = Jh[(((size_t)r * S + s) * K + k) * K + j];
   }
+  return VBMC_OK;
+}
+
+// test hook: y[i] = exp(x[i]) with the hot-loop implementations (variant 0: vb_exp, 1: vb_exp_tab)
+__global__ void k_test_exp(int n, int variant, const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double tab[64];
+  if (threadIdx.x < 64) tab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = variant ? vb_exp_tab(x[i], tab) : vb_exp(x[i]);
+}
+
+extern "C" vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const double* x, double* y) {
+  if (!ctx || n <= 0 || !x || !y) return VBMC_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { vbmc_status s_ = ensure(ctx, ctx->misc, 2 * (size_t)n * sizeof(double)); if (s_) return s_; }
+  double* dx = (double*)ctx->misc.p;
+  HIP_TRY(ctx, hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, variant, dx, dx + n);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(y, dx + n, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return VBMC_OK;
 }
 

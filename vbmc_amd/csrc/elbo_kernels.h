@@ -16,38 +16,7 @@
 #pragma once
 #include "common.h"
 #include "device_math.h"
-
-#define WAVE 64
-
-// ------------------------------------------------------------------------------------------
-// layouts
-// ------------------------------------------------------------------------------------------
-// vpd block per restart (doubles): mu[D*K] sigma[K] lambda[D] w[K] eta[K] lognf lnsigma[K] lnlambda[D]
-struct VpLayout {
-  int D, K;
-  __host__ __device__ int mu() const { return 0; }
-  __host__ __device__ int sigma() const { return D * K; }
-  __host__ __device__ int lambda() const { return D * K + K; }
-  __host__ __device__ int w() const { return D * K + K + D; }
-  __host__ __device__ int eta() const { return D * K + 2 * K + D; }
-  __host__ __device__ int lognf() const { return D * K + 3 * K + D; }
-  __host__ __device__ int lnsigma() const { return D * K + 3 * K + D + 1; }
-  __host__ __device__ int lnlambda() const { return D * K + 4 * K + D + 1; }
-  __host__ __device__ int stride() const { return D * K + 4 * K + 2 * D + 2; }
-};
-// packed per-component entropy parameters: [m_dk = mu_dk/lambda_d (D), h_k = -1/(2 sigma_k^2),
-// cK_k = -D log sigma_k, w_k, wi_k = w_k / sigma_k^2]
-#define ENTP_EXTRA 4
-// per-hyper-sample GP constants: ell2[D] xm[D] iom2[D] lnsf2_plus_sumlnell m0
-#define GPC_STRIDE(D) (3 * (D) + 2)
-// output block per restart: F G H varG varGss | dF[T] dG[T] dH[T]
-#define OUT_HDR 5
-
-struct ElboDims {
-  int D, K, R, S, N, T;
-  int opt[4];
-  int off_mu, off_sigma, off_lambda, off_eta;  // offsets into theta (or -1)
-};
+#include "elbo_types.h"
 
 // ------------------------------------------------------------------------------------------
 // k_prep: unpack theta exactly as misc/negelcbo_vbmc.m:33-48 does
@@ -212,15 +181,6 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
 // Lanes 0-31 own base samples with +eps, lanes 32-63 the antithetic -eps (:53-54).
 // partial layout PE[r][j][c][NCOL]: sum log q | G[D] | SG | LG[D] | W[K]   (NCOL = 1 if !GRAD)
 // ------------------------------------------------------------------------------------------
-struct EntArgs {
-  const double* entp;    // R x K x (D+4)
-  const double* vpd;     // R x VpLayout
-  const double* eps;     // D x Mh x K (x R) or null -> Philox
-  long long eps_stride_r;
-  double* part;
-  int D, K, Mh, C, tiles_per_chunk, ncol;
-  unsigned long long seed;
-};
 
 template <int DT, bool GRAD>
 __global__ void __launch_bounds__(WAVE) k_entropy(EntArgs a) {

@@ -2,7 +2,7 @@
 // organised around v_mfma_f64_16x16x4_f64, in the shape of a flash-attention tile:
 //
 //   S-step   E^T[k][i] = b_k . a_i - shift_i       (16 components x 16 samples, inner dim D+2)
-//   exp      n_ik = exp(E_ik)                       (the only transcendental; 4 per lane per tile)
+//   exp      n_ik = exp(E_ik)                       (the only transcendental; 4 per lane per k-tile)
 //   PV-step  Y[i][c] = sum_k n_ik V[k][c]           (16 samples x 16 columns: q', A', B'_1..D)
 //
 // with  a_i = [u'_i, |u'_i|^2, 1],  u'_i = eps_i * sigma_j  (coordinates centred on the sample's own
@@ -15,41 +15,48 @@
 //
 // One wave (= one 64-thread workgroup) per (sample chunk, source component j, restart r).  A tile is
 // 16 base samples, processed twice (+eps, -eps: antithetic, entmc_vbmc.m:53-54).  All mixture-side
-// MFMA operands are built once per wave and stay in registers; the only LDS traffic is the 16 x D eps
-// tile (read in two layouts) and 32 scalars.  Partials have the same layout as k_entropy
-// (sum log q | G[D] | SG | LG[D] | W[K]) and are reduced by k_finalize in a fixed order.
+// MFMA operands are built once per wave and stay in registers; LDS holds only the 16 x D eps tile
+// (read in two layouts), the 64-entry exp table and 16 scalars.  The number of k-tiles KT =
+// ceil(K/16) is a template parameter so the tile body is one straight-line block (4*KT independent
+// exp chains for the scheduler); padded components carry the constant -1e300 and vanish in the exp.
+// sum_i log q'_i is accumulated as a mantissa product + exponent sum (one log per 256 samples).
+// Partials have the same layout as k_entropy (sum log q | G[D] | SG | LG[D] | W[K]) and are reduced
+// by k_finalize in a fixed order.
 #pragma once
-#include "elbo_kernels.h"
+#include "device_math.h"
+#include "elbo_types.h"
 
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
-template <int QS, int KTM, bool GRAD>
+
+template <int QS, int KT, bool GRAD>
 __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
   __shared__ double Et[16 * DP];           // eps tile [i][d]
-  __shared__ double E2[16];                // |eps_i|^2
-  __shared__ double RQ[16];                // 1/q'_i
+  __shared__ double RQ[16];                // q'_i then 1/q'_i
+  __shared__ double TAB[64];               // 2^(j/64)
   const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
-  const int KT = (K + 15) >> 4;
   const int PSg = D + ENTP_EXTRA;
   const double* gp = a.entp + (size_t)r * K * PSg;  // [k][m_1..m_D, h, cK, w, wi]
   const double* pj = gp + (size_t)j * PSg;
   VpLayout L{D, K};
   const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
+  TAB[lane] = c_exp2_tab[lane];
+  const int nr_last = (K - 16 * (KT - 1) + 3) >> 2;  // accumulator registers with a valid component in the last k-tile (1..4)
 
   // ---- mixture-side operand fragments (registers, built once)
-  double SA[KTM][QS];          // S-step "A" operand: comp 16kt + li, inner c = 4q + lg
-  double VB[KTM][4][NPV];      // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD)
-  double WF[KTM][4];           // w_k for comp 16kt + 4r + lg                                  (!GRAD)
+  double SA[KT][QS];          // S-step "A" operand: comp 16kt + li, inner c = 4q + lg
+  double VB[KT][4][NPV];      // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD)
+  double WF[KT][4];           // w_k for comp 16kt + 4r + lg                                  (!GRAD)
 #pragma unroll
-  for (int kt = 0; kt < KTM; ++kt) {
+  for (int kt = 0; kt < KT; ++kt) {
     const int k = 16 * kt + li;
-    const bool kv = (kt < KT) && (k < K);
+    const bool kv = k < K;
     const double* pk = gp + (size_t)(kv ? k : 0) * PSg;
     double h = pk[D];
     double m2 = 0.0;
@@ -68,7 +75,7 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int k2 = 16 * kt + 4 * rr + lg;
-      const bool kv2 = (kt < KT) && (k2 < K);
+      const bool kv2 = k2 < K;
       const double* p2 = gp + (size_t)(kv2 ? k2 : 0) * PSg;
       if (GRAD) {
 #pragma unroll
@@ -76,8 +83,8 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
           const int col = 16 * pv + li;
           double v = 0.0;
           if (kv2) {
-            if (col == 0) v = p2[D + 2];                                   // w_k            -> q'
-            else if (col == 1) v = p2[D + 3];                              // w_k/sigma_k^2  -> A'
+            if (col == 0) v = p2[D + 2];                                        // w_k            -> q'
+            else if (col == 1) v = p2[D + 3];                                   // w_k/sigma_k^2  -> A'
             else if (col < 2 + D) v = p2[D + 3] * (p2[col - 2] - pj[col - 2]);  // -> B'_d
           }
           VB[kt][rr][pv] = v;
@@ -89,11 +96,13 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
   }
 
   double accH = 0.0, accG[NPV], accLG[NPV];
-  double Wacc[KTM][4];
+  double pm = 1.0;            // running product of mantissas of q'
+  int pe = 0, pcnt = 0;       // running sum of exponents
+  double Wacc[KT][4];
 #pragma unroll
   for (int pv = 0; pv < NPV; ++pv) { accG[pv] = 0.0; accLG[pv] = 0.0; }
 #pragma unroll
-  for (int kt = 0; kt < KTM; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = 0.0;
 
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
       }
     }
     __syncthreads();
-    // sample-side fragments for +eps: lane (li, lg) holds a_i[c = 4q + lg]
+    // sample-side fragments: lane (li, lg) holds a_i[c = 4q + lg]
     double ev[QS];
     double e2 = 0.0;
 #pragma unroll
@@ -132,10 +141,9 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
     }
     e2 += __shfl_xor(e2, 16, 64);
     e2 += __shfl_xor(e2, 32, 64);
-    if (lg == 0) E2[li] = e2;
     const double shift = cKj - 0.5 * e2;        // exponent of the sample's own component
     const double u2 = sigj * sigj * e2;         // |u'_i|^2
-    __syncthreads();
+    const bool svalid = b0 + li < a.Mh;
 
 #pragma unroll 1
     for (int sg = 0; sg < 2; ++sg) {
@@ -146,52 +154,74 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
         const int cc = 4 * q + lg;
         sf[q] = (cc < D) ? sgn * ev[q] * sigj : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
       }
-      // ---- S-step + exp
-      double n[KTM][4];
+      // ---- S-step: KT independent accumulator chains, then 4*KT straight-line exps
+      mf4 n[KT];
 #pragma unroll
-      for (int kt = 0; kt < KTM; ++kt) {
-        if (kt < KT) {
-          mf4 acc = {-shift, -shift, -shift, -shift};
+      for (int kt = 0; kt < KT; ++kt) {
+        n[kt] = (mf4){-shift, -shift, -shift, -shift};
 #pragma unroll
-          for (int q = 0; q < QS; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], acc, 0, 0, 0);
+        for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+      }
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) n[kt][rr] = (16 * kt + 4 * rr < K) ? vb_exp(acc[rr]) : 0.0;
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) n[kt][rr] = 0.0;
-        }
+      for (int kt = 0; kt < KT - 1; ++kt) n[kt] = vb_exp_tab4(n[kt], TAB);
+      if (nr_last == 4) {
+        n[KT - 1] = vb_exp_tab4(n[KT - 1], TAB);
+      } else {  // registers whose four components are all padding stay exactly zero
+        mf4 t = n[KT - 1];
+        n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
+        n[KT - 1][0] = vb_exp_tab(t[0], TAB);
+        if (nr_last > 1) n[KT - 1][1] = vb_exp_tab(t[1], TAB);
+        if (nr_last > 2) n[KT - 1][2] = vb_exp_tab(t[2], TAB);
       }
       if (GRAD) {
-        // ---- PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr
-        mf4 Y[NPV];
+        // ---- PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.
+        // Two accumulator sets halve the dependent MFMA chain.
+        mf4 Y[NPV], Y2[NPV];
 #pragma unroll
-        for (int pv = 0; pv < NPV; ++pv) Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0};
+        for (int pv = 0; pv < NPV; ++pv) { Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; Y2[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
-        for (int kt = 0; kt < KTM; ++kt) {
-          if (kt < KT) {
+        for (int kt = 0; kt < KT - 1; ++kt) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              if (16 * kt + 4 * rr < K) {
-#pragma unroll
-                for (int pv = 0; pv < NPV; ++pv)
-                  Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][rr], VB[kt][rr][pv], Y[pv], 0, 0, 0);
-              }
-            }
+          for (int pv = 0; pv < NPV; ++pv) {
+            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][0], VB[kt][0][pv], Y[pv], 0, 0, 0);
+            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][1], VB[kt][1][pv], Y2[pv], 0, 0, 0);
+            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][2], VB[kt][2][pv], Y[pv], 0, 0, 0);
+            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][3], VB[kt][3][pv], Y2[pv], 0, 0, 0);
           }
         }
-        // ---- epilogue in the PV output layout
+#pragma unroll
+        for (int pv = 0; pv < NPV; ++pv) {
+          Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][0], VB[KT - 1][0][pv], Y[pv], 0, 0, 0);
+          if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][1], VB[KT - 1][1][pv], Y2[pv], 0, 0, 0);
+          if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][2], VB[KT - 1][2][pv], Y[pv], 0, 0, 0);
+          if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][3], VB[KT - 1][3][pv], Y2[pv], 0, 0, 0);
+          Y[pv] += Y2[pv];
+        }
+        // ---- per-sample scalars in the sample layout (lane <-> sample li): q' from column 0
+        if (li == 0) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) RQ[lg + 4 * rr] = Y[0][rr];
+        }
+        __syncthreads();
+        const double qs_ = svalid ? RQ[li] : 1.0;
+        const double rqs = svalid ? vb_rcp(qs_) : 0.0;
+        pm *= __builtin_amdgcn_frexp_mant(qs_);   // sum log q' = ln2 * sum exp + log(prod mant)
+        pe += __builtin_amdgcn_frexp_exp(qs_);
+        if (svalid) accH += shift;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
+        __syncthreads();
+        if (lg == 0) RQ[li] = rqs;
+        __syncthreads();
+        // ---- gradient pieces in the PV output layout
         const int base = lane & 48;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int i = lg + 4 * rr;
-          const bool valid = b0 + i < a.Mh;
-          const double qv = __shfl(Y[0][rr], base, 64);        // q'_i  (column 0)
           const double Av = __shfl(Y[0][rr], base | 1, 64);    // A'_i  (column 1)
-          const double rq = valid ? 1.0 / qv : 0.0;
-          if (li == 0) {
-            RQ[i] = rq;
-            if (valid) accH += (cKj - 0.5 * E2[i]) + log(qv);  // log q - log nf  (entmc_vbmc.m:67)
-          }
+          const double rq = RQ[i];
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv) {
             const int d = 16 * pv + li - 2;
@@ -204,24 +234,28 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
           }
         }
         __syncthreads();
-        const double rqs = RQ[li];
-#pragma unroll
-        for (int kt = 0; kt < KTM; ++kt)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
-        __syncthreads();
       } else {
         double qp = 0.0;
 #pragma unroll
-        for (int kt = 0; kt < KTM; ++kt)
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
         qp += __shfl_xor(qp, 16, 64);
         qp += __shfl_xor(qp, 32, 64);
-        if (lg == 0 && b0 + li < a.Mh) accH += shift + log(qp);
+        const double qs_ = svalid ? qp : 1.0;
+        pm *= __builtin_amdgcn_frexp_mant(qs_);
+        pe += __builtin_amdgcn_frexp_exp(qs_);
+        if (svalid) accH += shift;
+      }
+      // fold the mantissa product before it can underflow (0.5^256 = 8.6e-78)
+      if (++pcnt == 256) {
+        accH += log(pm) + 0.693147180559945309417 * (double)pe;
+        pm = 1.0; pe = 0; pcnt = 0;
       }
     }
   }
+  accH += log(pm) + 0.693147180559945309417 * (double)pe;
+  if (lg != 0) accH = 0.0;   // the four lanes of a sample hold identical copies: count one
 
   // ---- fixed-order reductions and the partial record
   double* o = a.part + (((size_t)r * K + j) * a.C + c) * a.ncol;
@@ -242,7 +276,7 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
     sgsum = wave_sum(sgsum);            // SG = sum_d LG_d  (entmc_vbmc.m:87)
     if (lane == 0) o[1 + D] = sgsum;
 #pragma unroll
-    for (int kt = 0; kt < KTM; ++kt)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         double wv = Wacc[kt][rr];
