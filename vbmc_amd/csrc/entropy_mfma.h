@@ -18,7 +18,7 @@
 // MFMA operands are built once per wave and stay in registers; LDS holds only the 16 x D eps tile
 // (read in two layouts), the 64-entry exp table and 16 scalars.  The number of k-tiles KT =
 // ceil(K/16) is a template parameter so the tile body is one straight-line block (4*KT independent
-// exp chains for the scheduler); padded components carry the constant -1e300 and vanish in the exp.
+// exp chains for the scheduler); padded components carry the constant -1e6 and vanish in the exp.
 // sum_i log q'_i is accumulated as a mantissa product + exponent sum (one log per 256 samples).
 // Partials have the same layout as k_entropy (sum log q | G[D] | SG | LG[D] | W[K]) and are reduced
 // by k_finalize in a fixed order.
@@ -30,7 +30,7 @@ typedef double mf4 __attribute__((ext_vector_type(4)));
 
 
 template <int QS, int KT, bool GRAD>
-__global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
+__global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_entropy_mfma(EntArgs a) {
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
   __shared__ double Et[16 * DP];           // eps tile [i][d]
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(WAVE) k_entropy_mfma(EntArgs a) {
     for (int q = 0; q < QS; ++q) {
       const int cc = 4 * q + lg;
       double v;
-      if (!kv) v = (cc == D + 1) ? -1.0e300 : 0.0;          // padded component: exp -> 0
+      if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;            // padded component: exp -> 0
       else if (cc < D) v = -2.0 * h * (pk[cc] - pj[cc]);     // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
       else if (cc == D) v = h;
       else if (cc == D + 1) v = fma(h, m2, pk[D + 1]);       // -D ln sigma_k - |m'_k|^2/(2 sigma_k^2)
