@@ -100,6 +100,15 @@ vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanf
 vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
                          int ssflag, double* ymu, double* ys2, double* fmu, double* fs2);
 
+/*
+ * The O(N^2) pieces of gplite_post's rank-1 append of one training point x* (gplite/gplite_post.m:173-251),
+ * for every hyper-sample: Ks = k(X, x*) (N x S); for Lchol samples v = L' \ Ks and x = L \ v, so that
+ * alpha_update = x / sn2_eff (:227) and the new column of L is v / sn2_eff (:228); for low-noise samples
+ * x = L * Ks (alpha_update = -x, :234).  The O(N) assembly of the enlarged posterior is the caller's.
+ */
+vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, double* Ks, double* v,
+                                 double* x);
+
 /* C = sq_dist(a, b)   (utils/sq_dist.m:14-50): a is D x n, b is D x m (NULL -> b = a), C is n x m.
  * The a'b contraction runs on v_mfma_f64_16x16x4_f64. */
 vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const double* a, const double* b, double* C);

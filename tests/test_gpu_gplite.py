@@ -118,3 +118,20 @@ def test_posterior_feeds_elbo_without_reupload(va):
     out = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 0, 1, nargout=11)
     r = R.negelcbo_vbmc(theta, 0, vp, ref, 0, False, 1, separate_K=True)
     assert relerr(out[2], r["G"]) < 1e-7 and relerr(out[7], r["varG"]) < 1e-5
+
+
+def test_rank1_update_equals_full_posterior(va):
+    """gplite/gplite_test.m:87-105 property: appending a point by the rank-1 path == full recompute."""
+    p = synth_problem(24, 4, 45, 3, 3)
+    gp_small = va.gplite_post(p["hyp"], p["X"][:-1], p["y"][:-1], 1, 4)
+    gp_r1 = va.gplite_post_rank1(gp_small, p["X"][-1], p["y"][-1])
+    gp_full = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 4)
+    ref_r1 = R.gplite_post_rank1(R.gplite_post(p["hyp"], p["X"][:-1], p["y"][:-1], meanfun=4), p["X"][-1], p["y"][-1])
+    for a, b, c in zip(gp_r1["post"], gp_full["post"], ref_r1["post"]):
+        assert a["alpha"].shape == (45,) and a["L"].shape == (45, 45) and a["sW"].shape == (45,)
+        assert relerr(a["alpha"], c["alpha"]) < 1e-7 and relerr(a["L"], c["L"]) < 1e-8  # vs the oracle's rank-1
+        assert relerr(a["alpha"], b["alpha"]) < 1e-6 and relerr(a["L"], b["L"]) < 1e-7  # vs the full update
+    # the enlarged posterior is usable downstream
+    o = va.gplite_pred(gp_r1, p["X"][:5] + 0.1, None, None, False)
+    r = R.gplite_pred(R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4), p["X"][:5] + 0.1)
+    assert relerr(o[2], r[2]) < 1e-6

@@ -305,3 +305,42 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
   }
   return VBMC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// The O(N^2) pieces of the rank-1 append (gplite_post.m:210-237) for every hyper-sample:
+//   Ks = k(X, x*);  Lchol: v = L' \ Ks, x = L \ v  (alpha_update = x / sn2_eff, new column = v / sn2_eff)
+//                   else : x = L * Ks               (alpha_update = -x)
+// The O(N) assembly of the new alpha / L / sW stays with the caller (vbmc_amd/gplite.py, the MEX shim).
+extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, double* Ks,
+                                            double* v, double* x) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp || !xstar || !Ks || !v || !x) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves: null argument");
+  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves needs gp.post(s).L on the device");
+  const int N = gp->N, D = gp->D, S = gp->S;
+  const size_t tlds = ((size_t)N * 16 + 256) * 8;
+  if (tlds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  TmpBuf dxs, dKs, dV, dXo;
+  HIP_TRY(ctx, dxs.alloc((size_t)D * 8));
+  HIP_TRY(ctx, dKs.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dV.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dXo.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(dxs.p, xstar, (size_t)D * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_gp_ks, dim3(4, S), dim3(256), 0, st, N, D, gp->Nhyp, gp->X, dxs.as<double>(), gp->hyp, gp->d_meanX, dKs.as<double>());
+  HIP_TRY(ctx, hipMemcpyAsync(dV.p, dKs.p, (size_t)S * N * 8, hipMemcpyDeviceToDevice, st));
+  if (tlds > 64 * 1024) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+  }
+  // Lchol samples: triangular solves; the others (flag 0) are skipped by the kernels and handled by k_symm
+  hipLaunchKernelGGL(k_symm, dim3(8, S, 1), dim3(256), 0, st, N, 1, S, gp->L, gp->d_lchol, dKs.as<double>(), dXo.as<double>());
+  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, gp->L, gp->d_lchol, dV.as<double>());
+  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, gp->L, gp->d_lchol, dV.as<double>(), dXo.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(Ks, dKs.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(v, dV.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(x, dXo.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return VBMC_OK;
+}

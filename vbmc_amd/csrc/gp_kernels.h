@@ -411,3 +411,33 @@ __global__ void k_pred_avg(int Nstar, int S, const double* __restrict__ fmu, con
   out[i + 2 * (size_t)Nstar] = fbar;          // fmu
   out[i + 3 * (size_t)Nstar] = f2 / S + vf;   // fs2
 }
+
+// Cross-covariance column for the rank-1 update (gplite_post.m:210-216): Ks[s][n] = k_s(X_n, x*),
+// with sq_dist's two-argument centring for m = 1 test point.
+__global__ void __launch_bounds__(256) k_gp_ks(int N, int D, int Nhyp, const double* __restrict__ X,
+                                               const double* __restrict__ xstar, const double* __restrict__ hyp,
+                                               const double* __restrict__ meanX, double* __restrict__ Ks) {
+  const int s = blockIdx.y;
+  const double* h = hyp + (size_t)s * Nhyp;
+  __shared__ double ell[32], mu[32], xs[32];
+  if (threadIdx.x < D) {
+    const int d = threadIdx.x;
+    ell[d] = exp(h[d]);
+    const double n = (double)N, m = 1.0;
+    mu[d] = (m / (n + m)) * (xstar[d] / ell[d]) + (n / (n + m)) * (meanX[d] / ell[d]);
+    xs[d] = xstar[d] / ell[d] - mu[d];
+  }
+  __syncthreads();
+  const double sf2 = exp(2.0 * h[D]);
+  double bb = 0.0;
+  for (int d = 0; d < D; ++d) bb = fma(xs[d], xs[d], bb);
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    double aa = 0.0, dot = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double av = X[n + (size_t)N * d] / ell[d] - mu[d];
+      aa = fma(av, av, aa);
+      dot = fma(av, xs[d], dot);
+    }
+    Ks[(size_t)s * N + n] = sf2 * exp(-fmax(aa + (bb - 2.0 * dot), 0.0) / 2.0);
+  }
+}

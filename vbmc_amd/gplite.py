@@ -115,3 +115,61 @@ def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nowarpflag=Fal
                                    ptr(outs[2]), ptr(outs[3])))
     outs = [o.reshape(shape, order="F") if per else o for o in outs]
     return tuple(outs[: max(1, nargout)])
+
+
+def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, engine=None):
+    """gp = gplite_post(gp, xstar, ystar, [], [], [], [], 1): rank-1 append of one observation
+    (gplite/gplite_post.m:173-251).  Falls back to the full update when ``s2`` is present, as the
+    reference does (:76-79)."""
+    import copy
+    import math
+
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    xstar = np.asarray(xstar, dtype=np.float64).reshape(1, -1)
+    ystar = float(np.asarray(ystar).reshape(-1)[0])
+    if gp.get("s2") is not None or s2star is not None:  # heteroskedastic noise: standard update (:76-79,86-90)
+        hyp = np.stack([p["hyp"] for p in gp["post"]], axis=1)
+        s2new = np.concatenate([gp["s2"], [float(np.asarray(s2star).reshape(-1)[0])]])
+        return gplite_post(hyp, np.vstack([gp["X"], xstar]), np.concatenate([gp["y"], [ystar]]), 1, gp["meanfun"],
+                           gp["noisefun"], s2new, engine=engine)
+    N, D = np.asarray(gp["X"]).shape
+    S = len(gp["post"])
+    ymu, ys2, _, _ = gplite_pred(gp, xstar, np.array([ystar]), None, True, engine=engine)  # :189 (mstar, vstar)
+    mstar, vstar = np.asarray(ymu).reshape(S), np.asarray(ys2).reshape(S)
+    dgp = _device_gp_with_noise(engine, gp)
+    Ks = np.zeros((N, S), order="F")
+    v = np.zeros((N, S), order="F")
+    x = np.zeros((N, S), order="F")
+    ctx.check(ctx.lib.vbmc_gp_rank1_solves(ctx.h, dgp.h, ptr(f64(xstar.reshape(-1))), ptr(Ks), ptr(v), ptr(x)))
+    out = copy.deepcopy(gp)
+    Ncov = gp["Ncov"]
+    for s, post in enumerate(out["post"]):
+        hyp = post["hyp"]
+        sn2 = math.exp(2.0 * hyp[Ncov]) if gp["noisefun"][0] == 1 else float(np.finfo(np.float64).eps)
+        if len(gp["noisefun"]) > 2 and gp["noisefun"][2] == 1:
+            off = Ncov + (1 if gp["noisefun"][0] == 1 else 0) + (1 if gp["noisefun"][1] == 2 else 0)
+            sn2 += math.exp(2.0 * hyp[off + 1]) * max(0.0, hyp[off] - ystar) ** 2
+        sn2_eff = sn2 * post["sn2_mult"]                                              # :207
+        Kss = math.exp(2.0 * hyp[D])                                                  # :213
+        L = post["L"]
+        newL = np.zeros((N + 1, N + 1))
+        if post["Lchol"]:
+            alpha_update = x[:, s] / sn2_eff                                          # :227
+            col = v[:, s] / sn2_eff                                                   # :228-229
+            newL[:N, :N] = L
+            newL[:N, N] = col
+            newL[N, N] = math.sqrt(1.0 + Kss / sn2_eff - float(col @ col))            # :232
+        else:
+            alpha_update = -x[:, s]                                                   # :234
+            vv = -alpha_update / vstar[s]
+            newL[:N, :N] = L + np.outer(vv, alpha_update)
+            newL[:N, N] = -vv
+            newL[N, :N] = -vv
+            newL[N, N] = -1.0 / vstar[s]                                              # :236
+        post["L"] = newL
+        post["sW"] = np.concatenate([post["sW"], [1.0 / math.sqrt(sn2_eff)]])         # :239
+        post["alpha"] = np.concatenate([post["alpha"], [0.0]]) + (mstar[s] - ystar) / vstar[s] * np.concatenate([alpha_update, [-1.0]])
+    out["X"] = np.vstack([gp["X"], xstar])
+    out["y"] = np.concatenate([gp["y"], [ystar]])
+    return out
