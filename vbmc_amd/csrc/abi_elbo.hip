@@ -405,7 +405,7 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     int tpc = (ntile + C - 1) / C;
     C = (ntile + tpc - 1) / tpc;
     const int ncol = compute_grad ? (2 + 2 * D + K) : 1;
-    { vbmc_status s_ = ensure(ctx, ctx->entpart, (size_t)R * K * C * ncol * sizeof(double)); if (s_) return s_; }
+    { vbmc_status s_ = ensure(ctx, ctx->entpart, ((size_t)R * K * C * ncol + (size_t)R * K * ncol) * sizeof(double)); if (s_) return s_; }
     EntArgs ea{};
     ea.entp = d_entp; ea.vpd = d_vpd; ea.part = (double*)ctx->entpart.p;
     ea.D = D; ea.K = K; ea.Mh = Mh; ea.C = C; ea.tiles_per_chunk = tpc; ea.ncol = ncol; ea.seed = a->seed;
@@ -437,7 +437,10 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
       });
       if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     }
-    fa.entpart = ea.part; fa.entlb = nullptr; fa.M = Mh; fa.C = C; fa.ncol = ncol;
+    // chunk partials -> one record per (r, j), summed in chunk order
+    double* d_red = ea.part + (size_t)R * K * C * ncol;
+    hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(ncol >= 192 ? 256 : (ncol >= 96 ? 128 : 64)), 0, st, C, ncol, ea.part, d_red);
+    fa.entpart = d_red; fa.entlb = nullptr; fa.M = Mh; fa.C = 1; fa.ncol = ncol;
   } else {
     const size_t ebs = 1 + (size_t)D * K + 2 * K + D;
     { vbmc_status s_ = ensure(ctx, ctx->entpart, (size_t)R * ebs * sizeof(double)); if (s_) return s_; }

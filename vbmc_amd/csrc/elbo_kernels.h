@@ -463,6 +463,31 @@ __global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// k_ent_reduce: sum the per-chunk entropy partials over chunks, in chunk order, one thread per
+// column: red[r][j][col] = sum_c part[r][j][c][col].  Keeps k_finalize's latency independent of the
+// chunk count (which is large when few restarts must still fill the chip).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const double* __restrict__ part,
+                                                    double* __restrict__ red) {
+  const int j = blockIdx.x, r = blockIdx.y, K = gridDim.x;
+  const double* p = part + ((size_t)r * K + j) * C * ncol;
+  double* o = red + ((size_t)r * K + j) * ncol;
+  for (int col = threadIdx.x; col < ncol; col += blockDim.x) {
+    double acc = 0.0;
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+      double v0 = p[(size_t)(c + 0) * ncol + col], v1 = p[(size_t)(c + 1) * ncol + col];
+      double v2 = p[(size_t)(c + 2) * ncol + col], v3 = p[(size_t)(c + 3) * ncol + col];
+      double v4 = p[(size_t)(c + 4) * ncol + col], v5 = p[(size_t)(c + 5) * ncol + col];
+      double v6 = p[(size_t)(c + 6) * ncol + col], v7 = p[(size_t)(c + 7) * ncol + col];
+      acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+    }
+    for (; c < C; ++c) acc += p[(size_t)c * ncol + col];
+    o[col] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_finalize: reduce partials in a fixed order, apply Jacobians (gplogjoint.m:352-373,
 // entmc_vbmc.m:106-125), average over hyper-samples (gplogjoint.m:399-413), add the soft-bound
 // and weight penalties (negelcbo_vbmc.m:116-164), pack to theta order.
