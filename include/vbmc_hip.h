@@ -160,6 +160,20 @@ typedef struct vbmc_elbo_args {
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
 
+/*
+ * [x,f,xtab,ftab,iter] = fminadam(@(t) negelcbo_vbmc(t,beta,vp,gp,Ns,1,compute_var,~,thetabnd), x0, [], [],
+ *                                 TolFun, MaxIter, master_stepsize)          (utils/fminadam.m:1-104,
+ * call site misc/vpoptimize_vbmc.m:127) for R chains in lock-step, entirely on the device: per
+ * iteration one batched ELBO+grad pass and the Adam update (:48-61), every 20 iterations the slope /
+ * random-walk stopping test (:65-81); the host only polls R flags on those iterations.  args->theta
+ * holds the R starting points x0 (T x R); args->seed + iter keys the MC draws of iteration iter
+ * (eps_mode must be 0).  Outputs (any may be NULL): x T x R (mean of the last 20 iterates, :96),
+ * f R (:97), iters R, xtab T x MaxIter x R and ftab MaxIter x R (first iters(r) entries filled).
+ */
+vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, double TolFun, int MaxIter,
+                            double step_min, double step_max, double step_decay, double* x, double* f, int32_t* iters,
+                            double* xtab, double* ftab);
+
 /* Writes the exact standard-normal block eps (D x Ns/2 x K x R) that eps_mode 0 consumes for
  * `seed`, so that a host oracle can be fed the same draws (test hook; entmc_vbmc.m:53). */
 vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t seed, double* eps_host);

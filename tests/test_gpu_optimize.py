@@ -73,3 +73,28 @@ def test_vpoptimize_improves_elbo(va):
     assert abs(np.sum(vp2["w"]) - 1) < 1e-12 and abs(np.sum(vp2["lambda"] ** 2) - 3) < 1e-9
     assert vp2["stats"]["elbo"] > -f0 - 1.0  # optimisation did not make things (much) worse than the start
     assert vp2["stats"]["I_sk"].shape == (2, 3) and vp2["stats"]["J_sjk"].shape == (2, 3, 3)
+
+
+def test_device_adam_equals_host_adam(va):
+    """vbmc_adam_batch (whole loop on the device) vs utils/fminadam.m's loop on the host calling the same
+    device objective with the same per-iteration seeds: identical stopping iteration, iterates to round-off."""
+    p, gp, vp, theta = problem(34, 4, 50, 5, 3)
+    opts = dict(TolLength=1e-6, TolWeight=1e-2, TolConLoss=0.01, WeightPenalty=0.1)
+    vpb, tb = R.vpbounds(vp, gp, opts)
+    Ns, seed, MaxIter = 60, 77, 200
+    it = {"n": 0}
+
+    def fun(x):
+        it["n"] += 1
+        r = va.negelcbo_batch(x, 0, vpb, gp, Ns, True, 0, tb, seed=seed + it["n"])
+        return float(r["F"][0]), r["dF"][:, 0]
+
+    xh, fh, xth, fth, ith = va.fminadam(fun, theta, None, None, 1e-3, MaxIter)
+    xd, fd, xtd, ftd, itd = va.fminadam_device(theta, 0, vpb, gp, Ns, tb, 1e-3, MaxIter, seed=seed)
+    assert int(itd[0]) == ith
+    assert relerr(ftd[0], fth) < 1e-9 and relerr(xtd[0], xth) < 1e-9
+    assert relerr(xd[:, 0], xh) < 1e-9 and abs(fd[0] - fh) < 1e-9 * max(1, abs(fh))
+    # two chains in lock-step == the same chains run alone
+    x2 = np.stack([theta, theta + 0.05], axis=1)
+    xb, fb, xtb, ftb, itb = va.fminadam_device(x2, 0, vpb, gp, Ns, tb, 1e-3, 80, seed=seed)
+    assert relerr(ftb[0][: min(80, ith)], fth[: min(80, ith)]) < 1e-9

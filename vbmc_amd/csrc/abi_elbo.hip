@@ -278,12 +278,28 @@ static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out) {
 // ------------------------------------------------------------------------------------------
 // vbmc_elbo_batch
 // ------------------------------------------------------------------------------------------
-extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a) {
-  if (!ctx) return VBMC_ERR_INVALID;
+// Everything one evaluation pass needs, resolved once: dims, device pointers, launch geometry.
+struct ElboPlan {
+  ElboDims dm{};
+  int compute_grad = 0, compute_var = 0, dt = 0;
+  double beta = 0.0;
+  bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false;
+  int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, var_stride = 0;
+  size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0;
+  double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
+  double *d_vpd = nullptr, *d_entp = nullptr, *d_lj = nullptr, *d_out = nullptr, *d_part = nullptr, *d_red = nullptr;
+  double *d_Z = nullptr, *d_X = nullptr, *d_J = nullptr, *d_vg = nullptr, *d_var = nullptr;
+  const double* d_eps = nullptr;
+  long long eps_stride_r = 0;
+  double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0;
+};
+
+// Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
+static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
   if (a->struct_size != sizeof(vbmc_elbo_args))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(vbmc_elbo_args));
-  ElboDims dm{};
+  ElboDims& dm = P.dm;
   dm.D = a->D; dm.K = a->K; dm.R = a->R; dm.S = gp->S; dm.N = gp->N;
   if (dm.D != gp->D) return set_err(ctx, VBMC_ERR_INVALID, "vp.D = %d but gp has D = %d", dm.D, gp->D);
   if (dm.K <= 0 || dm.R <= 0) return set_err(ctx, VBMC_ERR_INVALID, "K and R must be positive");
@@ -300,8 +316,8 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   if (T > 0 && !a->theta) return set_err(ctx, VBMC_ERR_INVALID, "theta is null");
   if ((!dm.opt[0] && !a->vp_mu) || (!dm.opt[1] && !a->vp_sigma) || (!dm.opt[2] && !a->vp_lambda) || (!dm.opt[3] && !a->vp_w))
     return set_err(ctx, VBMC_ERR_INVALID, "a vp field is required for every group that is not optimised");
-  const int compute_grad = a->compute_grad ? 1 : 0;
-  const int compute_var = a->compute_var;
+  const int compute_grad = P.compute_grad = a->compute_grad ? 1 : 0;
+  const int compute_var = P.compute_var = a->compute_var;
   if (compute_var < 0 || compute_var > 2) return set_err(ctx, VBMC_ERR_INVALID, "compute_var must be 0, 1 or 2");
   // negelcbo_vbmc.m:21-24
   if (compute_grad && a->beta != 0.0 && compute_var != 2)
@@ -315,35 +331,37 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     return set_err(ctx, VBMC_ERR_INVALID, "compute_var != 0 needs gp.post(s).L: upload the GP with L");
   if (compute_var != 0 && ((size_t)dm.N * 16 + 256) * sizeof(double) > 160 * 1024)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1264 not accelerated", dm.N);
-  if (a->beta != 0.0 && !std::isfinite(a->beta)) { /* negelcbo_vbmc.m:15: non-finite beta -> 0 */ }
-  const double beta = (std::isfinite(a->beta)) ? a->beta : 0.0;
-  // theta must be finite (device exp() clamps would swallow NaN)
+  P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
+  // theta must be finite (the device exp does not propagate NaN)
   for (size_t i = 0; i < (size_t)T * R; ++i)
     if (!std::isfinite(a->theta[i])) return set_err(ctx, VBMC_ERR_INVALID, "theta contains a non-finite value at linear index %zu", i);
 
   int M = a->Ns;
   if (M < 0) return set_err(ctx, VBMC_ERR_INVALID, "Ns must be >= 0");
   M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
-  const int Mh = M / 2;
-  const bool mc = M > 0;
-  if (!mc && K > 128) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "entlb with K > 128 not accelerated");
-  if (mc && a->eps_mode != 0 && !a->eps) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode %d needs eps", a->eps_mode);
-  const int dt = pick_dt(D);
+  const int Mh = P.Mh = M / 2;
+  P.mc = M > 0;
+  if (!P.mc && K > 128) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "entlb with K > 128 not accelerated");
+  if (P.mc && a->eps_mode != 0 && !a->eps) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode %d needs eps", a->eps_mode);
+  if (a->eps_mode < 0 || a->eps_mode > 2) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode must be 0, 1 or 2");
+  P.dt = pick_dt(D);
+  if (P.dt < 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d not accelerated", D);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   VpLayout VL{D, K};
 
   // ---- uploads: theta, fixed vp, delta^2, bounds (one pinned staging buffer, one H2D)
-  const size_t n_theta = (size_t)T * R;
+  const size_t n_theta = P.n_theta = (size_t)T * R;
   const size_t n_fix = (size_t)D * K + 2 * K + D;
   const size_t n_delta = D;
   const int next_mu = dm.opt[0] ? D * K : 0;
   const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
   const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
-  const bool has_bnd = a->bnd_lb != nullptr && a->bnd_ub != nullptr;
-  const size_t n_bnd = has_bnd ? 2 * (size_t)Text : 0;
-  const size_t n_up = n_theta + n_fix + n_delta + n_bnd;
-  { vbmc_status s_ = ensure_pin(ctx, (n_up + (size_t)R * (OUT_HDR + 3 * T) + (size_t)S * K * R) * sizeof(double)); if (s_) return s_; }
+  P.has_bnd = a->bnd_lb != nullptr && a->bnd_ub != nullptr;
+  const size_t n_bnd = P.has_bnd ? 2 * (size_t)Text : 0;
+  const size_t n_up = P.n_up = n_theta + n_fix + n_delta + n_bnd;
+  P.out_n = (size_t)R * (OUT_HDR + 3 * T);
+  { vbmc_status s_ = ensure_pin(ctx, (n_up + P.out_n + (size_t)S * K * R) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->theta, n_up * sizeof(double)); if (s_) return s_; }
   double* hp = (double*)ctx->pin;
   if (n_theta) memcpy(hp, a->theta, n_theta * sizeof(double));
@@ -355,145 +373,159 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   if (a->vp_w) memcpy(hfix + D * K + K + D, a->vp_w, K * sizeof(double));
   double* hdel = hfix + n_fix;
   for (int d = 0; d < D; ++d) hdel[d] = a->vp_delta ? a->vp_delta[d] * a->vp_delta[d] : 0.0;
-  if (has_bnd) {
+  if (P.has_bnd) {
     memcpy(hdel + n_delta, a->bnd_lb, Text * sizeof(double));
     memcpy(hdel + n_delta + Text, a->bnd_ub, Text * sizeof(double));
   }
-  double* d_theta = (double*)ctx->theta.p;
-  double* d_fix = d_theta + n_theta;
-  double* d_delta2 = d_fix + n_fix;
-  double* d_bnd = d_delta2 + n_delta;
-  HIP_TRY(ctx, hipMemcpyAsync(d_theta, hp, n_up * sizeof(double), hipMemcpyHostToDevice, st));
+  P.d_theta = (double*)ctx->theta.p;
+  P.d_fix = P.d_theta + n_theta;
+  P.d_delta2 = P.d_fix + n_fix;
+  P.d_bnd = P.has_bnd ? P.d_delta2 + n_delta : nullptr;
+  HIP_TRY(ctx, hipMemcpyAsync(P.d_theta, hp, n_up * sizeof(double), hipMemcpyHostToDevice, st));
+  P.TolCon = a->TolCon; P.WeightThreshold = a->WeightThreshold; P.WeightPenalty = a->WeightPenalty;
 
   // ---- scratch
   { vbmc_status s_ = ensure(ctx, ctx->prep, (size_t)R * VL.stride() * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->entp, (size_t)R * K * (D + ENTP_EXTRA) * sizeof(double)); if (s_) return s_; }
   const int LJS = 2 * D + 2;
   { vbmc_status s_ = ensure(ctx, ctx->ljpart, (size_t)R * S * K * LJS * sizeof(double)); if (s_) return s_; }
-  const size_t out_n = (size_t)R * (OUT_HDR + 3 * T);
-  { vbmc_status s_ = ensure(ctx, ctx->out, out_n * sizeof(double)); if (s_) return s_; }
-  double* d_vpd = (double*)ctx->prep.p;
-  double* d_entp = (double*)ctx->entp.p;
-  double* d_lj = (double*)ctx->ljpart.p;
-  double* d_out = (double*)ctx->out.p;
+  { vbmc_status s_ = ensure(ctx, ctx->out, P.out_n * sizeof(double)); if (s_) return s_; }
+  P.d_vpd = (double*)ctx->prep.p;
+  P.d_entp = (double*)ctx->entp.p;
+  P.d_lj = (double*)ctx->ljpart.p;
+  P.d_out = (double*)ctx->out.p;
 
-  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, d_theta, d_fix, d_vpd, d_entp);
+  if (P.mc) {
+    const char* force = getenv("VBMC_ENT_KERNEL");  // "valu" (A/B testing); default: the MFMA kernel when it fits
+    P.use_mfma = mfma_entropy_fits(D, K, &P.qs, &P.kt);
+    if (force && !strcmp(force, "valu")) P.use_mfma = false;
+    const int tile_sz = P.use_mfma ? 16 : 32;          // base samples per tile
+    const int ntile = (Mh + tile_sz - 1) / tile_sz;
+    // enough waves to fill the chip several times over
+    long long target = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5) * 4;
+    int C = (int)((target + (long long)K * R - 1) / ((long long)K * R));
+    if (C < 1) C = 1;
+    if (C > ntile) C = ntile;
+    P.tpc = (ntile + C - 1) / C;
+    P.C = (ntile + P.tpc - 1) / P.tpc;
+    P.ncol = compute_grad ? (2 + 2 * D + K) : 1;
+    { vbmc_status s_ = ensure(ctx, ctx->entpart, ((size_t)R * K * P.C * P.ncol + (size_t)R * K * P.ncol) * sizeof(double)); if (s_) return s_; }
+    P.d_part = (double*)ctx->entpart.p;
+    P.d_red = P.d_part + (size_t)R * K * P.C * P.ncol;
+    const size_t eps_block = (size_t)D * Mh * K;
+    if (a->eps_mode == 1) {
+      const size_t n_eps = eps_block * (a->eps_shared ? 1 : (size_t)R);
+      { vbmc_status s_ = ensure(ctx, ctx->eps, n_eps * sizeof(double)); if (s_) return s_; }
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->eps.p, a->eps, n_eps * sizeof(double), hipMemcpyHostToDevice, st));
+      P.d_eps = (const double*)ctx->eps.p; P.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
+    } else if (a->eps_mode == 2) {
+      P.d_eps = a->eps; P.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
+    }
+    if (!P.use_mfma) {
+      P.ent_lds = ((size_t)K * (P.dt + ENTP_EXTRA) + WAVE + (compute_grad ? (size_t)K * 65 : 0)) * sizeof(double);
+      if (P.ent_lds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d needs %zu B of LDS (> 160 KiB)", K, D, P.ent_lds);
+    }
+  } else {
+    const size_t ebs = 1 + (size_t)D * K + 2 * K + D;
+    { vbmc_status s_ = ensure(ctx, ctx->entpart, (size_t)R * ebs * sizeof(double)); if (s_) return s_; }
+    P.d_part = (double*)ctx->entpart.p;
+  }
+  if (compute_var != 0) {
+    const int N = dm.N;
+    P.var_stride = 2 + T;
+    P.vgrad = compute_grad && compute_var == 2;
+    for (int s = 0; s < S; ++s) P.any_nochol |= (gp->Lchol[s] == 0);
+    const size_t nz = (size_t)R * S * K * N;
+    { vbmc_status s_ = ensure(ctx, ctx->zbuf, nz * sizeof(double)); if (s_) return s_; }
+    const size_t nJ = (size_t)R * S * K * K, nvg = (size_t)R * S * K * (2 * D + 1), nvo = (size_t)R * P.var_stride;
+    P.needX = P.vgrad || P.any_nochol;
+    { vbmc_status s_ = ensure(ctx, ctx->varbuf, ((P.needX ? nz : 0) + nJ + nvg + nvo) * sizeof(double)); if (s_) return s_; }
+    P.d_Z = (double*)ctx->zbuf.p;
+    P.d_X = (double*)ctx->varbuf.p;
+    P.d_J = P.d_X + (P.needX ? nz : 0);
+    P.d_vg = P.d_J + nJ;
+    P.d_var = P.d_vg + nvg;
+    P.tlds = ((size_t)N * 16 + 256) * sizeof(double);
+  }
+  return VBMC_OK;
+}
+
+// Enqueue one evaluation pass on the context's stream: reads theta from P.d_theta, leaves the packed
+// results [F G H varG varGss | dF dG dH] per restart in P.d_out.  No host synchronisation.
+static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan& P, unsigned long long seed) {
+  const ElboDims& dm = P.dm;
+  const int D = dm.D, K = dm.K, R = dm.R, S = dm.S, T = dm.T;
+  const int dt = P.dt;
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp);
 
   // ---- expected log joint
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
   DISPATCH_DT(dt, {
-    hipLaunchKernelGGL((k_logjoint<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, d_vpd, gp->X, gp->alpha, gp->gpc,
-                       d_delta2, d_lj, compute_grad);
+    hipLaunchKernelGGL((k_logjoint<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
+                       P.d_delta2, P.d_lj, P.compute_grad);
   });
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
 
   // ---- entropy
   FinArgs fa{};
   fa.dm = dm;
-  if (mc) {
-    int qs = 0, ktm = 0;
-    const char* force = getenv("VBMC_ENT_KERNEL");  // "valu" | "mfma" (A/B testing); default: mfma when it fits
-    bool use_mfma = mfma_entropy_fits(D, K, &qs, &ktm);
-    if (force && !strcmp(force, "valu")) use_mfma = false;
-    const int tile_sz = use_mfma ? 16 : 32;          // base samples per tile
-    const int ntile = (Mh + tile_sz - 1) / tile_sz;
-    // enough waves to fill the chip several times over
-    long long target = (long long)ctx->num_cu * (use_mfma ? 8 : 5) * 4;
-    int C = (int)((target + (long long)K * R - 1) / ((long long)K * R));
-    if (C < 1) C = 1;
-    if (C > ntile) C = ntile;
-    int tpc = (ntile + C - 1) / C;
-    C = (ntile + tpc - 1) / tpc;
-    const int ncol = compute_grad ? (2 + 2 * D + K) : 1;
-    { vbmc_status s_ = ensure(ctx, ctx->entpart, ((size_t)R * K * C * ncol + (size_t)R * K * ncol) * sizeof(double)); if (s_) return s_; }
+  if (P.mc) {
     EntArgs ea{};
-    ea.entp = d_entp; ea.vpd = d_vpd; ea.part = (double*)ctx->entpart.p;
-    ea.D = D; ea.K = K; ea.Mh = Mh; ea.C = C; ea.tiles_per_chunk = tpc; ea.ncol = ncol; ea.seed = a->seed;
-    const size_t eps_block = (size_t)D * Mh * K;
-    if (a->eps_mode == 0) {
-      ea.eps = nullptr; ea.eps_stride_r = 0;
-    } else if (a->eps_mode == 1) {
-      const size_t n_eps = eps_block * (a->eps_shared ? 1 : (size_t)R);
-      { vbmc_status s_ = ensure(ctx, ctx->eps, n_eps * sizeof(double)); if (s_) return s_; }
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->eps.p, a->eps, n_eps * sizeof(double), hipMemcpyHostToDevice, st));
-      ea.eps = (const double*)ctx->eps.p; ea.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
-    } else if (a->eps_mode == 2) {
-      ea.eps = a->eps; ea.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
-    } else {
-      return set_err(ctx, VBMC_ERR_INVALID, "eps_mode must be 0, 1 or 2");
-    }
-    if (use_mfma) {
-      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-      bool ok = launch_entropy_mfma(qs, ktm, compute_grad != 0, dim3(C, K, R), st, ea);
+    ea.entp = P.d_entp; ea.vpd = P.d_vpd; ea.part = P.d_part;
+    ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = P.C; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
+    ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r;
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    if (P.use_mfma) {
+      bool ok = launch_entropy_mfma(P.qs, P.kt, P.compute_grad != 0, dim3(P.C, K, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
-      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     } else {
-      size_t lds = ((size_t)K * (dt + ENTP_EXTRA) + WAVE + (compute_grad ? (size_t)K * 65 : 0)) * sizeof(double);
-      if (lds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d needs %zu B of LDS (> 160 KiB)", K, D, lds);
-      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+      const size_t lds = P.ent_lds;
       DISPATCH_DT(dt, {
-        HIP_TRY(ctx, set_entropy_lds<DT>(compute_grad != 0, lds));
-        launch_entropy<DT>(compute_grad != 0, dim3(C, K, R), lds, st, ea);
+        HIP_TRY(ctx, set_entropy_lds<DT>(P.compute_grad != 0, lds));
+        launch_entropy<DT>(P.compute_grad != 0, dim3(P.C, K, R), lds, st, ea);
       });
-      if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     }
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     // chunk partials -> one record per (r, j), summed in chunk order
-    double* d_red = ea.part + (size_t)R * K * C * ncol;
-    hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(ncol >= 192 ? 256 : (ncol >= 96 ? 128 : 64)), 0, st, C, ncol, ea.part, d_red);
-    fa.entpart = d_red; fa.entlb = nullptr; fa.M = Mh; fa.C = 1; fa.ncol = ncol;
+    hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
+                       P.d_part, P.d_red);
+    fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {
-    const size_t ebs = 1 + (size_t)D * K + 2 * K + D;
-    { vbmc_status s_ = ensure(ctx, ctx->entpart, (size_t)R * ebs * sizeof(double)); if (s_) return s_; }
     size_t lds = ((size_t)K * K + K + 256) * sizeof(double);
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_entlb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, d_vpd, (double*)ctx->entpart.p, compute_grad);
-    fa.entpart = nullptr; fa.entlb = (const double*)ctx->entpart.p;
+    hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, P.d_vpd, P.d_part, P.compute_grad);
+    fa.entpart = nullptr; fa.entlb = P.d_part;
   }
 
   // ---- variance of the expected log joint (gplogjoint.m:273-337,375-413)
-  double* d_J = nullptr;
-  double* d_var = nullptr;
-  const int var_stride = 2 + T;
-  if (compute_var != 0) {
+  if (P.compute_var != 0) {
     const int N = dm.N;
-    const bool vgrad = compute_grad && compute_var == 2;
-    bool any_nochol = false;
-    for (int s = 0; s < S; ++s) any_nochol |= (gp->Lchol[s] == 0);
-    const size_t nz = (size_t)R * S * K * N;
-    { vbmc_status s_ = ensure(ctx, ctx->zbuf, nz * sizeof(double)); if (s_) return s_; }
-    const size_t nJ = (size_t)R * S * K * K, nvg = (size_t)R * S * K * (2 * D + 1), nvo = (size_t)R * var_stride;
-    const bool needX = vgrad || any_nochol;
-    { vbmc_status s_ = ensure(ctx, ctx->varbuf, ((needX ? nz : 0) + nJ + nvg + nvo) * sizeof(double)); if (s_) return s_; }
-    double* d_Z = (double*)ctx->zbuf.p;
-    double* d_X = (double*)ctx->varbuf.p;
-    d_J = d_X + (needX ? nz : 0);
-    double* d_vg = d_J + nJ;
-    d_var = d_vg + nvg;
     DISPATCH_DT(dt, {
-      hipLaunchKernelGGL((k_var_z<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, d_vpd, gp->X, gp->gpc, d_delta2, d_Z);
+      hipLaunchKernelGGL((k_var_z<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2, P.d_Z);
     });
-    const size_t tlds = ((size_t)N * 16 + 256) * sizeof(double);
+    const size_t tlds = P.tlds;
     if (tlds > 64 * 1024) {
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
     }
     const dim3 tg((K + TR_CB - 1) / TR_CB, S, R);
-    if (any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, d_Z, d_X);
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, d_Z);
-    hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, d_vpd, gp->gpc, d_delta2, gp->d_sn2, gp->d_lchol,
-                       d_Z, d_X, d_J, compute_var == 1 ? 1 : 0);
-    if (vgrad) {
-      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, d_Z, d_X);
+    if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z);
+    hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
+                       P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);
+    if (P.vgrad) {
+      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
       DISPATCH_DT(dt, {
-        hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, d_vpd, gp->X, gp->gpc, d_delta2,
-                           gp->d_sn2, gp->d_lchol, d_X, d_vg);
+        hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2,
+                           gp->d_sn2, gp->d_lchol, P.d_X, P.d_vg);
       });
     }
     VarFinArgs va{};
-    va.dm = dm; va.vpd = d_vpd; va.gpc = gp->gpc; va.delta2 = d_delta2; va.lj = d_lj; va.J = d_J;
-    va.vg = vgrad ? d_vg : nullptr; va.compute_var = compute_var; va.want_grad = compute_grad; va.stride = var_stride;
-    va.out = d_var;
+    va.dm = dm; va.vpd = P.d_vpd; va.gpc = gp->gpc; va.delta2 = P.d_delta2; va.lj = P.d_lj; va.J = P.d_J;
+    va.vg = P.vgrad ? P.d_vg : nullptr; va.compute_var = P.compute_var; va.want_grad = P.compute_grad; va.stride = P.var_stride;
+    va.out = P.d_var;
     const size_t vlds = (256 + 2 * (size_t)S + 7 * (size_t)T + K + 8) * sizeof(double);
     if (vlds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
@@ -501,10 +533,10 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   }
 
   // ---- finalize
-  fa.vpd = d_vpd; fa.theta = d_theta; fa.lj = d_lj; fa.var = d_var; fa.var_stride = d_var ? var_stride : 0;
-  fa.bnd = has_bnd ? d_bnd : nullptr; fa.has_bnd = has_bnd ? 1 : 0;
-  fa.TolCon = a->TolCon; fa.WeightThreshold = a->WeightThreshold; fa.WeightPenalty = a->WeightPenalty;
-  fa.beta = beta; fa.want_grad = compute_grad; fa.out = d_out;
+  fa.vpd = P.d_vpd; fa.theta = P.d_theta; fa.lj = P.d_lj; fa.var = P.d_var; fa.var_stride = P.d_var ? P.var_stride : 0;
+  fa.bnd = P.d_bnd; fa.has_bnd = P.has_bnd ? 1 : 0;
+  fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
+  fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out;
   {
     size_t lds = (256 + 3 * (size_t)K + 3 * (size_t)T + 8) * sizeof(double);
     if (lds > 64 * 1024)
@@ -512,27 +544,38 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     hipLaunchKernelGGL(k_finalize, dim3(R), dim3(256), lds, st, fa);
   }
   HIP_TRY(ctx, hipGetLastError());
+  return VBMC_OK;
+}
 
-  // ---- results: one packed D2H (+ I_sk when requested)
-  double* hout = hp + n_up;
-  HIP_TRY(ctx, hipMemcpyAsync(hout, d_out, out_n * sizeof(double), hipMemcpyDeviceToHost, st));
-  double* hisk = hout + out_n;
+extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  ElboPlan P;
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed); if (s_) return s_; }
+  const ElboDims& dm = P.dm;
+  const int K = dm.K, R = dm.R, S = dm.S, T = dm.T, D = dm.D;
+  const int LJS = 2 * D + 2;
+  const int compute_grad = P.compute_grad;
+  hipStream_t st = ctx->stream;
+
+  // ---- results: one packed D2H (+ I_sk / J_sjk when requested)
+  double* hout = (double*)ctx->pin + P.n_up;
+  HIP_TRY(ctx, hipMemcpyAsync(hout, P.d_out, P.out_n * sizeof(double), hipMemcpyDeviceToHost, st));
   std::vector<double> ljh;
   if (a->separate_K && a->I_sk) {
     ljh.resize((size_t)R * S * K * LJS);
-    HIP_TRY(ctx, hipMemcpyAsync(ljh.data(), d_lj, ljh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ljh.data(), P.d_lj, ljh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   std::vector<double> Jh;
-  if (a->separate_K && a->J_sjk && d_J) {
+  if (a->separate_K && a->J_sjk && P.d_J) {
     Jh.resize((size_t)R * S * K * K);
-    HIP_TRY(ctx, hipMemcpyAsync(Jh.data(), d_J, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(Jh.data(), P.d_J, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
-  (void)hisk;
   if (ctx->profiling) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_lj_ms = ms;
-    if (mc && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ent_ms = ms;
+    if (P.mc && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ent_ms = ms;
   }
   const size_t OS = OUT_HDR + 3 * (size_t)T;
   for (int r = 0; r < R; ++r) {
@@ -559,6 +602,139 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
         for (int j = 0; j < K; ++j)
           for (int s = 0; s < S; ++s)
             a->J_sjk[s + (size_t)S * (j + (size_t)K * (k + (size_t)K * r))] = Jh[(((size_t)r * S + s) * K + k) * K + j];
+  }
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// On-device Adam (utils/fminadam.m:42-102) for R chains in lock-step: the whole loop
+// [ELBO+grad pass -> Adam update -> every 20 iterations the slope / random-walk stopping test]
+// is enqueued on the stream without host round trips; the host only polls R "done" flags every
+// 20 iterations (the reference tests termination on exactly those iterations, fminadam.m:65).
+// ------------------------------------------------------------------------------------------
+struct AdamState {
+  double *m, *v, *xtab, *ftab;  // T x R, T x R, T x MaxIter x R, MaxIter x R
+  int* done;                    // R: 0 = running, otherwise the iteration at which the chain stopped
+  int T, R, MaxIter;
+  double step_min, step_max, step_decay, TolFun;
+};
+
+__global__ void __launch_bounds__(256) k_adam_step(AdamState A, int iter, double* __restrict__ x /*T x R*/,
+                                                   const double* __restrict__ out /*R x (5+3T)*/) {
+  const int r = blockIdx.x;
+  if (A.done[r]) return;
+  const int T = A.T;
+  const double* o = out + (size_t)r * (OUT_HDR + 3 * T);
+  const double b1 = 0.9, b2 = 0.999, fudge = 1.4901161193847656e-08;  // sqrt(eps)  (fminadam.m:20-22)
+  const double c1 = 1.0 - pow(b1, (double)iter), c2 = 1.0 - pow(b2, (double)iter);
+  const double step = A.step_min + (A.step_max - A.step_min) * exp(-(double)iter / A.step_decay);  // :56-57
+  if (threadIdx.x == 0) A.ftab[(size_t)r * A.MaxIter + (iter - 1)] = o[0];
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    const double g = o[OUT_HDR + i];
+    double m = b1 * A.m[(size_t)r * T + i] + (1.0 - b1) * g;      // :51
+    double v = b2 * A.v[(size_t)r * T + i] + (1.0 - b2) * g * g;  // :52
+    A.m[(size_t)r * T + i] = m;
+    A.v[(size_t)r * T + i] = v;
+    const double mhat = m / c1, vhat = v / c2;
+    const double xn = x[(size_t)r * T + i] - step * mhat / (sqrt(vhat) + fudge);  // :59 (LB/UB are [] at the call site)
+    x[(size_t)r * T + i] = xn;
+    A.xtab[((size_t)r * A.MaxIter + (iter - 1)) * T + i] = xn;
+  }
+}
+
+// stopping test at iter (a multiple of 20, >= 40): fminadam.m:65-81
+__global__ void __launch_bounds__(256) k_adam_check(AdamState A, int iter) {
+  __shared__ double red[256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (A.done[r]) return;
+  const int T = A.T, B = 20;
+  const double* f = A.ftab + (size_t)r * A.MaxIter + (iter - B);
+  // dx = sqrt(sum((mean(x last B) - mean(x previous B)).^2 / B))
+  double part = 0.0;
+  for (int i = tid; i < T; i += blockDim.x) {
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < B; ++t) {
+      a += A.xtab[((size_t)r * A.MaxIter + (iter - B + t)) * T + i];
+      b += A.xtab[((size_t)r * A.MaxIter + (iter - 2 * B + t)) * T + i];
+    }
+    double d = a / B - b / B;
+    part += d * d / B;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  if (tid == 0) {
+    const double dx = sqrt(red[0]);
+    // degree-1 least squares on xxp = linspace(-(B-1)/2, (B-1)/2, B): slope and its variance A(1,1) (:66-69)
+    double fm = 0.0;
+    for (int t = 0; t < B; ++t) fm += f[t];
+    fm /= B;
+    double sxx = 0.0, sxy = 0.0;
+    for (int t = 0; t < B; ++t) { double xx = -(B - 1) / 2.0 + t; sxx += xx * xx; sxy += xx * (f[t] - fm); }
+    const double slope = sxy / sxx;
+    double rss = 0.0;
+    for (int t = 0; t < B; ++t) { double xx = -(B - 1) / 2.0 + t; double e = f[t] - (fm + slope * xx); rss += e * e; }
+    const double svar = rss / (B - 2) / sxx;
+    const double TolX = 0.001, TolX_max = 0.1, TolFun_max = A.TolFun * 100.0;
+    const double slope_err = sqrt(svar + A.TolFun * A.TolFun), slope_err_max = sqrt(svar + TolFun_max * TolFun_max);
+    if ((dx < TolX && fabs(slope) < slope_err_max) || (fabs(slope) < slope_err && dx < TolX_max)) A.done[r] = iter;  // :79
+  }
+}
+
+extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, double TolFun, int MaxIter,
+                                       double step_min, double step_max, double step_decay, double* x_out, double* f_out,
+                                       int32_t* iters_out, double* xtab_out, double* ftab_out) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!a || !a->compute_grad) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_adam_batch needs compute_grad = 1");
+  if (MaxIter < 1) return set_err(ctx, VBMC_ERR_INVALID, "MaxIter must be >= 1");
+  if (a->eps_mode != 0 && a->Ns > 0) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_adam_batch draws fresh device RNG every iteration (eps_mode 0)");
+  ElboPlan P;
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  const int T = P.dm.T, R = P.dm.R;
+  hipStream_t st = ctx->stream;
+  const size_t nT = (size_t)T * R, nx = (size_t)T * MaxIter * R, nf = (size_t)MaxIter * R;
+  { vbmc_status s_ = ensure(ctx, ctx->misc, (2 * nT + nx + nf) * sizeof(double) + (size_t)R * sizeof(int)); if (s_) return s_; }
+  AdamState A{};
+  A.m = (double*)ctx->misc.p; A.v = A.m + nT; A.xtab = A.v + nT; A.ftab = A.xtab + nx; A.done = (int*)(A.ftab + nf);
+  A.T = T; A.R = R; A.MaxIter = MaxIter; A.step_min = step_min; A.step_max = step_max; A.step_decay = step_decay; A.TolFun = TolFun;
+  HIP_TRY(ctx, hipMemsetAsync(A.m, 0, 2 * nT * sizeof(double), st));
+  HIP_TRY(ctx, hipMemsetAsync(A.done, 0, (size_t)R * sizeof(int), st));
+  std::vector<int> done(R, 0);
+  int iter = 0;
+  for (iter = 1; iter <= MaxIter; ++iter) {
+    { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter); if (s_) return s_; }
+    hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
+    if (iter % 20 == 0 && iter >= 40) {
+      hipLaunchKernelGGL(k_adam_check, dim3(R), dim3(256), 0, st, A, iter);
+      HIP_TRY(ctx, hipMemcpyAsync(done.data(), A.done, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      bool all = true;
+      for (int r = 0; r < R; ++r) all = all && done[r] != 0;
+      if (all) break;
+    }
+  }
+  if (iter > MaxIter) iter = MaxIter;
+  HIP_TRY(ctx, hipGetLastError());
+  // outputs: x = mean of the last 20 iterates, f = mean of the last 20 values (fminadam.m:96-97)
+  std::vector<double> xt(nx), ft(nf);
+  HIP_TRY(ctx, hipMemcpyAsync(xt.data(), A.xtab, nx * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ft.data(), A.ftab, nf * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(done.data(), A.done, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (int r = 0; r < R; ++r) {
+    const int it = done[r] ? done[r] : iter;
+    const int nb = it < 20 ? it : 20;
+    if (iters_out) iters_out[r] = it;
+    for (int i = 0; i < T; ++i) {
+      double acc = 0.0;
+      for (int t = it - nb; t < it; ++t) acc += xt[((size_t)r * MaxIter + t) * T + i];
+      if (x_out) x_out[(size_t)r * T + i] = acc / nb;
+    }
+    double fa = 0.0;
+    for (int t = it - nb; t < it; ++t) fa += ft[(size_t)r * MaxIter + t];
+    if (f_out) f_out[r] = fa / nb;
+    if (xtab_out) memcpy(xtab_out + (size_t)r * MaxIter * T, xt.data() + (size_t)r * MaxIter * T, (size_t)it * T * sizeof(double));
+    if (ftab_out) memcpy(ftab_out + (size_t)r * MaxIter, ft.data() + (size_t)r * MaxIter, (size_t)it * sizeof(double));
   }
   return VBMC_OK;
 }

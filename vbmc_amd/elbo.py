@@ -70,30 +70,16 @@ def _flags(vp):
             int(bool(vp["optimize_weights"])))
 
 
-def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
-                   separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
-                   want=("F", "dF", "G", "H", "dG", "dH")):
-    """R evaluations of negelcbo_vbmc in one device pass.
-
-    thetas: (T, R) column per restart (or (T,) for R = 1).  Returns a dict of arrays
-    F[R], dF[T,R], G[R], H[R], dG[T,R], dH[T,R], varG[R], varGss[R], I_sk[S,K,R], J_sjk[S,K,K,R].
-    eps: host array shaped (R, K, Ns/2, D) (or (K, Ns/2, D) with eps_shared) standing in for the
-    reference's randn stream (entmc_vbmc.m:53); None -> device Philox stream keyed by ``seed``.
-    """
-    engine = engine or default_engine()
-    ctx = engine.ctx
+def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps, eps_device_ptr, eps_shared,
+                seed, engine):
+    """Fill a vbmc_elbo_args for R = thetas.shape[1] restarts; returns (args, keep-alive list, compute_var)."""
     D, K = int(vp["D"]), int(vp["K"])
-    thetas = f64(thetas)
-    if thetas.ndim == 1:
-        thetas = f64(thetas.reshape(-1, 1))
     T, R = thetas.shape
     if beta is None or not np.isfinite(beta):
         beta = 0.0  # negelcbo_vbmc.m:15
     if compute_var is None:
         compute_var = 1 if beta != 0 else 0  # :16 (first clause; nargout clause handled by callers)
     compute_var = int(compute_var)
-    dgp = engine.device_gp(gp, need_L=compute_var != 0)
-    S = dgp.S
     a = ElboArgs()
     a.struct_size = C.sizeof(ElboArgs)
     a.D, a.K, a.R = D, K, R
@@ -143,6 +129,60 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
         a.TolCon = float(thetabnd["TolCon"])
         a.WeightThreshold = float(thetabnd.get("WeightThreshold", 0.0))
         a.WeightPenalty = float(thetabnd.get("WeightPenalty", 0.0))
+    return a, keep, compute_var
+
+
+def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10000, master_stepsize=None, *,
+                    compute_var=0, seed=0, engine=None):
+    """fminadam (utils/fminadam.m) with the objective negelcbo_vbmc(., beta, vp, gp, Ns, 1, compute_var, ~, thetabnd)
+    run entirely on the device for R chains in lock-step (x0: (T, R) or (T,)).
+
+    Returns (x, f, xtab, ftab, iters): x (T, R) mean of the last 20 iterates, f (R,), xtab list of (T, iters_r)
+    arrays, ftab list of (iters_r,) arrays, iters (R,) -- the reference's five outputs per chain."""
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    ms = {"max": 0.1, "min": 0.001, "decay": 200.0}
+    if master_stepsize:
+        ms.update({k: v for k, v in master_stepsize.items() if v is not None})
+    x0 = f64(x0)
+    if x0.ndim == 1:
+        x0 = f64(x0.reshape(-1, 1))
+    T, R = x0.shape
+    a, keep, _ = _build_args(x0, beta, vp, gp, Ns, True, compute_var, thetabnd, False, None, None, False, seed, engine)
+    MaxIter = int(MaxIter)
+    x = np.zeros((T, R), order="F")
+    f = np.zeros(R)
+    iters = np.zeros(R, dtype=np.int32)
+    xtab = np.zeros((R, MaxIter, T))   # C order == T x MaxIter x R column-major
+    ftab = np.zeros((R, MaxIter))
+    dgp = engine.device_gp(gp, need_L=int(compute_var or 0) != 0)
+    ctx.check(ctx.lib.vbmc_adam_batch(ctx.h, dgp.h, C.byref(a), float(TolFun), MaxIter, float(ms["min"]), float(ms["max"]),
+                                       float(ms["decay"]), ptr(x), ptr(f), iters.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       ptr(xtab), ptr(ftab)))
+    return x, f, [xtab[r, : iters[r]].T.copy() for r in range(R)], [ftab[r, : iters[r]].copy() for r in range(R)], iters
+
+
+def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
+                   separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
+                   want=("F", "dF", "G", "H", "dG", "dH")):
+    """R evaluations of negelcbo_vbmc in one device pass.
+
+    thetas: (T, R) column per restart (or (T,) for R = 1).  Returns a dict of arrays
+    F[R], dF[T,R], G[R], H[R], dG[T,R], dH[T,R], varG[R], varGss[R], I_sk[S,K,R], J_sjk[S,K,K,R].
+    eps: host array shaped (R, K, Ns/2, D) (or (K, Ns/2, D) with eps_shared) standing in for the
+    reference's randn stream (entmc_vbmc.m:53); None -> device Philox stream keyed by ``seed``.
+    """
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    thetas = f64(thetas)
+    if thetas.ndim == 1:
+        thetas = f64(thetas.reshape(-1, 1))
+    T, R = thetas.shape
+    D, K = int(vp["D"]), int(vp["K"])
+    a, keep, compute_var = _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps,
+                                       eps_device_ptr, eps_shared, seed, engine)
+    dgp = engine.device_gp(gp, need_L=compute_var != 0)
+    S = dgp.S
     out = {}
 
     def outbuf(name, shape):

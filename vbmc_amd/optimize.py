@@ -17,7 +17,7 @@ import math
 
 import numpy as np
 
-from .elbo import negelcbo_batch
+from .elbo import fminadam_device, negelcbo_batch
 from .vp import DEFAULT_OPTIONS, evaloption, get_vptheta, rescale_params, vpbounds
 
 EPS = float(np.finfo(np.float64).eps)
@@ -280,7 +280,7 @@ def eval_fullelcbo(theta, vp, gp, beta, options, *, seed=0, engine=None):
 
 
 def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, options=None, prnt=0, *, rng=None, seed=0,
-                    engine=None, shard=None):
+                    engine=None, shard=None, device_adam=True):
     """[vp,varss,pruned] = vpoptimize_vbmc(Nfastopts,Nslowopts,vp,gp,K,optimState,options,prnt)
     (misc/vpoptimize_vbmc.m:1-254), stochastic (Adam) path with NSentK > 0; the deterministic-entropy
     fminunc branch (:73-106) needs MATLAB's Optimization Toolbox and is not mirrored."""
@@ -320,7 +320,12 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
             r = negelcbo_batch(th, elcbo_beta, vp0, gp, NSentK, True, 0, thetabnd, seed=(seed << 20) + (iOpt << 16) + counter[0], engine=engine)
             return float(r["F"][0]), r["dF"][:, 0]
 
-        thetaopt, _, theta_lst, fval_lst, _ = fminadam(fun, theta0, None, None, options["TolFunStochastic"], MaxIter, ms)
+        if device_adam:  # the whole Adam loop on the device (vbmc_adam_batch), no host round trip per evaluation
+            xo, _, xt, ft, _ = fminadam_device(theta0, elcbo_beta, vp0, gp, NSentK, thetabnd, options["TolFunStochastic"], MaxIter, ms,
+                                               seed=(seed << 20) + (iOpt << 16), engine=engine)
+            thetaopt, theta_lst, fval_lst = xo[:, 0], xt[0], ft[0]
+        else:
+            thetaopt, _, theta_lst, fval_lst, _ = fminadam(fun, theta0, None, None, options["TolFunStochastic"], MaxIter, ms)
         if options["ELCBOmidpoint"]:
             imid = int(np.argmin(fval_lst))
             st = eval_fullelcbo(theta_lst[:, imid], vp0, gp, elcbo_beta, options, seed=seed + 7 * iOpt, engine=engine)
