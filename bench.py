@@ -123,19 +123,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("VBMC_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for single-GPU smoke tests
+    ndev = max(torch.cuda.device_count(), 1)
+    gpu = local_rank % ndev
+    torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", gpu)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective buffers live
 
     import vbmc_amd
 
     D, N, K, Ns, S, Rr = args.D, args.N, args.K, args.Ns, args.S, args.restarts
     inp = synth_inputs(0, D, N, K, S)  # same GP on every rank (replicated, 25.6 MB with L)
-    eng = vbmc_amd.Engine(local_rank)
+    eng = vbmc_amd.Engine(gpu)
     # GP posterior (alpha, L per hyper-sample) from the build's own device gplite_post -- outside the timed region
     gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)
     vp = vbmc_amd.make_vp(inp["mu"], inp["sigma"], inp["lam"], eta=inp["eta"])
@@ -145,12 +150,12 @@ def main():
     rng = np.random.default_rng(100 + rank)
     thetas = np.asfortranarray(theta0[:, None] + 0.05 * rng.standard_normal((T, Rr)))  # R jittered restarts
     eng.device_gp(gp)  # one-off upload (already resident after gplite_post), outside the timed region
-    gathered = torch.empty(world * Rr, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty(world * Rr, dtype=torch.float64, device=cdev) if world > 1 else None
 
     def step(i):
         out = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=(rank << 32) + i, engine=eng)
         if world > 1:
-            f = torch.from_numpy(out["F"]).to(dev)
+            f = torch.from_numpy(out["F"]).to(cdev)
             dist.all_gather_into_tensor(gathered, f)
             order = torch.argsort(gathered, stable=True)  # every rank: identical sieve order
             return out, order
@@ -169,7 +174,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert np.all(np.isfinite(out["F"])) and np.all(np.isfinite(out["dF"]))
@@ -198,6 +203,17 @@ def main():
                         "(SURVEY 8d) x R / kernel time; the P fp64 exp evaluations (11 fp64 ops each here) are NOT counted. "
                         "traffic: device-RNG mode reads no O(Ns) data from HBM (FETCH_SIZE per launch is in profiles/)"}
         extra["logjoint_kernel_ms"] = lj_ms
+        # single-chain latency: the on-device Adam loop (vbmc_adam_batch) vs one host round trip per evaluation
+        for Rc in (1, 2):
+            x0 = thetas[:, :Rc].copy()
+            vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 40, seed=5, engine=eng)  # warm-up
+            t1 = time.perf_counter()
+            _, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 200, seed=6, engine=eng)
+            extra["device_adam_R%d_evals_per_s" % Rc] = float(np.sum(its)) / (time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        for i in range(50):
+            vbmc_amd.negelcbo_batch(thetas[:, :1], 0, vp, gp, Ns, True, 0, seed=900 + i, engine=eng)
+        extra["host_loop_R1_evals_per_s"] = 50 / (time.perf_counter() - t1)
         if args.eps_stream:
             g = torch.Generator(device=dev)
             g.manual_seed(1)

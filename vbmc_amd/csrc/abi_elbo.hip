@@ -401,13 +401,25 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     if (force && !strcmp(force, "valu")) P.use_mfma = false;
     const int tile_sz = P.use_mfma ? 16 : 32;          // base samples per tile
     const int ntile = (Mh + tile_sz - 1) / tile_sz;
-    // enough waves to fill the chip several times over
-    long long target = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5) * 4;
-    int C = (int)((target + (long long)K * R - 1) / ((long long)K * R));
-    if (C < 1) C = 1;
-    if (C > ntile) C = ntile;
-    P.tpc = (ntile + C - 1) / C;
-    P.C = (ntile + P.tpc - 1) / P.tpc;
+    // chunks per (component, restart): minimise  ceil(waves / resident slots) * (setup + tiles per wave),
+    // i.e. whole rounds of resident waves, with the per-wave setup worth ~3 tiles
+    {
+      const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5);
+      const long long kr = (long long)K * R;
+      const double setup = 3.0;
+      double best = 1e300;
+      int bestC = 1;
+      for (int c = 1; c <= ntile; ++c) {
+        const int tpc = (ntile + c - 1) / c;
+        const int ceff = (ntile + tpc - 1) / tpc;
+        const long long rounds = (kr * ceff + slots - 1) / slots;
+        const double cost = (double)rounds * (setup + tpc);
+        if (cost < best - 1e-9) { best = cost; bestC = ceff; }
+        if (tpc == 1) break;
+      }
+      P.tpc = (ntile + bestC - 1) / bestC;
+      P.C = (ntile + P.tpc - 1) / P.tpc;
+    }
     P.ncol = compute_grad ? (2 + 2 * D + K) : 1;
     { vbmc_status s_ = ensure(ctx, ctx->entpart, ((size_t)R * K * P.C * P.ncol + (size_t)R * K * P.ncol) * sizeof(double)); if (s_) return s_; }
     P.d_part = (double*)ctx->entpart.p;

@@ -10,8 +10,9 @@
 
 template <int KT>
 static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
-  if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true>), grid, dim3(WAVE), 0, st, ea);
-  else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false>), grid, dim3(WAVE), 0, st, ea);
+  const size_t lds = (size_t)ea.K * (ea.D + ENTP_EXTRA) * sizeof(double);  // parameter block (<= 39 KB)
+  if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true>), grid, dim3(WAVE), lds, st, ea);
+  else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false>), grid, dim3(WAVE), lds, st, ea);
 }
 
 extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, unsigned gx, unsigned gy, unsigned gz, void* stream,

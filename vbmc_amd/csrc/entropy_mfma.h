@@ -41,12 +41,20 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
   const int PSg = D + ENTP_EXTRA;
-  const double* gp = a.entp + (size_t)r * K * PSg;  // [k][m_1..m_D, h, cK, w, wi]
+  // stage this restart's packed parameter block [k][m_1..m_D, h, cK, w, wi] in LDS with coalesced loads;
+  // the per-lane operand fragments below are gathered from LDS, not from global memory
+  extern __shared__ double PB[];
+  {
+    const double* gsrc = a.entp + (size_t)r * K * PSg;
+    for (int idx = lane; idx < K * PSg; idx += WAVE) PB[idx] = gsrc[idx];
+  }
+  TAB[lane] = c_exp2_tab[lane];
+  __syncthreads();
+  const double* gp = PB;
   const double* pj = gp + (size_t)j * PSg;
   VpLayout L{D, K};
   const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
-  TAB[lane] = c_exp2_tab[lane];
   const int nr_last = (K - 16 * (KT - 1) + 3) >> 2;  // accumulator registers with a valid component in the last k-tile (1..4)
 
   // ---- mixture-side operand fragments (registers, built once)
