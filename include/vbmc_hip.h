@@ -145,6 +145,9 @@ typedef struct vbmc_elbo_args {
   const double* bnd_lb;      /* length of theta_ext: [mu(:); lnscale(:) (D x K); eta]       */
   const double* bnd_ub;
   double TolCon, WeightThreshold, WeightPenalty;
+  double sparse_cutoff;      /* 0: dense (every sample x component term, as the reference).  c > 0: block-sparse -- a
+                              * 16-component tile is skipped for a 16-sample tile when every one of its terms is
+                              * provably < exp(-c) relative to q(x) (c = 100 changes results by < 1e-40 relative)   */
   /* outputs (any may be NULL) */
   double* F;                 /* R      negative EL(C)BO incl. penalties                     */
   double* dF;                /* T x R                                                       */

@@ -17,6 +17,7 @@
 // Errors are raised with mexErrMsgIdAndTxt AFTER all temporaries are released (it long-jumps);
 // VBMC_ERR_UNSUPPORTED becomes the id 'vbmc_hip:unsupported' which the shims catch to fall through
 // to the reference .m implementation (SURVEY.md 8b "Errors").
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -123,6 +124,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       a.bnd_lb = dbl(field(tb, "lb")); a.bnd_ub = dbl(field(tb, "ub")); a.TolCon = scalar_field(tb, "TolCon", 0.01);
       a.WeightThreshold = scalar_field(tb, "WeightThreshold", 0); a.WeightPenalty = scalar_field(tb, "WeightPenalty", 0);
     }
+    { const char* sc = getenv("VBMC_HIP_SPARSE_CUTOFF"); a.sparse_cutoff = sc ? atof(sc) : 0.0; }
     const mxArray* eps = nrhs > 10 ? prhs[10] : nullptr;  // D x Ns/2 x K block drawn by the shim with randn, or []
     if (eps && !mxIsEmpty(eps)) { a.eps_mode = 1; a.eps = mxGetDoubles(eps); a.eps_shared = 1; }
     else { a.eps_mode = 0; a.seed = (uint64_t)(nrhs > 11 ? mxGetScalar(prhs[11]) : 0); }

@@ -215,3 +215,23 @@ def test_device_exp_accuracy(va, variant):
     assert rel.max() < 4.5e-16, rel.max()
     assert np.all(y[x <= -800] == 0.0) and np.all(y[~ok] < 1e-299)
     assert np.isinf(ctx.test_exp(np.array([710.0, 1e4]), variant)).all()
+
+
+def test_block_sparse_mode_is_exact_to_rounding(va):
+    """sparse_cutoff = 100 skips component tiles whose terms are < e^-100 of q: results unchanged to ~1e-14,
+    on well-separated mixtures (most tiles skipped) and on overlapping ones (nothing skipped)."""
+    for scale, K in ((1.0, 40), (0.02, 40), (1.0, 70)):
+        p, gp, vp, theta = problem(51, 6, 60, K, 2)
+        vp = dict(vp)
+        vp["mu"] = vp["mu"] * scale          # scale << 1: all components overlap
+        theta = theta.copy()
+        theta[: 6 * K] *= scale
+        Ns = 64
+        eps = np.random.default_rng(3).standard_normal((K, Ns // 2, 6))
+        d = va.negelcbo_batch(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+        s_ = va.negelcbo_batch(theta, 0, vp, gp, Ns, True, 0, eps=eps, sparse_cutoff=100.0)
+        assert relerr(s_["H"], d["H"]) < 1e-13 and relerr(s_["dH"], d["dH"]) < 1e-12
+        v = va.negelcbo_batch(theta, 0, vp, gp, Ns, False, 0, eps=eps, sparse_cutoff=100.0)
+        assert relerr(v["H"], d["H"]) < 1e-13
+        ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+        assert relerr(s_["H"][0], ref["H"]) < RT_VAL and relerr(s_["dF"][:, 0], ref["dF"]) < RT_GRAD

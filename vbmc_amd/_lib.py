@@ -47,6 +47,7 @@ class ElboArgs(C.Structure):
         ("beta", C.c_double),
         ("bnd_lb", _dp), ("bnd_ub", _dp),
         ("TolCon", C.c_double), ("WeightThreshold", C.c_double), ("WeightPenalty", C.c_double),
+        ("sparse_cutoff", C.c_double),
         ("F", _dp), ("dF", _dp), ("G", _dp), ("H", _dp), ("dG", _dp), ("dH", _dp),
         ("varG", _dp), ("varGss", _dp), ("I_sk", _dp), ("J_sjk", _dp),
     ]

@@ -291,7 +291,7 @@ struct ElboPlan {
   double *d_Z = nullptr, *d_X = nullptr, *d_J = nullptr, *d_vg = nullptr, *d_var = nullptr;
   const double* d_eps = nullptr;
   long long eps_stride_r = 0;
-  double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0;
+  double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0, cutoff = 0.0;
 };
 
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
@@ -383,6 +383,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   P.d_bnd = P.has_bnd ? P.d_delta2 + n_delta : nullptr;
   HIP_TRY(ctx, hipMemcpyAsync(P.d_theta, hp, n_up * sizeof(double), hipMemcpyHostToDevice, st));
   P.TolCon = a->TolCon; P.WeightThreshold = a->WeightThreshold; P.WeightPenalty = a->WeightPenalty;
+  P.cutoff = a->sparse_cutoff > 0.0 ? a->sparse_cutoff : 0.0;
 
   // ---- scratch
   { vbmc_status s_ = ensure(ctx, ctx->prep, (size_t)R * VL.stride() * sizeof(double)); if (s_) return s_; }
@@ -486,7 +487,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     EntArgs ea{};
     ea.entp = P.d_entp; ea.vpd = P.d_vpd; ea.part = P.d_part;
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = P.C; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
-    ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r;
+    ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff;
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     if (P.use_mfma) {
       bool ok = launch_entropy_mfma(P.qs, P.kt, P.compute_grad != 0, dim3(P.C, K, R), st, ea);

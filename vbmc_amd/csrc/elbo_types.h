@@ -45,4 +45,5 @@ struct EntArgs {
   double* part;
   int D, K, Mh, C, tiles_per_chunk, ncol;
   unsigned long long seed;
+  double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
 };

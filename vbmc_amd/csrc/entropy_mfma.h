@@ -23,6 +23,8 @@
 // Partials have the same layout as k_entropy (sum log q | G[D] | SG | LG[D] | W[K]) and are reduced
 // by k_finalize in a fixed order.
 #pragma once
+#include <type_traits>
+
 #include "device_math.h"
 #include "elbo_types.h"
 
@@ -36,6 +38,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
   __shared__ double Et[16 * DP];           // eps tile [i][d]
   __shared__ double RQ[16];                // q'_i then 1/q'_i
   __shared__ double TAB[64];               // 2^(j/64)
+  __shared__ double BND[KT * 16 * 3];      // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -56,6 +59,8 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
   const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
   const int nr_last = (K - 16 * (KT - 1) + 3) >> 2;  // accumulator registers with a valid component in the last k-tile (1..4)
+  constexpr unsigned FULL_MASK = (1u << KT) - 1u;
+  const double logwj = log(pj[D + 2]);
 
   // ---- mixture-side operand fragments (registers, built once)
   double SA[KT][QS];          // S-step "A" operand: comp 16kt + li, inner c = 4q + lg
@@ -69,6 +74,11 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
     double h = pk[D];
     double m2 = 0.0;
     for (int d = 0; d < D; ++d) { double t = pk[d] - pj[d]; m2 = fma(t, t, m2); }
+    if (lg == 0) {
+      BND[(16 * kt + li) * 3 + 0] = sqrt(m2);
+      BND[(16 * kt + li) * 3 + 1] = kv ? pk[D + 1] - cKj : -1.0e30;
+      BND[(16 * kt + li) * 3 + 2] = h;
+    }
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
       const int cc = 4 * q + lg;
@@ -152,9 +162,30 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
     const double shift = cKj - 0.5 * e2;        // exponent of the sample's own component
     const double u2 = sigj * sigj * e2;         // |u'_i|^2
     const bool svalid = b0 + li < a.Mh;
+    // ---- block-sparse mode: which k-tiles can contribute more than exp(-cutoff) * q to any sample of this tile?
+    // n_ik / q'_i <= exp(cK_k - cK_j - (max(0, |m'_k| - |u'_i|))^2 / (2 sigma_k^2) + |u'_i|^2 / (2 sigma_j^2)) / w_j
+    unsigned act = FULL_MASK;
+    if (a.cutoff > 0.0) {
+      double e2m = e2;
+      e2m = fmax(e2m, __shfl_xor(e2m, 1, 64)); e2m = fmax(e2m, __shfl_xor(e2m, 2, 64));
+      e2m = fmax(e2m, __shfl_xor(e2m, 4, 64)); e2m = fmax(e2m, __shfl_xor(e2m, 8, 64));
+      const double umax = sigj * sqrt(e2m);
+      const double own = 0.5 * e2m - logwj;
+      act = 0u;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const double* bk = BND + (16 * kt + li) * 3;
+        const double t = fmax(0.0, bk[0] - umax);
+        const double bnd = fma(bk[2] * t, t, bk[1]) + own;
+        if (__any(bnd > -a.cutoff)) act |= 1u << kt;
+      }
+    }
 
+    // the tile body exists twice: dense (straight-line) and block-sparse (uniform per-k-tile branches)
+    auto tile_body = [&](auto sparse_tag) {
+      constexpr bool SP = decltype(sparse_tag)::value;
 #pragma unroll 1
-    for (int sg = 0; sg < 2; ++sg) {
+      for (int sg = 0; sg < 2; ++sg) {
       const double sgn = sg ? -1.0 : 1.0;
       double sf[QS];
 #pragma unroll
@@ -167,12 +198,19 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         n[kt] = (mf4){-shift, -shift, -shift, -shift};
+        if (!SP || ((act >> kt) & 1u)) {
 #pragma unroll
-        for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+          for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int kt = 0; kt < KT - 1; ++kt) n[kt] = vb_exp_tab4(n[kt], TAB);
-      if (nr_last == 4) {
+      for (int kt = 0; kt < KT - 1; ++kt) {
+        if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab4(n[kt], TAB);
+        else n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
+      }
+      if (SP && !((act >> (KT - 1)) & 1u)) {
+        n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
+      } else if (nr_last == 4) {
         n[KT - 1] = vb_exp_tab4(n[KT - 1], TAB);
       } else {  // registers whose four components are all padding stay exactly zero
         mf4 t = n[KT - 1];
@@ -189,6 +227,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
         for (int pv = 0; pv < NPV; ++pv) { Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; Y2[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
         for (int kt = 0; kt < KT - 1; ++kt) {
+          if (SP && !((act >> kt) & 1u)) continue;
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv) {
             Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][0], VB[kt][0][pv], Y[pv], 0, 0, 0);
@@ -199,6 +238,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
         }
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
+          if (SP && !((act >> (KT - 1)) & 1u)) { Y[pv] += Y2[pv]; continue; }
           Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][0], VB[KT - 1][0][pv], Y[pv], 0, 0, 0);
           if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][1], VB[KT - 1][1][pv], Y2[pv], 0, 0, 0);
           if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][2], VB[KT - 1][2][pv], Y[pv], 0, 0, 0);
@@ -217,9 +257,11 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
         pe += __builtin_amdgcn_frexp_exp(qs_);
         if (svalid) accH += shift;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT; ++kt) {
+          if (SP && !((act >> kt) & 1u)) continue;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
+        }
         __syncthreads();
         if (lg == 0) RQ[li] = rqs;
         __syncthreads();
@@ -260,7 +302,10 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
         accH += log(pm) + 0.693147180559945309417 * (double)pe;
         pm = 1.0; pe = 0; pcnt = 0;
       }
-    }
+          }
+    };
+    if (act == FULL_MASK) tile_body(std::false_type{});
+    else tile_body(std::true_type{});
   }
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
   if (lg != 0) accH = 0.0;   // the four lanes of a sample hold identical copies: count one

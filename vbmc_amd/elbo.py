@@ -71,7 +71,7 @@ def _flags(vp):
 
 
 def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps, eps_device_ptr, eps_shared,
-                seed, engine):
+                seed, engine, sparse_cutoff=0.0):
     """Fill a vbmc_elbo_args for R = thetas.shape[1] restarts; returns (args, keep-alive list, compute_var)."""
     D, K = int(vp["D"]), int(vp["K"])
     T, R = thetas.shape
@@ -123,6 +123,7 @@ def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, s
     a.compute_var = compute_var
     a.separate_K = 1 if separate_K else 0
     a.beta = float(beta)
+    a.sparse_cutoff = float(sparse_cutoff or 0.0)
     if thetabnd is not None:
         a.bnd_lb = hold(thetabnd["lb"])
         a.bnd_ub = hold(thetabnd["ub"])
@@ -133,7 +134,7 @@ def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, s
 
 
 def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10000, master_stepsize=None, *,
-                    compute_var=0, seed=0, engine=None):
+                    compute_var=0, seed=0, engine=None, sparse_cutoff=0.0):
     """fminadam (utils/fminadam.m) with the objective negelcbo_vbmc(., beta, vp, gp, Ns, 1, compute_var, ~, thetabnd)
     run entirely on the device for R chains in lock-step (x0: (T, R) or (T,)).
 
@@ -148,7 +149,8 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
     if x0.ndim == 1:
         x0 = f64(x0.reshape(-1, 1))
     T, R = x0.shape
-    a, keep, _ = _build_args(x0, beta, vp, gp, Ns, True, compute_var, thetabnd, False, None, None, False, seed, engine)
+    a, keep, _ = _build_args(x0, beta, vp, gp, Ns, True, compute_var, thetabnd, False, None, None, False, seed, engine,
+                             sparse_cutoff)
     MaxIter = int(MaxIter)
     x = np.zeros((T, R), order="F")
     f = np.zeros(R)
@@ -164,13 +166,14 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
 
 def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
                    separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
-                   want=("F", "dF", "G", "H", "dG", "dH")):
+                   sparse_cutoff=0.0):
     """R evaluations of negelcbo_vbmc in one device pass.
 
     thetas: (T, R) column per restart (or (T,) for R = 1).  Returns a dict of arrays
     F[R], dF[T,R], G[R], H[R], dG[T,R], dH[T,R], varG[R], varGss[R], I_sk[S,K,R], J_sjk[S,K,K,R].
     eps: host array shaped (R, K, Ns/2, D) (or (K, Ns/2, D) with eps_shared) standing in for the
     reference's randn stream (entmc_vbmc.m:53); None -> device Philox stream keyed by ``seed``.
+    sparse_cutoff: 0 dense; c > 0 skips 16-component tiles whose terms are provably < exp(-c) of q(x).
     """
     engine = engine or default_engine()
     ctx = engine.ctx
@@ -180,7 +183,7 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     T, R = thetas.shape
     D, K = int(vp["D"]), int(vp["K"])
     a, keep, compute_var = _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps,
-                                       eps_device_ptr, eps_shared, seed, engine)
+                                       eps_device_ptr, eps_shared, seed, engine, sparse_cutoff)
     dgp = engine.device_gp(gp, need_L=compute_var != 0)
     S = dgp.S
     out = {}
