@@ -11,8 +11,13 @@
 template <int KT>
 static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
   const size_t lds = (size_t)ea.K * (ea.D + ENTP_EXTRA) * sizeof(double);  // parameter block (<= 39 KB)
-  if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true>), grid, dim3(WAVE), lds, st, ea);
-  else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false>), grid, dim3(WAVE), lds, st, ea);
+  if (ea.cutoff > 0.0) {  // opt-in block-sparse variant
+    if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, true>), grid, dim3(WAVE), lds, st, ea);
+    else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, true>), grid, dim3(WAVE), lds, st, ea);
+  } else {
+    if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, false>), grid, dim3(WAVE), lds, st, ea);
+    else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, false>), grid, dim3(WAVE), lds, st, ea);
+  }
 }
 
 extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, unsigned gx, unsigned gy, unsigned gz, void* stream,

@@ -31,14 +31,15 @@
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
 
-template <int QS, int KT, bool GRAD>
+template <int QS, int KT, bool GRAD, bool SPARSE>
 __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_entropy_mfma(EntArgs a) {
+  constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
   __shared__ double Et[16 * DP];           // eps tile [i][d]
   __shared__ double RQ[16];                // q'_i then 1/q'_i
   __shared__ double TAB[64];               // 2^(j/64)
-  __shared__ double BND[KT * 16 * 3];      // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
+  __shared__ double BND[SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
   const double cKj = pj[D + 1];
   const int nr_last = (K - 16 * (KT - 1) + 3) >> 2;  // accumulator registers with a valid component in the last k-tile (1..4)
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
-  const double logwj = log(pj[D + 2]);
+  const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
   // ---- mixture-side operand fragments (registers, built once)
   double SA[KT][QS];          // S-step "A" operand: comp 16kt + li, inner c = 4q + lg
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
     double h = pk[D];
     double m2 = 0.0;
     for (int d = 0; d < D; ++d) { double t = pk[d] - pj[d]; m2 = fma(t, t, m2); }
-    if (lg == 0) {
+    if (SPARSE && lg == 0) {
       BND[(16 * kt + li) * 3 + 0] = sqrt(m2);
       BND[(16 * kt + li) * 3 + 1] = kv ? pk[D + 1] - cKj : -1.0e30;
       BND[(16 * kt + li) * 3 + 2] = h;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
     // ---- block-sparse mode: which k-tiles can contribute more than exp(-cutoff) * q to any sample of this tile?
     // n_ik / q'_i <= exp(cK_k - cK_j - (max(0, |m'_k| - |u'_i|))^2 / (2 sigma_k^2) + |u'_i|^2 / (2 sigma_j^2)) / w_j
     unsigned act = FULL_MASK;
-    if (a.cutoff > 0.0) {
+    if (SPARSE) {
       double e2m = e2;
       e2m = fmax(e2m, __shfl_xor(e2m, 1, 64)); e2m = fmax(e2m, __shfl_xor(e2m, 2, 64));
       e2m = fmax(e2m, __shfl_xor(e2m, 4, 64)); e2m = fmax(e2m, __shfl_xor(e2m, 8, 64));
@@ -181,9 +182,6 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
       }
     }
 
-    // the tile body exists twice: dense (straight-line) and block-sparse (uniform per-k-tile branches)
-    auto tile_body = [&](auto sparse_tag) {
-      constexpr bool SP = decltype(sparse_tag)::value;
 #pragma unroll 1
       for (int sg = 0; sg < 2; ++sg) {
       const double sgn = sg ? -1.0 : 1.0;
@@ -302,10 +300,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
         accH += log(pm) + 0.693147180559945309417 * (double)pe;
         pm = 1.0; pe = 0; pcnt = 0;
       }
-          }
-    };
-    if (act == FULL_MASK) tile_body(std::false_type{});
-    else tile_body(std::true_type{});
+      }
   }
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
   if (lg != 0) accH = 0.0;   // the four lanes of a sample hold identical copies: count one
