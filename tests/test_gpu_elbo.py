@@ -205,7 +205,7 @@ def test_device_exp_accuracy(va, variant):
     """The hot-loop exp implementations: <= 2 ulp over the working range, saturation at the ends."""
     ctx = va.default_engine().ctx
     rng = np.random.default_rng(0)
-    ends = [0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -800.0, -1e5, -1e6, -2e6] + ([-1e300] if variant == 0 else [])
+    ends = [0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -800.0, -1e5, -1e6, -2e6, -5e9, -1e300]
     x = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-40, 5, 20000), rng.uniform(-1e-3, 1e-3, 2000),
                         np.array(ends)])
     y = ctx.test_exp(x, variant)
@@ -235,3 +235,32 @@ def test_block_sparse_mode_is_exact_to_rounding(va):
         assert relerr(v["H"], d["H"]) < 1e-13
         ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
         assert relerr(s_["H"][0], ref["H"]) < RT_VAL and relerr(s_["dF"][:, 0], ref["dF"]) < RT_GRAD
+
+
+SWEEP = [(1, 3), (7, 16), (14, 17), (15, 33), (18, 64), (22, 65), (23, 40), (30, 20), (32, 12), (5, 128), (3, 130), (9, 1)]
+
+
+@pytest.mark.parametrize("dk", SWEEP, ids=["D%dK%d" % t for t in SWEEP])
+def test_kernel_instantiation_sweep(va, dk):
+    """Every (QS, KT) family of the MFMA entropy kernel and the VALU fallback (K > 128), value and gradient."""
+    D, K = dk
+    p, gp, vp, theta = problem(61, D, 30, K, 2)
+    Ns = 34
+    eps = np.random.default_rng(6).standard_normal((K, Ns // 2, D))
+    ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+    F, dF, G, H, _, dH = va.negelcbo_vbmc(theta, 0, vp, gp, Ns, 1, 0, nargout=6, eps=eps)
+    assert relerr(H, ref["H"]) < RT_VAL and relerr(G, ref["G"]) < RT_VAL
+    assert relerr(dH, ref["dH"]) < RT_GRAD and relerr(dF, ref["dF"]) < RT_GRAD
+    (Fv,) = va.negelcbo_vbmc(theta, 0, vp, gp, Ns, 0, 0, nargout=1, eps=eps)
+    assert relerr(Fv, ref["F"]) < RT_VAL
+
+
+def test_tiny_sigma_components_do_not_break_the_exp(va):
+    """VBMC starts with sigma = 1e-3 (misc/setupvars_vbmc.m:83): exponents of -1e8 and below must give exactly 0."""
+    p, gp, vp, theta = problem(62, 4, 30, 6, 1)
+    th = theta.copy()
+    th[4 * 6: 4 * 6 + 6] = np.log(1e-4)   # log sigma
+    eps = np.random.default_rng(7).standard_normal((6, 16, 4))
+    ref = R.negelcbo_vbmc(th, 0, vp, gp, 32, True, 0, eps=eps)
+    F, dF, G, H = va.negelcbo_vbmc(th, 0, vp, gp, 32, 1, 0, nargout=4, eps=eps)
+    assert np.isfinite(H) and relerr(H, ref["H"]) < RT_VAL and relerr(dF, ref["dF"]) < 1e-8

@@ -475,7 +475,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // ---- expected log joint
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
   DISPATCH_DT(dt, {
-    hipLaunchKernelGGL((k_logjoint<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
+    hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
                        P.d_delta2, P.d_lj, P.compute_grad);
   });
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));

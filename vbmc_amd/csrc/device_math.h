@@ -68,8 +68,10 @@ __device__ __forceinline__ double vb_exp_tab(double x, const double* __restrict_
   const double MAGIC = 6755399441055744.0;              // 1.5 * 2^52: round-to-nearest-integer by addition
   // n = rint(x * 64/ln2) through the magic-number trick: the integer lands in the low mantissa word,
   // so no v_rndne / v_cvt is needed.  Valid for |x| < 2^31 ln2/64 = 2.3e7; beyond that the low word
-  // wraps, which is harmless for x << 0 only if the caller keeps arguments above -2e7 (the kernels
-  // use -1e6 as the "minus infinity" sentinel and theta is validated finite on the host).
+  // wraps -- hence the clamp below (arguments above +2e7 cannot occur: they would need exp() = inf anyway).
+  // one-instruction lower clamp (plain v_max_f64; fmax() would add a canonicalising v_max first): keeps the
+  // magic-number trick valid for arbitrarily negative arguments (tiny sigma_k early in a VBMC run)
+  asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(x), "v"(-1.0e6));
   double t = fma(x, INV, MAGIC);
   int ni = __double2loint(t);
   double nf = t - MAGIC;

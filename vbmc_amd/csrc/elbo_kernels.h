@@ -80,9 +80,19 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, const double* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// k_logjoint: misc/gplogjoint.m:162-271 for one (k, s, r); lanes stride over training points
+// k_logjoint: misc/gplogjoint.m:162-271.  One wave = four (component k, hyper-sample s) cells: lane
+// (kq = lane>>4, ni = lane&15) strides over the training points n = ni, ni+16, ... for component
+// k = 4*blockIdx.x + kq.  The per-dimension constants tau_d, log tau_d are computed once by the lane
+// with ni = d (and d+16) and broadcast inside the 16-lane row; the 2D+2 sums are reduced over the
+// 16 lanes of a row only (4 butterfly steps, each shuffle serving four cells).
 // partial layout LJ[r][s][k][2D+2] = I_k, w_k*dmu[D], w_k*dsigma (no Jacobian), w_k*dlambda[D]
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double row16_sum(double v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
 template <int DT>
 __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __restrict__ vpd,
                                                    const double* __restrict__ X,      // N x D col-major
@@ -90,38 +100,54 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
                                                    const double* __restrict__ gpc,    // S x GPC_STRIDE
                                                    const double* __restrict__ delta2,  // D (delta.^2)
                                                    double* __restrict__ lj, int want_grad) {
-  const int k = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+  __shared__ double TAB[64];
+  const int s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+  const int ni = lane & 15, kq = lane >> 4, rowbase = lane & 48;
   const int D = dm.D, K = dm.K, N = dm.N;
+  const int kk = 4 * blockIdx.x + kq;
+  const bool kvalid = kk < K;
+  const int k = kvalid ? kk : K - 1;
+  TAB[lane] = c_exp2_tab[lane];
   VpLayout L{D, K};
   const double* v = vpd + (size_t)r * L.stride();
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);
   const double sig = v[L.sigma() + k];
   const double wk = v[L.w() + k];
-  // per-dimension constants: lane d computes tau_d once (sqrt, log, 1/x are ~75 fp64 ops), the
-  // values are then broadcast by shuffles instead of every lane redoing all D of them
-  double mu[DT], itau[DT], lam[DT];
-  double my_lam = 0.0, my_mu = 0.0, my_itau = 0.0, my_logtau = 0.0;
-  if (lane < D) {
-    my_lam = v[L.lambda() + lane];
-    my_mu = v[L.mu() + lane + D * k];
-    double tau = sqrt(sig * sig * my_lam * my_lam + g[lane] + delta2[lane]);  // :164
-    my_logtau = log(tau);
-    my_itau = 1.0 / tau;
+  // lane ni owns dimensions d = ni and ni + 16
+  double my_lam[2] = {0.0, 0.0}, my_mu[2] = {0.0, 0.0}, my_itau[2] = {0.0, 0.0};
+  double my_logtau = 0.0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int d = ni + 16 * h;
+    if (d < D && (h == 0 || DT > 16)) {
+      my_lam[h] = v[L.lambda() + d];
+      my_mu[h] = v[L.mu() + d + D * k];
+      double tau = sqrt(sig * sig * my_lam[h] * my_lam[h] + g[d] + delta2[d]);  // :164
+      my_logtau += log(tau);
+      my_itau[h] = 1.0 / tau;
+    }
   }
-  const double sumlogtau = wave_sum(my_logtau);
+  const double sumlogtau = row16_sum(my_logtau);
+  double mu[DT], itau[DT], c1[DT], c2[DT], c3[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
-    lam[d] = __shfl(my_lam, d, 64);
-    mu[d] = __shfl(my_mu, d, 64);
-    itau[d] = __shfl(my_itau, d, 64);   // lanes >= D hold zeros: padded dimensions vanish
+    const int src = rowbase | (d & 15), h = d >> 4;
+    const double lam_d = __shfl(my_lam[h], src, 64);
+    mu[d] = __shfl(my_mu[h], src, 64);
+    itau[d] = __shfl(my_itau[h], src, 64);     // zero for padded dimensions: they vanish below
+    const double li = lam_d * itau[d], si = sig * itau[d];
+    c1[d] = -itau[d];                          // dz_dmu factor      (:207)
+    c2[d] = li * li;                           // dz_dsigma factor   (:228)
+    c3[d] = si * si * lam_d;                   // dz_dlambda factor  (:249)
   }
   const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
+  __syncthreads();
   double accI = 0.0, accS = 0.0;
   double accM[DT], accL[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) { accM[d] = 0.0; accL[d] = 0.0; }
   const double* al = alpha + (size_t)s * N;
-  for (int n = lane; n < N; n += WAVE) {
+  for (int n = ni; n < N; n += 16) {
     double dl[DT];
     double a2 = 0.0;
 #pragma unroll
@@ -130,40 +156,36 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
       dl[d] = (mu[d] - x) * itau[d];  // delta_k :167
       a2 = fma(dl[d], dl[d], a2);
     }
-    double z = vb_exp(lnnf - 0.5 * a2);  // z_k :168
+    double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);  // z_k :168
     double za = z * al[n];
     accI += za;
     if (want_grad) {
       double ssum = 0.0;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        double li = lam[d] * itau[d];
-        double si = sig * itau[d];
         double q = fma(dl[d], dl[d], -1.0);
-        accM[d] = fma(-dl[d] * itau[d], za, accM[d]);  // dz_dmu*alpha :207-208
-        ssum = fma(li * li, q, ssum);                   // :228
-        accL[d] = fma(si * si * q * lam[d], za, accL[d]);  // :249-250
+        accM[d] = fma(dl[d] * c1[d], za, accM[d]);  // dz_dmu*alpha :207-208
+        ssum = fma(c2[d], q, ssum);                  // :228
+        accL[d] = fma(c3[d] * q, za, accL[d]);       // :249-250
       }
       accS = fma(ssum * sig, za, accS);
     }
   }
-  accI = wave_sum(accI);
+  accI = row16_sum(accI);
   if (want_grad) {
-    accS = wave_sum(accS);
+    accS = row16_sum(accS);
 #pragma unroll
-    for (int d = 0; d < DT; ++d) { accM[d] = wave_sum(accM[d]); accL[d] = wave_sum(accL[d]); }
+    for (int d = 0; d < DT; ++d) { accM[d] = row16_sum(accM[d]); accL[d] = row16_sum(accL[d]); }
   }
-  if (lane == 0) {
+  if (ni == 0 && kvalid) {
     double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
     // mean-function terms; iom2 = 0 and xm = 0 for meanfun 0/1 so they vanish  :169-174
     double nu = 0.0, sl2 = 0.0;
-#pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      if (d < D) {
-        double xm = g[D + d], iom2 = g[2 * D + d];
-        nu += iom2 * (mu[d] * mu[d] + sig * sig * lam[d] * lam[d] - 2.0 * mu[d] * xm + xm * xm + delta2[d]);
-        sl2 += iom2 * lam[d] * lam[d];
-      }
+    for (int d = 0; d < D; ++d) {
+      double xm = g[D + d], iom2 = g[2 * D + d];
+      double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
+      nu += iom2 * (mu_d * mu_d + sig * sig * lam_d * lam_d - 2.0 * mu_d * xm + xm * xm + delta2[d]);
+      sl2 += iom2 * lam_d * lam_d;
     }
     o[0] = accI + g[3 * D + 1] + (-0.5 * nu);
     if (want_grad) {
@@ -171,8 +193,9 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
       for (int d = 0; d < DT; ++d) {
         if (d < D) {
           double xm = g[D + d], iom2 = g[2 * D + d];
-          o[1 + d] = wk * accM[d] - wk * iom2 * (mu[d] - xm);                    // :208-210
-          o[2 + D + d] = wk * accL[d] - wk * sig * sig * iom2 * lam[d];          // :250-252
+          double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
+          o[1 + d] = wk * accM[d] - wk * iom2 * (mu_d - xm);                    // :208-210
+          o[2 + D + d] = wk * accL[d] - wk * sig * sig * iom2 * lam_d;          // :250-252
         }
       }
       o[1 + D] = wk * accS - wk * sig * sl2;                                     // :229-231
