@@ -117,7 +117,10 @@ def test_optimize_flag_subsets(va, flags):
         parts.append(vp["eta"] + 0.1)
     theta = np.concatenate(parts)
     if flags == (0, 0, 0, 1):
-        pytest.skip("weights-only branch uses cached I_sk (gplogjoint_weights); host-side, covered elsewhere")
+        # weights-only branch (negelcbo_vbmc.m:54,78-88 -> gplogjoint_weights.m) reads the cached per-component
+        # terms vp.stats.I_sk; the device path recomputes them from the unchanged mu/sigma/lambda: same value
+        st = R.gplogjoint(vp, gp, (0, 0, 0, 0), True, True, 1, separate_K=True)
+        vp["stats"] = {"I_sk": st["I_sk"], "J_sjk": st["J_sjk"]}
     eps = np.random.default_rng(7).standard_normal((6, 20, 4))
     ref = R.negelcbo_vbmc(theta, 0, vp, gp, 40, True, 0, eps=eps)
     F, dF = va.negelcbo_vbmc(theta, 0, vp, gp, 40, 1, 0, eps=eps)

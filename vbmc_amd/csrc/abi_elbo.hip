@@ -539,7 +539,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     va.dm = dm; va.vpd = P.d_vpd; va.gpc = gp->gpc; va.delta2 = P.d_delta2; va.lj = P.d_lj; va.J = P.d_J;
     va.vg = P.vgrad ? P.d_vg : nullptr; va.compute_var = P.compute_var; va.want_grad = P.compute_grad; va.stride = P.var_stride;
     va.out = P.d_var;
-    const size_t vlds = (256 + 2 * (size_t)S + 7 * (size_t)T + K + 8) * sizeof(double);
+    const size_t vlds = (256 + 2 * (size_t)S + 7 * (size_t)T + 2 * (size_t)K + 8) * sizeof(double);
     if (vlds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
     hipLaunchKernelGGL(k_var_final, dim3(R), dim3(256), vlds, st, va);

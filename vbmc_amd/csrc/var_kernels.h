@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256) k_var_final(VarFinArgs a) {
   double* acc2 = acc1 + T;    // T  sum_s F(s) dF(:,s)
   double* acc3 = acc2 + T;    // T  sum_s dF(:,s)
   double* tmpK = acc3 + T;    // K
+  double* tmpK2 = tmpK + K;   // K
   const int LJS = 2 * D + 2;
   const double* lj = a.lj + (size_t)r * S * K * LJS;
   const double* Jr = a.J + (size_t)r * S * K * K;
@@ -373,27 +374,27 @@ __global__ void __launch_bounds__(256) k_var_final(VarFinArgs a) {
           int d = p % D, k = p / D;
           dvs[dm.off_mu + p] = -w[k] * w[k] * (2.0 * vg[(size_t)k * (2 * D + 1) + d]);  // :289
         }
-      if (dm.opt[1])
-        for (int k = tid; k < K; k += nt) {
-          double slt = 0.0, sl2 = 0.0;
-          for (int d = 0; d < D; ++d) {
-            double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
-            slt += log(sqrt(t2));
-            sl2 += lam[d] * lam[d] / t2;
-          }
-          double nfkk = exp(g[3 * D] - slt);
-          dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * nfkk * sl2 + vg[(size_t)k * (2 * D + 1) + D]) * sigma[k];  // :293, Jacobian :382
+      // nf_kk and sum_d lambda_d^2 / tau_kk,d^2 once per component (:274-275,293)
+      for (int k = tid; k < K; k += nt) {
+        double slt = 0.0, sl2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
+          slt += log(sqrt(t2));
+          sl2 += lam[d] * lam[d] / t2;
         }
+        tmpK[k] = exp(g[3 * D] - slt);
+        tmpK2[k] = sl2;
+      }
+      __syncthreads();
+      if (dm.opt[1])
+        for (int k = tid; k < K; k += nt)
+          dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * tmpK[k] * tmpK2[k] + vg[(size_t)k * (2 * D + 1) + D]) * sigma[k];  // :293, Jacobian :382
       if (dm.opt[2])
         for (int d = tid; d < D; d += nt) {
           double accd = 0.0;
           for (int k = 0; k < K; ++k) {
-            double slt = 0.0;
-            for (int dd = 0; dd < D; ++dd)
-              slt += log(sqrt(2.0 * sigma[k] * sigma[k] * lam[dd] * lam[dd] + g[dd] + 2.0 * a.delta2[dd]));
-            double nfkk = exp(g[3 * D] - slt);
             double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
-            accd -= 2.0 * w[k] * w[k] * (sigma[k] * sigma[k] * nfkk * lam[d] / t2 + vg[(size_t)k * (2 * D + 1) + D + 1 + d]);  // :297
+            accd -= 2.0 * w[k] * w[k] * (sigma[k] * sigma[k] * tmpK[k] * lam[d] / t2 + vg[(size_t)k * (2 * D + 1) + D + 1 + d]);  // :297
           }
           dvs[dm.off_lambda + d] = accd * lam[d];  // Jacobian :386
         }
