@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--Ns", type=int, default=10000)
     ap.add_argument("--S", type=int, default=20)
     ap.add_argument("--eps-stream", action="store_true", help="also time the parity mode (eps streamed from HBM)")
+    ap.add_argument("--extras", action="store_true", help="also report on-device Adam, single-call latency and block-sparse mode")
     args = ap.parse_args()
 
     import torch
@@ -204,26 +205,28 @@ def main():
                         "traffic: device-RNG mode reads no O(Ns) data from HBM (FETCH_SIZE per launch is in profiles/)"}
         extra["logjoint_kernel_ms"] = lj_ms
         # single-chain latency: the on-device Adam loop (vbmc_adam_batch) vs one host round trip per evaluation
-        for Rc in (1, 2):
+        for Rc in ((1, 2) if args.extras else ()):
             x0 = thetas[:, :Rc].copy()
             vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 40, seed=5, engine=eng)  # warm-up
             t1 = time.perf_counter()
             _, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 200, seed=6, engine=eng)
             extra["device_adam_R%d_evals_per_s" % Rc] = float(np.sum(its)) / (time.perf_counter() - t1)
         t1 = time.perf_counter()
-        for i in range(50):
+        for i in range(50 if args.extras else 0):
             vbmc_amd.negelcbo_batch(thetas[:, :1], 0, vp, gp, Ns, True, 0, seed=900 + i, engine=eng)
-        extra["host_loop_R1_evals_per_s"] = 50 / (time.perf_counter() - t1)
+        if args.extras:
+            extra["host_loop_R1_evals_per_s"] = 50 / (time.perf_counter() - t1)
         # opt-in block-sparse mode (vbmc_elbo_args.sparse_cutoff = 100): same outputs to < 1e-13, component tiles whose
         # terms are < e^-100 of q(x) are skipped -- data dependent, NOT the headline value
-        for i in range(2):
+        for i in range(2 if args.extras else 0):
             sp = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=40 + i, engine=eng, sparse_cutoff=100.0)
-        dn = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=41, engine=eng)
-        t1 = time.perf_counter()
-        for i in range(5):
-            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=50 + i, engine=eng, sparse_cutoff=100.0)
-        extra["block_sparse"] = {"evals_per_s": 5 * Rr / (time.perf_counter() - t1), "cutoff": 100.0,
-                                 "max_rel_diff_vs_dense": float(np.max(np.abs(sp["dF"] - dn["dF"])) / np.max(np.abs(dn["dF"])))}
+        if args.extras:
+            dn = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=41, engine=eng)
+            t1 = time.perf_counter()
+            for i in range(5):
+                vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=50 + i, engine=eng, sparse_cutoff=100.0)
+            extra["block_sparse"] = {"evals_per_s": 5 * Rr / (time.perf_counter() - t1), "cutoff": 100.0,
+                                     "max_rel_diff_vs_dense": float(np.max(np.abs(sp["dF"] - dn["dF"])) / np.max(np.abs(dn["dF"])))}
         if args.eps_stream:
             g = torch.Generator(device=dev)
             g.manual_seed(1)
