@@ -287,6 +287,7 @@ struct ElboPlan {
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, var_stride = 0;
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
+  double *d_ljbar = nullptr;
   double *d_vpd = nullptr, *d_entp = nullptr, *d_lj = nullptr, *d_out = nullptr, *d_part = nullptr, *d_red = nullptr;
   double *d_Z = nullptr, *d_X = nullptr, *d_J = nullptr, *d_vg = nullptr, *d_var = nullptr;
   const double* d_eps = nullptr;
@@ -389,11 +390,12 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   { vbmc_status s_ = ensure(ctx, ctx->prep, (size_t)R * VL.stride() * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->entp, (size_t)R * K * (D + ENTP_EXTRA) * sizeof(double)); if (s_) return s_; }
   const int LJS = 2 * D + 2;
-  { vbmc_status s_ = ensure(ctx, ctx->ljpart, (size_t)R * S * K * LJS * sizeof(double)); if (s_) return s_; }
+  { vbmc_status s_ = ensure(ctx, ctx->ljpart, ((size_t)R * S * K * LJS + (size_t)R * K * LJS) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->out, P.out_n * sizeof(double)); if (s_) return s_; }
   P.d_vpd = (double*)ctx->prep.p;
   P.d_entp = (double*)ctx->entp.p;
   P.d_lj = (double*)ctx->ljpart.p;
+  P.d_ljbar = P.d_lj + (size_t)R * S * K * LJS;
   P.d_out = (double*)ctx->out.p;
 
   if (P.mc) {
@@ -546,7 +548,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   }
 
   // ---- finalize
-  fa.vpd = P.d_vpd; fa.theta = P.d_theta; fa.lj = P.d_lj; fa.var = P.d_var; fa.var_stride = P.d_var ? P.var_stride : 0;
+  // log-joint partials summed over hyper-samples (in sample order), one record per (r, k)
+  hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, st, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
+  fa.vpd = P.d_vpd; fa.theta = P.d_theta; fa.ljbar = P.d_ljbar; fa.var = P.d_var; fa.var_stride = P.d_var ? P.var_stride : 0;
   fa.bnd = P.d_bnd; fa.has_bnd = P.has_bnd ? 1 : 0;
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
   fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out;

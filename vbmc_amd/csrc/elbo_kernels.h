@@ -46,16 +46,21 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, const double* __restr
     v[L.lambda() + d] = dm.opt[2] ? exp(ll) : flam[d];
   }
   __syncthreads();
-  if (tid == 0) {
-    // vp.w = exp(eta)/sum(exp(eta)), no max-shift (:45-47); serial sum = MATLAB's sum order
-    double ssum = 0.0;
-    if (dm.opt[3]) {
-      for (int k = 0; k < K; ++k) ssum += exp(th[dm.off_eta + k]);
-    }
-    s_sum = ssum;
-    double slog = 0.0;
-    for (int d = 0; d < D; ++d) slog += log(v[L.lambda() + d]);
-    v[L.lognf()] = -0.5 * D * 1.8378770664093454835606594728112 - slog;  // log((2pi)^(-D/2)/prod(lambda))
+  {
+    // vp.w = exp(eta)/sum(exp(eta)), no max-shift (:45-47); log nf = -D/2 log(2 pi) - sum log lambda
+    __shared__ double redp[256];
+    double pe_ = 0.0, pl_ = 0.0;
+    if (dm.opt[3]) for (int k = tid; k < K; k += nt) pe_ += exp(th[dm.off_eta + k]);
+    for (int d = tid; d < D; d += nt) pl_ += log(v[L.lambda() + d]);
+    redp[tid] = pe_;
+    __syncthreads();
+    for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) redp[tid] += redp[tid + st]; __syncthreads(); }
+    if (tid == 0) s_sum = redp[0];
+    __syncthreads();
+    redp[tid] = pl_;
+    __syncthreads();
+    for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) redp[tid] += redp[tid + st]; __syncthreads(); }
+    if (tid == 0) v[L.lognf()] = -0.5 * D * 1.8378770664093454835606594728112 - redp[0];
   }
   __syncthreads();
   for (int k = tid; k < K; k += nt) {
@@ -510,6 +515,18 @@ __global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const doubl
   }
 }
 
+// k_lj_reduce: sum the log-joint partials over hyper-samples in sample order, one thread per column:
+// ljbar[r][k][col] = sum_s lj[r][s][k][col]   (gplogjoint.m:399-413 averages are linear in these sums)
+__global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const double* __restrict__ lj,
+                                                  double* __restrict__ ljbar) {
+  const int k = blockIdx.x, r = blockIdx.y;
+  for (int col = threadIdx.x; col < LJS; col += blockDim.x) {
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += lj[(((size_t)r * S + s) * K + k) * LJS + col];
+    ljbar[((size_t)r * K + k) * LJS + col] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_finalize: reduce partials in a fixed order, apply Jacobians (gplogjoint.m:352-373,
 // entmc_vbmc.m:106-125), average over hyper-samples (gplogjoint.m:399-413), add the soft-bound
@@ -519,7 +536,7 @@ struct FinArgs {
   ElboDims dm;
   const double* vpd;
   const double* theta;
-  const double* lj;       // R x S x K x (2D+2)
+  const double* ljbar;    // R x K x (2D+2): log-joint partials summed over hyper-samples
   const double* entpart;  // MC partials or null
   const double* entlb;    // entlb block or null
   const double* var;      // R x 2 (varG, varGss) + optional dvarG[T] per restart, or null
@@ -562,82 +579,31 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
   double* scal = dP + T;       // 8 scalars
   double* o = a.out + (size_t)r * (OUT_HDR + 3 * T);
   const int LJS = 2 * D + 2;
-  const double* lj = a.lj + (size_t)r * S * K * LJS;
   const double invS = 1.0 / S;
 
   for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
-  // ---- expected log joint: F(s) = sum_k w_k I_k ; G = sum_s F(s)/S
-  for (int k = tid; k < K; k += nt) {
-    double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS];
-    Ibar[k] = acc * invS;
-  }
+  // ---- expected log joint from the per-component sums over hyper-samples (k_lj_reduce):
+  // G = (1/S) sum_s sum_k w_k I_sk  (:203,:400)
+  const double* lb = a.ljbar + (size_t)r * K * LJS;
+  for (int k = tid; k < K; k += nt) Ibar[k] = lb[(size_t)k * LJS] * invS;
   __syncthreads();
-  // F(s) = sum_k w_k I_k in parallel over s (:203), then summed in order by one thread
-  if (S <= nt) {
-    if (tid < S) {
-      double Fs = 0.0;
-      for (int k = 0; k < K; ++k) Fs += w[k] * lj[((size_t)tid * K + k) * LJS];
-      red[tid] = Fs;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double G = 0.0;
-      for (int s = 0; s < S; ++s) G += red[s];
-      scal[0] = G * invS;  // Fbar (:400); equals F when S == 1
-    }
-    __syncthreads();
-  } else if (tid == 0) {
-    double G = 0.0;
-    for (int s = 0; s < S; ++s) {
-      double Fs = 0.0;
-      for (int k = 0; k < K; ++k) Fs += w[k] * lj[((size_t)s * K + k) * LJS];
-      G += Fs;
-    }
-    scal[0] = G * invS;
+  {
+    double part = 0.0;
+    for (int k = tid; k < K; k += nt) part += w[k] * Ibar[k];
+    double G = block_sum(part, red);
+    if (tid == 0) scal[0] = G;
   }
   if (a.want_grad) {
     if (dm.opt[0])
-      for (int p = tid; p < D * K; p += nt) {
-        int d = p % D, k = p / D;
-        double acc = 0.0;
-        for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS + 1 + d];
-        dG[dm.off_mu + p] = acc * invS;
-      }
+      for (int p = tid; p < D * K; p += nt) dG[dm.off_mu + p] = lb[(size_t)(p / D) * LJS + 1 + p % D] * invS;
     if (dm.opt[1])
-      for (int k = tid; k < K; k += nt) {
+      for (int k = tid; k < K; k += nt) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * sigma[k] * invS;  // Jacobian :356
+    if (dm.opt[2])
+      for (int d = tid; d < D; d += nt) {
         double acc = 0.0;
-        for (int s = 0; s < S; ++s) acc += lj[((size_t)s * K + k) * LJS + 1 + D] * sigma[k];  // Jacobian :356
-        dG[dm.off_sigma + k] = acc * invS;
+        for (int k = 0; k < K; ++k) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
+        dG[dm.off_lambda + d] = acc * lam[d] * invS;                            // :362
       }
-    if (dm.opt[2]) {
-      // lambda_grad(d,s) = sum_k (...) (:250): one thread per (d, s) when it fits, summed over s in order
-      if (D * S <= nt) {
-        if (tid < D * S) {
-          const int d = tid % D, s = tid / D;
-          double ls = 0.0;
-          for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
-          red[tid] = ls * lam[d];                                                        // :362
-        }
-        __syncthreads();
-        for (int d = tid; d < D; d += nt) {
-          double acc = 0.0;
-          for (int s = 0; s < S; ++s) acc += red[d + D * s];
-          dG[dm.off_lambda + d] = acc * invS;
-        }
-        __syncthreads();
-      } else {
-        for (int d = tid; d < D; d += nt) {
-          double acc = 0.0;
-          for (int s = 0; s < S; ++s) {
-            double ls = 0.0;
-            for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
-            acc += ls * lam[d];
-          }
-          dG[dm.off_lambda + d] = acc * invS;
-        }
-      }
-    }
   }
   __syncthreads();
   if (a.want_grad && dm.opt[3]) {
