@@ -330,8 +330,8 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     return set_err(ctx, VBMC_ERR_INVALID, "Computing the gradient of variational parameters and requesting per-component results at the same time.");
   if (compute_var != 0 && !gp->hasL)
     return set_err(ctx, VBMC_ERR_INVALID, "compute_var != 0 needs gp.post(s).L: upload the GP with L");
-  if (compute_var != 0 && ((size_t)dm.N * 16 + 256) * sizeof(double) > 160 * 1024)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1264 not accelerated", dm.N);
+  if (compute_var != 0 && TRSM_LDS_BYTES(dm.N) > 160 * 1024)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1184 not accelerated", dm.N);
   P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
   // theta must be finite (the device exp does not propagate NaN)
   for (size_t i = 0; i < (size_t)T * R; ++i)
@@ -460,7 +460,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     P.d_J = P.d_X + (P.needX ? nz : 0);
     P.d_vg = P.d_J + nJ;
     P.d_var = P.d_vg + nvg;
-    P.tlds = ((size_t)N * 16 + 256) * sizeof(double);
+    P.tlds = TRSM_LDS_BYTES(N);
   }
   return VBMC_OK;
 }
@@ -527,11 +527,11 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     }
     const dim3 tg((K + TR_CB - 1) / TR_CB, S, R);
     if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z);
     hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                        P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);
     if (P.vgrad) {
-      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(256), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
+      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
       DISPATCH_DT(dt, {
         hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2,
                            gp->d_sn2, gp->d_lchol, P.d_X, P.d_vg);

@@ -171,15 +171,15 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   const int moff = Ncov + Nnoise;
   hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
                      dhyp.as<double>(), dr.as<double>());
-  const size_t tlds = ((size_t)N * 16 + 256) * 8;
+  const size_t tlds = TRSM_LDS_BYTES(N);
   if (tlds > 64 * 1024) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
   }
   TmpBuf dal;
   HIP_TRY(ctx, dal.alloc((size_t)S * N * 8));
-  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, dA.as<double>(), dones.as<unsigned char>(), dr.as<double>());
-  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, dA.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
+  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, dA.as<double>(), dones.as<unsigned char>(), dr.as<double>());
+  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, dA.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
   hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, st, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
   HIP_TRY(ctx, hipGetLastError());
 
@@ -194,8 +194,8 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
       HIP_TRY(ctx, dXi.alloc((size_t)S * N * N * 8));
       hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, dZ.as<double>());
       dim3 tg((N + TR_CB - 1) / TR_CB, S, 1);
-      hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(256), tlds, st, N, N, S, dA.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
-      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(256), tlds, st, N, N, S, dA.as<double>(), dninv.as<unsigned char>(), dZ.as<double>(), dXi.as<double>());
+      hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
+      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dninv.as<unsigned char>(), dZ.as<double>(), dXi.as<double>());
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(st));
       for (int s = 0; s < S; ++s) {
@@ -251,7 +251,7 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
   if ((gp->noisefun[1] == 1 || gp->noisefun[1] == 2) && !s2star)
     return set_err(ctx, VBMC_ERR_INVALID, "gplite_pred: S2STAR is required by the noise function");
   const int N = gp->N, D = gp->D, S = gp->S;
-  const size_t plds = ((size_t)N * 16 + 256 + 256 + 16 * 32 + 64) * 8;
+  const size_t plds = TRSM_LDS_BYTES(N) + (size_t)16 * 32 * 8;
   if (plds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -262,7 +262,10 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
     for (int j = 0; j < Nstar; ++j) sb += Xstar[j + (size_t)Nstar * d];
     mb[d] = sb / Nstar;
   }
-  TmpBuf dXs, ds2, dmb, dout, davg;
+  TmpBuf dXs, ds2, dmb, dout, davg, dXc, daa, dmuv;
+  HIP_TRY(ctx, dXc.alloc((size_t)S * N * D * 8));
+  HIP_TRY(ctx, daa.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dmuv.alloc((size_t)S * 2 * D * 8));
   HIP_TRY(ctx, dXs.alloc((size_t)Nstar * D * 8));
   HIP_TRY(ctx, dmb.alloc((size_t)D * 8));
   HIP_TRY(ctx, dout.alloc((size_t)3 * Nstar * S * 8));
@@ -279,9 +282,10 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
   pa.alpha = gp->alpha; pa.L = gp->L; pa.sn2_eff = gp->d_sn2; pa.sn2_mult = gp->d_mult; pa.lchol = gp->d_lchol;
   pa.mean_a = gp->d_meanX; pa.mean_b = dmb.as<double>();
   pa.fmu = dout.as<double>(); pa.fs2 = pa.fmu + (size_t)Nstar * S; pa.ys2 = pa.fs2 + (size_t)Nstar * S;
+  hipLaunchKernelGGL(k_pred_prep, dim3(4, S), dim3(256), 0, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
   if (plds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-  hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(256), plds, st, pa);
+  hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(64), plds, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   const size_t ns = (size_t)Nstar * S;
   if (S > 1 && !ssflag) {
@@ -317,7 +321,7 @@ extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, co
   if (!gp || !xstar || !Ks || !v || !x) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves: null argument");
   if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves needs gp.post(s).L on the device");
   const int N = gp->N, D = gp->D, S = gp->S;
-  const size_t tlds = ((size_t)N * 16 + 256) * 8;
+  const size_t tlds = TRSM_LDS_BYTES(N);
   if (tlds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -335,8 +339,8 @@ extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, co
   }
   // Lchol samples: triangular solves; the others (flag 0) are skipped by the kernels and handled by k_symm
   hipLaunchKernelGGL(k_symm, dim3(8, S, 1), dim3(256), 0, st, N, 1, S, gp->L, gp->d_lchol, dKs.as<double>(), dXo.as<double>());
-  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, gp->L, gp->d_lchol, dV.as<double>());
-  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(256), tlds, st, N, 1, S, gp->L, gp->d_lchol, dV.as<double>(), dXo.as<double>());
+  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, gp->L, gp->d_lchol, dV.as<double>());
+  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, gp->L, gp->d_lchol, dV.as<double>(), dXo.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(Ks, dKs.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(v, dV.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));

@@ -10,7 +10,9 @@
 //   k_chol          in-place blocked (16) right-looking Cholesky, upper factor, one WG per sample,
 //                   reports MATLAB's p (> 0 = not positive definite) for the jitter retry
 //   k_gp_resid      r = y - m(X)
-//   k_gp_pred       fused: cross-kernel tile -> fmu = m* + Ks'alpha, V = L'\(sW.*Ks), fs2 = kss - |V|^2
+//   k_pred_prep     ell-scaled, sq_dist-centred training inputs per hyper-sample
+//   k_gp_pred       one wave per 16 test points: cross-kernel slab -> fmu = m* + Ks'alpha, V = L'\(sW.*Ks) by the
+//                   MFMA triangular solve (trsm_mfma.h), fs2 = kss - |V|^2
 //   k_pred_avg      hyper-sample averaging with between-sample variance (gplite_pred.m:154-165)
 #pragma once
 #include "common.h"
@@ -259,7 +261,7 @@ __global__ void k_negate_copy(size_t n, const double* __restrict__ src, double* 
 }
 
 // ------------------------------------------------------------------------------------------
-// Prediction: one workgroup = 16 test points x one hyper-sample.
+// Prediction: one wave = 16 test points x one hyper-sample.
 // ------------------------------------------------------------------------------------------
 struct PredArgs {
   int N, D, S, Nhyp, Nstar, meanfun, moff, noff, nf0, nf1;
@@ -279,113 +281,112 @@ struct PredArgs {
   double* ys2;
 };
 
-__global__ void __launch_bounds__(256) k_gp_pred(PredArgs a) {
-  extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y;
-  const int tid = threadIdx.x, c = tid & 15, ri = tid >> 4;
-  const int N = a.N, D = a.D;
-  const int jc = cb * 16 + c;
-  const bool cv = jc < a.Nstar;
+// k_pred_prep: per hyper-sample the ell-scaled, sq_dist-centred training inputs and their squared norms:
+// Xc[s][i][d] = X(i,d)/ell_d - mu_d,  aa[s][i] = |Xc_i|^2,  mu = (m/(n+m)) mean(b) + (n/(n+m)) mean(a)  (sq_dist.m:36)
+__global__ void __launch_bounds__(256) k_pred_prep(PredArgs a, double* __restrict__ Xc, double* __restrict__ aa,
+                                                   double* __restrict__ muv /* S x 2D: mu, 1/ell */) {
+  const int s = blockIdx.y, N = a.N, D = a.D;
   const double* h = a.hyp + (size_t)s * a.Nhyp;
-  double* V = lds;                   // N x 16
-  double* Rd = V + (size_t)N * 16;   // 256
-  double* red = Rd + 256;            // 256
-  double* xs = red + 256;            // 16 x D scaled centred test points
-  double* muv = xs + 16 * 32;        // D
-  double* ellv = muv + 32;           // D
-  const double sf2 = exp(2.0 * h[D]);
-  if (tid < D) {
-    ellv[tid] = exp(h[tid]);
-    // sq_dist(a,b) centring: mu = (m/(n+m)) mean(b) + (n/(n+m)) mean(a), on the ell-scaled inputs (sq_dist.m:36)
-    double ell = exp(h[tid]);
-    double n = (double)N, m = (double)a.Nstar;
-    muv[tid] = (m / (n + m)) * (a.mean_b[tid] / ell) + (n / (n + m)) * (a.mean_a[tid] / ell);
+  __shared__ double mu[32], iell[32];
+  if (threadIdx.x < D) {
+    const int d = threadIdx.x;
+    const double ie = 1.0 / exp(h[d]);   // diag(1./ell) * X'   (gplite_pred.m:73)
+    const double n = (double)N, m = (double)a.Nstar;
+    iell[d] = ie;
+    mu[d] = (m / (n + m)) * (a.mean_b[d] * ie) + (n / (n + m)) * (a.mean_a[d] * ie);
+    if (blockIdx.x == 0) { muv[(size_t)s * 2 * D + d] = mu[d]; muv[(size_t)s * 2 * D + D + d] = ie; }
   }
   __syncthreads();
-  if (ri == 0) {
-    for (int d = 0; d < D; ++d) xs[c * 32 + d] = cv ? a.Xs[jc + (size_t)a.Nstar * d] / ellv[d] - muv[d] : 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double v = a.X[i + (size_t)N * d] * iell[d] - mu[d];
+      Xc[((size_t)s * N + i) * D + d] = v;
+      acc = fma(v, v, acc);
+    }
+    aa[(size_t)s * N + i] = acc;
   }
+}
+
+// k_gp_pred: one wave = 16 test points x one hyper-sample.  The cross-kernel slab Ks (N x 16) is built
+// in LDS, fmu = m* + Ks' alpha is accumulated on the way, then V = L' \ (sW .* Ks) by the MFMA
+// triangular solve (trsm_mfma.h) and fs2 = kss - sum(V.^2)  (gplite_pred.m:73-104).
+__global__ void __launch_bounds__(64) k_gp_pred(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
+                                                const double* __restrict__ muv) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  const int li = lane & 15, lg = lane >> 4;
+  const int N = a.N, D = a.D;
+  const int Np = ((N + 15) >> 4) << 4;
+  double* V = lds;                        // Np x TR_VS
+  double* Rd = V + (size_t)Np * TR_VS;    // 256
+  double* IDG = Rd + 256;                 // 16
+  double* xs = IDG + 16;                  // 16 x 32 scaled centred test points
+  const double* h = a.hyp + (size_t)s * a.Nhyp;
+  const double* mu = muv + (size_t)s * 2 * D;
+  const double* iell = mu + D;
+  const int jc = cb * 16 + li;
+  const bool cv = jc < a.Nstar;
+  const double sf2 = exp(2.0 * h[D]);
+  for (int d = lg; d < D; d += 4) xs[li * 32 + d] = cv ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
   __syncthreads();
   double bb = 0.0;
-  for (int d = 0; d < D; ++d) bb = fma(xs[c * 32 + d], xs[c * 32 + d], bb);
+  for (int d = 0; d < D; ++d) bb = fma(xs[li * 32 + d], xs[li * 32 + d], bb);
   const double* al = a.alpha + (size_t)s * N;
+  const double* xcs = Xc + (size_t)s * N * D;
+  const double* aas = aa + (size_t)s * N;
+  const bool lc = a.lchol[s] != 0;
+  const double sW = lc ? 1.0 / sqrt(a.sn2_eff[s]) : 1.0;
   double fm = 0.0;
-  for (int i = ri; i < N; i += 16) {
-    double aa = 0.0, dot = 0.0;
-    for (int d = 0; d < D; ++d) {
-      double av = a.X[i + (size_t)N * d] / ellv[d] - muv[d];
-      aa = fma(av, av, aa);
-      dot = fma(av, xs[c * 32 + d], dot);
+  for (int i = lg; i < Np; i += 4) {
+    double ks = 0.0;
+    if (i < N) {
+      double dot = 0.0;
+      for (int d = 0; d < D; ++d) dot = fma(xcs[(size_t)i * D + d], xs[li * 32 + d], dot);
+      const double cdist = fmax(aas[i] + (bb - 2.0 * dot), 0.0);     // sq_dist.m:45,49
+      ks = sf2 * exp(-cdist / 2.0);                                  // gplite_pred.m:74
+      fm = fma(ks, al[i], fm);
     }
-    double cdist = fmax(aa + (bb - 2.0 * dot), 0.0);
-    double ks = sf2 * exp(-cdist / 2.0);   // gplite_pred.m:73-74
-    V[i * 16 + c] = ks;
-    fm = fma(ks, al[i], fm);
+    V[i * TR_VS + li] = ks * sW;                                     // sW .* Ks (:99); plain Ks when !Lchol
   }
-  red[tid] = fm;
+  fm += __shfl_xor(fm, 16, 64);
+  fm += __shfl_xor(fm, 32, 64);
+  double mstar = 0.0;
+  if (cv) mstar = gp_meanfun(a.meanfun, D, h + a.moff, a.Xs + jc, (size_t)a.Nstar);
+  const double fmu = mstar + fm;                                     // :83
   __syncthreads();
-  double fmu = 0.0;
-  if (ri == 0) {
-    for (int q = 0; q < 16; ++q) fmu += red[q * 16 + c];
-    const double* hm = h + a.moff;
-    double mstar = 0.0;
-    if (cv) mstar = gp_meanfun(a.meanfun, D, hm, a.Xs + jc, (size_t)a.Nstar);
-    fmu += mstar;  // :83
-  }
-  __syncthreads();
-  double fs2;
   const double* Rm = a.L + (size_t)s * N * N;
-  if (a.lchol[s]) {
-    const double sW = 1.0 / sqrt(a.sn2_eff[s]);
-    for (int i = ri; i < N; i += 16) V[i * 16 + c] *= sW;  // sW .* Ks  (:99)
-    __syncthreads();
-    for (int b0 = 0; b0 < N; b0 += TR_B) {
-      const int nb = min(TR_B, N - b0);
-      double acc = 0.0;
-      if (ri < nb) {
-        const double* col = Rm + (size_t)(b0 + ri) * N;
-        for (int j = 0; j < b0; ++j) acc = fma(col[j], V[j * 16 + c], acc);
-      }
-      {
-        int jj = tid >> 4, ii = tid & 15;
-        Rd[jj * 16 + ii] = (jj < nb && ii < nb) ? Rm[(size_t)(b0 + ii) * N + b0 + jj] : 0.0;
-      }
-      __syncthreads();
-      if (ri < nb) V[(b0 + ri) * 16 + c] -= acc;
-      __syncthreads();
-      if (ri == 0) {
-        for (int ii = 0; ii < nb; ++ii) {
-          double t = V[(b0 + ii) * 16 + c];
-          for (int jj = 0; jj < ii; ++jj) t = fma(-Rd[jj * 16 + ii], V[(b0 + jj) * 16 + c], t);
-          V[(b0 + ii) * 16 + c] = t / Rd[ii * 16 + ii];
-        }
-      }
-      __syncthreads();
-    }
+  double fs2;
+  if (lc) {
+    trsm_fwd_wave(N, Rm, V, Rd, IDG, lane);
     double part = 0.0;
-    for (int i = ri; i < N; i += 16) part = fma(V[i * 16 + c], V[i * 16 + c], part);
-    red[tid] = part;
-    __syncthreads();
-    double vv = 0.0;
-    if (ri == 0) for (int q = 0; q < 16; ++q) vv += red[q * 16 + c];
-    fs2 = sf2 - vv;  // kss - sum(V.*V)  (:100)
+    for (int i = lg; i < N; i += 4) part = fma(V[i * TR_VS + li], V[i * TR_VS + li], part);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    fs2 = sf2 - part;                                                // kss - sum(V.*V)  (:100)
   } else {
-    // fs2 = kss + sum(Ks .* (L*Ks))  (:103-104)
+    // fs2 = kss + sum(Ks .* (L*Ks))  (:103-104): U_b = L[b,:] * Ks by MFMA, 16 rows at a time
     double part = 0.0;
-    for (int i = ri; i < N; i += 16) {
-      double lk = 0.0;
-      for (int j = 0; j < N; ++j) lk = fma(Rm[(size_t)j * N + i], V[j * 16 + c], lk);
-      part = fma(V[i * 16 + c], lk, part);
+    const int nblk = Np >> 4;
+    for (int bi = 0; bi < nblk; ++bi) {
+      const int b0 = bi << 4;
+      tmf4 acc = {0.0, 0.0, 0.0, 0.0};
+      const bool rv = b0 + li < N;
+      for (int j0 = 0; j0 < Np; j0 += 4) {
+        const int j = j0 + lg;
+        const double av = (rv && j < N) ? Rm[(size_t)j * N + b0 + li] : 0.0;   // L[b0+li][j] (symmetric storage, full)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, V[j * TR_VS + li], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fma(V[(b0 + lg + 4 * r) * TR_VS + li], acc[r], part);
     }
-    red[tid] = part;
-    __syncthreads();
-    double vv = 0.0;
-    if (ri == 0) for (int q = 0; q < 16; ++q) vv += red[q * 16 + c];
-    fs2 = sf2 + vv;
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    fs2 = sf2 + part;
   }
-  if (ri == 0 && cv) {
+  if (lg == 0 && cv) {
     fs2 = fmax(fs2, 0.0);  // :120
-    // noise at the test points (gplite_noisefun.m:176-194; output-dependent term needs ystar: not here)
+    // noise at the test points (gplite_noisefun.m:176-194; the output-dependent term needs ystar: not here)
     double sn2s = a.nf0 ? exp(2.0 * h[a.noff]) : 2.220446049250313e-16;
     if (a.nf1 == 1 && a.s2s) sn2s += a.s2s[jc];
     else if (a.nf1 == 2 && a.s2s) sn2s += exp(h[a.noff + (a.nf0 ? 1 : 0)]) * a.s2s[jc];

@@ -7,7 +7,7 @@
 // agree to summation order.
 //
 //   k_var_z       Z[r][s][k][:] = z_k  (gplogjoint.m:164-168)
-//   k_trsm_fwd    V = L' \ Z   (L upper, MATLAB chol convention), 16 columns per workgroup in LDS
+//   k_trsm_fwd    V = L' \ Z   (L upper, MATLAB chol convention): trsm_mfma.h, one wave per 16 columns, MFMA f64
 //   k_trsm_bwd    X = L \ V    (only for the variance gradient: invKzk = X / sn2_eff, :277)
 //   k_symm        U = L * Z    (Lchol == false: L = -inv(K + sn2 I), :279,:321)
 //   k_var_gram    J[r][s][j][k] (:281,:318-322) and the raw varF(s) terms
@@ -17,6 +17,7 @@
 #include "common.h"
 #include "device_math.h"
 #include "elbo_kernels.h"
+#include "trsm_mfma.h"
 
 #define TR_CB 16   // right-hand-side columns per workgroup
 #define TR_B 16    // row block
@@ -56,109 +57,6 @@ __global__ void __launch_bounds__(WAVE) k_var_z(ElboDims dm, const double* __res
     }
     z[n] = vb_exp(lnnf - 0.5 * a2);
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Forward substitution with R' (R upper triangular, column-major N x N): solve R' V = Z in place.
-// One workgroup = 256 threads = 16 row-lanes x 16 columns; the N x 16 slab of V lives in LDS.
-// v_i = (z_i - sum_{j<i} R[j][i] v_j) / R[i][i]; column i of R is contiguous.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_trsm_fwd(int N, int K, int S, const double* __restrict__ Lall,
-                                                  const unsigned char* __restrict__ lchol, double* __restrict__ Z) {
-  extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
-  if (!lchol[s]) return;
-  const int tid = threadIdx.x, c = tid & 15, ri = tid >> 4;
-  const int k0 = cb * TR_CB;
-  const int kc = k0 + c;
-  const bool cv = kc < K;
-  const double* Rm = Lall + (size_t)s * N * N;
-  double* Zs = Z + ((size_t)r * S + s) * (size_t)K * N;
-  double* V = lds;                    // N x 16 (row-major: V[i*16 + c])
-  double* Rd = V + (size_t)N * 16;    // 16 x 16 diagonal block, Rd[jj*16 + ii] = R[b0+jj][b0+ii]
-  for (int i = ri; i < N; i += 16) V[i * 16 + c] = cv ? Zs[(size_t)kc * N + i] : 0.0;
-  __syncthreads();
-  for (int b0 = 0; b0 < N; b0 += TR_B) {
-    const int nb = min(TR_B, N - b0);
-    // trailing update from all solved rows j < b0
-    double acc = 0.0;
-    if (ri < nb) {
-      const double* col = Rm + (size_t)(b0 + ri) * N;  // column b0+ri of R
-      int j = 0;
-      for (; j + 4 <= b0; j += 4) {
-        acc = fma(col[j], V[j * 16 + c], acc);
-        acc = fma(col[j + 1], V[(j + 1) * 16 + c], acc);
-        acc = fma(col[j + 2], V[(j + 2) * 16 + c], acc);
-        acc = fma(col[j + 3], V[(j + 3) * 16 + c], acc);
-      }
-      for (; j < b0; ++j) acc = fma(col[j], V[j * 16 + c], acc);
-    }
-    // diagonal block to LDS
-    {
-      int jj = tid >> 4, ii = tid & 15;
-      Rd[jj * 16 + ii] = (jj < nb && ii < nb) ? Rm[(size_t)(b0 + ii) * N + b0 + jj] : 0.0;
-    }
-    __syncthreads();
-    if (ri < nb) V[(b0 + ri) * 16 + c] -= acc;
-    __syncthreads();
-    // sequential solve inside the block: thread c (ri == 0) owns column c
-    if (ri == 0) {
-      for (int ii = 0; ii < nb; ++ii) {
-        double t = V[(b0 + ii) * 16 + c];
-        for (int jj = 0; jj < ii; ++jj) t = fma(-Rd[jj * 16 + ii], V[(b0 + jj) * 16 + c], t);
-        V[(b0 + ii) * 16 + c] = t / Rd[ii * 16 + ii];
-      }
-    }
-    __syncthreads();
-  }
-  if (cv)
-    for (int i = ri; i < N; i += 16) Zs[(size_t)kc * N + i] = V[i * 16 + c];
-}
-
-// Backward substitution with R: solve R Xo = V (V read, Xo written).  x_i = (v_i - sum_{j>i} R[i][j] x_j)/R[i][i]
-__global__ void __launch_bounds__(256) k_trsm_bwd(int N, int K, int S, const double* __restrict__ Lall,
-                                                  const unsigned char* __restrict__ lchol,
-                                                  const double* __restrict__ Vin, double* __restrict__ Xo) {
-  extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
-  if (!lchol[s]) return;
-  const int tid = threadIdx.x, c = tid & 15, ri = tid >> 4;
-  const int kc = cb * TR_CB + c;
-  const bool cv = kc < K;
-  const double* Rm = Lall + (size_t)s * N * N;
-  const double* Vs = Vin + ((size_t)r * S + s) * (size_t)K * N;
-  double* Xs = Xo + ((size_t)r * S + s) * (size_t)K * N;
-  double* V = lds;
-  double* Rd = V + (size_t)N * 16;
-  for (int i = ri; i < N; i += 16) V[i * 16 + c] = cv ? Vs[(size_t)kc * N + i] : 0.0;
-  __syncthreads();
-  const int nblk = (N + TR_B - 1) / TR_B;
-  for (int bi = nblk - 1; bi >= 0; --bi) {
-    const int b0 = bi * TR_B;
-    const int nb = min(TR_B, N - b0);
-    const int e0 = b0 + nb;  // rows >= e0 are solved
-    double acc = 0.0;
-    if (ri < nb) {
-      for (int j = e0; j < N; ++j) acc = fma(Rm[(size_t)j * N + b0 + ri], V[j * 16 + c], acc);  // R[b0+ri][j]
-    }
-    {
-      int jj = tid >> 4, ii = tid & 15;  // Rd[ii*16 + jj] = R[b0+ii][b0+jj]
-      Rd[ii * 16 + jj] = (jj < nb && ii < nb) ? Rm[(size_t)(b0 + jj) * N + b0 + ii] : 0.0;
-    }
-    __syncthreads();
-    if (ri < nb) V[(b0 + ri) * 16 + c] -= acc;
-    __syncthreads();
-    if (ri == 0) {
-      for (int ii = nb - 1; ii >= 0; --ii) {
-        double t = V[(b0 + ii) * 16 + c];
-        for (int jj = ii + 1; jj < nb; ++jj) t = fma(-Rd[ii * 16 + jj], V[(b0 + jj) * 16 + c], t);
-        V[(b0 + ii) * 16 + c] = t / Rd[ii * 16 + ii];
-      }
-    }
-    __syncthreads();
-  }
-  if (cv)
-    for (int i = ri; i < N; i += 16) Xs[(size_t)kc * N + i] = V[i * 16 + c];
 }
 
 // U = Lm * Z for hyper-samples with Lchol == false (Lm = -inv(K + sn2 I), full symmetric N x N)
