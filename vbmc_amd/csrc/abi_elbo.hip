@@ -176,6 +176,13 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
     e = hipMalloc((void**)&gp->d_lchol, (size_t)S);
     if (e == hipSuccess) e = hipMemcpy(gp->d_lchol, gp->Lchol.data(), (size_t)S, hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && gp->hasL) {
+    e = hipMalloc((void**)&gp->d_finv, (size_t)S * TRSM_NBLK(N) * 256 * sizeof(double));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, ctx->stream, N, gp->L, gp->d_lchol, gp->d_finv);
+      e = hipStreamSynchronize(ctx->stream);
+    }
+  }
   if (e != hipSuccess) {
     vbmc_gp_free(ctx, gp);
     return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_upload: %s", hipGetErrorString(e));
@@ -195,6 +202,7 @@ extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
   if (gp->d_sn2) (void)hipFree(gp->d_sn2);
   if (gp->d_lchol) (void)hipFree(gp->d_lchol);
   if (gp->d_mult) (void)hipFree(gp->d_mult);
+  if (gp->d_finv) (void)hipFree(gp->d_finv);
   if (gp->d_meanX) (void)hipFree(gp->d_meanX);
   delete gp;
 }
@@ -527,11 +535,11 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     }
     const dim3 tg((K + TR_CB - 1) / TR_CB, S, R);
     if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_finv, gp->d_lchol, P.d_Z);
     hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                        P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);
     if (P.vgrad) {
-      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
+      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_finv, gp->d_lchol, P.d_Z, P.d_X);
       DISPATCH_DT(dt, {
         hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2,
                            gp->d_sn2, gp->d_lchol, P.d_X, P.d_vg);

@@ -276,6 +276,7 @@ struct PredArgs {
   const unsigned char* lchol;
   const double* mean_a;  // D  column means of X
   const double* mean_b;  // D  column means of Xstar
+  const double* finv;    // S x nblk x 256 inverse diagonal blocks (k_diag_inv)
   double* fmu;           // Nstar x S
   double* fs2;
   double* ys2;
@@ -319,9 +320,8 @@ __global__ void __launch_bounds__(64) k_gp_pred(PredArgs a, const double* __rest
   const int N = a.N, D = a.D;
   const int Np = ((N + 15) >> 4) << 4;
   double* V = lds;                        // Np x TR_VS
-  double* Rd = V + (size_t)Np * TR_VS;    // 256
-  double* IDG = Rd + 256;                 // 16
-  double* xs = IDG + 16;                  // 16 x 32 scaled centred test points
+  double* Pn = V + (size_t)Np * TR_VS;    // 64 x TR_VS panel staging of the triangular solve
+  double* xs = Pn + 64 * TR_VS;           // 16 x 32 scaled centred test points
   const double* h = a.hyp + (size_t)s * a.Nhyp;
   const double* mu = muv + (size_t)s * 2 * D;
   const double* iell = mu + D;
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) k_gp_pred(PredArgs a, const double* __rest
   const double* Rm = a.L + (size_t)s * N * N;
   double fs2;
   if (lc) {
-    trsm_fwd_wave(N, Rm, V, Rd, IDG, lane);
+    trsm_fwd_wave(N, Rm, a.finv + (size_t)s * TRSM_NBLK(N) * 256, V, Pn, lane);
     double part = 0.0;
     for (int i = lg; i < N; i += 4) part = fma(V[i * TR_VS + li], V[i * TR_VS + li], part);
     part += __shfl_xor(part, 16, 64);

@@ -6,9 +6,8 @@
 //     rhs_b -= R[0:b0, b]' * V[0:b0, :]      (forward, R' V = Z)
 //     rhs_b -= R[b, e0:N] * X[e0:N, :]       (backward, R X = V)
 // is a (16 x b0) x (b0 x 16) product accumulated by one MFMA per 4 rows of the inner dimension; the
-// 16 x 16 diagonal block is then solved by substitution with the block's right-hand sides held in
-// the MFMA accumulator layout (lane (li = column, lg): rows lg + 4 r), the freshly solved row being
-// broadcast inside the 4 lanes of a column each step.  Used by gplite_pred's V = L' \ (sW .* Ks)
+// 16 x 16 diagonal block is applied as four more MFMAs with its precomputed inverse (k_diag_inv: 16-step
+// substitution once per block, not once per block per column tile).  Used by gplite_pred's V = L' \ (sW .* Ks)
 // (gplite/gplite_pred.m:99), the BQ variance (misc/gplogjoint.m:277,318), alpha = L \ (L' \ (y-m))
 // (gplite/private/gplite_core.m:102) and the rank-1 update (gplite/gplite_post.m:227-229).
 #pragma once
@@ -17,9 +16,17 @@
 typedef double tmf4 __attribute__((ext_vector_type(4)));
 #define TR_VS 17  // LDS row stride of the right-hand-side slab (16 columns + 1 pad: conflict-free column fills)
 
-// Rd: 16 x 16 diagonal block (Rd[ii * 16 + jj] = R[b0+ii][b0+jj], identity beyond N), IDG: 1 / diag.
-__device__ __forceinline__ void trsm_load_diag(int N, const double* __restrict__ Rm, int b0, int lane,
-                                               double* __restrict__ Rd, double* __restrict__ IDG) {
+// k_diag_inv: Finv[s][b] = (R_bb')^{-1} for every 16 x 16 diagonal block of the upper factor (identity rows beyond
+// N), row-major 16 x 16.  The blocked solves apply it with four MFMAs instead of a 16-step substitution chain;
+// R_bb^{-1} (backward solve) is its transpose.  One wave per block: lane c < 16 solves R_bb' x = e_c.
+__global__ void __launch_bounds__(64) k_diag_inv(int N, const double* __restrict__ Lall, const unsigned char* __restrict__ lchol,
+                                                 double* __restrict__ Finv) {
+  __shared__ double Rd[256];
+  const int bi = blockIdx.x, s = blockIdx.y, lane = threadIdx.x, b0 = bi << 4;
+  const int nblk = gridDim.x;
+  double* out = Finv + ((size_t)s * nblk + bi) * 256;
+  if (!lchol[s]) return;
+  const double* Rm = Lall + (size_t)s * N * N;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int e = lane + 64 * t, ii = e >> 4, jj = e & 15;
@@ -28,81 +35,116 @@ __device__ __forceinline__ void trsm_load_diag(int N, const double* __restrict__
     Rd[e] = v;
   }
   __syncthreads();
-  if (lane < 16) IDG[lane] = 1.0 / Rd[lane * 17];
-  __syncthreads();
+  if (lane < 16) {
+    double x[16];
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {   // (R')x = e_c : x_ii = (e_c[ii] - sum_{jj<ii} R[jj][ii] x_jj) / R[ii][ii]
+      double t = (ii == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < ii; ++jj) t = fma(-Rd[jj * 16 + ii], x[jj], t);
+      x[ii] = t / Rd[ii * 17];
+    }
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) out[ii * 16 + lane] = x[ii];   // Finv[ii][c]
+  }
 }
 
 // forward substitution R' V = Z for the slab in LDS (in place)
-__device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ Rm, double* __restrict__ V,
-                                              double* __restrict__ Rd, double* __restrict__ IDG, int lane) {
+__device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ Rm, const double* __restrict__ Finv,
+                                              double* __restrict__ V, double* __restrict__ P, int lane) {
   const int li = lane & 15, lg = lane >> 4;
   const int nblk = (N + 15) >> 4;
   for (int bi = 0; bi < nblk; ++bi) {
     const int b0 = bi << 4;
-    tmf4 acc = {0.0, 0.0, 0.0, 0.0};
-    const bool cv = b0 + li < N;
-    const double* col = Rm + (size_t)(cv ? b0 + li : 0) * N;  // column b0+li of R (rows j contiguous)
-    for (int j0 = 0; j0 < b0; j0 += 4) {
-      const double a = cv ? col[j0 + lg] : 0.0;               // A[i = li][k = lg] = R[j0+lg][b0+li]
-      const double b = V[(j0 + lg) * TR_VS + li];                // B[k = lg][c = li]
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    trsm_load_diag(N, Rm, b0, lane, Rd, IDG);
-    double rhs[4];
+    // trailing update: the b0 x 16 panel R[0:b0, b0:b0+16] is streamed through LDS in 64-row chunks with
+    // fully coalesced loads (lane = row, one load per column, all 16 in flight), then consumed by MFMAs
+    tmf4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    double fv[4];   // A[i = li][k = 4u + lg] = Finv_b[li][4u + lg]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rhs[r] = V[(b0 + lg + 4 * r) * TR_VS + li] - acc[r];
-    // v_ii = (rhs_ii - sum_{jj<ii} R[jj][ii] v_jj) / R[ii][ii], right-looking inside the block
+    for (int u = 0; u < 4; ++u) fv[u] = Finv[(size_t)bi * 256 + li * 16 + 4 * u + lg];
+    double pv[16];
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-      const double mine = rhs[ii >> 2] * IDG[ii];
-      const double vi = __shfl(mine, li | ((ii & 3) << 4), 64);
+    for (int c = 0; c < 16; ++c) pv[c] = (lane < b0 && b0 + c < N) ? Rm[(size_t)(b0 + c) * N + lane] : 0.0;
+    for (int j0 = 0; j0 < b0; j0 += 64) {
+      const int nrow = min(64, b0 - j0);
+      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = lg + 4 * r;
-        if (row > ii) rhs[r] = fma(-Rd[ii * 16 + row], vi, rhs[r]);
-        else if (row == ii) rhs[r] = vi;
+      for (int c = 0; c < 16; ++c) P[lane * TR_VS + c] = pv[c];
+      __syncthreads();
+      // prefetch the next chunk of the panel while this one feeds the matrix core
+      const int jn = j0 + 64;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) pv[c] = (jn + lane < b0 && b0 + c < N) ? Rm[(size_t)(b0 + c) * N + jn + lane] : 0.0;
+      // nrow is a multiple of 16: four MFMAs per step, their eight LDS operands fetched before the first issues
+      for (int jj = 0; jj < nrow; jj += 16) {
+        double pa[4], pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          pa[u] = P[(jj + 4 * u + lg) * TR_VS + li];
+          pb[u] = V[(j0 + jj + 4 * u + lg) * TR_VS + li];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[1], pb[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[2], pb[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[3], pb[3], acc2, 0, 0, 0);
       }
     }
+    acc += acc2;
+    // v_b = (R_bb')^{-1} (z_b - update): rhs through LDS into the B-operand layout, four MFMAs with Finv
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = rhs[r];
+    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] -= acc[r];
+    __syncthreads();
+    tmf4 vb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], V[(b0 + 4 * u + lg) * TR_VS + li], vb, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = vb[r];
     __syncthreads();
   }
 }
 
 // backward substitution R X = V for the slab in LDS (in place)
-__device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ Rm, double* __restrict__ V,
-                                              double* __restrict__ Rd, double* __restrict__ IDG, int lane) {
+__device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ Rm, const double* __restrict__ Finv,
+                                              double* __restrict__ V, int lane) {
   const int li = lane & 15, lg = lane >> 4;
   const int nblk = (N + 15) >> 4;
   const int Np = nblk << 4;
   for (int bi = nblk - 1; bi >= 0; --bi) {
     const int b0 = bi << 4;
-    tmf4 acc = {0.0, 0.0, 0.0, 0.0};
+    // trailing update: A[i = li][k = lg] = R[b0+li][j] -- 16 consecutive doubles per inner index (coalesced);
+    // eight independent loads are issued per batch to cover the L2 latency
+    tmf4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
     const bool rv = b0 + li < N;
-    for (int j0 = b0 + 16; j0 < Np; j0 += 4) {
-      const int j = j0 + lg;
-      const double a = (rv && j < N) ? Rm[(size_t)j * N + b0 + li] : 0.0;  // A[i = li][k = lg] = R[b0+li][j]
-      const double b = V[j * TR_VS + li];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    trsm_load_diag(N, Rm, b0, lane, Rd, IDG);
-    double rhs[4];
+    double fv[4];   // A[i = li][k = 4u + lg] = (R_bb^{-1})[li][4u + lg] = Finv_b[4u + lg][li]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rhs[r] = V[(b0 + lg + 4 * r) * TR_VS + li] - acc[r];
-    // x_ii = (rhs_ii - sum_{jj>ii} R[ii][jj] x_jj) / R[ii][ii], from the bottom row up
+    for (int u = 0; u < 4; ++u) fv[u] = Finv[(size_t)bi * 256 + (4 * u + lg) * 16 + li];
+    for (int j0 = b0 + 16; j0 < Np; j0 += 32) {
+      double av[8];
 #pragma unroll
-    for (int ii = 15; ii >= 0; --ii) {
-      const double mine = rhs[ii >> 2] * IDG[ii];
-      const double xi = __shfl(mine, li | ((ii & 3) << 4), 64);
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + 4 * u + lg;
+        av[u] = (rv && j < N) ? Rm[(size_t)j * N + b0 + li] : 0.0;
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = lg + 4 * r;
-        if (row < ii) rhs[r] = fma(-Rd[row * 16 + ii], xi, rhs[r]);
-        else if (row == ii) rhs[r] = xi;
+      for (int u = 0; u < 8; u += 2) {
+        if (j0 + 4 * u < Np) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], V[(j0 + 4 * u + lg) * TR_VS + li], acc, 0, 0, 0);
+        if (j0 + 4 * (u + 1) < Np) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], V[(j0 + 4 * (u + 1) + lg) * TR_VS + li], acc2, 0, 0, 0);
       }
     }
+    acc += acc2;
+    // x_b = R_bb^{-1} (v_b - update) = Finv_b' * rhs
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = rhs[r];
+    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] -= acc[r];
+    __syncthreads();
+    tmf4 xb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], V[(b0 + 4 * u + lg) * TR_VS + li], xb, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = xb[r];
     __syncthreads();
   }
 }
@@ -125,34 +167,33 @@ __device__ __forceinline__ void trsm_slab_store(int N, int K, int k0, double* __
     for (int i = lane; i < N; i += 64) Zs[(size_t)(k0 + c) * N + i] = V[i * TR_VS + c];
   }
 }
-#define TRSM_LDS_BYTES(N) ((size_t)(((((N) + 15) >> 4) << 4) * TR_VS + 256 + 16) * sizeof(double))
+#define TRSM_LDS_BYTES(N) ((size_t)(((((N) + 15) >> 4) << 4) * TR_VS + 64 * TR_VS) * sizeof(double))
+#define TRSM_NBLK(N) (((N) + 15) >> 4)
 
 __global__ void __launch_bounds__(64) k_trsm_fwd(int N, int K, int S, const double* __restrict__ Lall,
-                                                 const unsigned char* __restrict__ lchol, double* __restrict__ Z) {
+                                                 const double* __restrict__ Finv, const unsigned char* __restrict__ lchol,
+                                                 double* __restrict__ Z) {
   extern __shared__ double lds[];
   const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
   if (!lchol[s]) return;
   const int Np = ((N + 15) >> 4) << 4;
   double* V = lds;
-  double* Rd = V + (size_t)Np * TR_VS;
-  double* IDG = Rd + 256;
+  double* P = V + (size_t)Np * TR_VS;
   double* Zs = Z + ((size_t)r * S + s) * (size_t)K * N;
   trsm_slab_load(N, K, cb * 16, Zs, V, lane);
-  trsm_fwd_wave(N, Lall + (size_t)s * N * N, V, Rd, IDG, lane);
+  trsm_fwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane);
   trsm_slab_store(N, K, cb * 16, Zs, V, lane);
 }
 
 __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const double* __restrict__ Lall,
-                                                 const unsigned char* __restrict__ lchol,
+                                                 const double* __restrict__ Finv, const unsigned char* __restrict__ lchol,
                                                  const double* __restrict__ Vin, double* __restrict__ Xo) {
   extern __shared__ double lds[];
   const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
   if (!lchol[s]) return;
   const int Np = ((N + 15) >> 4) << 4;
   double* V = lds;
-  double* Rd = V + (size_t)Np * TR_VS;
-  double* IDG = Rd + 256;
   trsm_slab_load(N, K, cb * 16, Vin + ((size_t)r * S + s) * (size_t)K * N, V, lane);
-  trsm_bwd_wave(N, Lall + (size_t)s * N * N, V, Rd, IDG, lane);
+  trsm_bwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, lane);
   trsm_slab_store(N, K, cb * 16, Xo + ((size_t)r * S + s) * (size_t)K * N, V, lane);
 }
