@@ -1,0 +1,87 @@
+"""CPU: the host-side mirror (vbmc_amd/vp.py, optimize.py) against the oracle's restatement of the same
+reference functions -- theta packing, rescaling, soft bounds, MATLAB sort semantics, Adam, vbinit shapes."""
+import numpy as np
+
+import vbmc_amd.optimize as opt
+import vbmc_amd.vp as vpm
+from oracle import vbmc_ref as R
+from tests._cases import synth_problem
+
+
+def mk(seed=0, D=4, N=30, K=5, S=2, flags=(1, 1, 1, 1)):
+    p = synth_problem(seed, D, N, K, S)
+    vp = vpm.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"], optimize=flags)
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    gp = {"X": p["X"], "y": p["y"]}
+    return p, vp, gp
+
+
+def test_theta_packing_and_rescale_match_oracle():
+    for flags in [(1, 1, 1, 1), (1, 1, 1, 0), (0, 1, 1, 1), (1, 0, 0, 1)]:
+        p, vp, gp = mk(flags=flags)
+        th_a, vp_a = vpm.get_vptheta(vp)
+        th_b, vp_b = R.get_vptheta(vp)
+        assert np.array_equal(th_a, th_b)
+        for k in ("mu", "sigma", "lambda", "w"):
+            assert np.array_equal(vp_a[k], vp_b[k])
+        th2 = th_a + 0.1
+        a, b = vpm.rescale_params(vp, th2), R.rescale_params(vp, th2)
+        for k in ("mu", "sigma", "lambda", "w"):
+            assert np.array_equal(a[k], b[k])
+        assert ("eta" in a) == (not flags[3])   # eta removed only when weights are optimised (:36-39)
+
+
+def test_vpbounds_match_oracle_and_accumulate():
+    p, vp, gp = mk()
+    o = dict(TolLength=1e-6, TolWeight=1e-2, TolConLoss=0.01, WeightPenalty=0.1)
+    va, ta = vpm.vpbounds(vp, gp, o)
+    vb, tb = R.vpbounds(vp, gp, o)
+    for k in ("lb", "ub"):
+        assert np.array_equal(ta[k], tb[k])
+    assert ta["WeightThreshold"] == tb["WeightThreshold"] and ta["TolCon"] == tb["TolCon"]
+    gp2 = {"X": p["X"] * 0.5, "y": p["y"]}
+    va2, ta2 = vpm.vpbounds(va, gp2, o)  # bounds only widen (vpbounds.m:18-24)
+    assert np.all(ta2["lb"] <= ta["lb"] + 1e-15) and np.all(ta2["ub"] >= ta["ub"] - 1e-15)
+
+
+def test_matlab_sort_semantics():
+    v = np.array([3.0, 1.0, np.nan, 1.0, -2.0, np.inf])
+    assert list(opt.sort_ascend(v)) == list(R.matlab_sort_ascend(v)) == [4, 1, 3, 0, 5, 2]
+    assert list(opt.sort_descend(v)) == list(R.matlab_sort_descend(v))
+    X = np.arange(20.0).reshape(10, 2)
+    y = np.array([1, 5, 3, 5, 2, 9, 0, 7, 7, 4.0])
+    a, b = opt.gethpd_vbmc(X, y, 0.8), R.gethpd_vbmc(X, y, 0.8)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_fminadam_matches_oracle_on_a_noisy_quadratic():
+    A = np.diag([1.0, 4.0, 9.0, 0.5])
+    noise = np.random.default_rng(0).standard_normal((3000, 4)) * 0.01
+    cnt = {"a": 0, "b": 0}
+
+    def fa(x):
+        cnt["a"] += 1
+        return 0.5 * x @ A @ x, A @ x + noise[cnt["a"]]
+
+    def fb(x):
+        cnt["b"] += 1
+        return 0.5 * x @ A @ x, A @ x + noise[cnt["b"]]
+
+    x0 = np.array([1.0, -1.0, 0.5, 2.0])
+    xa, f_a, xta, fta, ita = opt.fminadam(fa, x0, None, None, 1e-3, 2000)
+    xb, f_b, xtb, ftb, itb = R.fminadam(fb, x0, TolFun=1e-3, MaxIter=2000)
+    assert ita == itb and np.array_equal(xta, xtb) and np.array_equal(fta, ftb) and f_a == f_b
+
+
+def test_vbinit_types_and_shapes():
+    p, vp, gp = mk(K=4)
+    Xs, ys = opt.gethpd_vbmc(p["X"], p["y"], 0.8)
+    rng = np.random.default_rng(1)
+    for t in (1, 2, 3):
+        vs, ty = opt.vbinit_vbmc(t, 5, vp, 6, Xs, ys, rng)   # Knew > K: new components spawned for type 1
+        assert len(vs) == 5 and np.all(ty == t)
+        for v in vs:
+            assert v["mu"].shape == (4, 6) and v["sigma"].shape == (6,) and v["lambda"].shape == (4,)
+            assert abs(np.sum(v["w"]) - 1) < 1e-12 and np.all(v["sigma"] > 0)
+    vs, _ = opt.vbinit_vbmc(1, 3, vp, 4, Xs, ys, rng)
+    assert np.array_equal(vs[0]["mu"], vp["mu"])            # first type-1 candidate is the old vp verbatim (:59-61)
