@@ -220,6 +220,23 @@ def test_device_exp_accuracy(va, variant):
     assert np.isinf(ctx.test_exp(np.array([710.0, 1e4]), variant)).all()
 
 
+def test_device_exp_sum_mode_accuracy(va):
+    """vb_exp_tab<1> (the entropy kernel's exp; one-constant range reduction): relative error bounded by
+    (1.5 + |x|/2) ulp, i.e. an absolute error below 1e-16 wherever exp(x) <= 1, and the same saturation."""
+    ctx = va.default_engine().ctx
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-40, 5, 20000), rng.uniform(-1e-3, 1e-3, 2000),
+                        np.array([0.0, -0.0, 1.0, -1.0, 709.0, -745.0, -800.0, -1e5, -1e6, -5e9, -1e300])])
+    y = ctx.test_exp(x, 2)
+    ref = np.exp(np.maximum(x, -1e4))
+    ok = ref > 1e-300
+    rel = np.abs(y[ok] - ref[ok]) / ref[ok]
+    assert np.all(rel <= (1.5 + np.abs(x[ok]) / 2) * 2.220446049250313e-16), rel.max()
+    neg = ok & (x <= 0)
+    assert np.abs(y[neg] - ref[neg]).max() < 1.5e-16
+    assert np.all(y[x <= -800] == 0.0) and np.isinf(ctx.test_exp(np.array([710.0, 1e4]), 2)).all()
+
+
 def test_block_sparse_mode_is_exact_to_rounding(va):
     """sparse_cutoff = 100 skips component tiles whose terms are < e^-100 of q: results unchanged to ~1e-14,
     on well-separated mixtures (most tiles skipped) and on overlapping ones (nothing skipped)."""

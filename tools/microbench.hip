@@ -27,6 +27,9 @@ __global__ void k_fma(double* out, int iters, double a, double b) {
 
 template <int ILP, int MODE>
 __global__ void k_exp(double* out, int iters, double a) {
+  __shared__ double tab[VB_EXP_TAB_N];
+  for (int t = threadIdx.x; t < VB_EXP_TAB_N; t += blockDim.x) tab[t] = c_exp2_tab[t];
+  __syncthreads();
   double x[ILP];
 #pragma unroll
   for (int i = 0; i < ILP; ++i) x[i] = -(threadIdx.x * 1e-2 + i);
@@ -34,7 +37,7 @@ __global__ void k_exp(double* out, int iters, double a) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
-      double e = MODE == 0 ? vb_exp(x[i]) : exp(x[i]);
+      double e = MODE == 0 ? vb_exp(x[i]) : MODE == 1 ? exp(x[i]) : MODE == 2 ? vb_exp_tab<0>(x[i], tab) : vb_exp_tab<1>(x[i], tab);
       s += e;
       x[i] -= a;
     }
@@ -104,6 +107,12 @@ int main() {
   {
     double ms = time_ms([&] { hipLaunchKernelGGL((k_exp<4, 1>), dim3(blocks), dim3(threads), 0, 0, out, iters / 4, 1e-3); }, 5);
     printf(", \"ocml_exp_gexp_s\": %.1f", lanes * (iters / 4) * 4 / (ms * 1e-3) / 1e9);
+  }
+  {
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_exp<4, 2>), dim3(blocks), dim3(threads), 0, 0, out, iters / 4, 1e-3); }, 5);
+    printf(", \"vb_exp_tab0_gexp_s\": %.1f", lanes * (iters / 4) * 4 / (ms * 1e-3) / 1e9);
+    ms = time_ms([&] { hipLaunchKernelGGL((k_exp<4, 3>), dim3(blocks), dim3(threads), 0, 0, out, iters / 4, 1e-3); }, 5);
+    printf(", \"vb_exp_tab1_gexp_s\": %.1f", lanes * (iters / 4) * 4 / (ms * 1e-3) / 1e9);
   }
   {
     double waves = lanes / 64;

@@ -764,13 +764,13 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   return VBMC_OK;
 }
 
-// test hook: y[i] = exp(x[i]) with the hot-loop implementations (variant 0: vb_exp, 1: vb_exp_tab)
+// test hook: y[i] = exp(x[i]) with the hot-loop implementations (variant 0: vb_exp, 1: vb_exp_tab<0>, 2: vb_exp_tab<1>)
 __global__ void k_test_exp(int n, int variant, const double* __restrict__ x, double* __restrict__ y) {
-  __shared__ double tab[64];
-  if (threadIdx.x < 64) tab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  __shared__ double tab[VB_EXP_TAB_N];
+  for (int t = threadIdx.x; t < VB_EXP_TAB_N; t += blockDim.x) tab[t] = c_exp2_tab[t];
   __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = variant ? vb_exp_tab(x[i], tab) : vb_exp(x[i]);
+  if (i < n) y[i] = variant == 2 ? vb_exp_tab<1>(x[i], tab) : (variant ? vb_exp_tab<0>(x[i], tab) : vb_exp(x[i]));
 }
 
 extern "C" vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const double* x, double* y) {

@@ -38,52 +38,111 @@ __device__ __forceinline__ double vb_exp(double x) {
   return ldexp(p, (int)nf);
 }
 
-static __constant__ double c_exp2_tab[64] = {  // 2^(j/64), correctly rounded (generated with mpmath)
-    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
-    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
-    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
-    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
-    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
-    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
-    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
-    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
-    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
-    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
-    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
-    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
-    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
-    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
-    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
-    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+static __constant__ double c_exp2_tab[256] = {  // 2^(j/256), correctly rounded (generated with mpmath)
+    1.0, 1.0027112750502025, 1.0054299011128027, 1.0081558981184175,
+    1.0108892860517005, 1.0136300849514894, 1.016378314910953, 1.019133996077738,
+    1.0218971486541166, 1.0246677928971357, 1.0274459491187637, 1.030231637686041,
+    1.0330248790212284, 1.0358256936019572, 1.0386341019613787, 1.041450124688316,
+    1.0442737824274138, 1.0471050958792898, 1.0499440858006872, 1.0527907730046264,
+    1.0556451783605572, 1.0585073227945128, 1.061377227289262, 1.0642549128844645,
+    1.0671404006768237, 1.0700337118202419, 1.0729348675259756, 1.075843889062791,
+    1.0787607977571199, 1.0816856149932152, 1.0846183622133092, 1.0875590609177697,
+    1.0905077326652577, 1.0934643990728858, 1.0964290818163769, 1.099401802630222,
+    1.102382583307841, 1.1053714457017412, 1.1083684117236787, 1.1113735033448175,
+    1.1143867425958924, 1.1174081515673693, 1.1204377524096067, 1.12347556733302,
+    1.1265216186082418, 1.129575928566288, 1.1326385195987192, 1.1357094141578055,
+    1.1387886347566916, 1.1418762039695616, 1.1449721444318042, 1.148076478840179,
+    1.1511892299529827, 1.154310420590216, 1.1574400736337511, 1.1605782120274988,
+    1.1637248587775775, 1.1668800369524817, 1.1700437696832502, 1.1732160801636373,
+    1.1763969916502812, 1.1795865274628758, 1.182784710984341, 1.1859915656609938,
+    1.189207115002721, 1.1924313825831512, 1.1956643920398273, 1.1989061670743806,
+    1.202156731452703, 1.2054161090051239, 1.2086843236265816, 1.2119613992768012,
+    1.215247359980469, 1.2185422298274085, 1.2218460329727576, 1.2251587936371455,
+    1.22848053610687, 1.2318112847340759, 1.2351510639369334, 1.2384998981998165,
+    1.241857812073484, 1.245224830175258, 1.2486009771892048, 1.2519862778663162,
+    1.255380757024691, 1.2587844395497165, 1.2621973503942507, 1.2656195145788063,
+    1.2690509571917332, 1.2724917033894028, 1.275941778396392, 1.2794012075056693,
+    1.2828700160787783, 1.2863482295460256, 1.2898358734066657, 1.2933329732290895,
+    1.2968395546510096, 1.3003556433796506, 1.3038812651919358, 1.3074164459346773,
+    1.3109612115247644, 1.3145155879493546, 1.318079601266064, 1.3216532776031575,
+    1.3252366431597413, 1.3288297242059544, 1.3324325470831615, 1.3360451382041458,
+    1.339667524053303, 1.3432997311868353, 1.3469417862329458, 1.3505937158920345,
+    1.3542555469368927, 1.3579273062129011, 1.3616090206382248, 1.365300717204012,
+    1.3690024229745905, 1.3727141650876684, 1.3764359707545302, 1.380167867260238,
+    1.383909881963832, 1.387662042298529, 1.3914243757719262, 1.3951969099662003,
+    1.3989796725383112, 1.4027726912202048, 1.4065759938190154, 1.4103896082172707,
+    1.4142135623730951, 1.4180478843204152, 1.4218926021691656, 1.4257477441054942,
+    1.42961333839197, 1.433489413367789, 1.4373759974489824, 1.4412731191286257,
+    1.4451808069770467, 1.449099089642035, 1.4530279958490526, 1.4569675544014438,
+    1.460917794180647, 1.4648787441464057, 1.4688504333369818, 1.4728328908693675,
+    1.4768261459394993, 1.4808302278224719, 1.4848451658727524, 1.488870989524397,
+    1.4929077282912648, 1.4969554117672355, 1.5010140696264256, 1.5050837316234065,
+    1.5091644275934228, 1.5132561874526098, 1.5173590411982147, 1.5214730189088146,
+    1.5255981507445384, 1.529734466947287, 1.533881997840956, 1.5380407738316568,
+    1.5422108254079407, 1.5463921831410214, 1.550584877685, 1.5547889397770887,
+    1.559004400237837, 1.5632312899713576, 1.567469639965553, 1.5717194812923414,
+    1.5759808451078865, 1.5802537626528246, 1.5845382652524937, 1.588834384317164,
+    1.593142151342267, 1.597461597908627, 1.6017927556826934, 1.606135656416771,
+    1.6104903319492543, 1.6148568142048607, 1.6192351351948637, 1.6236253270173289,
+    1.6280274218573478, 1.632441451987275, 1.6368674497669644, 1.6413054476440063,
+    1.645755478153965, 1.6502175739206177, 1.6546917676561943, 1.6591780921616162,
+    1.6636765803267364, 1.6681872651305825, 1.6727101796415966, 1.6772453570178785,
+    1.681792830507429, 1.6863526334483934, 1.6909247992693053, 1.6955093614893326,
+    1.7001063537185235, 1.7047158096580513, 1.709337763100463, 1.713972247929926,
+    1.718619298122478, 1.723278947746274, 1.7279512309618377, 1.732636182022311,
+    1.7373338352737062, 1.7420442251551564, 1.746767386199169, 1.7515033530318782,
+    1.7562521603732995, 1.761013843037584, 1.7657884359332727, 1.7705759740635547,
+    1.7753764925265212, 1.7801900265154245, 1.785016611318935, 1.789856282321401,
+    1.7947090750031072, 1.7995750249405351, 1.804454167806624, 1.809346539371032,
+    1.8142521755003989, 1.8191711121586085, 1.8241033854070534, 1.8290490314048973,
+    1.8340080864093424, 1.8389805867758937, 1.843966568958626, 1.8489660695104508,
+    1.8539791250833855, 1.8590057724288205, 1.864046048397789, 1.8690999899412386,
+    1.8741676341103, 1.8792490180565602, 1.8843441790323345, 1.8894531543909392,
+    1.8945759815869656, 1.8997126981765553, 1.9048633418176741, 1.9100279502703899,
+    1.9152065613971474, 1.9203992131630474, 1.925605943636125, 1.930826790987627,
+    1.9360617934922943, 1.9413109895286405, 1.9465744175792332, 1.9518521162309783,
+    1.9571441241754002, 1.9624504802089273, 1.9677712232331759, 1.9731063922552343,
+    1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402,
+};
 
-// Table-driven exp for the MFMA entropy kernel: x = (64 m + j) ln2/64 + r, |r| <= ln2/128,
-// exp(x) = 2^m * T[j] * (1 + expm1(r)), T[j] = 2^(j/64) from a 64-entry LDS table, expm1 by a
-// degree-5 Taylor polynomial (remainder r^6/720 < 4e-17).  12 fp64 + 4 int ops + one ds_read_b64
-// per value instead of 22 fp64 ops; |rel err| <= ~1 ulp.  Underflows to 0 / overflows to +inf through
-// v_ldexp_f64; the argument must stay within +-2e7 (see below).
+// Table-driven exp: x = (256 m + j) ln2/256 + r, |r| <= ln2/512, exp(x) = 2^m * T[j] * (1 + expm1(r)),
+// T[j] = 2^(j/256) from a 256-entry (2 KB) LDS table, expm1 by a degree-4 Taylor polynomial (remainder
+// r^5/120 < 4e-17).  MODE 0 ("exact"): two-constant Cody-Waite reduction, |rel err| <= ~1 ulp over the whole
+// range -- 10 fp64 + 3 int ops + one ds_read_b64 per value.  MODE 1 ("sum"): one-constant reduction, for
+// terms of a sum that contains an O(1) term (the mixture density shifted by the sample's own component):
+// the reduction error is |n| * 9e-20 absolute in r, i.e. a relative error of exp(x) of ~1e-16 * (1 + |x|/3),
+// which weighted by exp(x) itself is < 1e-16 of the O(1) term for every x <= 0 -- one fp64 op fewer.
+// Underflows to 0 / overflows to +inf through v_ldexp_f64; the argument must stay within +-5e6 (see below).
+#define VB_EXP_TAB_N 256
+template <int MODE = 0>
 __device__ __forceinline__ double vb_exp_tab(double x, const double* __restrict__ tab) {
-  const double INV = 92.332482616893656759;            // 64/ln2
-  const double C_HI = 6.93147180369123816490e-01 / 64;  // ln2/64 split (exact scaling of fdlibm's pair)
-  const double C_LO = 1.90821492927058770002e-10 / 64;
+  const double INV = 369.3299304675746322841407;        // 256/ln2
+  const double C_HI = 6.93147180369123816490e-01 / 256;  // ln2/256 split (exact scaling of fdlibm's pair)
+  const double C_LO = 1.90821492927058770002e-10 / 256;
+  const double C_1 = 0.693147180559945309417232 / 256;
   const double MAGIC = 6755399441055744.0;              // 1.5 * 2^52: round-to-nearest-integer by addition
-  // n = rint(x * 64/ln2) through the magic-number trick: the integer lands in the low mantissa word,
-  // so no v_rndne / v_cvt is needed.  Valid for |x| < 2^31 ln2/64 = 2.3e7; beyond that the low word
-  // wraps -- hence the clamp below (arguments above +2e7 cannot occur: they would need exp() = inf anyway).
+  // n = rint(x * 256/ln2) through the magic-number trick: the integer lands in the low mantissa word,
+  // so no v_rndne / v_cvt is needed.  Valid for |x| < 2^31 ln2/256 = 5.8e6; beyond that the low word
+  // wraps -- hence the clamp below (arguments above +5e6 cannot occur: they would need exp() = inf anyway).
   // one-instruction lower clamp (plain v_max_f64; fmax() would add a canonicalising v_max first): keeps the
   // magic-number trick valid for arbitrarily negative arguments (tiny sigma_k early in a VBMC run)
   asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(x), "v"(-1.0e6));
   double t = fma(x, INV, MAGIC);
   int ni = __double2loint(t);
   double nf = t - MAGIC;
-  double r = fma(nf, -C_HI, x);
-  r = fma(nf, -C_LO, r);
-  double T = tab[ni & 63];
-  double p = fma(r, 8.3333333333333332177e-03, 4.1666666666666664354e-02);
-  p = fma(p, r, 1.6666666666666665741e-01);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = p * r;                       // expm1(r)
-  return ldexp(fma(T, p, T), ni >> 6);
+  double r;
+  if (MODE == 0) {
+    r = fma(nf, -C_HI, x);
+    r = fma(nf, -C_LO, r);
+  } else {
+    r = fma(nf, -C_1, x);
+  }
+  double T = tab[ni & (VB_EXP_TAB_N - 1)];
+  double v = r * r;
+  double u = fma(r, 1.6666666666666665741e-01, 0.5);
+  u = fma(v, 4.1666666666666664354e-02, u);
+  double p = fma(v, u, r);         // expm1(r) = r + r^2 (1/2 + r/6 + r^2/24)
+  return ldexp(fma(T, p, T), ni >> 8);
 }
 
 // Four independent exps in straight-line code (the scheduler interleaves the four Horner chains).
@@ -93,9 +152,11 @@ __device__ __forceinline__ vb_d4 vb_exp4(vb_d4 x) {
   y[0] = vb_exp(x[0]); y[1] = vb_exp(x[1]); y[2] = vb_exp(x[2]); y[3] = vb_exp(x[3]);
   return y;
 }
+template <int MODE = 0>
 __device__ __forceinline__ vb_d4 vb_exp_tab4(vb_d4 x, const double* __restrict__ tab) {
   vb_d4 y;
-  y[0] = vb_exp_tab(x[0], tab); y[1] = vb_exp_tab(x[1], tab); y[2] = vb_exp_tab(x[2], tab); y[3] = vb_exp_tab(x[3], tab);
+  y[0] = vb_exp_tab<MODE>(x[0], tab); y[1] = vb_exp_tab<MODE>(x[1], tab);
+  y[2] = vb_exp_tab<MODE>(x[2], tab); y[3] = vb_exp_tab<MODE>(x[3], tab);
   return y;
 }
 

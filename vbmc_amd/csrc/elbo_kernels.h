@@ -105,14 +105,14 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
                                                    const double* __restrict__ gpc,    // S x GPC_STRIDE
                                                    const double* __restrict__ delta2,  // D (delta.^2)
                                                    double* __restrict__ lj, int want_grad) {
-  __shared__ double TAB[64];
+  __shared__ double TAB[VB_EXP_TAB_N];
   const int s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
   const int ni = lane & 15, kq = lane >> 4, rowbase = lane & 48;
   const int D = dm.D, K = dm.K, N = dm.N;
   const int kk = 4 * blockIdx.x + kq;
   const bool kvalid = kk < K;
   const int k = kvalid ? kk : K - 1;
-  TAB[lane] = c_exp2_tab[lane];
+  for (int t = lane; t < VB_EXP_TAB_N; t += WAVE) TAB[t] = c_exp2_tab[t];
   VpLayout L{D, K};
   const double* v = vpd + (size_t)r * L.stride();
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);

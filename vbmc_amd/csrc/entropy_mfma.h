@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
   __shared__ double Et[16 * DP];           // eps tile [i][d]
   __shared__ double RQ[16];                // q'_i then 1/q'_i
-  __shared__ double TAB[64];               // 2^(j/64)
+  __shared__ double TAB[VB_EXP_TAB_N];     // 2^(j/256)
   __shared__ double BND[SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   const int lane = threadIdx.x;
   const int li = lane & 15, lg = lane >> 4;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
     const double* gsrc = a.entp + (size_t)r * K * PSg;
     for (int idx = lane; idx < K * PSg; idx += WAVE) PB[idx] = gsrc[idx];
   }
-  TAB[lane] = c_exp2_tab[lane];
+  for (int t = lane; t < VB_EXP_TAB_N; t += WAVE) TAB[t] = c_exp2_tab[t];
   __syncthreads();
   const double* gp = PB;
   const double* pj = gp + (size_t)j * PSg;
@@ -203,19 +203,19 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
       }
 #pragma unroll
       for (int kt = 0; kt < KT - 1; ++kt) {
-        if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab4(n[kt], TAB);
+        if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab4<1>(n[kt], TAB);
         else n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
       }
       if (SP && !((act >> (KT - 1)) & 1u)) {
         n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
       } else if (nr_last == 4) {
-        n[KT - 1] = vb_exp_tab4(n[KT - 1], TAB);
+        n[KT - 1] = vb_exp_tab4<1>(n[KT - 1], TAB);
       } else {  // registers whose four components are all padding stay exactly zero
         mf4 t = n[KT - 1];
         n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
-        n[KT - 1][0] = vb_exp_tab(t[0], TAB);
-        if (nr_last > 1) n[KT - 1][1] = vb_exp_tab(t[1], TAB);
-        if (nr_last > 2) n[KT - 1][2] = vb_exp_tab(t[2], TAB);
+        n[KT - 1][0] = vb_exp_tab<1>(t[0], TAB);
+        if (nr_last > 1) n[KT - 1][1] = vb_exp_tab<1>(t[1], TAB);
+        if (nr_last > 2) n[KT - 1][2] = vb_exp_tab<1>(t[2], TAB);
       }
       if (GRAD) {
         // ---- PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.
