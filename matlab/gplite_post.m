@@ -1,0 +1,48 @@
+function gp = gplite_post(hyp,X,y,covfun,meanfun,noisefun,s2,update1,outwarpfun)
+%GPLITE_POST Drop-in shim: GP posterior (kernel matrix, jittered Cholesky, alpha) for all hyper-parameter
+% samples in one batched device call through vbmc_hip_mex.
+%
+% Same signature and defaulting as the reference (gplite/gplite_post.m:1-29).  Accelerated: the
+% from-scratch form GPLITE_POST(HYP,X,Y,COVFUN,MEANFUN,NOISEFUN,S2) with SE-ARD covariance, mean
+% function 0/1/4, no integrated mean, no output warping.  The struct-input forms (re-computation,
+% rank-one update) and everything else are forwarded to the reference further down the path.
+if nargin < 4; covfun = []; end
+if nargin < 5; meanfun = []; end
+if nargin < 6; noisefun = []; end
+if nargin < 7; s2 = []; end
+if nargin < 8 || isempty(update1); update1 = false; end
+if nargin < 9; outwarpfun = []; end
+
+if isempty(covfun); cf = 1; else; cf = covfun; end
+if isempty(meanfun); mf = 1; else; mf = meanfun; end
+supported = ~isstruct(hyp) && ~update1 && isempty(outwarpfun) && ~iscell(mf) && isnumeric(mf) ...
+    && any(mf(1) == [0 1 4]) && isnumeric(cf) && cf(1) == 1 && ~isempty(hyp) && ~isempty(y);
+if ~supported
+    ref = vbmc_hip_reference('gplite_post');
+    args = {hyp,X,y,covfun,meanfun,noisefun,s2,update1,outwarpfun};
+    gp = ref(args{1:max(nargin,1)});
+    return;
+end
+
+% struct layout: gplite/gplite_post.m:94-157
+gp.X = X; gp.y = y; gp.s2 = s2;
+[Nhyp,Ns] = size(hyp);
+if isempty(noisefun); if isempty(s2); noisefun = [1 0 0]; else; noisefun = [1 1 0]; end; end
+[gp.Ncov,info] = gplite_covfun('info',X,cf);        gp.covfun = info.covfun;
+[gp.Nnoise,info] = gplite_noisefun('info',X,noisefun); gp.noisefun = info.noisefun;
+[gp.Nmean,info] = gplite_meanfun('info',X,mf,y);    gp.meanfun = info.meanfun; gp.meanfun_extras = info.extras;
+gp.intmeanfun = 0; gp.intmeanfun_mean = []; gp.intmeanfun_var = [];
+gp.outwarpfun = [];
+if Nhyp ~= gp.Ncov+gp.Nnoise+gp.Nmean
+    error('gplite_post:dimmismatch','Number of hyperparameters mismatched with GP model specification.');
+end
+[alpha,L,sW,mult,lch] = vbmc_hip_mex('gp_post',hyp,X,y,s2,gp.meanfun,gp.noisefun);
+for s = 1:Ns
+    gp.post(s).hyp = hyp(:,s);
+    gp.post(s).alpha = alpha(:,s);
+    gp.post(s).sW = sW(:,s);
+    gp.post(s).L = L(:,:,s);
+    gp.post(s).sn2_mult = mult(s);
+    gp.post(s).Lchol = logical(lch(s));
+end
+end

@@ -1,0 +1,35 @@
+function [ymu,ys2,fmu,fs2,lp] = gplite_pred(gp,Xstar,ystar,s2star,ssflag,nowarpflag)
+%GPLITE_PRED Drop-in shim: GP prediction on an MI355X through vbmc_hip_mex.
+%
+% Same signature and defaulting as the reference (gplite/gplite_pred.m:1-9).  The accelerated path
+% covers what VBMC's acquisition sweep uses (SE-ARD covariance, mean functions 0/1/4, Gaussian noise
+% models, no output warping, no integrated mean, no log-predictive output); every other call form
+% goes to the reference further down the path.
+if nargin < 3; ystar = []; end
+if nargin < 4; s2star = []; end
+if nargin < 5 || isempty(ssflag); ssflag = false; end
+if nargin < 6 || isempty(nowarpflag); nowarpflag = false; end
+
+supported = nargout < 5 && any(gp.meanfun == [0 1 4]) && gp.covfun(1) == 1 ...
+    && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) ...
+    && ~(isfield(gp,'outwarpfun') && ~isempty(gp.outwarpfun) && ~nowarpflag) ...
+    && ~isempty(gp.post(1).alpha);
+if ~supported
+    ref = vbmc_hip_reference('gplite_pred');
+    outs = cell(1,max(nargout,1));
+    [outs{:}] = ref(gp,Xstar,ystar,s2star,ssflag,nowarpflag);
+    outs(end+1:5) = {[]};
+    [ymu,ys2,fmu,fs2,lp] = outs{:};
+    return;
+end
+Nstar = size(Xstar,1);
+if ~isempty(ystar) && size(ystar,1) ~= Nstar
+    error('gplite_pred:ydimmismatch','YSTAR should be empty or a column vector of NSTAR observations.');
+end
+if ~isempty(s2star) && size(s2star,1) ~= Nstar
+    error('gplite_pred:s2dimmismatch','S2STAR should be empty or a column vector of NSTAR estimated variances.');
+end
+h = vbmc_hip_gp_handle(gp);
+[ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred',h,Xstar,s2star,double(ssflag),numel(gp.post));
+lp = [];
+end

@@ -1,0 +1,42 @@
+function [F,dF,varF,dvarF,varss,I_sk,J_sjk] = gplogjoint(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K)
+%GPLOGJOINT Drop-in shim: expected log joint (Bayesian quadrature) on an MI355X through vbmc_hip_mex.
+%
+% Same signature and defaulting as the reference (misc/gplogjoint.m:1-30).  Accelerated: averaged over
+% hyper-parameter samples (AVG_FLAG), Jacobian-transformed gradients (JACOBIAN_FLAG) for exactly the
+% parameter groups VP optimises, no gradient of the variance as a separate output.  Other call forms
+% go to the reference further down the path.
+if nargin < 3; grad_flags = []; end
+if nargin < 4 || isempty(avg_flag); avg_flag = true; end
+if nargin < 5 || isempty(jacobian_flag); jacobian_flag = true; end
+if nargin < 6; compute_var = []; end
+if nargin < 7 || isempty(separate_K); separate_K = nargout > 5; end
+if isempty(compute_var); compute_var = nargout > 2; end
+if nargout < 2; grad_flags = false; elseif isempty(grad_flags); grad_flags = true; end
+if isscalar(grad_flags); grad_flags = ones(1,4)*grad_flags; end
+compute_vargrad = nargout > 3 && compute_var && any(grad_flags);
+if compute_vargrad && compute_var ~= 2
+    error('gplogjoint:FullVarianceGradient', ...
+        'Computation of gradient of log joint variance is currently available only for diagonal approximation of the variance.');
+end
+
+vpflags = [vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambda, vp.optimize_weights];
+supported = avg_flag && jacobian_flag && ~compute_vargrad && any(gp.meanfun == [0 1 4]) ...
+    && (~any(grad_flags) || isequal(logical(grad_flags(:)'),logical(vpflags))) ...
+    && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) && (~vp.optimize_weights || isfield(vp,'eta'));
+if ~supported
+    ref = vbmc_hip_reference('gplogjoint');
+    outs = cell(1,max(nargout,1));
+    [outs{:}] = ref(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K);
+    outs(end+1:7) = {[]};
+    [F,dF,varF,dvarF,varss,I_sk,J_sjk] = outs{:};
+    return;
+end
+theta = get_vptheta(vp);                       % misc/get_vptheta.m
+h = vbmc_hip_gp_handle(gp);
+g = any(grad_flags);
+[~,~,F,~,varF,~,varss,I_sk,J_sjk,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,double(g), ...
+    double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+if ~g; dF = []; end
+dvarF = [];
+if ~compute_var; varF = []; varss = []; end
+end

@@ -10,6 +10,10 @@
 //          vbmc_hip_mex('gp_free', h)
 //     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
 //                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty)
+//     [F,dF,varG] = vbmc_hip_mex('elbo_batch', h, Theta /*T x R*/, vp, Ns, compute_grad, compute_var, beta,
+//                                thetabnd_or_empty, seed)      (the R candidates of vpsieve_vbmc.m:74-78 in one pass)
+//     [x,f,iters] = vbmc_hip_mex('adam', h, Theta0 /*T x R*/, vp, Ns, compute_var, beta, thetabnd_or_empty, seed,
+//                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device)
 //     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
 //     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
 //     C = vbmc_hip_mex('sq_dist', a, b)
@@ -54,6 +58,27 @@ static const mxArray* field(const mxArray* s, const char* name) { return mxGetFi
 static double scalar_field(const mxArray* s, const char* name, double dflt) {
   const mxArray* f = field(s, name);
   return (f && !mxIsEmpty(f)) ? mxGetScalar(f) : dflt;
+}
+
+// vp struct + thetabnd -> the parameter-layout part of vbmc_elbo_args (shared by 'elbo', 'elbo_batch', 'adam')
+static void fill_vp_args(vbmc_elbo_args& a, const mxArray* vp, const mxArray* tb, std::vector<double>& delta) {
+  memset(&a, 0, sizeof a);
+  a.struct_size = sizeof a;
+  a.D = (int)scalar_field(vp, "D", 0); a.K = (int)scalar_field(vp, "K", 0); a.R = 1;
+  a.optimize[0] = scalar_field(vp, "optimize_mu", 1) != 0; a.optimize[1] = scalar_field(vp, "optimize_sigma", 1) != 0;
+  a.optimize[2] = scalar_field(vp, "optimize_lambda", 1) != 0; a.optimize[3] = scalar_field(vp, "optimize_weights", 0) != 0;
+  a.vp_mu = dbl(field(vp, "mu")); a.vp_sigma = dbl(field(vp, "sigma")); a.vp_lambda = dbl(field(vp, "lambda")); a.vp_w = dbl(field(vp, "w"));
+  const mxArray* dl = field(vp, "delta");
+  if (dl && !mxIsEmpty(dl)) {  // scalar or D-vector (gplogjoint.m:85-89)
+    delta.assign(a.D, mxGetDoubles(dl)[0]);
+    if ((int)mxGetNumberOfElements(dl) == a.D) memcpy(delta.data(), mxGetDoubles(dl), a.D * sizeof(double));
+    a.vp_delta = delta.data();
+  }
+  if (tb && !mxIsEmpty(tb)) {
+    a.bnd_lb = dbl(field(tb, "lb")); a.bnd_ub = dbl(field(tb, "ub")); a.TolCon = scalar_field(tb, "TolCon", 0.01);
+    a.WeightThreshold = scalar_field(tb, "WeightThreshold", 0); a.WeightPenalty = scalar_field(tb, "WeightPenalty", 0);
+  }
+  { const char* sc = getenv("VBMC_HIP_SPARSE_CUTOFF"); a.sparse_cutoff = sc ? atof(sc) : 0.0; }
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
@@ -102,29 +127,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const mxArray* theta = prhs[2];
     const mxArray* vp = prhs[3];
     vbmc_elbo_args a;
-    memset(&a, 0, sizeof a);
-    a.struct_size = sizeof a;
-    a.D = (int)scalar_field(vp, "D", 0); a.K = (int)scalar_field(vp, "K", 0); a.R = 1;
-    a.optimize[0] = scalar_field(vp, "optimize_mu", 1) != 0; a.optimize[1] = scalar_field(vp, "optimize_sigma", 1) != 0;
-    a.optimize[2] = scalar_field(vp, "optimize_lambda", 1) != 0; a.optimize[3] = scalar_field(vp, "optimize_weights", 0) != 0;
-    a.theta = mxGetDoubles(theta);
-    a.vp_mu = dbl(field(vp, "mu")); a.vp_sigma = dbl(field(vp, "sigma")); a.vp_lambda = dbl(field(vp, "lambda")); a.vp_w = dbl(field(vp, "w"));
     std::vector<double> delta;
-    const mxArray* dl = field(vp, "delta");
-    if (dl && !mxIsEmpty(dl)) {  // scalar or D-vector (gplogjoint.m:85-89)
-      delta.assign(a.D, mxGetDoubles(dl)[0]);
-      if ((int)mxGetNumberOfElements(dl) == a.D) memcpy(delta.data(), mxGetDoubles(dl), a.D * sizeof(double));
-      a.vp_delta = delta.data();
-    }
+    fill_vp_args(a, vp, nrhs > 9 ? prhs[9] : nullptr, delta);
+    a.theta = mxGetDoubles(theta);
     a.Ns = (int)mxGetScalar(prhs[4]);
     a.compute_grad = (int)mxGetScalar(prhs[5]); a.compute_var = (int)mxGetScalar(prhs[6]); a.separate_K = (int)mxGetScalar(prhs[7]);
     a.beta = mxGetScalar(prhs[8]);
-    const mxArray* tb = nrhs > 9 ? prhs[9] : nullptr;
-    if (tb && !mxIsEmpty(tb)) {
-      a.bnd_lb = dbl(field(tb, "lb")); a.bnd_ub = dbl(field(tb, "ub")); a.TolCon = scalar_field(tb, "TolCon", 0.01);
-      a.WeightThreshold = scalar_field(tb, "WeightThreshold", 0); a.WeightPenalty = scalar_field(tb, "WeightPenalty", 0);
-    }
-    { const char* sc = getenv("VBMC_HIP_SPARSE_CUTOFF"); a.sparse_cutoff = sc ? atof(sc) : 0.0; }
     const mxArray* eps = nrhs > 10 ? prhs[10] : nullptr;  // D x Ns/2 x K block drawn by the shim with randn, or []
     if (eps && !mxIsEmpty(eps)) { a.eps_mode = 1; a.eps = mxGetDoubles(eps); a.eps_shared = 1; }
     else { a.eps_mode = 0; a.seed = (uint64_t)(nrhs > 11 ? mxGetScalar(prhs[11]) : 0); }
@@ -133,7 +141,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray *G = mxCreateDoubleMatrix(1, 1, mxREAL), *H = mxCreateDoubleMatrix(1, 1, mxREAL), *vG = mxCreateDoubleMatrix(1, 1, mxREAL);
     mxArray *dH = mxCreateDoubleMatrix(a.compute_grad ? T : 0, a.compute_grad ? 1 : 0, mxREAL), *vss = mxCreateDoubleMatrix(1, 1, mxREAL);
     a.F = mxGetDoubles(F); a.G = mxGetDoubles(G); a.H = mxGetDoubles(H); a.varG = mxGetDoubles(vG); a.varGss = mxGetDoubles(vss);
-    if (a.compute_grad) { a.dF = mxGetDoubles(dF); a.dH = mxGetDoubles(dH); }
+    mxArray* dG = mxCreateDoubleMatrix(a.compute_grad ? T : 0, a.compute_grad ? 1 : 0, mxREAL);  // 10th output (gplogjoint shim)
+    if (a.compute_grad) { a.dF = mxGetDoubles(dF); a.dH = mxGetDoubles(dH); a.dG = mxGetDoubles(dG); }
     mxArray *Isk = nullptr, *Jsjk = nullptr;
     if (a.separate_K) {
       // S is known to the library; query through a first call would cost a launch, so the shim passes numel(gp.post)
@@ -144,8 +153,61 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
     vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
     if (st != VBMC_OK) fail(st);  // MATLAB frees the mxArrays created above on error
-    mxArray* outs[9] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk};
-    for (int i = 0; i < 9 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    mxArray* outs[10] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG};
+    for (int i = 0; i < 10 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    return;
+  }
+
+  if (!strcmp(cmd, "elbo_batch")) {
+    // (h, Theta, vp, Ns, compute_grad, compute_var, beta, thetabnd, seed): R = size(Theta,2) candidates that share
+    // vp's flags and its non-optimised groups; device MC stream keyed by (seed, r)
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    const mxArray* Theta = prhs[2];
+    vbmc_elbo_args a;
+    std::vector<double> delta;
+    fill_vp_args(a, prhs[3], nrhs > 8 ? prhs[8] : nullptr, delta);
+    const size_t T = mxGetM(Theta);
+    a.R = (int)mxGetN(Theta);
+    a.theta = mxGetDoubles(Theta);
+    a.Ns = (int)mxGetScalar(prhs[4]); a.compute_grad = (int)mxGetScalar(prhs[5]); a.compute_var = (int)mxGetScalar(prhs[6]);
+    a.beta = mxGetScalar(prhs[7]);
+    a.eps_mode = 0; a.seed = (uint64_t)(nrhs > 9 ? mxGetScalar(prhs[9]) : 0);
+    mxArray *F = mxCreateDoubleMatrix(1, a.R, mxREAL), *dF = mxCreateDoubleMatrix(a.compute_grad ? T : 0, a.compute_grad ? a.R : 0, mxREAL);
+    mxArray* vG = mxCreateDoubleMatrix(1, a.R, mxREAL);
+    a.F = mxGetDoubles(F); a.varG = mxGetDoubles(vG);
+    if (a.compute_grad) a.dF = mxGetDoubles(dF);
+    vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
+    if (st != VBMC_OK) fail(st);
+    plhs[0] = F;
+    if (nlhs > 1) plhs[1] = dF;
+    if (nlhs > 2) plhs[2] = vG;
+    return;
+  }
+
+  if (!strcmp(cmd, "adam")) {
+    // (h, Theta0, vp, Ns, compute_var, beta, thetabnd, seed, TolFun, MaxIter, [step_min step_max step_decay])
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    const mxArray* Theta = prhs[2];
+    vbmc_elbo_args a;
+    std::vector<double> delta;
+    fill_vp_args(a, prhs[3], nrhs > 7 ? prhs[7] : nullptr, delta);
+    const size_t T = mxGetM(Theta);
+    a.R = (int)mxGetN(Theta);
+    a.theta = mxGetDoubles(Theta);
+    a.Ns = (int)mxGetScalar(prhs[4]); a.compute_grad = 1; a.compute_var = (int)mxGetScalar(prhs[5]); a.beta = mxGetScalar(prhs[6]);
+    a.eps_mode = 0; a.seed = (uint64_t)mxGetScalar(prhs[8]);
+    const double TolFun = mxGetScalar(prhs[9]);
+    const int MaxIter = (int)mxGetScalar(prhs[10]);
+    double step[3] = {0.001, 0.1, 200.0};  // fminadam.m:28-31 defaults
+    for (int i = 0; nrhs > 11 && i < 3 && i < (int)mxGetNumberOfElements(prhs[11]); ++i) step[i] = mxGetDoubles(prhs[11])[i];
+    mxArray *x = mxCreateDoubleMatrix(T, a.R, mxREAL), *f = mxCreateDoubleMatrix(1, a.R, mxREAL);
+    mxArray* it = mxCreateNumericMatrix(1, a.R, mxINT32_CLASS, mxREAL);
+    vbmc_status st = vbmc_adam_batch(g_ctx, h, &a, TolFun, MaxIter, step[0], step[1], step[2], mxGetDoubles(x), mxGetDoubles(f),
+                                     (int32_t*)mxGetData(it), nullptr, nullptr);
+    if (st != VBMC_OK) fail(st);
+    plhs[0] = x;
+    if (nlhs > 1) plhs[1] = f;
+    if (nlhs > 2) plhs[2] = it;
     return;
   }
 

@@ -37,6 +37,27 @@ def test_sieve_order_is_index_identical(va):
     assert np.array_equal(a[6], b[6])
 
 
+def test_sieve_with_fixed_groups_that_differ_between_candidates(va):
+    """Non-optimised groups are not part of theta; candidates that differ in one (here: fixed weights)
+    must still each be evaluated with their own values (sub-batching in sieve_evaluate)."""
+    from vbmc_amd.optimize import sieve_evaluate
+    p, gp, vp, _ = problem(35, 4, 60, 5, 3)
+    vp = dict(vp, optimize_weights=False)
+    vp.pop("eta", None)
+    rng = np.random.default_rng(2)
+    cands = []
+    for i in range(7):
+        v = dict(vp, mu=vp["mu"] + 0.1 * rng.standard_normal(vp["mu"].shape))
+        w = rng.dirichlet(np.ones(5)) if i % 3 else vp["w"]      # three distinct weight vectors + repeats
+        cands.append(dict(v, w=w))
+    vals, _ = sieve_evaluate(cands, gp, 0, False, 0.0, None)
+    ref = []
+    for v in cands:
+        th, v2 = R.get_vptheta(v)
+        ref.append(R.negelcbo_vbmc(th, 0, v2, gp, 0, False, 0)["F"])
+    assert relerr(vals, np.array(ref)) < 1e-10
+
+
 def test_adam_trajectory_matches_oracle(va):
     """utils/fminadam.m driven by the HIP objective vs by the oracle objective, same eps per iteration."""
     p, gp, vp, theta = problem(32, 4, 50, 5, 3)

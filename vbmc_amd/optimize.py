@@ -157,12 +157,21 @@ def sieve_evaluate(vp0_vec, gp, NSentKFast, compute_var, elcbo_beta, thetabnd, *
         rank, world, allgather = shard
         idx = idx[rank::world]
     vals = np.full(R, np.nan)
-    if idx.size:
-        out = negelcbo_batch(Th[:, idx], 0, vps[0], gp, NSentKFast, False, int(bool(compute_var)), thetabnd,
+    # the batched ABI shares the NON-optimised parameter groups across the batch (they are not part of theta);
+    # candidates that differ in such a group (e.g. fixed weights) are evaluated in separate sub-batches
+    fixed = [g for g, f in (("mu", "optimize_mu"), ("sigma", "optimize_sigma"), ("lambda", "optimize_lambda"),
+                            ("w", "optimize_weights")) if not vps[0][f]]
+    groups = {}
+    for i in idx:
+        key = tuple(np.asarray(vps[i][g], dtype=np.float64).tobytes() for g in fixed)
+        groups.setdefault(key, []).append(int(i))
+    local = np.zeros(idx.size)
+    pos = {int(i): p for p, i in enumerate(idx)}
+    for members in groups.values():
+        out = negelcbo_batch(Th[:, members], 0, vps[members[0]], gp, NSentKFast, False, int(bool(compute_var)), thetabnd,
                              seed=seed, engine=engine)
-        local = out["F"] + elcbo_beta * np.sqrt(out["varG"]) if compute_var else out["F"]
-    else:
-        local = np.zeros(0)
+        v = out["F"] + elcbo_beta * np.sqrt(out["varG"]) if compute_var else out["F"]
+        local[[pos[i] for i in members]] = v
     if shard is not None:
         vals = allgather(local, idx, R)
     else:
