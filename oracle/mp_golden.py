@@ -11,6 +11,8 @@ Formulas follow (reference paths, acerbilab/vbmc v1.0.12):
   logjoint misc/gplogjoint.m:97-413 (negquad mean, meanfun id 4; also 0 and 1)
   gp_post  gplite/private/gplite_core.m:33-102,278-291
   gp_pred  gplite/gplite_pred.m:52-165
+  nlZ      gplite/private/gplite_core.m:205 (value); its gradient (:236-275) is pinned by 50-digit central
+           differences of the value, i.e. independently of the reference's analytic Q-matrix formulas
 
 Run:  python oracle/mp_golden.py   (writes tests/golden/mp_case*.json)
 The inputs are drawn with numpy default_rng(seed) and stored in the JSON next to
@@ -268,6 +270,85 @@ def mp_logjoint(mu, sigma, lam, w, eta, X, posts, meanfun, compute_var):
     return Fs, dFs, I_sk, J_all, varFs
 
 
+# ------------------------------------------------------------------ GP marginal likelihood
+def mp_nlz(hyp, X, y, meanfun, noisefun, s2):
+    """-log N(y; m, K + diag(sn2)) straight from the definition (no sn2 rescaling, no retries)."""
+    N, D = len(X), len(X[0])
+    ell = [mp.e ** hyp[d] for d in range(D)]
+    sf2 = mp.e ** (2 * hyp[D])
+    idx = D + 1
+    sn2 = [mp.e ** (2 * hyp[idx])] * N
+    idx += 1
+    if noisefun[1] == 1:
+        sn2 = [sn2[n] + s2[n] for n in range(N)]
+    elif noisefun[1] == 2:
+        sn2 = [sn2[n] + mp.e ** hyp[idx] * s2[n] for n in range(N)]
+        idx += 1
+    hyp_mean = hyp[idx:]
+    A = [[sf2 * mp.e ** (-mp.fsum(((X[a][d] - X[b][d]) / ell[d]) ** 2 for d in range(D)) / 2) + (sn2[a] if a == b else 0)
+          for b in range(N)] for a in range(N)]
+    R = mp_chol_upper(A)
+    r = [y[n] - mp_meanfun(hyp_mean, X[n], meanfun, D) for n in range(N)]
+    v = mp_solve_ut_t(R, r)
+    return mp.fsum(t * t for t in v) / 2 + mp.fsum(mp.log(R[i][i]) for i in range(N)) + N * mp.log(2 * mp.pi) / 2
+
+
+def mp_nlz_grad(hyp, X, y, meanfun, noisefun, s2):
+    h = mp.mpf(10) ** -18
+    g = []
+    for i in range(len(hyp)):
+        hp = list(hyp)
+        hm = list(hyp)
+        hp[i] = hyp[i] + h
+        hm[i] = hyp[i] - h
+        g.append((mp_nlz(hp, X, y, meanfun, noisefun, s2) - mp_nlz(hm, X, y, meanfun, noisefun, s2)) / (2 * h))
+    return g
+
+
+NLZ_CASES = [
+    dict(seed=21, D=2, N=7, S=2, meanfun=4, noisefun=(1, 0, 0)),
+    dict(seed=22, D=3, N=10, S=2, meanfun=4, noisefun=(1, 1, 0)),
+    dict(seed=23, D=2, N=8, S=2, meanfun=1, noisefun=(1, 2, 0)),
+    dict(seed=24, D=3, N=9, S=1, meanfun=0, noisefun=(1, 0, 0)),
+]
+
+
+def make_nlz_case(seed, D, N, S, meanfun, noisefun):
+    rng = np.random.default_rng(seed)
+    X = 1.5 * rng.standard_normal((N, D))
+    y = -0.5 * np.sum((X / 1.3) ** 2, axis=1) + 0.3 * np.sin(X[:, 0]) + 0.05 * rng.standard_normal(N)
+    s2 = 0.01 + 0.05 * rng.random(N) if noisefun[1] else None
+    nnoise = 1 + (1 if noisefun[1] == 2 else 0)
+    nmean = {0: 0, 1: 1, 4: 2 * D + 1}[meanfun]
+    hyp = np.zeros((D + 1 + nnoise + nmean, S))
+    for s in range(S):
+        hyp[:D, s] = np.log(0.8) + 0.2 * rng.standard_normal(D)
+        hyp[D, s] = np.log(np.std(y)) + 0.1 * rng.standard_normal()
+        hyp[D + 1, s] = np.log(5e-2) + 0.1 * rng.standard_normal()
+        if noisefun[1] == 2:
+            hyp[D + 2, s] = 0.3 * rng.standard_normal()
+        o = D + 1 + nnoise
+        if meanfun >= 1:
+            hyp[o, s] = np.max(y) + 0.1 * rng.standard_normal()
+        if meanfun == 4:
+            hyp[o + 1 : o + 1 + D, s] = 0.2 * rng.standard_normal(D)
+            hyp[o + 1 + D :, s] = np.log(2.0) + 0.1 * rng.standard_normal(D)
+    return dict(seed=seed, D=D, N=N, S=S, meanfun=meanfun, noisefun=list(noisefun), X=X, y=y, s2=s2, hyp=hyp)
+
+
+def run_nlz_case(c):
+    N, D = c["X"].shape
+    X = [[M(c["X"][n, d]) for d in range(D)] for n in range(N)]
+    y = [M(t) for t in c["y"]]
+    s2 = None if c["s2"] is None else [M(t) for t in c["s2"]]
+    out = {"nlZ": [], "dnlZ": []}
+    for s in range(c["S"]):
+        hyp = [M(t) for t in c["hyp"][:, s]]
+        out["nlZ"].append(fl(mp_nlz(hyp, X, y, c["meanfun"], c["noisefun"], s2)))
+        out["dnlZ"].append(fl(mp_nlz_grad(hyp, X, y, c["meanfun"], c["noisefun"], s2)))
+    return out
+
+
 # ------------------------------------------------------------------ driver
 def tolist(a):
     return np.asarray(a, dtype=np.float64).tolist()
@@ -365,5 +446,23 @@ def main():
         print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
 
 
+def main_nlz():
+    outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    for i, spec in enumerate(NLZ_CASES):
+        c = make_nlz_case(**spec)
+        out = run_nlz_case(c)
+        rec = {"generator": "oracle/mp_golden.py nlz (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps),
+               "inputs": {k: (tolist(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()},
+               "expected": out}
+        path = os.path.join(outdir, "mp_nlz_case%d.json" % i)
+        with open(path, "w") as f:
+            json.dump(rec, f)
+        print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
+
+
 if __name__ == "__main__":
-    main()
+    if "nlz" in sys.argv[1:]:
+        main_nlz()      # only the marginal-likelihood fixtures
+    else:
+        main()
+        main_nlz()

@@ -255,6 +255,168 @@ def gplite_core_post(hyp, gp):
     return post
 
 
+def gplite_meanfun_grad(hyp_mean, X, meanfun):
+    """gplite/gplite_meanfun.m:395-436 with compute_grad: (m, dm) with dm N x Nmean (None for id 0)."""
+    X = np.asarray(X, dtype=np.float64)
+    N, D = X.shape
+    m = gplite_meanfun(hyp_mean, X, meanfun)
+    if meanfun == 0:
+        return m, None  # :402
+    if meanfun == 1:
+        return m, np.ones((N, 1))  # :406
+    xm = hyp_mean[1 : D + 1]
+    omega = np.exp(hyp_mean[D + 1 : 2 * D + 1])
+    z2 = ((X - xm[None, :]) / omega[None, :]) ** 2
+    dm = np.zeros((N, 2 * D + 1))
+    dm[:, 0] = 1.0  # :433
+    dm[:, 1 : D + 1] = (X - xm[None, :]) / omega[None, :] ** 2  # :434 with sgn = -1
+    dm[:, D + 1 :] = z2  # :435
+    return m, dm
+
+
+def gplite_noisefun_grad(hyp_noise, X, noisefun, y=None, s2=None):
+    """gplite/gplite_noisefun.m:164-210 with compute_grad: (sn2, dsn2); dsn2 is 1 x Nnoise for a
+    constant noise model and N x Nnoise otherwise (:166-171)."""
+    N = np.asarray(X).shape[0]
+    Nnoise = noisefun_nhyp(noisefun)
+    vector = any(v > 0 for v in noisefun[1:])
+    dsn2 = np.zeros((N if vector else 1, Nnoise))
+    idx = 0
+    if noisefun[0] == 0:
+        sn2 = EPS
+    else:
+        sn2 = math.exp(2.0 * hyp_noise[idx])
+        dsn2[:, idx] = 2.0 * sn2  # :182
+        idx += 1
+    if noisefun[1] == 1:
+        sn2 = sn2 + np.asarray(s2, dtype=np.float64)
+    elif noisefun[1] == 2:
+        sn2 = sn2 + math.exp(hyp_noise[idx]) * np.asarray(s2, dtype=np.float64)
+        dsn2[:, idx] = math.exp(hyp_noise[idx]) * np.asarray(s2, dtype=np.float64)  # :192
+        idx += 1
+    if len(noisefun) > 2 and noisefun[2] == 1:
+        if y is not None and np.size(y) > 0:
+            yv = np.asarray(y, dtype=np.float64)
+            ythresh = hyp_noise[idx]
+            w2 = math.exp(2.0 * hyp_noise[idx + 1])
+            zz = np.maximum(0.0, ythresh - yv)
+            sn2 = sn2 + w2 * zz**2
+            dsn2[:, idx] = 2.0 * w2 * (ythresh - yv) * (zz > 0)  # :204
+            dsn2[:, idx + 1] = 2.0 * w2 * zz**2  # :205
+        idx += 2
+    return sn2, dsn2
+
+
+def gplite_core_nlZ(hyp, gp, compute_grad=True):
+    """gplite/private/gplite_core.m:1-102 + the compute_nlZ branch :128-275 (covfun 1, no output
+    warping, no integrated mean): (nlZ, dnlZ).  A Cholesky that still fails after the 10
+    noise-inflation retries makes MATLAB error downstream; the caller (gplite_train.m:542-546) maps
+    that to NaN, and so does this function."""
+    X = gp["X"]
+    y = gp["y"]
+    N, D = X.shape
+    Ncov, Nnoise, Nmean = gp["Ncov"], gp["Nnoise"], gp["Nmean"]
+    hyp = np.asarray(hyp, dtype=np.float64).reshape(-1)
+    Nhyp = hyp.size
+    sn2, dsn2 = gplite_noisefun_grad(hyp[Ncov : Ncov + Nnoise], X, gp["noisefun"], y, gp.get("s2"))  # :36
+    sn2_mult = 1.0
+    m, dm = gplite_meanfun_grad(hyp[Ncov + Nnoise : Ncov + Nnoise + Nmean], X, gp["meanfun"])  # :44
+    ell = np.exp(hyp[0:D])
+    sf2 = math.exp(2.0 * hyp[D])
+    K_mat = sf2 * np.exp(-sq_dist(X.T / ell[:, None]) / 2.0)  # :55-56
+    scalar = np.ndim(sn2) == 0
+    Lchol = bool(np.min(sn2) >= 1e-6)
+    p = 1
+    if Lchol:
+        sn2div = float(sn2) if scalar else float(np.min(sn2))
+        sn2_mat = np.eye(N) if scalar else np.diag(sn2 / sn2div)
+        for _ in range(10):
+            L, p = chol_upper(K_mat / (sn2div * sn2_mult) + sn2_mat)
+            if p > 0:
+                sn2_mult *= 10.0
+            else:
+                break
+        sl = sn2div * sn2_mult
+    else:
+        sn2_mat = float(sn2) * np.eye(N) if scalar else np.diag(sn2)
+        for _ in range(10):
+            L, p = chol_upper(K_mat + sn2_mult * sn2_mat)
+            if p > 0:
+                sn2_mult *= 10.0
+            else:
+                break
+        sl = 1.0
+    if p > 0:
+        return float("nan"), np.full(Nhyp, np.nan)
+    alpha = solve_upper(L, solve_upper_t(L, y - m)) / sl  # :102
+    nlZ = float((y - m) @ alpha / 2.0 + np.sum(np.log(np.diag(L))) + N * math.log(2 * math.pi * sl) / 2.0)  # :205
+    if not compute_grad:
+        return nlZ, None
+    dnlZ = np.zeros(Nhyp)
+    Q = solve_upper(L, solve_upper_t(L, np.eye(N))) / sl - np.outer(alpha, alpha)  # :240
+    for i in range(D):  # :244-247
+        K_temp = K_mat * sq_dist(X[:, i][None, :] / ell[i])
+        dnlZ[i] = np.sum(Q * K_temp) / 2.0
+    dnlZ[D] = np.sum(Q * (2.0 * K_mat)) / 2.0  # :248
+    if scalar:  # :257-259
+        trQ = np.trace(Q)
+        for i in range(Nnoise):
+            dnlZ[Ncov + i] = 0.5 * sn2_mult * dsn2[0, i] * trQ
+    else:  # :261-262
+        dgQ = np.diag(Q)
+        for i in range(Nnoise):
+            dnlZ[Ncov + i] = 0.5 * sn2_mult * np.sum(dsn2[:, i] * dgQ)
+    if Nmean > 0:
+        dnlZ[Ncov + Nnoise : Ncov + Nnoise + Nmean] = -dm.T @ alpha  # :274
+    return nlZ, dnlZ
+
+
+def gplite_hypprior(hyp, hprior, compute_grad=True):
+    """gplite/gplite_hypprior.m:17-65: (lp, dlp) of independent uniform / Gaussian / Student-t priors."""
+    from math import lgamma
+
+    hyp = np.asarray(hyp, dtype=np.float64).reshape(-1)
+    Nhyp = hyp.size
+    mu = np.asarray(hprior["mu"], dtype=np.float64).reshape(-1)
+    sigma = np.abs(np.asarray(hprior["sigma"], dtype=np.float64).reshape(-1))
+    df = hprior.get("df")
+    df = 7.0 * np.ones(Nhyp) if df is None or np.size(df) == 0 else np.asarray(df, dtype=np.float64).reshape(-1)  # :32-36
+    uidx = ~np.isfinite(mu) | ~np.isfinite(sigma)
+    gidx = ~uidx & ((df == 0) | ~np.isfinite(df)) & np.isfinite(sigma)
+    tidx = ~uidx & (df > 0) & np.isfinite(df)
+    z2 = np.zeros(Nhyp)
+    gt = gidx | tidx
+    z2[gt] = ((hyp[gt] - mu[gt]) / sigma[gt]) ** 2
+    lp = 0.0
+    dlp = np.zeros(Nhyp)
+    if np.any(gidx):  # :47-52
+        lp -= 0.5 * np.sum(np.log(2 * math.pi * sigma[gidx] ** 2) + z2[gidx])
+        dlp[gidx] = -(hyp[gidx] - mu[gidx]) / sigma[gidx] ** 2
+    if np.any(tidx):  # :55-62
+        d = df[tidx]
+        lg = np.array([lgamma(0.5 * (v + 1)) - lgamma(0.5 * v) for v in d])
+        lp += np.sum(lg - 0.5 * np.log(math.pi * d) - np.log(sigma[tidx]) - 0.5 * (d + 1) * np.log1p(z2[tidx] / d))
+        dlp[tidx] = -(d + 1) / d / (1 + z2[tidx] / d) * (hyp[tidx] - mu[tidx]) / sigma[tidx] ** 2
+    return (float(lp), dlp) if compute_grad else (float(lp), None)
+
+
+def gplite_nlZ(hyp, gp, hprior=None, compute_grad=True):
+    """gplite/gplite_nlZ.m:1-72: negative log marginal likelihood (minus the log hyper-prior) and gradient."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    if hyp.ndim == 2 and hyp.shape[1] > 1 and compute_grad:
+        raise ValueError("gplite_nlZ:NoSampling")  # :41-44
+    hyp = hyp.reshape(-1)
+    if hyp.size != gp["Ncov"] + gp["Nnoise"] + gp["Nmean"]:
+        raise ValueError("gplite_nlZ:dimmismatch")  # :38-40
+    nlZ, dnlZ = gplite_core_nlZ(hyp, gp, compute_grad)
+    if hprior is not None:  # :58-68
+        P, dP = gplite_hypprior(hyp, hprior, compute_grad)
+        nlZ = nlZ - P
+        if compute_grad:
+            dnlZ = dnlZ - dP
+    return nlZ, dnlZ
+
+
 def gplite_post(hyp, X, y, meanfun=4, noisefun=(1, 0, 0), s2=None):
     """gplite/gplite_post.m:94-172 (fresh GP struct + full posterior per sample).
 

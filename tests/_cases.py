@@ -14,6 +14,25 @@ def golden_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, "mp_case*.json")))
 
 
+def nlz_golden_cases():
+    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mp_nlz_case*.json")))
+
+
+def load_nlz_golden(path):
+    """-> (gp dict without posterior, hyp Nhyp x S, expected dict)."""
+    with open(path) as f:
+        rec = json.load(f)
+    inp = rec["inputs"]
+    X = np.array(inp["X"], dtype=np.float64)
+    D = X.shape[1]
+    nf = tuple(inp["noisefun"])
+    gp = {"X": X, "y": np.array(inp["y"], dtype=np.float64),
+          "s2": None if inp["s2"] is None else np.array(inp["s2"], dtype=np.float64),
+          "covfun": 1, "Ncov": D + 1, "noisefun": nf, "Nnoise": R.noisefun_nhyp(nf), "meanfun": inp["meanfun"],
+          "Nmean": R.meanfun_nhyp(inp["meanfun"], D), "meanfun_extras": None, "intmeanfun": 0}
+    return gp, np.array(inp["hyp"], dtype=np.float64), {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
+
+
 def load_golden(path):
     with open(path) as f:
         rec = json.load(f)

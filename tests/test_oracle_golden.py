@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import vbmc_ref as R
-from tests._cases import golden_cases, load_golden, vp_from_inputs
+from tests._cases import golden_cases, load_golden, load_nlz_golden, nlz_golden_cases, vp_from_inputs
 
 RTOL = 1e-11  # fp64 restatement vs 50-digit evaluation; sums of <= ~100 terms
 
@@ -85,3 +85,31 @@ def test_averaging_over_hyper_samples():
     close(avg["varss"], varFss + np.std(vF, ddof=1))
     dvv = 2 * (F[None, :] * dF).sum(axis=1) / (S - 1) - 2 * Fbar * dF.sum(axis=1) / (S - 1)
     close(avg["dvarF"], dvF.sum(axis=1) / S + dvv)
+
+
+@pytest.mark.parametrize("path", nlz_golden_cases())
+def test_nlz_matches_mpmath(path):
+    """gplite_nlZ value against the 50-digit definition; the analytic gradient (Q-matrix formulas,
+    gplite_core.m:236-275) against 50-digit central differences of that value."""
+    gp, hyp, exp = load_nlz_golden(path)
+    for s in range(hyp.shape[1]):
+        nlZ, dnlZ = R.gplite_nlZ(hyp[:, s], gp)
+        close(nlZ, exp["nlZ"][s])
+        close(dnlZ, exp["dnlZ"][s], rtol=1e-10)
+
+
+def test_hypprior_closed_forms():
+    """gplite_hypprior.m: Gaussian / Student-t / flat entries against scipy.stats log-pdfs and their slopes."""
+    from scipy import stats
+    hyp = np.array([0.3, -1.2, 2.0, 0.7])
+    hp = {"mu": np.array([0.0, -1.0, np.nan, 1.0]), "sigma": np.array([2.0, 0.5, 1.0, np.inf]), "df": np.array([np.inf, 3.0, 3.0, 0.0])}
+    lp, dlp = R.gplite_hypprior(hyp, hp)
+    ref = stats.norm.logpdf(0.3, 0.0, 2.0) + stats.t.logpdf((-1.2 + 1.0) / 0.5, 3.0) - np.log(0.5)
+    close(lp, ref)
+    e = 1e-6
+    for i in range(4):
+        d = np.zeros(4)
+        d[i] = e
+        fd = (R.gplite_hypprior(hyp + d, hp)[0] - R.gplite_hypprior(hyp - d, hp)[0]) / (2 * e)
+        assert abs(fd - dlp[i]) < 1e-8
+    assert dlp[2] == 0.0 and dlp[3] == 0.0
