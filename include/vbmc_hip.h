@@ -93,6 +93,19 @@ vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanf
                          vbmc_gp** gp_out);
 
 /*
+ * [nlZ,dnlZ] = gplite_nlZ(hyp,gp,[])   (gplite/gplite_nlZ.m:1-72 -> gplite/private/gplite_core.m:1-102,128-275)
+ * for B hyper-parameter vectors at once (the walkers / restarts of gplite_train.m:181,251,292,330): negative
+ * log marginal likelihood nlZ (B) and, if compute_grad, its gradient dnlZ (Nhyp x B, column-major).  SE-ARD
+ * covariance, mean functions 0/1/4, noise models of gplite_noisefun.m:176-210, no integrated mean, no output
+ * warping, no hyper-prior (gplite_hypprior is O(Nhyp) host work; see vbmc_amd/gplite.py).  A matrix that is
+ * still not positive definite after the 10 noise-inflation retries yields NaN for that vector
+ * (gplite_train.m:542-546), not an error.
+ */
+vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int meanfun, const int32_t noisefun[3],
+                        const double* X, const double* y, const double* s2, const double* hyp, int compute_grad,
+                        double* nlZ, double* dnlZ);
+
+/*
  * [ymu,ys2,fmu,fs2] = gplite_pred(gp, Xstar, [], s2star, ssflag)   (gplite/gplite_pred.m:1-165).
  * Xstar is Nstar x D.  ssflag = 0: outputs are Nstar vectors averaged over hyper-samples with
  * the between-sample variance added (:154-165); ssflag = 1: Nstar x S per-sample outputs.

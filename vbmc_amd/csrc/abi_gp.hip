@@ -3,6 +3,7 @@
 // loop (gplite_core.m:77-80,91-94), launches, D2H of the posterior.
 #include <algorithm>
 #include <cmath>
+#include <limits>
 
 #include "gp_kernels.h"
 
@@ -78,31 +79,47 @@ extern "C" vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const do
 }
 
 // ------------------------------------------------------------------------------------------
-extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
-                                    const double* X, const double* y, const double* s2, const double* hyp,
-                                    double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
-                                    vbmc_gp** gp_out) {
-  if (!ctx) return VBMC_ERR_INVALID;
-  if (gp_out) *gp_out = nullptr;
+// Shared by vbmc_gp_post and vbmc_gp_nlz: kernel matrices, jittered Cholesky and alpha for S hyper-parameter
+// vectors, left on the device (gplite_core.m:33-102).
+namespace {
+
+struct GpFactor {
+  int Ncov = 0, Nnoise = 0, Nmean = 0;
+  std::vector<double> sn2all, scal, sn2min;         // host copies: S x N noise, S x 4 {sn2div, mult, lchol, sl}
+  std::vector<unsigned char> lch, failed;           // Lchol flag; 1 = Cholesky still failing after 10 retries
+  bool any_inv = false;
+  size_t tlds = 0;
+  TmpBuf dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dones, dninv, dal, dfinv;
+};
+
+// fail_is_error: vbmc_gp_post refuses a matrix that is still not positive definite after the retries;
+// vbmc_gp_nlz marks that hyper-parameter vector as failed (NaN result, gplite_train.m:542-546) and goes on.
+vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
+                         const double* X, const double* y, const double* s2, const double* hyp, bool fail_is_error,
+                         GpFactor& f) {
   if (N <= 0 || D <= 0 || S <= 0 || !X || !y || !hyp || !noisefun)
-    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_post: bad arguments");
+    return set_err(ctx, VBMC_ERR_INVALID, "%s: bad arguments", who);
   if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
   if (!(meanfun == 0 || meanfun == 1 || meanfun == 4))
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "gplite mean function %d not accelerated (0,1,4 are)", meanfun);
   const int Ncov = D + 1, Nnoise = noise_nhyp(noisefun);
   const int Nmean = meanfun == 0 ? 0 : (meanfun == 1 ? 1 : 2 * D + 1);
+  f.Ncov = Ncov; f.Nnoise = Nnoise; f.Nmean = Nmean;
   if (Nhyp != Ncov + Nnoise + Nmean)
-    return set_err(ctx, VBMC_ERR_INVALID, "gplite_post:dimmismatch Number of hyperparameters mismatched with GP model specification.");
+    return set_err(ctx, VBMC_ERR_INVALID, "%s:dimmismatch Number of hyperparameters mismatched with GP model specification.",
+                   fail_is_error ? "gplite_post" : "gplite_nlZ");
   if ((size_t)(16 * 17 + 16 * (size_t)N) * 8 > 160 * 1024)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 1260 not accelerated", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
   // host: noise vectors, Lchol flags (gplite_core.m:33-40,67)
-  std::vector<double> sn2all((size_t)S * N), scal((size_t)S * 4), sn2min(S);
-  std::vector<unsigned char> lch(S), active(S, 1), ones(S, 1), needinv(S);
+  std::vector<double>&sn2all = f.sn2all, &scal = f.scal, &sn2min = f.sn2min;
+  sn2all.assign((size_t)S * N, 0.0); scal.assign((size_t)S * 4, 0.0); sn2min.assign(S, 0.0);
+  std::vector<unsigned char>& lch = f.lch;
+  lch.assign(S, 0); f.failed.assign(S, 0);
+  std::vector<unsigned char> active(S, 1), ones(S, 1), needinv(S);
   std::vector<double> tmp;
-  bool any_inv = false;
   for (int s = 0; s < S; ++s) {
     noise_vector(noisefun, hyp + (size_t)s * Nhyp + Ncov, N, y, s2, tmp);
     std::copy(tmp.begin(), tmp.end(), sn2all.begin() + (size_t)s * N);
@@ -110,13 +127,14 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
     sn2min[s] = mn;
     lch[s] = mn >= 1e-6 ? 1 : 0;
     needinv[s] = lch[s] ? 0 : 1;
-    any_inv |= !lch[s];
+    f.any_inv |= !lch[s];
     scal[s * 4 + 0] = lch[s] ? mn : 1.0;  // sn2div
     scal[s * 4 + 1] = 1.0;                // sn2_mult
     scal[s * 4 + 2] = lch[s];
     scal[s * 4 + 3] = 1.0;                // sl (set after the retry loop)
   }
-  TmpBuf dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dones, dZ, dXi, dninv;
+  TmpBuf &dX = f.dX, &dy = f.dy, &dhyp = f.dhyp, &dXc = f.dXc, &daa = f.daa, &dsn2 = f.dsn2, &dscal = f.dscal, &dact = f.dact,
+         &dA = f.dA, &dpf = f.dpf, &dr = f.dr, &dones = f.dones, &dninv = f.dninv;
   HIP_TRY(ctx, dX.alloc((size_t)N * D * 8));
   HIP_TRY(ctx, dy.alloc((size_t)N * 8));
   HIP_TRY(ctx, dhyp.alloc((size_t)Nhyp * S * 8));
@@ -162,7 +180,9 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   }
   if (pending) {
     // MATLAB leaves the loop with the last multiplier even when chol still fails; we refuse instead.
-    return set_err(ctx, VBMC_ERR_NOT_POSDEF, "gplite_core: Cholesky failed after 10 noise-inflation retries");
+    if (fail_is_error)
+      return set_err(ctx, VBMC_ERR_NOT_POSDEF, "gplite_core: Cholesky failed after 10 noise-inflation retries");
+    for (int s = 0; s < S; ++s) f.failed[s] = active[s];
   }
   for (int s = 0; s < S; ++s) scal[s * 4 + 3] = lch[s] ? scal[s * 4 + 0] * scal[s * 4 + 1] : 1.0;  // sl (:82,:96)
   HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
@@ -172,11 +192,12 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
                      dhyp.as<double>(), dr.as<double>());
   const size_t tlds = TRSM_LDS_BYTES(N);
+  f.tlds = tlds;
   if (tlds > 64 * 1024) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
   }
-  TmpBuf dal, dfinv;
+  TmpBuf &dal = f.dal, &dfinv = f.dfinv;
   HIP_TRY(ctx, dal.alloc((size_t)S * N * 8));
   HIP_TRY(ctx, dfinv.alloc((size_t)S * TRSM_NBLK(N) * 256 * 8));
   hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, st, N, dA.as<double>(), dones.as<unsigned char>(), dfinv.as<double>());
@@ -184,6 +205,26 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
   hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, st, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
   HIP_TRY(ctx, hipGetLastError());
+  return VBMC_OK;
+}
+
+}  // namespace
+
+extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
+                                    const double* X, const double* y, const double* s2, const double* hyp,
+                                    double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
+                                    vbmc_gp** gp_out) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (gp_out) *gp_out = nullptr;
+  GpFactor f;
+  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_post", N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, true, f); if (s_ != VBMC_OK) return s_; }
+  hipStream_t st = ctx->stream;
+  const int Ncov = f.Ncov, Nnoise = f.Nnoise;
+  const bool any_inv = f.any_inv;
+  const size_t tlds = f.tlds;
+  std::vector<double>&scal = f.scal, &sn2min = f.sn2min;
+  std::vector<unsigned char>& lch = f.lch;
+  TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dZ, dXi;
 
   std::vector<double> Lh;
   if (L || gp_out) Lh.resize((size_t)S * N * N);
@@ -229,6 +270,77 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
     st2 = vbmc_gp_set_noise(ctx, *gp_out, noisefun, mult.data());
     if (st2 != VBMC_OK) return st2;
   }
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+namespace {
+// gplite_noisefun.m:164-210, gradient part, on the host: dsn2 as Nnoise x N (constant models replicated over n)
+void noise_grad(const int32_t nf[3], const double* hn, int N, const double* y, const double* s2, int Nnoise, double* dsn2) {
+  std::fill(dsn2, dsn2 + (size_t)Nnoise * N, 0.0);
+  int idx = 0;
+  if (nf[0] == 1) { const double v = 2.0 * std::exp(2.0 * hn[idx]); for (int n = 0; n < N; ++n) dsn2[(size_t)idx * N + n] = v; idx++; }
+  if (nf[1] == 2) { const double c = std::exp(hn[idx]); for (int n = 0; n < N; ++n) dsn2[(size_t)idx * N + n] = s2 ? c * s2[n] : 0.0; idx++; }
+  if (nf[2] == 1 && y) {
+    const double ythr = hn[idx], w2 = std::exp(2.0 * hn[idx + 1]);
+    for (int n = 0; n < N; ++n) {
+      const double zz = std::max(0.0, ythr - y[n]);
+      dsn2[(size_t)idx * N + n] = zz > 0 ? 2.0 * w2 * (ythr - y[n]) : 0.0;
+      dsn2[(size_t)(idx + 1) * N + n] = 2.0 * w2 * zz * zz;
+    }
+  }
+}
+}  // namespace
+
+extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int meanfun, const int32_t noisefun[3],
+                                   const double* X, const double* y, const double* s2, const double* hyp, int compute_grad,
+                                   double* nlZ, double* dnlZ) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!nlZ || (compute_grad && !dnlZ)) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_nlz: null output");
+  if (noisefun && (noisefun[1] == 1 || noisefun[1] == 2) && !s2)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_nlz: noise model uses s2 but s2 is NULL");
+  GpFactor f;
+  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f); if (s_ != VBMC_OK) return s_; }
+  hipStream_t st = ctx->stream;
+  const int Nnoise = f.Nnoise, Nmean = f.Nmean, moff = f.Ncov + f.Nnoise;
+  TmpBuf dnlz, dZ, dKi, dds, dpart, dg;
+  HIP_TRY(ctx, dnlz.alloc((size_t)B * 8));
+  hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
+                     f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(nlZ, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+  if (compute_grad) {
+    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240), two MFMA triangular solves of the identity
+    HIP_TRY(ctx, dZ.alloc((size_t)B * N * N * 8));
+    HIP_TRY(ctx, dKi.alloc((size_t)B * N * N * 8));
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)B * N * N + 255) / 256)), dim3(256), 0, st, N, B, dZ.as<double>());
+    dim3 tg((N + TR_CB - 1) / TR_CB, B, 1);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), f.tlds, st, N, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dZ.as<double>());
+    hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), f.tlds, st, N, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dZ.as<double>(), dKi.as<double>());
+    std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
+    for (int b = 0; b < B; ++b)
+      noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);
+    HIP_TRY(ctx, dds.alloc(dsn2h.size() * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(dds.p, dsn2h.data(), dsn2h.size() * 8, hipMemcpyHostToDevice, st));
+    const int ntile = (N + NLZ_TJ - 1) / NLZ_TJ, P = D + 1 + Nnoise;
+    HIP_TRY(ctx, dpart.alloc((size_t)B * ntile * P * 8));
+    HIP_TRY(ctx, dg.alloc((size_t)B * Nhyp * 8));
+    hipLaunchKernelGGL(k_nlz_grad, dim3(ntile, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(), f.dXc.as<double>(),
+                       f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dds.as<double>(), dpart.as<double>());
+    hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
+                       f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(dnlZ, dg.p, (size_t)B * Nhyp * 8, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  // a matrix still not positive definite after the retries: MATLAB errors downstream and the caller maps it to NaN
+  // (gplite_train.m:542-546)
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  for (int b = 0; b < B; ++b)
+    if (f.failed[b]) {
+      nlZ[b] = qnan;
+      if (compute_grad) for (int i = 0; i < Nhyp; ++i) dnlZ[(size_t)b * Nhyp + i] = qnan;
+    }
   return VBMC_OK;
 }
 

@@ -442,3 +442,139 @@ __global__ void __launch_bounds__(256) k_gp_ks(int N, int D, int Nhyp, const dou
     Ks[(size_t)s * N + n] = sf2 * exp(-fmax(aa + (bb - 2.0 * dot), 0.0) / 2.0);
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// gplite_nlZ (gplite/private/gplite_core.m:128-275, covfun 1, no integrated mean / output warping)
+// ------------------------------------------------------------------------------------------
+// nlZ = (y-m)'*alpha/2 + sum(log(diag(L))) + N*log(2*pi*sl)/2   (:205).  One block per hyper-parameter vector.
+__global__ void __launch_bounds__(256) k_nlz_value(int N, int D, int Nhyp, int moff, int meanfun,
+                                                   const double* __restrict__ X, const double* __restrict__ y,
+                                                   const double* __restrict__ hyp, const double* __restrict__ A,
+                                                   const double* __restrict__ alpha, const double* __restrict__ scal,
+                                                   double* __restrict__ nlz) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double* hm = hyp + (size_t)b * Nhyp + moff;
+  const double* Ab = A + (size_t)b * N * N;
+  double quad = 0.0, ld = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    const double r = y[n] - gp_meanfun(meanfun, D, hm, X + n, (size_t)N);
+    quad = fma(r, alpha[(size_t)b * N + n], quad);
+    ld += log(Ab[(size_t)n * N + n]);
+  }
+  quad = block_sum(quad, red);
+  ld = block_sum(ld, red);
+  if (tid == 0) nlz[b] = quad / 2.0 + ld + N * log(2.0 * 3.14159265358979323846 * scal[b * 4 + 3]) / 2.0;
+}
+
+// Partial sums of the Q-contractions over one tile of NLZ_TJ rows j and all k:
+//   Q = Kinv/sl - alpha*alpha'                                  (:240, Kinv = L\(L'\eye(N)))
+//   part[d]  = sum Q .* K .* sq_dist(X(:,d)'/ell_d), d < D       (:244-247; the 1/2 is applied in k_nlz_final)
+//   part[D]  = sum Q .* K                                       (:248)
+//   part[D+1+i] = sum_j dsn2(j,i) Q_jj                          (:257-262)
+// K is rebuilt exactly as k_gp_build forms it.  Fixed-order block reduction, no atomics.
+#define NLZ_TJ 8
+#define NLZ_MAXP (32 + 1 + 4)
+__global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nnoise, const double* __restrict__ hyp,
+                                                  const double* __restrict__ Xc, const double* __restrict__ aa,
+                                                  const double* __restrict__ Kinv, const double* __restrict__ alpha,
+                                                  const double* __restrict__ scal, const double* __restrict__ dsn2,  // B x Nnoise x N
+                                                  double* __restrict__ part) {
+  __shared__ double red[256];
+  __shared__ double xj[NLZ_TJ][32];
+  const int jt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int jl = tid >> 5, kl = tid & 31;
+  const int j = jt * NLZ_TJ + jl;
+  const bool jv = j < N;
+  const double* h = hyp + (size_t)b * Nhyp;
+  const double sf2 = exp(2.0 * h[D]);
+  const double isl = 1.0 / scal[b * 4 + 3];
+  const double* xs = Xc + (size_t)b * N * D;
+  const double* as = aa + (size_t)b * N;
+  const double* Kb = Kinv + (size_t)b * N * N;
+  const double* al = alpha + (size_t)b * N;
+  if (kl < D) xj[jl][kl] = jv ? xs[(size_t)j * D + kl] : 0.0;
+  __syncthreads();
+  double acc[NLZ_MAXP];
+#pragma unroll
+  for (int p = 0; p < NLZ_MAXP; ++p) acc[p] = 0.0;
+  if (jv) {
+    const double aj = as[j], alj = al[j];
+    for (int k = kl; k < N; k += 32) {
+      double dot = 0.0;
+      for (int d = 0; d < D; ++d) dot = fma(xj[jl][d], xs[(size_t)k * D + d], dot);
+      const double c = fmax(aj + (as[k] - 2.0 * dot), 0.0);
+      const double kv = sf2 * exp(-c / 2.0);
+      const double q = Kb[(size_t)j * N + k] * isl - alj * al[k];    // Kinv is symmetric: column j read along k (coalesced)
+      const double qk = q * kv;
+#pragma unroll
+      for (int d = 0; d < 32; ++d) {
+        if (d < D) {
+          const double df = xj[jl][d] - xs[(size_t)k * D + d];
+          acc[d] = fma(qk, df * df, acc[d]);
+        }
+      }
+      acc[32] += qk;
+      if (k == j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < Nnoise) acc[33 + i] = dsn2[((size_t)b * Nnoise + i) * N + j] * q;
+      }
+    }
+  }
+  double* o = part + ((size_t)b * gridDim.x + jt) * (D + 1 + Nnoise);
+  for (int d = 0; d < D; ++d) {
+    double t = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) if (dd == d) t = acc[dd];
+    t = block_sum(t, red);
+    if (tid == 0) o[d] = t;
+  }
+  {
+    double t = block_sum(acc[32], red);
+    if (tid == 0) o[D] = t;
+  }
+  for (int i = 0; i < Nnoise; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) if (ii == i) t = acc[33 + ii];
+    t = block_sum(t, red);
+    if (tid == 0) o[D + 1 + i] = t;
+  }
+}
+
+// dnlZ from the tile partials (summed in tile order) + the mean-function block -dm'*alpha (:274,
+// gplite_meanfun.m:402,406,433-435).  One block per hyper-parameter vector.
+__global__ void __launch_bounds__(256) k_nlz_final(int N, int D, int Nhyp, int Nnoise, int Nmean, int meanfun, int ntile,
+                                                   const double* __restrict__ X, const double* __restrict__ hyp,
+                                                   const double* __restrict__ alpha, const double* __restrict__ scal,
+                                                   const double* __restrict__ part, double* __restrict__ dnlz) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int P = D + 1 + Nnoise;
+  const double mult = scal[b * 4 + 1];
+  double* g = dnlz + (size_t)b * Nhyp;
+  if (tid < P) {
+    double t = 0.0;
+    for (int jt = 0; jt < ntile; ++jt) t += part[((size_t)b * ntile + jt) * P + tid];
+    if (tid < D) g[tid] = t / 2.0;                 // sum(sum(Q.*K_temp))/2
+    else if (tid == D) g[D] = t;                   // sum(sum(Q.*(2*K_mat)))/2
+    else g[tid] = 0.5 * mult * t;                  // 0.5*sn2_mult*sum(dsn2(:,i).*dgQ)
+  }
+  const int moff = D + 1 + Nnoise;
+  const double* hm = hyp + (size_t)b * Nhyp + moff;
+  const double* al = alpha + (size_t)b * N;
+  for (int i = 0; i < Nmean; ++i) {
+    double t = 0.0;
+    for (int n = tid; n < N; n += 256) {
+      double dm;
+      if (i == 0) dm = 1.0;
+      else if (i <= D) { const int d = i - 1; const double om = exp(hm[D + 1 + d]); dm = (X[n + (size_t)N * d] - hm[1 + d]) / (om * om); }
+      else { const int d = i - 1 - D; const double z = (X[n + (size_t)N * d] - hm[1 + d]) / exp(hm[D + 1 + d]); dm = z * z; }
+      t = fma(dm, al[n], t);
+    }
+    t = block_sum(t, red);
+    if (tid == 0) g[moff + i] = -t;
+  }
+  (void)meanfun;
+}

@@ -2,7 +2,8 @@
 
 ``gplite_post(hyp, X, y, covfun, meanfun, noisefun, s2)`` (gplite/gplite_post.m:1),
 ``gplite_pred(gp, Xstar, ystar, s2star, ssflag)`` (gplite/gplite_pred.m:1) and
-``sq_dist(a, b)`` (utils/sq_dist.m:14) keep the reference's positional arguments.  ``gp`` is a
+``gplite_nlZ(hyp, gp, hprior)`` (gplite/gplite_nlZ.m:1), ``gplite_hypprior(hyp, hprior)``
+(gplite/gplite_hypprior.m:1) and ``sq_dist(a, b)`` (utils/sq_dist.m:14) keep the reference's positional arguments.  ``gp`` is a
 dict with the reference's field names; its ``post`` list holds the per-hyper-sample
 {hyp, alpha, sW, L, sn2_mult, Lchol} exactly like ``gp.post(s)``.
 """
@@ -173,3 +174,77 @@ def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, engine=None):
     out["X"] = np.vstack([gp["X"], xstar])
     out["y"] = np.concatenate([gp["y"], [ystar]])
     return out
+
+
+def gplite_hypprior(hyp, hprior, nargout=2):
+    """[lp,dlp] = gplite_hypprior(hyp,hprior)  (gplite/gplite_hypprior.m:17-65): independent flat / Gaussian /
+    Student-t log-priors per hyper-parameter.  O(Nhyp) host arithmetic, no device work."""
+    from math import lgamma, pi
+
+    hyp = np.asarray(hyp, dtype=np.float64)
+    if hyp.ndim == 2 and hyp.shape[1] > 1:
+        raise ValueError("gplite_hypprior:nosampling Hyperparameter log priors are available only for one-sample hyperparameter inputs.")
+    hyp = hyp.reshape(-1)
+    n = hyp.size
+    mu = np.asarray(hprior["mu"], dtype=np.float64).reshape(-1)
+    sigma = np.abs(np.asarray(hprior["sigma"], dtype=np.float64).reshape(-1))
+    df = hprior.get("df")
+    df = np.full(n, 7.0) if df is None or np.size(df) == 0 else np.asarray(df, dtype=np.float64).reshape(-1)
+    flat = ~np.isfinite(mu) | ~np.isfinite(sigma)
+    gauss = ~flat & ((df == 0) | ~np.isfinite(df)) & np.isfinite(sigma)
+    stud = ~flat & (df > 0) & np.isfinite(df)
+    dev = np.zeros(n)
+    sel = gauss | stud
+    dev[sel] = (hyp[sel] - mu[sel]) / sigma[sel]
+    z2 = dev * dev
+    lp = -0.5 * float(np.sum(np.log(2 * pi * sigma[gauss] ** 2) + z2[gauss]))
+    dlp = np.zeros(n)
+    dlp[gauss] = -dev[gauss] / sigma[gauss]
+    if np.any(stud):
+        nu = df[stud]
+        const = np.array([lgamma(0.5 * (v + 1)) - lgamma(0.5 * v) for v in nu]) - 0.5 * np.log(pi * nu) - np.log(sigma[stud])
+        lp += float(np.sum(const - 0.5 * (nu + 1) * np.log1p(z2[stud] / nu)))
+        dlp[stud] = -(nu + 1) / nu / (1 + z2[stud] / nu) * dev[stud] / sigma[stud]
+    return (lp, dlp) if nargout > 1 else lp
+
+
+def gplite_nlZ(hyp, gp, hprior=None, nargout=2, *, engine=None):
+    """[nlZ,dnlZ] = gplite_nlZ(hyp,gp,hprior)  (gplite/gplite_nlZ.m:1-72).
+
+    ``hyp`` Nhyp (or Nhyp x 1) follows the reference: scalar nlZ and an Nhyp gradient.  Beyond the reference,
+    ``hyp`` Nhyp x B with B > 1 evaluates all B vectors (the walkers / restarts of gplite_train.m:181,251,292)
+    in ONE batched device pass and returns nlZ (B) and dnlZ (Nhyp x B); the reference raises
+    gplite_nlZ:NoSampling for that form when a gradient is requested (:41-44).
+    """
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    X = f64(gp["X"])
+    N, D = X.shape
+    y = f64(np.asarray(gp["y"], dtype=np.float64).reshape(-1))
+    s2 = gp.get("s2")
+    s2 = None if s2 is None or np.size(s2) == 0 else f64(np.asarray(s2, dtype=np.float64).reshape(-1))
+    H = np.asarray(hyp, dtype=np.float64)
+    single = H.ndim == 1 or H.shape[1] == 1
+    H = f64(H.reshape(H.shape[0], -1))
+    Nhyp, B = H.shape
+    noisefun = tuple(gp["noisefun"])
+    if Nhyp != gp["Ncov"] + gp["Nnoise"] + gp["Nmean"]:
+        raise ValueError("gplite_nlZ:dimmismatch Number of hyperparameters mismatched with dimension of training inputs.")
+    if gp.get("intmeanfun", 0) or gp.get("outwarpfun") is not None or int(np.atleast_1d(gp.get("covfun", 1))[0]) != 1:
+        from ._lib import VbmcUnsupported
+        raise VbmcUnsupported("gplite_nlZ: integrated mean / output warping / non-SE covariance are not accelerated")
+    nf = (C.c_int32 * 3)(*[int(v) for v in (list(noisefun) + [0, 0, 0])[:3]])
+    grad = nargout > 1
+    nlZ = np.zeros(B)
+    dnlZ = np.zeros((Nhyp, B), order="F") if grad else None
+    ctx.check(ctx.lib.vbmc_gp_nlz(ctx.h, N, D, B, Nhyp, int(gp["meanfun"]), nf, ptr(X), ptr(y), ptr(s2), ptr(H), int(grad),
+                                  ptr(nlZ), ptr(dnlZ)))
+    if hprior is not None:
+        for b in range(B):
+            P, dP = gplite_hypprior(H[:, b], hprior)
+            nlZ[b] -= P
+            if grad:
+                dnlZ[:, b] -= dP
+    if single:
+        return (float(nlZ[0]), dnlZ[:, 0].copy()) if grad else float(nlZ[0])
+    return (nlZ, dnlZ) if grad else nlZ
