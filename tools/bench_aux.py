@@ -1,4 +1,5 @@
-"""Timing of the non-headline device paths at the C3 shape: gplite_post, gplite_pred (2^13 points), full-variance ELCBO."""
+"""Timing of the non-headline device paths at the C3 shape: gplite_post, gplite_pred (2^13 points), full-variance ELCBO,
+gplite_nlZ + gradient batched over hyper-parameter vectors (with the NumPy/LAPACK oracle timed beside it)."""
 import json
 import sys
 import time
@@ -33,4 +34,33 @@ theta = np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]), 
 out["eval_fullelcbo_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta, 0, vp, gp, 4096, 0, 1, nargout=11, engine=eng), 5)
 out["diagvar_grad_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta, 1.0, vp, gp, 128, 1, 2, nargout=2, engine=eng), 5)
 out["entlb_sieve_R250_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)
+# GP hyper-parameter objective: B walkers, value + gradient
+gpd = {"X": inp["X"], "y": inp["y"], "s2": None, "covfun": 1, "Ncov": D + 1, "noisefun": (1, 0, 0), "Nnoise": 1, "meanfun": 4,
+       "Nmean": 2 * D + 1, "intmeanfun": 0}
+for B in (1, 16, 64, 256):
+    H = np.tile(inp["hyp"], (1, (B + S - 1) // S))[:, :B] + 0.01 * np.random.default_rng(1).standard_normal((inp["hyp"].shape[0], B))
+    ms = 1e3 * timeit(lambda: vbmc_amd.gplite_nlZ(H, gpd, engine=eng), 3)
+    out["nlz_grad_B%d_ms" % B] = ms
+    out["nlz_grad_B%d_evals_per_s" % B] = B / (ms * 1e-3)
+    msv = 1e3 * timeit(lambda: vbmc_amd.gplite_nlZ(H, gpd, nargout=1, engine=eng), 3)
+    out["nlz_value_B%d_evals_per_s" % B] = B / (msv * 1e-3)
+try:
+    from oracle import vbmc_ref as R   # CPU baseline: NumPy restatement (LAPACK-backed chol is not used there: pure loops)
+    import scipy.linalg as sla
+
+    def cpu_nlz(h):                     # LAPACK-backed equivalent of gplite_core.m:52-102,205,240-274 for a fair CPU number
+        ell = np.exp(h[:D]); sf2 = np.exp(2 * h[D]); sn2 = np.exp(2 * h[D + 1])
+        Xs_ = inp["X"] / ell
+        d2 = np.maximum(np.sum(Xs_**2, 1)[:, None] + np.sum(Xs_**2, 1)[None, :] - 2 * Xs_ @ Xs_.T, 0)
+        Km = sf2 * np.exp(-d2 / 2)
+        Lc = sla.cholesky(Km / sn2 + np.eye(N))
+        m = R.gplite_meanfun(h[D + 2:], inp["X"], 4)
+        al = sla.cho_solve((Lc, False), inp["y"] - m) / sn2
+        Q = sla.cho_solve((Lc, False), np.eye(N)) / sn2 - np.outer(al, al)
+        g = [np.sum(Q * Km * (Xs_[:, i][:, None] - Xs_[:, i][None, :]) ** 2) / 2 for i in range(D)]
+        return (inp["y"] - m) @ al / 2 + np.sum(np.log(np.diag(Lc))), g, np.sum(Q * Km), np.trace(Q)
+    t = timeit(lambda: cpu_nlz(inp["hyp"][:, 0]), 5)
+    out["nlz_grad_cpu_lapack_evals_per_s"] = 1.0 / t
+except Exception as e:  # noqa: BLE001
+    out["nlz_cpu_error"] = repr(e)
 print(json.dumps(out))

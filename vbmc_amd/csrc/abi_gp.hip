@@ -108,7 +108,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   if (Nhyp != Ncov + Nnoise + Nmean)
     return set_err(ctx, VBMC_ERR_INVALID, "%s:dimmismatch Number of hyperparameters mismatched with GP model specification.",
                    fail_is_error ? "gplite_post" : "gplite_nlZ");
-  if ((size_t)(16 * 17 + 16 * (size_t)N) * 8 > 160 * 1024)
+  if (CHOL_LDS_BYTES(N) > 160 * 1024)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 1260 not accelerated", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -157,7 +157,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>());
 
   // jittered Cholesky: up to 10 tries, noise multiplier x10 per failure (gplite_core.m:77-80,91-94)
-  const size_t chol_lds = (size_t)(16 * 17 + 16 * (size_t)N) * 8;
+  const size_t chol_lds = CHOL_LDS_BYTES(N);
   if (chol_lds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
   std::vector<int> pf(S);
@@ -167,7 +167,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     HIP_TRY(ctx, hipMemcpyAsync(dact.p, active.data(), S, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gp_build, dim3(64, S), dim3(256), 0, st, N, D, Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
                        dsn2.as<double>(), dscal.as<double>(), dact.as<unsigned char>(), dA.as<double>());
-    hipLaunchKernelGGL(k_chol, dim3(S), dim3(256), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>());
+    hipLaunchKernelGGL(k_chol, dim3(S), dim3(CH_THREADS), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(pf.data(), dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

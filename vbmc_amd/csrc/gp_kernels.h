@@ -140,93 +140,107 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
 // ------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, upper factor R (R'R = A) in place, strict lower part zeroed.
 // pfail[s] = 0 on success, j+1 when the j-th pivot is not positive (MATLAB's [R,p] = chol(A)).
+// One 1024-thread workgroup (16 waves) per matrix; per 16-column block step:
+//   wave 0     factors the 16 x 16 diagonal tile in LDS (wave-synchronous, no workgroup barriers),
+//   all lanes  solve the 16 x ntr panel row (one column per lane) and stage it in LDS,
+//   16 waves   apply the rank-16 trailing update A22 -= P'P tile by tile on the fp64 matrix cores
+//              (4 x v_mfma_f64_16x16x4 per 16 x 16 tile, upper triangle of tiles only).
 // ------------------------------------------------------------------------------------------
 #define CH_NB 16
-__global__ void __launch_bounds__(256) k_chol(int N, double* __restrict__ Aall, int* __restrict__ pfail,
-                                              const unsigned char* __restrict__ active) {
+#define CH_THREADS 1024
+#define CHOL_LDS_BYTES(N) ((size_t)(16 * 17 + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
+__global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__ Aall, int* __restrict__ pfail,
+                                                     const unsigned char* __restrict__ active) {
   extern __shared__ double lds[];
   const int s = blockIdx.x;
   if (!active[s]) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const int Np = ((N + 15) >> 4) << 4;
   double* A = Aall + (size_t)s * N * N;
   double* Dg = lds;                 // 16 x 17
-  double* P = Dg + 16 * 17;         // 16 x N  panel rows R[kb+t][*]
+  double* P = Dg + 16 * 17;         // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
   __shared__ int s_fail;
   if (tid == 0) s_fail = 0;
   __syncthreads();
-  const int ii = tid >> 4, jj = tid & 15;
   for (int kb = 0; kb < N; kb += CH_NB) {
     const int nb = min(CH_NB, N - kb);
-    Dg[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] : 0.0;
-    __syncthreads();
-    for (int t = 0; t < nb; ++t) {
-      if (tid == 0) {
-        double piv = Dg[t * 17 + t];
-        if (!(piv > 0.0) || !isfinite(piv)) { if (s_fail == 0) s_fail = kb + t + 1; Dg[t * 17 + t] = 1.0; }
-        else Dg[t * 17 + t] = sqrt(piv);
+    if (wave == 0) {
+      // ---- diagonal tile: upper Cholesky in LDS by one wave (LDS operations of a wave complete in order)
+      for (int e = lane; e < 256; e += 64) {
+        const int ii = e >> 4, jj = e & 15;
+        Dg[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] : (ii == jj ? 1.0 : 0.0);
       }
-      __syncthreads();
-      if (ii == t && jj > t && jj < nb) Dg[t * 17 + jj] /= Dg[t * 17 + t];
-      __syncthreads();
-      if (ii > t && jj >= ii && jj < nb) Dg[ii * 17 + jj] -= Dg[t * 17 + ii] * Dg[t * 17 + jj];
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < nb; ++t) {
+        double piv = Dg[t * 17 + t];
+        if (!(piv > 0.0) || !isfinite(piv)) {
+          if (lane == 0 && s_fail == 0) s_fail = kb + t + 1;
+          piv = 1.0;
+        }
+        const double rs = sqrt(piv);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == t) Dg[t * 17 + t] = rs;
+        else if (lane > t && lane < nb) Dg[t * 17 + lane] /= rs;
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < 256; e += 64) {
+          const int ii = e >> 4, jj = e & 15;
+          if (ii > t && jj >= ii && jj < nb) Dg[ii * 17 + jj] -= Dg[t * 17 + ii] * Dg[t * 17 + jj];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      for (int e = lane; e < 256; e += 64) {
+        const int ii = e >> 4, jj = e & 15;
+        if (ii < nb && jj < nb) A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] = (ii <= jj) ? Dg[ii * 17 + jj] : 0.0;
+      }
     }
-    if (s_fail) break;  // uniform: s_fail read after a barrier
-    if (ii < nb && jj < nb) A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] = (ii <= jj) ? Dg[ii * 17 + jj] : 0.0;
+    __syncthreads();
+    if (s_fail) break;            // uniform: read after the barrier
     const int t0 = kb + nb;       // first trailing column
     const int ntr = N - t0;
-    // panel: R[kb..kb+nb, j] = Rkk'^{-1} A[kb..kb+nb, j]
-    for (int j = tid; j < ntr; j += 256) {
+    const int ntrp = ((ntr + 15) >> 4) << 4;
+    // ---- panel: R[kb..kb+nb, j] = Rkk'^{-1} A[kb..kb+nb, j], one column per lane; rows >= nb and columns >= ntr are zero
+    for (int j = tid; j < ntrp; j += CH_THREADS) {
       double r[CH_NB];
 #pragma unroll
       for (int t = 0; t < CH_NB; ++t) {
-        if (t < nb) {
+        if (t < nb && j < ntr) {
           double v = A[(size_t)(kb + t) + (size_t)N * (t0 + j)];
           for (int u = 0; u < t; ++u) v = fma(-Dg[u * 17 + t], r[u], v);
           r[t] = v / Dg[t * 17 + t];
           A[(size_t)(kb + t) + (size_t)N * (t0 + j)] = r[t];
-          P[(size_t)t * ntr + j] = r[t];
         } else r[t] = 0.0;
+        P[(size_t)t * Np + j] = r[t];
       }
     }
     __syncthreads();
-    // trailing update A[i][j] -= sum_t P[t][i] P[t][j]  for i <= j, 4 x 4 register tiles
-    const int ntile = (ntr + 3) / 4;
-    for (int tl = tid; tl < ntile * ntile; tl += 256) {
-      const int ti = tl % ntile, tj = tl / ntile;
+    // ---- trailing update, transposed tiles so that lanes run along i (contiguous in the column-major matrix):
+    //      C'[j][i] = sum_t P[t][j0+j] P[t][i0+i];  A[t0+i0+i][t0+j0+j] -= C'[j][i]  for i <= j
+    const int nt = ntrp >> 4;
+    for (int tl = wave; tl < nt * nt; tl += CH_THREADS / 64) {
+      const int ti = tl % nt, tj = tl / nt;
       if (ti > tj) continue;
-      const int i0 = ti * 4, j0 = tj * 4;
-      double c[4][4];
+      const int i0 = ti << 4, j0 = tj << 4;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
-      for (int t = 0; t < nb; ++t) {
-        double pi[4], pj[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          pi[x] = (i0 + x < ntr) ? P[(size_t)t * ntr + i0 + x] : 0.0;
-          pj[x] = (j0 + x < ntr) ? P[(size_t)t * ntr + j0 + x] : 0.0;
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 4; ++y) c[x][y] = fma(pi[x], pj[y], c[x][y]);
+      for (int q = 0; q < 4; ++q) {
+        const double pa = P[(size_t)(4 * q + lg) * Np + j0 + li];
+        const double pb = P[(size_t)(4 * q + lg) * Np + i0 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
       }
+      const int i = i0 + li;
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int i = i0 + x, j = j0 + y;
-          if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] -= c[x][y];
-        }
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = j0 + lg + 4 * reg;
+        if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] -= acc[reg];
+      }
     }
     __syncthreads();
   }
   if (tid == 0) pfail[s] = s_fail;
   if (s_fail) return;
   // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
-  for (size_t idx = tid; idx < (size_t)N * N; idx += 256) {
+  for (size_t idx = tid; idx < (size_t)N * N; idx += CH_THREADS) {
     int i = (int)(idx % N), j = (int)(idx / N);
     if (i > j) A[idx] = 0.0;
   }
