@@ -44,6 +44,8 @@ extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
                     &ctx->eps, &ctx->bnd, &ctx->vpfix, &ctx->misc, &ctx->varbuf, &ctx->zbuf};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (auto& b : ctx->pool)
+    if (b.p) (void)hipFree(b.p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);

@@ -9,10 +9,11 @@
 
 namespace {
 
-struct TmpBuf {
+struct TmpBuf {   // a pooled device block (common.h pool_get/pool_put), returned to the context's pool on scope exit
   void* p = nullptr;
-  ~TmpBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  vbmc_ctx* owner = nullptr;
+  ~TmpBuf() { if (p) pool_put(owner, p); }
+  hipError_t alloc(vbmc_ctx* ctx, size_t bytes) { owner = ctx; return pool_get(ctx, bytes, &p); }
   template <typename T> T* as() { return (T*)p; }
 };
 
@@ -58,14 +59,14 @@ extern "C" vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const do
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   TmpBuf da, db, dmu, dC;
-  HIP_TRY(ctx, da.alloc((size_t)D * n * 8));
-  HIP_TRY(ctx, dmu.alloc((size_t)D * 8));
-  HIP_TRY(ctx, dC.alloc((size_t)n * m * 8));
+  HIP_TRY(ctx, da.alloc(ctx, (size_t)D * n * 8));
+  HIP_TRY(ctx, dmu.alloc(ctx, (size_t)D * 8));
+  HIP_TRY(ctx, dC.alloc(ctx, (size_t)n * m * 8));
   hipStream_t st = ctx->stream;
   HIP_TRY(ctx, hipMemcpyAsync(da.p, a, (size_t)D * n * 8, hipMemcpyHostToDevice, st));
   const double* dbp = da.as<double>();
   if (!self) {
-    HIP_TRY(ctx, db.alloc((size_t)D * m * 8));
+    HIP_TRY(ctx, db.alloc(ctx, (size_t)D * m * 8));
     HIP_TRY(ctx, hipMemcpyAsync(db.p, b, (size_t)D * m * 8, hipMemcpyHostToDevice, st));
     dbp = db.as<double>();
   }
@@ -135,19 +136,19 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   }
   TmpBuf &dX = f.dX, &dy = f.dy, &dhyp = f.dhyp, &dXc = f.dXc, &daa = f.daa, &dsn2 = f.dsn2, &dscal = f.dscal, &dact = f.dact,
          &dA = f.dA, &dpf = f.dpf, &dr = f.dr, &dones = f.dones, &dninv = f.dninv;
-  HIP_TRY(ctx, dX.alloc((size_t)N * D * 8));
-  HIP_TRY(ctx, dy.alloc((size_t)N * 8));
-  HIP_TRY(ctx, dhyp.alloc((size_t)Nhyp * S * 8));
-  HIP_TRY(ctx, dXc.alloc((size_t)S * N * D * 8));
-  HIP_TRY(ctx, daa.alloc((size_t)S * N * 8));
-  HIP_TRY(ctx, dsn2.alloc((size_t)S * N * 8));
-  HIP_TRY(ctx, dscal.alloc((size_t)S * 4 * 8));
-  HIP_TRY(ctx, dact.alloc(S));
-  HIP_TRY(ctx, dones.alloc(S));
-  HIP_TRY(ctx, dninv.alloc(S));
-  HIP_TRY(ctx, dA.alloc((size_t)S * N * N * 8));
-  HIP_TRY(ctx, dpf.alloc((size_t)S * sizeof(int)));
-  HIP_TRY(ctx, dr.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dX.alloc(ctx, (size_t)N * D * 8));
+  HIP_TRY(ctx, dy.alloc(ctx, (size_t)N * 8));
+  HIP_TRY(ctx, dhyp.alloc(ctx, (size_t)Nhyp * S * 8));
+  HIP_TRY(ctx, dXc.alloc(ctx, (size_t)S * N * D * 8));
+  HIP_TRY(ctx, daa.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dsn2.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dscal.alloc(ctx, (size_t)S * 4 * 8));
+  HIP_TRY(ctx, dact.alloc(ctx, S));
+  HIP_TRY(ctx, dones.alloc(ctx, S));
+  HIP_TRY(ctx, dninv.alloc(ctx, S));
+  HIP_TRY(ctx, dA.alloc(ctx, (size_t)S * N * N * 8));
+  HIP_TRY(ctx, dpf.alloc(ctx, (size_t)S * sizeof(int)));
+  HIP_TRY(ctx, dr.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, hipMemcpyAsync(dX.p, X, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dy.p, y, (size_t)N * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dhyp.p, hyp, (size_t)Nhyp * S * 8, hipMemcpyHostToDevice, st));
@@ -198,8 +199,8 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
   }
   TmpBuf &dal = f.dal, &dfinv = f.dfinv;
-  HIP_TRY(ctx, dal.alloc((size_t)S * N * 8));
-  HIP_TRY(ctx, dfinv.alloc((size_t)S * TRSM_NBLK(N) * 256 * 8));
+  HIP_TRY(ctx, dal.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
   hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, st, N, dA.as<double>(), dones.as<unsigned char>(), dfinv.as<double>());
   hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>());
   hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
@@ -233,8 +234,8 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   if (!Lh.empty()) {
     if (any_inv) {
       // pL = -L\(L'\eye(N)) for low-noise samples (:98)
-      HIP_TRY(ctx, dZ.alloc((size_t)S * N * N * 8));
-      HIP_TRY(ctx, dXi.alloc((size_t)S * N * N * 8));
+      HIP_TRY(ctx, dZ.alloc(ctx, (size_t)S * N * N * 8));
+      HIP_TRY(ctx, dXi.alloc(ctx, (size_t)S * N * N * 8));
       hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, dZ.as<double>());
       dim3 tg((N + TR_CB - 1) / TR_CB, S, 1);
       hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
@@ -304,15 +305,15 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
   hipStream_t st = ctx->stream;
   const int Nnoise = f.Nnoise, Nmean = f.Nmean, moff = f.Ncov + f.Nnoise;
   TmpBuf dnlz, dZ, dKi, dds, dpart, dg;
-  HIP_TRY(ctx, dnlz.alloc((size_t)B * 8));
+  HIP_TRY(ctx, dnlz.alloc(ctx, (size_t)B * 8));
   hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
                      f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(nlZ, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
   if (compute_grad) {
     // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240), two MFMA triangular solves of the identity
-    HIP_TRY(ctx, dZ.alloc((size_t)B * N * N * 8));
-    HIP_TRY(ctx, dKi.alloc((size_t)B * N * N * 8));
+    HIP_TRY(ctx, dZ.alloc(ctx, (size_t)B * N * N * 8));
+    HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
     hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)B * N * N + 255) / 256)), dim3(256), 0, st, N, B, dZ.as<double>());
     dim3 tg((N + TR_CB - 1) / TR_CB, B, 1);
     hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), f.tlds, st, N, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dZ.as<double>());
@@ -320,11 +321,11 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
     std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
     for (int b = 0; b < B; ++b)
       noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);
-    HIP_TRY(ctx, dds.alloc(dsn2h.size() * 8));
+    HIP_TRY(ctx, dds.alloc(ctx, dsn2h.size() * 8));
     HIP_TRY(ctx, hipMemcpyAsync(dds.p, dsn2h.data(), dsn2h.size() * 8, hipMemcpyHostToDevice, st));
     const int ntile = (N + NLZ_TJ - 1) / NLZ_TJ, P = D + 1 + Nnoise;
-    HIP_TRY(ctx, dpart.alloc((size_t)B * ntile * P * 8));
-    HIP_TRY(ctx, dg.alloc((size_t)B * Nhyp * 8));
+    HIP_TRY(ctx, dpart.alloc(ctx, (size_t)B * ntile * P * 8));
+    HIP_TRY(ctx, dg.alloc(ctx, (size_t)B * Nhyp * 8));
     hipLaunchKernelGGL(k_nlz_grad, dim3(ntile, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(), f.dXc.as<double>(),
                        f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dds.as<double>(), dpart.as<double>());
     hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
@@ -377,16 +378,16 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
     mb[d] = sb / Nstar;
   }
   TmpBuf dXs, ds2, dmb, dout, davg, dXc, daa, dmuv;
-  HIP_TRY(ctx, dXc.alloc((size_t)S * N * D * 8));
-  HIP_TRY(ctx, daa.alloc((size_t)S * N * 8));
-  HIP_TRY(ctx, dmuv.alloc((size_t)S * 2 * D * 8));
-  HIP_TRY(ctx, dXs.alloc((size_t)Nstar * D * 8));
-  HIP_TRY(ctx, dmb.alloc((size_t)D * 8));
-  HIP_TRY(ctx, dout.alloc((size_t)3 * Nstar * S * 8));
+  HIP_TRY(ctx, dXc.alloc(ctx, (size_t)S * N * D * 8));
+  HIP_TRY(ctx, daa.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dmuv.alloc(ctx, (size_t)S * 2 * D * 8));
+  HIP_TRY(ctx, dXs.alloc(ctx, (size_t)Nstar * D * 8));
+  HIP_TRY(ctx, dmb.alloc(ctx, (size_t)D * 8));
+  HIP_TRY(ctx, dout.alloc(ctx, (size_t)3 * Nstar * S * 8));
   HIP_TRY(ctx, hipMemcpyAsync(dXs.p, Xstar, (size_t)Nstar * D * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dmb.p, mb.data(), (size_t)D * 8, hipMemcpyHostToDevice, st));
   if (s2star) {
-    HIP_TRY(ctx, ds2.alloc((size_t)Nstar * 8));
+    HIP_TRY(ctx, ds2.alloc(ctx, (size_t)Nstar * 8));
     HIP_TRY(ctx, hipMemcpyAsync(ds2.p, s2star, (size_t)Nstar * 8, hipMemcpyHostToDevice, st));
   }
   PredArgs pa{};
@@ -403,7 +404,7 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
   HIP_TRY(ctx, hipGetLastError());
   const size_t ns = (size_t)Nstar * S;
   if (S > 1 && !ssflag) {
-    HIP_TRY(ctx, davg.alloc((size_t)4 * Nstar * 8));
+    HIP_TRY(ctx, davg.alloc(ctx, (size_t)4 * Nstar * 8));
     hipLaunchKernelGGL(k_pred_avg, dim3((Nstar + 255) / 256), dim3(256), 0, st, Nstar, S, pa.fmu, pa.fs2, pa.ys2, davg.as<double>());
     std::vector<double> h((size_t)4 * Nstar);
     HIP_TRY(ctx, hipMemcpyAsync(h.data(), davg.p, h.size() * 8, hipMemcpyDeviceToHost, st));
@@ -440,10 +441,10 @@ extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, co
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   TmpBuf dxs, dKs, dV, dXo;
-  HIP_TRY(ctx, dxs.alloc((size_t)D * 8));
-  HIP_TRY(ctx, dKs.alloc((size_t)S * N * 8));
-  HIP_TRY(ctx, dV.alloc((size_t)S * N * 8));
-  HIP_TRY(ctx, dXo.alloc((size_t)S * N * 8));
+  HIP_TRY(ctx, dxs.alloc(ctx, (size_t)D * 8));
+  HIP_TRY(ctx, dKs.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dV.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dXo.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, hipMemcpyAsync(dxs.p, xstar, (size_t)D * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_gp_ks, dim3(4, S), dim3(256), 0, st, N, D, gp->Nhyp, gp->X, dxs.as<double>(), gp->hyp, gp->d_meanX, dKs.as<double>());
   HIP_TRY(ctx, hipMemcpyAsync(dV.p, dKs.p, (size_t)S * N * 8, hipMemcpyDeviceToDevice, st));

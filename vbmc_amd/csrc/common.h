@@ -15,6 +15,15 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// Pool of device blocks for the per-call temporaries of the GP entry points (abi_gp.hip): hipMalloc/hipFree
+// cost ~0.1 ms each and synchronise the device, which dominated small calls.  Blocks are handed out only
+// between a call's start and its final stream synchronisation, so reuse across calls is safe.
+struct PoolBlk {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool busy = false;
+};
+
 struct vbmc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -30,7 +39,46 @@ struct vbmc_ctx {
   bool profiling = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double last_ent_ms = 0.0, last_lj_ms = 0.0;
+  std::vector<PoolBlk> pool;
+  size_t pool_bytes = 0;
 };
+
+static inline hipError_t pool_get(vbmc_ctx* ctx, size_t bytes, void** out) {
+  if (bytes < 256) bytes = 256;
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+    const PoolBlk& b = ctx->pool[i];
+    if (b.busy || b.cap < bytes || b.cap > 4 * bytes + (1u << 20)) continue;
+    if (best < 0 || b.cap < ctx->pool[best].cap) best = i;
+  }
+  if (best >= 0) { ctx->pool[best].busy = true; *out = ctx->pool[best].p; return hipSuccess; }
+  // keep the cache bounded: drop idle blocks (largest first) once more than 16 GiB are held
+  const size_t limit = (size_t)16 << 30;
+  while (ctx->pool_bytes + bytes > limit) {
+    int big = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i)
+      if (!ctx->pool[i].busy && (big < 0 || ctx->pool[i].cap > ctx->pool[big].cap)) big = i;
+    if (big < 0) break;
+    (void)hipFree(ctx->pool[big].p);
+    ctx->pool_bytes -= ctx->pool[big].cap;
+    ctx->pool.erase(ctx->pool.begin() + big);
+  }
+  const size_t want = bytes + bytes / 8;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) return e;
+  PoolBlk b;
+  b.p = p; b.cap = want; b.busy = true;
+  ctx->pool.push_back(b);
+  ctx->pool_bytes += want;
+  *out = p;
+  return hipSuccess;
+}
+
+static inline void pool_put(vbmc_ctx* ctx, void* p) {
+  for (auto& b : ctx->pool)
+    if (b.p == p) { b.busy = false; return; }
+}
 
 struct vbmc_gp {
   int N = 0, D = 0, S = 0, Nhyp = 0, Ncov = 0, Nnoise = 0, meanfun = 0;

@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
   double* Dg = lds;                 // 16 x 17
   double* P = Dg + 16 * 17;         // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
   __shared__ int s_fail;
+  __shared__ double Di[16];         // 1 / R[kb+t][kb+t]
   if (tid == 0) s_fail = 0;
   __syncthreads();
   for (int kb = 0; kb < N; kb += CH_NB) {
@@ -179,9 +180,10 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
           piv = 1.0;
         }
         const double rs = sqrt(piv);
+        const double ri = 1.0 / rs;                    // row scaled by the reciprocal, as LAPACK's dpotf2 does
         __builtin_amdgcn_wave_barrier();
-        if (lane == t) Dg[t * 17 + t] = rs;
-        else if (lane > t && lane < nb) Dg[t * 17 + lane] /= rs;
+        if (lane == t) { Dg[t * 17 + t] = rs; Di[t] = ri; }
+        else if (lane > t && lane < nb) Dg[t * 17 + lane] *= ri;
         __builtin_amdgcn_wave_barrier();
         for (int e = lane; e < 256; e += 64) {
           const int ii = e >> 4, jj = e & 15;
@@ -202,24 +204,57 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
     // ---- panel: R[kb..kb+nb, j] = Rkk'^{-1} A[kb..kb+nb, j], one column per lane; rows >= nb and columns >= ntr are zero
     for (int j = tid; j < ntrp; j += CH_THREADS) {
       double r[CH_NB];
+      if (j < ntr) {
+        const double* col = A + (size_t)kb + (size_t)N * (t0 + j);
 #pragma unroll
-      for (int t = 0; t < CH_NB; ++t) {
-        if (t < nb && j < ntr) {
-          double v = A[(size_t)(kb + t) + (size_t)N * (t0 + j)];
-          for (int u = 0; u < t; ++u) v = fma(-Dg[u * 17 + t], r[u], v);
-          r[t] = v / Dg[t * 17 + t];
-          A[(size_t)(kb + t) + (size_t)N * (t0 + j)] = r[t];
-        } else r[t] = 0.0;
-        P[(size_t)t * Np + j] = r[t];
+        for (int t = 0; t < CH_NB; ++t) r[t] = (t < nb) ? col[t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < CH_NB; ++t) {
+          if (t < nb) {
+            double v = r[t];
+#pragma unroll
+            for (int u = 0; u < t; ++u) v = fma(-Dg[u * 17 + t], r[u], v);
+            r[t] = v * Di[t];
+          }
+        }
+        double* colw = A + (size_t)kb + (size_t)N * (t0 + j);
+#pragma unroll
+        for (int t = 0; t < CH_NB; ++t) if (t < nb) colw[t] = r[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < CH_NB; ++t) r[t] = 0.0;
       }
+#pragma unroll
+      for (int t = 0; t < CH_NB; ++t) P[(size_t)t * Np + j] = r[t];
     }
     __syncthreads();
     // ---- trailing update, transposed tiles so that lanes run along i (contiguous in the column-major matrix):
-    //      C'[j][i] = sum_t P[t][j0+j] P[t][i0+i];  A[t0+i0+i][t0+j0+j] -= C'[j][i]  for i <= j
+    //      C'[j][i] = sum_t P[t][j0+j] P[t][i0+i];  A[t0+i0+i][t0+j0+j] -= C'[j][i]  for i <= j.
+    // The upper-triangular tile pairs are enumerated directly (balanced over the 16 waves); the global loads of
+    // a wave's next tile are issued before the MFMAs of the current one.
     const int nt = ntrp >> 4;
-    for (int tl = wave; tl < nt * nt; tl += CH_THREADS / 64) {
-      const int ti = tl % nt, tj = tl / nt;
-      if (ti > tj) continue;
+    const int npair = nt * (nt + 1) / 2;
+    auto decode = [](int u, int& ti, int& tj) {
+      int c = (int)((sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
+      while ((c + 1) * (c + 2) / 2 <= u) ++c;
+      while (c * (c + 1) / 2 > u) --c;
+      tj = c; ti = u - c * (c + 1) / 2;
+    };
+    double cur[4], nxt[4];
+    int u = wave, ti = 0, tj = 0;
+    auto load_tile = [&](int ti_, int tj_, double* dst) {
+      const int i = (ti_ << 4) + li;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int j = (tj_ << 4) + lg + 4 * reg;
+        dst[reg] = (i < ntr && j < ntr && i <= j) ? A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] : 0.0;
+      }
+    };
+    if (u < npair) { decode(u, ti, tj); load_tile(ti, tj, cur); }
+    while (u < npair) {
+      const int un = u + CH_THREADS / 64;
+      int tin = 0, tjn = 0;
+      if (un < npair) { decode(un, tin, tjn); load_tile(tin, tjn, nxt); }
       const int i0 = ti << 4, j0 = tj << 4;
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -232,8 +267,11 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int j = j0 + lg + 4 * reg;
-        if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] -= acc[reg];
+        if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] = cur[reg] - acc[reg];
       }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) cur[reg] = nxt[reg];
+      u = un; ti = tin; tj = tjn;
     }
     __syncthreads();
   }
