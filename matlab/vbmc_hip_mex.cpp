@@ -16,6 +16,7 @@
 //                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device)
 //     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
 //     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
+//     [nlZ,dnlZ] = vbmc_hip_mex('gp_nlz', Hyp /*Nhyp x B*/, X, y, s2, meanfun, noisefun)   (gplite_nlZ for B vectors)
 //     C = vbmc_hip_mex('sq_dist', a, b)
 //
 // Errors are raised with mexErrMsgIdAndTxt AFTER all temporaries are released (it long-jumps);
@@ -234,6 +235,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nlhs > 4) plhs[4] = lch;
     if (nlhs > 5) { plhs[5] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[5]) = (uint64_t)(uintptr_t)h; }
     else vbmc_gp_free(g_ctx, h);
+    return;
+  }
+
+  if (!strcmp(cmd, "gp_nlz")) {
+    const mxArray *hyp = prhs[1], *X = prhs[2], *y = prhs[3], *s2 = prhs[4];
+    const int N = (int)mxGetM(X), D = (int)mxGetN(X), Nhyp = (int)mxGetM(hyp), B = (int)mxGetN(hyp);
+    int32_t nf[3] = {1, 0, 0};
+    for (int i = 0; i < 3 && i < (int)mxGetNumberOfElements(prhs[6]); ++i) nf[i] = (int32_t)mxGetDoubles(prhs[6])[i];
+    plhs[0] = mxCreateDoubleMatrix(1, B, mxREAL);
+    mxArray* g = nlhs > 1 ? mxCreateDoubleMatrix(Nhyp, B, mxREAL) : nullptr;
+    vbmc_status st = vbmc_gp_nlz(g_ctx, N, D, B, Nhyp, (int)mxGetScalar(prhs[5]), nf, mxGetDoubles(X), mxGetDoubles(y), dbl(s2),
+                                 mxGetDoubles(hyp), g ? 1 : 0, mxGetDoubles(plhs[0]), g ? mxGetDoubles(g) : nullptr);
+    if (st != VBMC_OK) fail(st);
+    if (g) plhs[1] = g;
     return;
   }
 
