@@ -93,6 +93,25 @@ vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanf
                          vbmc_gp** gp_out);
 
 /*
+ * acq = acqwrapper_vbmc(Xs,vp,gp,optimState,0,acqFun,acqInfo)   (acq/acqwrapper_vbmc.m:11-46) for the
+ * density-based acquisition functions, with vp.delta = 0: gplite_pred for every hyper-sample (:17), fbar / vtot
+ * (:21-29), p = max(vbmc_pdf(vp,Xs,0),realmin), then
+ *   acq_id 0  acqf_vbmc     -vtot .* exp(fbar - ymax) .* p                       (acq/acqf_vbmc.m:9-10)
+ *   acq_id 1  acqflog_vbmc  -(log(vtot) + fbar - ymax + log(p))                  (acq/acqflog_vbmc.m:17-18)
+ *   acq_id 2  acqus_vbmc    -vtot .* p.^2                                        (acq/acqus_vbmc.m:9)
+ *   acq_id 3  acqfsn2_vbmc  -vtot .* (1 - sn2./(vtot+sn2)) .* exp(fbar - ymax) .* p, sn2 = gp.sn2new at the nearest
+ *             row of gp.X_rescaled to Xs ./ optimState.gplengthscale               (acq/acqfsn2_vbmc.m:9-17)
+ * followed by the variance regularisation (:35-45, if var_regularized) and max(acq,-realmax) (:46).  NOT done
+ * here: the integer mapping (:8) and the hard-bound test in the ORIGINAL parameter space (:49-51), which need the
+ * caller's warpvars_vbmc; the caller sets acq(outside) = Inf.  Xs is Nstar x D column-major in transformed
+ * coordinates; vp_mu D x K.  Optional outputs fbar, vtot (Nstar each, may be NULL).
+ */
+vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xs, int acq_id, int K,
+                          const double* vp_mu, const double* vp_sigma, const double* vp_lambda, const double* vp_w,
+                          double ymax, int var_regularized, double TolGPVar, const double* gplengthscale,
+                          const double* X_rescaled, const double* sn2new, double* acq, double* fbar, double* vtot);
+
+/*
  * [nlZ,dnlZ] = gplite_nlZ(hyp,gp,[])   (gplite/gplite_nlZ.m:1-72 -> gplite/private/gplite_core.m:1-102,128-275)
  * for B hyper-parameter vectors at once (the walkers / restarts of gplite_train.m:181,251,292,330): negative
  * log marginal likelihood nlZ (B) and, if compute_grad, its gradient dnlZ (Nhyp x B, column-major).  SE-ARD

@@ -16,6 +16,7 @@
 //                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device)
 //     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
 //     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
+//     [acq,fbar,vtot] = vbmc_hip_mex('acq', h, Xs, acq_id, vp, ymax, var_regularized, TolGPVar, gplengthscale, X_rescaled, sn2new)
 //     [nlZ,dnlZ] = vbmc_hip_mex('gp_nlz', Hyp /*Nhyp x B*/, X, y, s2, meanfun, noisefun)   (gplite_nlZ for B vectors)
 //     C = vbmc_hip_mex('sq_dist', a, b)
 //
@@ -235,6 +236,23 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nlhs > 4) plhs[4] = lch;
     if (nlhs > 5) { plhs[5] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[5]) = (uint64_t)(uintptr_t)h; }
     else vbmc_gp_free(g_ctx, h);
+    return;
+  }
+
+  if (!strcmp(cmd, "acq")) {
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    const mxArray *Xs = prhs[2], *vp = prhs[4];
+    const int Nstar = (int)mxGetM(Xs);
+    plhs[0] = mxCreateDoubleMatrix(Nstar, 1, mxREAL);
+    mxArray *fb = mxCreateDoubleMatrix(Nstar, 1, mxREAL), *vt = mxCreateDoubleMatrix(Nstar, 1, mxREAL);
+    vbmc_status st = vbmc_acq_eval(g_ctx, h, Nstar, mxGetDoubles(Xs), (int)mxGetScalar(prhs[3]), (int)scalar_field(vp, "K", 0),
+                                   dbl(field(vp, "mu")), dbl(field(vp, "sigma")), dbl(field(vp, "lambda")), dbl(field(vp, "w")),
+                                   mxGetScalar(prhs[5]), (int)mxGetScalar(prhs[6]), mxGetScalar(prhs[7]),
+                                   nrhs > 8 ? dbl(prhs[8]) : nullptr, nrhs > 9 ? dbl(prhs[9]) : nullptr, nrhs > 10 ? dbl(prhs[10]) : nullptr,
+                                   mxGetDoubles(plhs[0]), mxGetDoubles(fb), mxGetDoubles(vt));
+    if (st != VBMC_OK) fail(st);
+    if (nlhs > 1) plhs[1] = fb;
+    if (nlhs > 2) plhs[2] = vt;
     return;
   }
 

@@ -551,6 +551,80 @@ def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False):
 # --------------------------------------------------------------------------
 
 
+REALMIN = 2.2250738585072014e-308
+REALMAX = 1.7976931348623157e308
+
+
+def vbmc_pdf_transformed(vp, X):
+    """vbmc_pdf(vp,X,0) (vbmc_pdf.m:38-71): mixture density in the transformed space, Gaussian components."""
+    X = np.asarray(X, dtype=np.float64)
+    N, D = X.shape
+    lam = np.asarray(vp["lambda"], dtype=np.float64).reshape(-1)
+    nf = 1.0 / (2 * math.pi) ** (D / 2.0) / np.prod(lam)  # :58
+    y = np.zeros(N)
+    for k in range(vp["K"]):  # :60-63
+        d2 = np.sum(((X - vp["mu"][:, k][None, :]) / (vp["sigma"][k] * lam[None, :])) ** 2, axis=1)
+        y = y + nf * vp["w"][k] / vp["sigma"][k] ** D * np.exp(-0.5 * d2)
+    return y
+
+
+def _acq_sqdist_rows(a, b):
+    """Local sq_dist of acq/acqfsn2_vbmc.m:24-32 (points in ROWS, joint-mean centring)."""
+    n, m = a.shape[0], b.shape[0]
+    mu = (m / (n + m)) * np.mean(b, axis=0) + (n / (n + m)) * np.mean(a, axis=0)
+    a = a - mu
+    b = b - mu
+    C = np.sum(a * a, axis=1)[:, None] + (np.sum(b * b, axis=1)[None, :] - 2 * a @ b.T)
+    return np.maximum(C, 0.0)
+
+
+def acq_function(name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot):
+    """acq/acqf_vbmc.m:6-10, acq/acqflog_vbmc.m:14-18, acq/acqus_vbmc.m:6-9, acq/acqfsn2_vbmc.m:6-17."""
+    p = np.maximum(vbmc_pdf_transformed(vp, Xs), REALMIN)
+    z = optimState.get("ymax", 0.0)
+    if name == "acqf":
+        return -vtot * np.exp(fbar - z) * p
+    if name == "acqflog":
+        return -(np.log(vtot) + fbar - z + np.log(p))
+    if name == "acqus":
+        return -vtot * p**2
+    if name == "acqfsn2":
+        pos = np.argmin(_acq_sqdist_rows(Xs / optimState["gplengthscale"][None, :], gp["X_rescaled"]), axis=1)
+        sn2 = np.asarray(gp["sn2new"], dtype=np.float64)[pos]
+        return -vtot * (1 - sn2 / (vtot + sn2)) * np.exp(fbar - z) * p
+    raise NotImplementedError(name)
+
+
+ACQ_LOG_FLAG = {"acqf": False, "acqflog": True, "acqus": False, "acqfsn2": False}
+
+
+def acqwrapper_vbmc(Xs, vp, gp, optimState, acq_name, outside=None):
+    """acq/acqwrapper_vbmc.m:11-51 for vp.delta = 0, without the integer mapping (:8) and with the hard-bound
+    test (:46-49, needs the caller's warpvars inverse) supplied as the boolean mask ``outside``."""
+    Xs = np.asarray(Xs, dtype=np.float64)
+    _, _, fmu, fs2 = gplite_pred(gp, Xs, None, None, True)  # :17
+    fmu = np.asarray(fmu).reshape(Xs.shape[0], -1)
+    fs2 = np.asarray(fs2).reshape(Xs.shape[0], -1)
+    Ns = fmu.shape[1]
+    fbar = np.sum(fmu, axis=1) / Ns  # :22
+    vbar = np.sum(fs2, axis=1) / Ns
+    vf = np.sum((fmu - fbar[:, None]) ** 2, axis=1) / (Ns - 1) if Ns > 1 else 0.0  # :24-28
+    vtot = vf + vbar
+    acq = acq_function(acq_name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot)  # :32
+    if optimState.get("VarianceRegularizedAcqFcn", False):  # :35-45
+        TolVar = optimState["TolGPVar"]
+        idx = vtot < TolVar
+        if np.any(idx):
+            if ACQ_LOG_FLAG[acq_name]:
+                acq[idx] = acq[idx] + TolVar / vtot[idx] - 1
+            else:
+                acq[idx] = acq[idx] * np.exp(-(TolVar / vtot[idx] - 1))
+    acq = np.maximum(acq, -REALMAX)  # :46
+    if outside is not None:
+        acq = np.where(np.asarray(outside, dtype=bool), np.inf, acq)  # :49-51
+    return acq, fbar, vtot
+
+
 def softmax_jacobian(eta):
     """J_w = -exp(eta)' * exp(eta)/sum^2 + diag(exp(eta)/sum)
     (misc/gplogjoint.m:366-368, ent/entmc_vbmc.m:121-123)."""

@@ -200,3 +200,30 @@ def test_fminadam_quadratic():
 
     x, f, xtab, ftab, it = R.fminadam(fun, np.array([1.0, -1.0, 0.5]), MaxIter=2000)
     assert np.max(np.abs(x)) < 0.05 and it >= 40 and it % 20 == 0
+
+
+def test_vbmc_pdf_and_acq_restatement():
+    """vbmc_pdf (transformed space) against scipy's multivariate normal; acquisition formulas on a GP where the
+    prediction is known: far from the data fs2 -> sf2 and fmu -> the mean function."""
+    from scipy import stats
+
+    rng = np.random.default_rng(0)
+    D, K = 3, 4
+    vp = {"K": K, "D": D, "mu": rng.standard_normal((D, K)), "sigma": 0.5 + rng.random(K), "lambda": np.array([0.7, 1.0, 1.4]),
+          "w": np.array([0.1, 0.2, 0.3, 0.4])}
+    X = rng.standard_normal((6, D))
+    ref = sum(vp["w"][k] * stats.multivariate_normal.pdf(X, vp["mu"][:, k], np.diag((vp["sigma"][k] * vp["lambda"]) ** 2))
+              for k in range(K))
+    assert np.max(np.abs(R.vbmc_pdf_transformed(vp, X) - ref) / ref) < 1e-13
+    Xt = rng.standard_normal((12, D))
+    y = -0.5 * np.sum(Xt**2, axis=1)
+    hyp = np.array([np.log(0.5)] * D + [np.log(1.3), np.log(1e-2), 0.4])[:, None]
+    gp = R.gplite_post(hyp, Xt, y, meanfun=1)
+    far = 50.0 + rng.standard_normal((4, D))
+    st = {"ymax": float(np.max(y)), "VarianceRegularizedAcqFcn": True, "TolGPVar": 1e-4}
+    acq, fbar, vtot = R.acqwrapper_vbmc(far, vp, gp, st, "acqflog")
+    assert np.allclose(fbar, 0.4) and np.allclose(vtot, 1.3**2)
+    p = np.maximum(R.vbmc_pdf_transformed(vp, far), R.REALMIN)
+    assert np.allclose(acq, -(np.log(1.3**2) + 0.4 - st["ymax"] + np.log(p)))
+    a2, _, _ = R.acqwrapper_vbmc(far, vp, gp, st, "acqf", outside=np.array([True, False, False, False]))
+    assert np.isinf(a2[0]) and np.all(a2[1:] <= 0)

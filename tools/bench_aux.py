@@ -34,6 +34,8 @@ theta = np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]), 
 out["eval_fullelcbo_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta, 0, vp, gp, 4096, 0, 1, nargout=11, engine=eng), 5)
 out["diagvar_grad_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta, 1.0, vp, gp, 128, 1, 2, nargout=2, engine=eng), 5)
 out["entlb_sieve_R250_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)
+st = {"ymax": float(np.max(inp["y"])), "VarianceRegularizedAcqFcn": True, "TolGPVar": 1e-4}
+out["acqwrapper_acqf_8192_ms"] = 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None, engine=eng), 3)
 # GP hyper-parameter objective: B walkers, value + gradient
 gpd = {"X": inp["X"], "y": inp["y"], "s2": None, "covfun": 1, "Ncov": D + 1, "noisefun": (1, 0, 0), "Nnoise": 1, "meanfun": 4,
        "Nmean": 2 * D + 1, "intmeanfun": 0}

@@ -96,6 +96,8 @@ def load():
                                  _dp, _dp, _dp, _dp, u8p, C.POINTER(vp)]
     lib.vbmc_gp_pred.argtypes = [vp, vp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
     lib.vbmc_gp_rank1_solves.argtypes = [vp, vp, _dp, _dp, _dp, _dp]
+    lib.vbmc_acq_eval.argtypes = [vp, vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
+                                  _dp, _dp, _dp, _dp, _dp, _dp]
     lib.vbmc_gp_nlz.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
     lib.vbmc_test_exp.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
     lib.vbmc_sq_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]

@@ -1,0 +1,70 @@
+"""Acquisition sweep on the GPU behind the reference's call surface.
+
+``acqwrapper_vbmc(Xs, vp, gp, optimState, transpose_flag, acqFun, acqInfo)`` (acq/acqwrapper_vbmc.m:1) with the
+density-based acquisition functions ``acqf_vbmc`` (default, vbmc.m:213), ``acqflog_vbmc``, ``acqus_vbmc`` and
+``acqfsn2_vbmc``: GP prediction for every hyper-sample, the hyper-sample statistics, the variational-posterior
+density and the acquisition value are one fused device pass (``vbmc_acq_eval``).  The two steps that need VBMC's
+variable transform -- the integer mapping (:8) and the hard-bound test in the ORIGINAL space (:49-51) -- are the
+caller's: pass the boolean mask of out-of-bounds points as ``outside``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import VbmcUnsupported, f64, ptr
+from .elbo import default_engine
+from .gplite import _device_gp_with_noise
+
+ACQ_IDS = {"acqf_vbmc": 0, "acqflog_vbmc": 1, "acqus_vbmc": 2, "acqfsn2_vbmc": 3}
+
+
+def acq_info(acqFun):
+    """acqFun([]) info struct of the accelerated functions (acq/acqflog_vbmc.m:6-11)."""
+    name = acqFun if isinstance(acqFun, str) else getattr(acqFun, "__name__", str(acqFun))
+    name = name.lstrip("@")
+    if name not in ACQ_IDS:
+        raise VbmcUnsupported(-1, "acquisition function %s is not accelerated" % name)
+    return {"name": name, "log_flag": name == "acqflog_vbmc", "compute_varlogjoint": False}
+
+
+def acqwrapper_vbmc(Xs, vp, gp, optimState, transpose_flag=False, acqFun="acqf_vbmc", acqInfo=None, *, outside=None,
+                    nargout=1, engine=None):
+    """acq = acqwrapper_vbmc(Xs,vp,gp,optimState,transpose_flag,acqFun,acqInfo).
+
+    ``optimState`` keys used: ymax, VarianceRegularizedAcqFcn, TolGPVar (+ gplengthscale for acqfsn2, whose
+    gp needs X_rescaled and sn2new).  ``nargout=3`` also returns (fbar, vtot) of :21-29.
+    """
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    info = acq_info(acqFun)
+    acq_id = ACQ_IDS[info["name"]]
+    delta = vp.get("delta")
+    if delta is not None and np.any(np.asarray(delta) > 0):
+        raise VbmcUnsupported(-1, "vp.delta > 0 (gplite_quad, acqwrapper_vbmc.m:12-14) is not accelerated")
+    Xs = np.asarray(Xs, dtype=np.float64)
+    if transpose_flag:
+        Xs = Xs.T
+    Xs = f64(Xs.reshape(-1, gp["X"].shape[1]))
+    Nstar, D = Xs.shape
+    K = int(vp["K"])
+    dgp = _device_gp_with_noise(engine, gp)
+    mu = f64(np.asarray(vp["mu"], dtype=np.float64).reshape(D, K))
+    sigma = f64(np.asarray(vp["sigma"], dtype=np.float64).reshape(K))
+    lam = f64(np.asarray(vp["lambda"], dtype=np.float64).reshape(D))
+    w = f64(np.asarray(vp["w"], dtype=np.float64).reshape(K))
+    gl = xr = sn = None
+    if acq_id == 3:
+        gl = f64(np.asarray(optimState["gplengthscale"], dtype=np.float64).reshape(D))
+        xr = f64(np.asarray(gp["X_rescaled"], dtype=np.float64))
+        sn = f64(np.asarray(gp["sn2new"], dtype=np.float64).reshape(-1))
+    acq = np.zeros(Nstar)
+    fbar = np.zeros(Nstar)
+    vtot = np.zeros(Nstar)
+    ctx.check(ctx.lib.vbmc_acq_eval(ctx.h, dgp.h, Nstar, ptr(Xs), acq_id, K, ptr(mu), ptr(sigma), ptr(lam), ptr(w),
+                                    float(optimState.get("ymax", 0.0)), int(bool(optimState.get("VarianceRegularizedAcqFcn", False))),
+                                    float(optimState.get("TolGPVar", 0.0)), ptr(gl), ptr(xr), ptr(sn), ptr(acq), ptr(fbar), ptr(vtot)))
+    if outside is not None:
+        acq = np.where(np.asarray(outside, dtype=bool).reshape(-1), np.inf, acq)   # :49-51
+    if transpose_flag:
+        acq = acq.reshape(1, -1)
+    return (acq, fbar, vtot) if nargout >= 3 else acq

@@ -355,12 +355,18 @@ extern "C" vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32
 }
 
 // ------------------------------------------------------------------------------------------
-extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
-                                    int ssflag, double* ymu, double* ys2, double* fmu, double* fs2) {
-  if (!ctx) return VBMC_ERR_INVALID;
-  if (!gp || Nstar <= 0 || !Xstar) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_pred: bad arguments");
-  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_pred needs gp.post(s).L on the device");
-  if (!gp->has_noise) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_pred: call vbmc_gp_set_noise (noisefun, sn2_mult) first");
+namespace {
+struct PredBufs {
+  TmpBuf dXs, ds2, dmb, dout, dXc, daa, dmuv;
+  double *fmu = nullptr, *fs2 = nullptr, *ys2 = nullptr;   // Nstar x S each, inside dout
+};
+
+// gplite_pred for every hyper-sample, results left on the device (shared by vbmc_gp_pred and vbmc_acq_eval)
+vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
+                           PredBufs& pb) {
+  if (!gp || Nstar <= 0 || !Xstar) return set_err(ctx, VBMC_ERR_INVALID, "%s: bad arguments", who);
+  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "%s needs gp.post(s).L on the device", who);
+  if (!gp->has_noise) return set_err(ctx, VBMC_ERR_INVALID, "%s: call vbmc_gp_set_noise (noisefun, sn2_mult) first", who);
   if (gp->noisefun[2] == 1)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "output-dependent noise (noisefun(3) = 1) at test points not accelerated");
   if ((gp->noisefun[1] == 1 || gp->noisefun[1] == 2) && !s2star)
@@ -377,7 +383,7 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
     for (int j = 0; j < Nstar; ++j) sb += Xstar[j + (size_t)Nstar * d];
     mb[d] = sb / Nstar;
   }
-  TmpBuf dXs, ds2, dmb, dout, davg, dXc, daa, dmuv;
+  TmpBuf &dXs = pb.dXs, &ds2 = pb.ds2, &dmb = pb.dmb, &dout = pb.dout, &dXc = pb.dXc, &daa = pb.daa, &dmuv = pb.dmuv;
   HIP_TRY(ctx, dXc.alloc(ctx, (size_t)S * N * D * 8));
   HIP_TRY(ctx, daa.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, dmuv.alloc(ctx, (size_t)S * 2 * D * 8));
@@ -397,11 +403,26 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
   pa.alpha = gp->alpha; pa.L = gp->L; pa.sn2_eff = gp->d_sn2; pa.sn2_mult = gp->d_mult; pa.lchol = gp->d_lchol;
   pa.mean_a = gp->d_meanX; pa.mean_b = dmb.as<double>(); pa.finv = gp->d_finv;
   pa.fmu = dout.as<double>(); pa.fs2 = pa.fmu + (size_t)Nstar * S; pa.ys2 = pa.fs2 + (size_t)Nstar * S;
+  pb.fmu = pa.fmu; pb.fs2 = pa.fs2; pb.ys2 = pa.ys2;
   hipLaunchKernelGGL(k_pred_prep, dim3(4, S), dim3(256), 0, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
   if (plds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
   hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(64), plds, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
   HIP_TRY(ctx, hipGetLastError());
+  return VBMC_OK;
+}
+}  // namespace
+
+extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
+                                    int ssflag, double* ymu, double* ys2, double* fmu, double* fs2) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  PredBufs pb;
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_gp_pred", gp, Nstar, Xstar, s2star, pb); if (s_ != VBMC_OK) return s_; }
+  hipStream_t st = ctx->stream;
+  const int S = gp->S;
+  TmpBuf davg;
+  TmpBuf& dout = pb.dout;
+  struct { double *fmu, *fs2, *ys2; } pa{pb.fmu, pb.fs2, pb.ys2};
   const size_t ns = (size_t)Nstar * S;
   if (S > 1 && !ssflag) {
     HIP_TRY(ctx, davg.alloc(ctx, (size_t)4 * Nstar * 8));
@@ -422,6 +443,64 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
     if (fs2) memcpy(fs2, h.data() + ns, ns * 8);
     if (ys2) memcpy(ys2, h.data() + 2 * ns, ns * 8);
   }
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xs, int acq_id, int K,
+                                     const double* vp_mu, const double* vp_sigma, const double* vp_lambda, const double* vp_w,
+                                     double ymax, int var_regularized, double TolGPVar, const double* gplengthscale,
+                                     const double* X_rescaled, const double* sn2new, double* acq, double* fbar, double* vtot) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!acq || K <= 0 || !vp_mu || !vp_sigma || !vp_lambda || !vp_w) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_eval: bad arguments");
+  if (acq_id < 0 || acq_id > 3) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "acquisition function id %d not accelerated (0 acqf, 1 acqflog, 2 acqus, 3 acqfsn2)", acq_id);
+  if (acq_id == 3 && (!gplengthscale || !X_rescaled || !sn2new))
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_eval: acqfsn2 needs gplengthscale, X_rescaled and sn2new");
+  if (gp && (gp->noisefun[1] == 1 || gp->noisefun[1] == 2))
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_acq_eval: noise models that need s2 at the test points are not accelerated");
+  PredBufs pb;
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
+  hipStream_t st = ctx->stream;
+  const int N = gp->N, D = gp->D, S = gp->S;
+  if ((size_t)(2 * K * D + K) * 8 > 64 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_acq_eval: K*D = %d too large", K * D);
+  // host: O(K D) constants of vbmc_pdf.m:57-62 in the reference's order of operations
+  double prodl = 1.0;
+  for (int d = 0; d < D; ++d) prodl *= vp_lambda[d];
+  const double nf = 1.0 / std::pow(2.0 * 3.14159265358979323846, D / 2.0) / prodl;
+  std::vector<double> hb((size_t)K * D + K);
+  for (int k = 0; k < K; ++k) {
+    for (int d = 0; d < D; ++d) hb[(size_t)k * D + d] = 1.0 / (vp_sigma[k] * vp_lambda[d]);
+    hb[(size_t)K * D + k] = nf * vp_w[k] / std::pow(vp_sigma[k], D);
+  }
+  TmpBuf dmu, dhb, dgl, dXr, dsn, dres;
+  HIP_TRY(ctx, dmu.alloc(ctx, (size_t)D * K * 8));
+  HIP_TRY(ctx, dhb.alloc(ctx, hb.size() * 8));
+  HIP_TRY(ctx, dres.alloc(ctx, (size_t)3 * Nstar * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(dmu.p, vp_mu, (size_t)D * K * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dhb.p, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, st));
+  AcqArgs a{};
+  a.Nstar = Nstar; a.S = S; a.D = D; a.K = K; a.N = N; a.acq_id = acq_id; a.reg = var_regularized ? 1 : 0;
+  a.ymax = ymax; a.TolVar = TolGPVar;
+  a.Xs = pb.dXs.as<double>(); a.fmu = pb.fmu; a.fs2 = pb.fs2;
+  a.mu = dmu.as<double>(); a.isl = dhb.as<double>(); a.coef = dhb.as<double>() + (size_t)K * D;
+  if (acq_id == 3) {
+    HIP_TRY(ctx, dgl.alloc(ctx, (size_t)D * 8));
+    HIP_TRY(ctx, dXr.alloc(ctx, (size_t)N * D * 8));
+    HIP_TRY(ctx, dsn.alloc(ctx, (size_t)N * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(dgl.p, gplengthscale, (size_t)D * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dXr.p, X_rescaled, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dsn.p, sn2new, (size_t)N * 8, hipMemcpyHostToDevice, st));
+    a.gl = dgl.as<double>(); a.Xr = dXr.as<double>(); a.sn2new = dsn.as<double>();
+  }
+  a.acq = dres.as<double>(); a.fbar = a.acq + Nstar; a.vtot = a.fbar + Nstar;
+  hipLaunchKernelGGL(k_acq, dim3((Nstar + 255) / 256), dim3(256), (size_t)(2 * K * D + K) * 8, st, a);
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<double> h((size_t)3 * Nstar);
+  HIP_TRY(ctx, hipMemcpyAsync(h.data(), dres.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  memcpy(acq, h.data(), (size_t)Nstar * 8);
+  if (fbar) memcpy(fbar, h.data() + Nstar, (size_t)Nstar * 8);
+  if (vtot) memcpy(vtot, h.data() + 2 * (size_t)Nstar, (size_t)Nstar * 8);
   return VBMC_OK;
 }
 

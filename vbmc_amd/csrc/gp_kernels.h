@@ -630,3 +630,91 @@ __global__ void __launch_bounds__(256) k_nlz_final(int N, int D, int Nhyp, int N
   }
   (void)meanfun;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Acquisition sweep (acq/acqwrapper_vbmc.m:19-46) fused behind the prediction: per test point the
+// hyper-sample statistics fbar / vtot (:21-29), the variational-posterior density p = max(vbmc_pdf(vp,Xs,0),
+// realmin) (vbmc_pdf.m:57-63), the acquisition value (acqf_vbmc.m:9-10, acqflog_vbmc.m:17-18, acqus_vbmc.m:9,
+// acqfsn2_vbmc.m:9-17), the variance regularisation (:35-45) and the -realmax clamp (:46).
+// ------------------------------------------------------------------------------------------
+struct AcqArgs {
+  int Nstar, S, D, K, N, acq_id, reg;
+  double ymax, TolVar;
+  const double* Xs;     // Nstar x D col-major
+  const double* fmu;    // Nstar x S
+  const double* fs2;    // Nstar x S
+  const double* mu;     // D x K
+  const double* isl;    // K x D:  1 / (sigma_k lambda_d)
+  const double* coef;   // K:      nf * w_k / sigma_k^D
+  const double* gl;     // D       optimState.gplengthscale        (acq_id 3)
+  const double* Xr;     // N x D   gp.X_rescaled, col-major        (acq_id 3)
+  const double* sn2new; // N                                       (acq_id 3)
+  double* acq;          // Nstar
+  double* fbar;         // Nstar
+  double* vtot;         // Nstar
+};
+
+__global__ void __launch_bounds__(256) k_acq(AcqArgs a) {
+  extern __shared__ double lds[];
+  const int D = a.D, K = a.K, S = a.S, Nstar = a.Nstar;
+  double* s_mu = lds;              // K x D (k-major)
+  double* s_isl = s_mu + K * D;    // K x D
+  double* s_coef = s_isl + K * D;  // K
+  for (int idx = threadIdx.x; idx < K * D; idx += 256) {
+    const int k = idx / D, d = idx % D;
+    s_mu[idx] = a.mu[d + (size_t)D * k];
+    s_isl[idx] = a.isl[idx];
+  }
+  for (int k = threadIdx.x; k < K; k += 256) s_coef[k] = a.coef[k];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nstar) return;
+  double fbar = 0.0, vbar = 0.0;
+  for (int s = 0; s < S; ++s) { fbar += a.fmu[i + (size_t)Nstar * s]; vbar += a.fs2[i + (size_t)Nstar * s]; }
+  fbar /= S; vbar /= S;
+  double vf = 0.0;
+  if (S > 1) {
+    for (int s = 0; s < S; ++s) { const double d = a.fmu[i + (size_t)Nstar * s] - fbar; vf += d * d; }
+    vf /= (S - 1);
+  }
+  const double vtot = vf + vbar;
+  double x[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) x[d] = d < D ? a.Xs[i + (size_t)Nstar * d] : 0.0;
+  double p = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double d2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 32; ++d)
+      if (d < D) { const double t = (x[d] - s_mu[k * D + d]) * s_isl[k * D + d]; d2 = fma(t, t, d2); }
+    p += s_coef[k] * exp(-0.5 * d2);
+  }
+  p = fmax(p, 2.2250738585072014e-308);
+  double acq;
+  if (a.acq_id == 0) acq = -vtot * exp(fbar - a.ymax) * p;
+  else if (a.acq_id == 1) acq = -(log(vtot) + fbar - a.ymax + log(p));
+  else if (a.acq_id == 2) acq = -vtot * p * p;
+  else {
+    // observation noise at the nearest training input in length-scale units (acqfsn2_vbmc.m:11-13; first minimum wins)
+    double best = INFINITY;
+    int pos = 0;
+    for (int n = 0; n < a.N; ++n) {
+      double c = 0.0;
+#pragma unroll
+      for (int d = 0; d < 32; ++d)
+        if (d < D) { const double t = x[d] / a.gl[d] - a.Xr[n + (size_t)a.N * d]; c = fma(t, t, c); }
+      if (c < best) { best = c; pos = n; }
+    }
+    const double sn2 = a.sn2new[pos];
+    acq = -vtot * (1.0 - sn2 / (vtot + sn2)) * exp(fbar - a.ymax) * p;
+  }
+  if (a.reg && vtot < a.TolVar) {
+    if (a.acq_id == 1) acq = acq + a.TolVar / vtot - 1.0;
+    else acq = acq * exp(-(a.TolVar / vtot - 1.0));
+  }
+  acq = fmax(acq, -1.7976931348623157e308);
+  a.acq[i] = acq;
+  if (a.fbar) a.fbar[i] = fbar;
+  if (a.vtot) a.vtot[i] = vtot;
+}
