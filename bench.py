@@ -196,13 +196,24 @@ def main():
         M = Ns + (Ns % 2)
         f_ent, f_lj, P = algorithmic_flops(D, K, M, S, N)
         achieved = Rr * f_ent / (ent_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of THIS command
+        # (FETCH_SIZE / WRITE_SIZE need their own profiling run; collected and corrected as MI355X_MICROARCH.md prescribes)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_p4_pmc.json")
+        if os.path.exists(pmc_path) and (D, N, K, S, Rr) == (10, 400, 50, 20, 64) and not args.eps_stream:
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_p4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         roof = {"bound": "mfma", "kernel": "k_entropy_mfma<QS=%d,KT=%d,grad>" % ((D + 5) // 4, (K + 15) // 16), "achieved": achieved,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": Rr * 8 * (2 * (D * K + K + D + K) + 2),
                 "kernel_ms": ent_ms, "flops_per_launch": Rr * f_ent, "exp_per_launch": Rr * P,
                 "note": "fp64 pipe bound: v_mfma_f64_16x16x4_f64 and fp64 VALU share one pipe on gfx950 (measured: no overlap), "
                         "dense fp64 peak 78.6 TFLOP/s for either.  achieved = algorithmic flops P(5D+7)+K*Ns(5D+4) per eval "
-                        "(SURVEY 8d) x R / kernel time; the P fp64 exp evaluations (11 fp64 ops each here) are NOT counted. "
-                        "traffic: device-RNG mode reads no O(Ns) data from HBM (FETCH_SIZE per launch is in profiles/)"}
+                        "(SURVEY 8d) x R / kernel time; the P fp64 exp evaluations (9 fp64 ops each here) are NOT counted. "
+                        "traffic: device-RNG mode reads no O(Ns) data from HBM; the bytes are per-chunk partial records "
+                        "(written once, reduced by k_ent_reduce) and the packed mixture parameters"}
         extra["logjoint_kernel_ms"] = lj_ms
         # single-chain latency: the on-device Adam loop (vbmc_adam_batch) vs one host round trip per evaluation
         for Rc in ((1, 2) if args.extras else ()):

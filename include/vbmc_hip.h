@@ -112,6 +112,30 @@ vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const dou
                           const double* X_rescaled, const double* sn2new, double* acq, double* fbar, double* vtot);
 
 /*
+ * Importance-sampled IQR acquisition functions: acqviqr_vbmc (acq/acqviqr_vbmc.m:36-109) and acqimiqr_vbmc
+ * (acq/acqimiqr_vbmc.m:30-95) behind acqwrapper_vbmc (acq/acqwrapper_vbmc.m:11-46, log-valued).
+ *
+ * vbmc_acq_is_create uploads optimState.ActiveImportanceSampling for one gp: the Na importance points Xa
+ * (Na x D, or Na x D x S if per_sample_inputs), lnw (S x Na; NULL = zeros, i.e. VIQR), fs2a (Na x S; NULL = computed
+ * here with gplite_pred, shared inputs only) and Ctmp_mat (N x Na x S; NULL = computed here as in
+ * private/activeimportancesampling_vbmc.m:248-276: (L\(L'\Kax'))/sn2_eff for Lchol samples, L*Kax' otherwise).
+ * IMIQR's per-call solve (acqimiqr_vbmc.m:77-79) is the same matrix, so one state serves both functions.
+ *
+ * vbmc_acq_iqr_eval: per hyper-sample C = Ka -/+ Ks'*Ctmp (:84-90), tau2 = C.^2 ./ ys2 with ys2 = fs2 + sn2new at
+ * the nearest row of X_rescaled (:42-45), s_pred = sqrt(max(fs2a' - tau2, 0)), log-sum-exp of
+ * lnw + u*s_pred + log1p(-exp(-2*u*s_pred)) over the importance points (:97-102), log-mean-exp over hyper-samples
+ * (:104-107), the wrapper's variance regulariser and clamp.  The integer mapping and hard-bound test stay with the
+ * caller (see vbmc_acq_eval).  Xs: Nstar x D column-major, transformed coordinates.
+ */
+typedef struct vbmc_acq_is vbmc_acq_is;
+vbmc_status vbmc_acq_is_create(vbmc_ctx* ctx, const vbmc_gp* gp, int Na, const double* Xa, int per_sample_inputs,
+                               const double* lnw, const double* fs2a, const double* Ctmp, vbmc_acq_is** out);
+void vbmc_acq_is_free(vbmc_ctx* ctx, vbmc_acq_is* is);
+vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_acq_is* is, int Nstar, const double* Xs,
+                              const double* gplengthscale, const double* X_rescaled, const double* sn2new,
+                              int var_regularized, double TolGPVar, double* acq, double* fbar, double* vtot);
+
+/*
  * [nlZ,dnlZ] = gplite_nlZ(hyp,gp,[])   (gplite/gplite_nlZ.m:1-72 -> gplite/private/gplite_core.m:1-102,128-275)
  * for B hyper-parameter vectors at once (the walkers / restarts of gplite_train.m:181,251,292,330): negative
  * log marginal likelihood nlZ (B) and, if compute_grad, its gradient dnlZ (Nhyp x B, column-major).  SE-ARD

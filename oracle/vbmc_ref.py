@@ -595,7 +595,86 @@ def acq_function(name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot):
     raise NotImplementedError(name)
 
 
-ACQ_LOG_FLAG = {"acqf": False, "acqflog": True, "acqus": False, "acqfsn2": False}
+def acq_is_precompute(gp, Xa):
+    """private/activeimportancesampling_vbmc.m:248-276 (Step 3): cross-kernel of the importance points with the
+    training inputs and Ctmp = (L\(L'\Kax'))/sn2_eff (Lchol) or L*Kax' per hyper-sample.  Xa: Na x D, or
+    Na x D x S for per-hyper-sample inputs.  Returns (Kax_mat Na x N x S, Ctmp_mat N x Na x S)."""
+    X = gp["X"]
+    N, D = X.shape
+    S = len(gp["post"])
+    Xa = np.asarray(Xa, dtype=np.float64)
+    Na = Xa.shape[0]
+    Kax = np.zeros((Na, N, S))
+    Ctmp = np.zeros((N, Na, S))
+    for s, post in enumerate(gp["post"]):
+        xa = Xa if Xa.ndim == 2 else Xa[:, :, s]
+        hyp = post["hyp"]
+        ell = np.exp(hyp[0:D])
+        sf2 = math.exp(2.0 * hyp[D])
+        Kax[:, :, s] = sf2 * np.exp(-_acq_sqdist_rows(xa / ell[None, :], X / ell[None, :]) / 2.0)  # :264-265
+        L = post["L"]
+        if post["Lchol"]:
+            sn2_eff = 1.0 / post["sW"][0] ** 2
+            Ctmp[:, :, s] = solve_upper(L, solve_upper_t(L, Kax[:, :, s].T)) / sn2_eff  # :271
+        else:
+            Ctmp[:, :, s] = L @ Kax[:, :, s].T  # :273
+    return Kax, Ctmp
+
+
+ACQ_U = 0.6745  # norminv(0.75), acqviqr_vbmc.m:4 / acqimiqr_vbmc.m:4
+
+
+def acq_iqr(name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot):
+    """acq/acqviqr_vbmc.m:36-109 (name 'acqviqr') and acq/acqimiqr_vbmc.m:30-95 ('acqimiqr'), SE-ARD
+    covariance, no integrated mean.  optimState['ActiveImportanceSampling'] holds Xa, fs2a (Na x S), lnw (S x Na)
+    and, for VIQR, Ctmp_mat (N x Na x S); IMIQR uses Kax_mat (Na x N x S) and redoes the solve per call."""
+    u = ACQ_U
+    Xs = np.asarray(Xs, dtype=np.float64)
+    Nx, D = Xs.shape
+    Ns = fmu.shape[1]
+    AIS = optimState["ActiveImportanceSampling"]
+    pos = np.argmin(_acq_sqdist_rows(Xs / optimState["gplengthscale"][None, :], gp["X_rescaled"]), axis=1)
+    sn2 = np.asarray(gp["sn2new"], dtype=np.float64)[pos]
+    ys2 = fs2 + sn2[:, None]  # predictive variance at the test points
+    Xa_all = np.asarray(AIS["Xa"], dtype=np.float64)
+    acq = np.zeros((Nx, Ns))
+    X = gp["X"]
+    for s, post in enumerate(gp["post"]):
+        hyp = post["hyp"]
+        ell = np.exp(hyp[0:D])
+        sf2 = math.exp(2.0 * hyp[D])
+        Xa = Xa_all if Xa_all.ndim == 2 else Xa_all[:, :, s]
+        Xs_ell = Xs / ell[None, :]
+        Ks_mat = sf2 * np.exp(-_acq_sqdist_rows(X / ell[None, :], Xs_ell) / 2.0)  # N x Nx
+        if name == "acqviqr":
+            Ka_mat = sf2 * np.exp(-_acq_sqdist_rows(Xs_ell, Xa / ell[None, :]) / 2.0)  # Nx x Na   (:73-74)
+            Ct = AIS["Ctmp_mat"][:, :, s]
+            C = Ka_mat - Ks_mat.T @ Ct if post["Lchol"] else Ka_mat + Ks_mat.T @ Ct  # :84-90
+            lnw = 0.0  # VIQR: plain Monte Carlo (:103-105)
+        else:
+            Ka_mat = sf2 * np.exp(-_acq_sqdist_rows(Xa / ell[None, :], Xs_ell) / 2.0)  # Na x Nx   (:67-68)
+            Kax = AIS["Kax_mat"][:, :, s]
+            L = post["L"]
+            if post["Lchol"]:
+                sn2_eff = 1.0 / post["sW"][0] ** 2
+                C = Ka_mat.T - Ks_mat.T @ (solve_upper(L, solve_upper_t(L, Kax.T))) / sn2_eff  # :77
+            else:
+                C = Ka_mat.T + Ks_mat.T @ (L @ Kax.T)  # :79
+            lnw = np.asarray(AIS["lnw"], dtype=np.float64)[s, :][None, :]  # :85
+        tau2 = C**2 / ys2[:, s][:, None]
+        s_pred = np.sqrt(np.maximum(np.asarray(AIS["fs2a"])[:, s][None, :] - tau2, 0.0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            zz = lnw + u * s_pred + np.log1p(-np.exp(-2 * u * s_pred))
+            lnmax = np.max(zz, axis=1)
+            acq[:, s] = np.log(np.sum(np.exp(zz - lnmax[:, None]), axis=1)) + lnmax
+    if Ns > 1:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            M = np.max(acq, axis=1)
+            return M + np.log(np.sum(np.exp(acq - M[:, None]), axis=1) / Ns)
+    return acq[:, 0]
+
+
+ACQ_LOG_FLAG = {"acqf": False, "acqflog": True, "acqus": False, "acqfsn2": False, "acqviqr": True, "acqimiqr": True}
 
 
 def acqwrapper_vbmc(Xs, vp, gp, optimState, acq_name, outside=None):
@@ -610,7 +689,10 @@ def acqwrapper_vbmc(Xs, vp, gp, optimState, acq_name, outside=None):
     vbar = np.sum(fs2, axis=1) / Ns
     vf = np.sum((fmu - fbar[:, None]) ** 2, axis=1) / (Ns - 1) if Ns > 1 else 0.0  # :24-28
     vtot = vf + vbar
-    acq = acq_function(acq_name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot)  # :32
+    if acq_name in ("acqviqr", "acqimiqr"):
+        acq = acq_iqr(acq_name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot)  # :32
+    else:
+        acq = acq_function(acq_name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot)  # :32
     if optimState.get("VarianceRegularizedAcqFcn", False):  # :35-45
         TolVar = optimState["TolGPVar"]
         idx = vtot < TolVar

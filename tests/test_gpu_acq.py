@@ -65,6 +65,53 @@ def test_acqfsn2_nearest_neighbour_noise(va):
 def test_acq_unsupported_forms(va):
     gp, vp, Xs, st, _ = setup(3, 3, 20, 2, 2)
     with pytest.raises(va.VbmcUnsupported):
-        va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqviqr_vbmc", None)
+        va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqeig_vbmc", None)
     with pytest.raises(va.VbmcUnsupported):
         va.acqwrapper_vbmc(Xs, dict(vp, delta=np.array([0.1, 0.0, 0.0])), gp, st, False, "acqf_vbmc", None)
+
+
+def iqr_setup(va, seed, D, N, K, S, Na, per_s=False, lnw_zero=True):
+    gp, vp, Xs, st, rng = setup(seed, D, N, K, S)
+    gl = np.exp(np.mean(np.stack([p["hyp"][:D] for p in gp["post"]], axis=1), axis=1))
+    gp = dict(gp, X_rescaled=gp["X"] / gl[None, :], sn2new=0.02 + 0.1 * rng.random(N))
+    Xa = 1.1 * rng.standard_normal((Na, D, S)) if per_s else 1.1 * rng.standard_normal((Na, D))
+    Kax, Ct = R.acq_is_precompute(gp, Xa)
+    if per_s:
+        fs2a = np.stack([np.asarray(R.gplite_pred(gp, Xa[:, :, s], None, None, True)[3]).reshape(Na, -1)[:, s] for s in range(S)], axis=1)
+    else:
+        fs2a = np.asarray(R.gplite_pred(gp, Xa, None, None, True)[3]).reshape(Na, -1)
+    lnw = np.zeros((S, Na)) if lnw_zero else 0.7 * rng.standard_normal((S, Na))
+    ais = {"Xa": Xa, "Kax_mat": Kax, "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": lnw}
+    st = dict(st, gplengthscale=gl, ActiveImportanceSampling=ais)
+    return gp, vp, Xs, st
+
+
+@pytest.mark.parametrize("cfg", [(4, 60, 5, 3, 30), (10, 200, 12, 4, 100), (3, 40, 3, 1, 16), (6, 90, 4, 2, 37)])
+def test_acqviqr_matches_oracle(va, cfg):
+    D, N, K, S, Na = cfg
+    gp, vp, Xs, st = iqr_setup(va, 11, D, N, K, S, Na)
+    ref, fbar_r, vtot_r = R.acqwrapper_vbmc(Xs, vp, gp, st, "acqviqr")
+    # state computed entirely on the device (Ctmp, fs2a from Xa) ...
+    st_dev = dict(st, ActiveImportanceSampling={"Xa": st["ActiveImportanceSampling"]["Xa"]})
+    acq, fbar, vtot = va.acqwrapper_vbmc(Xs, vp, gp, st_dev, False, "acqviqr_vbmc", None, nargout=3)
+    # ... and uploaded as the reference's optimState.ActiveImportanceSampling holds it
+    acq2 = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqviqr_vbmc", None)
+    far = vtot_r > st["TolGPVar"]             # away from the regulariser's amplification (see test_acq_matches_oracle)
+    assert far.sum() > 200
+    assert np.max(np.abs(acq[far] - ref[far])) < 1e-8 and np.max(np.abs(acq2[far] - ref[far])) < 1e-8
+    assert relerr(fbar, fbar_r) < 1e-10
+    near = ~far
+    assert np.all(np.isfinite(acq[near])) and np.all(acq[near] >= ref[near] - 1e-3 * np.abs(ref[near]) - 1.0)
+
+
+@pytest.mark.parametrize("per_s", [False, True])
+def test_acqimiqr_matches_oracle(va, per_s):
+    gp, vp, Xs, st = iqr_setup(va, 13, 5, 80, 6, 3, 50, per_s=per_s, lnw_zero=False)
+    ref, _, vtot_r = R.acqwrapper_vbmc(Xs, vp, gp, st, "acqimiqr")
+    ais = dict(st["ActiveImportanceSampling"])
+    ais.pop("Ctmp_mat")                        # IMIQR does not cache Ctmp (acqimiqr_vbmc.m:77): computed on the device
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, dict(st, ActiveImportanceSampling=ais), False, "acqimiqr_vbmc", None)
+    far = vtot_r > st["TolGPVar"]
+    assert np.max(np.abs(acq[far] - ref[far])) < 1e-8
+    info = va.acq_info("acqimiqr_vbmc")
+    assert info["log_flag"] and info["importance_sampling"] and not info["variational_importance_sampling"]

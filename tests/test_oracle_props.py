@@ -227,3 +227,33 @@ def test_vbmc_pdf_and_acq_restatement():
     assert np.allclose(acq, -(np.log(1.3**2) + 0.4 - st["ymax"] + np.log(p)))
     a2, _, _ = R.acqwrapper_vbmc(far, vp, gp, st, "acqf", outside=np.array([True, False, False, False]))
     assert np.isinf(a2[0]) and np.all(a2[1:] <= 0)
+
+
+def test_iqr_lookahead_variance_identity():
+    """The quantity inside acqviqr/acqimiqr, s_pred^2 = fs2a - C^2/ys2, is the GP posterior variance at the
+    importance points after one more (noisy) observation at the candidate -- checked against an actual rank-one
+    update of the oracle GP (constant noise, one hyper-sample), which shares no code with acq_iqr."""
+    rng = np.random.default_rng(4)
+    D, N, Na = 3, 25, 9
+    X = rng.standard_normal((N, D))
+    y = -0.5 * np.sum(X**2, axis=1)
+    hyp = np.array([np.log(0.7)] * D + [np.log(1.1), np.log(0.15), 0.2])[:, None]
+    gp = R.gplite_post(hyp, X, y, meanfun=1)
+    sn2 = np.exp(2 * hyp[D + 1, 0])
+    Xa = rng.standard_normal((Na, D))
+    xs = rng.standard_normal((1, D))
+    _, Ct = R.acq_is_precompute(gp, Xa)
+    fs2a = np.asarray(R.gplite_pred(gp, Xa, None, None, True)[3]).reshape(Na, 1)
+    gl = np.ones(D)
+    gp2 = dict(gp, X_rescaled=X.copy(), sn2new=np.full(N, sn2))
+    st = {"gplengthscale": gl, "ActiveImportanceSampling": {"Xa": Xa, "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": np.zeros((1, Na))}}
+    _, _, fmu, fs2 = R.gplite_pred(gp, xs, None, None, True)
+    fmu = np.asarray(fmu).reshape(1, 1)
+    fs2 = np.asarray(fs2).reshape(1, 1)
+    val = R.acq_iqr("acqviqr", xs, None, gp2, st, fmu, fs2, fmu[:, 0], fs2[:, 0])
+    gp_new = R.gplite_post_rank1(gp, xs, 0.123)
+    s_new = np.sqrt(np.asarray(R.gplite_pred(gp_new, Xa, None, None, True)[3]).reshape(Na))
+    u = R.ACQ_U
+    zz = u * s_new + np.log1p(-np.exp(-2 * u * s_new))
+    ref = np.log(np.sum(np.exp(zz - zz.max()))) + zz.max()
+    assert abs(val[0] - ref) < 1e-9

@@ -36,6 +36,12 @@ out["diagvar_grad_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta, 1.0,
 out["entlb_sieve_R250_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)
 st = {"ymax": float(np.max(inp["y"])), "VarianceRegularizedAcqFcn": True, "TolGPVar": 1e-4}
 out["acqwrapper_acqf_8192_ms"] = 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None, engine=eng), 3)
+gl = np.exp(np.mean(inp["hyp"][:D], axis=1))
+gpn = dict(gp, X_rescaled=inp["X"] / gl[None, :], sn2new=np.full(N, 0.05))
+Xa = 1.2 * np.random.default_rng(2).standard_normal((100, D))
+stv = dict(st, gplengthscale=gl, ActiveImportanceSampling={"Xa": Xa})
+out["acqwrapper_acqviqr_8192_Na100_ms"] = 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gpn, stv, False, "acqviqr_vbmc", None, engine=eng), 3)
+out["acqviqr_mfma_gflop"] = 2.0 * 8192 * 112 * N * S / 1e9
 # GP hyper-parameter objective: B walkers, value + gradient
 gpd = {"X": inp["X"], "y": inp["y"], "s2": None, "covfun": 1, "Ncov": D + 1, "noisefun": (1, 0, 0), "Nnoise": 1, "meanfun": 4,
        "Nmean": 2 * D + 1, "intmeanfun": 0}

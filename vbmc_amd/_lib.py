@@ -98,6 +98,10 @@ def load():
     lib.vbmc_gp_rank1_solves.argtypes = [vp, vp, _dp, _dp, _dp, _dp]
     lib.vbmc_acq_eval.argtypes = [vp, vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
                                   _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.vbmc_acq_is_create.argtypes = [vp, vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.POINTER(vp)]
+    lib.vbmc_acq_is_free.argtypes = [vp, vp]
+    lib.vbmc_acq_is_free.restype = None
+    lib.vbmc_acq_iqr_eval.argtypes = [vp, vp, vp, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_double, _dp, _dp, _dp]
     lib.vbmc_gp_nlz.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
     lib.vbmc_test_exp.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
     lib.vbmc_sq_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]

@@ -1,8 +1,8 @@
 """Acquisition sweep on the GPU behind the reference's call surface.
 
 ``acqwrapper_vbmc(Xs, vp, gp, optimState, transpose_flag, acqFun, acqInfo)`` (acq/acqwrapper_vbmc.m:1) with the
-density-based acquisition functions ``acqf_vbmc`` (default, vbmc.m:213), ``acqflog_vbmc``, ``acqus_vbmc`` and
-``acqfsn2_vbmc``: GP prediction for every hyper-sample, the hyper-sample statistics, the variational-posterior
+density-based acquisition functions ``acqf_vbmc`` (default, vbmc.m:213), ``acqflog_vbmc``, ``acqus_vbmc``,
+``acqfsn2_vbmc`` and the importance-sampled ``acqviqr_vbmc`` / ``acqimiqr_vbmc`` (noisy targets): GP prediction for every hyper-sample, the hyper-sample statistics, the variational-posterior
 density and the acquisition value are one fused device pass (``vbmc_acq_eval``).  The two steps that need VBMC's
 variable transform -- the integer mapping (:8) and the hard-bound test in the ORIGINAL space (:49-51) -- are the
 caller's: pass the boolean mask of out-of-bounds points as ``outside``.
@@ -15,7 +15,47 @@ from ._lib import VbmcUnsupported, f64, ptr
 from .elbo import default_engine
 from .gplite import _device_gp_with_noise
 
-ACQ_IDS = {"acqf_vbmc": 0, "acqflog_vbmc": 1, "acqus_vbmc": 2, "acqfsn2_vbmc": 3}
+ACQ_IDS = {"acqf_vbmc": 0, "acqflog_vbmc": 1, "acqus_vbmc": 2, "acqfsn2_vbmc": 3, "acqviqr_vbmc": 10, "acqimiqr_vbmc": 11}
+
+
+class ImportanceState:
+    """Device copy of optimState.ActiveImportanceSampling (vbmc_acq_is_create); freed with the object."""
+
+    def __init__(self, engine, dgp, ais):
+        import ctypes as C
+
+        self.ctx = engine.ctx
+        Xa = np.asarray(ais["Xa"], dtype=np.float64)
+        per_s = Xa.ndim == 3
+        Na = Xa.shape[0]
+        xa = f64(Xa.reshape(Na, -1, order="F")) if per_s else f64(Xa)
+        lnw = ais.get("lnw")
+        lnw = None if lnw is None or np.size(lnw) == 0 else f64(np.asarray(lnw, dtype=np.float64).reshape(dgp.S, Na))
+        fs2a = ais.get("fs2a")
+        fs2a = None if fs2a is None else f64(np.asarray(fs2a, dtype=np.float64).reshape(Na, dgp.S))
+        ct = ais.get("Ctmp_mat")
+        ct = None if ct is None else f64(np.asarray(ct, dtype=np.float64).reshape(dgp.N, -1, order="F"))
+        self.h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.vbmc_acq_is_create(self.ctx.h, dgp.h, Na, ptr(xa), int(per_s), ptr(lnw), ptr(fs2a), ptr(ct),
+                                                       C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.vbmc_acq_is_free(self.ctx.h, self.h)
+                self.h = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def _importance_state(engine, dgp, ais):
+    """One-entry cache on the ActiveImportanceSampling dict itself (it is rebuilt once per active-sampling step,
+    private/activesample_vbmc.m:209-212, and then reused by every acquisition call of that step)."""
+    st = ais.get("_device")
+    if st is None or st[0] is not dgp:
+        st = (dgp, ImportanceState(engine, dgp, ais))
+        ais["_device"] = st
+    return st[1]
 
 
 def acq_info(acqFun):
@@ -24,7 +64,11 @@ def acq_info(acqFun):
     name = name.lstrip("@")
     if name not in ACQ_IDS:
         raise VbmcUnsupported(-1, "acquisition function %s is not accelerated" % name)
-    return {"name": name, "log_flag": name == "acqflog_vbmc", "compute_varlogjoint": False}
+    iqr = name in ("acqviqr_vbmc", "acqimiqr_vbmc")
+    info = {"name": name, "log_flag": name == "acqflog_vbmc" or iqr, "compute_varlogjoint": False}
+    if iqr:  # acq/acqviqr_vbmc.m:8-11, acq/acqimiqr_vbmc.m:8-10
+        info.update(importance_sampling=True, importance_sampling_vp=False, variational_importance_sampling=name == "acqviqr_vbmc")
+    return info
 
 
 def acqwrapper_vbmc(Xs, vp, gp, optimState, transpose_flag=False, acqFun="acqf_vbmc", acqInfo=None, *, outside=None,
@@ -53,6 +97,22 @@ def acqwrapper_vbmc(Xs, vp, gp, optimState, transpose_flag=False, acqFun="acqf_v
     lam = f64(np.asarray(vp["lambda"], dtype=np.float64).reshape(D))
     w = f64(np.asarray(vp["w"], dtype=np.float64).reshape(K))
     gl = xr = sn = None
+    if acq_id >= 10:
+        gl = f64(np.asarray(optimState["gplengthscale"], dtype=np.float64).reshape(D))
+        xr = f64(np.asarray(gp["X_rescaled"], dtype=np.float64))
+        sn = f64(np.asarray(gp["sn2new"], dtype=np.float64).reshape(-1))
+        ist = _importance_state(engine, dgp, optimState["ActiveImportanceSampling"])
+        acq = np.zeros(Nstar)
+        fbar = np.zeros(Nstar)
+        vtot = np.zeros(Nstar)
+        ctx.check(ctx.lib.vbmc_acq_iqr_eval(ctx.h, dgp.h, ist.h, Nstar, ptr(Xs), ptr(gl), ptr(xr), ptr(sn),
+                                            int(bool(optimState.get("VarianceRegularizedAcqFcn", False))),
+                                            float(optimState.get("TolGPVar", 0.0)), ptr(acq), ptr(fbar), ptr(vtot)))
+        if outside is not None:
+            acq = np.where(np.asarray(outside, dtype=bool).reshape(-1), np.inf, acq)
+        if transpose_flag:
+            acq = acq.reshape(1, -1)
+        return (acq, fbar, vtot) if nargout >= 3 else acq
     if acq_id == 3:
         gl = f64(np.asarray(optimState["gplengthscale"], dtype=np.float64).reshape(D))
         xr = f64(np.asarray(gp["X_rescaled"], dtype=np.float64))

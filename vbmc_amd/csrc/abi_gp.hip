@@ -505,6 +505,152 @@ extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar
 }
 
 // ------------------------------------------------------------------------------------------
+// Importance-sampling state of the IQR acquisition functions (optimState.ActiveImportanceSampling)
+struct vbmc_acq_is {
+  int Na = 0, Nap = 0, per_s = 0, S = 0, N = 0, D = 0;
+  bool has_lnw = false;
+  double *Xa = nullptr, *CT = nullptr, *fs2a = nullptr, *lnw = nullptr;
+};
+
+extern "C" void vbmc_acq_is_free(vbmc_ctx* ctx, vbmc_acq_is* h) {
+  if (!h) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  for (double* p : {h->Xa, h->CT, h->fs2a, h->lnw})
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+extern "C" vbmc_status vbmc_acq_is_create(vbmc_ctx* ctx, const vbmc_gp* gp, int Na, const double* Xa, int per_sample_inputs,
+                                          const double* lnw, const double* fs2a, const double* Ctmp, vbmc_acq_is** out) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (out) *out = nullptr;
+  if (!gp || !out || Na <= 0 || !Xa) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_is_create: bad arguments");
+  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_is_create needs gp.post(s).L on the device");
+  if (per_sample_inputs && !fs2a)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_is_create: per-hyper-sample importance points need fs2a from the caller");
+  const int N = gp->N, D = gp->D, S = gp->S;
+  const int Nap = ((Na + 15) / 16) * 16;
+  if (Nap > 16 * 16) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "Na = %d > 256 importance points not accelerated", Na);
+  const size_t tlds = TRSM_LDS_BYTES(N);
+  if (tlds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  vbmc_acq_is* h = new vbmc_acq_is();
+  h->Na = Na; h->Nap = Nap; h->per_s = per_sample_inputs ? 1 : 0; h->S = S; h->N = N; h->D = D;
+  const size_t nxa = (size_t)Na * D * (per_sample_inputs ? S : 1);
+  auto fail = [&](vbmc_status st_) { vbmc_acq_is_free(ctx, h); return st_; };
+#define IS_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(set_err(ctx, VBMC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); } while (0)
+  IS_TRY(hipMalloc((void**)&h->Xa, nxa * 8));
+  IS_TRY(hipMalloc((void**)&h->CT, (size_t)S * N * Nap * 8));
+  IS_TRY(hipMalloc((void**)&h->fs2a, (size_t)S * Nap * 8));
+  IS_TRY(hipMemcpyAsync(h->Xa, Xa, nxa * 8, hipMemcpyHostToDevice, st));
+  // lnw (S x Na, column-major as in MATLAB) -> S x Nap rows, -inf in the padding
+  std::vector<double> hb((size_t)S * Nap);
+  if (lnw) {
+    h->has_lnw = true;
+    IS_TRY(hipMalloc((void**)&h->lnw, (size_t)S * Nap * 8));
+    for (int s = 0; s < S; ++s)
+      for (int a = 0; a < Nap; ++a) hb[(size_t)s * Nap + a] = a < Na ? lnw[s + (size_t)S * a] : -INFINITY;
+    IS_TRY(hipMemcpyAsync(h->lnw, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, st));
+    IS_TRY(hipStreamSynchronize(st));
+  }
+  // fs2a (Na x S): given, or gplite_pred at the (shared) importance points
+  std::vector<double> f2((size_t)S * Nap, 0.0);
+  if (fs2a) {
+    for (int s = 0; s < S; ++s)
+      for (int a = 0; a < Na; ++a) f2[(size_t)s * Nap + a] = fs2a[a + (size_t)Na * s];
+  } else {
+    std::vector<double> tmp((size_t)Na * S);
+    vbmc_status ps = vbmc_gp_pred(ctx, gp, Na, Xa, nullptr, 1, nullptr, nullptr, nullptr, tmp.data());
+    if (ps != VBMC_OK) return fail(ps);
+    for (int s = 0; s < S; ++s)
+      for (int a = 0; a < Na; ++a) f2[(size_t)s * Nap + a] = tmp[a + (size_t)Na * s];
+  }
+  IS_TRY(hipMemcpyAsync(h->fs2a, f2.data(), f2.size() * 8, hipMemcpyHostToDevice, st));
+  // Ctmp (N x Na x S): given, or (L\(L'\Kax'))/sn2_eff | L*Kax' computed here (activeimportancesampling_vbmc.m:255-275)
+  TmpBuf dZ, dU;
+  IS_TRY(dZ.alloc(ctx, (size_t)S * N * Na * 8));
+  IS_TRY(dU.alloc(ctx, (size_t)S * N * Na * 8));
+  if (Ctmp) {
+    IS_TRY(hipMemcpyAsync(dU.p, Ctmp, (size_t)S * N * Na * 8, hipMemcpyHostToDevice, st));
+    // already scaled: pack with unit scale (flag array of zeros -> sc = 1)
+    TmpBuf dzero;
+    IS_TRY(dzero.alloc(ctx, S));
+    IS_TRY(hipMemsetAsync(dzero.p, 0, S, st));
+    hipLaunchKernelGGL(k_ctmp_pack, dim3(64, S), dim3(256), 0, st, N, Na, Nap, dU.as<double>(), gp->d_sn2, dzero.as<unsigned char>(), h->CT);
+    IS_TRY(hipGetLastError());
+    IS_TRY(hipStreamSynchronize(st));
+  } else {
+    hipLaunchKernelGGL(k_cross_kernel, dim3(64, S), dim3(256), 0, st, N, D, gp->Nhyp, Na, h->per_s, gp->X, h->Xa, gp->hyp, dZ.as<double>());
+    if (tlds > 64 * 1024) {
+      IS_TRY(hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+      IS_TRY(hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    }
+    hipLaunchKernelGGL(k_symm, dim3(64, S, 1), dim3(256), 0, st, N, Na, S, gp->L, gp->d_lchol, dZ.as<double>(), dU.as<double>());
+    dim3 tg((Na + TR_CB - 1) / TR_CB, S, 1);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, Na, S, gp->L, gp->d_finv, gp->d_lchol, dZ.as<double>());
+    hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, Na, S, gp->L, gp->d_finv, gp->d_lchol, dZ.as<double>(), dU.as<double>());
+    hipLaunchKernelGGL(k_ctmp_pack, dim3(64, S), dim3(256), 0, st, N, Na, Nap, dU.as<double>(), gp->d_sn2, gp->d_lchol, h->CT);
+    IS_TRY(hipGetLastError());
+    IS_TRY(hipStreamSynchronize(st));
+  }
+#undef IS_TRY
+  *out = h;
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_acq_is* is, int Nstar, const double* Xs,
+                                         const double* gplengthscale, const double* X_rescaled, const double* sn2new,
+                                         int var_regularized, double TolGPVar, double* acq, double* fbar, double* vtot) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!is || !acq || !gplengthscale || !X_rescaled || !sn2new) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_iqr_eval: bad arguments");
+  if (gp && (is->N != gp->N || is->S != gp->S || is->D != gp->D))
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_iqr_eval: importance-sampling state belongs to a different GP");
+  if (gp && (gp->noisefun[1] == 1 || gp->noisefun[1] == 2))
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_acq_iqr_eval: noise models that need s2 at the test points are not accelerated");
+  PredBufs pb;
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
+  hipStream_t st = ctx->stream;
+  const int N = gp->N, D = gp->D, S = gp->S;
+  TmpBuf dgl, dXr, dsn, dsx, dacqs, dres;
+  HIP_TRY(ctx, dgl.alloc(ctx, (size_t)D * 8));
+  HIP_TRY(ctx, dXr.alloc(ctx, (size_t)N * D * 8));
+  HIP_TRY(ctx, dsn.alloc(ctx, (size_t)N * 8));
+  HIP_TRY(ctx, dsx.alloc(ctx, (size_t)Nstar * 8));
+  HIP_TRY(ctx, dacqs.alloc(ctx, (size_t)Nstar * S * 8));
+  HIP_TRY(ctx, dres.alloc(ctx, (size_t)3 * Nstar * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(dgl.p, gplengthscale, (size_t)D * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dXr.p, X_rescaled, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dsn.p, sn2new, (size_t)N * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_nn_noise, dim3((Nstar + 255) / 256), dim3(256), 0, st, Nstar, N, D, pb.dXs.as<double>(), dgl.as<double>(),
+                     dXr.as<double>(), dsn.as<double>(), dsx.as<double>());
+  IqrArgs a{};
+  a.N = N; a.D = D; a.S = S; a.Nhyp = gp->Nhyp; a.Nstar = Nstar; a.Na = is->Na; a.Nap = is->Nap; a.per_s = is->per_s;
+  a.Xs = pb.dXs.as<double>(); a.Xa = is->Xa; a.hyp = gp->hyp; a.Xc = pb.dXc.as<double>(); a.muv = pb.dmuv.as<double>();
+  a.CT = is->CT; a.fs2a = is->fs2a; a.lnw = is->has_lnw ? is->lnw : nullptr; a.fs2 = pb.fs2; a.sn2x = dsx.as<double>();
+  a.lchol = gp->d_lchol; a.acqs = dacqs.as<double>();
+  dim3 grid((Nstar + 15) / 16, S);
+  switch (is->Nap / 16) {
+#define IQR_CASE(NT) case NT: hipLaunchKernelGGL((k_acq_iqr<NT>), grid, dim3(64), 0, st, a); break;
+    IQR_CASE(1) IQR_CASE(2) IQR_CASE(3) IQR_CASE(4) IQR_CASE(5) IQR_CASE(6) IQR_CASE(7) IQR_CASE(8)
+    IQR_CASE(9) IQR_CASE(10) IQR_CASE(11) IQR_CASE(12) IQR_CASE(13) IQR_CASE(14) IQR_CASE(15) IQR_CASE(16)
+#undef IQR_CASE
+    default: return set_err(ctx, VBMC_ERR_UNSUPPORTED, "Na = %d not accelerated", is->Na);
+  }
+  double* r = dres.as<double>();
+  hipLaunchKernelGGL(k_iqr_final, dim3((Nstar + 255) / 256), dim3(256), 0, st, Nstar, S, var_regularized ? 1 : 0, TolGPVar,
+                     dacqs.as<double>(), pb.fmu, pb.fs2, r, r + Nstar, r + 2 * (size_t)Nstar);
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<double> hres((size_t)3 * Nstar);
+  HIP_TRY(ctx, hipMemcpyAsync(hres.data(), dres.p, hres.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  memcpy(acq, hres.data(), (size_t)Nstar * 8);
+  if (fbar) memcpy(fbar, hres.data() + Nstar, (size_t)Nstar * 8);
+  if (vtot) memcpy(vtot, hres.data() + 2 * (size_t)Nstar, (size_t)Nstar * 8);
+  return VBMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // The O(N^2) pieces of the rank-1 append (gplite_post.m:210-237) for every hyper-sample:
 //   Ks = k(X, x*);  Lchol: v = L' \ Ks, x = L \ v  (alpha_update = x / sn2_eff, new column = v / sn2_eff)
 //                   else : x = L * Ks               (alpha_update = -x)

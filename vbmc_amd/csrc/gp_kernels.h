@@ -718,3 +718,203 @@ __global__ void __launch_bounds__(256) k_acq(AcqArgs a) {
   if (a.fbar) a.fbar[i] = fbar;
   if (a.vtot) a.vtot[i] = vtot;
 }
+
+// ------------------------------------------------------------------------------------------
+// Importance-sampled IQR acquisition functions (acq/acqviqr_vbmc.m:50-109, acq/acqimiqr_vbmc.m:40-95) and the
+// Step-3 precomputation of private/activeimportancesampling_vbmc.m:248-276.
+// ------------------------------------------------------------------------------------------
+// Kax'[s] (N x Na, column a at a*N): k_s(X_n, Xa_a)  (:264-265)
+__global__ void __launch_bounds__(256) k_cross_kernel(int N, int D, int Nhyp, int Na, int per_s, const double* __restrict__ X,
+                                                      const double* __restrict__ Xa /* Na x D (x S) col-major */,
+                                                      const double* __restrict__ hyp, double* __restrict__ Z) {
+  const int s = blockIdx.y;
+  const double* h = hyp + (size_t)s * Nhyp;
+  __shared__ double iell[32];
+  if (threadIdx.x < D) iell[threadIdx.x] = 1.0 / exp(h[threadIdx.x]);
+  __syncthreads();
+  const double sf2 = exp(2.0 * h[D]);
+  const double* xa = Xa + (per_s ? (size_t)s * Na * D : 0);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)N * Na; idx += (size_t)gridDim.x * 256) {
+    const int n = (int)(idx % N), a = (int)(idx / N);
+    double c = 0.0;
+    for (int d = 0; d < D; ++d) { const double t = (X[n + (size_t)N * d] - xa[a + (size_t)Na * d]) * iell[d]; c = fma(t, t, c); }
+    Z[(size_t)s * N * Na + idx] = sf2 * exp(-c / 2.0);
+  }
+}
+
+// CtmpT[s][n][a] (a fastest, padded to Nap with zeros) = U[s][a*N + n] / sn2_eff (Lchol, :271) or U (else, :273)
+__global__ void __launch_bounds__(256) k_ctmp_pack(int N, int Na, int Nap, const double* __restrict__ U,
+                                                   const double* __restrict__ sn2_eff, const unsigned char* __restrict__ lchol,
+                                                   double* __restrict__ CT) {
+  const int s = blockIdx.y;
+  const double sc = lchol[s] ? 1.0 / sn2_eff[s] : 1.0;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)N * Nap; idx += (size_t)gridDim.x * 256) {
+    const int a = (int)(idx % Nap), n = (int)(idx / Nap);
+    CT[(size_t)s * N * Nap + idx] = a < Na ? U[(size_t)s * N * Na + (size_t)a * N + n] * sc : 0.0;
+  }
+}
+
+// observation noise at the nearest training input in length-scale units (acqviqr_vbmc.m:42-43); first minimum wins
+__global__ void __launch_bounds__(256) k_nn_noise(int Nstar, int N, int D, const double* __restrict__ Xs, const double* __restrict__ gl,
+                                                  const double* __restrict__ Xr, const double* __restrict__ sn2new,
+                                                  double* __restrict__ sn2x) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nstar) return;
+  double x[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) x[d] = d < D ? Xs[i + (size_t)Nstar * d] / gl[d] : 0.0;
+  double best = INFINITY;
+  int pos = 0;
+  for (int n = 0; n < N; ++n) {
+    double c = 0.0;
+#pragma unroll
+    for (int d = 0; d < 32; ++d)
+      if (d < D) { const double t = x[d] - Xr[n + (size_t)N * d]; c = fma(t, t, c); }
+    if (c < best) { best = c; pos = n; }
+  }
+  sn2x[i] = sn2new[pos];
+}
+
+struct IqrArgs {
+  int N, D, S, Nhyp, Nstar, Na, Nap, per_s;
+  const double* Xs;      // Nstar x D col-major
+  const double* Xa;      // Na x D (x S) col-major
+  const double* hyp;     // Nhyp x S
+  const double* Xc;      // S x N x D   ell-scaled, centred training inputs (k_pred_prep)
+  const double* muv;     // S x 2D      centre, 1/ell
+  const double* CT;      // S x N x Nap
+  const double* fs2a;    // S x Nap
+  const double* lnw;     // S x Nap (-inf in the padding) or null
+  const double* fs2;     // Nstar x S   (k_gp_pred)
+  const double* sn2x;    // Nstar
+  const unsigned char* lchol;
+  double* acqs;          // Nstar x S
+};
+
+// One wave = 16 test points x one hyper-sample.  C[i][a] = Ka[i][a] -/+ sum_n Ks[n][i] Ctmp[n][a] on the fp64 matrix
+// cores: the A operand Ks[n][i] = k_s(X_n, xs_i) is produced in registers on the fly (each element exactly once), the
+// B operand streams CtmpT rows (16 consecutive a per lane group), NT = Nap/16 accumulator tiles live at once.
+// Epilogue per element: tau2 = C^2/ys2_i, s_pred = sqrt(max(fs2a_a - tau2, 0)), zz = lnw_a + u s + log1p(-exp(-2 u s)),
+// then a log-sum-exp over a (16 lanes x NT tiles).
+template <int NT>
+__global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
+  __shared__ double xs_s[16][33];   // ell-scaled, centred test points of the tile
+  __shared__ double ys2_s[16];
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int i0 = blockIdx.x * 16, s = blockIdx.y;
+  const int N = a.N, D = a.D, Nap = a.Nap;
+  const double* h = a.hyp + (size_t)s * a.Nhyp;
+  const double sf2 = exp(2.0 * h[D]);
+  const double* mu = a.muv + (size_t)s * 2 * D;
+  const double* iell = mu + D;
+  for (int idx = lane; idx < 16 * D; idx += 64) {
+    const int i = idx / D, d = idx % D;
+    const int gi = min(i0 + i, a.Nstar - 1);
+    xs_s[i][d] = a.Xs[gi + (size_t)a.Nstar * d] * iell[d] - mu[d];
+  }
+  if (lane < 16) {
+    const int gi = min(i0 + lane, a.Nstar - 1);
+    ys2_s[lane] = a.fs2[gi + (size_t)a.Nstar * s] + a.sn2x[gi];
+  }
+  __syncthreads();
+  double xi[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) xi[d] = d < D ? xs_s[li][d] : 0.0;
+  d4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  const double* xc = a.Xc + (size_t)s * N * D;
+  const double* ct = a.CT + (size_t)s * N * Nap;
+  for (int n0 = 0; n0 < N; n0 += 4) {
+    const int n = n0 + lg;
+    double kv = 0.0;
+    if (n < N) {
+      double c = 0.0;
+#pragma unroll
+      for (int d = 0; d < 32; ++d)
+        if (d < D) { const double t = xi[d] - xc[(size_t)n * D + d]; c = fma(t, t, c); }
+      kv = sf2 * exp(-c / 2.0);
+    }
+    const double* row = ct + (size_t)min(n, N - 1) * Nap + li;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double b = (n < N) ? row[16 * t] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv, b, acc[t], 0, 0, 0);
+    }
+  }
+  // epilogue: lane (li, lg) holds C'[i = lg + 4r][a = 16t + li]
+  const double u = 0.6745;
+  const double sgn = a.lchol[s] ? -1.0 : 1.0;
+  const double* xa = a.Xa + (a.per_s ? (size_t)s * a.Na * D : 0);
+  double zz[NT][4];
+  double mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int aa_ = 16 * t + li;
+    const bool av = aa_ < a.Na;
+    double xad[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) xad[d] = (d < D && av) ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0;
+    const double fa = av ? a.fs2a[(size_t)s * Nap + aa_] : 0.0;
+    const double lw = av ? (a.lnw ? a.lnw[(size_t)s * Nap + aa_] : 0.0) : -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = lg + 4 * r;
+      double c = 0.0;
+#pragma unroll
+      for (int d = 0; d < 32; ++d)
+        if (d < D) { const double tt = xs_s[i][d] - xad[d]; c = fma(tt, tt, c); }
+      const double ka = sf2 * exp(-c / 2.0);
+      const double C = ka + sgn * acc[t][r];
+      const double tau2 = C * C / ys2_s[i];
+      const double sp = sqrt(fmax(fa - tau2, 0.0));
+      const double z = av ? lw + (u * sp + log1p(-exp(-2.0 * u * sp))) : -INFINITY;
+      zz[t][r] = z;
+      mx[r] = fmax(mx[r], z);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double m = mx[r];
+    m = fmax(m, __shfl_xor(m, 1, 64)); m = fmax(m, __shfl_xor(m, 2, 64));
+    m = fmax(m, __shfl_xor(m, 4, 64)); m = fmax(m, __shfl_xor(m, 8, 64));
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sum += exp(zz[t][r] - m);   // all -inf: -inf - -inf = NaN, as in MATLAB
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
+    const int gi = i0 + lg + 4 * r;
+    if (li == 0 && gi < a.Nstar) a.acqs[gi + (size_t)a.Nstar * s] = log(sum) + m;
+  }
+}
+
+// acq = M + log(sum(exp(acq_s - M))/Ns) over hyper-samples (:104-107), then the log-flag variance regulariser and the
+// clamp of acq/acqwrapper_vbmc.m:35-46; also fbar / vtot (:21-29)
+__global__ void __launch_bounds__(256) k_iqr_final(int Nstar, int S, int reg, double TolVar, const double* __restrict__ acqs,
+                                                   const double* __restrict__ fmu, const double* __restrict__ fs2,
+                                                   double* __restrict__ acq, double* __restrict__ fbar_o, double* __restrict__ vtot_o) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Nstar) return;
+  double fbar = 0.0, vbar = 0.0;
+  for (int s = 0; s < S; ++s) { fbar += fmu[i + (size_t)Nstar * s]; vbar += fs2[i + (size_t)Nstar * s]; }
+  fbar /= S; vbar /= S;
+  double vf = 0.0;
+  if (S > 1) {
+    for (int s = 0; s < S; ++s) { const double d = fmu[i + (size_t)Nstar * s] - fbar; vf += d * d; }
+    vf /= (S - 1);
+  }
+  const double vtot = vf + vbar;
+  double v;
+  if (S > 1) {
+    double M = -INFINITY;
+    for (int s = 0; s < S; ++s) M = fmax(M, acqs[i + (size_t)Nstar * s]);
+    double sum = 0.0;
+    for (int s = 0; s < S; ++s) sum += exp(acqs[i + (size_t)Nstar * s] - M);
+    v = M + log(sum / S);
+  } else v = acqs[i];
+  if (reg && vtot < TolVar) v = v + TolVar / vtot - 1.0;
+  v = fmax(v, -1.7976931348623157e308);
+  acq[i] = v;
+  if (fbar_o) fbar_o[i] = fbar;
+  if (vtot_o) vtot_o[i] = vtot;
+}
