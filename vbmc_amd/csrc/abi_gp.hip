@@ -622,7 +622,7 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   HIP_TRY(ctx, hipMemcpyAsync(dgl.p, gplengthscale, (size_t)D * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dXr.p, X_rescaled, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dsn.p, sn2new, (size_t)N * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_nn_noise, dim3((Nstar + 255) / 256), dim3(256), 0, st, Nstar, N, D, pb.dXs.as<double>(), dgl.as<double>(),
+  hipLaunchKernelGGL(k_nn_noise, dim3((Nstar + 63) / 64), dim3(64), 0, st, Nstar, N, D, pb.dXs.as<double>(), dgl.as<double>(),
                      dXr.as<double>(), dsn.as<double>(), dsx.as<double>());
   IqrArgs a{};
   a.N = N; a.D = D; a.S = S; a.Nhyp = gp->Nhyp; a.Nstar = Nstar; a.Na = is->Na; a.Nap = is->Nap; a.per_s = is->per_s;

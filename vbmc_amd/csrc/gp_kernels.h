@@ -755,24 +755,29 @@ __global__ void __launch_bounds__(256) k_ctmp_pack(int N, int Na, int Nap, const
 }
 
 // observation noise at the nearest training input in length-scale units (acqviqr_vbmc.m:42-43); first minimum wins
-__global__ void __launch_bounds__(256) k_nn_noise(int Nstar, int N, int D, const double* __restrict__ Xs, const double* __restrict__ gl,
-                                                  const double* __restrict__ Xr, const double* __restrict__ sn2new,
-                                                  double* __restrict__ sn2x) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Nstar) return;
-  double x[32];
-#pragma unroll
-  for (int d = 0; d < 32; ++d) x[d] = d < D ? Xs[i + (size_t)Nstar * d] / gl[d] : 0.0;
+__global__ void __launch_bounds__(64) k_nn_noise(int Nstar, int N, int D, const double* __restrict__ Xs, const double* __restrict__ gl,
+                                                 const double* __restrict__ Xr, const double* __restrict__ sn2new,
+                                                 double* __restrict__ sn2x) {
+  __shared__ double xr_s[64][33];   // a chunk of 64 training rows, [n][d]
+  __shared__ double x_s[64][33];    // this block's 64 test points in length-scale units
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int gi = min(i, Nstar - 1);
+  for (int d = 0; d < D; ++d) x_s[threadIdx.x][d] = Xs[gi + (size_t)Nstar * d] / gl[d];
   double best = INFINITY;
   int pos = 0;
-  for (int n = 0; n < N; ++n) {
-    double c = 0.0;
-#pragma unroll
-    for (int d = 0; d < 32; ++d)
-      if (d < D) { const double t = x[d] - Xr[n + (size_t)N * d]; c = fma(t, t, c); }
-    if (c < best) { best = c; pos = n; }
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    __syncthreads();
+    const int nl = min(64, N - c0);
+    if ((int)threadIdx.x < nl)
+      for (int d = 0; d < D; ++d) xr_s[threadIdx.x][d] = Xr[c0 + threadIdx.x + (size_t)N * d];
+    __syncthreads();
+    for (int n = 0; n < nl; ++n) {
+      double c = 0.0;
+      for (int d = 0; d < D; ++d) { const double t = x_s[threadIdx.x][d] - xr_s[n][d]; c = fma(t, t, c); }
+      if (c < best) { best = c; pos = c0 + n; }
+    }
   }
-  sn2x[i] = sn2new[pos];
+  if (i < Nstar) sn2x[i] = sn2new[pos];
 }
 
 struct IqrArgs {
@@ -817,30 +822,39 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
     ys2_s[lane] = a.fs2[gi + (size_t)a.Nstar * s] + a.sn2x[gi];
   }
   __syncthreads();
-  double xi[32];
-#pragma unroll
-  for (int d = 0; d < 32; ++d) xi[d] = d < D ? xs_s[li][d] : 0.0;
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
   const double* xc = a.Xc + (size_t)s * N * D;
   const double* ct = a.CT + (size_t)s * N * Nap;
-  for (int n0 = 0; n0 < N; n0 += 4) {
-    const int n = n0 + lg;
-    double kv = 0.0;
-    if (n < N) {
-      double c = 0.0;
-#pragma unroll
-      for (int d = 0; d < 32; ++d)
-        if (d < D) { const double t = xi[d] - xc[(size_t)n * D + d]; c = fma(t, t, c); }
-      kv = sf2 * exp(-c / 2.0);
-    }
+  const double* xrow = &xs_s[li][0];
+  // software pipeline: the B operands (CtmpT row n, 16 consecutive a per tile) of step n0 + 4 are in flight while the
+  // A operand of step n0 (one kernel value per lane) is computed and the NT MFMAs of step n0 issue
+  double bcur[NT], bnxt[NT];
+  {
+    const int n = lg;
     const double* row = ct + (size_t)min(n, N - 1) * Nap + li;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const double b = (n < N) ? row[16 * t] : 0.0;
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv, b, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) bcur[t] = (n < N) ? row[16 * t] : 0.0;
+  }
+  for (int n0 = 0; n0 < N; n0 += 4) {
+    const int n = n0 + lg, nn = n + 4;
+    {
+      const double* row = ct + (size_t)min(nn, N - 1) * Nap + li;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bnxt[t] = (nn < N) ? row[16 * t] : 0.0;
     }
+    double kv = 0.0;
+    if (n < N) {
+      const double* xn = xc + (size_t)n * D;
+      double c = 0.0;
+      for (int d = 0; d < D; ++d) { const double t = xrow[d] - xn[d]; c = fma(t, t, c); }
+      kv = sf2 * exp(-c / 2.0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv, bcur[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bcur[t] = bnxt[t];
   }
   // epilogue: lane (li, lg) holds C'[i = lg + 4r][a = 16t + li]
   const double u = 0.6745;
@@ -852,19 +866,18 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
   for (int t = 0; t < NT; ++t) {
     const int aa_ = 16 * t + li;
     const bool av = aa_ < a.Na;
-    double xad[32];
+    double c4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int d = 0; d < D; ++d) {
+      const double xv = av ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0;
 #pragma unroll
-    for (int d = 0; d < 32; ++d) xad[d] = (d < D && av) ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0;
+      for (int r = 0; r < 4; ++r) { const double tt = xs_s[lg + 4 * r][d] - xv; c4[r] = fma(tt, tt, c4[r]); }
+    }
     const double fa = av ? a.fs2a[(size_t)s * Nap + aa_] : 0.0;
     const double lw = av ? (a.lnw ? a.lnw[(size_t)s * Nap + aa_] : 0.0) : -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lg + 4 * r;
-      double c = 0.0;
-#pragma unroll
-      for (int d = 0; d < 32; ++d)
-        if (d < D) { const double tt = xs_s[i][d] - xad[d]; c = fma(tt, tt, c); }
-      const double ka = sf2 * exp(-c / 2.0);
+      const double ka = sf2 * exp(-c4[r] / 2.0);
       const double C = ka + sgn * acc[t][r];
       const double tau2 = C * C / ys2_s[i];
       const double sp = sqrt(fmax(fa - tau2, 0.0));
