@@ -205,6 +205,7 @@ extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
   if (gp->d_lchol) (void)hipFree(gp->d_lchol);
   if (gp->d_mult) (void)hipFree(gp->d_mult);
   if (gp->d_finv) (void)hipFree(gp->d_finv);
+  if (gp->d_tinv) (void)hipFree(gp->d_tinv);
   if (gp->d_meanX) (void)hipFree(gp->d_meanX);
   delete gp;
 }

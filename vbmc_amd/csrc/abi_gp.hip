@@ -372,10 +372,23 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   if ((gp->noisefun[1] == 1 || gp->noisefun[1] == 2) && !s2star)
     return set_err(ctx, VBMC_ERR_INVALID, "gplite_pred: S2STAR is required by the noise function");
   const int N = gp->N, D = gp->D, S = gp->S;
-  const size_t plds = TRSM_LDS_BYTES(N) + (size_t)16 * 32 * 8;
-  if (plds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
+  const size_t plds = PRED_LDS_BYTES(N);
+  const size_t tlds0 = TRSM_LDS_BYTES(N);
+  if (plds > 160 * 1024 || tlds0 > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  if (!gp->d_tinv) {
+    // Tinv = inv(L') = L' \ I for the Lchol samples, once per GP (the kernels skip the others)
+    double* t = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&t, (size_t)S * N * N * 8));
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, t);
+    if (tlds0 > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds0));
+    hipLaunchKernelGGL(k_trsm_fwd, dim3((N + TR_CB - 1) / TR_CB, S, 1), dim3(64), tlds0, st, N, N, S, gp->L, gp->d_finv, gp->d_lchol, t);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { (void)hipFree(t); return set_err(ctx, VBMC_ERR_HIP, "inv(L') failed: %s", hipGetErrorString(e_)); }
+    gp->d_tinv = t;
+  }
   // column means for sq_dist's centring (sq_dist.m:36), O((N + Nstar) D) on the host in MATLAB's order
   std::vector<double> mb(D);
   for (int d = 0; d < D; ++d) {
@@ -401,13 +414,13 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   pa.moff = gp->Ncov + gp->Nnoise; pa.noff = gp->Ncov; pa.nf0 = gp->noisefun[0]; pa.nf1 = gp->noisefun[1];
   pa.X = gp->X; pa.Xs = dXs.as<double>(); pa.s2s = s2star ? ds2.as<double>() : nullptr; pa.hyp = gp->hyp;
   pa.alpha = gp->alpha; pa.L = gp->L; pa.sn2_eff = gp->d_sn2; pa.sn2_mult = gp->d_mult; pa.lchol = gp->d_lchol;
-  pa.mean_a = gp->d_meanX; pa.mean_b = dmb.as<double>(); pa.finv = gp->d_finv;
+  pa.mean_a = gp->d_meanX; pa.mean_b = dmb.as<double>(); pa.finv = gp->d_finv; pa.tinv = gp->d_tinv;
   pa.fmu = dout.as<double>(); pa.fs2 = pa.fmu + (size_t)Nstar * S; pa.ys2 = pa.fs2 + (size_t)Nstar * S;
   pb.fmu = pa.fmu; pb.fs2 = pa.fs2; pb.ys2 = pa.ys2;
   hipLaunchKernelGGL(k_pred_prep, dim3(4, S), dim3(256), 0, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
   if (plds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-  hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(64), plds, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
+  hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(PRED_THREADS), plds, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;
 }

@@ -92,6 +92,7 @@ struct vbmc_gp {
   unsigned char* d_lchol = nullptr;  // S
   double* d_mult = nullptr;   // S  sn2_mult (prediction)
   double* d_finv = nullptr;   // S x nblk x 256: inverses of the 16 x 16 diagonal blocks of L' (trsm_mfma.h)
+  mutable double* d_tinv = nullptr;  // S x N x N: inv(L') per Lchol sample (built on the first prediction, abi_gp.hip)
   double* d_meanX = nullptr;  // D  column means of X (sq_dist centring in gplite_pred)
   int noisefun[3] = {1, 0, 0};
   bool has_noise = false;

@@ -11,8 +11,8 @@
 //                   reports MATLAB's p (> 0 = not positive definite) for the jitter retry
 //   k_gp_resid      r = y - m(X)
 //   k_pred_prep     ell-scaled, sq_dist-centred training inputs per hyper-sample
-//   k_gp_pred       one wave per 16 test points: cross-kernel slab -> fmu = m* + Ks'alpha, V = L'\(sW.*Ks) by the
-//                   MFMA triangular solve (trsm_mfma.h), fs2 = kss - |V|^2
+//   k_gp_pred       four waves per 16 test points: cross-kernel slab -> fmu = m* + Ks'alpha, V = inv(L')*(sW.*Ks) as
+//                   MFMA products against the precomputed triangular inverse, fs2 = kss - |V|^2
 //   k_pred_avg      hyper-sample averaging with between-sample variance (gplite_pred.m:154-165)
 #pragma once
 #include "common.h"
@@ -329,6 +329,7 @@ struct PredArgs {
   const double* mean_a;  // D  column means of X
   const double* mean_b;  // D  column means of Xstar
   const double* finv;    // S x nblk x 256 inverse diagonal blocks (k_diag_inv)
+  const double* tinv;    // S x N x N  inv(L') per Lchol sample, element (row, col) at col*N + row
   double* fmu;           // Nstar x S
   double* fs2;
   double* ys2;
@@ -361,26 +362,36 @@ __global__ void __launch_bounds__(256) k_pred_prep(PredArgs a, double* __restric
   }
 }
 
-// k_gp_pred: one wave = 16 test points x one hyper-sample.  The cross-kernel slab Ks (N x 16) is built
-// in LDS, fmu = m* + Ks' alpha is accumulated on the way, then V = L' \ (sW .* Ks) by the MFMA
-// triangular solve (trsm_mfma.h) and fs2 = kss - sum(V.^2)  (gplite_pred.m:73-104).
-__global__ void __launch_bounds__(64) k_gp_pred(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
-                                                const double* __restrict__ muv) {
+// k_gp_pred: one 4-wave workgroup = 16 test points x one hyper-sample.
+//   phase 1  all 256 lanes build the cross-kernel slab Ks (N x 16, sW-scaled) in LDS and fmu = m* + Ks' alpha (:74-83)
+//   phase 2  V = L' \ (sW .* Ks) as the product Tinv * (sW .* Ks) with Tinv = inv(L') precomputed once per GP
+//            (k_trsm_fwd on the identity): no sequential substitution, the 16-row output tiles are dealt to the four
+//            waves (balanced over the triangle), each tile a chain of v_mfma_f64_16x16x4_f64 with the Tinv operand
+//            streamed from L2 one step ahead and the Ks operand read from LDS; fs2 = kss - sum(V.^2)  (:99-100).
+//            Low-noise samples (Lchol = false, L = -inv(K + sn2 I)): U = L * Ks over the full row, fs2 = kss +
+//            sum(Ks .* U)  (:103-104) through the same loop.
+// |inv(L')| <= 1 because L'L = K/sl + I >= I, so the explicit inverse is as well conditioned as the substitution.
+#define PRED_THREADS 256
+#define PRED_LDS_BYTES(N) ((size_t)((((((N) + 15) >> 4) << 4) * 16) + 16 * 32 + 64 + 64) * sizeof(double))
+__global__ void __launch_bounds__(PRED_THREADS) k_gp_pred(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
+                                                          const double* __restrict__ muv) {
   extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
-  const int li = lane & 15, lg = lane >> 4;
+  const int cb = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int N = a.N, D = a.D;
   const int Np = ((N + 15) >> 4) << 4;
-  double* V = lds;                        // Np x TR_VS
-  double* Pn = V + (size_t)Np * TR_VS;    // 64 x TR_VS panel staging of the triangular solve
-  double* xs = Pn + 64 * TR_VS;           // 16 x 32 scaled centred test points
+  double* V = lds;                        // Np x 16: (sW .* Ks)[n][point]
+  double* xs = V + (size_t)Np * 16;       // 16 x 32 scaled centred test points
+  double* redf = xs + 16 * 32;            // 4 x 16 fmu partials
+  double* redv = redf + 64;               // 4 x 16 variance partials
   const double* h = a.hyp + (size_t)s * a.Nhyp;
   const double* mu = muv + (size_t)s * 2 * D;
   const double* iell = mu + D;
   const int jc = cb * 16 + li;
   const bool cv = jc < a.Nstar;
   const double sf2 = exp(2.0 * h[D]);
-  for (int d = lg; d < D; d += 4) xs[li * 32 + d] = cv ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
+  if (wave == 0)
+    for (int d = lg; d < D; d += 4) xs[li * 32 + d] = cv ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
   __syncthreads();
   double bb = 0.0;
   for (int d = 0; d < D; ++d) bb = fma(xs[li * 32 + d], xs[li * 32 + d], bb);
@@ -390,7 +401,7 @@ __global__ void __launch_bounds__(64) k_gp_pred(PredArgs a, const double* __rest
   const bool lc = a.lchol[s] != 0;
   const double sW = lc ? 1.0 / sqrt(a.sn2_eff[s]) : 1.0;
   double fm = 0.0;
-  for (int i = lg; i < Np; i += 4) {
+  for (int i = wave * 4 + lg; i < Np; i += 16) {
     double ks = 0.0;
     if (i < N) {
       double dot = 0.0;
@@ -399,44 +410,48 @@ __global__ void __launch_bounds__(64) k_gp_pred(PredArgs a, const double* __rest
       ks = sf2 * exp(-cdist / 2.0);                                  // gplite_pred.m:74
       fm = fma(ks, al[i], fm);
     }
-    V[i * TR_VS + li] = ks * sW;                                     // sW .* Ks (:99); plain Ks when !Lchol
+    V[i * 16 + li] = ks * sW;                                        // sW .* Ks (:99); plain Ks when !Lchol
   }
   fm += __shfl_xor(fm, 16, 64);
   fm += __shfl_xor(fm, 32, 64);
-  double mstar = 0.0;
-  if (cv) mstar = gp_meanfun(a.meanfun, D, h + a.moff, a.Xs + jc, (size_t)a.Nstar);
-  const double fmu = mstar + fm;                                     // :83
+  if (lg == 0) redf[wave * 16 + li] = fm;
   __syncthreads();
-  const double* Rm = a.L + (size_t)s * N * N;
-  double fs2;
-  if (lc) {
-    trsm_fwd_wave(N, Rm, a.finv + (size_t)s * TRSM_NBLK(N) * 256, V, Pn, lane);
-    double part = 0.0;
-    for (int i = lg; i < N; i += 4) part = fma(V[i * TR_VS + li], V[i * TR_VS + li], part);
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    fs2 = sf2 - part;                                                // kss - sum(V.*V)  (:100)
-  } else {
-    // fs2 = kss + sum(Ks .* (L*Ks))  (:103-104): U_b = L[b,:] * Ks by MFMA, 16 rows at a time
-    double part = 0.0;
-    const int nblk = Np >> 4;
-    for (int bi = 0; bi < nblk; ++bi) {
-      const int b0 = bi << 4;
-      tmf4 acc = {0.0, 0.0, 0.0, 0.0};
-      const bool rv = b0 + li < N;
-      for (int j0 = 0; j0 < Np; j0 += 4) {
-        const int j = j0 + lg;
-        const double av = (rv && j < N) ? Rm[(size_t)j * N + b0 + li] : 0.0;   // L[b0+li][j] (symmetric storage, full)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, V[j * TR_VS + li], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part = fma(V[(b0 + lg + 4 * r) * TR_VS + li], acc[r], part);
+  // ---- phase 2
+  const double* Am = (lc ? a.tinv : a.L) + (size_t)s * N * N;   // element (row, col) at col*N + row (Tinv lower-triangular; L symmetric)
+  const int nblk = Np >> 4;
+  double part = 0.0;
+  for (int bi = 0; bi < nblk; ++bi) {
+    const int g = bi >> 2, m = bi & 3;
+    if (((g & 1) ? 3 - m : m) != wave) continue;                    // snake dealing: balanced triangle
+    const int b0 = bi << 4;
+    const int jend = lc ? b0 + 16 : Np;
+    const bool rv = b0 + li < N;
+    tmf4 acc = {0.0, 0.0, 0.0, 0.0};
+    double acur = (rv && lg < N) ? Am[(size_t)lg * N + b0 + li] : 0.0;
+    for (int j0 = 0; j0 < jend; j0 += 4) {
+      const int jn = j0 + 4 + lg;
+      const double anxt = (rv && jn < N && j0 + 4 < jend) ? Am[(size_t)jn * N + b0 + li] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(acur, V[(j0 + lg) * 16 + li], acc, 0, 0, 0);
+      acur = anxt;
     }
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    fs2 = sf2 + part;
+    if (lc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fma(acc[r], acc[r], part);                          // sum(V.*V)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fma(V[(b0 + lg + 4 * r) * 16 + li], acc[r], part);  // sum(Ks .* (L*Ks))
+    }
   }
-  if (lg == 0 && cv) {
+  part += __shfl_xor(part, 16, 64);
+  part += __shfl_xor(part, 32, 64);
+  if (lg == 0) redv[wave * 16 + li] = part;
+  __syncthreads();
+  if (wave == 0 && lg == 0 && cv) {
+    const double fmt = (redf[li] + redf[16 + li]) + (redf[32 + li] + redf[48 + li]);
+    const double pv = (redv[li] + redv[16 + li]) + (redv[32 + li] + redv[48 + li]);
+    const double mstar = gp_meanfun(a.meanfun, D, h + a.moff, a.Xs + jc, (size_t)a.Nstar);
+    const double fmu = mstar + fmt;                                  // :83
+    double fs2 = lc ? sf2 - pv : sf2 + pv;                           // :100 / :104
     fs2 = fmax(fs2, 0.0);  // :120
     // noise at the test points (gplite_noisefun.m:176-194; the output-dependent term needs ystar: not here)
     double sn2s = a.nf0 ? exp(2.0 * h[a.noff]) : 2.220446049250313e-16;
