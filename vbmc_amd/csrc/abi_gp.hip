@@ -357,7 +357,7 @@ extern "C" vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32
 // ------------------------------------------------------------------------------------------
 namespace {
 struct PredBufs {
-  TmpBuf dXs, ds2, dmb, dout, dXc, daa, dmuv;
+  TmpBuf dXs, ds2, dmb, dout, dXc, daa, dmuv, dgrp, dpV, dpF, dKs;
   double *fmu = nullptr, *fs2 = nullptr, *ys2 = nullptr;   // Nstar x S each, inside dout
 };
 
@@ -372,9 +372,9 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   if ((gp->noisefun[1] == 1 || gp->noisefun[1] == 2) && !s2star)
     return set_err(ctx, VBMC_ERR_INVALID, "gplite_pred: S2STAR is required by the noise function");
   const int N = gp->N, D = gp->D, S = gp->S;
-  const size_t plds = PRED_LDS_BYTES(N);
+  const int Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
   const size_t tlds0 = TRSM_LDS_BYTES(N);
-  if (plds > 160 * 1024 || tlds0 > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
+  if ((size_t)16 * Np * 8 > PRED_LDS_MAX || nblk > PRED_MAXG || tlds0 > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   if (!gp->d_tinv) {
@@ -418,9 +418,52 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   pa.fmu = dout.as<double>(); pa.fs2 = pa.fmu + (size_t)Nstar * S; pa.ys2 = pa.fs2 + (size_t)Nstar * S;
   pb.fmu = pa.fmu; pb.fs2 = pa.fs2; pb.ys2 = pa.ys2;
   hipLaunchKernelGGL(k_pred_prep, dim3(4, S), dim3(256), 0, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
-  if (plds > 64 * 1024)
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-  hipLaunchKernelGGL(k_gp_pred, dim3((Nstar + 15) / 16, S), dim3(PRED_THREADS), plds, st, pa, dXc.as<double>(), daa.as<double>(), dmuv.as<double>());
+  // resident row blocks of Tinv per hyper-sample: consecutive 16-row tiles, balanced by area (tile b costs b + 1),
+  // bounded by PRED_MAXR tiles and PRED_LDS_MAX bytes of LDS (two workgroups per CU)
+  std::vector<int> grp((size_t)S + 2 * (size_t)S * PRED_MAXG, 0);
+  int maxg = 0;
+  size_t maxlds = 0;
+  for (int s = 0; s < S; ++s) {
+    int ng = 0;
+    if (gp->Lchol[s]) {
+      int t0 = 0;
+      for (int b = 0; b < nblk; ++b) {
+        const int R = b - t0 + 1;
+        const size_t lds_need = (size_t)R * 16 * (size_t)(b + 1) * 16 * 8;
+        if (b > t0 && (R > PRED_MAXR || lds_need > PRED_LDS_MAX)) {
+          grp[S + (size_t)s * PRED_MAXG + ng] = t0; grp[S + (size_t)S * PRED_MAXG + (size_t)s * PRED_MAXG + ng] = b; ++ng;
+          maxlds = std::max(maxlds, (size_t)(b - t0) * 16 * (size_t)b * 16 * 8);
+          t0 = b;
+        }
+      }
+      grp[S + (size_t)s * PRED_MAXG + ng] = t0; grp[S + (size_t)S * PRED_MAXG + (size_t)s * PRED_MAXG + ng] = nblk; ++ng;
+      maxlds = std::max(maxlds, (size_t)(nblk - t0) * 16 * (size_t)nblk * 16 * 8);
+    } else {
+      for (int b = 0; b < nblk; ++b) { grp[S + (size_t)s * PRED_MAXG + ng] = b; grp[S + (size_t)S * PRED_MAXG + (size_t)s * PRED_MAXG + ng] = b + 1; ++ng; }
+      maxlds = std::max(maxlds, (size_t)16 * Np * 8);
+    }
+    grp[s] = ng;
+    maxg = std::max(maxg, ng);
+  }
+  // one workgroup per CU (its LDS is full): slice the point tiles over gridDim.z until the chip is covered
+  const int ntile_ = (Nstar + 15) / 16;
+  int PZ = std::max(1, ctx->num_cu / std::max(1, maxg * S));
+  PZ = std::min(PZ, std::max(1, ntile_ / (PRED_THREADS / 64)));
+  HIP_TRY(ctx, pb.dgrp.alloc(ctx, grp.size() * sizeof(int)));
+  HIP_TRY(ctx, pb.dpV.alloc(ctx, (size_t)maxg * S * Nstar * 8));
+  HIP_TRY(ctx, pb.dpF.alloc(ctx, (size_t)S * Nstar * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(pb.dgrp.p, grp.data(), grp.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, pb.dKs.alloc(ctx, (size_t)S * N * Nstar * 8));
+  // the padded dimension of the per-lane test point (registers): buckets of 4
+#define PRED_KS(DTV) hipLaunchKernelGGL((k_pred_ks<DTV>), dim3((Nstar + 15) / 16, S), dim3(64), 0, st, pa, dXc.as<double>(), daa.as<double>(), \
+                                        dmuv.as<double>(), pb.dKs.as<double>(), pb.dpF.as<double>());
+  if (D <= 4) PRED_KS(4) else if (D <= 8) PRED_KS(8) else if (D <= 12) PRED_KS(12) else if (D <= 16) PRED_KS(16)
+  else if (D <= 24) PRED_KS(24) else PRED_KS(32)
+#undef PRED_KS
+  if (maxlds > 64 * 1024)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxlds));
+  hipLaunchKernelGGL(k_gp_pred, dim3(maxg, S, PZ), dim3(PRED_THREADS), maxlds, st, pa, pb.dKs.as<double>(), pb.dgrp.as<int>(), pb.dpV.as<double>());
+  hipLaunchKernelGGL(k_pred_final, dim3((Nstar + 255) / 256, S), dim3(256), 0, st, pa, pb.dgrp.as<int>(), pb.dpV.as<double>(), pb.dpF.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;
 }
@@ -641,7 +684,7 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   a.N = N; a.D = D; a.S = S; a.Nhyp = gp->Nhyp; a.Nstar = Nstar; a.Na = is->Na; a.Nap = is->Nap; a.per_s = is->per_s;
   a.Xs = pb.dXs.as<double>(); a.Xa = is->Xa; a.hyp = gp->hyp; a.Xc = pb.dXc.as<double>(); a.muv = pb.dmuv.as<double>();
   a.CT = is->CT; a.fs2a = is->fs2a; a.lnw = is->has_lnw ? is->lnw : nullptr; a.fs2 = pb.fs2; a.sn2x = dsx.as<double>();
-  a.lchol = gp->d_lchol; a.acqs = dacqs.as<double>();
+  a.lchol = gp->d_lchol; a.acqs = dacqs.as<double>(); a.KsW = pb.dKs.as<double>(); a.sn2_eff = gp->d_sn2;
   dim3 grid((Nstar + 15) / 16, S);
   switch (is->Nap / 16) {
 #define IQR_CASE(NT) case NT: hipLaunchKernelGGL((k_acq_iqr<NT>), grid, dim3(64), 0, st, a); break;

@@ -362,105 +362,152 @@ __global__ void __launch_bounds__(256) k_pred_prep(PredArgs a, double* __restric
   }
 }
 
-// k_gp_pred: one 4-wave workgroup = 16 test points x one hyper-sample.
-//   phase 1  all 256 lanes build the cross-kernel slab Ks (N x 16, sW-scaled) in LDS and fmu = m* + Ks' alpha (:74-83)
-//   phase 2  V = L' \ (sW .* Ks) as the product Tinv * (sW .* Ks) with Tinv = inv(L') precomputed once per GP
-//            (k_trsm_fwd on the identity): no sequential substitution, the 16-row output tiles are dealt to the four
-//            waves (balanced over the triangle), each tile a chain of v_mfma_f64_16x16x4_f64 with the Tinv operand
-//            streamed from L2 one step ahead and the Ks operand read from LDS; fs2 = kss - sum(V.^2)  (:99-100).
-//            Low-noise samples (Lchol = false, L = -inv(K + sn2 I)): U = L * Ks over the full row, fs2 = kss +
-//            sum(Ks .* U)  (:103-104) through the same loop.
-// |inv(L')| <= 1 because L'L = K/sl + I >= I, so the explicit inverse is as well conditioned as the substitution.
-#define PRED_THREADS 256
-#define PRED_LDS_BYTES(N) ((size_t)((((((N) + 15) >> 4) << 4) * 16) + 16 * 32 + 64 + 64) * sizeof(double))
-__global__ void __launch_bounds__(PRED_THREADS) k_gp_pred(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
-                                                          const double* __restrict__ muv) {
-  extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+// k_pred_ks: the sW-scaled cross-kernel matrix for every hyper-sample, KsW[s][n][i] = sW_s * k_s(X_n, Xstar_i)
+// (points fastest), each element computed exactly once, and fmu's data term Ks' alpha (gplite_pred.m:74,83).
+// One wave per (16 test points, hyper-sample): lane (li, lg) walks n = lg, lg + 4, ...
+template <int DT>
+__global__ void __launch_bounds__(64) k_pred_ks(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
+                                                const double* __restrict__ muv, double* __restrict__ KsW, double* __restrict__ partF) {
+  const int pt = blockIdx.x, s = blockIdx.y, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
   const int N = a.N, D = a.D;
-  const int Np = ((N + 15) >> 4) << 4;
-  double* V = lds;                        // Np x 16: (sW .* Ks)[n][point]
-  double* xs = V + (size_t)Np * 16;       // 16 x 32 scaled centred test points
-  double* redf = xs + 16 * 32;            // 4 x 16 fmu partials
-  double* redv = redf + 64;               // 4 x 16 variance partials
   const double* h = a.hyp + (size_t)s * a.Nhyp;
   const double* mu = muv + (size_t)s * 2 * D;
   const double* iell = mu + D;
-  const int jc = cb * 16 + li;
-  const bool cv = jc < a.Nstar;
   const double sf2 = exp(2.0 * h[D]);
-  if (wave == 0)
-    for (int d = lg; d < D; d += 4) xs[li * 32 + d] = cv ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
-  __syncthreads();
+  const double sW = a.lchol[s] ? 1.0 / sqrt(a.sn2_eff[s]) : 1.0;
+  const int jc = pt * 16 + li;
+  const bool cv = jc < a.Nstar;
+  double xi[DT];
   double bb = 0.0;
-  for (int d = 0; d < D; ++d) bb = fma(xs[li * 32 + d], xs[li * 32 + d], bb);
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    xi[d] = (d < D && cv) ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
+    bb = fma(xi[d], xi[d], bb);
+  }
   const double* al = a.alpha + (size_t)s * N;
   const double* xcs = Xc + (size_t)s * N * D;
   const double* aas = aa + (size_t)s * N;
-  const bool lc = a.lchol[s] != 0;
-  const double sW = lc ? 1.0 / sqrt(a.sn2_eff[s]) : 1.0;
+  double* out = KsW + (size_t)s * N * a.Nstar;
   double fm = 0.0;
-  for (int i = wave * 4 + lg; i < Np; i += 16) {
-    double ks = 0.0;
-    if (i < N) {
-      double dot = 0.0;
-      for (int d = 0; d < D; ++d) dot = fma(xcs[(size_t)i * D + d], xs[li * 32 + d], dot);
-      const double cdist = fmax(aas[i] + (bb - 2.0 * dot), 0.0);     // sq_dist.m:45,49
-      ks = sf2 * exp(-cdist / 2.0);                                  // gplite_pred.m:74
-      fm = fma(ks, al[i], fm);
-    }
-    V[i * 16 + li] = ks * sW;                                        // sW .* Ks (:99); plain Ks when !Lchol
+  for (int n = lg; n < N; n += 4) {
+    const double* xn = xcs + (size_t)n * D;
+    double dot = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      if (d < D) dot = fma(xn[d], xi[d], dot);
+    const double cdist = fmax(aas[n] + (bb - 2.0 * dot), 0.0);   // sq_dist.m:45,49
+    const double ks = sf2 * exp(-cdist / 2.0);                   // gplite_pred.m:74
+    fm = fma(ks, al[n], fm);
+    if (cv) out[(size_t)n * a.Nstar + jc] = ks * sW;             // sW .* Ks (:99); plain Ks when !Lchol
   }
   fm += __shfl_xor(fm, 16, 64);
   fm += __shfl_xor(fm, 32, 64);
-  if (lg == 0) redf[wave * 16 + li] = fm;
+  if (lg == 0 && cv) partF[(size_t)s * a.Nstar + jc] = fm;
+}
+
+// k_gp_pred: V = L' \ (sW .* Ks) as the product Tinv * (sW .* Ks), Tinv = inv(L') precomputed once per GP
+// (k_trsm_fwd on the identity; |inv(L')| <= 1 because L'L = K/sl + I >= I, so the explicit inverse is as well
+// conditioned as the substitution).  The operand that is REUSED is made resident:
+//   * a workgroup owns a block of up to 8 consecutive 16-row tiles of Tinv (rows [r0, r1), columns [0, r1): lower
+//     triangle), as large as one CU's LDS allows (156 KB), and keeps it there for its whole life;
+//   * its 16 waves stream over (a z-slice of) the test-point tiles: per k-step (4 training points) a lane reads ONE cross-kernel value
+//     of k_pred_ks's matrix (the MFMA B operand, coalesced over the 16 points, two steps ahead) and issues one MFMA per
+//     resident row tile (A from LDS);
+//   * per point tile it writes sum_rows V^2 to a partial slot; k_pred_final adds the partials in block order:
+//     fs2 = kss - sum(V.^2) (gplite_pred.m:99-100).
+// Low-noise samples (Lchol = false, L = -inv(K + sn2 I), :103-104) use single-tile blocks over all columns and
+// accumulate Ks .* (L*Ks) instead.  Tinv / L are read from HBM/L2 once per workgroup, not once per point tile.
+#define PRED_THREADS 1024
+#define PRED_MAXG 80
+#define PRED_MAXR 8
+#define PRED_LDS_MAX (156 * 1024)
+// group table (ints): ng[s] at [s]; t0 at [S + s*PRED_MAXG + g]; t1 at [S + S*PRED_MAXG + s*PRED_MAXG + g]
+__global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const double* __restrict__ KsW, const int* __restrict__ grp,
+                                                             double* __restrict__ partV /* G x S x Nstar */) {
+  extern __shared__ double lds[];
+  const int g = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  if (g >= grp[s]) return;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int N = a.N;
+  const int tb = grp[a.S + s * PRED_MAXG + g], te = grp[a.S + a.S * PRED_MAXG + s * PRED_MAXG + g];
+  const int R = te - tb;                       // resident row tiles
+  const int RB = R * 16;                       // resident rows
+  const bool lc = a.lchol[s] != 0;
+  const int Np = ((N + 15) >> 4) << 4;
+  const int ncol = lc ? te * 16 : Np;          // columns that matter (lower triangle / full)
+  double* T = lds;                             // ncol x RB: T[col * RB + row_local]
+  const double* Am = (lc ? a.tinv : a.L) + (size_t)s * N * N;   // element (row, col) at col*N + row
+  for (int idx = tid; idx < ncol * RB; idx += PRED_THREADS) {
+    const int col = idx / RB, rl = idx % RB, row = tb * 16 + rl;
+    T[idx] = (col < N && row < N) ? Am[(size_t)col * N + row] : 0.0;
+  }
   __syncthreads();
-  // ---- phase 2
-  const double* Am = (lc ? a.tinv : a.L) + (size_t)s * N * N;   // element (row, col) at col*N + row (Tinv lower-triangular; L symmetric)
-  const int nblk = Np >> 4;
-  double part = 0.0;
-  for (int bi = 0; bi < nblk; ++bi) {
-    const int g = bi >> 2, m = bi & 3;
-    if (((g & 1) ? 3 - m : m) != wave) continue;                    // snake dealing: balanced triangle
-    const int b0 = bi << 4;
-    const int jend = lc ? b0 + 16 : Np;
-    const bool rv = b0 + li < N;
-    tmf4 acc = {0.0, 0.0, 0.0, 0.0};
-    double acur = (rv && lg < N) ? Am[(size_t)lg * N + b0 + li] : 0.0;
-    for (int j0 = 0; j0 < jend; j0 += 4) {
-      const int jn = j0 + 4 + lg;
-      const double anxt = (rv && jn < N && j0 + 4 < jend) ? Am[(size_t)jn * N + b0 + li] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(acur, V[(j0 + lg) * 16 + li], acc, 0, 0, 0);
-      acur = anxt;
+  const double* ksw = KsW + (size_t)s * N * a.Nstar;
+  const int ntile = (a.Nstar + 15) >> 4;
+  for (int pt = wave + (PRED_THREADS / 64) * blockIdx.z; pt < ntile; pt += (PRED_THREADS / 64) * gridDim.z) {
+    const int jc = pt * 16 + li;
+    const bool cv = jc < a.Nstar;
+    const double* kcol = ksw + min(jc, a.Nstar - 1);
+    tmf4 acc[PRED_MAXR];
+#pragma unroll
+    for (int r = 0; r < PRED_MAXR; ++r) acc[r] = (tmf4){0.0, 0.0, 0.0, 0.0};
+    // B operand (one cross-kernel value per lane and k-step) two steps ahead of its MFMAs
+    double b0 = (cv && lg < N) ? kcol[(size_t)lg * a.Nstar] : 0.0;
+    double b1 = (cv && 4 + lg < N && 4 < ncol) ? kcol[(size_t)(4 + lg) * a.Nstar] : 0.0;
+    for (int n0 = 0; n0 < ncol; n0 += 4) {
+      const int n2 = n0 + 8 + lg;
+      const double b2 = (cv && n2 < N && n0 + 8 < ncol) ? kcol[(size_t)n2 * a.Nstar] : 0.0;
+      const double* trow = T + (size_t)(n0 + lg) * RB + li;
+#pragma unroll
+      for (int r = 0; r < PRED_MAXR; ++r)
+        if (r < R) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(trow[16 * r], b0, acc[r], 0, 0, 0);
+      b0 = b1; b1 = b2;
     }
+    // C layout: lane (col = li = point, row = lg + 4 reg) of each resident tile
+    double part = 0.0;
     if (lc) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fma(acc[r], acc[r], part);                          // sum(V.*V)
+      for (int r = 0; r < PRED_MAXR; ++r)
+        if (r < R) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) part = fma(acc[r][q], acc[r][q], part);   // sum(V.*V)
+        }
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fma(V[(b0 + lg + 4 * r) * 16 + li], acc[r], part);  // sum(Ks .* (L*Ks))
+      for (int q = 0; q < 4; ++q) {                                              // sum(Ks .* (L*Ks)), R == 1
+        const int row = tb * 16 + lg + 4 * q;
+        const double kv = (cv && row < N) ? kcol[(size_t)row * a.Nstar] : 0.0;
+        part = fma(kv, acc[0][q], part);
+      }
     }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lg == 0 && cv) partV[((size_t)g * a.S + s) * a.Nstar + jc] = part;
   }
-  part += __shfl_xor(part, 16, 64);
-  part += __shfl_xor(part, 32, 64);
-  if (lg == 0) redv[wave * 16 + li] = part;
-  __syncthreads();
-  if (wave == 0 && lg == 0 && cv) {
-    const double fmt = (redf[li] + redf[16 + li]) + (redf[32 + li] + redf[48 + li]);
-    const double pv = (redv[li] + redv[16 + li]) + (redv[32 + li] + redv[48 + li]);
-    const double mstar = gp_meanfun(a.meanfun, D, h + a.moff, a.Xs + jc, (size_t)a.Nstar);
-    const double fmu = mstar + fmt;                                  // :83
-    double fs2 = lc ? sf2 - pv : sf2 + pv;                           // :100 / :104
-    fs2 = fmax(fs2, 0.0);  // :120
-    // noise at the test points (gplite_noisefun.m:176-194; the output-dependent term needs ystar: not here)
-    double sn2s = a.nf0 ? exp(2.0 * h[a.noff]) : 2.220446049250313e-16;
-    if (a.nf1 == 1 && a.s2s) sn2s += a.s2s[jc];
-    else if (a.nf1 == 2 && a.s2s) sn2s += exp(h[a.noff + (a.nf0 ? 1 : 0)]) * a.s2s[jc];
-    a.fmu[jc + (size_t)a.Nstar * s] = fmu;
-    a.fs2[jc + (size_t)a.Nstar * s] = fs2;
-    a.ys2[jc + (size_t)a.Nstar * s] = fs2 + sn2s * a.sn2_mult[s];  // :121
-  }
+}
+
+// fmu = m* + Ks' alpha (:83), fs2 = max(kss -/+ sum of the block partials, 0) (:100,:104,:120), ys2 (:121)
+__global__ void __launch_bounds__(256) k_pred_final(PredArgs a, const int* __restrict__ grp, const double* __restrict__ partV,
+                                                    const double* __restrict__ partF) {
+  const int i = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  if (i >= a.Nstar) return;
+  const int D = a.D;
+  const double* h = a.hyp + (size_t)s * a.Nhyp;
+  const double sf2 = exp(2.0 * h[D]);
+  const bool lc = a.lchol[s] != 0;
+  double pv = 0.0;
+  for (int g = 0; g < grp[s]; ++g) pv += partV[((size_t)g * a.S + s) * a.Nstar + i];
+  const double mstar = gp_meanfun(a.meanfun, D, h + a.moff, a.Xs + i, (size_t)a.Nstar);
+  const double fmu = mstar + partF[(size_t)s * a.Nstar + i];
+  double fs2 = lc ? sf2 - pv : sf2 + pv;
+  fs2 = fmax(fs2, 0.0);
+  // noise at the test points (gplite_noisefun.m:176-194; the output-dependent term needs ystar: not here)
+  double sn2s = a.nf0 ? exp(2.0 * h[a.noff]) : 2.220446049250313e-16;
+  if (a.nf1 == 1 && a.s2s) sn2s += a.s2s[i];
+  else if (a.nf1 == 2 && a.s2s) sn2s += exp(h[a.noff + (a.nf0 ? 1 : 0)]) * a.s2s[i];
+  a.fmu[i + (size_t)a.Nstar * s] = fmu;
+  a.fs2[i + (size_t)a.Nstar * s] = fs2;
+  a.ys2[i + (size_t)a.Nstar * s] = fs2 + sn2s * a.sn2_mult[s];
 }
 
 // gplite_pred.m:154-165 averaging over hyper-samples (in place into column 0 of the *_avg outputs)
@@ -806,6 +853,8 @@ struct IqrArgs {
   const double* fs2a;    // S x Nap
   const double* lnw;     // S x Nap (-inf in the padding) or null
   const double* fs2;     // Nstar x S   (k_gp_pred)
+  const double* KsW;     // S x N x Nstar  sW-scaled cross-kernel matrix (k_pred_ks)
+  const double* sn2_eff; // S
   const double* sn2x;    // Nstar
   const unsigned char* lchol;
   double* acqs;          // Nstar x S
@@ -840,9 +889,10 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  const double* xc = a.Xc + (size_t)s * N * D;
   const double* ct = a.CT + (size_t)s * N * Nap;
-  const double* xrow = &xs_s[li][0];
+  const bool gvalid = i0 + li < a.Nstar;
+  const double* kcol = a.KsW + (size_t)s * N * a.Nstar + min(i0 + li, a.Nstar - 1);
+  const double isw = a.lchol[s] ? sqrt(a.sn2_eff[s]) : 1.0;   // undo sW = 1/sqrt(sn2_eff)
   // software pipeline: the B operands (CtmpT row n, 16 consecutive a per tile) of step n0 + 4 are in flight while the
   // A operand of step n0 (one kernel value per lane) is computed and the NT MFMAs of step n0 issue
   double bcur[NT], bnxt[NT];
@@ -859,13 +909,8 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) bnxt[t] = (nn < N) ? row[16 * t] : 0.0;
     }
-    double kv = 0.0;
-    if (n < N) {
-      const double* xn = xc + (size_t)n * D;
-      double c = 0.0;
-      for (int d = 0; d < D; ++d) { const double t = xrow[d] - xn[d]; c = fma(t, t, c); }
-      kv = sf2 * exp(-c / 2.0);
-    }
+    // A operand: the cross-kernel value k_s(X_n, xs_i), already computed once by k_pred_ks (stored sW-scaled)
+    const double kv = (n < N && gvalid) ? kcol[(size_t)n * a.Nstar] * isw : 0.0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv, bcur[t], acc[t], 0, 0, 0);
 #pragma unroll
