@@ -17,6 +17,9 @@
 //     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
 //     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
 //     [acq,fbar,vtot] = vbmc_hip_mex('acq', h, Xs, acq_id, vp, ymax, var_regularized, TolGPVar, gplengthscale, X_rescaled, sn2new)
+//     his = vbmc_hip_mex('is_create', h, Xa, lnw_or_empty, fs2a_or_empty, Ctmp_or_empty)   (ActiveImportanceSampling state)
+//           vbmc_hip_mex('is_free', his)
+//     [acq,fbar,vtot] = vbmc_hip_mex('acq_iqr', h, his, Xs, gplengthscale, X_rescaled, sn2new, var_regularized, TolGPVar)
 //     [nlZ,dnlZ] = vbmc_hip_mex('gp_nlz', Hyp /*Nhyp x B*/, X, y, s2, meanfun, noisefun)   (gplite_nlZ for B vectors)
 //     C = vbmc_hip_mex('sq_dist', a, b)
 //
@@ -250,6 +253,36 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                    mxGetScalar(prhs[5]), (int)mxGetScalar(prhs[6]), mxGetScalar(prhs[7]),
                                    nrhs > 8 ? dbl(prhs[8]) : nullptr, nrhs > 9 ? dbl(prhs[9]) : nullptr, nrhs > 10 ? dbl(prhs[10]) : nullptr,
                                    mxGetDoubles(plhs[0]), mxGetDoubles(fb), mxGetDoubles(vt));
+    if (st != VBMC_OK) fail(st);
+    if (nlhs > 1) plhs[1] = fb;
+    if (nlhs > 2) plhs[2] = vt;
+    return;
+  }
+
+  if (!strcmp(cmd, "is_create")) {
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    const mxArray* Xa = prhs[2];
+    const mwSize nd = mxGetNumberOfDimensions(Xa);
+    const int Na = (int)mxGetDimensions(Xa)[0];
+    vbmc_acq_is* is = nullptr;
+    vbmc_status st = vbmc_acq_is_create(g_ctx, h, Na, mxGetDoubles(Xa), nd > 2 ? 1 : 0, nrhs > 3 ? dbl(prhs[3]) : nullptr,
+                                        nrhs > 4 ? dbl(prhs[4]) : nullptr, nrhs > 5 ? dbl(prhs[5]) : nullptr, &is);
+    if (st != VBMC_OK) fail(st);
+    plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+    *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)is;
+    return;
+  }
+  if (!strcmp(cmd, "is_free")) { vbmc_acq_is_free(g_ctx, (vbmc_acq_is*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return; }
+
+  if (!strcmp(cmd, "acq_iqr")) {
+    vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    vbmc_acq_is* is = (vbmc_acq_is*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[2]));
+    const mxArray* Xs = prhs[3];
+    const int Nstar = (int)mxGetM(Xs);
+    plhs[0] = mxCreateDoubleMatrix(Nstar, 1, mxREAL);
+    mxArray *fb = mxCreateDoubleMatrix(Nstar, 1, mxREAL), *vt = mxCreateDoubleMatrix(Nstar, 1, mxREAL);
+    vbmc_status st = vbmc_acq_iqr_eval(g_ctx, h, is, Nstar, mxGetDoubles(Xs), dbl(prhs[4]), dbl(prhs[5]), dbl(prhs[6]),
+                                       (int)mxGetScalar(prhs[7]), mxGetScalar(prhs[8]), mxGetDoubles(plhs[0]), mxGetDoubles(fb), mxGetDoubles(vt));
     if (st != VBMC_OK) fail(st);
     if (nlhs > 1) plhs[1] = fb;
     if (nlhs > 2) plhs[2] = vt;

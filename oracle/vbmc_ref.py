@@ -127,6 +127,8 @@ def gplite_noisefun(hyp_noise, X, noisefun, y=None, s2=None):
     else:
         sn2 = math.exp(2.0 * hyp_noise[idx])  # :181
         idx += 1
+    if s2 is None or np.size(s2) == 0:
+        s2 = 0.0  # :51  (empty s2 counts as zero, e.g. gplite_pred without s2star)
     if noisefun[1] == 1:
         sn2 = sn2 + np.asarray(s2, dtype=np.float64)  # :188
     elif noisefun[1] == 2:
@@ -288,6 +290,8 @@ def gplite_noisefun_grad(hyp_noise, X, noisefun, y=None, s2=None):
         sn2 = math.exp(2.0 * hyp_noise[idx])
         dsn2[:, idx] = 2.0 * sn2  # :182
         idx += 1
+    if s2 is None or np.size(s2) == 0:
+        s2 = 0.0  # :51
     if noisefun[1] == 1:
         sn2 = sn2 + np.asarray(s2, dtype=np.float64)
     elif noisefun[1] == 2:

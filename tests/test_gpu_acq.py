@@ -115,3 +115,27 @@ def test_acqimiqr_matches_oracle(va, per_s):
     assert np.max(np.abs(acq[far] - ref[far])) < 1e-8
     info = va.acq_info("acqimiqr_vbmc")
     assert info["log_flag"] and info["importance_sampling"] and not info["variational_importance_sampling"]
+
+
+def test_noisy_gp_prediction_and_viqr_without_s2star(va):
+    """Noisy targets (noisefun [1 1 0], user-supplied s2 at the training points): the acquisition sweep calls
+    gplite_pred with empty s2star, which counts as zero (gplite_noisefun.m:51); VIQR on such a GP."""
+    p, gp, vp, _ = problem(21, 5, 70, 4, 3, noisy=True)
+    assert tuple(gp["noisefun"])[:2] == (1, 1) and gp["s2"] is not None
+    rng = np.random.default_rng(5)
+    Xs = 1.2 * rng.standard_normal((200, 5))
+    ymu, ys2, fmu, fs2 = va.gplite_pred(gp, Xs, None, None, True)
+    r = R.gplite_pred(gp, Xs, None, None, True)
+    sf2 = np.exp(2 * gp["post"][0]["hyp"][5])
+    assert relerr(fmu, r[2]) < 1e-9 and np.max(np.abs(np.asarray(ys2) - np.asarray(r[1]))) < 1e-9 * sf2
+    gl = np.exp(np.mean(np.stack([q["hyp"][:5] for q in gp["post"]], axis=1), axis=1))
+    gp = dict(gp, X_rescaled=gp["X"] / gl[None, :], sn2new=np.asarray(gp["s2"]) + 0.01)
+    Xa = 1.1 * rng.standard_normal((40, 5))
+    st = {"ymax": float(np.max(gp["y"])), "VarianceRegularizedAcqFcn": False, "TolGPVar": 1e-4, "gplengthscale": gl,
+          "ActiveImportanceSampling": {"Xa": Xa}}
+    Kax, Ct = R.acq_is_precompute(gp, Xa)
+    fs2a = np.asarray(R.gplite_pred(gp, Xa, None, None, True)[3]).reshape(40, -1)
+    st_ref = dict(st, ActiveImportanceSampling={"Xa": Xa, "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": np.zeros((3, 40))})
+    ref, _, _ = R.acqwrapper_vbmc(Xs, vp, gp, st_ref, "acqviqr")
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqviqr_vbmc", None)
+    assert np.max(np.abs(acq - ref)) < 1e-8

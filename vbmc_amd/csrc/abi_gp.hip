@@ -298,8 +298,6 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
                                    double* nlZ, double* dnlZ) {
   if (!ctx) return VBMC_ERR_INVALID;
   if (!nlZ || (compute_grad && !dnlZ)) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_nlz: null output");
-  if (noisefun && (noisefun[1] == 1 || noisefun[1] == 2) && !s2)
-    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_nlz: noise model uses s2 but s2 is NULL");
   GpFactor f;
   { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
@@ -369,8 +367,7 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   if (!gp->has_noise) return set_err(ctx, VBMC_ERR_INVALID, "%s: call vbmc_gp_set_noise (noisefun, sn2_mult) first", who);
   if (gp->noisefun[2] == 1)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "output-dependent noise (noisefun(3) = 1) at test points not accelerated");
-  if ((gp->noisefun[1] == 1 || gp->noisefun[1] == 2) && !s2star)
-    return set_err(ctx, VBMC_ERR_INVALID, "gplite_pred: S2STAR is required by the noise function");
+  // an empty s2star counts as zero (gplite_noisefun.m:51): the kernels add nothing when the pointer is null
   const int N = gp->N, D = gp->D, S = gp->S;
   const int Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
   const size_t tlds0 = TRSM_LDS_BYTES(N);
@@ -512,8 +509,6 @@ extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar
   if (acq_id < 0 || acq_id > 3) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "acquisition function id %d not accelerated (0 acqf, 1 acqflog, 2 acqus, 3 acqfsn2)", acq_id);
   if (acq_id == 3 && (!gplengthscale || !X_rescaled || !sn2new))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_eval: acqfsn2 needs gplengthscale, X_rescaled and sn2new");
-  if (gp && (gp->noisefun[1] == 1 || gp->noisefun[1] == 2))
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_acq_eval: noise models that need s2 at the test points are not accelerated");
   PredBufs pb;
   { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
@@ -662,8 +657,6 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   if (!is || !acq || !gplengthscale || !X_rescaled || !sn2new) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_iqr_eval: bad arguments");
   if (gp && (is->N != gp->N || is->S != gp->S || is->D != gp->D))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_iqr_eval: importance-sampling state belongs to a different GP");
-  if (gp && (gp->noisefun[1] == 1 || gp->noisefun[1] == 2))
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_acq_iqr_eval: noise models that need s2 at the test points are not accelerated");
   PredBufs pb;
   { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
