@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import c_oracle
+from oracle import vbmc_ref as R
 from tests._cases import synth_problem
 from tests.test_gpu_elbo import relerr
 
@@ -67,3 +68,37 @@ def test_c5_shape_small_sample_against_numpy_oracle(va):
     ref = R.negelcbo_vbmc(theta, 0, vp, gp, 50, True, 0, eps=eps)
     F, dF = va.negelcbo_vbmc(theta, 0, vp, gp, 50, 1, 0, eps=eps)
     assert relerr(F, ref["F"]) < 1e-10 and relerr(dF, ref["dF"]) < 1e-9
+
+
+def test_c5_noisy_path_prediction_and_iqr_acquisition(va):
+    """BASELINE configs[4] GP shape (D=20, N=800, noisy likelihood with user-supplied s2): gplite_post on the device,
+    gplite_pred and the VIQR / IMIQR acquisition functions against the oracle, fp64 end to end."""
+    p = synth_problem(5, 20, 800, 100, 3, noisy=True)
+    gp_o = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"], noisefun=p["noisefun"], s2=p["s2"])
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, p["meanfun"], p["noisefun"], p["s2"])
+    for a, b in zip(gp["post"], gp_o["post"]):
+        assert relerr(a["alpha"], b["alpha"]) < 1e-8 and a["Lchol"] == b["Lchol"] and a["sn2_mult"] == b["sn2_mult"]
+    rng = np.random.default_rng(1)
+    D = 20
+    Xs = 1.3 * rng.standard_normal((150, D))
+    Xa = 1.3 * rng.standard_normal((100, D))
+    r_o = R.gplite_pred(gp_o, Xs, None, None, True)
+    r_d = va.gplite_pred(gp, Xs, None, None, True)
+    sf2 = np.exp(2 * gp_o["post"][0]["hyp"][D])
+    assert relerr(r_d[2], r_o[2]) < 1e-8 and np.max(np.abs(np.asarray(r_d[3]) - np.asarray(r_o[3]))) < 1e-9 * sf2
+    gl = np.exp(np.mean(np.stack([q["hyp"][:D] for q in gp_o["post"]], axis=1), axis=1))
+    extra = dict(X_rescaled=p["X"] / gl[None, :], sn2new=np.asarray(p["s2"]) + 0.01)
+    gp_o = dict(gp_o, **extra)
+    gp = dict(gp, **extra)
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    Kax, Ct = R.acq_is_precompute(gp_o, Xa)
+    fs2a = np.asarray(R.gplite_pred(gp_o, Xa, None, None, True)[3]).reshape(100, -1)
+    lnw = 0.5 * rng.standard_normal((3, 100))
+    st = {"ymax": float(np.max(p["y"])), "VarianceRegularizedAcqFcn": False, "TolGPVar": 1e-4, "gplengthscale": gl}
+    ais_o = {"Xa": Xa, "Kax_mat": Kax, "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": lnw}
+    for name in ("acqviqr", "acqimiqr"):
+        ref, _, _ = R.acqwrapper_vbmc(Xs, vp, gp_o, dict(st, ActiveImportanceSampling=ais_o), name)
+        ais_d = {"Xa": Xa, "lnw": (np.zeros_like(lnw) if name == "acqviqr" else lnw)}      # Ctmp / fs2a built on the device
+        acq = va.acqwrapper_vbmc(Xs, vp, gp, dict(st, ActiveImportanceSampling=ais_d), False, name + "_vbmc", None)
+        assert np.max(np.abs(acq - ref)) < 1e-7, (name, np.max(np.abs(acq - ref)))
