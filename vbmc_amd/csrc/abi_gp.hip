@@ -451,11 +451,10 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   HIP_TRY(ctx, pb.dpF.alloc(ctx, (size_t)S * Nstar * 8));
   HIP_TRY(ctx, hipMemcpyAsync(pb.dgrp.p, grp.data(), grp.size() * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, pb.dKs.alloc(ctx, (size_t)S * N * Nstar * 8));
-  // the padded dimension of the per-lane test point (registers): buckets of 4
-#define PRED_KS(DTV) hipLaunchKernelGGL((k_pred_ks<DTV>), dim3((Nstar + 15) / 16, S), dim3(64), 0, st, pa, dXc.as<double>(), daa.as<double>(), \
-                                        dmuv.as<double>(), pb.dKs.as<double>(), pb.dpF.as<double>());
-  if (D <= 4) PRED_KS(4) else if (D <= 8) PRED_KS(8) else if (D <= 12) PRED_KS(12) else if (D <= 16) PRED_KS(16)
-  else if (D <= 24) PRED_KS(24) else PRED_KS(32)
+  // inner dimension of the MFMA distance blocks: QS = ceil(D / 4) steps
+#define PRED_KS(QSV) case QSV: hipLaunchKernelGGL((k_pred_ks<QSV>), dim3((Nstar + 15) / 16, S), dim3(64), 0, st, pa, dXc.as<double>(), \
+                                                  daa.as<double>(), dmuv.as<double>(), pb.dKs.as<double>(), pb.dpF.as<double>()); break;
+  switch ((D + 3) / 4) { PRED_KS(1) PRED_KS(2) PRED_KS(3) PRED_KS(4) PRED_KS(5) PRED_KS(6) PRED_KS(7) PRED_KS(8) default: break; }
 #undef PRED_KS
   if (maxlds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxlds));

@@ -364,41 +364,62 @@ __global__ void __launch_bounds__(256) k_pred_prep(PredArgs a, double* __restric
 
 // k_pred_ks: the sW-scaled cross-kernel matrix for every hyper-sample, KsW[s][n][i] = sW_s * k_s(X_n, Xstar_i)
 // (points fastest), each element computed exactly once, and fmu's data term Ks' alpha (gplite_pred.m:74,83).
-// One wave per (16 test points, hyper-sample): lane (li, lg) walks n = lg, lg + 4, ...
-template <int DT>
+// One wave per (16 test points, hyper-sample).  The inner products of sq_dist's expansion |a|^2 + |b|^2 - 2 a.b
+// (sq_dist.m:45) for a 16 x 16 block of (training point, test point) pairs are QS MFMAs (inner dimension D in steps
+// of 4); the accumulator layout (row n = lg + 4 reg, column point = li) is exactly the coalesced store pattern.
+template <int QS>
 __global__ void __launch_bounds__(64) k_pred_ks(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
                                                 const double* __restrict__ muv, double* __restrict__ KsW, double* __restrict__ partF) {
+  __shared__ double tab[VB_EXP_TAB_N];
   const int pt = blockIdx.x, s = blockIdx.y, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
   const int N = a.N, D = a.D;
+  for (int t = lane; t < VB_EXP_TAB_N; t += 64) tab[t] = c_exp2_tab[t];
   const double* h = a.hyp + (size_t)s * a.Nhyp;
   const double* mu = muv + (size_t)s * 2 * D;
   const double* iell = mu + D;
   const double sf2 = exp(2.0 * h[D]);
+  const double lsf2 = 2.0 * h[D];
   const double sW = a.lchol[s] ? 1.0 / sqrt(a.sn2_eff[s]) : 1.0;
   const int jc = pt * 16 + li;
   const bool cv = jc < a.Nstar;
-  double xi[DT];
+  // B operand: this lane's test point li, dimensions 4q + lg; |b|^2 of the point by a 4-lane-group reduction
+  double xb[QS];
   double bb = 0.0;
 #pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    xi[d] = (d < D && cv) ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
-    bb = fma(xi[d], xi[d], bb);
+  for (int q = 0; q < QS; ++q) {
+    const int d = 4 * q + lg;
+    xb[q] = (d < D && cv) ? a.Xs[jc + (size_t)a.Nstar * d] * iell[d] - mu[d] : 0.0;
+    bb = fma(xb[q], xb[q], bb);
   }
+  bb += __shfl_xor(bb, 16, 64);
+  bb += __shfl_xor(bb, 32, 64);
+  __syncthreads();
   const double* al = a.alpha + (size_t)s * N;
   const double* xcs = Xc + (size_t)s * N * D;
   const double* aas = aa + (size_t)s * N;
   double* out = KsW + (size_t)s * N * a.Nstar;
   double fm = 0.0;
-  for (int n = lg; n < N; n += 4) {
-    const double* xn = xcs + (size_t)n * D;
-    double dot = 0.0;
+  (void)sf2;
+  for (int n0 = 0; n0 < N; n0 += 16) {
+    // A operand: training point n0 + li, dimensions 4q + lg
+    const int na = min(n0 + li, N - 1);
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
-      if (d < D) dot = fma(xn[d], xi[d], dot);
-    const double cdist = fmax(aas[n] + (bb - 2.0 * dot), 0.0);   // sq_dist.m:45,49
-    const double ks = sf2 * exp(-cdist / 2.0);                   // gplite_pred.m:74
-    fm = fma(ks, al[n], fm);
-    if (cv) out[(size_t)n * a.Nstar + jc] = ks * sW;             // sW .* Ks (:99); plain Ks when !Lchol
+    for (int q = 0; q < QS; ++q) {
+      const int d = 4 * q + lg;
+      const double av = d < D ? xcs[(size_t)na * D + d] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + lg + 4 * r;
+      if (n < N) {
+        const double cdist = fmax(aas[n] + (bb - 2.0 * acc[r]), 0.0);      // sq_dist.m:45,49
+        const double ks = vb_exp_tab<0>(lsf2 - cdist / 2.0, tab);          // sf2 * exp(-K/2)  (gplite_pred.m:74)
+        fm = fma(ks, al[n], fm);
+        if (cv) out[(size_t)n * a.Nstar + jc] = ks * sW;                   // sW .* Ks (:99); plain Ks when !Lchol
+      }
+    }
   }
   fm += __shfl_xor(fm, 16, 64);
   fm += __shfl_xor(fm, 32, 64);
