@@ -487,10 +487,22 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
 
   // ---- expected log joint
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-  DISPATCH_DT(dt, {
-    hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
-                       P.d_delta2, P.d_lj, P.compute_grad);
-  });
+  {
+    // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu forces the latter.
+    const char* ljf = getenv("VBMC_LJ_KERNEL");
+    const bool lj_mfma = P.compute_grad && K <= 256 && !(ljf && !strcmp(ljf, "valu"));
+    DISPATCH_DT(dt, {
+      if (lj_mfma) {
+        constexpr int NCT = (2 * DT + 1 + 15) / 16;
+        const int nw = (K + 15) / 16;
+        hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), (size_t)nw * 16 * 16 * NCT * sizeof(double), st, dm, P.d_vpd,
+                           gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
+      } else {
+        hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
+                           P.d_delta2, P.d_lj, P.compute_grad);
+      }
+    });
+  }
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
 
   // ---- entropy

@@ -209,6 +209,125 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
 }
 
 // ------------------------------------------------------------------------------------------
+// k_logjoint_mfma: the value + gradient form of k_logjoint with the O(N D) gradient sums moved to the fp64 matrix
+// cores.  Every gradient of gplogjoint.m:206-252 is a combination of the moments of za_n = z_k(n) alpha_n,
+//     M0 = sum_n za_n,   M1_d = sum_n za_n x'_nd,   M2_d = sum_n za_n x'_nd^2        (x' = x - column mean),
+// since delta = (mu' - x') / tau:  sum za delta_d = (mu'_d M0 - M1_d)/tau_d,  sum za delta_d^2 = (mu'_d^2 M0 -
+// 2 mu'_d M1_d + M2_d)/tau_d^2.  A workgroup = one (restart, hyper-sample); wave w owns the 16 components 16w + li.
+// Per k-step (4 training points) a lane evaluates ONE z (its component, point 4q + lg: the MFMA A operand) and the
+// 2D + 1 moment columns are NCT = ceil((2D+1)/16) MFMAs against the feature rows [1, x', x'^2] read from the
+// LDS-staged chunk of X.  The exponent itself stays on the VALU in the reference's (mu - x)/tau form (no
+// cancellation); centring keeps the moment recombination at ~1e-14 relative.
+// ------------------------------------------------------------------------------------------
+#define LJ_CH 64   // training points staged per chunk
+template <int DT>
+__global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const double* __restrict__ vpd,
+                                                        const double* __restrict__ X,       // N x D col-major
+                                                        const double* __restrict__ meanX,   // D column means of X
+                                                        const double* __restrict__ alpha,   // N x S
+                                                        const double* __restrict__ gpc,     // S x GPC_STRIDE
+                                                        const double* __restrict__ delta2,  // D (delta.^2)
+                                                        double* __restrict__ lj) {
+  constexpr int NCT = (2 * DT + 1 + 15) / 16;
+  __shared__ double TAB[VB_EXP_TAB_N];
+  __shared__ double XT[LJ_CH][DT];        // centred chunk of X, [n][d], zero beyond D / N
+  __shared__ double ALC[LJ_CH];
+  extern __shared__ double MOM[];         // nw x 16 x (16 NCT): moments per wave, [cell][column]
+  const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  const int kk = 16 * wv + li;
+  const bool kvalid = kk < K;
+  const int k = kvalid ? kk : K - 1;
+  for (int t = tid; t < VB_EXP_TAB_N; t += nthr) TAB[t] = c_exp2_tab[t];
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
+  const double sig = v[L.sigma() + k];
+  const double wk = v[L.w() + k];
+  double mu[DT], itau[DT];
+  double sumlogtau = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    if (d < D) {
+      const double lam_d = v[L.lambda() + d];
+      const double tau = sqrt(sig * sig * lam_d * lam_d + g[d] + delta2[d]);  // :164
+      sumlogtau += log(tau);
+      itau[d] = 1.0 / tau;
+      mu[d] = v[L.mu() + d + D * k] - meanX[d];
+    } else { itau[d] = 0.0; mu[d] = 0.0; }
+  }
+  const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
+  typedef double lj4 __attribute__((ext_vector_type(4)));
+  lj4 acc[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) acc[t] = (lj4){0.0, 0.0, 0.0, 0.0};
+  const double* al = alpha + (size_t)s * N;
+  for (int c0 = 0; c0 < N; c0 += LJ_CH) {
+    __syncthreads();
+    for (int idx = tid; idx < LJ_CH * DT; idx += nthr) {
+      const int nl = idx / DT, d = idx - nl * DT, n = c0 + nl;
+      XT[nl][d] = (d < D && n < N) ? X[n + (size_t)N * d] - meanX[d] : 0.0;
+    }
+    for (int nl = tid; nl < LJ_CH; nl += nthr) ALC[nl] = (c0 + nl < N) ? al[c0 + nl] : 0.0;
+    __syncthreads();
+#pragma unroll 2
+    for (int q = 0; q < LJ_CH / 4; ++q) {
+      const int nl = 4 * q + lg;
+      const double* xr = XT[nl];
+      double a2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) { const double dl = (mu[d] - xr[d]) * itau[d]; a2 = fma(dl, dl, a2); }   // delta_k :167
+      const double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);                                                    // z_k :168
+      const double za = kvalid ? z * ALC[nl] : 0.0;       // alpha is zero beyond N
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) {
+        const int col = 16 * t + li;
+        double b;
+        if (col == 0) b = 1.0;
+        else if (col <= D) b = xr[col - 1];
+        else if (col <= 2 * D) { const double xv = xr[col - 1 - D]; b = xv * xv; }
+        else b = 0.0;
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // moments -> LDS: accumulator (row = cell lg + 4 reg, column = 16 t + li)
+  double* mw = MOM + (size_t)wv * 16 * (16 * NCT);
+#pragma unroll
+  for (int t = 0; t < NCT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) mw[(lg + 4 * rr) * (16 * NCT) + 16 * t + li] = acc[t][rr];
+  __syncthreads();
+  if (lg == 0 && kvalid) {
+    const double* m = mw + li * (16 * NCT);
+    const double M0 = m[0];
+    double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
+    double nu = 0.0, sl2 = 0.0, accS = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      if (d < D) {
+        const double xm = g[D + d], iom2 = g[2 * D + d];
+        const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
+        const double M1 = m[1 + d], M2 = m[1 + D + d];
+        const double S1 = (mu[d] * M0 - M1) * itau[d];                                      // sum za delta_d
+        const double S2 = ((mu[d] * mu[d]) * M0 - 2.0 * mu[d] * M1 + M2) * (itau[d] * itau[d]);   // sum za delta_d^2
+        const double lit = lam_d * itau[d], sit = sig * itau[d];
+        const double accM = -itau[d] * S1;                       // dz_dmu*alpha      :207-208
+        const double accL = (sit * sit * lam_d) * (S2 - M0);     // dz_dlambda*alpha  :249-250
+        accS = fma(lit * lit, S2 - M0, accS);                    // :228
+        nu += iom2 * (mu_d * mu_d + sig * sig * lam_d * lam_d - 2.0 * mu_d * xm + xm * xm + delta2[d]);
+        sl2 += iom2 * lam_d * lam_d;
+        o[1 + d] = wk * accM - wk * iom2 * (mu_d - xm);                    // :208-210
+        o[2 + D + d] = wk * accL - wk * sig * sig * iom2 * lam_d;          // :250-252
+      }
+    }
+    o[0] = M0 + g[3 * D + 1] + (-0.5 * nu);                                // :169-174
+    o[1 + D] = wk * (accS * sig) - wk * sig * sl2;                         // :229-231
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_entropy: ent/entmc_vbmc.m:49-104.  One wave per (chunk of samples, component j, restart r).
 // Lanes 0-31 own base samples with +eps, lanes 32-63 the antithetic -eps (:53-54).
 // partial layout PE[r][j][c][NCOL]: sum log q | G[D] | SG | LG[D] | W[K]   (NCOL = 1 if !GRAD)
