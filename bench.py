@@ -154,7 +154,8 @@ def main():
     gathered = torch.empty(world * Rr, dtype=torch.float64, device=cdev) if world > 1 else None
 
     def step(i):
-        out = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=(rank << 32) + i, engine=eng)
+        # the optimiser-loop call [F,dF] = negelcbo_vbmc(theta,0,vp,gp,Ns,1,0) (vpoptimize_vbmc.m:71,127): F and dF come back
+        out = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=(rank << 32) + i, engine=eng, outputs=("F", "dF"))
         if world > 1:
             f = torch.from_numpy(out["F"]).to(cdev)
             dist.all_gather_into_tensor(gathered, f)

@@ -284,3 +284,15 @@ def test_tiny_sigma_components_do_not_break_the_exp(va):
     ref = R.negelcbo_vbmc(th, 0, vp, gp, 32, True, 0, eps=eps)
     F, dF, G, H = va.negelcbo_vbmc(th, 0, vp, gp, 32, 1, 0, nargout=4, eps=eps)
     assert np.isfinite(H) and relerr(H, ref["H"]) < RT_VAL and relerr(dF, ref["dF"]) < 1e-8
+
+
+def test_output_subset_equals_full_outputs(va):
+    """outputs=("F","dF") (the optimiser-loop call) moves only the leading part of each record; same numbers."""
+    p, gp, vp, theta = problem(77, 5, 40, 6, 3)
+    Th = np.asfortranarray(theta[:, None] + 0.01 * np.random.default_rng(0).standard_normal((theta.size, 7)))
+    full = va.negelcbo_batch(Th, 0, vp, gp, 64, True, 0, seed=9)
+    part = va.negelcbo_batch(Th, 0, vp, gp, 64, True, 0, seed=9, outputs=("F", "dF"))
+    assert set(part) == {"F", "dF"}
+    assert np.array_equal(part["F"], full["F"]) and np.array_equal(part["dF"], full["dF"])
+    one = va.negelcbo_batch(Th[:, :1], 0, vp, gp, 64, True, 0, seed=9, outputs=("F", "dF"))
+    assert np.array_equal(one["F"], full["F"][:1]) and np.array_equal(one["dF"], full["dF"][:, :1])

@@ -600,7 +600,15 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
 
   // ---- results: one packed D2H (+ I_sk / J_sjk when requested)
   double* hout = (double*)ctx->pin + P.n_up;
-  HIP_TRY(ctx, hipMemcpyAsync(hout, P.d_out, P.out_n * sizeof(double), hipMemcpyDeviceToHost, st));
+  {
+    // record per restart: [F G H varG varGss | dF (T) | dG (T) | dH (T)]; without dG / dH only the leading part moves
+    const size_t OSr = OUT_HDR + 3 * (size_t)T;
+    if (compute_grad && !a->dG && !a->dH && R > 1)
+      HIP_TRY(ctx, hipMemcpy2DAsync(hout, OSr * sizeof(double), P.d_out, OSr * sizeof(double), (OUT_HDR + (size_t)T) * sizeof(double), R,
+                                    hipMemcpyDeviceToHost, st));
+    else
+      HIP_TRY(ctx, hipMemcpyAsync(hout, P.d_out, P.out_n * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   std::vector<double> ljh;
   if (a->separate_K && a->I_sk) {
     ljh.resize((size_t)R * S * K * LJS);

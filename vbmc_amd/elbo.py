@@ -166,9 +166,12 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
 
 def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
                    separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
-                   sparse_cutoff=0.0):
+                   sparse_cutoff=0.0, outputs=None):
     """R evaluations of negelcbo_vbmc in one device pass.
 
+    outputs: None = everything below; a subset such as ("F", "dF") -- what the optimiser loop reads,
+    misc/vpoptimize_vbmc.m:71 -- leaves the other ABI output pointers NULL so that only the requested
+    gradients cross PCIe.
     thetas: (T, R) column per restart (or (T,) for R = 1).  Returns a dict of arrays
     F[R], dF[T,R], G[R], H[R], dG[T,R], dH[T,R], varG[R], varGss[R], I_sk[S,K,R], J_sjk[S,K,K,R].
     eps: host array shaped (R, K, Ns/2, D) (or (K, Ns/2, D) with eps_shared) standing in for the
@@ -189,7 +192,9 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     out = {}
 
     def outbuf(name, shape):
-        arr = np.zeros(shape, dtype=np.float64, order="F")
+        if outputs is not None and name not in outputs:
+            return None
+        arr = np.empty(shape, dtype=np.float64, order="F")
         out[name] = arr
         return ptr(arr)
 
