@@ -169,12 +169,16 @@ __device__ __forceinline__ double vb_rcp(double q) {
   return fma(r, e, r);
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter = (c0,c1,c2,c3), key = (k0,k1).
-__device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsigned k1) {
+// Philox4x32-7 (Salmon, Moraes, Dror & Shaw, SC'11: seven rounds are the fewest that pass BigCrush for the 4x32 variant;
+// ten is the conservative default), counter = (c0,c1,c2,c3), key = (k0,k1).  The 32x32 -> 64-bit products are written
+// as one 64-bit multiply each (v_mad_u64_u32: one quarter-rate instruction instead of v_mul_hi + v_mul_lo).
+#define VB_PHILOX_ROUNDS 7
+__device__ __forceinline__ void philox4x32(unsigned c[4], unsigned k0, unsigned k1) {
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+  for (int i = 0; i < VB_PHILOX_ROUNDS; ++i) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     unsigned n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -184,11 +188,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned c[4], unsigned k0, unsign
 // Four standard normals for (sample b, component j, restart r, dim-block q4) under `seed`.
 // Box-Muller on 24-bit uniforms in fp32 (the draws only need to be N(0,1) to MC accuracy; they
 // are then *defined* as the fp64 values returned here, which vbmc_rng_dump reproduces bit for
-// bit -- hence noinline: one body, identical code in every caller).
-__device__ __noinline__ void vb_normal4(unsigned long long seed, unsigned b, unsigned j, unsigned r,
-                                        unsigned q4, double z[4]) {
+// bit -- hence noinline: one body, identical code in every caller; the four values come back in registers).
+__device__ __noinline__ vb_d4 vb_normal4v(unsigned long long seed, unsigned b, unsigned j, unsigned r, unsigned q4) {
+  vb_d4 z;
   unsigned c[4] = {b, j, r, q4};
-  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+  philox4x32(c, (unsigned)seed, (unsigned)(seed >> 32));
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0,1)
@@ -199,4 +203,9 @@ __device__ __noinline__ void vb_normal4(unsigned long long seed, unsigned b, uns
     z[2 * h] = (double)(rad * cs);
     z[2 * h + 1] = (double)(rad * sn);
   }
+  return z;
+}
+__device__ __forceinline__ void vb_normal4(unsigned long long seed, unsigned b, unsigned j, unsigned r, unsigned q4, double z[4]) {
+  const vb_d4 v = vb_normal4v(seed, b, j, r, q4);
+  z[0] = v[0]; z[1] = v[1]; z[2] = v[2]; z[3] = v[3];
 }
