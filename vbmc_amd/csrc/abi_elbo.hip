@@ -490,7 +490,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   {
     // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu forces the latter.
     const char* ljf = getenv("VBMC_LJ_KERNEL");
-    const bool lj_mfma = P.compute_grad && K <= 256 && !(ljf && !strcmp(ljf, "valu"));
+    // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
+    // kernel has the lower latency
+    const bool lj_mfma = P.compute_grad && K <= 256 && (long long)S * R >= ctx->num_cu / 2 && !(ljf && !strcmp(ljf, "valu"));
     DISPATCH_DT(dt, {
       if (lj_mfma) {
         constexpr int NCT = (2 * DT + 1 + 15) / 16;
