@@ -200,11 +200,11 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of THIS command
         # (FETCH_SIZE / WRITE_SIZE need their own profiling run; collected and corrected as MI355X_MICROARCH.md prescribes)
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_p4_pmc.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
         if os.path.exists(pmc_path) and (D, N, K, S, Rr) == (10, 400, 50, 20, 64) and not args.eps_stream:
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_p4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         roof = {"bound": "mfma", "kernel": "k_entropy_mfma<QS=%d,KT=%d,grad>" % ((D + 5) // 4, (K + 15) // 16), "achieved": achieved,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
