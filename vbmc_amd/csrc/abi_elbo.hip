@@ -581,6 +581,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out;
   {
     size_t lds = (256 + 3 * (size_t)K + 3 * (size_t)T + 8) * sizeof(double);
+    const size_t stage_b = ((size_t)K * (2 * D + 2) + (fa.entpart ? (size_t)K * fa.C * fa.ncol : 0)) * sizeof(double);
+    fa.stage = (lds + stage_b <= 96 * 1024) ? 1 : 0;
+    if (fa.stage) lds += stage_b;
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_finalize, dim3(R), dim3(256), lds, st, fa);

@@ -662,6 +662,7 @@ struct FinArgs {
   const double* bnd;      // lb[Text] ub[Text] or null
   double TolCon, WeightThreshold, WeightPenalty, beta;
   int M, C, ncol, want_grad, has_bnd, var_stride;
+  int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* out;            // R x (OUT_HDR + 3T)
 };
 
@@ -704,6 +705,18 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
   // ---- expected log joint from the per-component sums over hyper-samples (k_lj_reduce):
   // G = (1/S) sum_s sum_k w_k I_sk  (:203,:400)
   const double* lb = a.ljbar + (size_t)r * K * LJS;
+  const double* pe_src = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;
+  if (a.stage) {
+    // the per-restart records are read in column order by few threads below: stage them in LDS with coalesced loads
+    // (a single chain, R = 1, is bound by exactly this latency)
+    double* lbL = scal + 8;
+    double* peL = lbL + K * LJS;
+    for (int i = tid; i < K * LJS; i += nt) lbL[i] = lb[i];
+    if (pe_src) for (int i = tid; i < K * a.C * a.ncol; i += nt) peL[i] = pe_src[i];
+    lb = lbL;
+    if (pe_src) pe_src = peL;
+    __syncthreads();
+  }
   for (int k = tid; k < K; k += nt) Ibar[k] = lb[(size_t)k * LJS] * invS;
   __syncthreads();
   {
@@ -738,7 +751,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
   const double lognf = v[L.lognf()];
   if (a.entpart) {
     const double invM = 1.0 / (2.0 * a.M);  // Ns = 2*Mh samples per component
-    const double* pe = a.entpart + (size_t)r * K * a.C * a.ncol;
+    const double* pe = pe_src;
     for (int j = tid; j < K; j += nt) {
       double acc = 0.0;
       for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol];
