@@ -135,3 +135,22 @@ def test_rank1_update_equals_full_posterior(va):
     o = va.gplite_pred(gp_r1, p["X"][:5] + 0.1, None, None, False)
     r = R.gplite_pred(R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4), p["X"][:5] + 0.1)
     assert relerr(o[2], r[2]) < 1e-6
+
+
+def test_pred_and_acq_chunking_over_many_points(va):
+    """Sweeps whose S x N x Nstar cross-kernel matrix would exceed 1 GiB are cut into chunks of test points; the
+    chunked result equals the one-shot result up to the sq_dist centring constant (rounding)."""
+    from tests.test_gpu_elbo import problem
+    p, gp, vp, _ = problem(61, 6, 300, 5, 24)          # S*N*8 = 57.6 KB per point -> chunks of 18640 points
+    rng = np.random.default_rng(0)
+    Xs = 1.3 * rng.standard_normal((40000, 6))
+    fmu, fs2 = va.gplite_pred(gp, Xs, None, None, True)[2:4]
+    idx = rng.choice(40000, 600, replace=False)
+    fmu_s, fs2_s = va.gplite_pred(gp, Xs[idx], None, None, True)[2:4]
+    sf2 = np.exp(2 * gp["post"][0]["hyp"][6])
+    assert relerr(np.asarray(fmu)[idx], fmu_s) < 1e-10 and np.max(np.abs(np.asarray(fs2)[idx] - np.asarray(fs2_s))) < 1e-10 * sf2
+    st = {"ymax": float(np.max(gp["y"])), "VarianceRegularizedAcqFcn": False, "TolGPVar": 1e-4}
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqflog_vbmc", None)
+    acq_s = va.acqwrapper_vbmc(Xs[idx], vp, gp, st, False, "acqflog_vbmc", None)
+    far = np.asarray(fs2_s).mean(axis=1) > 1e-6 * sf2
+    assert np.max(np.abs(acq[idx][far] - acq_s[far])) < 1e-7

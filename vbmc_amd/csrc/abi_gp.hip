@@ -465,9 +465,46 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
 }
 }  // namespace
 
+namespace {
+// The prediction pipeline materialises S x N x Nstar cross-kernel values; very large sweeps are cut into chunks of
+// test points whose matrix stays below 1 GiB (the sq_dist centring constant then differs per chunk: rounding only).
+int pred_chunk_points(const vbmc_gp* gp, int Nstar) {
+  if (!gp) return Nstar;
+  const size_t per_point = (size_t)gp->S * gp->N * 8;
+  const size_t cap = ((size_t)1 << 30) / std::max<size_t>(per_point, 1);
+  const size_t ch = std::max<size_t>(256, (cap / 16) * 16);
+  return (size_t)Nstar <= ch ? Nstar : (int)ch;
+}
+// rows [i0, i0 + n) of a column-major Ntot x C matrix -> contiguous n x C
+void gather_rows(const double* src, int Ntot, int C, int i0, int n, std::vector<double>& dst) {
+  dst.resize((size_t)n * C);
+  for (int c = 0; c < C; ++c) memcpy(dst.data() + (size_t)c * n, src + (size_t)c * Ntot + i0, (size_t)n * 8);
+}
+void scatter_rows(const std::vector<double>& src, int Ntot, int C, int i0, int n, double* dst) {
+  if (!dst) return;
+  for (int c = 0; c < C; ++c) memcpy(dst + (size_t)c * Ntot + i0, src.data() + (size_t)c * n, (size_t)n * 8);
+}
+}  // namespace
+
 extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
                                     int ssflag, double* ymu, double* ys2, double* fmu, double* fs2) {
   if (!ctx) return VBMC_ERR_INVALID;
+  if (gp && Xstar && Nstar > pred_chunk_points(gp, Nstar)) {
+    const int CH = pred_chunk_points(gp, Nstar), D = gp->D;
+    const int nc = (ssflag && gp->S > 1) ? gp->S : 1;
+    std::vector<double> xs, s2c, o[4];
+    for (int i0 = 0; i0 < Nstar; i0 += CH) {
+      const int n = std::min(CH, Nstar - i0);
+      gather_rows(Xstar, Nstar, D, i0, n, xs);
+      if (s2star) s2c.assign(s2star + i0, s2star + i0 + n);
+      for (auto& v : o) v.assign((size_t)n * nc, 0.0);
+      vbmc_status st_ = vbmc_gp_pred(ctx, gp, n, xs.data(), s2star ? s2c.data() : nullptr, ssflag, o[0].data(), o[1].data(), o[2].data(), o[3].data());
+      if (st_ != VBMC_OK) return st_;
+      scatter_rows(o[0], Nstar, nc, i0, n, ymu); scatter_rows(o[1], Nstar, nc, i0, n, ys2);
+      scatter_rows(o[2], Nstar, nc, i0, n, fmu); scatter_rows(o[3], Nstar, nc, i0, n, fs2);
+    }
+    return VBMC_OK;
+  }
   PredBufs pb;
   { vbmc_status s_ = pred_on_device(ctx, "vbmc_gp_pred", gp, Nstar, Xstar, s2star, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
@@ -508,6 +545,20 @@ extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar
   if (acq_id < 0 || acq_id > 3) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "acquisition function id %d not accelerated (0 acqf, 1 acqflog, 2 acqus, 3 acqfsn2)", acq_id);
   if (acq_id == 3 && (!gplengthscale || !X_rescaled || !sn2new))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_eval: acqfsn2 needs gplengthscale, X_rescaled and sn2new");
+  if (gp && Xs && Nstar > pred_chunk_points(gp, Nstar)) {
+    const int CH = pred_chunk_points(gp, Nstar);
+    std::vector<double> xs, o[3];
+    for (int i0 = 0; i0 < Nstar; i0 += CH) {
+      const int n = std::min(CH, Nstar - i0);
+      gather_rows(Xs, Nstar, gp->D, i0, n, xs);
+      for (auto& v : o) v.assign(n, 0.0);
+      vbmc_status st_ = vbmc_acq_eval(ctx, gp, n, xs.data(), acq_id, K, vp_mu, vp_sigma, vp_lambda, vp_w, ymax, var_regularized, TolGPVar,
+                                      gplengthscale, X_rescaled, sn2new, o[0].data(), o[1].data(), o[2].data());
+      if (st_ != VBMC_OK) return st_;
+      scatter_rows(o[0], Nstar, 1, i0, n, acq); scatter_rows(o[1], Nstar, 1, i0, n, fbar); scatter_rows(o[2], Nstar, 1, i0, n, vtot);
+    }
+    return VBMC_OK;
+  }
   PredBufs pb;
   { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
@@ -656,6 +707,20 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   if (!is || !acq || !gplengthscale || !X_rescaled || !sn2new) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_iqr_eval: bad arguments");
   if (gp && (is->N != gp->N || is->S != gp->S || is->D != gp->D))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_iqr_eval: importance-sampling state belongs to a different GP");
+  if (gp && Xs && Nstar > pred_chunk_points(gp, Nstar)) {
+    const int CH = pred_chunk_points(gp, Nstar);
+    std::vector<double> xs, o[3];
+    for (int i0 = 0; i0 < Nstar; i0 += CH) {
+      const int n = std::min(CH, Nstar - i0);
+      gather_rows(Xs, Nstar, gp->D, i0, n, xs);
+      for (auto& v : o) v.assign(n, 0.0);
+      vbmc_status st_ = vbmc_acq_iqr_eval(ctx, gp, is, n, xs.data(), gplengthscale, X_rescaled, sn2new, var_regularized, TolGPVar,
+                                          o[0].data(), o[1].data(), o[2].data());
+      if (st_ != VBMC_OK) return st_;
+      scatter_rows(o[0], Nstar, 1, i0, n, acq); scatter_rows(o[1], Nstar, 1, i0, n, fbar); scatter_rows(o[2], Nstar, 1, i0, n, vtot);
+    }
+    return VBMC_OK;
+  }
   PredBufs pb;
   { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
