@@ -298,6 +298,20 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
                                    double* nlZ, double* dnlZ) {
   if (!ctx) return VBMC_ERR_INVALID;
   if (!nlZ || (compute_grad && !dnlZ)) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_nlz: null output");
+  {
+    // three B x N x N work matrices: keep each below 2 GiB by cutting the batch
+    const size_t per = (size_t)N * N * 8;
+    const int CHB = (int)std::max<size_t>(1, ((size_t)2 << 30) / std::max<size_t>(per, 1));
+    if (N > 0 && B > CHB && hyp) {
+      for (int b0 = 0; b0 < B; b0 += CHB) {
+        const int nb = std::min(CHB, B - b0);
+        vbmc_status st_ = vbmc_gp_nlz(ctx, N, D, nb, Nhyp, meanfun, noisefun, X, y, s2, hyp + (size_t)b0 * Nhyp, compute_grad, nlZ + b0,
+                                      compute_grad ? dnlZ + (size_t)b0 * Nhyp : nullptr);
+        if (st_ != VBMC_OK) return st_;
+      }
+      return VBMC_OK;
+    }
+  }
   GpFactor f;
   { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
