@@ -72,12 +72,37 @@ def acq_info(acqFun):
 
 
 def acqwrapper_vbmc(Xs, vp, gp, optimState, transpose_flag=False, acqFun="acqf_vbmc", acqInfo=None, *, outside=None,
-                    nargout=1, engine=None):
+                    nargout=1, engine=None, shard=None):
     """acq = acqwrapper_vbmc(Xs,vp,gp,optimState,transpose_flag,acqFun,acqInfo).
 
-    ``optimState`` keys used: ymax, VarianceRegularizedAcqFcn, TolGPVar (+ gplengthscale for acqfsn2, whose
-    gp needs X_rescaled and sn2new).  ``nargout=3`` also returns (fbar, vtot) of :21-29.
-    """
+    ``optimState`` keys used: ymax, VarianceRegularizedAcqFcn, TolGPVar (+ gplengthscale for acqfsn2 / acqviqr /
+    acqimiqr, whose gp needs X_rescaled and sn2new, + ActiveImportanceSampling for the IQR functions).
+    ``nargout=3`` also returns (fbar, vtot) of :21-29.
+
+    Sharded form: ``shard`` = (rank, world, allgather) from vbmc_amd.dist.shard_spec() makes every rank evaluate the
+    test points i = rank (mod world) on its own GPU (full GP replica) and all-gather the acquisition values, so that
+    all ranks hold the identical vector and pick the identical argmin (private/activesample_vbmc.m:227-233)."""
+    if shard is not None:
+        rank, world, allgather = shard
+        X_ = np.asarray(Xs, dtype=np.float64)
+        if transpose_flag:
+            X_ = X_.T
+        X_ = X_.reshape(-1, gp["X"].shape[1])
+        n = X_.shape[0]
+        idx = np.arange(n)[rank::world]
+        out_l = None if outside is None else np.asarray(outside, dtype=bool).reshape(-1)[idx]
+        if idx.size:
+            loc = _acq_local(X_[idx], vp, gp, optimState, acqFun, out_l, 3, engine)
+        else:
+            loc = (np.zeros(0), np.zeros(0), np.zeros(0))
+        full = [allgather(v, idx, n) for v in (loc if nargout >= 3 else loc[:1])]
+        acq = full[0].reshape(1, -1) if transpose_flag else full[0]
+        return (acq, full[1], full[2]) if nargout >= 3 else acq
+    return _acq_local(Xs, vp, gp, optimState, acqFun, outside, nargout, engine, transpose_flag)
+
+
+def _acq_local(Xs, vp, gp, optimState, acqFun, outside, nargout, engine, transpose_flag=False):
+    """The single-GPU evaluation behind acqwrapper_vbmc (one fused device pass)."""
     engine = engine or default_engine()
     ctx = engine.ctx
     info = acq_info(acqFun)
