@@ -1,0 +1,71 @@
+"""GPU parity on randomly drawn problem shapes and flag combinations (hypothesis, derandomised): the HIP path
+through the C ABI against the oracle -- the three-way cross-check of SURVEY 8c(4) with the mpmath vectors pinning
+the oracle itself (tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import vbmc_ref as R
+from tests._cases import synth_problem
+from tests.test_gpu_elbo import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+shape = st.tuples(st.integers(1, 8), st.integers(1, 20), st.integers(5, 60), st.integers(1, 4))
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=shape, seed=st.integers(0, 10**6), flags=st.tuples(st.booleans(), st.booleans(), st.booleans(), st.booleans()),
+       ns_half=st.integers(0, 20), compute_var=st.sampled_from([0, 0, 1, 2]), meanfun=st.sampled_from([0, 1, 4, 4]),
+       beta=st.sampled_from([0.0, 0.0, 1.3]), grad=st.booleans())
+def test_negelcbo_random_shapes(va, shape, seed, flags, ns_half, compute_var, meanfun, beta, grad):
+    D, K, N, S = shape
+    if not any(flags[:3]):
+        flags = (True,) + flags[1:]                  # the weights-only branch (negelcbo_vbmc.m:54) is host-side, cached-stats code
+    p = synth_problem(seed, D, N, K, S, meanfun=meanfun)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=meanfun, noisefun=p["noisefun"], s2=p["s2"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"], optimize=flags)
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta, vp = R.get_vptheta(vp)
+    Ns = 2 * ns_half
+    if grad and compute_var == 1:
+        compute_var = 2                              # a gradient with variance needs the diagonal approximation (gplogjoint.m:28-32)
+    if beta != 0.0 and compute_var == 0:
+        beta = 0.0
+    eps = np.random.default_rng(seed + 1).standard_normal((K, max(ns_half, 1), D))[:, :ns_half, :] if Ns > 0 else None
+    ref = R.negelcbo_vbmc(theta, beta, vp, gp, Ns, grad, compute_var, eps=eps)
+    out = va.negelcbo_batch(theta, beta, vp, gp, Ns, grad, compute_var, eps=eps)
+    assert relerr(out["F"][0], ref["F"]) < 1e-9, (shape, flags, Ns, compute_var, meanfun, beta)
+    if grad:
+        assert relerr(out["dF"][:, 0], ref["dF"]) < 1e-8
+    assert relerr(out["G"][0], ref["G"]) < 1e-9 and relerr(out["H"][0], ref["H"]) < 1e-9
+    if compute_var:
+        assert relerr(out["varG"][0], ref["varG"]) < 1e-7
+
+
+@settings(max_examples=15, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 8), st.integers(5, 70), st.integers(1, 4)), seed=st.integers(0, 10**6),
+       meanfun=st.sampled_from([0, 1, 4]), nstar=st.integers(1, 90), noisy=st.booleans())
+def test_gp_post_pred_random_shapes(va, shape, seed, meanfun, nstar, noisy):
+    D, N, S = shape
+    p = synth_problem(seed, D, N, 2, S, meanfun=meanfun, noisy=noisy)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=meanfun, noisefun=p["noisefun"], s2=p["s2"])
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, meanfun, p["noisefun"], p["s2"])
+    for a, b in zip(gp["post"], ref["post"]):
+        assert a["Lchol"] == b["Lchol"] and a["sn2_mult"] == b["sn2_mult"]
+        assert relerr(a["alpha"], b["alpha"]) < 1e-8
+    Xs = 1.3 * np.random.default_rng(seed + 2).standard_normal((nstar, D))
+    r_d = va.gplite_pred(gp, Xs, None, None, True)
+    r_o = R.gplite_pred(ref, Xs, None, None, True)
+    sf2 = np.exp(2 * ref["post"][0]["hyp"][D])
+    assert relerr(np.asarray(r_d[2]).reshape(-1), np.asarray(r_o[2]).reshape(-1)) < 1e-8
+    assert np.max(np.abs(np.asarray(r_d[3]).reshape(-1) - np.asarray(r_o[3]).reshape(-1))) < 1e-8 * sf2
