@@ -383,6 +383,7 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "output-dependent noise (noisefun(3) = 1) at test points not accelerated");
   // an empty s2star counts as zero (gplite_noisefun.m:51): the kernels add nothing when the pointer is null
   const int N = gp->N, D = gp->D, S = gp->S;
+  if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
   const int Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
   const size_t tlds0 = TRSM_LDS_BYTES(N);
   if ((size_t)16 * Np * 8 > PRED_LDS_MAX || nblk > PRED_MAXG || tlds0 > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
