@@ -494,10 +494,11 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     // kernel has the lower latency
     const bool lj_mfma = P.compute_grad && K <= 256 && (long long)S * R >= ctx->num_cu / 2 && !(ljf && !strcmp(ljf, "valu"));
     DISPATCH_DT(dt, {
-      if (lj_mfma) {
-        constexpr int NCT = (2 * DT + 1 + 15) / 16;
-        const int nw = (K + 15) / 16;
-        hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), (size_t)nw * 16 * 16 * NCT * sizeof(double), st, dm, P.d_vpd,
+      constexpr int NCT = (2 * DT + 1 + 15) / 16;
+      const int nw = (K + 15) / 16;
+      const size_t mom_lds = (size_t)nw * 16 * 16 * NCT * sizeof(double);   // moment exchange; large K x D falls back to the VALU kernel
+      if (lj_mfma && mom_lds <= 48 * 1024) {
+        hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, st, dm, P.d_vpd,
                            gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
       } else {
         hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
