@@ -296,3 +296,28 @@ def test_output_subset_equals_full_outputs(va):
     assert np.array_equal(part["F"], full["F"]) and np.array_equal(part["dF"], full["dF"])
     one = va.negelcbo_batch(Th[:, :1], 0, vp, gp, 64, True, 0, seed=9, outputs=("F", "dF"))
     assert np.array_equal(one["F"], full["F"][:1]) and np.array_equal(one["dF"], full["dF"][:, :1])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 9, 1), (3, 16, 40, 2), (10, 50, 130, 3), (17, 33, 70, 2), (32, 20, 50, 2), (6, 100, 64, 2),
+                                   (12, 7, 65, 1)])
+def test_logjoint_mfma_and_valu_kernels_agree_with_oracle(va, shape, monkeypatch):
+    """k_logjoint_mfma (gradient sums as moments on the matrix cores; chosen for large S x R grids) and k_logjoint
+    (VALU sums) forced in turn on the same small problems: both against the oracle, all optimise-flag subsets."""
+    D, K, N, S = shape
+    p, gp, vp, theta = problem(500 + D + K, D, N, K, S)
+    Th = np.asfortranarray(theta[:, None] + 0.02 * np.random.default_rng(1).standard_normal((theta.size, 3)))
+    ref = [R.negelcbo_vbmc(Th[:, r], 0, vp, gp, 0, True, 0) for r in range(3)]
+    for kern in ("mfma", "valu"):
+        monkeypatch.setenv("VBMC_LJ_KERNEL", kern)
+        out = va.negelcbo_batch(Th, 0, vp, gp, 0, True, 0)
+        for r in range(3):
+            assert relerr(out["G"][r], ref[r]["G"]) < 1e-10, (kern, shape)
+            assert relerr(out["dG"][:, r], ref[r]["dG"]) < 1e-9, (kern, shape, relerr(out["dG"][:, r], ref[r]["dG"]))
+    monkeypatch.setenv("VBMC_LJ_KERNEL", "mfma")
+    for flags in [(1, 0, 0, 0), (0, 1, 1, 0), (1, 1, 1, 0)]:
+        vpf = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"], optimize=flags)
+        vpf["w"] = vp["w"]
+        th, vpf = R.get_vptheta(vpf)
+        o = va.negelcbo_batch(th, 0, vpf, gp, 0, True, 0)
+        rr = R.negelcbo_vbmc(th, 0, vpf, gp, 0, True, 0)
+        assert relerr(o["dG"][:, 0], rr["dG"]) < 1e-9, (flags, shape)

@@ -488,11 +488,12 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // ---- expected log joint
   if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
   {
-    // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu forces the latter.
+    // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
     const char* ljf = getenv("VBMC_LJ_KERNEL");
     // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
     // kernel has the lower latency
-    const bool lj_mfma = P.compute_grad && K <= 256 && (long long)S * R >= ctx->num_cu / 2 && !(ljf && !strcmp(ljf, "valu"));
+    const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
+    const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
     DISPATCH_DT(dt, {
       constexpr int NCT = (2 * DT + 1 + 15) / 16;
       const int nw = (K + 15) / 16;
