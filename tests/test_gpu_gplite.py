@@ -154,3 +154,20 @@ def test_pred_and_acq_chunking_over_many_points(va):
     acq_s = va.acqwrapper_vbmc(Xs[idx], vp, gp, st, False, "acqflog_vbmc", None)
     far = np.asarray(fs2_s).mean(axis=1) > 1e-6 * sf2
     assert np.max(np.abs(acq[idx][far] - acq_s[far])) < 1e-7
+
+
+@pytest.mark.parametrize("cfg", [(4, 60, 3, 3000), (7, 130, 1, 2500), (3, 17, 2, 1111)])
+def test_pred_many_points_few_samples(va, cfg):
+    """Few hyper-samples and many test points: the point tiles are sliced over gridDim.z so that the chip is covered."""
+    from tests.test_gpu_elbo import problem
+    D, N, S, nstar = cfg
+    p, gp, vp, _ = problem(71, D, N, 3, S)
+    Xs = 1.4 * np.random.default_rng(3).standard_normal((nstar, D))
+    r_d = va.gplite_pred(gp, Xs, None, None, True)
+    r_o = R.gplite_pred(gp, Xs, None, None, True)
+    sf2 = np.exp(2 * gp["post"][0]["hyp"][D])
+    assert relerr(np.asarray(r_d[2]).reshape(-1), np.asarray(r_o[2]).reshape(-1)) < 1e-9
+    assert np.max(np.abs(np.asarray(r_d[3]).reshape(-1) - np.asarray(r_o[3]).reshape(-1))) < 1e-9 * sf2
+    avg_d = va.gplite_pred(gp, Xs, None, None, False)        # hyper-sample average + between-sample variance (:154-165)
+    avg_o = R.gplite_pred(gp, Xs, None, None, False)
+    assert relerr(avg_d[0], avg_o[0]) < 1e-9 and np.max(np.abs(np.asarray(avg_d[1]) - np.asarray(avg_o[1]))) < 1e-9 * sf2
