@@ -257,7 +257,8 @@ def test_block_sparse_mode_is_exact_to_rounding(va):
         assert relerr(s_["H"][0], ref["H"]) < RT_VAL and relerr(s_["dF"][:, 0], ref["dF"]) < RT_GRAD
 
 
-SWEEP = [(1, 3), (7, 16), (14, 17), (15, 33), (18, 64), (22, 65), (23, 40), (30, 20), (32, 12), (5, 128), (3, 130), (9, 1)]
+SWEEP = [(1, 3), (7, 16), (14, 17), (15, 33), (18, 64), (22, 65), (23, 40), (30, 20), (32, 12), (5, 128), (3, 130), (9, 1),
+         (26, 100), (12, 96), (10, 97), (32, 70)]   # the last four: components split over two waves (64 < K <= 128)
 
 
 @pytest.mark.parametrize("dk", SWEEP, ids=["D%dK%d" % t for t in SWEEP])

@@ -261,29 +261,32 @@ static hipError_t set_entropy_lds(bool grad, size_t lds) {
 // ---- MFMA entropy kernel dispatch: QS = ceil((D+2)/4) in 1..9 (one translation unit each,
 // ent_mfma_inst.hip), KT = ceil(K/16) in 1..8 (1..4 for QS > 6: register budget)
 extern "C" {
-int vbmc_launch_ent_mfma_qs1(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs2(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs3(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs4(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs5(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs6(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs7(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs8(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
-int vbmc_launch_ent_mfma_qs9(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs1(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs2(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs3(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs4(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs5(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs6(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs7(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs8(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_mfma_qs9(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 }
-static bool launch_entropy_mfma(int qs, int kt, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
-  typedef int (*fn_t)(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
+  typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
   static const fn_t fns[9] = {vbmc_launch_ent_mfma_qs1, vbmc_launch_ent_mfma_qs2, vbmc_launch_ent_mfma_qs3,
                               vbmc_launch_ent_mfma_qs4, vbmc_launch_ent_mfma_qs5, vbmc_launch_ent_mfma_qs6,
                               vbmc_launch_ent_mfma_qs7, vbmc_launch_ent_mfma_qs8, vbmc_launch_ent_mfma_qs9};
   if (qs < 1 || qs > 9) return false;
-  return fns[qs - 1](kt, grad ? 1 : 0, g.x, g.y, g.z, (void*)st, &ea) == 0;
+  return fns[qs - 1](kt, grad ? 1 : 0, hv, g.x, g.y, g.z, (void*)st, &ea) == 0;
 }
-static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out) {
-  const int qs = (D + 2 + 3) / 4, kt = (K + 15) / 16;
-  *qs_out = qs; *kt_out = kt;
-  if (qs < 1 || qs > 9 || kt < 1 || kt > 8) return false;
-  return qs <= 6 || kt <= 4;
+// K <= 64: one wave per (chunk, component, restart) with kt = ceil(K/16) k-tiles; 64 < K <= 128: the components are split
+// over the two waves of a workgroup (hv = 2), kt = ceil(ceil(K/2)/16) in {3, 4}.  D <= 34 (qs <= 9).
+static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out, int* hv_out) {
+  const int qs = (D + 2 + 3) / 4;
+  const int hv = K <= 64 ? 1 : 2;
+  const int kt = (((K + hv - 1) / hv) + 15) / 16;
+  *qs_out = qs; *kt_out = kt; *hv_out = hv;
+  return qs >= 1 && qs <= 9 && K >= 1 && K <= 128 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -295,7 +298,7 @@ struct ElboPlan {
   int compute_grad = 0, compute_var = 0, dt = 0;
   double beta = 0.0;
   bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false;
-  int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, var_stride = 0;
+  int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
   double *d_ljbar = nullptr;
@@ -411,7 +414,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
 
   if (P.mc) {
     const char* force = getenv("VBMC_ENT_KERNEL");  // "valu" (A/B testing); default: the MFMA kernel when it fits
-    P.use_mfma = mfma_entropy_fits(D, K, &P.qs, &P.kt);
+    P.use_mfma = mfma_entropy_fits(D, K, &P.qs, &P.kt, &P.hv);
     if (force && !strcmp(force, "valu")) P.use_mfma = false;
     const int tile_sz = P.use_mfma ? 16 : 32;          // base samples per tile
     const int ntile = (Mh + tile_sz - 1) / tile_sz;
@@ -419,7 +422,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     // i.e. whole rounds of resident waves, with the per-wave setup worth ~3 tiles
     {
       const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5);
-      const long long kr = (long long)K * R;
+      const long long kr = (long long)K * R * (P.use_mfma ? P.hv : 1);   // waves per chunk index
       const double setup = 3.0;
       double best = 1e300;
       int bestC = 1;
@@ -519,7 +522,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff;
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     if (P.use_mfma) {
-      bool ok = launch_entropy_mfma(P.qs, P.kt, P.compute_grad != 0, dim3(P.C, K, R), st, ea);
+      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(P.C, K, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
     } else {
       const size_t lds = P.ent_lds;

@@ -17,7 +17,7 @@
 // 16 base samples, processed twice (+eps, -eps: antithetic, entmc_vbmc.m:53-54).  All mixture-side
 // MFMA operands are built once per wave and stay in registers; LDS holds only the 16 x D eps tile
 // (read in two layouts), the 64-entry exp table and 16 scalars.  The number of k-tiles KT =
-// ceil(K/16) is a template parameter so the tile body is one straight-line block (4*KT independent
+// ceil(K/16) <= 4 is a template parameter (64 < K <= 128: see HV below) so the tile body is one straight-line block (4*KT independent
 // exp chains for the scheduler); padded components carry the constant -1e6 and vanish in the exp.
 // sum_i log q'_i is accumulated as a mantissa product + exponent sum (one log per 256 samples).
 // Partials have the same layout as k_entropy (sum log q | G[D] | SG | LG[D] | W[K]) and are reduced
@@ -31,35 +31,47 @@
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
 
-template <int QS, int KT, bool GRAD, bool SPARSE>
-__global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_entropy_mfma(EntArgs a) {
+// HV = 2 (64 < K <= 128): the components are split between the two waves of a workgroup, each running the KT <= 4
+// register-resident body on its half; per sign the waves exchange their partial PV outputs (16 x 16 NPV doubles per wave
+// through LDS, one workgroup barrier) and both continue with the full q', A', B' -- identical bits on both sides
+// (a + b == b + a).  Wave 0 owns the per-sample accumulators (H, G, LG); each wave owns the weight gradient of its half.
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1>
+__global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(EntArgs a) {
+  static_assert(KT <= 4, "larger mixtures are split over two waves (HV = 2)");
   constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
-  __shared__ double Et[16 * DP];           // eps tile [i][d]
-  __shared__ double RQ[16];                // q'_i then 1/q'_i
+  __shared__ double Et_all[1][16 * DP];    // eps tile [i][d], staged by wave 0 and shared by the waves of the workgroup
+  __shared__ double RQ_all[HV][16];        // q'_i then 1/q'_i
   __shared__ double TAB[VB_EXP_TAB_N];     // 2^(j/256)
-  __shared__ double BND[SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
-  const int lane = threadIdx.x;
+  __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
+  __shared__ double YX[HV == 2 ? 2 : 1][HV == 2 ? NPV * 4 * WAVE : 1];   // partial PV outputs of the two halves
+  const int tid = threadIdx.x, hv = HV == 2 ? tid >> 6 : 0, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
+  double* Et = Et_all[0];
+  double* RQ = RQ_all[hv];
+  double* BND = BND_all[hv];
+  const int Kh = (K + HV - 1) / HV;                    // components per wave
+  const int kbase = hv * Kh;
+  const int Kw = min(K, kbase + Kh) - kbase;           // this wave's components: kbase .. kbase + Kw - 1
   const int PSg = D + ENTP_EXTRA;
   // stage this restart's packed parameter block [k][m_1..m_D, h, cK, w, wi] in LDS with coalesced loads;
   // the per-lane operand fragments below are gathered from LDS, not from global memory
   extern __shared__ double PB[];
   {
     const double* gsrc = a.entp + (size_t)r * K * PSg;
-    for (int idx = lane; idx < K * PSg; idx += WAVE) PB[idx] = gsrc[idx];
+    for (int idx = tid; idx < K * PSg; idx += WAVE * HV) PB[idx] = gsrc[idx];
   }
-  for (int t = lane; t < VB_EXP_TAB_N; t += WAVE) TAB[t] = c_exp2_tab[t];
+  for (int t = tid; t < VB_EXP_TAB_N; t += WAVE * HV) TAB[t] = c_exp2_tab[t];
   __syncthreads();
   const double* gp = PB;
   const double* pj = gp + (size_t)j * PSg;
   VpLayout L{D, K};
   const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
-  const int nr_last = (K - 16 * (KT - 1) + 3) >> 2;  // accumulator registers with a valid component in the last k-tile (1..4)
+  const int nr_last = max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
@@ -70,8 +82,8 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
     const int k = 16 * kt + li;
-    const bool kv = k < K;
-    const double* pk = gp + (size_t)(kv ? k : 0) * PSg;
+    const bool kv = k < Kw;
+    const double* pk = gp + (size_t)(kv ? kbase + k : 0) * PSg;
     double h = pk[D];
     double m2 = 0.0;
     for (int d = 0; d < D; ++d) { double t = pk[d] - pj[d]; m2 = fma(t, t, m2); }
@@ -94,8 +106,8 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int k2 = 16 * kt + 4 * rr + lg;
-      const bool kv2 = k2 < K;
-      const double* p2 = gp + (size_t)(kv2 ? k2 : 0) * PSg;
+      const bool kv2 = k2 < Kw;
+      const double* p2 = gp + (size_t)(kv2 ? kbase + k2 : 0) * PSg;
       if (GRAD) {
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
@@ -134,7 +146,9 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
     const int b0 = tile * 16;
     // ---- stage the 16 x D eps tile in LDS (zeros for padded dims / samples beyond Mh)
     __syncthreads();
-    if (epsr) {
+    if (HV == 2 && hv != 0) {
+      // wave 0 stages (and, in device-RNG mode, draws) the tile for both
+    } else if (epsr) {
       for (int idx = lane; idx < 16 * DP; idx += WAVE) {
         const int i = idx / DP, d = idx - i * DP;
         Et[idx] = (d < D && b0 + i < a.Mh) ? epsr[(size_t)(b0 + i) * D + d] : 0.0;
@@ -243,6 +257,18 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
           if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][3], VB[KT - 1][3][pv], Y2[pv], 0, 0, 0);
           Y[pv] += Y2[pv];
         }
+        if (HV == 2) {
+          // both halves of the mixture: add the other wave's partial q', A', B'
+#pragma unroll
+          for (int pv = 0; pv < NPV; ++pv)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) YX[hv][(pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
+          __syncthreads();
+#pragma unroll
+          for (int pv = 0; pv < NPV; ++pv)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Y[pv][rr] += YX[hv ^ 1][(pv * 4 + rr) * WAVE + lane];
+        }
         // ---- per-sample scalars in the sample layout (lane <-> sample li): q' from column 0
         if (li == 0) {
 #pragma unroll
@@ -272,6 +298,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
           const double rq = RQ[i];
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv) {
+            if (HV == 2 && (pv & 1) != hv) continue;      // the two waves share the column blocks of the gradient
             const int d = 16 * pv + li - 2;
             if (d >= 0 && d < D) {
               const double e = sgn * Et[i * DP + d];
@@ -290,6 +317,12 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
           for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
         qp += __shfl_xor(qp, 16, 64);
         qp += __shfl_xor(qp, 32, 64);
+        if (HV == 2) {
+          YX[hv][lane] = qp;
+          __syncthreads();
+          qp += YX[hv ^ 1][lane];
+          __syncthreads();
+        }
         const double qs_ = svalid ? qp : 1.0;
         pm *= __builtin_amdgcn_frexp_mant(qs_);
         pe += __builtin_amdgcn_frexp_exp(qs_);
@@ -308,7 +341,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
   // ---- fixed-order reductions and the partial record
   double* o = a.part + (((size_t)r * K + j) * a.C + c) * a.ncol;
   accH = wave_sum(accH);
-  if (lane == 0) o[0] = accH;
+  if (lane == 0 && hv == 0) o[0] = accH;
   if (GRAD) {
     double sgsum = 0.0;
 #pragma unroll
@@ -318,11 +351,18 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
       lgd += __shfl_xor(lgd, 16, 64); lgd += __shfl_xor(lgd, 32, 64);
       const int d = 16 * pv + li - 2;
       const bool dv = d >= 0 && d < D;
-      if (dv && lg == 0) { o[1 + d] = g; o[2 + D + d] = lgd; }
-      sgsum += (dv && lg == 0) ? lgd : 0.0;
+      const bool mine = HV == 1 || (pv & 1) == hv;
+      if (dv && lg == 0 && mine) { o[1 + d] = g; o[2 + D + d] = lgd; }
+      sgsum += (dv && lg == 0 && mine) ? lgd : 0.0;
     }
     sgsum = wave_sum(sgsum);            // SG = sum_d LG_d  (entmc_vbmc.m:87)
-    if (lane == 0) o[1 + D] = sgsum;
+    if (HV == 2) {
+      __syncthreads();
+      if (lane == 0) YX[hv][0] = sgsum;
+      __syncthreads();
+      sgsum = YX[0][0] + YX[1][0];
+    }
+    if (lane == 0 && hv == 0) o[1 + D] = sgsum;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -331,7 +371,7 @@ __global__ void __launch_bounds__(WAVE, (KT <= 2 ? 3 : (KT <= 4 ? 2 : 1))) k_ent
         wv += __shfl_xor(wv, 1, 64); wv += __shfl_xor(wv, 2, 64);
         wv += __shfl_xor(wv, 4, 64); wv += __shfl_xor(wv, 8, 64);
         const int k = 16 * kt + 4 * rr + lg;
-        if (li == 0 && k < K) o[2 + 2 * D + k] = wv;
+        if (li == 0 && k < Kw) o[2 + 2 * D + kbase + k] = wv;
       }
   }
 }
