@@ -139,3 +139,22 @@ def test_noisy_gp_prediction_and_viqr_without_s2star(va):
     ref, _, _ = R.acqwrapper_vbmc(Xs, vp, gp, st_ref, "acqviqr")
     acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqviqr_vbmc", None)
     assert np.max(np.abs(acq - ref)) < 1e-8
+
+
+def test_viqr_end_to_end_through_the_mirror(va):
+    """activeimportancesampling_vbmc (draws from the variational posterior) -> acqwrapper_vbmc(acqviqr): everything
+    but the draws on the device; the oracle gets the same importance points."""
+    gp, vp, Xs, st, rng = setup(17, 4, 70, 5, 3)
+    gl = np.exp(np.mean(np.stack([q["hyp"][:4] for q in gp["post"]], axis=1), axis=1))
+    gp = dict(gp, X_rescaled=gp["X"] / gl[None, :], sn2new=np.full(70, 0.05))
+    ais = va.activeimportancesampling_vbmc(vp, gp, "acqviqr_vbmc", None, {"ActiveImportanceSamplingMCMCSamples": 64},
+                                           rng=np.random.default_rng(3))
+    assert ais["Xa"].shape == (64, 4) and ais["lnw"].shape == (3, 64)
+    st = dict(st, gplengthscale=gl, VarianceRegularizedAcqFcn=False, ActiveImportanceSampling=ais)
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqviqr_vbmc", None)
+    Kax, Ct = R.acq_is_precompute(gp, ais["Xa"])
+    fs2a = np.asarray(R.gplite_pred(gp, ais["Xa"], None, None, True)[3]).reshape(64, -1)
+    st_o = dict(st, ActiveImportanceSampling={"Xa": ais["Xa"], "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": ais["lnw"]})
+    ref, _, _ = R.acqwrapper_vbmc(Xs, vp, gp, st_o, "acqviqr")
+    assert np.max(np.abs(acq - ref)) < 1e-8
+    assert int(np.argmin(acq)) == int(np.argmin(ref))

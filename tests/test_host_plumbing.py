@@ -85,3 +85,24 @@ def test_vbinit_types_and_shapes():
             assert abs(np.sum(v["w"]) - 1) < 1e-12 and np.all(v["sigma"] > 0)
     vs, _ = opt.vbinit_vbmc(1, 3, vp, 4, Xs, ys, rng)
     assert np.array_equal(vs[0]["mu"], vp["mu"])            # first type-1 candidate is the old vp verbatim (:59-61)
+
+
+def test_vbmc_rnd_moments_and_balanced_split():
+    """vbmc_rnd.m: mixture draws have the mixture's mean / per-dimension variance; the balanced variant places
+    floor(w N) draws in every component."""
+    import vbmc_amd.acq as acq
+
+    rng = np.random.default_rng(0)
+    D, K = 3, 4
+    vp = {"D": D, "K": K, "mu": rng.standard_normal((D, K)), "sigma": np.array([0.3, 0.5, 0.2, 0.4]),
+          "lambda": np.array([0.8, 1.0, 1.2]), "w": np.array([0.1, 0.2, 0.3, 0.4])}
+    X, I = acq.vbmc_rnd(vp, 200000, False, rng=np.random.default_rng(1))
+    mean = vp["mu"] @ vp["w"]
+    var = (vp["w"][None, :] * ((vp["sigma"][None, :] * vp["lambda"][:, None]) ** 2 + vp["mu"] ** 2)).sum(1) - mean**2
+    assert np.max(np.abs(X.mean(0) - mean)) < 0.01 and np.max(np.abs(X.var(0) - var) / var) < 0.02
+    assert np.max(np.abs(np.bincount(I, minlength=K) / 200000 - vp["w"])) < 0.005
+    Xb, Ib = acq.vbmc_rnd(vp, 1003, False, True, rng=np.random.default_rng(2))
+    cnt = np.bincount(Ib, minlength=K)
+    assert Xb.shape == (1003, D) and np.all(cnt >= np.floor(vp["w"] * 1003) - 3) and cnt.sum() == 1003
+    X1, I1 = acq.vbmc_rnd(dict(vp, K=1, mu=vp["mu"][:, :1], sigma=vp["sigma"][:1], w=np.ones(1)), 50000, False, rng=np.random.default_rng(3))
+    assert np.max(np.abs(X1.std(0) - vp["sigma"][0] * vp["lambda"])) < 0.01 and np.all(I1 == 0)

@@ -153,3 +153,56 @@ def _acq_local(Xs, vp, gp, optimState, acqFun, outside, nargout, engine, transpo
     if transpose_flag:
         acq = acq.reshape(1, -1)
     return (acq, fbar, vtot) if nargout >= 3 else acq
+
+
+def vbmc_rnd(vp, N, origflag=False, balanceflag=False, *, rng=None):
+    """[X,I] = vbmc_rnd(vp,N,0,balanceflag)  (vbmc_rnd.m:50-109): N draws from the Gaussian-mixture variational
+    posterior in the TRANSFORMED space (origflag must be false here: the inverse variable transform is VBMC's
+    warpvars_vbmc).  Host-side; used to place the importance points of the IQR acquisition functions."""
+    if origflag:
+        raise VbmcUnsupported(-1, "vbmc_rnd: origflag = 1 needs warpvars_vbmc (caller's side)")
+    rng = np.random.default_rng() if rng is None else rng
+    D, K = int(vp["D"]), int(vp["K"])
+    N = int(N)
+    if N < 1:
+        return np.zeros((0, D)), np.zeros(0, dtype=int)
+    w = np.asarray(vp["w"], dtype=np.float64).reshape(K)
+    mu_t = np.asarray(vp["mu"], dtype=np.float64).reshape(D, K).T
+    sigma = np.asarray(vp["sigma"], dtype=np.float64).reshape(K)
+    lam = np.asarray(vp["lambda"], dtype=np.float64).reshape(D)
+    if K > 1:
+        if balanceflag:                                       # exact split by weight + weighted remainder (:69-88)
+            n_floor = np.floor(w * N).astype(int)
+            I = np.repeat(np.arange(K), n_floor)
+            if N > I.size:
+                w_extra = w * N - n_floor
+                n_extra = int(np.ceil(np.sum(w_extra)))
+                w_extra = w_extra + w * (n_extra - np.sum(w_extra))
+                I = np.concatenate([I, rng.choice(K, size=n_extra, p=w_extra / np.sum(w_extra))])
+            I = I[rng.permutation(I.size)[:N]]
+        else:
+            I = rng.choice(K, size=N, p=w / np.sum(w))        # catrnd(w,N) (:90)
+        X = mu_t[I] + lam[None, :] * (rng.standard_normal((N, D)) * sigma[I][:, None])      # :95
+    else:
+        I = np.zeros(N, dtype=int)
+        X = mu_t + lam[None, :] * (rng.standard_normal((N, D)) * sigma[0])                   # :103
+    return X, I
+
+
+def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *, rng=None, engine=None):
+    """ActiveImportanceSampling = activeimportancesampling_vbmc(vp,gp,acqfun,acqinfo,options) for the branch VBMC takes
+    with acqviqr_vbmc (variational_importance_sampling: private/activeimportancesampling_vbmc.m:36-52,92-100 and the
+    Step-3 precomputation :248-276): Na draws from the variational posterior, lnw = 0, and -- on the device, inside
+    vbmc_acq_is_create at the first acquisition call -- fs2a = gplite_pred at the draws and Ctmp = (L\\(L'\\Kax'))/sn2_eff.
+    The MCMC refinement (:54-90, only for acqimiqr-style functions or a tiny effective sample size) is not mirrored."""
+    info = acqInfo or acq_info(acqFun)
+    if not info.get("variational_importance_sampling", False):
+        raise VbmcUnsupported(-1, "activeimportancesampling_vbmc: only the variational (VIQR) branch is mirrored")
+    opts = dict(options or {})
+    na = opts.get("ActiveImportanceSamplingMCMCSamples", 100)          # vbmc.m:337 default '100'
+    Na = int(np.ceil(na(int(vp["K"]), int(vp["D"])) if callable(na) else na))
+    if Na <= 0:
+        raise ValueError("OPTIONS.ActiveImportanceSamplingMCMCSamples should be (or evaluate to) a positive integer.")
+    Xa, _ = vbmc_rnd(vp, Na, False, rng=rng)
+    S = len(gp["post"])
+    return {"Xa": Xa, "lnw": np.zeros((S, Na))}        # fs2a / Ctmp_mat are produced on the device from Xa
