@@ -4,6 +4,7 @@
 
 #include "elbo_kernels.h"
 #include "var_kernels.h"
+#include "gp_kernels.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
@@ -101,10 +102,12 @@ extern "C" vbmc_status vbmc_memcpy_d2h(vbmc_ctx* ctx, void* dst, const void* src
 // ------------------------------------------------------------------------------------------
 // GP upload
 // ------------------------------------------------------------------------------------------
-extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Ncov, int Nnoise,
-                                      int meanfun, const double* X, const double* hyp, const double* alpha,
-                                      const double* L, const double* sW1, const uint8_t* Lchol,
-                                      vbmc_gp** out) {
+// L comes either from the host (L) or, for a posterior just computed on the device (vbmc_gp_post), from device memory:
+// dL_chol holds the Cholesky factors (all samples), dL_inv the solves L\(L'\I) of the low-noise samples (negated here).
+static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Ncov, int Nnoise,
+                                  int meanfun, const double* X, const double* hyp, const double* alpha,
+                                  const double* L, const double* dL_chol, const double* dL_inv, const double* sW1,
+                                  const uint8_t* Lchol, vbmc_gp** out) {
   if (!ctx || !out) return VBMC_ERR_INVALID;
   *out = nullptr;
   if (N <= 0 || D <= 0 || S <= 0 || !X || !hyp || !alpha || !sW1)
@@ -163,6 +166,15 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
   if (e == hipSuccess && L) {
     e = up(&gp->L, L, (size_t)N * N * S);
     gp->hasL = true;
+  } else if (e == hipSuccess && dL_chol) {
+    e = hipMalloc((void**)&gp->L, (size_t)N * N * S * sizeof(double));
+    for (int s = 0; s < S && e == hipSuccess; ++s) {
+      const size_t off = (size_t)s * N * N;
+      if (gp->Lchol[s] || !dL_inv) e = hipMemcpyAsync(gp->L + off, dL_chol + off, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+      else hipLaunchKernelGGL(k_negate_copy, dim3((unsigned)(((size_t)N * N + 255) / 256)), dim3(256), 0, ctx->stream, (size_t)N * N, dL_inv + off, gp->L + off);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    gp->hasL = true;
   }
   if (e == hipSuccess) e = up(&gp->d_sn2, gp->sn2_eff.data(), (size_t)S);
   if (e == hipSuccess) {
@@ -191,6 +203,13 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
   }
   *out = gp;
   return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Ncov, int Nnoise,
+                                      int meanfun, const double* X, const double* hyp, const double* alpha,
+                                      const double* L, const double* sW1, const uint8_t* Lchol,
+                                      vbmc_gp** out) {
+  return gp_upload_impl(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alpha, L, nullptr, nullptr, sW1, Lchol, out);
 }
 
 extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {

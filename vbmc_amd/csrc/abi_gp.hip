@@ -227,33 +227,30 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   std::vector<unsigned char>& lch = f.lch;
   TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dZ, dXi;
 
-  std::vector<double> Lh;
-  if (L || gp_out) Lh.resize((size_t)S * N * N);
   std::vector<double> alh((size_t)S * N);
   HIP_TRY(ctx, hipMemcpyAsync(alh.data(), dal.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
-  if (!Lh.empty()) {
-    if (any_inv) {
-      // pL = -L\(L'\eye(N)) for low-noise samples (:98)
-      HIP_TRY(ctx, dZ.alloc(ctx, (size_t)S * N * N * 8));
-      HIP_TRY(ctx, dXi.alloc(ctx, (size_t)S * N * N * 8));
-      hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, dZ.as<double>());
-      dim3 tg((N + TR_CB - 1) / TR_CB, S, 1);
-      hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
-      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>(), dXi.as<double>());
-      HIP_TRY(ctx, hipGetLastError());
-      HIP_TRY(ctx, hipStreamSynchronize(st));
-      for (int s = 0; s < S; ++s) {
-        if (lch[s]) HIP_TRY(ctx, hipMemcpyAsync(Lh.data() + (size_t)s * N * N, dA.as<double>() + (size_t)s * N * N, (size_t)N * N * 8, hipMemcpyDeviceToHost, st));
-        else HIP_TRY(ctx, hipMemcpyAsync(Lh.data() + (size_t)s * N * N, dXi.as<double>() + (size_t)s * N * N, (size_t)N * N * 8, hipMemcpyDeviceToHost, st));
-      }
-    } else {
-      HIP_TRY(ctx, hipMemcpyAsync(Lh.data(), dA.p, (size_t)S * N * N * 8, hipMemcpyDeviceToHost, st));
+  const bool wantL = L != nullptr || gp_out != nullptr;
+  if (wantL && any_inv) {
+    // pL = -L\(L'\eye(N)) for low-noise samples (:98); the sign is applied where the matrix is consumed
+    HIP_TRY(ctx, dZ.alloc(ctx, (size_t)S * N * N * 8));
+    HIP_TRY(ctx, dXi.alloc(ctx, (size_t)S * N * N * 8));
+    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, dZ.as<double>());
+    dim3 tg((N + TR_CB - 1) / TR_CB, S, 1);
+    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
+    hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>(), dXi.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (L) {
+    // the caller's copy of gp.post(s).L (D2H only when asked for)
+    for (int s = 0; s < S; ++s) {
+      const double* src = (lch[s] || !any_inv) ? dA.as<double>() + (size_t)s * N * N : dXi.as<double>() + (size_t)s * N * N;
+      HIP_TRY(ctx, hipMemcpyAsync(L + (size_t)s * N * N, src, (size_t)N * N * 8, hipMemcpyDeviceToHost, st));
     }
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
-  if (any_inv && !Lh.empty())
+  if (L && any_inv)
     for (int s = 0; s < S; ++s)
-      if (!lch[s]) for (size_t i = 0; i < (size_t)N * N; ++i) Lh[(size_t)s * N * N + i] = -Lh[(size_t)s * N * N + i];
+      if (!lch[s]) for (size_t i = 0; i < (size_t)N * N; ++i) L[(size_t)s * N * N + i] = -L[(size_t)s * N * N + i];
 
   std::vector<double> sW1(S), mult(S);
   for (int s = 0; s < S; ++s) {
@@ -261,12 +258,13 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
     sW1[s] = 1.0 / std::sqrt(sn2min[s] * mult[s]);  // post.sW = ones(N,1)./sqrt(min(sn2)*sn2_mult)  (:281)
   }
   if (alpha) memcpy(alpha, alh.data(), (size_t)S * N * 8);
-  if (L) memcpy(L, Lh.data(), (size_t)S * N * N * 8);
   if (sW) for (int s = 0; s < S; ++s) for (int n = 0; n < N; ++n) sW[(size_t)s * N + n] = sW1[s];
   if (sn2_mult) memcpy(sn2_mult, mult.data(), S * 8);
   if (Lchol) memcpy(Lchol, lch.data(), S);
   if (gp_out) {
-    vbmc_status st2 = vbmc_gp_upload(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alh.data(), Lh.data(), sW1.data(), lch.data(), gp_out);
+    // the device-resident posterior is assembled from the device buffers (no round trip of the S N x N matrices)
+    vbmc_status st2 = gp_upload_impl(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alh.data(), nullptr, dA.as<double>(),
+                                     any_inv ? dXi.as<double>() : nullptr, sW1.data(), lch.data(), gp_out);
     if (st2 != VBMC_OK) return st2;
     st2 = vbmc_gp_set_noise(ctx, *gp_out, noisefun, mult.data());
     if (st2 != VBMC_OK) return st2;
