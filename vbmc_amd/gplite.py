@@ -84,7 +84,8 @@ def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engin
     gp = {
         "X": X, "y": y, "s2": s2a, "covfun": 1, "meanfun": int(meanfun), "noisefun": noisefun,
         "Ncov": D + 1, "Nnoise": _nnoise(noisefun), "Nmean": _nmean(meanfun, D), "meanfun_extras": None, "intmeanfun": 0,
-        "post": [{"hyp": hyp[:, s].copy(), "alpha": alpha[:, s].copy(), "sW": sW[:, s].copy(), "L": L[:, :, s].copy(),
+        # L[:, :, s] is a contiguous (column-major) view of the N x N x S block written by the library: no second copy
+        "post": [{"hyp": hyp[:, s].copy(), "alpha": alpha[:, s].copy(), "sW": sW[:, s].copy(), "L": L[:, :, s],
                   "sn2_mult": float(mult[s]), "Lchol": bool(lch[s])} for s in range(S)],
     }
     dgp = DeviceGP.from_handle(ctx, h, N, D, S)
