@@ -69,3 +69,36 @@ def test_gp_post_pred_random_shapes(va, shape, seed, meanfun, nstar, noisy):
     sf2 = np.exp(2 * ref["post"][0]["hyp"][D])
     assert relerr(np.asarray(r_d[2]).reshape(-1), np.asarray(r_o[2]).reshape(-1)) < 1e-8
     assert np.max(np.abs(np.asarray(r_d[3]).reshape(-1) - np.asarray(r_o[3]).reshape(-1))) < 1e-8 * sf2
+
+
+@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 8), st.integers(5, 60), st.integers(1, 3), st.integers(1, 12)), seed=st.integers(0, 10**6),
+       nstar=st.integers(1, 60), na=st.integers(1, 40), name=st.sampled_from(["acqf", "acqflog", "acqus", "acqfsn2", "acqviqr", "acqimiqr"]))
+def test_acquisition_random_shapes(va, shape, seed, nstar, na, name):
+    D, N, S, K = shape
+    p = synth_problem(seed, D, N, K, S)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    rng = np.random.default_rng(seed + 3)
+    Xs = 1.3 * rng.standard_normal((nstar, D))
+    gl = np.exp(np.mean(np.stack([q["hyp"][:D] for q in gp["post"]], axis=1), axis=1))
+    gp = dict(gp, X_rescaled=p["X"] / gl[None, :], sn2new=0.02 + 0.1 * rng.random(N))
+    st_ = {"ymax": float(np.max(p["y"])), "VarianceRegularizedAcqFcn": False, "TolGPVar": 1e-4, "gplengthscale": gl}
+    if name in ("acqviqr", "acqimiqr"):
+        Xa = 1.2 * rng.standard_normal((na, D))
+        Kax, Ct = R.acq_is_precompute(gp, Xa)
+        fs2a = np.asarray(R.gplite_pred(gp, Xa, None, None, True)[3]).reshape(na, -1)
+        lnw = np.zeros((S, na)) if name == "acqviqr" else 0.5 * rng.standard_normal((S, na))
+        st_o = dict(st_, ActiveImportanceSampling={"Xa": Xa, "Kax_mat": Kax, "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": lnw})
+        st_d = dict(st_, ActiveImportanceSampling={"Xa": Xa, "lnw": lnw})
+    else:
+        st_o = st_d = st_
+    ref, _, vtot = R.acqwrapper_vbmc(Xs, vp, gp, st_o, name)
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, st_d, False, name + "_vbmc", None)
+    sf2 = np.exp(2 * gp["post"][0]["hyp"][D])
+    ok = np.isfinite(ref) & (vtot > 1e-7 * sf2)
+    if name in ("acqflog", "acqviqr", "acqimiqr"):
+        assert np.all(np.abs(acq[ok] - ref[ok]) < 1e-7 * (1 + np.abs(ref[ok]))), (shape, name)
+    else:
+        assert np.all(np.abs(acq[ok] - ref[ok]) <= 1e-7 * np.abs(ref[ok]) + 1e-300), (shape, name)
