@@ -102,3 +102,21 @@ def test_acquisition_random_shapes(va, shape, seed, nstar, na, name):
         assert np.all(np.abs(acq[ok] - ref[ok]) < 1e-7 * (1 + np.abs(ref[ok]))), (shape, name)
     else:
         assert np.all(np.abs(acq[ok] - ref[ok]) <= 1e-7 * np.abs(ref[ok]) + 1e-300), (shape, name)
+
+
+@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 8), st.integers(3, 80), st.integers(1, 6)), seed=st.integers(0, 10**6),
+       meanfun=st.sampled_from([0, 1, 4]), noisefun=st.sampled_from([(1, 0, 0), (1, 1, 0), (1, 2, 0), (1, 0, 1), (1, 2, 1)]))
+def test_nlz_random_shapes(va, shape, seed, meanfun, noisefun):
+    from tests.test_gpu_nlz import make_gp
+
+    D, N, B = shape
+    gp, draw = make_gp(np.random.default_rng(seed), N, D, meanfun, noisefun)
+    H = np.stack([draw() for _ in range(B)], axis=1)
+    nlZ, dnlZ = va.gplite_nlZ(H, gp) if B > 1 else va.gplite_nlZ(H[:, 0], gp)
+    nlZ = np.atleast_1d(nlZ)
+    dnlZ = np.asarray(dnlZ).reshape(H.shape[0], -1)
+    for b in range(B):
+        f, g = R.gplite_nlZ(H[:, b], gp)
+        assert abs(nlZ[b] - f) < 1e-9 * max(1.0, abs(f)), (shape, meanfun, noisefun)
+        assert relerr(dnlZ[:, b], g) < 1e-7, (shape, meanfun, noisefun, relerr(dnlZ[:, b], g))
