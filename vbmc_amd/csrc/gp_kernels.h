@@ -443,6 +443,50 @@ __global__ void __launch_bounds__(64) k_pred_ks(PredArgs a, const double* __rest
 #define PRED_MAXR 8
 #define PRED_LDS_MAX (156 * 1024)
 // group table (ints): ng[s] at [s]; t0 at [S + s*PRED_MAXG + g]; t1 at [S + S*PRED_MAXG + s*PRED_MAXG + g]
+// One point tile against RR resident row tiles: sum over the rows of V^2 (Lchol) or Ks .* (L Ks) (low-noise samples).
+// The B operand (one cross-kernel value per lane and k-step, coalesced over the 16 points) is loaded four k-steps
+// ahead of its MFMAs; the A operands come from the LDS-resident block T[col][row].
+template <int RR>
+__device__ __forceinline__ double pred_tile(const double* __restrict__ T, int RB, const double* __restrict__ kcol, size_t ldk, int N,
+                                            int ncol, bool cv, bool lc, int tb, int li, int lg) {
+  tmf4 acc[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) acc[r] = (tmf4){0.0, 0.0, 0.0, 0.0};
+  auto ldb = [&](int n0) { const int n = n0 + lg; return (cv && n < N && n0 < ncol) ? kcol[(size_t)n * ldk] : 0.0; };
+  double bq[4] = {ldb(0), ldb(4), ldb(8), ldb(12)};
+  for (int n0 = 0; n0 < ncol; n0 += 16) {
+    double bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bn[u] = ldb(n0 + 16 + 4 * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (n0 + 4 * u < ncol) {
+        const double* trow = T + (size_t)(n0 + 4 * u + lg) * RB + li;
+#pragma unroll
+        for (int r = 0; r < RR; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(trow[16 * r], bq[u], acc[r], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bq[u] = bn[u];
+  }
+  // C layout: lane (col = li = point, row = lg + 4 reg) of each resident tile
+  double part = 0.0;
+  if (lc) {
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fma(acc[r][q], acc[r][q], part);   // sum(V.*V)
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                            // sum(Ks .* (L*Ks)), one row tile per block
+      const int row = tb * 16 + lg + 4 * q;
+      const double kv = (cv && row < N) ? kcol[(size_t)row * ldk] : 0.0;
+      part = fma(kv, acc[0][q], part);
+    }
+  }
+  return part;
+}
+
 __global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const double* __restrict__ KsW, const int* __restrict__ grp,
                                                              double* __restrict__ partV /* G x S x Nstar */) {
   extern __shared__ double lds[];
@@ -469,37 +513,12 @@ __global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const d
     const int jc = pt * 16 + li;
     const bool cv = jc < a.Nstar;
     const double* kcol = ksw + min(jc, a.Nstar - 1);
-    tmf4 acc[PRED_MAXR];
-#pragma unroll
-    for (int r = 0; r < PRED_MAXR; ++r) acc[r] = (tmf4){0.0, 0.0, 0.0, 0.0};
-    // B operand (one cross-kernel value per lane and k-step) two steps ahead of its MFMAs
-    double b0 = (cv && lg < N) ? kcol[(size_t)lg * a.Nstar] : 0.0;
-    double b1 = (cv && 4 + lg < N && 4 < ncol) ? kcol[(size_t)(4 + lg) * a.Nstar] : 0.0;
-    for (int n0 = 0; n0 < ncol; n0 += 4) {
-      const int n2 = n0 + 8 + lg;
-      const double b2 = (cv && n2 < N && n0 + 8 < ncol) ? kcol[(size_t)n2 * a.Nstar] : 0.0;
-      const double* trow = T + (size_t)(n0 + lg) * RB + li;
-#pragma unroll
-      for (int r = 0; r < PRED_MAXR; ++r)
-        if (r < R) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(trow[16 * r], b0, acc[r], 0, 0, 0);
-      b0 = b1; b1 = b2;
-    }
-    // C layout: lane (col = li = point, row = lg + 4 reg) of each resident tile
     double part = 0.0;
-    if (lc) {
-#pragma unroll
-      for (int r = 0; r < PRED_MAXR; ++r)
-        if (r < R) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) part = fma(acc[r][q], acc[r][q], part);   // sum(V.*V)
-        }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {                                              // sum(Ks .* (L*Ks)), R == 1
-        const int row = tb * 16 + lg + 4 * q;
-        const double kv = (cv && row < N) ? kcol[(size_t)row * a.Nstar] : 0.0;
-        part = fma(kv, acc[0][q], part);
-      }
+    switch (R) {   // one straight-line instantiation per number of resident row tiles
+#define PRED_CASE(RR) case RR: part = pred_tile<RR>(T, RB, kcol, (size_t)a.Nstar, N, ncol, cv, lc, tb, li, lg); break;
+      PRED_CASE(1) PRED_CASE(2) PRED_CASE(3) PRED_CASE(4) PRED_CASE(5) PRED_CASE(6) PRED_CASE(7) PRED_CASE(8)
+#undef PRED_CASE
+      default: break;
     }
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
