@@ -1,0 +1,79 @@
+function dump_golden(repo_root, vbmc_root)
+%DUMP_GOLDEN Evaluate the committed golden INPUTS with the real reference (acerbilab/vbmc, MATLAB).
+%
+%   dump_golden('/path/to/this/repo', '/path/to/vbmc')
+%
+% For every tests/golden/mp_case*.json and mp_nlz_case*.json this runs the reference's own functions
+% (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ) on the stored inputs and writes
+% tests/golden/matlab_case*.json / matlab_nlz_case*.json next to them.  tools/compare_matlab_golden.py then
+% compares those files with the mpmath vectors (and thereby with the oracle and the HIP path, which are pinned to
+% the mpmath vectors by the test-suite).  Nothing here is needed by CI: the development container has no MATLAB,
+% which is exactly why the oracle is documented as "parity unpinned by the reference" -- this script is how a
+% maintainer WITH MATLAB closes that gap.
+%
+% The Monte-Carlo draws of entmc_vbmc come from the global randn stream (ent/entmc_vbmc.m:53).  To feed it the stored
+% draws the script puts a temporary randn.m in front of the built-in that pops pre-loaded blocks (restored afterwards).
+addpath(vbmc_root); vbmc('all');                                   % adds acq, ent, gplite, misc, shared, utils (vbmc.m:1056-1078)
+gold = fullfile(repo_root,'tests','golden');
+files = dir(fullfile(gold,'mp_case*.json'));
+shadow = tempname; mkdir(shadow);
+fid = fopen(fullfile(shadow,'randn.m'),'w');
+fprintf(fid,'function r = randn(varargin)\nglobal DUMP_GOLDEN_QUEUE\nr = DUMP_GOLDEN_QUEUE{1}; DUMP_GOLDEN_QUEUE(1) = [];\nassert(isequal(size(r),[varargin{:}]));\nend\n');
+fclose(fid);
+cleanup = onCleanup(@() rmpath(shadow));
+for f = 1:numel(files)
+    rec = jsondecode(fileread(fullfile(gold,files(f).name)));
+    in = rec.inputs; D = in.D; K = in.K; S = in.S; Mh = in.Mh;
+    X = reshape_rows(in.X,D); y = in.y(:); hyp = reshape_rows(in.hyp,S);
+    mu = reshape_rows(in.mu,K); eps3 = in.eps;                     % eps: K x Mh x D
+    gp = gplite_post(hyp,X,y,1,in.meanfun);                        % covfun 1 (SE-ARD), noisefun default [1 0 0]
+    vp = struct('D',D,'K',K,'mu',mu,'sigma',in.sigma(:)','lambda',in.lam(:),'w',in.w(:)','eta',in.eta(:)', ...
+        'optimize_mu',true,'optimize_sigma',true,'optimize_lambda',true,'optimize_weights',true,'delta',[],'trinfo',[]);
+    out = struct();
+    % entropy (Monte Carlo, stored draws in the reference's order: K blocks randn(D,1,Mh))
+    global DUMP_GOLDEN_QUEUE %#ok<TLEV>
+    DUMP_GOLDEN_QUEUE = cell(1,K);
+    for j = 1:K; DUMP_GOLDEN_QUEUE{j} = reshape(permute(eps3(j,:,:),[3 1 2]),[D,1,Mh]); end
+    addpath(shadow,'-begin');
+    [out.entmc_H,out.entmc_dH] = entmc_vbmc(vp,2*Mh,true,true);
+    rmpath(shadow);
+    [out.entlb_H,out.entlb_dH] = entlb_vbmc(vp,true,true);
+    % GP posterior and prediction
+    Xs = reshape_rows(in.Xstar,D);
+    [~,~,fmu,fs2] = gplite_pred(gp,Xs,[],[],1,0);
+    out.alpha = cell(1,S); out.L = cell(1,S);
+    for s = 1:S; out.alpha{s} = gp.post(s).alpha; out.L{s} = gp.post(s).L; end
+    out.pred_fmu = fmu'; out.pred_fs2 = fs2';
+    % expected log joint per hyper-sample (avg_flag = 0), gradient, full and diagonal variance
+    [Fs,dFs,varF1,~,~,I_sk,J_sjk] = gplogjoint(vp,gp,[1 1 1 1],0,1,1,1);  %#ok<ASGLU>  gradient of the VALUE only
+    out.G_s = Fs(:)'; out.dG_s = dFs'; out.I_sk = I_sk; out.J_sjk = J_sjk; out.varG_s_full = varF1(:)';
+    [~,~,varF2] = gplogjoint(vp,gp,[0 0 0 0],0,1,2,0);
+    out.varG_s_diag = varF2(:)';
+    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+end
+files = dir(fullfile(gold,'mp_nlz_case*.json'));
+for f = 1:numel(files)
+    rec = jsondecode(fileread(fullfile(gold,files(f).name)));
+    in = rec.inputs; D = in.D; S = in.S;
+    X = reshape_rows(in.X,D); y = in.y(:); hyp = reshape_rows(in.hyp,S);
+    s2 = []; if ~isempty(in.s2); s2 = in.s2(:); end
+    gp = gplite_post(hyp(:,1),X,y,1,in.meanfun,in.noisefun(:)',s2);
+    out = struct('nlZ',zeros(1,S),'dnlZ',zeros(S,size(hyp,1)));
+    for s = 1:S
+        [out.nlZ(s),g] = gplite_nlZ(hyp(:,s),gp,[]);
+        out.dnlZ(s,:) = g(:)';
+    end
+    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+end
+end
+
+function A = reshape_rows(v,ncol)
+% jsondecode returns a matrix for rectangular nested lists (rows = outer list): make sure of the shape
+A = v; if isvector(A) && ncol > 1 && numel(A) ~= ncol; A = A(:); end
+if size(A,2) ~= ncol && size(A,1) == ncol; A = A'; end
+end
+
+function write_json(path,s)
+fid = fopen(path,'w'); fwrite(fid,jsonencode(s)); fclose(fid);
+fprintf('wrote %s\n',path);
+end
