@@ -1,7 +1,8 @@
 """CPU oracle (NumPy) for the VBMC ELBO inner loop -- TEST INFRASTRUCTURE ONLY.
 
 This module is a line-by-line NumPy restatement of the MATLAB reference
-(acerbilab/vbmc v1.0.12) for the hot path named in BASELINE.json.  It is the
+(acerbilab/vbmc v1.0.12) for the hot path named in BASELINE.json and its SURVEY 8(f) neighbours (gplite_nlZ, the
+acquisition functions).  It is the
 *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py`` may import it.  The product path (``vbmc_amd``) never does.
 
@@ -14,7 +15,11 @@ to generate vectors.  What pins this restatement instead is committed under
   * closed forms (K=1 entropy, alpha=0 log-joint, identical-component bounds),
   * finite differences where the reference's gradient is an exact derivative
     (all of gplogjoint, entlb; the eta block of entmc),
-  * linear-algebra identities for gplite_post / gplite_pred, rank-1 == full.
+  * linear-algebra identities for gplite_post / gplite_pred, rank-1 == full,
+  * for the rows added after the ELBO path: gplite_nlZ against the 50-digit definition and 50-digit
+    central differences (``tests/golden/mp_nlz_case*.json``); the IQR acquisition's look-ahead variance against an
+    actual rank-one update; vbmc_pdf and gplite_hypprior against SciPy.
+``tools/dump_golden.m`` + ``tools/compare_matlab_golden.py`` let anyone with MATLAB pin the vectors to the reference.
 
 Every function cites the reference file:line it follows (paths relative to the
 reference checkout).  MATLAB shapes are kept: ``mu`` is D x K, ``sigma`` (K,),
