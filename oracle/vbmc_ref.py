@@ -507,7 +507,7 @@ def gplite_post_rank1(gp, xstar, ystar):
 # --------------------------------------------------------------------------
 
 
-def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False):
+def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nargout=4):
     """gplite/gplite_pred.m:1-165 -> (ymu, ys2, fmu, fs2); Nstar x S if ssflag
     else Nstar x 1 vectors (returned as (Nstar,S) / (Nstar,) arrays)."""
     X = gp["X"]
@@ -542,6 +542,13 @@ def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False):
             fs2[:, s] = kss + np.sum(Ks_mat * LKs, axis=0)  # :103
         fs2[:, s] = np.maximum(fs2[:, s], 0.0)  # :120
         ys2[:, s] = fs2[:, s] + sn2_star * sn2_mult  # :121
+    lp = None
+    if ystar is not None and np.size(ystar) > 0 and nargout > 4:  # :124-127 (per hyper-sample, never averaged)
+        ys_ = np.asarray(ystar, dtype=np.float64).reshape(-1, 1)
+        lp = -0.5 * (ys_ - ymu) ** 2 / ys2 - 0.5 * np.log(2 * math.pi * ys2)
+    if nargout > 4:
+        avg = gplite_pred(gp, Xstar, ystar, s2star, ssflag)
+        return tuple(avg) + (lp,)
     if S > 1 and not ssflag:  # :154-165
         fbar = np.sum(fmu, axis=1) / S
         ybar = np.sum(ymu, axis=1) / S

@@ -171,3 +171,18 @@ def test_pred_many_points_few_samples(va, cfg):
     avg_d = va.gplite_pred(gp, Xs, None, None, False)        # hyper-sample average + between-sample variance (:154-165)
     avg_o = R.gplite_pred(gp, Xs, None, None, False)
     assert relerr(avg_d[0], avg_o[0]) < 1e-9 and np.max(np.abs(np.asarray(avg_d[1]) - np.asarray(avg_o[1]))) < 1e-9 * sf2
+
+
+def test_pred_log_predictive_density(va):
+    """lp (5th output of gplite_pred, :124-127): per hyper-sample, also when the other outputs are averaged."""
+    from tests.test_gpu_elbo import problem
+    p, gp, vp, _ = problem(81, 4, 50, 3, 3)
+    rng = np.random.default_rng(1)
+    Xs = 1.2 * rng.standard_normal((40, 4))
+    ys = rng.standard_normal(40) - 3.0
+    for ss in (True, False):
+        d = va.gplite_pred(gp, Xs, ys, None, ss, nargout=5)
+        o = R.gplite_pred(gp, Xs, ys, None, ss, nargout=5)
+        assert d[4].shape == (40, 3) and relerr(d[4], o[4]) < 1e-8
+        assert relerr(d[0], o[0]) < 1e-9 and np.asarray(d[0]).shape == np.asarray(o[0]).shape
+    assert va.gplite_pred(gp, Xs, None, None, True, nargout=5)[4] is None

@@ -100,7 +100,20 @@ def _device_gp_with_noise(engine, gp):
 
 
 def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nowarpflag=False, nargout=4, *, engine=None):
-    """[ymu,ys2,fmu,fs2] = gplite_pred(gp,Xstar,ystar,s2star,ssflag)."""
+    """[ymu,ys2,fmu,fs2,lp] = gplite_pred(gp,Xstar,ystar,s2star,ssflag).  ``nargout=5`` with ``ystar`` adds the log
+    predictive density lp (Nstar x S, per hyper-sample also when the other outputs are averaged: gplite_pred.m:124-127)."""
+    if nargout > 4:
+        Ns = np.asarray(Xstar).shape[0]
+        if ystar is not None and np.size(ystar) and np.asarray(ystar).reshape(-1).shape[0] != Ns:
+            raise ValueError("gplite_pred:ydimmismatch YSTAR should be empty or a column vector of NSTAR observations.")
+        ymu_s, ys2_s = gplite_pred(gp, Xstar, None, s2star, True, nowarpflag, 2, engine=engine)
+        lp = None
+        if ystar is not None and np.size(ystar):
+            ymu_s = np.asarray(ymu_s).reshape(Ns, -1)
+            ys2_s = np.asarray(ys2_s).reshape(Ns, -1)
+            yv = np.asarray(ystar, dtype=np.float64).reshape(-1, 1)
+            lp = -0.5 * (yv - ymu_s) ** 2 / ys2_s - 0.5 * np.log(2 * np.pi * ys2_s)   # O(Nstar S) on the host
+        return tuple(gplite_pred(gp, Xstar, None, s2star, ssflag, nowarpflag, 4, engine=engine)) + (lp,)
     engine = engine or default_engine()
     ctx = engine.ctx
     Xs = f64(Xstar)
