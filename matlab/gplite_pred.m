@@ -3,14 +3,14 @@ function [ymu,ys2,fmu,fs2,lp] = gplite_pred(gp,Xstar,ystar,s2star,ssflag,nowarpf
 %
 % Same signature and defaulting as the reference (gplite/gplite_pred.m:1-9).  The accelerated path
 % covers what VBMC's acquisition sweep uses (SE-ARD covariance, mean functions 0/1/4, Gaussian noise
-% models, no output warping, no integrated mean, no log-predictive output); every other call form
+% models, no output warping, no integrated mean); every other call form
 % goes to the reference further down the path.
 if nargin < 3; ystar = []; end
 if nargin < 4; s2star = []; end
 if nargin < 5 || isempty(ssflag); ssflag = false; end
 if nargin < 6 || isempty(nowarpflag); nowarpflag = false; end
 
-supported = nargout < 5 && any(gp.meanfun == [0 1 4]) && gp.covfun(1) == 1 ...
+supported = any(gp.meanfun == [0 1 4]) && gp.covfun(1) == 1 ...
     && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) ...
     && ~(isfield(gp,'outwarpfun') && ~isempty(gp.outwarpfun) && ~nowarpflag) ...
     && ~isempty(gp.post(1).alpha);
@@ -32,4 +32,12 @@ end
 h = vbmc_hip_gp_handle(gp);
 [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred',h,Xstar,s2star,double(ssflag),numel(gp.post));
 lp = [];
+if ~isempty(ystar) && nargout > 4       % log predictive density per hyper-sample (gplite_pred.m:124-127), O(Nstar*Ns) here
+    if ssflag || numel(gp.post) == 1
+        ymu_s = ymu; ys2_s = ys2;
+    else
+        [ymu_s,ys2_s] = vbmc_hip_mex('gp_pred',h,Xstar,s2star,1,numel(gp.post));
+    end
+    lp = -0.5*bsxfun(@minus,ystar,ymu_s).^2./ys2_s - 0.5*log(2*pi*ys2_s);
+end
 end
