@@ -322,3 +322,16 @@ def test_logjoint_mfma_and_valu_kernels_agree_with_oracle(va, shape, monkeypatch
         o = va.negelcbo_batch(th, 0, vpf, gp, 0, True, 0)
         rr = R.negelcbo_vbmc(th, 0, vpf, gp, 0, True, 0)
         assert relerr(o["dG"][:, 0], rr["dG"]) < 1e-9, (flags, shape)
+
+
+def test_prepared_objective_equals_batch_call(va):
+    """PreparedObjective (arguments and buffers resolved once, as the closure of vpoptimize_vbmc.m:71) returns exactly what
+    negelcbo_batch returns, call after call."""
+    p, gp, vp, theta = problem(78, 5, 40, 6, 3)
+    rng = np.random.default_rng(0)
+    obj = va.PreparedObjective(theta.size, 4, 0, vp, gp, 40, 0, None)
+    for it in range(3):
+        Th = np.asfortranarray(theta[:, None] + 0.01 * rng.standard_normal((theta.size, 4)))
+        F, dF = obj(Th, seed=100 + it)
+        ref = va.negelcbo_batch(Th, 0, vp, gp, 40, True, 0, seed=100 + it)
+        assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])

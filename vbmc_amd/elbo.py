@@ -215,6 +215,32 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     return out
 
 
+class PreparedObjective:
+    """The optimiser-loop objective @(theta) negelcbo_vbmc(theta,beta,vp,gp,Ns,1,compute_var,0,thetabnd) with everything
+    that does not change between calls resolved once (misc/vpoptimize_vbmc.m:71 builds exactly such a closure): the
+    argument struct, the fixed vp groups, bounds, the device GP and the output buffers.  A call copies the new theta
+    (T x R) into place and runs one batched device pass; it returns views of the same (F, dF) buffers every time."""
+
+    def __init__(self, T, R, beta, vp, gp, Ns, compute_var=0, thetabnd=None, *, engine=None, sparse_cutoff=0.0):
+        self.engine = engine or default_engine()
+        self.theta = np.zeros((T, R), order="F")
+        self.args, self._keep, cv = _build_args(self.theta, beta, vp, gp, Ns, True, compute_var, thetabnd, False, None, None,
+                                                False, 0, self.engine, sparse_cutoff)
+        self.dgp = self.engine.device_gp(gp, need_L=cv != 0)
+        self.F = np.empty(R)
+        self.dF = np.empty((T, R), order="F")
+        self.args.F = ptr(self.F)
+        self.args.dF = ptr(self.dF)
+        self._ref = C.byref(self.args)
+
+    def __call__(self, thetas, seed=0):
+        np.copyto(self.theta, np.asarray(thetas, dtype=np.float64).reshape(self.theta.shape, order="F"))
+        self.args.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        ctx = self.engine.ctx
+        ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, self.dgp.h, self._ref))
+        return self.F, self.dF
+
+
 def negelcbo_vbmc(theta, beta, vp, gp, Ns=0, compute_grad=None, compute_var=None, altent_flag=False, thetabnd=None,
                   entropy_alpha=0, nargout=2, *, eps=None, seed=0, engine=None):
     """[F,dF,G,H,varF,dH,varGss,varG,varH,I_sk,J_sjk] = negelcbo_vbmc(...)  (misc/negelcbo_vbmc.m:1).
