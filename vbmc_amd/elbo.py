@@ -28,11 +28,13 @@ class Engine:
         self._gp_cache = {}
 
     def device_gp(self, gp, need_L=False):
-        key = id(gp)
-        ent = self._gp_cache.get(key)
-        if ent is not None and ent[0] is gp and (ent[2] or not need_L) and ent[3] == self._fingerprint(gp):
-            return ent[1]
+        # keyed on the identity of the posterior list: shallow copies of the gp dict that only add fields (X_rescaled, sn2new
+        # for the acquisition functions) share the uploaded posterior
         post = gp["post"]
+        key = id(post)
+        ent = self._gp_cache.get(key)
+        if ent is not None and ent[0] is post and (ent[2] or not need_L) and ent[3] == self._fingerprint(gp):
+            return ent[1]
         S = len(post)
         X = np.asarray(gp["X"], dtype=np.float64)
         N = X.shape[0]
@@ -44,14 +46,14 @@ class Engine:
         sW1 = np.array([np.asarray(p["sW"]).reshape(-1)[0] for p in post])
         lch = np.array([1 if p["Lchol"] else 0 for p in post], dtype=np.uint8)
         dgp = DeviceGP(self.ctx, X, hyp, alpha, L, sW1, lch, gp["meanfun"], gp["Ncov"], gp["Nnoise"])
-        self._gp_cache = {key: (gp, dgp, need_L, self._fingerprint(gp))}  # one live GP per engine
+        self._gp_cache = {key: (post, dgp, need_L, self._fingerprint(gp))}  # one live GP per engine
         return dgp
 
     @staticmethod
     def _fingerprint(gp):
         p0 = gp["post"][0]
-        return (np.asarray(gp["X"]).shape, len(gp["post"]), float(np.asarray(p0["alpha"]).reshape(-1)[0]),
-                float(np.asarray(p0["hyp"]).reshape(-1)[0]))
+        return (id(gp["X"]), np.asarray(gp["X"]).shape, len(gp["post"]), int(gp["meanfun"]), int(gp["Ncov"]), int(gp["Nnoise"]),
+                float(np.asarray(p0["alpha"]).reshape(-1)[0]), float(np.asarray(p0["hyp"]).reshape(-1)[0]))
 
     def invalidate(self):
         self._gp_cache = {}

@@ -89,7 +89,7 @@ def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engin
                   "sn2_mult": float(mult[s]), "Lchol": bool(lch[s])} for s in range(S)],
     }
     dgp = DeviceGP.from_handle(ctx, h, N, D, S)
-    engine._gp_cache = {id(gp): (gp, dgp, True, engine._fingerprint(gp))}
+    engine._gp_cache = {id(gp["post"]): (gp["post"], dgp, True, engine._fingerprint(gp))}
     return gp
 
 
