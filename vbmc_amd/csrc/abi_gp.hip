@@ -586,7 +586,7 @@ extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar
     for (int d = 0; d < D; ++d) hb[(size_t)k * D + d] = 1.0 / (vp_sigma[k] * vp_lambda[d]);
     hb[(size_t)K * D + k] = nf * vp_w[k] / std::pow(vp_sigma[k], D);
   }
-  TmpBuf dmu, dhb, dgl, dXr, dsn, dres;
+  TmpBuf dmu, dhb, dgl, dXr, dsn, dsx, dres;
   HIP_TRY(ctx, dmu.alloc(ctx, (size_t)D * K * 8));
   HIP_TRY(ctx, dhb.alloc(ctx, hb.size() * 8));
   HIP_TRY(ctx, dres.alloc(ctx, (size_t)3 * Nstar * 8));
@@ -604,7 +604,15 @@ extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar
     HIP_TRY(ctx, hipMemcpyAsync(dgl.p, gplengthscale, (size_t)D * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dXr.p, X_rescaled, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dsn.p, sn2new, (size_t)N * 8, hipMemcpyHostToDevice, st));
-    a.gl = dgl.as<double>(); a.Xr = dXr.as<double>(); a.sn2new = dsn.as<double>();
+    HIP_TRY(ctx, dsx.alloc(ctx, (size_t)Nstar * 8));
+    switch ((D + 3) / 4) {
+#define NN_CASE(QSV) case QSV: hipLaunchKernelGGL((k_nn_noise<QSV>), dim3((Nstar + 15) / 16), dim3(64), 0, st, Nstar, N, D, pb.dXs.as<double>(), \
+                                                 dgl.as<double>(), dXr.as<double>(), dsn.as<double>(), dsx.as<double>()); break;
+      NN_CASE(1) NN_CASE(2) NN_CASE(3) NN_CASE(4) NN_CASE(5) NN_CASE(6) NN_CASE(7) NN_CASE(8)
+#undef NN_CASE
+      default: break;
+    }
+    a.sn2x = dsx.as<double>();
   }
   a.acq = dres.as<double>(); a.fbar = a.acq + Nstar; a.vtot = a.fbar + Nstar;
   hipLaunchKernelGGL(k_acq, dim3((Nstar + 255) / 256), dim3(256), (size_t)(2 * K * D + K) * 8, st, a);
@@ -748,8 +756,13 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   HIP_TRY(ctx, hipMemcpyAsync(dgl.p, gplengthscale, (size_t)D * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dXr.p, X_rescaled, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(dsn.p, sn2new, (size_t)N * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_nn_noise, dim3((Nstar + 63) / 64), dim3(64), 0, st, Nstar, N, D, pb.dXs.as<double>(), dgl.as<double>(),
-                     dXr.as<double>(), dsn.as<double>(), dsx.as<double>());
+  switch ((D + 3) / 4) {
+#define NN_CASE(QSV) case QSV: hipLaunchKernelGGL((k_nn_noise<QSV>), dim3((Nstar + 15) / 16), dim3(64), 0, st, Nstar, N, D, pb.dXs.as<double>(), \
+                                                 dgl.as<double>(), dXr.as<double>(), dsn.as<double>(), dsx.as<double>()); break;
+    NN_CASE(1) NN_CASE(2) NN_CASE(3) NN_CASE(4) NN_CASE(5) NN_CASE(6) NN_CASE(7) NN_CASE(8)
+#undef NN_CASE
+    default: break;
+  }
   IqrArgs a{};
   a.N = N; a.D = D; a.S = S; a.Nhyp = gp->Nhyp; a.Nstar = Nstar; a.Na = is->Na; a.Nap = is->Nap; a.per_s = is->per_s;
   a.Xs = pb.dXs.as<double>(); a.Xa = is->Xa; a.hyp = gp->hyp; a.Xc = pb.dXc.as<double>(); a.muv = pb.dmuv.as<double>();

@@ -749,9 +749,7 @@ struct AcqArgs {
   const double* mu;     // D x K
   const double* isl;    // K x D:  1 / (sigma_k lambda_d)
   const double* coef;   // K:      nf * w_k / sigma_k^D
-  const double* gl;     // D       optimState.gplengthscale        (acq_id 3)
-  const double* Xr;     // N x D   gp.X_rescaled, col-major        (acq_id 3)
-  const double* sn2new; // N                                       (acq_id 3)
+  const double* sn2x;   // Nstar   gp.sn2new at the nearest row of gp.X_rescaled (k_nn_noise)   (acq_id 3)
   double* acq;          // Nstar
   double* fbar;         // Nstar
   double* vtot;         // Nstar
@@ -798,17 +796,7 @@ __global__ void __launch_bounds__(256) k_acq(AcqArgs a) {
   else if (a.acq_id == 1) acq = -(log(vtot) + fbar - a.ymax + log(p));
   else if (a.acq_id == 2) acq = -vtot * p * p;
   else {
-    // observation noise at the nearest training input in length-scale units (acqfsn2_vbmc.m:11-13; first minimum wins)
-    double best = INFINITY;
-    int pos = 0;
-    for (int n = 0; n < a.N; ++n) {
-      double c = 0.0;
-#pragma unroll
-      for (int d = 0; d < 32; ++d)
-        if (d < D) { const double t = x[d] / a.gl[d] - a.Xr[n + (size_t)a.N * d]; c = fma(t, t, c); }
-      if (c < best) { best = c; pos = n; }
-    }
-    const double sn2 = a.sn2new[pos];
+    const double sn2 = a.sn2x[i];   // observation noise at the nearest training input (k_nn_noise; acqfsn2_vbmc.m:11-13)
     acq = -vtot * (1.0 - sn2 / (vtot + sn2)) * exp(fbar - a.ymax) * p;
   }
   if (a.reg && vtot < a.TolVar) {
@@ -856,30 +844,53 @@ __global__ void __launch_bounds__(256) k_ctmp_pack(int N, int Na, int Nap, const
   }
 }
 
-// observation noise at the nearest training input in length-scale units (acqviqr_vbmc.m:42-43); first minimum wins
+// observation noise at the nearest training input in length-scale units (acqviqr_vbmc.m:42-43); first minimum wins.
+// One wave per 16 test points; the inner products of |x - xr_n|^2 = |x|^2 + |xr_n|^2 - 2 x.xr_n for 16 x 16 blocks of
+// (training point, test point) pairs are QS MFMAs, each lane then scans its four candidates in increasing n.
+template <int QS>
 __global__ void __launch_bounds__(64) k_nn_noise(int Nstar, int N, int D, const double* __restrict__ Xs, const double* __restrict__ gl,
                                                  const double* __restrict__ Xr, const double* __restrict__ sn2new,
                                                  double* __restrict__ sn2x) {
-  __shared__ double xr_s[64][33];   // a chunk of 64 training rows, [n][d]
-  __shared__ double x_s[64][33];    // this block's 64 test points in length-scale units
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int i = blockIdx.x * 16 + li;
   const int gi = min(i, Nstar - 1);
-  for (int d = 0; d < D; ++d) x_s[threadIdx.x][d] = Xs[gi + (size_t)Nstar * d] / gl[d];
+  double xb[QS];                                   // B operand: test point li, dimensions 4q + lg
+#pragma unroll
+  for (int q = 0; q < QS; ++q) {
+    const int d = 4 * q + lg;
+    xb[q] = d < D ? Xs[gi + (size_t)Nstar * d] / gl[d] : 0.0;
+  }
   double best = INFINITY;
   int pos = 0;
-  for (int c0 = 0; c0 < N; c0 += 64) {
-    __syncthreads();
-    const int nl = min(64, N - c0);
-    if ((int)threadIdx.x < nl)
-      for (int d = 0; d < D; ++d) xr_s[threadIdx.x][d] = Xr[c0 + threadIdx.x + (size_t)N * d];
-    __syncthreads();
-    for (int n = 0; n < nl; ++n) {
-      double c = 0.0;
-      for (int d = 0; d < D; ++d) { const double t = x_s[threadIdx.x][d] - xr_s[n][d]; c = fma(t, t, c); }
-      if (c < best) { best = c; pos = c0 + n; }
+  for (int n0 = 0; n0 < N; n0 += 16) {
+    const int na = min(n0 + li, N - 1);            // A operand: training point n0 + li, dimensions 4q + lg
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double rr = 0.0;
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      const int d = 4 * q + lg;
+      const double av = d < D ? Xr[na + (size_t)N * d] : 0.0;
+      rr = fma(av, av, rr);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[q], acc, 0, 0, 0);
+    }
+    rr += __shfl_xor(rr, 16, 64);                  // |xr_n|^2 for n = n0 + li, on every lane group
+    rr += __shfl_xor(rr, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nl = lg + 4 * r, n = n0 + nl;       // accumulator row
+      const double rn = __shfl(rr, nl, 64);         // |xr_n|^2 lives on lane li == nl
+      const double c = rn - 2.0 * acc[r];           // + |x|^2, the same for every n
+      if (n < N && c < best) { best = c; pos = n; }
     }
   }
-  if (i < Nstar) sn2x[i] = sn2new[pos];
+  // the four lane groups hold disjoint n: smallest distance, ties to the smaller index
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const double ob = __shfl_xor(best, o, 64);
+    const int op = __shfl_xor(pos, o, 64);
+    if (ob < best || (ob == best && op < pos)) { best = ob; pos = op; }
+  }
+  if (lg == 0 && i < Nstar) sn2x[i] = sn2new[pos];
 }
 
 struct IqrArgs {
