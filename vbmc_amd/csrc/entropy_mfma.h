@@ -31,6 +31,19 @@
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
 
+// Ordering point for LDS words that only one wave touches: a workgroup barrier when the workgroup is one wave, a
+// wave-level fence when it is two (the waves then meet only at the eps staging and at the PV exchange).
+template <int HV>
+__device__ __forceinline__ void ent_sync() {
+  if (HV == 1) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // HV = 2 (64 < K <= 128): the components are split between the two waves of a workgroup, each running the KT <= 4
 // register-resident body on its half; per sign the waves exchange their partial PV outputs (16 x 16 NPV doubles per wave
 // through LDS, one workgroup barrier) and both continue with the full q', A', B' -- identical bits on both sides
@@ -45,7 +58,8 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   __shared__ double RQ_all[HV][16];        // q'_i then 1/q'_i
   __shared__ double TAB[VB_EXP_TAB_N];     // 2^(j/256)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
-  __shared__ double YX[HV == 2 ? 2 : 1][HV == 2 ? NPV * 4 * WAVE : 1];   // partial PV outputs of the two halves
+  // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
+  __shared__ double YX[HV == 2 ? 2 : 1][HV == 2 ? 2 : 1][HV == 2 ? NPV * 4 * WAVE : 1];
   const int tid = threadIdx.x, hv = HV == 2 ? tid >> 6 : 0, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -262,19 +276,19 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) YX[hv][(pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
+            for (int rr = 0; rr < 4; ++rr) YX[sg][hv][(pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
           __syncthreads();
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) Y[pv][rr] += YX[hv ^ 1][(pv * 4 + rr) * WAVE + lane];
+            for (int rr = 0; rr < 4; ++rr) Y[pv][rr] += YX[sg][hv ^ 1][(pv * 4 + rr) * WAVE + lane];
         }
         // ---- per-sample scalars in the sample layout (lane <-> sample li): q' from column 0
         if (li == 0) {
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) RQ[lg + 4 * rr] = Y[0][rr];
         }
-        __syncthreads();
+        ent_sync<HV>();   // RQ is private to the wave
         const double qs_ = svalid ? RQ[li] : 1.0;
         const double rqs = svalid ? vb_rcp(qs_) : 0.0;
         pm *= __builtin_amdgcn_frexp_mant(qs_);   // sum log q' = ln2 * sum exp + log(prod mant)
@@ -286,9 +300,9 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
         }
-        __syncthreads();
+        ent_sync<HV>();
         if (lg == 0) RQ[li] = rqs;
-        __syncthreads();
+        ent_sync<HV>();
         // ---- gradient pieces in the PV output layout
         const int base = lane & 48;
 #pragma unroll
@@ -308,7 +322,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
             }
           }
         }
-        __syncthreads();
+        ent_sync<HV>();
       } else {
         double qp = 0.0;
 #pragma unroll
@@ -318,10 +332,9 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
         qp += __shfl_xor(qp, 16, 64);
         qp += __shfl_xor(qp, 32, 64);
         if (HV == 2) {
-          YX[hv][lane] = qp;
+          YX[sg][hv][lane] = qp;
           __syncthreads();
-          qp += YX[hv ^ 1][lane];
-          __syncthreads();
+          qp += YX[sg][hv ^ 1][lane];
         }
         const double qs_ = svalid ? qp : 1.0;
         pm *= __builtin_amdgcn_frexp_mant(qs_);
@@ -358,9 +371,9 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
     sgsum = wave_sum(sgsum);            // SG = sum_d LG_d  (entmc_vbmc.m:87)
     if (HV == 2) {
       __syncthreads();
-      if (lane == 0) YX[hv][0] = sgsum;
+      if (lane == 0) YX[0][hv][0] = sgsum;
       __syncthreads();
-      sgsum = YX[0][0] + YX[1][0];
+      sgsum = YX[0][0][0] + YX[0][1][0];
     }
     if (lane == 0 && hv == 0) o[1 + D] = sgsum;
 #pragma unroll
