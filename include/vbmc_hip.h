@@ -174,6 +174,11 @@ vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const double* a, co
  * compute_var, ~, thetabnd) (misc/negelcbo_vbmc.m:1) -- R = 1 is the Adam-loop call
  * (misc/vpoptimize_vbmc.m:71, utils/fminadam.m:48), R > 1 is the sieve batch
  * (misc/vpsieve_vbmc.m:74-78).
+ * gp == NULL evaluates the entropy term alone: H, dH (and F = -H + penalties) are then
+ * [H,dH] = entmc_vbmc(vp,Ns,grad_flags,1) (ent/entmc_vbmc.m:1) for Ns > 0 and entlb_vbmc(vp,grad_flags,1)
+ * (ent/entlb_vbmc.m:1) for Ns = 0, with grad_flags = optimize[]; G = 0, dG = 0; compute_var and
+ * separate_K must be 0.  With Ns = 0 and a surrogate, G, dG, varG, varGss, I_sk, J_sjk are the outputs of
+ * gplogjoint(vp,gp,grad_flags,1,1,compute_var,separate_K) (misc/gplogjoint.m:1) on its own.
  */
 typedef struct vbmc_elbo_args {
   uint32_t struct_size;      /* = sizeof(vbmc_elbo_args), for ABI versioning                */

@@ -1,0 +1,40 @@
+function [H,dH] = entmc_vbmc(vp,Ns,grad_flags,jacobian_flag)
+%ENTMC_VBMC Drop-in shim: Monte Carlo entropy of the variational posterior on an MI355X.
+%
+% Same signature and defaulting as the reference (ent/entmc_vbmc.m:1-14).  The device path evaluates the
+% entropy term alone (vbmc_elbo_batch with a NULL surrogate, include/vbmc_hip.h) and returns the gradient for
+% the flagged groups in the order [mu(:); log sigma; log lambda; eta] with the Jacobians applied
+% (:110-125).  JACOBIAN_FLAG = 0 with gradients goes to the reference further down the path.
+% VBMC_HIP_PARITY=1: the K blocks randn(D,1,Ns/2) are drawn here in the reference's order (:53).
+if nargin < 2 || isempty(Ns); Ns = 10; end
+if nargout < 2; grad_flags = false; elseif nargin < 3 || isempty(grad_flags); grad_flags = true; end
+if isscalar(grad_flags); grad_flags = ones(1,4)*grad_flags; end
+if nargin < 4 || isempty(jacobian_flag); jacobian_flag = true; end
+g = any(grad_flags);
+if g && ~jacobian_flag
+    ref = vbmc_hip_reference('entmc_vbmc');
+    [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag);
+    return;
+end
+vpt = vp;
+if g
+    vpt.optimize_mu = logical(grad_flags(1)); vpt.optimize_sigma = logical(grad_flags(2));
+    vpt.optimize_lambda = logical(grad_flags(3)); vpt.optimize_weights = logical(grad_flags(4));
+end
+theta = get_vptheta(vpt);                      % misc/get_vptheta.m
+epsblk = [];
+if strcmp(getenv('VBMC_HIP_PARITY'),'1')
+    Nse = ceil(Ns/2)*2;
+    epsblk = zeros(vp.D,Nse/2,vp.K);
+    for j = 1:vp.K; epsblk(:,:,j) = reshape(randn(vp.D,1,Nse/2),[vp.D,Nse/2]); end
+end
+try
+    [~,~,~,H,~,dH] = vbmc_hip_mex('elbo',uint64(0),theta(:),vpt,Ns,double(g),0,0,0,[],epsblk,randi(2^31-1),1);
+catch err
+    if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+    ref = vbmc_hip_reference('entmc_vbmc');
+    if nargout > 1; [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag); else; H = ref(vp,Ns,grad_flags,jacobian_flag); end
+    return;
+end
+if ~g; dH = []; end
+end

@@ -1,0 +1,114 @@
+"""GPU parity of the path's pieces called on their own, as the reference allows: entmc_vbmc / entlb_vbmc
+(ent/entmc_vbmc.m:1, ent/entlb_vbmc.m:1) without a surrogate and gplogjoint (misc/gplogjoint.m:1, called directly at
+private/activesample_vbmc.m:155) without an entropy term, with every grad_flags subset the reference accepts.
+fp64; tolerance 1e-10 on values, 1e-9 on gradients (summation order)."""
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._cases import synth_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+def make(seed, D, N, K, S):
+    p = synth_problem(seed, D, N, K, S)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"], noisefun=p["noisefun"], s2=p["s2"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    return p, gp, vp
+
+
+FLAGS = [(1, 1, 1, 1), (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1), (1, 1, 0, 0), (0, 1, 1, 1), (1, 0, 1, 0)]
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+def test_entmc_alone(va, flags):
+    p, gp, vp = make(3, 5, 40, 7, 2)
+    Ns = 90
+    eps = p["rng"].standard_normal((vp["K"], Ns // 2, vp["D"]))
+    H, dH = va.entmc_vbmc(vp, Ns, flags, True, eps=eps)
+    Ho, dHo = R.entmc_vbmc(vp, Ns, flags, True, eps=eps)
+    assert relerr(H, Ho) < 1e-10
+    assert dH.shape == np.asarray(dHo).reshape(-1).shape
+    assert relerr(dH, np.asarray(dHo).reshape(-1)) < 1e-9
+    # value only: one output, no gradient work
+    assert relerr(va.entmc_vbmc(vp, Ns, None, True, nargout=1, eps=eps), Ho) < 1e-10
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+def test_entlb_alone(va, flags):
+    p, gp, vp = make(4, 6, 30, 9, 1)
+    H, dH = va.entlb_vbmc(vp, flags, True)
+    Ho, dHo = R.entlb_vbmc(vp, flags, True)[:2]
+    assert relerr(H, Ho) < 1e-10
+    assert relerr(dH, np.asarray(dHo).reshape(-1)) < 1e-9
+
+
+def test_entropy_defaults_and_refusals(va):
+    p, gp, vp = make(5, 3, 20, 4, 1)
+    # grad_flags omitted with two outputs -> all four groups (entmc_vbmc.m:8-10)
+    H, dH = va.entlb_vbmc(vp)
+    assert dH.size == 3 * 4 + 4 + 3 + 4
+    # K = 1: exact entropy (entlb_vbmc.m:32-47); the Monte Carlo estimator has the same expectation
+    vp1 = R.make_vp(p["mu"][:, :1], p["sigma"][:1], p["lam"], eta=np.zeros(1))
+    vp1["w"] = np.ones(1)
+    exact = 0.5 * 3 * (1 + np.log(2 * np.pi)) + 3 * np.log(vp1["sigma"][0]) + np.sum(np.log(vp1["lambda"]))
+    assert relerr(va.entlb_vbmc(vp1, nargout=1), exact) < 1e-12
+    assert abs(va.entmc_vbmc(vp1, 20000, nargout=1, seed=3) - exact) < 0.05
+    with pytest.raises(va.VbmcUnsupported):
+        va.entmc_vbmc(vp, 10, True, False)   # untransformed gradients stay with the reference
+    with pytest.raises(va.VbmcUnsupported):
+        va.entlb_vbmc(vp, True, False)
+    # the ABI refuses variance outputs without a surrogate
+    theta, _ = va.get_vptheta(vp)
+    with pytest.raises(ValueError):
+        va.negelcbo_batch(theta, 0.0, vp, None, 0, False, 1)
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+def test_gplogjoint_alone(va, flags):
+    p, gp, vp = make(6, 4, 35, 6, 3)
+    F, dF = va.gplogjoint(vp, gp, flags, nargout=2)
+    o = R.gplogjoint(vp, gp, flags, True, True, 0)
+    assert relerr(F, o["F"]) < 1e-10
+    assert relerr(dF, np.asarray(o["dF"]).reshape(-1)) < 1e-9
+
+
+@pytest.mark.parametrize("cv", [1, 2])
+def test_gplogjoint_variance_and_components(va, cv):
+    p, gp, vp = make(7, 3, 25, 5, 2)
+    o = R.gplogjoint(vp, gp, (0, 0, 0, 0), True, True, cv, separate_K=True)
+    F, dF, varF, dvarF, varss, I_sk, J_sjk = va.gplogjoint(vp, gp, (0, 0, 0, 0), True, True, cv, nargout=7)
+    assert dF.size == 0 and dvarF is None
+    assert relerr(F, o["F"]) < 1e-10
+    assert relerr(varF, o["varF"]) < 1e-8
+    assert relerr(varss, o["varss"]) < 1e-8
+    assert relerr(I_sk, o["I_sk"]) < 1e-10
+    assert relerr(J_sjk, o["J_sjk"]) < 1e-8
+    # three outputs: compute_var defaults to nargout > 2 (gplogjoint.m:14)
+    F3, _, v3 = va.gplogjoint(vp, gp, (0, 0, 0, 0), nargout=3)
+    assert relerr(v3, R.gplogjoint(vp, gp, (0, 0, 0, 0), True, True, 1)["varF"]) < 1e-8
+
+
+def test_gplogjoint_refusals(va):
+    p, gp, vp = make(8, 3, 20, 4, 2)
+    with pytest.raises(va.VbmcUnsupported):
+        va.gplogjoint(vp, gp, True, False, nargout=2)            # avg_flag = 0
+    with pytest.raises(va.VbmcUnsupported):
+        va.gplogjoint(vp, gp, True, True, False, nargout=2)      # jacobian_flag = 0
+    with pytest.raises(ValueError, match="FullVarianceGradient"):
+        va.gplogjoint(vp, gp, True, True, True, 1, nargout=4)    # gplogjoint.m:27-30

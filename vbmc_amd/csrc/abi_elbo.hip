@@ -47,6 +47,7 @@ extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   for (auto& b : ctx->pool)
     if (b.p) (void)hipFree(b.p);
+  for (vbmc_gp* g : ctx->null_gp) vbmc_gp_free(ctx, g);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
@@ -616,8 +617,30 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   return VBMC_OK;
 }
 
+// The surrogate behind an entropy-only call: N = 1, alpha = 0, meanfun 0  =>  G = 0 and dG = 0 exactly, so that
+// H, dH (and F = -H + penalties) are entmc_vbmc / entlb_vbmc on their own (ent/entmc_vbmc.m:1, ent/entlb_vbmc.m:1).
+static vbmc_status null_gp_for(vbmc_ctx* ctx, int D, const vbmc_gp** out) {
+  if (D <= 0 || D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d not accelerated", D);
+  if (!ctx->null_gp[D]) {
+    std::vector<double> X(D, 0.0), hyp(D + 2, 0.0);
+    const double alpha = 0.0, sW1 = 1.0;
+    const uint8_t lchol = 1;
+    vbmc_status s_ = gp_upload_impl(ctx, 1, D, 1, D + 2, D + 1, 1, 0, X.data(), hyp.data(), &alpha, nullptr, nullptr, nullptr, &sW1,
+                                    &lchol, &ctx->null_gp[D]);
+    if (s_) return s_;
+  }
+  *out = ctx->null_gp[D];
+  return VBMC_OK;
+}
+
 extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a) {
   if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp && a) {  // entropy only
+    if (a->compute_var != 0 || a->separate_K)
+      return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: an entropy-only call (gp == NULL) has no variance / per-component outputs");
+    vbmc_status s_ = null_gp_for(ctx, a->D, &gp);
+    if (s_) return s_;
+  }
   ElboPlan P;
   { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
   { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed); if (s_) return s_; }
@@ -678,7 +701,8 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
       for (int k = 0; k < K; ++k)
         for (int j = 0; j < K; ++j)
           for (int s = 0; s < S; ++s)
-            a->J_sjk[s + (size_t)S * (j + (size_t)K * (k + (size_t)K * r))] = Jh[(((size_t)r * S + s) * K + k) * K + j];
+            a->J_sjk[s + (size_t)S * (j + (size_t)K * (k + (size_t)K * r))] =   // diagonal approximation: only J_kk is set (gplogjoint.m:283)
+                (P.compute_var == 2 && j != k) ? 0.0 : Jh[(((size_t)r * S + s) * K + k) * K + j];
   }
   return VBMC_OK;
 }

@@ -41,6 +41,9 @@ struct vbmc_ctx {
   double last_ent_ms = 0.0, last_lj_ms = 0.0;
   std::vector<PoolBlk> pool;
   size_t pool_bytes = 0;
+  // entropy-only evaluations (vbmc_elbo_batch with gp == NULL): a one-point surrogate with alpha = 0 and a zero mean
+  // function per dimension, whose expected log joint is exactly 0
+  vbmc_gp* null_gp[33] = {};
 };
 
 static inline hipError_t pool_get(vbmc_ctx* ctx, size_t bytes, void** out) {

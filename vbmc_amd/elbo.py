@@ -15,7 +15,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Context, DeviceGP, ElboArgs, f64, ptr
+from ._lib import Context, DeviceGP, ElboArgs, VbmcUnsupported, f64, ptr
+from .vp import get_vptheta
 
 _engines = {}
 
@@ -189,8 +190,13 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     D, K = int(vp["D"]), int(vp["K"])
     a, keep, compute_var = _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps,
                                        eps_device_ptr, eps_shared, seed, engine, sparse_cutoff)
-    dgp = engine.device_gp(gp, need_L=compute_var != 0)
-    S = dgp.S
+    if gp is None:   # entropy only (entmc_vbmc / entlb_vbmc on their own): the ABI takes a NULL surrogate
+        if compute_var or separate_K:
+            raise ValueError("an entropy-only evaluation has no variance or per-component outputs")
+        dgp_h, S = None, 0
+    else:
+        dgp = engine.device_gp(gp, need_L=compute_var != 0)
+        dgp_h, S = dgp.h, dgp.S
     out = {}
 
     def outbuf(name, shape):
@@ -213,8 +219,83 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
         a.I_sk = outbuf("I_sk", (S, K, R))
         if compute_var:
             a.J_sjk = outbuf("J_sjk", (S, K, K, R))
-    ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, dgp.h, C.byref(a)))
+    ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, dgp_h, C.byref(a)))
     return out
+
+
+def _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, who):
+    """grad_flags defaulting of the reference (ent/entmc_vbmc.m:5-11, misc/gplogjoint.m:17-23) -> (vp whose optimize_*
+    flags select exactly the groups a gradient is wanted for, theta, any gradient)."""
+    if nargout < 2:
+        grad_flags = False
+    elif grad_flags is None or np.size(grad_flags) == 0:
+        grad_flags = True
+    gf = np.broadcast_to(np.asarray(grad_flags, dtype=bool).reshape(-1), (4,)) if np.size(grad_flags) == 1 \
+        else np.asarray(grad_flags, dtype=bool).reshape(4)
+    if gf.any() and not jacobian_flag:
+        raise VbmcUnsupported(-1, who + ": gradients without the Jacobian of the parameter transformation (jacobian_flag = 0) "
+                              "are not accelerated")
+    vpt = dict(vp)
+    if gf.any():
+        for name, f in zip(("optimize_mu", "optimize_sigma", "optimize_lambda", "optimize_weights"), gf):
+            vpt[name] = bool(f)
+    theta, _ = get_vptheta(vpt)
+    return vpt, theta, bool(gf.any())
+
+
+def entmc_vbmc(vp, Ns=10, grad_flags=None, jacobian_flag=True, nargout=2, *, eps=None, seed=0, engine=None):
+    """[H,dH] = entmc_vbmc(vp,Ns,grad_flags,jacobian_flag)  (ent/entmc_vbmc.m:1): Monte Carlo entropy of the mixture on
+    its own.  dH holds the flagged groups in theta order [mu(:); log sigma; log lambda; eta] (:110-125)."""
+    if Ns is None:
+        Ns = 10   # :4
+    vpt, theta, g = _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, "entmc_vbmc")
+    r = negelcbo_batch(theta, 0.0, vpt, None, int(Ns), g, 0, None, eps=eps, seed=seed, engine=engine,
+                       outputs=("H", "dH") if g else ("H",))
+    H = float(r["H"][0])
+    return (H, r["dH"][:, 0].copy() if g else np.zeros(0)) if nargout > 1 else H
+
+
+def entlb_vbmc(vp, grad_flags=None, jacobian_flag=True, nargout=2, *, engine=None):
+    """[H,dH] = entlb_vbmc(vp,grad_flags,jacobian_flag)  (ent/entlb_vbmc.m:1): deterministic entropy lower bound."""
+    vpt, theta, g = _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, "entlb_vbmc")
+    r = negelcbo_batch(theta, 0.0, vpt, None, 0, g, 0, None, engine=engine, outputs=("H", "dH") if g else ("H",))
+    H = float(r["H"][0])
+    return (H, r["dH"][:, 0].copy() if g else np.zeros(0)) if nargout > 1 else H
+
+
+def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compute_var=None, separate_K=None, nargout=1, *,
+               engine=None):
+    """[F,dF,varF,dvarF,varss,I_sk,J_sjk] = gplogjoint(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K)
+    (misc/gplogjoint.m:1-30; direct caller acq/../activesample_vbmc.m:155).  Accelerated call forms: averaged over the
+    hyper-parameter samples (avg_flag), transformed gradients (jacobian_flag); the gradient of the variance is not a
+    separate output of the device path (dvarF is returned as None unless asked for together with gradients, which is
+    refused like the other unsupported forms)."""
+    if separate_K is None:
+        separate_K = nargout > 5            # :13
+    if compute_var is None:
+        compute_var = nargout > 2           # :14
+    compute_var = int(compute_var)
+    vpt, theta, g = _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, "gplogjoint")
+    if nargout > 3 and compute_var and g:
+        if compute_var != 2:                # :27-30
+            raise ValueError("gplogjoint:FullVarianceGradient Computation of gradient of log joint variance is currently "
+                             "available only for diagonal approximation of the variance.")
+        raise VbmcUnsupported(-1, "gplogjoint: dvarF as a separate output is not accelerated")
+    if not avg_flag:
+        raise VbmcUnsupported(-1, "gplogjoint: per-hyper-sample outputs (avg_flag = 0) are not accelerated")
+    if separate_K and g:
+        raise VbmcUnsupported(-1, "gplogjoint: per-component outputs together with gradients are not accelerated")
+    want = ["G"] + (["dG"] if g else []) + (["varG", "varGss"] if compute_var else [])
+    if separate_K:
+        want += ["I_sk"] + (["J_sjk"] if compute_var else [])
+    r = negelcbo_batch(theta, 0.0, vpt, gp, 0, g, compute_var, None, separate_K=bool(separate_K), engine=engine,
+                       outputs=tuple(want))
+    outs = (float(r["G"][0]), r["dG"][:, 0].copy() if g else np.zeros(0),
+            float(r["varG"][0]) if compute_var else None, None,
+            float(r["varGss"][0]) if compute_var else None,
+            r["I_sk"][:, :, 0].copy() if separate_K else None,
+            r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
+    return outs[0] if nargout <= 1 else outs[:nargout]
 
 
 class PreparedObjective:
