@@ -33,6 +33,18 @@ extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out)
   }
   for (auto& e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return VBMC_ERR_HIP; }
+  {
+    int lo = 0, hi = 0;   // numerically larger = lower priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char* ov = getenv("VBMC_LJ_OVERLAP");   // "0": everything on one stream (A/B testing)
+    ctx->overlap = !(ov && !strcmp(ov, "0"));
+    if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+      delete ctx;
+      return VBMC_ERR_HIP;
+    }
+  }
   *out = ctx;
   return VBMC_OK;
 }
@@ -51,6 +63,9 @@ extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -508,29 +523,42 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp);
 
-  // ---- expected log joint
-  if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-  {
-    // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
-    const char* ljf = getenv("VBMC_LJ_KERNEL");
-    // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
-    // kernel has the lower latency
-    const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
-    const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
-    DISPATCH_DT(dt, {
-      constexpr int NCT = (2 * DT + 1 + 15) / 16;
-      const int nw = (K + 15) / 16;
-      const size_t mom_lds = (size_t)nw * 16 * 16 * NCT * sizeof(double);   // moment exchange; large K x D falls back to the VALU kernel
-      if (lj_mfma && mom_lds <= 48 * 1024) {
-        hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, st, dm, P.d_vpd,
-                           gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
-      } else {
-        hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
-                           P.d_delta2, P.d_lj, P.compute_grad);
-      }
-    });
+  // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
+  const bool fork = ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
+  auto enqueue_logjoint = [&](hipStream_t ls) -> vbmc_status {
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ls));
+    {
+      // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
+      const char* ljf = getenv("VBMC_LJ_KERNEL");
+      // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
+      // kernel has the lower latency
+      const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
+      const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
+      DISPATCH_DT(dt, {
+        constexpr int NCT = (2 * DT + 1 + 15) / 16;
+        const int nw = (K + 15) / 16;
+        const size_t mom_lds = (size_t)nw * 16 * 16 * NCT * sizeof(double);   // moment exchange; large K x D falls back to the VALU kernel
+        if (lj_mfma && mom_lds <= 48 * 1024) {
+          hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, ls, dm, P.d_vpd,
+                             gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
+        } else {
+          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
+                             P.d_delta2, P.d_lj, P.compute_grad);
+        }
+      });
+    }
+    if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ls));
+    // log-joint partials summed over hyper-samples (in sample order), one record per (r, k)
+    hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, ls, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
+    return VBMC_OK;
+  };
+  if (fork) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+  } else {
+    vbmc_status s_ = enqueue_logjoint(st);
+    if (s_) return s_;
   }
-  if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
 
   // ---- entropy
   FinArgs fa{};
@@ -562,6 +590,13 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_entlb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, P.d_vpd, P.d_part, P.compute_grad);
     fa.entpart = nullptr; fa.entlb = P.d_part;
+  }
+
+  if (fork) {   // the entropy kernel is already queued on the main stream: the log joint fills in around it
+    vbmc_status s_ = enqueue_logjoint(ctx->aux);
+    if (s_) return s_;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   }
 
   // ---- variance of the expected log joint (gplogjoint.m:273-337,375-413)
@@ -598,8 +633,6 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   }
 
   // ---- finalize
-  // log-joint partials summed over hyper-samples (in sample order), one record per (r, k)
-  hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, st, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
   fa.vpd = P.d_vpd; fa.theta = P.d_theta; fa.ljbar = P.d_ljbar; fa.var = P.d_var; fa.var_stride = P.d_var ? P.var_stride : 0;
   fa.bnd = P.d_bnd; fa.has_bnd = P.has_bnd ? 1 : 0;
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;

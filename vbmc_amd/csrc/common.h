@@ -28,6 +28,11 @@ struct vbmc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // the expected log joint runs beside the entropy kernel on a second, lower-priority stream (fork after k_prep, join
+  // before the variance / finalize kernels): it fills the entropy kernel's tail, or, for a single chain, the idle CUs
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   std::string err;
   int num_cu = 256;
   // grow-only scratch
