@@ -666,15 +666,15 @@ struct FinArgs {
   double* out;            // R x (OUT_HDR + 3T)
 };
 
+// Sum over the workgroup (blockDim.x a multiple of 64; `red` holds at least one double per wave): a fixed-order butterfly
+// inside each wave, then the wave totals in wave order -- two barriers instead of a log2(blockDim) LDS tree.
 __device__ inline double block_sum(double v, double* red) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
+  const int tid = threadIdx.x, nw = blockDim.x >> 6;
+  v = wave_sum(v);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
-  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
   double r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
   __syncthreads();
   return r;
 }
