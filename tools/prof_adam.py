@@ -15,8 +15,15 @@ vp = vbmc_amd.make_vp(inp["mu"], inp["sigma"], inp["lam"], eta=inp["eta"])
 vp["w"] = np.exp(inp["eta"]) / np.sum(np.exp(inp["eta"]))
 theta = np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]), np.log(inp["lam"]), inp["eta"]])
 x0 = np.asfortranarray(theta[:, None])
-vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 40, seed=5, engine=eng)
+# soft bounds as vpoptimize_vbmc passes them (misc/vpbounds.m): the production call has thetabnd
+opts = {"TolConLoss": 0.01, "TolWeight": 1e-2, "WeightPenalty": 0.1, "TolLength": 1e-6}
+try:
+    vp, thetabnd = vbmc_amd.vpbounds(vp, {"X": inp["X"], "y": inp["y"]}, opts, K)
+except Exception as e:  # noqa: BLE001
+    print("no bounds:", e)
+    thetabnd = None
+vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, thetabnd, 0.0, 40, seed=5, engine=eng)
 import time
 t = time.perf_counter()
-_, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 200, seed=6, engine=eng)
+_, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, thetabnd, 0.0, 200, seed=6, engine=eng)
 print("us/iter", 1e6 * (time.perf_counter() - t) / int(its[0]))

@@ -542,7 +542,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
           hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, ls, dm, P.d_vpd,
                              gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
         } else {
-          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
+          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(dm.N > 64 ? WAVE * LJ_MAXW : WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
                              P.d_delta2, P.d_lj, P.compute_grad);
         }
       });
@@ -638,13 +638,17 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
   fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out;
   {
-    size_t lds = (256 + 3 * (size_t)K + 3 * (size_t)T + 8) * sizeof(double);
-    const size_t stage_b = ((size_t)K * (2 * D + 2) + (fa.entpart ? (size_t)K * fa.C * fa.ncol : 0)) * sizeof(double);
-    fa.stage = (lds + stage_b <= 96 * 1024) ? 1 : 0;
-    if (fa.stage) lds += stage_b;
+    size_t lds = (FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8) * sizeof(double);
+    const int next_mu = dm.opt[0] ? D * K : 0;
+    const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
+    const size_t stage_rec = ((size_t)K * (2 * D + 2) + (fa.entpart ? (size_t)K * fa.C * fa.ncol : 0)) * sizeof(double);
+    const size_t stage_vp = ((size_t)VpLayout{D, K}.stride() + (P.has_bnd ? 2 * (size_t)Text : 0)) * sizeof(double);
+    fa.stage = 0;
+    if (lds + stage_vp <= 96 * 1024) { fa.stage |= 2; lds += stage_vp; }
+    if (lds + stage_rec <= 96 * 1024) { fa.stage |= 1; lds += stage_rec; }
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_finalize, dim3(R), dim3(256), lds, st, fa);
+    hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);
   }
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;

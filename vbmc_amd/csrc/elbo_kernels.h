@@ -98,21 +98,25 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+#define LJ_MAXW 4   // waves per workgroup of k_logjoint: each takes every LJ_MAXW-th 16-point slab of the training set
+
 template <int DT>
-__global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __restrict__ vpd,
-                                                   const double* __restrict__ X,      // N x D col-major
-                                                   const double* __restrict__ alpha,  // N x S
-                                                   const double* __restrict__ gpc,    // S x GPC_STRIDE
-                                                   const double* __restrict__ delta2,  // D (delta.^2)
-                                                   double* __restrict__ lj, int want_grad) {
+__global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const double* __restrict__ vpd,
+                                                             const double* __restrict__ X,      // N x D col-major
+                                                             const double* __restrict__ alpha,  // N x S
+                                                             const double* __restrict__ gpc,    // S x GPC_STRIDE
+                                                             const double* __restrict__ delta2,  // D (delta.^2)
+                                                             double* __restrict__ lj, int want_grad) {
+  constexpr int NC = 2 * DT + 2;                 // I, M[DT], S, L[DT]
   __shared__ double TAB[VB_EXP_TAB_N];
-  const int s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
+  __shared__ double PART[LJ_MAXW][4][NC];        // per wave and component: the 16-lane row sums
+  const int s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int ni = lane & 15, kq = lane >> 4, rowbase = lane & 48;
   const int D = dm.D, K = dm.K, N = dm.N;
   const int kk = 4 * blockIdx.x + kq;
   const bool kvalid = kk < K;
   const int k = kvalid ? kk : K - 1;
-  for (int t = lane; t < VB_EXP_TAB_N; t += WAVE) TAB[t] = c_exp2_tab[t];
+  for (int t = threadIdx.x; t < VB_EXP_TAB_N; t += blockDim.x) TAB[t] = c_exp2_tab[t];
   VpLayout L{D, K};
   const double* v = vpd + (size_t)r * L.stride();
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);
@@ -152,17 +156,29 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
 #pragma unroll
   for (int d = 0; d < DT; ++d) { accM[d] = 0.0; accL[d] = 0.0; }
   const double* al = alpha + (size_t)s * N;
-  for (int n = ni; n < N; n += 16) {
+  // the loads of the next slab are issued before the arithmetic of the current one (a single chain is bound by this
+  // kernel's memory latency, not its flops)
+  const int step = 16 * NW;
+  int n = ni + 16 * wv;
+  double xc[DT], ac = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) xc[d] = (d < D && n < N) ? X[n + (size_t)N * d] : 0.0;
+  if (n < N) ac = al[n];
+  while (n < N) {
+    const int nn = n + step;
+    double xn[DT], an = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) xn[d] = (d < D && nn < N) ? X[nn + (size_t)N * d] : 0.0;
+    if (nn < N) an = al[nn];
     double dl[DT];
     double a2 = 0.0;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
-      double x = (d < D) ? X[n + (size_t)N * d] : 0.0;
-      dl[d] = (mu[d] - x) * itau[d];  // delta_k :167
+      dl[d] = (mu[d] - xc[d]) * itau[d];  // delta_k :167
       a2 = fma(dl[d], dl[d], a2);
     }
     double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);  // z_k :168
-    double za = z * al[n];
+    double za = z * ac;
     accI += za;
     if (want_grad) {
       double ssum = 0.0;
@@ -175,6 +191,10 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
       }
       accS = fma(ssum * sig, za, accS);
     }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) xc[d] = xn[d];
+    ac = an;
+    n = nn;
   }
   accI = row16_sum(accI);
   if (want_grad) {
@@ -182,28 +202,42 @@ __global__ void __launch_bounds__(WAVE) k_logjoint(ElboDims dm, const double* __
 #pragma unroll
     for (int d = 0; d < DT; ++d) { accM[d] = row16_sum(accM[d]); accL[d] = row16_sum(accL[d]); }
   }
-  if (ni == 0 && kvalid) {
-    double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
-    // mean-function terms; iom2 = 0 and xm = 0 for meanfun 0/1 so they vanish  :169-174
-    double nu = 0.0, sl2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      double xm = g[D + d], iom2 = g[2 * D + d];
-      double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
-      nu += iom2 * (mu_d * mu_d + sig * sig * lam_d * lam_d - 2.0 * mu_d * xm + xm * xm + delta2[d]);
-      sl2 += iom2 * lam_d * lam_d;
-    }
-    o[0] = accI + g[3 * D + 1] + (-0.5 * nu);
+  if (ni == 0) {
+    double* pp = PART[wv][kq];
+    pp[0] = accI;
     if (want_grad) {
+      pp[1 + DT] = accS;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        if (d < D) {
-          double xm = g[D + d], iom2 = g[2 * D + d];
-          double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
-          o[1 + d] = wk * accM[d] - wk * iom2 * (mu_d - xm);                    // :208-210
-          o[2 + D + d] = wk * accL[d] - wk * sig * sig * iom2 * lam_d;          // :250-252
-        }
+      for (int d = 0; d < DT; ++d) { pp[1 + d] = accM[d]; pp[2 + DT + d] = accL[d]; }
+    }
+  }
+  __syncthreads();
+  // ---- epilogue by wave 0, one lane per output column of its component; wave partials added in wave order
+  if (wv != 0 || !kvalid) return;
+  double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
+  const int ncol = want_grad ? 2 * D + 2 : 1;
+  for (int c = ni; c < ncol; c += 16) {
+    // column c of the output record <-> slot of PART (padded to DT)
+    const int d = (c >= 1 && c <= D) ? c - 1 : (c >= D + 2 ? c - D - 2 : 0);
+    const int slot = c == 0 ? 0 : (c <= D ? c : (c == D + 1 ? 1 + DT : 2 + DT + d));
+    double acc = PART[0][kq][slot];
+    for (int w2 = 1; w2 < NW; ++w2) acc += PART[w2][kq][slot];
+    // mean-function terms; iom2 = 0 and xm = 0 for meanfun 0/1 so they vanish  :169-174
+    if (c == 0 || c == D + 1) {
+      double nu = 0.0, sl2 = 0.0;
+      for (int e = 0; e < D; ++e) {
+        double xm = g[D + e], iom2 = g[2 * D + e];
+        double lam_e = v[L.lambda() + e], mu_e = v[L.mu() + e + D * k];
+        nu += iom2 * (mu_e * mu_e + sig * sig * lam_e * lam_e - 2.0 * mu_e * xm + xm * xm + delta2[e]);
+        sl2 += iom2 * lam_e * lam_e;
       }
-      o[1 + D] = wk * accS - wk * sig * sl2;                                     // :229-231
+      o[c] = c == 0 ? acc + g[3 * D + 1] + (-0.5 * nu)          // I_k
+                    : wk * acc - wk * sig * sl2;                 // :229-231
+    } else {
+      const double xm = g[D + d], iom2 = g[2 * D + d];
+      const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
+      o[c] = c <= D ? wk * acc - wk * iom2 * (mu_d - xm)                   // :208-210
+                    : wk * acc - wk * sig * sig * iom2 * lam_d;            // :250-252
     }
   }
 }
@@ -641,7 +675,17 @@ __global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const d
   const int k = blockIdx.x, r = blockIdx.y;
   for (int col = threadIdx.x; col < LJS; col += blockDim.x) {
     double acc = 0.0;
-    for (int s = 0; s < S; ++s) acc += lj[(((size_t)r * S + s) * K + k) * LJS + col];
+    const double* p = lj + ((size_t)r * S * K + k) * LJS + col;
+    const size_t st = (size_t)K * LJS;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {   // eight loads in flight; summed in sample order
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(s + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; s < S; ++s) acc += p[(size_t)s * st];
     ljbar[((size_t)r * K + k) * LJS + col] = acc;
   }
 }
@@ -679,16 +723,28 @@ __device__ inline double block_sum(double v, double* red) {
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
+#define FIN_THREADS 1024
+// global -> LDS copy with eight independent loads in flight per thread (the plain loop waits for each load in turn)
+__device__ __forceinline__ void stage_copy(double* __restrict__ dst, const double* __restrict__ src, int n, int tid, int nt) {
+  int i = tid;
+  for (; i + 7 * nt < n; i += 8 * nt) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[i + u * nt];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[i + u * nt] = t[u];
+  }
+  for (; i < n; i += nt) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(FIN_THREADS) k_finalize(FinArgs a) {
   extern __shared__ double lds[];
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const ElboDims& dm = a.dm;
   const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
   VpLayout L{D, K};
   const double* v = a.vpd + (size_t)r * L.stride();
-  const double* w = v + L.w();
-  const double* sigma = v + L.sigma();
-  const double* lam = v + L.lambda();
+  const double* bnd = a.bnd;
   double* red = lds;           // nt
   double* Ibar = red + nt;     // K   mean_s I_sk
   double* Hj = Ibar + K;       // K   (1/M) sum_i log q' for component j
@@ -697,22 +753,44 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
   double* dH = dG + T;         // T
   double* dP = dH + T;         // T   penalty gradient
   double* scal = dP + T;       // 8 scalars
+  // w, sigma, lambda are read inside serial loops over the components below: LDS copies keep those loops off the
+  // global-memory latency (a single chain, R = 1, is bound by exactly this kernel's dependent chains)
+  double* gsc = scal + 8;      // D x K   soft-bound gradient of the lnscale block per (d, k)
+  double* stg = gsc + D * K;   // staging area (a.stage says what fits)
+  // Everything this workgroup reads more than once sits in LDS: the vp record and the bounds (stage & 2), the
+  // log-joint / entropy records of the restart (stage & 1).  A single chain (R = 1) is bound by exactly this kernel's
+  // chains of dependent global loads, so they are issued in a few wide batches up front.
+  if (a.stage & 2) {
+    stage_copy(stg, v, L.stride(), tid, nt);
+    v = stg;
+    stg += L.stride();
+    if (a.has_bnd) {
+      const int next_mu = dm.opt[0] ? D * K : 0;
+      const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
+      stage_copy(stg, a.bnd, 2 * Text, tid, nt);
+      bnd = stg;
+      stg += 2 * Text;
+    }
+  }
+  const double* w = v + L.w();
+  const double* sigma = v + L.sigma();
+  const double* lam = v + L.lambda();
   double* o = a.out + (size_t)r * (OUT_HDR + 3 * T);
   const int LJS = 2 * D + 2;
   const double invS = 1.0 / S;
 
   for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
+  __syncthreads();
   // ---- expected log joint from the per-component sums over hyper-samples (k_lj_reduce):
   // G = (1/S) sum_s sum_k w_k I_sk  (:203,:400)
   const double* lb = a.ljbar + (size_t)r * K * LJS;
   const double* pe_src = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;
-  if (a.stage) {
-    // the per-restart records are read in column order by few threads below: stage them in LDS with coalesced loads
-    // (a single chain, R = 1, is bound by exactly this latency)
-    double* lbL = scal + 8;
+  if (a.stage & 1) {
+    // the per-restart records are read in column order by few threads below
+    double* lbL = stg;
     double* peL = lbL + K * LJS;
-    for (int i = tid; i < K * LJS; i += nt) lbL[i] = lb[i];
-    if (pe_src) for (int i = tid; i < K * a.C * a.ncol; i += nt) peL[i] = pe_src[i];
+    stage_copy(lbL, lb, K * LJS, tid, nt);
+    if (pe_src) stage_copy(peL, pe_src, K * a.C * a.ncol, tid, nt);
     lb = lbL;
     if (pe_src) pe_src = peL;
     __syncthreads();
@@ -724,6 +802,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
     for (int k = tid; k < K; k += nt) part += w[k] * Ibar[k];
     double G = block_sum(part, red);
     if (tid == 0) scal[0] = G;
+    __syncthreads();
   }
   if (a.want_grad) {
     if (dm.opt[0])
@@ -731,19 +810,15 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
     if (dm.opt[1])
       for (int k = tid; k < K; k += nt) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * sigma[k] * invS;  // Jacobian :356
     if (dm.opt[2])
-      for (int d = tid; d < D; d += nt) {
+      for (int d = tid >> 4; d < D; d += nt >> 4) {   // sums over the components: 16 lanes per output (see row16 note above)
         double acc = 0.0;
-        for (int k = 0; k < K; ++k) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
-        dG[dm.off_lambda + d] = acc * lam[d] * invS;                            // :362
+        for (int k = tid & 15; k < K; k += 16) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
+        acc = row16_sum(acc);
+        if ((tid & 15) == 0) dG[dm.off_lambda + d] = acc * lam[d] * invS;                // :362
       }
-  }
-  __syncthreads();
-  if (a.want_grad && dm.opt[3]) {
-    // softmax Jacobian J_w = diag(w) - w w' (gplogjoint.m:366-368) applied to w_grad = I_k
-    double part = 0.0;
-    for (int k = tid; k < K; k += nt) part += w[k] * Ibar[k];
-    double dot = block_sum(part, red);
-    for (int k = tid; k < K; k += nt) dG[dm.off_eta + k] = w[k] * Ibar[k] - w[k] * dot;
+    // softmax Jacobian J_w = diag(w) - w w' (gplogjoint.m:366-368) applied to w_grad = I_k; w' I = G
+    if (dm.opt[3])
+      for (int k = tid; k < K; k += nt) dG[dm.off_eta + k] = w[k] * Ibar[k] - w[k] * scal[0];
   }
   __syncthreads();
 
@@ -758,10 +833,11 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
       Hj[j] = lognf + acc * invM;  // mean_i log q(x_i), x_i ~ component j
     }
     __syncthreads();
-    if (tid == 0) {
-      double H = 0.0;
-      for (int j = 0; j < K; ++j) H -= w[j] * Hj[j];  // :67
-      scal[1] = H;
+    {
+      double part = 0.0;
+      for (int j = tid; j < K; j += nt) part -= w[j] * Hj[j];  // :67
+      double H = block_sum(part, red);
+      if (tid == 0) scal[1] = H;
     }
     if (a.want_grad) {
       if (dm.opt[0])
@@ -778,24 +854,26 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
           dH[dm.off_sigma + j] = w[j] * acc * invM * sigma[j];  // :88 and Jacobian :113
         }
       if (dm.opt[2])
-        for (int d = tid; d < D; d += nt) {
+        for (int d = tid >> 4; d < D; d += nt >> 4) {
           double acc = 0.0;
-          for (int j = 0; j < K; ++j) {
+          for (int j = tid & 15; j < K; j += 16) {
             double aj = 0.0;
             for (int c = 0; c < a.C; ++c) aj += pe[((size_t)j * a.C + c) * a.ncol + 2 + D + d];
             acc += w[j] * sigma[j] * aj * invM;  // :93 (the /lambda of lsum cancels the *lambda of :107)
           }
-          dH[dm.off_lambda + d] = acc;
+          acc = row16_sum(acc);
+          if ((tid & 15) == 0) dH[dm.off_lambda + d] = acc;
         }
       if (dm.opt[3])
-        for (int l = tid; l < K; l += nt) {
+        for (int l = tid >> 4; l < K; l += nt >> 4) {
           double acc = 0.0;
-          for (int j = 0; j < K; ++j) {
+          for (int j = tid & 15; j < K; j += 16) {
             double aj = 0.0;
             for (int c = 0; c < a.C; ++c) aj += pe[((size_t)j * a.C + c) * a.ncol + 2 + 2 * D + l];
             acc += w[j] * aj * invM;  // :100
           }
-          wraw[l] = -Hj[l] - acc;  // :97
+          acc = row16_sum(acc);
+          if ((tid & 15) == 0) wraw[l] = -Hj[l] - acc;  // :97
         }
     }
   } else {
@@ -823,8 +901,8 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
     const int next_mu = dm.opt[0] ? D * K : 0;
     const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
     const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
-    const double* lb = a.bnd;
-    const double* ub = a.bnd + Text;
+    const double* lb = bnd;
+    const double* ub = bnd + Text;
     double part = 0.0;
     // mu block
     if (dm.opt[0])
@@ -833,59 +911,45 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
         if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; dP[dm.off_mu + p] += (x - l) / (ell * ell); }
         if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; dP[dm.off_mu + p] += (x - u) / (ell * ell); }
       }
-    pen += block_sum(part, red);
     // lnscale block D x K : lnsigma_k + lnlambda_d (vpbndloss.m:36); gradient summed over d / k
     if (has_sc) {
-      part = 0.0;
-      // pass 1: loss
+      // pass 1: loss, and the per-(d, k) gradient contributions parked in LDS for the two marginal sums below
       for (int p = tid; p < D * K; p += nt) {
         int d = p % D, k = p / D;
         double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
         double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
-        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; }
-        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; }
+        double g = 0.0;
+        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; g += (x - l) / (ell * ell); }
+        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; g += (x - u) / (ell * ell); }
+        gsc[p] = g;
       }
-      pen += block_sum(part, red);
+      __syncthreads();
       if (a.want_grad) {
         if (dm.opt[1])
-          for (int k = tid; k < K; k += nt) {
+          for (int k = tid >> 4; k < K; k += nt >> 4) {
             double acc = 0.0;
-            for (int d = 0; d < D; ++d) {
-              int p = d + D * k;
-              double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
-              double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
-              if (x < l) acc += (x - l) / (ell * ell);
-              if (x > u) acc += (x - u) / (ell * ell);
-            }
-            dP[dm.off_sigma + k] += acc;
+            for (int d = tid & 15; d < D; d += 16) acc += gsc[d + D * k];
+            acc = row16_sum(acc);
+            if ((tid & 15) == 0) dP[dm.off_sigma + k] += acc;
           }
         if (dm.opt[2])
-          for (int d = tid; d < D; d += nt) {
+          for (int d = tid >> 4; d < D; d += nt >> 4) {
             double acc = 0.0;
-            for (int k = 0; k < K; ++k) {
-              int p = d + D * k;
-              double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
-              double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
-              if (x < l) acc += (x - l) / (ell * ell);
-              if (x > u) acc += (x - u) / (ell * ell);
-            }
-            dP[dm.off_lambda + d] += acc;
+            for (int k = tid & 15; k < K; k += 16) acc += gsc[d + D * k];
+            acc = row16_sum(acc);
+            if ((tid & 15) == 0) dP[dm.off_lambda + d] += acc;
           }
       }
     }
     if (dm.opt[3]) {
-      part = 0.0;
       const int o3 = next_mu + has_sc * D * K;
       for (int k = tid; k < K; k += nt) {
         double x = v[L.eta() + k], l = lb[o3 + k], u = ub[o3 + k], ell = (u - l) * a.TolCon;
         if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; dP[dm.off_eta + k] += (x - l) / (ell * ell); }
         if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; dP[dm.off_eta + k] += (x - u) / (ell * ell); }
       }
-      pen += block_sum(part, red);
       // weight-size penalty :146-162
-      part = 0.0;
-      for (int k = tid; k < K; k += nt) part += (w[k] < a.WeightThreshold) ? w[k] : a.WeightThreshold;
-      pen += block_sum(part, red) * a.WeightPenalty;
+      for (int k = tid; k < K; k += nt) part += a.WeightPenalty * ((w[k] < a.WeightThreshold) ? w[k] : a.WeightThreshold);
       if (a.want_grad) {
         double pd = 0.0;
         for (int k = tid; k < K; k += nt) pd += (w[k] < a.WeightThreshold) ? w[k] * a.WeightPenalty : 0.0;
@@ -896,6 +960,7 @@ __global__ void __launch_bounds__(256) k_finalize(FinArgs a) {
         }
       }
     }
+    pen = block_sum(part, red);   // one sum for every soft-bound and weight term of the restart
   }
   __syncthreads();
   // ---- assemble
