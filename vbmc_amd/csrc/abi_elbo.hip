@@ -516,12 +516,15 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
 
 // Enqueue one evaluation pass on the context's stream: reads theta from P.d_theta, leaves the packed
 // results [F G H varG varGss | dF dG dH] per restart in P.d_out.  No host synchronisation.
-static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan& P, unsigned long long seed) {
+// pend / pend_iter: inside the optimiser loop, the Adam update of iteration pend_iter that k_prep applies before unpacking.
+static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan& P, unsigned long long seed,
+                                const AdamState* pend = nullptr, int pend_iter = 0) {
   const ElboDims& dm = P.dm;
   const int D = dm.D, K = dm.K, R = dm.R, S = dm.S, T = dm.T;
   const int dt = P.dt;
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp);
+  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
+                     pend ? pend_iter : 0, (const double*)P.d_out);
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
   const bool fork = ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
@@ -548,8 +551,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       });
     }
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ls));
-    // log-joint partials summed over hyper-samples (in sample order), one record per (r, k)
-    hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, ls, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
+    // log-joint partials summed over hyper-samples (in sample order), one record per (r, k); on the main stream of an MC
+    // evaluation this shares a launch with the entropy reduction below
+    if (fork || !P.mc) hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, ls, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
     return VBMC_OK;
   };
   if (fork) {
@@ -581,8 +585,12 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     }
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     // chunk partials -> one record per (r, j), summed in chunk order
-    hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
-                       P.d_part, P.d_red);
+    if (fork)
+      hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
+                         P.d_part, P.d_red);
+    else
+      hipLaunchKernelGGL(k_reduce_both, dim3(K, R, 2), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
+                         P.d_part, P.d_red, S, 2 * D + 2, P.d_lj, P.d_ljbar);
     fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {
     size_t lds = ((size_t)K * K + K + 256) * sizeof(double);
@@ -750,34 +758,9 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
 // is enqueued on the stream without host round trips; the host only polls R "done" flags every
 // 20 iterations (the reference tests termination on exactly those iterations, fminadam.m:65).
 // ------------------------------------------------------------------------------------------
-struct AdamState {
-  double *m, *v, *xtab, *ftab;  // T x R, T x R, T x MaxIter x R, MaxIter x R
-  int* done;                    // R: 0 = running, otherwise the iteration at which the chain stopped
-  int T, R, MaxIter;
-  double step_min, step_max, step_decay, TolFun;
-};
-
 __global__ void __launch_bounds__(256) k_adam_step(AdamState A, int iter, double* __restrict__ x /*T x R*/,
                                                    const double* __restrict__ out /*R x (5+3T)*/) {
-  const int r = blockIdx.x;
-  if (A.done[r]) return;
-  const int T = A.T;
-  const double* o = out + (size_t)r * (OUT_HDR + 3 * T);
-  const double b1 = 0.9, b2 = 0.999, fudge = 1.4901161193847656e-08;  // sqrt(eps)  (fminadam.m:20-22)
-  const double c1 = 1.0 - pow(b1, (double)iter), c2 = 1.0 - pow(b2, (double)iter);
-  const double step = A.step_min + (A.step_max - A.step_min) * exp(-(double)iter / A.step_decay);  // :56-57
-  if (threadIdx.x == 0) A.ftab[(size_t)r * A.MaxIter + (iter - 1)] = o[0];
-  for (int i = threadIdx.x; i < T; i += blockDim.x) {
-    const double g = o[OUT_HDR + i];
-    double m = b1 * A.m[(size_t)r * T + i] + (1.0 - b1) * g;      // :51
-    double v = b2 * A.v[(size_t)r * T + i] + (1.0 - b2) * g * g;  // :52
-    A.m[(size_t)r * T + i] = m;
-    A.v[(size_t)r * T + i] = v;
-    const double mhat = m / c1, vhat = v / c2;
-    const double xn = x[(size_t)r * T + i] - step * mhat / (sqrt(vhat) + fudge);  // :59 (LB/UB are [] at the call site)
-    x[(size_t)r * T + i] = xn;
-    A.xtab[((size_t)r * A.MaxIter + (iter - 1)) * T + i] = xn;
-  }
+  adam_update_chain(A, iter, x, out, blockIdx.x);
 }
 
 // stopping test at iter (a multiple of 20, >= 40): fminadam.m:65-81
@@ -839,10 +822,16 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   HIP_TRY(ctx, hipMemsetAsync(A.done, 0, (size_t)R * sizeof(int), st));
   std::vector<int> done(R, 0);
   int iter = 0;
+  bool pending = false;   // the update of iteration iter - 1 rides on this iteration's k_prep
   for (iter = 1; iter <= MaxIter; ++iter) {
-    { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter); if (s_) return s_; }
-    hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
-    if (iter % 20 == 0 && iter >= 40) {
+    { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, pending ? &A : nullptr, iter - 1); if (s_) return s_; }
+    pending = true;
+    const bool check = iter % 20 == 0 && iter >= 40;
+    if (check || iter == MaxIter) {   // the stopping test and the final read-back need this iteration's update now
+      hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
+      pending = false;
+    }
+    if (check) {
       hipLaunchKernelGGL(k_adam_check, dim3(R), dim3(256), 0, st, A, iter);
       HIP_TRY(ctx, hipMemcpyAsync(done.data(), A.done, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -19,14 +19,52 @@
 #include "elbo_types.h"
 
 // ------------------------------------------------------------------------------------------
-// k_prep: unpack theta exactly as misc/negelcbo_vbmc.m:33-48 does
+// On-device Adam state (utils/fminadam.m:42-102, R chains in lock-step) and the update of one chain by its workgroup.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_prep(ElboDims dm, const double* __restrict__ theta,
+struct AdamState {
+  double *m, *v, *xtab, *ftab;  // T x R, T x R, T x MaxIter x R, MaxIter x R
+  int* done;                    // R: 0 = running, otherwise the iteration at which the chain stopped
+  int T, R, MaxIter;
+  double step_min, step_max, step_decay, TolFun;
+};
+
+__device__ inline void adam_update_chain(const AdamState& A, int iter, double* __restrict__ x /*T x R*/,
+                                         const double* __restrict__ out /*R x (5+3T)*/, int r) {
+  if (A.done[r]) return;
+  const int T = A.T;
+  const double* o = out + (size_t)r * (OUT_HDR + 3 * T);
+  const double b1 = 0.9, b2 = 0.999, fudge = 1.4901161193847656e-08;  // sqrt(eps)  (fminadam.m:20-22)
+  const double c1 = 1.0 - pow(b1, (double)iter), c2 = 1.0 - pow(b2, (double)iter);
+  const double step = A.step_min + (A.step_max - A.step_min) * exp(-(double)iter / A.step_decay);  // :56-57
+  if (threadIdx.x == 0) A.ftab[(size_t)r * A.MaxIter + (iter - 1)] = o[0];
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    const double g = o[OUT_HDR + i];
+    double m = b1 * A.m[(size_t)r * T + i] + (1.0 - b1) * g;      // :51
+    double v = b2 * A.v[(size_t)r * T + i] + (1.0 - b2) * g * g;  // :52
+    A.m[(size_t)r * T + i] = m;
+    A.v[(size_t)r * T + i] = v;
+    const double mhat = m / c1, vhat = v / c2;
+    const double xn = x[(size_t)r * T + i] - step * mhat / (sqrt(vhat) + fudge);  // :59 (LB/UB are [] at the call site)
+    x[(size_t)r * T + i] = xn;
+    A.xtab[((size_t)r * A.MaxIter + (iter - 1)) * T + i] = xn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_prep: unpack theta exactly as misc/negelcbo_vbmc.m:33-48 does.  Inside the on-device optimiser loop the Adam update
+// of the previous iteration (adam_iter > 0) is applied first by the same workgroup, which saves one launch per iteration.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ theta,
                                               const double* __restrict__ vpfix,  // mu sigma lambda w (fixed vp) packed
-                                              double* __restrict__ vpd, double* __restrict__ entp) {
+                                              double* __restrict__ vpd, double* __restrict__ entp, AdamState A, int adam_iter,
+                                              const double* __restrict__ prev_out) {
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int D = dm.D, K = dm.K;
   VpLayout L{D, K};
+  if (adam_iter > 0) {
+    adam_update_chain(A, adam_iter, theta, prev_out, r);
+    __syncthreads();
+  }
   const double* th = theta + (size_t)r * dm.T;
   double* v = vpd + (size_t)r * L.stride();
   const double* fmu = vpfix;
@@ -648,9 +686,8 @@ __global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __rest
 // column: red[r][j][col] = sum_c part[r][j][c][col].  Keeps k_finalize's latency independent of the
 // chunk count (which is large when few restarts must still fill the chip).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const double* __restrict__ part,
-                                                    double* __restrict__ red) {
-  const int j = blockIdx.x, r = blockIdx.y, K = gridDim.x;
+__device__ __forceinline__ void ent_reduce_body(int j, int r, int K, int C, int ncol, const double* __restrict__ part,
+                                                double* __restrict__ red) {
   const double* p = part + ((size_t)r * K + j) * C * ncol;
   double* o = red + ((size_t)r * K + j) * ncol;
   for (int col = threadIdx.x; col < ncol; col += blockDim.x) {
@@ -668,11 +705,15 @@ __global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const doubl
   }
 }
 
+__global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const double* __restrict__ part,
+                                                    double* __restrict__ red) {
+  ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red);
+}
+
 // k_lj_reduce: sum the log-joint partials over hyper-samples in sample order, one thread per column:
 // ljbar[r][k][col] = sum_s lj[r][s][k][col]   (gplogjoint.m:399-413 averages are linear in these sums)
-__global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const double* __restrict__ lj,
-                                                  double* __restrict__ ljbar) {
-  const int k = blockIdx.x, r = blockIdx.y;
+__device__ __forceinline__ void lj_reduce_body(int k, int r, int S, int K, int LJS, const double* __restrict__ lj,
+                                               double* __restrict__ ljbar) {
   for (int col = threadIdx.x; col < LJS; col += blockDim.x) {
     double acc = 0.0;
     const double* p = lj + ((size_t)r * S * K + k) * LJS + col;
@@ -688,6 +729,18 @@ __global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const d
     for (; s < S; ++s) acc += p[(size_t)s * st];
     ljbar[((size_t)r * K + k) * LJS + col] = acc;
   }
+}
+
+__global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const double* __restrict__ lj,
+                                                  double* __restrict__ ljbar) {
+  lj_reduce_body(blockIdx.x, blockIdx.y, S, K, LJS, lj, ljbar);
+}
+
+// both reductions in one launch (blockIdx.z = 0: entropy chunks, 1: hyper-samples) when they sit on the same stream
+__global__ void __launch_bounds__(256) k_reduce_both(int C, int ncol, const double* __restrict__ part, double* __restrict__ red,
+                                                     int S, int LJS, const double* __restrict__ lj, double* __restrict__ ljbar) {
+  if (blockIdx.z == 0) ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red);
+  else lj_reduce_body(blockIdx.x, blockIdx.y, S, gridDim.x, LJS, lj, ljbar);
 }
 
 // ------------------------------------------------------------------------------------------
