@@ -523,7 +523,10 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const int D = dm.D, K = dm.K, R = dm.R, S = dm.S, T = dm.T;
   const int dt = P.dt;
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), 0, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
+  const size_t prep_lds = ((size_t)D * K + 3 * K + D + 8) * sizeof(double);
+  if (prep_lds > 64 * 1024)
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), prep_lds, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
                      pend ? pend_iter : 0, (const double*)P.d_out);
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel

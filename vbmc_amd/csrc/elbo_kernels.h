@@ -18,6 +18,19 @@
 #include "device_math.h"
 #include "elbo_types.h"
 
+// Sum over the workgroup (blockDim.x a multiple of 64; `red` holds at least one double per wave): a fixed-order butterfly
+// inside each wave, then the wave totals in wave order -- two barriers instead of a log2(blockDim) LDS tree.
+__device__ inline double block_sum(double v, double* red) {
+  const int tid = threadIdx.x, nw = blockDim.x >> 6;
+  v = wave_sum(v);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  for (int i = 1; i < nw; ++i) r += red[i];
+  __syncthreads();
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // On-device Adam state (utils/fminadam.m:42-102, R chains in lock-step) and the update of one chain by its workgroup.
 // ------------------------------------------------------------------------------------------
@@ -71,53 +84,52 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
   const double* fsig = vpfix + D * K;
   const double* flam = fsig + K;
   const double* fw = flam + D;
-  __shared__ double s_sum;
-  for (int i = tid; i < D * K; i += nt) v[L.mu() + i] = dm.opt[0] ? th[dm.off_mu + i] : fmu[i];
+  // the unpacked record is kept in LDS as well, so that the later phases do not wait for their own global writes
+  extern __shared__ double sh[];
+  double* s_mu = sh;               // D x K
+  double* s_sig = s_mu + D * K;    // K
+  double* s_lnsig = s_sig + K;     // K
+  double* s_lam = s_lnsig + K;     // D
+  double* s_w = s_lam + D;         // K
+  double* red = s_w + K;           // one double per wave
+  for (int i = tid; i < D * K; i += nt) { double m = dm.opt[0] ? th[dm.off_mu + i] : fmu[i]; s_mu[i] = m; v[L.mu() + i] = m; }
+  double pe_ = 0.0, pl_ = 0.0;
   for (int k = tid; k < K; k += nt) {
     double ls = dm.opt[1] ? th[dm.off_sigma + k] : log(fsig[k]);
-    v[L.lnsigma() + k] = ls;
-    v[L.sigma() + k] = dm.opt[1] ? exp(ls) : fsig[k];  // vp.sigma = exp(theta) (:40)
+    double sg = dm.opt[1] ? exp(ls) : fsig[k];  // vp.sigma = exp(theta) (:40)
+    v[L.lnsigma() + k] = ls; s_lnsig[k] = ls;
+    v[L.sigma() + k] = sg; s_sig[k] = sg;
+    if (dm.opt[3]) pe_ += exp(th[dm.off_eta + k]);
   }
   for (int d = tid; d < D; d += nt) {
     double ll = dm.opt[2] ? th[dm.off_lambda + d] : log(flam[d]);
+    double lm = dm.opt[2] ? exp(ll) : flam[d];
     v[L.lnlambda() + d] = ll;
-    v[L.lambda() + d] = dm.opt[2] ? exp(ll) : flam[d];
+    v[L.lambda() + d] = lm; s_lam[d] = lm;
+    pl_ += log(lm);
   }
-  __syncthreads();
-  {
-    // vp.w = exp(eta)/sum(exp(eta)), no max-shift (:45-47); log nf = -D/2 log(2 pi) - sum log lambda
-    __shared__ double redp[256];
-    double pe_ = 0.0, pl_ = 0.0;
-    if (dm.opt[3]) for (int k = tid; k < K; k += nt) pe_ += exp(th[dm.off_eta + k]);
-    for (int d = tid; d < D; d += nt) pl_ += log(v[L.lambda() + d]);
-    redp[tid] = pe_;
-    __syncthreads();
-    for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) redp[tid] += redp[tid + st]; __syncthreads(); }
-    if (tid == 0) s_sum = redp[0];
-    __syncthreads();
-    redp[tid] = pl_;
-    __syncthreads();
-    for (int st = nt / 2; st > 0; st >>= 1) { if (tid < st) redp[tid] += redp[tid + st]; __syncthreads(); }
-    if (tid == 0) v[L.lognf()] = -0.5 * D * 1.8378770664093454835606594728112 - redp[0];
-  }
-  __syncthreads();
+  // vp.w = exp(eta)/sum(exp(eta)), no max-shift (:45-47); log nf = -D/2 log(2 pi) - sum log lambda
+  const double s_sum = block_sum(pe_, red);
+  const double sum_loglam = block_sum(pl_, red);
+  if (tid == 0) v[L.lognf()] = -0.5 * D * 1.8378770664093454835606594728112 - sum_loglam;
   for (int k = tid; k < K; k += nt) {
     double eta = dm.opt[3] ? th[dm.off_eta + k] : log(fw[k]);
+    double wk = dm.opt[3] ? exp(eta) / s_sum : fw[k];
     v[L.eta() + k] = eta;
-    v[L.w() + k] = dm.opt[3] ? exp(eta) / s_sum : fw[k];
+    v[L.w() + k] = wk; s_w[k] = wk;
   }
   __syncthreads();
   // packed entropy parameters
   double* ep = entp + (size_t)r * K * (D + ENTP_EXTRA);
   for (int i = tid; i < K * (D + ENTP_EXTRA); i += nt) {
     int k = i / (D + ENTP_EXTRA), c = i % (D + ENTP_EXTRA);
-    double sg = v[L.sigma() + k];
+    double sg = s_sig[k];
     double val;
-    if (c < D) val = v[L.mu() + c + D * k] / v[L.lambda() + c];
+    if (c < D) val = s_mu[c + D * k] / s_lam[c];
     else if (c == D) val = -0.5 / (sg * sg);
-    else if (c == D + 1) val = -(double)D * v[L.lnsigma() + k];
-    else if (c == D + 2) val = v[L.w() + k];
-    else val = v[L.w() + k] / (sg * sg);
+    else if (c == D + 1) val = -(double)D * s_lnsig[k];
+    else if (c == D + 2) val = s_w[k];
+    else val = s_w[k] / (sg * sg);
     ep[i] = val;
   }
 }
@@ -762,19 +774,6 @@ struct FinArgs {
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* out;            // R x (OUT_HDR + 3T)
 };
-
-// Sum over the workgroup (blockDim.x a multiple of 64; `red` holds at least one double per wave): a fixed-order butterfly
-// inside each wave, then the wave totals in wave order -- two barriers instead of a log2(blockDim) LDS tree.
-__device__ inline double block_sum(double v, double* red) {
-  const int tid = threadIdx.x, nw = blockDim.x >> 6;
-  v = wave_sum(v);
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  double r = red[0];
-  for (int i = 1; i < nw; ++i) r += red[i];
-  __syncthreads();
-  return r;
-}
 
 #define FIN_THREADS 1024
 // global -> LDS copy with eight independent loads in flight per thread (the plain loop waits for each load in turn)
