@@ -75,10 +75,34 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   // the per-lane operand fragments below are gathered from LDS, not from global memory
   extern __shared__ double PB[];
   {
+    // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
+    // single chain) this setup is a quarter of the kernel
     const double* gsrc = a.entp + (size_t)r * K * PSg;
-    for (int idx = tid; idx < K * PSg; idx += WAVE * HV) PB[idx] = gsrc[idx];
+    constexpr int NT = WAVE * HV;
+    const int n = K * PSg;
+    int idx = tid;
+    for (; idx + 7 * NT < n; idx += 8 * NT) {
+      double t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t8[u] = gsrc[idx + u * NT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) PB[idx + u * NT] = t8[u];
+    }
+    {
+      double t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t8[u] = (idx + u * NT < n) ? gsrc[idx + u * NT] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (idx + u * NT < n) PB[idx + u * NT] = t8[u];
+    }
   }
-  for (int t = tid; t < VB_EXP_TAB_N; t += WAVE * HV) TAB[t] = c_exp2_tab[t];
+  {
+    double tt[VB_EXP_TAB_N / (WAVE * HV)];
+#pragma unroll
+    for (int u = 0; u < VB_EXP_TAB_N / (WAVE * HV); ++u) tt[u] = c_exp2_tab[tid + u * WAVE * HV];
+#pragma unroll
+    for (int u = 0; u < VB_EXP_TAB_N / (WAVE * HV); ++u) TAB[tid + u * WAVE * HV] = tt[u];
+  }
   __syncthreads();
   const double* gp = PB;
   const double* pj = gp + (size_t)j * PSg;
