@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   VpLayout L{D, K};
   const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
+  const double hj_neg = 0.5 / (sigj * sigj);   // = -h_j bit for bit (k_prep computes h = -0.5/(sigma*sigma))
   const int nr_last = max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
@@ -136,8 +137,8 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       double v;
       if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;            // padded component: exp -> 0
       else if (cc < D) v = -2.0 * h * (pk[cc] - pj[cc]);     // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
-      else if (cc == D) v = h;
-      else if (cc == D + 1) v = fma(h, m2, pk[D + 1]);       // -D ln sigma_k - |m'_k|^2/(2 sigma_k^2)
+      else if (cc == D) v = h + hj_neg;                      // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2)
+      else if (cc == D + 1) v = fma(h, m2, pk[D + 1]) - cKj;  // is folded into the two constant columns: accumulators start at 0
       else v = 0.0;
       SA[kt][q] = v;
     }
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       mf4 n[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        n[kt] = (mf4){-shift, -shift, -shift, -shift};
+        n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
         if (!SP || ((act >> kt) & 1u)) {
 #pragma unroll
           for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
