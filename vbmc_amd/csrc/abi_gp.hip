@@ -225,19 +225,18 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   const size_t tlds = f.tlds;
   std::vector<double>&scal = f.scal, &sn2min = f.sn2min;
   std::vector<unsigned char>& lch = f.lch;
-  TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dZ, dXi;
+  TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dXi;
 
   std::vector<double> alh((size_t)S * N);
   HIP_TRY(ctx, hipMemcpyAsync(alh.data(), dal.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
   const bool wantL = L != nullptr || gp_out != nullptr;
   if (wantL && any_inv) {
     // pL = -L\(L'\eye(N)) for low-noise samples (:98); the sign is applied where the matrix is consumed
-    HIP_TRY(ctx, dZ.alloc(ctx, (size_t)S * N * N * 8));
     HIP_TRY(ctx, dXi.alloc(ctx, (size_t)S * N * N * 8));
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, dZ.as<double>());
-    dim3 tg((N + TR_CB - 1) / TR_CB, S, 1);
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>());
-    hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dZ.as<double>(), dXi.as<double>());
+    if (tlds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_spd_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    hipLaunchKernelGGL(k_spd_inverse, dim3((N + TR_CB - 1) / TR_CB, S), dim3(64), tlds, st, N, dA.as<double>(), dfinv.as<double>(),
+                       dninv.as<unsigned char>(), dXi.as<double>());
     HIP_TRY(ctx, hipGetLastError());
   }
   if (L) {
@@ -314,20 +313,20 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
   { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int Nnoise = f.Nnoise, Nmean = f.Nmean, moff = f.Ncov + f.Nnoise;
-  TmpBuf dnlz, dZ, dKi, dds, dpart, dg;
+  TmpBuf dnlz, dKi, dds, dpart, dg;
   HIP_TRY(ctx, dnlz.alloc(ctx, (size_t)B * 8));
   hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
                      f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(nlZ, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
   if (compute_grad) {
-    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240), two MFMA triangular solves of the identity
-    HIP_TRY(ctx, dZ.alloc(ctx, (size_t)B * N * N * 8));
+    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240): both triangular solves of the identity in one
+    // kernel that only forms the lower triangle (k_spd_inverse)
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)B * N * N + 255) / 256)), dim3(256), 0, st, N, B, dZ.as<double>());
-    dim3 tg((N + TR_CB - 1) / TR_CB, B, 1);
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), f.tlds, st, N, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dZ.as<double>());
-    hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), f.tlds, st, N, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dZ.as<double>(), dKi.as<double>());
+    if (f.tlds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_spd_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.tlds));
+    hipLaunchKernelGGL(k_spd_inverse, dim3((N + TR_CB - 1) / TR_CB, B), dim3(64), f.tlds, st, N, f.dA.as<double>(), f.dfinv.as<double>(),
+                       f.dones.as<unsigned char>(), dKi.as<double>());
     std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
     for (int b = 0; b < B; ++b)
       noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);

@@ -50,11 +50,14 @@ __global__ void __launch_bounds__(64) k_diag_inv(int N, const double* __restrict
 }
 
 // forward substitution R' V = Z for the slab in LDS (in place)
+// bi_start > 0: the slab is known to be zero above row 16 * bi_start (columns of the identity), so is the solution:
+// the substitution starts there and the trailing updates skip the zero rows.
 __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ Rm, const double* __restrict__ Finv,
-                                              double* __restrict__ V, double* __restrict__ P, int lane) {
+                                              double* __restrict__ V, double* __restrict__ P, int lane, int bi_start = 0) {
   const int li = lane & 15, lg = lane >> 4;
   const int nblk = (N + 15) >> 4;
-  for (int bi = 0; bi < nblk; ++bi) {
+  const int r0 = bi_start << 4;
+  for (int bi = bi_start; bi < nblk; ++bi) {
     const int b0 = bi << 4;
     // trailing update: the b0 x 16 panel R[0:b0, b0:b0+16] is streamed through LDS in 64-row chunks with
     // fully coalesced loads (lane = row, one load per column, all 16 in flight), then consumed by MFMAs
@@ -64,8 +67,8 @@ __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ 
     for (int u = 0; u < 4; ++u) fv[u] = Finv[(size_t)bi * 256 + li * 16 + 4 * u + lg];
     double pv[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) pv[c] = (lane < b0 && b0 + c < N) ? Rm[(size_t)(b0 + c) * N + lane] : 0.0;
-    for (int j0 = 0; j0 < b0; j0 += 64) {
+    for (int c = 0; c < 16; ++c) pv[c] = (r0 + lane < b0 && b0 + c < N) ? Rm[(size_t)(b0 + c) * N + r0 + lane] : 0.0;
+    for (int j0 = r0; j0 < b0; j0 += 64) {
       const int nrow = min(64, b0 - j0);
       __syncthreads();
 #pragma unroll
@@ -106,12 +109,13 @@ __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ 
 }
 
 // backward substitution R X = V for the slab in LDS (in place)
+// bi_stop > 0: only the rows from 16 * bi_stop down are wanted (the lower triangle of a symmetric solution)
 __device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ Rm, const double* __restrict__ Finv,
-                                              double* __restrict__ V, int lane) {
+                                              double* __restrict__ V, int lane, int bi_stop = 0) {
   const int li = lane & 15, lg = lane >> 4;
   const int nblk = (N + 15) >> 4;
   const int Np = nblk << 4;
-  for (int bi = nblk - 1; bi >= 0; --bi) {
+  for (int bi = nblk - 1; bi >= bi_stop; --bi) {
     const int b0 = bi << 4;
     // trailing update: A[i = li][k = lg] = R[b0+li][j] -- 16 consecutive doubles per inner index (coalesced);
     // eight independent loads are issued per batch to cover the L2 latency
@@ -196,4 +200,39 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
   trsm_slab_load(N, K, cb * 16, Vin + ((size_t)r * S + s) * (size_t)K * N, V, lane);
   trsm_bwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, lane);
   trsm_slab_store(N, K, cb * 16, Xo + ((size_t)r * S + s) * (size_t)K * N, V, lane);
+}
+
+// k_spd_inverse: X = R^{-1} R^{-T} = inv(R'R) for the factors flagged in `on`, one wave per 16 columns of the identity:
+// forward substitution from the column block's own rows (the slab is zero above them), backward substitution down to
+// the same rows, i.e. the block column of the LOWER triangle, written together with its mirror image.  A third of the
+// flops of two full-width solves on the identity, and no intermediate matrix in global memory.  Used for
+// Kinv in the GP marginal-likelihood gradient (gplite_core.m:146-147) and for the stored -inv(K + sn2 I) of
+// low-noise posteriors (gplite_core.m:84).
+__global__ void __launch_bounds__(64) k_spd_inverse(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                    const unsigned char* __restrict__ on, double* __restrict__ Xo) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  if (!on[s]) return;
+  const int Np = ((N + 15) >> 4) << 4;
+  double* V = lds;
+  double* P = V + (size_t)Np * TR_VS;
+  const int k0 = cb << 4;
+  for (int c = 0; c < 16; ++c)
+    for (int i = lane; i < Np; i += 64) V[i * TR_VS + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
+  __syncthreads();
+  const double* Rm = Lall + (size_t)s * N * N;
+  const double* Fi = Finv + (size_t)s * TRSM_NBLK(N) * 256;
+  trsm_fwd_wave(N, Rm, Fi, V, P, lane, cb);
+  trsm_bwd_wave(N, Rm, Fi, V, lane, cb);
+  double* X = Xo + (size_t)s * N * N;
+  // columns of the block: rows from the block's own first row down (the diagonal block as computed, both halves)
+  for (int c = 0; c < 16; ++c) {
+    const int j = k0 + c;
+    if (j >= N) break;
+    for (int i = k0 + lane; i < N; i += 64) X[(size_t)j * N + i] = V[i * TR_VS + c];
+  }
+  // mirror image of the part below the diagonal block: 4 rows x 16 consecutive columns per store
+  const int cc = lane & 15;
+  if (k0 + cc < N)
+    for (int i = k0 + 16 + (lane >> 4); i < N; i += 4) X[(size_t)(k0 + cc) + (size_t)i * N] = V[i * TR_VS + cc];
 }
