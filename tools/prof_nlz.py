@@ -12,7 +12,7 @@ inp = synth_inputs(0, D, N, K, S)
 eng = vbmc_amd.Engine(0)
 gpd = {"X": inp["X"], "y": inp["y"], "s2": None, "covfun": 1, "Ncov": D + 1, "noisefun": (1, 0, 0), "Nnoise": 1, "meanfun": 4,
        "Nmean": 2 * D + 1, "intmeanfun": 0}
-for B in (1, 64):
+for B in (1, 64, 256):
     H = np.tile(inp["hyp"], (1, (B + S - 1) // S))[:, :B]
     for _ in range(10):
         vbmc_amd.gplite_nlZ(H, gpd, engine=eng)

@@ -166,7 +166,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   for (int iter = 0; iter < 10 && pending; ++iter) {
     HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dact.p, active.data(), S, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gp_build, dim3(64, S), dim3(256), 0, st, N, D, Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
+    hipLaunchKernelGGL(k_gp_build, dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D, Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
                        dsn2.as<double>(), dscal.as<double>(), dact.as<unsigned char>(), dA.as<double>());
     hipLaunchKernelGGL(k_chol, dim3(S), dim3(CH_THREADS), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>());
     HIP_TRY(ctx, hipGetLastError());
@@ -332,10 +332,10 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
       noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);
     HIP_TRY(ctx, dds.alloc(ctx, dsn2h.size() * 8));
     HIP_TRY(ctx, hipMemcpyAsync(dds.p, dsn2h.data(), dsn2h.size() * 8, hipMemcpyHostToDevice, st));
-    const int ntile = (N + NLZ_TJ - 1) / NLZ_TJ, P = D + 1 + Nnoise;
+    const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
     HIP_TRY(ctx, dpart.alloc(ctx, (size_t)B * ntile * P * 8));
     HIP_TRY(ctx, dg.alloc(ctx, (size_t)B * Nhyp * 8));
-    hipLaunchKernelGGL(k_nlz_grad, dim3(ntile, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(), f.dXc.as<double>(),
+    hipLaunchKernelGGL(k_nlz_grad, dim3(nt1, nt1, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(), f.dXc.as<double>(),
                        f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dds.as<double>(), dpart.as<double>());
     hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
                        f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg.as<double>());

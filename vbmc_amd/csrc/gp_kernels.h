@@ -110,13 +110,23 @@ __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const 
   }
 }
 
+// One workgroup per 64 x 64 tile of the UPPER triangle (k_chol reads i <= j only; it zeroes the strict lower part
+// itself): both 64-point slabs of the scaled inputs are staged in LDS dimension-major, a lane keeps its own point in
+// registers and walks 16 columns whose coordinates are wave-uniform LDS broadcasts; exponent by the table exp.
+#define GPB_T 64
 __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const double* __restrict__ hyp,
                                                   const double* __restrict__ Xc, const double* __restrict__ aa,
                                                   const double* __restrict__ sn2,      // S x N  noise variance per point
                                                   const double* __restrict__ scal,     // S x 4: sn2div, mult, lchol, _
                                                   const unsigned char* __restrict__ active, double* __restrict__ A) {
-  const int s = blockIdx.y;
+  const int s = blockIdx.z;
   if (!active[s]) return;
+  const int i0 = blockIdx.x * GPB_T, j0 = blockIdx.y * GPB_T;
+  if (i0 > j0) return;                               // tile entirely below the diagonal
+  __shared__ double TAB[VB_EXP_TAB_N];
+  __shared__ double XI[32 * GPB_T], XJ[32 * GPB_T];  // [d][point]
+  __shared__ double AJ[GPB_T];
+  const int tid = threadIdx.x, ti = tid & 63, tj = tid >> 6;
   const double* h = hyp + (size_t)s * Nhyp;
   const double sf2 = exp(2.0 * h[D]);
   const double sn2div = scal[s * 4 + 0], mult = scal[s * 4 + 1];
@@ -124,16 +134,35 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
   const double* xs = Xc + (size_t)s * N * D;
   const double* as = aa + (size_t)s * N;
   double* As = A + (size_t)s * N * N;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)N * N; idx += (size_t)gridDim.x * blockDim.x) {
-    int i = (int)(idx % N), j = (int)(idx / N);
+  TAB[tid] = c_exp2_tab[tid];
+  // the rows i0 .. i0+63 of the point-major Xc are one contiguous block: coalesced reads, transposed into LDS
+  for (int e = tid; e < GPB_T * D; e += 256) {
+    const int pnt = e / D, d = e - pnt * D;
+    XI[d * GPB_T + pnt] = (i0 + pnt < N) ? xs[(size_t)i0 * D + e] : 0.0;
+    XJ[d * GPB_T + pnt] = (j0 + pnt < N) ? xs[(size_t)j0 * D + e] : 0.0;
+  }
+  if (tid < GPB_T) AJ[tid] = (j0 + tid < N) ? as[j0 + tid] : 0.0;
+  __syncthreads();
+  const int i = i0 + ti;
+  if (i >= N) return;
+  double xi[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) xi[d] = (d < D) ? XI[d * GPB_T + ti] : 0.0;
+  const double ai = as[i];
+  const double sdiv = sn2div * mult;
+  for (int t = 0; t < 16; ++t) {
+    const int jl = tj * 16 + t, j = j0 + jl;
+    if (j >= N) break;
     double dot = 0.0;
-    for (int d = 0; d < D; ++d) dot = fma(xs[(size_t)i * D + d], xs[(size_t)j * D + d], dot);
-    double c = fmax(as[i] + (as[j] - 2.0 * dot), 0.0);
-    double k = sf2 * exp(-c / 2.0);
+#pragma unroll
+    for (int d = 0; d < 32; ++d)
+      if (d < D) dot = fma(xi[d], XJ[d * GPB_T + jl], dot);
+    const double c = fmax(ai + (AJ[jl] - 2.0 * dot), 0.0);
+    const double k = sf2 * vb_exp_tab<0>(-0.5 * c, TAB);
     double v;
-    if (lchol) v = k / (sn2div * mult) + (i == j ? sn2[(size_t)s * N + i] / sn2div : 0.0);  // :78
-    else v = k + (i == j ? mult * sn2[(size_t)s * N + i] : 0.0);                            // :92
-    As[idx] = v;
+    if (lchol) v = k / sdiv + (i == j ? sn2[(size_t)s * N + i] / sn2div : 0.0);  // :78
+    else v = k + (i == j ? mult * sn2[(size_t)s * N + i] : 0.0);               // :92
+    As[(size_t)j * N + i] = v;
   }
 }
 
@@ -621,25 +650,33 @@ __global__ void __launch_bounds__(256) k_nlz_value(int N, int D, int Nhyp, int m
   if (tid == 0) nlz[b] = quad / 2.0 + ld + N * log(2.0 * 3.14159265358979323846 * scal[b * 4 + 3]) / 2.0;
 }
 
-// Partial sums of the Q-contractions over one tile of NLZ_TJ rows j and all k:
+// Partial sums of the Q-contractions over one 64 x 64 tile of (k, j):
 //   Q = Kinv/sl - alpha*alpha'                                  (:240, Kinv = L\(L'\eye(N)))
 //   part[d]  = sum Q .* K .* sq_dist(X(:,d)'/ell_d), d < D       (:244-247; the 1/2 is applied in k_nlz_final)
 //   part[D]  = sum Q .* K                                       (:248)
 //   part[D+1+i] = sum_j dsn2(j,i) Q_jj                          (:257-262)
 // K is rebuilt exactly as k_gp_build forms it.  Fixed-order block reduction, no atomics.
-#define NLZ_TJ 8
+#define NLZ_T 64
 #define NLZ_MAXP (32 + 1 + 4)
+// One workgroup per 64 x 64 tile (k along the lanes, 16 rows j per wave) of the upper triangle of tiles; off-diagonal
+// tiles count twice (Q, K and the distance matrices are symmetric), tiles below the diagonal write zeros.
 __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nnoise, const double* __restrict__ hyp,
                                                   const double* __restrict__ Xc, const double* __restrict__ aa,
                                                   const double* __restrict__ Kinv, const double* __restrict__ alpha,
                                                   const double* __restrict__ scal, const double* __restrict__ dsn2,  // B x Nnoise x N
                                                   double* __restrict__ part) {
   __shared__ double red[256];
-  __shared__ double xj[NLZ_TJ][32];
-  const int jt = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int jl = tid >> 5, kl = tid & 31;
-  const int j = jt * NLZ_TJ + jl;
-  const bool jv = j < N;
+  __shared__ double TAB[VB_EXP_TAB_N];
+  __shared__ double XK[32 * NLZ_T], XJ[32 * NLZ_T];  // [d][point]
+  __shared__ double AJ[NLZ_T], ALJ[NLZ_T];
+  const int b = blockIdx.z, tid = threadIdx.x, tk = tid & 63, tj = tid >> 6;
+  const int k0 = blockIdx.x * NLZ_T, j0 = blockIdx.y * NLZ_T;
+  const int P = D + 1 + Nnoise;
+  double* o = part + ((size_t)b * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * P;
+  if (k0 > j0) {
+    for (int p = tid; p < P; p += 256) o[p] = 0.0;
+    return;
+  }
   const double* h = hyp + (size_t)b * Nhyp;
   const double sf2 = exp(2.0 * h[D]);
   const double isl = 1.0 / scal[b * 4 + 3];
@@ -647,24 +684,42 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
   const double* as = aa + (size_t)b * N;
   const double* Kb = Kinv + (size_t)b * N * N;
   const double* al = alpha + (size_t)b * N;
-  if (kl < D) xj[jl][kl] = jv ? xs[(size_t)j * D + kl] : 0.0;
+  TAB[tid] = c_exp2_tab[tid];
+  for (int e = tid; e < NLZ_T * D; e += 256) {
+    const int pnt = e / D, d = e - pnt * D;
+    XK[d * NLZ_T + pnt] = (k0 + pnt < N) ? xs[(size_t)k0 * D + e] : 0.0;
+    XJ[d * NLZ_T + pnt] = (j0 + pnt < N) ? xs[(size_t)j0 * D + e] : 0.0;
+  }
+  if (tid < NLZ_T) {
+    AJ[tid] = (j0 + tid < N) ? as[j0 + tid] : 0.0;
+    ALJ[tid] = (j0 + tid < N) ? al[j0 + tid] : 0.0;
+  }
   __syncthreads();
   double acc[NLZ_MAXP];
 #pragma unroll
   for (int p = 0; p < NLZ_MAXP; ++p) acc[p] = 0.0;
-  if (jv) {
-    const double aj = as[j], alj = al[j];
-    for (int k = kl; k < N; k += 32) {
+  const int k = k0 + tk;
+  if (k < N) {
+    double xk[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) xk[d] = (d < D) ? XK[d * NLZ_T + tk] : 0.0;
+    const double ak = as[k], alk = al[k];
+    const double sym = (k0 < j0) ? 2.0 : 1.0;
+    for (int t = 0; t < 16; ++t) {
+      const int jl = tj * 16 + t, j = j0 + jl;
+      if (j >= N) break;
       double dot = 0.0;
-      for (int d = 0; d < D; ++d) dot = fma(xj[jl][d], xs[(size_t)k * D + d], dot);
-      const double c = fmax(aj + (as[k] - 2.0 * dot), 0.0);
-      const double kv = sf2 * exp(-c / 2.0);
-      const double q = Kb[(size_t)j * N + k] * isl - alj * al[k];    // Kinv is symmetric: column j read along k (coalesced)
-      const double qk = q * kv;
+#pragma unroll
+      for (int d = 0; d < 32; ++d)
+        if (d < D) dot = fma(xk[d], XJ[d * NLZ_T + jl], dot);
+      const double c = fmax(AJ[jl] + (ak - 2.0 * dot), 0.0);
+      const double kv = sf2 * vb_exp_tab<0>(-0.5 * c, TAB);
+      const double q = Kb[(size_t)j * N + k] * isl - ALJ[jl] * alk;    // column j read along k (coalesced)
+      const double qk = sym * (q * kv);
 #pragma unroll
       for (int d = 0; d < 32; ++d) {
         if (d < D) {
-          const double df = xj[jl][d] - xs[(size_t)k * D + d];
+          const double df = XJ[d * NLZ_T + jl] - xk[d];
           acc[d] = fma(qk, df * df, acc[d]);
         }
       }
@@ -676,7 +731,6 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
       }
     }
   }
-  double* o = part + ((size_t)b * gridDim.x + jt) * (D + 1 + Nnoise);
   for (int d = 0; d < D; ++d) {
     double t = 0.0;
 #pragma unroll
