@@ -380,7 +380,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   if (compute_var != 0 && !gp->hasL)
     return set_err(ctx, VBMC_ERR_INVALID, "compute_var != 0 needs gp.post(s).L: upload the GP with L");
   if (compute_var != 0 && TRSM_LDS_BYTES(dm.N) > 160 * 1024)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1184 not accelerated", dm.N);
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1136 not accelerated", dm.N);
   P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
   // theta must be finite (the device exp does not propagate NaN)
   for (size_t i = 0; i < (size_t)T * R; ++i)

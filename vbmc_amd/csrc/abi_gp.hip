@@ -109,8 +109,8 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   if (Nhyp != Ncov + Nnoise + Nmean)
     return set_err(ctx, VBMC_ERR_INVALID, "%s:dimmismatch Number of hyperparameters mismatched with GP model specification.",
                    fail_is_error ? "gplite_post" : "gplite_nlZ");
-  if (CHOL_LDS_BYTES(N) > 160 * 1024)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 1260 not accelerated", N);
+  if (CHOL_LDS_BYTES(N) > 160 * 1024 || TRSM_LDS_BYTES(N) > 160 * 1024)   // LDS-resident panels / right-hand-side slabs
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 1136 not accelerated", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
@@ -166,8 +166,9 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   for (int iter = 0; iter < 10 && pending; ++iter) {
     HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dact.p, active.data(), S, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_gp_build, dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D, Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
-                       dsn2.as<double>(), dscal.as<double>(), dact.as<unsigned char>(), dA.as<double>());
+    DISPATCH_GPDT(D, hipLaunchKernelGGL((k_gp_build<DT>), dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D,
+                                        Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(), dsn2.as<double>(), dscal.as<double>(),
+                                        dact.as<unsigned char>(), dA.as<double>()));
     hipLaunchKernelGGL(k_chol, dim3(S), dim3(CH_THREADS), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>());
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(pf.data(), dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -233,10 +234,7 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   if (wantL && any_inv) {
     // pL = -L\(L'\eye(N)) for low-noise samples (:98); the sign is applied where the matrix is consumed
     HIP_TRY(ctx, dXi.alloc(ctx, (size_t)S * N * N * 8));
-    if (tlds > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_spd_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-    hipLaunchKernelGGL(k_spd_inverse, dim3((N + TR_CB - 1) / TR_CB, S), dim3(64), tlds, st, N, dA.as<double>(), dfinv.as<double>(),
-                       dninv.as<unsigned char>(), dXi.as<double>());
+    SPD_INVERSE_LAUNCH(ctx, N, S, st, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dXi.as<double>());
     HIP_TRY(ctx, hipGetLastError());
   }
   if (L) {
@@ -323,10 +321,7 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
     // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240): both triangular solves of the identity in one
     // kernel that only forms the lower triangle (k_spd_inverse)
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
-    if (f.tlds > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_spd_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.tlds));
-    hipLaunchKernelGGL(k_spd_inverse, dim3((N + TR_CB - 1) / TR_CB, B), dim3(64), f.tlds, st, N, f.dA.as<double>(), f.dfinv.as<double>(),
-                       f.dones.as<unsigned char>(), dKi.as<double>());
+    SPD_INVERSE_LAUNCH(ctx, N, B, st, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dKi.as<double>());
     std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
     for (int b = 0; b < B; ++b)
       noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);
@@ -335,8 +330,9 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
     const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
     HIP_TRY(ctx, dpart.alloc(ctx, (size_t)B * ntile * P * 8));
     HIP_TRY(ctx, dg.alloc(ctx, (size_t)B * Nhyp * 8));
-    hipLaunchKernelGGL(k_nlz_grad, dim3(nt1, nt1, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(), f.dXc.as<double>(),
-                       f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dds.as<double>(), dpart.as<double>());
+    DISPATCH_GPDT(D, hipLaunchKernelGGL((k_nlz_grad<DT>), dim3(nt1, nt1, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(),
+                                        f.dXc.as<double>(), f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(),
+                                        dds.as<double>(), dpart.as<double>()));
     hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
                        f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg.as<double>());
     HIP_TRY(ctx, hipGetLastError());

@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const 
 // itself): both 64-point slabs of the scaled inputs are staged in LDS dimension-major, a lane keeps its own point in
 // registers and walks 16 columns whose coordinates are wave-uniform LDS broadcasts; exponent by the table exp.
 #define GPB_T 64
+template <int DT>   // D padded to DT with zero coordinates: the dimension loops are branch-free
 __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const double* __restrict__ hyp,
                                                   const double* __restrict__ Xc, const double* __restrict__ aa,
                                                   const double* __restrict__ sn2,      // S x N  noise variance per point
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
   const int i0 = blockIdx.x * GPB_T, j0 = blockIdx.y * GPB_T;
   if (i0 > j0) return;                               // tile entirely below the diagonal
   __shared__ double TAB[VB_EXP_TAB_N];
-  __shared__ double XI[32 * GPB_T], XJ[32 * GPB_T];  // [d][point]
+  __shared__ double XI[DT * GPB_T], XJ[DT * GPB_T];  // [d][point]
   __shared__ double AJ[GPB_T];
   const int tid = threadIdx.x, ti = tid & 63, tj = tid >> 6;
   const double* h = hyp + (size_t)s * Nhyp;
@@ -136,6 +137,7 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
   double* As = A + (size_t)s * N * N;
   TAB[tid] = c_exp2_tab[tid];
   // the rows i0 .. i0+63 of the point-major Xc are one contiguous block: coalesced reads, transposed into LDS
+  for (int e = tid; e < GPB_T * (DT - D); e += 256) { XI[D * GPB_T + e] = 0.0; XJ[D * GPB_T + e] = 0.0; }   // padded dimensions
   for (int e = tid; e < GPB_T * D; e += 256) {
     const int pnt = e / D, d = e - pnt * D;
     XI[d * GPB_T + pnt] = (i0 + pnt < N) ? xs[(size_t)i0 * D + e] : 0.0;
@@ -145,9 +147,9 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
   __syncthreads();
   const int i = i0 + ti;
   if (i >= N) return;
-  double xi[32];
+  double xi[DT];
 #pragma unroll
-  for (int d = 0; d < 32; ++d) xi[d] = (d < D) ? XI[d * GPB_T + ti] : 0.0;
+  for (int d = 0; d < DT; ++d) xi[d] = XI[d * GPB_T + ti];
   const double ai = as[i];
   const double sdiv = sn2div * mult;
   for (int t = 0; t < 16; ++t) {
@@ -155,8 +157,7 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
     if (j >= N) break;
     double dot = 0.0;
 #pragma unroll
-    for (int d = 0; d < 32; ++d)
-      if (d < D) dot = fma(xi[d], XJ[d * GPB_T + jl], dot);
+    for (int d = 0; d < DT; ++d) dot = fma(xi[d], XJ[d * GPB_T + jl], dot);
     const double c = fmax(ai + (AJ[jl] - 2.0 * dot), 0.0);
     const double k = sf2 * vb_exp_tab<0>(-0.5 * c, TAB);
     double v;
@@ -657,9 +658,9 @@ __global__ void __launch_bounds__(256) k_nlz_value(int N, int D, int Nhyp, int m
 //   part[D+1+i] = sum_j dsn2(j,i) Q_jj                          (:257-262)
 // K is rebuilt exactly as k_gp_build forms it.  Fixed-order block reduction, no atomics.
 #define NLZ_T 64
-#define NLZ_MAXP (32 + 1 + 4)
 // One workgroup per 64 x 64 tile (k along the lanes, 16 rows j per wave) of the upper triangle of tiles; off-diagonal
 // tiles count twice (Q, K and the distance matrices are symmetric), tiles below the diagonal write zeros.
+template <int DT>
 __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nnoise, const double* __restrict__ hyp,
                                                   const double* __restrict__ Xc, const double* __restrict__ aa,
                                                   const double* __restrict__ Kinv, const double* __restrict__ alpha,
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
                                                   double* __restrict__ part) {
   __shared__ double red[256];
   __shared__ double TAB[VB_EXP_TAB_N];
-  __shared__ double XK[32 * NLZ_T], XJ[32 * NLZ_T];  // [d][point]
+  __shared__ double XK[DT * NLZ_T], XJ[DT * NLZ_T];  // [d][point]
   __shared__ double AJ[NLZ_T], ALJ[NLZ_T];
   const int b = blockIdx.z, tid = threadIdx.x, tk = tid & 63, tj = tid >> 6;
   const int k0 = blockIdx.x * NLZ_T, j0 = blockIdx.y * NLZ_T;
@@ -685,6 +686,7 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
   const double* Kb = Kinv + (size_t)b * N * N;
   const double* al = alpha + (size_t)b * N;
   TAB[tid] = c_exp2_tab[tid];
+  for (int e = tid; e < NLZ_T * (DT - D); e += 256) { XK[D * NLZ_T + e] = 0.0; XJ[D * NLZ_T + e] = 0.0; }
   for (int e = tid; e < NLZ_T * D; e += 256) {
     const int pnt = e / D, d = e - pnt * D;
     XK[d * NLZ_T + pnt] = (k0 + pnt < N) ? xs[(size_t)k0 * D + e] : 0.0;
@@ -695,14 +697,14 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
     ALJ[tid] = (j0 + tid < N) ? al[j0 + tid] : 0.0;
   }
   __syncthreads();
-  double acc[NLZ_MAXP];
+  double acc[DT], accK = 0.0, accN[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int p = 0; p < NLZ_MAXP; ++p) acc[p] = 0.0;
+  for (int p = 0; p < DT; ++p) acc[p] = 0.0;
   const int k = k0 + tk;
   if (k < N) {
-    double xk[32];
+    double xk[DT];
 #pragma unroll
-    for (int d = 0; d < 32; ++d) xk[d] = (d < D) ? XK[d * NLZ_T + tk] : 0.0;
+    for (int d = 0; d < DT; ++d) xk[d] = XK[d * NLZ_T + tk];
     const double ak = as[k], alk = al[k];
     const double sym = (k0 < j0) ? 2.0 : 1.0;
     for (int t = 0; t < 16; ++t) {
@@ -710,46 +712,52 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
       if (j >= N) break;
       double dot = 0.0;
 #pragma unroll
-      for (int d = 0; d < 32; ++d)
-        if (d < D) dot = fma(xk[d], XJ[d * NLZ_T + jl], dot);
+      for (int d = 0; d < DT; ++d) dot = fma(xk[d], XJ[d * NLZ_T + jl], dot);
       const double c = fmax(AJ[jl] + (ak - 2.0 * dot), 0.0);
       const double kv = sf2 * vb_exp_tab<0>(-0.5 * c, TAB);
       const double q = Kb[(size_t)j * N + k] * isl - ALJ[jl] * alk;    // column j read along k (coalesced)
       const double qk = sym * (q * kv);
 #pragma unroll
-      for (int d = 0; d < 32; ++d) {
-        if (d < D) {
-          const double df = XJ[d * NLZ_T + jl] - xk[d];
-          acc[d] = fma(qk, df * df, acc[d]);
-        }
+      for (int d = 0; d < DT; ++d) {
+        const double df = XJ[d * NLZ_T + jl] - xk[d];
+        acc[d] = fma(qk, df * df, acc[d]);
       }
-      acc[32] += qk;
+      accK += qk;
       if (k == j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (i < Nnoise) acc[33 + i] = dsn2[((size_t)b * Nnoise + i) * N + j] * q;
+          if (i < Nnoise) accN[i] = dsn2[((size_t)b * Nnoise + i) * N + j] * q;
       }
     }
   }
-  for (int d = 0; d < D; ++d) {
-    double t = 0.0;
 #pragma unroll
-    for (int dd = 0; dd < 32; ++dd) if (dd == d) t = acc[dd];
-    t = block_sum(t, red);
-    if (tid == 0) o[d] = t;
+  for (int d = 0; d < DT; ++d) {
+    const double t = block_sum(acc[d], red);
+    if (tid == 0 && d < D) o[d] = t;
   }
   {
-    double t = block_sum(acc[32], red);
+    double t = block_sum(accK, red);
     if (tid == 0) o[D] = t;
   }
-  for (int i = 0; i < Nnoise; ++i) {
-    double t = 0.0;
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) if (ii == i) t = acc[33 + ii];
-    t = block_sum(t, red);
-    if (tid == 0) o[D + 1 + i] = t;
+  for (int i = 0; i < 4; ++i) {
+    if (i < Nnoise) {
+      const double t = block_sum(accN[i], red);
+      if (tid == 0) o[D + 1 + i] = t;
+    }
   }
 }
+
+// D -> padded DT for k_gp_build / k_nlz_grad
+#define DISPATCH_GPDT(D_, ...)                                   \
+  do {                                                           \
+    if ((D_) <= 4) { constexpr int DT = 4; __VA_ARGS__; }        \
+    else if ((D_) <= 8) { constexpr int DT = 8; __VA_ARGS__; }   \
+    else if ((D_) <= 12) { constexpr int DT = 12; __VA_ARGS__; } \
+    else if ((D_) <= 16) { constexpr int DT = 16; __VA_ARGS__; } \
+    else if ((D_) <= 24) { constexpr int DT = 24; __VA_ARGS__; } \
+    else { constexpr int DT = 32; __VA_ARGS__; }                 \
+  } while (0)
 
 // dnlZ from the tile partials (summed in tile order) + the mean-function block -dm'*alpha (:274,
 // gplite_meanfun.m:402,406,433-435).  One block per hyper-parameter vector.

@@ -49,6 +49,14 @@ __global__ void __launch_bounds__(64) k_diag_inv(int N, const double* __restrict
   }
 }
 
+// The slab and the panel buffer of a solve belong to ONE wave: ordering its LDS writes before its later reads needs a
+// wave-level fence, not a workgroup barrier -- which lets several waves of a workgroup run solves of different length.
+__device__ __forceinline__ void trsm_wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // forward substitution R' V = Z for the slab in LDS (in place)
 // bi_start > 0: the slab is known to be zero above row 16 * bi_start (columns of the identity), so is the solution:
 // the substitution starts there and the trailing updates skip the zero rows.
@@ -70,10 +78,10 @@ __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ 
     for (int c = 0; c < 16; ++c) pv[c] = (r0 + lane < b0 && b0 + c < N) ? Rm[(size_t)(b0 + c) * N + r0 + lane] : 0.0;
     for (int j0 = r0; j0 < b0; j0 += 64) {
       const int nrow = min(64, b0 - j0);
-      __syncthreads();
+      trsm_wsync();
 #pragma unroll
       for (int c = 0; c < 16; ++c) P[lane * TR_VS + c] = pv[c];
-      __syncthreads();
+      trsm_wsync();
       // prefetch the next chunk of the panel while this one feeds the matrix core
       const int jn = j0 + 64;
 #pragma unroll
@@ -96,15 +104,15 @@ __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ 
     // v_b = (R_bb')^{-1} (z_b - update): rhs through LDS into the B-operand layout, four MFMAs with Finv
 #pragma unroll
     for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] -= acc[r];
-    __syncthreads();
+    trsm_wsync();
     tmf4 vb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], V[(b0 + 4 * u + lg) * TR_VS + li], vb, 0, 0, 0);
-    __syncthreads();
+    trsm_wsync();
 #pragma unroll
     for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = vb[r];
-    __syncthreads();
+    trsm_wsync();
   }
 }
 
@@ -141,15 +149,15 @@ __device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ 
     // x_b = R_bb^{-1} (v_b - update) = Finv_b' * rhs
 #pragma unroll
     for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] -= acc[r];
-    __syncthreads();
+    trsm_wsync();
     tmf4 xb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       xb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], V[(b0 + 4 * u + lg) * TR_VS + li], xb, 0, 0, 0);
-    __syncthreads();
+    trsm_wsync();
 #pragma unroll
     for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = xb[r];
-    __syncthreads();
+    trsm_wsync();
   }
 }
 
@@ -208,18 +216,26 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
 // flops of two full-width solves on the identity, and no intermediate matrix in global memory.  Used for
 // Kinv in the GP marginal-likelihood gradient (gplite_core.m:146-147) and for the stored -inv(K + sn2 I) of
 // low-noise posteriors (gplite_core.m:84).
-__global__ void __launch_bounds__(64) k_spd_inverse(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+// Two waves per workgroup take the column blocks cb and nblk-1-cb: a long and a short solve, so that every workgroup does
+// the same work and the two slabs (rows from the block's own first row down) together need Np + 16 rows of LDS.
+#define SPDINV_LDS_BYTES(N) ((size_t)((((((N) + 15) >> 4) << 4) + 16) * TR_VS + 2 * 64 * TR_VS) * sizeof(double))
+__global__ void __launch_bounds__(128) k_spd_inverse(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                     const unsigned char* __restrict__ on, double* __restrict__ Xo) {
   extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  const int s = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (!on[s]) return;
-  const int Np = ((N + 15) >> 4) << 4;
-  double* V = lds;
-  double* P = V + (size_t)Np * TR_VS;
+  const int nblk = (N + 15) >> 4, Np = nblk << 4;
+  const bool paired = blockDim.x == 128;              // 64 threads: one column block per workgroup (N too large to pair)
+  const int cb = wv == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+  if (wv == 1 && cb == (int)blockIdx.x) return;       // odd block count: the middle block is done by wave 0
   const int k0 = cb << 4;
+  // wave 0's slab holds rows k0 .. Np-1 at the start of the buffer, wave 1's (shorter) slab follows it
+  double* Vbase = wv == 0 ? lds : lds + (size_t)(Np - ((int)blockIdx.x << 4)) * TR_VS;
+  double* V = Vbase - (size_t)k0 * TR_VS;              // indexed by absolute row; rows < k0 are never touched
+  double* P = lds + (size_t)(paired ? Np + 16 : Np) * TR_VS + (size_t)wv * 64 * TR_VS;
   for (int c = 0; c < 16; ++c)
-    for (int i = lane; i < Np; i += 64) V[i * TR_VS + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
-  __syncthreads();
+    for (int i = k0 + lane; i < Np; i += 64) V[i * TR_VS + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
+  trsm_wsync();
   const double* Rm = Lall + (size_t)s * N * N;
   const double* Fi = Finv + (size_t)s * TRSM_NBLK(N) * 256;
   trsm_fwd_wave(N, Rm, Fi, V, P, lane, cb);
@@ -236,3 +252,14 @@ __global__ void __launch_bounds__(64) k_spd_inverse(int N, const double* __restr
   if (k0 + cc < N)
     for (int i = k0 + 16 + (lane >> 4); i < N; i += 4) X[(size_t)(k0 + cc) + (size_t)i * N] = V[i * TR_VS + cc];
 }
+
+// host side: pick the paired launch when its LDS fits, else one column block per workgroup
+#define SPD_INVERSE_LAUNCH(ctx_, N_, S_, st_, Lall_, Finv_, on_, Xo_)                                                         \
+  do {                                                                                                                        \
+    const bool pair_ = SPDINV_LDS_BYTES(N_) <= 160 * 1024;                                                                    \
+    const size_t il_ = pair_ ? SPDINV_LDS_BYTES(N_) : TRSM_LDS_BYTES(N_);                                                     \
+    if (il_ > 64 * 1024)                                                                                                      \
+      HIP_TRY(ctx_, hipFuncSetAttribute((const void*)k_spd_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)il_));   \
+    hipLaunchKernelGGL(k_spd_inverse, dim3(pair_ ? (TRSM_NBLK(N_) + 1) / 2 : TRSM_NBLK(N_), S_), dim3(pair_ ? 128 : 64), il_, st_, \
+                       N_, Lall_, Finv_, on_, Xo_);                                                                           \
+  } while (0)
