@@ -77,6 +77,21 @@ def test_nlz_batch_matches_oracle(va, cfg):
     assert f1 == nlZ[2] and np.array_equal(g1, dnlZ[:, 2])
 
 
+@pytest.mark.parametrize("N,D", [(16, 2), (17, 3), (48, 13), (81, 20), (1080, 6)])
+def test_nlz_inverse_kernel_shapes(va, N, D):
+    """Kinv = L\\(L'\\eye(N)) (gplite_core.m:240) is formed by k_spd_inverse from paired column blocks: one block (N <= 16),
+    an odd block count (the middle block has no partner), D padded to the next kernel instantiation (13 -> 16, 20 -> 24),
+    and N = 1080, where the paired slabs no longer fit the LDS and one column block per workgroup is used."""
+    rng = np.random.default_rng(N)
+    gp, draw = make_gp(rng, N, D, 4, (1, 0, 0))
+    H = np.stack([draw() for _ in range(2)], axis=1)
+    nlZ, dnlZ = va.gplite_nlZ(H, gp)
+    for b in range(2):
+        f, g = R.gplite_nlZ(H[:, b], gp)
+        assert abs(nlZ[b] - f) < 1e-10 * max(1.0, abs(f))
+        assert relerr(dnlZ[:, b], g) < 1e-8
+
+
 def test_nlz_low_noise_branch_and_retries(va):
     """min(sn2) < 1e-6 takes the Lchol = false branch (gplite_core.m:84-99); duplicated inputs with tiny
     noise force the x10 noise-inflation retries (:91-94), and sn2_mult enters the noise gradient (:257-262)."""
