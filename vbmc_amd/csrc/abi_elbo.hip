@@ -61,6 +61,9 @@ extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     if (b.p) (void)hipFree(b.p);
   for (vbmc_gp* g : ctx->null_gp) vbmc_gp_free(ctx, g);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+  for (auto& e : ctx->bounce_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }

@@ -239,9 +239,15 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   }
   if (L) {
     // the caller's copy of gp.post(s).L (D2H only when asked for)
-    for (int s = 0; s < S; ++s) {
-      const double* src = (lch[s] || !any_inv) ? dA.as<double>() + (size_t)s * N * N : dXi.as<double>() + (size_t)s * N * N;
-      HIP_TRY(ctx, hipMemcpyAsync(L + (size_t)s * N * N, src, (size_t)N * N * 8, hipMemcpyDeviceToHost, st));
+    if (!any_inv) {   // every sample on the Cholesky branch: one contiguous block
+      vbmc_status s_ = d2h_bounced(ctx, L, dA.as<double>(), (size_t)S * N * N * 8);
+      if (s_) return s_;
+    } else {
+      for (int s = 0; s < S; ++s) {
+        const double* src = lch[s] ? dA.as<double>() + (size_t)s * N * N : dXi.as<double>() + (size_t)s * N * N;
+        vbmc_status s_ = d2h_bounced(ctx, L + (size_t)s * N * N, src, (size_t)N * N * 8);
+        if (s_) return s_;
+      }
     }
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));

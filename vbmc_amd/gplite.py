@@ -72,9 +72,9 @@ def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engin
         noisefun = (1, 0, 0) if s2 is None else (1, 1, 0)  # :104-106
     noisefun = tuple(int(v) for v in noisefun) + (0,) * (3 - len(noisefun))
     s2a = None if s2 is None else f64(np.asarray(s2, dtype=np.float64).reshape(-1))
-    alpha = np.zeros((N, S), order="F")
-    L = np.zeros((N, N, S), order="F")
-    sW = np.zeros((N, S), order="F")
+    alpha = np.empty((N, S), order="F")      # all three are overwritten in full by the library
+    L = np.empty((N, N, S), order="F")
+    sW = np.empty((N, S), order="F")
     mult = np.zeros(S)
     lch = np.zeros(S, dtype=np.uint8)
     nf = (C.c_int32 * 3)(*noisefun)
