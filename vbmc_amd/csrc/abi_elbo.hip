@@ -542,6 +542,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
       // kernel has the lower latency
       const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
+      // VALU kernel: four waves per cell (training set split, lower latency) while the grid is small, one wave per cell (no
+      // replicated per-wave setup) once there are enough cells to fill the chip several times over
+      const bool lj_split = dm.N > 64 && (long long)((K + 3) / 4) * S * R < 8LL * ctx->num_cu;
       const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
       DISPATCH_DT(dt, {
         constexpr int NCT = (2 * DT + 1 + 15) / 16;
@@ -551,7 +554,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
           hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, ls, dm, P.d_vpd,
                              gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
         } else {
-          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(dm.N > 64 ? WAVE * LJ_MAXW : WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
+          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(lj_split ? WAVE * LJ_MAXW : WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
                              P.d_delta2, P.d_lj, P.compute_grad);
         }
       });
