@@ -170,15 +170,43 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
 // ------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, upper factor R (R'R = A) in place, strict lower part zeroed.
 // pfail[s] = 0 on success, j+1 when the j-th pivot is not positive (MATLAB's [R,p] = chol(A)).
-// One 1024-thread workgroup (16 waves) per matrix; per 16-column block step:
-//   wave 0     factors the 16 x 16 diagonal tile in LDS (wave-synchronous, no workgroup barriers),
-//   all lanes  solve the 16 x ntr panel row (one column per lane) and stage it in LDS,
-//   16 waves   apply the rank-16 trailing update A22 -= P'P tile by tile on the fp64 matrix cores
-//              (4 x v_mfma_f64_16x16x4 per 16 x 16 tile, upper triangle of tiles only).
+// (structure: see k_chol below)
 // ------------------------------------------------------------------------------------------
 #define CH_NB 16
 #define CH_THREADS 1024
-#define CHOL_LDS_BYTES(N) ((size_t)(16 * 17 + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
+#define CHOL_LDS_BYTES(N) ((size_t)(2 * 16 * 17 + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
+
+// Upper Cholesky of the 16 x 16 tile held in LDS (Dg, row stride 17; identity beyond nb) by ONE wave: wave-synchronous,
+// no workgroup barriers (the LDS operations of a wave complete in order).  Di[t] = 1 / R[t][t].  A non-positive or
+// non-finite pivot records kb + t + 1 in *s_fail (first failure wins) and is replaced by 1 so that the sweep completes.
+__device__ __forceinline__ void chol_diag_tile(double* __restrict__ Dg, double* __restrict__ Di, int nb, int kb, int lane,
+                                               int* s_fail) {
+  for (int t = 0; t < nb; ++t) {
+    double piv = Dg[t * 17 + t];
+    if (!(piv > 0.0) || !isfinite(piv)) {
+      if (lane == 0 && *s_fail == 0) *s_fail = kb + t + 1;
+      piv = 1.0;
+    }
+    const double rs = sqrt(piv);
+    const double ri = 1.0 / rs;                    // row scaled by the reciprocal, as LAPACK's dpotf2 does
+    __builtin_amdgcn_wave_barrier();
+    if (lane == t) { Dg[t * 17 + t] = rs; Di[t] = ri; }
+    else if (lane > t && lane < nb) Dg[t * 17 + lane] *= ri;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < 256; e += 64) {
+      const int ii = e >> 4, jj = e & 15;
+      if (ii > t && jj >= ii && jj < nb) Dg[ii * 17 + jj] -= Dg[t * 17 + ii] * Dg[t * 17 + jj];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// One 1024-thread workgroup (16 waves) per matrix; per 16-column block step:
+//   all lanes     solve the 16 x ntr panel row with the already factored diagonal tile and stage it in LDS,
+//   waves 1..15   apply the rank-16 trailing update A22 -= P'P tile by tile on the fp64 matrix cores
+//                 (4 x v_mfma_f64_16x16x4 per 16 x 16 tile, upper triangle of tiles only),
+//   wave 0        LOOK-AHEAD: updates the next diagonal tile first and factors it (in LDS, wave-synchronous) while the
+//                 other waves are still updating -- the 16 sequential pivot steps leave the critical path.
 __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__ Aall, int* __restrict__ pfail,
                                                      const unsigned char* __restrict__ active) {
   extern __shared__ double lds[];
@@ -188,48 +216,36 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
   const int li = lane & 15, lg = lane >> 4;
   const int Np = ((N + 15) >> 4) << 4;
   double* A = Aall + (size_t)s * N * N;
-  double* Dg = lds;                 // 16 x 17
-  double* P = Dg + 16 * 17;         // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
+  double* DgB = lds;                // two 16 x 17 diagonal tiles: this step's and the next one's
+  double* P = DgB + 2 * 16 * 17;    // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
   __shared__ int s_fail;
-  __shared__ double Di[16];         // 1 / R[kb+t][kb+t]
+  __shared__ double DiB[2][16];     // 1 / R[kb+t][kb+t]
   if (tid == 0) s_fail = 0;
   __syncthreads();
-  for (int kb = 0; kb < N; kb += CH_NB) {
-    const int nb = min(CH_NB, N - kb);
-    if (wave == 0) {
-      // ---- diagonal tile: upper Cholesky in LDS by one wave (LDS operations of a wave complete in order)
-      for (int e = lane; e < 256; e += 64) {
-        const int ii = e >> 4, jj = e & 15;
-        Dg[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] : (ii == jj ? 1.0 : 0.0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (int t = 0; t < nb; ++t) {
-        double piv = Dg[t * 17 + t];
-        if (!(piv > 0.0) || !isfinite(piv)) {
-          if (lane == 0 && s_fail == 0) s_fail = kb + t + 1;
-          piv = 1.0;
-        }
-        const double rs = sqrt(piv);
-        const double ri = 1.0 / rs;                    // row scaled by the reciprocal, as LAPACK's dpotf2 does
-        __builtin_amdgcn_wave_barrier();
-        if (lane == t) { Dg[t * 17 + t] = rs; Di[t] = ri; }
-        else if (lane > t && lane < nb) Dg[t * 17 + lane] *= ri;
-        __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < 256; e += 64) {
-          const int ii = e >> 4, jj = e & 15;
-          if (ii > t && jj >= ii && jj < nb) Dg[ii * 17 + jj] -= Dg[t * 17 + ii] * Dg[t * 17 + jj];
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      for (int e = lane; e < 256; e += 64) {
-        const int ii = e >> 4, jj = e & 15;
-        if (ii < nb && jj < nb) A[(size_t)(kb + ii) + (size_t)N * (kb + jj)] = (ii <= jj) ? Dg[ii * 17 + jj] : 0.0;
-      }
+  if (wave == 0) {
+    // ---- first diagonal tile
+    const int nb = min(CH_NB, N);
+    for (int e = lane; e < 256; e += 64) {
+      const int ii = e >> 4, jj = e & 15;
+      DgB[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)ii + (size_t)N * jj] : (ii == jj ? 1.0 : 0.0);
     }
-    __syncthreads();
-    if (s_fail) break;            // uniform: read after the barrier
+    __builtin_amdgcn_wave_barrier();
+    chol_diag_tile(DgB, DiB[0], nb, 0, lane, &s_fail);
+    for (int e = lane; e < 256; e += 64) {
+      const int ii = e >> 4, jj = e & 15;
+      if (ii < nb && jj < nb) A[(size_t)ii + (size_t)N * jj] = (ii <= jj) ? DgB[ii * 17 + jj] : 0.0;
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kb = 0; kb < N; kb += CH_NB, cur ^= 1) {
+    if (s_fail) break;            // uniform: written before the last barrier
+    const int nb = min(CH_NB, N - kb);
+    const double* Dg = DgB + cur * 16 * 17;
+    const double* Di = DiB[cur];
     const int t0 = kb + nb;       // first trailing column
     const int ntr = N - t0;
+    if (ntr <= 0) break;
     const int ntrp = ((ntr + 15) >> 4) << 4;
     // ---- panel: R[kb..kb+nb, j] = Rkk'^{-1} A[kb..kb+nb, j], one column per lane; rows >= nb and columns >= ntr are zero
     for (int j = tid; j < ntrp; j += CH_THREADS) {
@@ -260,8 +276,8 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
     __syncthreads();
     // ---- trailing update, transposed tiles so that lanes run along i (contiguous in the column-major matrix):
     //      C'[j][i] = sum_t P[t][j0+j] P[t][i0+i];  A[t0+i0+i][t0+j0+j] -= C'[j][i]  for i <= j.
-    // The upper-triangular tile pairs are enumerated directly (balanced over the 16 waves); the global loads of
-    // a wave's next tile are issued before the MFMAs of the current one.
+    // The upper-triangular tile pairs are enumerated directly; pair 0 = the next diagonal tile belongs to wave 0, the
+    // others are dealt to waves 1..15, whose next tile is loaded before the MFMAs of the current one.
     const int nt = ntrp >> 4;
     const int npair = nt * (nt + 1) / 2;
     auto decode = [](int u, int& ti, int& tj) {
@@ -270,8 +286,6 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
       while (c * (c + 1) / 2 > u) --c;
       tj = c; ti = u - c * (c + 1) / 2;
     };
-    double cur[4], nxt[4];
-    int u = wave, ti = 0, tj = 0;
     auto load_tile = [&](int ti_, int tj_, double* dst) {
       const int i = (ti_ << 4) + li;
 #pragma unroll
@@ -280,38 +294,63 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
         dst[reg] = (i < ntr && j < ntr && i <= j) ? A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] : 0.0;
       }
     };
-    if (u < npair) { decode(u, ti, tj); load_tile(ti, tj, cur); }
-    while (u < npair) {
-      const int un = u + CH_THREADS / 64;
-      int tin = 0, tjn = 0;
-      if (un < npair) { decode(un, tin, tjn); load_tile(tin, tjn, nxt); }
-      const int i0 = ti << 4, j0 = tj << 4;
+    if (wave == 0) {
+      // next diagonal tile: update, factor in LDS, write the factor
+      const int nb2 = min(CH_NB, ntr);
+      double* Dn = DgB + (cur ^ 1) * 16 * 17;
+      double c0[4];
+      load_tile(0, 0, c0);
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double pa = P[(size_t)(4 * q + lg) * Np + j0 + li];
-        const double pb = P[(size_t)(4 * q + lg) * Np + i0 + li];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+        const double pa = P[(size_t)(4 * q + lg) * Np + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pa, acc, 0, 0, 0);
       }
-      const int i = i0 + li;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int j = j0 + lg + 4 * reg;
-        if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] = cur[reg] - acc[reg];
+        const int ii = li, jj = lg + 4 * reg;      // element (row ii, column jj) of the tile
+        Dn[ii * 17 + jj] = (ii < nb2 && jj < nb2 && ii <= jj) ? c0[reg] - acc[reg] : (ii == jj ? 1.0 : 0.0);
       }
+      __builtin_amdgcn_wave_barrier();
+      chol_diag_tile(Dn, DiB[cur ^ 1], nb2, t0, lane, &s_fail);
+      for (int e = lane; e < 256; e += 64) {
+        const int ii = e >> 4, jj = e & 15;
+        if (ii < nb2 && jj < nb2) A[(size_t)(t0 + ii) + (size_t)N * (t0 + jj)] = (ii <= jj) ? Dn[ii * 17 + jj] : 0.0;
+      }
+    } else {
+      double curv[4], nxt[4];
+      int u = wave, ti = 0, tj = 0;           // pairs 1, 2, ... over waves 1..15
+      if (u < npair) { decode(u, ti, tj); load_tile(ti, tj, curv); }
+      while (u < npair) {
+        const int un = u + (CH_THREADS / 64 - 1);
+        int tin = 0, tjn = 0;
+        if (un < npair) { decode(un, tin, tjn); load_tile(tin, tjn, nxt); }
+        const int i0 = ti << 4, j0 = tj << 4;
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) cur[reg] = nxt[reg];
-      u = un; ti = tin; tj = tjn;
+        for (int q = 0; q < 4; ++q) {
+          const double pa = P[(size_t)(4 * q + lg) * Np + j0 + li];
+          const double pb = P[(size_t)(4 * q + lg) * Np + i0 + li];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+        }
+        const int i = i0 + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int j = j0 + lg + 4 * reg;
+          if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] = curv[reg] - acc[reg];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) curv[reg] = nxt[reg];
+        u = un; ti = tin; tj = tjn;
+      }
     }
     __syncthreads();
   }
   if (tid == 0) pfail[s] = s_fail;
   if (s_fail) return;
   // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
-  for (size_t idx = tid; idx < (size_t)N * N; idx += CH_THREADS) {
-    int i = (int)(idx % N), j = (int)(idx / N);
-    if (i > j) A[idx] = 0.0;
-  }
+  for (int j = tid >> 6; j < N; j += CH_THREADS >> 6)
+    for (int i = j + 1 + lane; i < N; i += 64) A[(size_t)i + (size_t)N * j] = 0.0;
 }
 
 // r = y - m(X)  per sample
