@@ -91,12 +91,16 @@ __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const 
   const double* h = hyp + (size_t)s * Nhyp;
   __shared__ double mean[32];
   const int tid = threadIdx.x;
-  if (tid < D) {
-    // mean over n of X(n,d)/ell_d in MATLAB's order: mean(a,2)
-    double ell = exp(h[tid]);
+  {
+    // mean over n of X(n,d)/ell_d  (mean(a,2), sq_dist.m:36): 8 lanes per dimension, fixed-order butterfly
+    const int d = tid >> 3, sub = tid & 7;     // 256 threads = 32 dimensions x 8 lanes
     double acc = 0.0;
-    for (int n = 0; n < N; ++n) acc += X[n + (size_t)N * tid] / ell;
-    mean[tid] = acc / N;
+    if (d < D) {
+      const double ell = exp(h[d]);
+      for (int n = sub; n < N; n += 8) acc += X[n + (size_t)N * d] / ell;
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    if (d < D && sub == 0) mean[d] = acc / N;
   }
   __syncthreads();
   for (int n = blockIdx.x * blockDim.x + tid; n < N; n += gridDim.x * blockDim.x) {
