@@ -4,14 +4,36 @@ function gp = gplite_post(hyp,X,y,covfun,meanfun,noisefun,s2,update1,outwarpfun)
 %
 % Same signature and defaulting as the reference (gplite/gplite_post.m:1-29).  Accelerated: the
 % from-scratch form GPLITE_POST(HYP,X,Y,COVFUN,MEANFUN,NOISEFUN,S2) with SE-ARD covariance, mean
-% function 0/1/4, no integrated mean, no output warping.  The struct-input forms (re-computation,
-% rank-one update) and everything else are forwarded to the reference further down the path.
+% function 0/1/4, no integrated mean, no output warping; and the rank-one append
+% GPLITE_POST(GP,XSTAR,YSTAR,[],[],[],[],1) of one noiseless-input observation (:173-251), which runs on the
+% device and leaves the enlarged surrogate there.  The re-computation form and everything else are
+% forwarded to the reference further down the path.
 if nargin < 4; covfun = []; end
 if nargin < 5; meanfun = []; end
 if nargin < 6; noisefun = []; end
 if nargin < 7; s2 = []; end
 if nargin < 8 || isempty(update1); update1 = false; end
 if nargin < 9; outwarpfun = []; end
+
+if isstruct(hyp) && update1 && isempty(s2) && isempty(outwarpfun) && size(X,1) == 1 && rank1_supported(hyp)
+    gp = hyp; xstar = X; ystar = y;
+    [mstar,vstar] = gplite_pred(gp,xstar,ystar,[],1,1);            % :189 (through the shim)
+    Ns = numel(gp.post); sn2_eff = zeros(Ns,1);
+    for s = 1:Ns
+        hn = gp.post(s).hyp(gp.Ncov+1:gp.Ncov+gp.Nnoise);
+        sn2_eff(s) = gplite_noisefun(hn,xstar,gp.noisefun,ystar,[])*gp.post(s).sn2_mult;   % :205-207
+    end
+    Xn = [gp.X; xstar];
+    [alpha,L,hnew] = vbmc_hip_mex('gp_rank1',vbmc_hip_gp_handle(gp),Xn,ystar,mstar(:),vstar(:),sn2_eff);
+    for s = 1:Ns
+        gp.post(s).alpha = alpha(:,s);
+        gp.post(s).L = L(:,:,s);
+        gp.post(s).sW = [gp.post(s).sW; 1/sqrt(sn2_eff(s))];     % :239
+    end
+    gp.X = Xn; gp.y = [gp.y; ystar];
+    vbmc_hip_gp_handle(gp,hnew);                                   % the enlarged surrogate is already on the device
+    return;
+end
 
 if isempty(covfun); cf = 1; else; cf = covfun; end
 if isempty(meanfun); mf = 1; else; mf = meanfun; end
@@ -45,4 +67,11 @@ for s = 1:Ns
     gp.post(s).sn2_mult = mult(s);
     gp.post(s).Lchol = logical(lch(s));
 end
+end
+
+function ok = rank1_supported(gp)
+% the configurations the device append covers; the reference itself takes the full update for the others (:76-90)
+ok = gp.covfun(1) == 1 && isnumeric(gp.meanfun) && any(gp.meanfun(1) == [0 1 4]) && isempty(gp.s2) ...
+    && ~(isfield(gp,'intmeanfun') && ~isempty(gp.intmeanfun) && gp.intmeanfun > 0) ...
+    && ~(isfield(gp,'outwarpfun') && ~isempty(gp.outwarpfun));
 end

@@ -137,6 +137,42 @@ def test_rank1_update_equals_full_posterior(va):
     assert relerr(o[2], r[2]) < 1e-6
 
 
+def test_rank1_chain_on_device_and_low_noise_branch(va):
+    """Three appends in a row with the factors kept on the device only (need_L=False), then a prediction from the device
+    copy, against the oracle's chained rank-1 updates; and one append on the low-noise branch, where gp.post(s).L is
+    -inv(K + sn2 I) and the update is the bordered-inverse formula (gplite_post.m:234-236)."""
+    p = synth_problem(31, 3, 40, 3, 2)
+    n0 = 37
+    gp = va.gplite_post(p["hyp"], p["X"][:n0], p["y"][:n0], 1, 4)
+    ref = R.gplite_post(p["hyp"], p["X"][:n0], p["y"][:n0], meanfun=4)
+    for i in range(n0, 40):
+        gp = va.gplite_post_rank1(gp, p["X"][i], p["y"][i], need_L=False)
+        ref = R.gplite_post_rank1(ref, p["X"][i], p["y"][i])
+        assert gp["post"][0]["L"] is None and gp["X"].shape == (i + 1, 3)
+        for a, c in zip(gp["post"], ref["post"]):
+            assert relerr(a["alpha"], c["alpha"]) < 1e-7 and relerr(a["sW"], c["sW"]) < 1e-12
+    Xq = p["X"][:7] + 0.2
+    o = va.gplite_pred(gp, Xq, None, None, True)
+    r = R.gplite_pred(ref, Xq, ssflag=True)
+    assert relerr(o[2], r[2]) < 1e-7 and relerr(o[3], r[3]) < 1e-6
+    # the last append with L read back equals the oracle's matrix
+    gpL = va.gplite_post_rank1(va.gplite_post(p["hyp"], p["X"][:39], p["y"][:39], 1, 4), p["X"][39], p["y"][39])
+    refL = R.gplite_post_rank1(R.gplite_post(p["hyp"], p["X"][:39], p["y"][:39], meanfun=4), p["X"][39], p["y"][39])
+    for a, c in zip(gpL["post"], refL["post"]):
+        assert relerr(a["L"], c["L"]) < 1e-8
+    # low-noise branch
+    hyp = p["hyp"].copy()
+    hyp[4, :] = np.log(3e-4)          # sn2 = 9e-8 < 1e-6 -> Lchol = false (gplite_core.m:67)
+    g0 = va.gplite_post(hyp, p["X"][:39], p["y"][:39], 1, 4)
+    r0 = R.gplite_post(hyp, p["X"][:39], p["y"][:39], meanfun=4)
+    assert not g0["post"][0]["Lchol"]
+    g1 = va.gplite_post_rank1(g0, p["X"][39], p["y"][39])
+    r1 = R.gplite_post_rank1(r0, p["X"][39], p["y"][39])
+    for a, c in zip(g1["post"], r1["post"]):
+        scale = np.max(np.abs(c["L"]))
+        assert np.max(np.abs(a["L"] - c["L"])) < 1e-6 * scale and relerr(a["alpha"], c["alpha"]) < 1e-5
+
+
 def test_pred_and_acq_chunking_over_many_points(va):
     """Sweeps whose S x N x Nstar cross-kernel matrix would exceed 1 GiB are cut into chunks of test points; the
     chunked result equals the one-shot result up to the sq_dist centring constant (rounding)."""

@@ -96,6 +96,7 @@ def load():
                                  _dp, _dp, _dp, _dp, u8p, C.POINTER(vp)]
     lib.vbmc_gp_pred.argtypes = [vp, vp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
     lib.vbmc_gp_rank1_solves.argtypes = [vp, vp, _dp, _dp, _dp, _dp]
+    lib.vbmc_gp_rank1_update.argtypes = [vp, vp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, C.POINTER(vp)]
     lib.vbmc_acq_eval.argtypes = [vp, vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
                                   _dp, _dp, _dp, _dp, _dp, _dp]
     lib.vbmc_acq_is_create.argtypes = [vp, vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.POINTER(vp)]

@@ -795,17 +795,16 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
 //   Ks = k(X, x*);  Lchol: v = L' \ Ks, x = L \ v  (alpha_update = x / sn2_eff, new column = v / sn2_eff)
 //                   else : x = L * Ks               (alpha_update = -x)
 // The O(N) assembly of the new alpha / L / sW stays with the caller (vbmc_amd/gplite.py, the MEX shim).
-extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, double* Ks,
-                                            double* v, double* x) {
-  if (!ctx) return VBMC_ERR_INVALID;
-  if (!gp || !xstar || !Ks || !v || !x) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves: null argument");
-  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves needs gp.post(s).L on the device");
+namespace {
+// Ks = k(X, xstar), v = L' \ Ks, x = L \ v per hyper-sample on the device (gplite_post.m:226-237); for the samples that store
+// -inv(K + sn2 I) instead of a factor, x = L Ks (k_symm) and v is unused.
+vbmc_status rank1_solves_dev(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, TmpBuf& dKs, TmpBuf& dV, TmpBuf& dXo) {
   const int N = gp->N, D = gp->D, S = gp->S;
   const size_t tlds = TRSM_LDS_BYTES(N);
   if (tlds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  TmpBuf dxs, dKs, dV, dXo;
+  TmpBuf dxs;
   HIP_TRY(ctx, dxs.alloc(ctx, (size_t)D * 8));
   HIP_TRY(ctx, dKs.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, dV.alloc(ctx, (size_t)S * N * 8));
@@ -822,9 +821,73 @@ extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, co
   hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, gp->L, gp->d_finv, gp->d_lchol, dV.as<double>());
   hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, gp->L, gp->d_finv, gp->d_lchol, dV.as<double>(), dXo.as<double>());
   HIP_TRY(ctx, hipGetLastError());
+  return VBMC_OK;
+}
+}  // namespace
+
+extern "C" vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, double* Ks,
+                                            double* v, double* x) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp || !xstar || !Ks || !v || !x) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves: null argument");
+  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_solves needs gp.post(s).L on the device");
+  const int N = gp->N, S = gp->S;
+  TmpBuf dKs, dV, dXo;
+  { vbmc_status s_ = rank1_solves_dev(ctx, gp, xstar, dKs, dV, dXo); if (s_) return s_; }
+  hipStream_t st = ctx->stream;
   HIP_TRY(ctx, hipMemcpyAsync(Ks, dKs.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(v, dV.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(x, dXo.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, const double* X_new, double ystar, const double* mstar,
+                                            const double* vstar, const double* sn2_eff, double* alpha_new, double* L_new,
+                                            vbmc_gp** out) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp || !X_new || !mstar || !vstar || !sn2_eff || !out)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_update: null argument");
+  *out = nullptr;
+  if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_update needs gp.post(s).L on the device");
+  const int N = gp->N, D = gp->D, S = gp->S, N1 = N + 1;
+  if (TRSM_LDS_BYTES(N1) > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N1);
+  std::vector<double> xs(D);
+  for (int d = 0; d < D; ++d) xs[d] = X_new[(size_t)N + (size_t)N1 * d];   // the appended row of the (N+1) x D matrix
+  TmpBuf dKs, dV, dXo, dsc, dLn, dan;
+  { vbmc_status s_ = rank1_solves_dev(ctx, gp, xs.data(), dKs, dV, dXo); if (s_) return s_; }
+  hipStream_t st = ctx->stream;
+  // per-sample scalars: sn2_eff (:207), Kss = sf2 (:213), (mstar - ystar)/vstar (:245), vstar
+  std::vector<double> sc((size_t)S * 4);
+  for (int s = 0; s < S; ++s) {
+    sc[s * 4 + 0] = sn2_eff[s];
+    sc[s * 4 + 1] = std::exp(2.0 * gp->hyp_host[(size_t)s * gp->Nhyp + D]);
+    sc[s * 4 + 2] = (mstar[s] - ystar) / vstar[s];
+    sc[s * 4 + 3] = vstar[s];
+  }
+  HIP_TRY(ctx, dsc.alloc(ctx, sc.size() * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(dsc.p, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, dLn.alloc(ctx, (size_t)S * N1 * N1 * 8));
+  HIP_TRY(ctx, dan.alloc(ctx, (size_t)S * N1 * 8));
+  hipLaunchKernelGGL(k_rank1_assemble, dim3(N1, S), dim3(256), 0, st, N, gp->L, gp->alpha, gp->d_lchol, dV.as<double>(), dXo.as<double>(),
+                     dsc.as<double>(), dLn.as<double>(), dan.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<double> ah((size_t)S * N1), sW1(S);
+  HIP_TRY(ctx, hipMemcpyAsync(ah.data(), dan.p, ah.size() * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (int s = 0; s < S; ++s) sW1[s] = 1.0 / std::sqrt(gp->sn2_eff[s]);   // post.sW(1) is unchanged by the append (:239)
+  vbmc_gp* ng = nullptr;
+  vbmc_status st2 = gp_upload_impl(ctx, N1, D, S, gp->Nhyp, gp->Ncov, gp->Nnoise, gp->meanfun, X_new, gp->hyp_host.data(), ah.data(), nullptr,
+                                   dLn.as<double>(), nullptr, sW1.data(), gp->Lchol.data(), &ng);
+  if (st2 != VBMC_OK) return st2;
+  if (gp->has_noise) {
+    for (int i = 0; i < 3; ++i) ng->noisefun[i] = gp->noisefun[i];
+    hipError_t e = hipMalloc((void**)&ng->d_mult, (size_t)S * 8);
+    if (e == hipSuccess) e = hipMemcpy(ng->d_mult, gp->d_mult, (size_t)S * 8, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { vbmc_gp_free(ctx, ng); return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_rank1_update: %s", hipGetErrorString(e)); }
+    ng->has_noise = true;
+  }
+  if (alpha_new) memcpy(alpha_new, ah.data(), ah.size() * 8);
+  if (L_new) { vbmc_status s_ = d2h_bounced(ctx, L_new, ng->L, (size_t)S * N1 * N1 * 8); if (s_) { vbmc_gp_free(ctx, ng); return s_; } }
+  *out = ng;
   return VBMC_OK;
 }

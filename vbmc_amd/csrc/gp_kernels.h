@@ -413,6 +413,44 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
   for (int i = tid; i < N; i += ASOLVE_THREADS) Xo[(size_t)s * N + i] = v[i];
 }
 
+// Rank-one append of one observation (gplite/gplite_post.m:226-245): column j of the new (N+1) x (N+1) matrix per workgroup.
+//   factor samples:   Lnew = [L, v/sn2_eff; 0, sqrt(1 + Kss/sn2_eff - |v/sn2_eff|^2)]            (:228-232)
+//   inverse samples:  Lnew = [L + vv*au', -vv; -vv', -1/vstar],  au = -x, vv = -au/vstar          (:234-236)
+//   alpha_new = [alpha; 0] + (mstar - ystar)/vstar * [au; -1],   au = x/sn2_eff (factor) or -x     (:227,234,245)
+// sc[s] = {sn2_eff, Kss, (mstar - ystar)/vstar, vstar}.
+__global__ void __launch_bounds__(256) k_rank1_assemble(int N, const double* __restrict__ Lall, const double* __restrict__ alpha,
+                                                        const unsigned char* __restrict__ lchol, const double* __restrict__ V,
+                                                        const double* __restrict__ Xs, const double* __restrict__ sc,
+                                                        double* __restrict__ Lnew, double* __restrict__ anew) {
+  __shared__ double red[256];
+  const int j = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, N1 = N + 1;
+  const double sn2 = sc[s * 4 + 0], Kss = sc[s * 4 + 1], coef = sc[s * 4 + 2], vstar = sc[s * 4 + 3];
+  const bool ch = lchol[s] != 0;
+  const double* L = Lall + (size_t)s * N * N;
+  const double* v = V + (size_t)s * N;
+  const double* x = Xs + (size_t)s * N;
+  double* o = Lnew + (size_t)s * N1 * N1 + (size_t)j * N1;
+  if (j < N) {
+    const double xj = x[j];
+    for (int i = tid; i < N; i += 256) o[i] = ch ? L[(size_t)j * N + i] : L[(size_t)j * N + i] - x[i] * xj / vstar;
+    if (tid == 0) o[N] = ch ? 0.0 : -xj / vstar;
+    // alpha, one entry per column block
+    if (tid == 1) anew[(size_t)s * N1 + j] = alpha[(size_t)s * N + j] + coef * (ch ? xj / sn2 : -xj);
+  } else {
+    double part = 0.0;
+    for (int i = tid; i < N; i += 256) {
+      const double c = ch ? v[i] / sn2 : -x[i] / vstar;
+      o[i] = c;
+      part = fma(c, c, part);
+    }
+    const double cc = block_sum(part, red);
+    if (tid == 0) {
+      o[N] = ch ? sqrt(1.0 + Kss / sn2 - cc) : -1.0 / vstar;
+      anew[(size_t)s * N1 + N] = -coef;
+    }
+  }
+}
+
 // r = y - m(X)  per sample
 __global__ void __launch_bounds__(256) k_gp_resid(int N, int D, int Nhyp, int moff, int meanfun,
                                                   const double* __restrict__ X, const double* __restrict__ y,

@@ -43,12 +43,23 @@ class Engine:
         alpha = np.stack([np.asarray(p["alpha"], dtype=np.float64).reshape(-1) for p in post], axis=1)
         L = None
         if need_L:
+            if any(p["L"] is None for p in post):
+                raise ValueError("this gp was produced with need_L=False (factors kept on the device only) and its device copy "
+                                 "is no longer cached: rebuild it with gplite_post or request need_L=True")
             L = np.stack([np.asarray(p["L"], dtype=np.float64) for p in post], axis=2)
         sW1 = np.array([np.asarray(p["sW"]).reshape(-1)[0] for p in post])
         lch = np.array([1 if p["Lchol"] else 0 for p in post], dtype=np.uint8)
         dgp = DeviceGP(self.ctx, X, hyp, alpha, L, sW1, lch, gp["meanfun"], gp["Ncov"], gp["Nnoise"])
-        self._gp_cache = {key: (post, dgp, need_L, self._fingerprint(gp))}  # one live GP per engine
+        self._remember(gp, dgp, need_L)
         return dgp
+
+    def _remember(self, gp, dgp, has_L):
+        """Keep the device copies of the last few surrogates (the current one and the ones it was appended from / to):
+        a few tens of MB each against 288 GB of HBM."""
+        self._gp_cache.pop(id(gp["post"]), None)
+        self._gp_cache[id(gp["post"])] = (gp["post"], dgp, has_L, self._fingerprint(gp))
+        while len(self._gp_cache) > 4:
+            self._gp_cache.pop(next(iter(self._gp_cache)))
 
     @staticmethod
     def _fingerprint(gp):

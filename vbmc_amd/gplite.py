@@ -89,7 +89,7 @@ def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engin
                   "sn2_mult": float(mult[s]), "Lchol": bool(lch[s])} for s in range(S)],
     }
     dgp = DeviceGP.from_handle(ctx, h, N, D, S)
-    engine._gp_cache = {id(gp["post"]): (gp["post"], dgp, True, engine._fingerprint(gp))}
+    engine._remember(gp, dgp, True)
     return gp
 
 
@@ -132,11 +132,11 @@ def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nowarpflag=Fal
     return tuple(outs[: max(1, nargout)])
 
 
-def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, engine=None):
+def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, need_L=True, engine=None):
     """gp = gplite_post(gp, xstar, ystar, [], [], [], [], 1): rank-1 append of one observation
     (gplite/gplite_post.m:173-251).  Falls back to the full update when ``s2`` is present, as the
-    reference does (:76-79)."""
-    import copy
+    reference does (:76-79).  need_L=False leaves post[s]["L"] = None on the host: the updated factors stay on the
+    device, where this package's own consumers (gplite_pred, acqwrapper_vbmc, negelcbo_vbmc, the next append) read them."""
     import math
 
     engine = engine or default_engine()
@@ -151,42 +151,34 @@ def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, engine=None):
     N, D = np.asarray(gp["X"]).shape
     S = len(gp["post"])
     ymu, ys2, _, _ = gplite_pred(gp, xstar, np.array([ystar]), None, True, engine=engine)  # :189 (mstar, vstar)
-    mstar, vstar = np.asarray(ymu).reshape(S), np.asarray(ys2).reshape(S)
+    mstar, vstar = f64(np.asarray(ymu).reshape(S)), f64(np.asarray(ys2).reshape(S))
     dgp = _device_gp_with_noise(engine, gp)
-    Ks = np.zeros((N, S), order="F")
-    v = np.zeros((N, S), order="F")
-    x = np.zeros((N, S), order="F")
-    ctx.check(ctx.lib.vbmc_gp_rank1_solves(ctx.h, dgp.h, ptr(f64(xstar.reshape(-1))), ptr(Ks), ptr(v), ptr(x)))
-    out = copy.deepcopy(gp)
     Ncov = gp["Ncov"]
-    for s, post in enumerate(out["post"]):
+    sn2_eff = np.zeros(S)
+    for s, post in enumerate(gp["post"]):
         hyp = post["hyp"]
         sn2 = math.exp(2.0 * hyp[Ncov]) if gp["noisefun"][0] == 1 else float(np.finfo(np.float64).eps)
         if len(gp["noisefun"]) > 2 and gp["noisefun"][2] == 1:
             off = Ncov + (1 if gp["noisefun"][0] == 1 else 0) + (1 if gp["noisefun"][1] == 2 else 0)
             sn2 += math.exp(2.0 * hyp[off + 1]) * max(0.0, hyp[off] - ystar) ** 2
-        sn2_eff = sn2 * post["sn2_mult"]                                              # :207
-        Kss = math.exp(2.0 * hyp[D])                                                  # :213
-        L = post["L"]
-        newL = np.zeros((N + 1, N + 1))
-        if post["Lchol"]:
-            alpha_update = x[:, s] / sn2_eff                                          # :227
-            col = v[:, s] / sn2_eff                                                   # :228-229
-            newL[:N, :N] = L
-            newL[:N, N] = col
-            newL[N, N] = math.sqrt(1.0 + Kss / sn2_eff - float(col @ col))            # :232
-        else:
-            alpha_update = -x[:, s]                                                   # :234
-            vv = -alpha_update / vstar[s]
-            newL[:N, :N] = L + np.outer(vv, alpha_update)
-            newL[:N, N] = -vv
-            newL[N, :N] = -vv
-            newL[N, N] = -1.0 / vstar[s]                                              # :236
-        post["L"] = newL
-        post["sW"] = np.concatenate([post["sW"], [1.0 / math.sqrt(sn2_eff)]])         # :239
-        post["alpha"] = np.concatenate([post["alpha"], [0.0]]) + (mstar[s] - ystar) / vstar[s] * np.concatenate([alpha_update, [-1.0]])
-    out["X"] = np.vstack([gp["X"], xstar])
+        sn2_eff[s] = sn2 * post["sn2_mult"]                                           # :207
+    # the append itself runs on the device (k_rank1_assemble) and yields a new surrogate handle; L crosses PCIe only if wanted
+    Xn = f64(np.vstack([gp["X"], xstar]))
+    alpha = np.empty((N + 1, S), order="F")
+    Lh = np.empty((N + 1, N + 1, S), order="F") if need_L else None
+    h = C.c_void_p()
+    ctx.check(ctx.lib.vbmc_gp_rank1_update(ctx.h, dgp.h, ptr(Xn), C.c_double(ystar), ptr(mstar), ptr(vstar), ptr(f64(sn2_eff)), ptr(alpha),
+                                           ptr(Lh) if need_L else None, C.byref(h)))
+    out = {k: v for k, v in gp.items() if k != "post"}
+    out["X"] = Xn
     out["y"] = np.concatenate([gp["y"], [ystar]])
+    out["post"] = [{"hyp": p["hyp"].copy(), "alpha": alpha[:, s].copy(),
+                    "sW": np.concatenate([p["sW"], [1.0 / math.sqrt(sn2_eff[s])]]),   # :239
+                    "L": Lh[:, :, s] if need_L else None, "sn2_mult": p["sn2_mult"], "Lchol": p["Lchol"]}
+                   for s, p in enumerate(gp["post"])]
+    ndgp = DeviceGP.from_handle(ctx, h, N + 1, D, S)
+    ndgp.set_noise(gp["noisefun"], [p["sn2_mult"] for p in gp["post"]])
+    engine._remember(out, ndgp, True)
     return out
 
 
