@@ -216,24 +216,6 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
 // flops of two full-width solves on the identity, and no intermediate matrix in global memory.  Used for
 // Kinv in the GP marginal-likelihood gradient (gplite_core.m:146-147) and for the stored -inv(K + sn2 I) of
 // low-noise posteriors (gplite_core.m:84).
-// X = R \ (R' \ Z) in one launch: the slab stays in LDS between the two substitutions
-__global__ void __launch_bounds__(64) k_trsm_solve(int N, int K, int S, const double* __restrict__ Lall,
-                                                   const double* __restrict__ Finv, const unsigned char* __restrict__ lchol,
-                                                   const double* __restrict__ Zin, double* __restrict__ Xo) {
-  extern __shared__ double lds[];
-  const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x;
-  if (!lchol[s]) return;
-  const int Np = ((N + 15) >> 4) << 4;
-  double* V = lds;
-  double* P = V + (size_t)Np * TR_VS;
-  trsm_slab_load(N, K, cb * 16, Zin + ((size_t)r * S + s) * (size_t)K * N, V, lane);
-  const double* Rm = Lall + (size_t)s * N * N;
-  const double* Fi = Finv + (size_t)s * TRSM_NBLK(N) * 256;
-  trsm_fwd_wave(N, Rm, Fi, V, P, lane);
-  trsm_bwd_wave(N, Rm, Fi, V, lane);
-  trsm_slab_store(N, K, cb * 16, Xo + ((size_t)r * S + s) * (size_t)K * N, V, lane);
-}
-
 // Two waves per workgroup take the column blocks cb and nblk-1-cb: a long and a short solve, so that every workgroup does
 // the same work and the two slabs (rows from the block's own first row down) together need Np + 16 rows of LDS.
 #define SPDINV_LDS_BYTES(N) ((size_t)((((((N) + 15) >> 4) << 4) + 16) * TR_VS + 2 * 64 * TR_VS) * sizeof(double))
