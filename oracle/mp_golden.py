@@ -431,6 +431,114 @@ CASES = [
 ]
 
 
+# ------------------------------------------------------------------ acquisition functions
+def mp_lse(z):
+    m = max(z)
+    return m + mp.log(mp.fsum(mp.e ** (t - m) for t in z))
+
+
+def run_acq_case(c):
+    """acqwrapper_vbmc.m:17-33 without the variance regulariser, for acqf / acqflog / acqus / acqfsn2 / acqviqr
+    (acq/acqf_vbmc.m:6-10, acqflog_vbmc.m:14-18, acqus_vbmc.m:6-9, acqfsn2_vbmc.m:6-17, acqviqr_vbmc.m:36-109), from the
+    definitions: exact GP algebra and exact log-sum-exps in 50 digits."""
+    D, K, N, S = c["D"], c["K"], c["N"], c["S"]
+    X = [[M(c["X"][n, d]) for d in range(D)] for n in range(N)]
+    y = [M(t) for t in c["y"]]
+    Xs = [[M(c["Xstar"][i, d]) for d in range(D)] for i in range(c["Xstar"].shape[0])]
+    Xa = [[M(c["Xa"][i, d]) for d in range(D)] for i in range(c["Xa"].shape[0])]
+    Nx, Na = len(Xs), len(Xa)
+    mu = [[M(c["mu"][d, k]) for k in range(K)] for d in range(D)]
+    sigma = [M(t) for t in c["sigma"]]
+    lam = [M(t) for t in c["lam"]]
+    w = [M(t) for t in c["w"]]
+    gl = [M(t) for t in c["gplengthscale"]]
+    sn2new = [M(t) for t in c["sn2new"]]
+    ymax = M(c["ymax"])
+    u = M(0.6745)
+    fmu, fs2, acq_s = [], [], []
+    for s in range(S):
+        hyp = [M(t) for t in c["hyp"][:, s]]
+        alpha, L, sn2 = mp_gp_post(hyp, X, y, c["meanfun"])
+        a, b = mp_gp_pred(hyp, X, alpha, L, sn2, Xs, c["meanfun"])
+        fmu.append(a)
+        fs2.append(b)
+    fbar = [mp.fsum(fmu[s][i] for s in range(S)) / S for i in range(Nx)]
+    vbar = [mp.fsum(fs2[s][i] for s in range(S)) / S for i in range(Nx)]
+    vf = [mp.fsum((fmu[s][i] - fbar[i]) ** 2 for s in range(S)) / (S - 1) if S > 1 else mp.mpf(0) for i in range(Nx)]
+    vtot = [vf[i] + vbar[i] for i in range(Nx)]
+    # vbmc_pdf in the transformed space (vbmc_pdf.m:86-97)
+    pdf = []
+    for x in Xs:
+        acc = mp.mpf(0)
+        for k in range(K):
+            q = mp.fsum(((x[d] - mu[d][k]) / (sigma[k] * lam[d])) ** 2 for d in range(D))
+            nf = (2 * mp.pi) ** (-mp.mpf(D) / 2) / mp.fprod(sigma[k] * lam[d] for d in range(D))
+            acc += w[k] * nf * mp.e ** (-q / 2)
+        pdf.append(acc)
+    # nearest training input in the rescaled space (acqfsn2_vbmc.m:10-12, acqviqr_vbmc.m:48-50)
+    pos = []
+    for x in Xs:
+        d2 = [mp.fsum((x[d] / gl[d] - X[n][d] / gl[d]) ** 2 for d in range(D)) for n in range(N)]
+        pos.append(d2.index(min(d2)))
+    out = {
+        "fbar": fl(fbar), "vtot": fl(vtot),
+        "acqf": fl([-vtot[i] * mp.e ** (fbar[i] - ymax) * pdf[i] for i in range(Nx)]),
+        "acqflog": fl([-(mp.log(vtot[i]) + fbar[i] - ymax + mp.log(pdf[i])) for i in range(Nx)]),
+        "acqus": fl([-vtot[i] * pdf[i] ** 2 for i in range(Nx)]),
+        "acqfsn2": fl([-vtot[i] * (1 - sn2new[pos[i]] / (vtot[i] + sn2new[pos[i]])) * mp.e ** (fbar[i] - ymax) * pdf[i] for i in range(Nx)]),
+        "pos": pos,
+    }
+    # VIQR: expected log IQR of the posterior after observing at x, importance points Xa with unit weights
+    for s in range(S):
+        hyp = [M(t) for t in c["hyp"][:, s]]
+        ell = [mp.e ** hyp[d] for d in range(D)]
+        sf2 = mp.e ** (2 * hyp[D])
+        alpha, L, sn2 = mp_gp_post(hyp, X, y, c["meanfun"])
+        kern = lambda p, q: sf2 * mp.e ** (-mp.fsum(((p[d] - q[d]) / ell[d]) ** 2 for d in range(D)) / 2)  # noqa: E731
+        _, fs2a = mp_gp_pred(hyp, X, alpha, L, sn2, Xa, c["meanfun"])
+        # Ctmp(:, a) = (L \ (L' \ k(X, xa))) / sn2_eff   (activeimportancesampling_vbmc.m:271)
+        Ct = [[t / sn2 for t in mp_solve_ut(L, mp_solve_ut_t(L, [kern(X[n], xa) for n in range(N)]))] for xa in Xa]
+        row = []
+        for i, x in enumerate(Xs):
+            ks = [kern(X[n], x) for n in range(N)]
+            ys2 = fs2[s][i] + sn2new[pos[i]]
+            zz = []
+            for a_, xa in enumerate(Xa):
+                C = kern(x, xa) - mp.fsum(ks[n] * Ct[a_][n] for n in range(N))          # acqviqr_vbmc.m:84-86
+                sp = mp.sqrt(max(fs2a[a_] - C * C / ys2, mp.mpf(0)))                      # :93-95
+                zz.append(u * sp + mp.log1p(-mp.e ** (-2 * u * sp)))                      # :97-99
+            row.append(mp_lse(zz))
+        acq_s.append(row)
+    out["acqviqr"] = fl([mp_lse([acq_s[s][i] for s in range(S)]) - mp.log(S) for i in range(Nx)])   # :107-109
+    return out
+
+
+ACQ_CASES = [
+    dict(seed=21, D=2, K=3, N=9, S=1, Mh=2, meanfun=4),
+    dict(seed=22, D=3, K=4, N=12, S=3, Mh=2, meanfun=4),
+    dict(seed=23, D=4, K=2, N=10, S=2, Mh=2, meanfun=1),
+]
+
+
+def main_acq():
+    outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    for i, spec in enumerate(ACQ_CASES):
+        c = make_case(**spec)
+        rng = np.random.default_rng(1000 + spec["seed"])
+        c["Xa"] = 1.2 * rng.standard_normal((6, spec["D"]))
+        c["gplengthscale"] = np.exp(0.2 * rng.standard_normal(spec["D"]))
+        c["sn2new"] = 1e-3 * (1.0 + rng.random(spec["N"]))
+        c["ymax"] = float(np.max(c["y"]))
+        out = run_acq_case(c)
+        rec = {"generator": "oracle/mp_golden.py acq (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps),
+               "inputs": {k: (tolist(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()},
+               "expected": out}
+        path = os.path.join(outdir, "mp_acq_case%d.json" % i)
+        with open(path, "w") as f:
+            json.dump(rec, f)
+        print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
+
+
 def main():
     outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -463,6 +571,9 @@ def main_nlz():
 if __name__ == "__main__":
     if "nlz" in sys.argv[1:]:
         main_nlz()      # only the marginal-likelihood fixtures
+    elif "acq" in sys.argv[1:]:
+        main_acq()      # only the acquisition-function fixtures
     else:
         main()
         main_nlz()
+        main_acq()

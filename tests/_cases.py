@@ -33,6 +33,25 @@ def load_nlz_golden(path):
     return gp, np.array(inp["hyp"], dtype=np.float64), {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
 
 
+def acq_golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "mp_acq_case*.json")))
+
+
+def load_acq_golden(path):
+    """-> (vp, gp with X_rescaled / sn2new, Xs, optimState with the importance points Xa only, expected dict)."""
+    with open(path) as f:
+        rec = json.load(f)
+    inp = {k: (np.array(v, dtype=np.float64) if isinstance(v, list) else v) for k, v in rec["inputs"].items()}
+    vp = R.make_vp(inp["mu"], inp["sigma"], inp["lam"], eta=inp["eta"])
+    vp["w"] = inp["w"]
+    gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"])
+    gp = dict(gp, X_rescaled=inp["X"] / inp["gplengthscale"][None, :], sn2new=inp["sn2new"])
+    st = {"ymax": inp["ymax"], "VarianceRegularizedAcqFcn": False, "TolGPVar": 1e-4, "gplengthscale": inp["gplengthscale"],
+          "ActiveImportanceSampling": {"Xa": inp["Xa"]}}
+    exp = {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
+    return vp, gp, inp["Xstar"], st, exp
+
+
 def load_golden(path):
     with open(path) as f:
         rec = json.load(f)

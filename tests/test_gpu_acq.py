@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import vbmc_ref as R
+from tests._cases import acq_golden_cases, load_acq_golden
 from tests.test_gpu_elbo import problem, relerr
 
 pytestmark = pytest.mark.gpu
@@ -158,3 +159,15 @@ def test_viqr_end_to_end_through_the_mirror(va):
     ref, _, _ = R.acqwrapper_vbmc(Xs, vp, gp, st_o, "acqviqr")
     assert np.max(np.abs(acq - ref)) < 1e-8
     assert int(np.argmin(acq)) == int(np.argmin(ref))
+
+
+@pytest.mark.parametrize("path", acq_golden_cases())
+def test_acquisition_golden_vectors(va, path):
+    """Device acquisition sweep against the committed 50-digit mpmath vectors: prediction, vbmc_pdf, the four closed-form
+    acquisition functions and VIQR with Ctmp / fs2a computed on the device from the importance points alone."""
+    vp, gp, Xs, st, exp = load_acq_golden(path)
+    for name in ("acqf", "acqflog", "acqus", "acqfsn2", "acqviqr"):
+        acq, fbar, vtot = va.acqwrapper_vbmc(Xs, vp, gp, st, False, name + "_vbmc", None, nargout=3)
+        tol = 1e-8 if name == "acqviqr" else 1e-9
+        assert np.max(np.abs(acq - exp[name]) / np.maximum(1e-300, np.abs(exp[name]))) < tol, (name, acq, exp[name])
+        assert np.max(np.abs(fbar - exp["fbar"])) < 1e-10 and np.max(np.abs(vtot - exp["vtot"]) / exp["vtot"]) < 1e-9

@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 
 from oracle import vbmc_ref as R
-from tests._cases import golden_cases, load_golden, load_nlz_golden, nlz_golden_cases, vp_from_inputs
+from tests._cases import (acq_golden_cases, golden_cases, load_acq_golden, load_golden, load_nlz_golden, nlz_golden_cases,
+                          vp_from_inputs)
 
 RTOL = 1e-11  # fp64 restatement vs 50-digit evaluation; sums of <= ~100 terms
 
@@ -113,3 +114,20 @@ def test_hypprior_closed_forms():
         fd = (R.gplite_hypprior(hyp + d, hp)[0] - R.gplite_hypprior(hyp - d, hp)[0]) / (2 * e)
         assert abs(fd - dlp[i]) < 1e-8
     assert dlp[2] == 0.0 and dlp[3] == 0.0
+
+
+@pytest.mark.parametrize("path", acq_golden_cases())
+def test_oracle_acquisition_vs_mpmath(path):
+    """acqwrapper_vbmc restatement (acqf, acqflog, acqus, acqfsn2, acqviqr with Ctmp / fs2a from the oracle's own
+    precomputation) against the 50-digit evaluation of the definitions (tests/golden/mp_acq_case*.json)."""
+    vp, gp, Xs, st, exp = load_acq_golden(path)
+    Xa = st["ActiveImportanceSampling"]["Xa"]
+    S, Na = len(gp["post"]), Xa.shape[0]
+    _, Ct = R.acq_is_precompute(gp, Xa)
+    fs2a = np.asarray(R.gplite_pred(gp, Xa, None, None, True)[3]).reshape(Na, -1)
+    st = dict(st, ActiveImportanceSampling={"Xa": Xa, "Ctmp_mat": Ct, "fs2a": fs2a, "lnw": np.zeros((S, Na))})
+    for name in ("acqf", "acqflog", "acqus", "acqfsn2", "acqviqr"):
+        acq, fbar, vtot = R.acqwrapper_vbmc(Xs, vp, gp, st, name)
+        tol = 1e-9 if name == "acqviqr" else 1e-11
+        assert np.max(np.abs(acq - exp[name]) / np.maximum(1e-300, np.abs(exp[name]))) < tol, name
+        assert np.max(np.abs(fbar - exp["fbar"])) < 1e-11 and np.max(np.abs(vtot - exp["vtot"]) / exp["vtot"]) < 1e-10
