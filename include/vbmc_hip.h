@@ -73,6 +73,8 @@ vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Nco
                            int meanfun, const double* X, const double* hyp, const double* alpha,
                            const double* L, const double* sW1, const uint8_t* Lchol,
                            vbmc_gp** out);
+/* Releases a surrogate.  Its device blocks belong to the creating context's pool: pass that context while it is alive
+ * (after vbmc_ctx_destroy the blocks are already gone and ctx may be NULL). */
 void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp);
 /* Noise model needed by vbmc_gp_pred: gp.noisefun (3 ids, gplite_noisefun.m:176-210) and
  * gp.post(s).sn2_mult (S). */

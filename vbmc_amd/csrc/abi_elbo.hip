@@ -173,8 +173,11 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
     g[3 * D] = 2.0 * h[D] + sum_lnell;
     g[3 * D + 1] = meanfun > 0 ? h[mo] : 0.0;
   }
+  // device blocks of a surrogate come from the context's pool (hipMalloc / hipFree cost ~0.1 ms each and serialise the
+  // device: an append or a re-upload per acquired point would pay for a dozen of them)
+  gp->pooled = true;
   auto up = [&](double** dst, const double* src, size_t n) -> hipError_t {
-    hipError_t e = hipMalloc((void**)dst, n * sizeof(double));
+    hipError_t e = pool_get(ctx, n * sizeof(double), (void**)dst);
     if (e != hipSuccess) return e;
     return hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice);
   };
@@ -186,7 +189,7 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
     e = up(&gp->L, L, (size_t)N * N * S);
     gp->hasL = true;
   } else if (e == hipSuccess && dL_chol) {
-    e = hipMalloc((void**)&gp->L, (size_t)N * N * S * sizeof(double));
+    e = pool_get(ctx, (size_t)N * N * S * sizeof(double), (void**)&gp->L);
     for (int s = 0; s < S && e == hipSuccess; ++s) {
       const size_t off = (size_t)s * N * N;
       if (gp->Lchol[s] || !dL_inv) e = hipMemcpyAsync(gp->L + off, dL_chol + off, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
@@ -206,11 +209,11 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
     e = up(&gp->d_meanX, mx.data(), (size_t)D);
   }
   if (e == hipSuccess) {
-    e = hipMalloc((void**)&gp->d_lchol, (size_t)S);
+    e = pool_get(ctx, (size_t)S, (void**)&gp->d_lchol);
     if (e == hipSuccess) e = hipMemcpy(gp->d_lchol, gp->Lchol.data(), (size_t)S, hipMemcpyHostToDevice);
   }
   if (e == hipSuccess && gp->hasL) {
-    e = hipMalloc((void**)&gp->d_finv, (size_t)S * TRSM_NBLK(N) * 256 * sizeof(double));
+    e = pool_get(ctx, (size_t)S * TRSM_NBLK(N) * 256 * sizeof(double), (void**)&gp->d_finv);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, ctx->stream, N, gp->L, gp->d_lchol, gp->d_finv);
       e = hipStreamSynchronize(ctx->stream);
@@ -232,19 +235,14 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
 }
 
 extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
-  (void)ctx;
   if (!gp) return;
-  if (gp->X) (void)hipFree(gp->X);
-  if (gp->alpha) (void)hipFree(gp->alpha);
-  if (gp->L) (void)hipFree(gp->L);
-  if (gp->gpc) (void)hipFree(gp->gpc);
-  if (gp->hyp) (void)hipFree(gp->hyp);
-  if (gp->d_sn2) (void)hipFree(gp->d_sn2);
-  if (gp->d_lchol) (void)hipFree(gp->d_lchol);
-  if (gp->d_mult) (void)hipFree(gp->d_mult);
-  if (gp->d_finv) (void)hipFree(gp->d_finv);
-  if (gp->d_tinv) (void)hipFree(gp->d_tinv);
-  if (gp->d_meanX) (void)hipFree(gp->d_meanX);
+  // pooled blocks go back to the context's pool; without a live context (destroyed first) they are already gone with it
+  void* blocks[] = {gp->X, gp->alpha, gp->L, gp->gpc, gp->hyp, gp->d_sn2, gp->d_lchol, gp->d_mult, gp->d_finv, gp->d_tinv, gp->d_meanX};
+  for (void* b : blocks) {
+    if (!b) continue;
+    if (gp->pooled) { if (ctx) pool_put(ctx, b); }
+    else (void)hipFree(b);
+  }
   delete gp;
 }
 

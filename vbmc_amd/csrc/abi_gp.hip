@@ -359,7 +359,7 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
 extern "C" vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32_t noisefun[3], const double* sn2_mult) {
   if (!ctx || !gp || !noisefun || !sn2_mult) return VBMC_ERR_INVALID;
   for (int i = 0; i < 3; ++i) gp->noisefun[i] = noisefun[i];
-  if (!gp->d_mult) HIP_TRY(ctx, hipMalloc((void**)&gp->d_mult, (size_t)gp->S * 8));
+  if (!gp->d_mult) HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)gp->S * 8, (void**)&gp->d_mult) : hipMalloc((void**)&gp->d_mult, (size_t)gp->S * 8));
   HIP_TRY(ctx, hipMemcpy(gp->d_mult, sn2_mult, (size_t)gp->S * 8, hipMemcpyHostToDevice));
   gp->has_noise = true;
   return VBMC_OK;
@@ -391,13 +391,15 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   if (!gp->d_tinv) {
     // Tinv = inv(L') = L' \ I for the Lchol samples, once per GP (the kernels skip the others)
     double* t = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&t, (size_t)S * N * N * 8));
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)S * N * N + 255) / 256)), dim3(256), 0, st, N, S, t);
+    HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)S * N * N * 8, (void**)&t) : hipMalloc((void**)&t, (size_t)S * N * N * 8));
     if (tlds0 > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds0));
-    hipLaunchKernelGGL(k_trsm_fwd, dim3((N + TR_CB - 1) / TR_CB, S, 1), dim3(64), tlds0, st, N, N, S, gp->L, gp->d_finv, gp->d_lchol, t);
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds0));
+    hipLaunchKernelGGL(k_tri_inverse, dim3((N + TR_CB - 1) / TR_CB, S, 1), dim3(64), tlds0, st, N, S, gp->L, gp->d_finv, gp->d_lchol, t);
     hipError_t e_ = hipGetLastError();
-    if (e_ != hipSuccess) { (void)hipFree(t); return set_err(ctx, VBMC_ERR_HIP, "inv(L') failed: %s", hipGetErrorString(e_)); }
+    if (e_ != hipSuccess) {
+      if (gp->pooled) pool_put(ctx, t); else (void)hipFree(t);
+      return set_err(ctx, VBMC_ERR_HIP, "inv(L') failed: %s", hipGetErrorString(e_));
+    }
     gp->d_tinv = t;
   }
   // column means for sq_dist's centring (sq_dist.m:36), O((N + Nstar) D) on the host in MATLAB's order
@@ -881,7 +883,7 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
   if (st2 != VBMC_OK) return st2;
   if (gp->has_noise) {
     for (int i = 0; i < 3; ++i) ng->noisefun[i] = gp->noisefun[i];
-    hipError_t e = hipMalloc((void**)&ng->d_mult, (size_t)S * 8);
+    hipError_t e = pool_get(ctx, (size_t)S * 8, (void**)&ng->d_mult);
     if (e == hipSuccess) e = hipMemcpy(ng->d_mult, gp->d_mult, (size_t)S * 8, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) { vbmc_gp_free(ctx, ng); return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_rank1_update: %s", hipGetErrorString(e)); }
     ng->has_noise = true;

@@ -93,6 +93,7 @@ static inline void pool_put(vbmc_ctx* ctx, void* p) {
 struct vbmc_gp {
   int N = 0, D = 0, S = 0, Nhyp = 0, Ncov = 0, Nnoise = 0, meanfun = 0;
   bool hasL = false;
+  bool pooled = false;      // device blocks below belong to the creating context's pool (pool_get / pool_put)
   double* X = nullptr;      // N x D col-major
   double* alpha = nullptr;  // N x S
   double* L = nullptr;      // N x N x S

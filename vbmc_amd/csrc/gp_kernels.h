@@ -466,14 +466,6 @@ __global__ void k_scale_vec(size_t n, int per, const double* __restrict__ scal, 
   if (i < n) v[i] = v[i] / scal[(i / per) * 4 + scol];
 }
 
-__global__ void k_set_identity(int N, int S, double* __restrict__ Z) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)S * N * N) {
-    size_t e = i % ((size_t)N * N);
-    Z[i] = (e % N == e / N) ? 1.0 : 0.0;
-  }
-}
-
 __global__ void k_negate_copy(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = -src[i];

@@ -216,6 +216,23 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
 // flops of two full-width solves on the identity, and no intermediate matrix in global memory.  Used for
 // Kinv in the GP marginal-likelihood gradient (gplite_core.m:146-147) and for the stored -inv(K + sn2 I) of
 // low-noise posteriors (gplite_core.m:84).
+// T = inv(R') = R' \ I (lower triangular), one wave per 16 columns: the identity slab is formed in LDS and the substitution
+// starts at the column block's own rows (everything above is zero and is written as such).
+__global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                    const unsigned char* __restrict__ lchol, double* __restrict__ T) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  if (!lchol[s]) return;
+  const int Np = ((N + 15) >> 4) << 4, k0 = cb << 4;
+  double* V = lds;
+  double* P = V + (size_t)Np * TR_VS;
+  for (int c = 0; c < 16; ++c)
+    for (int i = lane; i < Np; i += 64) V[i * TR_VS + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
+  trsm_wsync();
+  trsm_fwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane, cb);
+  trsm_slab_store(N, N, k0, T + (size_t)s * N * N, V, lane);
+}
+
 // Two waves per workgroup take the column blocks cb and nblk-1-cb: a long and a short solve, so that every workgroup does
 // the same work and the two slabs (rows from the block's own first row down) together need Np + 16 rows of LDS.
 #define SPDINV_LDS_BYTES(N) ((size_t)((((((N) + 15) >> 4) << 4) + 16) * TR_VS + 2 * 64 * TR_VS) * sizeof(double))
