@@ -77,7 +77,7 @@ def test_nlz_batch_matches_oracle(va, cfg):
     assert f1 == nlZ[2] and np.array_equal(g1, dnlZ[:, 2])
 
 
-@pytest.mark.parametrize("N,D", [(16, 2), (17, 3), (48, 13), (81, 20), (1080, 6)])
+@pytest.mark.parametrize("N,D", [(16, 2), (17, 3), (48, 13), (81, 20), (70, 32), (1080, 6)])
 def test_nlz_inverse_kernel_shapes(va, N, D):
     """Kinv = L\\(L'\\eye(N)) (gplite_core.m:240) is formed by k_spd_inverse from paired column blocks: one block (N <= 16),
     an odd block count (the middle block has no partner), D padded to the next kernel instantiation (13 -> 16, 20 -> 24),
