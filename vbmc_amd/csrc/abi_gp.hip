@@ -771,9 +771,14 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   a.Xs = pb.dXs.as<double>(); a.Xa = is->Xa; a.hyp = gp->hyp; a.Xc = pb.dXc.as<double>(); a.muv = pb.dmuv.as<double>();
   a.CT = is->CT; a.fs2a = is->fs2a; a.lnw = is->has_lnw ? is->lnw : nullptr; a.fs2 = pb.fs2; a.sn2x = dsx.as<double>();
   a.lchol = gp->d_lchol; a.acqs = dacqs.as<double>(); a.KsW = pb.dKs.as<double>(); a.sn2_eff = gp->d_sn2;
-  dim3 grid((Nstar + 15) / 16, S);
+  dim3 grid((Nstar + 63) / 64, S);
   switch (is->Nap / 16) {
-#define IQR_CASE(NT) case NT: hipLaunchKernelGGL((k_acq_iqr<NT>), grid, dim3(64), 0, st, a); break;
+#define IQR_CASE(NT)                                                                                                                   \
+  case NT:                                                                                                                             \
+    if (IQR_LDS_BYTES(NT) > 64 * 1024)                                                                                                 \
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_acq_iqr<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IQR_LDS_BYTES(NT))); \
+    hipLaunchKernelGGL((k_acq_iqr<NT>), grid, dim3(256), IQR_LDS_BYTES(NT), st, a);                                                      \
+    break;
     IQR_CASE(1) IQR_CASE(2) IQR_CASE(3) IQR_CASE(4) IQR_CASE(5) IQR_CASE(6) IQR_CASE(7) IQR_CASE(8)
     IQR_CASE(9) IQR_CASE(10) IQR_CASE(11) IQR_CASE(12) IQR_CASE(13) IQR_CASE(14) IQR_CASE(15) IQR_CASE(16)
 #undef IQR_CASE

@@ -1102,32 +1102,40 @@ struct IqrArgs {
   double* acqs;          // Nstar x S
 };
 
-// One wave = 16 test points x one hyper-sample.  C[i][a] = Ka[i][a] -/+ sum_n Ks[n][i] Ctmp[n][a] on the fp64 matrix
-// cores: the A operand Ks[n][i] = k_s(X_n, xs_i) is produced in registers on the fly (each element exactly once), the
-// B operand streams CtmpT rows (16 consecutive a per lane group), NT = Nap/16 accumulator tiles live at once.
+// One workgroup = 4 waves = 64 test points x one hyper-sample; wave w owns 16 of the points.
+// C[i][a] = Ka[i][a] -/+ sum_n Ks[n][i] Ctmp[n][a] on the fp64 matrix cores: the A operand Ks[n][i] comes from the
+// cross-kernel matrix k_pred_ks left in memory (one coalesced value per lane and k-step); the B operand -- rows of CtmpT,
+// the same for all points -- is staged through LDS in chunks of 16 rows shared by the four waves (double-buffered: the
+// global loads of chunk c+1 are in flight while chunk c feeds the MFMAs), which cuts the L2 traffic of the B stream by
+// four; NT = Nap/16 accumulator tiles live at once.
 // Epilogue per element: tau2 = C^2/ys2_i, s_pred = sqrt(max(fs2a_a - tau2, 0)), zz = lnw_a + u s + log1p(-exp(-2 u s)),
 // then a log-sum-exp over a (16 lanes x NT tiles).
+#define IQR_KC 16
+#define IQR_LDS_BYTES(NT) ((size_t)(2 * IQR_KC * (16 * (NT) + 8) + 64 * 33 + 64) * sizeof(double))
 template <int NT>
-__global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
-  __shared__ double xs_s[16][33];   // ell-scaled, centred test points of the tile
-  __shared__ double ys2_s[16];
-  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
-  const int i0 = blockIdx.x * 16, s = blockIdx.y;
+__global__ void __launch_bounds__(256) k_acq_iqr(IqrArgs a) {
+  constexpr int BS = 16 * NT + 8;          // padded row stride of a staged chunk
+  constexpr int PER = (IQR_KC * 16 * NT + 255) / 256;   // staged elements per thread
+  extern __shared__ double iq_lds[];
+  double* BL = iq_lds;                              // [2][IQR_KC][BS]
+  double (*xs_s)[33] = (double (*)[33])(iq_lds + 2 * IQR_KC * BS);   // ell-scaled, centred test points of the 64-point block
+  double* ys2_s = iq_lds + 2 * IQR_KC * BS + 64 * 33;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int ib = blockIdx.x * 64, i0 = ib + 16 * wv, s = blockIdx.y;
   const int N = a.N, D = a.D, Nap = a.Nap;
   const double* h = a.hyp + (size_t)s * a.Nhyp;
   const double sf2 = exp(2.0 * h[D]);
   const double* mu = a.muv + (size_t)s * 2 * D;
   const double* iell = mu + D;
-  for (int idx = lane; idx < 16 * D; idx += 64) {
+  for (int idx = tid; idx < 64 * D; idx += 256) {
     const int i = idx / D, d = idx % D;
-    const int gi = min(i0 + i, a.Nstar - 1);
+    const int gi = min(ib + i, a.Nstar - 1);
     xs_s[i][d] = a.Xs[gi + (size_t)a.Nstar * d] * iell[d] - mu[d];
   }
-  if (lane < 16) {
-    const int gi = min(i0 + lane, a.Nstar - 1);
-    ys2_s[lane] = a.fs2[gi + (size_t)a.Nstar * s] + a.sn2x[gi];
+  if (tid < 64) {
+    const int gi = min(ib + tid, a.Nstar - 1);
+    ys2_s[tid] = a.fs2[gi + (size_t)a.Nstar * s] + a.sn2x[gi];
   }
-  __syncthreads();
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
@@ -1135,29 +1143,60 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
   const bool gvalid = i0 + li < a.Nstar;
   const double* kcol = a.KsW + (size_t)s * N * a.Nstar + min(i0 + li, a.Nstar - 1);
   const double isw = a.lchol[s] ? sqrt(a.sn2_eff[s]) : 1.0;   // undo sW = 1/sqrt(sn2_eff)
-  // software pipeline: the B operands (CtmpT row n, 16 consecutive a per tile) of step n0 + 4 are in flight while the
-  // A operand of step n0 (one kernel value per lane) is computed and the NT MFMAs of step n0 issue
-  double bcur[NT], bnxt[NT];
-  {
-    const int n = lg;
-    const double* row = ct + (size_t)min(n, N - 1) * Nap + li;
+  // chunk c = rows 16c .. 16c+15 of CtmpT (contiguous in memory: row-major N x Nap), zero beyond N
+  double pre[PER];
+  auto fetch = [&](int c) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bcur[t] = (n < N) ? row[16 * t] : 0.0;
-  }
-  for (int n0 = 0; n0 < N; n0 += 4) {
-    const int n = n0 + lg, nn = n + 4;
-    {
-      const double* row = ct + (size_t)min(nn, N - 1) * Nap + li;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bnxt[t] = (nn < N) ? row[16 * t] : 0.0;
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u;
+      pre[u] = (e < IQR_KC * Nap && 16 * c * Nap + e < N * Nap) ? ct[(size_t)16 * c * Nap + e] : 0.0;
     }
-    // A operand: the cross-kernel value k_s(X_n, xs_i), already computed once by k_pred_ks (stored sW-scaled)
-    const double kv = (n < N && gvalid) ? kcol[(size_t)n * a.Nstar] * isw : 0.0;
+  };
+  auto stash = [&](int buf) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv, bcur[t], acc[t], 0, 0, 0);
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + 256 * u;
+      if (e < IQR_KC * Nap) { const int row = e / Nap, col = e - row * Nap; BL[(buf * IQR_KC + row) * BS + col] = pre[u]; }
+    }
+  };
+  const int nch = (N + IQR_KC - 1) / IQR_KC;
+  // A operands of the four k-steps of a chunk: the cross-kernel values k_s(X_n, xs_i) (stored sW-scaled), loaded one
+  // chunk ahead like the B rows
+  double kv[4], kvn[4], kvn2[4];   // this chunk, the next one and the one after (the A stream comes from HBM)
+  auto fetch_a = [&](int c, double* dst) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bcur[t] = bnxt[t];
+    for (int q = 0; q < 4; ++q) {
+      const int n = 16 * c + 4 * q + lg;
+      dst[q] = (n < N && gvalid) ? kcol[(size_t)n * a.Nstar] : 0.0;
+    }
+  };
+  fetch(0);
+  fetch_a(0, kv);
+  fetch_a(1, kvn);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    if (c + 1 < nch) fetch(c + 1);
+    fetch_a(c + 2, kvn2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kv[q] *= isw;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* brow = BL + (cur * IQR_KC + 4 * q + lg) * BS + li;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kv[q], brow[16 * t], acc[t], 0, 0, 0);
+    }
+    if (c + 1 < nch) stash(cur ^ 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { kv[q] = kvn[q]; kvn[q] = kvn2[q]; }
+    __syncthreads();
   }
+  const int xo = 16 * wv;   // this wave's rows of xs_s / ys2_s
+  // the staged chunks are no longer needed: the exp table takes their place
+  double* TAB = BL;
+  for (int t = tid; t < VB_EXP_TAB_N; t += 256) TAB[t] = c_exp2_tab[t];
+  __syncthreads();
   // epilogue: lane (li, lg) holds C'[i = lg + 4r][a = 16t + li]
   const double u = 0.6745;
   const double sgn = a.lchol[s] ? -1.0 : 1.0;
@@ -1172,18 +1211,18 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
     for (int d = 0; d < D; ++d) {
       const double xv = av ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const double tt = xs_s[lg + 4 * r][d] - xv; c4[r] = fma(tt, tt, c4[r]); }
+      for (int r = 0; r < 4; ++r) { const double tt = xs_s[xo + lg + 4 * r][d] - xv; c4[r] = fma(tt, tt, c4[r]); }
     }
     const double fa = av ? a.fs2a[(size_t)s * Nap + aa_] : 0.0;
     const double lw = av ? (a.lnw ? a.lnw[(size_t)s * Nap + aa_] : 0.0) : -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lg + 4 * r;
-      const double ka = sf2 * exp(-c4[r] / 2.0);
+      const double ka = sf2 * vb_exp_tab<0>(-0.5 * c4[r], TAB);
       const double C = ka + sgn * acc[t][r];
-      const double tau2 = C * C / ys2_s[i];
+      const double tau2 = C * C / ys2_s[xo + i];
       const double sp = sqrt(fmax(fa - tau2, 0.0));
-      const double z = av ? lw + (u * sp + log1p(-exp(-2.0 * u * sp))) : -INFINITY;
+      const double z = av ? lw + (u * sp + log1p(-vb_exp_tab<0>(-2.0 * u * sp, TAB))) : -INFINITY;
       zz[t][r] = z;
       mx[r] = fmax(mx[r], z);
     }
@@ -1195,11 +1234,12 @@ __global__ void __launch_bounds__(64) k_acq_iqr(IqrArgs a) {
     m = fmax(m, __shfl_xor(m, 4, 64)); m = fmax(m, __shfl_xor(m, 8, 64));
     double sum = 0.0;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sum += exp(zz[t][r] - m);   // all -inf: -inf - -inf = NaN, as in MATLAB
+    for (int t = 0; t < NT; ++t) sum += vb_exp_tab<0>(zz[t][r] - m, TAB);
     sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
     sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
     const int gi = i0 + lg + 4 * r;
-    if (li == 0 && gi < a.Nstar) a.acqs[gi + (size_t)a.Nstar * s] = log(sum) + m;
+    // every term -inf: MATLAB's -inf - -inf = NaN propagates (the table exp itself swallows NaN)
+    if (li == 0 && gi < a.Nstar) a.acqs[gi + (size_t)a.Nstar * s] = (m == -INFINITY) ? NAN : log(sum) + m;
   }
 }
 
