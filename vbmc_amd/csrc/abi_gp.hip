@@ -466,7 +466,7 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   HIP_TRY(ctx, pb.dpV.alloc(ctx, (size_t)maxg * S * Nstar * 8));
   HIP_TRY(ctx, pb.dpF.alloc(ctx, (size_t)S * Nstar * 8));
   HIP_TRY(ctx, hipMemcpyAsync(pb.dgrp.p, grp.data(), grp.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, pb.dKs.alloc(ctx, (size_t)S * N * Nstar * 8));
+  HIP_TRY(ctx, pb.dKs.alloc(ctx, (size_t)S * N * (((size_t)Nstar + 15) / 16) * 16 * 8));   // tiled by 16 points
   // inner dimension of the MFMA distance blocks: QS = ceil(D / 4) steps
 #define PRED_KS(QSV) case QSV: hipLaunchKernelGGL((k_pred_ks<QSV>), dim3((Nstar + 15) / 16, S), dim3(64), 0, st, pa, dXc.as<double>(), \
                                                   daa.as<double>(), dmuv.as<double>(), pb.dKs.as<double>(), pb.dpF.as<double>()); break;
@@ -771,13 +771,13 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
   a.Xs = pb.dXs.as<double>(); a.Xa = is->Xa; a.hyp = gp->hyp; a.Xc = pb.dXc.as<double>(); a.muv = pb.dmuv.as<double>();
   a.CT = is->CT; a.fs2a = is->fs2a; a.lnw = is->has_lnw ? is->lnw : nullptr; a.fs2 = pb.fs2; a.sn2x = dsx.as<double>();
   a.lchol = gp->d_lchol; a.acqs = dacqs.as<double>(); a.KsW = pb.dKs.as<double>(); a.sn2_eff = gp->d_sn2;
-  dim3 grid((Nstar + 63) / 64, S);
+  dim3 grid((Nstar + IQR_PTS - 1) / IQR_PTS, S);
   switch (is->Nap / 16) {
 #define IQR_CASE(NT)                                                                                                                   \
   case NT:                                                                                                                             \
     if (IQR_LDS_BYTES(NT) > 64 * 1024)                                                                                                 \
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_acq_iqr<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IQR_LDS_BYTES(NT))); \
-    hipLaunchKernelGGL((k_acq_iqr<NT>), grid, dim3(256), IQR_LDS_BYTES(NT), st, a);                                                      \
+    hipLaunchKernelGGL((k_acq_iqr<NT>), grid, dim3(IQR_THREADS), IQR_LDS_BYTES(NT), st, a);                                                     \
     break;
     IQR_CASE(1) IQR_CASE(2) IQR_CASE(3) IQR_CASE(4) IQR_CASE(5) IQR_CASE(6) IQR_CASE(7) IQR_CASE(8)
     IQR_CASE(9) IQR_CASE(10) IQR_CASE(11) IQR_CASE(12) IQR_CASE(13) IQR_CASE(14) IQR_CASE(15) IQR_CASE(16)

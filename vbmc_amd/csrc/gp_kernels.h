@@ -521,8 +521,8 @@ __global__ void __launch_bounds__(256) k_pred_prep(PredArgs a, double* __restric
   }
 }
 
-// k_pred_ks: the sW-scaled cross-kernel matrix for every hyper-sample, KsW[s][n][i] = sW_s * k_s(X_n, Xstar_i)
-// (points fastest), each element computed exactly once, and fmu's data term Ks' alpha (gplite_pred.m:74,83).
+// k_pred_ks: the sW-scaled cross-kernel matrix for every hyper-sample, KsW[s][i/16][n][i%16] = sW_s * k_s(X_n, Xstar_i)
+// (tiled by 16 points), each element computed exactly once, and fmu's data term Ks' alpha (gplite_pred.m:74,83).
 // One wave per (16 test points, hyper-sample).  The inner products of sq_dist's expansion |a|^2 + |b|^2 - 2 a.b
 // (sq_dist.m:45) for a 16 x 16 block of (training point, test point) pairs are QS MFMAs (inner dimension D in steps
 // of 4); the accumulator layout (row n = lg + 4 reg, column point = li) is exactly the coalesced store pattern.
@@ -556,7 +556,9 @@ __global__ void __launch_bounds__(64) k_pred_ks(PredArgs a, const double* __rest
   const double* al = a.alpha + (size_t)s * N;
   const double* xcs = Xc + (size_t)s * N * D;
   const double* aas = aa + (size_t)s * N;
-  double* out = KsW + (size_t)s * N * a.Nstar;
+  // tiled layout KsW[s][point tile][n][16]: each 16-point tile is one contiguous N x 16 block, written here and streamed by
+  // k_gp_pred / k_acq_iqr front to back (a row-major N x Nstar matrix made every consumer hop 8 * Nstar bytes per step)
+  double* out = KsW + ((size_t)s * gridDim.x + pt) * (size_t)N * 16;
   double fm = 0.0;
   (void)sf2;
   for (int n0 = 0; n0 < N; n0 += 16) {
@@ -576,7 +578,7 @@ __global__ void __launch_bounds__(64) k_pred_ks(PredArgs a, const double* __rest
         const double cdist = fmax(aas[n] + (bb - 2.0 * acc[r]), 0.0);      // sq_dist.m:45,49
         const double ks = vb_exp_tab<0>(lsf2 - cdist / 2.0, tab);          // sf2 * exp(-K/2)  (gplite_pred.m:74)
         fm = fma(ks, al[n], fm);
-        if (cv) out[(size_t)n * a.Nstar + jc] = ks * sW;                   // sW .* Ks (:99); plain Ks when !Lchol
+        if (cv) out[(size_t)n * 16 + li] = ks * sW;                        // sW .* Ks (:99); plain Ks when !Lchol
       }
     }
   }
@@ -666,15 +668,15 @@ __global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const d
     T[idx] = (col < N && row < N) ? Am[(size_t)col * N + row] : 0.0;
   }
   __syncthreads();
-  const double* ksw = KsW + (size_t)s * N * a.Nstar;
   const int ntile = (a.Nstar + 15) >> 4;
+  const double* ksw = KsW + (size_t)s * ntile * N * 16;   // [point tile][n][16]
   for (int pt = wave + (PRED_THREADS / 64) * blockIdx.z; pt < ntile; pt += (PRED_THREADS / 64) * gridDim.z) {
     const int jc = pt * 16 + li;
     const bool cv = jc < a.Nstar;
-    const double* kcol = ksw + min(jc, a.Nstar - 1);
+    const double* kcol = ksw + (size_t)pt * N * 16 + li;
     double part = 0.0;
     switch (R) {   // one straight-line instantiation per number of resident row tiles
-#define PRED_CASE(RR) case RR: part = pred_tile<RR>(T, RB, kcol, (size_t)a.Nstar, N, ncol, cv, lc, tb, li, lg); break;
+#define PRED_CASE(RR) case RR: part = pred_tile<RR>(T, RB, kcol, (size_t)16, N, ncol, cv, lc, tb, li, lg); break;
       PRED_CASE(1) PRED_CASE(2) PRED_CASE(3) PRED_CASE(4) PRED_CASE(5) PRED_CASE(6) PRED_CASE(7) PRED_CASE(8)
 #undef PRED_CASE
       default: break;
@@ -1095,7 +1097,7 @@ struct IqrArgs {
   const double* fs2a;    // S x Nap
   const double* lnw;     // S x Nap (-inf in the padding) or null
   const double* fs2;     // Nstar x S   (k_gp_pred)
-  const double* KsW;     // S x N x Nstar  sW-scaled cross-kernel matrix (k_pred_ks)
+  const double* KsW;     // S x ceil(Nstar/16) x N x 16  sW-scaled cross-kernel matrix, tiled by 16 points (k_pred_ks)
   const double* sn2_eff; // S
   const double* sn2x;    // Nstar
   const unsigned char* lchol;
@@ -1105,34 +1107,37 @@ struct IqrArgs {
 // One workgroup = 4 waves = 64 test points x one hyper-sample; wave w owns 16 of the points.
 // C[i][a] = Ka[i][a] -/+ sum_n Ks[n][i] Ctmp[n][a] on the fp64 matrix cores: the A operand Ks[n][i] comes from the
 // cross-kernel matrix k_pred_ks left in memory (one coalesced value per lane and k-step); the B operand -- rows of CtmpT,
-// the same for all points -- is staged through LDS in chunks of 16 rows shared by the four waves (double-buffered: the
-// global loads of chunk c+1 are in flight while chunk c feeds the MFMAs), which cuts the L2 traffic of the B stream by
-// four; NT = Nap/16 accumulator tiles live at once.
+// the same for all points -- is staged through LDS in chunks of 16 rows shared by its waves (double-buffered: the
+// global loads of chunk c+1 are in flight while chunk c feeds the MFMAs), which divides the L2 traffic of the B stream by
+// IQR_WPB; NT = Nap/16 accumulator tiles live at once.
 // Epilogue per element: tau2 = C^2/ys2_i, s_pred = sqrt(max(fs2a_a - tau2, 0)), zz = lnw_a + u s + log1p(-exp(-2 u s)),
 // then a log-sum-exp over a (16 lanes x NT tiles).
 #define IQR_KC 16
-#define IQR_LDS_BYTES(NT) ((size_t)(2 * IQR_KC * (16 * (NT) + 8) + 64 * 33 + 64) * sizeof(double))
+#define IQR_WPB 8                       // waves (16-point tiles) per workgroup
+#define IQR_PTS (16 * IQR_WPB)
+#define IQR_THREADS (64 * IQR_WPB)
+#define IQR_LDS_BYTES(NT) ((size_t)(2 * IQR_KC * (16 * (NT) + 8) + IQR_PTS * 33 + IQR_PTS) * sizeof(double))
 template <int NT>
-__global__ void __launch_bounds__(256) k_acq_iqr(IqrArgs a) {
+__global__ void __launch_bounds__(IQR_THREADS) k_acq_iqr(IqrArgs a) {
   constexpr int BS = 16 * NT + 8;          // padded row stride of a staged chunk
-  constexpr int PER = (IQR_KC * 16 * NT + 255) / 256;   // staged elements per thread
+  constexpr int PER = (IQR_KC * 16 * NT + IQR_THREADS - 1) / IQR_THREADS;   // staged elements per thread
   extern __shared__ double iq_lds[];
   double* BL = iq_lds;                              // [2][IQR_KC][BS]
-  double (*xs_s)[33] = (double (*)[33])(iq_lds + 2 * IQR_KC * BS);   // ell-scaled, centred test points of the 64-point block
-  double* ys2_s = iq_lds + 2 * IQR_KC * BS + 64 * 33;
+  double (*xs_s)[33] = (double (*)[33])(iq_lds + 2 * IQR_KC * BS);   // ell-scaled, centred test points of the workgroup's points
+  double* ys2_s = iq_lds + 2 * IQR_KC * BS + IQR_PTS * 33;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-  const int ib = blockIdx.x * 64, i0 = ib + 16 * wv, s = blockIdx.y;
+  const int ib = blockIdx.x * IQR_PTS, i0 = ib + 16 * wv, s = blockIdx.y;
   const int N = a.N, D = a.D, Nap = a.Nap;
   const double* h = a.hyp + (size_t)s * a.Nhyp;
   const double sf2 = exp(2.0 * h[D]);
   const double* mu = a.muv + (size_t)s * 2 * D;
   const double* iell = mu + D;
-  for (int idx = tid; idx < 64 * D; idx += 256) {
+  for (int idx = tid; idx < IQR_PTS * D; idx += IQR_THREADS) {
     const int i = idx / D, d = idx % D;
     const int gi = min(ib + i, a.Nstar - 1);
     xs_s[i][d] = a.Xs[gi + (size_t)a.Nstar * d] * iell[d] - mu[d];
   }
-  if (tid < 64) {
+  if (tid < IQR_PTS) {
     const int gi = min(ib + tid, a.Nstar - 1);
     ys2_s[tid] = a.fs2[gi + (size_t)a.Nstar * s] + a.sn2x[gi];
   }
@@ -1141,21 +1146,21 @@ __global__ void __launch_bounds__(256) k_acq_iqr(IqrArgs a) {
   for (int t = 0; t < NT; ++t) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
   const double* ct = a.CT + (size_t)s * N * Nap;
   const bool gvalid = i0 + li < a.Nstar;
-  const double* kcol = a.KsW + (size_t)s * N * a.Nstar + min(i0 + li, a.Nstar - 1);
+  const double* kcol = a.KsW + ((size_t)s * ((a.Nstar + 15) >> 4) + (i0 >> 4)) * (size_t)N * 16 + li;   // [s][point tile][n][16]
   const double isw = a.lchol[s] ? sqrt(a.sn2_eff[s]) : 1.0;   // undo sW = 1/sqrt(sn2_eff)
   // chunk c = rows 16c .. 16c+15 of CtmpT (contiguous in memory: row-major N x Nap), zero beyond N
   double pre[PER];
   auto fetch = [&](int c) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int e = tid + 256 * u;
+      const int e = tid + IQR_THREADS * u;
       pre[u] = (e < IQR_KC * Nap && 16 * c * Nap + e < N * Nap) ? ct[(size_t)16 * c * Nap + e] : 0.0;
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int e = tid + 256 * u;
+      const int e = tid + IQR_THREADS * u;
       if (e < IQR_KC * Nap) { const int row = e / Nap, col = e - row * Nap; BL[(buf * IQR_KC + row) * BS + col] = pre[u]; }
     }
   };
@@ -1167,7 +1172,7 @@ __global__ void __launch_bounds__(256) k_acq_iqr(IqrArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = 16 * c + 4 * q + lg;
-      dst[q] = (n < N && gvalid) ? kcol[(size_t)n * a.Nstar] : 0.0;
+      dst[q] = (n < N && gvalid) ? kcol[(size_t)n * 16] : 0.0;
     }
   };
   fetch(0);
@@ -1195,12 +1200,20 @@ __global__ void __launch_bounds__(256) k_acq_iqr(IqrArgs a) {
   const int xo = 16 * wv;   // this wave's rows of xs_s / ys2_s
   // the staged chunks are no longer needed: the exp table takes their place
   double* TAB = BL;
-  for (int t = tid; t < VB_EXP_TAB_N; t += 256) TAB[t] = c_exp2_tab[t];
+  for (int t = tid; t < VB_EXP_TAB_N; t += IQR_THREADS) TAB[t] = c_exp2_tab[t];
+  // ... and the ell-scaled, centred importance points XA[d][a] (each is needed by 4 lanes of every wave)
+  double* XA = BL + VB_EXP_TAB_N;
+  const double* xa = a.Xa + (a.per_s ? (size_t)s * a.Na * D : 0);
+  const bool xa_lds = (size_t)(VB_EXP_TAB_N + D * Nap) <= (size_t)2 * IQR_KC * BS;
+  if (xa_lds)
+    for (int e = tid; e < D * Nap; e += IQR_THREADS) {
+      const int d = e / Nap, aa_ = e - d * Nap;
+      XA[e] = aa_ < a.Na ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0;
+    }
   __syncthreads();
   // epilogue: lane (li, lg) holds C'[i = lg + 4r][a = 16t + li]
   const double u = 0.6745;
   const double sgn = a.lchol[s] ? -1.0 : 1.0;
-  const double* xa = a.Xa + (a.per_s ? (size_t)s * a.Na * D : 0);
   double zz[NT][4];
   double mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -1209,7 +1222,7 @@ __global__ void __launch_bounds__(256) k_acq_iqr(IqrArgs a) {
     const bool av = aa_ < a.Na;
     double c4[4] = {0.0, 0.0, 0.0, 0.0};
     for (int d = 0; d < D; ++d) {
-      const double xv = av ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0;
+      const double xv = xa_lds ? XA[d * Nap + aa_] : (av ? xa[aa_ + (size_t)a.Na * d] * iell[d] - mu[d] : 0.0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const double tt = xs_s[xo + lg + 4 * r][d] - xv; c4[r] = fma(tt, tt, c4[r]); }
     }
