@@ -173,6 +173,28 @@ def test_rank1_chain_on_device_and_low_noise_branch(va):
         assert np.max(np.abs(a["L"] - c["L"])) < 1e-6 * scale and relerr(a["alpha"], c["alpha"]) < 1e-5
 
 
+@pytest.mark.parametrize("N", [39, 1070])
+def test_low_noise_posterior_inverse(va, N):
+    """Low-noise samples store L = -inv(K + sn2 I) (gplite_core.m:84,98), formed by k_spd_inverse: paired column blocks with
+    an odd block count (N = 39), and N = 1070 where the two slabs no longer share the LDS (one column block per workgroup)."""
+    rng = np.random.default_rng(N)
+    D = 3
+    X = 1.5 * rng.standard_normal((N, D))
+    y = -0.5 * np.sum(X ** 2, axis=1) + 0.1 * rng.standard_normal(N)
+    hyp = np.zeros((D + 2 + 2 * D + 1, 1))
+    hyp[:D, 0] = np.log(0.25)                  # short length scales keep K + sn2 I well conditioned at sn2 = 9e-8
+    hyp[D, 0] = np.log(np.std(y))
+    hyp[D + 1, 0] = np.log(3e-4)
+    hyp[D + 2, 0] = np.max(y)
+    hyp[D + 3 + D:, 0] = np.log(2.0)
+    gp = va.gplite_post(hyp, X, y, 1, 4)
+    ref = R.gplite_post(hyp, X, y, meanfun=4)
+    assert not gp["post"][0]["Lchol"] and not ref["post"][0]["Lchol"]
+    Lr = ref["post"][0]["L"]
+    assert np.max(np.abs(gp["post"][0]["L"] - Lr)) < 1e-7 * np.max(np.abs(Lr))
+    assert relerr(gp["post"][0]["alpha"], ref["post"][0]["alpha"]) < 1e-6
+
+
 def test_pred_and_acq_chunking_over_many_points(va):
     """Sweeps whose S x N x Nstar cross-kernel matrix would exceed 1 GiB are cut into chunks of test points; the
     chunked result equals the one-shot result up to the sq_dist centring constant (rounding)."""

@@ -79,9 +79,9 @@ def test_nlz_batch_matches_oracle(va, cfg):
 
 @pytest.mark.parametrize("N,D", [(16, 2), (17, 3), (48, 13), (81, 20), (70, 32), (1080, 6)])
 def test_nlz_inverse_kernel_shapes(va, N, D):
-    """Kinv = L\\(L'\\eye(N)) (gplite_core.m:240) is formed by k_spd_inverse from paired column blocks: one block (N <= 16),
-    an odd block count (the middle block has no partner), D padded to the next kernel instantiation (13 -> 16, 20 -> 24),
-    and N = 1080, where the paired slabs no longer fit the LDS and one column block per workgroup is used."""
+    """Kinv = L\\(L'\\eye(N)) (gplite_core.m:240) is formed as T'T, T = inv(L') (k_tri_inverse + k_syrk_tt on 64 x 64 tiles):
+    a single 16-block (N <= 16), N not a multiple of the tile sizes, D padded to the next kernel instantiation
+    (13 -> 16, 20 -> 24, 32), and N = 1080 near the LDS limit of the triangular-solve slab."""
     rng = np.random.default_rng(N)
     gp, draw = make_gp(rng, N, D, 4, (1, 0, 0))
     H = np.stack([draw() for _ in range(2)], axis=1)

@@ -324,10 +324,18 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(nlZ, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
   if (compute_grad) {
-    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240): both triangular solves of the identity in one
-    // kernel that only forms the lower triangle (k_spd_inverse)
+    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
+    // identity (k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores (k_syrk_tt);
+    // only the upper triangle is formed -- the part k_nlz_grad reads
+    TmpBuf dTT;
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
-    SPD_INVERSE_LAUNCH(ctx, N, B, st, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dKi.as<double>());
+    HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
+    if (f.tlds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.tlds));
+    hipLaunchKernelGGL(k_tri_inverse, dim3((N + TR_CB - 1) / TR_CB, B, 1), dim3(64), f.tlds, st, N, B, f.dA.as<double>(), f.dfinv.as<double>(),
+                       f.dones.as<unsigned char>(), dTT.as<double>(), 1);
+    hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
+                       dKi.as<double>());
     std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
     for (int b = 0; b < B; ++b)
       noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);
@@ -394,7 +402,7 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
     HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)S * N * N * 8, (void**)&t) : hipMalloc((void**)&t, (size_t)S * N * N * 8));
     if (tlds0 > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds0));
-    hipLaunchKernelGGL(k_tri_inverse, dim3((N + TR_CB - 1) / TR_CB, S, 1), dim3(64), tlds0, st, N, S, gp->L, gp->d_finv, gp->d_lchol, t);
+    hipLaunchKernelGGL(k_tri_inverse, dim3((N + TR_CB - 1) / TR_CB, S, 1), dim3(64), tlds0, st, N, S, gp->L, gp->d_finv, gp->d_lchol, t, 0);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) {
       if (gp->pooled) pool_put(ctx, t); else (void)hipFree(t);

@@ -218,8 +218,9 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
 // low-noise posteriors (gplite_core.m:84).
 // T = inv(R') = R' \ I (lower triangular), one wave per 16 columns: the identity slab is formed in LDS and the substitution
 // starts at the column block's own rows (everything above is zero and is written as such).
+// transposed != 0 writes T' instead (row k of inv(R') contiguous: the operand layout k_syrk_tt wants).
 __global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
-                                                    const unsigned char* __restrict__ lchol, double* __restrict__ T) {
+                                                    const unsigned char* __restrict__ lchol, double* __restrict__ T, int transposed) {
   extern __shared__ double lds[];
   const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
   if (!lchol[s]) return;
@@ -230,7 +231,68 @@ __global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* 
     for (int i = lane; i < Np; i += 64) V[i * TR_VS + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
   trsm_wsync();
   trsm_fwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane, cb);
-  trsm_slab_store(N, N, k0, T + (size_t)s * N * N, V, lane);
+  if (!transposed) {
+    trsm_slab_store(N, N, k0, T + (size_t)s * N * N, V, lane);
+  } else {
+    // TT[k][i] = T[k][i] at k * N + i: 4 rows x 16 consecutive columns per store; rows above the block are zero
+    double* TT = T + (size_t)s * N * N;
+    const int cc = lane & 15;
+    if (k0 + cc < N)
+      for (int k = lane >> 4; k < N; k += 4) TT[(size_t)k * N + k0 + cc] = V[k * TR_VS + cc];
+  }
+}
+
+// C = T'T for lower-triangular T given as TT[k][i] (row k contiguous): the 64 x 64 tiles on and above the diagonal (column j,
+// row i at j * N + i; diagonal tiles in full): C[i][j] = sum_{k >= max(i, j)} TT[k][i] TT[k][j].  With T = inv(R') this is inv(R'R), the inverse the
+// marginal-likelihood gradient contracts with (gplite_core.m:240), formed by a parallel rank-k update on the matrix cores
+// instead of a second, sequential triangular solve.  One workgroup = 4 waves = a 64 x 64 tile (2 x 2 waves of 32 x 32);
+// the roles of the MFMA operands are swapped (rows <-> j) so that the stores run along i.
+__global__ void __launch_bounds__(256) k_syrk_tt(int N, const double* __restrict__ TTall, const unsigned char* __restrict__ on,
+                                                 double* __restrict__ Call) {
+  const int ti = blockIdx.x, tj = blockIdx.y, s = blockIdx.z;
+  if (!on[s] || ti > tj) return;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  const int i0 = ti * 64 + 32 * (wv & 1), j0 = tj * 64 + 32 * (wv >> 1);
+  if (i0 >= N || j0 >= N) return;                      // sub-tile outside the matrix (diagonal tiles are formed in full)
+  const double* TT = TTall + (size_t)s * N * N;
+  double* C = Call + (size_t)s * N * N;
+  tmf4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (tmf4){0.0, 0.0, 0.0, 0.0};
+  const int kmin = (j0 > i0 ? j0 : i0) & ~3;           // rows above max(i, j) hold zeros in one of the two factors
+  const int ia[2] = {i0 + li, i0 + 16 + li}, ja[2] = {j0 + li, j0 + 16 + li};
+  double an[2], bn[2];
+  auto ld = [&](int k, double* av, double* bv) {
+    const int kk = k + lg;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      av[u] = (kk < N && ja[u] < N) ? TT[(size_t)kk * N + ja[u]] : 0.0;   // "A" operand: the j side (rows of the accumulator)
+      bv[u] = (kk < N && ia[u] < N) ? TT[(size_t)kk * N + ia[u]] : 0.0;   // "B" operand: the i side (columns)
+    }
+  };
+  double ac[2], bc[2];
+  ld(kmin, ac, bc);
+  for (int k = kmin; k < N; k += 4) {
+    ld(k + 4, an, bn);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[a], bc[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+  }
+  // acc[a][b]: row = j0 + 16a + lg + 4r, column = i0 + 16b + li
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + 16 * a + lg + 4 * r, i = i0 + 16 * b + li;
+        if (j < N && i < N && (ti == tj || i <= j)) C[(size_t)j * N + i] = acc[a][b][r];
+      }
 }
 
 // Two waves per workgroup take the column blocks cb and nblk-1-cb: a long and a short solve, so that every workgroup does
