@@ -171,8 +171,8 @@ vbmc_status vbmc_gp_rank1_solves(vbmc_ctx* ctx, const vbmc_gp* gp, const double*
  * The a'b contraction runs on v_mfma_f64_16x16x4_f64. */
 /* gp = gplite_post(gp, xstar, ystar, [], [], [], [], 1): rank-one append of one observation, entirely on the device
  * (gplite/gplite_post.m:173-251).  X_new is the (N+1) x D training matrix with xstar as its last row; mstar, vstar (S each)
- * are [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1) (:189) and sn2_eff (S) the noise at the new point times
- * sn2_mult (:196-207), which the caller has.  *out is a NEW surrogate handle with N+1 points (the old one stays valid);
+ * are [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1) (:189) -- or both NULL, in which case they are computed here from
+ * the solves of the append itself -- and sn2_eff (S) the noise at the new point times sn2_mult (:196-207), which the caller has.  *out is a NEW surrogate handle with N+1 points (the old one stays valid);
  * alpha_new ((N+1) x S) and L_new ((N+1) x (N+1) x S) are optional host copies of the new gp.post(s).alpha / .L. */
 vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, const double* X_new, double ystar, const double* mstar,
                                  const double* vstar, const double* sn2_eff, double* alpha_new, double* L_new, vbmc_gp** out);

@@ -17,14 +17,13 @@ if nargin < 9; outwarpfun = []; end
 
 if isstruct(hyp) && update1 && isempty(s2) && isempty(outwarpfun) && size(X,1) == 1 && rank1_supported(hyp)
     gp = hyp; xstar = X; ystar = y;
-    [mstar,vstar] = gplite_pred(gp,xstar,ystar,[],1,1);            % :189 (through the shim)
-    Ns = numel(gp.post); sn2_eff = zeros(Ns,1);
+    Ns = numel(gp.post); sn2_eff = zeros(Ns,1);                    % [mstar,vstar] of :189 are formed inside the library
     for s = 1:Ns
         hn = gp.post(s).hyp(gp.Ncov+1:gp.Ncov+gp.Nnoise);
         sn2_eff(s) = gplite_noisefun(hn,xstar,gp.noisefun,ystar,[])*gp.post(s).sn2_mult;   % :205-207
     end
     Xn = [gp.X; xstar];
-    [alpha,L,hnew] = vbmc_hip_mex('gp_rank1',vbmc_hip_gp_handle(gp),Xn,ystar,mstar(:),vstar(:),sn2_eff);
+    [alpha,L,hnew] = vbmc_hip_mex('gp_rank1',vbmc_hip_gp_handle(gp),Xn,ystar,[],[],sn2_eff);
     for s = 1:Ns
         gp.post(s).alpha = alpha(:,s);
         gp.post(s).L = L(:,:,s);

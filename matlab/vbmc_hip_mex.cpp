@@ -243,15 +243,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   }
 
   if (!strcmp(cmd, "gp_rank1")) {
-    // (h, Xnew, ystar, mstar, vstar, sn2_eff) -> alpha (N+1 x S), L (N+1 x N+1 x S), new handle
+    // (h, Xnew, ystar, mstar | [], vstar | [], sn2_eff) -> alpha (N+1 x S), L (N+1 x N+1 x S), new handle
     vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
     const mxArray* Xn = prhs[2];
-    const int N1 = (int)mxGetM(Xn), S = (int)mxGetNumberOfElements(prhs[4]);
+    const int N1 = (int)mxGetM(Xn), S = (int)mxGetNumberOfElements(prhs[6]);
     mwSize ld[3] = {(mwSize)N1, (mwSize)N1, (mwSize)S};
     plhs[0] = mxCreateDoubleMatrix(N1, S, mxREAL);
     mxArray* L = mxCreateNumericArray(3, ld, mxDOUBLE_CLASS, mxREAL);
     vbmc_gp* hn = nullptr;
-    vbmc_status st = vbmc_gp_rank1_update(g_ctx, h, mxGetDoubles(Xn), mxGetScalar(prhs[3]), mxGetDoubles(prhs[4]), mxGetDoubles(prhs[5]),
+    vbmc_status st = vbmc_gp_rank1_update(g_ctx, h, mxGetDoubles(Xn), mxGetScalar(prhs[3]), dbl(prhs[4]), dbl(prhs[5]),
                                           mxGetDoubles(prhs[6]), mxGetDoubles(plhs[0]), nlhs > 1 ? mxGetDoubles(L) : nullptr, &hn);
     if (st != VBMC_OK) fail(st);
     if (nlhs > 1) plhs[1] = L;

@@ -860,8 +860,8 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
                                             const double* vstar, const double* sn2_eff, double* alpha_new, double* L_new,
                                             vbmc_gp** out) {
   if (!ctx) return VBMC_ERR_INVALID;
-  if (!gp || !X_new || !mstar || !vstar || !sn2_eff || !out)
-    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_update: null argument");
+  if (!gp || !X_new || !sn2_eff || !out || ((mstar == nullptr) != (vstar == nullptr)))
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_update: null argument (mstar and vstar go together)");
   *out = nullptr;
   if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_update needs gp.post(s).L on the device");
   const int N = gp->N, D = gp->D, S = gp->S, N1 = N + 1;
@@ -876,11 +876,18 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
   for (int s = 0; s < S; ++s) {
     sc[s * 4 + 0] = sn2_eff[s];
     sc[s * 4 + 1] = std::exp(2.0 * gp->hyp_host[(size_t)s * gp->Nhyp + D]);
-    sc[s * 4 + 2] = (mstar[s] - ystar) / vstar[s];
-    sc[s * 4 + 3] = vstar[s];
+    sc[s * 4 + 2] = mstar ? (mstar[s] - ystar) / vstar[s] : 0.0;
+    sc[s * 4 + 3] = mstar ? vstar[s] : 0.0;
   }
   HIP_TRY(ctx, dsc.alloc(ctx, sc.size() * 8));
   HIP_TRY(ctx, hipMemcpyAsync(dsc.p, sc.data(), sc.size() * 8, hipMemcpyHostToDevice, st));
+  if (!mstar) {   // the prediction at the new point from the solves at hand (no separate gplite_pred pass)
+    TmpBuf dx1;
+    HIP_TRY(ctx, dx1.alloc(ctx, (size_t)D * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(dx1.p, xs.data(), (size_t)D * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rank1_stats, dim3(S), dim3(256), 0, st, N, D, gp->Nhyp, gp->Ncov + gp->Nnoise, gp->meanfun, gp->hyp, dx1.as<double>(),
+                       gp->alpha, gp->d_lchol, dKs.as<double>(), dV.as<double>(), dXo.as<double>(), ystar, dsc.as<double>());
+  }
   HIP_TRY(ctx, dLn.alloc(ctx, (size_t)S * N1 * N1 * 8));
   HIP_TRY(ctx, dan.alloc(ctx, (size_t)S * N1 * 8));
   hipLaunchKernelGGL(k_rank1_assemble, dim3(N1, S), dim3(256), 0, st, N, gp->L, gp->alpha, gp->d_lchol, dV.as<double>(), dXo.as<double>(),

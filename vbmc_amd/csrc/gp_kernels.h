@@ -413,6 +413,37 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
   for (int i = tid; i < N; i += ASOLVE_THREADS) Xo[(size_t)s * N + i] = v[i];
 }
 
+// [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1, 1) (gplite_post.m:189) from the solves the append needs anyway:
+//   mstar = m(xstar) + Ks' alpha                                                         (gplite_pred.m:83)
+//   vstar = max(fs2, 0) + sn2_eff,  fs2 = kss - |v|^2/sn2_eff (factor) or kss + Ks' x (stored inverse)   (:99-104,120-121)
+// and the coefficient (mstar - ystar)/vstar of the alpha update; writes them over sc[s][2], sc[s][3].
+__global__ void __launch_bounds__(256) k_rank1_stats(int N, int D, int Nhyp, int moff, int meanfun, const double* __restrict__ hyp,
+                                                     const double* __restrict__ xstar, const double* __restrict__ alpha,
+                                                     const unsigned char* __restrict__ lchol, const double* __restrict__ Ks,
+                                                     const double* __restrict__ V, const double* __restrict__ Xs, double ystar,
+                                                     double* __restrict__ sc) {
+  __shared__ double red[256];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const bool ch = lchol[s] != 0;
+  const double* ks = Ks + (size_t)s * N;
+  double d1 = 0.0, d2 = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    d1 = fma(ks[n], alpha[(size_t)s * N + n], d1);
+    const double t = ch ? V[(size_t)s * N + n] : 0.0;
+    d2 = ch ? fma(t, t, d2) : fma(ks[n], Xs[(size_t)s * N + n], d2);
+  }
+  d1 = block_sum(d1, red);
+  d2 = block_sum(d2, red);
+  if (tid == 0) {
+    const double sn2 = sc[s * 4 + 0], kss = sc[s * 4 + 1];
+    const double mstar = gp_meanfun(meanfun, D, hyp + (size_t)s * Nhyp + moff, xstar, 1) + d1;
+    const double fs2 = ch ? kss - d2 / sn2 : kss + d2;
+    const double vstar = fmax(fs2, 0.0) + sn2;
+    sc[s * 4 + 2] = (mstar - ystar) / vstar;
+    sc[s * 4 + 3] = vstar;
+  }
+}
+
 // Rank-one append of one observation (gplite/gplite_post.m:226-245): column j of the new (N+1) x (N+1) matrix per workgroup.
 //   factor samples:   Lnew = [L, v/sn2_eff; 0, sqrt(1 + Kss/sn2_eff - |v/sn2_eff|^2)]            (:228-232)
 //   inverse samples:  Lnew = [L + vv*au', -vv; -vv', -1/vstar],  au = -x, vv = -au/vstar          (:234-236)

@@ -150,8 +150,7 @@ def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, need_L=True, engine=None
                            gp["noisefun"], s2new, engine=engine)
     N, D = np.asarray(gp["X"]).shape
     S = len(gp["post"])
-    ymu, ys2, _, _ = gplite_pred(gp, xstar, np.array([ystar]), None, True, engine=engine)  # :189 (mstar, vstar)
-    mstar, vstar = f64(np.asarray(ymu).reshape(S)), f64(np.asarray(ys2).reshape(S))
+    # [mstar, vstar] of :189 are formed inside the library from the solves of the append itself
     dgp = _device_gp_with_noise(engine, gp)
     Ncov = gp["Ncov"]
     sn2_eff = np.zeros(S)
@@ -167,7 +166,7 @@ def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, need_L=True, engine=None
     alpha = np.empty((N + 1, S), order="F")
     Lh = np.empty((N + 1, N + 1, S), order="F") if need_L else None
     h = C.c_void_p()
-    ctx.check(ctx.lib.vbmc_gp_rank1_update(ctx.h, dgp.h, ptr(Xn), C.c_double(ystar), ptr(mstar), ptr(vstar), ptr(f64(sn2_eff)), ptr(alpha),
+    ctx.check(ctx.lib.vbmc_gp_rank1_update(ctx.h, dgp.h, ptr(Xn), C.c_double(ystar), None, None, ptr(f64(sn2_eff)), ptr(alpha),
                                            ptr(Lh) if need_L else None, C.byref(h)))
     out = {k: v for k, v in gp.items() if k != "post"}
     out["X"] = Xn
