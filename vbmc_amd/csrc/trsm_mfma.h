@@ -263,25 +263,33 @@ __global__ void __launch_bounds__(256) k_syrk_tt(int N, const double* __restrict
     for (int b = 0; b < 2; ++b) acc[a][b] = (tmf4){0.0, 0.0, 0.0, 0.0};
   const int kmin = (j0 > i0 ? j0 : i0) & ~3;           // rows above max(i, j) hold zeros in one of the two factors
   const int ia[2] = {i0 + li, i0 + 16 + li}, ja[2] = {j0 + li, j0 + 16 + li};
-  double an[2], bn[2];
-  auto ld = [&](int k, double* av, double* bv) {
-    const int kk = k + lg;
+  // groups of SY_G k-steps: the 4 * SY_G operand loads of the next group are in flight during the 4 * SY_G MFMAs of this one
+  constexpr int SY_G = 8;
+  double ac[SY_G][2], bc[SY_G][2], an[SY_G][2], bn[SY_G][2];
+  auto ldg = [&](int k0, double (*av)[2], double (*bv)[2]) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      av[u] = (kk < N && ja[u] < N) ? TT[(size_t)kk * N + ja[u]] : 0.0;   // "A" operand: the j side (rows of the accumulator)
-      bv[u] = (kk < N && ia[u] < N) ? TT[(size_t)kk * N + ia[u]] : 0.0;   // "B" operand: the i side (columns)
+    for (int g = 0; g < SY_G; ++g) {
+      const int kk = k0 + 4 * g + lg;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        av[g][u] = (kk < N && ja[u] < N) ? TT[(size_t)kk * N + ja[u]] : 0.0;   // "A" operand: the j side (rows of the accumulator)
+        bv[g][u] = (kk < N && ia[u] < N) ? TT[(size_t)kk * N + ia[u]] : 0.0;   // "B" operand: the i side (columns)
+      }
     }
   };
-  double ac[2], bc[2];
-  ld(kmin, ac, bc);
-  for (int k = kmin; k < N; k += 4) {
-    ld(k + 4, an, bn);
+  ldg(kmin, ac, bc);
+  for (int k = kmin; k < N; k += 4 * SY_G) {
+    if (k + 4 * SY_G < N) ldg(k + 4 * SY_G, an, bn);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int g = 0; g < SY_G; ++g)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[a], bc[b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g][a], bc[g][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < SY_G; ++g)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { ac[g][u] = an[g][u]; bc[g][u] = bn[g][u]; }
   }
   // acc[a][b]: row = j0 + 16a + lg + 4r, column = i0 + 16b + li
 #pragma unroll
