@@ -942,19 +942,24 @@ __global__ void __launch_bounds__(256) k_nlz_final(int N, int D, int Nhyp, int N
   const int moff = D + 1 + Nnoise;
   const double* hm = hyp + (size_t)b * Nhyp + moff;
   const double* al = alpha + (size_t)b * N;
-  for (int i = 0; i < Nmean; ++i) {
+  // -dm' * alpha, one mean-function hyper-parameter per wave at a time (fixed-order wave sums, no workgroup barriers)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int i = wave; i < Nmean; i += 4) {
     double t = 0.0;
-    for (int n = tid; n < N; n += 256) {
-      double dm;
-      if (i == 0) dm = 1.0;
-      else if (i <= D) { const int d = i - 1; const double om = exp(hm[D + 1 + d]); dm = (X[n + (size_t)N * d] - hm[1 + d]) / (om * om); }
-      else { const int d = i - 1 - D; const double z = (X[n + (size_t)N * d] - hm[1 + d]) / exp(hm[D + 1 + d]); dm = z * z; }
-      t = fma(dm, al[n], t);
+    if (i == 0) {
+      for (int n = lane; n < N; n += 64) t += al[n];
+    } else {
+      const int d = i <= D ? i - 1 : i - 1 - D;
+      const double om = exp(hm[D + 1 + d]), xm = hm[1 + d];
+      for (int n = lane; n < N; n += 64) {
+        const double z = (X[n + (size_t)N * d] - xm) / om;
+        t = fma(i <= D ? z / om : z * z, al[n], t);     // gplite_meanfun.m:433-435
+      }
     }
-    t = block_sum(t, red);
-    if (tid == 0) g[moff + i] = -t;
+    t = wave_sum(t);
+    if (lane == 0) g[moff + i] = -t;
   }
-  (void)meanfun;
+  (void)meanfun; (void)red;
 }
 
 
