@@ -258,7 +258,8 @@ def test_block_sparse_mode_is_exact_to_rounding(va):
 
 
 SWEEP = [(1, 3), (7, 16), (14, 17), (15, 33), (18, 64), (22, 65), (23, 40), (30, 20), (32, 12), (5, 128), (3, 130), (9, 1),
-         (26, 100), (12, 96), (10, 97), (32, 70)]   # the last four: components split over two waves (64 < K <= 128)
+         (26, 100), (12, 96), (10, 97), (32, 70),   # these four: components split over two waves (64 < K <= 128)
+         (32, 140)]                                  # largest D with a K beyond the MFMA kernels: VALU fallback, big finalize record
 
 
 @pytest.mark.parametrize("dk", SWEEP, ids=["D%dK%d" % t for t in SWEEP])
@@ -274,6 +275,14 @@ def test_kernel_instantiation_sweep(va, dk):
     assert relerr(dH, ref["dH"]) < RT_GRAD and relerr(dF, ref["dF"]) < RT_GRAD
     (Fv,) = va.negelcbo_vbmc(theta, 0, vp, gp, Ns, 0, 0, nargout=1, eps=eps)
     assert relerr(Fv, ref["F"]) < RT_VAL
+
+
+def test_oversized_mixture_is_refused_cleanly(va):
+    """D x K beyond what k_finalize keeps in LDS: a clean VBMC_ERR_UNSUPPORTED (the shim falls through to the reference),
+    not a failed launch."""
+    p, gp, vp, theta = problem(5, 32, 40, 200, 1)
+    with pytest.raises(va.VbmcUnsupported):
+        va.negelcbo_vbmc(theta, 0, vp, gp, 0, 1, 0)
 
 
 def test_tiny_sigma_components_do_not_break_the_exp(va):

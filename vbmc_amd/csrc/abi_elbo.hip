@@ -397,6 +397,9 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   if (a->eps_mode < 0 || a->eps_mode > 2) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode must be 0, 1 or 2");
   P.dt = pick_dt(D);
   if (P.dt < 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d not accelerated", D);
+  // k_finalize keeps three T-vectors, the D x K soft-bound table and its reduction scratch in LDS
+  if ((FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8) * sizeof(double) > 160 * 1024)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d with K = %d (4 D K + 9 K > 19400) not accelerated", D, K);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   VpLayout VL{D, K};
