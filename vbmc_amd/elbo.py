@@ -35,6 +35,7 @@ class Engine:
         key = id(post)
         ent = self._gp_cache.get(key)
         if ent is not None and ent[0] is post and (ent[2] or not need_L) and ent[3] == self._fingerprint(gp):
+            self._gp_cache[key] = self._gp_cache.pop(key)   # most recently used last
             return ent[1]
         S = len(post)
         X = np.asarray(gp["X"], dtype=np.float64)
