@@ -180,29 +180,47 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
 #define CH_THREADS 1024
 #define CHOL_LDS_BYTES(N) ((size_t)(2 * 16 * 17 + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
 
-// Upper Cholesky of the 16 x 16 tile held in LDS (Dg, row stride 17; identity beyond nb) by ONE wave: wave-synchronous,
-// no workgroup barriers (the LDS operations of a wave complete in order).  Di[t] = 1 / R[t][t].  A non-positive or
-// non-finite pivot records kb + t + 1 in *s_fail (first failure wins) and is replaced by 1 so that the sweep completes.
+// Upper Cholesky of the 16 x 16 tile held in LDS (Dg, row stride 17; identity beyond nb) by ONE wave, in registers: lane c
+// (c = lane & 15; the four 16-lane groups work redundantly) gathers column c, the 16 pivot steps run on registers with the
+// pivot row broadcast through v_readlane (all lane indices are compile-time constants), and the factor goes back to LDS
+// once -- no LDS round trip or wave barrier per pivot.  Di[t] = 1 / R[t][t].  A non-positive or non-finite pivot records
+// kb + t + 1 in *s_fail (first failure wins) and is replaced by 1 so that the sweep completes.
+__device__ __forceinline__ double chol_readlane(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void chol_diag_tile(double* __restrict__ Dg, double* __restrict__ Di, int nb, int kb, int lane,
                                                int* s_fail) {
-  for (int t = 0; t < nb; ++t) {
-    double piv = Dg[t * 17 + t];
-    if (!(piv > 0.0) || !isfinite(piv)) {
-      if (lane == 0 && *s_fail == 0) *s_fail = kb + t + 1;
+  const int c = lane & 15;
+  double a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = Dg[r * 17 + c];
+  int fail = 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    double piv = chol_readlane(a[t], t);
+    if (t < nb && (!(piv > 0.0) || !isfinite(piv))) {     // uniform: piv is a broadcast value
+      if (fail == 0) fail = kb + t + 1;
       piv = 1.0;
     }
     const double rs = sqrt(piv);
     const double ri = 1.0 / rs;                    // row scaled by the reciprocal, as LAPACK's dpotf2 does
-    __builtin_amdgcn_wave_barrier();
-    if (lane == t) { Dg[t * 17 + t] = rs; Di[t] = ri; }
-    else if (lane > t && lane < nb) Dg[t * 17 + lane] *= ri;
-    __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < 256; e += 64) {
-      const int ii = e >> 4, jj = e & 15;
-      if (ii > t && jj >= ii && jj < nb) Dg[ii * 17 + jj] -= Dg[t * 17 + ii] * Dg[t * 17 + jj];
+    a[t] = (c == t) ? rs : a[t] * ri;              // R[t][c] for c > t (entries with c < t are never read)
+    if (lane == t) Di[t] = ri;
+#pragma unroll
+    for (int ii = t + 1; ii < 16; ++ii) {
+      const double rti = chol_readlane(a[t], ii);  // R[t][ii]
+      a[ii] = (c >= ii) ? fma(-rti, a[t], a[ii]) : a[ii];
     }
-    __builtin_amdgcn_wave_barrier();
   }
+  if (fail && lane == 0 && *s_fail == 0) *s_fail = fail;
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Dg[r * 17 + c] = a[r];
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 // One 1024-thread workgroup (16 waves) per matrix; per 16-column block step:
@@ -322,30 +340,38 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
         if (ii < nb2 && jj < nb2) A[(size_t)(t0 + ii) + (size_t)N * (t0 + jj)] = (ii <= jj) ? Dn[ii * 17 + jj] : 0.0;
       }
     } else {
-      double curv[4], nxt[4];
-      int u = wave, ti = 0, tj = 0;           // pairs 1, 2, ... over waves 1..15
-      if (u < npair) { decode(u, ti, tj); load_tile(ti, tj, curv); }
-      while (u < npair) {
-        const int un = u + (CH_THREADS / 64 - 1);
-        int tin = 0, tjn = 0;
-        if (un < npair) { decode(un, tin, tjn); load_tile(tin, tjn, nxt); }
-        const int i0 = ti << 4, j0 = tj << 4;
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      // pairs 1, 2, ... dealt to waves 1..15, taken four at a time: the 16 loads of a group are issued together, so one L2
+      // round trip is paid per four tiles (one tile ahead left every tile waiting a full round trip; the 128-VGPR budget of
+      // a 1024-thread workgroup has no room for a second group in flight)
+      constexpr int CH_G = 4, WSTR = CH_THREADS / 64 - 1;
+      for (int u = wave; u < npair; u += CH_G * WSTR) {
+        double cv[CH_G][4];
+        int gi[CH_G], gj[CH_G];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double pa = P[(size_t)(4 * q + lg) * Np + j0 + li];
-          const double pb = P[(size_t)(4 * q + lg) * Np + i0 + li];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
-        }
-        const int i = i0 + li;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int j = j0 + lg + 4 * reg;
-          if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] = curv[reg] - acc[reg];
+        for (int g = 0; g < CH_G; ++g) {
+          const int uu = u + g * WSTR;
+          gi[g] = -1; gj[g] = 0;
+          if (uu < npair) { decode(uu, gi[g], gj[g]); load_tile(gi[g], gj[g], cv[g]); }
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) curv[reg] = nxt[reg];
-        u = un; ti = tin; tj = tjn;
+        for (int g = 0; g < CH_G; ++g) {
+          if (gi[g] >= 0) {
+            const int i0 = gi[g] << 4, j0 = gj[g] << 4;
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double pa = P[(size_t)(4 * q + lg) * Np + j0 + li];
+              const double pb = P[(size_t)(4 * q + lg) * Np + i0 + li];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
+            }
+            const int i = i0 + li;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int j = j0 + lg + 4 * reg;
+              if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] = cv[g][reg] - acc[reg];
+            }
+          }
+        }
       }
     }
     __syncthreads();
