@@ -308,12 +308,14 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
       while (c * (c + 1) / 2 > u) --c;
       tj = c; ti = u - c * (c + 1) / 2;
     };
+    double* At = A + (size_t)t0 + (size_t)N * t0;     // trailing matrix; 32-bit offsets inside it (N <= 1136)
     auto load_tile = [&](int ti_, int tj_, double* dst) {
-      const int i = (ti_ << 4) + li;
+      const int i = (ti_ << 4) + li, jb = (tj_ << 4) + lg;
+      const int off = jb * N + i;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int j = (tj_ << 4) + lg + 4 * reg;
-        dst[reg] = (i < ntr && j < ntr && i <= j) ? A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] : 0.0;
+        const int j = jb + 4 * reg;
+        dst[reg] = (i < ntr && j < ntr && i <= j) ? At[off + 4 * reg * N] : 0.0;
       }
     };
     if (wave == 0) {
@@ -343,32 +345,38 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
       // pairs 1, 2, ... dealt to waves 1..15, taken four at a time: the 16 loads of a group are issued together, so one L2
       // round trip is paid per four tiles (one tile ahead left every tile waiting a full round trip; the 128-VGPR budget of
       // a 1024-thread workgroup has no room for a second group in flight)
+      // The pair index advances by WSTR per tile; (ti, tj) follow it incrementally (column tj of the triangle holds the
+      // pairs ti = 0..tj) instead of being decoded with a square root per tile: with four waves per SIMD the per-tile
+      // bookkeeping, not the matrix cores, set the pace of this phase.
       constexpr int CH_G = 4, WSTR = CH_THREADS / 64 - 1;
+      int ti, tj;
+      decode(wave, ti, tj);
       for (int u = wave; u < npair; u += CH_G * WSTR) {
         double cv[CH_G][4];
         int gi[CH_G], gj[CH_G];
 #pragma unroll
         for (int g = 0; g < CH_G; ++g) {
-          const int uu = u + g * WSTR;
-          gi[g] = -1; gj[g] = 0;
-          if (uu < npair) { decode(uu, gi[g], gj[g]); load_tile(gi[g], gj[g], cv[g]); }
+          gi[g] = (u + g * WSTR < npair) ? ti : -1;
+          gj[g] = tj;
+          if (gi[g] >= 0) load_tile(ti, tj, cv[g]);
+          ti += WSTR;
+          while (ti > tj) { ti -= tj + 1; ++tj; }
         }
 #pragma unroll
         for (int g = 0; g < CH_G; ++g) {
           if (gi[g] >= 0) {
             const int i0 = gi[g] << 4, j0 = gj[g] << 4;
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            const double* pj = P + (size_t)lg * Np + j0 + li;
+            const double* pi = P + (size_t)lg * Np + i0 + li;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const double pa = P[(size_t)(4 * q + lg) * Np + j0 + li];
-              const double pb = P[(size_t)(4 * q + lg) * Np + i0 + li];
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, acc, 0, 0, 0);
-            }
-            const int i = i0 + li;
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[4 * q * Np], pi[4 * q * Np], acc, 0, 0, 0);
+            const int i = i0 + li, jb = j0 + lg;
+            const int off = jb * N + i;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-              const int j = j0 + lg + 4 * reg;
-              if (i < ntr && j < ntr && i <= j) A[(size_t)(t0 + i) + (size_t)N * (t0 + j)] = cv[g][reg] - acc[reg];
+              const int j = jb + 4 * reg;
+              if (i < ntr && j < ntr && i <= j) At[off + 4 * reg * N] = cv[g][reg] - acc[reg];
             }
           }
         }
