@@ -1,6 +1,7 @@
 """CPU: the host-side mirror (vbmc_amd/vp.py, optimize.py) against the oracle's restatement of the same
 reference functions -- theta packing, rescaling, soft bounds, MATLAB sort semantics, Adam, vbinit shapes."""
 import numpy as np
+import pytest
 
 import vbmc_amd.optimize as opt
 import vbmc_amd.vp as vpm
@@ -106,3 +107,28 @@ def test_vbmc_rnd_moments_and_balanced_split():
     assert Xb.shape == (1003, D) and np.all(cnt >= np.floor(vp["w"] * 1003) - 3) and cnt.sum() == 1003
     X1, I1 = acq.vbmc_rnd(dict(vp, K=1, mu=vp["mu"][:, :1], sigma=vp["sigma"][:1], w=np.ones(1)), 50000, False, rng=np.random.default_rng(3))
     assert np.max(np.abs(X1.std(0) - vp["sigma"][0] * vp["lambda"])) < 0.01 and np.all(I1 == 0)
+
+
+def test_grad_flag_defaulting_of_the_standalone_wrappers():
+    """entmc_vbmc / entlb_vbmc / gplogjoint resolve grad_flags like the reference (ent/entmc_vbmc.m:5-11,
+    misc/gplogjoint.m:17-23): no second output -> no gradient, omitted flags -> all four groups, a scalar flag is
+    broadcast; theta then holds exactly the flagged groups, and untransformed gradients are refused.  Host logic only."""
+    from vbmc_amd.elbo import _with_grad_groups
+    from vbmc_amd import VbmcUnsupported
+
+    rng = np.random.default_rng(0)
+    D, K = 3, 4
+    vp = vpm.make_vp(rng.standard_normal((D, K)), np.exp(rng.standard_normal(K)), np.ones(D), eta=rng.standard_normal(K))
+    vp["w"] = np.exp(vp["eta"]) / np.sum(np.exp(vp["eta"]))
+    _, th, g = _with_grad_groups(vp, None, 1, True, "entmc_vbmc")
+    assert not g and th.size == D * K + K + D + K                  # value only: theta of the vp's own flags
+    vpt, th, g = _with_grad_groups(vp, None, 2, True, "entmc_vbmc")
+    assert g and all(vpt["optimize_" + n] for n in ("mu", "sigma", "lambda", "weights")) and th.size == D * K + K + D + K
+    vpt, th, g = _with_grad_groups(vp, (0, 1, 0, 1), 2, True, "gplogjoint")
+    assert g and (vpt["optimize_mu"], vpt["optimize_sigma"], vpt["optimize_lambda"], vpt["optimize_weights"]) == (False, True, False, True)
+    assert th.size == 2 * K
+    vpt, th, g = _with_grad_groups(vp, True, 2, True, "entlb_vbmc")
+    assert g and th.size == D * K + K + D + K
+    with pytest.raises(VbmcUnsupported):
+        _with_grad_groups(vp, True, 2, False, "entlb_vbmc")
+    assert vp["optimize_mu"] and vp["optimize_weights"]            # the caller's vp is not modified
