@@ -3,9 +3,9 @@ function dump_golden(repo_root, vbmc_root)
 %
 %   dump_golden('/path/to/this/repo', '/path/to/vbmc')
 %
-% For every tests/golden/mp_case*.json and mp_nlz_case*.json this runs the reference's own functions
-% (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ) on the stored inputs and writes
-% tests/golden/matlab_case*.json / matlab_nlz_case*.json next to them.  tools/compare_matlab_golden.py then
+% For every tests/golden/mp_case*.json, mp_nlz_case*.json and mp_acq_case*.json this runs the reference's own functions
+% (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ, acqf/acqflog/acqus/acqfsn2/acqviqr_vbmc) on the stored
+% inputs and writes tests/golden/matlab_case*.json / matlab_nlz_case*.json / matlab_acq_case*.json next to them.  tools/compare_matlab_golden.py then
 % compares those files with the mpmath vectors (and thereby with the oracle and the HIP path, which are pinned to
 % the mpmath vectors by the test-suite).  Nothing here is needed by CI: the development container has no MATLAB,
 % which is exactly why the oracle is documented as "parity unpinned by the reference" -- this script is how a
@@ -63,6 +63,41 @@ for f = 1:numel(files)
         [out.nlZ(s),g] = gplite_nlZ(hyp(:,s),gp,[]);
         out.dnlZ(s,:) = g(:)';
     end
+    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+end
+% acquisition functions (acq/acqf_vbmc.m, acqflog_vbmc.m, acqus_vbmc.m, acqfsn2_vbmc.m, acqviqr_vbmc.m) on the stored points, called
+% directly with the statistics acqwrapper_vbmc.m:17-29 forms (the wrapper itself needs vp.trinfo / warpvars_vbmc)
+files = dir(fullfile(gold,'mp_acq_case*.json'));
+for f = 1:numel(files)
+    rec = jsondecode(fileread(fullfile(gold,files(f).name)));
+    in = rec.inputs; D = in.D; K = in.K; S = in.S;
+    X = reshape_rows(in.X,D); y = in.y(:); hyp = reshape_rows(in.hyp,S);
+    gp = gplite_post(hyp,X,y,1,in.meanfun);
+    gl = in.gplengthscale(:)';
+    gp.X_rescaled = bsxfun(@rdivide,X,gl); gp.sn2new = in.sn2new(:);
+    vp = struct('D',D,'K',K,'mu',reshape_rows(in.mu,K),'sigma',in.sigma(:)','lambda',in.lam(:),'w',in.w(:)','delta',[],'trinfo',[]);
+    Xs = reshape_rows(in.Xstar,D); Xa = reshape_rows(in.Xa,D); Na = size(Xa,1); N = size(X,1);
+    [~,~,fmu,fs2] = gplite_pred(gp,Xs,[],[],1,0);                                   % acqwrapper_vbmc.m:17
+    fbar = sum(fmu,2)/S; vbar = sum(fs2,2)/S;                                       % :21-29
+    if S > 1; vf = sum(bsxfun(@minus,fmu,fbar).^2,2)/(S-1); else; vf = 0; end
+    vtot = vf + vbar;
+    optimState = struct('ymax',in.ymax,'gplengthscale',gl,'VarianceRegularizedAcqFcn',false,'TolGPVar',1e-4);
+    % importance-sampling state as private/activeimportancesampling_vbmc.m:248-276 leaves it (unit weights)
+    AIS = struct('Xa',Xa,'lnw',zeros(S,Na),'Kax_mat',zeros(Na,N,S),'Ctmp_mat',zeros(N,Na,S));
+    [~,~,~,fs2a] = gplite_pred(gp,Xa,[],[],1,0); AIS.fs2a = fs2a;
+    for s = 1:S
+        h = gp.post(s).hyp; ell = exp(h(1:D)); sf2 = exp(2*h(D+1)); L = gp.post(s).L;
+        Kax = sf2*exp(-sq_dist(diag(1./ell)*Xa',diag(1./ell)*X')/2);
+        AIS.Kax_mat(:,:,s) = Kax;
+        if gp.post(s).Lchol; sn2_eff = 1/gp.post(s).sW(1)^2; AIS.Ctmp_mat(:,:,s) = (L\(L'\Kax'))/sn2_eff; else; AIS.Ctmp_mat(:,:,s) = L*Kax'; end
+    end
+    optimState.ActiveImportanceSampling = AIS;
+    out = struct('fbar',fbar(:)','vtot',vtot(:)');
+    out.acqf = acqf_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
+    out.acqflog = acqflog_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
+    out.acqus = acqus_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
+    out.acqfsn2 = acqfsn2_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
+    out.acqviqr = acqviqr_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
     write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
 end
 end
