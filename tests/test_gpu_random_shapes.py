@@ -1,6 +1,8 @@
 """GPU parity on randomly drawn problem shapes and flag combinations (hypothesis, derandomised): the HIP path
 through the C ABI against the oracle -- the three-way cross-check of SURVEY 8c(4) with the mpmath vectors pinning
 the oracle itself (tests/test_oracle_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -20,10 +22,13 @@ def va():
     return vbmc_amd
 
 
+# VBMC_HYP_SCALE=10 multiplies the example counts for an occasional deeper sweep (the default keeps the suite at seconds)
+SCALE = int(os.environ.get("VBMC_HYP_SCALE", "1"))
+
 shape = st.tuples(st.integers(1, 8), st.integers(1, 20), st.integers(5, 60), st.integers(1, 4))
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=30 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(shape=shape, seed=st.integers(0, 10**6), flags=st.tuples(st.booleans(), st.booleans(), st.booleans(), st.booleans()),
        ns_half=st.integers(0, 20), compute_var=st.sampled_from([0, 0, 1, 2]), meanfun=st.sampled_from([0, 1, 4, 4]),
        beta=st.sampled_from([0.0, 0.0, 1.3]), grad=st.booleans())
@@ -52,7 +57,7 @@ def test_negelcbo_random_shapes(va, shape, seed, flags, ns_half, compute_var, me
         assert relerr(out["varG"][0], ref["varG"]) < 1e-7
 
 
-@settings(max_examples=15, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=15 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(shape=st.tuples(st.integers(1, 8), st.integers(5, 70), st.integers(1, 4)), seed=st.integers(0, 10**6),
        meanfun=st.sampled_from([0, 1, 4]), nstar=st.integers(1, 90), noisy=st.booleans())
 def test_gp_post_pred_random_shapes(va, shape, seed, meanfun, nstar, noisy):
@@ -71,7 +76,7 @@ def test_gp_post_pred_random_shapes(va, shape, seed, meanfun, nstar, noisy):
     assert np.max(np.abs(np.asarray(r_d[3]).reshape(-1) - np.asarray(r_o[3]).reshape(-1))) < 1e-8 * sf2
 
 
-@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=20 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(shape=st.tuples(st.integers(1, 8), st.integers(5, 60), st.integers(1, 3), st.integers(1, 12)), seed=st.integers(0, 10**6),
        nstar=st.integers(1, 60), na=st.integers(1, 40), name=st.sampled_from(["acqf", "acqflog", "acqus", "acqfsn2", "acqviqr", "acqimiqr"]))
 def test_acquisition_random_shapes(va, shape, seed, nstar, na, name):
@@ -98,13 +103,16 @@ def test_acquisition_random_shapes(va, shape, seed, nstar, na, name):
     acq = va.acqwrapper_vbmc(Xs, vp, gp, st_d, False, name + "_vbmc", None)
     sf2 = np.exp(2 * gp["post"][0]["hyp"][D])
     ok = np.isfinite(ref) & (vtot > 1e-7 * sf2)
+    # fs2 = kss - |V|^2 cancels near training inputs: both implementations carry an absolute error ~ 1e-12 sf2 there, i.e. a
+    # relative one of 1e-12 sf2 / vtot in everything proportional to vtot (found by the 10x sweep: D=1, N=36, vtot = 1e-5 sf2)
+    rt = 1e-7 + 1e-11 * sf2 / np.maximum(vtot[ok], 1e-300)
     if name in ("acqflog", "acqviqr", "acqimiqr"):
-        assert np.all(np.abs(acq[ok] - ref[ok]) < 1e-7 * (1 + np.abs(ref[ok]))), (shape, name)
+        assert np.all(np.abs(acq[ok] - ref[ok]) < rt * (1 + np.abs(ref[ok]))), (shape, name)
     else:
-        assert np.all(np.abs(acq[ok] - ref[ok]) <= 1e-7 * np.abs(ref[ok]) + 1e-300), (shape, name)
+        assert np.all(np.abs(acq[ok] - ref[ok]) <= rt * np.abs(ref[ok]) + 1e-300), (shape, name)
 
 
-@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=20 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(shape=st.tuples(st.integers(1, 8), st.integers(3, 80), st.integers(1, 6)), seed=st.integers(0, 10**6),
        meanfun=st.sampled_from([0, 1, 4]), noisefun=st.sampled_from([(1, 0, 0), (1, 1, 0), (1, 2, 0), (1, 0, 1), (1, 2, 1)]))
 def test_nlz_random_shapes(va, shape, seed, meanfun, noisefun):
