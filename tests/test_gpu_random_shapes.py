@@ -57,6 +57,39 @@ def test_negelcbo_random_shapes(va, shape, seed, flags, ns_half, compute_var, me
         assert relerr(out["varG"][0], ref["varG"]) < 1e-7
 
 
+wide = st.tuples(st.integers(1, 32), st.integers(1, 140), st.integers(5, 220), st.integers(1, 3))
+
+
+@settings(max_examples=8 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=wide, seed=st.integers(0, 10**6), ns_half=st.integers(0, 10), compute_var=st.sampled_from([0, 0, 2]), grad=st.booleans())
+def test_negelcbo_random_shapes_wide(va, shape, seed, ns_half, compute_var, grad):
+    """The same comparison over the whole supported range of D (<= 32), K (MFMA kernels up to 128 incl. the two-wave split, the
+    VALU kernel beyond) and N of a few hundred: every padded-dimension / k-tile instantiation is reachable from here."""
+    D, K, N, S = shape
+    if 4 * D * K + 9 * K > 19400:
+        K = max(1, 19400 // (4 * D + 9))              # the documented limit of the finalize record
+    p = synth_problem(seed, D, N, K, S, meanfun=4)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4, noisefun=p["noisefun"], s2=p["s2"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta, vp = R.get_vptheta(vp)
+    Ns = 2 * ns_half
+    eps = np.random.default_rng(seed + 1).standard_normal((K, max(ns_half, 1), D))[:, :ns_half, :] if Ns > 0 else None
+    too_big = (Ns == 0 and K > 128) or (grad and compute_var == 2 and 5 * theta.size + 2 * (S + K) + 264 > 20480)
+    if too_big:    # documented limits: the K x K table of the deterministic-entropy kernel, the five T-vectors of the variance gradient
+        with pytest.raises(va.VbmcUnsupported):
+            va.negelcbo_batch(theta, 0.0, vp, gp, Ns, grad, compute_var)
+        return
+    ref = R.negelcbo_vbmc(theta, 0.0, vp, gp, Ns, grad, compute_var, eps=eps)
+    out = va.negelcbo_batch(theta, 0.0, vp, gp, Ns, grad, compute_var, eps=eps)
+    assert relerr(out["G"][0], ref["G"]) < 1e-9 and relerr(out["H"][0], ref["H"]) < 1e-9, (shape, Ns, compute_var)
+    assert relerr(out["F"][0], ref["F"]) < 1e-9
+    if grad:
+        assert relerr(out["dF"][:, 0], ref["dF"]) < 1e-8, (shape, Ns, compute_var)
+    if compute_var:
+        assert relerr(out["varG"][0], ref["varG"]) < 1e-6
+
+
 @settings(max_examples=15 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(shape=st.tuples(st.integers(1, 8), st.integers(5, 70), st.integers(1, 4)), seed=st.integers(0, 10**6),
        meanfun=st.sampled_from([0, 1, 4]), nstar=st.integers(1, 90), noisy=st.booleans())

@@ -96,3 +96,21 @@ def test_low_noise_branch_Lchol_false(va):
     F, dF = va.negelcbo_vbmc(theta, beta, vp, gp, 0, 1, 2)
     ref2 = R.negelcbo_vbmc(theta, beta, vp, gp, 0, True, 2)
     assert relerr(F, ref2["F"]) < 1e-8 and relerr(dF, ref2["dF"]) < 1e-6
+
+
+def test_variance_paths_at_large_parameter_counts(va):
+    """T = D K + 2 K + D in the thousands (found by the wide random sweep): the variance kernels size their LDS by T only
+    when a gradient is wanted; the variance gradient beyond ~4000 parameters is refused cleanly, and a refused call leaves
+    no stale device error behind for the next one."""
+    p, gp, vp, theta = problem(7, 28, 150, 100, 2)          # T = 3028
+    for cv, grad in ((1, False), (2, False), (2, True)):
+        ref = R.negelcbo_vbmc(theta, 1.0 if cv == 2 else 0.0, vp, gp, 0, grad, cv)
+        out = va.negelcbo_batch(theta, 1.0 if cv == 2 else 0.0, vp, gp, 0, grad, cv)
+        assert relerr(out["varG"][0], ref["varG"]) < 1e-6 and relerr(out["F"][0], ref["F"]) < 1e-8
+        if grad:
+            assert relerr(out["dF"][:, 0], ref["dF"]) < 1e-6
+    p2, gp2, vp2, theta2 = problem(7, 32, 60, 141, 1)       # T = 4826
+    with pytest.raises(va.VbmcUnsupported):
+        va.negelcbo_batch(theta2, 1.0, vp2, gp2, 10, True, 2, seed=1)
+    out = va.negelcbo_batch(theta2, 0.0, vp2, gp2, 10, True, 0, seed=1)    # the next call is unaffected
+    assert np.isfinite(out["F"][0]) and np.all(np.isfinite(out["dF"]))

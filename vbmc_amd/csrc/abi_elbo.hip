@@ -345,6 +345,8 @@ struct ElboPlan {
   double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0, cutoff = 0.0;
 };
 
+// dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
+#define VAR_FINAL_LDS(S_, K_, Tg_) ((256 + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
 static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
@@ -380,6 +382,8 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     return set_err(ctx, VBMC_ERR_INVALID, "Computing the gradient of variational parameters and requesting per-component results at the same time.");
   if (compute_var != 0 && !gp->hasL)
     return set_err(ctx, VBMC_ERR_INVALID, "compute_var != 0 needs gp.post(s).L: upload the GP with L");
+  if (compute_var != 0 && VAR_FINAL_LDS(S, K, compute_grad ? T : 0) > 160 * 1024)   // k_var_final: five T-vectors in LDS
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance gradient with %d variational parameters (> 4000) not accelerated", T);
   if (compute_var != 0 && TRSM_LDS_BYTES(dm.N) > 160 * 1024)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1136 not accelerated", dm.N);
   P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
@@ -521,6 +525,13 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
 // Enqueue one evaluation pass on the context's stream: reads theta from P.d_theta, leaves the packed
 // results [F G H varG varGss | dF dG dH] per restart in P.d_out.  No host synchronisation.
 // pend / pend_iter: inside the optimiser loop, the Adam update of iteration pend_iter that k_prep applies before unpacking.
+// cheap (no synchronisation) attribution of a failed launch to its kernel
+#define LAUNCH_CHECK(ctx_, what)                                                                            \
+  do {                                                                                                      \
+    hipError_t le_ = hipGetLastError();                                                                     \
+    if (le_ != hipSuccess) return set_err(ctx_, VBMC_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(le_)); \
+  } while (0)
+
 static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan& P, unsigned long long seed,
                                 const AdamState* pend = nullptr, int pend_iter = 0) {
   const ElboDims& dm = P.dm;
@@ -532,6 +543,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
   hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), prep_lds, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
                      pend ? pend_iter : 0, (const double*)P.d_out);
+  LAUNCH_CHECK(ctx, "k_prep");
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
   const bool fork = ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
@@ -554,9 +566,11 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         if (lj_mfma && mom_lds <= 48 * 1024) {
           hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, ls, dm, P.d_vpd,
                              gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
+          LAUNCH_CHECK(ctx, "k_logjoint_mfma");
         } else {
           hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(lj_split ? WAVE * LJ_MAXW : WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
                              P.d_delta2, P.d_lj, P.compute_grad);
+          LAUNCH_CHECK(ctx, "k_logjoint");
         }
       });
     }
@@ -564,6 +578,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     // log-joint partials summed over hyper-samples (in sample order), one record per (r, k); on the main stream of an MC
     // evaluation this shares a launch with the entropy reduction below
     if (fork || !P.mc) hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, ls, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
+    LAUNCH_CHECK(ctx, "k_lj_reduce");
     return VBMC_OK;
   };
   if (fork) {
@@ -593,6 +608,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         launch_entropy<DT>(P.compute_grad != 0, dim3(P.C, K, R), lds, st, ea);
       });
     }
+    LAUNCH_CHECK(ctx, "the entropy kernel");
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     // chunk partials -> one record per (r, j), summed in chunk order
     if (fork)
@@ -601,12 +617,14 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     else
       hipLaunchKernelGGL(k_reduce_both, dim3(K, R, 2), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
                          P.d_part, P.d_red, S, 2 * D + 2, P.d_lj, P.d_ljbar);
+    LAUNCH_CHECK(ctx, "k_ent_reduce / k_reduce_both");
     fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {
     size_t lds = ((size_t)K * K + K + 256) * sizeof(double);
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_entlb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, P.d_vpd, P.d_part, P.compute_grad);
+    LAUNCH_CHECK(ctx, "k_entlb");
     fa.entpart = nullptr; fa.entlb = P.d_part;
   }
 
@@ -622,6 +640,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     const int N = dm.N;
     DISPATCH_DT(dt, {
       hipLaunchKernelGGL((k_var_z<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2, P.d_Z);
+      LAUNCH_CHECK(ctx, "k_var_z");
     });
     const size_t tlds = P.tlds;
     if (tlds > 64 * 1024) {
@@ -630,24 +649,30 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     }
     const dim3 tg((K + TR_CB - 1) / TR_CB, S, R);
     if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
+    LAUNCH_CHECK(ctx, "k_symm");
     hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_finv, gp->d_lchol, P.d_Z);
+    LAUNCH_CHECK(ctx, "k_trsm_fwd");
     hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                        P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);
+    LAUNCH_CHECK(ctx, "k_var_gram");
     if (P.vgrad) {
       hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_finv, gp->d_lchol, P.d_Z, P.d_X);
+      LAUNCH_CHECK(ctx, "k_trsm_bwd");
       DISPATCH_DT(dt, {
         hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2,
                            gp->d_sn2, gp->d_lchol, P.d_X, P.d_vg);
+        LAUNCH_CHECK(ctx, "k_vargrad");
       });
     }
     VarFinArgs va{};
     va.dm = dm; va.vpd = P.d_vpd; va.gpc = gp->gpc; va.delta2 = P.d_delta2; va.lj = P.d_lj; va.J = P.d_J;
     va.vg = P.vgrad ? P.d_vg : nullptr; va.compute_var = P.compute_var; va.want_grad = P.compute_grad; va.stride = P.var_stride;
     va.out = P.d_var;
-    const size_t vlds = (256 + 2 * (size_t)S + 7 * (size_t)T + 2 * (size_t)K + 8) * sizeof(double);
+    const size_t vlds = VAR_FINAL_LDS(S, K, P.compute_grad ? T : 0);
     if (vlds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
     hipLaunchKernelGGL(k_var_final, dim3(R), dim3(256), vlds, st, va);
+    LAUNCH_CHECK(ctx, "k_var_final");
   }
 
   // ---- finalize
@@ -667,6 +692,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+    LAUNCH_CHECK(ctx, "k_finalize");
   }
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;

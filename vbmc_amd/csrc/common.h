@@ -127,9 +127,11 @@ static inline vbmc_status set_err(vbmc_ctx* ctx, vbmc_status st, const char* fmt
 #define HIP_TRY(ctx, call)                                                                   \
   do {                                                                                       \
     hipError_t e_ = (call);                                                                  \
-    if (e_ != hipSuccess)                                                                    \
+    if (e_ != hipSuccess) {                                                                  \
+      (void)hipGetLastError(); /* do not leave the error for the next call's launch checks */ \
       return set_err(ctx, VBMC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                      __FILE__, __LINE__);                                                    \
+    }                                                                                        \
   } while (0)
 
 static inline vbmc_status ensure(vbmc_ctx* ctx, DevBuf& b, size_t bytes) {

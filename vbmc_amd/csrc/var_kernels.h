@@ -220,12 +220,13 @@ __global__ void __launch_bounds__(256) k_var_final(VarFinArgs a) {
   double* red = lds;          // nt
   double* Fs = red + nt;      // S
   double* vFs = Fs + S;       // S
+  const int Tg = a.want_grad ? T : 0;   // the five gradient vectors exist only when a gradient is wanted (host sizing follows)
   double* dFs = vFs + S;      // T  per-sample gradient (after Jacobians), reused per s
-  double* dvs = dFs + T;      // T  per-sample variance gradient
-  double* acc1 = dvs + T;     // T  sum_s dvarF(:,s)
-  double* acc2 = acc1 + T;    // T  sum_s F(s) dF(:,s)
-  double* acc3 = acc2 + T;    // T  sum_s dF(:,s)
-  double* tmpK = acc3 + T;    // K
+  double* dvs = dFs + Tg;     // T  per-sample variance gradient
+  double* acc1 = dvs + Tg;    // T  sum_s dvarF(:,s)
+  double* acc2 = acc1 + Tg;   // T  sum_s F(s) dF(:,s)
+  double* acc3 = acc2 + Tg;   // T  sum_s dF(:,s)
+  double* tmpK = acc3 + Tg;   // K
   double* tmpK2 = tmpK + K;   // K
   const int LJS = 2 * D + 2;
   const double* lj = a.lj + (size_t)r * S * K * LJS;
