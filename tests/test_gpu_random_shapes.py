@@ -161,3 +161,38 @@ def test_nlz_random_shapes(va, shape, seed, meanfun, noisefun):
         f, g = R.gplite_nlZ(H[:, b], gp)
         assert abs(nlZ[b] - f) < 1e-9 * max(1.0, abs(f)), (shape, meanfun, noisefun)
         assert relerr(dnlZ[:, b], g) < 1e-7, (shape, meanfun, noisefun, relerr(dnlZ[:, b], g))
+
+
+@settings(max_examples=5 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 32), st.integers(5, 420), st.integers(1, 3)), seed=st.integers(0, 10**6),
+       meanfun=st.sampled_from([0, 1, 4]), nstar=st.integers(1, 400), noisy=st.booleans(), rank1=st.booleans())
+def test_gp_side_random_shapes_wide(va, shape, seed, meanfun, nstar, noisy, rank1):
+    """gplite_post / gplite_pred / rank-one append / gplite_nlZ over the supported range of D (padded kernel instantiations up to
+    32) and training-set sizes of a few hundred (several 64 x 64 tiles, several resident row groups in the prediction kernel)."""
+    from tests.test_gpu_nlz import make_gp
+
+    D, N, S = shape
+    p = synth_problem(seed, D, N, 2, S, meanfun=meanfun, noisy=noisy)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=meanfun, noisefun=p["noisefun"], s2=p["s2"])
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, meanfun, p["noisefun"], p["s2"])
+    for a, b in zip(gp["post"], ref["post"]):
+        assert a["Lchol"] == b["Lchol"] and relerr(a["alpha"], b["alpha"]) < 1e-7 and relerr(a["L"], b["L"]) < 1e-8
+    if rank1 and not noisy:
+        xs = 1.2 * np.random.default_rng(seed + 5).standard_normal(D)
+        gp = va.gplite_post_rank1(gp, xs, 0.3, need_L=False)
+        ref = R.gplite_post_rank1(ref, xs, 0.3)
+        for a, b in zip(gp["post"], ref["post"]):
+            assert relerr(a["alpha"], b["alpha"]) < 1e-6
+    Xs = 1.3 * np.random.default_rng(seed + 2).standard_normal((nstar, D))
+    r_d = va.gplite_pred(gp, Xs, None, None, True)
+    r_o = R.gplite_pred(ref, Xs, None, None, True)
+    sf2 = np.exp(2 * ref["post"][0]["hyp"][D])
+    assert relerr(np.asarray(r_d[2]).reshape(-1), np.asarray(r_o[2]).reshape(-1)) < 1e-7
+    assert np.max(np.abs(np.asarray(r_d[3]).reshape(-1) - np.asarray(r_o[3]).reshape(-1))) < 1e-7 * sf2
+    # marginal likelihood and gradient at the same sizes
+    gpn, draw = make_gp(np.random.default_rng(seed + 9), N, D, meanfun, (1, 0, 0))
+    H = np.stack([draw() for _ in range(2)], axis=1)
+    nlZ, dnlZ = va.gplite_nlZ(H, gpn)
+    for b in range(2):
+        f, g = R.gplite_nlZ(H[:, b], gpn)
+        assert abs(nlZ[b] - f) < 1e-9 * max(1.0, abs(f)) and relerr(dnlZ[:, b], g) < 1e-6, (shape, meanfun)
