@@ -113,6 +113,19 @@ def test_gp_post_pred_random_shapes(va, shape, seed, meanfun, nstar, noisy):
 @given(shape=st.tuples(st.integers(1, 8), st.integers(5, 60), st.integers(1, 3), st.integers(1, 12)), seed=st.integers(0, 10**6),
        nstar=st.integers(1, 60), na=st.integers(1, 40), name=st.sampled_from(["acqf", "acqflog", "acqus", "acqfsn2", "acqviqr", "acqimiqr"]))
 def test_acquisition_random_shapes(va, shape, seed, nstar, na, name):
+    _acquisition_case(va, shape, seed, nstar, na, name)
+
+
+@settings(max_examples=5 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 32), st.integers(5, 300), st.integers(1, 3), st.integers(1, 60)), seed=st.integers(0, 10**6),
+       nstar=st.integers(1, 600), na=st.integers(1, 256), name=st.sampled_from(["acqf", "acqfsn2", "acqviqr", "acqviqr", "acqimiqr"]))
+def test_acquisition_random_shapes_wide(va, shape, seed, nstar, na, name):
+    """Up to 256 importance points (all 16 accumulator-tile instantiations of k_acq_iqr, the > 64 KB LDS variants), several
+    128-point workgroups, D up to 32, training sets of a few hundred points."""
+    _acquisition_case(va, shape, seed, nstar, na, name)
+
+
+def _acquisition_case(va, shape, seed, nstar, na, name):
     D, N, S, K = shape
     p = synth_problem(seed, D, N, K, S)
     gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
