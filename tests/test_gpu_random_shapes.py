@@ -209,3 +209,34 @@ def test_gp_side_random_shapes_wide(va, shape, seed, meanfun, nstar, noisy, rank
     for b in range(2):
         f, g = R.gplite_nlZ(H[:, b], gpn)
         assert abs(nlZ[b] - f) < 1e-9 * max(1.0, abs(f)) and relerr(dnlZ[:, b], g) < 1e-6, (shape, meanfun)
+
+
+@settings(max_examples=5 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 20), st.integers(1, 128), st.integers(5, 150), st.integers(1, 3)), seed=st.integers(0, 10**6),
+       ns_half=st.integers(1, 12), grad=st.booleans(), R_=st.sampled_from([2, 48, 130]))
+def test_negelcbo_batched_wide(va, shape, seed, ns_half, grad, R_):
+    """R restarts in one call (sieve batch / lock-step chains): few (one stream), and enough of them that the log joint moves to
+    the second stream beside the entropy kernel and takes its MFMA form; three distinct thetas repeated, one shared set of draws."""
+    D, K, N, S = shape
+    p = synth_problem(seed, D, N, K, S, meanfun=4)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4, noisefun=p["noisefun"], s2=p["s2"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta, vp = R.get_vptheta(vp)
+    rng = np.random.default_rng(seed + 4)
+    base = [theta + 0.05 * rng.standard_normal(theta.size) for _ in range(3)]
+    cols = [base[r % 3] for r in range(R_)]
+    Th = np.asfortranarray(np.stack(cols, axis=1))
+    Ns = 2 * ns_half
+    eps = rng.standard_normal((K, ns_half, D))
+    refs = []
+    for b in base:
+        refs.append(R.negelcbo_vbmc(b, 0.0, vp, gp, Ns, grad, 0, eps=eps))
+    out = va.negelcbo_batch(Th, 0.0, vp, gp, Ns, grad, 0, eps=eps, eps_shared=True)
+    for r in range(R_):
+        ref = refs[r % 3]
+        assert relerr(out["F"][r], ref["F"]) < 1e-9, (shape, R_, r)
+        if grad:
+            assert relerr(out["dF"][:, r], ref["dF"]) < 1e-8, (shape, R_, r)
+    # identical columns give identical bits (fixed-order reductions)
+    assert out["F"][0] == out["F"][3 % R_] or R_ < 4
