@@ -240,3 +240,39 @@ def test_negelcbo_batched_wide(va, shape, seed, ns_half, grad, R_):
             assert relerr(out["dF"][:, r], ref["dF"]) < 1e-8, (shape, R_, r)
     # identical columns give identical bits (fixed-order reductions)
     assert out["F"][0] == out["F"][3 % R_] or R_ < 4
+
+
+@settings(max_examples=3 * SCALE, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(shape=st.tuples(st.integers(1, 12), st.integers(2, 70), st.integers(8, 90), st.integers(1, 3)), seed=st.integers(0, 10**6),
+       ns_half=st.integers(2, 30), flags=st.sampled_from([(1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 1)]), chains=st.sampled_from([1, 2, 5]))
+def test_device_adam_random_shapes(va, shape, seed, ns_half, flags, chains):
+    """The on-device optimiser loop (Adam update folded into the next k_prep, stopping test every 20 iterations) against the host
+    loop of utils/fminadam.m driving the same device objective with the same per-iteration seeds: same stopping iteration, same
+    iterates -- for random shapes, warm-up style flag sets (weights fixed) and several chains in lock-step."""
+    D, K, N, S = shape
+    p = synth_problem(seed, D, N, K, S, meanfun=4)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4, noisefun=p["noisefun"], s2=p["s2"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"], optimize=flags)
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    opts = dict(TolLength=1e-6, TolWeight=1e-2, TolConLoss=0.01, WeightPenalty=0.1)
+    vpb, tb = R.vpbounds(vp, gp, opts)
+    theta, vpb = R.get_vptheta(vpb)
+    Ns, MaxIter, sd = 2 * ns_half, 60, seed % 1000
+    X0 = np.asfortranarray(np.stack([theta + 0.03 * c for c in range(chains)], axis=1))
+    xd, fd, xtd, ftd, itd = va.fminadam_device(X0, 0, vpb, gp, Ns, tb, 1e-3, MaxIter, seed=sd)
+    c = chains - 1                      # compare the last chain with a host loop of its own
+    it = {"n": 0}
+
+    def fun(x):
+        it["n"] += 1
+        Th = X0.copy()
+        Th[:, c] = x                    # same restart index -> same device RNG stream (keyed by seed, restart, component, sample)
+        r = va.negelcbo_batch(Th, 0, vpb, gp, Ns, True, 0, tb, seed=sd + it["n"])
+        return float(r["F"][c]), r["dF"][:, c].copy()
+
+    xh, fh, xth, fth, ith = va.fminadam(fun, X0[:, c].copy(), None, None, 1e-3, MaxIter)
+    assert int(itd[c]) == ith, (shape, flags, chains)
+    # Adam's update m / (sqrt(v) + 1.5e-8) amplifies last-bit differences (device pow / exp / sqrt vs NumPy's) wherever a gradient
+    # component is ~ 0; over 60 iterations the two trajectories stay together to ~ 1e-7 (1e-9 in the fixed case of
+    # tests/test_gpu_optimize.py), far below anything the stopping rule reads
+    assert relerr(ftd[c], fth) < 1e-5 and relerr(xtd[c], xth) < 1e-5, (shape, flags, chains)
