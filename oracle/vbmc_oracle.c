@@ -42,7 +42,10 @@ static void softmax_jac_apply(int K, const double* eta, const double* g, double*
   free(e);
 }
 
-/* ent/entmc_vbmc.m:1-128 with explicit eps; dH = [mu(:); sigma; lambda; eta] (all four groups) */
+/* ent/entmc_vbmc.m:1-128 with explicit eps; dH = [mu(:); sigma; lambda; eta] (all four groups).
+   As in the reference, everything that depends on the mixture only is formed once outside the sample loops (sigmalambda :34,
+   nf ./ sigma.^D :61-63, sigmalambda.^2 :78); the samples of one component are split over the OpenMP team, one parallel region
+   for the whole evaluation. */
 void oracle_entmc(int D, int K, int Mh, const double* mu, const double* sigma, const double* lambda, const double* w,
                   const double* eta, const double* eps, int grad, double* H_out, double* dH) {
   const int Ns = 2 * Mh;
@@ -54,25 +57,34 @@ void oracle_entmc(int D, int K, int Mh, const double* mu, const double* sigma, c
   double* sg_g = (double*)calloc(K, sizeof(double));
   double* lam_g = (double*)calloc(D, sizeof(double));
   double* w_g = (double*)calloc(K, sizeof(double));
-  for (int j = 0; j < K; ++j) { /* :49 */
-    double Hj = 0.0, sgj = 0.0, wjlog = 0.0;
-    double* muj = (double*)calloc(D, sizeof(double));
-    double* lamj = (double*)calloc(D, sizeof(double));
-    double* wl = (double*)calloc(K, sizeof(double));
+  double* sl = (double*)malloc(sizeof(double) * D * K);   /* sigma_k lambda_d        :34 */
+  double* sl2 = (double*)malloc(sizeof(double) * D * K);  /* (sigma_k lambda_d)^2    :78 */
+  double* nfk = (double*)malloc(sizeof(double) * K);      /* nf / sigma_k^D          :61-63 */
+  for (int k = 0; k < K; ++k) {
+    nfk[k] = nf / pow(sigma[k], D);
+    for (int d = 0; d < D; ++d) { sl[d + (size_t)D * k] = sigma[k] * lambda[d]; sl2[d + (size_t)D * k] = sl[d + (size_t)D * k] * sl[d + (size_t)D * k]; }
+  }
+  /* per-component accumulators, shared by the team */
+  double Hj = 0.0, sgj = 0.0, wjlog = 0.0;
+  double* muj = (double*)calloc(D, sizeof(double));
+  double* lamj = (double*)calloc(D, sizeof(double));
+  double* wl = (double*)calloc(K, sizeof(double));
 #ifdef _OPENMP
 #pragma omp parallel
 #endif
-    {
-      double* x = (double*)malloc(sizeof(double) * D);
-      double* e = (double*)malloc(sizeof(double) * D);
-      double* nrm = (double*)malloc(sizeof(double) * K);
-      double* lsum = (double*)malloc(sizeof(double) * D);
-      double* muj_p = (double*)calloc(D, sizeof(double));
-      double* lamj_p = (double*)calloc(D, sizeof(double));
-      double* wl_p = (double*)calloc(K, sizeof(double));
+  {
+    double* x = (double*)malloc(sizeof(double) * D);
+    double* e = (double*)malloc(sizeof(double) * D);
+    double* nrm = (double*)malloc(sizeof(double) * K);
+    double* muj_p = (double*)malloc(sizeof(double) * D);
+    double* lamj_p = (double*)malloc(sizeof(double) * D);
+    double* wl_p = (double*)malloc(sizeof(double) * K);
+    for (int j = 0; j < K; ++j) { /* :49 */
       double Hj_p = 0.0, sgj_p = 0.0, wjlog_p = 0.0;
+      for (int d = 0; d < D; ++d) { muj_p[d] = 0.0; lamj_p[d] = 0.0; }
+      for (int l = 0; l < K; ++l) wl_p[l] = 0.0;
 #ifdef _OPENMP
-#pragma omp for schedule(static)
+#pragma omp for schedule(static) nowait
 #endif
       for (int i = 0; i < Ns; ++i) {
         const int b = i < Mh ? i : i - Mh;
@@ -85,10 +97,10 @@ void oracle_entmc(int D, int K, int Mh, const double* mu, const double* sigma, c
         for (int k = 0; k < K; ++k) { /* :60-65 */
           double d2 = 0.0;
           for (int d = 0; d < D; ++d) {
-            double t = (x[d] - mu[d + (size_t)D * k]) / (sigma[k] * lambda[d]);
+            double t = (x[d] - mu[d + (size_t)D * k]) / sl[d + (size_t)D * k];
             d2 += t * t;
           }
-          nrm[k] = nf / pow(sigma[k], D) * exp(-0.5 * d2);
+          nrm[k] = nfk[k] * exp(-0.5 * d2);
           q += w[k] * nrm[k];
         }
         Hj_p += log(q);
@@ -96,11 +108,7 @@ void oracle_entmc(int D, int K, int Mh, const double* mu, const double* sigma, c
           double isum = 0.0;
           for (int d = 0; d < D; ++d) { /* :77-79 */
             double acc = 0.0;
-            for (int k = 0; k < K; ++k) {
-              double sl = sigma[k] * lambda[d];
-              acc += (x[d] - mu[d + (size_t)D * k]) / (sl * sl) * nrm[k] * w[k];
-            }
-            lsum[d] = acc;
+            for (int k = 0; k < K; ++k) acc += (x[d] - mu[d + (size_t)D * k]) / sl2[d + (size_t)D * k] * nrm[k] * w[k];
             muj_p[d] += acc / q;                         /* :82 */
             isum += acc * e[d] * lambda[d];              /* :87 */
             lamj_p[d] += acc * e[d] / q;                 /* :93 (w_j sigma_j applied below) */
@@ -118,19 +126,27 @@ void oracle_entmc(int D, int K, int Mh, const double* mu, const double* sigma, c
         for (int d = 0; d < D; ++d) { muj[d] += muj_p[d]; lamj[d] += lamj_p[d]; }
         for (int l = 0; l < K; ++l) wl[l] += wl_p[l];
       }
-      free(x); free(e); free(nrm); free(lsum); free(muj_p); free(lamj_p); free(wl_p);
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp single
+#endif
+      {
+        H -= w[j] * Hj / Ns; /* :67 */
+        if (grad) {
+          for (int d = 0; d < D; ++d) {
+            mu_g[d + (size_t)D * j] = w[j] * muj[d] / Ns;
+            lam_g[d] += w[j] * sigma[j] * lamj[d] / Ns;
+          }
+          sg_g[j] = w[j] * sgj / Ns;
+          w_g[j] -= wjlog / Ns;
+          for (int l = 0; l < K; ++l) w_g[l] -= w[j] * wl[l] / Ns;
+        }
+        Hj = 0.0; sgj = 0.0; wjlog = 0.0;
+        for (int d = 0; d < D; ++d) { muj[d] = 0.0; lamj[d] = 0.0; }
+        for (int l = 0; l < K; ++l) wl[l] = 0.0;
+      } /* implicit barrier of the single: the next component starts from zeroed accumulators */
     }
-    H -= w[j] * Hj / Ns; /* :67 */
-    if (grad) {
-      for (int d = 0; d < D; ++d) {
-        mu_g[d + (size_t)D * j] = w[j] * muj[d] / Ns;
-        lam_g[d] += w[j] * sigma[j] * lamj[d] / Ns;
-      }
-      sg_g[j] = w[j] * sgj / Ns;
-      w_g[j] -= wjlog / Ns;
-      for (int l = 0; l < K; ++l) w_g[l] -= w[j] * wl[l] / Ns;
-    }
-    free(muj); free(lamj); free(wl);
+    free(x); free(e); free(nrm); free(muj_p); free(lamj_p); free(wl_p);
   }
   *H_out = H;
   if (grad) {
@@ -139,7 +155,7 @@ void oracle_entmc(int D, int K, int Mh, const double* mu, const double* sigma, c
     for (int d = 0; d < D; ++d) dH[D * K + K + d] = lam_g[d] * lambda[d];    /* :107 */
     softmax_jac_apply(K, eta, w_g, dH + D * K + K + D);
   }
-  free(mu_g); free(sg_g); free(lam_g); free(w_g);
+  free(mu_g); free(sg_g); free(lam_g); free(w_g); free(sl); free(sl2); free(nfk); free(muj); free(lamj); free(wl);
 }
 
 /* misc/gplogjoint.m value + gradient, negquad/const/zero mean (ids 4/1/0), no variance, averaged over S.
