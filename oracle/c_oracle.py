@@ -20,7 +20,28 @@ def load(openmp=False):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     lib = C.CDLL(path)
     lib.oracle_num_threads.restype = C.c_int
+    if openmp:
+        lib.oracle_set_threads(C.c_int(usable_cores()))
     return lib
+
+
+def usable_cores():
+    """Cores this process may really use: the cgroup CPU quota if there is one (a container that sees 256 logical CPUs but is
+    granted 16 only thrashes with a 256-thread team), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def negelcbo(theta, X, hyp, alpha, eps, meanfun=4, Nnoise=1, grad=True, openmp=False):

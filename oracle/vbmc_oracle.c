@@ -29,6 +29,15 @@ int oracle_num_threads(void) {
 #endif
 }
 
+/* team size for the OpenMP build (the caller passes the cores the process may actually use: cgroup quota / affinity) */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* softmax Jacobian applied to a vector: (diag(w) - w w') g, w = exp(eta)/sum  (entmc_vbmc.m:121-123) */
 static void softmax_jac_apply(int K, const double* eta, const double* g, double* out) {
   double* e = (double*)malloc(sizeof(double) * K);
