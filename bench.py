@@ -9,6 +9,14 @@ inside the timed region, GP upload outside it.  N GPUs: one process per GPU, eac
 R restarts (weak scaling), and the per-step exchange is an all-gather of the R ELCBO values over RCCL
 (misc/vpsieve_vbmc.m:81 sorts them; every rank ends with the full vector).
 
+Launch forms (both give one process per GPU over torch.distributed, backend nccl == RCCL):
+  * `python bench.py --gpus N ...`            -- this process re-executes itself N times (RANK / LOCAL_RANK / WORLD_SIZE /
+                                                MASTER_ADDR=127.0.0.1 / MASTER_PORT set per child) and relays rank 0's JSON line;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` -- the ranks are already there (WORLD_SIZE in
+                                                the environment) and are used as they are.
+The JSON line carries what was actually observed: `n_gpus` = the torch.distributed world size, `ranks` = per-rank device,
+evals/s and wall time, `backend`.
+
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
 """
 from __future__ import annotations
@@ -102,6 +110,47 @@ def cpu_baseline(inp, gp, D, K, Ns_full, budget_s=20.0):
             "all_cores": {"value": vo[0], "cores": int(lib.oracle_num_threads()), "sample": "same port with OpenMP, Ns=%d" % vo[1]}}
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU, and wait for them.
+    Rank 0 prints the JSON line on the inherited stdout.  Children are killed by PID if one of them fails."""
+    import subprocess
+
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VBMC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:   # one rank died: the others would wait in a collective forever
+                        q.kill()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +165,12 @@ def main():
     ap.add_argument("--S", type=int, default=20)
     ap.add_argument("--eps-stream", action="store_true", help="also time the parity mode (eps streamed from HBM)")
     ap.add_argument("--extras", action="store_true", help="also report on-device Adam, single-call latency and block-sparse mode")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="rendezvous only: every rank reports (rank, pid, device) through an all-gather and rank 0 prints them; no GPU work")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -125,17 +179,42 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("VBMC_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for single-GPU smoke tests
-    ndev = max(torch.cuda.device_count(), 1)
-    gpu = local_rank % ndev
-    torch.cuda.set_device(gpu)
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher created WORLD_SIZE=%d ranks; reporting the %d ranks that exist"
+              % (args.gpus, world, world), file=sys.stderr)
+    ndev_real = torch.cuda.device_count()
+    ndev = max(ndev_real, 1)
+    gpu = local_rank % ndev   # fewer devices than ranks (a 1-GPU box): ranks share a device -- gloo only, RCCL refuses duplicates
+    if ndev_real:
+        torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            if world > ndev_real:
+                raise SystemExit("bench.py: %d ranks but %d GPU(s): RCCL needs one device per rank (set VBMC_DIST_BACKEND=gloo "
+                                 "to share a device for a functional check)" % (world, ndev_real))
             dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend)
     dev = torch.device("cuda", gpu)
-    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective buffers live
+    cdev = dev if (backend == "nccl" and ndev_real) else torch.device("cpu")  # where collective buffers live
+
+    if args.check_launch:
+        me = torch.tensor([rank, os.getpid(), gpu if ndev_real else -1], dtype=torch.int64, device=cdev)
+        if world > 1:
+            allr = torch.empty(world * 3, dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(allr, me)
+            dist.barrier()
+        else:
+            allr = me
+        if rank == 0:
+            rows = allr.cpu().numpy().reshape(world, 3)
+            print(json.dumps({"check_launch": True, "n_gpus": world, "backend": backend if world > 1 else None,
+                              "spawned_by_bench": os.environ.get("VBMC_BENCH_SPAWNED") == "1",
+                              "ranks": [{"rank": int(a), "pid": int(b), "device": int(c)} for a, b, c in rows]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import vbmc_amd
 
@@ -179,10 +258,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_rows = [[float(rank), float(gpu), elapsed]]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor(rank_rows[0], dtype=torch.float64, device=cdev)
+        allr = torch.empty(world * 3, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine)
+        rank_rows = allr.cpu().numpy().reshape(world, 3).tolist()
+        elapsed = max(r[2] for r in rank_rows)   # MAX over ranks
     assert np.all(np.isfinite(out["F"])) and np.all(np.isfinite(out["dF"]))
 
     # ---- roofline leg (rank 0): HIP-event duration of the dominant kernel, outside the timed region
@@ -282,9 +364,12 @@ def main():
             "value": evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded lumpy 12-component target, SURVEY 8d); device Philox MC draws",
-            "config": {"workload": "BASELINE configs[2]: D=%d N=%d K=%d Ns=%d/component S=%d, R=%d restarts batched per GPU per step, "
-                                   "value+gradient, beta=0, no variance" % (D, N, K, Ns, S, Rr),
+            "config": {"workload": "BASELINE configs[%d]: D=%d N=%d K=%d Ns=%d/component S=%d, R=%d restarts batched per GPU per step, "
+                                   "value+gradient, beta=0, no variance" % (3 if world > 1 else 2, D, N, K, Ns, S, Rr),
                        "restarts_per_gpu": Rr, "parallelism": "restart-sharded x%d, all-gather of ELCBO" % world},
+            "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if world > 1 else None),
+            "world_size_observed": (dist.get_world_size() if world > 1 else 1),
+            "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],
             "roofline": roof, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -1,0 +1,66 @@
+"""bench.py --gpus N must really create N ranks (the flag was parsed and ignored).
+
+CPU: the rendezvous-only mode (--check-launch) under gloo, both launch forms -- self-spawn and an external launcher.
+GPU: a short real run with two ranks; RCCL (nccl) when the box has >= 2 devices, otherwise gloo with both ranks on device 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _last_json(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out
+    return json.loads(lines[-1])
+
+
+def _run(cmd, env_extra, timeout):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return _last_json(r.stdout)
+
+
+@pytest.mark.timeout(240)
+def test_gpus_flag_spawns_that_many_ranks():
+    line = _run([sys.executable, BENCH, "--gpus", "2", "--check-launch"], {"VBMC_DIST_BACKEND": "gloo"}, 200)
+    assert line["n_gpus"] == 2 and line["spawned_by_bench"] is True and line["backend"] == "gloo"
+    pids = {r["pid"] for r in line["ranks"]}
+    assert len(pids) == 2 and os.getpid() not in pids
+    assert sorted(r["rank"] for r in line["ranks"]) == [0, 1]
+
+
+@pytest.mark.timeout(240)
+def test_external_launcher_ranks_are_used_as_they_are():
+    line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", "29713", BENCH, "--gpus", "2", "--check-launch"], {"VBMC_DIST_BACKEND": "gloo"}, 200)
+    assert line["n_gpus"] == 2 and line["spawned_by_bench"] is False
+    assert len({r["pid"] for r in line["ranks"]}) == 2
+
+
+def test_single_rank_default():
+    line = _run([sys.executable, BENCH, "--check-launch"], {}, 120)
+    assert line["n_gpus"] == 1 and len(line["ranks"]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_bench_on_hardware():
+    import torch
+
+    nccl = torch.cuda.device_count() >= 2
+    line = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--restarts", "8", "--Ns", "2000", "--no-cpu-baseline"],
+                {"VBMC_DIST_BACKEND": "nccl" if nccl else "gloo"}, 500)
+    assert line["n_gpus"] == 2 and line["world_size_observed"] == 2
+    assert line["backend"].startswith("nccl" if nccl else "gloo")
+    assert len(line["ranks"]) == 2 and all(r["evals_per_s"] > 0 for r in line["ranks"])
+    if nccl:
+        assert {r["device"] for r in line["ranks"]} == {0, 1}
+    assert line["value"] > 0 and line["scaling"] == "weak"
