@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VBMC_ABI_VERSION 1
+#define VBMC_ABI_VERSION 2
 
 typedef int vbmc_status;
 enum {
@@ -151,12 +151,15 @@ vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int meanfu
                         double* nlZ, double* dnlZ);
 
 /*
- * [ymu,ys2,fmu,fs2] = gplite_pred(gp, Xstar, [], s2star, ssflag)   (gplite/gplite_pred.m:1-165).
+ * [ymu,ys2,fmu,fs2] = gplite_pred(gp, Xstar, ystar, s2star, ssflag)   (gplite/gplite_pred.m:1-165).
  * Xstar is Nstar x D.  ssflag = 0: outputs are Nstar vectors averaged over hyper-samples with
  * the between-sample variance added (:154-165); ssflag = 1: Nstar x S per-sample outputs.
+ * ystar (Nstar, may be NULL = []) only enters the noise at the test points for output-dependent noise models
+ * (gp.noisefun(3) = 1: sn2 += w^2 max(0, ythresh - ystar)^2, gplite_noisefun.m:198-207; skipped when ystar is empty, as in
+ * the reference); fmu / fs2 never depend on it.
  */
-vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
-                         int ssflag, double* ymu, double* ys2, double* fmu, double* fs2);
+vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* ystar,
+                         const double* s2star, int ssflag, double* ymu, double* ys2, double* fmu, double* fs2);
 
 /*
  * The O(N^2) pieces of gplite_post's rank-1 append of one training point x* (gplite/gplite_post.m:173-251),

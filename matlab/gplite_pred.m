@@ -30,13 +30,13 @@ if ~isempty(s2star) && size(s2star,1) ~= Nstar
     error('gplite_pred:s2dimmismatch','S2STAR should be empty or a column vector of NSTAR estimated variances.');
 end
 h = vbmc_hip_gp_handle(gp);
-[ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred',h,Xstar,s2star,double(ssflag),numel(gp.post));
+[ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred',h,Xstar,ystar,s2star,double(ssflag),numel(gp.post));
 lp = [];
 if ~isempty(ystar) && nargout > 4       % log predictive density per hyper-sample (gplite_pred.m:124-127), O(Nstar*Ns) here
     if ssflag || numel(gp.post) == 1
         ymu_s = ymu; ys2_s = ys2;
     else
-        [ymu_s,ys2_s] = vbmc_hip_mex('gp_pred',h,Xstar,s2star,1,numel(gp.post));
+        [ymu_s,ys2_s] = vbmc_hip_mex('gp_pred',h,Xstar,ystar,s2star,1,numel(gp.post));
     end
     lp = -0.5*bsxfun(@minus,ystar,ymu_s).^2./ys2_s - 0.5*log(2*pi*ys2_s);
 end

@@ -324,10 +324,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (!strcmp(cmd, "gp_pred")) {
     vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
     const mxArray* Xs = prhs[2];
-    const int Nstar = (int)mxGetM(Xs), ss = (int)mxGetScalar(prhs[4]), S = (int)mxGetScalar(prhs[5]);
+    // vbmc_hip_mex('gp_pred', h, Xstar, ystar, s2star, ssflag, numel(gp.post))
+    const int Nstar = (int)mxGetM(Xs), ss = (int)mxGetScalar(prhs[5]), S = (int)mxGetScalar(prhs[6]);
     const int nc = (ss && S > 1) ? S : 1;
     for (int i = 0; i < 4; ++i) plhs[i] = mxCreateDoubleMatrix(Nstar, nc, mxREAL);
-    vbmc_status st = vbmc_gp_pred(g_ctx, h, Nstar, mxGetDoubles(Xs), dbl(prhs[3]), ss || S == 1, mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]),
+    vbmc_status st = vbmc_gp_pred(g_ctx, h, Nstar, mxGetDoubles(Xs), dbl(prhs[3]), dbl(prhs[4]), ss || S == 1, mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]),
                                   mxGetDoubles(plhs[2]), mxGetDoubles(plhs[3]));
     if (st != VBMC_OK) fail(st);
     return;

@@ -31,7 +31,9 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 10
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.vbmc_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "vbmc_hip.h")).read()
+    ver = int(re.search(r"#define\s+VBMC_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.vbmc_abi_version() == ver == _lib.ABI_VERSION
 
 
 def test_no_cpu_fallback_without_gpu():

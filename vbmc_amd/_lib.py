@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvbmc_hip.so")
 
+ABI_VERSION = 2   # include/vbmc_hip.h: VBMC_ABI_VERSION
 VBMC_OK, VBMC_ERR_INVALID, VBMC_ERR_NO_DEVICE, VBMC_ERR_HIP, VBMC_ERR_UNSUPPORTED, VBMC_ERR_NOT_POSDEF = range(6)
 _STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "UNSUPPORTED", 5: "NOT_POSDEF"}
 
@@ -94,7 +95,7 @@ def load():
     lib.vbmc_gp_set_noise.argtypes = [vp, vp, i32p, _dp]
     lib.vbmc_gp_post.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, _dp, _dp, _dp, _dp,
                                  _dp, _dp, _dp, _dp, u8p, C.POINTER(vp)]
-    lib.vbmc_gp_pred.argtypes = [vp, vp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
+    lib.vbmc_gp_pred.argtypes = [vp, vp, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
     lib.vbmc_gp_rank1_solves.argtypes = [vp, vp, _dp, _dp, _dp, _dp]
     lib.vbmc_gp_rank1_update.argtypes = [vp, vp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp, C.POINTER(vp)]
     lib.vbmc_acq_eval.argtypes = [vp, vp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
@@ -109,7 +110,7 @@ def load():
     for name in DECLARED_OPTIONAL:
         if hasattr(lib, name):
             pass
-    if lib.vbmc_abi_version() != 1:
+    if lib.vbmc_abi_version() != ABI_VERSION:
         raise ImportError("libvbmc_hip.so ABI version mismatch")
     _lib = lib
     return lib

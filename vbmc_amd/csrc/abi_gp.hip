@@ -376,18 +376,18 @@ extern "C" vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32
 // ------------------------------------------------------------------------------------------
 namespace {
 struct PredBufs {
-  TmpBuf dXs, ds2, dmb, dout, dXc, daa, dmuv, dgrp, dpV, dpF, dKs;
+  TmpBuf dXs, ds2, dys, dmb, dout, dXc, daa, dmuv, dgrp, dpV, dpF, dKs;
   double *fmu = nullptr, *fs2 = nullptr, *ys2 = nullptr;   // Nstar x S each, inside dout
 };
 
 // gplite_pred for every hyper-sample, results left on the device (shared by vbmc_gp_pred and vbmc_acq_eval)
-vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
-                           PredBufs& pb) {
+vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* ystar,
+                           const double* s2star, PredBufs& pb) {
   if (!gp || Nstar <= 0 || !Xstar) return set_err(ctx, VBMC_ERR_INVALID, "%s: bad arguments", who);
   if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "%s needs gp.post(s).L on the device", who);
   if (!gp->has_noise) return set_err(ctx, VBMC_ERR_INVALID, "%s: call vbmc_gp_set_noise (noisefun, sn2_mult) first", who);
-  if (gp->noisefun[2] == 1)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "output-dependent noise (noisefun(3) = 1) at test points not accelerated");
+  // output-dependent noise (noisefun(3) = 1) enters ys2 only, and only with a non-empty ystar (gplite_noisefun.m:198-207);
+  // fmu / fs2 -- all the acquisition functions read (acqwrapper_vbmc.m:17) -- never depend on it
   // an empty s2star counts as zero (gplite_noisefun.m:51): the kernels add nothing when the pointer is null
   const int N = gp->N, D = gp->D, S = gp->S;
   if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
@@ -430,10 +430,15 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
     HIP_TRY(ctx, ds2.alloc(ctx, (size_t)Nstar * 8));
     HIP_TRY(ctx, hipMemcpyAsync(ds2.p, s2star, (size_t)Nstar * 8, hipMemcpyHostToDevice, st));
   }
+  if (ystar && gp->noisefun[2] == 1) {
+    HIP_TRY(ctx, pb.dys.alloc(ctx, (size_t)Nstar * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(pb.dys.p, ystar, (size_t)Nstar * 8, hipMemcpyHostToDevice, st));
+  }
   PredArgs pa{};
   pa.N = N; pa.D = D; pa.S = S; pa.Nhyp = gp->Nhyp; pa.Nstar = Nstar; pa.meanfun = gp->meanfun;
-  pa.moff = gp->Ncov + gp->Nnoise; pa.noff = gp->Ncov; pa.nf0 = gp->noisefun[0]; pa.nf1 = gp->noisefun[1];
+  pa.moff = gp->Ncov + gp->Nnoise; pa.noff = gp->Ncov; pa.nf0 = gp->noisefun[0]; pa.nf1 = gp->noisefun[1]; pa.nf2 = gp->noisefun[2];
   pa.X = gp->X; pa.Xs = dXs.as<double>(); pa.s2s = s2star ? ds2.as<double>() : nullptr; pa.hyp = gp->hyp;
+  pa.ys = (ystar && gp->noisefun[2] == 1) ? pb.dys.as<double>() : nullptr;
   pa.alpha = gp->alpha; pa.L = gp->L; pa.sn2_eff = gp->d_sn2; pa.sn2_mult = gp->d_mult; pa.lchol = gp->d_lchol;
   pa.mean_a = gp->d_meanX; pa.mean_b = dmb.as<double>(); pa.finv = gp->d_finv; pa.tinv = gp->d_tinv;
   pa.fmu = dout.as<double>(); pa.fs2 = pa.fmu + (size_t)Nstar * S; pa.ys2 = pa.fs2 + (size_t)Nstar * S;
@@ -510,19 +515,20 @@ void scatter_rows(const std::vector<double>& src, int Ntot, int C, int i0, int n
 }
 }  // namespace
 
-extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* s2star,
-                                    int ssflag, double* ymu, double* ys2, double* fmu, double* fs2) {
+extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* ystar,
+                                    const double* s2star, int ssflag, double* ymu, double* ys2, double* fmu, double* fs2) {
   if (!ctx) return VBMC_ERR_INVALID;
   if (gp && Xstar && Nstar > pred_chunk_points(gp, Nstar)) {
     const int CH = pred_chunk_points(gp, Nstar), D = gp->D;
     const int nc = (ssflag && gp->S > 1) ? gp->S : 1;
-    std::vector<double> xs, s2c, o[4];
+    std::vector<double> xs, s2c, ysc, o[4];
     for (int i0 = 0; i0 < Nstar; i0 += CH) {
       const int n = std::min(CH, Nstar - i0);
       gather_rows(Xstar, Nstar, D, i0, n, xs);
       if (s2star) s2c.assign(s2star + i0, s2star + i0 + n);
+      if (ystar) ysc.assign(ystar + i0, ystar + i0 + n);
       for (auto& v : o) v.assign((size_t)n * nc, 0.0);
-      vbmc_status st_ = vbmc_gp_pred(ctx, gp, n, xs.data(), s2star ? s2c.data() : nullptr, ssflag, o[0].data(), o[1].data(), o[2].data(), o[3].data());
+      vbmc_status st_ = vbmc_gp_pred(ctx, gp, n, xs.data(), ystar ? ysc.data() : nullptr, s2star ? s2c.data() : nullptr, ssflag, o[0].data(), o[1].data(), o[2].data(), o[3].data());
       if (st_ != VBMC_OK) return st_;
       scatter_rows(o[0], Nstar, nc, i0, n, ymu); scatter_rows(o[1], Nstar, nc, i0, n, ys2);
       scatter_rows(o[2], Nstar, nc, i0, n, fmu); scatter_rows(o[3], Nstar, nc, i0, n, fs2);
@@ -530,7 +536,7 @@ extern "C" vbmc_status vbmc_gp_pred(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar,
     return VBMC_OK;
   }
   PredBufs pb;
-  { vbmc_status s_ = pred_on_device(ctx, "vbmc_gp_pred", gp, Nstar, Xstar, s2star, pb); if (s_ != VBMC_OK) return s_; }
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_gp_pred", gp, Nstar, Xstar, ystar, s2star, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int S = gp->S;
   TmpBuf davg;
@@ -584,7 +590,7 @@ extern "C" vbmc_status vbmc_acq_eval(vbmc_ctx* ctx, const vbmc_gp* gp, int Nstar
     return VBMC_OK;
   }
   PredBufs pb;
-  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_eval", gp, Nstar, Xs, nullptr, nullptr, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int N = gp->N, D = gp->D, S = gp->S;
   if ((size_t)(2 * K * D + K) * 8 > 64 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_acq_eval: K*D = %d too large", K * D);
@@ -694,7 +700,7 @@ extern "C" vbmc_status vbmc_acq_is_create(vbmc_ctx* ctx, const vbmc_gp* gp, int 
       for (int a = 0; a < Na; ++a) f2[(size_t)s * Nap + a] = fs2a[a + (size_t)Na * s];
   } else {
     std::vector<double> tmp((size_t)Na * S);
-    vbmc_status ps = vbmc_gp_pred(ctx, gp, Na, Xa, nullptr, 1, nullptr, nullptr, nullptr, tmp.data());
+    vbmc_status ps = vbmc_gp_pred(ctx, gp, Na, Xa, nullptr, nullptr, 1, nullptr, nullptr, nullptr, tmp.data());
     if (ps != VBMC_OK) return fail(ps);
     for (int s = 0; s < S; ++s)
       for (int a = 0; a < Na; ++a) f2[(size_t)s * Nap + a] = tmp[a + (size_t)Na * s];
@@ -754,7 +760,7 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
     return VBMC_OK;
   }
   PredBufs pb;
-  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, pb); if (s_ != VBMC_OK) return s_; }
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, nullptr, pb); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int N = gp->N, D = gp->D, S = gp->S;
   TmpBuf dgl, dXr, dsn, dsx, dacqs, dres;

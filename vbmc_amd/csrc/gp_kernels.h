@@ -540,10 +540,11 @@ __global__ void k_negate_copy(size_t n, const double* __restrict__ src, double* 
 // Prediction: one wave = 16 test points x one hyper-sample.
 // ------------------------------------------------------------------------------------------
 struct PredArgs {
-  int N, D, S, Nhyp, Nstar, meanfun, moff, noff, nf0, nf1;
+  int N, D, S, Nhyp, Nstar, meanfun, moff, noff, nf0, nf1, nf2;
   const double* X;       // N x D
   const double* Xs;      // Nstar x D (column-major)
   const double* s2s;     // Nstar or null
+  const double* ys;      // Nstar or null: ystar, only for the output-dependent noise term
   const double* hyp;     // Nhyp x S
   const double* alpha;   // N x S
   const double* L;       // N x N x S
@@ -767,10 +768,15 @@ __global__ void __launch_bounds__(256) k_pred_final(PredArgs a, const int* __res
   const double fmu = mstar + partF[(size_t)s * a.Nstar + i];
   double fs2 = lc ? sf2 - pv : sf2 + pv;
   fs2 = fmax(fs2, 0.0);
-  // noise at the test points (gplite_noisefun.m:176-194; the output-dependent term needs ystar: not here)
+  // noise at the test points (gplite_noisefun.m:176-207); the output-dependent term only with a non-empty ystar (:199)
   double sn2s = a.nf0 ? exp(2.0 * h[a.noff]) : 2.220446049250313e-16;
   if (a.nf1 == 1 && a.s2s) sn2s += a.s2s[i];
   else if (a.nf1 == 2 && a.s2s) sn2s += exp(h[a.noff + (a.nf0 ? 1 : 0)]) * a.s2s[i];
+  if (a.nf2 == 1 && a.ys) {
+    const int io = a.noff + (a.nf0 ? 1 : 0) + (a.nf1 == 2 ? 1 : 0);
+    const double zz = fmax(0.0, h[io] - a.ys[i]);
+    sn2s += exp(2.0 * h[io + 1]) * zz * zz;
+  }
   a.fmu[i + (size_t)a.Nstar * s] = fmu;
   a.fs2[i + (size_t)a.Nstar * s] = fs2;
   a.ys2[i + (size_t)a.Nstar * s] = fs2 + sn2s * a.sn2_mult[s];

@@ -251,8 +251,11 @@ def _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, who):
     if gf.any():
         for name, f in zip(("optimize_mu", "optimize_sigma", "optimize_lambda", "optimize_weights"), gf):
             vpt[name] = bool(f)
-    theta, _ = get_vptheta(vpt)
-    return vpt, theta, bool(gf.any())
+    # get_vptheta rescales (sigma*nl, lambda/nl, misc/rescale_params.m:26-32): the NON-flagged groups are read from the
+    # returned vp, so it must be the rescaled one -- otherwise an un-normalised vp.lambda makes theta and the fixed
+    # sigma / lambda inconsistent by the factor nl
+    theta, vpr = get_vptheta(vpt)
+    return vpr, theta, bool(gf.any())
 
 
 def entmc_vbmc(vp, Ns=10, grad_flags=None, jacobian_flag=True, nargout=2, *, eps=None, seed=0, engine=None):

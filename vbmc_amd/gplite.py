@@ -106,14 +106,14 @@ def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nowarpflag=Fal
         Ns = np.asarray(Xstar).shape[0]
         if ystar is not None and np.size(ystar) and np.asarray(ystar).reshape(-1).shape[0] != Ns:
             raise ValueError("gplite_pred:ydimmismatch YSTAR should be empty or a column vector of NSTAR observations.")
-        ymu_s, ys2_s = gplite_pred(gp, Xstar, None, s2star, True, nowarpflag, 2, engine=engine)
+        ymu_s, ys2_s = gplite_pred(gp, Xstar, ystar, s2star, True, nowarpflag, 2, engine=engine)
         lp = None
         if ystar is not None and np.size(ystar):
             ymu_s = np.asarray(ymu_s).reshape(Ns, -1)
             ys2_s = np.asarray(ys2_s).reshape(Ns, -1)
             yv = np.asarray(ystar, dtype=np.float64).reshape(-1, 1)
             lp = -0.5 * (yv - ymu_s) ** 2 / ys2_s - 0.5 * np.log(2 * np.pi * ys2_s)   # O(Nstar S) on the host
-        return tuple(gplite_pred(gp, Xstar, None, s2star, ssflag, nowarpflag, 4, engine=engine)) + (lp,)
+        return tuple(gplite_pred(gp, Xstar, ystar, s2star, ssflag, nowarpflag, 4, engine=engine)) + (lp,)
     engine = engine or default_engine()
     ctx = engine.ctx
     Xs = f64(Xstar)
@@ -121,12 +121,16 @@ def gplite_pred(gp, Xstar, ystar=None, s2star=None, ssflag=False, nowarpflag=Fal
     if s2star is not None and np.size(s2star) and np.asarray(s2star).reshape(-1).shape[0] != Nstar:
         raise ValueError("gplite_pred:s2dimmismatch S2STAR should be empty or a column vector of NSTAR estimated variances.")
     s2s = None if s2star is None or np.size(s2star) == 0 else f64(np.asarray(s2star, dtype=np.float64).reshape(-1))
+    if ystar is not None and np.size(ystar) and np.asarray(ystar).reshape(-1).shape[0] != Nstar:
+        raise ValueError("gplite_pred:ydimmismatch YSTAR should be empty or a column vector of NSTAR observations.")
+    # ystar only matters for output-dependent noise at the test points (gplite_noisefun.m:198-207)
+    ys = None if ystar is None or np.size(ystar) == 0 else f64(np.asarray(ystar, dtype=np.float64).reshape(-1))
     dgp = _device_gp_with_noise(engine, gp)
     S = dgp.S
     per = bool(ssflag) or S == 1
     shape = (Nstar, S) if (per and S > 1) else (Nstar,)
     outs = [np.zeros((Nstar, S) if per else (Nstar,), order="F") for _ in range(4)]
-    ctx.check(ctx.lib.vbmc_gp_pred(ctx.h, dgp.h, Nstar, ptr(Xs), ptr(s2s), 1 if per else 0, ptr(outs[0]), ptr(outs[1]),
+    ctx.check(ctx.lib.vbmc_gp_pred(ctx.h, dgp.h, Nstar, ptr(Xs), ptr(ys), ptr(s2s), 1 if per else 0, ptr(outs[0]), ptr(outs[1]),
                                    ptr(outs[2]), ptr(outs[3])))
     outs = [o.reshape(shape, order="F") if per else o for o in outs]
     return tuple(outs[: max(1, nargout)])
@@ -143,9 +147,14 @@ def gplite_post_rank1(gp, xstar, ystar, s2star=None, *, need_L=True, engine=None
     ctx = engine.ctx
     xstar = np.asarray(xstar, dtype=np.float64).reshape(1, -1)
     ystar = float(np.asarray(ystar).reshape(-1)[0])
-    if gp.get("s2") is not None or s2star is not None:  # heteroskedastic noise: standard update (:76-79,86-90)
+    has_s2 = gp.get("s2") is not None and np.size(gp["s2"]) > 0
+    new_s2 = s2star is not None and np.size(s2star) > 0
+    if has_s2 != new_s2:
+        raise ValueError("gplite_post: the new observation %s an estimated variance s2star but gp.s2 is %s"
+                         % ("has" if new_s2 else "lacks", "empty" if not has_s2 else "set"))
+    if new_s2:  # heteroskedastic noise: the reference leaves the rank-1 path when the new s2 is non-empty (:76-79,86-90)
         hyp = np.stack([p["hyp"] for p in gp["post"]], axis=1)
-        s2new = np.concatenate([gp["s2"], [float(np.asarray(s2star).reshape(-1)[0])]])
+        s2new = np.concatenate([np.asarray(gp["s2"], dtype=np.float64).reshape(-1), [float(np.asarray(s2star).reshape(-1)[0])]])
         return gplite_post(hyp, np.vstack([gp["X"], xstar]), np.concatenate([gp["y"], [ystar]]), 1, gp["meanfun"],
                            gp["noisefun"], s2new, engine=engine)
     N, D = np.asarray(gp["X"]).shape
@@ -236,8 +245,8 @@ def gplite_nlZ(hyp, gp, hprior=None, nargout=2, *, engine=None):
     if Nhyp != gp["Ncov"] + gp["Nnoise"] + gp["Nmean"]:
         raise ValueError("gplite_nlZ:dimmismatch Number of hyperparameters mismatched with dimension of training inputs.")
     if gp.get("intmeanfun", 0) or gp.get("outwarpfun") is not None or int(np.atleast_1d(gp.get("covfun", 1))[0]) != 1:
-        from ._lib import VbmcUnsupported
-        raise VbmcUnsupported("gplite_nlZ: integrated mean / output warping / non-SE covariance are not accelerated")
+        from ._lib import VBMC_ERR_UNSUPPORTED, VbmcUnsupported
+        raise VbmcUnsupported(VBMC_ERR_UNSUPPORTED, "gplite_nlZ: integrated mean / output warping / non-SE covariance are not accelerated")
     nf = (C.c_int32 * 3)(*[int(v) for v in (list(noisefun) + [0, 0, 0])[:3]])
     grad = nargout > 1
     nlZ = np.zeros(B)
