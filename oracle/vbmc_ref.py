@@ -1559,3 +1559,305 @@ def matlab_sort_descend(v):
 def sieve_order(nelcbo_fill):
     """misc/vpsieve_vbmc.m:81: ``[~,vp0_ord] = sort(nelcbo_fill,'ascend')``."""
     return matlab_sort_ascend(nelcbo_fill)
+
+
+# --------------------------------------------------------------------------
+# vbinit / vpsieve / vpoptimize (sequential, as the reference runs them)
+# --------------------------------------------------------------------------
+
+VBMC_OPTIONS = {  # the defaults of vbmc.m:158-366 that the path reads
+    "TolLength": 1e-6, "TolWeight": 1e-2, "TolConLoss": 0.01, "WeightPenalty": 0.1, "HPDFrac": 0.8,
+    "NSent": lambda K: 100 * K ** (2.0 / 3.0), "NSentFast": 0, "NSentFine": lambda K: 2**12 * K,
+    "NSelbo": lambda K: 50 * K, "ELCBOWeight": 0, "SGDStepSize": 0.005, "TolFunStochastic": 1e-3,
+    "MaxIterStochastic": None, "ELCBOmidpoint": True, "StochasticOptimizer": "adam", "TolImprovement": 0.01,
+    "ELCBOImproWeight": 3, "PruningThresholdMultiplier": lambda K: 1.0 / math.sqrt(K), "VariationalInitRepo": False,
+}
+
+
+def evaloption_vbmc(option, N):
+    """misc/evaloption_vbmc.m:4-8."""
+    return option(N) if callable(option) else option
+
+
+def _var_rows(A):
+    """MATLAB var(A,[],2) of a D x n matrix (normalised by n-1) as a length-D vector."""
+    return np.var(A, axis=1, ddof=1)
+
+
+def vbinit_vbmc(type_, Nopts, vp, Knew, Xstar, ystar, rng):
+    """misc/vbinit_vbmc.m:1-140 -> (list of vp, type vector).  MATLAB's randn / rand / randi / randperm become calls
+    on ``rng`` (a numpy Generator) in the order the reference draws them: randn(1,Knew) -> standard_normal(Knew),
+    randn(size(mu)) -> standard_normal((D,K)), randi(K) -> integers(K), rand() -> random(), randperm(n) -> permutation(n)."""
+    D, K = vp["D"], vp["K"]
+    Nstar = Xstar.shape[0]
+    type_vec = type_ * np.ones(Nopts, dtype=np.int64)  # :17
+    lambda0 = vp["lambda"].copy()
+    mu0 = vp["mu"].copy()
+    w0 = vp["w"].copy()
+    if type_ == 1:  # :23-24
+        sigma0 = vp["sigma"].copy()
+    elif type_ == 2:  # :25-32
+        ord_ = matlab_sort_descend(ystar)
+        if vp["optimize_mu"]:
+            idx_ord = np.tile(np.arange(min(Knew, Nstar)), int(math.ceil(Knew / Nstar)))
+            mu0 = Xstar[ord_[idx_ord[:Knew]], :].T.copy()
+        V = _var_rows(mu0) if K > 1 else np.var(Xstar, axis=0, ddof=1)
+        sigma0 = np.sqrt(np.mean(V / lambda0**2) / Knew) * np.exp(0.2 * rng.standard_normal(Knew))
+    elif type_ == 3:  # :33-35
+        if vp["optimize_mu"]:
+            mu0 = np.zeros((D, K))
+        sigma0 = np.zeros(K)
+    else:
+        raise ValueError("vbinit:UnknownType")
+    vp0_vec = []
+    for iOpt in range(1, Nopts + 1):  # :38
+        v = copy_vp(vp)
+        v["K"] = Knew
+        mu, sigma, lam = mu0.copy(), sigma0.copy(), lambda0.copy()
+        w = w0.copy() if vp["optimize_weights"] else None
+        add_jitter = True
+        if type_ == 1:  # :50-73
+            if iOpt == 1:
+                add_jitter = False
+            if Knew > vp["K"]:
+                grow = Knew - vp["K"]
+                mu = np.hstack([mu, np.zeros((D, grow))])
+                sigma = np.concatenate([sigma, np.zeros(grow)])
+                if w is not None:
+                    w = np.concatenate([w, np.zeros(grow)])
+                for iNew in range(vp["K"], Knew):
+                    idx = int(rng.integers(vp["K"]))
+                    mu[:, iNew] = mu[:, idx]
+                    sigma[iNew] = sigma[idx]
+                    mu[:, iNew] = mu[:, iNew] + 0.5 * sigma[iNew] * lam * rng.standard_normal(D)
+                    if vp["optimize_sigma"]:
+                        sigma[iNew] = sigma[iNew] * math.exp(0.2 * rng.standard_normal())
+                    if vp["optimize_weights"]:
+                        xi = 0.25 + 0.25 * rng.random()
+                        w[iNew] = xi * w[idx]
+                        w[idx] = (1 - xi) * w[idx]
+        elif type_ == 2:  # :75-85
+            if iOpt == 1:
+                add_jitter = False
+            if vp["optimize_lambda"]:
+                lam = np.std(Xstar, axis=0, ddof=1)
+                lam = lam * math.sqrt(D / np.sum(lam**2))
+            if vp["optimize_weights"]:
+                w = np.ones(Knew) / Knew
+        else:  # :87-106
+            ord_ = rng.permutation(Nstar)
+            if vp["optimize_mu"]:
+                idx_ord = np.tile(np.arange(min(Knew, Nstar)), int(math.ceil(Knew / Nstar)))
+                mu = Xstar[ord_[idx_ord[:Knew]], :].T.copy()
+            else:
+                mu = mu0.copy()
+            V = _var_rows(mu) if K > 1 else np.var(Xstar, axis=0, ddof=1)
+            if vp["optimize_sigma"]:
+                sigma = math.sqrt(np.mean(V) / Knew) * np.exp(0.2 * rng.standard_normal(Knew))
+            if vp["optimize_lambda"]:
+                lam = np.std(Xstar, axis=0, ddof=1)
+                lam = lam * math.sqrt(D / np.sum(lam**2))
+            if vp["optimize_weights"]:
+                w = np.ones(Knew) / Knew
+        if add_jitter:  # :113-127
+            if vp["optimize_mu"]:
+                mu = mu + sigma[None, :] * (lam[:, None] * rng.standard_normal(mu.shape))
+            if vp["optimize_sigma"]:
+                sigma = sigma * np.exp(0.2 * rng.standard_normal(Knew))
+            if vp["optimize_lambda"]:
+                lam = lam * np.exp(0.2 * rng.standard_normal(D))
+            if vp["optimize_weights"]:
+                w = w * np.exp(0.2 * rng.standard_normal(Knew))
+                w = w / np.sum(w)
+        v["w"] = w if vp["optimize_weights"] else np.ones(Knew) / Knew  # :129-133
+        v["mu"] = mu if vp["optimize_mu"] else mu0.copy()
+        v["sigma"] = sigma
+        v["lambda"] = lam
+        vp0_vec.append(v)
+    return vp0_vec, type_vec
+
+
+def vpsieve_vbmc(Ninit, Nbest, vp, gp, optimState, options, K=None, *, rng, eps_for=None):
+    """misc/vpsieve_vbmc.m:1-90 -> (vp0_vec, vp0_type, elcbo_beta, compute_var, NSentK, NSentKFast, nelcbo_fill sorted input).
+    ``eps_for(kind, slot, it, K, Ns)`` supplies the standard normals an MC-entropy evaluation consumes (kind 'sieve',
+    slot = candidate index in generation order)."""
+    optimState = dict(optimState or {})
+    optimState.setdefault("delta", 0)
+    optimState.setdefault("EntropySwitch", False)
+    optimState.setdefault("Neff", gp["X"].shape[0])
+    if Nbest is None:
+        Nbest = 1
+    if K is None:
+        K = vp["K"]
+    vp = copy_vp(vp)
+    vp["delta"] = optimState["delta"]  # :18
+    if Ninit is None:
+        Ninit = int(math.ceil(evaloption_vbmc(options["NSelbo"], K)))
+    NSentK = int(math.ceil(evaloption_vbmc(options["NSent"], K) / K))  # :26
+    NSentKFast = int(math.ceil(evaloption_vbmc(options["NSentFast"], K) / K))
+    if optimState["EntropySwitch"] or K == 1:  # :30-33
+        NSentK = NSentKFast = 0
+    elcbo_beta = evaloption_vbmc(options["ELCBOWeight"], optimState["Neff"])  # :36
+    compute_var = elcbo_beta != 0
+    vp, thetabnd = vpbounds(vp, gp, options, K)  # :40
+    if Ninit > 0:
+        Xstar, ystar = gethpd_vbmc(gp["X"], gp["y"], options["HPDFrac"])  # :46
+        if Nbest == 1:
+            vp0_vec, vp0_type = vbinit_vbmc(1, Ninit, vp, K, Xstar, ystar, rng)
+        else:
+            n3 = int(math.ceil(Ninit / 3))
+            v1, t1 = vbinit_vbmc(1, n3, vp, K, Xstar, ystar, rng)
+            v2, t2 = vbinit_vbmc(2, n3, vp, K, Xstar, ystar, rng)
+            v3, t3 = vbinit_vbmc(3, Ninit - 2 * n3, vp, K, Xstar, ystar, rng)
+            vp0_vec = v1 + v2 + v3
+            vp0_type = np.concatenate([t1, t2, t3])
+        repo = optimState.get("vp_repo")
+        if repo and options.get("VariationalInitRepo"):  # :62-72
+            Ntheta = get_vptheta(vp0_vec[0])[0].size
+            extra = [rescale_params(vp0_vec[0], th) for th in repo if np.size(th) == Ntheta]
+            vp0_vec = vp0_vec + extra
+            vp0_type = np.concatenate([vp0_type, np.ones(len(extra), dtype=np.int64)])
+        nelcbo_fill = np.zeros(len(vp0_vec))
+        for iOpt in range(len(vp0_vec)):  # :75-79
+            theta0, vp0_vec[iOpt] = get_vptheta(vp0_vec[iOpt], vp["optimize_mu"], vp["optimize_sigma"], vp["optimize_lambda"],
+                                                vp["optimize_weights"])
+            eps = eps_for("sieve", iOpt, 0, K, NSentKFast) if (NSentKFast > 0 and eps_for) else None
+            r = negelcbo_vbmc(theta0, 0, vp0_vec[iOpt], gp, NSentKFast, False, int(compute_var), thetabnd=thetabnd, eps=eps,
+                              rng=None if eps is not None else rng)
+            nelcbo_fill[iOpt] = r["F"] + elcbo_beta * math.sqrt(r["varF"])
+        order = matlab_sort_ascend(nelcbo_fill)  # :82
+        vp0_vec = [vp0_vec[i] for i in order]
+        vp0_type = vp0_type[order]
+    else:
+        vp0_vec, vp0_type, nelcbo_fill = [vp], np.array([1]), np.zeros(0)
+    return vp0_vec, vp0_type, elcbo_beta, compute_var, NSentK, NSentKFast, nelcbo_fill
+
+
+def eval_fullelcbo(theta, vp, gp, beta, options, eps=None, rng=None):
+    """eval_fullelcbo, misc/vpoptimize_vbmc.m:257-305 (the filling branch) -> dict of the fields it stores."""
+    K = vp["K"]
+    NSentFineK = int(math.ceil(evaloption_vbmc(options["NSentFine"], K) / K))  # :278
+    computevar_flag = not options.get("SkipELBOVariance", False)
+    theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    r = negelcbo_vbmc(theta, 0, vp, gp, NSentFineK, False, 1 if computevar_flag else 0, thetabnd=None, separate_K=True, eps=eps,
+                      rng=rng)  # :288-289
+    return {"nelbo": r["F"], "G": r["G"], "H": r["H"], "varF": r["varF"], "varG": r["varG"], "varH": r["varH"],
+            "varss": r["varGss"], "nelcbo": r["F"] + beta * math.sqrt(r["varF"]), "theta": theta.copy(), "I_sk": r["I_sk"],
+            "J_sjk": r["J_sjk"]}
+
+
+def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, options=None, *, rng, eps_for):
+    """misc/vpoptimize_vbmc.m:1-254, the gradient-available stochastic branch (ELCBOWeight = 0, NSentK > 0, Adam :108-135)
+    plus the pruning loop (:196-243) -> (vp, varss, pruned).  ``eps_for(kind, slot, it, K, Ns)`` supplies the draws of
+    every MC-entropy evaluation: kind 'adam' (slot = chain iOpt-1, it = Adam iteration 1..), 'full' (slot = 2*(iOpt-1) for
+    the midpoint, +1 for the endpoint), 'prune' (slot = running count 1..)."""
+    options = dict(VBMC_OPTIONS, **(options or {}))
+    optimState = dict(optimState or {})
+    if K is None:
+        K = vp["K"]
+    optimState.setdefault("Warmup", not vp["optimize_weights"])  # :18
+    optimState.setdefault("temperature", 1)
+    vp0_vec, vp0_type, elcbo_beta, compute_var, NSentK, _, _ = vpsieve_vbmc(Nfastopts, Nslowopts, vp, gp, optimState, options, K,
+                                                                            rng=rng, eps_for=eps_for)  # :23-24
+    vp, thetabnd = vpbounds(vp, gp, options, K)  # :27
+    if compute_var or NSentK == 0:
+        raise NotImplementedError("only the Adam branch is restated (CMA-ES / fminunc are third-party optimisers)")
+    D = vp["D"]
+    vp0_type = list(vp0_type)
+    nslot = 2 * Nslowopts
+    stats = [None] * nslot
+    nelcbo = np.full(nslot, np.inf)  # :262-269
+    vp0_fine = [None] * nslot
+    for iOpt in range(1, Nslowopts + 1):  # :49
+        iOpt_mid, iOpt_end = 2 * iOpt - 2, 2 * iOpt - 1
+        if Nslowopts == 1:  # :54-61
+            idx = 0
+        elif Nslowopts == 2:
+            idx = [i for i, t in enumerate(vp0_type) if (t == 1 if iOpt == 1 else (t == 2 or t == 3))][0]
+        else:
+            idx = [i for i, t in enumerate(vp0_type) if t == ((iOpt - 1) % 3) + 1][0]
+        vp0 = rescale_params(vp0_vec[idx])  # :65
+        vp0_type.pop(idx)
+        vp0_vec.pop(idx)
+        parts = []  # :68-71
+        if vp["optimize_mu"]:
+            parts.append(vp0["mu"].reshape(-1, order="F"))
+        if vp["optimize_sigma"]:
+            parts.append(np.log(vp0["sigma"]))
+        if vp["optimize_lambda"]:
+            parts.append(np.log(vp0["lambda"]))
+        if vp["optimize_weights"]:
+            parts.append(np.log(vp0["w"]))
+        theta0 = np.concatenate(parts)
+        it_box = [0]
+
+        def vbtrainmc_fun(theta_, vp0=vp0, iOpt=iOpt):  # :74
+            it_box[0] += 1
+            r = negelcbo_vbmc(theta_, elcbo_beta, vp0, gp, NSentK, True, 0, thetabnd=thetabnd,
+                              eps=eps_for("adam", iOpt - 1, it_box[0], K, NSentK))
+            return r["F"], r["dF"]
+
+        ms = {"min": min(options["SGDStepSize"], 0.001)}  # :112-127
+        if optimState["Warmup"] or not vp["optimize_weights"]:
+            scaling_factor = min(0.1, options["SGDStepSize"] * 10)
+        else:
+            scaling_factor = min(0.1, options["SGDStepSize"])
+        ms["max"] = max(ms["min"], scaling_factor)
+        ms["decay"] = 200
+        MaxIter = int(min(options["MaxIterStochastic"] or 100 * (2 + D), 1e4))
+        thetaopt, _, theta_lst, fval_lst, _ = fminadam(vbtrainmc_fun, theta0, TolFun=options["TolFunStochastic"], MaxIter=MaxIter,
+                                                       master_stepsize=ms)  # :128-129
+        if options["ELCBOmidpoint"]:  # :131-136
+            idx_mid = int(np.argmin(fval_lst))
+            stats[iOpt_mid] = eval_fullelcbo(theta_lst[:, idx_mid], vp0, gp, elcbo_beta, options,
+                                             eps=eps_for("full", iOpt_mid, 0, K, None))
+            nelcbo[iOpt_mid] = stats[iOpt_mid]["nelcbo"]
+        stats[iOpt_end] = eval_fullelcbo(thetaopt, vp0, gp, elcbo_beta, options, eps=eps_for("full", iOpt_end, 0, K, None))  # :165
+        nelcbo[iOpt_end] = stats[iOpt_end]["nelcbo"]
+        vp0_fine[iOpt_mid] = vp0
+        vp0_fine[iOpt_end] = vp0
+    idx = int(np.argmin(nelcbo))  # :176
+    s = stats[idx]
+    elbo = -s["nelbo"]
+    elbo_sd = math.sqrt(s["varF"])
+    G, H, varss, varG, varH = s["G"], s["H"], s["varss"], s["varG"], s["varH"]
+    I_sk = np.array(s["I_sk"], copy=True)
+    J_sjk = np.array(s["J_sjk"], copy=True)
+    vp = rescale_params(vp0_fine[idx], s["theta"])  # :189-190
+    vp["temperature"] = optimState["temperature"]
+    pruned = 0  # :196
+    if vp["optimize_weights"]:
+        alreadychecked = np.zeros(vp["K"], dtype=bool)
+        count = 0
+        while np.any((vp["w"] < options["TolWeight"]) & ~alreadychecked):  # :201
+            vp_pruned = copy_vp(vp)
+            cand = np.nonzero((vp_pruned["w"] < options["TolWeight"]) & ~alreadychecked)[0]
+            idx = int(cand[int(rng.integers(cand.size))])  # :206
+            vp_pruned["w"] = np.delete(vp_pruned["w"], idx)
+            if "eta" in vp_pruned:
+                vp_pruned["eta"] = np.delete(vp_pruned["eta"], idx)
+            vp_pruned["sigma"] = np.delete(vp_pruned["sigma"], idx)
+            vp_pruned["mu"] = np.delete(vp_pruned["mu"], idx, axis=1)
+            vp_pruned["K"] -= 1
+            theta_pruned, vp_pruned = get_vptheta(vp_pruned, vp_pruned["optimize_mu"], vp_pruned["optimize_sigma"],
+                                                  vp_pruned["optimize_lambda"], vp_pruned["optimize_weights"])  # :212
+            count += 1
+            sp = eval_fullelcbo(theta_pruned, vp_pruned, gp, elcbo_beta, options, eps=eps_for("prune", count, 0, vp_pruned["K"], None))
+            elbo_pruned = -sp["nelbo"]
+            elbo_pruned_sd = math.sqrt(sp["varF"])
+            delta_elcbo = abs((elbo_pruned - options["ELCBOImproWeight"] * elbo_pruned_sd)
+                              - (elbo - options["ELCBOImproWeight"] * elbo_sd))  # :220-221
+            PruningThreshold = options["TolImprovement"] * evaloption_vbmc(options["PruningThresholdMultiplier"], K)  # :224-225
+            if delta_elcbo < PruningThreshold:
+                vp = vp_pruned
+                elbo, elbo_sd = elbo_pruned, elbo_pruned_sd
+                G, H, varss, varG, varH = sp["G"], sp["H"], sp["varss"], sp["varG"], sp["varH"]
+                pruned += 1
+                alreadychecked = np.delete(alreadychecked, idx)
+                I_sk = np.delete(I_sk, idx, axis=1)  # :238
+                J_sjk = np.delete(J_sjk, idx, axis=2)  # :239: third dimension only
+            else:
+                alreadychecked[idx] = True
+    vp["stats"] = {"elbo": elbo, "elbo_sd": elbo_sd, "elogjoint": G, "elogjoint_sd": math.sqrt(varG), "entropy": H,
+                   "entropy_sd": math.sqrt(varH), "stable": False, "I_sk": I_sk, "J_sjk": J_sjk}
+    return vp, varss, pruned

@@ -1,0 +1,76 @@
+"""GPU: vbmc_amd.vpoptimize_vbmc (batched chains on the device, batched eval_fullelcbo, pruning) against the sequential
+oracle restatement of misc/vpoptimize_vbmc.m fed the dumped device streams (vbmc_rng_dump): the selected vp, elbo,
+pruned, I_sk and J_sjk must agree -- not just "did not get worse"."""
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._vpopt import OPTS, compare, eps_from_trace, vpopt_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+def _device_stream(va, D):
+    eng = va.default_engine()
+    cache = {}
+
+    def stream(seed, r, R_, K, Ns):
+        key = (seed, R_, K, Ns)
+        if key not in cache:
+            cache.clear()
+            cache[key] = eng.ctx.rng_dump(D, K, R_, Ns, seed)
+        return cache[key][r]
+
+    return stream
+
+
+@pytest.mark.parametrize("device_adam", [True, False])
+@pytest.mark.parametrize("nslow,midpoint", [(2, True), (3, False)])
+def test_vpoptimize_matches_oracle_on_the_device_streams(va, device_adam, nslow, midpoint):
+    p, gp, vp = vpopt_problem()
+    opts = dict(OPTS, ELCBOmidpoint=midpoint)
+    trace = []
+    vpa, varss_a, pruned_a = va.vpoptimize_vbmc(12, nslow, vp, gp, options=opts, rng=np.random.default_rng(3), seed=5,
+                                                device_adam=device_adam, trace=trace)
+    vpb, varss_b, pruned_b = R.vpoptimize_vbmc(12, nslow, vp, gp, options=opts, rng=np.random.default_rng(3),
+                                               eps_for=eps_from_trace(trace, _device_stream(va, vp["D"])))
+    # 60 Adam iterations amplify the 1e-12 differences of single evaluations a little; the variance terms are differences of
+    # nearly equal numbers (tests/test_gpu_variance.py)
+    compare(vpa, vpb, varss_a, varss_b, pruned_a, pruned_b, 1e-6)
+    assert pruned_a >= 1
+
+
+def test_device_and_host_loop_agree(va):
+    p, gp, vp = vpopt_problem(seed=43)
+    a = va.vpoptimize_vbmc(12, 2, vp, gp, options=OPTS, rng=np.random.default_rng(1), seed=9, device_adam=True)
+    b = va.vpoptimize_vbmc(12, 2, vp, gp, options=OPTS, rng=np.random.default_rng(1), seed=9, device_adam=False)
+    compare(a[0], b[0], a[1], b[1], a[2], b[2], 1e-8)
+
+
+def test_elcbo_weighted_path_runs_cmaes_on_batched_values(va):
+    """ELCBOWeight ~= 0: the sieve adds beta*sqrt(varF) (vpsieve_vbmc.m:36-37,78) and the optimiser is CMA-ES on the value
+    (vpoptimize_vbmc.m:38-46,137-160).  Property checks: the sieve values are the oracle's, the result is a valid vp, and
+    the optimised ELCBO is not worse than the best sieve candidate's."""
+    p, gp, vp = vpopt_problem(seed=44, K=3, weights=(0.5, 0.3, 0.2))
+    opts = dict(OPTS, ELCBOWeight=0.7, CMAESMaxFunEvals=1500, TolWeight=0.01)
+    out = va.vpsieve_vbmc(9, 2, vp, gp, options=opts, rng=np.random.default_rng(2))
+    assert out[3] and out[2] == 0.7
+    _, tb = R.vpbounds(vp, gp, dict(R.VBMC_OPTIONS, **opts))
+    for v, val in zip(out[0], np.sort(out[6])):
+        th, v2 = R.get_vptheta(v)
+        r = R.negelcbo_vbmc(th, 0, v2, gp, 0, False, 1, thetabnd=tb)
+        assert abs(r["F"] + 0.7 * np.sqrt(r["varF"]) - val) < 1e-7 * max(1.0, abs(val))
+    trace = []
+    vp2, varss, pruned = va.vpoptimize_vbmc(9, 2, vp, gp, options=opts, rng=np.random.default_rng(2), seed=3, trace=trace)
+    assert [t["kind"] for t in trace if t["kind"] == "cmaes"] == ["cmaes", "cmaes"]
+    assert abs(np.sum(vp2["w"]) - 1) < 1e-12 and abs(np.sum(vp2["lambda"] ** 2) - vp["D"]) < 1e-9
+    s = vp2["stats"]
+    assert np.isfinite(s["elbo"]) and s["elbo_sd"] > 0
+    assert -(s["elbo"]) + 0.7 * s["elbo_sd"] < np.min(out[6]) + 0.5   # soft bounds / MC noise differ between the two evaluations
