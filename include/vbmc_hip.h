@@ -190,7 +190,8 @@ vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const double* a, co
  * [H,dH] = entmc_vbmc(vp,Ns,grad_flags,1) (ent/entmc_vbmc.m:1) for Ns > 0 and entlb_vbmc(vp,grad_flags,1)
  * (ent/entlb_vbmc.m:1) for Ns = 0, with grad_flags = optimize[]; G = 0, dG = 0; compute_var and
  * separate_K must be 0.  With Ns = 0 and a surrogate, G, dG, varG, varGss, I_sk, J_sjk are the outputs of
- * gplogjoint(vp,gp,grad_flags,1,1,compute_var,separate_K) (misc/gplogjoint.m:1) on its own.
+ * gplogjoint(vp,gp,grad_flags,1,1,compute_var,separate_K) (misc/gplogjoint.m:1) on its own; G_s / varG_s are its
+ * avg_flag = 0 outputs.
  */
 typedef struct vbmc_elbo_args {
   uint32_t struct_size;      /* = sizeof(vbmc_elbo_args), for ABI versioning                */
@@ -232,6 +233,10 @@ typedef struct vbmc_elbo_args {
   double* varGss;            /* R                                                           */
   double* I_sk;              /* S x K x R                                                   */
   double* J_sjk;             /* S x K x K x R                                               */
+  /* per-hyper-sample outputs of gplogjoint(vp,gp,0,0,...) (avg_flag = 0, misc/gplogjoint.m:399: no averaging) -- what
+   * private/activesample_vbmc.m:155 ([~,~,varF] = gplogjoint(vp,gp,0,0,0,1)) and misc/vpoptimizeweights_vbmc.m:42 read */
+  double* G_s;               /* S x R  F(s) = sum_k w_k I_sk  (:203)                        */
+  double* varG_s;            /* S x R  varF(s), each max(.,eps) (:283,:329-332,:350); needs compute_var */
 } vbmc_elbo_args;
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);

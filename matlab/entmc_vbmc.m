@@ -21,7 +21,7 @@ if g
     vpt.optimize_mu = logical(grad_flags(1)); vpt.optimize_sigma = logical(grad_flags(2));
     vpt.optimize_lambda = logical(grad_flags(3)); vpt.optimize_weights = logical(grad_flags(4));
 end
-theta = get_vptheta(vpt);                      % misc/get_vptheta.m
+[theta,vpt] = get_vptheta(vpt);                % misc/get_vptheta.m: the rescaled vp, so that theta and the fixed groups agree
 epsblk = [];
 if strcmp(getenv('VBMC_HIP_PARITY'),'1')
     Nse = ceil(Ns/2)*2;

@@ -1,10 +1,12 @@
 function [F,dF,varF,dvarF,varss,I_sk,J_sjk] = gplogjoint(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K)
 %GPLOGJOINT Drop-in shim: expected log joint (Bayesian quadrature) on an MI355X through vbmc_hip_mex.
 %
-% Same signature and defaulting as the reference (misc/gplogjoint.m:1-30).  Accelerated: averaged over
-% hyper-parameter samples (AVG_FLAG), Jacobian-transformed gradients (JACOBIAN_FLAG) for exactly the
-% parameter groups VP optimises, no gradient of the variance as a separate output.  Other call forms
-% go to the reference further down the path.
+% Same signature and defaulting as the reference (misc/gplogjoint.m:1-30).  Accelerated: (a) averaged over
+% hyper-parameter samples (AVG_FLAG = 1) with Jacobian-transformed gradients (JACOBIAN_FLAG) for exactly the
+% parameter groups VP optimises; (b) per-hyper-sample values WITHOUT gradients (AVG_FLAG = 0: F and VARF are
+% 1-by-Ns, VARSS = 0) -- the forms private/activesample_vbmc.m:155 ([~,~,varF] = gplogjoint(vp,gp,0,0,0,1)) and
+% misc/vpoptimizeweights_vbmc.m:42 ([~,~,~,~,~,I_sk,J_sjk] = gplogjoint(vp,gp,0,0,0,1,1)) use.  No gradient of the
+% variance as a separate output.  Other call forms go to the reference further down the path.
 if nargin < 3; grad_flags = []; end
 if nargin < 4 || isempty(avg_flag); avg_flag = true; end
 if nargin < 5 || isempty(jacobian_flag); jacobian_flag = true; end
@@ -20,7 +22,7 @@ if compute_vargrad && compute_var ~= 2
 end
 
 vpflags = [vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambda, vp.optimize_weights];
-supported = avg_flag && jacobian_flag && ~compute_vargrad && any(gp.meanfun == [0 1 4]) ...
+supported = (avg_flag || ~any(grad_flags)) && (jacobian_flag || ~any(grad_flags)) && ~compute_vargrad && any(gp.meanfun == [0 1 4]) ...
     && (~any(grad_flags) || isequal(logical(grad_flags(:)'),logical(vpflags))) ...
     && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) && (~vp.optimize_weights || isfield(vp,'eta'));
 if ~supported
@@ -31,11 +33,18 @@ if ~supported
     [F,dF,varF,dvarF,varss,I_sk,J_sjk] = outs{:};
     return;
 end
-theta = get_vptheta(vp);                       % misc/get_vptheta.m
+[theta,vp] = get_vptheta(vp);                  % misc/get_vptheta.m: the rescaled vp, so that theta and the fixed groups agree
 h = vbmc_hip_gp_handle(gp);
 g = any(grad_flags);
-[~,~,F,~,varF,~,varss,I_sk,J_sjk,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,double(g), ...
-    double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+if avg_flag || numel(gp.post) == 1
+    [~,~,F,~,varF,~,varss,I_sk,J_sjk,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,double(g), ...
+        double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+    if ~avg_flag; varss = 0; end
+else                                            % misc/gplogjoint.m:398-399: no averaging, varss stays 0
+    [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0, ...
+        double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+    varss = 0;
+end
 if ~g; dF = []; end
 dvarF = [];
 if ~compute_var; varF = []; varss = []; end

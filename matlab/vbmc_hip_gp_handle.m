@@ -1,11 +1,14 @@
 function h = vbmc_hip_gp_handle(gp,newhandle)
 %VBMC_HIP_GP_HANDLE Upload gp.post once per distinct GP; free the previous one.
 % The objective handle closes over a constant gp for a whole vpoptimize_vbmc call
-% (misc/vpoptimize_vbmc.m:71), so a one-entry cache keyed on a cheap fingerprint suffices.
+% (misc/vpoptimize_vbmc.m:71), so a one-entry cache suffices.  The key is a fingerprint of EVERYTHING the device copy
+% is built from -- gp.X, every gp.post(s).hyp and every gp.post(s).alpha (alpha changes whenever y, s2 or a
+% hyper-parameter does; L is a function of X, hyp and s2) -- as three differently weighted checksums, O(N*D + S*N) per
+% call: a stale hit would return silently wrong numbers, so no field is sampled.
 % VBMC_HIP_GP_HANDLE(GP,NEWHANDLE) registers a device surrogate that already exists for GP (the rank-one
 % append of gplite_post builds it on the device), so that the next call does not upload it again.
 persistent key handle
-k = [size(gp.X), numel(gp.post), gp.post(1).alpha(1), gp.post(1).hyp(1), gp.post(end).alpha(end)];
+k = fingerprint(gp);
 if nargin > 1
     if ~isempty(handle) && handle ~= newhandle; vbmc_hip_mex('gp_free',handle); end
     handle = newhandle; key = k;
@@ -15,4 +18,15 @@ elseif isempty(key) || ~isequal(k,key)
     key = k;
 end
 h = handle;
+end
+
+function k = fingerprint(gp)
+S = numel(gp.post);
+hyp = [gp.post.hyp];                      % Nhyp x S
+alpha = [gp.post.alpha];                  % N x S
+mult = [gp.post.sn2_mult];
+v = [gp.X(:); hyp(:); alpha(:); mult(:)];
+n = numel(v);
+w = 1 + mod((1:n)'*0.6180339887498949,1); % fixed, position-dependent weights
+k = [size(gp.X), S, gp.meanfun, double(gp.noisefun(:)'), sum(v), w'*v, sum(abs(v).*w.^2)];
 end

@@ -8,12 +8,16 @@
 //     vbmc_hip_mex('open', device)                         -> (context kept in a persistent, mexLock'ed)
 //     h  = vbmc_hip_mex('gp_upload', gpstruct)             -> uint64 handle of a device-resident gp.post
 //          vbmc_hip_mex('gp_free', h)
-//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
-//                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty)
-//     [F,dF,varG] = vbmc_hip_mex('elbo_batch', h, Theta /*T x R*/, vp, Ns, compute_grad, compute_var, beta,
-//                                thetabnd_or_empty, seed)      (the R candidates of vpsieve_vbmc.m:74-78 in one pass)
-//     [x,f,iters] = vbmc_hip_mex('adam', h, Theta0 /*T x R*/, vp, Ns, compute_var, beta, thetabnd_or_empty, seed,
-//                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device)
+//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk,dG,G_s,varG_s] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
+//                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty, seed, numel(gp.post))
+//                                     (G_s, varG_s: the per-hyper-sample outputs of gplogjoint(...,avg_flag = 0))
+//     [F,dF,varG,G,H,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo_batch', h, Theta /*T x R*/, vp, Ns, compute_grad, compute_var, beta,
+//                                thetabnd_or_empty, seed, separate_K, numel(gp.post))
+//                                (the R candidates of vpsieve_vbmc.m:74-78, or the 2*Nslowopts eval_fullelcbo calls of
+//                                 vpoptimize_vbmc.m:134,165, in one pass; I_sk is S x K x R, J_sjk S x K x K x R)
+//     [x,f,iters,xtab,ftab] = vbmc_hip_mex('adam', h, Theta0 /*T x R*/, vp, Ns, compute_var, beta, thetabnd_or_empty, seed,
+//                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device; xtab is
+//                                T x MaxIter x R, ftab MaxIter x R, the first iters(r) entries of chain r filled)
 //     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
 //     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
 //     [acq,fbar,vtot] = vbmc_hip_mex('acq', h, Xs, acq_id, vp, ymax, var_regularized, TolGPVar, gplengthscale, X_rescaled, sn2new)
@@ -23,9 +27,12 @@
 //     [nlZ,dnlZ] = vbmc_hip_mex('gp_nlz', Hyp /*Nhyp x B*/, X, y, s2, meanfun, noisefun)   (gplite_nlZ for B vectors)
 //     C = vbmc_hip_mex('sq_dist', a, b)
 //
-// Errors are raised with mexErrMsgIdAndTxt AFTER all temporaries are released (it long-jumps);
+// Errors: mexErrMsgIdAndTxt long-jumps out of the MEX function without running C++ destructors, so it is called from
+// exactly one place -- mexFunction itself, which owns no C++ object -- after dispatch() has RETURNED (all its
+// std::vector / std::string temporaries destroyed) with the id and message parked in static character buffers.
 // VBMC_ERR_UNSUPPORTED becomes the id 'vbmc_hip:unsupported' which the shims catch to fall through
 // to the reference .m implementation (SURVEY.md 8b "Errors").
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -40,22 +47,39 @@ static void at_exit() {
   if (g_ctx) { vbmc_ctx_destroy(g_ctx); g_ctx = nullptr; }
 }
 
-static void ensure_ctx(int device) {
-  if (g_ctx) return;
-  vbmc_status st = vbmc_ctx_create(device, nullptr, &g_ctx);
-  if (st != VBMC_OK) mexErrMsgIdAndTxt("vbmc_hip:nodevice", "libvbmc_hip: no gfx950 (MI355X) device available (status %d)", st);
-  mexLock();
-  mexAtExit(at_exit);
+// pending error of the current call (plain static storage: survives the long jump, owns nothing)
+static char g_err_id[96];
+static char g_err_msg[640];
+
+static int raise(const char* id, const char* msg) {
+  snprintf(g_err_id, sizeof g_err_id, "%s", id);
+  snprintf(g_err_msg, sizeof g_err_msg, "%s", msg);
+  return 1;
 }
 
-static void fail(vbmc_status st) {
-  std::string msg = vbmc_last_error(g_ctx);
-  if (st == VBMC_ERR_UNSUPPORTED) mexErrMsgIdAndTxt("vbmc_hip:unsupported", "%s", msg.c_str());
-  // messages of INVALID errors start with the reference's own error id where one exists
-  size_t sp = msg.find(' ');
-  if (st == VBMC_ERR_INVALID && sp != std::string::npos && msg.find(':') < sp)
-    mexErrMsgIdAndTxt(msg.substr(0, sp).c_str(), "%s", msg.c_str() + sp + 1);
-  mexErrMsgIdAndTxt("vbmc_hip:error", "%s", msg.c_str());
+// library status -> pending MATLAB error; returns nonzero so that call sites read `if (st != VBMC_OK) return fail(st);`
+static int fail(vbmc_status st) {
+  const char* msg = g_ctx ? vbmc_last_error(g_ctx) : "no context";
+  if (st == VBMC_ERR_UNSUPPORTED) return raise("vbmc_hip:unsupported", msg);
+  // messages of INVALID errors start with the reference's own error id where one exists ("gplogjoint:FullVarianceGradient ...")
+  const char* sp = strchr(msg, ' ');
+  const char* col = strchr(msg, ':');
+  if (st == VBMC_ERR_INVALID && sp && col && col < sp && (size_t)(sp - msg) < sizeof g_err_id) {
+    memcpy(g_err_id, msg, (size_t)(sp - msg));
+    g_err_id[sp - msg] = 0;
+    snprintf(g_err_msg, sizeof g_err_msg, "%s", sp + 1);
+    return 1;
+  }
+  return raise("vbmc_hip:error", msg);
+}
+
+static int ensure_ctx(int device) {
+  if (g_ctx) return 0;
+  vbmc_status st = vbmc_ctx_create(device, nullptr, &g_ctx);
+  if (st != VBMC_OK) return raise("vbmc_hip:nodevice", "libvbmc_hip: no gfx950 (MI355X) device available");
+  mexLock();
+  mexAtExit(at_exit);
+  return 0;
 }
 
 static const double* dbl(const mxArray* a) { return (a && !mxIsEmpty(a)) ? mxGetDoubles(a) : nullptr; }
@@ -86,13 +110,14 @@ static void fill_vp_args(vbmc_elbo_args& a, const mxArray* vp, const mxArray* tb
   { const char* sc = getenv("VBMC_HIP_SPARSE_CUTOFF"); a.sparse_cutoff = sc ? atof(sc) : 0.0; }
 }
 
-void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
-  if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("vbmc_hip:usage", "first argument must be a command string");
+// Every command; returns 0 on success, nonzero with g_err_id / g_err_msg set.  All C++ objects live in here.
+static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  if (nrhs < 1 || !mxIsChar(prhs[0])) return raise("vbmc_hip:usage", "first argument must be a command string");
   char cmd[32];
   mxGetString(prhs[0], cmd, sizeof cmd);
 
-  if (!strcmp(cmd, "open")) { ensure_ctx(nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0); return; }
-  ensure_ctx(0);
+  if (!strcmp(cmd, "open")) return ensure_ctx(nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0);
+  if (ensure_ctx(0)) return 1;
 
   if (!strcmp(cmd, "gp_upload")) {
     const mxArray* gp = prhs[1];
@@ -119,12 +144,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                     sW1.data(), lch.data(), &h);
     if (st == VBMC_OK) st = vbmc_gp_set_noise(g_ctx, h, nf, mult.data());
     hyp = {}; alpha = {}; L = {};
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
     *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
-    return;
+    return 0;
   }
-  if (!strcmp(cmd, "gp_free")) { vbmc_gp_free(g_ctx, (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return; }
+  if (!strcmp(cmd, "gp_free")) { vbmc_gp_free(g_ctx, (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return 0; }
 
   if (!strcmp(cmd, "elbo")) {
     // (h, theta, vp, Ns, compute_grad, compute_var, separate_K, beta, thetabnd, eps)
@@ -156,11 +181,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       a.I_sk = mxGetDoubles(Isk);
       if (a.compute_var) { mwSize dims[3] = {(mwSize)S, (mwSize)a.K, (mwSize)a.K}; Jsjk = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); a.J_sjk = mxGetDoubles(Jsjk); }
     }
+    mxArray *Gs = nullptr, *vGs = nullptr;
+    if (nlhs > 10 && nrhs > 12) {   // per-hyper-sample values (gplogjoint avg_flag = 0)
+      const int S = (int)mxGetScalar(prhs[12]);
+      Gs = mxCreateDoubleMatrix(1, S, mxREAL);
+      a.G_s = mxGetDoubles(Gs);
+      if (nlhs > 11 && a.compute_var) { vGs = mxCreateDoubleMatrix(1, S, mxREAL); a.varG_s = mxGetDoubles(vGs); }
+    }
     vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
-    if (st != VBMC_OK) fail(st);  // MATLAB frees the mxArrays created above on error
-    mxArray* outs[10] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG};
-    for (int i = 0; i < 10 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
-    return;
+    if (st != VBMC_OK) return fail(st);  // MATLAB frees the mxArrays created above on error
+    mxArray* outs[12] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs};
+    for (int i = 0; i < 12 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    return 0;
   }
 
   if (!strcmp(cmd, "elbo_batch")) {
@@ -181,12 +213,24 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray* vG = mxCreateDoubleMatrix(1, a.R, mxREAL);
     a.F = mxGetDoubles(F); a.varG = mxGetDoubles(vG);
     if (a.compute_grad) a.dF = mxGetDoubles(dF);
+    mxArray *G = nullptr, *H = nullptr, *vss = nullptr, *Isk = nullptr, *Jsjk = nullptr;
+    if (nlhs > 3) { G = mxCreateDoubleMatrix(1, a.R, mxREAL); a.G = mxGetDoubles(G); }
+    if (nlhs > 4) { H = mxCreateDoubleMatrix(1, a.R, mxREAL); a.H = mxGetDoubles(H); }
+    if (nlhs > 5) { vss = mxCreateDoubleMatrix(1, a.R, mxREAL); a.varGss = mxGetDoubles(vss); }
+    a.separate_K = (nrhs > 10 && nlhs > 6) ? (int)mxGetScalar(prhs[10]) : 0;
+    if (a.separate_K) {
+      if (nrhs < 12) return raise("vbmc_hip:usage", "elbo_batch with separate_K needs numel(gp.post) as its 12th argument");
+      const mwSize S = (mwSize)mxGetScalar(prhs[11]);
+      mwSize d3[3] = {S, (mwSize)a.K, (mwSize)a.R}, d4[4] = {S, (mwSize)a.K, (mwSize)a.K, (mwSize)a.R};
+      Isk = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+      a.I_sk = mxGetDoubles(Isk);
+      if (a.compute_var && nlhs > 7) { Jsjk = mxCreateNumericArray(4, d4, mxDOUBLE_CLASS, mxREAL); a.J_sjk = mxGetDoubles(Jsjk); }
+    }
     vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
-    if (st != VBMC_OK) fail(st);
-    plhs[0] = F;
-    if (nlhs > 1) plhs[1] = dF;
-    if (nlhs > 2) plhs[2] = vG;
-    return;
+    if (st != VBMC_OK) return fail(st);
+    mxArray* outs[8] = {F, dF, vG, G, H, vss, Isk, Jsjk};
+    for (int i = 0; i < 8 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    return 0;
   }
 
   if (!strcmp(cmd, "adam")) {
@@ -207,13 +251,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     for (int i = 0; nrhs > 11 && i < 3 && i < (int)mxGetNumberOfElements(prhs[11]); ++i) step[i] = mxGetDoubles(prhs[11])[i];
     mxArray *x = mxCreateDoubleMatrix(T, a.R, mxREAL), *f = mxCreateDoubleMatrix(1, a.R, mxREAL);
     mxArray* it = mxCreateNumericMatrix(1, a.R, mxINT32_CLASS, mxREAL);
+    mxArray *xtab = nullptr, *ftab = nullptr;
+    if (nlhs > 3) { mwSize d3[3] = {(mwSize)T, (mwSize)MaxIter, (mwSize)a.R}; xtab = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL); }
+    if (nlhs > 4) ftab = mxCreateDoubleMatrix(MaxIter, a.R, mxREAL);
     vbmc_status st = vbmc_adam_batch(g_ctx, h, &a, TolFun, MaxIter, step[0], step[1], step[2], mxGetDoubles(x), mxGetDoubles(f),
-                                     (int32_t*)mxGetData(it), nullptr, nullptr);
-    if (st != VBMC_OK) fail(st);
+                                     (int32_t*)mxGetData(it), xtab ? mxGetDoubles(xtab) : nullptr, ftab ? mxGetDoubles(ftab) : nullptr);
+    if (st != VBMC_OK) return fail(st);
     plhs[0] = x;
     if (nlhs > 1) plhs[1] = f;
     if (nlhs > 2) plhs[2] = it;
-    return;
+    if (nlhs > 3) plhs[3] = xtab;
+    if (nlhs > 4) plhs[4] = ftab;
+    return 0;
   }
 
   if (!strcmp(cmd, "gp_post")) {
@@ -232,14 +281,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     vbmc_status st = vbmc_gp_post(g_ctx, N, D, S, Nhyp, (int)mxGetScalar(prhs[5]), nf, mxGetDoubles(X), mxGetDoubles(y), dbl(s2),
                                   mxGetDoubles(hyp), mxGetDoubles(plhs[0]), mxGetDoubles(L), mxGetDoubles(sW), mxGetDoubles(mult),
                                   (uint8_t*)mxGetData(lch), &h);
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     if (nlhs > 1) plhs[1] = L;
     if (nlhs > 2) plhs[2] = sW;
     if (nlhs > 3) plhs[3] = mult;
     if (nlhs > 4) plhs[4] = lch;
     if (nlhs > 5) { plhs[5] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[5]) = (uint64_t)(uintptr_t)h; }
     else vbmc_gp_free(g_ctx, h);
-    return;
+    return 0;
   }
 
   if (!strcmp(cmd, "gp_rank1")) {
@@ -253,11 +302,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     vbmc_gp* hn = nullptr;
     vbmc_status st = vbmc_gp_rank1_update(g_ctx, h, mxGetDoubles(Xn), mxGetScalar(prhs[3]), dbl(prhs[4]), dbl(prhs[5]),
                                           mxGetDoubles(prhs[6]), mxGetDoubles(plhs[0]), nlhs > 1 ? mxGetDoubles(L) : nullptr, &hn);
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     if (nlhs > 1) plhs[1] = L;
     if (nlhs > 2) { plhs[2] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[2]) = (uint64_t)(uintptr_t)hn; }
     else vbmc_gp_free(g_ctx, hn);
-    return;
+    return 0;
   }
 
   if (!strcmp(cmd, "acq")) {
@@ -271,10 +320,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                    mxGetScalar(prhs[5]), (int)mxGetScalar(prhs[6]), mxGetScalar(prhs[7]),
                                    nrhs > 8 ? dbl(prhs[8]) : nullptr, nrhs > 9 ? dbl(prhs[9]) : nullptr, nrhs > 10 ? dbl(prhs[10]) : nullptr,
                                    mxGetDoubles(plhs[0]), mxGetDoubles(fb), mxGetDoubles(vt));
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     if (nlhs > 1) plhs[1] = fb;
     if (nlhs > 2) plhs[2] = vt;
-    return;
+    return 0;
   }
 
   if (!strcmp(cmd, "is_create")) {
@@ -285,12 +334,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     vbmc_acq_is* is = nullptr;
     vbmc_status st = vbmc_acq_is_create(g_ctx, h, Na, mxGetDoubles(Xa), nd > 2 ? 1 : 0, nrhs > 3 ? dbl(prhs[3]) : nullptr,
                                         nrhs > 4 ? dbl(prhs[4]) : nullptr, nrhs > 5 ? dbl(prhs[5]) : nullptr, &is);
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
     *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)is;
-    return;
+    return 0;
   }
-  if (!strcmp(cmd, "is_free")) { vbmc_acq_is_free(g_ctx, (vbmc_acq_is*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return; }
+  if (!strcmp(cmd, "is_free")) { vbmc_acq_is_free(g_ctx, (vbmc_acq_is*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return 0; }
 
   if (!strcmp(cmd, "acq_iqr")) {
     vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
@@ -301,10 +350,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray *fb = mxCreateDoubleMatrix(Nstar, 1, mxREAL), *vt = mxCreateDoubleMatrix(Nstar, 1, mxREAL);
     vbmc_status st = vbmc_acq_iqr_eval(g_ctx, h, is, Nstar, mxGetDoubles(Xs), dbl(prhs[4]), dbl(prhs[5]), dbl(prhs[6]),
                                        (int)mxGetScalar(prhs[7]), mxGetScalar(prhs[8]), mxGetDoubles(plhs[0]), mxGetDoubles(fb), mxGetDoubles(vt));
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     if (nlhs > 1) plhs[1] = fb;
     if (nlhs > 2) plhs[2] = vt;
-    return;
+    return 0;
   }
 
   if (!strcmp(cmd, "gp_nlz")) {
@@ -316,9 +365,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray* g = nlhs > 1 ? mxCreateDoubleMatrix(Nhyp, B, mxREAL) : nullptr;
     vbmc_status st = vbmc_gp_nlz(g_ctx, N, D, B, Nhyp, (int)mxGetScalar(prhs[5]), nf, mxGetDoubles(X), mxGetDoubles(y), dbl(s2),
                                  mxGetDoubles(hyp), g ? 1 : 0, mxGetDoubles(plhs[0]), g ? mxGetDoubles(g) : nullptr);
-    if (st != VBMC_OK) fail(st);
+    if (st != VBMC_OK) return fail(st);
     if (g) plhs[1] = g;
-    return;
+    return 0;
   }
 
   if (!strcmp(cmd, "gp_pred")) {
@@ -330,19 +379,24 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     for (int i = 0; i < 4; ++i) plhs[i] = mxCreateDoubleMatrix(Nstar, nc, mxREAL);
     vbmc_status st = vbmc_gp_pred(g_ctx, h, Nstar, mxGetDoubles(Xs), dbl(prhs[3]), dbl(prhs[4]), ss || S == 1, mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]),
                                   mxGetDoubles(plhs[2]), mxGetDoubles(plhs[3]));
-    if (st != VBMC_OK) fail(st);
-    return;
+    if (st != VBMC_OK) return fail(st);
+    return 0;
   }
 
   if (!strcmp(cmd, "sq_dist")) {
     const mxArray* a = prhs[1];
     const mxArray* b = (nrhs > 2 && !mxIsEmpty(prhs[2])) ? prhs[2] : nullptr;
     const int D = (int)mxGetM(a), n = (int)mxGetN(a), m = b ? (int)mxGetN(b) : n;
-    if (b && (int)mxGetM(b) != D) mexErrMsgTxt("Error: column lengths must agree.");
+    if (b && (int)mxGetM(b) != D) return raise("vbmc_hip:sq_dist", "Error: column lengths must agree.");
     plhs[0] = mxCreateDoubleMatrix(n, m, mxREAL);
     vbmc_status st = vbmc_sq_dist(g_ctx, D, n, m, mxGetDoubles(a), b ? mxGetDoubles(b) : nullptr, mxGetDoubles(plhs[0]));
-    if (st != VBMC_OK) fail(st);
-    return;
+    if (st != VBMC_OK) return fail(st);
+    return 0;
   }
-  mexErrMsgIdAndTxt("vbmc_hip:usage", "unknown command '%s'", cmd);
+  return raise("vbmc_hip:usage", "unknown command");
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  g_err_id[0] = 0;
+  if (dispatch(nlhs, plhs, nrhs, prhs)) mexErrMsgIdAndTxt(g_err_id, "%s", g_err_msg);   // no C++ object alive here
 }

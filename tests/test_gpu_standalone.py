@@ -112,3 +112,37 @@ def test_gplogjoint_refusals(va):
         va.gplogjoint(vp, gp, True, True, False, nargout=2)      # jacobian_flag = 0
     with pytest.raises(ValueError, match="FullVarianceGradient"):
         va.gplogjoint(vp, gp, True, True, True, 1, nargout=4)    # gplogjoint.m:27-30
+
+
+@pytest.mark.parametrize("cfg", [(4, 50, 6, 5), (3, 30, 3, 1), (10, 120, 20, 8)])
+def test_gplogjoint_per_hyper_sample_outputs(va, cfg):
+    """avg_flag = 0 (misc/gplogjoint.m:398-413 skipped): the call forms the reference's own callers use --
+    [~,~,varF] = gplogjoint(vp,gp,0,0,0,1) at private/activesample_vbmc.m:155 and
+    [~,~,~,~,~,I_sk,J_sjk] = gplogjoint(vp,gp,0,0,0,1,1) at misc/vpoptimizeweights_vbmc.m:42."""
+    D, N, K, S = cfg
+    p, gp, vp = make(17, D, N, K, S)
+    ref = R.gplogjoint(vp, gp, grad_flags=0, avg_flag=False, jacobian_flag=False, compute_var=1, separate_K=True)
+    F, dF, varF = va.gplogjoint(vp, gp, 0, 0, 0, 1, nargout=3)
+    assert np.shape(F) == np.shape(ref["F"]) and np.size(dF) == 0
+    assert relerr(F, ref["F"]) < 1e-10
+    assert np.max(np.abs(np.asarray(varF) - ref["varF"])) < 1e-7 * max(1.0, np.max(np.abs(ref["varF"])))
+    out = va.gplogjoint(vp, gp, 0, 0, 0, 1, 1, nargout=7)
+    assert out[4] == 0.0 or S == 1                      # varss is only formed when averaging (:398-404)
+    assert relerr(out[5], ref["I_sk"]) < 1e-10
+    assert np.max(np.abs(out[6] - ref["J_sjk"])) < 1e-7 * max(1.0, np.max(np.abs(ref["J_sjk"])))
+    # diagonal approximation and value only
+    refd = R.gplogjoint(vp, gp, grad_flags=0, avg_flag=False, compute_var=2)
+    Fd, _, varFd = va.gplogjoint(vp, gp, 0, 0, 0, 2, nargout=3)
+    assert relerr(Fd, refd["F"]) < 1e-10 and np.max(np.abs(np.asarray(varFd) - refd["varF"])) < 1e-7 * max(1.0, np.max(np.abs(refd["varF"])))
+    F0 = va.gplogjoint(vp, gp, 0, 0, nargout=1)
+    assert relerr(F0, ref["F"]) < 1e-10
+    # averaging the per-sample outputs on the host reproduces the averaged call (:399-411)
+    Fa, _, varFa, _, varss = va.gplogjoint(vp, gp, 0, 1, 1, 1, nargout=5)
+    if S > 1:
+        Fs, vs = np.asarray(F), np.asarray(varF)
+        assert abs(np.mean(Fs) - Fa) < 1e-12 * max(1.0, abs(Fa))
+        vss = np.var(Fs, ddof=1)
+        assert abs(np.mean(vs) + vss - varFa) < 1e-9 * max(1.0, abs(varFa))
+        assert abs(vss + np.std(vs, ddof=1) - varss) < 1e-9 * max(1.0, abs(varss))
+    with pytest.raises(va.VbmcUnsupported):
+        va.gplogjoint(vp, gp, 1, 0, 1, 0, nargout=2)    # per-sample gradients: not accelerated, the shim falls through

@@ -51,6 +51,7 @@ class ElboArgs(C.Structure):
         ("sparse_cutoff", C.c_double),
         ("F", _dp), ("dF", _dp), ("G", _dp), ("H", _dp), ("dG", _dp), ("dH", _dp),
         ("varG", _dp), ("varGss", _dp), ("I_sk", _dp), ("J_sjk", _dp),
+        ("G_s", _dp), ("varG_s", _dp),
     ]
 
 

@@ -756,7 +756,24 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     Jh.resize((size_t)R * S * K * K);
     HIP_TRY(ctx, hipMemcpyAsync(Jh.data(), P.d_J, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<double> psh;
+  double* d_ps = nullptr;
+  if (a->G_s || a->varG_s) {   // gplogjoint's avg_flag = 0 outputs
+    if (a->varG_s && !P.compute_var) return set_err(ctx, VBMC_ERR_INVALID, "varG_s needs compute_var != 0");
+    HIP_TRY(ctx, pool_get(ctx, 2 * (size_t)S * R * sizeof(double), (void**)&d_ps));
+    hipLaunchKernelGGL(k_per_sample, dim3((S + 63) / 64, R), dim3(64), 0, st, dm, P.d_vpd, P.d_lj, P.d_J, P.compute_var, d_ps,
+                       a->varG_s ? d_ps + (size_t)S * R : nullptr);
+    psh.resize(2 * (size_t)S * R);
+    hipError_t e_ = hipMemcpyAsync(psh.data(), d_ps, psh.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e_ != hipSuccess) { pool_put(ctx, d_ps); return set_err(ctx, VBMC_ERR_HIP, "per-sample read-back: %s", hipGetErrorString(e_)); }
+  }
+  {
+    hipError_t e_ = hipStreamSynchronize(st);
+    if (d_ps) pool_put(ctx, d_ps);
+    if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_batch: %s", hipGetErrorString(e_)); }
+  }
+  if (a->G_s) memcpy(a->G_s, psh.data(), (size_t)S * R * sizeof(double));
+  if (a->varG_s) memcpy(a->varG_s, psh.data() + (size_t)S * R, (size_t)S * R * sizeof(double));
   if (ctx->profiling) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_lj_ms = ms;

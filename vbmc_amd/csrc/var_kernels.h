@@ -192,6 +192,39 @@ __global__ void __launch_bounds__(WAVE) k_vargrad(ElboDims dm, const double* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// k_per_sample: the avg_flag = 0 outputs of gplogjoint -- F(s) = sum_k w_k I_k (gplogjoint.m:203) and, with the
+// variance, varF(s) accumulated over (j <= k) in the reference's order with the diagonal clamp (:283, :329-332) and the
+// final max(varF, eps) (:350).  One thread per (hyper-sample, restart); O(K^2) each.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_per_sample(ElboDims dm, const double* __restrict__ vpd, const double* __restrict__ lj,
+                                                    const double* __restrict__ J, int compute_var, double* __restrict__ Gs,
+                                                    double* __restrict__ vGs) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  const int D = dm.D, K = dm.K, S = dm.S;
+  if (s >= S) return;
+  const double EPS = 2.220446049250313e-16;
+  VpLayout L{D, K};
+  const double* w = vpd + (size_t)r * L.stride() + L.w();
+  const int LJS = 2 * D + 2;
+  const double* l = lj + ((size_t)r * S + s) * K * LJS;
+  double F = 0.0;
+  for (int k = 0; k < K; ++k) F += w[k] * l[(size_t)k * LJS];
+  Gs[s + (size_t)S * r] = F;
+  if (compute_var && vGs) {
+    const double* Js = J + ((size_t)r * S + s) * K * K;
+    double v = 0.0;
+    for (int k = 0; k < K; ++k) {
+      if (compute_var == 2) { v += w[k] * w[k] * fmax(EPS, Js[k + (size_t)K * k]); continue; }
+      for (int j = 0; j <= k; ++j) {
+        const double Jjk = Js[j + (size_t)K * k];
+        v += (j == k) ? w[k] * w[k] * fmax(EPS, Jjk) : 2.0 * w[j] * w[k] * Jjk;
+      }
+    }
+    vGs[s + (size_t)S * r] = fmax(v, EPS);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_var_final: one workgroup per restart.  out VR[r] = varG, varGss, dvarG[T]
 // ------------------------------------------------------------------------------------------
 struct VarFinArgs {

@@ -231,6 +231,11 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
         a.I_sk = outbuf("I_sk", (S, K, R))
         if compute_var:
             a.J_sjk = outbuf("J_sjk", (S, K, K, R))
+    if outputs is not None and gp is not None:     # per-hyper-sample outputs only on request (gplogjoint avg_flag = 0)
+        if "G_s" in outputs:
+            a.G_s = outbuf("G_s", (S, R))
+        if "varG_s" in outputs and compute_var:
+            a.varG_s = outbuf("varG_s", (S, R))
     ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, dgp_h, C.byref(a)))
     return out
 
@@ -281,10 +286,11 @@ def entlb_vbmc(vp, grad_flags=None, jacobian_flag=True, nargout=2, *, engine=Non
 def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compute_var=None, separate_K=None, nargout=1, *,
                engine=None):
     """[F,dF,varF,dvarF,varss,I_sk,J_sjk] = gplogjoint(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K)
-    (misc/gplogjoint.m:1-30; direct caller acq/../activesample_vbmc.m:155).  Accelerated call forms: averaged over the
-    hyper-parameter samples (avg_flag), transformed gradients (jacobian_flag); the gradient of the variance is not a
-    separate output of the device path (dvarF is returned as None unless asked for together with gradients, which is
-    refused like the other unsupported forms)."""
+    (misc/gplogjoint.m:1-30).  Accelerated call forms: averaged over the hyper-parameter samples (avg_flag = 1) with
+    transformed gradients (jacobian_flag), and per-hyper-sample values without gradients (avg_flag = 0: F and varF are
+    length-S vectors, varss = 0 -- the forms of private/activesample_vbmc.m:155 and misc/vpoptimizeweights_vbmc.m:42);
+    the gradient of the variance is not a separate output of the device path (dvarF is returned as None unless asked for
+    together with gradients, which is refused like the other unsupported forms)."""
     if separate_K is None:
         separate_K = nargout > 5            # :13
     if compute_var is None:
@@ -296,18 +302,25 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
             raise ValueError("gplogjoint:FullVarianceGradient Computation of gradient of log joint variance is currently "
                              "available only for diagonal approximation of the variance.")
         raise VbmcUnsupported(-1, "gplogjoint: dvarF as a separate output is not accelerated")
-    if not avg_flag:
-        raise VbmcUnsupported(-1, "gplogjoint: per-hyper-sample outputs (avg_flag = 0) are not accelerated")
+    if not avg_flag and g:
+        raise VbmcUnsupported(-1, "gplogjoint: per-hyper-sample gradients (avg_flag = 0 with grad_flags) are not accelerated")
     if separate_K and g:
         raise VbmcUnsupported(-1, "gplogjoint: per-component outputs together with gradients are not accelerated")
     want = ["G"] + (["dG"] if g else []) + (["varG", "varGss"] if compute_var else [])
     if separate_K:
         want += ["I_sk"] + (["J_sjk"] if compute_var else [])
+    if not avg_flag:
+        want += ["G_s"] + (["varG_s"] if compute_var else [])
     r = negelcbo_batch(theta, 0.0, vpt, gp, 0, g, compute_var, None, separate_K=bool(separate_K), engine=engine,
                        outputs=tuple(want))
+    if not avg_flag and r["G_s"].shape[0] > 1:     # :399: no averaging -> F, varF are 1 x S; varss stays 0 (:398)
+        outs = (r["G_s"][:, 0].copy(), np.zeros(0), r["varG_s"][:, 0].copy() if compute_var else None, None, 0.0,
+                r["I_sk"][:, :, 0].copy() if separate_K else None,
+                r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
+        return outs[0] if nargout <= 1 else outs[:nargout]
     outs = (float(r["G"][0]), r["dG"][:, 0].copy() if g else np.zeros(0),
             float(r["varG"][0]) if compute_var else None, None,
-            float(r["varGss"][0]) if compute_var else None,
+            (float(r["varGss"][0]) if avg_flag else 0.0) if compute_var else None,
             r["I_sk"][:, :, 0].copy() if separate_K else None,
             r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
     return outs[0] if nargout <= 1 else outs[:nargout]
