@@ -242,6 +242,25 @@ typedef struct vbmc_elbo_args {
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
 
 /*
+ * ONE evaluation (or a batch with fewer restarts than GPUs) sharded over `world` ranks, one process per GPU, each with a
+ * full replica of the surrogate: rank g evaluates the expected-log-joint records of its hyper-samples (the iterations of
+ * misc/gplogjoint.m:98 are independent until the averaging at :399-413) and the Monte-Carlo entropy partials of its share
+ * of the sample chunks (ent/entmc_vbmc.m:49-104: the samples are independent) into one contiguous device block;
+ *   vbmc_elbo_shard_size    number of doubles of that block (equal on every rank);
+ *   vbmc_elbo_shard_begin   fills d_send (device memory of the caller, e.g. a torch tensor) and synchronises;
+ *   -- the caller all-gathers the blocks in rank order (RCCL ncclAllGather over xGMI: torch.distributed
+ *      all_gather_into_tensor; ~0.3 MB per rank at the headline shape) --
+ *   vbmc_elbo_shard_finish  scatters the gathered blocks into the unsharded record layouts, runs the unsharded
+ *                           fixed-order reductions and k_finalize on every rank and returns the outputs of
+ *                           vbmc_elbo_batch: BIT-IDENTICAL to the 1-GPU evaluation (same chunking, same summation order).
+ * Covers value + gradient without variance (compute_var = 0, separate_K = 0), device RNG (eps_mode 0): the optimiser-loop
+ * call of misc/vpoptimize_vbmc.m:71.  args must be identical on all ranks and in all three calls.
+ */
+vbmc_status vbmc_elbo_shard_size(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int world, size_t* n_doubles);
+vbmc_status vbmc_elbo_shard_begin(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int rank, int world, double* d_send);
+vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int world, const double* d_gathered);
+
+/*
  * [x,f,xtab,ftab,iter] = fminadam(@(t) negelcbo_vbmc(t,beta,vp,gp,Ns,1,compute_var,~,thetabnd), x0, [], [],
  *                                 TolFun, MaxIter, master_stepsize)          (utils/fminadam.m:1-104,
  * call site misc/vpoptimize_vbmc.m:127) for R chains in lock-step, entirely on the device: per

@@ -86,6 +86,9 @@ def load():
     lib.vbmc_elbo_batch.argtypes = [vp, vp, C.POINTER(ElboArgs)]
     lib.vbmc_adam_batch.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
                                     _dp, _dp, C.POINTER(C.c_int32), _dp, _dp]
+    lib.vbmc_elbo_shard_size.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, C.POINTER(C.c_size_t)]
+    lib.vbmc_elbo_shard_begin.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, C.c_int, vp]
+    lib.vbmc_elbo_shard_finish.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, vp]
     lib.vbmc_rng_dump.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp]
     lib.vbmc_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.vbmc_device_free.argtypes = [vp, vp]

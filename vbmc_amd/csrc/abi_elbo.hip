@@ -1,5 +1,6 @@
 // C-ABI entry points of libvbmc_hip.so for the ELBO objective (include/vbmc_hip.h).
 // Host side: argument validation, device scratch, launches, one packed D2H per call.
+#include <algorithm>
 #include <cmath>
 
 #include "elbo_kernels.h"
@@ -536,12 +537,64 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     if (le_ != hipSuccess) return set_err(ctx_, VBMC_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(le_)); \
   } while (0)
 
+// Sharding of ONE evaluation over `world` ranks when there are fewer restarts than GPUs: rank g computes the
+// expected-log-joint records of the hyper-samples [g perS, (g+1) perS) (misc/gplogjoint.m:98: the iterations over s are
+// independent until the averaging at :399-413) and the entropy partial records of the sample chunks [g perC, (g+1) perC)
+// -- with the SAME chunking the unsharded evaluation uses -- into one contiguous block; after the all-gather every rank
+// scatters the blocks back into the unsharded layouts and runs the unsharded reductions + k_finalize, so the result is
+// bit-identical to the 1-GPU evaluation by construction.
+struct ShardSpec {
+  int mode = 0;          // 0: unsharded; 1: begin (prep + own records -> send); 2: finish (prep + scatter + reductions + finalize)
+  int rank = 0, world = 1;
+  double* send = nullptr;            // mode 1: device block of shard_doubles(P, world)
+  const double* gathered = nullptr;  // mode 2: device, world blocks in rank order
+};
+static inline int shard_per(int n, int world) { return (n + world - 1) / world; }
+static inline size_t shard_lj_doubles(const ElboPlan& P, int world) {
+  return (size_t)P.dm.R * shard_per(P.dm.S, world) * P.dm.K * (2 * P.dm.D + 2);
+}
+static inline size_t shard_doubles(const ElboPlan& P, int world) {
+  return shard_lj_doubles(P, world) + (P.mc ? (size_t)P.dm.R * P.dm.K * shard_per(P.C, world) * P.ncol : 0);
+}
+
+// gathered blocks -> the unsharded record layouts lj[r][s][k][LJS] and part[r][j][c][ncol]
+__global__ void __launch_bounds__(256) k_shard_scatter(int R, int S, int K, int LJS, int C, int ncol, int world, int perS, int perC,
+                                                       size_t blk, size_t ljn, const double* __restrict__ g,
+                                                       double* __restrict__ lj, double* __restrict__ part) {
+  const size_t nlj = (size_t)R * S * K * LJS, npe = part ? (size_t)R * K * C * ncol : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlj + npe; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nlj) {
+      const int col = (int)(i % LJS);
+      size_t t = i / LJS;
+      const int k = (int)(t % K); t /= K;
+      const int sidx = (int)(t % S), r = (int)(t / S);
+      const int gk = sidx / perS, sl = sidx - gk * perS;
+      lj[i] = g[(size_t)gk * blk + (((size_t)r * perS + sl) * K + k) * LJS + col];
+    } else {
+      const size_t e = i - nlj;
+      const int col = (int)(e % ncol);
+      size_t t = e / ncol;
+      const int c = (int)(t % C); t /= C;
+      const int j = (int)(t % K), r = (int)(t / K);
+      const int gk = c / perC, cl = c - gk * perC;
+      part[e] = g[(size_t)gk * blk + ljn + (((size_t)r * K + j) * perC + cl) * ncol + col];
+    }
+  }
+}
+
 static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan& P, unsigned long long seed,
-                                const AdamState* pend = nullptr, int pend_iter = 0) {
+                                const AdamState* pend = nullptr, int pend_iter = 0, const ShardSpec* shp = nullptr) {
   const ElboDims& dm = P.dm;
   const int D = dm.D, K = dm.K, R = dm.R, S = dm.S, T = dm.T;
   const int dt = P.dt;
   hipStream_t st = ctx->stream;
+  const ShardSpec sh = shp ? *shp : ShardSpec{};
+  // this rank's slice of the hyper-samples and of the entropy chunks (everything when unsharded)
+  const int perS = shard_per(S, sh.world), s0 = sh.mode == 1 ? std::min(S, sh.rank * perS) : 0;
+  const int ns = sh.mode == 1 ? std::min(S, s0 + perS) - s0 : S;
+  const int perC = shard_per(P.C, sh.world), c0 = sh.mode == 1 ? std::min(P.C, sh.rank * perC) : 0;
+  const int nc = sh.mode == 1 ? std::min(P.C, c0 + perC) - c0 : P.C;
+  double* const lj_out = sh.mode == 1 ? sh.send : P.d_lj;
   const size_t prep_lds = ((size_t)D * K + 3 * K + D + 8) * sizeof(double);
   if (prep_lds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
@@ -550,7 +603,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   LAUNCH_CHECK(ctx, "k_prep");
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
-  const bool fork = ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
+  const bool fork = sh.mode == 0 && ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
   auto enqueue_logjoint = [&](hipStream_t ls) -> vbmc_status {
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ls));
     {
@@ -567,13 +620,21 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         constexpr int NCT = (2 * DT + 1 + 15) / 16;
         const int nw = (K + 15) / 16;
         const size_t mom_lds = (size_t)nw * 16 * 16 * NCT * sizeof(double);   // moment exchange; large K x D falls back to the VALU kernel
-        if (lj_mfma && mom_lds <= 48 * 1024) {
-          hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(S, R), dim3(WAVE * nw), mom_lds, ls, dm, P.d_vpd,
-                             gp->X, gp->d_meanX, gp->alpha, gp->gpc, P.d_delta2, P.d_lj);
+        // the kernels reach hyper-sample s only through alpha + s N and gpc + s GPC_STRIDE and use dm.S as the record
+        // stride: a slice [s0, s0 + ns) is the same launch with shifted pointers (the variant choice above uses the FULL S,
+        // so a sharded evaluation runs the kernel the unsharded one would)
+        ElboDims dml = dm;
+        dml.S = sh.mode == 1 ? perS : S;
+        const double* al = gp->alpha + (size_t)s0 * dm.N;
+        const double* gc = gp->gpc + (size_t)s0 * GPC_STRIDE(D);
+        if (ns <= 0) {
+        } else if (lj_mfma && mom_lds <= 48 * 1024) {
+          hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(ns, R), dim3(WAVE * nw), mom_lds, ls, dml, P.d_vpd,
+                             gp->X, gp->d_meanX, al, gc, P.d_delta2, lj_out);
           LAUNCH_CHECK(ctx, "k_logjoint_mfma");
         } else {
-          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, S, R), dim3(lj_split ? WAVE * LJ_MAXW : WAVE), 0, ls, dm, P.d_vpd, gp->X, gp->alpha, gp->gpc,
-                             P.d_delta2, P.d_lj, P.compute_grad);
+          hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, ns, R), dim3(lj_split ? WAVE * LJ_MAXW : WAVE), 0, ls, dml, P.d_vpd, gp->X, al, gc,
+                             P.d_delta2, lj_out, P.compute_grad);
           LAUNCH_CHECK(ctx, "k_logjoint");
         }
       });
@@ -581,16 +642,24 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ls));
     // log-joint partials summed over hyper-samples (in sample order), one record per (r, k); on the main stream of an MC
     // evaluation this shares a launch with the entropy reduction below
-    if (fork || !P.mc) hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, ls, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
+    if (sh.mode == 0 && (fork || !P.mc)) hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, ls, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
     LAUNCH_CHECK(ctx, "k_lj_reduce");
     return VBMC_OK;
   };
   if (fork) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-  } else {
+  } else if (sh.mode != 2) {
     vbmc_status s_ = enqueue_logjoint(st);
     if (s_) return s_;
+  }
+  if (sh.mode == 2) {   // the gathered records of all ranks -> the unsharded layouts
+    const size_t blk = shard_doubles(P, sh.world), ljn = shard_lj_doubles(P, sh.world);
+    const size_t tot = (size_t)R * S * K * (2 * D + 2) + (P.mc ? (size_t)R * K * P.C * P.ncol : 0);
+    hipLaunchKernelGGL(k_shard_scatter, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), 0, st, R, S, K, 2 * D + 2,
+                       P.C, P.ncol, sh.world, perS, perC, blk, ljn, sh.gathered, P.d_lj, P.mc ? P.d_part : nullptr);
+    LAUNCH_CHECK(ctx, "k_shard_scatter");
+    if (!P.mc) hipLaunchKernelGGL(k_lj_reduce, dim3(K, R), dim3(64), 0, st, S, K, 2 * D + 2, P.d_lj, P.d_ljbar);
   }
 
   // ---- entropy
@@ -598,22 +667,26 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.dm = dm;
   if (P.mc) {
     EntArgs ea{};
-    ea.entp = P.d_entp; ea.vpd = P.d_vpd; ea.part = P.d_part;
-    ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = P.C; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
+    ea.entp = P.d_entp; ea.vpd = P.d_vpd;
+    // sharded: this rank's chunks [c0, c0 + nc) of the unsharded chunking, written to slots 0 .. nc-1 of a perC-slot record
+    ea.part = sh.mode == 1 ? sh.send + shard_lj_doubles(P, sh.world) : P.d_part;
+    ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff;
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-    if (P.use_mfma) {
-      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(P.C, K, R), st, ea);
+    if (sh.mode == 2 || nc <= 0) {
+    } else if (P.use_mfma) {
+      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(nc, K, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
     } else {
       const size_t lds = P.ent_lds;
       DISPATCH_DT(dt, {
         HIP_TRY(ctx, set_entropy_lds<DT>(P.compute_grad != 0, lds));
-        launch_entropy<DT>(P.compute_grad != 0, dim3(P.C, K, R), lds, st, ea);
+        launch_entropy<DT>(P.compute_grad != 0, dim3(nc, K, R), lds, st, ea);
       });
     }
     LAUNCH_CHECK(ctx, "the entropy kernel");
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+    if (sh.mode == 1) return VBMC_OK;   // the records are in the send block; the exchange and the rest follow in mode 2
     // chunk partials -> one record per (r, j), summed in chunk order
     if (fork)
       hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
@@ -624,6 +697,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     LAUNCH_CHECK(ctx, "k_ent_reduce / k_reduce_both");
     fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {
+    if (sh.mode == 1) return VBMC_OK;   // the deterministic bound is O(K^2 D): every rank evaluates it in mode 2
     size_t lds = ((size_t)K * K + K + 256) * sizeof(double);
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_entlb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -718,17 +792,8 @@ static vbmc_status null_gp_for(vbmc_ctx* ctx, int D, const vbmc_gp** out) {
   return VBMC_OK;
 }
 
-extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a) {
-  if (!ctx) return VBMC_ERR_INVALID;
-  if (!gp && a) {  // entropy only
-    if (a->compute_var != 0 || a->separate_K)
-      return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: an entropy-only call (gp == NULL) has no variance / per-component outputs");
-    vbmc_status s_ = null_gp_for(ctx, a->D, &gp);
-    if (s_) return s_;
-  }
-  ElboPlan P;
-  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
-  { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed); if (s_) return s_; }
+// One packed D2H of the results of an enqueued pass (+ I_sk / J_sjk / per-sample outputs when requested); synchronises.
+static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbmc_elbo_args* a) {
   const ElboDims& dm = P.dm;
   const int K = dm.K, R = dm.R, S = dm.S, T = dm.T, D = dm.D;
   const int LJS = 2 * D + 2;
@@ -807,6 +872,68 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
                 (P.compute_var == 2 && j != k) ? 0.0 : Jh[(((size_t)r * S + s) * K + k) * K + j];
   }
   return VBMC_OK;
+}
+
+
+extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!gp && a) {  // entropy only
+    if (a->compute_var != 0 || a->separate_K)
+      return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: an entropy-only call (gp == NULL) has no variance / per-component outputs");
+    vbmc_status s_ = null_gp_for(ctx, a->D, &gp);
+    if (s_) return s_;
+  }
+  ElboPlan P;
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed); if (s_) return s_; }
+  return elbo_read_results(ctx, P, a);
+}
+
+// ---- one evaluation sharded over `world` ranks along the hyper-sample axis and the entropy sample chunks (see ShardSpec)
+static vbmc_status shard_check(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int rank, int world) {
+  if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_shard_*: null gp / args");
+  if (world < 1 || rank < 0 || rank >= world) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_shard_*: rank %d of world %d", rank, world);
+  if (a->compute_var != 0 || a->separate_K || a->G_s || a->varG_s)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_shard_*: the sharded evaluation covers value + gradient without variance "
+                                              "(the optimiser-loop call, misc/vpoptimize_vbmc.m:71)");
+  if (a->eps_mode != 0 && a->Ns > 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_shard_*: device RNG only (eps_mode 0)");
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_shard_size(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int world, size_t* n_doubles) {
+  if (!ctx || !n_doubles) return VBMC_ERR_INVALID;
+  { vbmc_status s_ = shard_check(ctx, gp, a, 0, world); if (s_) return s_; }
+  ElboPlan P;
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *n_doubles = shard_doubles(P, world);
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_shard_begin(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int rank, int world,
+                                             double* d_send) {
+  if (!ctx || !d_send) return VBMC_ERR_INVALID;
+  { vbmc_status s_ = shard_check(ctx, gp, a, rank, world); if (s_) return s_; }
+  ElboPlan P;
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  ShardSpec sh;
+  sh.mode = 1; sh.rank = rank; sh.world = world; sh.send = d_send;
+  HIP_TRY(ctx, hipMemsetAsync(d_send, 0, shard_doubles(P, world) * sizeof(double), ctx->stream));   // unused slots of an uneven split
+  { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed, nullptr, 0, &sh); if (s_) return s_; }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the exchange runs on the caller's stream / communicator
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int world,
+                                              const double* d_gathered) {
+  if (!ctx || !d_gathered) return VBMC_ERR_INVALID;
+  { vbmc_status s_ = shard_check(ctx, gp, a, 0, world); if (s_) return s_; }
+  ElboPlan P;
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  ShardSpec sh;
+  sh.mode = 2; sh.world = world; sh.gathered = d_gathered;
+  { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed, nullptr, 0, &sh); if (s_) return s_; }
+  return elbo_read_results(ctx, P, a);
 }
 
 // ------------------------------------------------------------------------------------------

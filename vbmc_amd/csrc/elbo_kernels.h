@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(WAVE) k_entropy(EntArgs a) {
   double accW[KW] = {0.0, 0.0, 0.0, 0.0};
 
   const int nt = (a.Mh + 31) / 32;
-  const int t0 = c * a.tiles_per_chunk;
+  const int t0 = (c + a.c0) * a.tiles_per_chunk;
   const int t1 = min(t0 + a.tiles_per_chunk, nt);
   const double sgn = (lane < 32) ? 1.0 : -1.0;
   const double* epsr = a.eps ? a.eps + (size_t)r * a.eps_stride_r + (size_t)j * a.Mh * D : nullptr;

@@ -36,7 +36,8 @@ struct ElboDims {
 
 
 // k_entropy / k_entropy_mfma arguments.
-// partial layout PE[r][j][c][NCOL]: sum log q | G[D] | SG | LG[D] | W[K]   (NCOL = 1 if !GRAD)
+// partial layout PE[r][j][c][NCOL]: sum log q | G[D] | SG | LG[D] | W[K]   (NCOL = 1 if !GRAD); c = blockIdx.x is the
+// slot in the output record (C slots per (r, j)), c0 + blockIdx.x the chunk of samples it covers
 struct EntArgs {
   const double* entp;    // R x K x (D+4)
   const double* vpd;     // R x VpLayout
@@ -44,6 +45,7 @@ struct EntArgs {
   long long eps_stride_r;
   double* part;
   int D, K, Mh, C, tiles_per_chunk, ncol;
+  int c0;                // first chunk of this launch (blockIdx.x + c0 is the chunk index; 0 unless the chunks are sharded over ranks)
   unsigned long long seed;
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
 };

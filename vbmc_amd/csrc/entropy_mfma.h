@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
     for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = 0.0;
 
   const int ntile = (a.Mh + 15) >> 4;
-  const int t0 = c * a.tiles_per_chunk;
+  const int t0 = (c + a.c0) * a.tiles_per_chunk;
   const int t1 = min(t0 + a.tiles_per_chunk, ntile);
   const double* epsr = a.eps ? a.eps + (size_t)r * a.eps_stride_r + (size_t)j * a.Mh * D : nullptr;
 

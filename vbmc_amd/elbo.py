@@ -240,6 +240,37 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     return out
 
 
+def negelcbo_shard(thetas, beta, vp, gp, Ns, compute_grad=True, thetabnd=None, *, rank, world, exchange, seed=0, engine=None,
+                   outputs=("F", "dF")):
+    """ONE negelcbo evaluation (or a batch with fewer restarts than GPUs) sharded over ``world`` ranks along the GP
+    hyper-sample axis (misc/gplogjoint.m:98) and the Monte-Carlo sample chunks of the entropy (ent/entmc_vbmc.m:49-104);
+    every rank returns the outputs of ``negelcbo_batch`` -- bit-identical to the 1-GPU evaluation (vbmc_elbo_shard_*).
+
+    ``exchange`` (vbmc_amd.dist.ShardExchange or anything with the same two methods): ``send_buffer(n)`` -> device
+    pointer of n doubles this rank fills; ``all_gather()`` -> device pointer of the world blocks in rank order.
+    Value + gradient without variance, device RNG (the optimiser-loop call, misc/vpoptimize_vbmc.m:71)."""
+    engine = engine or default_engine()
+    ctx = engine.ctx
+    thetas = f64(thetas)
+    if thetas.ndim == 1:
+        thetas = f64(thetas.reshape(-1, 1))
+    T, R = thetas.shape
+    a, keep, _ = _build_args(thetas, beta, vp, gp, Ns, compute_grad, 0, thetabnd, False, None, None, False, seed, engine)
+    dgp = engine.device_gp(gp)
+    out = {}
+    for name, shape in (("F", (R,)), ("G", (R,)), ("H", (R,))) + ((("dF", (T, R)), ("dG", (T, R)), ("dH", (T, R))) if compute_grad else ()):
+        if outputs is None or name in outputs:
+            out[name] = np.empty(shape, dtype=np.float64, order="F")
+            setattr(a, name, ptr(out[name]))
+    n = C.c_size_t(0)
+    ctx.check(ctx.lib.vbmc_elbo_shard_size(ctx.h, dgp.h, C.byref(a), int(world), C.byref(n)))
+    send = exchange.send_buffer(int(n.value))
+    ctx.check(ctx.lib.vbmc_elbo_shard_begin(ctx.h, dgp.h, C.byref(a), int(rank), int(world), C.c_void_p(int(send))))
+    gathered = exchange.all_gather()
+    ctx.check(ctx.lib.vbmc_elbo_shard_finish(ctx.h, dgp.h, C.byref(a), int(world), C.c_void_p(int(gathered))))
+    return out
+
+
 def _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, who):
     """grad_flags defaulting of the reference (ent/entmc_vbmc.m:5-11, misc/gplogjoint.m:17-23) -> (vp whose optimize_*
     flags select exactly the groups a gradient is wanted for, theta, any gradient)."""
