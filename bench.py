@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--S", type=int, default=20)
     ap.add_argument("--eps-stream", action="store_true", help="also time the parity mode (eps streamed from HBM)")
     ap.add_argument("--extras", action="store_true", help="also report on-device Adam, single-call latency and block-sparse mode")
+    ap.add_argument("--shard-s", action="store_true",
+                    help="fewer restarts than GPUs (SURVEY 8e): every step is ONE batch of --restarts evaluations sharded over the ranks "
+                         "along the GP hyper-sample axis and the entropy sample chunks (strong scaling, bit-identical to 1 GPU)")
     ap.add_argument("--check-launch", action="store_true",
                     help="rendezvous only: every rank reports (rank, pid, device) through an all-gather and rank 0 prints them; no GPU work")
     args = ap.parse_args()
@@ -236,7 +239,17 @@ def main():
     # and buffers resolved once; every step still moves theta H2D and (F, dF) D2H
     objective = vbmc_amd.PreparedObjective(T, Rr, 0, vp, gp, Ns, 0, None, engine=eng)
 
+    shard_ex = None
+    if args.shard_s and world > 1:
+        from vbmc_amd.dist import ShardExchange
+
+        thetas = np.asfortranarray(theta0[:, None] + 0.05 * np.random.default_rng(100).standard_normal((T, Rr)))  # the SAME batch on every rank
+        shard_ex = ShardExchange(device=dev)
+
     def step(i):
+        if shard_ex is not None:
+            o = vbmc_amd.negelcbo_shard(thetas, 0, vp, gp, Ns, True, None, rank=rank, world=world, exchange=shard_ex, seed=i, engine=eng)
+            return {"F": o["F"], "dF": o["dF"]}, None
         F_, dF_ = objective(thetas, seed=(rank << 32) + i)
         out = {"F": F_, "dF": dF_}
         if world > 1:
@@ -357,16 +370,18 @@ def main():
         cpu = cpu_baseline(inp, gp, D, K, Ns)
 
     if rank == 0:
-        evals = world * Rr * args.steps
+        evals = (1 if shard_ex is not None else world) * Rr * args.steps
         line = {
             "metric": "ELBO+grad evals/sec (Ns=1e4, K=50, D=10, N=400)" if (D, N, K, Ns) == (10, 400, 50, 10000)
             else "ELBO+grad evals/sec (Ns=%d, K=%d, D=%d, N=%d)" % (Ns, K, D, N),
             "value": evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if shard_ex is not None else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded lumpy 12-component target, SURVEY 8d); device Philox MC draws",
             "config": {"workload": "BASELINE configs[%d]: D=%d N=%d K=%d Ns=%d/component S=%d, R=%d restarts batched per GPU per step, "
                                    "value+gradient, beta=0, no variance" % (3 if world > 1 else 2, D, N, K, Ns, S, Rr),
-                       "restarts_per_gpu": Rr, "parallelism": "restart-sharded x%d, all-gather of ELCBO" % world},
+                       "restarts_per_gpu": Rr,
+                       "parallelism": ("hyper-sample x sample-chunk sharded x%d (one batch of %d), all-gather of the partial records" % (world, Rr))
+                       if shard_ex is not None else "restart-sharded x%d, all-gather of ELCBO" % world},
             "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if world > 1 else None),
             "world_size_observed": (dist.get_world_size() if world > 1 else 1),
             "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],
