@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvbmc_hip.so")
+# VBMC_HIP_LIB: an alternative build of the SAME library (kernel A/B experiments, tools/ent_experiments.py)
+LIB_PATH = os.environ.get("VBMC_HIP_LIB") or os.path.join(_HERE, "lib", "libvbmc_hip.so")
 
 ABI_VERSION = 2   # include/vbmc_hip.h: VBMC_ABI_VERSION
 VBMC_OK, VBMC_ERR_INVALID, VBMC_ERR_NO_DEVICE, VBMC_ERR_HIP, VBMC_ERR_UNSUPPORTED, VBMC_ERR_NOT_POSDEF = range(6)

@@ -30,6 +30,34 @@
 
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
+// Phase switches for timing experiments (tools/ent_experiments.py builds variants of the library with -DVBMC_EXP_NO...;
+// results are then meaningless -- only the kernel duration is read).  All true in the product build.
+#ifdef VBMC_EXP_NOEXP
+constexpr bool X_EXP = false;
+#else
+constexpr bool X_EXP = true;
+#endif
+#ifdef VBMC_EXP_NOPV
+constexpr bool X_PV = false;
+#else
+constexpr bool X_PV = true;
+#endif
+#ifdef VBMC_EXP_NOEPI
+constexpr bool X_EPI = false;
+#else
+constexpr bool X_EPI = true;
+#endif
+#ifdef VBMC_EXP_NOW
+constexpr bool X_W = false;
+#else
+constexpr bool X_W = true;
+#endif
+#ifdef VBMC_EXP_NOS
+constexpr bool X_S = false;
+#else
+constexpr bool X_S = true;
+#endif
+
 
 // Ordering point for LDS words that only one wave touches: a workgroup barrier when the workgroup is one wave, a
 // wave-level fence when it is two (the waves then meet only at the eps staging and at the PV exchange).
@@ -54,12 +82,18 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
+  constexpr int QL = QS;                   // MFMAs of the linear part of the S-step (inner index c = 4q + lg < D, zero operands beyond D: for
+                                           // D mod 4 in {3, 0} the last one multiplies zeros -- a compile-time count keeps the KT chains branch-free)
   __shared__ double Et_all[1][16 * DP];    // eps tile [i][d], staged by wave 0 and shared by the waves of the workgroup
   __shared__ double RQ_all[HV][16];        // q'_i then 1/q'_i
   __shared__ double TAB[VB_EXP_TAB_N];     // 2^(j/256)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
   __shared__ double YX[HV == 2 ? 2 : 1][HV == 2 ? 2 : 1][HV == 2 ? NPV * 4 * WAVE : 1];
+  // PV "B" operands of large mixtures live in LDS (lane-contiguous: conflict-free ds_read_b64 right before the MFMA that
+  // consumes them) -- the 32 VGPRs they would occupy hold the second sign's exponents instead (see the S-step)
+  constexpr bool VBL = GRAD && KT >= 3;
+  __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
   const int tid = threadIdx.x, hv = HV == 2 ? tid >> 6 : 0, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -67,6 +101,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   double* Et = Et_all[0];
   double* RQ = RQ_all[hv];
   double* BND = BND_all[hv];
+  double* VBS = VBS_all[hv];
   const int Kh = (K + HV - 1) / HV;                    // components per wave
   const int kbase = hv * Kh;
   const int Kw = min(K, kbase + Kh) - kbase;           // this wave's components: kbase .. kbase + Kw - 1
@@ -115,8 +150,9 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
   // ---- mixture-side operand fragments (registers, built once)
-  double SA[KT][QS];          // S-step "A" operand: comp 16kt + li, inner c = 4q + lg
-  double VB[KT][4][NPV];      // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD)
+  double SA[KT][QL];          // S-step "A" operand, linear part: comp 16kt + li, inner c = 4q + lg < D
+  double SC[KT];              // S-step "A" operand, even part: inner index lg = 0 (coefficient of |u'|^2), 1 (constant), 2, 3 (zero)
+  double VB[VBL ? 1 : KT][4][NPV];   // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD; in LDS when VBL)
   double WF[KT][4];           // w_k for comp 16kt + 4r + lg                                  (!GRAD)
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
@@ -131,17 +167,17 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       BND[(16 * kt + li) * 3 + 1] = kv ? pk[D + 1] - cKj : -1.0e30;
       BND[(16 * kt + li) * 3 + 2] = h;
     }
+    // E_ik = [linear in u'_i] + [even in u'_i]: the antithetic pair +-eps shares the even part and flips the linear one, so
+    // per tile the S-step is ONE even product C (inner dimension 4: |u'|^2, 1, 0, 0) and ONE linear product L (inner
+    // dimension D) for both signs: E+ = C + L accumulates L on top of C, E- = 2C - E+
 #pragma unroll
-    for (int q = 0; q < QS; ++q) {
+    for (int q = 0; q < QL; ++q) {
       const int cc = 4 * q + lg;
-      double v;
-      if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;            // padded component: exp -> 0
-      else if (cc < D) v = -2.0 * h * (pk[cc] - pj[cc]);     // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
-      else if (cc == D) v = h + hj_neg;                      // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2)
-      else if (cc == D + 1) v = fma(h, m2, pk[D + 1]) - cKj;  // is folded into the two constant columns: accumulators start at 0
-      else v = 0.0;
-      SA[kt][q] = v;
+      SA[kt][q] = (kv && cc < D) ? -2.0 * h * (pk[cc] - pj[cc]) : 0.0;     // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
     }
+    // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2) is folded into the two even columns: accumulators start at 0
+    SC[kt] = !kv ? (lg == 1 ? -1.0e6 : 0.0)                                 // padded component: exp -> 0
+                 : (lg == 0 ? h + hj_neg : (lg == 1 ? fma(h, m2, pk[D + 1]) - cKj : 0.0));
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int k2 = 16 * kt + 4 * rr + lg;
@@ -157,7 +193,8 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
             else if (col == 1) v = p2[D + 3];                                   // w_k/sigma_k^2  -> A'
             else if (col < 2 + D) v = p2[D + 3] * (p2[col - 2] - pj[col - 2]);  // -> B'_d
           }
-          VB[kt][rr][pv] = v;
+          if (VBL) VBS[((kt * 4 + rr) * NPV + pv) * WAVE + lane] = v;
+          else VB[VBL ? 0 : kt][rr][pv] = v;
         }
       } else {
         WF[kt][rr] = kv2 ? p2[D + 2] : 0.0;
@@ -165,6 +202,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
     }
   }
 
+#define VBV(kt_, rr_, pv_) (VBL ? VBS[(((kt_) * 4 + (rr_)) * NPV + (pv_)) * WAVE + lane] : VB[VBL ? 0 : (kt_)][rr_][pv_])
   double accH = 0.0, accG[NPV], accLG[NPV];
   double pm = 1.0;            // running product of mantissas of q'
   int pe = 0, pcnt = 0;       // running sum of exponents
@@ -197,7 +235,11 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
 #pragma unroll
       for (int q = lg; q < QS; q += 4) {
         double z4[4] = {0.0, 0.0, 0.0, 0.0};
+#ifdef VBMC_EXP_NORNG
+        if (q < (D + 3) / 4) { z4[0] = 1e-3 * (double)((b0 + li) & 1023) - 0.5; z4[1] = 0.25 * z4[0]; z4[2] = -z4[0]; z4[3] = 0.5 - z4[1]; }
+#else
         if (q < (D + 3) / 4) vb_normal4(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)r, (unsigned)q, z4);
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = (bv && 4 * q + t < D) ? z4[t] : 0.0;
       }
@@ -235,31 +277,45 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       }
     }
 
-#pragma unroll 1
-      for (int sg = 0; sg < 2; ++sg) {
-      const double sgn = sg ? -1.0 : 1.0;
-      double sf[QS];
+    // ---- S-step, once per tile for both signs
+    mf4 n[KT], nm[KT];
+    {
+      const double sfc = lg == 0 ? u2 : (lg == 1 ? 1.0 : 0.0);
+      double sfl[QL];
 #pragma unroll
-      for (int q = 0; q < QS; ++q) {
-        const int cc = 4 * q + lg;
-        sf[q] = (cc < D) ? sgn * ev[q] * sigj : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
-      }
-      // ---- S-step: KT independent accumulator chains, then 4*KT straight-line exps
-      mf4 n[KT];
+      for (int q = 0; q < QL; ++q) sfl[q] = ev[q] * sigj;       // u'_ic (zero beyond D)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
+        nm[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
         if (!SP || ((act >> kt) & 1u)) {
+          const mf4 cacc = X_S ? __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0) : (mf4){SC[kt] * sfc, sfl[0], SA[kt][0], -1.0};
+          n[kt] = cacc;
 #pragma unroll
-          for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+          for (int q = 0; q < QL; ++q)
+            if (X_S) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sfl[q], n[kt], 0, 0, 0);
+          nm[kt] = 2.0 * cacc - n[kt];
         }
       }
+    }
+
+#pragma unroll 1
+      for (int sg = 0; sg < 2; ++sg) {
+      const double sgn = sg ? -1.0 : 1.0;
+      if (sg) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) n[kt] = nm[kt];
+      }
+      // ---- 4*KT straight-line exps
+      if (X_EXP) {
 #pragma unroll
       for (int kt = 0; kt < KT - 1; ++kt) {
         if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab4<1>(n[kt], TAB);
         else n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
       }
-      if (SP && !((act >> (KT - 1)) & 1u)) {
+      }
+      if (!X_EXP) {
+      } else if (SP && !((act >> (KT - 1)) & 1u)) {
         n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
       } else if (nr_last == 4) {
         n[KT - 1] = vb_exp_tab4<1>(n[KT - 1], TAB);
@@ -279,21 +335,23 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
 #pragma unroll
         for (int kt = 0; kt < KT - 1; ++kt) {
           if (SP && !((act >> kt) & 1u)) continue;
+          if (!X_PV) { Y[0] += n[kt]; continue; }
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv) {
-            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][0], VB[kt][0][pv], Y[pv], 0, 0, 0);
-            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][1], VB[kt][1][pv], Y2[pv], 0, 0, 0);
-            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][2], VB[kt][2][pv], Y[pv], 0, 0, 0);
-            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][3], VB[kt][3][pv], Y2[pv], 0, 0, 0);
+            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][0], VBV(kt, 0, pv), Y[pv], 0, 0, 0);
+            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][1], VBV(kt, 1, pv), Y2[pv], 0, 0, 0);
+            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][2], VBV(kt, 2, pv), Y[pv], 0, 0, 0);
+            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][3], VBV(kt, 3, pv), Y2[pv], 0, 0, 0);
           }
         }
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
           if (SP && !((act >> (KT - 1)) & 1u)) { Y[pv] += Y2[pv]; continue; }
-          Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][0], VB[KT - 1][0][pv], Y[pv], 0, 0, 0);
-          if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][1], VB[KT - 1][1][pv], Y2[pv], 0, 0, 0);
-          if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][2], VB[KT - 1][2][pv], Y[pv], 0, 0, 0);
-          if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][3], VB[KT - 1][3][pv], Y2[pv], 0, 0, 0);
+          if (!X_PV) { Y[pv] += n[KT - 1]; continue; }
+          Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][0], VBV(KT - 1, 0, pv), Y[pv], 0, 0, 0);
+          if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][1], VBV(KT - 1, 1, pv), Y2[pv], 0, 0, 0);
+          if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
+          if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][3], VBV(KT - 1, 3, pv), Y2[pv], 0, 0, 0);
           Y[pv] += Y2[pv];
         }
         if (HV == 2) {
@@ -323,7 +381,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
         for (int kt = 0; kt < KT; ++kt) {
           if (SP && !((act >> kt) & 1u)) continue;
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
+          for (int rr = 0; rr < 4; ++rr) if (X_W || (kt == 0 && rr == 0)) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
         }
         ent_sync<HV>();
         if (lg == 0) RQ[li] = rqs;
@@ -331,7 +389,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
         // ---- gradient pieces in the PV output layout
         const int base = lane & 48;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
           const int i = lg + 4 * rr;
           const double Av = __shfl(Y[0][rr], base | 1, 64);    // A'_i  (column 1)
           const double rq = RQ[i];
@@ -412,4 +470,5 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
         if (li == 0 && k < Kw) o[2 + 2 * D + kbase + k] = wv;
       }
   }
+#undef VBV
 }
