@@ -59,17 +59,21 @@ constexpr bool X_S = true;
 #endif
 
 
-// Ordering point for LDS words that only one wave touches: a workgroup barrier when the workgroup is one wave, a
-// wave-level fence when it is two (the waves then meet only at the eps staging and at the PV exchange).
+// Ordering point for LDS words that only ONE wave touches (lanes of a wave exchanging values through LDS): the hardware
+// executes a wave's LDS instructions in order, so no s_barrier and no full s_waitcnt drain is needed -- only the compiler must
+// keep the accesses in program order (wave-level fence).  The waves of a two-wave workgroup meet only at the eps staging and
+// at the PV exchange (__syncthreads there).
 template <int HV>
 __device__ __forceinline__ void ent_sync() {
-  if (HV == 1) {
-    __syncthreads();
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the eps tile is shared by the waves of a workgroup: a real barrier when there are two, the wave-level fence when there is one
+template <int HV>
+__device__ __forceinline__ void ent_sync_wg() {
+  if (HV == 1) ent_sync<1>();
+  else __syncthreads();
 }
 
 // HV = 2 (64 < K <= 128): the components are split between the two waves of a workgroup, each running the KT <= 4
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   for (int tile = t0; tile < t1; ++tile) {
     const int b0 = tile * 16;
     // ---- stage the 16 x D eps tile in LDS (zeros for padded dims / samples beyond Mh)
-    __syncthreads();
+    ent_sync_wg<HV>();
     if (HV == 2 && hv != 0) {
       // wave 0 stages (and, in device-RNG mode, draws) the tile for both
     } else if (epsr) {
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
         for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = (bv && 4 * q + t < D) ? z4[t] : 0.0;
       }
     }
-    __syncthreads();
+    ent_sync_wg<HV>();
     // sample-side fragments: lane (li, lg) holds a_i[c = 4q + lg]
     double ev[QS];
     double e2 = 0.0;
