@@ -303,13 +303,12 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       }
     }
 
+      // one loop body for both signs (two copies would not fit the register budget); the second sign's exponents are MOVED
+      // into n on the back edge -- written as a conditional at the loop head the compiler turns them into 32 selects per sign
+      int sg = 0;
+      double sgn = 1.0;
 #pragma unroll 1
-      for (int sg = 0; sg < 2; ++sg) {
-      const double sgn = sg ? -1.0 : 1.0;
-      if (sg) {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) n[kt] = nm[kt];
-      }
+      for (;;) {
       // ---- 4*KT straight-line exps
       if (X_EXP) {
 #pragma unroll
@@ -433,6 +432,11 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
         accH += log(pm) + 0.693147180559945309417 * (double)pe;
         pm = 1.0; pe = 0; pcnt = 0;
       }
+      if (sg) break;
+      sg = 1;
+      sgn = -1.0;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) n[kt] = nm[kt];
       }
   }
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
