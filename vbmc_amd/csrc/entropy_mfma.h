@@ -96,7 +96,11 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   __shared__ double YX[HV == 2 ? 2 : 1][HV == 2 ? 2 : 1][HV == 2 ? NPV * 4 * WAVE : 1];
   // PV "B" operands of large mixtures live in LDS (lane-contiguous: conflict-free ds_read_b64 right before the MFMA that
   // consumes them) -- the 32 VGPRs they would occupy hold the second sign's exponents instead (see the S-step)
-  constexpr bool VBL = GRAD && KT >= 3;
+  // EO: the even / odd split of the S-step below (needs 32 more VGPRs for the second sign's exponents, paid for by VBL).
+  // Two-wave workgroups (K > 64) keep the plain per-sign S-step with everything in registers: their LDS already holds the PV
+  // exchange buffers and a larger parameter block, and 32 KB more would halve the resident waves.
+  constexpr bool EO = HV == 1;
+  constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
   const int tid = threadIdx.x, hv = HV == 2 ? tid >> 6 : 0, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
@@ -177,7 +181,17 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
 #pragma unroll
     for (int q = 0; q < QL; ++q) {
       const int cc = 4 * q + lg;
-      SA[kt][q] = (kv && cc < D) ? -2.0 * h * (pk[cc] - pj[cc]) : 0.0;     // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+      if (EO) {
+        SA[kt][q] = (kv && cc < D) ? -2.0 * h * (pk[cc] - pj[cc]) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+      } else {   // plain S-step: linear and even columns in one (D + 2)-column operand, QS MFMAs per sign
+        double v;
+        if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;
+        else if (cc < D) v = -2.0 * h * (pk[cc] - pj[cc]);
+        else if (cc == D) v = h + hj_neg;
+        else if (cc == D + 1) v = fma(h, m2, pk[D + 1]) - cKj;
+        else v = 0.0;
+        SA[kt][q] = v;
+      }
     }
     // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2) is folded into the two even columns: accumulators start at 0
     SC[kt] = !kv ? (lg == 1 ? -1.0e6 : 0.0)                                 // padded component: exp -> 0
@@ -282,8 +296,8 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
     }
 
     // ---- S-step, once per tile for both signs
-    mf4 n[KT], nm[KT];
-    {
+    mf4 n[KT], nm[EO ? KT : 1];
+    if (EO) {
       const double sfc = lg == 0 ? u2 : (lg == 1 ? 1.0 : 0.0);
       double sfl[QL];
 #pragma unroll
@@ -291,14 +305,14 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
-        nm[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
+        nm[EO ? kt : 0] = (mf4){0.0, 0.0, 0.0, 0.0};
         if (!SP || ((act >> kt) & 1u)) {
           const mf4 cacc = X_S ? __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0) : (mf4){SC[kt] * sfc, sfl[0], SA[kt][0], -1.0};
           n[kt] = cacc;
 #pragma unroll
           for (int q = 0; q < QL; ++q)
             if (X_S) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sfl[q], n[kt], 0, 0, 0);
-          nm[kt] = 2.0 * cacc - n[kt];
+          nm[EO ? kt : 0] = 2.0 * cacc - n[kt];
         }
       }
     }
@@ -309,6 +323,20 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       double sgn = 1.0;
 #pragma unroll 1
       for (;;) {
+      if (!EO) {   // plain S-step of this sign: KT independent accumulator chains
+        double sf[QS];
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+          const int cc = 4 * q + lg;
+          sf[q] = (cc < D) ? sgn * ev[q] * sigj : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+        }
+      }
       // ---- 4*KT straight-line exps
       if (X_EXP) {
 #pragma unroll
@@ -435,8 +463,10 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       if (sg) break;
       sg = 1;
       sgn = -1.0;
+      if (EO) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) n[kt] = nm[kt];
+        for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
+      }
       }
   }
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
