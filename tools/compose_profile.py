@@ -1,9 +1,23 @@
 #!/usr/bin/env python
-"""Assemble profiles/r01_<tag>_summary.md (and refresh profiles/r01_pmc.json) from the files tools/profile_round.sh left in
-gpurun_out/<tag>/.   usage: python tools/compose_profile.py p8 "what changed since the previous profile" """
+"""Assemble profiles/<round>_<tag>_summary.md (and refresh profiles/<round>_pmc.json) from the files tools/profile_round.sh left
+in gpurun_out/<tag>/.   usage: [ROUND=r02] python tools/compose_profile.py p1 "what changed since the previous profile" """
+import hashlib
 import json
+import os
 import re
+import subprocess
 import sys
+
+RND = os.environ.get("ROUND", "r02")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """Identifies the entropy-kernel sources a PMC figure belongs to (bench.py flags a stale figure)."""
+    h = hashlib.sha256()
+    for f in ("entropy_mfma.h", "ent_mfma_inst.hip", "device_math.h", "elbo_types.h"):
+        h.update(open(os.path.join(ROOT, "vbmc_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 tag, changes = sys.argv[1], sys.argv[2]
 o = "gpurun_out/%s/" % tag
@@ -19,18 +33,21 @@ def grab(txt, kern, ctr):
 kern = "`void k_entropy_mfma<3, 4, true, false, 1>(EntArgs)`"
 fetch, write = grab(pa, kern, "FETCH_SIZE"), grab(pb, kern, "WRITE_SIZE")
 hbm = int(round(fetch * 1024 * 2 + write * 1024))
-json.dump({"profile": "profiles/r01_%s_summary.md" % tag, "kernel": "k_entropy_mfma<3,4,true,false,1>",
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_entropy_mfma<3,4,true,false,1>", "commit": commit,
+           "kernel_source_sha256_16": kernel_source_hash(),
            "workload": "python bench.py (R=64, C3, device RNG)", "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); "
                          "WRITE_SIZE as reported (uncalibrated)",
-           "hbm_bytes_per_launch": hbm}, open("profiles/r01_pmc.json", "w"), indent=1)
+           "hbm_bytes_per_launch": hbm}, open("profiles/%s_pmc.json" % RND, "w"), indent=1)
 busy, act = grab(pa, kern, "SQ_VALU_MFMA_BUSY_CYCLES"), grab(pa, kern, "SQ_ACTIVE_INST_VALU")
 b = json.loads(rd("bench.json"))
 bt = json.loads(rd("bench_traced.json").splitlines()[-1])
 aux = json.loads(rd("bench_aux.json"))
 r = b["roofline"]
 mf, va = busy / 1024 / 2.4e9 * 1e3, act * 4 / 1024 / 2.4e9 * 1e3
-txt = f"""# Round 1, profile {tag[1:]}
+isa = rd("isa_meta.txt") if os.path.exists(o + "isa_meta.txt") else "(not collected)"
+txt = f"""# Round {int(RND[1:])}, profile {tag[1:]}
 
 Produced by `bash tools/profile_round.sh {tag}` on the MI355X box (`cd /tmp && export TMPDIR=/tmp` first): full GPU
 test suite, `python bench.py --extras`, `tools/bench_aux.py`, `tools/microbench.hip`, then
@@ -56,6 +73,15 @@ which its workgroups were fitted into the entropy kernel's idle slots (alone it 
 ## Kernel trace (tools/rocpd_summary.py; 28 ELBO launches = 3 warm-up + 20 timed + 5 roofline-leg; k_chol / k_gp_* / k_alpha_solve = the one-off gplite_post that builds the synthetic GP posterior, outside the timed region)
 
 {rd('kernel_trace.md')}
+
+## Registers / LDS / scratch of the entropy kernels from the compiler's own metadata (`tools/isa_meta.py 3`)
+
+The `vgpr_count` column of the rocprofv3 table above is the dispatch packet's arch-VGPR allocation field, not the register
+count (VERDICT r1 asked: 128 there vs 255 claimed); the authoritative figures are the `.amdgpu_metadata` of the code object:
+
+```
+{isa}
+```
 
 ## PMC per launch (R = 64 evaluations), pass A
 
@@ -83,13 +109,13 @@ which its workgroups were fitted into the entropy kernel's idle slots (alone it 
   ({bt['value'] / 1e3:.1f} k in the traced run); C port of the MATLAB loop nest on the box's host: {b['cpu_baseline']['value']:.2f} evals/s on 1 core
   ({b['cpu_baseline']['all_cores']['value']:.1f} with OpenMP on {b['cpu_baseline']['all_cores']['cores']} threads).
 * `k_entropy_mfma` {r['kernel_ms']:.2f} ms by HIP events in `bench.py` (rocprofv3 average in the table above): per tile-sign (800
-  sample x component pairs) 25 MFMA + ~330 VALU instructions.  MFMA busy {busy:.4g} cycles / 1024 SIMDs = {mf:.2f} ms,
+  sample x component pairs) 21 MFMA (8 S-step, the antithetic pair sharing the even part + 13 PV) + ~300 VALU instructions.  MFMA busy {busy:.4g} cycles / 1024 SIMDs = {mf:.2f} ms,
   VALU active {act:.3g} x 4 / 1024 = {va:.2f} ms; the two do not overlap for fp64 -> fp64 pipe ~{100 * (mf + va) / r['kernel_ms']:.0f} % busy.
   Register-limited to 2 waves/SIMD.
 * Algorithmic flops (SURVEY 8d) 9.29e10 per launch -> {r['achieved']:.1f} TFLOP/s = **{100 * r['frac']:.0f} % of the 78.6 TFLOP/s dense fp64 peak**
   (exponentials -- 1.6e9 per launch, 9-10 fp64 ops each -- and tile padding not counted).
 * HBM: FETCH_SIZE {fetch:.0f} KB (x2, gfx950 correction) + WRITE_SIZE {write:.0f} KB = {hbm / 1e6:.1f} MB per launch
-  (`profiles/r01_pmc.json`), < 0.1 % of HBM bandwidth: per-chunk partial records and the packed mixture parameters.
+  (`profiles/{RND}_pmc.json`), < 0.1 % of HBM bandwidth: per-chunk partial records and the packed mixture parameters.
 * On-device Adam, one chain: {b['device_adam_R1_evals_per_s'] / 1e3:.1f} k evals/s ({b['host_loop_R1_evals_per_s'] / 1e3:.1f} k with one host call per evaluation
   through the prepared objective); two chains in lock-step {b['device_adam_R2_evals_per_s'] / 1e3:.1f} k; block-sparse mode
   {b['block_sparse']['evals_per_s'] / 1e3:.1f} k evals/s with identical output.
@@ -98,5 +124,5 @@ which its workgroups were fitted into the entropy kernel's idle slots (alone it 
   `eval_fullelcbo` {aux['eval_fullelcbo_ms']:.2f} ms; value-only `entlb` sieve of 250 candidates {aux['entlb_sieve_R250_ms']:.2f} ms;
   `gplite_nlZ`+gradient {aux['nlz_grad_B1_evals_per_s']:.0f} / {aux['nlz_grad_B16_evals_per_s'] / 1e3:.1f} k / {aux['nlz_grad_B64_evals_per_s'] / 1e3:.1f} k / {aux['nlz_grad_B256_evals_per_s'] / 1e3:.1f} k evals/s at B = 1 / 16 / 64 / 256.
 """
-open("profiles/r01_%s_summary.md" % tag, "w").write(txt)
-print("wrote profiles/r01_%s_summary.md" % tag, len(txt))
+open("profiles/%s_%s_summary.md" % (RND, tag), "w").write(txt)
+print("wrote profiles/%s_%s_summary.md" % (RND, tag), len(txt))

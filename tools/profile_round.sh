@@ -11,6 +11,7 @@ timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $out/pytest_gpu.t
 python bench.py --extras 2> $out/bench_stderr.txt | tail -1 > $out/bench.json
 python tools/bench_aux.py 2>/dev/null | tail -1 > $out/bench_aux.json
 vbmc_amd/lib/microbench > $out/microbench.json 2>&1
+[ -f profiles/isa_meta_qs3.txt ] && cp profiles/isa_meta_qs3.txt $out/isa_meta.txt
 rocprofv3 --kernel-trace --stats -d $out/t -o p -- python bench.py --no-cpu-baseline > $out/bench_traced.json 2> $out/trace_stderr.txt
 python tools/rocpd_summary.py $(find $out/t -name '*.db' | head -1) > $out/kernel_trace.md
 rm -rf $out/t
