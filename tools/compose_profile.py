@@ -42,6 +42,7 @@ json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_ent
            "hbm_bytes_per_launch": hbm}, open("profiles/%s_pmc.json" % RND, "w"), indent=1)
 busy, act = grab(pa, kern, "SQ_VALU_MFMA_BUSY_CYCLES"), grab(pa, kern, "SQ_ACTIVE_INST_VALU")
 b = json.loads(rd("bench.json"))
+b.update(b.get("aux", {}))   # round 2: the auxiliary legs are nested under "aux"
 bt = json.loads(rd("bench_traced.json").splitlines()[-1])
 aux = json.loads(rd("bench_aux.json"))
 r = b["roofline"]
@@ -52,7 +53,7 @@ txt = f"""# Round {int(RND[1:])}, profile {tag[1:]}
 Produced by `bash tools/profile_round.sh {tag}` on the MI355X box (`cd /tmp && export TMPDIR=/tmp` first): full GPU
 test suite, `python bench.py --extras`, `tools/bench_aux.py`, `tools/microbench.hip`, then
 `rocprofv3 --kernel-trace --stats` and two separate `--pmc` passes of
-`python bench.py [--steps 3 --warmup 1] --no-cpu-baseline`; assembled by `tools/compose_profile.py`.  {changes}
+`python bench.py [--steps 3 --warmup 1] --no-cpu-baseline --no-aux` (the timed region of the default command; the auxiliary legs and the CPU baseline run after it); assembled by `tools/compose_profile.py`.  {changes}
 `k_logjoint_mfma` runs on the second, lower-priority stream beside the entropy kernel: its traced duration is the span over
 which its workgroups were fitted into the entropy kernel's idle slots (alone it takes 0.14 ms, `r01_p6_summary.md`).
 
@@ -117,7 +118,8 @@ count (VERDICT r1 asked: 128 there vs 255 claimed); the authoritative figures ar
 * HBM: FETCH_SIZE {fetch:.0f} KB (x2, gfx950 correction) + WRITE_SIZE {write:.0f} KB = {hbm / 1e6:.1f} MB per launch
   (`profiles/{RND}_pmc.json`), < 0.1 % of HBM bandwidth: per-chunk partial records and the packed mixture parameters.
 * On-device Adam, one chain: {b['device_adam_R1_evals_per_s'] / 1e3:.1f} k evals/s ({b['host_loop_R1_evals_per_s'] / 1e3:.1f} k with one host call per evaluation
-  through the prepared objective); two chains in lock-step {b['device_adam_R2_evals_per_s'] / 1e3:.1f} k; block-sparse mode
+  through the prepared objective); two chains in lock-step {b['device_adam_R2_evals_per_s'] / 1e3:.1f} k; parity mode (fp64 eps streamed
+  from HBM, {b['eps_streamed']['eps_stream_GBps']:.0f} GB/s) {b['eps_streamed']['evals_per_s'] / 1e3:.1f} k evals/s; block-sparse mode
   {b['block_sparse']['evals_per_s'] / 1e3:.1f} k evals/s with identical output.
 * GP side (`tools/bench_aux.py`): `gplite_post` (S = 20, N = 400) {aux['gplite_post_ms']:.1f} ms; `gplite_pred` 8192 x 20: {aux['gplite_pred_8192_ms']:.2f} ms wall;
   acquisition sweep on 8192 points: `acqf` {aux['acqwrapper_acqf_8192_ms']:.2f} ms, VIQR with 100 importance points {aux['acqwrapper_acqviqr_8192_Na100_ms']:.2f} ms;
