@@ -237,6 +237,10 @@ typedef struct vbmc_elbo_args {
    * private/activesample_vbmc.m:155 ([~,~,varF] = gplogjoint(vp,gp,0,0,0,1)) and misc/vpoptimizeweights_vbmc.m:42 read */
   double* G_s;               /* S x R  F(s) = sum_k w_k I_sk  (:203)                        */
   double* varG_s;            /* S x R  varF(s), each max(.,eps) (:283,:329-332,:350); needs compute_var */
+  int32_t chunk_world;       /* 0 / 1: the Monte-Carlo samples of a (restart, component) are split into as many chunks as fill
+                              * THIS device once.  W > 1: as many as fill W devices -- the chunking vbmc_elbo_shard_* use for a
+                              * world of W ranks, so that an unsharded evaluation with chunk_world = W is their bit-exact
+                              * reference (the chunk count only moves the summation order of the entropy partials) */
 } vbmc_elbo_args;
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
@@ -252,7 +256,9 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  *      all_gather_into_tensor; ~0.3 MB per rank at the headline shape) --
  *   vbmc_elbo_shard_finish  scatters the gathered blocks into the unsharded record layouts, runs the unsharded
  *                           fixed-order reductions and k_finalize on every rank and returns the outputs of
- *                           vbmc_elbo_batch: BIT-IDENTICAL to the 1-GPU evaluation (same chunking, same summation order).
+ *                           vbmc_elbo_batch: BIT-IDENTICAL to the 1-GPU evaluation with args.chunk_world = world (the
+ *                           samples are split into `world` times as many chunks as one device needs, so that every rank's
+ *                           share still fills its device; same chunking, same summation order => same bits).
  * Covers value + gradient without variance (compute_var = 0, separate_K = 0), device RNG (eps_mode 0): the optimiser-loop
  * call of misc/vpoptimize_vbmc.m:71.  args must be identical on all ranks and in all three calls.
  */

@@ -1,5 +1,6 @@
 """GPU: ONE evaluation sharded along the GP hyper-sample axis and the entropy's sample chunks (SURVEY 8e, R < G) is
-BIT-IDENTICAL to the unsharded evaluation -- same chunking, same summation order (vbmc_elbo_shard_begin / _finish).
+BIT-IDENTICAL to the unsharded evaluation with the same chunking (chunk_world = world) -- same summation order
+(vbmc_elbo_shard_begin / _finish).
 World sizes up to 8 are emulated in one process on one GPU (each rank's block is computed in turn and the blocks are
 concatenated as an all-gather would); a real two-process run follows."""
 import json
@@ -17,23 +18,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class LocalExchange:
-    """Stands in for the all-gather of vbmc_amd.dist.ShardExchange inside one process: rank g's block is written at offset g n."""
+    """Stands in for the all-gather of vbmc_amd.dist.ShardExchange inside one process: rank g's block is written at offset g n
+    of one device buffer from the library's own allocator (vbmc_device_alloc: no torch in this process)."""
 
-    def __init__(self, world):
-        import torch
-
-        self.torch, self.world, self.buf, self.rank = torch, world, None, 0
+    def __init__(self, ctx, world):
+        self.ctx, self.world, self.ptr, self.n, self.rank = ctx, world, None, 0, 0
 
     def send_buffer(self, n):
-        if self.buf is None or self.buf.numel() != n * self.world:
-            self.buf = self.torch.zeros(n * self.world, dtype=self.torch.float64, device="cuda")
-            self.torch.cuda.synchronize()
-        self.n = n
-        return self.buf.data_ptr() + 8 * n * self.rank
+        import ctypes as C
+
+        if self.ptr is None or self.n != n:
+            self.free()
+            p = C.c_void_p()
+            self.ctx.check(self.ctx.lib.vbmc_device_alloc(self.ctx.h, C.c_size_t(8 * n * self.world), C.byref(p)))
+            self.ptr, self.n = p.value, n
+        return self.ptr + 8 * n * self.rank
 
     def all_gather(self):
-        self.torch.cuda.synchronize()
-        return self.buf.data_ptr()
+        return self.ptr
+
+    def free(self):
+        import ctypes as C
+
+        if self.ptr is not None:
+            self.ctx.lib.vbmc_device_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
 
 
 def _setup(va, seed, D, N, K, S):
@@ -53,9 +62,9 @@ def _sharded(va, world, thetas, vp, gp, Ns, tb, seed, grad=True):
 
     from vbmc_amd import elbo as E
 
-    ex = LocalExchange(world)
     eng = va.default_engine()
     ctx = eng.ctx
+    ex = LocalExchange(ctx, world)
     th = E.f64(thetas if thetas.ndim == 2 else thetas.reshape(-1, 1))
     a, keep, _ = E._build_args(th, 0.0, vp, gp, Ns, grad, 0, tb, False, None, None, False, seed, eng)
     dgp = eng.device_gp(gp)
@@ -71,6 +80,7 @@ def _sharded(va, world, thetas, vp, gp, Ns, tb, seed, grad=True):
         ex.rank = g
         ctx.check(ctx.lib.vbmc_elbo_shard_begin(ctx.h, dgp.h, C.byref(a), g, world, C.c_void_p(ex.send_buffer(n.value))))
     ctx.check(ctx.lib.vbmc_elbo_shard_finish(ctx.h, dgp.h, C.byref(a), world, C.c_void_p(ex.all_gather())))
+    ex.free()
     return out
 
 
@@ -84,11 +94,13 @@ def test_sharded_evaluation_is_bit_identical(cfg, world):
     gp, vp, theta, tb = _setup(va, 11, D, N, K, S)
     rng = np.random.default_rng(1)
     thetas = np.asfortranarray(theta[:, None] + 0.05 * rng.standard_normal((theta.size, R)))
-    ref = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, tb, seed=99)
+    ref = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, tb, seed=99, chunk_world=world)
+    plain = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, tb, seed=99)   # default chunking: same numbers to summation order
+    assert np.allclose(plain["F"], ref["F"], rtol=1e-12, atol=0) and np.allclose(plain["dF"], ref["dF"], rtol=1e-9, atol=1e-12)
     got = _sharded(va, world, thetas, vp, gp, Ns, tb, 99)
     for k in ("F", "G", "H", "dF", "dG", "dH"):
         assert np.array_equal(got[k], ref[k]), (k, float(np.max(np.abs(got[k] - ref[k]))))
-    ref0 = va.negelcbo_batch(thetas, 0, vp, gp, Ns, False, 0, tb, seed=99)
+    ref0 = va.negelcbo_batch(thetas, 0, vp, gp, Ns, False, 0, tb, seed=99, chunk_world=world)
     got0 = _sharded(va, world, thetas, vp, gp, Ns, tb, 99, grad=False)
     assert np.array_equal(got0["F"], ref0["F"]) and np.array_equal(got0["H"], ref0["H"])
 
@@ -124,7 +136,7 @@ eng = va.Engine(rank %% nd)
 gp, vp, theta, tb = _setup(va, 11, 10, 400, 50, 20)
 gp = va.gplite_post(np.stack([p["hyp"] for p in gp["post"]], axis=1), gp["X"], gp["y"], 1, 4, (1, 0, 0), None, engine=eng)
 ex = ShardExchange(device=torch.device("cuda", rank %% nd))
-ref = va.negelcbo_batch(theta, 0, vp, gp, 10000, True, 0, tb, seed=5, engine=eng)
+ref = va.negelcbo_batch(theta, 0, vp, gp, 10000, True, 0, tb, seed=5, engine=eng, chunk_world=world)
 got = va.negelcbo_shard(theta, 0, vp, gp, 10000, True, tb, rank=rank, world=world, exchange=ex, seed=5, engine=eng, outputs=("F", "dF", "H"))
 ok = bool(np.array_equal(got["F"], ref["F"]) and np.array_equal(got["dF"], ref["dF"]) and np.array_equal(got["H"], ref["H"]))
 allok = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")

@@ -79,7 +79,7 @@ def main():
     # ---- 3. independence across the counters
     P("## 3. Correlations across the stream's counters (values / squares; |r| should be ~ 1/sqrt(n))\n")
     P("| pair | n pairs | r(values) | r(squares) | 3/sqrt(n) |\n|---|---|---|---|---|")
-    A = eng.ctx.rng_dump(12, 8, 6, 8000, 7)   # (R, K, Mh, D): D = 12 -> three full dim-blocks of four
+    A = eng.ctx.rng_dump(12, 8, 6, 80000, 7)   # (R, K, Mh, D): D = 12 -> three full dim-blocks of four
 
     def corr(a, b, name):
         a, b = a.reshape(-1), b.reshape(-1)
@@ -98,9 +98,9 @@ def main():
     corr(A[:, :, :-16, :], A[:, :, 16:, :], "sample i and i+16 (next tile)")
     corr(A[:, :-1], A[:, 1:], "component j and j+1")
     corr(A[:-1], A[1:], "restart r and r+1")
-    B = eng.ctx.rng_dump(12, 8, 6, 8000, 8)
+    B = eng.ctx.rng_dump(12, 8, 6, 80000, 8)
     corr(A, B, "seed s and s+1 (consecutive Adam iterations)")
-    Bh = eng.ctx.rng_dump(12, 8, 6, 8000, 7 + (1 << 32))
+    Bh = eng.ctx.rng_dump(12, 8, 6, 80000, 7 + (1 << 32))
     corr(A, Bh, "seeds differing in the high key word only")
     P("")
 

@@ -53,5 +53,6 @@ for W in (2, 4, 8):
         ctx.check(ctx.lib.vbmc_elbo_shard_begin(ctx.h, dgp.h, C.byref(a), g, W, C.c_void_p(buf.data_ptr() + 8 * n.value * g)))
     tb = timeit(lambda: ctx.check(ctx.lib.vbmc_elbo_shard_begin(ctx.h, dgp.h, C.byref(a), 0, W, C.c_void_p(buf.data_ptr()))))
     tf = timeit(lambda: ctx.check(ctx.lib.vbmc_elbo_shard_finish(ctx.h, dgp.h, C.byref(a), W, C.c_void_p(buf.data_ptr()))))
+    a.chunk_world = 0
     print("world %d: block %.0f KB per rank; begin %.1f us + finish %.1f us = %.1f us (+ all-gather) -> x%.2f of the unsharded pass"
           % (W, n.value * 8 / 1024, tb, tf, tb + tf, base / (tb + tf)))

@@ -53,6 +53,7 @@ class ElboArgs(C.Structure):
         ("F", _dp), ("dF", _dp), ("G", _dp), ("H", _dp), ("dG", _dp), ("dH", _dp),
         ("varG", _dp), ("varGss", _dp), ("I_sk", _dp), ("J_sjk", _dp),
         ("G_s", _dp), ("varG_s", _dp),
+        ("chunk_world", C.c_int32),
     ]
 
 

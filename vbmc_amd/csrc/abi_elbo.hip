@@ -349,7 +349,7 @@ struct ElboPlan {
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
 #define VAR_FINAL_LDS(S_, K_, Tg_) ((256 + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
-static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P) {
+static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
   if (a->struct_size != sizeof(vbmc_elbo_args))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(vbmc_elbo_args));
@@ -465,7 +465,8 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     // chunks per (component, restart): minimise  ceil(waves / resident slots) * (setup + tiles per wave),
     // i.e. whole rounds of resident waves, with the per-wave setup worth ~1.5 tiles
     {
-      const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5);
+      const int cw = chunk_world > 0 ? chunk_world : (a->chunk_world > 1 ? a->chunk_world : 1);   // sharded over cw devices
+      const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5) * cw;
       const long long kr = (long long)K * R * (P.use_mfma ? P.hv : 1);   // waves per chunk index
       const double setup = 1.5;   // measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
       double best = 1e300;
@@ -904,7 +905,7 @@ extern "C" vbmc_status vbmc_elbo_shard_size(vbmc_ctx* ctx, const vbmc_gp* gp, co
   if (!ctx || !n_doubles) return VBMC_ERR_INVALID;
   { vbmc_status s_ = shard_check(ctx, gp, a, 0, world); if (s_) return s_; }
   ElboPlan P;
-  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P, world); if (s_) return s_; }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *n_doubles = shard_doubles(P, world);
   return VBMC_OK;
@@ -915,7 +916,7 @@ extern "C" vbmc_status vbmc_elbo_shard_begin(vbmc_ctx* ctx, const vbmc_gp* gp, c
   if (!ctx || !d_send) return VBMC_ERR_INVALID;
   { vbmc_status s_ = shard_check(ctx, gp, a, rank, world); if (s_) return s_; }
   ElboPlan P;
-  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P, world); if (s_) return s_; }
   ShardSpec sh;
   sh.mode = 1; sh.rank = rank; sh.world = world; sh.send = d_send;
   HIP_TRY(ctx, hipMemsetAsync(d_send, 0, shard_doubles(P, world) * sizeof(double), ctx->stream));   // unused slots of an uneven split
@@ -929,7 +930,7 @@ extern "C" vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, 
   if (!ctx || !d_gathered) return VBMC_ERR_INVALID;
   { vbmc_status s_ = shard_check(ctx, gp, a, 0, world); if (s_) return s_; }
   ElboPlan P;
-  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P, world); if (s_) return s_; }
   ShardSpec sh;
   sh.mode = 2; sh.world = world; sh.gathered = d_gathered;
   { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed, nullptr, 0, &sh); if (s_) return s_; }

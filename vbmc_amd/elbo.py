@@ -86,7 +86,7 @@ def _flags(vp):
 
 
 def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps, eps_device_ptr, eps_shared,
-                seed, engine, sparse_cutoff=0.0):
+                seed, engine, sparse_cutoff=0.0, chunk_world=0):
     """Fill a vbmc_elbo_args for R = thetas.shape[1] restarts; returns (args, keep-alive list, compute_var)."""
     D, K = int(vp["D"]), int(vp["K"])
     T, R = thetas.shape
@@ -139,6 +139,7 @@ def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, s
     a.separate_K = 1 if separate_K else 0
     a.beta = float(beta)
     a.sparse_cutoff = float(sparse_cutoff or 0.0)
+    a.chunk_world = int(chunk_world or 0)
     if thetabnd is not None:
         a.bnd_lb = hold(thetabnd["lb"])
         a.bnd_ub = hold(thetabnd["ub"])
@@ -181,7 +182,7 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
 
 def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
                    separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
-                   sparse_cutoff=0.0, outputs=None):
+                   sparse_cutoff=0.0, outputs=None, chunk_world=0):
     """R evaluations of negelcbo_vbmc in one device pass.
 
     outputs: None = everything below; a subset such as ("F", "dF") -- what the optimiser loop reads,
@@ -192,6 +193,7 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     eps: host array shaped (R, K, Ns/2, D) (or (K, Ns/2, D) with eps_shared) standing in for the
     reference's randn stream (entmc_vbmc.m:53); None -> device Philox stream keyed by ``seed``.
     sparse_cutoff: 0 dense; c > 0 skips 16-component tiles whose terms are provably < exp(-c) of q(x).
+    chunk_world: W > 1 chunks the MC samples as negelcbo_shard does for a world of W ranks (its bit-exact 1-GPU reference).
     """
     engine = engine or default_engine()
     ctx = engine.ctx
@@ -201,7 +203,7 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     T, R = thetas.shape
     D, K = int(vp["D"]), int(vp["K"])
     a, keep, compute_var = _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps,
-                                       eps_device_ptr, eps_shared, seed, engine, sparse_cutoff)
+                                       eps_device_ptr, eps_shared, seed, engine, sparse_cutoff, chunk_world)
     if gp is None:   # entropy only (entmc_vbmc / entlb_vbmc on their own): the ABI takes a NULL surrogate
         if compute_var or separate_K:
             raise ValueError("an entropy-only evaluation has no variance or per-component outputs")
@@ -244,7 +246,8 @@ def negelcbo_shard(thetas, beta, vp, gp, Ns, compute_grad=True, thetabnd=None, *
                    outputs=("F", "dF")):
     """ONE negelcbo evaluation (or a batch with fewer restarts than GPUs) sharded over ``world`` ranks along the GP
     hyper-sample axis (misc/gplogjoint.m:98) and the Monte-Carlo sample chunks of the entropy (ent/entmc_vbmc.m:49-104);
-    every rank returns the outputs of ``negelcbo_batch`` -- bit-identical to the 1-GPU evaluation (vbmc_elbo_shard_*).
+    every rank returns the outputs of ``negelcbo_batch`` -- bit-identical to the 1-GPU evaluation with
+    ``chunk_world=world`` (vbmc_elbo_shard_*: the samples are cut into ``world`` times as many chunks as one device needs).
 
     ``exchange`` (vbmc_amd.dist.ShardExchange or anything with the same two methods): ``send_buffer(n)`` -> device
     pointer of n doubles this rank fills; ``all_gather()`` -> device pointer of the world blocks in rank order.
