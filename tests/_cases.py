@@ -116,3 +116,24 @@ def synth_problem(seed, D, N, K, S, meanfun=4, noisy=False, target="lumpy"):
     eta = 0.3 * rng.standard_normal(K)
     return dict(D=D, N=N, K=K, S=S, X=X, y=y, s2=s2, hyp=hyp, meanfun=meanfun, noisefun=noisefun,
                 mu=mu, sigma=sigma, lam=lam, eta=eta, rng=rng)
+
+
+def block_relerr(a, b, D, K, opt=(1, 1, 1, 1)):
+    """Per-block relative error of a theta-shaped gradient [mu (D K) | log sigma (K) | log lambda (D) | eta (K)] (only the
+    optimised groups present): each block against ITS OWN largest reference entry, so that a wrong small block (a lambda
+    gradient of 1e-4 beside a mu gradient of 1e2) cannot hide behind the largest entry of the whole vector.  A block that
+    is itself pure cancellation noise (the mu-gradient of the entropy of well separated components: O(1) sample terms
+    summing to 1e-9) is measured against 1e-6 of the vector's largest entry instead -- six orders below it, still far
+    finer than the whole-vector check."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    sizes = [D * K if opt[0] else 0, K if opt[1] else 0, D if opt[2] else 0, K if opt[3] else 0]
+    assert a.size == b.size == sum(sizes), (a.size, b.size, sizes)
+    out, i = {}, 0
+    floor = 1e-6 * float(np.max(np.abs(b))) if b.size else 0.0
+    for name, n in zip(("mu", "sigma", "lambda", "eta"), sizes):
+        if n:
+            sc = max(float(np.max(np.abs(b[i:i + n]))), floor)
+            out[name] = float(np.max(np.abs(a[i:i + n] - b[i:i + n]))) / sc if sc > 0 else float(np.max(np.abs(a[i:i + n])))
+        i += n
+    return out

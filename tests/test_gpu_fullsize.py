@@ -8,7 +8,7 @@ import pytest
 
 from oracle import c_oracle
 from oracle import vbmc_ref as R
-from tests._cases import synth_problem
+from tests._cases import block_relerr, synth_problem
 from tests.test_gpu_elbo import relerr
 
 pytestmark = pytest.mark.gpu
@@ -48,6 +48,7 @@ def test_full_size_parity_and_properties(va, cfg):
     F, dF, G, H = c_oracle.negelcbo(theta, p["X"], p["hyp"], alpha, eps, meanfun=4, Nnoise=Nnoise, openmp=True)
     assert relerr(a["G"][0], G) < 1e-10 and relerr(a["H"][0], H) < 1e-10 and relerr(a["F"][0], F) < 1e-10
     assert relerr(a["dF"][:, 0], dF) < 1e-9
+    assert all(v < 1e-9 for v in block_relerr(a["dF"][:, 0], dF, D, K).values())   # each parameter group against its own scale
     # batch of jittered restarts == the same restarts one by one (shared seed -> restart r uses stream r)
     th = theta[:, None] + 0.02 * np.random.default_rng(1).standard_normal((theta.size, 3))
     bt = va.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=seed)
