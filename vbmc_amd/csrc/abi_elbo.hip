@@ -334,7 +334,8 @@ struct ElboPlan {
   ElboDims dm{};
   int compute_grad = 0, compute_var = 0, dt = 0;
   double beta = 0.0;
-  bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false;
+  bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false;
+  double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
@@ -397,14 +398,13 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
   const int Mh = P.Mh = M / 2;
   P.mc = M > 0;
-  if (!P.mc && K > 128) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "entlb with K > 128 not accelerated");
   if (P.mc && a->eps_mode != 0 && !a->eps) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode %d needs eps", a->eps_mode);
   if (a->eps_mode < 0 || a->eps_mode > 2) return set_err(ctx, VBMC_ERR_INVALID, "eps_mode must be 0, 1 or 2");
   P.dt = pick_dt(D);
   if (P.dt < 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d not accelerated", D);
-  // k_finalize keeps three T-vectors, the D x K soft-bound table and its reduction scratch in LDS
-  if ((FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8) * sizeof(double) > 160 * 1024)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d with K = %d (4 D K + 9 K > 19400) not accelerated", D, K);
+  // k_finalize keeps three T-vectors, the D x K soft-bound table and its reduction scratch in LDS; beyond 160 KB
+  // (4 D K + 9 K > 19400, e.g. D = 32 with K > 141) they move to a global scratch block
+  P.fin_big = (FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8) * sizeof(double) > 160 * 1024;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   VpLayout VL{D, K};
@@ -450,6 +450,15 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   const int LJS = 2 * D + 2;
   { vbmc_status s_ = ensure(ctx, ctx->ljpart, ((size_t)R * S * K * LJS + (size_t)R * K * LJS) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->out, P.out_n * sizeof(double)); if (s_) return s_; }
+  {
+    const size_t nbig = P.fin_big ? (size_t)R * (3 * (size_t)T + (size_t)D * K) : 0;
+    const size_t ngam = (!(a->Ns > 0) && K > 128) ? (size_t)R * K * K : 0;      // entlb's K x K table beyond the LDS
+    if (nbig + ngam) {
+      vbmc_status s_ = ensure(ctx, ctx->bnd, (nbig + ngam) * sizeof(double)); if (s_) return s_;
+      P.d_finbig = nbig ? (double*)ctx->bnd.p : nullptr;
+      P.d_gamma = ngam ? (double*)ctx->bnd.p + nbig : nullptr;
+    }
+  }
   P.d_vpd = (double*)ctx->prep.p;
   P.d_entp = (double*)ctx->entp.p;
   P.d_lj = (double*)ctx->ljpart.p;
@@ -699,10 +708,10 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {
     if (sh.mode == 1) return VBMC_OK;   // the deterministic bound is O(K^2 D): every rank evaluates it in mode 2
-    size_t lds = ((size_t)K * K + K + 256) * sizeof(double);
+    size_t lds = ((P.d_gamma ? 0 : (size_t)K * K) + K + 256) * sizeof(double);
     if (lds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_entlb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, P.d_vpd, P.d_part, P.compute_grad);
+    hipLaunchKernelGGL(k_entlb, dim3(R), dim3(256), lds, st, dm, P.d_vpd, P.d_part, P.compute_grad, P.d_gamma);
     LAUNCH_CHECK(ctx, "k_entlb");
     fa.entpart = nullptr; fa.entlb = P.d_part;
   }
@@ -760,7 +769,8 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
   fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out;
   {
-    size_t lds = (FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8) * sizeof(double);
+    size_t lds = (FIN_THREADS + 3 * (size_t)K + (P.fin_big ? 0 : (size_t)D * K + 3 * (size_t)T) + 8) * sizeof(double);
+    fa.big = P.d_finbig;
     const int next_mu = dm.opt[0] ? D * K : 0;
     const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
     const size_t stage_rec = ((size_t)K * (2 * D + 2) + (fa.entpart ? (size_t)K * fa.C * fa.ncol : 0)) * sizeof(double);

@@ -592,7 +592,7 @@ __global__ void k_rng_dump(int D, int K, int R, int Mh, unsigned long long seed,
 // applied) | lambda_grad[D] | w_grad_raw[K] (softmax Jacobian applied in k_finalize).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __restrict__ vpd,
-                                               double* __restrict__ eb, int want_grad) {
+                                               double* __restrict__ eb, int want_grad, double* __restrict__ gamma_g) {
   extern __shared__ double lds[];
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int D = dm.D, K = dm.K;
@@ -603,8 +603,10 @@ __global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __rest
   const double* lam = v + L.lambda();
   const double* w = v + L.w();
   double* o = eb + (size_t)r * (1 + D * K + 2 * K + D);
-  double* gamma = lds;              // K*K  gamma[j + K*k]
-  double* gammasum = gamma + K * K; // K
+  // K*K  gamma[j + K*k]: in LDS up to K = 128; larger mixtures keep it in a global scratch block of the restart (the
+  // workgroup barriers below order its writes before the reads)
+  double* gamma = gamma_g ? gamma_g + (size_t)r * K * K : lds;
+  double* gammasum = gamma_g ? lds : lds + K * K; // K
   double* red = gammasum + K;       // nt
   if (K == 1) {  // :32-47 exact entropy
     if (tid == 0) {
@@ -772,6 +774,7 @@ struct FinArgs {
   double TolCon, WeightThreshold, WeightPenalty, beta;
   int M, C, ncol, want_grad, has_bnd, var_stride;
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
+  double* big;            // null, or R x (3T + DK) doubles of global scratch for dG | dH | dP | gsc when they exceed the LDS
   double* out;            // R x (OUT_HDR + 3T)
 };
 
@@ -801,14 +804,17 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(FinArgs a) {
   double* Ibar = red + nt;     // K   mean_s I_sk
   double* Hj = Ibar + K;       // K   (1/M) sum_i log q' for component j
   double* wraw = Hj + K;       // K   raw w-gradient of H
-  double* dG = wraw + K;       // T (packed)
+  // the three T-vectors and the D x K soft-bound table: LDS, or for very large D x K the restart's slice of a global scratch
+  // block (workgroup barriers order the accesses either way)
+  double* bigr = a.big ? a.big + (size_t)r * (3 * (size_t)T + (size_t)D * K) : nullptr;
+  double* dG = bigr ? bigr : wraw + K;       // T (packed)
   double* dH = dG + T;         // T
   double* dP = dH + T;         // T   penalty gradient
-  double* scal = dP + T;       // 8 scalars
+  double* scal = bigr ? wraw + K : dP + T;   // 8 scalars
   // w, sigma, lambda are read inside serial loops over the components below: LDS copies keep those loops off the
   // global-memory latency (a single chain, R = 1, is bound by exactly this kernel's dependent chains)
-  double* gsc = scal + 8;      // D x K   soft-bound gradient of the lnscale block per (d, k)
-  double* stg = gsc + D * K;   // staging area (a.stage says what fits)
+  double* gsc = bigr ? dP + T : scal + 8;    // D x K   soft-bound gradient of the lnscale block per (d, k)
+  double* stg = bigr ? scal + 8 : gsc + D * K;   // staging area (a.stage says what fits)
   // Everything this workgroup reads more than once sits in LDS: the vp record and the bounds (stage & 2), the
   // log-joint / entropy records of the restart (stage & 1).  A single chain (R = 1) is bound by exactly this kernel's
   // chains of dependent global loads, so they are issued in a few wide batches up front.
