@@ -53,3 +53,76 @@ def test_mixtures_whose_finalize_record_exceeds_the_lds(va, cfg):
     assert abs(got["G"][0] - ref["G"]) < 1e-10 * max(1.0, abs(ref["G"])) and abs(got["H"][0] - ref["H"]) < 1e-10 * max(1.0, abs(ref["H"]))
     for key in ("dF", "dG", "dH"):
         assert all(v < 1e-9 for v in block_relerr(got[key][:, 0], ref[key], D, K).values()), key
+
+
+# ---- N beyond the 16-column right-hand-side slab (N > 1136): narrow slabs (8 columns up to N = 2144, 4 up to 3872), the
+# Cholesky panel in global scratch (N > 1232), slab-solve prediction (N > 1248).  VBMC's default MaxFunEvals = 50 (2 + D)
+# reaches N = 1150 at D = 21 and 1700 at D = 32.
+def _big_gp(seed, D, N, S, noisy=False, low_noise=False):
+    p = synth_problem(seed, D, N, 4, S, noisy=noisy)
+    if low_noise:
+        p["hyp"][D + 1, :] = np.log(3e-4)      # sn2 = 9e-8 < 1e-6: the stored -inv(K + sn2 I) branch (gplite_core.m:84)
+    return p
+
+
+@pytest.mark.parametrize("cfg", [(6, 1500, 2, False), (4, 2200, 1, False), (5, 1300, 2, True)])
+def test_gp_post_pred_rank1_beyond_the_wide_slab(va, cfg):
+    D, N, S, low = cfg
+    p = _big_gp(81, D, N, S, low_noise=low)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 4, (1, 0, 0), None)
+    for a, b in zip(gp["post"], ref["post"]):
+        assert a["Lchol"] == b["Lchol"] == (not low) and a["sn2_mult"] == b["sn2_mult"]
+        sc = np.max(np.abs(b["L"]))
+        assert np.max(np.abs(a["L"] - b["L"])) < (1e-9 if not low else 1e-6) * sc
+        assert np.max(np.abs(a["alpha"] - b["alpha"])) < 1e-6 * np.max(np.abs(b["alpha"]))
+    Xs = 1.4 * np.random.default_rng(1).standard_normal((70, D))
+    o = va.gplite_pred(gp, Xs, None, None, True)
+    r = R.gplite_pred(ref, Xs, None, None, ssflag=True)
+    sf2 = np.exp(2 * p["hyp"][D, 0])
+    flat = lambda z: np.asarray(z, dtype=np.float64).reshape(-1, order="F")   # noqa: E731  (S = 1: (Nstar,) vs (Nstar, 1))
+    assert np.max(np.abs(flat(o[2]) - flat(r[2]))) < 1e-6 * max(1.0, np.max(np.abs(r[2])))
+    assert np.max(np.abs(flat(o[3]) - flat(r[3]))) < 1e-7 * sf2
+    # acquisition sweep on the same surrogate (prediction fused behind it)
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    st = {"ymax": float(np.max(p["y"])), "VarianceRegularizedAcqFcn": False, "TolGPVar": 1e-4}
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None)
+    acr = R.acqwrapper_vbmc(Xs, vp, ref, st, "acqf")[0]
+    assert np.max(np.abs(acq - acr)) < 1e-6 * max(1e-300, np.max(np.abs(acr)))
+    if not low:
+        # rank-one append == full update with the extra point
+        xs, ys = 0.3 * np.ones(D), float(np.mean(p["y"]))
+        g1 = va.gplite_post_rank1(gp, xs, ys)
+        g2 = R.gplite_post(p["hyp"], np.vstack([p["X"], xs[None, :]]), np.concatenate([p["y"], [ys]]), meanfun=4)
+        for a, b in zip(g1["post"], g2["post"]):
+            assert np.max(np.abs(a["alpha"] - b["alpha"])) < 1e-5 * np.max(np.abs(b["alpha"]))
+            assert np.max(np.abs(a["L"] - b["L"])) < 1e-8 * np.max(np.abs(b["L"]))
+
+
+def test_variance_paths_and_nlz_beyond_the_wide_slab(va):
+    D, N, S, K = 5, 1300, 2, 6
+    p = synth_problem(83, D, N, K, S)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    ref = R.negelcbo_vbmc(theta, 0, vp, gp, 0, False, 1, separate_K=True)
+    got = va.negelcbo_batch(theta, 0, vp, gp, 0, False, 1, separate_K=True)
+    assert abs(got["G"][0] - ref["G"]) < 1e-10 * max(1.0, abs(ref["G"]))
+    assert abs(got["varG"][0] - ref["varG"]) < 1e-6 * max(abs(ref["varG"]), 1e-12) + 1e-9
+    assert np.max(np.abs(got["J_sjk"][:, :, :, 0] - ref["J_sjk"])) < 1e-7 * max(1.0, np.max(np.abs(ref["J_sjk"])))
+    refd = R.negelcbo_vbmc(theta, 0.5, vp, gp, 0, True, 2)
+    gotd = va.negelcbo_batch(theta, 0.5, vp, gp, 0, True, 2)
+    assert abs(gotd["F"][0] - refd["F"]) < 1e-8 * max(1.0, abs(refd["F"]))
+    assert all(v < 1e-6 for v in block_relerr(gotd["dF"][:, 0], refd["dF"], D, K).values())
+    # GP marginal likelihood + gradient (inv(K) as T'T with the narrow triangular inverse)
+    gpd = {"X": p["X"], "y": p["y"], "s2": None, "covfun": 1, "Ncov": D + 1, "noisefun": (1, 0, 0), "Nnoise": 1, "meanfun": 4,
+           "Nmean": 2 * D + 1, "meanfun_extras": None, "intmeanfun": 0}
+    H = p["hyp"].copy()
+    H[D + 1, :] = np.log(5e-2)
+    nlz, dnlz = va.gplite_nlZ(H, gpd)
+    for b in range(S):
+        rz, rg = R.gplite_nlZ(H[:, b], gpd)
+        assert abs(nlz[b] - rz) < 1e-9 * max(1.0, abs(rz))
+        assert np.max(np.abs(dnlz[:, b] - rg)) < 1e-7 * max(1.0, np.max(np.abs(rg)))

@@ -386,8 +386,8 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     return set_err(ctx, VBMC_ERR_INVALID, "compute_var != 0 needs gp.post(s).L: upload the GP with L");
   if (compute_var != 0 && VAR_FINAL_LDS(S, K, compute_grad ? T : 0) > 160 * 1024)   // k_var_final: five T-vectors in LDS
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance gradient with %d variational parameters (> 4000) not accelerated", T);
-  if (compute_var != 0 && TRSM_LDS_BYTES(dm.N) > 160 * 1024)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 1136 not accelerated", dm.N);
+  if (compute_var != 0 && trsm_cw_for(dm.N) == 0)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 3872 not accelerated", dm.N);
   P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
   // theta must be finite (the device exp does not propagate NaN)
   for (size_t i = 0; i < (size_t)T * R; ++i)
@@ -532,7 +532,6 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     P.d_J = P.d_X + (P.needX ? nz : 0);
     P.d_vg = P.d_J + nJ;
     P.d_var = P.d_vg + nvg;
-    P.tlds = TRSM_LDS_BYTES(N);
   }
   return VBMC_OK;
 }
@@ -730,22 +729,14 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       hipLaunchKernelGGL((k_var_z<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2, P.d_Z);
       LAUNCH_CHECK(ctx, "k_var_z");
     });
-    const size_t tlds = P.tlds;
-    if (tlds > 64 * 1024) {
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-    }
-    const dim3 tg((K + TR_CB - 1) / TR_CB, S, R);
     if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
     LAUNCH_CHECK(ctx, "k_symm");
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_finv, gp->d_lchol, P.d_Z);
-    LAUNCH_CHECK(ctx, "k_trsm_fwd");
+    HIP_TRY(ctx, trsm_fwd_launch(st, N, K, S, R, gp->L, gp->d_finv, gp->d_lchol, P.d_Z));
     hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                        P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);
     LAUNCH_CHECK(ctx, "k_var_gram");
     if (P.vgrad) {
-      hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, K, S, gp->L, gp->d_finv, gp->d_lchol, P.d_Z, P.d_X);
-      LAUNCH_CHECK(ctx, "k_trsm_bwd");
+      HIP_TRY(ctx, trsm_bwd_launch(st, N, K, S, R, gp->L, gp->d_finv, gp->d_lchol, P.d_Z, P.d_X));
       DISPATCH_DT(dt, {
         hipLaunchKernelGGL((k_vargrad<DT>), dim3(K, S, R), dim3(WAVE), 0, st, dm, P.d_vpd, gp->X, gp->gpc, P.d_delta2,
                            gp->d_sn2, gp->d_lchol, P.d_X, P.d_vg);

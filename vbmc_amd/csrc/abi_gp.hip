@@ -85,7 +85,7 @@ extern "C" vbmc_status vbmc_sq_dist(vbmc_ctx* ctx, int D, int n, int m, const do
 namespace {
 
 struct GpFactor {
-  int Ncov = 0, Nnoise = 0, Nmean = 0;
+  int Ncov = 0, Nnoise = 0, Nmean = 0, cw = 16;      // cw: slab width of the triangular solves at this N (trsm_cw_for)
   std::vector<double> sn2all, scal, sn2min;         // host copies: S x N noise, S x 4 {sn2div, mult, lchol, sl}
   std::vector<unsigned char> lch, failed;           // Lchol flag; 1 = Cholesky still failing after 10 retries
   bool any_inv = false;
@@ -109,8 +109,9 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   if (Nhyp != Ncov + Nnoise + Nmean)
     return set_err(ctx, VBMC_ERR_INVALID, "%s:dimmismatch Number of hyperparameters mismatched with GP model specification.",
                    fail_is_error ? "gplite_post" : "gplite_nlZ");
-  if (CHOL_LDS_BYTES(N) > 160 * 1024 || TRSM_LDS_BYTES(N) > 160 * 1024)   // LDS-resident panels / right-hand-side slabs
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 1136 not accelerated", N);
+  // right-hand-side slabs of the triangular solves live in LDS: 16 columns wide up to N = 1136, narrower beyond (trsm_cw_for);
+  // the Cholesky panel moves to a global scratch block when it no longer fits
+  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 3872 not accelerated", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
@@ -158,7 +159,11 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>());
 
   // jittered Cholesky: up to 10 tries, noise multiplier x10 per failure (gplite_core.m:77-80,91-94)
-  const size_t chol_lds = CHOL_LDS_BYTES(N);
+  // the 16 x N panel of the Cholesky lives in LDS up to N = 1232, in a global scratch block beyond
+  const bool chol_gpanel = CHOL_LDS_BYTES(N) > 160 * 1024;
+  const size_t chol_lds = chol_gpanel ? (size_t)2 * 16 * 17 * sizeof(double) : CHOL_LDS_BYTES(N);
+  TmpBuf dPg;
+  if (chol_gpanel) HIP_TRY(ctx, dPg.alloc(ctx, (size_t)S * 16 * (size_t)(((N + 15) >> 4) << 4) * 8));
   if (chol_lds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
   std::vector<int> pf(S);
@@ -169,7 +174,8 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     DISPATCH_GPDT(D, hipLaunchKernelGGL((k_gp_build<DT>), dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D,
                                         Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(), dsn2.as<double>(), dscal.as<double>(),
                                         dact.as<unsigned char>(), dA.as<double>()));
-    hipLaunchKernelGGL(k_chol, dim3(S), dim3(CH_THREADS), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>());
+    hipLaunchKernelGGL(k_chol, dim3(S), dim3(CH_THREADS), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>(),
+                       chol_gpanel ? dPg.as<double>() : nullptr);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(pf.data(), dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -193,12 +199,8 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   const int moff = Ncov + Nnoise;
   hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
                      dhyp.as<double>(), dr.as<double>());
-  const size_t tlds = TRSM_LDS_BYTES(N);
-  f.tlds = tlds;
-  if (tlds > 64 * 1024) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-  }
+  f.cw = trsm_cw_for(N);
+  f.tlds = TRSM_LDS_BYTES_CW(N, f.cw);
   TmpBuf &dal = f.dal, &dfinv = f.dfinv;
   HIP_TRY(ctx, dal.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
@@ -330,10 +332,7 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
     TmpBuf dTT;
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
     HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
-    if (f.tlds > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.tlds));
-    hipLaunchKernelGGL(k_tri_inverse, dim3((N + TR_CB - 1) / TR_CB, B, 1), dim3(64), f.tlds, st, N, B, f.dA.as<double>(), f.dfinv.as<double>(),
-                       f.dones.as<unsigned char>(), dTT.as<double>(), 1);
+    HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
     hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
                        dKi.as<double>());
     std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
@@ -392,18 +391,16 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   const int N = gp->N, D = gp->D, S = gp->S;
   if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
   const int Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
-  const size_t tlds0 = TRSM_LDS_BYTES(N);
-  if ((size_t)16 * Np * 8 > PRED_LDS_MAX || nblk > PRED_MAXG || tlds0 > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the fused prediction kernel", N);
+  // beyond N = 1248 a 16-row tile of inv(L') no longer fits the LDS: the variance then comes from slab solves (k_pred_slab)
+  const bool slab_pred = (size_t)16 * Np * 8 > PRED_LDS_MAX || nblk > PRED_MAXG || trsm_cw_for(N) != 16;
+  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the prediction kernels", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  if (!gp->d_tinv) {
+  if (!gp->d_tinv && !slab_pred) {
     // Tinv = inv(L') = L' \ I for the Lchol samples, once per GP (the kernels skip the others)
     double* t = nullptr;
     HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)S * N * N * 8, (void**)&t) : hipMalloc((void**)&t, (size_t)S * N * N * 8));
-    if (tlds0 > 64 * 1024)
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_tri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds0));
-    hipLaunchKernelGGL(k_tri_inverse, dim3((N + TR_CB - 1) / TR_CB, S, 1), dim3(64), tlds0, st, N, S, gp->L, gp->d_finv, gp->d_lchol, t, 0);
-    hipError_t e_ = hipGetLastError();
+    hipError_t e_ = tri_inverse_launch(st, N, S, gp->L, gp->d_finv, gp->d_lchol, t, 0);
     if (e_ != hipSuccess) {
       if (gp->pooled) pool_put(ctx, t); else (void)hipFree(t);
       return set_err(ctx, VBMC_ERR_HIP, "inv(L') failed: %s", hipGetErrorString(e_));
@@ -451,7 +448,9 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   size_t maxlds = 0;
   for (int s = 0; s < S; ++s) {
     int ng = 0;
-    if (gp->Lchol[s]) {
+    if (slab_pred) {
+      ng = 1;                                  // k_pred_slab writes block partial 0
+    } else if (gp->Lchol[s]) {
       int t0 = 0;
       for (int b = 0; b < nblk; ++b) {
         const int R = b - t0 + 1;
@@ -485,9 +484,18 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
                                                   daa.as<double>(), dmuv.as<double>(), pb.dKs.as<double>(), pb.dpF.as<double>()); break;
   switch ((D + 3) / 4) { PRED_KS(1) PRED_KS(2) PRED_KS(3) PRED_KS(4) PRED_KS(5) PRED_KS(6) PRED_KS(7) PRED_KS(8) default: break; }
 #undef PRED_KS
-  if (maxlds > 64 * 1024)
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxlds));
-  hipLaunchKernelGGL(k_gp_pred, dim3(maxg, S, PZ), dim3(PRED_THREADS), maxlds, st, pa, pb.dKs.as<double>(), pb.dgrp.as<int>(), pb.dpV.as<double>());
+  if (slab_pred) {
+    TRSM_DISPATCH_CW(trsm_cw_for(N), {
+      const size_t sl = TRSM_LDS_BYTES_CW(N, CW);
+      if (sl > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pred_slab<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl));
+      hipLaunchKernelGGL((k_pred_slab<CW>), dim3((Nstar + CW - 1) / CW, S), dim3(64), sl, st, pa, pb.dKs.as<double>(), pb.dpV.as<double>());
+    });
+  } else {
+    if (maxlds > 64 * 1024)
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_gp_pred, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxlds));
+    hipLaunchKernelGGL(k_gp_pred, dim3(maxg, S, PZ), dim3(PRED_THREADS), maxlds, st, pa, pb.dKs.as<double>(), pb.dgrp.as<int>(), pb.dpV.as<double>());
+  }
   hipLaunchKernelGGL(k_pred_final, dim3((Nstar + 255) / 256, S), dim3(256), 0, st, pa, pb.dgrp.as<int>(), pb.dpV.as<double>(), pb.dpF.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;
@@ -670,8 +678,7 @@ extern "C" vbmc_status vbmc_acq_is_create(vbmc_ctx* ctx, const vbmc_gp* gp, int 
   const int N = gp->N, D = gp->D, S = gp->S;
   const int Nap = ((Na + 15) / 16) * 16;
   if (Nap > 16 * 16) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "Na = %d > 256 importance points not accelerated", Na);
-  const size_t tlds = TRSM_LDS_BYTES(N);
-  if (tlds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
+  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   vbmc_acq_is* h = new vbmc_acq_is();
@@ -721,14 +728,9 @@ extern "C" vbmc_status vbmc_acq_is_create(vbmc_ctx* ctx, const vbmc_gp* gp, int 
     IS_TRY(hipStreamSynchronize(st));
   } else {
     hipLaunchKernelGGL(k_cross_kernel, dim3(64, S), dim3(256), 0, st, N, D, gp->Nhyp, Na, h->per_s, gp->X, h->Xa, gp->hyp, dZ.as<double>());
-    if (tlds > 64 * 1024) {
-      IS_TRY(hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-      IS_TRY(hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-    }
     hipLaunchKernelGGL(k_symm, dim3(64, S, 1), dim3(256), 0, st, N, Na, S, gp->L, gp->d_lchol, dZ.as<double>(), dU.as<double>());
-    dim3 tg((Na + TR_CB - 1) / TR_CB, S, 1);
-    hipLaunchKernelGGL(k_trsm_fwd, tg, dim3(64), tlds, st, N, Na, S, gp->L, gp->d_finv, gp->d_lchol, dZ.as<double>());
-    hipLaunchKernelGGL(k_trsm_bwd, tg, dim3(64), tlds, st, N, Na, S, gp->L, gp->d_finv, gp->d_lchol, dZ.as<double>(), dU.as<double>());
+    IS_TRY(trsm_fwd_launch(st, N, Na, S, 1, gp->L, gp->d_finv, gp->d_lchol, dZ.as<double>()));
+    IS_TRY(trsm_bwd_launch(st, N, Na, S, 1, gp->L, gp->d_finv, gp->d_lchol, dZ.as<double>(), dU.as<double>()));
     hipLaunchKernelGGL(k_ctmp_pack, dim3(64, S), dim3(256), 0, st, N, Na, Nap, dU.as<double>(), gp->d_sn2, gp->d_lchol, h->CT);
     IS_TRY(hipGetLastError());
     IS_TRY(hipStreamSynchronize(st));
@@ -821,8 +823,7 @@ namespace {
 // -inv(K + sn2 I) instead of a factor, x = L Ks (k_symm) and v is unused.
 vbmc_status rank1_solves_dev(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, TmpBuf& dKs, TmpBuf& dV, TmpBuf& dXo) {
   const int N = gp->N, D = gp->D, S = gp->S;
-  const size_t tlds = TRSM_LDS_BYTES(N);
-  if (tlds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
+  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   TmpBuf dxs;
@@ -833,14 +834,10 @@ vbmc_status rank1_solves_dev(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xst
   HIP_TRY(ctx, hipMemcpyAsync(dxs.p, xstar, (size_t)D * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_gp_ks, dim3(4, S), dim3(256), 0, st, N, D, gp->Nhyp, gp->X, dxs.as<double>(), gp->hyp, gp->d_meanX, dKs.as<double>());
   HIP_TRY(ctx, hipMemcpyAsync(dV.p, dKs.p, (size_t)S * N * 8, hipMemcpyDeviceToDevice, st));
-  if (tlds > 64 * 1024) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_trsm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
-  }
   // Lchol samples: triangular solves; the others (flag 0) are skipped by the kernels and handled by k_symm
   hipLaunchKernelGGL(k_symm, dim3(8, S, 1), dim3(256), 0, st, N, 1, S, gp->L, gp->d_lchol, dKs.as<double>(), dXo.as<double>());
-  hipLaunchKernelGGL(k_trsm_fwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, gp->L, gp->d_finv, gp->d_lchol, dV.as<double>());
-  hipLaunchKernelGGL(k_trsm_bwd, dim3(1, S, 1), dim3(64), tlds, st, N, 1, S, gp->L, gp->d_finv, gp->d_lchol, dV.as<double>(), dXo.as<double>());
+  HIP_TRY(ctx, trsm_fwd_launch(st, N, 1, S, 1, gp->L, gp->d_finv, gp->d_lchol, dV.as<double>()));
+  HIP_TRY(ctx, trsm_bwd_launch(st, N, 1, S, 1, gp->L, gp->d_finv, gp->d_lchol, dV.as<double>(), dXo.as<double>()));
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;
 }
@@ -871,7 +868,7 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
   *out = nullptr;
   if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_rank1_update needs gp.post(s).L on the device");
   const int N = gp->N, D = gp->D, S = gp->S, N1 = N + 1;
-  if (TRSM_LDS_BYTES(N1) > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N1);
+  if (trsm_cw_for(N1) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N1);
   std::vector<double> xs(D);
   for (int d = 0; d < D; ++d) xs[d] = X_new[(size_t)N + (size_t)N1 * d];   // the appended row of the (N+1) x D matrix
   TmpBuf dKs, dV, dXo, dsc, dLn, dan;

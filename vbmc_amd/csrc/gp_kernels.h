@@ -229,8 +229,10 @@ __device__ __forceinline__ void chol_diag_tile(double* __restrict__ Dg, double* 
 //                 (4 x v_mfma_f64_16x16x4 per 16 x 16 tile, upper triangle of tiles only),
 //   wave 0        LOOK-AHEAD: updates the next diagonal tile first and factors it (in LDS, wave-synchronous) while the
 //                 other waves are still updating -- the 16 sequential pivot steps leave the critical path.
+// Pg: null, or S x 16 x Np doubles of global scratch that hold the panel rows when they no longer fit the LDS (N > 1232):
+// same layout, same code, the workgroup barriers order the accesses; the panel is then read through the L2.
 __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__ Aall, int* __restrict__ pfail,
-                                                     const unsigned char* __restrict__ active) {
+                                                     const unsigned char* __restrict__ active, double* __restrict__ Pg) {
   extern __shared__ double lds[];
   const int s = blockIdx.x;
   if (!active[s]) return;
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
   const int Np = ((N + 15) >> 4) << 4;
   double* A = Aall + (size_t)s * N * N;
   double* DgB = lds;                // two 16 x 17 diagonal tiles: this step's and the next one's
-  double* P = DgB + 2 * 16 * 17;    // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
+  double* P = Pg ? Pg + (size_t)s * 16 * Np : DgB + 2 * 16 * 17;    // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
   __shared__ int s_fail;
   __shared__ double DiB[2][16];     // 1 / R[kb+t][kb+t]
   if (tid == 0) s_fail = 0;
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__
       while (c * (c + 1) / 2 > u) --c;
       tj = c; ti = u - c * (c + 1) / 2;
     };
-    double* At = A + (size_t)t0 + (size_t)N * t0;     // trailing matrix; 32-bit offsets inside it (N <= 1136)
+    double* At = A + (size_t)t0 + (size_t)N * t0;     // trailing matrix; 32-bit offsets inside it (N <= 3872)
     auto load_tile = [&](int ti_, int tj_, double* dst) {
       const int i = (ti_ << 4) + li, jb = (tj_ << 4) + lg;
       const int off = jb * N + i;
@@ -750,6 +752,50 @@ __global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const d
     part += __shfl_xor(part, 16, 64);
     part += __shfl_xor(part, 32, 64);
     if (lg == 0 && cv) partV[((size_t)g * a.S + s) * a.Nstar + jc] = part;
+  }
+}
+
+// k_pred_slab: the large-N form of the prediction variance (N beyond what k_gp_pred keeps resident: a 16-row tile of the
+// triangular inverse no longer fits the LDS).  One wave per CW test points: their sW-scaled cross-kernel columns form a slab
+// in LDS, V = L' \ (sW .* Ks) by the blocked substitution of trsm_mfma.h (gplite_pred.m:99), sum(V.^2) per point (:100);
+// low-noise samples (L = -inv(K + sn2 I)) accumulate Ks .* (L * Ks) (:103-104) with lanes along the rows.  Writes block
+// partial 0 (k_pred_final is told there is one block per hyper-sample).
+template <int CW>
+__global__ void __launch_bounds__(64) k_pred_slab(PredArgs a, const double* __restrict__ KsW, double* __restrict__ partV) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  const int N = a.N, Np = ((N + 15) >> 4) << 4;
+  const int ntile = (a.Nstar + 15) >> 4;
+  const int j0 = cb * CW;                       // first test point of the slab
+  double* V = lds;
+  double* P = V + (size_t)Np * (CW + 1);
+  const double* ksw = KsW + (size_t)s * ntile * N * 16;   // [point tile][n][16]
+  for (int c = 0; c < CW; ++c) {
+    const int j = j0 + c;
+    const double* col = ksw + (size_t)(j >> 4) * N * 16 + (j & 15);
+    for (int i = lane; i < Np; i += 64) V[i * (CW + 1) + c] = (j < a.Nstar && i < N) ? col[(size_t)i * 16] : 0.0;
+  }
+  trsm_wsync();
+  if (a.lchol[s]) {
+    trsm_fwd_wave<CW>(N, a.L + (size_t)s * N * N, a.finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane);
+    for (int c = 0; c < CW; ++c) {
+      double part = 0.0;
+      for (int i = lane; i < N; i += 64) { const double v = V[i * (CW + 1) + c]; part = fma(v, v, part); }
+      part = wave_sum(part);
+      if (lane == 0 && j0 + c < a.Nstar) partV[(size_t)s * a.Nstar + j0 + c] = part;
+    }
+  } else {
+    const double* Lm = a.L + (size_t)s * N * N;    // symmetric: element (i, j) at j * N + i
+    for (int c = 0; c < CW; ++c) {
+      double part = 0.0;
+      for (int i = lane; i < N; i += 64) {
+        double acc = 0.0;
+        for (int j = 0; j < N; ++j) acc = fma(Lm[(size_t)j * N + i], V[j * (CW + 1) + c], acc);
+        part = fma(V[i * (CW + 1) + c], acc, part);
+      }
+      part = wave_sum(part);
+      if (lane == 0 && j0 + c < a.Nstar) partV[(size_t)s * a.Nstar + j0 + c] = part;
+    }
   }
 }
 

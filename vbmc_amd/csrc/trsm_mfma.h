@@ -14,7 +14,19 @@
 #include <hip/hip_runtime.h>
 
 typedef double tmf4 __attribute__((ext_vector_type(4)));
-#define TR_VS 17  // LDS row stride of the right-hand-side slab (16 columns + 1 pad: conflict-free column fills)
+#define TR_VS 17  // LDS row stride of the 16-column right-hand-side slab and of the panel buffer (16 columns + 1 pad)
+// Narrow slabs for large N: the slab of a wave holds CW = 16, 8 or 4 right-hand sides (row stride CW + 1), the MFMAs still
+// run 16 columns wide with zeros beyond CW.  16 columns fit the 160 KB of LDS up to N = 1136, 8 up to N = 2144, 4 up to
+// N = 3872 (VBMC's default MaxFunEvals = 50 (2 + D) reaches N = 1700 at D = 32): a fallback that trades matrix-core
+// utilisation for range, chosen per call by trsm_cw_for(N).
+template <int CW>
+__device__ __forceinline__ double trsm_vld(const double* __restrict__ V, int row, int li) {
+  return (CW == 16 || li < CW) ? V[row * (CW + 1) + (CW == 16 ? li : (li < CW ? li : 0))] : 0.0;
+}
+template <int CW>
+__device__ __forceinline__ void trsm_vst(double* __restrict__ V, int row, int li, double x) {
+  if (CW == 16 || li < CW) V[row * (CW + 1) + li] = x;
+}
 
 // k_diag_inv: Finv[s][b] = (R_bb')^{-1} for every 16 x 16 diagonal block of the upper factor (identity rows beyond
 // N), row-major 16 x 16.  The blocked solves apply it with four MFMAs instead of a 16-step substitution chain;
@@ -60,6 +72,7 @@ __device__ __forceinline__ void trsm_wsync() {
 // forward substitution R' V = Z for the slab in LDS (in place)
 // bi_start > 0: the slab is known to be zero above row 16 * bi_start (columns of the identity), so is the solution:
 // the substitution starts there and the trailing updates skip the zero rows.
+template <int CW = 16>
 __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ Rm, const double* __restrict__ Finv,
                                               double* __restrict__ V, double* __restrict__ P, int lane, int bi_start = 0) {
   const int li = lane & 15, lg = lane >> 4;
@@ -92,7 +105,7 @@ __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           pa[u] = P[(jj + 4 * u + lg) * TR_VS + li];
-          pb[u] = V[(j0 + jj + 4 * u + lg) * TR_VS + li];
+          pb[u] = trsm_vld<CW>(V, j0 + jj + 4 * u + lg, li);
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[1], pb[1], acc2, 0, 0, 0);
@@ -103,21 +116,22 @@ __device__ __forceinline__ void trsm_fwd_wave(int N, const double* __restrict__ 
     acc += acc2;
     // v_b = (R_bb')^{-1} (z_b - update): rhs through LDS into the B-operand layout, four MFMAs with Finv
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] -= acc[r];
+    for (int r = 0; r < 4; ++r) trsm_vst<CW>(V, b0 + lg + 4 * r, li, trsm_vld<CW>(V, b0 + lg + 4 * r, li) - acc[r]);
     trsm_wsync();
     tmf4 vb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], V[(b0 + 4 * u + lg) * TR_VS + li], vb, 0, 0, 0);
+      vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], trsm_vld<CW>(V, b0 + 4 * u + lg, li), vb, 0, 0, 0);
     trsm_wsync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = vb[r];
+    for (int r = 0; r < 4; ++r) trsm_vst<CW>(V, b0 + lg + 4 * r, li, vb[r]);
     trsm_wsync();
   }
 }
 
 // backward substitution R X = V for the slab in LDS (in place)
 // bi_stop > 0: only the rows from 16 * bi_stop down are wanted (the lower triangle of a symmetric solution)
+template <int CW = 16>
 __device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ Rm, const double* __restrict__ Finv,
                                               double* __restrict__ V, int lane, int bi_stop = 0) {
   const int li = lane & 15, lg = lane >> 4;
@@ -141,22 +155,22 @@ __device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ 
       }
 #pragma unroll
       for (int u = 0; u < 8; u += 2) {
-        if (j0 + 4 * u < Np) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], V[(j0 + 4 * u + lg) * TR_VS + li], acc, 0, 0, 0);
-        if (j0 + 4 * (u + 1) < Np) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], V[(j0 + 4 * (u + 1) + lg) * TR_VS + li], acc2, 0, 0, 0);
+        if (j0 + 4 * u < Np) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], trsm_vld<CW>(V, j0 + 4 * u + lg, li), acc, 0, 0, 0);
+        if (j0 + 4 * (u + 1) < Np) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], trsm_vld<CW>(V, j0 + 4 * (u + 1) + lg, li), acc2, 0, 0, 0);
       }
     }
     acc += acc2;
     // x_b = R_bb^{-1} (v_b - update) = Finv_b' * rhs
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] -= acc[r];
+    for (int r = 0; r < 4; ++r) trsm_vst<CW>(V, b0 + lg + 4 * r, li, trsm_vld<CW>(V, b0 + lg + 4 * r, li) - acc[r]);
     trsm_wsync();
     tmf4 xb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], V[(b0 + 4 * u + lg) * TR_VS + li], xb, 0, 0, 0);
+      xb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], trsm_vld<CW>(V, b0 + 4 * u + lg, li), xb, 0, 0, 0);
     trsm_wsync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) V[(b0 + lg + 4 * r) * TR_VS + li] = xb[r];
+    for (int r = 0; r < 4; ++r) trsm_vst<CW>(V, b0 + lg + 4 * r, li, xb[r]);
     trsm_wsync();
   }
 }
@@ -165,23 +179,40 @@ __device__ __forceinline__ void trsm_bwd_wave(int N, const double* __restrict__ 
 // Standalone kernels: Z is laid out [r][s][k][N] (column k of the right-hand sides contiguous);
 // one wave per (16 columns, hyper-sample s, restart r).  lchol[s] == 0 samples are skipped.
 // ------------------------------------------------------------------------------------------
+template <int CW = 16>
 __device__ __forceinline__ void trsm_slab_load(int N, int K, int k0, const double* __restrict__ Zs, double* __restrict__ V, int lane) {
   const int Np = ((N + 15) >> 4) << 4;
-  for (int c = 0; c < 16; ++c) {
+  for (int c = 0; c < CW; ++c) {
     const bool cv = k0 + c < K;
-    for (int i = lane; i < Np; i += 64) V[i * TR_VS + c] = (cv && i < N) ? Zs[(size_t)(k0 + c) * N + i] : 0.0;
+    for (int i = lane; i < Np; i += 64) V[i * (CW + 1) + c] = (cv && i < N) ? Zs[(size_t)(k0 + c) * N + i] : 0.0;
   }
   __syncthreads();
 }
+template <int CW = 16>
 __device__ __forceinline__ void trsm_slab_store(int N, int K, int k0, double* __restrict__ Zs, const double* __restrict__ V, int lane) {
-  for (int c = 0; c < 16; ++c) {
+  for (int c = 0; c < CW; ++c) {
     if (k0 + c >= K) break;
-    for (int i = lane; i < N; i += 64) Zs[(size_t)(k0 + c) * N + i] = V[i * TR_VS + c];
+    for (int i = lane; i < N; i += 64) Zs[(size_t)(k0 + c) * N + i] = V[i * (CW + 1) + c];
   }
 }
-#define TRSM_LDS_BYTES(N) ((size_t)(((((N) + 15) >> 4) << 4) * TR_VS + 64 * TR_VS) * sizeof(double))
+#define TRSM_LDS_BYTES_CW(N, CW) ((size_t)(((((N) + 15) >> 4) << 4) * ((CW) + 1) + 64 * TR_VS) * sizeof(double))
+#define TRSM_LDS_BYTES(N) TRSM_LDS_BYTES_CW(N, 16)
 #define TRSM_NBLK(N) (((N) + 15) >> 4)
+// slab width for a problem of N rows: the widest that fits the 160 KB of LDS (0: none does)
+static inline int trsm_cw_for(int N) {
+  if (TRSM_LDS_BYTES_CW(N, 16) <= 160 * 1024) return 16;
+  if (TRSM_LDS_BYTES_CW(N, 8) <= 160 * 1024) return 8;
+  if (TRSM_LDS_BYTES_CW(N, 4) <= 160 * 1024) return 4;
+  return 0;
+}
+#define TRSM_DISPATCH_CW(cwv_, ...)                                 \
+  switch (cwv_) {                                                   \
+    case 16: { constexpr int CW = 16; __VA_ARGS__; } break;         \
+    case 8: { constexpr int CW = 8; __VA_ARGS__; } break;           \
+    default: { constexpr int CW = 4; __VA_ARGS__; } break;          \
+  }
 
+template <int CW>
 __global__ void __launch_bounds__(64) k_trsm_fwd(int N, int K, int S, const double* __restrict__ Lall,
                                                  const double* __restrict__ Finv, const unsigned char* __restrict__ lchol,
                                                  double* __restrict__ Z) {
@@ -190,13 +221,14 @@ __global__ void __launch_bounds__(64) k_trsm_fwd(int N, int K, int S, const doub
   if (!lchol[s]) return;
   const int Np = ((N + 15) >> 4) << 4;
   double* V = lds;
-  double* P = V + (size_t)Np * TR_VS;
+  double* P = V + (size_t)Np * (CW + 1);
   double* Zs = Z + ((size_t)r * S + s) * (size_t)K * N;
-  trsm_slab_load(N, K, cb * 16, Zs, V, lane);
-  trsm_fwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane);
-  trsm_slab_store(N, K, cb * 16, Zs, V, lane);
+  trsm_slab_load<CW>(N, K, cb * CW, Zs, V, lane);
+  trsm_fwd_wave<CW>(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane);
+  trsm_slab_store<CW>(N, K, cb * CW, Zs, V, lane);
 }
 
+template <int CW>
 __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const double* __restrict__ Lall,
                                                  const double* __restrict__ Finv, const unsigned char* __restrict__ lchol,
                                                  const double* __restrict__ Vin, double* __restrict__ Xo) {
@@ -205,11 +237,40 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
   if (!lchol[s]) return;
   const int Np = ((N + 15) >> 4) << 4;
   double* V = lds;
-  trsm_slab_load(N, K, cb * 16, Vin + ((size_t)r * S + s) * (size_t)K * N, V, lane);
-  trsm_bwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, lane);
-  trsm_slab_store(N, K, cb * 16, Xo + ((size_t)r * S + s) * (size_t)K * N, V, lane);
+  trsm_slab_load<CW>(N, K, cb * CW, Vin + ((size_t)r * S + s) * (size_t)K * N, V, lane);
+  trsm_bwd_wave<CW>(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, lane);
+  trsm_slab_store<CW>(N, K, cb * CW, Xo + ((size_t)r * S + s) * (size_t)K * N, V, lane);
 }
 
+// host side: the slab solves with the slab width that fits N (one wave per CW columns, hyper-sample s, restart r)
+static inline hipError_t trsm_fwd_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
+                                         const unsigned char* lchol, double* Z) {
+  const int cw = trsm_cw_for(N);
+  if (cw == 0) return hipErrorInvalidValue;
+  TRSM_DISPATCH_CW(cw, {
+    const size_t lds = TRSM_LDS_BYTES_CW(N, CW);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_trsm_fwd<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_trsm_fwd<CW>), dim3((K + CW - 1) / CW, S, R), dim3(64), lds, st, N, K, S, Lall, Finv, lchol, Z);
+  });
+  return hipGetLastError();
+}
+static inline hipError_t trsm_bwd_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
+                                         const unsigned char* lchol, const double* Vin, double* Xo) {
+  const int cw = trsm_cw_for(N);
+  if (cw == 0) return hipErrorInvalidValue;
+  TRSM_DISPATCH_CW(cw, {
+    const size_t lds = TRSM_LDS_BYTES_CW(N, CW);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_trsm_bwd<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_trsm_bwd<CW>), dim3((K + CW - 1) / CW, S, R), dim3(64), lds, st, N, K, S, Lall, Finv, lchol, Vin, Xo);
+  });
+  return hipGetLastError();
+}
 // k_spd_inverse: X = R^{-1} R^{-T} = inv(R'R) for the factors flagged in `on`, one wave per 16 columns of the identity:
 // forward substitution from the column block's own rows (the slab is zero above them), backward substitution down to
 // the same rows, i.e. the block column of the LOWER triangle, written together with its mirror image.  A third of the
@@ -219,27 +280,44 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
 // T = inv(R') = R' \ I (lower triangular), one wave per 16 columns: the identity slab is formed in LDS and the substitution
 // starts at the column block's own rows (everything above is zero and is written as such).
 // transposed != 0 writes T' instead (row k of inv(R') contiguous: the operand layout k_syrk_tt wants).
+template <int CW>
 __global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                     const unsigned char* __restrict__ lchol, double* __restrict__ T, int transposed) {
   extern __shared__ double lds[];
   const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
   if (!lchol[s]) return;
-  const int Np = ((N + 15) >> 4) << 4, k0 = cb << 4;
+  const int Np = ((N + 15) >> 4) << 4, k0 = cb * CW;
   double* V = lds;
-  double* P = V + (size_t)Np * TR_VS;
-  for (int c = 0; c < 16; ++c)
-    for (int i = lane; i < Np; i += 64) V[i * TR_VS + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
+  double* P = V + (size_t)Np * (CW + 1);
+  for (int c = 0; c < CW; ++c)
+    for (int i = lane; i < Np; i += 64) V[i * (CW + 1) + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
   trsm_wsync();
-  trsm_fwd_wave(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane, cb);
+  trsm_fwd_wave<CW>(N, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, V, P, lane, k0 >> 4);
   if (!transposed) {
-    trsm_slab_store(N, N, k0, T + (size_t)s * N * N, V, lane);
+    trsm_slab_store<CW>(N, N, k0, T + (size_t)s * N * N, V, lane);
   } else {
-    // TT[k][i] = T[k][i] at k * N + i: 4 rows x 16 consecutive columns per store; rows above the block are zero
+    // TT[k][i] = T[k][i] at k * N + i: 64 / CW rows x CW consecutive columns per store; rows above the block are zero
     double* TT = T + (size_t)s * N * N;
-    const int cc = lane & 15;
+    const int cc = lane % CW;
     if (k0 + cc < N)
-      for (int k = lane >> 4; k < N; k += 4) TT[(size_t)k * N + k0 + cc] = V[k * TR_VS + cc];
+      for (int k = lane / CW; k < N; k += 64 / CW) TT[(size_t)k * N + k0 + cc] = V[k * (CW + 1) + cc];
   }
+}
+
+// T = inv(R') (transposed != 0: its transpose), see k_tri_inverse
+static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const double* Lall, const double* Finv,
+                                            const unsigned char* lchol, double* T, int transposed) {
+  const int cw = trsm_cw_for(N);
+  if (cw == 0) return hipErrorInvalidValue;
+  TRSM_DISPATCH_CW(cw, {
+    const size_t lds = TRSM_LDS_BYTES_CW(N, CW);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_tri_inverse<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_tri_inverse<CW>), dim3((N + CW - 1) / CW, S, 1), dim3(64), lds, st, N, S, Lall, Finv, lchol, T, transposed);
+  });
+  return hipGetLastError();
 }
 
 // C = T'T for lower-triangular T given as TT[k][i] (row k contiguous): the 64 x 64 tiles on and above the diagonal (column j,
@@ -325,8 +403,8 @@ __global__ void __launch_bounds__(128) k_spd_inverse(int N, const double* __rest
   trsm_wsync();
   const double* Rm = Lall + (size_t)s * N * N;
   const double* Fi = Finv + (size_t)s * TRSM_NBLK(N) * 256;
-  trsm_fwd_wave(N, Rm, Fi, V, P, lane, cb);
-  trsm_bwd_wave(N, Rm, Fi, V, lane, cb);
+  trsm_fwd_wave<16>(N, Rm, Fi, V, P, lane, cb);
+  trsm_bwd_wave<16>(N, Rm, Fi, V, lane, cb);
   double* X = Xo + (size_t)s * N * N;
   // columns of the block: rows from the block's own first row down (the diagonal block as computed, both halves)
   for (int c = 0; c < 16; ++c) {
@@ -340,9 +418,48 @@ __global__ void __launch_bounds__(128) k_spd_inverse(int N, const double* __rest
     for (int i = k0 + 16 + (lane >> 4); i < N; i += 4) X[(size_t)(k0 + cc) + (size_t)i * N] = V[i * TR_VS + cc];
 }
 
-// host side: pick the paired launch when its LDS fits, else one column block per workgroup
+// Narrow-slab variant for N beyond the 16-column slab (see trsm_vld): one wave per CW columns of the identity, full-height slab.
+// Element (i, j) of the symmetric inverse with i >= j is written by the slab of column j, together with its mirror image.
+template <int CW>
+__global__ void __launch_bounds__(64) k_spd_inverse_narrow(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                           const unsigned char* __restrict__ on, double* __restrict__ Xo) {
+  extern __shared__ double lds[];
+  const int cb = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  if (!on[s]) return;
+  const int Np = ((N + 15) >> 4) << 4, k0 = cb * CW, bi0 = k0 >> 4;
+  double* V = lds;
+  double* P = V + (size_t)Np * (CW + 1);
+  for (int c = 0; c < CW; ++c)
+    for (int i = lane; i < Np; i += 64) V[i * (CW + 1) + c] = (i == k0 + c && i < N) ? 1.0 : 0.0;
+  trsm_wsync();
+  const double* Rm = Lall + (size_t)s * N * N;
+  const double* Fi = Finv + (size_t)s * TRSM_NBLK(N) * 256;
+  trsm_fwd_wave<CW>(N, Rm, Fi, V, P, lane, bi0);
+  trsm_bwd_wave<CW>(N, Rm, Fi, V, lane, bi0);
+  double* X = Xo + (size_t)s * N * N;
+  for (int c = 0; c < CW; ++c) {
+    const int j = k0 + c;
+    if (j >= N) break;
+    for (int i = j + lane; i < N; i += 64) {
+      const double v = V[i * (CW + 1) + c];
+      X[(size_t)j * N + i] = v;
+      if (i > j) X[(size_t)i * N + j] = v;
+    }
+  }
+}
+
+// host side: pick the paired launch when its LDS fits, else one column block per workgroup; narrow slabs beyond N = 1136
 #define SPD_INVERSE_LAUNCH(ctx_, N_, S_, st_, Lall_, Finv_, on_, Xo_)                                                         \
   do {                                                                                                                        \
+    const int cwv_ = trsm_cw_for(N_);                                                                                         \
+    if (cwv_ != 16) {                                                                                                         \
+      TRSM_DISPATCH_CW(cwv_, {                                                                                                \
+        const size_t nl_ = TRSM_LDS_BYTES_CW(N_, CW);                                                                         \
+        HIP_TRY(ctx_, hipFuncSetAttribute((const void*)k_spd_inverse_narrow<CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nl_)); \
+        hipLaunchKernelGGL((k_spd_inverse_narrow<CW>), dim3(((N_) + CW - 1) / CW, S_), dim3(64), nl_, st_, N_, Lall_, Finv_, on_, Xo_); \
+      });                                                                                                                     \
+      break;                                                                                                                  \
+    }                                                                                                                         \
     const bool pair_ = SPDINV_LDS_BYTES(N_) <= 160 * 1024;                                                                    \
     const size_t il_ = pair_ ? SPDINV_LDS_BYTES(N_) : TRSM_LDS_BYTES(N_);                                                     \
     if (il_ > 64 * 1024)                                                                                                      \
