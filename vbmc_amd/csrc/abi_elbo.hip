@@ -348,7 +348,7 @@ struct ElboPlan {
 };
 
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
-#define VAR_FINAL_LDS(S_, K_, Tg_) ((256 + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
+#define VAR_FINAL_LDS(S_, K_, Tg_) ((VARFIN_THREADS + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
 static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
@@ -750,7 +750,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     const size_t vlds = VAR_FINAL_LDS(S, K, P.compute_grad ? T : 0);
     if (vlds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
-    hipLaunchKernelGGL(k_var_final, dim3(R), dim3(256), vlds, st, va);
+    hipLaunchKernelGGL(k_var_final, dim3(R), dim3(VARFIN_THREADS), vlds, st, va);
     LAUNCH_CHECK(ctx, "k_var_final");
   }
 
