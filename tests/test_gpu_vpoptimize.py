@@ -74,3 +74,22 @@ def test_elcbo_weighted_path_runs_cmaes_on_batched_values(va):
     s = vp2["stats"]
     assert np.isfinite(s["elbo"]) and s["elbo_sd"] > 0
     assert -(s["elbo"]) + 0.7 * s["elbo_sd"] < np.min(out[6]) + 0.5   # soft bounds / MC noise differ between the two evaluations
+
+
+def test_deterministic_entropy_branch_runs_a_quasi_newton_optimiser(va):
+    """NSentK = 0 (EntropySwitch, misc/vpsieve_vbmc.m:30-33): the reference calls fminunc (misc/vpoptimize_vbmc.m:73-81);
+    SciPy's BFGS drives the same objective here.  The optimum is a stationary point of the deterministic-entropy objective
+    (checked with the ORACLE's gradient) and not worse than the best sieve candidate."""
+    p, gp, vp = vpopt_problem(seed=45, K=3, weights=(0.5, 0.3, 0.2))
+    opts = dict(OPTS, TolWeight=0.01)
+    trace = []
+    vp2, varss, pruned = va.vpoptimize_vbmc(9, 1, vp, gp, optimState={"EntropySwitch": True}, options=opts, rng=np.random.default_rng(4),
+                                            seed=2, trace=trace)
+    assert [t["kind"] for t in trace if t["kind"] == "bfgs"] == ["bfgs"]
+    _, tb = R.vpbounds(vp, gp, dict(R.VBMC_OPTIONS, **opts))
+    th, v2 = R.get_vptheta(vp2)
+    v2["eta"] = th[-v2["K"]:].copy()
+    r = R.negelcbo_vbmc(th, 0, v2, gp, 0, True, 0, thetabnd=tb)
+    assert np.max(np.abs(r["dF"])) < 5e-2 * max(1.0, abs(r["F"]))          # fminunc's own first-order tolerance scale
+    sieve = va.vpsieve_vbmc(9, 1, vp, gp, optimState={"EntropySwitch": True}, options=opts, rng=np.random.default_rng(4))
+    assert r["F"] <= np.min(sieve[6]) + 1e-6

@@ -475,8 +475,8 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
 
     Branches: NSentK > 0 with ELCBOWeight = 0 -> Adam (:108-135).  ELCBOWeight ~= 0 -> the reference has no gradient of the
     full variance and switches to CMA-ES on the value (:38-46,137-160): mirrored with cmaes_batched, each generation one
-    batched value-only pass with compute_var = 1.  NSentK = 0 (deterministic entropy) -> the reference calls fminunc from
-    MATLAB's Optimization Toolbox (:73-81), which is not restated: refused with NotImplementedError.
+    batched value-only pass with compute_var = 1.  NSentK = 0 (deterministic entropy: EntropySwitch or K = 1) -> the reference
+    calls fminunc from MATLAB's Optimization Toolbox (:73-81); SciPy's BFGS drives the same device objective here.
 
     Device-stream schedule (``seed`` = s; tests replay it through ``trace``): sieve s; Adam iteration it of chain group g
     (s << 20) + (1 << 16) + (g << 12) + it; eval_fullelcbo batch (s << 20) + (2 << 16); pruning evaluation number c
@@ -490,12 +490,17 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
     vp0_vec, vp0_type, elcbo_beta, compute_var, NSentK, _, _ = vpsieve_vbmc(Nfastopts, Nslowopts, vp, gp, optimState, options, K,
                                                                             rng=rng, seed=seed, engine=engine, shard=shard)
     vp, thetabnd = vpbounds(vp, gp, options, K)
-    if NSentK == 0:
-        raise NotImplementedError("vpoptimize_vbmc: the deterministic-entropy branch (NSentK = 0, misc/vpoptimize_vbmc.m:73-106) "
-                                  "drives fminunc from MATLAB's Optimization Toolbox and is not mirrored")
     gradient_available = not compute_var          # :38
     optimizer = str(options["StochasticOptimizer"]).lower() if gradient_available else "cmaes"   # :44
-    if optimizer not in ("adam", "cmaes"):
+    if NSentK == 0:
+        # deterministic entropy (EntropySwitch or K = 1, :73-106): the reference calls fminunc (MATLAB's Optimization Toolbox,
+        # quasi-Newton BFGS, TolFun = DetEntTolOpt, MaxFunEvals = 50 (D + 2)); here SciPy's BFGS stands in its place, one
+        # device evaluation (value + gradient, entlb_vbmc entropy) per objective call
+        if not gradient_available:
+            raise NotImplementedError("vpoptimize_vbmc: deterministic entropy with ELCBOWeight ~= 0 runs fminunc on finite differences "
+                                      "(misc/vpoptimize_vbmc.m:43-46,80): not mirrored")
+        optimizer = "bfgs"
+    if optimizer not in ("adam", "cmaes", "bfgs"):
         raise ValueError("vbmc:VPoptimize Unknown stochastic optimizer.")
     D = vp["D"]
     vp0_type = list(vp0_type)
@@ -519,7 +524,20 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
     # ---- optimisation
     thetaopt = [None] * Nslowopts
     theta_mid = [None] * Nslowopts
-    if optimizer == "adam":
+    if optimizer == "bfgs":
+        from scipy.optimize import minimize
+
+        for i, vp0 in enumerate(starts):
+            def fun(th, vp0=vp0):
+                r = negelcbo_batch(np.asarray(th, dtype=np.float64), elcbo_beta, vp0, gp, 0, True, 0, thetabnd, engine=engine, outputs=("F", "dF"))
+                return float(r["F"][0]), r["dF"][:, 0].copy()
+
+            res = minimize(fun, theta0s[i], jac=True, method="BFGS",
+                           options={"gtol": options["DetEntTolOpt"], "maxiter": 50 * (D + 2)})
+            thetaopt[i] = np.asarray(res.x, dtype=np.float64)
+            if trace is not None:
+                trace.append({"kind": "bfgs", "slot": i, "nfev": int(res.nfev), "fun": float(res.fun)})
+    elif optimizer == "adam":
         ms = {"min": min(options["SGDStepSize"], 0.001)}
         scaling = min(0.1, options["SGDStepSize"] * 10) if (optimState["Warmup"] or not vp["optimize_weights"]) else min(0.1, options["SGDStepSize"])
         ms["max"] = max(ms["min"], scaling)
