@@ -285,10 +285,28 @@ def main():
         elapsed = max(r[2] for r in rank_rows)   # MAX over ranks
     assert np.all(np.isfinite(out["F"])) and np.all(np.isfinite(out["dF"]))
 
-    # ---- roofline leg (rank 0): HIP-event duration of the dominant kernel, outside the timed region
+    # ---- everything below runs AFTER the timed region.  Each leg is guarded: a failing side measurement is recorded as
+    # {"error": ...} in its place and never suppresses the headline line.
     roof = None
     extra = {}
-    if rank == 0:
+    leg_errors = {}
+
+    def leg(name, fn):
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            leg_errors[name] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            try:
+                eng.ctx.set_profiling(False)
+            except Exception:  # noqa: BLE001
+                pass
+            return None
+
+    M = Ns + (Ns % 2)
+    aux_on = rank == 0 and world == 1 and not args.no_aux
+
+    def roofline_leg():
+        """HIP-event duration of the dominant kernel (rank 0)."""
         eng.ctx.set_profiling(True)
         ent_ms, lj_ms = [], []
         for i in range(5):
@@ -298,21 +316,20 @@ def main():
             lj_ms.append(b)
         eng.ctx.set_profiling(False)
         ent_ms, lj_ms = float(np.mean(ent_ms)), float(np.mean(lj_ms))
-        M = Ns + (Ns % 2)
         f_ent, f_lj, P = algorithmic_flops(D, K, M, S, N)
         achieved = Rr * f_ent / (ent_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass of THIS command
-        # (FETCH_SIZE / WRITE_SIZE need their own profiling run; collected and corrected as MI355X_MICROARCH.md prescribes)
-        # (hardware counters cannot be read from inside the run: they come from the committed rocprofv3 --pmc passes of this same
-        # command, stamped with the commit and a hash of the kernel sources they were taken at; a figure whose hash no longer
-        # matches the sources in this tree is reported as stale)
+        # HBM bytes per launch of the dominant kernel: hardware counters cannot be read from inside the run; they come from the
+        # committed rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+        # MI355X_MICROARCH.md prescribes), stamped with the commit and a hash of the kernel sources they were taken at; a figure
+        # whose hash no longer matches the sources in this tree is reported as stale
         traffic, traffic_src, traffic_stale = None, None, None
         here = os.path.dirname(os.path.abspath(__file__))
-        pmc_files = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith("_pmc.json")) if os.path.isdir(os.path.join(here, "profiles")) else []
-        if pmc_files and (D, N, K, S, Rr) == (10, 400, 50, 20, 64) and not args.eps_stream:
+        pdir = os.path.join(here, "profiles")
+        pmc_files = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc.json")) if os.path.isdir(pdir) else []
+        if pmc_files and (D, N, K, S, Rr) == (10, 400, 50, 20, 64):
             import hashlib
 
-            with open(os.path.join(here, "profiles", pmc_files[-1])) as f:
+            with open(os.path.join(pdir, pmc_files[-1])) as f:
                 pmc = json.load(f)
             hh = hashlib.sha256()
             for fn in ("entropy_mfma.h", "ent_mfma_inst.hip", "device_math.h", "elbo_types.h"):
@@ -320,7 +337,8 @@ def main():
             traffic = pmc["hbm_bytes_per_launch"]
             traffic_stale = pmc.get("kernel_source_sha256_16") != hh.hexdigest()[:16]
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s)" % (pmc_files[-1], pmc.get("commit", "?"))
-        roof = {"bound": "mfma", "kernel": "k_entropy_mfma<QS=%d,KT=%d,grad>" % ((D + 5) // 4, (K + 15) // 16), "achieved": achieved,
+        extra["logjoint_kernel_ms"] = lj_ms
+        return {"bound": "mfma", "kernel": "k_entropy_mfma<QS=%d,KT=%d,grad>" % ((D + 5) // 4, (K + 15) // 16), "achieved": achieved,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": Rr * 8 * (2 * (D * K + K + D + K) + 2),
@@ -330,94 +348,116 @@ def main():
                         "(SURVEY 8d) x R / kernel time; the P fp64 exp evaluations (9 fp64 ops each here) are NOT counted. "
                         "traffic: device-RNG mode reads no O(Ns) data from HBM; the bytes are per-chunk partial records "
                         "(written once, reduced by k_ent_reduce) and the packed mixture parameters"}
-        extra["logjoint_kernel_ms"] = lj_ms
-        # single-chain latency: the on-device Adam loop (vbmc_adam_batch) vs one host round trip per evaluation
-        aux_on = not args.no_aux and world == 1
-        for Rc in ((1, 2) if (args.extras or aux_on) else ()):
+
+    def adam_leg():
+        """single-chain latency: the on-device Adam loop (vbmc_adam_batch)"""
+        out_ = {}
+        for Rc in (1, 2):
             x0 = thetas[:, :Rc].copy()
             vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 40, seed=5, engine=eng)  # warm-up
             t1 = time.perf_counter()
             _, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 200, seed=6, engine=eng)
-            extra["device_adam_R%d_evals_per_s" % Rc] = float(np.sum(its)) / (time.perf_counter() - t1)
-        if args.extras:
-            # one host round trip per evaluation (what utils/fminadam.m does through the shim), arguments resolved once
-            obj1 = vbmc_amd.PreparedObjective(thetas.shape[0], 1, 0.0, vp, gp, Ns, 0, None, engine=eng)
-            for i in range(10):
-                obj1(thetas[:, :1], seed=800 + i)
-            t1 = time.perf_counter()
-            for i in range(200):
-                obj1(thetas[:, :1], seed=900 + i)
-            extra["host_loop_R1_evals_per_s"] = 200 / (time.perf_counter() - t1)
+            out_["device_adam_R%d_evals_per_s" % Rc] = float(np.sum(its)) / (time.perf_counter() - t1)
+        return out_
+
+    def extras_leg():
+        out_ = {}
+        # one host round trip per evaluation (what utils/fminadam.m does through the shim), arguments resolved once
+        obj1 = vbmc_amd.PreparedObjective(thetas.shape[0], 1, 0.0, vp, gp, Ns, 0, None, engine=eng)
+        for i in range(10):
+            obj1(thetas[:, :1], seed=800 + i)
+        t1 = time.perf_counter()
+        for i in range(200):
+            obj1(thetas[:, :1], seed=900 + i)
+        out_["host_loop_R1_evals_per_s"] = 200 / (time.perf_counter() - t1)
         # opt-in block-sparse mode (vbmc_elbo_args.sparse_cutoff = 100): same outputs to < 1e-13, component tiles whose
         # terms are < e^-100 of q(x) are skipped -- data dependent, NOT the headline value
-        for i in range(2 if args.extras else 0):
+        for i in range(2):
             sp = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=40 + i, engine=eng, sparse_cutoff=100.0)
-        if args.extras:
-            dn = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=41, engine=eng)
-            t1 = time.perf_counter()
-            for i in range(5):
-                vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=50 + i, engine=eng, sparse_cutoff=100.0)
-            extra["block_sparse"] = {"evals_per_s": 5 * Rr / (time.perf_counter() - t1), "cutoff": 100.0,
-                                     "max_rel_diff_vs_dense": float(np.max(np.abs(sp["dF"] - dn["dF"])) / np.max(np.abs(dn["dF"])))}
-        if args.eps_stream or aux_on:
-            # parity mode: every restart reads its own D x Ns/2 x K block of standard normals from HBM (the reference's randn
-            # stream, entmc_vbmc.m:53), already resident on the device -- R x 20 MB per launch at the headline shape
-            g = torch.Generator(device=dev)
-            g.manual_seed(1)
-            eps_d = torch.randn((Rr, K, M // 2, D), dtype=torch.float64, device=dev, generator=g)
-            torch.cuda.synchronize()
-            kw = dict(eps_device_ptr=eps_d.data_ptr(), eps_shared=False, engine=eng, outputs=("F", "dF"))
-            for _ in range(2):
-                vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, **kw)
-            eng.ctx.set_profiling(True)
-            t1 = time.perf_counter()
-            ems = []
-            for _ in range(5):
-                vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, **kw)
-                ems.append(eng.ctx.last_kernel_ms()[0])
-            dt_ = time.perf_counter() - t1
-            eng.ctx.set_profiling(False)
-            eps_bytes = Rr * K * (M // 2) * D * 8
-            extra["eps_streamed"] = {"evals_per_s": 5 * Rr / dt_, "entropy_kernel_ms": float(np.mean(ems)),
-                                     "eps_bytes_per_launch": eps_bytes,
-                                     "eps_stream_GBps": eps_bytes / (float(np.mean(ems)) * 1e-3) / 1e9}
+        dn = vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=41, engine=eng)
+        t1 = time.perf_counter()
+        for i in range(5):
+            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=50 + i, engine=eng, sparse_cutoff=100.0)
+        out_["block_sparse"] = {"evals_per_s": 5 * Rr / (time.perf_counter() - t1), "cutoff": 100.0,
+                                "max_rel_diff_vs_dense": float(np.max(np.abs(sp["dF"] - dn["dF"])) / np.max(np.abs(dn["dF"])))}
+        return out_
 
-    # ---- auxiliary legs: the other entry points of the path at the same GP shape (wall time per call incl. H2D / D2H), so that
-    # the driver's record carries them; none of this is inside the timed region above
-    if rank == 0 and world == 1 and not args.no_aux:
-        def timeit(f, n=5):
+    def eps_leg():
+        """parity mode: every restart reads its own D x Ns/2 x K block of standard normals from HBM (the reference's randn
+        stream, entmc_vbmc.m:53), already resident on the device -- R x 20 MB per launch at the headline shape"""
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        eps_d = torch.randn((Rr, K, M // 2, D), dtype=torch.float64, device=dev, generator=g)
+        torch.cuda.synchronize()
+        kw = dict(eps_device_ptr=eps_d.data_ptr(), eps_shared=False, engine=eng, outputs=("F", "dF"))
+        for _ in range(2):
+            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, **kw)
+        eng.ctx.set_profiling(True)
+        t1 = time.perf_counter()
+        ems = []
+        for _ in range(5):
+            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, **kw)
+            ems.append(eng.ctx.last_kernel_ms()[0])
+        dt_ = time.perf_counter() - t1
+        eng.ctx.set_profiling(False)
+        eps_bytes = Rr * K * (M // 2) * D * 8
+        return {"evals_per_s": 5 * Rr / dt_, "entropy_kernel_ms": float(np.mean(ems)), "eps_bytes_per_launch": eps_bytes,
+                "eps_stream_GBps": eps_bytes / (float(np.mean(ems)) * 1e-3) / 1e9}
+
+    def timeit(f, n=5):
+        f()
+        t1 = time.perf_counter()
+        for _ in range(n):
             f()
-            t1 = time.perf_counter()
-            for _ in range(n):
-                f()
-            return (time.perf_counter() - t1) / n
+        return (time.perf_counter() - t1) / n
 
-        aux = {}
-        aux["gplite_post_ms"] = 1e3 * timeit(lambda: vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng), 3)
+    def gp_legs(aux):
+        """the other entry points of the path at the same GP shape (wall time per call incl. H2D / D2H)"""
         Xs = 1.5 * np.random.default_rng(0).standard_normal((8192, D))
-        aux["gplite_pred_8192_ms"] = 1e3 * timeit(lambda: vbmc_amd.gplite_pred(gp, Xs, None, None, False, engine=eng), 3)
-        aux["gplite_pred_8192_gflop"] = S * 8192 * (N * N + 2.0 * N * D) / 1e9    # S N* (N^2/2 + N D) multiply-adds
-        aux["eval_fullelcbo_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta0, 0, vp, gp, 4096, 0, 1, nargout=11, engine=eng), 5)
-        aux["diagvar_grad_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta0, 1.0, vp, gp, 128, 1, 2, nargout=2, engine=eng), 5)
-        aux["entlb_sieve_R250_ms"] = 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta0[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)
         st = {"ymax": float(np.max(inp["y"])), "VarianceRegularizedAcqFcn": True, "TolGPVar": 1e-4}
-        aux["acqwrapper_acqf_8192_ms"] = 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None, engine=eng), 3)
         gl = np.exp(np.mean(inp["hyp"][:D], axis=1))
         gpn = dict(gp, X_rescaled=inp["X"] / gl[None, :], sn2new=np.full(N, 0.05))
         stv = dict(st, gplengthscale=gl, ActiveImportanceSampling={"Xa": 1.2 * np.random.default_rng(2).standard_normal((100, D))})
-        aux["acqwrapper_acqviqr_8192_Na100_ms"] = 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gpn, stv, False, "acqviqr_vbmc", None, engine=eng), 3)
         gpd = {"X": inp["X"], "y": inp["y"], "s2": None, "covfun": 1, "Ncov": D + 1, "noisefun": (1, 0, 0), "Nnoise": 1, "meanfun": 4,
                "Nmean": 2 * D + 1, "intmeanfun": 0}
+        legs = [
+            ("gplite_post_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng), 3)),
+            ("gplite_pred_8192_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.gplite_pred(gp, Xs, None, None, False, engine=eng), 3)),
+            ("eval_fullelcbo_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta0, 0, vp, gp, 4096, 0, 1, nargout=11, engine=eng), 5)),
+            ("diagvar_grad_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta0, 1.0, vp, gp, 128, 1, 2, nargout=2, engine=eng), 5)),
+            ("entlb_sieve_R250_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta0[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)),
+            ("acqwrapper_acqf_8192_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None, engine=eng), 3)),
+            ("acqwrapper_acqviqr_8192_Na100_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gpn, stv, False, "acqviqr_vbmc", None, engine=eng), 3)),
+        ]
         for B in (1, 64, 256):
             H = np.tile(inp["hyp"], (1, (B + S - 1) // S))[:, :B] + 0.01 * np.random.default_rng(1).standard_normal((inp["hyp"].shape[0], B))
-            aux["nlz_grad_B%d_evals_per_s" % B] = B / timeit(lambda: vbmc_amd.gplite_nlZ(H, gpd, engine=eng), 3)
-        for k in [k for k in extra if k.startswith(("device_adam", "eps_streamed"))]:
-            aux[k] = extra.pop(k)
+            legs.append(("nlz_grad_B%d_evals_per_s" % B, lambda H=H, B=B: B / timeit(lambda: vbmc_amd.gplite_nlZ(H, gpd, engine=eng), 3)))
+        for name, fn in legs:
+            v = leg("aux." + name, fn)
+            if v is not None:
+                aux[name] = v
+        aux["gplite_pred_8192_gflop"] = S * 8192.0 * N * N / 1e9    # S N* N^2 flops: two per multiply-add of the triangle inv(L') (sW Ks)
+
+    if rank == 0:
+        roof = leg("roofline", roofline_leg)
+        if args.extras:
+            extra.update(leg("extras", extras_leg) or {})
+    if aux_on:
+        aux = {}
+        aux.update(leg("aux.device_adam", adam_leg) or {})
+        v = leg("aux.eps_streamed", eps_leg)
+        if v is not None:
+            aux["eps_streamed"] = v
+        gp_legs(aux)
         extra["aux"] = aux
+    elif rank == 0 and args.eps_stream:
+        extra["eps_streamed"] = leg("eps_streamed", eps_leg)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(inp, gp, D, K, Ns)
+        cpu = leg("cpu_baseline", lambda: cpu_baseline(inp, gp, D, K, Ns))
+    if leg_errors:
+        extra["leg_errors"] = leg_errors
 
     if rank == 0:
         evals = (1 if shard_ex is not None else world) * Rr * args.steps
