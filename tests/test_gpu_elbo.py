@@ -279,13 +279,12 @@ def test_kernel_instantiation_sweep(va, dk):
 
 def test_oversized_mixture_is_refused_cleanly(va):
     """Beyond the supported shapes the library answers with a clean VBMC_ERR_UNSUPPORTED (the shim falls through to the
-    reference), not with a failed launch: more than 256 components; the Monte-Carlo entropy of a mixture too large for the
-    two-wave MFMA kernel (K > 128) AND for the LDS tiles of the VALU kernel.  (A D x K record too large for k_finalize's LDS
-    is no longer refused: tests/test_gpu_limits.py.)"""
+    reference), not with a failed launch: more than 256 components.  (A D x K record too large for k_finalize's LDS, entlb
+    beyond 128 components and the Monte-Carlo entropy of 128 < K <= 256 components are no longer refused:
+    tests/test_gpu_limits.py.)"""
     p, gp, vp, theta = problem(5, 4, 40, 257, 1)
     with pytest.raises(va.VbmcUnsupported):
         va.negelcbo_vbmc(theta, 0, vp, gp, 0, 1, 0)
-    p, gp, vp, theta = problem(5, 24, 40, 250, 1)
     with pytest.raises(va.VbmcUnsupported):
         va.negelcbo_vbmc(theta, 0, vp, gp, 20, 1, 0)
 

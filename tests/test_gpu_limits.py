@@ -41,10 +41,11 @@ def test_entlb_beyond_128_components(va, cfg):
     assert abs(H - Hr) < 1e-10 * max(1.0, abs(Hr))
 
 
-@pytest.mark.parametrize("cfg", [(32, 40, 160, 2, 24), (32, 40, 150, 1, 0), (24, 30, 250, 1, 0), (28, 30, 190, 1, 12)])
+@pytest.mark.parametrize("cfg", [(32, 40, 160, 2, 24), (32, 40, 150, 1, 0), (24, 30, 250, 1, 0), (28, 30, 190, 1, 12), (24, 30, 250, 1, 20),
+                                 (5, 40, 200, 2, 64), (10, 40, 129, 1, 40), (6, 30, 256, 1, 32)])
 def test_mixtures_whose_finalize_record_exceeds_the_lds(va, cfg):
     D, N, K, S, Ns = cfg
-    assert 4 * D * K + 9 * K > 19400
+    assert 4 * D * K + 9 * K > 19400 or K > 128      # the old finalize-record limit, or the four-wave MFMA entropy kernel (K > 128)
     gp, vp, theta, tb = _problem(72, D, N, K, S)
     eps = np.random.default_rng(4).standard_normal((K, max(Ns, 2) // 2, D)) if Ns else None
     ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, thetabnd=tb, eps=eps)

@@ -73,11 +73,8 @@ def test_negelcbo_random_shapes_wide(va, shape, seed, ns_half, compute_var, grad
     theta, vp = R.get_vptheta(vp)
     Ns = 2 * ns_half
     eps = np.random.default_rng(seed + 1).standard_normal((K, max(ns_half, 1), D))[:, :ns_half, :] if Ns > 0 else None
-    # documented limits: the Monte-Carlo entropy of 128 < K <= 256 components needs the VALU kernel's LDS tiles (K (DT + 69) + 64
-    # doubles, DT = D padded); the variance gradient keeps five T-vectors in LDS
-    dt = next(t for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 20, 24, 28, 32) if t >= D)
-    too_big = (Ns > 0 and K > 128 and (K * (dt + 4) + 64 + (K * 65 if grad else 0)) * 8 > 160 * 1024) \
-        or (grad and compute_var == 2 and 5 * theta.size + 2 * (S + K) + 1024 + 8 > 20480)
+    # documented limit: the variance gradient keeps five T-vectors in LDS
+    too_big = grad and compute_var == 2 and 5 * theta.size + 2 * (S + K) + 1024 + 8 > 20480
     if too_big:
         with pytest.raises(va.VbmcUnsupported):
             va.negelcbo_batch(theta, 0.0, vp, gp, Ns, grad, compute_var)

@@ -308,6 +308,7 @@ int vbmc_launch_ent_mfma_qs7(int, int, int, unsigned, unsigned, unsigned, void*,
 int vbmc_launch_ent_mfma_qs8(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 int vbmc_launch_ent_mfma_qs9(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 }
+#define ENT_HV_MID 2   // waves per workgroup for 64 < K <= 128: two (four measured 11-15 % slower there: more exchange and barrier coupling)
 static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
   static const fn_t fns[9] = {vbmc_launch_ent_mfma_qs1, vbmc_launch_ent_mfma_qs2, vbmc_launch_ent_mfma_qs3,
@@ -316,14 +317,17 @@ static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipSt
   if (qs < 1 || qs > 9) return false;
   return fns[qs - 1](kt, grad ? 1 : 0, hv, g.x, g.y, g.z, (void*)st, &ea) == 0;
 }
-// K <= 64: one wave per (chunk, component, restart) with kt = ceil(K/16) k-tiles; 64 < K <= 128: the components are split
-// over the two waves of a workgroup (hv = 2), kt = ceil(ceil(K/2)/16) in {3, 4}.  D <= 34 (qs <= 9).
+// K <= 64: one wave per (chunk, component, restart) with kt = ceil(K/16) k-tiles; larger mixtures split their components
+// over the hv = 2 or 4 waves of a workgroup, kt = ceil(ceil(K/hv)/16) <= 4: two waves up to K = 128, four up to K = 256.
+// VBMC_ENT_HV = 2 / 4 forces the split where both fit (A/B runs).  D <= 34 (qs <= 9).
 static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out, int* hv_out) {
   const int qs = (D + 2 + 3) / 4;
-  const int hv = K <= 64 ? 1 : 2;
+  int hv = K <= 64 ? 1 : (K <= 128 ? ENT_HV_MID : 4);
+  if (K > 64 && K <= 128)
+    if (const char* f = getenv("VBMC_ENT_HV")) { const int v = atoi(f); if (v == 2 || v == 4) hv = v; }
   const int kt = (((K + hv - 1) / hv) + 15) / 16;
   *qs_out = qs; *kt_out = kt; *hv_out = hv;
-  return qs >= 1 && qs <= 9 && K >= 1 && K <= 128 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3);
+  return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3) && !(hv == 4 && kt < 2);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // One translation unit per QS (compiled with -DQS_VALUE=n, in parallel, see vbmc_amd/build.py):
-// instantiates k_entropy_mfma<QS, KT, grad, sparse, HV> for KT = 1..4 (HV = 1) and KT = 3, 4 with the components split over
-// two waves (HV = 2), and exports a launcher.
+// instantiates k_entropy_mfma<QS, KT, grad, sparse, HV> for KT = 1..4 (HV = 1), KT = 3, 4 with the components split over
+// two waves (HV = 2) and KT = 2..4 over four waves (HV = 4), and exports a launcher.
 #include "entropy_mfma.h"
 
 #ifndef QS_VALUE
@@ -11,7 +11,15 @@
 
 template <int KT, int HV>
 static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
-  const size_t lds = (size_t)ea.K * (ea.D + ENTP_EXTRA) * sizeof(double);  // parameter block (<= 39 KB)
+  // dynamic LDS: the parameter block (<= 74 KB at K = 256, D = 32), reused by the PV exchange of multi-wave workgroups
+  // (2 signs x HV waves x NPV x 4 x 64 doubles)
+  constexpr int NPV_ = (4 * QS_VALUE + 15) / 16;
+  size_t lds = (size_t)ea.K * (ea.D + ENTP_EXTRA) * sizeof(double);
+  if (HV > 1) lds = lds > (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double) ? lds : (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double);
+  if (lds > 64 * 1024) {
+    if (grad) (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, true, false, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, false, false, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (ea.cutoff > 0.0 && HV == 1) {  // opt-in block-sparse variant (single-wave kernels only)
     if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, true, 1>), grid, dim3(WAVE), lds, st, ea);
     else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, true, 1>), grid, dim3(WAVE), lds, st, ea);
@@ -26,13 +34,16 @@ extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, 
                                                       const EntArgs* ea) {
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(gx, gy, gz);
-  switch (kt + 4 * (hv - 1)) {
-    case 1: launch_kt<1, 1>(grad, grid, st, *ea); return 0;
-    case 2: launch_kt<2, 1>(grad, grid, st, *ea); return 0;
-    case 3: launch_kt<3, 1>(grad, grid, st, *ea); return 0;
-    case 4: launch_kt<4, 1>(grad, grid, st, *ea); return 0;
-    case 7: launch_kt<3, 2>(grad, grid, st, *ea); return 0;   // 64 < K <= 96
-    case 8: launch_kt<4, 2>(grad, grid, st, *ea); return 0;   // 96 < K <= 128
+  switch (kt + 16 * hv) {
+    case 16 + 1: launch_kt<1, 1>(grad, grid, st, *ea); return 0;
+    case 16 + 2: launch_kt<2, 1>(grad, grid, st, *ea); return 0;
+    case 16 + 3: launch_kt<3, 1>(grad, grid, st, *ea); return 0;
+    case 16 + 4: launch_kt<4, 1>(grad, grid, st, *ea); return 0;
+    case 32 + 3: launch_kt<3, 2>(grad, grid, st, *ea); return 0;   // 64 < K <= 96, two waves
+    case 32 + 4: launch_kt<4, 2>(grad, grid, st, *ea); return 0;   // 96 < K <= 128
+    case 64 + 2: launch_kt<2, 4>(grad, grid, st, *ea); return 0;   // 64 < K <= 128, four waves
+    case 64 + 3: launch_kt<3, 4>(grad, grid, st, *ea); return 0;   // 128 < K <= 192
+    case 64 + 4: launch_kt<4, 4>(grad, grid, st, *ea); return 0;   // 192 < K <= 256
     default: return 1;
   }
 }

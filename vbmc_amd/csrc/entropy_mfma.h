@@ -76,13 +76,15 @@ __device__ __forceinline__ void ent_sync_wg() {
   else __syncthreads();
 }
 
-// HV = 2 (64 < K <= 128): the components are split between the two waves of a workgroup, each running the KT <= 4
-// register-resident body on its half; per sign the waves exchange their partial PV outputs (16 x 16 NPV doubles per wave
-// through LDS, one workgroup barrier) and both continue with the full q', A', B' -- identical bits on both sides
-// (a + b == b + a).  Wave 0 owns the per-sample accumulators (H, G, LG); each wave owns the weight gradient of its half.
+// HV = 2 or 4 (K > 64): the components are split between the HV waves of a workgroup, each running the KT <= 4
+// register-resident body on its share; per sign the waves exchange their partial PV outputs (16 x 16 NPV doubles per wave
+// through LDS, one workgroup barrier) and all continue with the full q', A', B' -- the partials are added in wave order on
+// every wave, so all hold identical bits.  Wave 0 owns the entropy accumulator, the column blocks of the gradient are dealt
+// to the waves, each wave owns the weight gradient of its components.  The exchange buffers reuse the parameter block's LDS
+// (needed only while the operand fragments are built).
 template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1>
-__global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(EntArgs a) {
-  static_assert(KT <= 4, "larger mixtures are split over two waves (HV = 2)");
+__global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_entropy_mfma(EntArgs a) {
+  static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
   constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   __shared__ double TAB[VB_EXP_TAB_N];     // 2^(j/256)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
-  __shared__ double YX[HV == 2 ? 2 : 1][HV == 2 ? 2 : 1][HV == 2 ? NPV * 4 * WAVE : 1];
+  constexpr int YXN = NPV * 4 * WAVE;      // doubles per (sign, wave) slot of the PV exchange (in the dynamic LDS, see PB)
   // PV "B" operands of large mixtures live in LDS (lane-contiguous: conflict-free ds_read_b64 right before the MFMA that
   // consumes them) -- the 32 VGPRs they would occupy hold the second sign's exponents instead (see the S-step)
   // EO: the even / odd split of the S-step below (needs 32 more VGPRs for the second sign's exponents, paid for by VBL).
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   constexpr bool EO = HV == 1;
   constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
-  const int tid = threadIdx.x, hv = HV == 2 ? tid >> 6 : 0, lane = tid & 63;
+  const int tid = threadIdx.x, hv = HV == 1 ? 0 : tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
@@ -117,6 +119,8 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
   // stage this restart's packed parameter block [k][m_1..m_D, h, cK, w, wi] in LDS with coalesced loads;
   // the per-lane operand fragments below are gathered from LDS, not from global memory
   extern __shared__ double PB[];
+  double* const YX = PB;   // [sign][wave][YXN]: written for the first time after the first tile's workgroup barrier, when no
+                           // wave reads the parameter block any more (the launcher sizes the dynamic LDS for the larger of the two)
   {
     // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
     // single chain) this setup is a quarter of the kernel
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
     const int b0 = tile * 16;
     // ---- stage the 16 x D eps tile in LDS (zeros for padded dims / samples beyond Mh)
     ent_sync_wg<HV>();
-    if (HV == 2 && hv != 0) {
+    if (HV > 1 && hv != 0) {
       // wave 0 stages (and, in device-RNG mode, draws) the tile for both
     } else if (epsr) {
       for (int idx = lane; idx < 16 * DP; idx += WAVE) {
@@ -385,17 +389,22 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
           if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][3], VBV(KT - 1, 3, pv), Y2[pv], 0, 0, 0);
           Y[pv] += Y2[pv];
         }
-        if (HV == 2) {
-          // both halves of the mixture: add the other wave's partial q', A', B'
+        if (HV > 1) {
+          // all shares of the mixture: the partial q', A', B' of every wave, added in wave order
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) YX[sg][hv][(pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
+            for (int rr = 0; rr < 4; ++rr) YX[(sg * HV + hv) * YXN + (pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
           __syncthreads();
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) Y[pv][rr] += YX[sg][hv ^ 1][(pv * 4 + rr) * WAVE + lane];
+            for (int rr = 0; rr < 4; ++rr) {
+              double t = YX[(sg * HV + 0) * YXN + (pv * 4 + rr) * WAVE + lane];
+#pragma unroll
+              for (int w = 1; w < HV; ++w) t += YX[(sg * HV + w) * YXN + (pv * 4 + rr) * WAVE + lane];
+              Y[pv][rr] = t;
+            }
         }
         // ---- per-sample scalars in the sample layout (lane <-> sample li): q' from column 0
         if (li == 0) {
@@ -426,7 +435,7 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
           const double rq = RQ[i];
 #pragma unroll
           for (int pv = 0; pv < NPV; ++pv) {
-            if (HV == 2 && (pv & 1) != hv) continue;      // the two waves share the column blocks of the gradient
+            if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
             const int d = 16 * pv + li - 2;
             if (d >= 0 && d < D) {
               const double e = sgn * Et[i * DP + d];
@@ -445,10 +454,12 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
           for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
         qp += __shfl_xor(qp, 16, 64);
         qp += __shfl_xor(qp, 32, 64);
-        if (HV == 2) {
-          YX[sg][hv][lane] = qp;
+        if (HV > 1) {
+          YX[(sg * HV + hv) * YXN + lane] = qp;
           __syncthreads();
-          qp += YX[sg][hv ^ 1][lane];
+          qp = YX[(sg * HV + 0) * YXN + lane];
+#pragma unroll
+          for (int w = 1; w < HV; ++w) qp += YX[(sg * HV + w) * YXN + lane];
         }
         const double qs_ = svalid ? qp : 1.0;
         pm *= __builtin_amdgcn_frexp_mant(qs_);
@@ -485,16 +496,18 @@ __global__ void __launch_bounds__(WAVE * HV, (KT <= 2 ? 3 : 2)) k_entropy_mfma(E
       lgd += __shfl_xor(lgd, 16, 64); lgd += __shfl_xor(lgd, 32, 64);
       const int d = 16 * pv + li - 2;
       const bool dv = d >= 0 && d < D;
-      const bool mine = HV == 1 || (pv & 1) == hv;
+      const bool mine = HV == 1 || (pv % HV) == hv;
       if (dv && lg == 0 && mine) { o[1 + d] = g; o[2 + D + d] = lgd; }
       sgsum += (dv && lg == 0 && mine) ? lgd : 0.0;
     }
     sgsum = wave_sum(sgsum);            // SG = sum_d LG_d  (entmc_vbmc.m:87)
-    if (HV == 2) {
+    if (HV > 1) {
       __syncthreads();
-      if (lane == 0) YX[0][hv][0] = sgsum;
+      if (lane == 0) YX[hv * YXN] = sgsum;
       __syncthreads();
-      sgsum = YX[0][0][0] + YX[0][1][0];
+      sgsum = YX[0];
+#pragma unroll
+      for (int w = 1; w < HV; ++w) sgsum += YX[w * YXN];
     }
     if (lane == 0 && hv == 0) o[1 + D] = sgsum;
 #pragma unroll
