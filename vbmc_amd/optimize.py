@@ -585,7 +585,10 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
                 return r["F"]
 
             thetaopt[i], info = cmaes_batched(fun_batch, theta0s[i], insigma, TolX=1e-6 * float(np.max(insigma)), TolFun=1e-4, TolHistFun=1e-5,
-                                              MaxFunEvals=options.get("CMAESMaxFunEvals", np.inf), rng=rng)   # :145-149
+                                              MaxFunEvals=options.get("CMAESMaxFunEvals") or 1000 * (D + 2), rng=rng)   # :145-149
+            # (the reference leaves MaxFunEvals at Inf and relies on cmaes_modded's uncertainty handling, Noise.on = 1, to end a
+            # run on the noisy objective; the plain CMA-ES here has none, hence a cap: five times the 200 (D + 2) the reference
+            # allows its own deterministic CMA-ES fallback, :97)
             if trace is not None:
                 trace.append(dict(kind="cmaes", slot=i, **{k: info[k] for k in ("stop", "generations", "evals")}))
 
