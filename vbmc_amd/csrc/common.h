@@ -33,7 +33,7 @@ struct vbmc_ctx {
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
-  void* bounce = nullptr;                       // 2 x BOUNCE_CHUNK pinned bytes (d2h_bounced)
+  void* bounce = nullptr;                       // (unused since round 2: see d2h_bounced)
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
   std::string err;
   int num_cu = 256;
@@ -145,31 +145,13 @@ static inline vbmc_status ensure(vbmc_ctx* ctx, DevBuf& b, size_t bytes) {
   return VBMC_OK;
 }
 
-// Large device -> pageable-host copy through two pinned bounce buffers: the DMA of chunk i+1 runs while the CPU moves
-// chunk i into the caller's array (a direct hipMemcpy into pageable memory runs at a fraction of the link rate).
-// Synchronises the stream before returning.
-#define BOUNCE_CHUNK ((size_t)1 << 20)
+// Large device -> pageable-host copy.  Round 1 staged it through two pinned bounce buffers with a CPU memcpy per chunk; measured
+// on the box in round 2 (tools/d2h_probe.py, 25.6 MB = gp.post(1:20).L at N = 400): the runtime's own path into pageable memory
+// runs at 55 GB/s into touched pages and 24 GB/s into a fresh array (first-touch faults), the bounce path at ~11 GB/s (bound by
+// the single-threaded memcpy) -- so the plain copy it is.  Synchronises the stream before returning.
 static inline vbmc_status d2h_bounced(vbmc_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  hipStream_t st = ctx->stream;
-  if (!ctx->bounce) {
-    HIP_TRY(ctx, hipHostMalloc(&ctx->bounce, 2 * BOUNCE_CHUNK, hipHostMallocDefault));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bounce_ev[0], hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bounce_ev[1], hipEventDisableTiming));
-  }
-  char* b = (char*)ctx->bounce;
-  const size_t nch = (bytes + BOUNCE_CHUNK - 1) / BOUNCE_CHUNK;
-  for (size_t c = 0; c <= nch; ++c) {
-    if (c < nch) {
-      const size_t off = c * BOUNCE_CHUNK, n = bytes - off < BOUNCE_CHUNK ? bytes - off : BOUNCE_CHUNK;
-      HIP_TRY(ctx, hipMemcpyAsync(b + (c & 1) * BOUNCE_CHUNK, (const char*)src + off, n, hipMemcpyDeviceToHost, st));
-      HIP_TRY(ctx, hipEventRecord(ctx->bounce_ev[c & 1], st));
-    }
-    if (c > 0) {
-      const size_t p = c - 1, off = p * BOUNCE_CHUNK, n = bytes - off < BOUNCE_CHUNK ? bytes - off : BOUNCE_CHUNK;
-      HIP_TRY(ctx, hipEventSynchronize(ctx->bounce_ev[p & 1]));
-      memcpy((char*)dst + off, b + (p & 1) * BOUNCE_CHUNK, n);
-    }
-  }
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return VBMC_OK;
 }
 
