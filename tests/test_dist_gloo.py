@@ -113,3 +113,45 @@ def test_sharded_acquisition_sweep_picks_the_same_point():
         pr.join(timeout=30)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]
+
+
+def _exchange_worker(rank, world, port, q):
+    import ctypes
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vbmc_amd.dist import ShardExchange
+
+    ex = ShardExchange(device=torch.device("cpu"))      # the exchange of negelcbo_shard, on host tensors
+    ok = True
+    for n in (7, 1000, 7):                                # buffers are re-made when the block size changes
+        p = ex.send_buffer(n)
+        mine = (np.arange(n, dtype=np.float64) + 1000.0 * rank)
+        ctypes.memmove(p, mine.ctypes.data, 8 * n)        # what vbmc_elbo_shard_begin does on the device
+        g = ex.all_gather()
+        got = np.ctypeslib.as_array(ctypes.cast(g, ctypes.POINTER(ctypes.c_double)), shape=(world * n,)).copy()
+        want = np.concatenate([np.arange(n, dtype=np.float64) + 1000.0 * r for r in range(world)])   # rank order
+        ok = ok and np.array_equal(got, want)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_shard_exchange_gathers_the_blocks_in_rank_order():
+    """The one collective of the hyper-sample / sample-chunk sharded evaluation (vbmc_amd.dist.ShardExchange): every rank ends
+    with all blocks in rank order -- what vbmc_elbo_shard_finish expects.  (The bit-identity of the sharded evaluation itself
+    needs the device: tests/test_gpu_shard_s.py.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=30)
+    assert all(ok for _, ok in res), res

@@ -49,15 +49,20 @@ class ShardExchange:
 
         self.torch, self.dist, self.group = torch, dist, group
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.is_cuda = self.device.type == "cuda"    # a CPU device only for the gloo tests of the exchange itself
         self.world = dist.get_world_size(group)
         self.on_device = dist.get_backend(group) == "nccl"
         self.send = self.recv = None
+
+    def _sync(self):
+        if self.is_cuda:
+            self.torch.cuda.synchronize(self.device)
 
     def send_buffer(self, n):
         if self.send is None or self.send.numel() != n:
             self.send = self.torch.empty(n, dtype=self.torch.float64, device=self.device)
             self.recv = self.torch.empty(n * self.world, dtype=self.torch.float64, device=self.device)
-            self.torch.cuda.synchronize(self.device)
+            self._sync()
         return self.send.data_ptr()
 
     def all_gather(self):
@@ -68,7 +73,7 @@ class ShardExchange:
             hr = self.torch.empty(h.numel() * self.world, dtype=self.torch.float64)
             self.dist.all_gather_into_tensor(hr, h, group=self.group)
             self.recv.copy_(hr)
-        self.torch.cuda.synchronize(self.device)   # the library reads recv on its own stream
+        self._sync()   # the library reads recv on its own stream
         return self.recv.data_ptr()
 
 
