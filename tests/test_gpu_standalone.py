@@ -146,3 +146,26 @@ def test_gplogjoint_per_hyper_sample_outputs(va, cfg):
         assert abs(vss + np.std(vs, ddof=1) - varss) < 1e-9 * max(1.0, abs(varss))
     with pytest.raises(va.VbmcUnsupported):
         va.gplogjoint(vp, gp, 1, 0, 1, 0, nargout=2)    # per-sample gradients: not accelerated, the shim falls through
+
+
+def test_gplogjoint_per_hyper_sample_outputs_against_mpmath_vectors(va):
+    """avg_flag = 0 pinned directly on the committed 50-digit vectors (tests/golden/mp_case*.json: G_s, varG_s_full,
+    varG_s_diag, I_sk, J_sjk), not only on the NumPy oracle: the per-sample F and varF the device hands back for
+    [F,~,varF] = gplogjoint(vp,gp,0,0,0,compute_var) (misc/gplogjoint.m:398 skipped)."""
+    from tests._cases import golden_cases, load_golden, vp_from_inputs
+
+    for path in golden_cases():
+        inp, exp = load_golden(path)
+        vp = vp_from_inputs(inp)
+        gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"])
+        for s, post in enumerate(gp["post"]):
+            post["alpha"] = np.array(exp["alpha"][s])
+            post["L"] = np.array(exp["L"][s])
+        out = va.gplogjoint(vp, gp, 0, 0, 0, 1, 1, nargout=7)
+        F, varF, I_sk, J_sjk = np.atleast_1d(out[0]), np.atleast_1d(out[2]), out[5], out[6]
+        assert relerr(F, exp["G_s"]) < 1e-11
+        assert relerr(I_sk, np.array(exp["I_sk"])) < 1e-11
+        assert relerr(J_sjk, np.array(exp["J_sjk"])) < 1e-8      # z' K^-1 z cancels against nf_jk
+        assert relerr(varF, exp["varG_s_full"]) < 1e-8
+        _, _, varFd = va.gplogjoint(vp, gp, 0, 0, 0, 2, nargout=3)
+        assert relerr(np.atleast_1d(varFd), exp["varG_s_diag"]) < 1e-8

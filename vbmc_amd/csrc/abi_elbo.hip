@@ -1065,13 +1065,28 @@ __global__ void k_test_exp(int n, int variant, const double* __restrict__ x, dou
   if (i < n) y[i] = variant == 2 ? vb_exp_tab<1>(x[i], tab) : (variant ? vb_exp_tab<0>(x[i], tab) : vb_exp(x[i]));
 }
 
+// variant 3: vb_exp_tab1k, the entropy kernel's exp, on y = x * 1024/ln2 (in the kernel the factor sits in the MFMA operands)
+#include "exp2_tab1k.h"
+__global__ void k_test_exp1k(int n, const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double tab[VB_EXP_TAB1K_N];
+  for (int t = threadIdx.x; t < VB_EXP_TAB1K_N; t += blockDim.x) tab[t] = c_exp2_tab1k[t];
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double ys;   // a ROUNDED product, as the MFMA delivers it: the compiler must not contract it into the reduction's subtraction
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(ys) : "v"(x[i]), "v"(VB_EXP_TAB1K_SCALE));
+    y[i] = vb_exp_tab1k(ys, tab);
+  }
+}
+
 extern "C" vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const double* x, double* y) {
   if (!ctx || n <= 0 || !x || !y) return VBMC_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   { vbmc_status s_ = ensure(ctx, ctx->misc, 2 * (size_t)n * sizeof(double)); if (s_) return s_; }
   double* dx = (double*)ctx->misc.p;
   HIP_TRY(ctx, hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, variant, dx, dx + n);
+  if (variant == 3) hipLaunchKernelGGL(k_test_exp1k, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, dx, dx + n);
+  else hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, variant, dx, dx + n);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(y, dx + n, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

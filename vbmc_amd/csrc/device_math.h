@@ -160,6 +160,34 @@ __device__ __forceinline__ vb_d4 vb_exp_tab4(vb_d4 x, const double* __restrict__
   return y;
 }
 
+// The entropy kernel's exp (entropy_mfma.h): the argument arrives PRE-SCALED, y = x * 1024/ln2 (the factor is folded into the
+// S-step's MFMA operands), so the reduction is r' = y - rint(y) in [-1/2, 1/2] -- no multiply, and the saturating
+// v_cvt_i32_f64 makes the clamp of the magic-number variant unnecessary (y < -2^31: index 0, exponent -2^21 -> 0; y > 2^31:
+// +inf).  1024-entry table (8 KB of LDS), exp(x) = 2^(n >> 10) T[n & 1023] (1 + c r' (1 + c r'/2 + (c r')^2/6)), c = ln2/1024:
+// remainder (c/2)^4/24 < 6e-16 before, 1.4e-16 after the economisation below.  11 VALU ops + one ds_read_b64 (vb_exp_tab<1>: 13; tools/exp_variants.hip: +11 % on the box).
+// Accuracy as vb_exp_tab<1> ("sum" mode): the argument's own rounding, |x| 1e-16, dominates.
+#define VB_EXP_TAB1K_N 1024
+#define VB_EXP_TAB1K_SCALE 1477.3197218702985291365628   // 1024 / ln 2
+__device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restrict__ tab) {
+  const double c = 0.693147180559945309417232 / 1024;
+  const double nr = __builtin_rint(y);
+  const int ni = __double2int_rz(nr);
+  const double r = y - nr;
+  const double T = tab[ni & (VB_EXP_TAB1K_N - 1)];
+  // the dropped quartic term (c r')^4/24 is economised into the quadratic one (r'^4 ~ r'^2/4 - 1/128 on [-1/2, 1/2]:
+  // Chebyshev), which leaves a remainder of c^4/24/64 = 1.4e-16 instead of 5.4e-16 at no cost
+  double u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96);
+  u = fma(r, u, c);
+  const double Tr = T * r;
+  return ldexp(fma(Tr, u, T), ni >> 10);
+}
+__device__ __forceinline__ vb_d4 vb_exp_tab1k4(vb_d4 y, const double* __restrict__ tab) {
+  vb_d4 e;
+  e[0] = vb_exp_tab1k(y[0], tab); e[1] = vb_exp_tab1k(y[1], tab);
+  e[2] = vb_exp_tab1k(y[2], tab); e[3] = vb_exp_tab1k(y[3], tab);
+  return e;
+}
+
 // 1/q for q > 0 finite: v_rcp_f64 seed + two Newton steps (<= 1 ulp), instead of the IEEE division sequence
 __device__ __forceinline__ double vb_rcp(double q) {
   double r = __builtin_amdgcn_rcp(q);

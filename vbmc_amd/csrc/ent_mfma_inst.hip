@@ -11,11 +11,13 @@
 
 template <int KT, int HV>
 static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
-  // dynamic LDS: the parameter block (<= 74 KB at K = 256, D = 32), reused by the PV exchange of multi-wave workgroups
-  // (2 signs x HV waves x NPV x 4 x 64 doubles)
+  // dynamic LDS: the parameter block (<= 74 KB at K = 256, D = 32), reused by the exp table (8 KB) and the PV exchange of
+  // multi-wave workgroups (2 signs x HV waves x NPV x 4 x 64 doubles)
   constexpr int NPV_ = (4 * QS_VALUE + 15) / 16;
   size_t lds = (size_t)ea.K * (ea.D + ENTP_EXTRA) * sizeof(double);
-  if (HV > 1) lds = lds > (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double) ? lds : (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double);
+  size_t after = (size_t)VB_EXP_TAB1K_N * sizeof(double);          // the exp table takes the block's place once the operands are built
+  if (HV > 1) after += (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double);
+  if (after > lds) lds = after;
   if (lds > 64 * 1024) {
     if (grad) (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, true, false, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     else (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, false, false, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

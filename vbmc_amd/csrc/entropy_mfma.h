@@ -27,6 +27,7 @@
 
 #include "device_math.h"
 #include "elbo_types.h"
+#include "exp2_tab1k.h"
 
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
@@ -92,7 +93,6 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
                                            // D mod 4 in {3, 0} the last one multiplies zeros -- a compile-time count keeps the KT chains branch-free)
   __shared__ double Et_all[1][16 * DP];    // eps tile [i][d], staged by wave 0 and shared by the waves of the workgroup
   __shared__ double RQ_all[HV][16];        // q'_i then 1/q'_i
-  __shared__ double TAB[VB_EXP_TAB_N];     // 2^(j/256)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
   constexpr int YXN = NPV * 4 * WAVE;      // doubles per (sign, wave) slot of the PV exchange (in the dynamic LDS, see PB)
@@ -119,8 +119,11 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   // stage this restart's packed parameter block [k][m_1..m_D, h, cK, w, wi] in LDS with coalesced loads;
   // the per-lane operand fragments below are gathered from LDS, not from global memory
   extern __shared__ double PB[];
-  double* const YX = PB;   // [sign][wave][YXN]: written for the first time after the first tile's workgroup barrier, when no
-                           // wave reads the parameter block any more (the launcher sizes the dynamic LDS for the larger of the two)
+  // The parameter block is needed only while the operand fragments are built; afterwards its LDS holds the exp table
+  // 2^(j/1024) (8 KB) and, behind it, the PV exchange buffers of multi-wave workgroups [sign][wave][YXN] (the launcher sizes the
+  // dynamic LDS for the larger of the two uses)
+  double* const TAB = PB;
+  double* const YX = PB + VB_EXP_TAB1K_N;
   {
     // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
     // single chain) this setup is a quarter of the kernel
@@ -143,13 +146,6 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       for (int u = 0; u < 8; ++u) if (idx + u * NT < n) PB[idx + u * NT] = t8[u];
     }
   }
-  {
-    double tt[VB_EXP_TAB_N / (WAVE * HV)];
-#pragma unroll
-    for (int u = 0; u < VB_EXP_TAB_N / (WAVE * HV); ++u) tt[u] = c_exp2_tab[tid + u * WAVE * HV];
-#pragma unroll
-    for (int u = 0; u < VB_EXP_TAB_N / (WAVE * HV); ++u) TAB[tid + u * WAVE * HV] = tt[u];
-  }
   __syncthreads();
   const double* gp = PB;
   const double* pj = gp + (size_t)j * PSg;
@@ -161,7 +157,9 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
-  // ---- mixture-side operand fragments (registers, built once)
+  // ---- mixture-side operand fragments (registers, built once).  The S-step operands carry the factor 1024/ln2 of the exp's
+  // range reduction (device_math.h: vb_exp_tab1k): the MFMAs deliver E * 1024/ln2
+  constexpr double ESC = VB_EXP_TAB1K_SCALE;
   double SA[KT][QL];          // S-step "A" operand, linear part: comp 16kt + li, inner c = 4q + lg < D
   double SC[KT];              // S-step "A" operand, even part: inner index lg = 0 (coefficient of |u'|^2), 1 (constant), 2, 3 (zero)
   double VB[VBL ? 1 : KT][4][NPV];   // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD; in LDS when VBL)
@@ -186,7 +184,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
     for (int q = 0; q < QL; ++q) {
       const int cc = 4 * q + lg;
       if (EO) {
-        SA[kt][q] = (kv && cc < D) ? -2.0 * h * (pk[cc] - pj[cc]) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+        SA[kt][q] = (kv && cc < D) ? ESC * (-2.0 * h * (pk[cc] - pj[cc])) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
       } else {   // plain S-step: linear and even columns in one (D + 2)-column operand, QS MFMAs per sign
         double v;
         if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;
@@ -194,12 +192,12 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         else if (cc == D) v = h + hj_neg;
         else if (cc == D + 1) v = fma(h, m2, pk[D + 1]) - cKj;
         else v = 0.0;
-        SA[kt][q] = v;
+        SA[kt][q] = ESC * v;
       }
     }
     // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2) is folded into the two even columns: accumulators start at 0
-    SC[kt] = !kv ? (lg == 1 ? -1.0e6 : 0.0)                                 // padded component: exp -> 0
-                 : (lg == 0 ? h + hj_neg : (lg == 1 ? fma(h, m2, pk[D + 1]) - cKj : 0.0));
+    SC[kt] = ESC * (!kv ? (lg == 1 ? -1.0e6 : 0.0)                          // padded component: exp -> 0
+                        : (lg == 0 ? h + hj_neg : (lg == 1 ? fma(h, m2, pk[D + 1]) - cKj : 0.0)));
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int k2 = 16 * kt + 4 * rr + lg;
@@ -223,6 +221,18 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       }
     }
   }
+
+  // ---- the parameter block is dead: its LDS becomes the exp table
+  __syncthreads();
+  {
+    constexpr int NTB = VB_EXP_TAB1K_N / (WAVE * HV);
+    double tt[NTB];
+#pragma unroll
+    for (int u = 0; u < NTB; ++u) tt[u] = c_exp2_tab1k[tid + u * WAVE * HV];
+#pragma unroll
+    for (int u = 0; u < NTB; ++u) TAB[tid + u * WAVE * HV] = tt[u];
+  }
+  __syncthreads();
 
 #define VBV(kt_, rr_, pv_) (VBL ? VBS[(((kt_) * 4 + (rr_)) * NPV + (pv_)) * WAVE + lane] : VB[VBL ? 0 : (kt_)][rr_][pv_])
   double accH = 0.0, accG[NPV], accLG[NPV];
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       if (X_EXP) {
 #pragma unroll
       for (int kt = 0; kt < KT - 1; ++kt) {
-        if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab4<1>(n[kt], TAB);
+        if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab1k4(n[kt], TAB);
         else n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
       }
       }
@@ -353,13 +363,13 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       } else if (SP && !((act >> (KT - 1)) & 1u)) {
         n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
       } else if (nr_last == 4) {
-        n[KT - 1] = vb_exp_tab4<1>(n[KT - 1], TAB);
+        n[KT - 1] = vb_exp_tab1k4(n[KT - 1], TAB);
       } else {  // registers whose four components are all padding stay exactly zero
         mf4 t = n[KT - 1];
         n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
-        n[KT - 1][0] = vb_exp_tab<1>(t[0], TAB);
-        if (nr_last > 1) n[KT - 1][1] = vb_exp_tab<1>(t[1], TAB);
-        if (nr_last > 2) n[KT - 1][2] = vb_exp_tab<1>(t[2], TAB);
+        n[KT - 1][0] = vb_exp_tab1k(t[0], TAB);
+        if (nr_last > 1) n[KT - 1][1] = vb_exp_tab1k(t[1], TAB);
+        if (nr_last > 2) n[KT - 1][2] = vb_exp_tab1k(t[2], TAB);
       }
       if (GRAD) {
         // ---- PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.
