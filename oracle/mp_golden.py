@@ -11,6 +11,8 @@ Formulas follow (reference paths, acerbilab/vbmc v1.0.12):
   logjoint misc/gplogjoint.m:97-413 (negquad mean, meanfun id 4; also 0 and 1)
   gp_post  gplite/private/gplite_core.m:33-102,278-291
   gp_pred  gplite/gplite_pred.m:52-165
+  pred     gplite/gplite_noisefun.m:176-210 + gplite_core.m:33-102 + gplite_pred.m:60-127 with the general noise models,
+           ystar / s2star and the log predictive density lp (mp_pred_case*.json)
   nlZ      gplite/private/gplite_core.m:205 (value); its gradient (:236-275) is pinned by 50-digit central
            differences of the value, i.e. independently of the reference's analytic Q-matrix formulas
 
@@ -21,6 +23,7 @@ the expected outputs, so the fixtures are self-contained data.
 from __future__ import annotations
 
 import json
+import math
 import os
 import sys
 
@@ -349,6 +352,130 @@ def run_nlz_case(c):
     return out
 
 
+
+# ------------------------------------------------------------------ prediction with the general noise models
+def mp_noise(hyp_noise, noisefun, yv, s2v, n):
+    """gplite/gplite_noisefun.m:176-210 for n points: constant + provided (scaled) s2 + output-dependent term."""
+    idx = 0
+    if noisefun[0] == 1:
+        sn2 = [mp.e ** (2 * hyp_noise[idx])] * n
+        idx += 1
+    else:
+        sn2 = [mp.mpf(2) ** -52] * n
+    if noisefun[1] == 1:
+        sn2 = [sn2[i] + s2v[i] for i in range(n)]
+    elif noisefun[1] == 2:
+        sn2 = [sn2[i] + mp.e ** hyp_noise[idx] * s2v[i] for i in range(n)]
+        idx += 1
+    if noisefun[2] == 1 and yv is not None:
+        yth, w2 = hyp_noise[idx], mp.e ** (2 * hyp_noise[idx + 1])
+        sn2 = [sn2[i] + w2 * max(mp.mpf(0), yth - yv[i]) ** 2 for i in range(n)]
+    return sn2
+
+
+def mp_pred_general(hyp, X, y, s2, Xs, ystar, s2star, meanfun, noisefun):
+    """gplite_post + gplite_pred from the definitions (gplite_core.m:33-102 is algebraically alpha = (K + diag(sn2))^-1 (y - m)
+    in BOTH its Lchol branches, gplite_pred.m:83-121 is fmu = m* + ks' alpha, fs2 = kss - ks' (K + diag(sn2))^-1 ks,
+    ys2 = fs2 + sn2*, lp the Gaussian log density of ystar): one hyper-sample, 50 digits, no jitter retries (sn2_mult = 1)."""
+    N, D = len(X), len(X[0])
+    nn = int(noisefun[0] == 1) + int(noisefun[1] == 2) + 2 * int(noisefun[2] == 1)
+    ell = [mp.e ** hyp[d] for d in range(D)]
+    sf2 = mp.e ** (2 * hyp[D])
+    hyp_noise, hyp_mean = hyp[D + 1 : D + 1 + nn], hyp[D + 1 + nn :]
+    sn2 = mp_noise(hyp_noise, noisefun, y, s2, N)
+    kern = lambda p, q: sf2 * mp.e ** (-mp.fsum(((p[d] - q[d]) / ell[d]) ** 2 for d in range(D)) / 2)  # noqa: E731
+    A = [[kern(X[a], X[b]) + (sn2[a] if a == b else 0) for b in range(N)] for a in range(N)]
+    R = mp_chol_upper(A)
+    r = [y[n] - mp_meanfun(hyp_mean, X[n], meanfun, D) for n in range(N)]
+    alpha = mp_solve_ut(R, mp_solve_ut_t(R, r))
+    sn2s = mp_noise(hyp_noise, noisefun, ystar, s2star, len(Xs))
+    fmu, fs2, ys2, lp = [], [], [], []
+    for i, xs in enumerate(Xs):
+        ks = [kern(X[n], xs) for n in range(N)]
+        fmu.append(mp_meanfun(hyp_mean, xs, meanfun, D) + mp.fsum(ks[n] * alpha[n] for n in range(N)))
+        v = mp_solve_ut_t(R, ks)
+        fs2.append(max(sf2 - mp.fsum(t * t for t in v), mp.mpf(0)))
+        ys2.append(fs2[-1] + sn2s[i])
+        lp.append(-(ystar[i] - fmu[-1]) ** 2 / ys2[-1] / 2 - mp.log(2 * mp.pi * ys2[-1]) / 2)
+    return alpha, fmu, fs2, ys2, lp, min(sn2)
+
+
+PRED_CASES = [
+    # tiny constant noise: min(sn2) < 1e-6 -> the Lchol = false branch (L = -inv(K + sn2 I), gplite_core.m:84-98)
+    dict(seed=31, D=2, N=8, S=2, meanfun=4, noisefun=(1, 0, 0), logsn=math.log(5e-4)),
+    dict(seed=32, D=3, N=9, S=2, meanfun=1, noisefun=(1, 1, 0), logsn=math.log(5e-2)),   # provided s2 (heteroscedastic Lchol branch)
+    dict(seed=33, D=2, N=7, S=1, meanfun=4, noisefun=(1, 2, 0), logsn=math.log(3e-2)),   # scaled s2
+    dict(seed=34, D=3, N=10, S=2, meanfun=0, noisefun=(1, 1, 1), logsn=math.log(5e-2)),  # + output-dependent noise (needs ystar)
+    dict(seed=35, D=2, N=9, S=2, meanfun=4, noisefun=(1, 0, 1), logsn=math.log(2e-2)),
+]
+
+
+def make_pred_case(seed, D, N, S, meanfun, noisefun, logsn):
+    rng = np.random.default_rng(seed)
+    X = 1.5 * rng.standard_normal((N, D))
+    y = -0.5 * np.sum((X / 1.3) ** 2, axis=1) + 0.3 * np.sin(X[:, 0]) + 0.05 * rng.standard_normal(N)
+    s2 = 0.01 + 0.05 * rng.random(N) if noisefun[1] else None
+    Ns = 5
+    Xstar = 1.2 * rng.standard_normal((Ns, D))
+    Xstar[0] = X[1] + 1e-3                       # next to a training input
+    ystar = -0.5 * np.sum((Xstar / 1.3) ** 2, axis=1) + 0.2 * rng.standard_normal(Ns)
+    s2star = 0.01 + 0.05 * rng.random(Ns) if noisefun[1] else None
+    nnoise = int(noisefun[0] == 1) + int(noisefun[1] == 2) + 2 * int(noisefun[2] == 1)
+    nmean = {0: 0, 1: 1, 4: 2 * D + 1}[meanfun]
+    hyp = np.zeros((D + 1 + nnoise + nmean, S))
+    for s in range(S):
+        hyp[:D, s] = np.log(0.8) + 0.2 * rng.standard_normal(D)
+        hyp[D, s] = np.log(np.std(y)) + 0.1 * rng.standard_normal()
+        o = D + 1
+        hyp[o, s] = logsn + 0.1 * rng.standard_normal()
+        o += 1
+        if noisefun[1] == 2:
+            hyp[o, s] = 0.3 * rng.standard_normal()
+            o += 1
+        if noisefun[2] == 1:
+            hyp[o, s] = np.median(y) + 0.1 * rng.standard_normal()      # threshold: about half of the outputs below it
+            hyp[o + 1, s] = np.log(0.3) + 0.1 * rng.standard_normal()
+            o += 2
+        if meanfun >= 1:
+            hyp[o, s] = np.max(y) + 0.1 * rng.standard_normal()
+        if meanfun == 4:
+            hyp[o + 1 : o + 1 + D, s] = 0.2 * rng.standard_normal(D)
+            hyp[o + 1 + D :, s] = np.log(2.0) + 0.1 * rng.standard_normal(D)
+    return dict(seed=seed, D=D, N=N, S=S, meanfun=meanfun, noisefun=list(noisefun), X=X, y=y, s2=s2, hyp=hyp, Xstar=Xstar,
+                ystar=ystar, s2star=s2star)
+
+
+def run_pred_case(c):
+    N, D = c["X"].shape
+    X = [[M(c["X"][n, d]) for d in range(D)] for n in range(N)]
+    y = [M(t) for t in c["y"]]
+    s2 = None if c["s2"] is None else [M(t) for t in c["s2"]]
+    Xs = [[M(c["Xstar"][i, d]) for d in range(D)] for i in range(c["Xstar"].shape[0])]
+    ystar = [M(t) for t in c["ystar"]]
+    s2star = None if c["s2star"] is None else [M(t) for t in c["s2star"]]
+    out = {k: [] for k in ("alpha", "fmu", "fs2", "ys2", "lp", "min_sn2")}
+    for s in range(c["S"]):
+        hyp = [M(t) for t in c["hyp"][:, s]]
+        alpha, fmu, fs2, ys2, lp, mn = mp_pred_general(hyp, X, y, s2, Xs, ystar, s2star, c["meanfun"], c["noisefun"])
+        for k, v in zip(("alpha", "fmu", "fs2", "ys2", "lp", "min_sn2"), (alpha, fmu, fs2, ys2, lp, mn)):
+            out[k].append(fl(v))
+    return out
+
+
+def main_pred():
+    outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    for i, spec in enumerate(PRED_CASES):
+        c = make_pred_case(**spec)
+        out = run_pred_case(c)
+        rec = {"generator": "oracle/mp_golden.py pred (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps),
+               "inputs": {k: (tolist(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()},
+               "expected": out}
+        path = os.path.join(outdir, "mp_pred_case%d.json" % i)
+        with open(path, "w") as f:
+            json.dump(rec, f)
+        print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
+
+
 # ------------------------------------------------------------------ driver
 def tolist(a):
     return np.asarray(a, dtype=np.float64).tolist()
@@ -571,9 +698,12 @@ def main_nlz():
 if __name__ == "__main__":
     if "nlz" in sys.argv[1:]:
         main_nlz()      # only the marginal-likelihood fixtures
+    elif "pred" in sys.argv[1:]:
+        main_pred()
     elif "acq" in sys.argv[1:]:
         main_acq()      # only the acquisition-function fixtures
     else:
         main()
         main_nlz()
         main_acq()
+        main_pred()

@@ -33,6 +33,19 @@ def load_nlz_golden(path):
     return gp, np.array(inp["hyp"], dtype=np.float64), {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
 
 
+def pred_golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "mp_pred_case*.json")))
+
+
+def load_pred_golden(path):
+    """-> (inputs dict with arrays / None, expected dict of S x ... arrays): prediction with the general noise models."""
+    with open(path) as f:
+        rec = json.load(f)
+    inp = {k: (np.array(v, dtype=np.float64) if isinstance(v, list) and k != "noisefun" else v) for k, v in rec["inputs"].items()}
+    inp["noisefun"] = tuple(inp["noisefun"])
+    return inp, {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
+
+
 def acq_golden_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, "mp_acq_case*.json")))
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import vbmc_ref as R
-from tests._cases import golden_cases, load_golden, synth_problem
+from tests._cases import golden_cases, load_golden, load_pred_golden, pred_golden_cases, synth_problem
 from tests.test_gpu_elbo import relerr
 
 pytestmark = pytest.mark.gpu
@@ -244,3 +244,23 @@ def test_pred_log_predictive_density(va):
         assert d[4].shape == (40, 3) and relerr(d[4], o[4]) < 1e-8
         assert relerr(d[0], o[0]) < 1e-9 and np.asarray(d[0]).shape == np.asarray(o[0]).shape
     assert va.gplite_pred(gp, Xs, None, None, True, nargout=5)[4] is None
+
+
+@pytest.mark.parametrize("path", pred_golden_cases())
+def test_pred_general_noise_golden(va, path):
+    """Device gplite_post + gplite_pred(gp,Xstar,ystar,s2star,1) with every noise model of gplite_noisefun.m:176-210
+    (incl. the output-dependent term, which needs ystar at the test points) and lp, on both Lchol branches, against the
+    50-digit vectors tests/golden/mp_pred_case*.json."""
+    from tests.test_oracle_golden import check_pred_against_golden
+    inp, exp = load_pred_golden(path)
+    gp = va.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, inp["meanfun"], inp["noisefun"], inp["s2"])
+    out = va.gplite_pred(gp, inp["Xstar"], inp["ystar"], inp["s2star"], True, nargout=5)
+    check_pred_against_golden(gp, out, exp, bool(np.min(exp["min_sn2"]) >= 1e-6))
+    # averaged outputs (gplite_pred.m:154-165) from the per-sample vectors
+    S = exp["fmu"].shape[0]
+    if S > 1:
+        ymu, ys2, fmu, fs2 = va.gplite_pred(gp, inp["Xstar"], inp["ystar"], inp["s2star"], False)
+        fbar = np.mean(exp["fmu"], axis=0)
+        assert relerr(fmu, fbar) < 1e-8 and relerr(ymu, fbar) < 1e-8
+        assert relerr(fs2, np.mean(exp["fs2"], axis=0) + np.var(exp["fmu"], axis=0, ddof=1)) < 1e-8
+        assert relerr(ys2, np.mean(exp["ys2"], axis=0) + np.var(exp["fmu"], axis=0, ddof=1)) < 1e-8

@@ -3,8 +3,8 @@ import numpy as np
 import pytest
 
 from oracle import vbmc_ref as R
-from tests._cases import (acq_golden_cases, golden_cases, load_acq_golden, load_golden, load_nlz_golden, nlz_golden_cases,
-                          vp_from_inputs)
+from tests._cases import (acq_golden_cases, golden_cases, load_acq_golden, load_golden, load_nlz_golden, load_pred_golden,
+                          nlz_golden_cases, pred_golden_cases, vp_from_inputs)
 
 RTOL = 1e-11  # fp64 restatement vs 50-digit evaluation; sums of <= ~100 terms
 
@@ -131,3 +131,26 @@ def test_oracle_acquisition_vs_mpmath(path):
         tol = 1e-9 if name == "acqviqr" else 1e-11
         assert np.max(np.abs(acq - exp[name]) / np.maximum(1e-300, np.abs(exp[name]))) < tol, name
         assert np.max(np.abs(fbar - exp["fbar"])) < 1e-11 and np.max(np.abs(vtot - exp["vtot"]) / exp["vtot"]) < 1e-10
+
+
+def check_pred_against_golden(gp, out, exp, lchol_expected):
+    """shared by the oracle test here and the device test (tests/test_gpu_gplite.py): alpha, ymu, ys2, fmu, fs2, lp of
+    gplite_post + gplite_pred(gp,Xstar,ystar,s2star,1) against tests/golden/mp_pred_case*.json.  Relative to max(1, |.|);
+    the low-noise case (min sn2 = 2.6e-7, condition number ~1e7) is compared at 1e-8, the others at 1e-11."""
+    tol = 1e-11 if lchol_expected else 1e-8
+    for s, post in enumerate(gp["post"]):
+        assert bool(post["Lchol"]) == lchol_expected and post["sn2_mult"] == 1.0
+        close(post["alpha"], exp["alpha"][s], rtol=tol)
+    ymu, ys2, fmu, fs2, lp = out
+    for got, key in ((ymu, "fmu"), (ys2, "ys2"), (fmu, "fmu"), (fs2, "fs2"), (lp, "lp")):
+        close(np.asarray(got).reshape(exp[key].T.shape), exp[key].T, rtol=tol)   # S = 1: a column either way
+
+
+@pytest.mark.parametrize("path", pred_golden_cases())
+def test_pred_general_noise_matches_mpmath(path):
+    """gplite_noisefun.m:176-210 (constant, provided / scaled s2, output-dependent term), both branches of
+    gplite_core.m:67-100 and gplite_pred.m:60-127 with ystar, s2star and lp."""
+    inp, exp = load_pred_golden(path)
+    gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"], noisefun=inp["noisefun"], s2=inp["s2"])
+    out = R.gplite_pred(gp, inp["Xstar"], inp["ystar"], inp["s2star"], True, nargout=5)
+    check_pred_against_golden(gp, out, exp, bool(np.min(exp["min_sn2"]) >= 1e-6))

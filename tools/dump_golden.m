@@ -3,7 +3,7 @@ function dump_golden(repo_root, vbmc_root)
 %
 %   dump_golden('/path/to/this/repo', '/path/to/vbmc')
 %
-% For every tests/golden/mp_case*.json, mp_nlz_case*.json and mp_acq_case*.json this runs the reference's own functions
+% For every tests/golden/mp_case*.json, mp_nlz_case*.json, mp_pred_case*.json and mp_acq_case*.json this runs the reference's own functions
 % (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ, acqf/acqflog/acqus/acqfsn2/acqviqr_vbmc) on the stored
 % inputs and writes tests/golden/matlab_case*.json / matlab_nlz_case*.json / matlab_acq_case*.json next to them.  tools/compare_matlab_golden.py then
 % compares those files with the mpmath vectors (and thereby with the oracle and the HIP path, which are pinned to
@@ -62,6 +62,24 @@ for f = 1:numel(files)
     for s = 1:S
         [out.nlZ(s),g] = gplite_nlZ(hyp(:,s),gp,[]);
         out.dnlZ(s,:) = g(:)';
+    end
+    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+end
+% prediction with the general noise models (gplite_noisefun.m:176-210), ystar / s2star and the log predictive density
+files = dir(fullfile(gold,'mp_pred_case*.json'));
+for f = 1:numel(files)
+    rec = jsondecode(fileread(fullfile(gold,files(f).name)));
+    in = rec.inputs; D = in.D; S = in.S;
+    X = reshape_rows(in.X,D); y = in.y(:); hyp = reshape_rows(in.hyp,S);
+    s2 = []; if ~isempty(in.s2); s2 = in.s2(:); end
+    s2star = []; if ~isempty(in.s2star); s2star = in.s2star(:); end
+    gp = gplite_post(hyp,X,y,1,in.meanfun,in.noisefun(:)',s2);
+    Xs = reshape_rows(in.Xstar,D);
+    [~,ys2,fmu,fs2,lp] = gplite_pred(gp,Xs,in.ystar(:),s2star,1,0);
+    out = struct('fmu',fmu','fs2',fs2','ys2',ys2','lp',lp','alpha',zeros(S,size(X,1)),'min_sn2',zeros(1,S));
+    for s = 1:S
+        out.alpha(s,:) = gp.post(s).alpha';
+        out.min_sn2(s) = 1/gp.post(s).sW(1)^2/gp.post(s).sn2_mult;     % gplite_core.m:281
     end
     write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
 end

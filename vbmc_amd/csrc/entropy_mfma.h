@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       // one loop body for both signs (two copies would not fit the register budget); the second sign's exponents are MOVED
       // into n on the back edge -- written as a conditional at the loop head the compiler turns them into 32 selects per sign
       int sg = 0;
-      double sgn = 1.0;
+      double ssig = sigj;          // +-sigma_j
 #pragma unroll 1
       for (;;) {
       if (!EO) {   // plain S-step of this sign: KT independent accumulator chains
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
 #pragma unroll
         for (int q = 0; q < QS; ++q) {
           const int cc = 4 * q + lg;
-          sf[q] = (cc < D) ? sgn * ev[q] * sigj : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
+          sf[q] = (cc < D) ? ssig * ev[q] : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -448,10 +448,10 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
             if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
             const int d = 16 * pv + li - 2;
             if (d >= 0 && d < D) {
-              const double e = sgn * Et[i * DP + d];
-              const double gd = (e * sigj * Av - Y[pv][rr]) * rq;  // lambda_d lsum_d / q  (:77-79)
+              const double t = ssig * Et[i * DP + d];              // u'_id = +-eps_id sigma_j
+              const double gd = (t * Av - Y[pv][rr]) * rq;         // lambda_d lsum_d / q  (:77-79)
               accG[pv] += gd;                                      // -> mu_grad (:82)
-              accLG[pv] = fma(e, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93)
+              accLG[pv] = fma(t, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93), times sigma_j (divided out at the end)
             }
           }
         }
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       }
       if (sg) break;
       sg = 1;
-      sgn = -1.0;
+      ssig = -sigj;
       if (EO) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
     double sgsum = 0.0;
 #pragma unroll
     for (int pv = 0; pv < NPV; ++pv) {
-      double g = accG[pv], lgd = accLG[pv];
+      double g = accG[pv], lgd = accLG[pv] / sigj;   // accLG carried u' = eps sigma_j in place of eps
       g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
       lgd += __shfl_xor(lgd, 16, 64); lgd += __shfl_xor(lgd, 32, 64);
       const int d = 16 * pv + li - 2;
