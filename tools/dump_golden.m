@@ -5,7 +5,7 @@ function dump_golden(repo_root, vbmc_root)
 %
 % For every tests/golden/mp_case*.json, mp_nlz_case*.json, mp_pred_case*.json and mp_acq_case*.json this runs the reference's own functions
 % (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ, acqf/acqflog/acqus/acqfsn2/acqviqr_vbmc) on the stored
-% inputs and writes tests/golden/matlab_case*.json / matlab_nlz_case*.json / matlab_acq_case*.json next to them.  tools/compare_matlab_golden.py then
+% inputs and writes tests/golden/matlab_case*.json / matlab_nlz_case*.json / matlab_pred_case*.json / matlab_acq_case*.json next to them.  tools/compare_matlab_golden.py then
 % compares those files with the mpmath vectors (and thereby with the oracle and the HIP path, which are pinned to
 % the mpmath vectors by the test-suite).  Nothing here is needed by CI: the development container has no MATLAB,
 % which is exactly why the oracle is documented as "parity unpinned by the reference" -- this script is how a
