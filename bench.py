@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--shard-s", action="store_true",
                     help="fewer restarts than GPUs (SURVEY 8e): every step is ONE batch of --restarts evaluations sharded over the ranks "
                          "along the GP hyper-sample axis and the entropy sample chunks (strong scaling, bit-identical to 1 GPU)")
+    ap.add_argument("--sync-steps", action="store_true", help="one blocking vbmc_elbo_batch call per step instead of the pipelined submit / collect")
     ap.add_argument("--check-launch", action="store_true",
                     help="rendezvous only: every rank reports (rank, pid, device) through an all-gather and rank 0 prints them; no GPU work")
     args = ap.parse_args()
@@ -264,14 +265,42 @@ def main():
             return out, order
         return out, None
 
-    for i in range(args.warmup):
-        step(i)
+    # The steps are independent batches (the sieve's candidates, misc/vpsieve_vbmc.m:74-78: batch i + 1 does not depend on the
+    # result of batch i), so by default they go through the pipelined form of the same ABI call -- vbmc_elbo_submit /
+    # vbmc_elbo_collect, two batches in flight: the host stages theta of step i + 1 while the device works on step i.  Every
+    # step still moves its theta H2D, runs the full pass and moves (F, dF) D2H, and every step's results are consumed (the
+    # all-gather + sort of the sieve when world > 1) before the timed region ends.  --sync-steps: one blocking call per step.
+    pipelined = shard_ex is None and not args.sync_steps
+
+    def finish(slot):
+        F_, dF_ = objective.collect(slot)
+        o = {"F": F_, "dF": dF_}
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, torch.from_numpy(F_).to(cdev))
+            torch.argsort(gathered, stable=True)  # every rank: identical sieve order
+        return o
+
+    def run_steps(i0, n):
+        o, pend = None, []
+        if not pipelined:
+            for i in range(n):
+                o, _ = step(i0 + i)
+            return o
+        for i in range(n):
+            objective.submit(thetas, seed=(rank << 32) + i0 + i, slot=i & 1)
+            pend.append(i & 1)
+            if len(pend) == 2:
+                o = finish(pend.pop(0))
+        while pend:
+            o = finish(pend.pop(0))
+        return o
+
+    run_steps(0, args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out, _ = step(args.warmup + i)
+    out = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -438,6 +467,20 @@ def main():
                 aux[name] = v
         aux["gplite_pred_8192_gflop"] = S * 8192.0 * N * N / 1e9    # S N* N^2 flops: two per multiply-add of the triangle inv(L') (sW Ks)
 
+    def sync_leg():
+        """the same steps as one blocking call each (round 1's stepping): what a DEPENDENT sequence of batches gets"""
+        n = max(5, min(args.steps, 20))
+        step(0)
+        t1 = time.perf_counter()
+        for i in range(n):
+            step(1000 + i)
+        return 1e3 * (time.perf_counter() - t1) / n
+
+    if rank == 0 and pipelined and world == 1:
+        v = leg("sync_steps", sync_leg)
+        if v is not None:
+            extra["blocking_call_ms_per_step"] = v
+            extra["blocking_call_evals_per_s"] = Rr / (v * 1e-3)
     if rank == 0:
         roof = leg("roofline", roofline_leg)
         if args.extras:
@@ -471,7 +514,9 @@ def main():
                                    "value+gradient, beta=0, no variance" % (3 if world > 1 else 2, D, N, K, Ns, S, Rr),
                        "restarts_per_gpu": Rr,
                        "parallelism": ("hyper-sample x sample-chunk sharded x%d (one batch of %d), all-gather of the partial records" % (world, Rr))
-                       if shard_ex is not None else "restart-sharded x%d, all-gather of ELCBO" % world},
+                       if shard_ex is not None else "restart-sharded x%d, all-gather of ELCBO" % world,
+                       "stepping": ("pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, two in flight; every step moves "
+                                    "its theta H2D and its (F, dF) D2H" if pipelined else "one blocking vbmc_elbo_batch call per step")},
             "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if world > 1 else None),
             "world_size_observed": (dist.get_world_size() if world > 1 else 1),
             "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],

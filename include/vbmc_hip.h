@@ -246,6 +246,25 @@ typedef struct vbmc_elbo_args {
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
 
 /*
+ * The same pass, pipelined, for a stream of INDEPENDENT batches -- the candidates of the sieve are evaluated one after the
+ * other with no dependence between them (misc/vpsieve_vbmc.m:74-78), and so are the full-ELCBO re-evaluations of
+ * misc/vpoptimize_vbmc.m:134-165:
+ *   vbmc_elbo_submit   validates and stages the inputs of one batch in the slot's own pinned block, enqueues the H2D, the
+ *                      kernels and the packed D2H on the context's stream and returns WITHOUT waiting;
+ *   vbmc_elbo_collect  waits for that slot's pass and fills the outputs named in args (F, dF, G, H, dG, dH, varG, varGss).
+ * Two slots (0 and 1): while the device works on one batch the host stages the next, so that the device never waits for the
+ * host between batches.  Measured: 2.82 -> 2.77 ms per batch of 64 at the headline shape (the device is busy 98 % of a
+ * blocking call already), 113 -> 103 us per single evaluation; the batches still execute one after the other on the
+ * context's stream, so the chain of dependent kernels inside a small batch is not hidden.  Passes execute in submission order; each
+ * slot must be collected before it is submitted again.  Results are bit-identical to vbmc_elbo_batch with the same args.
+ * Not offered here: separate_K / I_sk / J_sjk / G_s / varG_s outputs and host-resident draws (eps_mode 1) -- their copies
+ * go through pageable memory; use vbmc_elbo_batch.  Other entry points of the same context may be called between a submit and
+ * its collect (they queue behind it on the stream).
+ */
+vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int slot);
+vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* args, int slot);
+
+/*
  * ONE evaluation (or a batch with fewer restarts than GPUs) sharded over `world` ranks, one process per GPU, each with a
  * full replica of the surrogate: rank g evaluates the expected-log-joint records of its hyper-samples (the iterations of
  * misc/gplogjoint.m:98 are independent until the averaging at :399-413) and the Monte-Carlo entropy partials of its share

@@ -1,0 +1,105 @@
+"""vbmc_elbo_submit / vbmc_elbo_collect (include/vbmc_hip.h): the pipelined form of the batched evaluation for streams of
+independent batches (the sieve's candidates, misc/vpsieve_vbmc.m:74-78).  Bit-identical to vbmc_elbo_batch, in order, with
+other entry points of the same context called in between; misuse is refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._cases import synth_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+def setup(va, seed, D, N, K, S, Rr):
+    p = synth_problem(seed, D, N, K, S)
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, p["meanfun"])
+    vp = va.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    rng = np.random.default_rng(seed)
+    batches = [np.asfortranarray(theta[:, None] + 0.05 * rng.standard_normal((theta.size, Rr))) for _ in range(5)]
+    return p, gp, vp, batches
+
+
+@pytest.mark.parametrize("cfg", [(4, 40, 5, 3, 8, 200), (10, 120, 50, 4, 16, 1000), (3, 30, 70, 2, 4, 64), (5, 50, 6, 2, 3, 0)])
+def test_pipelined_batches_are_bit_identical_and_in_order(va, cfg):
+    D, N, K, S, Rr, Ns = cfg
+    p, gp, vp, batches = setup(va, 3, D, N, K, S, Rr)
+    T = batches[0].shape[0]
+    obj = va.PreparedObjective(T, Rr, 0, vp, gp, Ns, 0, None)
+    ref = []
+    for i, th in enumerate(batches):
+        F, dF = obj(th, seed=100 + i)
+        ref.append((F.copy(), dF.copy()))
+    got = list(obj.stream(batches, seeds=[100 + i for i in range(len(batches))]))
+    assert len(got) == len(ref)
+    for (F, dF), (Fr, dFr) in zip(got, ref):
+        assert np.array_equal(F, Fr) and np.array_equal(dF, dFr)
+    # against the oracle too (entropy on the dumped device stream), first batch, first restart
+    if Ns > 0:
+        eps = va.default_engine().ctx.rng_dump(D, K, 1, Ns, 100)[0]
+        gpo = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"])
+        o = R.negelcbo_vbmc(batches[0][:, 0], 0, vp, gpo, Ns, True, 0, eps=eps)
+        assert abs(got[0][0][0] - o["F"]) < 1e-9 * max(1.0, abs(o["F"]))
+        assert np.max(np.abs(got[0][1][:, 0] - o["dF"])) < 1e-8 * max(1.0, np.max(np.abs(o["dF"])))
+
+
+def test_other_calls_between_submit_and_collect(va):
+    """A synchronous evaluation, a prediction and a posterior update issued while two passes are in flight queue behind them on
+    the stream; the collected results are those of the submitted batches."""
+    p, gp, vp, batches = setup(va, 5, 6, 80, 12, 3, 8)
+    T = batches[0].shape[0]
+    obj = va.PreparedObjective(T, 8, 0, vp, gp, 400, 0, None)
+    ref = [tuple(x.copy() for x in obj(th, seed=7 + i)) for i, th in enumerate(batches[:2])]
+    obj.submit(batches[0], seed=7, slot=0)
+    obj.submit(batches[1], seed=8, slot=1)
+    other = va.negelcbo_batch(batches[2], 0, vp, gp, 400, True, 0, seed=9)          # synchronous call on the same context
+    Xs = np.random.default_rng(0).standard_normal((33, 6))
+    pred = va.gplite_pred(gp, Xs, None, None, False)
+    gp2 = va.gplite_post(p["hyp"], p["X"], p["y"] + 0.1, 1, p["meanfun"])
+    F1, dF1 = obj.collect(1)                                                        # any order
+    F0, dF0 = obj.collect(0)
+    assert np.array_equal(F0, ref[0][0]) and np.array_equal(dF0, ref[0][1])
+    assert np.array_equal(F1, ref[1][0]) and np.array_equal(dF1, ref[1][1])
+    assert np.array_equal(other["F"], va.negelcbo_batch(batches[2], 0, vp, gp, 400, True, 0, seed=9)["F"])
+    assert np.all(np.isfinite(pred[2])) and gp2["post"][0]["alpha"].shape == (80,)
+
+
+def test_pipeline_misuse_is_refused(va):
+    p, gp, vp, batches = setup(va, 6, 3, 25, 4, 2, 4)
+    T = batches[0].shape[0]
+    obj = va.PreparedObjective(T, 4, 0, vp, gp, 100, 0, None)
+    ctx = va.default_engine().ctx
+    with pytest.raises(va.VbmcHipError, match="nothing submitted"):
+        obj.collect(0)
+    obj.submit(batches[0], seed=1, slot=0)
+    with pytest.raises(va.VbmcHipError, match="uncollected"):
+        obj.submit(batches[1], seed=2, slot=0)
+    with pytest.raises(va.VbmcHipError, match="slot must be 0 or 1"):
+        obj.submit(batches[1], seed=2, slot=2)
+    F, dF = obj.collect(0)
+    assert np.all(np.isfinite(F))
+    # per-component outputs are not offered through the pipelined form
+    a, _, _ = obj._slot(0)
+    b = type(a).from_buffer_copy(a)
+    b.separate_K = 1
+    b.compute_grad = 0
+    with pytest.raises(va.VbmcUnsupported):
+        ctx.check(ctx.lib.vbmc_elbo_submit(ctx.h, obj.dgp.h, C.byref(b), 0))
+    # a failed submit leaves the slot free
+    bad = batches[0].copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(va.VbmcHipError, match="non-finite"):
+        obj.submit(bad, seed=3, slot=0)
+    obj.submit(batches[0], seed=1, slot=0)
+    F2, _ = obj.collect(0)
+    assert np.array_equal(F2, F)

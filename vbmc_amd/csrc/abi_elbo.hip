@@ -50,6 +50,8 @@ extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out)
   return VBMC_OK;
 }
 
+static void elbo_plan_free(void* plan);   // (ElboPlan is defined further down)
+
 extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
@@ -62,6 +64,11 @@ extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
     if (b.p) (void)hipFree(b.p);
   for (vbmc_gp* g : ctx->null_gp) vbmc_gp_free(ctx, g);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  for (int sl = 0; sl < 2; ++sl) {
+    if (ctx->slot_pin[sl]) (void)hipHostFree(ctx->slot_pin[sl]);
+    if (ctx->slot_ev[sl]) (void)hipEventDestroy(ctx->slot_ev[sl]);
+    elbo_plan_free(ctx->slot_plan[sl]);
+  }
   if (ctx->bounce) (void)hipHostFree(ctx->bounce);
   for (auto& e : ctx->bounce_ev)
     if (e) (void)hipEventDestroy(e);
@@ -798,6 +805,38 @@ static vbmc_status null_gp_for(vbmc_ctx* ctx, int D, const vbmc_gp** out) {
   return VBMC_OK;
 }
 
+// The packed read-back of an enqueued pass into pinned memory (no synchronisation) ...
+static vbmc_status elbo_enqueue_readback(vbmc_ctx* ctx, const ElboPlan& P, const vbmc_elbo_args* a, double* hout) {
+  const int R = P.dm.R, T = P.dm.T;
+  // record per restart: [F G H varG varGss | dF (T) | dG (T) | dH (T)]; without dG / dH only the leading part moves
+  const size_t OSr = OUT_HDR + 3 * (size_t)T;
+  if (P.compute_grad && !a->dG && !a->dH && R > 1)
+    HIP_TRY(ctx, hipMemcpy2DAsync(hout, OSr * sizeof(double), P.d_out, OSr * sizeof(double), (OUT_HDR + (size_t)T) * sizeof(double), R,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+  else
+    HIP_TRY(ctx, hipMemcpyAsync(hout, P.d_out, P.out_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  return VBMC_OK;
+}
+
+// ... and, once it has landed, its unpacking into the caller's arrays
+static void elbo_unpack(const ElboPlan& P, const vbmc_elbo_args* a, const double* hout) {
+  const int R = P.dm.R, T = P.dm.T;
+  const size_t OS = OUT_HDR + 3 * (size_t)T;
+  for (int r = 0; r < R; ++r) {
+    const double* o = hout + (size_t)r * OS;
+    if (a->F) a->F[r] = o[0];
+    if (a->G) a->G[r] = o[1];
+    if (a->H) a->H[r] = o[2];
+    if (a->varG) a->varG[r] = o[3];
+    if (a->varGss) a->varGss[r] = o[4];
+    if (P.compute_grad) {
+      if (a->dF) memcpy(a->dF + (size_t)r * T, o + OUT_HDR, T * sizeof(double));
+      if (a->dG) memcpy(a->dG + (size_t)r * T, o + OUT_HDR + T, T * sizeof(double));
+      if (a->dH) memcpy(a->dH + (size_t)r * T, o + OUT_HDR + 2 * T, T * sizeof(double));
+    }
+  }
+}
+
 // One packed D2H of the results of an enqueued pass (+ I_sk / J_sjk / per-sample outputs when requested); synchronises.
 static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbmc_elbo_args* a) {
   const ElboDims& dm = P.dm;
@@ -808,15 +847,7 @@ static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbm
 
   // ---- results: one packed D2H (+ I_sk / J_sjk when requested)
   double* hout = (double*)ctx->pin + P.n_up;
-  {
-    // record per restart: [F G H varG varGss | dF (T) | dG (T) | dH (T)]; without dG / dH only the leading part moves
-    const size_t OSr = OUT_HDR + 3 * (size_t)T;
-    if (compute_grad && !a->dG && !a->dH && R > 1)
-      HIP_TRY(ctx, hipMemcpy2DAsync(hout, OSr * sizeof(double), P.d_out, OSr * sizeof(double), (OUT_HDR + (size_t)T) * sizeof(double), R,
-                                    hipMemcpyDeviceToHost, st));
-    else
-      HIP_TRY(ctx, hipMemcpyAsync(hout, P.d_out, P.out_n * sizeof(double), hipMemcpyDeviceToHost, st));
-  }
+  { vbmc_status s_ = elbo_enqueue_readback(ctx, P, a, hout); if (s_) return s_; }
   std::vector<double> ljh;
   if (a->separate_K && a->I_sk) {
     ljh.resize((size_t)R * S * K * LJS);
@@ -850,20 +881,7 @@ static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbm
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_lj_ms = ms;
     if (P.mc && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ent_ms = ms;
   }
-  const size_t OS = OUT_HDR + 3 * (size_t)T;
-  for (int r = 0; r < R; ++r) {
-    const double* o = hout + (size_t)r * OS;
-    if (a->F) a->F[r] = o[0];
-    if (a->G) a->G[r] = o[1];
-    if (a->H) a->H[r] = o[2];
-    if (a->varG) a->varG[r] = o[3];
-    if (a->varGss) a->varGss[r] = o[4];
-    if (compute_grad) {
-      if (a->dF) memcpy(a->dF + (size_t)r * T, o + OUT_HDR, T * sizeof(double));
-      if (a->dG) memcpy(a->dG + (size_t)r * T, o + OUT_HDR + T, T * sizeof(double));
-      if (a->dH) memcpy(a->dH + (size_t)r * T, o + OUT_HDR + 2 * T, T * sizeof(double));
-    }
-  }
+  elbo_unpack(P, a, hout);
   if (a->separate_K && a->I_sk) {
     for (int r = 0; r < R; ++r)
       for (int k = 0; k < K; ++k)
@@ -893,6 +911,63 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
   { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed); if (s_) return s_; }
   return elbo_read_results(ctx, P, a);
+}
+
+// ---- pipelined form for streams of independent batches (include/vbmc_hip.h): submit enqueues and returns, collect waits
+struct SlotPlan {
+  ElboPlan P;
+  double* hout = nullptr;
+};
+static void elbo_plan_free(void* plan) { delete (SlotPlan*)plan; }
+
+extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: null args");
+  if (slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slot must be 0 or 1");
+  if (ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slot %d holds an uncollected pass", slot);
+  if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_submit: per-component / per-hyper-sample outputs only through vbmc_elbo_batch");
+  if (a->eps_mode == 1)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_submit: host-resident draws (eps_mode 1) only through vbmc_elbo_batch");
+  if (!gp) {
+    if (a->compute_var != 0) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: an entropy-only call (gp == NULL) has no variance");
+    vbmc_status s_ = null_gp_for(ctx, a->D, &gp);
+    if (s_) return s_;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->slot_ev[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_ev[slot], hipEventDisableTiming));
+  if (!ctx->slot_plan[slot]) ctx->slot_plan[slot] = new SlotPlan();
+  SlotPlan* sp = (SlotPlan*)ctx->slot_plan[slot];
+  sp->P = ElboPlan{};
+  // the slot's own pinned block stands in for the context's while the inputs are staged and the copies are enqueued
+  std::swap(ctx->pin, ctx->slot_pin[slot]);
+  std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
+  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P);
+  if (!s_) s_ = elbo_enqueue(ctx, gp, sp->P, a->seed);
+  if (!s_) {
+    sp->hout = (double*)ctx->pin + sp->P.n_up;
+    s_ = elbo_enqueue_readback(ctx, sp->P, a, sp->hout);
+  }
+  std::swap(ctx->pin, ctx->slot_pin[slot]);
+  std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
+  if (s_) { (void)hipStreamSynchronize(ctx->stream); return s_; }   // nothing of a failed submit stays in flight
+  HIP_TRY(ctx, hipEventRecord(ctx->slot_ev[slot], ctx->stream));
+  ctx->slot_busy[slot] = true;
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (!a || slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: null args / slot not 0 or 1");
+  if (!ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: nothing submitted in slot %d", slot);
+  const SlotPlan* sp = (const SlotPlan*)ctx->slot_plan[slot];
+  if (a->D != sp->P.dm.D || a->K != sp->P.dm.K || a->R != sp->P.dm.R)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: args differ from the submitted ones (D, K, R)");
+  ctx->slot_busy[slot] = false;
+  hipError_t e_ = hipEventSynchronize(ctx->slot_ev[slot]);
+  if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_collect: %s", hipGetErrorString(e_)); }
+  elbo_unpack(sp->P, a, sp->hout);
+  return VBMC_OK;
 }
 
 // ---- one evaluation sharded over `world` ranks along the hyper-sample axis and the entropy sample chunks (see ShardSpec)

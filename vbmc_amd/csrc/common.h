@@ -48,6 +48,13 @@ struct vbmc_ctx {
   double last_ent_ms = 0.0, last_lj_ms = 0.0;
   std::vector<PoolBlk> pool;
   size_t pool_bytes = 0;
+  // pipelined evaluations (vbmc_elbo_submit / vbmc_elbo_collect, abi_elbo.hip): each of the two slots has its own pinned
+  // staging block (swapped into `pin` for the duration of a submit), the plan of the pass in flight and its completion event
+  void* slot_pin[2] = {nullptr, nullptr};
+  size_t slot_pin_cap[2] = {0, 0};
+  hipEvent_t slot_ev[2] = {nullptr, nullptr};
+  void* slot_plan[2] = {nullptr, nullptr};     // ElboPlan*
+  bool slot_busy[2] = {false, false};
   // entropy-only evaluations (vbmc_elbo_batch with gp == NULL): a one-point surrogate with alpha = 0 and a zero mean
   // function per dimension, whose expected log joint is exactly 0
   vbmc_gp* null_gp[33] = {};

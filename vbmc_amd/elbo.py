@@ -377,6 +377,7 @@ class PreparedObjective:
         self.args.F = ptr(self.F)
         self.args.dF = ptr(self.dF)
         self._ref = C.byref(self.args)
+        self._slots = None
 
     def __call__(self, thetas, seed=0):
         np.copyto(self.theta, np.asarray(thetas, dtype=np.float64).reshape(self.theta.shape, order="F"))
@@ -384,6 +385,46 @@ class PreparedObjective:
         ctx = self.engine.ctx
         ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, self.dgp.h, self._ref))
         return self.F, self.dF
+
+    # ---- pipelined form (vbmc_elbo_submit / vbmc_elbo_collect): for streams of INDEPENDENT batches, e.g. the candidates of
+    # the sieve (misc/vpsieve_vbmc.m:74-78); the host stages batch i + 1 while the device works on batch i
+    def _slot(self, slot):
+        if self._slots is None:
+            self._slots = {}
+        if slot not in self._slots:
+            a = type(self.args).from_buffer_copy(self.args)      # same inputs, its own output buffers
+            F, dF = np.empty_like(self.F), np.empty_like(self.dF)
+            a.F, a.dF = ptr(F), ptr(dF)
+            self._slots[slot] = (a, F, dF)
+        return self._slots[slot]
+
+    def submit(self, thetas, seed=0, slot=0):
+        """Enqueue one batch in ``slot`` (0 or 1) and return without waiting; theta is copied before the call returns."""
+        a, _, _ = self._slot(slot)
+        np.copyto(self.theta, np.asarray(thetas, dtype=np.float64).reshape(self.theta.shape, order="F"))
+        a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        ctx = self.engine.ctx
+        ctx.check(ctx.lib.vbmc_elbo_submit(ctx.h, self.dgp.h, C.byref(a), int(slot)))
+
+    def collect(self, slot=0):
+        """Wait for the batch submitted in ``slot``; returns views of that slot's (F, dF) buffers."""
+        a, F, dF = self._slot(slot)
+        ctx = self.engine.ctx
+        ctx.check(ctx.lib.vbmc_elbo_collect(ctx.h, C.byref(a), int(slot)))
+        return F, dF
+
+    def stream(self, batches, seeds=None):
+        """Generator over an iterable of theta batches (T x R each): yields (F, dF) copies in order, two batches in flight."""
+        pending = []
+        for i, th in enumerate(batches):
+            self.submit(th, seed=(seeds[i] if seeds is not None else i), slot=i & 1)
+            pending.append(i & 1)
+            if len(pending) == 2:
+                F, dF = self.collect(pending.pop(0))
+                yield F.copy(), dF.copy()
+        while pending:
+            F, dF = self.collect(pending.pop(0))
+            yield F.copy(), dF.copy()
 
 
 def negelcbo_vbmc(theta, beta, vp, gp, Ns=0, compute_grad=None, compute_var=None, altent_flag=False, thetabnd=None,
