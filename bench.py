@@ -374,7 +374,7 @@ def main():
                 "kernel_ms": ent_ms, "flops_per_launch": Rr * f_ent, "exp_per_launch": Rr * P,
                 "note": "fp64 pipe bound: v_mfma_f64_16x16x4_f64 and fp64 VALU share one pipe on gfx950 (measured: no overlap), "
                         "dense fp64 peak 78.6 TFLOP/s for either.  achieved = algorithmic flops P(5D+7)+K*Ns(5D+4) per eval "
-                        "(SURVEY 8d) x R / kernel time; the P fp64 exp evaluations (9 fp64 ops each here) are NOT counted. "
+                        "(SURVEY 8d) x R / kernel time; the P fp64 exp evaluations (8 fp64 + 3 int VALU ops each here) are NOT counted. "
                         "traffic: device-RNG mode reads no O(Ns) data from HBM; the bytes are per-chunk partial records "
                         "(written once, reduced by k_ent_reduce) and the packed mixture parameters"}
 
