@@ -53,6 +53,14 @@ constexpr bool X_W = false;
 #else
 constexpr bool X_W = true;
 #endif
+// -DVBMC_STAG: both signs in straight-line code, the second sign's exponentials issued inside the first sign's per-sample
+// latency chain.  Measured (tools/ent_experiments.py, variants stag / now_stag / now): -2.1 % when the registers are there (weight
+// gradient compiled out) but 31 VGPRs spilled and +2.6 % in the product kernel -- off.
+#ifdef VBMC_STAG
+constexpr bool STAG = true;
+#else
+constexpr bool STAG = false;
+#endif
 #ifdef VBMC_EXP_NOS
 constexpr bool X_S = false;
 #else
@@ -331,164 +339,218 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       }
     }
 
-      // one loop body for both signs (two copies would not fit the register budget); the second sign's exponents are MOVED
-      // into n on the back edge -- written as a conditional at the loop head the compiler turns them into 32 selects per sign
-      int sg = 0;
-      double ssig = sigj;          // +-sigma_j
-#pragma unroll 1
-      for (;;) {
-      if (!EO) {   // plain S-step of this sign: KT independent accumulator chains
-        double sf[QS];
+    // ---- the phases of one sign as inlined pieces (x: the sign's exponents, overwritten by their exponentials)
+    auto exps = [&](mf4 (&x)[KT], auto k0c, auto k1c) {   // k-tiles k0 .. k1-1: 4 straight-line exps each
+      constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
+      if (!X_EXP) return;
 #pragma unroll
-        for (int q = 0; q < QS; ++q) {
-          const int cc = 4 * q + lg;
-          sf[q] = (cc < D) ? ssig * ev[q] : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
-        }
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+      for (int kt = k0; kt < k1; ++kt) {
+        if (kt < KT - 1) {
+          if (!SP || ((act >> kt) & 1u)) x[kt] = vb_exp_tab1k4(x[kt], TAB);
+          else x[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
+        } else if (SP && !((act >> (KT - 1)) & 1u)) {
+          x[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
+        } else if (nr_last == 4) {
+          x[KT - 1] = vb_exp_tab1k4(x[KT - 1], TAB);
+        } else {  // registers whose four components are all padding stay exactly zero
+          mf4 t = x[KT - 1];
+          x[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
+          x[KT - 1][0] = vb_exp_tab1k(t[0], TAB);
+          if (nr_last > 1) x[KT - 1][1] = vb_exp_tab1k(t[1], TAB);
+          if (nr_last > 2) x[KT - 1][2] = vb_exp_tab1k(t[2], TAB);
         }
       }
-      // ---- 4*KT straight-line exps
-      if (X_EXP) {
+    };
+    // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
+    auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg) {
+      mf4 Y2[NPV];
+#pragma unroll
+      for (int pv = 0; pv < NPV; ++pv) { Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; Y2[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
       for (int kt = 0; kt < KT - 1; ++kt) {
-        if (!SP || ((act >> kt) & 1u)) n[kt] = vb_exp_tab1k4(n[kt], TAB);
-        else n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
-      }
-      }
-      if (!X_EXP) {
-      } else if (SP && !((act >> (KT - 1)) & 1u)) {
-        n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
-      } else if (nr_last == 4) {
-        n[KT - 1] = vb_exp_tab1k4(n[KT - 1], TAB);
-      } else {  // registers whose four components are all padding stay exactly zero
-        mf4 t = n[KT - 1];
-        n[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
-        n[KT - 1][0] = vb_exp_tab1k(t[0], TAB);
-        if (nr_last > 1) n[KT - 1][1] = vb_exp_tab1k(t[1], TAB);
-        if (nr_last > 2) n[KT - 1][2] = vb_exp_tab1k(t[2], TAB);
-      }
-      if (GRAD) {
-        // ---- PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.
-        // Two accumulator sets halve the dependent MFMA chain.
-        mf4 Y[NPV], Y2[NPV];
-#pragma unroll
-        for (int pv = 0; pv < NPV; ++pv) { Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; Y2[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll
-        for (int kt = 0; kt < KT - 1; ++kt) {
-          if (SP && !((act >> kt) & 1u)) continue;
-          if (!X_PV) { Y[0] += n[kt]; continue; }
-#pragma unroll
-          for (int pv = 0; pv < NPV; ++pv) {
-            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][0], VBV(kt, 0, pv), Y[pv], 0, 0, 0);
-            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][1], VBV(kt, 1, pv), Y2[pv], 0, 0, 0);
-            Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][2], VBV(kt, 2, pv), Y[pv], 0, 0, 0);
-            Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[kt][3], VBV(kt, 3, pv), Y2[pv], 0, 0, 0);
-          }
-        }
+        if (SP && !((act >> kt) & 1u)) continue;
+        if (!X_PV) { Y[0] += x[kt]; continue; }
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
-          if (SP && !((act >> (KT - 1)) & 1u)) { Y[pv] += Y2[pv]; continue; }
-          if (!X_PV) { Y[pv] += n[KT - 1]; continue; }
-          Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][0], VBV(KT - 1, 0, pv), Y[pv], 0, 0, 0);
-          if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][1], VBV(KT - 1, 1, pv), Y2[pv], 0, 0, 0);
-          if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
-          if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(n[KT - 1][3], VBV(KT - 1, 3, pv), Y2[pv], 0, 0, 0);
-          Y[pv] += Y2[pv];
+          Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][0], VBV(kt, 0, pv), Y[pv], 0, 0, 0);
+          Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][1], VBV(kt, 1, pv), Y2[pv], 0, 0, 0);
+          Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][2], VBV(kt, 2, pv), Y[pv], 0, 0, 0);
+          Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][3], VBV(kt, 3, pv), Y2[pv], 0, 0, 0);
         }
-        if (HV > 1) {
-          // all shares of the mixture: the partial q', A', B' of every wave, added in wave order
+      }
 #pragma unroll
-          for (int pv = 0; pv < NPV; ++pv)
+      for (int pv = 0; pv < NPV; ++pv) {
+        if (SP && !((act >> (KT - 1)) & 1u)) { Y[pv] += Y2[pv]; continue; }
+        if (!X_PV) { Y[pv] += x[KT - 1]; continue; }
+        Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][0], VBV(KT - 1, 0, pv), Y[pv], 0, 0, 0);
+        if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][1], VBV(KT - 1, 1, pv), Y2[pv], 0, 0, 0);
+        if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
+        if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][3], VBV(KT - 1, 3, pv), Y2[pv], 0, 0, 0);
+        Y[pv] += Y2[pv];
+      }
+      if (HV > 1) {
+        // all shares of the mixture: the partial q', A', B' of every wave, added in wave order
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) YX[(sg * HV + hv) * YXN + (pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
-          __syncthreads();
+        for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-          for (int pv = 0; pv < NPV; ++pv)
+          for (int rr = 0; rr < 4; ++rr) YX[(sg * HV + hv) * YXN + (pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
+        __syncthreads();
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              double t = YX[(sg * HV + 0) * YXN + (pv * 4 + rr) * WAVE + lane];
+        for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-              for (int w = 1; w < HV; ++w) t += YX[(sg * HV + w) * YXN + (pv * 4 + rr) * WAVE + lane];
-              Y[pv][rr] = t;
-            }
-        }
-        // ---- per-sample scalars in the sample layout (lane <-> sample li): q' from column 0
-        if (li == 0) {
+          for (int rr = 0; rr < 4; ++rr) {
+            double t = YX[(sg * HV + 0) * YXN + (pv * 4 + rr) * WAVE + lane];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) RQ[lg + 4 * rr] = Y[0][rr];
-        }
-        ent_sync<HV>();   // RQ is private to the wave
-        const double qs_ = svalid ? RQ[li] : 1.0;
-        const double rqs = svalid ? vb_rcp(qs_) : 0.0;
-        pm *= __builtin_amdgcn_frexp_mant(qs_);   // sum log q' = ln2 * sum exp + log(prod mant)
-        pe += __builtin_amdgcn_frexp_exp(qs_);
-        if (svalid) accH += shift;
+            for (int w = 1; w < HV; ++w) t += YX[(sg * HV + w) * YXN + (pv * 4 + rr) * WAVE + lane];
+            Y[pv][rr] = t;
+          }
+      }
+    };
+    // per-sample scalars in the sample layout (lane <-> sample li): q' from column 0, through LDS
+    auto put_q = [&](mf4 (&Y)[NPV]) {
+      if (li == 0) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          if (SP && !((act >> kt) & 1u)) continue;
+        for (int rr = 0; rr < 4; ++rr) RQ[lg + 4 * rr] = Y[0][rr];
+      }
+      ent_sync<HV>();   // RQ is private to the wave
+    };
+    auto get_rq = [&]() -> double {
+      const double qs_ = svalid ? RQ[li] : 1.0;
+      const double rqs = svalid ? vb_rcp(qs_) : 0.0;
+      pm *= __builtin_amdgcn_frexp_mant(qs_);   // sum log q' = ln2 * sum exp + log(prod mant)
+      pe += __builtin_amdgcn_frexp_exp(qs_);
+      if (svalid) accH += shift;
+      return rqs;
+    };
+    auto wacc = [&](mf4 (&x)[KT], double rqs) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) if (X_W || (kt == 0 && rr == 0)) Wacc[kt][rr] = fma(n[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
-        }
-        ent_sync<HV>();
-        if (lg == 0) RQ[li] = rqs;
-        ent_sync<HV>();
-        // ---- gradient pieces in the PV output layout
-        const int base = lane & 48;
+      for (int kt = 0; kt < KT; ++kt) {
+        if (SP && !((act >> kt) & 1u)) continue;
 #pragma unroll
-        for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
-          const int i = lg + 4 * rr;
-          const double Av = __shfl(Y[0][rr], base | 1, 64);    // A'_i  (column 1)
-          const double rq = RQ[i];
+        for (int rr = 0; rr < 4; ++rr) if (X_W || (kt == 0 && rr == 0)) Wacc[kt][rr] = fma(x[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
+      }
+    };
+    auto put_rq = [&](double rqs) {
+      ent_sync<HV>();
+      if (lg == 0) RQ[li] = rqs;
+      ent_sync<HV>();
+    };
+    // gradient pieces in the PV output layout
+    auto gradpieces = [&](mf4 (&Y)[NPV], double ssig) {
+      const int base = lane & 48;
 #pragma unroll
-          for (int pv = 0; pv < NPV; ++pv) {
-            if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
-            const int d = 16 * pv + li - 2;
-            if (d >= 0 && d < D) {
-              const double t = ssig * Et[i * DP + d];              // u'_id = +-eps_id sigma_j
-              const double gd = (t * Av - Y[pv][rr]) * rq;         // lambda_d lsum_d / q  (:77-79)
-              accG[pv] += gd;                                      // -> mu_grad (:82)
-              accLG[pv] = fma(t, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93), times sigma_j (divided out at the end)
-            }
+      for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
+        const int i = lg + 4 * rr;
+        const double Av = __shfl(Y[0][rr], base | 1, 64);    // A'_i  (column 1)
+        const double rq = RQ[i];
+#pragma unroll
+        for (int pv = 0; pv < NPV; ++pv) {
+          if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
+          const int d = 16 * pv + li - 2;
+          if (d >= 0 && d < D) {
+            const double t = ssig * Et[i * DP + d];              // u'_id = +-eps_id sigma_j
+            const double gd = (t * Av - Y[pv][rr]) * rq;         // lambda_d lsum_d / q  (:77-79)
+            accG[pv] += gd;                                      // -> mu_grad (:82)
+            accLG[pv] = fma(t, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93), times sigma_j (divided out at the end)
           }
         }
-        ent_sync<HV>();
-      } else {
-        double qp = 0.0;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
-        qp += __shfl_xor(qp, 16, 64);
-        qp += __shfl_xor(qp, 32, 64);
-        if (HV > 1) {
-          YX[(sg * HV + hv) * YXN + lane] = qp;
-          __syncthreads();
-          qp = YX[(sg * HV + 0) * YXN + lane];
-#pragma unroll
-          for (int w = 1; w < HV; ++w) qp += YX[(sg * HV + w) * YXN + lane];
-        }
-        const double qs_ = svalid ? qp : 1.0;
-        pm *= __builtin_amdgcn_frexp_mant(qs_);
-        pe += __builtin_amdgcn_frexp_exp(qs_);
-        if (svalid) accH += shift;
       }
-      // fold the mantissa product before it can underflow (0.5^256 = 8.6e-78)
+      ent_sync<HV>();
+    };
+    // fold the mantissa product before it can underflow (0.5^256 = 8.6e-78)
+    auto fold = [&]() {
       if (++pcnt == 256) {
         accH += log(pm) + 0.693147180559945309417 * (double)pe;
         pm = 1.0; pe = 0; pcnt = 0;
       }
-      if (sg) break;
-      sg = 1;
-      ssig = -sigj;
-      if (EO) {
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, (KT + 1) / 2>;
+    using IK = std::integral_constant<int, KT>;
+
+    if constexpr (EO && GRAD && STAG) {
+      // Both signs in straight-line code, staggered: the second sign's exponentials (independent of everything the first
+      // sign's per-sample chain waits for -- the q' exchange through LDS, the reciprocal, the 1/q' exchange) are issued
+      // inside that chain, so this wave keeps the pipe busy across its own latencies instead of leaving them to the one
+      // other wave on the SIMD.  No copies on a loop back edge either: each sign works on its own registers.
+      mf4 Y[NPV];
+      exps(n, I0{}, IK{});
+      pvstep(n, Y, 0);
+      put_q(Y);
+      exps(nm, I0{}, IH{});
+      const double rqs = get_rq();
+      put_rq(rqs);
+      exps(nm, IH{}, IK{});
+      wacc(n, rqs);
+      gradpieces(Y, sigj);
+      fold();
+      pvstep(nm, Y, 1);
+      put_q(Y);
+      const double rqs2 = get_rq();
+      wacc(nm, rqs2);
+      put_rq(rqs2);
+      gradpieces(Y, -sigj);
+      fold();
+    } else {
+      // one loop body for both signs; the second sign's exponents are MOVED into n on the back edge -- written as a
+      // conditional at the loop head the compiler turns them into 32 selects per sign
+      int sg = 0;
+      double ssig = sigj;          // +-sigma_j
+#pragma unroll 1
+      for (;;) {
+        if (!EO) {   // plain S-step of this sign: KT independent accumulator chains
+          double sf[QS];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
+          for (int q = 0; q < QS; ++q) {
+            const int cc = 4 * q + lg;
+            sf[q] = (cc < D) ? ssig * ev[q] : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
+          }
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+          }
+        }
+        exps(n, I0{}, IK{});
+        if (GRAD) {
+          mf4 Y[NPV];
+          pvstep(n, Y, sg);
+          put_q(Y);
+          const double rqs = get_rq();
+          wacc(n, rqs);
+          put_rq(rqs);
+          gradpieces(Y, ssig);
+        } else {
+          double qp = 0.0;
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
+          qp += __shfl_xor(qp, 16, 64);
+          qp += __shfl_xor(qp, 32, 64);
+          if (HV > 1) {
+            YX[(sg * HV + hv) * YXN + lane] = qp;
+            __syncthreads();
+            qp = YX[(sg * HV + 0) * YXN + lane];
+#pragma unroll
+            for (int w = 1; w < HV; ++w) qp += YX[(sg * HV + w) * YXN + lane];
+          }
+          const double qs_ = svalid ? qp : 1.0;
+          pm *= __builtin_amdgcn_frexp_mant(qs_);
+          pe += __builtin_amdgcn_frexp_exp(qs_);
+          if (svalid) accH += shift;
+        }
+        fold();
+        if (sg) break;
+        sg = 1;
+        ssig = -sigj;
+        if (EO) {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
+        }
       }
-      }
+    }
   }
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
   if (lg != 0) accH = 0.0;   // the four lanes of a sample hold identical copies: count one
