@@ -315,7 +315,11 @@ int vbmc_launch_ent_mfma_qs7(int, int, int, unsigned, unsigned, unsigned, void*,
 int vbmc_launch_ent_mfma_qs8(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 int vbmc_launch_ent_mfma_qs9(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 }
-#define ENT_HV_MID 2   // waves per workgroup for 64 < K <= 128: two (four measured 11-15 % slower there: more exchange and barrier coupling)
+// Waves per workgroup for 64 < K <= 128 (tools/tune_sweep.py, round 2): two -- four are 10-30 % slower (more exchange and barrier
+// coupling) -- EXCEPT where the two-wave kernel with four k-tiles per wave and a wide operand (D >= 15) spills its way down:
+// there four waves with two k-tiles each fit their registers (D = 24, K = 128: 3.4 vs 5.7 ms; D = 20, K = 128: 3.9 vs 5.0;
+// D = 20, K = 100 the other way: 50 vs 57 ms at configs[4]).
+static int ent_hv_mid(int qs, int K) { return (K > 96 && (qs >= 7 || (qs >= 5 && K > 112))) ? 4 : 2; }
 static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
   static const fn_t fns[9] = {vbmc_launch_ent_mfma_qs1, vbmc_launch_ent_mfma_qs2, vbmc_launch_ent_mfma_qs3,
@@ -329,7 +333,7 @@ static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipSt
 // VBMC_ENT_HV = 2 / 4 forces the split where both fit (A/B runs).  D <= 34 (qs <= 9).
 static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out, int* hv_out) {
   const int qs = (D + 2 + 3) / 4;
-  int hv = K <= 64 ? 1 : (K <= 128 ? ENT_HV_MID : 4);
+  int hv = K <= 64 ? 1 : (K <= 128 ? ent_hv_mid(qs, K) : 4);
   if (K > 64 && K <= 128)
     if (const char* f = getenv("VBMC_ENT_HV")) { const int v = atoi(f); if (v == 2 || v == 4) hv = v; }
   const int kt = (((K + hv - 1) / hv) + 15) / 16;

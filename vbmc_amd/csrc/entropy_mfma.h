@@ -362,31 +362,40 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       }
     };
     // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
+    // (NPV >= 2: the column blocks are independent chains already, one set is enough -- 16 VGPRs less.)
     auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg) {
-      mf4 Y2[NPV];
+#ifdef VBMC_TUNE_PV2
+      constexpr bool TWO = (VBMC_TUNE_PV2) != 0 || NPV == 1;
+#else
+      constexpr bool TWO = NPV == 1;
+#endif
+      mf4 Y2s[TWO ? NPV : 1];
+      mf4 (&Y2)[TWO ? NPV : 1] = Y2s;
 #pragma unroll
-      for (int pv = 0; pv < NPV; ++pv) { Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; Y2[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; }
+      for (int pv = 0; pv < NPV; ++pv) { Y[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; if (TWO) Y2[pv] = (mf4){0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
       for (int kt = 0; kt < KT - 1; ++kt) {
         if (SP && !((act >> kt) & 1u)) continue;
         if (!X_PV) { Y[0] += x[kt]; continue; }
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
+          mf4& Yb = TWO ? Y2[TWO ? pv : 0] : Y[pv];
           Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][0], VBV(kt, 0, pv), Y[pv], 0, 0, 0);
-          Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][1], VBV(kt, 1, pv), Y2[pv], 0, 0, 0);
+          Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][1], VBV(kt, 1, pv), Yb, 0, 0, 0);
           Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][2], VBV(kt, 2, pv), Y[pv], 0, 0, 0);
-          Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][3], VBV(kt, 3, pv), Y2[pv], 0, 0, 0);
+          Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[kt][3], VBV(kt, 3, pv), Yb, 0, 0, 0);
         }
       }
 #pragma unroll
       for (int pv = 0; pv < NPV; ++pv) {
-        if (SP && !((act >> (KT - 1)) & 1u)) { Y[pv] += Y2[pv]; continue; }
+        mf4& Yb = TWO ? Y2[TWO ? pv : 0] : Y[pv];
+        if (SP && !((act >> (KT - 1)) & 1u)) { if (TWO) Y[pv] += Yb; continue; }
         if (!X_PV) { Y[pv] += x[KT - 1]; continue; }
         Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][0], VBV(KT - 1, 0, pv), Y[pv], 0, 0, 0);
-        if (nr_last > 1) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][1], VBV(KT - 1, 1, pv), Y2[pv], 0, 0, 0);
+        if (nr_last > 1) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][1], VBV(KT - 1, 1, pv), Yb, 0, 0, 0);
         if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
-        if (nr_last > 3) Y2[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][3], VBV(KT - 1, 3, pv), Y2[pv], 0, 0, 0);
-        Y[pv] += Y2[pv];
+        if (nr_last > 3) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][3], VBV(KT - 1, 3, pv), Yb, 0, 0, 0);
+        if (TWO) Y[pv] += Yb;
       }
       if (HV > 1) {
         // all shares of the mixture: the partial q', A', B' of every wave, added in wave order
@@ -503,7 +512,14 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
 #pragma unroll
           for (int q = 0; q < QS; ++q) {
             const int cc = 4 * q + lg;
-            sf[q] = (cc < D) ? ssig * ev[q] : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
+            // the sample-side fragment: kept in registers across the sign loop, or re-read from the LDS tile (2 QS registers
+            // less) where the kernel is short of them -- tools/tune_sweep.py: four k-tiles per wave or D >= 27
+#ifdef VBMC_TUNE_EVREG
+            constexpr bool EVREG = (VBMC_TUNE_EVREG) != 0;
+#else
+            constexpr bool EVREG = KT <= 3 && QS <= 7;
+#endif
+            sf[q] = (cc < D) ? ssig * (EVREG ? ev[q] : Et[li * DP + 4 * q + lg]) : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
           }
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
