@@ -345,6 +345,26 @@ static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out, int* hv_ou
 // vbmc_elbo_batch
 // ------------------------------------------------------------------------------------------
 // Everything one evaluation pass needs, resolved once: dims, device pointers, launch geometry.
+// Small transfers between the pinned staging block and device memory by a kernel instead of the copy engines: the pinned block
+// (hipHostMalloc: mapped into the device's address space, coherent) is read / written by the kernel directly over the host link.
+// A DMA-engine copy between two kernels of a stream costs 50-100 us of hand-over latency each way (measured: 190-215 us between
+// k_finalize of one batch and k_prep of the next at the headline shape, where the copies themselves are 0.3 MB); a kernel
+// launch costs ~10 us.  VBMC_COPY_ENGINE=1 restores the hipMemcpyAsync path (A/B runs); larger transfers always use it.
+#define COPY_KERNEL_MAX_BYTES ((size_t)4 << 20)
+__global__ void k_copy_f64(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// rows of `width` doubles, row r at src + r * stride -> dst + r * stride (same stride on both sides)
+__global__ void k_copy_rows_f64(int rows, size_t stride, size_t width, const double* __restrict__ src, double* __restrict__ dst) {
+  for (int r = blockIdx.y; r < rows; r += gridDim.y)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (size_t)gridDim.x * blockDim.x)
+      dst[(size_t)r * stride + i] = src[(size_t)r * stride + i];
+}
+static bool copy_by_kernel(size_t bytes) {
+  static const int engine = [] { const char* e = getenv("VBMC_COPY_ENGINE"); return (e && !strcmp(e, "1")) ? 1 : 0; }();
+  return !engine && bytes <= COPY_KERNEL_MAX_BYTES;
+}
+
 struct ElboPlan {
   ElboDims dm{};
   int compute_grad = 0, compute_var = 0, dt = 0;
@@ -455,7 +475,12 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   P.d_fix = P.d_theta + n_theta;
   P.d_delta2 = P.d_fix + n_fix;
   P.d_bnd = P.has_bnd ? P.d_delta2 + n_delta : nullptr;
-  HIP_TRY(ctx, hipMemcpyAsync(P.d_theta, hp, n_up * sizeof(double), hipMemcpyHostToDevice, st));
+  if (copy_by_kernel(n_up * sizeof(double))) {
+    hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((n_up + 255) / 256, 1024)), dim3(256), 0, st, n_up, (const double*)hp, P.d_theta);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(P.d_theta, hp, n_up * sizeof(double), hipMemcpyHostToDevice, st));
+  }
   P.TolCon = a->TolCon; P.WeightThreshold = a->WeightThreshold; P.WeightPenalty = a->WeightPenalty;
   P.cutoff = a->sparse_cutoff > 0.0 ? a->sparse_cutoff : 0.0;
 
@@ -814,11 +839,22 @@ static vbmc_status elbo_enqueue_readback(vbmc_ctx* ctx, const ElboPlan& P, const
   const int R = P.dm.R, T = P.dm.T;
   // record per restart: [F G H varG varGss | dF (T) | dG (T) | dH (T)]; without dG / dH only the leading part moves
   const size_t OSr = OUT_HDR + 3 * (size_t)T;
-  if (P.compute_grad && !a->dG && !a->dH && R > 1)
-    HIP_TRY(ctx, hipMemcpy2DAsync(hout, OSr * sizeof(double), P.d_out, OSr * sizeof(double), (OUT_HDR + (size_t)T) * sizeof(double), R,
+  const bool lead = P.compute_grad && !a->dG && !a->dH && R > 1;
+  const size_t width = OUT_HDR + (size_t)T;
+  if (copy_by_kernel((lead ? (size_t)R * width : P.out_n) * sizeof(double))) {
+    if (lead)
+      hipLaunchKernelGGL(k_copy_rows_f64, dim3((unsigned)((width + 255) / 256), (unsigned)std::min(R, 1024)), dim3(256), 0, ctx->stream, R, OSr,
+                         width, (const double*)P.d_out, hout);
+    else
+      hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((P.out_n + 255) / 256, 1024)), dim3(256), 0, ctx->stream, P.out_n,
+                         (const double*)P.d_out, hout);
+    HIP_TRY(ctx, hipGetLastError());
+  } else if (lead) {
+    HIP_TRY(ctx, hipMemcpy2DAsync(hout, OSr * sizeof(double), P.d_out, OSr * sizeof(double), width * sizeof(double), R,
                                   hipMemcpyDeviceToHost, ctx->stream));
-  else
+  } else {
     HIP_TRY(ctx, hipMemcpyAsync(hout, P.d_out, P.out_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
   return VBMC_OK;
 }
 
