@@ -434,11 +434,14 @@ def main():
                 "eps_stream_GBps": eps_bytes / (float(np.mean(ems)) * 1e-3) / 1e9}
 
     def timeit(f, n=5):
+        """median wall time of n calls after one warm-up (a single slow call -- a first-use allocation -- is not the rate)"""
         f()
-        t1 = time.perf_counter()
+        ts = []
         for _ in range(n):
+            t1 = time.perf_counter()
             f()
-        return (time.perf_counter() - t1) / n
+            ts.append(time.perf_counter() - t1)
+        return float(np.median(ts))
 
     def gp_legs(aux):
         """the other entry points of the path at the same GP shape (wall time per call incl. H2D / D2H)"""
