@@ -171,7 +171,10 @@ __device__ __forceinline__ vb_d4 vb_exp_tab4(vb_d4 x, const double* __restrict__
 __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restrict__ tab) {
   const double c = 0.693147180559945309417232 / 1024;
   const double nr = __builtin_rint(y);
-  const int ni = __double2int_rz(nr);
+  // the conversion must SATURATE for |y| >= 2^31 (that is what makes a clamp unnecessary): the hardware instruction does, a
+  // C++ cast of an out-of-range value is undefined -- hence the instruction itself
+  int ni;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(ni) : "v"(nr));
   const double r = y - nr;
   const double T = tab[ni & (VB_EXP_TAB1K_N - 1)];
   // the dropped quartic term (c r')^4/24 is economised into the quadratic one (r'^4 ~ r'^2/4 - 1/128 on [-1/2, 1/2]:
