@@ -16,7 +16,7 @@ VARIANTS = {"base": [], "norng": ["-DVBMC_EXP_NORNG"], "noexp": ["-DVBMC_EXP_NOE
             "noepi": ["-DVBMC_EXP_NOEPI"], "now": ["-DVBMC_EXP_NOW"], "nos": ["-DVBMC_EXP_NOS"],
             "nomfma": ["-DVBMC_EXP_NOS", "-DVBMC_EXP_NOPV"],
             "novalu": ["-DVBMC_EXP_NORNG", "-DVBMC_EXP_NOEXP", "-DVBMC_EXP_NOEPI", "-DVBMC_EXP_NOW"],
-            "stag": ["-DVBMC_STAG"], "now_stag": ["-DVBMC_EXP_NOW", "-DVBMC_STAG"],   # the staggered two-sign schedule instead of the sign loop
+            "stag": ["-DVBMC_STAG"], "now_stag": ["-DVBMC_EXP_NOW", "-DVBMC_STAG"],   # the staggered two-sign schedule at four k-tiles too
             "bare": ["-DVBMC_EXP_NORNG", "-DVBMC_EXP_NOEXP", "-DVBMC_EXP_NOEPI", "-DVBMC_EXP_NOW", "-DVBMC_EXP_NOS", "-DVBMC_EXP_NOPV"]}
 
 

@@ -1,5 +1,6 @@
-"""Builds variants of the library with the entropy kernel's tuning knobs set (-DVBMC_TUNE_PV2=0/1 -DVBMC_TUNE_EVREG=0/1) into
-vbmc_amd/lib/tune/lib_<pv2><evreg>.so (all nine QS translation units each).  For tools/tune_sweep.sh."""
+"""Builds variants of the library with extra -D flags on the entropy-kernel translation units (all nine QS) into
+vbmc_amd/lib/tune/lib_<name>.so.   usage: python tools/tune_build.py base: stag:-DVBMC_STAG pv2:-DVBMC_TUNE_PV2=1,-DVBMC_TUNE_EVREG=0
+For tools/tune_sweep.py."""
 import os
 import subprocess
 import sys
@@ -8,19 +9,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "vbmc_amd", "lib", "tune")
 OBJ = os.path.join(ROOT, "vbmc_amd", "lib", "obj")
 os.makedirs(OUT, exist_ok=True)
-variants = sys.argv[1:] or ["00", "01", "10", "11"]
-procs = []
-for v in variants:
+variants = [(v.split(":", 1)[0], [f for f in v.split(":", 1)[1].split(",") if f]) for v in (sys.argv[1:] or ["base:"])]
+for name, flags in variants:
+    procs = []
     for q in range(1, 10):
-        o = os.path.join(OUT, "ent_%s_qs%d.o" % (v, q))
-        procs.append((v, o, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-                                              "-Wno-pass-failed", "-DQS_VALUE=%d" % q, "-DVBMC_TUNE_PV2=%s" % v[0], "-DVBMC_TUNE_EVREG=%s" % v[1],
-                                              "-c", os.path.join(ROOT, "vbmc_amd", "csrc", "ent_mfma_inst.hip"), "-o", o])))
-    for _, o, p in [x for x in procs if x[0] == v]:
+        o = os.path.join(OUT, "ent_%s_qs%d.o" % (name, q))
+        procs.append((o, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+                                           "-Wno-pass-failed", "-DQS_VALUE=%d" % q] + flags +
+                                          ["-c", os.path.join(ROOT, "vbmc_amd", "csrc", "ent_mfma_inst.hip"), "-o", o])))
+    for o, p in procs:
         assert p.wait() == 0, o
-    objs = [o for vv, o, _ in procs if vv == v]
+    objs = [o for o, _ in procs]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(OBJ, "vbmc_hip.o")] + objs +
-                          ["-o", os.path.join(OUT, "lib_%s.so" % v)])
+                          ["-o", os.path.join(OUT, "lib_%s.so" % name)])
     for o in objs:
         os.remove(o)
-    print("built", v, flush=True)
+    print("built", name, flags, flush=True)

@@ -1,6 +1,7 @@
 """Entropy-kernel duration over a grid of mixture shapes for each tuning variant built by tools/tune_build.py (GPU box):
 
-    python tools/tune_sweep.py            -> table: shape x variant, kernel ms (entropy-only evaluations, R restarts batched)
+    python tools/tune_sweep.py [small]    -> table: shape x variant, kernel ms (entropy-only evaluations, R restarts batched);
+                                             "small": K <= 64 only, and no forced four-wave column
 
 Each variant runs in its own process (the library is chosen at import through VBMC_HIP_LIB)."""
 import json
@@ -9,7 +10,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(D, K) for K in (48, 64, 80, 96, 112, 128, 192, 256) for D in (6, 10, 14, 18, 20, 24, 28, 32)]
+SMALL = "small" in sys.argv[1:] or os.environ.get("TUNE_SMALL") == "1"
+SHAPES = ([(D, K) for K in (8, 16, 24, 32, 40, 48, 56, 64) for D in (2, 6, 10, 14, 20, 28)] if SMALL else
+          [(D, K) for K in (48, 64, 80, 96, 112, 128, 192, 256) for D in (6, 10, 14, 18, 20, 24, 28, 32)])
 
 
 def one():
@@ -21,7 +24,7 @@ def one():
     out = {}
     for D, K in SHAPES:
         rng = np.random.default_rng(D * 1000 + K)
-        R, Ns = (16 if K <= 64 else 8), 8192     # steady state: >= 30 tiles per wave after chunking
+        R, Ns = (64 if K <= 16 else 16 if K <= 64 else 8), 8192     # steady state: >= 30 tiles per wave after chunking
         mu = 1.5 * rng.standard_normal((D, K))
         vp = vbmc_amd.make_vp(mu, 0.3 * np.exp(0.2 * rng.standard_normal(K)), np.ones(D), eta=0.3 * rng.standard_normal(K))
         vp["w"] = np.exp(vp["eta"]) / np.sum(np.exp(vp["eta"]))
@@ -47,13 +50,13 @@ def main():
     libs = sorted(f for f in os.listdir(tune) if f.endswith(".so"))
     res = {}
     for lib in libs:
-        for hv in ("", "4"):
-            env = dict(os.environ, VBMC_HIP_LIB=os.path.join(tune, lib))
+        for hv in (("",) if SMALL else ("", "4")):
+            env = dict(os.environ, VBMC_HIP_LIB=os.path.join(tune, lib), TUNE_SMALL="1" if SMALL else "0")
             if hv:
                 env["VBMC_ENT_HV"] = hv
             o = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
             line = [ln for ln in o.stdout.splitlines() if ln.startswith("{")]
-            res[lib[4:6] + ("/hv4" if hv else "")] = json.loads(line[-1]) if line else {"error": o.stderr[-300:]}
+            res[lib[4:-3] + ("/hv4" if hv else "")] = json.loads(line[-1]) if line else {"error": o.stderr[-300:]}
     names = list(res)
     print("shape(D,K)  Ns   " + "  ".join("%8s" % n for n in names))
     for D, K in SHAPES:

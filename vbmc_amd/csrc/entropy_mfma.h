@@ -53,13 +53,17 @@ constexpr bool X_W = false;
 #else
 constexpr bool X_W = true;
 #endif
-// -DVBMC_STAG: both signs in straight-line code, the second sign's exponentials issued inside the first sign's per-sample
-// latency chain.  Measured (tools/ent_experiments.py, variants stag / now_stag / now): -2.1 % when the registers are there (weight
-// gradient compiled out) but 31 VGPRs spilled and +2.6 % in the product kernel -- off.
-#ifdef VBMC_STAG
-constexpr bool STAG = true;
+// The staggered schedule: both signs in straight-line code, the second sign's exponentials issued inside the first sign's
+// per-sample latency chain.  It pays where the registers are there: one and three k-tiles per wave (K <= 16, 33..48: no spills,
+// 0-6 % faster, tools/tune_sweep.py small); with two k-tiles (168-VGPR budget of three waves per SIMD) and with four (256) it
+// spills and loses 2-12 %, so those keep the sign loop.  -DVBMC_STAG forces it everywhere, -DVBMC_NO_STAG nowhere (A/B builds;
+// with the weight gradient compiled out -- registers to spare -- it gains 2.6 % at four k-tiles too: tools/ent_experiments.py).
+#if defined(VBMC_STAG)
+#define VBMC_STAG_FOR(KT_) true
+#elif defined(VBMC_NO_STAG)
+#define VBMC_STAG_FOR(KT_) false
 #else
-constexpr bool STAG = false;
+#define VBMC_STAG_FOR(KT_) ((KT_) == 1 || (KT_) == 3)
 #endif
 #ifdef VBMC_EXP_NOS
 constexpr bool X_S = false;
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
     using IH = std::integral_constant<int, (KT + 1) / 2>;
     using IK = std::integral_constant<int, KT>;
 
-    if constexpr (EO && GRAD && STAG) {
+    if constexpr (EO && GRAD && VBMC_STAG_FOR(KT)) {
       // Both signs in straight-line code, staggered: the second sign's exponentials (independent of everything the first
       // sign's per-sample chain waits for -- the q' exchange through LDS, the reciprocal, the 1/q' exchange) are issued
       // inside that chain, so this wave keeps the pipe busy across its own latencies instead of leaving them to the one
