@@ -69,6 +69,20 @@ CONFIGS = [
     ("D13-pad", 13, 60, 6, 2, 64, "lumpy"),
     ("D20", 20, 90, 7, 2, 64, "lumpy"),
     ("K70", 4, 40, 70, 2, 66, "lumpy"),
+    # K mod 16 in 1..4 (K > 16): the last components run as a lane-layout tail beside K / 16 full k-tiles (entropy_mfma.h, TL)
+    ("tail-K17-D3", 3, 30, 17, 2, 40, "lumpy"),
+    ("tail-K20-D1", 1, 20, 20, 1, 50, "lumpy"),
+    ("tail-K18-D10", 10, 40, 18, 2, 70, "lumpy"),
+    ("tail-K33-D32", 32, 40, 33, 1, 20, "lumpy"),
+    ("tail-K36-D13", 13, 40, 36, 2, 36, "lumpy"),
+    ("tail-K34-D6", 6, 40, 34, 2, 130, "student"),
+    ("tail-K49-D5", 5, 40, 49, 2, 34, "lumpy"),
+    ("tail-K50-D10", 10, 60, 50, 2, 100, "lumpy"),
+    ("tail-K51-D15", 15, 40, 51, 1, 38, "lumpy"),
+    ("tail-K52-D20", 20, 60, 52, 2, 40, "lumpy"),
+    # neighbours without a tail: K mod 16 = 0 and 5
+    ("K48-D10", 10, 40, 48, 2, 40, "lumpy"),
+    ("K53-D10", 10, 40, 53, 2, 40, "lumpy"),
 ]
 
 

@@ -331,14 +331,19 @@ static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipSt
 // K <= 64: one wave per (chunk, component, restart) with kt = ceil(K/16) k-tiles; larger mixtures split their components
 // over the hv = 2 or 4 waves of a workgroup, kt = ceil(ceil(K/hv)/16) <= 4: two waves up to K = 128, four up to K = 256.
 // VBMC_ENT_HV = 2 / 4 forces the split where both fit (A/B runs).  D <= 34 (qs <= 9).
-static bool mfma_entropy_fits(int D, int K, int* qs_out, int* kt_out, int* hv_out) {
+// hv = 17: one wave with kt = K / 16 full k-tiles and the K mod 16 <= 4 remaining components as a lane-layout TAIL instead of a
+// k-tile of their own (entropy_mfma.h, TL): K = 17..20, 33..36, 49..52.  VBMC_ENT_TAIL=0 keeps the padded k-tile (A/B runs);
+// the block-sparse mode (cutoff > 0) always does.
+static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_out, int* hv_out) {
   const int qs = (D + 2 + 3) / 4;
   int hv = K <= 64 ? 1 : (K <= 128 ? ent_hv_mid(qs, K) : 4);
   if (K > 64 && K <= 128)
     if (const char* f = getenv("VBMC_ENT_HV")) { const int v = atoi(f); if (v == 2 || v == 4) hv = v; }
-  const int kt = (((K + hv - 1) / hv) + 15) / 16;
+  int kt = (((K + hv - 1) / hv) + 15) / 16;
+  static const bool tail_on = [] { const char* e = getenv("VBMC_ENT_TAIL"); return !(e && !strcmp(e, "0")); }();
+  if (tail_on && hv == 1 && K > 16 && K % 16 >= 1 && K % 16 <= 4 && !(cutoff > 0.0)) { hv = 17; kt = K / 16; }
   *qs_out = qs; *kt_out = kt; *hv_out = hv;
-  return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3) && !(hv == 4 && kt < 2);
+  return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3) && !(hv == 4 && kt < 2) && !(hv == 17 && kt > 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -507,7 +512,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
 
   if (P.mc) {
     const char* force = getenv("VBMC_ENT_KERNEL");  // "valu" (A/B testing); default: the MFMA kernel when it fits
-    P.use_mfma = mfma_entropy_fits(D, K, &P.qs, &P.kt, &P.hv);
+    P.use_mfma = mfma_entropy_fits(D, K, P.cutoff, &P.qs, &P.kt, &P.hv);
     if (force && !strcmp(force, "valu")) P.use_mfma = false;
     const int tile_sz = P.use_mfma ? 16 : 32;          // base samples per tile
     const int ntile = (Mh + tile_sz - 1) / tile_sz;
@@ -516,7 +521,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     {
       const int cw = chunk_world > 0 ? chunk_world : (a->chunk_world > 1 ? a->chunk_world : 1);   // sharded over cw devices
       const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5) * cw;
-      const long long kr = (long long)K * R * (P.use_mfma ? P.hv : 1);   // waves per chunk index
+      const long long kr = (long long)K * R * (P.use_mfma ? (P.hv == 17 ? 1 : P.hv) : 1);   // waves per chunk index (hv 17: one wave with a component tail)
       const double setup = 1.5;   // measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
       double best = 1e300;
       int bestC = 1;

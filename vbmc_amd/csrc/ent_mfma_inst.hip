@@ -1,5 +1,5 @@
 // One translation unit per QS (compiled with -DQS_VALUE=n, in parallel, see vbmc_amd/build.py):
-// instantiates k_entropy_mfma<QS, KT, grad, sparse, HV> for KT = 1..4 (HV = 1), KT = 3, 4 with the components split over
+// instantiates k_entropy_mfma<QS, KT, grad, sparse, HV, TL> for KT = 1..4 (HV = 1; KT = 1..3 also with a component tail), KT = 3, 4 with the components split over
 // two waves (HV = 2) and KT = 2..4 over four waves (HV = 4), and exports a launcher.
 #include "entropy_mfma.h"
 
@@ -9,7 +9,7 @@
 #define CAT2(a, b) a##b
 #define CAT(a, b) CAT2(a, b)
 
-template <int KT, int HV>
+template <int KT, int HV, bool TL = false>
 static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
   // dynamic LDS: the parameter block (<= 74 KB at K = 256, D = 32), reused by the exp table (8 KB) and the PV exchange of
   // multi-wave workgroups (2 signs x HV waves x NPV x 4 x 64 doubles)
@@ -19,15 +19,15 @@ static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
   if (HV > 1) after += (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double);
   if (after > lds) lds = after;
   if (lds > 64 * 1024) {
-    if (grad) (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, true, false, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, false, false, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (grad) (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, true, false, HV, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, false, false, HV, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (ea.cutoff > 0.0 && HV == 1) {  // opt-in block-sparse variant (single-wave kernels only)
+  if (ea.cutoff > 0.0 && HV == 1 && !TL) {  // opt-in block-sparse variant (single-wave kernels only, no component tail)
     if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, true, 1>), grid, dim3(WAVE), lds, st, ea);
     else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, true, 1>), grid, dim3(WAVE), lds, st, ea);
   } else {
-    if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, false, HV>), grid, dim3(WAVE * HV), lds, st, ea);
-    else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, false, HV>), grid, dim3(WAVE * HV), lds, st, ea);
+    if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, false, HV, TL>), grid, dim3(WAVE * HV), lds, st, ea);
+    else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, false, HV, TL>), grid, dim3(WAVE * HV), lds, st, ea);
   }
 }
 
@@ -41,6 +41,9 @@ extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, 
     case 16 + 2: launch_kt<2, 1>(grad, grid, st, *ea); return 0;
     case 16 + 3: launch_kt<3, 1>(grad, grid, st, *ea); return 0;
     case 16 + 4: launch_kt<4, 1>(grad, grid, st, *ea); return 0;
+    case 272 + 1: launch_kt<1, 1, true>(grad, grid, st, *ea); return 0;   // hv = 17: one wave, kt full k-tiles + a tail of K mod 16 <= 4 components
+    case 272 + 2: launch_kt<2, 1, true>(grad, grid, st, *ea); return 0;
+    case 272 + 3: launch_kt<3, 1, true>(grad, grid, st, *ea); return 0;
     case 32 + 3: launch_kt<3, 2>(grad, grid, st, *ea); return 0;   // 64 < K <= 96, two waves
     case 32 + 4: launch_kt<4, 2>(grad, grid, st, *ea); return 0;   // 96 < K <= 128
     case 64 + 2: launch_kt<2, 4>(grad, grid, st, *ea); return 0;   // 64 < K <= 128, four waves

@@ -95,9 +95,16 @@ __device__ __forceinline__ void ent_sync_wg() {
 // every wave, so all hold identical bits.  Wave 0 owns the entropy accumulator, the column blocks of the gradient are dealt
 // to the waves, each wave owns the weight gradient of its components.  The exchange buffers reuse the parameter block's LDS
 // (needed only while the operand fragments are built).
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1>
+//
+// TL (single-wave workgroups): the last K mod 16 <= 4 components do not get a k-tile of their own.  A 16-wide k-tile for two
+// components (K = 50) costs four S-step MFMAs, 26 VGPRs of operands / exponents / accumulators and an exp register per sign; as a
+// TAIL they live in the lane layout (sample li, tail component lg) -- one value per lane: the linear part of the exponent is D
+// FMAs per tile from two LDS rows (the sample's draws, the component's coefficients), one exp per sign, and the lane's value IS
+// the A operand of one PV MFMA (component index = inner index lg), its weight-gradient term one lane-local FMA.
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, bool TL = false>
 __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_entropy_mfma(EntArgs a) {
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
+  static_assert(!TL || (HV == 1 && !SPARSE), "the component tail exists for dense single-wave workgroups only");
   constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
@@ -116,6 +123,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   constexpr bool EO = HV == 1;
   constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
+  __shared__ double BTL[TL ? 4 * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   const int tid = threadIdx.x, hv = HV == 1 ? 0 : tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
   const double hj_neg = 0.5 / (sigj * sigj);   // = -h_j bit for bit (k_prep computes h = -0.5/(sigma*sigma))
-  const int nr_last = max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
+  const int nr_last = TL ? 4 : max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
@@ -231,6 +239,40 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       } else {
         WF[kt][rr] = kv2 ? p2[D + 2] : 0.0;
       }
+    }
+  }
+
+  // ---- tail components 16 KT + lg (TL): even-part coefficients, PV operand and weight in registers (one component per lane
+  // group), the linear coefficients as a row of BTL
+  double tC0 = 0.0, tC1 = 0.0, VBt[NPV], WFt = 0.0, Wt = 0.0;
+#pragma unroll
+  for (int pv = 0; pv < NPV; ++pv) VBt[pv] = 0.0;
+  if (TL) {
+    const int kq = 16 * KT + lg;
+    const bool kvq = kq < Kw;
+    const double* pq = gp + (size_t)(kvq ? kq : 0) * PSg;
+    const double h = pq[D];
+    double m2 = 0.0;
+    for (int d = 0; d < D; ++d) { double t = pq[d] - pj[d]; m2 = fma(t, t, m2); }
+    tC0 = kvq ? ESC * (h + hj_neg) : 0.0;
+    tC1 = ESC * (kvq ? fma(h, m2, pq[D + 1]) - cKj : -1.0e6);            // absent component: exp -> 0
+    if (li < DP) BTL[lg * DP + li] = (kvq && li < D) ? ESC * (-2.0 * h * (pq[li] - pj[li])) : 0.0;
+    if (DP > 16 && li + 16 < DP) BTL[lg * DP + li + 16] = (kvq && li + 16 < D) ? ESC * (-2.0 * h * (pq[li + 16] - pj[li + 16])) : 0.0;
+    if (DP > 32 && li + 32 < DP) BTL[lg * DP + li + 32] = (kvq && li + 32 < D) ? ESC * (-2.0 * h * (pq[li + 32] - pj[li + 32])) : 0.0;
+    if (GRAD) {
+#pragma unroll
+      for (int pv = 0; pv < NPV; ++pv) {     // PV "B" operand: inner index lg <-> tail component, column 16 pv + li
+        const int col = 16 * pv + li;
+        double v = 0.0;
+        if (kvq) {
+          if (col == 0) v = pq[D + 2];
+          else if (col == 1) v = pq[D + 3];
+          else if (col < 2 + D) v = pq[D + 3] * (pq[col - 2] - pj[col - 2]);
+        }
+        VBt[pv] = v;
+      }
+    } else {
+      WFt = kvq ? pq[D + 2] : 0.0;
     }
   }
 
@@ -343,6 +385,18 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       }
     }
 
+    // tail components: E+- = even +- linear, one value per lane (sample li, tail component lg)
+    double ntl = 0.0, ntm = 0.0;
+    if (TL) {
+      double lt = 0.0;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) lt = fma(BTL[lg * DP + d], Et[li * DP + d], lt);    // zero beyond D on both sides
+      lt *= sigj;
+      const double ct = fma(tC0, u2, tC1);
+      ntl = ct + lt;
+      ntm = ct - lt;
+    }
+
     // ---- the phases of one sign as inlined pieces (x: the sign's exponents, overwritten by their exponentials)
     auto exps = [&](mf4 (&x)[KT], auto k0c, auto k1c) {   // k-tiles k0 .. k1-1: 4 straight-line exps each
       constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
@@ -365,9 +419,10 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         }
       }
     };
+    auto texp = [&](double& t) { if (TL && X_EXP) t = vb_exp_tab1k(t, TAB); };
     // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
     // (NPV >= 2: the column blocks are independent chains already, one set is enough -- 16 VGPRs less.)
-    auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg) {
+    auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg, double tn) {
 #ifdef VBMC_TUNE_PV2
       constexpr bool TWO = (VBMC_TUNE_PV2) != 0 || NPV == 1;
 #else
@@ -399,6 +454,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         if (nr_last > 1) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][1], VBV(KT - 1, 1, pv), Yb, 0, 0, 0);
         if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
         if (nr_last > 3) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][3], VBV(KT - 1, 3, pv), Yb, 0, 0, 0);
+        if (TL) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(tn, VBt[pv], Y[pv], 0, 0, 0);   // the tail: inner index lg = tail component
         if (TWO) Y[pv] += Yb;
       }
       if (HV > 1) {
@@ -435,7 +491,8 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       if (svalid) accH += shift;
       return rqs;
     };
-    auto wacc = [&](mf4 (&x)[KT], double rqs) {
+    auto wacc = [&](mf4 (&x)[KT], double rqs, double tn) {
+      if (TL) Wt = fma(tn, rqs, Wt);
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (SP && !((act >> kt) & 1u)) continue;
@@ -488,19 +545,21 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       // other wave on the SIMD.  No copies on a loop back edge either: each sign works on its own registers.
       mf4 Y[NPV];
       exps(n, I0{}, IK{});
-      pvstep(n, Y, 0);
+      texp(ntl);
+      pvstep(n, Y, 0, ntl);
       put_q(Y);
       exps(nm, I0{}, IH{});
       const double rqs = get_rq();
       put_rq(rqs);
       exps(nm, IH{}, IK{});
-      wacc(n, rqs);
+      texp(ntm);
+      wacc(n, rqs, ntl);
       gradpieces(Y, sigj);
       fold();
-      pvstep(nm, Y, 1);
+      pvstep(nm, Y, 1, ntm);
       put_q(Y);
       const double rqs2 = get_rq();
-      wacc(nm, rqs2);
+      wacc(nm, rqs2, ntm);
       put_rq(rqs2);
       gradpieces(Y, -sigj);
       fold();
@@ -533,12 +592,13 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
           }
         }
         exps(n, I0{}, IK{});
+        texp(ntl);
         if (GRAD) {
           mf4 Y[NPV];
-          pvstep(n, Y, sg);
+          pvstep(n, Y, sg, ntl);
           put_q(Y);
           const double rqs = get_rq();
-          wacc(n, rqs);
+          wacc(n, rqs, ntl);
           put_rq(rqs);
           gradpieces(Y, ssig);
         } else {
@@ -547,6 +607,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
           for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
+          if (TL) qp = fma(WFt, ntl, qp);
           qp += __shfl_xor(qp, 16, 64);
           qp += __shfl_xor(qp, 32, 64);
           if (HV > 1) {
@@ -569,6 +630,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
         }
+        ntl = ntm;
       }
     }
   }
@@ -612,6 +674,12 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         const int k = 16 * kt + 4 * rr + lg;
         if (li == 0 && k < Kw) o[2 + 2 * D + kbase + k] = wv;
       }
+    if (TL) {
+      double wv = Wt;
+      wv += __shfl_xor(wv, 1, 64); wv += __shfl_xor(wv, 2, 64);
+      wv += __shfl_xor(wv, 4, 64); wv += __shfl_xor(wv, 8, 64);
+      if (li == 0 && 16 * KT + lg < Kw) o[2 + 2 * D + 16 * KT + lg] = wv;
+    }
   }
 #undef VBV
 }
