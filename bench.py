@@ -154,6 +154,16 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def entropy_kernel_label(D, K):
+    """the instantiation mfma_entropy_fits (vbmc_amd/csrc/abi_elbo.hip) picks: waves per workgroup, k-tiles per wave, component tail"""
+    qs = (D + 5) // 4
+    hv = 1 if K <= 64 else ((4 if (K > 96 and (qs >= 7 or (qs >= 5 and K > 112))) else 2) if K <= 128 else 4)
+    Kh = (K + hv - 1) // hv
+    tail = Kh > 16 and 1 <= Kh % 16 <= 4 and not (hv > 1 and Kh // 16 < 2)
+    kt = Kh // 16 if tail else (Kh + 15) // 16
+    return "k_entropy_mfma<QS=%d,KT=%d%s,grad%s>" % (qs, kt, "+tail" if tail else "", "" if hv == 1 else ",HV=%d" % hv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,7 +377,7 @@ def main():
             traffic_stale = pmc.get("kernel_source_sha256_16") != hh.hexdigest()[:16]
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s)" % (pmc_files[-1], pmc.get("commit", "?"))
         extra["logjoint_kernel_ms"] = lj_ms
-        return {"bound": "mfma", "kernel": "k_entropy_mfma<QS=%d,KT=%d,grad>" % ((D + 5) // 4, (K + 15) // 16), "achieved": achieved,
+        return {"bound": "mfma", "kernel": entropy_kernel_label(D, K), "achieved": achieved,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": Rr * 8 * (2 * (D * K + K + D + K) + 2),

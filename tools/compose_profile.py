@@ -30,17 +30,19 @@ def grab(txt, kern, ctr):
     return float(re.search(r"- %s = ([0-9.e+]+)" % ctr, seg).group(1))
 
 
-kern = "`void k_entropy_mfma<3, 4, true, false, 1>(EntArgs)`"
+kern = "`void k_entropy_mfma<3, 3, true, false, 1, true>(EntArgs)`"   # the headline instantiation: QS 3, three k-tiles + component tail
 fetch, write = grab(pa, kern, "FETCH_SIZE"), grab(pb, kern, "WRITE_SIZE")
 hbm = int(round(fetch * 1024 * 2 + write * 1024))
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_entropy_mfma<3,4,true,false,1>", "commit": commit,
+json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_entropy_mfma<3,3,true,false,1,true>", "commit": commit,
            "kernel_source_sha256_16": kernel_source_hash(),
            "workload": "python bench.py (R=64, C3, device RNG)", "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); "
                          "WRITE_SIZE as reported (uncalibrated)",
            "hbm_bytes_per_launch": hbm}, open("profiles/%s_pmc.json" % RND, "w"), indent=1)
 busy, act = grab(pa, kern, "SQ_VALU_MFMA_BUSY_CYCLES"), grab(pa, kern, "SQ_ACTIVE_INST_VALU")
+n_mfma, n_valu = grab(pa, kern, "SQ_INSTS_MFMA"), grab(pa, kern, "SQ_INSTS_VALU")
+TS = 64 * 50 * 313 * 2.0     # tile-signs per launch at the headline shape: R x K x ceil(5000 / 16) tiles x 2 signs
 b = json.loads(rd("bench.json"))
 b.update(b.get("aux", {}))   # round 2: the auxiliary legs are nested under "aux"
 bt = json.loads(rd("bench_traced.json").splitlines()[-1])
@@ -110,11 +112,12 @@ count (VERDICT r1 asked: 128 there vs 255 claimed); the authoritative figures ar
   ({bt['value'] / 1e3:.1f} k in the traced run); C port of the MATLAB loop nest on the box's host: {b['cpu_baseline']['value']:.2f} evals/s on 1 core
   ({b['cpu_baseline']['all_cores']['value']:.1f} with OpenMP on {b['cpu_baseline']['all_cores']['cores']} threads).
 * `k_entropy_mfma` {r['kernel_ms']:.2f} ms by HIP events in `bench.py` (rocprofv3 average in the table above): per tile-sign (800
-  sample x component pairs) 21 MFMA (8 S-step, the antithetic pair sharing the even part + 13 PV) + ~300 VALU instructions.  MFMA busy {busy:.4g} cycles / 1024 SIMDs = {mf:.2f} ms,
+  sample x component pairs) {n_mfma / TS:.1f} MFMA (6 S-step, the antithetic pair sharing the even part, + 13 PV: three k-tiles and the
+  two-component tail) + {n_valu / TS:.0f} VALU instructions (`SQ_INSTS_MFMA`, `SQ_INSTS_VALU` over {TS:.4g} tile-signs).  MFMA busy {busy:.4g} cycles / 1024 SIMDs = {mf:.2f} ms,
   VALU active {act:.3g} x 4 / 1024 = {va:.2f} ms; the two do not overlap for fp64 -> fp64 pipe ~{100 * (mf + va) / r['kernel_ms']:.0f} % busy.
   Register-limited to 2 waves/SIMD.
 * Algorithmic flops (SURVEY 8d) 9.29e10 per launch -> {r['achieved']:.1f} TFLOP/s = **{100 * r['frac']:.0f} % of the 78.6 TFLOP/s dense fp64 peak**
-  (exponentials -- 1.6e9 per launch, 9-10 fp64 ops each -- and tile padding not counted).
+  (exponentials -- 1.6e9 per launch, 8 fp64 + 3 int ops each -- and tile padding not counted).
 * HBM: FETCH_SIZE {fetch:.0f} KB (x2, gfx950 correction) + WRITE_SIZE {write:.0f} KB = {hbm / 1e6:.1f} MB per launch
   (`profiles/{RND}_pmc.json`), < 0.1 % of HBM bandwidth: per-chunk partial records and the packed mixture parameters.
 * On-device Adam, one chain: {b['device_adam_R1_evals_per_s'] / 1e3:.1f} k evals/s ({b['host_loop_R1_evals_per_s'] / 1e3:.1f} k with one host call per evaluation

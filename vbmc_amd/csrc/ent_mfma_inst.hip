@@ -44,6 +44,10 @@ extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, 
     case 272 + 1: launch_kt<1, 1, true>(grad, grid, st, *ea); return 0;   // hv = 17: one wave, kt full k-tiles + a tail of K mod 16 <= 4 components
     case 272 + 2: launch_kt<2, 1, true>(grad, grid, st, *ea); return 0;
     case 272 + 3: launch_kt<3, 1, true>(grad, grid, st, *ea); return 0;
+    case 288 + 2: launch_kt<2, 2, true>(grad, grid, st, *ea); return 0;   // hv = 18: two waves, each kt full k-tiles + a tail (K = 66..72)
+    case 288 + 3: launch_kt<3, 2, true>(grad, grid, st, *ea); return 0;   //          K = 98..104
+    case 320 + 2: launch_kt<2, 4, true>(grad, grid, st, *ea); return 0;   // hv = 20: four waves + tails (K = 130..144)
+    case 320 + 3: launch_kt<3, 4, true>(grad, grid, st, *ea); return 0;   //          K = 194..208
     case 32 + 3: launch_kt<3, 2>(grad, grid, st, *ea); return 0;   // 64 < K <= 96, two waves
     case 32 + 4: launch_kt<4, 2>(grad, grid, st, *ea); return 0;   // 96 < K <= 128
     case 64 + 2: launch_kt<2, 4>(grad, grid, st, *ea); return 0;   // 64 < K <= 128, four waves

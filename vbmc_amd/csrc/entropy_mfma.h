@@ -96,7 +96,7 @@ __device__ __forceinline__ void ent_sync_wg() {
 // to the waves, each wave owns the weight gradient of its components.  The exchange buffers reuse the parameter block's LDS
 // (needed only while the operand fragments are built).
 //
-// TL (single-wave workgroups): the last K mod 16 <= 4 components do not get a k-tile of their own.  A 16-wide k-tile for two
+// TL: the last (components of the wave) mod 16 <= 4 components do not get a k-tile of their own.  A 16-wide k-tile for two
 // components (K = 50) costs four S-step MFMAs, 26 VGPRs of operands / exponents / accumulators and an exp register per sign; as a
 // TAIL they live in the lane layout (sample li, tail component lg) -- one value per lane: the linear part of the exponent is D
 // FMAs per tile from two LDS rows (the sample's draws, the component's coefficients), one exp per sign, and the lane's value IS
@@ -104,7 +104,7 @@ __device__ __forceinline__ void ent_sync_wg() {
 template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, bool TL = false>
 __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_entropy_mfma(EntArgs a) {
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
-  static_assert(!TL || (HV == 1 && !SPARSE), "the component tail exists for dense single-wave workgroups only");
+  static_assert(!TL || !SPARSE, "the component tail exists for the dense kernels only");
   constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   constexpr bool EO = HV == 1;
   constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
-  __shared__ double BTL[TL ? 4 * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
+  __shared__ double BTL_all[HV][TL ? 4 * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   const int tid = threadIdx.x, hv = HV == 1 ? 0 : tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   double* RQ = RQ_all[hv];
   double* BND = BND_all[hv];
   double* VBS = VBS_all[hv];
+  double* BTL = BTL_all[hv];
   const int Kh = (K + HV - 1) / HV;                    // components per wave
   const int kbase = hv * Kh;
   const int Kw = min(K, kbase + Kh) - kbase;           // this wave's components: kbase .. kbase + Kw - 1
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   if (TL) {
     const int kq = 16 * KT + lg;
     const bool kvq = kq < Kw;
-    const double* pq = gp + (size_t)(kvq ? kq : 0) * PSg;
+    const double* pq = gp + (size_t)(kvq ? kbase + kq : 0) * PSg;
     const double h = pq[D];
     double m2 = 0.0;
     for (int d = 0; d < D; ++d) { double t = pq[d] - pj[d]; m2 = fma(t, t, m2); }
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       double wv = Wt;
       wv += __shfl_xor(wv, 1, 64); wv += __shfl_xor(wv, 2, 64);
       wv += __shfl_xor(wv, 4, 64); wv += __shfl_xor(wv, 8, 64);
-      if (li == 0 && 16 * KT + lg < Kw) o[2 + 2 * D + 16 * KT + lg] = wv;
+      if (li == 0 && 16 * KT + lg < Kw) o[2 + 2 * D + kbase + 16 * KT + lg] = wv;
     }
   }
 #undef VBV
