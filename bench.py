@@ -159,9 +159,13 @@ def entropy_kernel_label(D, K):
     qs = (D + 5) // 4
     hv = 1 if K <= 64 else ((4 if (K > 96 and (qs >= 7 or (qs >= 5 and K > 112))) else 2) if K <= 128 else 4)
     Kh = (K + hv - 1) // hv
-    tail = Kh > 16 and 1 <= Kh % 16 <= 4 and not (hv > 1 and Kh // 16 < 2)
-    kt = Kh // 16 if tail else (Kh + 15) // 16
-    return "k_entropy_mfma<QS=%d,KT=%d%s,grad%s>" % (qs, kt, "+tail" if tail else "", "" if hv == 1 else ",HV=%d" % hv)
+    ktf, rem = Kh // 16, Kh % 16
+    tl = (rem + 3) // 4
+    tail8_ok = ktf == 1 or (hv == 1 and ktf == 2 and (qs >= 5 or rem <= 6)) or (hv == 1 and ktf == 3 and qs <= 4) or \
+        (hv > 1 and ktf == 2) or (hv > 1 and ktf == 3 and qs >= 5)
+    tail = Kh > 16 and (tl == 1 or (tl == 2 and tail8_ok)) and not (hv > 1 and ktf < 2)
+    kt = ktf if tail else (Kh + 15) // 16
+    return "k_entropy_mfma<QS=%d,KT=%d%s,grad%s>" % (qs, kt, "+tail%d" % rem if tail else "", "" if hv == 1 else ",HV=%d" % hv)
 
 
 def main():

@@ -80,9 +80,19 @@ CONFIGS = [
     ("tail-K50-D10", 10, 60, 50, 2, 100, "lumpy"),
     ("tail-K51-D15", 15, 40, 51, 1, 38, "lumpy"),
     ("tail-K52-D20", 20, 60, 52, 2, 40, "lumpy"),
-    # neighbours without a tail: K mod 16 = 0 and 5
+    # 5..8 tail components: two values per lane
+    ("tail8-K21-D3", 3, 30, 21, 2, 40, "lumpy"),
+    ("tail8-K24-D10", 10, 40, 24, 2, 50, "lumpy"),
+    ("tail8-K38-D6", 6, 40, 38, 2, 66, "student"),
+    ("tail8-K40-D20", 20, 50, 40, 1, 36, "lumpy"),
+    ("tail8-K53-D10", 10, 40, 53, 2, 40, "lumpy"),
+    ("tail8-K56-D13", 13, 40, 56, 1, 34, "lumpy"),
+    ("tail8-K77-D5", 5, 40, 77, 2, 34, "lumpy"),
+    ("tail8-K110-D20", 20, 50, 110, 1, 32, "lumpy"),
+    ("tail8-K150-D4", 4, 30, 150, 1, 32, "lumpy"),
+    # neighbours without a tail: K mod 16 = 0 and 9
     ("K48-D10", 10, 40, 48, 2, 40, "lumpy"),
-    ("K53-D10", 10, 40, 53, 2, 40, "lumpy"),
+    ("K57-D10", 10, 40, 57, 2, 40, "lumpy"),
 ]
 
 

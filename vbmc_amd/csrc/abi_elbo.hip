@@ -332,8 +332,9 @@ static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipSt
 // over the hv = 2 or 4 waves of a workgroup, kt = ceil(ceil(K/hv)/16) <= 4: two waves up to K = 128, four up to K = 256.
 // VBMC_ENT_HV = 2 / 4 forces the split where both fit (A/B runs).  D <= 34 (qs <= 9).
 // hv + 16: every wave runs kt = Kh / 16 full k-tiles and its Kh mod 16 <= 4 remaining components (Kh = components per wave) as a
-// lane-layout TAIL instead of a k-tile of their own (entropy_mfma.h, TL): K = 17..20, 33..36, 49..52 on one wave, 66..72 and
-// 98..104 on two, 130..144 and 194..208 on four.  VBMC_ENT_TAIL=0 keeps the padded k-tile (A/B runs);
+// lane-layout TAIL instead of a k-tile of their own (entropy_mfma.h, TL = values per lane): one value for up to 4 components
+// (K = 17..20, 33..36, 49..52 on one wave, 66..72 and 98..104 on two, 130..144 and 194..208 on four), two for 5..8 where that
+// kernel keeps its registers (tail8_ok below).  VBMC_ENT_TAIL=0 keeps the padded k-tile (A/B runs);
 // the block-sparse mode (cutoff > 0) always does.
 static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_out, int* hv_out) {
   const int qs = (D + 2 + 3) / 4;
@@ -344,7 +345,16 @@ static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_
   static const bool tail_on = [] { const char* e = getenv("VBMC_ENT_TAIL"); return !(e && !strcmp(e, "0")); }();
   {
     const int Kh = (K + hv - 1) / hv;      // components of the first waves (the last one may hold fewer: its tail lanes idle)
-    if (tail_on && Kh > 16 && Kh % 16 >= 1 && Kh % 16 <= 4 && !(cutoff > 0.0) && !(hv > 1 && Kh / 16 < 2)) { kt = Kh / 16; hv += 16; }
+    static const int tail_max = [] { const char* e = getenv("VBMC_ENT_TAIL"); return e ? atoi(e) : 2; }();   // 0 / 1 / 2 values per lane at most (A/B runs)
+    const int tl = (Kh % 16 + 3) / 4;         // tail values per lane that would be needed: 1 for 1..4 components, 2 for 5..8
+    // two values per lane pay except where that kernel runs out of registers (tools/tail_sweep.py: 57 shapes x tail limit 0 / 1 / 2)
+    const int ktf = Kh / 16, rem = Kh % 16;
+    const bool tail8_ok = ktf == 1 || (hv == 1 && ktf == 2 && (qs >= 5 || rem <= 6)) || (hv == 1 && ktf == 3 && qs <= 4) ||
+                          (hv > 1 && ktf == 2) || (hv > 1 && ktf == 3 && qs >= 5);
+    if (tail_on && Kh > 16 && tl >= 1 && tl <= tail_max && (tl == 1 || (tl == 2 && tail8_ok)) && !(cutoff > 0.0) && !(hv > 1 && ktf < 2)) {
+      kt = ktf;
+      hv += 16 * tl;
+    }
   }
   *qs_out = qs; *kt_out = kt; *hv_out = hv;
   return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3) && !(hv == 4 && kt < 2) && !(hv > 16 && kt > 3);
@@ -525,7 +535,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     {
       const int cw = chunk_world > 0 ? chunk_world : (a->chunk_world > 1 ? a->chunk_world : 1);   // sharded over cw devices
       const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5) * cw;
-      const long long kr = (long long)K * R * (P.use_mfma ? (P.hv & 15) : 1);   // waves per chunk index (hv + 16: with a component tail)
+      const long long kr = (long long)K * R * (P.use_mfma ? (P.hv & 15) : 1);   // waves per chunk index (hv + 16 TL: with a component tail)
       const double setup = 1.5;   // measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
       double best = 1e300;
       int bestC = 1;

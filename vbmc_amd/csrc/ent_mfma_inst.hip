@@ -9,7 +9,7 @@
 #define CAT2(a, b) a##b
 #define CAT(a, b) CAT2(a, b)
 
-template <int KT, int HV, bool TL = false>
+template <int KT, int HV, int TL = 0>
 static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
   // dynamic LDS: the parameter block (<= 74 KB at K = 256, D = 32), reused by the exp table (8 KB) and the PV exchange of
   // multi-wave workgroups (2 signs x HV waves x NPV x 4 x 64 doubles)
@@ -41,13 +41,21 @@ extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, 
     case 16 + 2: launch_kt<2, 1>(grad, grid, st, *ea); return 0;
     case 16 + 3: launch_kt<3, 1>(grad, grid, st, *ea); return 0;
     case 16 + 4: launch_kt<4, 1>(grad, grid, st, *ea); return 0;
-    case 272 + 1: launch_kt<1, 1, true>(grad, grid, st, *ea); return 0;   // hv = 17: one wave, kt full k-tiles + a tail of K mod 16 <= 4 components
-    case 272 + 2: launch_kt<2, 1, true>(grad, grid, st, *ea); return 0;
-    case 272 + 3: launch_kt<3, 1, true>(grad, grid, st, *ea); return 0;
-    case 288 + 2: launch_kt<2, 2, true>(grad, grid, st, *ea); return 0;   // hv = 18: two waves, each kt full k-tiles + a tail (K = 66..72)
-    case 288 + 3: launch_kt<3, 2, true>(grad, grid, st, *ea); return 0;   //          K = 98..104
-    case 320 + 2: launch_kt<2, 4, true>(grad, grid, st, *ea); return 0;   // hv = 20: four waves + tails (K = 130..144)
-    case 320 + 3: launch_kt<3, 4, true>(grad, grid, st, *ea); return 0;   //          K = 194..208
+    // hv + 16 TL: kt full k-tiles per wave + a tail of (components per wave) mod 16 <= 4 TL components, TL values per lane
+    case 272 + 1: launch_kt<1, 1, 1>(grad, grid, st, *ea); return 0;   // one wave: K = 17..20
+    case 272 + 2: launch_kt<2, 1, 1>(grad, grid, st, *ea); return 0;   //           33..36
+    case 272 + 3: launch_kt<3, 1, 1>(grad, grid, st, *ea); return 0;   //           49..52
+    case 288 + 2: launch_kt<2, 2, 1>(grad, grid, st, *ea); return 0;   // two waves: K = 66..72
+    case 288 + 3: launch_kt<3, 2, 1>(grad, grid, st, *ea); return 0;   //            98..104
+    case 320 + 2: launch_kt<2, 4, 1>(grad, grid, st, *ea); return 0;   // four waves: K = 130..144
+    case 320 + 3: launch_kt<3, 4, 1>(grad, grid, st, *ea); return 0;   //             194..208
+    case 528 + 1: launch_kt<1, 1, 2>(grad, grid, st, *ea); return 0;   // two values per lane: K = 21..24
+    case 528 + 2: launch_kt<2, 1, 2>(grad, grid, st, *ea); return 0;   //                      37..40
+    case 528 + 3: launch_kt<3, 1, 2>(grad, grid, st, *ea); return 0;   //                      53..56
+    case 544 + 2: launch_kt<2, 2, 2>(grad, grid, st, *ea); return 0;   // two waves: K = 74..80
+    case 544 + 3: launch_kt<3, 2, 2>(grad, grid, st, *ea); return 0;   //            106..112
+    case 576 + 2: launch_kt<2, 4, 2>(grad, grid, st, *ea); return 0;   // four waves: K = 146..160
+    case 576 + 3: launch_kt<3, 4, 2>(grad, grid, st, *ea); return 0;   //             210..224
     case 32 + 3: launch_kt<3, 2>(grad, grid, st, *ea); return 0;   // 64 < K <= 96, two waves
     case 32 + 4: launch_kt<4, 2>(grad, grid, st, *ea); return 0;   // 96 < K <= 128
     case 64 + 2: launch_kt<2, 4>(grad, grid, st, *ea); return 0;   // 64 < K <= 128, four waves

@@ -96,15 +96,16 @@ __device__ __forceinline__ void ent_sync_wg() {
 // to the waves, each wave owns the weight gradient of its components.  The exchange buffers reuse the parameter block's LDS
 // (needed only while the operand fragments are built).
 //
-// TL: the last (components of the wave) mod 16 <= 4 components do not get a k-tile of their own.  A 16-wide k-tile for two
+// TL = 1, 2: the last (components of the wave) mod 16 <= 4 TL components do not get a k-tile of their own.  A 16-wide k-tile for two
 // components (K = 50) costs four S-step MFMAs, 26 VGPRs of operands / exponents / accumulators and an exp register per sign; as a
 // TAIL they live in the lane layout (sample li, tail component lg) -- one value per lane: the linear part of the exponent is D
 // FMAs per tile from two LDS rows (the sample's draws, the component's coefficients), one exp per sign, and the lane's value IS
 // the A operand of one PV MFMA (component index = inner index lg), its weight-gradient term one lane-local FMA.
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, bool TL = false>
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0>
 __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_entropy_mfma(EntArgs a) {
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
-  static_assert(!TL || !SPARSE, "the component tail exists for the dense kernels only");
+  static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
+  constexpr int TLN = TL > 0 ? TL : 1;     // tail values per lane: tail component 4u + lg, u < TL (the layout of a k-tile's register u)
   constexpr bool SP = SPARSE;  // block-sparse variant: uniform per-k-tile branches; the dense variant is branch-free
   constexpr int DP = 4 * QS;               // padded eps row length
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
   constexpr bool EO = HV == 1;
   constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
-  __shared__ double BTL_all[HV][TL ? 4 * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
+  __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   const int tid = threadIdx.x, hv = HV == 1 ? 0 : tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
   const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
@@ -245,35 +246,41 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
 
   // ---- tail components 16 KT + lg (TL): even-part coefficients, PV operand and weight in registers (one component per lane
   // group), the linear coefficients as a row of BTL
-  double tC0 = 0.0, tC1 = 0.0, VBt[NPV], WFt = 0.0, Wt = 0.0;
+  double tC0[TLN], tC1[TLN], VBt[TLN][NPV], WFt[TLN], Wt[TLN];
 #pragma unroll
-  for (int pv = 0; pv < NPV; ++pv) VBt[pv] = 0.0;
+  for (int u = 0; u < TLN; ++u) {
+    tC0[u] = 0.0; tC1[u] = 0.0; WFt[u] = 0.0; Wt[u] = 0.0;
+#pragma unroll
+    for (int pv = 0; pv < NPV; ++pv) VBt[u][pv] = 0.0;
+  }
   if (TL) {
-    const int kq = 16 * KT + lg;
-    const bool kvq = kq < Kw;
-    const double* pq = gp + (size_t)(kvq ? kbase + kq : 0) * PSg;
-    const double h = pq[D];
-    double m2 = 0.0;
-    for (int d = 0; d < D; ++d) { double t = pq[d] - pj[d]; m2 = fma(t, t, m2); }
-    tC0 = kvq ? ESC * (h + hj_neg) : 0.0;
-    tC1 = ESC * (kvq ? fma(h, m2, pq[D + 1]) - cKj : -1.0e6);            // absent component: exp -> 0
-    if (li < DP) BTL[lg * DP + li] = (kvq && li < D) ? ESC * (-2.0 * h * (pq[li] - pj[li])) : 0.0;
-    if (DP > 16 && li + 16 < DP) BTL[lg * DP + li + 16] = (kvq && li + 16 < D) ? ESC * (-2.0 * h * (pq[li + 16] - pj[li + 16])) : 0.0;
-    if (DP > 32 && li + 32 < DP) BTL[lg * DP + li + 32] = (kvq && li + 32 < D) ? ESC * (-2.0 * h * (pq[li + 32] - pj[li + 32])) : 0.0;
-    if (GRAD) {
 #pragma unroll
-      for (int pv = 0; pv < NPV; ++pv) {     // PV "B" operand: inner index lg <-> tail component, column 16 pv + li
-        const int col = 16 * pv + li;
-        double v = 0.0;
-        if (kvq) {
-          if (col == 0) v = pq[D + 2];
-          else if (col == 1) v = pq[D + 3];
-          else if (col < 2 + D) v = pq[D + 3] * (pq[col - 2] - pj[col - 2]);
+    for (int u = 0; u < TLN; ++u) {
+      const int tq = 4 * u + lg;               // tail component of this lane group
+      const int kq = 16 * KT + tq;
+      const bool kvq = kq < Kw;
+      const double* pq = gp + (size_t)(kvq ? kbase + kq : 0) * PSg;
+      const double h = pq[D];
+      double m2 = 0.0;
+      for (int d = 0; d < D; ++d) { double t = pq[d] - pj[d]; m2 = fma(t, t, m2); }
+      tC0[u] = kvq ? ESC * (h + hj_neg) : 0.0;
+      tC1[u] = ESC * (kvq ? fma(h, m2, pq[D + 1]) - cKj : -1.0e6);            // absent component: exp -> 0
+      for (int d = li; d < DP; d += 16) BTL[tq * DP + d] = (kvq && d < D) ? ESC * (-2.0 * h * (pq[d] - pj[d])) : 0.0;
+      if (GRAD) {
+#pragma unroll
+        for (int pv = 0; pv < NPV; ++pv) {     // PV "B" operand: inner index lg <-> tail component 4u + lg, column 16 pv + li
+          const int col = 16 * pv + li;
+          double v = 0.0;
+          if (kvq) {
+            if (col == 0) v = pq[D + 2];
+            else if (col == 1) v = pq[D + 3];
+            else if (col < 2 + D) v = pq[D + 3] * (pq[col - 2] - pj[col - 2]);
+          }
+          VBt[u][pv] = v;
         }
-        VBt[pv] = v;
+      } else {
+        WFt[u] = kvq ? pq[D + 2] : 0.0;
       }
-    } else {
-      WFt = kvq ? pq[D + 2] : 0.0;
     }
   }
 
@@ -386,16 +393,21 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       }
     }
 
-    // tail components: E+- = even +- linear, one value per lane (sample li, tail component lg)
-    double ntl = 0.0, ntm = 0.0;
-    if (TL) {
-      double lt = 0.0;
+    // tail components: E+- = even +- linear, TL values per lane (sample li, tail component 4u + lg)
+    double ntl[TLN], ntm[TLN];
 #pragma unroll
-      for (int d = 0; d < DP; ++d) lt = fma(BTL[lg * DP + d], Et[li * DP + d], lt);    // zero beyond D on both sides
-      lt *= sigj;
-      const double ct = fma(tC0, u2, tC1);
-      ntl = ct + lt;
-      ntm = ct - lt;
+    for (int u = 0; u < TLN; ++u) { ntl[u] = 0.0; ntm[u] = 0.0; }
+    if (TL) {
+#pragma unroll
+      for (int u = 0; u < TLN; ++u) {
+        double lt = 0.0;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) lt = fma(BTL[(4 * u + lg) * DP + d], Et[li * DP + d], lt);    // zero beyond D on both sides
+        lt *= sigj;
+        const double ct = fma(tC0[u], u2, tC1[u]);
+        ntl[u] = ct + lt;
+        ntm[u] = ct - lt;
+      }
     }
 
     // ---- the phases of one sign as inlined pieces (x: the sign's exponents, overwritten by their exponentials)
@@ -420,10 +432,15 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         }
       }
     };
-    auto texp = [&](double& t) { if (TL && X_EXP) t = vb_exp_tab1k(t, TAB); };
+    auto texp = [&](double (&t)[TLN]) {
+      if (TL && X_EXP) {
+#pragma unroll
+        for (int u = 0; u < TLN; ++u) t[u] = vb_exp_tab1k(t[u], TAB);
+      }
+    };
     // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
     // (NPV >= 2: the column blocks are independent chains already, one set is enough -- 16 VGPRs less.)
-    auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg, double tn) {
+    auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg, const double (&tn)[TLN]) {
 #ifdef VBMC_TUNE_PV2
       constexpr bool TWO = (VBMC_TUNE_PV2) != 0 || NPV == 1;
 #else
@@ -455,7 +472,10 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         if (nr_last > 1) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][1], VBV(KT - 1, 1, pv), Yb, 0, 0, 0);
         if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
         if (nr_last > 3) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][3], VBV(KT - 1, 3, pv), Yb, 0, 0, 0);
-        if (TL) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(tn, VBt[pv], Y[pv], 0, 0, 0);   // the tail: inner index lg = tail component
+        if (TL) {   // the tail: inner index lg <-> tail component 4u + lg
+#pragma unroll
+          for (int u = 0; u < TLN; ++u) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(tn[u], VBt[u][pv], Y[pv], 0, 0, 0);
+        }
         if (TWO) Y[pv] += Yb;
       }
       if (HV > 1) {
@@ -492,8 +512,11 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
       if (svalid) accH += shift;
       return rqs;
     };
-    auto wacc = [&](mf4 (&x)[KT], double rqs, double tn) {
-      if (TL) Wt = fma(tn, rqs, Wt);
+    auto wacc = [&](mf4 (&x)[KT], double rqs, const double (&tn)[TLN]) {
+      if (TL) {
+#pragma unroll
+        for (int u = 0; u < TLN; ++u) Wt[u] = fma(tn[u], rqs, Wt[u]);
+      }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (SP && !((act >> kt) & 1u)) continue;
@@ -608,7 +631,10 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
           for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) qp = fma(WF[kt][rr], n[kt][rr], qp);
-          if (TL) qp = fma(WFt, ntl, qp);
+          if (TL) {
+#pragma unroll
+            for (int u = 0; u < TLN; ++u) qp = fma(WFt[u], ntl[u], qp);
+          }
           qp += __shfl_xor(qp, 16, 64);
           qp += __shfl_xor(qp, 32, 64);
           if (HV > 1) {
@@ -631,7 +657,8 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
         }
-        ntl = ntm;
+#pragma unroll
+        for (int u = 0; u < TLN; ++u) ntl[u] = ntm[u];
       }
     }
   }
@@ -676,10 +703,14 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
         if (li == 0 && k < Kw) o[2 + 2 * D + kbase + k] = wv;
       }
     if (TL) {
-      double wv = Wt;
-      wv += __shfl_xor(wv, 1, 64); wv += __shfl_xor(wv, 2, 64);
-      wv += __shfl_xor(wv, 4, 64); wv += __shfl_xor(wv, 8, 64);
-      if (li == 0 && 16 * KT + lg < Kw) o[2 + 2 * D + kbase + 16 * KT + lg] = wv;
+#pragma unroll
+      for (int u = 0; u < TLN; ++u) {
+        double wv = Wt[u];
+        wv += __shfl_xor(wv, 1, 64); wv += __shfl_xor(wv, 2, 64);
+        wv += __shfl_xor(wv, 4, 64); wv += __shfl_xor(wv, 8, 64);
+        const int k = 16 * KT + 4 * u + lg;
+        if (li == 0 && k < Kw) o[2 + 2 * D + kbase + k] = wv;
+      }
     }
   }
 #undef VBV
