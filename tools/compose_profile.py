@@ -30,11 +30,11 @@ def grab(txt, kern, ctr):
     return float(re.search(r"- %s = ([0-9.e+]+)" % ctr, seg).group(1))
 
 
-kern = "`void k_entropy_mfma<3, 3, true, false, 1, true>(EntArgs)`"   # the headline instantiation: QS 3, three k-tiles + component tail
+kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1>(EntArgs)`"   # the headline instantiation: QS 3, three k-tiles + component tail
 fetch, write = grab(pa, kern, "FETCH_SIZE"), grab(pb, kern, "WRITE_SIZE")
 hbm = int(round(fetch * 1024 * 2 + write * 1024))
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_entropy_mfma<3,3,true,false,1,true>", "commit": commit,
+json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_entropy_mfma<3,3,true,false,1,1>", "commit": commit,
            "kernel_source_sha256_16": kernel_source_hash(),
            "workload": "python bench.py (R=64, C3, device RNG)", "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); "
