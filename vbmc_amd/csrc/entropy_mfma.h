@@ -14,14 +14,18 @@
 // W_l = sum_i n_il / q_i (entmc_vbmc.m:100) is one lane-local FMA per pair.
 //
 // One wave (= one 64-thread workgroup) per (sample chunk, source component j, restart r).  A tile is
-// 16 base samples, processed twice (+eps, -eps: antithetic, entmc_vbmc.m:53-54).  All mixture-side
-// MFMA operands are built once per wave and stay in registers; LDS holds only the 16 x D eps tile
-// (read in two layouts), the 64-entry exp table and 16 scalars.  The number of k-tiles KT =
-// ceil(K/16) <= 4 is a template parameter (64 < K <= 128: see HV below) so the tile body is one straight-line block (4*KT independent
-// exp chains for the scheduler); padded components carry the constant -1e6 and vanish in the exp.
+// 16 base samples, processed twice (+eps, -eps: antithetic, entmc_vbmc.m:53-54).  The pair shares the even part of the
+// exponent: E+ = C + L, E- = 2C - E+ with ONE even product C and ONE linear product L per tile (see the S-step below).
+// The S-step operands are built once per wave and stay in registers, the PV operands of larger mixtures in LDS; LDS also
+// holds the 16 x D eps tile (read in two layouts), the 1024-entry exp table (in the space of the parameter block, which is
+// dead once the operands are built; the table's factor 1024/ln2 rides in the S-step operands) and 16 scalars.  The number of
+// k-tiles per wave KT <= 4 is a template parameter (K > 64: HV = 2 or 4 waves per workgroup share the components, see below);
+// the last (components per wave) mod 16 <= 8 components can run as a lane-layout TAIL instead of a k-tile (TL, see below).
+// The tile body is straight-line code: the sign loop, or -- where its registers allow -- both signs staggered (VBMC_STAG_FOR).
+// Padded components carry the constant -1e6 and vanish in the exp.
 // sum_i log q'_i is accumulated as a mantissa product + exponent sum (one log per 256 samples).
 // Partials have the same layout as k_entropy (sum log q | G[D] | SG | LG[D] | W[K]) and are reduced
-// by k_finalize in a fixed order.
+// by k_ent_reduce / k_finalize in a fixed order.
 #pragma once
 #include <type_traits>
 
