@@ -154,6 +154,21 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def kernel_source_hash():
+    """Identifies the CODE of the entropy kernel a PMC figure (profiles/*_pmc.json) belongs to: sha256 over its sources with
+    // comments and all white space removed, so that editing a comment does not make a measured figure look stale."""
+    import hashlib
+    import re
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    hh = hashlib.sha256()
+    for fn in ("entropy_mfma.h", "ent_mfma_inst.hip", "device_math.h", "elbo_types.h"):
+        txt = open(os.path.join(here, "vbmc_amd", "csrc", fn)).read()
+        txt = re.sub(r"//[^\n]*", "", txt)
+        hh.update(re.sub(r"\s+", "", txt).encode())
+    return hh.hexdigest()[:16]
+
+
 def entropy_kernel_label(D, K):
     """the instantiation mfma_entropy_fits (vbmc_amd/csrc/abi_elbo.hip) picks: waves per workgroup, k-tiles per wave, component tail"""
     qs = (D + 5) // 4
@@ -370,15 +385,10 @@ def main():
         pdir = os.path.join(here, "profiles")
         pmc_files = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc.json")) if os.path.isdir(pdir) else []
         if pmc_files and (D, N, K, S, Rr) == (10, 400, 50, 20, 64):
-            import hashlib
-
             with open(os.path.join(pdir, pmc_files[-1])) as f:
                 pmc = json.load(f)
-            hh = hashlib.sha256()
-            for fn in ("entropy_mfma.h", "ent_mfma_inst.hip", "device_math.h", "elbo_types.h"):
-                hh.update(open(os.path.join(here, "vbmc_amd", "csrc", fn), "rb").read())
             traffic = pmc["hbm_bytes_per_launch"]
-            traffic_stale = pmc.get("kernel_source_sha256_16") != hh.hexdigest()[:16]
+            traffic_stale = pmc.get("kernel_source_sha256_16") != kernel_source_hash()
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s)" % (pmc_files[-1], pmc.get("commit", "?"))
         extra["logjoint_kernel_ms"] = lj_ms
         return {"bound": "mfma", "kernel": entropy_kernel_label(D, K), "achieved": achieved,

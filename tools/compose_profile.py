@@ -12,12 +12,8 @@ RND = os.environ.get("ROUND", "r02")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def kernel_source_hash():
-    """Identifies the entropy-kernel sources a PMC figure belongs to (bench.py flags a stale figure)."""
-    h = hashlib.sha256()
-    for f in ("entropy_mfma.h", "ent_mfma_inst.hip", "device_math.h", "elbo_types.h"):
-        h.update(open(os.path.join(ROOT, "vbmc_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402  (code-only hash: comments and white space do not count)
 
 tag, changes = sys.argv[1], sys.argv[2]
 o = "gpurun_out/%s/" % tag
