@@ -13,6 +13,7 @@ Formulas follow (reference paths, acerbilab/vbmc v1.0.12):
   gp_pred  gplite/gplite_pred.m:52-165
   pred     gplite/gplite_noisefun.m:176-210 + gplite_core.m:33-102 + gplite_pred.m:60-127 with the general noise models,
            ystar / s2star and the log predictive density lp (mp_pred_case*.json)
+  pen      misc/vpbndloss.m:1-73, utils/softbndloss.m:1-30, misc/negelcbo_vbmc.m:146-162 (mp_pen_case*.json)
   nlZ      gplite/private/gplite_core.m:205 (value); its gradient (:236-275) is pinned by 50-digit central
            differences of the value, i.e. independently of the reference's analytic Q-matrix formulas
 
@@ -476,6 +477,142 @@ def main_pred():
         print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
 
 
+
+# ------------------------------------------------------------------ soft-bound and weight penalties
+def mp_penalties(theta, D, K, opt, fixed, lb, ub, TolCon, Wthresh, Wpen):
+    """misc/vpbndloss.m:1-73 + utils/softbndloss.m:1-30 + the weight penalty of misc/negelcbo_vbmc.m:146-162, from the formulas:
+    theta in the reference order [mu(:); ln sigma; ln lambda; eta] (optimised groups only), `fixed` the values of the others.
+    Returns (L_bnd, dL_bnd[T], L_w, dL_w[T])."""
+    i = 0
+    if opt[0]:
+        mu = theta[i : i + D * K]; i += D * K
+    else:
+        mu = fixed["mu"]
+    if opt[1]:
+        lns = theta[i : i + K]; i += K
+    else:
+        lns = [mp.log(t) for t in fixed["sigma"]]
+    if opt[2]:
+        lnl = theta[i : i + D]; i += D
+    else:
+        lnl = [mp.log(t) for t in fixed["lambda"]]
+    eta = theta[i : i + K] if opt[3] else None
+    ext, kind = [], []
+    if opt[0]:
+        ext += list(mu); kind += [("mu", p) for p in range(D * K)]
+    if opt[1] or opt[2]:
+        for k in range(K):                      # lnscale(:) of a D x K matrix: d fastest
+            for d in range(D):
+                ext.append(lns[k] + lnl[d]); kind.append(("sc", d, k))
+    if opt[3]:
+        ext += list(eta); kind += [("eta", k) for k in range(K)]
+    assert len(ext) == len(lb) == len(ub)
+    L = mp.mpf(0)
+    dext = [mp.mpf(0)] * len(ext)
+    for q, x in enumerate(ext):
+        ell = (ub[q] - lb[q]) * TolCon
+        if x < lb[q]:
+            L += ((lb[q] - x) / ell) ** 2 / 2
+            dext[q] = (x - lb[q]) / ell ** 2
+        if x > ub[q]:
+            L += ((x - ub[q]) / ell) ** 2 / 2
+            dext[q] = (x - ub[q]) / ell ** 2
+    T = len(theta)
+    dL = [mp.mpf(0)] * T
+    i = 0
+    off = {}
+    if opt[0]:
+        off["mu"] = i; i += D * K
+    if opt[1]:
+        off["sigma"] = i; i += K
+    if opt[2]:
+        off["lambda"] = i; i += D
+    if opt[3]:
+        off["eta"] = i
+    for q, kd in enumerate(kind):
+        if kd[0] == "mu":
+            dL[off["mu"] + kd[1]] += dext[q]
+        elif kd[0] == "sc":
+            if opt[1]:
+                dL[off["sigma"] + kd[2]] += dext[q]
+            if opt[2]:
+                dL[off["lambda"] + kd[1]] += dext[q]
+        else:
+            dL[off["eta"] + kd[1]] += dext[q]
+    Lw, dLw = mp.mpf(0), [mp.mpf(0)] * T
+    if opt[3]:
+        ee = [mp.e ** t for t in eta]
+        ssum = mp.fsum(ee)
+        w = [t / ssum for t in ee]
+        Lw = Wpen * mp.fsum(wk if wk < Wthresh else Wthresh for wk in w)
+        g = [Wpen if wk < Wthresh else mp.mpf(0) for wk in w]
+        Jw = softmax_jac(eta)
+        gw = matvec(Jw, g)
+        for k in range(K):
+            dLw[off["eta"] + k] = gw[k]
+    return L, dL, Lw, dLw
+
+
+PEN_CASES = [
+    dict(seed=41, D=3, K=4, opt=(1, 1, 1, 1)),
+    dict(seed=42, D=2, K=5, opt=(1, 1, 1, 0)),      # warm-up: weights fixed (setupvars_vbmc.m:89-91)
+    dict(seed=43, D=4, K=3, opt=(1, 0, 0, 1)),
+    dict(seed=44, D=2, K=6, opt=(0, 1, 1, 1)),
+    dict(seed=45, D=3, K=2, opt=(1, 1, 0, 1)),
+]
+
+
+def make_pen_case(seed, D, K, opt):
+    rng = np.random.default_rng(seed)
+    mu = 1.5 * rng.standard_normal((D, K))
+    sigma = 0.4 * np.exp(0.3 * rng.standard_normal(K))
+    lam = np.exp(0.2 * rng.standard_normal(D))
+    eta = 1.5 * rng.standard_normal(K)
+    eta[0] = -6.0                                   # a weight below the threshold
+    theta = np.concatenate([x for x, o in ((mu.reshape(-1, order="F"), opt[0]), (np.log(sigma), opt[1]), (np.log(lam), opt[2]), (eta, opt[3])) if o])
+    next_ = (D * K if opt[0] else 0) + (D * K if (opt[1] or opt[2]) else 0) + (K if opt[3] else 0)
+    # bounds that some entries violate on either side (and some sit exactly on)
+    lb, ub = [], []
+    if opt[0]:
+        lb += list(mu.reshape(-1, order="F") - np.where(rng.random(D * K) < 0.3, -0.4, 1.0))
+        ub += list(mu.reshape(-1, order="F") + np.where(rng.random(D * K) < 0.3, -0.3, 1.2))
+    if opt[1] or opt[2]:
+        sc = (np.log(sigma)[None, :] + np.log(lam)[:, None]).reshape(-1, order="F")
+        lb += list(sc - np.where(rng.random(D * K) < 0.25, -0.2, 0.8))
+        ub += list(sc + np.where(rng.random(D * K) < 0.25, -0.25, 0.9))
+    if opt[3]:
+        lb += list(np.full(K, -4.0))
+        ub += list(np.zeros(K))
+    lb, ub = np.array(lb), np.array(ub)
+    swap = lb > ub                                  # keep lb < ub where both shifts went inwards
+    lb[swap], ub[swap] = ub[swap] - 0.1, lb[swap] + 0.1
+    assert lb.size == next_
+    return dict(seed=seed, D=D, K=K, opt=list(opt), theta=theta, mu=mu, sigma=sigma, lam=lam, eta=eta, lb=lb, ub=ub,
+                TolCon=0.01, WeightThreshold=0.05, WeightPenalty=0.1)
+
+
+def run_pen_case(c):
+    D, K, opt = c["D"], c["K"], c["opt"]
+    fixed = {"mu": [M(t) for t in c["mu"].reshape(-1, order="F")], "sigma": [M(t) for t in c["sigma"]], "lambda": [M(t) for t in c["lam"]]}
+    L, dL, Lw, dLw = mp_penalties([M(t) for t in c["theta"]], D, K, opt, fixed, [M(t) for t in c["lb"]], [M(t) for t in c["ub"]],
+                                  M(c["TolCon"]), M(c["WeightThreshold"]), M(c["WeightPenalty"]))
+    return {"L_bnd": fl(L), "dL_bnd": fl(dL), "L_w": fl(Lw), "dL_w": fl(dLw)}
+
+
+def main_pen():
+    outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    for i, spec in enumerate(PEN_CASES):
+        c = make_pen_case(**spec)
+        out = run_pen_case(c)
+        rec = {"generator": "oracle/mp_golden.py pen (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps),
+               "inputs": {k: (tolist(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()},
+               "expected": out}
+        path = os.path.join(outdir, "mp_pen_case%d.json" % i)
+        with open(path, "w") as f:
+            json.dump(rec, f)
+        print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
+
+
 # ------------------------------------------------------------------ driver
 def tolist(a):
     return np.asarray(a, dtype=np.float64).tolist()
@@ -700,6 +837,8 @@ if __name__ == "__main__":
         main_nlz()      # only the marginal-likelihood fixtures
     elif "pred" in sys.argv[1:]:
         main_pred()
+    elif "pen" in sys.argv[1:]:
+        main_pen()
     elif "acq" in sys.argv[1:]:
         main_acq()      # only the acquisition-function fixtures
     else:
@@ -707,3 +846,4 @@ if __name__ == "__main__":
         main_nlz()
         main_acq()
         main_pred()
+        main_pen()

@@ -46,6 +46,25 @@ def load_pred_golden(path):
     return inp, {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
 
 
+def pen_golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "mp_pen_case*.json")))
+
+
+def load_pen_golden(path):
+    """-> (vp with the optimise flags of the case, theta, thetabnd, expected dict): soft-bound and weight penalties."""
+    with open(path) as f:
+        rec = json.load(f)
+    inp = rec["inputs"]
+    a = lambda k: np.array(inp[k], dtype=np.float64)  # noqa: E731
+    vp = R.make_vp(a("mu"), a("sigma"), a("lam"), eta=a("eta"))
+    e = np.exp(a("eta"))
+    vp["w"] = e / np.sum(e)
+    for name, o in zip(("optimize_mu", "optimize_sigma", "optimize_lambda", "optimize_weights"), inp["opt"]):
+        vp[name] = bool(o)
+    tb = {"lb": a("lb"), "ub": a("ub"), "TolCon": inp["TolCon"], "WeightThreshold": inp["WeightThreshold"], "WeightPenalty": inp["WeightPenalty"]}
+    return vp, a("theta"), tb, {k: np.array(v, dtype=np.float64) for k, v in rec["expected"].items()}
+
+
 def acq_golden_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, "mp_acq_case*.json")))
 

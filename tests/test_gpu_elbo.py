@@ -376,3 +376,20 @@ def test_prepared_objective_equals_batch_call(va):
         F, dF = obj(Th, seed=100 + it)
         ref = va.negelcbo_batch(Th, 0, vp, gp, 40, True, 0, seed=100 + it)
         assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])
+
+
+def test_penalties_against_mpmath_vectors(va):
+    """The soft-bound and weight penalties k_finalize adds (negelcbo_vbmc.m:136-164, vpbndloss.m, softbndloss.m) against the
+    50-digit vectors tests/golden/mp_pen_case*.json -- every optimise-flag subset of the fixtures -- as the difference of the
+    device evaluations with and without thetabnd (deterministic entropy: everything else cancels exactly)."""
+    from tests._cases import load_pen_golden, pen_golden_cases
+    from tests.test_oracle_golden import penalty_problem
+
+    for path in pen_golden_cases():
+        vp, theta, tb, exp = load_pen_golden(path)
+        gp = penalty_problem(vp)
+        F1, dF1 = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 1, 0, False, tb)
+        F0, dF0 = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 1, 0)
+        sc = max(1.0, abs(F1))
+        assert abs((F1 - F0) - (exp["L_bnd"] + exp["L_w"])) < 1e-12 * sc, path
+        assert np.max(np.abs((dF1 - dF0) - (exp["dL_bnd"] + exp["dL_w"]))) < 1e-12 * max(1.0, np.max(np.abs(dF1))), path

@@ -3,8 +3,8 @@ import numpy as np
 import pytest
 
 from oracle import vbmc_ref as R
-from tests._cases import (acq_golden_cases, golden_cases, load_acq_golden, load_golden, load_nlz_golden, load_pred_golden,
-                          nlz_golden_cases, pred_golden_cases, vp_from_inputs)
+from tests._cases import (acq_golden_cases, golden_cases, load_acq_golden, load_golden, load_nlz_golden, load_pen_golden, load_pred_golden,
+                          nlz_golden_cases, pen_golden_cases, pred_golden_cases, synth_problem, vp_from_inputs)
 
 RTOL = 1e-11  # fp64 restatement vs 50-digit evaluation; sums of <= ~100 terms
 
@@ -154,3 +154,25 @@ def test_pred_general_noise_matches_mpmath(path):
     gp = R.gplite_post(inp["hyp"], inp["X"], inp["y"], meanfun=inp["meanfun"], noisefun=inp["noisefun"], s2=inp["s2"])
     out = R.gplite_pred(gp, inp["Xstar"], inp["ystar"], inp["s2star"], True, nargout=5)
     check_pred_against_golden(gp, out, exp, bool(np.min(exp["min_sn2"]) >= 1e-6))
+
+
+def penalty_problem(vp):
+    """a small surrogate for the penalty tests: the penalties are the difference of two negelcbo calls (with / without thetabnd)"""
+    p = synth_problem(9, vp["D"], 12, vp["K"], 2)
+    return R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"])
+
+
+@pytest.mark.parametrize("path", pen_golden_cases())
+def test_penalties_match_mpmath(path):
+    """vpbndloss.m + softbndloss.m directly, and the soft-bound + weight penalties as negelcbo_vbmc.m:136-164 adds them
+    (difference of the calls with and without thetabnd; deterministic entropy), against tests/golden/mp_pen_case*.json."""
+    vp, theta, tb, exp = load_pen_golden(path)
+    L, dL = R.vpbndloss(theta, vp, tb, tb["TolCon"])
+    close(L, exp["L_bnd"], rtol=1e-13)
+    close(dL, exp["dL_bnd"], rtol=1e-13)
+    gp = penalty_problem(vp)
+    r1 = R.negelcbo_vbmc(theta, 0, vp, gp, 0, True, 0, thetabnd=tb)
+    r0 = R.negelcbo_vbmc(theta, 0, vp, gp, 0, True, 0)
+    sc = max(1.0, abs(r1["F"]))
+    assert abs((r1["F"] - r0["F"]) - (exp["L_bnd"] + exp["L_w"])) < 1e-12 * sc
+    assert np.max(np.abs((r1["dF"] - r0["dF"]) - (exp["dL_bnd"] + exp["dL_w"]))) < 1e-12 * max(1.0, np.max(np.abs(r1["dF"])))

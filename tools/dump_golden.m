@@ -3,8 +3,8 @@ function dump_golden(repo_root, vbmc_root)
 %
 %   dump_golden('/path/to/this/repo', '/path/to/vbmc')
 %
-% For every tests/golden/mp_case*.json, mp_nlz_case*.json, mp_pred_case*.json and mp_acq_case*.json this runs the reference's own functions
-% (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ, acqf/acqflog/acqus/acqfsn2/acqviqr_vbmc) on the stored
+% For every tests/golden/mp_case*.json, mp_nlz_case*.json, mp_pred_case*.json, mp_pen_case*.json and mp_acq_case*.json this runs the reference's own functions
+% (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ, vpbndloss, negelcbo_vbmc, acqf/acqflog/acqus/acqfsn2/acqviqr_vbmc) on the stored
 % inputs and writes tests/golden/matlab_case*.json / matlab_nlz_case*.json / matlab_pred_case*.json / matlab_acq_case*.json next to them.  tools/compare_matlab_golden.py then
 % compares those files with the mpmath vectors (and thereby with the oracle and the HIP path, which are pinned to
 % the mpmath vectors by the test-suite).  Nothing here is needed by CI: the development container has no MATLAB,
@@ -81,6 +81,25 @@ for f = 1:numel(files)
         out.alpha(s,:) = gp.post(s).alpha';
         out.min_sn2(s) = 1/gp.post(s).sW(1)^2/gp.post(s).sn2_mult;     % gplite_core.m:281
     end
+    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+end
+% soft-bound and weight penalties (misc/vpbndloss.m, utils/softbndloss.m, misc/negelcbo_vbmc.m:146-162): vpbndloss directly, the
+% weight penalty as negelcbo_vbmc adds it (difference of the calls with and without thetabnd on a one-point surrogate, no entropy
+% samples: everything else cancels)
+files = dir(fullfile(gold,'mp_pen_case*.json'));
+for f = 1:numel(files)
+    rec = jsondecode(fileread(fullfile(gold,files(f).name)));
+    in = rec.inputs; D = in.D; K = in.K; o = logical(in.opt(:)');
+    vp = struct('D',D,'K',K,'mu',reshape_rows(in.mu,K),'sigma',in.sigma(:)','lambda',in.lam(:),'eta',in.eta(:)', ...
+        'w',exp(in.eta(:)')/sum(exp(in.eta(:))),'optimize_mu',o(1),'optimize_sigma',o(2),'optimize_lambda',o(3),'optimize_weights',o(4), ...
+        'delta',[],'trinfo',[]);
+    tb = struct('lb',in.lb(:),'ub',in.ub(:),'TolCon',in.TolCon,'WeightThreshold',in.WeightThreshold,'WeightPenalty',in.WeightPenalty);
+    theta = in.theta(:);
+    [Lb,dLb] = vpbndloss(theta,vp,tb,tb.TolCon);
+    gp1 = gplite_post([zeros(D,1); 0; log(1e-3); 0],zeros(1,D),0,1,1);      % one training point, constant mean
+    [F1,dF1] = negelcbo_vbmc(theta,0,vp,gp1,0,1,0,0,tb);
+    [F0,dF0] = negelcbo_vbmc(theta,0,vp,gp1,0,1,0,0,[]);
+    out = struct('L_bnd',Lb,'dL_bnd',dLb(:)','L_w',(F1-F0)-Lb,'dL_w',(dF1(:)-dF0(:))'-dLb(:)');
     write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
 end
 % acquisition functions (acq/acqf_vbmc.m, acqflog_vbmc.m, acqus_vbmc.m, acqfsn2_vbmc.m, acqviqr_vbmc.m) on the stored points, called
