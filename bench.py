@@ -170,17 +170,18 @@ def kernel_source_hash():
 
 
 def entropy_kernel_label(D, K):
-    """the instantiation mfma_entropy_fits (vbmc_amd/csrc/abi_elbo.hip) picks: waves per workgroup, k-tiles per wave, component tail"""
-    qs = (D + 5) // 4
-    hv = 1 if K <= 64 else ((4 if (K > 96 and (qs >= 7 or (qs >= 5 and K > 112))) else 2) if K <= 128 else 4)
-    Kh = (K + hv - 1) // hv
-    ktf, rem = Kh // 16, Kh % 16
-    tl = (rem + 3) // 4
-    tail8_ok = ktf == 1 or (hv == 1 and ktf == 2 and (qs >= 5 or rem <= 6)) or (hv == 1 and ktf == 3 and qs <= 4) or \
-        (hv > 1 and ktf == 2) or (hv > 1 and ktf == 3 and qs >= 5)
-    tail = Kh > 16 and (tl == 1 or (tl == 2 and tail8_ok)) and not (hv > 1 and ktf < 2)
-    kt = ktf if tail else (Kh + 15) // 16
-    return "k_entropy_mfma<QS=%d,KT=%d%s,grad%s>" % (qs, kt, "+tail%d" % rem if tail else "", "" if hv == 1 else ",HV=%d" % hv)
+    """the instantiation the library's own policy (mfma_entropy_fits, vbmc_amd/csrc/abi_elbo.hip) picks for this shape, asked
+    through the reporting hook vbmc_entropy_plan: k-tiles per wave, component tail, waves per workgroup"""
+    import ctypes
+
+    from vbmc_amd import _lib
+
+    qs, kt, hv, tl = (ctypes.c_int() for _ in range(4))
+    if not _lib.load().vbmc_entropy_plan(int(D), int(K), ctypes.byref(qs), ctypes.byref(kt), ctypes.byref(hv), ctypes.byref(tl)):
+        return "k_entropy<D=%d,grad> (VALU)" % D
+    Kh = (K + hv.value - 1) // hv.value
+    return "k_entropy_mfma<QS=%d,KT=%d%s,grad%s>" % (qs.value, kt.value, "+tail%d" % (Kh - 16 * kt.value) if tl.value else "",
+                                                     "" if hv.value == 1 else ",HV=%d" % hv.value)
 
 
 def main():

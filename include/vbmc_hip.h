@@ -303,6 +303,12 @@ vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * `seed`, so that a host oracle can be fed the same draws (test hook; entmc_vbmc.m:53). */
 vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t seed, double* eps_host);
 
+/* Reporting hook: which instantiation of the Monte-Carlo entropy kernel (vbmc_amd/csrc/entropy_mfma.h) a D-dimensional,
+ * K-component mixture runs on in dense mode: qs = ceil((D+2)/4), kt = 16-component k-tiles per wave, hv = waves per workgroup,
+ * tail = values per lane of the component tail (0: none).  Returns 1, or 0 when the VALU kernel serves the shape.  bench.py
+ * labels the kernel it measures with it. */
+int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* tail);
+
 /* Test hook: y = exp(x) evaluated by the hot-loop device implementations (0: polynomial, 1: table). */
 vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const double* x, double* y);
 

@@ -94,6 +94,8 @@ def load():
     lib.vbmc_elbo_shard_begin.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, C.c_int, vp]
     lib.vbmc_elbo_shard_finish.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, vp]
     lib.vbmc_rng_dump.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _dp]
+    lib.vbmc_entropy_plan.argtypes = [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4
+    lib.vbmc_entropy_plan.restype = C.c_int
     lib.vbmc_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.vbmc_device_free.argtypes = [vp, vp]
     lib.vbmc_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]

@@ -1190,6 +1190,19 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   return VBMC_OK;
 }
 
+// test / reporting hook: the instantiation the Monte-Carlo entropy of a D-dimensional K-component mixture runs on (dense mode):
+// qs = ceil((D + 2) / 4), kt = k-tiles per wave, hv = waves per workgroup, tail = tail values per lane (0: none).  Returns 0 when
+// the matrix-core kernel does not serve the shape (the VALU kernel does).
+extern "C" int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* tail) {
+  int q = 0, k = 0, h = 0;
+  const bool ok = mfma_entropy_fits(D, K, 0.0, &q, &k, &h);
+  if (qs) *qs = q;
+  if (kt) *kt = k;
+  if (hv) *hv = h & 15;
+  if (tail) *tail = h >> 4;
+  return ok ? 1 : 0;
+}
+
 // test hook: y[i] = exp(x[i]) with the hot-loop implementations (variant 0: vb_exp, 1: vb_exp_tab<0>, 2: vb_exp_tab<1>)
 __global__ void k_test_exp(int n, int variant, const double* __restrict__ x, double* __restrict__ y) {
   __shared__ double tab[VB_EXP_TAB_N];
