@@ -791,7 +791,12 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
     LAUNCH_CHECK(ctx, "k_symm");
     HIP_TRY(ctx, trsm_fwd_launch(st, N, K, S, R, gp->L, gp->d_finv, gp->d_lchol, P.d_Z));
-    hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
+    static const bool gram_valu = [] { const char* e = getenv("VBMC_VAR_GRAM"); return e && !strcmp(e, "valu"); }();   // A/B runs
+    if (P.compute_var == 1 && !gram_valu)   // full K x K matrix: Gram products on the matrix cores, one workgroup per (s, r)
+      hipLaunchKernelGGL(k_var_gram_mfma, dim3(S, R), dim3(1024), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
+                         P.d_Z, P.d_X, P.d_J);
+    else
+      hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                        P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);
     LAUNCH_CHECK(ctx, "k_var_gram");
     if (P.vgrad) {

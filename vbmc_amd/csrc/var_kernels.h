@@ -125,6 +125,76 @@ __global__ void __launch_bounds__(256) k_var_gram(ElboDims dm, const double* __r
   }
 }
 
+// The full K x K variance matrix with the Gram products on the matrix cores (round 2): k_var_gram spends one wave per pair on
+// a 7-trip dot product and lane 0 on the pair's scalar term (194 us at K = 50, N = 400, S = 20: 39 % of eval_fullelcbo).  Here one
+// 1024-thread workgroup per (hyper-sample, restart): phase A, the 16 x 16 tiles of V'V (or Z'U for Lchol == false) on or
+// above the diagonal dealt to the 16 waves, inner dimension N in steps of four, raw dots parked in J; phase B, one THREAD per
+// pair (j <= k) for nf_jk (gplogjoint.m:313-317) and the combination (:318-322), mirrored.
+__global__ void __launch_bounds__(1024) k_var_gram_mfma(ElboDims dm, const double* __restrict__ vpd,
+                                                        const double* __restrict__ gpc, const double* __restrict__ delta2,
+                                                        const double* __restrict__ sn2_eff, const unsigned char* __restrict__ lchol,
+                                                        const double* __restrict__ ZV, const double* __restrict__ XU,
+                                                        double* __restrict__ J) {
+  typedef double vg4 __attribute__((ext_vector_type(4)));
+  const int s = blockIdx.x, r = blockIdx.y;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
+  const double* Zs = ZV + ((size_t)r * dm.S + s) * (size_t)K * N;
+  const bool lc = lchol[s] != 0;
+  const double* Vs = (lc ? ZV : XU) + ((size_t)r * dm.S + s) * (size_t)K * N;
+  double* Js = J + ((size_t)r * dm.S + s) * (size_t)K * K;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int nt = (K + 15) >> 4, ntile = nt * (nt + 1) / 2;
+  // ---- phase A: dot[j][k] = sum_n A_j[n] B_k[n] for j <= k (tile-wise), A = V (Lchol) or U, B = V or Z
+  for (int t = wv; t < ntile; t += 16) {
+    int tk = 0;
+    while ((tk + 1) * (tk + 2) / 2 <= t) ++tk;     // tile (tj, tk), tj <= tk: t = tk (tk + 1) / 2 + tj
+    const int tj = t - tk * (tk + 1) / 2;
+    const int ja = min(16 * tj + li, K - 1), kb = min(16 * tk + li, K - 1);
+    const double* pa = Vs + (size_t)ja * N + lg;   // MFMA A operand: row j = li, inner index lg
+    const double* pb = Zs + (size_t)kb * N + lg;   //      B operand: inner index lg, column k = li   (Lchol: Zs == Vs)
+    vg4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+      const double a0 = pa[n], b0 = pb[n], a1 = pa[n + 4], b1 = pb[n + 4];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc2, 0, 0, 0);
+    }
+    for (; n < N; n += 4) {
+      const bool in = n + lg < N;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? pa[n] : 0.0, in ? pb[n] : 0.0, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {               // D[m = lg + 4 rr][n = li]
+      const int j = 16 * tj + lg + 4 * rr, k = 16 * tk + li;
+      if (j < K && k < K && j <= k) Js[j + (size_t)K * k] = acc[rr] + acc2[rr];
+    }
+  }
+  __syncthreads();
+  // ---- phase B: one thread per pair
+  const double sn2 = sn2_eff[s];
+  for (int p = tid; p < K * K; p += 1024) {
+    const int j = p % K, k = p / K;
+    if (j > k) continue;
+    const double dot = Js[j + (size_t)K * k];
+    const double sj = v[L.sigma() + j], sk = v[L.sigma() + k];
+    double slt = 0.0, d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double lam = v[L.lambda() + d];
+      const double t2 = (sj * sj + sk * sk) * lam * lam + g[d] + 2.0 * delta2[d];  // tau_jk^2 (:313), tau_kk (:274)
+      slt += log(sqrt(t2));
+      const double dm_ = v[L.mu() + d + D * j] - v[L.mu() + d + D * k];
+      d2 += dm_ * dm_ / t2;
+    }
+    const double nf = exp(g[3 * D] - slt - 0.5 * d2);
+    const double val = lc ? nf - dot / sn2 : nf + dot;  // :318-322
+    Js[j + (size_t)K * k] = val;
+    if (j != k) Js[k + (size_t)K * j] = val;
+  }
+}
+
 // raw dots of the variance gradient for compute_var == 2: one wave per (k, s, r)
 // VG[r][s][k][2D+1] = dz_dmu*x [D], dz_dsigma*x, dz_dlambda*x [D]   with x = invKzk
 template <int DT>
