@@ -384,11 +384,32 @@ static bool copy_by_kernel(size_t bytes) {
   return !engine && bytes <= COPY_KERNEL_MAX_BYTES;
 }
 
+// inv(L') of the Lchol samples, once per surrogate (gplite_pred's triangular product and the full-variance path use it); null when
+// a 16-row tile of it does not fit the prediction kernel's LDS (N > 1248: those paths fall back to substitutions)
+static vbmc_status ensure_tinv(vbmc_ctx* ctx, const vbmc_gp* gp, bool* have) {
+  const int N = gp->N, S = gp->S;
+  const int Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
+  *have = false;
+  if (!gp->hasL || (size_t)16 * Np * 8 > PRED_LDS_MAX || nblk > PRED_MAXG || trsm_cw_for(N) != 16) return VBMC_OK;
+  if (!gp->d_tinv) {
+    double* t = nullptr;
+    HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)S * N * N * 8, (void**)&t) : hipMalloc((void**)&t, (size_t)S * N * N * 8));
+    hipError_t e_ = tri_inverse_launch(ctx->stream, N, S, gp->L, gp->d_finv, gp->d_lchol, t, 0);
+    if (e_ != hipSuccess) {
+      if (gp->pooled) pool_put(ctx, t); else (void)hipFree(t);
+      return set_err(ctx, VBMC_ERR_HIP, "inv(L') failed: %s", hipGetErrorString(e_));
+    }
+    gp->d_tinv = t;
+  }
+  *have = true;
+  return VBMC_OK;
+}
+
 struct ElboPlan {
   ElboDims dm{};
   int compute_grad = 0, compute_var = 0, dt = 0;
   double beta = 0.0;
-  bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false;
+  bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false, tri_gemm = false;
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0;
@@ -584,7 +605,20 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     const size_t nz = (size_t)R * S * K * N;
     { vbmc_status s_ = ensure(ctx, ctx->zbuf, nz * sizeof(double)); if (s_) return s_; }
     const size_t nJ = (size_t)R * S * K * K, nvg = (size_t)R * S * K * (2 * D + 1), nvo = (size_t)R * P.var_stride;
-    P.needX = P.vgrad || P.any_nochol;
+    // full variance without its gradient (eval_fullelcbo): V = inv(L') Z as a product with the explicit inverse (k_tri_gemm, out of
+    // place into the X block) instead of the substitution; VBMC_VAR_TRSM=1 keeps the substitution (A/B runs)
+    {
+      static const bool keep_trsm = [] { const char* e = getenv("VBMC_VAR_TRSM"); return e && !strcmp(e, "1"); }();
+      bool any_chol = false;
+      for (int s = 0; s < S; ++s) any_chol |= (gp->Lchol[s] != 0);
+      if (compute_var == 1 && any_chol && !keep_trsm) {
+        bool have = false;
+        vbmc_status s_ = ensure_tinv(ctx, gp, &have);
+        if (s_) return s_;
+        P.tri_gemm = have;
+      }
+    }
+    P.needX = P.vgrad || P.any_nochol || P.tri_gemm;
     { vbmc_status s_ = ensure(ctx, ctx->varbuf, ((P.needX ? nz : 0) + nJ + nvg + nvo) * sizeof(double)); if (s_) return s_; }
     P.d_Z = (double*)ctx->zbuf.p;
     P.d_X = (double*)ctx->varbuf.p;
@@ -790,11 +824,17 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     });
     if (P.any_nochol) hipLaunchKernelGGL(k_symm, dim3(32, S, R), dim3(256), 0, st, N, K, S, gp->L, gp->d_lchol, P.d_Z, P.d_X);
     LAUNCH_CHECK(ctx, "k_symm");
-    HIP_TRY(ctx, trsm_fwd_launch(st, N, K, S, R, gp->L, gp->d_finv, gp->d_lchol, P.d_Z));
+    if (P.tri_gemm) {
+      hipLaunchKernelGGL(k_tri_gemm, dim3(((N + 15) / 16) * ((K + 15) / 16), S, R), dim3(64), 0, st, N, K, S, gp->d_tinv, gp->d_lchol,
+                         (const double*)P.d_Z, P.d_X);
+      LAUNCH_CHECK(ctx, "k_tri_gemm");
+    } else {
+      HIP_TRY(ctx, trsm_fwd_launch(st, N, K, S, R, gp->L, gp->d_finv, gp->d_lchol, P.d_Z));
+    }
     static const bool gram_valu = [] { const char* e = getenv("VBMC_VAR_GRAM"); return e && !strcmp(e, "valu"); }();   // A/B runs
-    if (P.compute_var == 1 && !gram_valu)   // full K x K matrix: Gram products on the matrix cores, one workgroup per (s, r)
+    if (P.compute_var == 1 && (!gram_valu || P.tri_gemm))   // full K x K matrix: Gram products on the matrix cores, one workgroup per (s, r)
       hipLaunchKernelGGL(k_var_gram_mfma, dim3(S, R), dim3(1024), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
-                         P.d_Z, P.d_X, P.d_J);
+                         P.d_Z, P.d_X, P.d_J, P.tri_gemm ? 1 : 0);
     else
       hipLaunchKernelGGL(k_var_gram, dim3(16, S, R), dim3(256), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                        P.d_Z, P.d_X, P.d_J, P.compute_var == 1 ? 1 : 0);

@@ -396,16 +396,10 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large for the prediction kernels", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  if (!gp->d_tinv && !slab_pred) {
-    // Tinv = inv(L') = L' \ I for the Lchol samples, once per GP (the kernels skip the others)
-    double* t = nullptr;
-    HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)S * N * N * 8, (void**)&t) : hipMalloc((void**)&t, (size_t)S * N * N * 8));
-    hipError_t e_ = tri_inverse_launch(st, N, S, gp->L, gp->d_finv, gp->d_lchol, t, 0);
-    if (e_ != hipSuccess) {
-      if (gp->pooled) pool_put(ctx, t); else (void)hipFree(t);
-      return set_err(ctx, VBMC_ERR_HIP, "inv(L') failed: %s", hipGetErrorString(e_));
-    }
-    gp->d_tinv = t;
+  if (!slab_pred) {   // Tinv = inv(L') = L' \ I for the Lchol samples, once per GP (the kernels skip the others)
+    bool have = false;
+    vbmc_status s_ = ensure_tinv(ctx, gp, &have);
+    if (s_) return s_;
   }
   // column means for sq_dist's centring (sq_dist.m:36), O((N + Nstar) D) on the host in MATLAB's order
   std::vector<double> mb(D);

@@ -125,6 +125,44 @@ __global__ void __launch_bounds__(256) k_var_gram(ElboDims dm, const double* __r
   }
 }
 
+// V = L' \ Z as a PRODUCT with the explicit triangular inverse T = inv(L') (S x N x N, element (i, n) at n N + i, formed once per
+// surrogate for gplite_pred: ||inv(L')|| <= 1 since L'L = K/sl + I >= I) instead of a substitution: k_trsm_fwd walks the 25 block
+// rows of N = 400 one after the other on 80 waves (142 us, latency-bound); the product has no dependence between output tiles.
+// One wave per 16 x 16 tile of V (components k x rows i), inner index n <= i in steps of four: Vout[k][i] = sum_n T[i][n] Z[k][n].
+// Lchol samples only (the others go through k_symm).  Out of place.
+__global__ void __launch_bounds__(64) k_tri_gemm(int N, int K, int S, const double* __restrict__ Tall, const unsigned char* __restrict__ lchol,
+                                                 const double* __restrict__ Z, double* __restrict__ Vout) {
+  typedef double vg4 __attribute__((ext_vector_type(4)));
+  const int nkb = (K + 15) >> 4;
+  const int ib = blockIdx.x / nkb, kb = blockIdx.x - ib * nkb, s = blockIdx.y, r = blockIdx.z;
+  if (!lchol[s]) return;
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const double* T = Tall + (size_t)s * N * N;
+  const double* Zs = Z + ((size_t)r * S + s) * (size_t)K * N;
+  double* Vs = Vout + ((size_t)r * S + s) * (size_t)K * N;
+  const int i0 = 16 * ib, k0 = 16 * kb;
+  const int ka = min(k0 + li, K - 1), ii = min(i0 + li, N - 1);
+  const double* pa = Zs + (size_t)ka * N + lg;          // A operand: row m = component k0 + li, inner index n0 + lg
+  const double* pb = T + (size_t)lg * N + ii;           // B operand: inner index n0 + lg, column = row i0 + li of V
+  vg4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  const int nend = min(i0 + 16, N);                     // T[i][n] = 0 for n > i
+  int n = 0;
+  for (; n + 8 <= nend; n += 8) {
+    const double a0 = pa[n], b0 = pb[(size_t)n * N], a1 = pa[n + 4], b1 = pb[(size_t)(n + 4) * N];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc2, 0, 0, 0);
+  }
+  for (; n < nend; n += 4) {
+    const bool in = n + lg < N;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? pa[n] : 0.0, in ? pb[(size_t)n * N] : 0.0, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {                      // D[m = lg + 4 rr -> component][n = li -> row i]
+    const int k = k0 + lg + 4 * rr, i = i0 + li;
+    if (k < K && i < N) Vs[(size_t)k * N + i] = acc[rr] + acc2[rr];
+  }
+}
+
 // The full K x K variance matrix with the Gram products on the matrix cores (round 2): k_var_gram spends one wave per pair on
 // a 7-trip dot product and lane 0 on the pair's scalar term (194 us at K = 50, N = 400, S = 20: 39 % of eval_fullelcbo).  Here one
 // 1024-thread workgroup per (hyper-sample, restart): phase A, the 16 x 16 tiles of V'V (or Z'U for Lchol == false) on or
@@ -134,7 +172,7 @@ __global__ void __launch_bounds__(1024) k_var_gram_mfma(ElboDims dm, const doubl
                                                         const double* __restrict__ gpc, const double* __restrict__ delta2,
                                                         const double* __restrict__ sn2_eff, const unsigned char* __restrict__ lchol,
                                                         const double* __restrict__ ZV, const double* __restrict__ XU,
-                                                        double* __restrict__ J) {
+                                                        double* __restrict__ J, int lc_in_x) {   // lc_in_x: V of the Lchol samples is in XU (k_tri_gemm)
   typedef double vg4 __attribute__((ext_vector_type(4)));
   const int s = blockIdx.x, r = blockIdx.y;
   const int D = dm.D, K = dm.K, N = dm.N;
@@ -143,7 +181,8 @@ __global__ void __launch_bounds__(1024) k_var_gram_mfma(ElboDims dm, const doubl
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);
   const double* Zs = ZV + ((size_t)r * dm.S + s) * (size_t)K * N;
   const bool lc = lchol[s] != 0;
-  const double* Vs = (lc ? ZV : XU) + ((size_t)r * dm.S + s) * (size_t)K * N;
+  const double* Vs = ((lc && !lc_in_x) ? ZV : XU) + ((size_t)r * dm.S + s) * (size_t)K * N;
+  if (lc) Zs = Vs;                                  // Lchol: both operands are V
   double* Js = J + ((size_t)r * dm.S + s) * (size_t)K * K;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int nt = (K + 15) >> 4, ntile = nt * (nt + 1) / 2;
