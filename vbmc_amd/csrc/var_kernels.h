@@ -147,6 +147,16 @@ __global__ void __launch_bounds__(64) k_tri_gemm(int N, int K, int S, const doub
   vg4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
   const int nend = min(i0 + 16, N);                     // T[i][n] = 0 for n > i
   int n = 0;
+  for (; n + 32 <= nend; n += 32) {     // sixteen loads in flight
+    double av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { av[u] = pa[n + 4 * u]; bv[u] = pb[(size_t)(n + 4 * u) * N]; }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bv[u + 1], acc2, 0, 0, 0);
+    }
+  }
   for (; n + 8 <= nend; n += 8) {
     const double a0 = pa[n], b0 = pb[(size_t)n * N], a1 = pa[n + 4], b1 = pb[(size_t)(n + 4) * N];
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
@@ -196,6 +206,16 @@ __global__ void __launch_bounds__(1024) k_var_gram_mfma(ElboDims dm, const doubl
     const double* pb = Zs + (size_t)kb * N + lg;   //      B operand: inner index lg, column k = li   (Lchol: Zs == Vs)
     vg4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
     int n = 0;
+    for (; n + 32 <= N; n += 32) {      // sixteen strided loads in flight: the loop is bound by their latency, not by the MFMAs
+      double av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { av[u] = pa[n + 4 * u]; bv[u] = pb[n + 4 * u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u + 1], bv[u + 1], acc2, 0, 0, 0);
+      }
+    }
     for (; n + 8 <= N; n += 8) {
       const double a0 = pa[n], b0 = pb[n], a1 = pa[n + 4], b1 = pb[n + 4];
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
@@ -381,6 +401,9 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
   // ---- per-hyper-sample F(s) and varF(s) (:203, :283, :329-332, :350): the S samples are independent, one WAVE each (16 at a
   // time), lanes along the component pairs, fixed-order wave butterfly -- instead of S sequential workgroup-wide reductions
   // (a single full-ELCBO evaluation spent 0.26-0.39 ms of its 0.72 ms here)
+  double* wl = red;            // the weights in LDS for the pair loop below (red is free until the reductions further down)
+  for (int k = tid; k < K; k += nt) wl[k] = w[k];
+  __syncthreads();
   {
     const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     for (int s = wave; s < S; s += nw) {
@@ -389,10 +412,21 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
       if (a.compute_var == 2) {
         for (int k = lane; k < K; k += 64) part += w[k] * w[k] * fmax(EPS, Js[k + (size_t)K * k]);
       } else {
-        for (int k = 0; k < K; ++k) {
-          const double wk = w[k];
-          const double* col = Js + (size_t)K * k;
-          for (int j = lane; j <= k; j += 64) part += (j == k) ? wk * wk * fmax(EPS, col[j]) : 2.0 * w[j] * wk * col[j];
+        // all K^2 entries of the (mirrored) symmetric matrix, coalesced along j, eight loads in flight per lane: the loop over the
+        // upper triangle column by column was a chain of K dependent load latencies (64 us of a 0.39 ms evaluation)
+        const int KK = K * K;
+        for (int p0 = 0; p0 < KK; p0 += 8 * 64) {
+          double jv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int p = p0 + 64 * u + lane; jv[u] = p < KK ? Js[p] : 0.0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 64 * u + lane;
+            if (p < KK) {
+              const int k = p / K, j = p - k * K;
+              part = fma(wl[j] * wl[k], (j == k) ? fmax(EPS, jv[u]) : jv[u], part);
+            }
+          }
         }
       }
       const double vf = wave_sum(part);
