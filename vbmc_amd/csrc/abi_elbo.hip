@@ -379,6 +379,24 @@ __global__ void k_copy_rows_f64(int rows, size_t stride, size_t width, const dou
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (size_t)gridDim.x * blockDim.x)
       dst[(size_t)r * stride + i] = src[(size_t)r * stride + i];
 }
+// separate_K outputs straight into the caller's layouts, written to the pinned block by the kernel: I_sk (S x K x R, s fastest)
+// from the log-joint records, J_sjk (S x K x K x R) from the variance matrices (diagonal approximation: only J_kk is set,
+// gplogjoint.m:283).  Replaces two pageable D2H copies and a host-side transposition (~0.15 ms of a 0.34 ms eval_fullelcbo).
+__global__ void k_pack_sepk(int R, int S, int K, int LJS, int diag_only, const double* __restrict__ lj, const double* __restrict__ J,
+                            double* __restrict__ hI, double* __restrict__ hJ) {
+  const size_t nI = (size_t)R * S * K, nJ = J ? (size_t)R * S * K * K : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nI + nJ; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nI) {
+      const int s = (int)(i % S), k = (int)((i / S) % K), r = (int)(i / ((size_t)S * K));
+      hI[i] = lj[(((size_t)r * S + s) * K + k) * LJS];
+    } else {
+      const size_t q = i - nI;
+      const int s = (int)(q % S), j = (int)((q / S) % K), k = (int)((q / ((size_t)S * K)) % K), r = (int)(q / ((size_t)S * K * K));
+      hJ[q] = (diag_only && j != k) ? 0.0 : J[(((size_t)r * S + s) * K + k) * K + j];
+    }
+  }
+}
+
 static bool copy_by_kernel(size_t bytes) {
   static const int engine = [] { const char* e = getenv("VBMC_COPY_ENGINE"); return (e && !strcmp(e, "1")) ? 1 : 0; }();
   return !engine && bytes <= COPY_KERNEL_MAX_BYTES;
@@ -412,7 +430,7 @@ struct ElboPlan {
   bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false, tri_gemm = false;
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
-  size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0;
+  size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0, n_sepk = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
   double *d_ljbar = nullptr;
   double *d_vpd = nullptr, *d_entp = nullptr, *d_lj = nullptr, *d_out = nullptr, *d_part = nullptr, *d_red = nullptr;
@@ -495,7 +513,11 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   const size_t n_bnd = P.has_bnd ? 2 * (size_t)Text : 0;
   const size_t n_up = P.n_up = n_theta + n_fix + n_delta + n_bnd;
   P.out_n = (size_t)R * (OUT_HDR + 3 * T);
-  { vbmc_status s_ = ensure_pin(ctx, (n_up + P.out_n + (size_t)S * K * R) * sizeof(double)); if (s_) return s_; }
+  // pinned block: staged inputs | result records | (separate_K) I_sk and J_sjk in the caller's layouts, when they are small enough
+  // to be packed by a kernel (k_pack_sepk)
+  P.n_sepk = (a->separate_K && (a->I_sk || a->J_sjk)) ? (size_t)S * K * R * (1 + (size_t)K) : 0;
+  if (P.n_sepk * sizeof(double) > COPY_KERNEL_MAX_BYTES * 4) P.n_sepk = 0;
+  { vbmc_status s_ = ensure_pin(ctx, (n_up + P.out_n + (size_t)S * K * R + P.n_sepk) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->theta, n_up * sizeof(double)); if (s_) return s_; }
   double* hp = (double*)ctx->pin;
   if (n_theta) memcpy(hp, a->theta, n_theta * sizeof(double));
@@ -953,14 +975,25 @@ static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbm
   double* hout = (double*)ctx->pin + P.n_up;
   { vbmc_status s_ = elbo_enqueue_readback(ctx, P, a, hout); if (s_) return s_; }
   std::vector<double> ljh;
-  if (a->separate_K && a->I_sk) {
-    ljh.resize((size_t)R * S * K * LJS);
-    HIP_TRY(ctx, hipMemcpyAsync(ljh.data(), P.d_lj, ljh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  }
   std::vector<double> Jh;
-  if (a->separate_K && a->J_sjk && P.d_J) {
-    Jh.resize((size_t)R * S * K * K);
-    HIP_TRY(ctx, hipMemcpyAsync(Jh.data(), P.d_J, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  double* hI = hout + P.out_n + (size_t)S * K * R;   // (behind the slack the block has always carried)
+  double* hJ = hI + (size_t)S * K * R;
+  const bool packed = P.n_sepk != 0 && copy_by_kernel(0);
+  const bool wantJ = a->separate_K && a->J_sjk && P.d_J;
+  if (packed) {
+    const size_t tot = (size_t)R * S * K * (1 + (wantJ ? (size_t)K : 0));
+    hipLaunchKernelGGL(k_pack_sepk, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, st, R, S, K, LJS,
+                       P.compute_var == 2 ? 1 : 0, (const double*)P.d_lj, wantJ ? (const double*)P.d_J : nullptr, hI, hJ);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    if (a->separate_K && a->I_sk) {
+      ljh.resize((size_t)R * S * K * LJS);
+      HIP_TRY(ctx, hipMemcpyAsync(ljh.data(), P.d_lj, ljh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (wantJ) {
+      Jh.resize((size_t)R * S * K * K);
+      HIP_TRY(ctx, hipMemcpyAsync(Jh.data(), P.d_J, Jh.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
   }
   std::vector<double> psh;
   double* d_ps = nullptr;
@@ -986,7 +1019,10 @@ static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbm
     if (P.mc && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ent_ms = ms;
   }
   elbo_unpack(P, a, hout);
-  if (a->separate_K && a->I_sk) {
+  if (packed) {
+    if (a->I_sk) memcpy(a->I_sk, hI, (size_t)R * S * K * sizeof(double));
+    if (wantJ) memcpy(a->J_sjk, hJ, (size_t)R * S * K * K * sizeof(double));
+  } else if (a->separate_K && a->I_sk) {
     for (int r = 0; r < R; ++r)
       for (int k = 0; k < K; ++k)
         for (int s = 0; s < S; ++s) a->I_sk[s + (size_t)S * (k + (size_t)K * r)] = ljh[(((size_t)r * S + s) * K + k) * LJS];
