@@ -18,7 +18,7 @@ import math
 import numpy as np
 
 from .elbo import fminadam_device, negelcbo_batch
-from .vp import DEFAULT_OPTIONS, evaloption, get_vptheta, rescale_params, vpbounds
+from .vp import DEFAULT_OPTIONS, copy_vp, evaloption, get_vptheta, rescale_params, vpbounds
 
 EPS = float(np.finfo(np.float64).eps)
 
@@ -71,7 +71,7 @@ def vbinit_vbmc(type_, Nopts, vp, Knew, Xstar, ystar, rng):
         raise ValueError("vbinit:UnknownType Unknown TYPE for initialization of variational posteriors.")
     out = []
     for iOpt in range(Nopts):
-        v = copy.deepcopy(vp)
+        v = copy_vp(vp)
         v["K"] = Knew
         mu, sigma, lam = mu0.copy(), sigma0.copy(), lambda0.copy()
         w = w0.copy() if vp["optimize_weights"] else None
@@ -185,7 +185,7 @@ def vpsieve_vbmc(Ninit, Nbest, vp, gp, optimState=None, options=None, K=None, *,
     if Nbest is None:
         Nbest = 1
     K = vp["K"] if K is None else K
-    vp = copy.deepcopy(vp)
+    vp = copy_vp(vp)
     vp["delta"] = optimState["delta"]
     if Ninit is None:
         Ninit = int(math.ceil(evaloption(options["NSelbo"], K)))
@@ -627,7 +627,7 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
         while np.any((vp["w"] < options["TolWeight"]) & ~alreadychecked):
             cand = np.nonzero((vp["w"] < options["TolWeight"]) & ~alreadychecked)[0]
             idx = int(cand[int(rng.integers(cand.size))])          # idx(randi(numel(idx)))
-            vpp = copy.deepcopy(vp)
+            vpp = copy_vp(vp)
             vpp["w"] = np.delete(vpp["w"], idx)
             if "eta" in vpp:
                 vpp["eta"] = np.delete(vpp["eta"], idx)

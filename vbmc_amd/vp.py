@@ -31,9 +31,27 @@ def make_vp(mu, sigma, lambda_, w=None, eta=None, optimize=(True, True, True, Tr
     return vp
 
 
+def copy_vp(vp):
+    """An independent copy of a variational-posterior dict (what MATLAB's value semantics give the reference for free): arrays
+    copied, nested dicts (stats, bounds, trinfo) one level deep with their arrays copied -- a tenth of copy.deepcopy's time,
+    which was a fifth of a vpsieve_vbmc call with 100 candidates."""
+    out = {}
+    for k, v in vp.items():
+        if isinstance(v, np.ndarray):
+            out[k] = v.copy()
+        elif isinstance(v, dict):
+            out[k] = {kk: (vv.copy() if isinstance(vv, np.ndarray) else copy.deepcopy(vv) if isinstance(vv, (dict, list)) else vv)
+                      for kk, vv in v.items()}
+        elif isinstance(v, list):
+            out[k] = copy.deepcopy(v)
+        else:
+            out[k] = v
+    return out
+
+
 def rescale_params(vp, theta=None):
     """misc/rescale_params.m:1-40: assign theta, renormalise lambda (sum lambda^2 = D), weights."""
-    vp = copy.deepcopy(vp)
+    vp = copy_vp(vp)
     D = vp["D"]
     if theta is not None and np.size(theta) > 0:
         theta = np.asarray(theta, dtype=np.float64).reshape(-1)
