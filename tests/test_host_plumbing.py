@@ -132,3 +132,33 @@ def test_grad_flag_defaulting_of_the_standalone_wrappers():
     with pytest.raises(VbmcUnsupported):
         _with_grad_groups(vp, True, 2, False, "entlb_vbmc")
     assert vp["optimize_mu"] and vp["optimize_weights"]            # the caller's vp is not modified
+
+
+def test_copy_vp_is_independent_and_complete():
+    """copy_vp stands in for MATLAB's value semantics (every `vp0_vec(i) = vp` of misc/vbinit_vbmc.m copies the struct): equal to
+    copy.deepcopy field by field, and nothing of the copy aliases the original -- arrays, nested stats / bounds, lists."""
+    import copy
+
+    p, vp, gp = mk()
+    vp["stats"] = {"I_sk": np.arange(10.0).reshape(2, 5), "J_sjk": np.ones((2, 5, 5)), "elbo": 1.5, "nested": {"a": np.zeros(3)}}
+    vp["bounds"] = {"mu_lb": np.zeros(4), "mu_ub": np.ones(4)}
+    vp["trinfo"] = None
+    vp["hist"] = [np.zeros(2), {"b": np.ones(2)}]
+    c, d = vpm.copy_vp(vp), copy.deepcopy(vp)
+
+    def same(a, b):
+        if isinstance(a, np.ndarray):
+            return isinstance(b, np.ndarray) and a.shape == b.shape and np.array_equal(a, b)
+        if isinstance(a, dict):
+            return isinstance(b, dict) and a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, list):
+            return isinstance(b, list) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b or (a is None and b is None)
+
+    assert same(c, d)
+    c["mu"][0, 0] += 1.0
+    c["stats"]["I_sk"][0, 0] = -7.0
+    c["stats"]["nested"]["a"][0] = 3.0
+    c["bounds"]["mu_lb"][1] = 9.0
+    c["hist"][1]["b"][0] = 5.0
+    assert same(vp, d)          # the original saw none of it
