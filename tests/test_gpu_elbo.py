@@ -393,3 +393,26 @@ def test_penalties_against_mpmath_vectors(va):
         sc = max(1.0, abs(F1))
         assert abs((F1 - F0) - (exp["L_bnd"] + exp["L_w"])) < 1e-12 * sc, path
         assert np.max(np.abs((dF1 - dF0) - (exp["dL_bnd"] + exp["dL_w"]))) < 1e-12 * max(1.0, np.max(np.abs(dF1))), path
+
+
+@pytest.mark.parametrize("K", [12, 18, 50, 70])
+def test_extreme_exponents_saturate_cleanly(va, K):
+    """Components with sigma = 1e-7 beside ordinary ones: the exponents of the other components at their samples (and of them at
+    the others' samples) are ~ -1e13, far below the int32 range of the pre-scaled exponent (x 1024/ln2): the kernel's exp must
+    return exactly 0 there (saturating conversion, device_math.h: vb_exp_tab1k) on every path -- full k-tiles, the component
+    tail (K = 18: the tiny component 17 is a tail component; K = 50), two-wave workgroups (K = 70) -- and H, dH must still match
+    the oracle."""
+    D, N, S, Ns = 3, 30, 2, 40
+    p, gp, vp, theta = problem(21, D, N, K, S)
+    sig = np.array(vp["sigma"], dtype=np.float64).copy()
+    tiny = [1, K - 1] if K > 2 else [0]
+    sig[tiny] = 1e-7
+    vp = dict(vp, sigma=sig)
+    theta = theta.copy()
+    theta[D * K + np.array(tiny)] = np.log(1e-7)
+    eps = np.random.default_rng(9).standard_normal((K, Ns // 2, D))
+    ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+    F, dF, G, H, varF, dH = va.negelcbo_vbmc(theta, 0, vp, gp, Ns, 1, 0, nargout=6, eps=eps)
+    assert np.isfinite(H) and np.all(np.isfinite(dH))
+    assert relerr(H, ref["H"]) < RT_VAL
+    assert relerr(dH, ref["dH"]) < RT_GRAD
