@@ -90,6 +90,10 @@ CONFIGS = [
     ("tail8-K77-D5", 5, 40, 77, 2, 34, "lumpy"),
     ("tail8-K110-D20", 20, 50, 110, 1, 32, "lumpy"),
     ("tail8-K150-D4", 4, 30, 150, 1, 32, "lumpy"),
+    # multi-wave workgroups whose LAST wave holds fewer components than the others: its tail lanes idle (K = 97: 49 + 48) or are
+    # partly filled (K = 213 on four waves: 54 + 54 + 54 + 51)
+    ("tail-K97-HV2", 4, 30, 97, 1, 32, "lumpy"),
+    ("tail8-K213-HV4", 3, 30, 213, 1, 32, "lumpy"),
     # neighbours without a tail: K mod 16 = 0 and 9
     ("K48-D10", 10, 40, 48, 2, 40, "lumpy"),
     ("K57-D10", 10, 40, 57, 2, 40, "lumpy"),
