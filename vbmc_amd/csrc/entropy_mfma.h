@@ -62,12 +62,14 @@ constexpr bool X_W = true;
 // 0-6 % faster, tools/tune_sweep.py small); with two k-tiles (168-VGPR budget of three waves per SIMD) and with four (256) it
 // spills and loses 2-12 %, so those keep the sign loop.  -DVBMC_STAG forces it everywhere, -DVBMC_NO_STAG nowhere (A/B builds;
 // with the weight gradient compiled out -- registers to spare -- it gains 2.6 % at four k-tiles too: tools/ent_experiments.py).
+// At three k-tiles with a component tail and D >= 19 (QS >= 6), and without a tail at D >= 31, the staggered code spills too
+// (37-90 VGPRs) and the loop is 2-10 % faster again.
 #if defined(VBMC_STAG)
-#define VBMC_STAG_FOR(KT_) true
+#define VBMC_STAG_FOR(KT_, QS_, TL_) true
 #elif defined(VBMC_NO_STAG)
-#define VBMC_STAG_FOR(KT_) false
+#define VBMC_STAG_FOR(KT_, QS_, TL_) false
 #else
-#define VBMC_STAG_FOR(KT_) ((KT_) == 1 || (KT_) == 3)
+#define VBMC_STAG_FOR(KT_, QS_, TL_) ((KT_) == 1 || ((KT_) == 3 && (QS_) <= ((TL_) ? 5 : 8)))
 #endif
 #ifdef VBMC_EXP_NOS
 constexpr bool X_S = false;
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
     using IH = std::integral_constant<int, (KT + 1) / 2>;
     using IK = std::integral_constant<int, KT>;
 
-    if constexpr (EO && GRAD && VBMC_STAG_FOR(KT)) {
+    if constexpr (EO && GRAD && VBMC_STAG_FOR(KT, QS, TL)) {
       // Both signs in straight-line code, staggered: the second sign's exponentials (independent of everything the first
       // sign's per-sample chain waits for -- the q' exchange through LDS, the reciprocal, the 1/q' exchange) are issued
       // inside that chain, so this wave keeps the pipe busy across its own latencies instead of leaving them to the one
