@@ -55,3 +55,19 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), os.path.join(dirpath, fn)
+
+
+def test_entropy_plan_reporting_hook():
+    """vbmc_entropy_plan is a pure host function (no device needed): the instantiation the library's policy picks.  Locks the
+    choices the profiles were taken with: the headline shape runs three k-tiles + a two-component tail on one wave, configs[4]
+    three k-tiles + tail on two waves, K = 64 four full k-tiles, D > 34 the VALU kernel."""
+    import bench
+
+    assert bench.entropy_kernel_label(10, 50) == "k_entropy_mfma<QS=3,KT=3+tail2,grad>"
+    assert bench.entropy_kernel_label(20, 100) == "k_entropy_mfma<QS=6,KT=3+tail2,grad,HV=2>"
+    assert bench.entropy_kernel_label(10, 64) == "k_entropy_mfma<QS=3,KT=4,grad>"
+    assert bench.entropy_kernel_label(10, 56) == "k_entropy_mfma<QS=3,KT=3+tail8,grad>"
+    assert bench.entropy_kernel_label(20, 56) == "k_entropy_mfma<QS=6,KT=4,grad>"          # two values per lane would spill there
+    assert bench.entropy_kernel_label(6, 10) == "k_entropy_mfma<QS=2,KT=1,grad>"
+    assert bench.entropy_kernel_label(10, 200) == "k_entropy_mfma<QS=3,KT=3+tail2,grad,HV=4>"
+    assert bench.entropy_kernel_label(40, 10).startswith("k_entropy<D=40")
