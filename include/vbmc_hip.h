@@ -258,7 +258,8 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * context's stream, so the chain of dependent kernels inside a small batch is not hidden.  Passes execute in submission order; each
  * slot must be collected before it is submitted again.  Results are bit-identical to vbmc_elbo_batch with the same args.
  * Not offered here: separate_K / I_sk / J_sjk / G_s / varG_s outputs and host-resident draws (eps_mode 1) -- their copies
- * go through pageable memory; use vbmc_elbo_batch.  Other entry points of the same context may be called between a submit and
+ * go through pageable memory; use vbmc_elbo_batch.  The surrogate handle and the arrays named in args must stay valid until the
+ * slot is collected (the inputs are copied at submit, the outputs are written at collect).  Other entry points of the same context may be called between a submit and
  * its collect (they queue behind it on the stream).
  */
 vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int slot);
