@@ -14,7 +14,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
 from ._lib import Context, DeviceGP, ElboArgs, VbmcUnsupported, f64, ptr
 from .vp import get_vptheta
 

@@ -12,7 +12,6 @@ bit-wise, identical to a MATLAB run; the numerics of every objective evaluation 
 """
 from __future__ import annotations
 
-import copy
 import math
 
 import numpy as np
