@@ -120,6 +120,31 @@ def test_posterior_feeds_elbo_without_reupload(va):
     assert relerr(out[2], r["G"]) < 1e-7 and relerr(out[7], r["varG"]) < 1e-5
 
 
+def test_posterior_factors_kept_on_device(va):
+    """gplite_post(..., need_L=False): no N x N x S readback; prediction, the full-variance ELBO and a rank-one append all
+    read the device copy and agree with the oracle working from its own host factors."""
+    p = synth_problem(29, 4, 60, 5, 3)
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 4, need_L=False)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
+    assert all(q["L"] is None for q in gp["post"])
+    for a, c in zip(gp["post"], ref["post"]):
+        assert relerr(a["alpha"], c["alpha"]) < 1e-7 and relerr(a["sW"], c["sW"]) < 1e-12 and a["Lchol"] == c["Lchol"]
+    Xq = p["X"][:9] + 0.15
+    o = va.gplite_pred(gp, Xq, None, None, True)
+    r = R.gplite_pred(ref, Xq, ssflag=True)
+    assert relerr(o[2], r[2]) < 1e-7 and relerr(o[3], r[3]) < 1e-6
+    vp = va.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    out = va.negelcbo_vbmc(theta, 0, vp, gp, 0, 0, 1, nargout=11)
+    rr = R.negelcbo_vbmc(theta, 0, vp, ref, 0, False, 1, separate_K=True)
+    assert relerr(out[2], rr["G"]) < 1e-7 and relerr(out[7], rr["varG"]) < 1e-5
+    gp1 = va.gplite_post_rank1(gp, Xq[0], 0.4)
+    ref1 = R.gplite_post_rank1(ref, Xq[0], 0.4)
+    for a, c in zip(gp1["post"], ref1["post"]):
+        assert relerr(a["alpha"], c["alpha"]) < 1e-7 and relerr(a["L"], c["L"]) < 1e-8
+
+
 def test_rank1_update_equals_full_posterior(va):
     """gplite/gplite_test.m:87-105 property: appending a point by the rank-1 path == full recompute."""
     p = synth_problem(24, 4, 45, 3, 3)

@@ -966,9 +966,8 @@ static void elbo_unpack(const ElboPlan& P, const vbmc_elbo_args* a, const double
 // One packed D2H of the results of an enqueued pass (+ I_sk / J_sjk / per-sample outputs when requested); synchronises.
 static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbmc_elbo_args* a) {
   const ElboDims& dm = P.dm;
-  const int K = dm.K, R = dm.R, S = dm.S, T = dm.T, D = dm.D;
+  const int K = dm.K, R = dm.R, S = dm.S, D = dm.D;
   const int LJS = 2 * D + 2;
-  const int compute_grad = P.compute_grad;
   hipStream_t st = ctx->stream;
 
   // ---- results: one packed D2H (+ I_sk / J_sjk when requested)

@@ -43,8 +43,12 @@ def sq_dist(a, b=None, *, engine=None):
     return Cm
 
 
-def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engine=None):
+def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, need_L=True, engine=None):
     """gp = gplite_post(hyp,X,y,covfun,meanfun,noisefun,s2): full posterior for every hyper-sample.
+
+    ``need_L=False`` keeps the N x N x S factors on the device only (``post[s]["L"]`` is None): every accelerated consumer
+    (gplite_pred, the ELBO, the acquisition sweep, the rank-one append) reads the device copy, and the 8 N^2 S bytes of
+    readback -- 25.6 MB at N = 400, S = 20, most of the call's wall time -- are skipped.
 
     Only the VBMC configuration is accelerated: covfun 1 (SE-ARD), meanfun in {0, 1, 4}; anything
     else raises VbmcUnsupported so a caller can fall through to the reference implementation.
@@ -73,7 +77,7 @@ def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engin
     noisefun = tuple(int(v) for v in noisefun) + (0,) * (3 - len(noisefun))
     s2a = None if s2 is None else f64(np.asarray(s2, dtype=np.float64).reshape(-1))
     alpha = np.empty((N, S), order="F")      # all three are overwritten in full by the library
-    L = np.empty((N, N, S), order="F")
+    L = np.empty((N, N, S), order="F") if need_L else None
     sW = np.empty((N, S), order="F")
     mult = np.zeros(S)
     lch = np.zeros(S, dtype=np.uint8)
@@ -85,7 +89,7 @@ def gplite_post(hyp, X, y, covfun=1, meanfun=1, noisefun=None, s2=None, *, engin
         "X": X, "y": y, "s2": s2a, "covfun": 1, "meanfun": int(meanfun), "noisefun": noisefun,
         "Ncov": D + 1, "Nnoise": _nnoise(noisefun), "Nmean": _nmean(meanfun, D), "meanfun_extras": None, "intmeanfun": 0,
         # L[:, :, s] is a contiguous (column-major) view of the N x N x S block written by the library: no second copy
-        "post": [{"hyp": hyp[:, s].copy(), "alpha": alpha[:, s].copy(), "sW": sW[:, s].copy(), "L": L[:, :, s],
+        "post": [{"hyp": hyp[:, s].copy(), "alpha": alpha[:, s].copy(), "sW": sW[:, s].copy(), "L": L[:, :, s] if need_L else None,
                   "sn2_mult": float(mult[s]), "Lchol": bool(lch[s])} for s in range(S)],
     }
     dgp = DeviceGP.from_handle(ctx, h, N, D, S)
