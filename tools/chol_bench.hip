@@ -1,0 +1,146 @@
+// Stand-alone check + timing of the blocked Cholesky kernel of vbmc_amd/csrc/chol_mfma.h (k_chol2): S copies of a
+// random SPD matrix of order N, result against a host Cholesky, MATLAB's failure index on an indefinite matrix, kernel time by HIP
+// events (median of reps) and -- built with -DCHOL_TS -- the per-step phase stamps of matrix 0.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCHOL_TS -Iinclude -o vbmc_amd/lib/chol_bench tools/chol_bench.hip
+//   vbmc_amd/lib/chol_bench [variant=1] [N=400] [S=20] [reps=20] [stamps=0 | print every n-th step]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../vbmc_amd/csrc/gp_kernels.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+static int host_chol_upper(int N, std::vector<double>& A) {   // column-major, upper factor in place, strict lower zeroed; returns p
+  for (int j = 0; j < N; ++j) {
+    for (int i = 0; i <= j; ++i) {
+      long double v = A[i + (size_t)N * j];
+      for (int t = 0; t < i; ++t) v -= (long double)A[t + (size_t)N * i] * A[t + (size_t)N * j];
+      if (i == j) {
+        if (!(v > 0)) return j + 1;
+        A[j + (size_t)N * j] = (double)sqrtl(v);
+      } else {
+        A[i + (size_t)N * j] = (double)(v / A[i + (size_t)N * i]);
+      }
+    }
+    for (int i = j + 1; i < N; ++i) A[i + (size_t)N * j] = 0.0;
+  }
+  return 0;
+}
+
+static hipError_t launch(int variant, int N, int S, double* dA, int* dpf, unsigned char* dact, double* dPg, hipStream_t st) {
+  switch (variant) {
+    case 1: return chol2_launch(N, S, dA, dpf, dact, dPg, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+int main(int argc, char** argv) {
+  const int variant = argc > 1 ? atoi(argv[1]) : 1, N = argc > 2 ? atoi(argv[2]) : 400, S = argc > 3 ? atoi(argv[3]) : 20;
+  const int reps = argc > 4 ? atoi(argv[4]) : 20, stamps = argc > 5 ? atoi(argv[5]) : 0;
+  const size_t NN = (size_t)N * N;
+  std::vector<double> G(NN), A(NN);
+  unsigned long long sd = 88172645463325252ull;
+  auto rnd = [&]() { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; return (double)(sd >> 11) / 9007199254740992.0 - 0.5; };
+  for (auto& g : G) g = rnd();
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i <= j; ++i) {
+      double v = 0;
+      for (int t = 0; t < N; ++t) v += G[i + (size_t)N * t] * G[j + (size_t)N * t];
+      A[i + (size_t)N * j] = A[j + (size_t)N * i] = v / N + (i == j ? 0.05 : 0.0);
+    }
+  std::vector<double> R = A;
+  if (host_chol_upper(N, R)) { printf("host chol failed\n"); return 1; }
+  const int Np = ((N + 15) >> 4) << 4;
+  double *dA0, *dA, *dPg;
+  int* dpf;
+  unsigned char* dact;
+  CHECK(hipMalloc(&dA0, S * NN * 8)); CHECK(hipMalloc(&dA, S * NN * 8)); CHECK(hipMalloc(&dPg, (size_t)S * 16 * Np * 8));
+  CHECK(hipMalloc(&dpf, S * sizeof(int))); CHECK(hipMalloc(&dact, S));
+  std::vector<unsigned char> ones(S, 1);
+  CHECK(hipMemcpy(dact, ones.data(), S, hipMemcpyHostToDevice));
+  for (int s = 0; s < S; ++s) CHECK(hipMemcpy(dA0 + s * NN, A.data(), NN * 8, hipMemcpyHostToDevice));
+  hipStream_t st;
+  CHECK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  std::vector<float> ms;
+  for (int r = 0; r < reps + 3; ++r) {
+    CHECK(hipMemcpyAsync(dA, dA0, S * NN * 8, hipMemcpyDeviceToDevice, st));
+    CHECK(hipEventRecord(e0, st));
+    CHECK(launch(variant, N, S, dA, dpf, dact, dPg, st));
+    CHECK(hipEventRecord(e1, st));
+    CHECK(hipStreamSynchronize(st));
+    float t;
+    CHECK(hipEventElapsedTime(&t, e0, e1));
+    if (r >= 3) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  // accuracy: every copy against the host factor
+  std::vector<double> out(S * NN);
+  std::vector<int> pf(S);
+  CHECK(hipMemcpy(out.data(), dA, S * NN * 8, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(pf.data(), dpf, S * sizeof(int), hipMemcpyDeviceToHost));
+  double worst = 0, lowmax = 0;
+  int anyfail = 0;
+  for (int s = 0; s < S; ++s) {
+    anyfail |= pf[s];
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        const double v = out[s * NN + i + (size_t)N * j], r = R[i + (size_t)N * j];
+        if (i <= j) worst = std::max(worst, std::fabs(v - r) / (std::fabs(r) + 1e-3));
+        else lowmax = std::max(lowmax, std::fabs(v));
+      }
+  }
+  // failure index: make the leading minor of order jf+1 indefinite
+  const int jf = std::min(N - 1, (2 * N) / 3);
+  std::vector<double> B = A;
+  B[jf + (size_t)N * jf] = -1.0;
+  std::vector<double> RB = B;
+  const int pref = host_chol_upper(N, RB);
+  CHECK(hipMemcpy(dA, B.data(), NN * 8, hipMemcpyHostToDevice));
+  CHECK(launch(variant, N, 1, dA, dpf, dact, dPg, st));
+  CHECK(hipStreamSynchronize(st));
+  int pgot = -1;
+  CHECK(hipMemcpy(&pgot, dpf, sizeof(int), hipMemcpyDeviceToHost));
+  printf("{\"variant\": %d, \"N\": %d, \"S\": %d, \"ms_median\": %.4f, \"ms_min\": %.4f, \"max_rel_err\": %.3e, \"lower_max\": %.1e, \"pfail\": %d, "
+         "\"p_indefinite\": [%d, %d], \"ok\": %s}\n", variant, N, S, ms[ms.size() / 2], ms[0], worst, lowmax, anyfail, pgot, pref,
+         (worst < 1e-11 && lowmax == 0 && !anyfail && pgot == pref) ? "true" : "false");
+#ifdef CHOL_TS
+  if (stamps) {
+    CHECK(hipMemcpyAsync(dA, dA0, S * NN * 8, hipMemcpyDeviceToDevice, st));
+    CHECK(launch(variant, N, S, dA, dpf, dact, dPg, st));
+    CHECK(hipStreamSynchronize(st));
+    std::vector<long long> ts(4 * 512);
+    CHECK(hipMemcpyFromSymbol(ts.data(), HIP_SYMBOL(g_chol_ts), ts.size() * 8));
+    const int nstep = (N + 15) / 16 - 1;
+    printf("step: panel  lookahead-done(after panel)  update+barrier   (us; 100 MHz stamps)\n");
+    double sp = 0, su = 0;
+    for (int k = 0; k < nstep; ++k) {
+      const double p = (ts[4 * k + 1] - ts[4 * k + 0]) * 0.01, la = (ts[4 * k + 2] - ts[4 * k + 1]) * 0.01, u = (ts[4 * k + 3] - ts[4 * k + 1]) * 0.01;
+      sp += p; su += u;
+      if (k % stamps == 0) printf("%3d: %6.2f %6.2f %6.2f\n", k, p, la, u);
+    }
+    printf("sum panel %.1f us, sum update %.1f us, first stamp to last %.1f us\n", sp, su, (ts[4 * (nstep - 1) + 3] - ts[0]) * 0.01);
+    {
+      std::vector<long long> gs(8 * 64);
+      int gn = 0;
+      CHECK(hipMemcpyFromSymbol(gs.data(), HIP_SYMBOL(g_chol_gs), gs.size() * 8));
+      CHECK(hipMemcpyFromSymbol(&gn, HIP_SYMBOL(g_chol_gn), sizeof(int)));
+      printf("wave 1, step 0, per group (shader cycles): address+issue loads | issue LDS reads+wait | MFMAs | sub+stores | to next group\n");
+      for (int g = 0; g < gn && g < 64; ++g)
+        printf("  g%02d: %6lld %6lld %6lld %6lld %6lld\n", g, gs[8 * g + 1] - gs[8 * g], gs[8 * g + 2] - gs[8 * g + 1], gs[8 * g + 3] - gs[8 * g + 2],
+               gs[8 * g + 4] - gs[8 * g + 3], g + 1 < gn ? gs[8 * (g + 1)] - gs[8 * g + 4] : 0);
+    }
+    std::vector<long long> ck(2 * 512);
+    CHECK(hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(g_chol_clk), ck.size() * 8));
+    printf("shader clock over the factorisation: %.0f MHz (clock64 ticks / wall_clock64 time)\n",
+           (double)(ck[2 * (nstep - 1) + 1] - ck[0]) / ((ts[4 * (nstep - 1) + 3] - ts[0]) * 0.01));
+  }
+#endif
+  return 0;
+}

@@ -159,13 +159,9 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>());
 
   // jittered Cholesky: up to 10 tries, noise multiplier x10 per failure (gplite_core.m:77-80,91-94)
-  // the 16 x N panel of the Cholesky lives in LDS up to N = 1232, in a global scratch block beyond
-  const bool chol_gpanel = CHOL_LDS_BYTES(N) > 160 * 1024;
-  const size_t chol_lds = chol_gpanel ? (size_t)2 * 16 * 17 * sizeof(double) : CHOL_LDS_BYTES(N);
+  // the 16 x N panel of the Cholesky lives in LDS up to N = 1200, in a global scratch block beyond (chol_mfma.h)
   TmpBuf dPg;
-  if (chol_gpanel) HIP_TRY(ctx, dPg.alloc(ctx, (size_t)S * 16 * (size_t)(((N + 15) >> 4) << 4) * 8));
-  if (chol_lds > 64 * 1024)
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
+  if (chol2_needs_gpanel(N)) HIP_TRY(ctx, dPg.alloc(ctx, (size_t)S * 16 * (size_t)(((N + 15) >> 4) << 4) * 8));
   std::vector<int> pf(S);
   bool pending = true;
   for (int iter = 0; iter < 10 && pending; ++iter) {
@@ -174,9 +170,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     DISPATCH_GPDT(D, hipLaunchKernelGGL((k_gp_build<DT>), dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D,
                                         Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(), dsn2.as<double>(), dscal.as<double>(),
                                         dact.as<unsigned char>(), dA.as<double>()));
-    hipLaunchKernelGGL(k_chol, dim3(S), dim3(CH_THREADS), chol_lds, st, N, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>(),
-                       chol_gpanel ? dPg.as<double>() : nullptr);
-    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, chol2_launch(N, S, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>(), dPg.p ? dPg.as<double>() : nullptr, st));
     HIP_TRY(ctx, hipMemcpyAsync(pf.data(), dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     pending = false;

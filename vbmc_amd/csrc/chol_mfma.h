@@ -1,0 +1,363 @@
+// Blocked right-looking Cholesky (upper factor R, R'R = A, in place, strict lower part zeroed), second generation:
+// one 512-thread workgroup (8 waves, 256 VGPRs each) per matrix, every O(N^3) and O(N^2) part on v_mfma_f64_16x16x4_f64.
+// Reference: gplite/private/gplite_core.m:77-100 ([L,p] = chol(K)), the p > 0 semantics of MATLAB's chol.
+//
+// Per 16-row block step (kb):
+//   panel     R[kb.., j] = inv(Rkk') A[kb.., j] as an MFMA product with the explicit inverse of the 16 x 16 diagonal factor
+//             (computed once per step by wave 0 next to the factorisation) instead of a 16-step substitution per column;
+//             the tile is fetched straight into the B-operand layout (row = 4q + lane/16, column = lane%16), the product
+//             leaves the MFMA as P[t = lane/16 + 4r][j = lane%16]: LDS panel rows are written conflict-free.
+//   update    A22 -= P'P on the upper triangle of 16 x 16 tiles.  Tiles are handed out in groups of CH2_G through an LDS
+//             counter (wave 0 joins after its look-ahead), the loads of the NEXT group are issued before the MFMAs of the
+//             current one (two register buffers), the panel operands come from LDS with ds_read (the first generation
+//             addressed LDS-or-global through one flat pointer: every operand fetch then waited for all global loads).
+//   look-ahead wave 0 updates the next diagonal tile first, factors it in registers (chol_diag_tile), inverts the factor.
+// GP = true: the 16 x Np panel does not fit the LDS (N > CH2_MAX_LDS_N) and lives in a global scratch block.
+#pragma once
+
+#ifndef CH2_THREADS
+#define CH2_THREADS 512
+#endif
+#define CH2_W (CH2_THREADS / 64)
+#define CH2_G 4
+// LDS doubles: 2 diagonal tiles + 2 inverses (16 x 17 each) + the panel
+#define CH2_LDS_FIXED (4 * 16 * 17)
+#define CHOL2_LDS_BYTES(N) ((size_t)(CH2_LDS_FIXED + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
+
+// sqrt(p) and 1/sqrt(p) from the v_rsq_f64 seed with two Goldschmidt steps and a final residual correction (the sequence of
+// the compiler's own sqrt expansion, which also yields the reciprocal root): ~12 dependent operations instead of an IEEE sqrt
+// followed by an IEEE division (~80) on the critical path of every pivot.  p is positive and finite here.
+__device__ __forceinline__ void chol_sqrt_rsqrt(double p, double& rs, double& ri) {
+  // scale into [2^-512, 2^512) as the library sqrt does, so that p*y and the residual neither overflow nor go subnormal
+  const bool small = p < 0x1p-767, big = p > 0x1p+767;
+  const double ps = small ? p * 0x1p+512 : (big ? p * 0x1p-512 : p);
+  const double y = __builtin_amdgcn_rsq(ps);
+  double g = ps * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double d = fma(-g, g, ps);
+  g = fma(d, h, g);
+  const double sc = small ? 0x1p-256 : (big ? 0x1p+256 : 1.0);
+  rs = g * sc;
+  ri = (h + h) * (small ? 0x1p+256 : (big ? 0x1p-256 : 1.0));
+}
+
+// Upper Cholesky of the 16 x 16 tile held in LDS (Dg, row stride 17; identity beyond nb) by ONE wave, in registers: lane c
+// (c = lane & 15; the four 16-lane groups work redundantly) gathers column c, the 16 pivot steps run on registers with the
+// pivot row broadcast through v_readlane (all lane indices are compile-time constants), and the factor goes back to LDS
+// once -- no LDS round trip or wave barrier per pivot.  Di[t] = 1 / R[t][t].  A non-positive or non-finite pivot records
+// kb + t + 1 in *s_fail (first failure wins) and is replaced by 1 so that the sweep completes.
+__device__ __forceinline__ void chol_diag_tile2(double* __restrict__ Dg, double* __restrict__ Di, int nb, int kb, int lane,
+                                                int* s_fail) {
+  const int c = lane & 15;
+  double a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = Dg[r * 17 + c];
+  int fail = 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    double piv = chol_readlane(a[t], t);
+    if (t < nb && (!(piv > 0.0) || !isfinite(piv))) {     // uniform: piv is a broadcast value
+      if (fail == 0) fail = kb + t + 1;
+      piv = 1.0;
+    }
+    double rs, ri;
+    chol_sqrt_rsqrt(piv, rs, ri);
+    a[t] = (c == t) ? rs : a[t] * ri;              // R[t][c] for c > t (entries with c < t are never read)
+    if (lane == t) Di[t] = ri;
+#pragma unroll
+    for (int ii = t + 1; ii < 16; ++ii) {
+      const double rti = chol_readlane(a[t], ii);  // R[t][ii]
+      a[ii] = fma(-rti, a[t], a[ii]);              // lanes c < ii compute entries below the diagonal that nobody reads
+    }
+  }
+  if (fail && lane == 0 && *s_fail == 0) *s_fail = fail;
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Dg[r * 17 + c] = a[r];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// inverse of the upper factor held in Dg (row stride 17, identity beyond nb): Ri[c][t] = inv(R)[c][t] = inv(R')[t][c].
+// Lane c (= lane & 15) solves R' x = e_c by forward substitution; Di[t] = 1 / R[t][t].
+__device__ __forceinline__ void chol_tile_inverse(const double* __restrict__ Dg, const double* __restrict__ Di, double* __restrict__ Ri,
+                                                  int lane) {
+  const int c = lane & 15;
+  double r[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    double v = (t == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int u = 0; u < t; ++u) v = fma(-Dg[u * 17 + t], r[u], v);
+    r[t] = v * Di[t];     // r[u] = 0 for u < c falls out of the recursion
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) Ri[c * 17 + t] = r[t];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+#ifdef CHOL_TS   // harness only: shader-clock stamps inside the groups of wave 1 during step 0 (slot x group)
+__device__ long long g_chol_gs[8 * 64];
+__device__ int g_chol_gn;
+#define CH2_GSTAMP(slot) do { if (blockIdx.x == 0 && wave == 1 && kb == 0 && gcount < 64) { __builtin_amdgcn_sched_barrier(0); \
+    if ((slot) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    if ((slot) == 3) asm volatile("s_nop 7\n s_nop 7\n s_nop 7" ::: "memory"); \
+    g_chol_gs[8 * gcount + (slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); if ((slot) == 4) { ++gcount; g_chol_gn = gcount; } } } while (0)
+#else
+#define CH2_GSTAMP(slot) do { } while (0)
+#endif
+
+template <bool GP>
+__global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict__ Aall, int* __restrict__ pfail,
+                                                       const unsigned char* __restrict__ active, double* __restrict__ Pg) {
+  extern __shared__ __attribute__((aligned(32))) double lds_c2[];   // 32-byte vectors of the panel
+  double* lds = lds_c2;
+  const int s = blockIdx.x;
+  if (!active[s]) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform in an SGPR: tile walks and tile base addresses stay scalar
+  const int li = lane & 15, lg = lane >> 4;
+  const int Np = ((N + 15) >> 4) << 4;
+  double* A = Aall + (size_t)s * N * N;
+  double* DgB = lds;                      // [2][16 x 17] diagonal tiles: this step's and the next one's
+  double* RiB = lds + 2 * 16 * 17;        // [2][16 x 17] their inverses
+  double* Pl = lds + CH2_LDS_FIXED;       // 16 x Np panel rows (LDS variant)
+  double* Pgl = GP ? Pg + (size_t)s * 16 * Np : nullptr;
+  __shared__ int s_fail;
+  __shared__ double DiB[2][16];
+  // Panel layout: row t = 4 q + g of the 16 x Np panel lives at ((g * Np + col) * 4 + q): the four q-slices an MFMA operand
+  // needs for one column are 32 contiguous bytes (one vector read per operand set, one vector write per product column).
+  typedef double d4v __attribute__((ext_vector_type(4)));
+  auto ldP4 = [&](int g, int col) -> d4v {
+    return GP ? *(const d4v*)(Pgl + (((size_t)g * Np + col) << 2)) : *(const d4v*)(Pl + ((g * Np + col) << 2));
+  };
+  auto stP4 = [&](int g, int col, d4v v) {
+    if (GP) *(d4v*)(Pgl + (((size_t)g * Np + col) << 2)) = v; else *(d4v*)(Pl + ((g * Np + col) << 2)) = v;
+  };
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  if (wave == 0) {
+    const int nb = min(16, N);
+    for (int e = lane; e < 256; e += 64) {
+      const int ii = e >> 4, jj = e & 15;
+      DgB[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)ii + (size_t)N * jj] : (ii == jj ? 1.0 : 0.0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    chol_diag_tile2(DgB, DiB[0], nb, 0, lane, &s_fail);
+    chol_tile_inverse(DgB, DiB[0], RiB, lane);
+    for (int e = lane; e < 256; e += 64) {
+      const int ii = e >> 4, jj = e & 15;
+      if (ii < nb && jj < nb) A[(size_t)ii + (size_t)N * jj] = (ii <= jj) ? DgB[ii * 17 + jj] : 0.0;
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  int gcount = 0; (void)gcount;
+  for (int kb = 0; kb < N; kb += 16, cur ^= 1) {
+    if (s_fail) break;            // uniform: written before the last barrier
+    const int nb = min(16, N - kb);
+    const int t0 = kb + nb;       // first trailing column
+    const int ntr = N - t0;
+    if (ntr <= 0) break;
+    const int nt = (ntr + 15) >> 4;
+    const double* Ri = RiB + cur * 16 * 17;
+    if (tid == 0) CHOL_STAMP(0, kb >> 4);
+    // ---- panel: tile tj of the row block (16 x 16, rows kb.., columns t0 + 16 tj..) times inv(Rkk')
+    {
+      double av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[q] = Ri[(4 * q + lg) * 17 + li];      // A operand: inv(Rkk')[t = li][u = 4q + lg]
+      constexpr int PT = CH2_W >= 16 ? 2 : 3;                              // tiles in flight per wave
+      for (int tb = wave; tb < nt; tb += PT * CH2_W) {
+        double bv[PT][4];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          const int tj = tb + p * CH2_W, j = (tj << 4) + li;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int u = 4 * q + lg;
+            const bool ok = tj < nt && u < nb && j < ntr;
+            const double v = A[ok ? (size_t)(kb + u) + (size_t)N * (t0 + j) : 0];
+            bv[p][q] = ok ? v : 0.0;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          const int tj = tb + p * CH2_W, j = (tj << 4) + li;
+          if (tj < nt) {                                                   // wave-uniform
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[p][q], acc, 0, 0, 0);
+            stP4(lg, j, acc);                                              // acc[r] = R[kb + lg + 4r][t0 + j]; zero for rows >= nb, j >= ntr
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int t = lg + 4 * r;
+              if (t < nb && j < ntr) A[(size_t)(kb + t) + (size_t)N * (t0 + j)] = acc[r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) CHOL_STAMP(1, kb >> 4);
+    // ---- trailing update.  Tile pair u = tj (tj + 1) / 2 + ti (ti <= tj) of the nt x nt tile triangle; transposed tiles so
+    //      that lanes run along i (contiguous in the column-major matrix): lane (li, lg) register r holds
+    //      A[t0 + 16 ti + li][t0 + 16 tj + lg + 4 r]  -=  sum_t P[t][16 tj + lg + 4 r] P[t][16 ti + li].
+    const int npair = nt * (nt + 1) / 2;
+    double* At = A + (size_t)t0 + (size_t)N * t0;     // trailing matrix; 32-bit offsets inside it (N <= 3872)
+    if (wave == 0) {
+      // look-ahead: next diagonal tile (pair 0)
+      const int nb2 = min(16, ntr);
+      double* Dn = DgB + (cur ^ 1) * 16 * 17;
+      double c0[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = lg + 4 * r;
+        const bool ok = li < nb2 && j < nb2 && li <= j;
+        const double v = At[ok ? j * N + li : 0];
+        c0[r] = ok ? v : 0.0;
+      }
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      const d4v pa = ldP4(lg, li);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[q], pa[q], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = li, jj = lg + 4 * r;      // element (row ii, column jj) of the tile
+        Dn[ii * 17 + jj] = (ii < nb2 && jj < nb2 && ii <= jj) ? c0[r] - acc[r] : (ii == jj ? 1.0 : 0.0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      chol_diag_tile2(Dn, DiB[cur ^ 1], nb2, t0, lane, &s_fail);
+      chol_tile_inverse(Dn, DiB[cur ^ 1], RiB + (cur ^ 1) * 16 * 17, lane);
+      for (int e = lane; e < 256; e += 64) {
+        const int ii = e >> 4, jj = e & 15;
+        if (ii < nb2 && jj < nb2) A[(size_t)(t0 + ii) + (size_t)N * (t0 + jj)] = (ii <= jj) ? Dn[ii * 17 + jj] : 0.0;
+      }
+      if (lane == 0) CHOL_STAMP(2, kb >> 4);
+    }
+    if (wave > 0) {
+      // Static deal: group n of wave w = pairs 1 + CH2_G (w - 1 + (CH2_W - 1) n) .. + CH2_G - 1, walked incrementally (an LDS
+      // work counter was measured: the atomic's round trip at the head of every group cost more than the imbalance it removes).
+      // FAST groups lie entirely in full tile columns (16 (tj + 1) <= ntr): no masks -- the entries below the diagonal of a
+      // diagonal tile are updated like the rest (they hold whatever the builder left there, nobody reads them, and the
+      // strict lower triangle is zeroed at the end).
+      constexpr int STRIDE = CH2_G * (CH2_W - 1);
+      const int ntf = ntr >> 4;
+      const int ufast = ntf * (ntf + 1) / 2;
+      unsigned lob[4];                          // byte offset of this lane's element in register r of a tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lob[r] = (unsigned)(((lg + 4 * r) * N + li) * 8);
+      const char* Ab = reinterpret_cast<const char*>(At);
+      int u0 = 1 + CH2_G * (wave - 1);
+      int ti, tj;                               // pair u0 = tj (tj + 1) / 2 + ti
+      {
+        int c = (int)((sqrtf(8.0f * (float)u0 + 1.0f) - 1.0f) * 0.5f);
+        c += ((c + 1) * (c + 2) / 2 <= u0) ? 1 : 0;
+        c -= (c * (c + 1) / 2 > u0) ? 1 : 0;
+        tj = c; ti = u0 - c * (c + 1) / 2;
+      }
+      auto advance = [&](int by) { ti += by; while (ti > tj) { ti -= tj + 1; ++tj; } };
+      // One fast group: CH2_G x 4 loads, all operand reads, the CH2_G accumulation chains back to back, CH2_G x 4 stores from
+      // the registers the loads filled through one 32-bit byte offset each (SGPR base + VGPR offset addressing).
+      auto group = [&]() {
+        double c[CH2_G][4];
+        unsigned ob[CH2_G][4];
+        int i0_[CH2_G], j0_[CH2_G];
+        CH2_GSTAMP(0);
+        {
+          int a = ti, b = tj;
+#pragma unroll
+          for (int g = 0; g < CH2_G; ++g) {
+            i0_[g] = a << 4; j0_[g] = b << 4;
+            const unsigned tpb = (unsigned)((j0_[g] * N + i0_[g]) * 8);   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              ob[g][r] = tpb + lob[r];
+              c[g][r] = *reinterpret_cast<const double*>(Ab + ob[g][r]);
+            }
+            const bool wrap = a == b;
+            a = wrap ? 0 : a + 1;
+            b += wrap ? 1 : 0;
+          }
+        }
+        CH2_GSTAMP(1);
+        d4v pj[CH2_G], pi[CH2_G];
+#pragma unroll
+        for (int g = 0; g < CH2_G; ++g) { pj[g] = ldP4(lg, j0_[g] + li); pi[g] = ldP4(lg, i0_[g] + li); }
+        CH2_GSTAMP(2);
+        d4_t acc[CH2_G];
+#pragma unroll
+        for (int g = 0; g < CH2_G; ++g) {
+          acc[g] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[g][q], pi[g][q], acc[g], 0, 0, 0);
+        }
+        CH2_GSTAMP(3);
+#pragma unroll
+        for (int g = 0; g < CH2_G; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            c[g][r] -= acc[g][r];
+            *reinterpret_cast<double*>(const_cast<char*>(Ab) + ob[g][r]) = c[g][r];
+          }
+        CH2_GSTAMP(4);
+      };
+      for (; u0 + CH2_G <= ufast; u0 += STRIDE, advance(STRIDE)) group();
+      // the rest: groups that touch the ragged last tile column or run past the last pair, tile by tile with masks
+      for (; u0 < npair; u0 += STRIDE, advance(STRIDE)) {
+        int a = ti, b = tj;
+        for (int g = 0; g < CH2_G && u0 + g < npair; ++g) {
+          const int i0 = a << 4, j0 = b << 4, i = i0 + li, jb = j0 + lg;
+          double c[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = jb + 4 * r;
+            const bool ok = i < ntr && j < ntr;
+            c[r] = At[ok ? j * N + i : 0];
+          }
+          const d4v pj = ldP4(lg, j0 + li), pi = ldP4(lg, i0 + li);
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[q], pi[q], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = jb + 4 * r;
+            if (i < ntr && j < ntr && i <= j) At[j * N + i] = c[r] - acc[r];
+          }
+          const bool wrap = a == b;
+          a = wrap ? 0 : a + 1;
+          b += wrap ? 1 : 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) CHOL_STAMP(3, kb >> 4);
+  }
+  if (tid == 0) pfail[s] = s_fail;
+  if (s_fail) return;
+  // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
+  for (int j = wave; j < N; j += CH2_W)
+    for (int i = j + 1 + lane; i < N; i += 64) A[(size_t)i + (size_t)N * j] = 0.0;
+}
+
+// Launch on stream st: S matrices of order N in dA (N x N x S), pfail S ints, active S flags; Pg = S x 16 x Np doubles of
+// scratch, needed only when chol2_needs_gpanel(N).
+static inline bool chol2_needs_gpanel(int N) { return CHOL2_LDS_BYTES(N) > 159 * 1024; }   // + ~0.3 KB of static LDS
+static inline hipError_t chol2_launch(int N, int S, double* dA, int* dpf, const unsigned char* dact, double* dPg, hipStream_t st) {
+  if (chol2_needs_gpanel(N)) {
+    hipLaunchKernelGGL((k_chol2<true>), dim3(S), dim3(CH2_THREADS), (size_t)CH2_LDS_FIXED * sizeof(double), st, N, dA, dpf, dact, dPg);
+  } else {
+    const size_t lds = CHOL2_LDS_BYTES(N);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_chol2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_chol2<false>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr);
+  }
+  return hipGetLastError();
+}

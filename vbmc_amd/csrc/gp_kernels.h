@@ -7,7 +7,7 @@
 //
 //   k_sq_dist_mfma  C = max(|a|^2 + |b|^2 - 2 a'b, 0), the a'b contraction on v_mfma_f64_16x16x4_f64
 //   k_gp_build      A_s = K/(sn2div*mult) + diag(sn2/sn2div)   (Lchol)   or  K + mult*diag(sn2)
-//   k_chol          in-place blocked (16) right-looking Cholesky, upper factor, one WG per sample,
+//   k_chol2         (chol_mfma.h) in-place blocked (16) right-looking Cholesky, upper factor, one WG per sample,
 //                   reports MATLAB's p (> 0 = not positive definite) for the jitter retry
 //   k_gp_resid      r = y - m(X)
 //   k_pred_prep     ell-scaled, sq_dist-centred training inputs per hyper-sample
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const 
   }
 }
 
-// One workgroup per 64 x 64 tile of the UPPER triangle (k_chol reads i <= j only; it zeroes the strict lower part
+// One workgroup per 64 x 64 tile of the UPPER triangle (k_chol2 reads i <= j only; it zeroes the strict lower part
 // itself): both 64-point slabs of the scaled inputs are staged in LDS dimension-major, a lane keeps its own point in
 // registers and walks 16 columns whose coordinates are wave-uniform LDS broadcasts; exponent by the table exp.
 #define GPB_T 64
@@ -172,226 +172,25 @@ __global__ void __launch_bounds__(256) k_gp_build(int N, int D, int Nhyp, const 
 }
 
 // ------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky, upper factor R (R'R = A) in place, strict lower part zeroed.
+// Blocked right-looking Cholesky, upper factor R (R'R = A) in place, strict lower part zeroed: k_chol2 in chol_mfma.h.
 // pfail[s] = 0 on success, j+1 when the j-th pivot is not positive (MATLAB's [R,p] = chol(A)).
-// (structure: see k_chol below)
 // ------------------------------------------------------------------------------------------
-#define CH_NB 16
-#define CH_THREADS 1024
-#define CHOL_LDS_BYTES(N) ((size_t)(2 * 16 * 17 + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
+#ifdef CHOL_TS   // tools/chol_bench.hip only: per-step phase stamps of matrix 0 (wall_clock64, 100 MHz)
+__device__ long long g_chol_ts[4 * 512];
+__device__ long long g_chol_clk[2 * 512];   // shader-clock readings next to slot 0 / slot 3: cycles per microsecond = the clock the CU really ran at
+#define CHOL_STAMP(slot, step) do { if (blockIdx.x == 0 && (step) < 512) { g_chol_ts[4 * (step) + (slot)] = wall_clock64(); if ((slot) == 0) g_chol_clk[2 * (step)] = clock64(); if ((slot) == 3) g_chol_clk[2 * (step) + 1] = clock64(); } } while (0)
+#else
+#define CHOL_STAMP(slot, step) do { } while (0)
+#endif
 
-// Upper Cholesky of the 16 x 16 tile held in LDS (Dg, row stride 17; identity beyond nb) by ONE wave, in registers: lane c
-// (c = lane & 15; the four 16-lane groups work redundantly) gathers column c, the 16 pivot steps run on registers with the
-// pivot row broadcast through v_readlane (all lane indices are compile-time constants), and the factor goes back to LDS
-// once -- no LDS round trip or wave barrier per pivot.  Di[t] = 1 / R[t][t].  A non-positive or non-finite pivot records
-// kb + t + 1 in *s_fail (first failure wins) and is replaced by 1 so that the sweep completes.
 __device__ __forceinline__ double chol_readlane(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, l);
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void chol_diag_tile(double* __restrict__ Dg, double* __restrict__ Di, int nb, int kb, int lane,
-                                               int* s_fail) {
-  const int c = lane & 15;
-  double a[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = Dg[r * 17 + c];
-  int fail = 0;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    double piv = chol_readlane(a[t], t);
-    if (t < nb && (!(piv > 0.0) || !isfinite(piv))) {     // uniform: piv is a broadcast value
-      if (fail == 0) fail = kb + t + 1;
-      piv = 1.0;
-    }
-    const double rs = sqrt(piv);
-    const double ri = 1.0 / rs;                    // row scaled by the reciprocal, as LAPACK's dpotf2 does
-    a[t] = (c == t) ? rs : a[t] * ri;              // R[t][c] for c > t (entries with c < t are never read)
-    if (lane == t) Di[t] = ri;
-#pragma unroll
-    for (int ii = t + 1; ii < 16; ++ii) {
-      const double rti = chol_readlane(a[t], ii);  // R[t][ii]
-      a[ii] = (c >= ii) ? fma(-rti, a[t], a[ii]) : a[ii];
-    }
-  }
-  if (fail && lane == 0 && *s_fail == 0) *s_fail = fail;
-  if (lane < 16) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Dg[r * 17 + c] = a[r];
-  }
-  __builtin_amdgcn_wave_barrier();
-}
 
-// One 1024-thread workgroup (16 waves) per matrix; per 16-column block step:
-//   all lanes     solve the 16 x ntr panel row with the already factored diagonal tile and stage it in LDS,
-//   waves 1..15   apply the rank-16 trailing update A22 -= P'P tile by tile on the fp64 matrix cores
-//                 (4 x v_mfma_f64_16x16x4 per 16 x 16 tile, upper triangle of tiles only),
-//   wave 0        LOOK-AHEAD: updates the next diagonal tile first and factors it (in LDS, wave-synchronous) while the
-//                 other waves are still updating -- the 16 sequential pivot steps leave the critical path.
-// Pg: null, or S x 16 x Np doubles of global scratch that hold the panel rows when they no longer fit the LDS (N > 1232):
-// same layout, same code, the workgroup barriers order the accesses; the panel is then read through the L2.
-__global__ void __launch_bounds__(CH_THREADS) k_chol(int N, double* __restrict__ Aall, int* __restrict__ pfail,
-                                                     const unsigned char* __restrict__ active, double* __restrict__ Pg) {
-  extern __shared__ double lds[];
-  const int s = blockIdx.x;
-  if (!active[s]) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, lg = lane >> 4;
-  const int Np = ((N + 15) >> 4) << 4;
-  double* A = Aall + (size_t)s * N * N;
-  double* DgB = lds;                // two 16 x 17 diagonal tiles: this step's and the next one's
-  double* P = Pg ? Pg + (size_t)s * 16 * Np : DgB + 2 * 16 * 17;    // 16 x Np  panel rows R[kb+t][t0 + *], zero-padded
-  __shared__ int s_fail;
-  __shared__ double DiB[2][16];     // 1 / R[kb+t][kb+t]
-  if (tid == 0) s_fail = 0;
-  __syncthreads();
-  if (wave == 0) {
-    // ---- first diagonal tile
-    const int nb = min(CH_NB, N);
-    for (int e = lane; e < 256; e += 64) {
-      const int ii = e >> 4, jj = e & 15;
-      DgB[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)ii + (size_t)N * jj] : (ii == jj ? 1.0 : 0.0);
-    }
-    __builtin_amdgcn_wave_barrier();
-    chol_diag_tile(DgB, DiB[0], nb, 0, lane, &s_fail);
-    for (int e = lane; e < 256; e += 64) {
-      const int ii = e >> 4, jj = e & 15;
-      if (ii < nb && jj < nb) A[(size_t)ii + (size_t)N * jj] = (ii <= jj) ? DgB[ii * 17 + jj] : 0.0;
-    }
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int kb = 0; kb < N; kb += CH_NB, cur ^= 1) {
-    if (s_fail) break;            // uniform: written before the last barrier
-    const int nb = min(CH_NB, N - kb);
-    const double* Dg = DgB + cur * 16 * 17;
-    const double* Di = DiB[cur];
-    const int t0 = kb + nb;       // first trailing column
-    const int ntr = N - t0;
-    if (ntr <= 0) break;
-    const int ntrp = ((ntr + 15) >> 4) << 4;
-    // ---- panel: R[kb..kb+nb, j] = Rkk'^{-1} A[kb..kb+nb, j], one column per lane; rows >= nb and columns >= ntr are zero
-    for (int j = tid; j < ntrp; j += CH_THREADS) {
-      double r[CH_NB];
-      if (j < ntr) {
-        const double* col = A + (size_t)kb + (size_t)N * (t0 + j);
-#pragma unroll
-        for (int t = 0; t < CH_NB; ++t) r[t] = (t < nb) ? col[t] : 0.0;
-#pragma unroll
-        for (int t = 0; t < CH_NB; ++t) {
-          if (t < nb) {
-            double v = r[t];
-#pragma unroll
-            for (int u = 0; u < t; ++u) v = fma(-Dg[u * 17 + t], r[u], v);
-            r[t] = v * Di[t];
-          }
-        }
-        double* colw = A + (size_t)kb + (size_t)N * (t0 + j);
-#pragma unroll
-        for (int t = 0; t < CH_NB; ++t) if (t < nb) colw[t] = r[t];
-      } else {
-#pragma unroll
-        for (int t = 0; t < CH_NB; ++t) r[t] = 0.0;
-      }
-#pragma unroll
-      for (int t = 0; t < CH_NB; ++t) P[(size_t)t * Np + j] = r[t];
-    }
-    __syncthreads();
-    // ---- trailing update, transposed tiles so that lanes run along i (contiguous in the column-major matrix):
-    //      C'[j][i] = sum_t P[t][j0+j] P[t][i0+i];  A[t0+i0+i][t0+j0+j] -= C'[j][i]  for i <= j.
-    // The upper-triangular tile pairs are enumerated directly; pair 0 = the next diagonal tile belongs to wave 0, the
-    // others are dealt to waves 1..15, whose next tile is loaded before the MFMAs of the current one.
-    const int nt = ntrp >> 4;
-    const int npair = nt * (nt + 1) / 2;
-    auto decode = [](int u, int& ti, int& tj) {
-      int c = (int)((sqrtf(8.0f * (float)u + 1.0f) - 1.0f) * 0.5f);
-      while ((c + 1) * (c + 2) / 2 <= u) ++c;
-      while (c * (c + 1) / 2 > u) --c;
-      tj = c; ti = u - c * (c + 1) / 2;
-    };
-    double* At = A + (size_t)t0 + (size_t)N * t0;     // trailing matrix; 32-bit offsets inside it (N <= 3872)
-    auto load_tile = [&](int ti_, int tj_, double* dst) {
-      const int i = (ti_ << 4) + li, jb = (tj_ << 4) + lg;
-      const int off = jb * N + i;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int j = jb + 4 * reg;
-        dst[reg] = (i < ntr && j < ntr && i <= j) ? At[off + 4 * reg * N] : 0.0;
-      }
-    };
-    if (wave == 0) {
-      // next diagonal tile: update, factor in LDS, write the factor
-      const int nb2 = min(CH_NB, ntr);
-      double* Dn = DgB + (cur ^ 1) * 16 * 17;
-      double c0[4];
-      load_tile(0, 0, c0);
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double pa = P[(size_t)(4 * q + lg) * Np + li];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pa, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int ii = li, jj = lg + 4 * reg;      // element (row ii, column jj) of the tile
-        Dn[ii * 17 + jj] = (ii < nb2 && jj < nb2 && ii <= jj) ? c0[reg] - acc[reg] : (ii == jj ? 1.0 : 0.0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      chol_diag_tile(Dn, DiB[cur ^ 1], nb2, t0, lane, &s_fail);
-      for (int e = lane; e < 256; e += 64) {
-        const int ii = e >> 4, jj = e & 15;
-        if (ii < nb2 && jj < nb2) A[(size_t)(t0 + ii) + (size_t)N * (t0 + jj)] = (ii <= jj) ? Dn[ii * 17 + jj] : 0.0;
-      }
-    } else {
-      // pairs 1, 2, ... dealt to waves 1..15, taken four at a time: the 16 loads of a group are issued together, so one L2
-      // round trip is paid per four tiles (one tile ahead left every tile waiting a full round trip; the 128-VGPR budget of
-      // a 1024-thread workgroup has no room for a second group in flight)
-      // The pair index advances by WSTR per tile; (ti, tj) follow it incrementally (column tj of the triangle holds the
-      // pairs ti = 0..tj) instead of being decoded with a square root per tile: with four waves per SIMD the per-tile
-      // bookkeeping, not the matrix cores, set the pace of this phase.
-      constexpr int CH_G = 4, WSTR = CH_THREADS / 64 - 1;
-      int ti, tj;
-      decode(wave, ti, tj);
-      for (int u = wave; u < npair; u += CH_G * WSTR) {
-        double cv[CH_G][4];
-        int gi[CH_G], gj[CH_G];
-#pragma unroll
-        for (int g = 0; g < CH_G; ++g) {
-          gi[g] = (u + g * WSTR < npair) ? ti : -1;
-          gj[g] = tj;
-          if (gi[g] >= 0) load_tile(ti, tj, cv[g]);
-          ti += WSTR;
-          while (ti > tj) { ti -= tj + 1; ++tj; }
-        }
-#pragma unroll
-        for (int g = 0; g < CH_G; ++g) {
-          if (gi[g] >= 0) {
-            const int i0 = gi[g] << 4, j0 = gj[g] << 4;
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-            const double* pj = P + (size_t)lg * Np + j0 + li;
-            const double* pi = P + (size_t)lg * Np + i0 + li;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[4 * q * Np], pi[4 * q * Np], acc, 0, 0, 0);
-            const int i = i0 + li, jb = j0 + lg;
-            const int off = jb * N + i;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const int j = jb + 4 * reg;
-              if (i < ntr && j < ntr && i <= j) At[off + 4 * reg * N] = cv[g][reg] - acc[reg];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) pfail[s] = s_fail;
-  if (s_fail) return;
-  // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
-  for (int j = tid >> 6; j < N; j += CH_THREADS >> 6)
-    for (int i = j + 1 + lane; i < N; i += 64) A[(size_t)i + (size_t)N * j] = 0.0;
-}
+#include "chol_mfma.h"
 
 // alpha-type solve x = R \ (R' \ z) for ONE right-hand side per matrix, latency-shaped: one 1024-thread workgroup per
 // matrix, the vector in LDS.  Per 16-row block step the 16 dot products with the already solved part are one wave each
