@@ -32,6 +32,38 @@ static int host_chol_upper(int N, std::vector<double>& A) {   // column-major, u
   return 0;
 }
 
+// How fast can ONE compute unit stream 16 x 16 tiles of a column-major matrix through the L2?  (variant 9)
+// mode 0: loads only; mode 1: load, +1, store back.  G tiles (4 loads of 512 B per wave each) in flight per wave.
+template <int G>
+__global__ void __launch_bounds__(512) k_tile_stream(int N, double* A, int mode, int passes, double* out) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4, nt = N >> 4;
+  unsigned lob[4];
+  for (int r = 0; r < 4; ++r) lob[r] = (unsigned)(((lg + 4 * r) * N + li) * 8);
+  char* Ab = reinterpret_cast<char*>(A);
+  double sum = 0.0;
+  for (int p = 0; p < passes; ++p)
+    for (int t = wave * G; t + G <= nt * nt; t += 8 * G) {
+      double c[G][4];
+      unsigned ob[G][4];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int ti = (t + g) % nt, tj = (t + g) / nt;
+        const unsigned tpb = (unsigned)(((tj << 4) * N + (ti << 4)) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ob[g][r] = tpb + lob[r]; c[g][r] = *reinterpret_cast<const double*>(Ab + ob[g][r]); }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (mode) *reinterpret_cast<double*>(Ab + ob[g][r]) = c[g][r] + 1.0;
+          else sum += c[g][r];
+        }
+    }
+  if (sum == 1.2345e300) out[0] = sum;
+}
+
 static hipError_t launch(int variant, int N, int S, double* dA, int* dpf, unsigned char* dact, double* dPg, hipStream_t st) {
   switch (variant) {
     case 1: return chol2_launch(N, S, dA, dpf, dact, dPg, st);
@@ -43,6 +75,33 @@ int main(int argc, char** argv) {
   const int variant = argc > 1 ? atoi(argv[1]) : 1, N = argc > 2 ? atoi(argv[2]) : 400, S = argc > 3 ? atoi(argv[3]) : 20;
   const int reps = argc > 4 ? atoi(argv[4]) : 20, stamps = argc > 5 ? atoi(argv[5]) : 0;
   const size_t NN = (size_t)N * N;
+  if (variant == 9) {
+    double *dA, *dout;
+    CHECK(hipMalloc(&dA, NN * 8)); CHECK(hipMalloc(&dout, 8));
+    CHECK(hipMemset(dA, 0, NN * 8));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int passes = 20;
+    for (int G = 4; G <= 16; G *= 2)
+      for (int mode = 0; mode < 2; ++mode) {
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+          CHECK(hipEventRecord(e0, 0));
+          if (G == 4) hipLaunchKernelGGL((k_tile_stream<4>), dim3(S), dim3(512), 0, 0, N, dA, mode, passes, dout);
+          else if (G == 8) hipLaunchKernelGGL((k_tile_stream<8>), dim3(S), dim3(512), 0, 0, N, dA, mode, passes, dout);
+          else hipLaunchKernelGGL((k_tile_stream<16>), dim3(S), dim3(512), 0, 0, N, dA, mode, passes, dout);
+          CHECK(hipEventRecord(e1, 0));
+          CHECK(hipDeviceSynchronize());
+          float t;
+          CHECK(hipEventElapsedTime(&t, e0, e1));
+          best = std::min(best, t);
+        }
+        const double bytes = (double)passes * (N / 16) * (N / 16) * 2048.0 * (mode ? 2 : 1);
+        printf("tile stream N=%d WGs=%d (same matrix) G=%d %s: %.3f ms  %.1f GB/s per WG\n", N, S, G, mode ? "load+store" : "load only", best,
+               bytes / best * 1e-6);
+      }
+    return 0;
+  }
   std::vector<double> G(NN), A(NN);
   unsigned long long sd = 88172645463325252ull;
   auto rnd = [&]() { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; return (double)(sd >> 11) / 9007199254740992.0 - 0.5; };
@@ -135,6 +194,12 @@ int main(int argc, char** argv) {
       for (int g = 0; g < gn && g < 64; ++g)
         printf("  g%02d: %6lld %6lld %6lld %6lld %6lld\n", g, gs[8 * g + 1] - gs[8 * g], gs[8 * g + 2] - gs[8 * g + 1], gs[8 * g + 3] - gs[8 * g + 2],
                gs[8 * g + 4] - gs[8 * g + 3], g + 1 < gn ? gs[8 * (g + 1)] - gs[8 * g + 4] : 0);
+    }
+    {
+      long long la[8];
+      CHECK(hipMemcpyFromSymbol(la, HIP_SYMBOL(g_chol_la), sizeof(la)));
+      printf("look-ahead of step 12 (shader cycles): load tile %lld | MFMA + tile to LDS %lld | factor %lld | invert %lld | store %lld\n", la[1] - la[0],
+             la[2] - la[1], la[3] - la[2], la[4] - la[3], la[5] - la[4]);
     }
     std::vector<long long> ck(2 * 512);
     CHECK(hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(g_chol_clk), ck.size() * 8));

@@ -20,65 +20,96 @@
 #endif
 #define CH2_W (CH2_THREADS / 64)
 #define CH2_G 4
-// LDS doubles: 2 diagonal tiles + 2 inverses (16 x 17 each) + the panel
-#define CH2_LDS_FIXED (4 * 16 * 17)
+#ifndef CH2_IDLE4
+#define CH2_IDLE4 1
+#endif
+// LDS doubles: 2 diagonal tiles + 2 inverses (16 x 17 each) + 64 of gather scratch for the tile factorisation + the panel
+#define CH2_LDS_FIXED (4 * 16 * 17 + 64)
 #define CHOL2_LDS_BYTES(N) ((size_t)(CH2_LDS_FIXED + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
 
 // sqrt(p) and 1/sqrt(p) from the v_rsq_f64 seed with two Goldschmidt steps and a final residual correction (the sequence of
 // the compiler's own sqrt expansion, which also yields the reciprocal root): ~12 dependent operations instead of an IEEE sqrt
 // followed by an IEEE division (~80) on the critical path of every pivot.  p is positive and finite here.
 __device__ __forceinline__ void chol_sqrt_rsqrt(double p, double& rs, double& ri) {
-  // scale into [2^-512, 2^512) as the library sqrt does, so that p*y and the residual neither overflow nor go subnormal
-  const bool small = p < 0x1p-767, big = p > 0x1p+767;
-  const double ps = small ? p * 0x1p+512 : (big ? p * 0x1p-512 : p);
-  const double y = __builtin_amdgcn_rsq(ps);
-  double g = ps * y, h = 0.5 * y;
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
   r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
-  const double d = fma(-g, g, ps);
-  g = fma(d, h, g);
-  const double sc = small ? 0x1p-256 : (big ? 0x1p+256 : 1.0);
-  rs = g * sc;
-  ri = (h + h) * (small ? 0x1p+256 : (big ? 0x1p-256 : 1.0));
+  const double d = fma(-g, g, p);
+  rs = fma(d, h, g);
+  ri = h + h;
+  if (__builtin_expect(p < 0x1p-767, 0)) {       // tiny pivot (never on the critical path of a sane matrix): redo it scaled by
+    const double ps = __builtin_amdgcn_ldexp(p, 256);   // 2^256 as the library sqrt does -- p * y and the residual went subnormal
+    const double y2 = __builtin_amdgcn_rsq(ps);
+    g = ps * y2; h = 0.5 * y2;
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d2 = fma(-g, g, ps);
+    rs = __builtin_amdgcn_ldexp(fma(d2, h, g), -128);
+    ri = __builtin_amdgcn_ldexp(h, 129);
+  }
 }
 
-// Upper Cholesky of the 16 x 16 tile held in LDS (Dg, row stride 17; identity beyond nb) by ONE wave, in registers: lane c
-// (c = lane & 15; the four 16-lane groups work redundantly) gathers column c, the 16 pivot steps run on registers with the
-// pivot row broadcast through v_readlane (all lane indices are compile-time constants), and the factor goes back to LDS
-// once -- no LDS round trip or wave barrier per pivot.  Di[t] = 1 / R[t][t].  A non-positive or non-finite pivot records
-// kb + t + 1 in *s_fail (first failure wins) and is replaced by 1 so that the sweep completes.
-__device__ __forceinline__ void chol_diag_tile2(double* __restrict__ Dg, double* __restrict__ Di, int nb, int kb, int lane,
-                                                int* s_fail) {
-  const int c = lane & 15;
-  double a[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = Dg[r * 17 + c];
+// Lower Cholesky of a 16 x 16 tile held by ONE wave in the MFMA accumulator layout: lane (li, lg), register r holds
+// T[i = li][j = lg + 4 r], valid on and below the diagonal (i >= j; identity beyond nb).  Four blocks of four columns:
+//   gather   the block's four columns live in the four lane groups (register b): through 512 bytes of LDS every lane gets the
+//            four entries of ITS ROW (w[0..3]);
+//   factor   four pivots on w: root / reciprocal root of the broadcast pivot (v_readlane, wave-uniform), scale, and the <= 3
+//            updates inside the block with the broadcast multiplier -- 6 broadcast-FMA pairs per block instead of 54;
+//   scatter  X[b] = w[lg]: every lane already holds all four entries of its row, no cross-lane traffic;
+//   update   the rank-4 update of the columns to the right is ONE v_mfma_f64_16x16x4 with X[b] as both operands -- its output
+//            layout is the tile's own layout.
+// On exit X[r] = L[li][lg + 4 r] (i >= j), Dg[t * 17 + c] = R[t][c] = L[c][t] (upper factor, row stride 17), Di[t] = 1 / R[t][t].
+// A non-positive or non-finite pivot records kb + t + 1 in *s_fail (first failure wins) and is replaced by 1.
+__device__ __forceinline__ void chol_diag_tile3(double (&X)[4], double* __restrict__ Dg, double* __restrict__ Di, double* __restrict__ scr,
+                                                int nb, int kb, int lane, int* s_fail) {
+  typedef double d4w __attribute__((ext_vector_type(4)));
+  const int li = lane & 15, lg = lane >> 4;
   int fail = 0;
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    double piv = chol_readlane(a[t], t);
-    if (t < nb && (!(piv > 0.0) || !isfinite(piv))) {     // uniform: piv is a broadcast value
-      if (fail == 0) fail = kb + t + 1;
-      piv = 1.0;
-    }
-    double rs, ri;
-    chol_sqrt_rsqrt(piv, rs, ri);
-    a[t] = (c == t) ? rs : a[t] * ri;              // R[t][c] for c > t (entries with c < t are never read)
-    if (lane == t) Di[t] = ri;
+  for (int b = 0; b < 4; ++b) {
+    scr[li * 4 + lg] = X[b];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const d4w wv = *reinterpret_cast<const d4w*>(scr + li * 4);
+    double w[4] = {wv[0], wv[1], wv[2], wv[3]};
+    __builtin_amdgcn_wave_barrier();             // the next block's writes must not overtake these reads
 #pragma unroll
-    for (int ii = t + 1; ii < 16; ++ii) {
-      const double rti = chol_readlane(a[t], ii);  // R[t][ii]
-      a[ii] = fma(-rti, a[t], a[ii]);              // lanes c < ii compute entries below the diagonal that nobody reads
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      const int t = 4 * b + sidx;
+      double piv = chol_readlane(w[sidx], t);
+      // the validity test runs beside the root chain, not in front of it: a bad pivot only poisons rs / ri, replaced below
+      const bool bad = !(piv > 0.0 && piv < __builtin_inf());             // uniform (a broadcast value)
+      fail = (bad && t < nb && fail == 0) ? kb + t + 1 : fail;
+      double rs, ri;
+      chol_sqrt_rsqrt(bad ? 1.0 : piv, rs, ri);
+      w[sidx] = (li == t) ? rs : w[sidx] * ri;              // L[li][t] for li > t (rows above the diagonal are never read)
+      if (lane == t) Di[t] = ri;
+#pragma unroll
+      for (int s2 = sidx + 1; s2 < 4; ++s2) {
+        const double m = chol_readlane(w[sidx], 4 * b + s2); // L[t'][t]
+        w[s2] = fma(-m, w[sidx], w[s2]);
+      }
+    }
+    X[b] = lg == 0 ? w[0] : (lg == 1 ? w[1] : (lg == 2 ? w[2] : w[3]));
+    if (b < 3) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[b], X[b], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = b + 1; r < 4; ++r) X[r] -= acc[r];
     }
   }
   if (fail && lane == 0 && *s_fail == 0) *s_fail = fail;
-  if (lane < 16) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Dg[r * 17 + c] = a[r];
-  }
+  for (int r = 0; r < 4; ++r) Dg[(lg + 4 * r) * 17 + li] = X[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // inverse of the upper factor held in Dg (row stride 17, identity beyond nb): Ri[c][t] = inv(R)[c][t] = inv(R')[t][c].
@@ -108,11 +139,16 @@ __device__ int g_chol_gn;
     if ((slot) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     if ((slot) == 3) asm volatile("s_nop 7\n s_nop 7\n s_nop 7" ::: "memory"); \
     g_chol_gs[8 * gcount + (slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); if ((slot) == 4) { ++gcount; g_chol_gn = gcount; } } } while (0)
+// shader-clock stamps inside the look-ahead of wave 0 at step 12
+__device__ long long g_chol_la[8];
+#define CH2_LSTAMP(slot) do { if (blockIdx.x == 0 && kb == 12 * 16) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if (lane == 0) g_chol_la[slot] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define CH2_GSTAMP(slot) do { } while (0)
+#define CH2_LSTAMP(slot) do { } while (0)
 #endif
 
-template <bool GP>
+template <bool GP, bool TWO>
 __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict__ Aall, int* __restrict__ pfail,
                                                        const unsigned char* __restrict__ active, double* __restrict__ Pg) {
   extern __shared__ __attribute__((aligned(32))) double lds_c2[];   // 32-byte vectors of the panel
@@ -126,34 +162,46 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
   double* A = Aall + (size_t)s * N * N;
   double* DgB = lds;                      // [2][16 x 17] diagonal tiles: this step's and the next one's
   double* RiB = lds + 2 * 16 * 17;        // [2][16 x 17] their inverses
-  double* Pl = lds + CH2_LDS_FIXED;       // 16 x Np panel rows (LDS variant)
+  double* scr = lds + 4 * 16 * 17;        // 64 doubles (chol_diag_tile3)
+  double* Pl = lds + CH2_LDS_FIXED;       // 16 x Np panel rows (LDS variant); TWO: a second panel behind it
   double* Pgl = GP ? Pg + (size_t)s * 16 * Np : nullptr;
+  static_assert(!(GP && TWO), "the two-panel scheme keeps both panels in LDS");
   __shared__ int s_fail;
   __shared__ double DiB[2][16];
   // Panel layout: row t = 4 q + g of the 16 x Np panel lives at ((g * Np + col) * 4 + q): the four q-slices an MFMA operand
   // needs for one column are 32 contiguous bytes (one vector read per operand set, one vector write per product column).
   typedef double d4v __attribute__((ext_vector_type(4)));
-  auto ldP4 = [&](int g, int col) -> d4v {
-    return GP ? *(const d4v*)(Pgl + (((size_t)g * Np + col) << 2)) : *(const d4v*)(Pl + ((g * Np + col) << 2));
+  auto ldP4 = [&](int buf, int g, int col) -> d4v {        // buf: 0 / 1 = first / second panel (TWO only)
+    return GP ? *(const d4v*)(Pgl + (((size_t)g * Np + col) << 2)) : *(const d4v*)(Pl + buf * 16 * Np + ((g * Np + col) << 2));
   };
-  auto stP4 = [&](int g, int col, d4v v) {
-    if (GP) *(d4v*)(Pgl + (((size_t)g * Np + col) << 2)) = v; else *(d4v*)(Pl + ((g * Np + col) << 2)) = v;
+  auto stP4 = [&](int buf, int g, int col, d4v v) {
+    if (GP) *(d4v*)(Pgl + (((size_t)g * Np + col) << 2)) = v; else *(d4v*)(Pl + buf * 16 * Np + ((g * Np + col) << 2)) = v;
   };
   if (tid == 0) s_fail = 0;
   __syncthreads();
+  // the tile in the accumulator layout from the UPPER triangle of the symmetric matrix: T[i = li][j] = A[j][i] for i >= j
+  auto load_diag = [&](const double* Ad, int nbt, double (&X)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = lg + 4 * r;
+      const bool ok = li < nbt && j < nbt && li >= j;
+      const double v = Ad[ok ? (size_t)li * N + j : 0];
+      X[r] = ok ? v : (li == j ? 1.0 : 0.0);
+    }
+  };
+  auto store_diag = [&](double* Ad, int nbt, const double* Dg) {
+    for (int e = lane; e < 256; e += 64) {
+      const int ii = e >> 4, jj = e & 15;
+      if (ii < nbt && jj < nbt) Ad[(size_t)ii + (size_t)N * jj] = (ii <= jj) ? Dg[ii * 17 + jj] : 0.0;
+    }
+  };
   if (wave == 0) {
     const int nb = min(16, N);
-    for (int e = lane; e < 256; e += 64) {
-      const int ii = e >> 4, jj = e & 15;
-      DgB[ii * 17 + jj] = (ii < nb && jj < nb && ii <= jj) ? A[(size_t)ii + (size_t)N * jj] : (ii == jj ? 1.0 : 0.0);
-    }
-    __builtin_amdgcn_wave_barrier();
-    chol_diag_tile2(DgB, DiB[0], nb, 0, lane, &s_fail);
+    double X[4];
+    load_diag(A, nb, X);
+    chol_diag_tile3(X, DgB, DiB[0], scr, nb, 0, lane, &s_fail);
     chol_tile_inverse(DgB, DiB[0], RiB, lane);
-    for (int e = lane; e < 256; e += 64) {
-      const int ii = e >> 4, jj = e & 15;
-      if (ii < nb && jj < nb) A[(size_t)ii + (size_t)N * jj] = (ii <= jj) ? DgB[ii * 17 + jj] : 0.0;
-    }
+    store_diag(A, nb, DgB);
   }
   __syncthreads();
   int cur = 0;
@@ -166,6 +214,10 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     if (ntr <= 0) break;
     const int nt = (ntr + 15) >> 4;
     const double* Ri = RiB + cur * 16 * 17;
+    // TWO: the trailing matrix is read and written once per TWO block steps.  Even step (A): panel A, the look-ahead, and the
+    // update of the next row block only (what panel B is made of).  Odd step (B): panel B, then every remaining tile takes the
+    // rank-32 update of both panels in one pass -- the update is bound by the L2 bandwidth of one CU, and this halves its traffic.
+    const int pbuf = TWO ? ((kb >> 4) & 1) : 0;
     if (tid == 0) CHOL_STAMP(0, kb >> 4);
     // ---- panel: tile tj of the row block (16 x 16, rows kb.., columns t0 + 16 tj..) times inv(Rkk')
     {
@@ -193,7 +245,7 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[p][q], acc, 0, 0, 0);
-            stP4(lg, j, acc);                                              // acc[r] = R[kb + lg + 4r][t0 + j]; zero for rows >= nb, j >= ntr
+            stP4(pbuf, lg, j, acc);                                        // acc[r] = R[kb + lg + 4r][t0 + j]; zero for rows >= nb, j >= ntr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int t = lg + 4 * r;
@@ -214,46 +266,84 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       // look-ahead: next diagonal tile (pair 0)
       const int nb2 = min(16, ntr);
       double* Dn = DgB + (cur ^ 1) * 16 * 17;
-      double c0[4];
+      CH2_LSTAMP(0);
+      double X[4];
+      load_diag(At, nb2, X);
+      CH2_LSTAMP(1);
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      const d4v pa = ldP4(pbuf, lg, li);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[q], pa[q], acc, 0, 0, 0);
+      if (TWO && pbuf == 1) {                 // B step: the tile has not seen panel A yet (its columns sit 16 further in A's panel)
+        const d4v pa0 = ldP4(0, lg, 16 + li);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa0[q], pa0[q], acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = lg + 4 * r;
-        const bool ok = li < nb2 && j < nb2 && li <= j;
-        const double v = At[ok ? j * N + li : 0];
-        c0[r] = ok ? v : 0.0;
+        if (li < nb2 && j < nb2 && li >= j) X[r] -= acc[r];     // the product is symmetric: either triangle of it will do
       }
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      const d4v pa = ldP4(lg, li);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[q], pa[q], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ii = li, jj = lg + 4 * r;      // element (row ii, column jj) of the tile
-        Dn[ii * 17 + jj] = (ii < nb2 && jj < nb2 && ii <= jj) ? c0[r] - acc[r] : (ii == jj ? 1.0 : 0.0);
-      }
-      __builtin_amdgcn_wave_barrier();
-      chol_diag_tile2(Dn, DiB[cur ^ 1], nb2, t0, lane, &s_fail);
+      CH2_LSTAMP(2);
+      chol_diag_tile3(X, Dn, DiB[cur ^ 1], scr, nb2, t0, lane, &s_fail);
+      CH2_LSTAMP(3);
       chol_tile_inverse(Dn, DiB[cur ^ 1], RiB + (cur ^ 1) * 16 * 17, lane);
-      for (int e = lane; e < 256; e += 64) {
-        const int ii = e >> 4, jj = e & 15;
-        if (ii < nb2 && jj < nb2) A[(size_t)(t0 + ii) + (size_t)N * (t0 + jj)] = (ii <= jj) ? Dn[ii * 17 + jj] : 0.0;
-      }
+      CH2_LSTAMP(4);
+      store_diag(At, nb2, Dn);
+      CH2_LSTAMP(5);
       if (lane == 0) CHOL_STAMP(2, kb >> 4);
     }
-    if (wave > 0) {
-      // Static deal: group n of wave w = pairs 1 + CH2_G (w - 1 + (CH2_W - 1) n) .. + CH2_G - 1, walked incrementally (an LDS
+    // Wave 0 (look-ahead) is a long chain of dependent fp64 VALU operations, and an fp64 MFMA of another wave on the same SIMD
+    // blocks its issue: where the look-ahead is the critical path (small updates, A steps) wave 4, which shares SIMD 0 with it,
+    // stays out of the update; a large update hides the look-ahead anyway and wants all four matrix pipes.
+    const bool idle4 = CH2_IDLE4 && !((!TWO || pbuf == 1) && npair > 48);
+    const int UW = CH2_W - (idle4 ? 2 : 1);                              // waves that update
+    const int uslot = (idle4 && wave > 4) ? wave - 2 : wave - 1;         // their index 0 .. UW - 1
+    if (wave > 0 && !(idle4 && wave == 4)) {
+      // one tile with masks: ragged edges, diagonal tiles of the slow path, the row block of an A step
+      auto tile_masked = [&](int a, int b, bool both) {
+        const int i0 = a << 4, j0 = b << 4, i = i0 + li, jb = j0 + lg;
+        double c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = jb + 4 * r;
+          const bool ok = i < ntr && j < ntr;
+          c[r] = At[ok ? j * N + i : 0];
+        }
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        {
+          const d4v pj = ldP4(pbuf, lg, j0 + li), pi = ldP4(pbuf, lg, i0 + li);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[q], pi[q], acc, 0, 0, 0);
+        }
+        if (TWO && both) {
+          const d4v pj = ldP4(0, lg, 16 + j0 + li), pi = ldP4(0, lg, 16 + i0 + li);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[q], pi[q], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = jb + 4 * r;
+          if (i < ntr && j < ntr && i <= j) At[j * N + i] = c[r] - acc[r];
+        }
+      };
+      if (TWO && pbuf == 0) {
+        // A step: only the next row block, tiles (0, tj), tj = 1 .. nt - 1 (the diagonal tile is the look-ahead's)
+        for (int tjj = 1 + uslot; tjj < nt; tjj += UW) tile_masked(0, tjj, false);
+      } else {
+      // Static deal: group n of update wave w' = pairs 1 + CH2_G (w' + UW n) .. + CH2_G - 1, walked incrementally (an LDS
       // work counter was measured: the atomic's round trip at the head of every group cost more than the imbalance it removes).
       // FAST groups lie entirely in full tile columns (16 (tj + 1) <= ntr): no masks -- the entries below the diagonal of a
       // diagonal tile are updated like the rest (they hold whatever the builder left there, nobody reads them, and the
       // strict lower triangle is zeroed at the end).
-      constexpr int STRIDE = CH2_G * (CH2_W - 1);
+      const int STRIDE = CH2_G * UW;
       const int ntf = ntr >> 4;
       const int ufast = ntf * (ntf + 1) / 2;
       unsigned lob[4];                          // byte offset of this lane's element in register r of a tile
 #pragma unroll
       for (int r = 0; r < 4; ++r) lob[r] = (unsigned)(((lg + 4 * r) * N + li) * 8);
       const char* Ab = reinterpret_cast<const char*>(At);
-      int u0 = 1 + CH2_G * (wave - 1);
+      int u0 = 1 + CH2_G * uslot;
       int ti, tj;                               // pair u0 = tj (tj + 1) / 2 + ti
       {
         int c = (int)((sqrtf(8.0f * (float)u0 + 1.0f) - 1.0f) * 0.5f);
@@ -262,8 +352,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
         tj = c; ti = u0 - c * (c + 1) / 2;
       }
       auto advance = [&](int by) { ti += by; while (ti > tj) { ti -= tj + 1; ++tj; } };
-      // One fast group: CH2_G x 4 loads, all operand reads, the CH2_G accumulation chains back to back, CH2_G x 4 stores from
-      // the registers the loads filled through one 32-bit byte offset each (SGPR base + VGPR offset addressing).
+      // One fast group: CH2_G x 4 loads, the operand reads, the CH2_G accumulation chains back to back (per panel), CH2_G x 4
+      // stores from the registers the loads filled through one 32-bit byte offset each (SGPR base + VGPR offset addressing).
       auto group = [&]() {
         double c[CH2_G][4];
         unsigned ob[CH2_G][4];
@@ -286,16 +376,20 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
           }
         }
         CH2_GSTAMP(1);
-        d4v pj[CH2_G], pi[CH2_G];
-#pragma unroll
-        for (int g = 0; g < CH2_G; ++g) { pj[g] = ldP4(lg, j0_[g] + li); pi[g] = ldP4(lg, i0_[g] + li); }
-        CH2_GSTAMP(2);
         d4_t acc[CH2_G];
 #pragma unroll
-        for (int g = 0; g < CH2_G; ++g) {
-          acc[g] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < CH2_G; ++g) acc[g] = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[g][q], pi[g][q], acc[g], 0, 0, 0);
+        for (int pn = 0; pn < (TWO ? 2 : 1); ++pn) {
+          const int buf = TWO ? 1 - pn : 0, sh = (TWO && pn == 1) ? 16 : 0;   // panel B first (its columns start at this step's t0)
+          d4v pj[CH2_G], pi[CH2_G];
+#pragma unroll
+          for (int g = 0; g < CH2_G; ++g) { pj[g] = ldP4(buf, lg, sh + j0_[g] + li); pi[g] = ldP4(buf, lg, sh + i0_[g] + li); }
+          if (pn == 0) CH2_GSTAMP(2);
+#pragma unroll
+          for (int g = 0; g < CH2_G; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[g][q], pi[g][q], acc[g], 0, 0, 0);
         }
         CH2_GSTAMP(3);
 #pragma unroll
@@ -312,27 +406,12 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       for (; u0 < npair; u0 += STRIDE, advance(STRIDE)) {
         int a = ti, b = tj;
         for (int g = 0; g < CH2_G && u0 + g < npair; ++g) {
-          const int i0 = a << 4, j0 = b << 4, i = i0 + li, jb = j0 + lg;
-          double c[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = jb + 4 * r;
-            const bool ok = i < ntr && j < ntr;
-            c[r] = At[ok ? j * N + i : 0];
-          }
-          const d4v pj = ldP4(lg, j0 + li), pi = ldP4(lg, i0 + li);
-          d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[q], pi[q], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = jb + 4 * r;
-            if (i < ntr && j < ntr && i <= j) At[j * N + i] = c[r] - acc[r];
-          }
+          tile_masked(a, b, true);
           const bool wrap = a == b;
           a = wrap ? 0 : a + 1;
           b += wrap ? 1 : 0;
         }
+      }
       }
     }
     __syncthreads();
@@ -346,18 +425,26 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
 }
 
 // Launch on stream st: S matrices of order N in dA (N x N x S), pfail S ints, active S flags; Pg = S x 16 x Np doubles of
-// scratch, needed only when chol2_needs_gpanel(N).
+// scratch, needed only when chol2_needs_gpanel(N).  Two panels in LDS up to N = 592, one up to N = 1200, global panel beyond.
+#define CHOL2_LDS_BYTES2(N) ((size_t)(CH2_LDS_FIXED + 32 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
 static inline bool chol2_needs_gpanel(int N) { return CHOL2_LDS_BYTES(N) > 159 * 1024; }   // + ~0.3 KB of static LDS
 static inline hipError_t chol2_launch(int N, int S, double* dA, int* dpf, const unsigned char* dact, double* dPg, hipStream_t st) {
   if (chol2_needs_gpanel(N)) {
-    hipLaunchKernelGGL((k_chol2<true>), dim3(S), dim3(CH2_THREADS), (size_t)CH2_LDS_FIXED * sizeof(double), st, N, dA, dpf, dact, dPg);
-  } else {
+    hipLaunchKernelGGL((k_chol2<true, false>), dim3(S), dim3(CH2_THREADS), (size_t)CH2_LDS_FIXED * sizeof(double), st, N, dA, dpf, dact, dPg);
+  } else if (CHOL2_LDS_BYTES2(N) > 159 * 1024) {
     const size_t lds = CHOL2_LDS_BYTES(N);
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_chol2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)k_chol2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_chol2<false>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr);
+    hipLaunchKernelGGL((k_chol2<false, false>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr);
+  } else {
+    const size_t lds = CHOL2_LDS_BYTES2(N);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_chol2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_chol2<false, true>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr);
   }
   return hipGetLastError();
 }
