@@ -162,3 +162,29 @@ def test_copy_vp_is_independent_and_complete():
     c["bounds"]["mu_lb"][1] = 9.0
     c["hist"][1]["b"][0] = 5.0
     assert same(vp, d)          # the original saw none of it
+
+
+def test_build_dependency_lists_cover_every_included_source():
+    """vbmc_amd/build.py rebuilds a translation unit when a file of its dependency list is newer than the object: every local
+    #include reachable from vbmc_hip.hip / ent_mfma_inst.hip has to be on the list, or an edited header ships a stale library."""
+    import os
+    import re
+
+    from vbmc_amd import build as B
+
+    def closure(start):
+        seen, todo = set(), [start]
+        while todo:
+            f = todo.pop()
+            if f in seen:
+                continue
+            seen.add(f)
+            for inc in re.findall(r'^\s*#include\s+"([^"]+)"', open(os.path.join(B.CSRC, f)).read(), flags=re.M):
+                if os.path.exists(os.path.join(B.CSRC, inc)):
+                    todo.append(os.path.normpath(inc))
+        return seen
+
+    main = {os.path.normpath(d) for d in B.MAIN_DEPS}
+    mfma = {os.path.normpath(d) for d in B.MFMA_DEPS}
+    assert closure("vbmc_hip.hip") <= main, sorted(closure("vbmc_hip.hip") - main)
+    assert closure("ent_mfma_inst.hip") <= mfma, sorted(closure("ent_mfma_inst.hip") - mfma)

@@ -3,16 +3,21 @@
 // Reference: gplite/private/gplite_core.m:77-100 ([L,p] = chol(K)), the p > 0 semantics of MATLAB's chol.
 //
 // Per 16-row block step (kb):
-//   panel     R[kb.., j] = inv(Rkk') A[kb.., j] as an MFMA product with the explicit inverse of the 16 x 16 diagonal factor
-//             (computed once per step by wave 0 next to the factorisation) instead of a 16-step substitution per column;
-//             the tile is fetched straight into the B-operand layout (row = 4q + lane/16, column = lane%16), the product
-//             leaves the MFMA as P[t = lane/16 + 4r][j = lane%16]: LDS panel rows are written conflict-free.
-//   update    A22 -= P'P on the upper triangle of 16 x 16 tiles.  Tiles are handed out in groups of CH2_G through an LDS
-//             counter (wave 0 joins after its look-ahead), the loads of the NEXT group are issued before the MFMAs of the
-//             current one (two register buffers), the panel operands come from LDS with ds_read (the first generation
-//             addressed LDS-or-global through one flat pointer: every operand fetch then waited for all global loads).
-//   look-ahead wave 0 updates the next diagonal tile first, factors it in registers (chol_diag_tile), inverts the factor.
-// GP = true: the 16 x Np panel does not fit the LDS (N > CH2_MAX_LDS_N) and lives in a global scratch block.
+//   panel      R[kb.., j] = inv(Rkk') A[kb.., j] as an MFMA product with the explicit inverse of the 16 x 16 diagonal factor
+//              (computed once per step by wave 0 next to the factorisation) instead of a 16-step substitution per column;
+//              the tile is fetched straight into the B-operand layout (row = 4q + lane/16, column = lane%16), the product
+//              leaves the MFMA as P[t = lane/16 + 4r][j = lane%16] and goes to the LDS panel as one 32-byte vector per lane.
+//   update     A22 -= P'P on the upper triangle of 16 x 16 tiles, groups of CH2_G tiles per wave dealt statically (scalar tile
+//              walk): CH2_G x 4 loads, one 32-byte LDS read per operand set, the accumulation chains back to back, stores
+//              through SGPR-base + 32-bit-offset addressing.  This phase is bound by what ONE compute unit can stream through
+//              the L2 (measured with tools/chol_bench.hip 9: ~65 GB/s for load + store of such tiles), so
+//   two panels (TWO, N <= 592: both fit the LDS) the trailing matrix is read and written once per TWO steps: an even step
+//              updates only the next row block, the following odd step applies both panels (rank 32) to everything else.
+//   look-ahead wave 0 updates the next diagonal tile first, factors it in the accumulator layout (chol_diag_tile3: four
+//              pivots at a time, the rank-4 updates inside the tile as one MFMA each) and inverts the factor, while the other
+//              waves update; where that chain is the critical path wave 4 (same SIMD) stays idle.
+// GP = true: the 16 x Np panel does not fit the LDS (N > 1200) and lives in a global scratch block.
+// Measured (tools/chol_bench.hip, MI355X): N = 400: 0.28 ms for one matrix, 0.35 ms for 256 (first generation: 0.52 / 0.66).
 #pragma once
 
 #ifndef CH2_THREADS
