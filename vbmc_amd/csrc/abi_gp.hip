@@ -199,8 +199,12 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   HIP_TRY(ctx, dal.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
   hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, st, N, dA.as<double>(), dones.as<unsigned char>(), dfinv.as<double>());
-  hipLaunchKernelGGL(k_alpha_solve, dim3(S), dim3(ASOLVE_THREADS), (size_t)((TRSM_NBLK(N) << 4) + 16) * sizeof(double), st, N, dA.as<double>(),
-                     dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
+  if (N <= ASOLVE1_THREADS)
+    hipLaunchKernelGGL(k_alpha_solve1, dim3(S), dim3(ASOLVE1_THREADS), 0, st, N, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(),
+                       dr.as<double>(), dal.as<double>());
+  else
+    hipLaunchKernelGGL(k_alpha_solve, dim3(S), dim3(ASOLVE_THREADS), (size_t)((TRSM_NBLK(N) << 4) + 16) * sizeof(double), st, N, dA.as<double>(),
+                       dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
   hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, st, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;

@@ -248,6 +248,115 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
   for (int i = tid; i < N; i += ASOLVE_THREADS) Xo[(size_t)s * N + i] = v[i];
 }
 
+// The same solve for N <= ASOLVE1_THREADS, right-looking: thread e owns element e of the vector in a register.  Per 16-row block step the
+// 16 owner lanes (one wave) exchange their entries through LDS and apply the inverse of the diagonal block -- no workgroup
+// barrier inside that --, publish x_b, and after ONE barrier every thread behind (forward) / ahead of (backward) the block
+// subtracts its 16-term product with x_b.  The 16 matrix entries a thread needs for the NEXT step (and the owner lanes' row
+// of the block inverse) are fetched before the barrier: no L2 round trip on the critical path, no 64-lane reduction.
+// (k_alpha_solve above stays as the path for larger N; 512 threads: the 32 prefetched values need the 256-VGPR budget.)
+#define ASOLVE1_THREADS 512
+__global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                                 const unsigned char* __restrict__ on, const double* __restrict__ Zin,
+                                                                 double* __restrict__ Xo) {
+  __shared__ double xb[2][16], tb[16];
+  const int s = blockIdx.x;
+  if (!on[s]) return;
+  const int e = threadIdx.x, lane = e & 63, k = e & 15, myblk = e >> 4;
+  const int nblk = (N + 15) >> 4;
+  const double* R = Lall + (size_t)s * N * N;
+  const double* Fi = Finv + (size_t)s * nblk * 256;
+  double z = e < N ? Zin[(size_t)s * N + e] : 0.0;
+  double pre[16], fi[16];
+  // ---- forward: R' v = z.  Step b needs R[b0 + r][e] (column e, 16 contiguous rows) for e >= b0 + 16.
+  auto fetch_fwd = [&](int b) {
+    const int b0 = b << 4;
+    const bool mine = e >= b0 + 16 && e < N && b < nblk;
+    // 16 contiguous rows of column e: 16-byte loads (a lane per column means every load instruction touches 64 cache lines;
+    // half as many instructions as with 8-byte loads).  The last block of a ragged N goes element by element.
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    if (b0 + 16 <= N) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        d2u v2 = {0.0, 0.0};
+        if (mine) v2 = *reinterpret_cast<const d2u*>(R + (size_t)e * N + b0 + r);
+        pre[r] = v2[0]; pre[r + 1] = v2[1];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pre[r] = (mine && b0 + r < N) ? R[(size_t)e * N + b0 + r] : 0.0;
+    }
+    if (myblk == b + 1 && b + 1 < nblk) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) fi[c] = Fi[(size_t)(b + 1) * 256 + k * 16 + c];      // row k of (R_bb')^{-1}
+    }
+  };
+  if (myblk == 0) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) fi[c] = Fi[k * 16 + c];
+  }
+  fetch_fwd(0);
+  for (int b = 0; b < nblk; ++b) {
+    if (myblk == b) {                     // 16 lanes of one wave
+      tb[k] = z;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};          // four short chains instead of one of 16 dependent FMAs
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a4[c & 3] = fma(fi[c], tb[c], a4[c & 3]);
+      const double a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      z = e < N ? a : 0.0;
+      xb[b & 1][k] = z;
+    }
+    // LDS-only barrier: __syncthreads() would also wait for the global loads just issued for the next step (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    double p4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p4[r & 3] = fma(pre[r], xb[b & 1][r], p4[r & 3]);   // zero for the threads at or before the block
+    z -= (p4[0] + p4[1]) + (p4[2] + p4[3]);
+    fetch_fwd(b + 1);
+  }
+  __syncthreads();
+  // ---- backward: R x = v.  Step b needs R[e][b0 + c] (row e, 16 columns) for e < b0.
+  auto fetch_bwd = [&](int b) {
+    const int b0 = b << 4;
+    const bool mine = b >= 0 && e < b0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pre[c] = (mine && b0 + c < N) ? R[(size_t)(b0 + c) * N + e] : 0.0;
+    if (b >= 1 && myblk == b - 1) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) fi[c] = Fi[(size_t)(b - 1) * 256 + c * 16 + k];      // row k of R_bb^{-1} = column k of (R_bb')^{-1}
+    }
+  };
+  if (myblk == nblk - 1) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) fi[c] = Fi[(size_t)(nblk - 1) * 256 + c * 16 + k];
+  }
+  fetch_bwd(nblk - 1);
+  for (int b = nblk - 1; b >= 0; --b) {
+    if (myblk == b) {
+      tb[k] = z;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};          // four short chains instead of one of 16 dependent FMAs
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a4[c & 3] = fma(fi[c], tb[c], a4[c & 3]);
+      const double a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      z = e < N ? a : 0.0;
+      xb[b & 1][k] = z;
+    }
+    // LDS-only barrier: __syncthreads() would also wait for the global loads just issued for the next step (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    double p4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 16; ++c) p4[c & 3] = fma(pre[c], xb[b & 1][c], p4[c & 3]);
+    z -= (p4[0] + p4[1]) + (p4[2] + p4[3]);
+    fetch_bwd(b - 1);
+  }
+  if (e < N) Xo[(size_t)s * N + e] = z;
+}
+
 // [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1, 1) (gplite_post.m:189) from the solves the append needs anyway:
 //   mstar = m(xstar) + Ks' alpha                                                         (gplite_pred.m:83)
 //   vstar = max(fs2, 0) + sn2_eff,  fs2 = kss - |v|^2/sn2_eff (factor) or kss + Ks' x (stored inverse)   (:99-104,120-121)
