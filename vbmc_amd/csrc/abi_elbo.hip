@@ -184,10 +184,12 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
   // device blocks of a surrogate come from the context's pool (hipMalloc / hipFree cost ~0.1 ms each and serialise the
   // device: an append or a re-upload per acquired point would pay for a dozen of them)
   gp->pooled = true;
+  // uploads are queued on the context's stream and awaited once at the end (every source outlives this function's last
+  // synchronisation): a blocking hipMemcpy per array cost ~50 us each, seven of them per surrogate
   auto up = [&](double** dst, const double* src, size_t n) -> hipError_t {
     hipError_t e = pool_get(ctx, n * sizeof(double), (void**)dst);
     if (e != hipSuccess) return e;
-    return hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice);
+    return hipMemcpyAsync(*dst, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   };
   hipError_t e = up(&gp->X, X, (size_t)N * D);
   if (e == hipSuccess) e = up(&gp->alpha, alpha, (size_t)N * S);
@@ -198,17 +200,20 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
     gp->hasL = true;
   } else if (e == hipSuccess && dL_chol) {
     e = pool_get(ctx, (size_t)N * N * S * sizeof(double), (void**)&gp->L);
-    for (int s = 0; s < S && e == hipSuccess; ++s) {
-      const size_t off = (size_t)s * N * N;
-      if (gp->Lchol[s] || !dL_inv) e = hipMemcpyAsync(gp->L + off, dL_chol + off, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
-      else hipLaunchKernelGGL(k_negate_copy, dim3((unsigned)(((size_t)N * N + 255) / 256)), dim3(256), 0, ctx->stream, (size_t)N * N, dL_inv + off, gp->L + off);
+    if (e == hipSuccess && !dL_inv) {       // every sample on the Cholesky branch: one contiguous copy
+      e = hipMemcpyAsync(gp->L, dL_chol, (size_t)S * N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+    } else {
+      for (int s = 0; s < S && e == hipSuccess; ++s) {
+        const size_t off = (size_t)s * N * N;
+        if (gp->Lchol[s]) e = hipMemcpyAsync(gp->L + off, dL_chol + off, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+        else hipLaunchKernelGGL(k_negate_copy, dim3((unsigned)(((size_t)N * N + 255) / 256)), dim3(256), 0, ctx->stream, (size_t)N * N, dL_inv + off, gp->L + off);
+      }
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     gp->hasL = true;
   }
   if (e == hipSuccess) e = up(&gp->d_sn2, gp->sn2_eff.data(), (size_t)S);
+  std::vector<double> mx(D);          // function scope: its copy is queued, not awaited, below
   if (e == hipSuccess) {
-    std::vector<double> mx(D);
     for (int d = 0; d < D; ++d) {
       double acc = 0.0;
       for (int n = 0; n < N; ++n) acc += X[n + (size_t)N * d];
@@ -218,15 +223,14 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
   }
   if (e == hipSuccess) {
     e = pool_get(ctx, (size_t)S, (void**)&gp->d_lchol);
-    if (e == hipSuccess) e = hipMemcpy(gp->d_lchol, gp->Lchol.data(), (size_t)S, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpyAsync(gp->d_lchol, gp->Lchol.data(), (size_t)S, hipMemcpyHostToDevice, ctx->stream);
   }
   if (e == hipSuccess && gp->hasL) {
     e = pool_get(ctx, (size_t)S * TRSM_NBLK(N) * 256 * sizeof(double), (void**)&gp->d_finv);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, ctx->stream, N, gp->L, gp->d_lchol, gp->d_finv);
-      e = hipStreamSynchronize(ctx->stream);
-    }
+    if (e == hipSuccess) hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, ctx->stream, N, gp->L, gp->d_lchol, gp->d_finv);
   }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the one wait for everything queued above
+  else (void)hipStreamSynchronize(ctx->stream);                   // sources of queued copies die with this frame
   if (e != hipSuccess) {
     vbmc_gp_free(ctx, gp);
     return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_upload: %s", hipGetErrorString(e));
