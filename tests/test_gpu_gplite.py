@@ -145,6 +145,21 @@ def test_posterior_factors_kept_on_device(va):
         assert relerr(a["alpha"], c["alpha"]) < 1e-7 and relerr(a["L"], c["L"]) < 1e-8
 
 
+@pytest.mark.parametrize("seed,D,N", [(0, 1, 19), (0, 1, 40), (5, 2, 70), (0, 1, 150)])
+def test_posterior_on_ill_conditioned_kernel_matrices(va, seed, D, N):
+    """Kernel matrices of condition 1e7 .. 2e7 (noise-free, one or two dimensions).  The first of them is the example the
+    random-shape sweep found at 15x depth when the Cholesky panel became a product with the explicit inverse of the diagonal
+    block: alpha was off by 2e-8.  With one step of iterative refinement in the panel the factorisation is as accurate as the
+    substitution it replaced."""
+    p = synth_problem(seed, D, N, 2, 2, meanfun=0, noisy=False)
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=0, noisefun=p["noisefun"], s2=p["s2"])
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 0, p["noisefun"], p["s2"])
+    for a, b in zip(gp["post"], ref["post"]):
+        assert a["Lchol"] == b["Lchol"] and a["sn2_mult"] == b["sn2_mult"]
+        assert relerr(a["alpha"], b["alpha"]) < 1e-8
+        assert relerr(a["L"], b["L"]) < 1e-10
+
+
 def test_rank1_update_equals_full_posterior(va):
     """gplite/gplite_test.m:87-105 property: appending a point by the rank-1 path == full recompute."""
     p = synth_problem(24, 4, 45, 3, 3)

@@ -41,6 +41,7 @@ and assembled by `tools/compose_chol_profile.py`.
 | `chol_bench 9`: one CU streams such tiles at 75 GB/s (loads) / 65 GB/s (load + store) | | the update of the first steps IS at that bound; software pipelining, more waves, register double buffering: no change (all measured) |
 | diagonal tile factored in the accumulator layout, 4 pivots + one rank-4 MFMA at a time; shorter pivot chain | 0.296 | look-ahead 7.3 -> 5.4 us per step (factor 10 700 -> 6 200 cycles) |
 | two panels per pass over the trailing matrix (half the traffic), wave 4 idle when the look-ahead is critical | **0.283** | update 198 us; 256 matrices at once: 0.66 -> **0.35 ms** (that case was bound by L2/HBM traffic: 3 GB per launch) |
+| one step of iterative refinement in the panel (P += W (A - Rkk' P), 8 more MFMAs per panel tile) | **0.291** | accuracy, not speed: the product with the explicit inverse is accurate to cond(Rkk) eps only -- the 15x random-shape sweep found alpha off by 2e-8 on a kernel matrix of condition 1e7 (tolerance 1e-8; the substitution it replaced is backward stable); with the refinement the 40x sweep and `test_posterior_on_ill_conditioned_kernel_matrices` pass; 256 matrices: 0.38 ms |
 
 `k_alpha_solve1` (alpha = R \\ (R' \\ (y - m)), one right-hand side): 92 -> 55 us at N = 400.  The old kernel spent a 64-lane reduction,
 two barriers and two L2 round trips per block step; the new one keeps the vector element of a thread in a register, fetches the

@@ -6,7 +6,8 @@
 //   panel      R[kb.., j] = inv(Rkk') A[kb.., j] as an MFMA product with the explicit inverse of the 16 x 16 diagonal factor
 //              (computed once per step by wave 0 next to the factorisation) instead of a 16-step substitution per column;
 //              the tile is fetched straight into the B-operand layout (row = 4q + lane/16, column = lane%16), the product
-//              leaves the MFMA as P[t = lane/16 + 4r][j = lane%16] and goes to the LDS panel as one 32-byte vector per lane.
+//              leaves the MFMA as P[t = lane/16 + 4r][j = lane%16] and goes to the LDS panel as one 32-byte vector per lane;
+//              one step of iterative refinement (P += W (A - Rkk' P)) restores the accuracy of a substitution.
 //   update     A22 -= P'P on the upper triangle of 16 x 16 tiles, groups of CH2_G tiles per wave dealt statically (scalar tile
 //              walk): CH2_G x 4 loads, one 32-byte LDS read per operand set, the accumulation chains back to back, stores
 //              through SGPR-base + 32-bit-offset addressing.  This phase is bound by what ONE compute unit can stream through
@@ -17,7 +18,7 @@
 //              pivots at a time, the rank-4 updates inside the tile as one MFMA each) and inverts the factor, while the other
 //              waves update; where that chain is the critical path wave 4 (same SIMD) stays idle.
 // GP = true: the 16 x Np panel does not fit the LDS (N > 1200) and lives in a global scratch block.
-// Measured (tools/chol_bench.hip, MI355X): N = 400: 0.28 ms for one matrix, 0.35 ms for 256 (first generation: 0.52 / 0.66).
+// Measured (tools/chol_bench.hip, MI355X): N = 400: 0.29 ms for one matrix, 0.38 ms for 256 (first generation: 0.52 / 0.66).
 #pragma once
 
 #ifndef CH2_THREADS
@@ -226,9 +227,13 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     if (tid == 0) CHOL_STAMP(0, kb >> 4);
     // ---- panel: tile tj of the row block (16 x 16, rows kb.., columns t0 + 16 tj..) times inv(Rkk')
     {
-      double av[4];
+      double av[4], rv[4];
+      const double* Dgc = DgB + cur * 16 * 17;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) av[q] = Ri[(4 * q + lg) * 17 + li];      // A operand: inv(Rkk')[t = li][u = 4q + lg]
+      for (int q = 0; q < 4; ++q) {
+        av[q] = Ri[(4 * q + lg) * 17 + li];                                // A operand: inv(Rkk')[t = li][u = 4q + lg]
+        rv[q] = (4 * q + lg <= li) ? Dgc[(4 * q + lg) * 17 + li] : 0.0;    // A operand: Rkk'[t = li][u = 4q + lg] (lower triangular)
+      }
       constexpr int PT = CH2_W >= 16 ? 2 : 3;                              // tiles in flight per wave
       for (int tb = wave; tb < nt; tb += PT * CH2_W) {
         double bv[PT][4];
@@ -250,6 +255,17 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[p][q], acc, 0, 0, 0);
+            // One step of iterative refinement: the product with the explicit inverse is only accurate to cond(Rkk) eps (2e-8 in
+            // alpha on a kernel matrix of condition 1e7, found by the random-shape sweep), the substitution it replaces was
+            // backward stable.  res = A - Rkk' P (register q of the accumulator layout IS k-slice q of a B operand), P += W res.
+            d4_t res = {bv[p][0], bv[p][1], bv[p][2], bv[p][3]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(-rv[q], acc[q], res, 0, 0, 0);
+            {
+              const d4_t rr = res;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], rr[q], acc, 0, 0, 0);
+            }
             stP4(pbuf, lg, j, acc);                                        // acc[r] = R[kb + lg + 4r][t0 + j]; zero for rows >= nb, j >= ntr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
