@@ -190,7 +190,7 @@ int main(int argc, char** argv) {
       int gn = 0;
       CHECK(hipMemcpyFromSymbol(gs.data(), HIP_SYMBOL(g_chol_gs), gs.size() * 8));
       CHECK(hipMemcpyFromSymbol(&gn, HIP_SYMBOL(g_chol_gn), sizeof(int)));
-      printf("wave 1, step 0, per group (shader cycles): address+issue loads | issue LDS reads+wait | MFMAs | sub+stores | to next group\n");
+      printf("wave 1, first full update, per group (shader cycles): address+issue loads | issue LDS reads+wait | MFMAs | sub+stores | to next group\n");
       for (int g = 0; g < gn && g < 64; ++g)
         printf("  g%02d: %6lld %6lld %6lld %6lld %6lld\n", g, gs[8 * g + 1] - gs[8 * g], gs[8 * g + 2] - gs[8 * g + 1], gs[8 * g + 3] - gs[8 * g + 2],
                gs[8 * g + 4] - gs[8 * g + 3], g + 1 < gn ? gs[8 * (g + 1)] - gs[8 * g + 4] : 0);

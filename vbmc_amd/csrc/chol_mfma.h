@@ -138,10 +138,10 @@ __device__ __forceinline__ void chol_tile_inverse(const double* __restrict__ Dg,
   __builtin_amdgcn_wave_barrier();
 }
 
-#ifdef CHOL_TS   // harness only: shader-clock stamps inside the groups of wave 1 during step 0 (slot x group)
+#ifdef CHOL_TS   // harness only: shader-clock stamps inside the groups of wave 1 during the first full update (slot x group)
 __device__ long long g_chol_gs[8 * 64];
 __device__ int g_chol_gn;
-#define CH2_GSTAMP(slot) do { if (blockIdx.x == 0 && wave == 1 && kb == 0 && gcount < 64) { __builtin_amdgcn_sched_barrier(0); \
+#define CH2_GSTAMP(slot) do { if (blockIdx.x == 0 && wave == 1 && kb == (TWO ? 16 : 0) && gcount < 64) { __builtin_amdgcn_sched_barrier(0); \
     if ((slot) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     if ((slot) == 3) asm volatile("s_nop 7\n s_nop 7\n s_nop 7" ::: "memory"); \
     g_chol_gs[8 * gcount + (slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); if ((slot) == 4) { ++gcount; g_chol_gn = gcount; } } } while (0)
