@@ -59,6 +59,12 @@ def build(force=False, verbose=True):
     mb = os.path.join(LIBDIR, "microbench")
     if os.path.exists(mb_src) and (force or _newer(mb, [mb_src, os.path.join(CSRC, "device_math.h")])):
         _run([hipcc] + FLAGS[:3] + ["-Wno-unused-value", mb_src, "-o", mb], verbose)
+    # stand-alone harness of the Cholesky kernel (profiles/r02_chol.md): built with the phase stamps compiled in
+    cb_src = os.path.join(ROOT, "tools", "chol_bench.hip")
+    cb = os.path.join(LIBDIR, "chol_bench")
+    cb_deps = [cb_src] + [os.path.join(CSRC, d) for d in ("chol_mfma.h", "gp_kernels.h", "var_kernels.h", "trsm_mfma.h", "common.h", "device_math.h")]
+    if os.path.exists(cb_src) and (force or _newer(cb, cb_deps)):
+        _run([hipcc] + FLAGS[:3] + ["-Wno-unused-value", "-DCHOL_TS", "-I" + os.path.join(ROOT, "include"), cb_src, "-o", cb], verbose)
     return lib
 
 
