@@ -51,3 +51,57 @@ def test_pivot_times_reciprocal_root_reproduces_the_root():
         p = float(np.exp(rng.uniform(np.log(1e-8), np.log(1e8))))
         rs, ri = chol_sqrt_rsqrt(p, 2.0 ** -21)
         assert abs(p * ri - rs) <= 4 * math.ulp(rs)
+
+
+def _blocked_chol_model(A, refine, two_panel):
+    """NumPy model of k_chol2's algorithm (16-row block steps, panel = inv(Rkk') A12 as a PRODUCT with the explicit inverse,
+    optionally one step of iterative refinement, trailing updates deferred over two panels when two_panel) -- the arithmetic
+    order differs from the kernel's, the error mechanism is the same."""
+    A = np.array(A, dtype=np.float64)
+    N = A.shape[0]
+    R = np.zeros_like(A)
+    pend = []                                   # panels not yet applied to the trailing matrix beyond the next row block
+    for k0 in range(0, N, 16):
+        k1 = min(k0 + 16, N)
+        Rkk = np.linalg.cholesky(A[k0:k1, k0:k1]).T
+        R[k0:k1, k0:k1] = Rkk
+        if k1 == N:
+            break
+        W = np.linalg.inv(Rkk.T)                # explicit inverse of the diagonal factor
+        P = W @ A[k0:k1, k1:]
+        if refine:
+            P = P + W @ (A[k0:k1, k1:] - Rkk.T @ P)
+        R[k0:k1, k1:] = P
+        pend.append((k1, P))
+        n1 = min(k1 + 16, N)
+        # the next row block (and its diagonal tile) always sees every pending panel before it is factored
+        for (c0, Pp) in pend:
+            off = k1 - c0
+            A[k1:n1, k1:] -= Pp[:, off:off + (n1 - k1)].T @ Pp[:, off:]
+        if not two_panel or len(pend) == 2 or n1 == N:
+            for (c0, Pp) in pend:
+                off = n1 - c0
+                A[n1:, n1:] -= Pp[:, off:].T @ Pp[:, off:]
+            pend = []
+        else:
+            pass                                # A step: the rest of the trailing matrix waits for the second panel
+    return R
+
+
+def test_blocked_cholesky_model_needs_the_refinement_step():
+    """A kernel matrix of condition ~1e9: the factor from the explicit-inverse panel misses R'R = A by orders of magnitude more
+    than a backward-stable factorisation does; one refinement step closes the gap.  (The GPU regression test is
+    tests/test_gpu_gplite.py::test_posterior_on_ill_conditioned_kernel_matrices.)"""
+    rng = np.random.default_rng(11)
+    x = np.sort(rng.uniform(-3, 3, 90))
+    K = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 0.9 ** 2) + 1e-9 * np.eye(90)
+    ref = np.linalg.cholesky(K).T
+    back = lambda R: np.max(np.abs(R.T @ R - K)) / np.max(np.abs(K))   # noqa: E731  backward error of the factorisation
+    e_ref = back(ref)
+    for two in (False, True):
+        e_plain = back(_blocked_chol_model(K, False, two))
+        e_fix = back(_blocked_chol_model(K, True, two))
+        assert e_fix < 20 * max(e_ref, 1e-16), (two, e_fix, e_ref)
+        assert e_plain > 20 * e_fix, (two, e_plain, e_fix)
+    # and the two-panel order is the same factorisation up to rounding
+    assert np.max(np.abs(_blocked_chol_model(K, True, True) - _blocked_chol_model(K, True, False))) < 1e-6 * np.max(np.abs(ref))
