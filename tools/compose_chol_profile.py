@@ -22,12 +22,8 @@ txt = f"""# Round 2: the Cholesky kernel, second generation (`k_chol2`, `vbmc_am
 chain of `gplite_train` is a SEQUENCE of such evaluations) and 65 % of the device time of `gplite_post`.  Everything below is from
 `tools/chol_bench.hip` (stand-alone harness: random SPD matrix, result against a host long-double Cholesky, MATLAB's failure index on
 an indefinite copy, HIP-event times, and with `-DCHOL_TS` the phase stamps inside the kernel) on the MI355X box; collected with
-
-    for n in 16 37 100 250 400 592 593 800 1200 1300 2000; do vbmc_amd/lib/chol_bench 1 $n 20 10 0; done
-    vbmc_amd/lib/chol_bench 1 400 256 20 0; vbmc_amd/lib/chol_bench 1 400 1 20 1; vbmc_amd/lib/chol_bench 9 400 1
-    python tools/bench_aux.py; python tools/gp_post_probe.py; NEED_L=1 python tools/gp_post_probe.py
-    rocprofv3 --kernel-trace --stats -- python tools/prof_nlz.py        (summarised by tools/rocpd_summary.py)
-
+`bash tools/profile_chol.sh` (chol_bench over sizes, its phase stamps and tile-stream mode, `tools/bench_aux.py`, `tools/gp_post_probe.py`,
+`rocprofv3 --kernel-trace --stats -- python tools/prof_nlz.py` summarised by `tools/rocpd_summary.py`)
 and assembled by `tools/compose_chol_profile.py`.
 
 ## What changed, with the measurement that motivated each step (N = 400, one matrix)
