@@ -160,6 +160,22 @@ def test_posterior_on_ill_conditioned_kernel_matrices(va, seed, D, N):
         assert relerr(a["L"], b["L"]) < 1e-10
 
 
+@pytest.mark.parametrize("N", [497, 512, 513, 592, 593])
+def test_posterior_at_the_kernel_switch_points(va, N):
+    """N = 512 | 513: the single right-hand-side solve changes kernels (k_alpha_solve1 keeps one vector element per thread of a
+    512-thread workgroup); N = 592 | 593: the Cholesky kernel drops from two panels in LDS to one; 497: a ragged last block."""
+    p = synth_problem(40 + N, 3, N, 2, 2, meanfun=4, noisy=True)      # condition ~1e3: the tolerances test the kernels, not the problem
+    ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4, noisefun=p["noisefun"], s2=p["s2"])
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 4, p["noisefun"], p["s2"])
+    for a, b in zip(gp["post"], ref["post"]):
+        assert a["Lchol"] == b["Lchol"] and a["sn2_mult"] == b["sn2_mult"]
+        assert relerr(a["alpha"], b["alpha"]) < 1e-9 and relerr(a["L"], b["L"]) < 1e-11
+    Xq = p["X"][:6] + 0.05
+    o = va.gplite_pred(gp, Xq, None, None, True)
+    r = R.gplite_pred(ref, Xq, ssflag=True)
+    assert relerr(o[2], r[2]) < 1e-7 and np.max(np.abs(o[3] - r[3])) < 1e-6 * max(1.0, np.max(np.abs(r[3])))
+
+
 def test_rank1_update_equals_full_posterior(va):
     """gplite/gplite_test.m:87-105 property: appending a point by the rank-1 path == full recompute."""
     p = synth_problem(24, 4, 45, 3, 3)
