@@ -44,3 +44,35 @@ def test_shims_use_only_commands_the_gateway_implements():
         if fn.endswith(".m"):
             used |= set(re.findall(r"vbmc_hip_mex\('([a-z_0-9]+)'", open(os.path.join(ROOT, "matlab", fn)).read()))
     assert used and used <= cmds, used - cmds
+
+
+def test_gateway_links_and_runs_against_the_functional_mock():
+    """The gateway + tests/mock_mex/mock_mx.cpp + libvbmc_hip.so link into one object and mexFunction EXECUTES (tests/_mex.py):
+    without a GPU every command stops at the context ('vbmc_hip:nodevice', raised through the mock's mexErrMsgIdAndTxt), usage
+    errors are reported before that, and nothing a failed call created stays alive.  The command-by-command comparison with
+    the ctypes path is tests/test_gpu_mex.py."""
+    import numpy as np
+    import pytest
+
+    from tests import _mex
+
+    m = _mex.mex()
+    with pytest.raises(_mex.MexError) as e:
+        m.call(0, 5.0)
+    assert e.value.identifier == "vbmc_hip:usage"
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(_mex.MexError) as e:
+            m.call(1, "sq_dist", np.zeros((2, 3)))
+        assert e.value.identifier == "vbmc_hip:nodevice"
+    assert m.live_arrays() == 0
+    # the mock's own value mapping: what MATLAB would hand the gateway, read back unchanged
+    a = np.arange(24, dtype=np.float64).reshape(2, 3, 4)
+    h = m.to_mx(a)
+    assert np.array_equal(m.from_mx(h), a)
+    m.lib.mxDestroyArray(h)
+    h = m.to_mx([{"x": 1.0, "s": "ab"}, {"x": np.ones((2, 2)), "s": None}])
+    assert m.live_arrays() == 5
+    m.lib.mxDestroyArray(h)
+    assert m.live_arrays() == 0
