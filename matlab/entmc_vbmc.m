@@ -5,7 +5,8 @@ function [H,dH] = entmc_vbmc(vp,Ns,grad_flags,jacobian_flag)
 % entropy term alone (vbmc_elbo_batch with a NULL surrogate, include/vbmc_hip.h) and returns the gradient for
 % the flagged groups in the order [mu(:); log sigma; log lambda; eta] with the Jacobians applied
 % (:110-125).  JACOBIAN_FLAG = 0 with gradients goes to the reference further down the path.
-% VBMC_HIP_PARITY=1: the K blocks randn(D,1,Ns/2) are drawn here in the reference's order (:53).
+% VBMC_HIP_PARITY=1: the K blocks randn(D,1,Ns/2) are drawn here in the reference's order (:53), and nothing else is drawn.
+% K > 256 (the library's limit) goes to the reference before any draw.
 if nargin < 2 || isempty(Ns); Ns = 10; end
 if nargout < 2; grad_flags = false; elseif nargin < 3 || isempty(grad_flags); grad_flags = true; end
 if isscalar(grad_flags); grad_flags = ones(1,4)*grad_flags; end
@@ -16,22 +17,30 @@ if g && ~jacobian_flag
     [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag);
     return;
 end
+if vp.K > 256 || vp.D > 32
+    ref = vbmc_hip_reference('entmc_vbmc');
+    if nargout > 1; [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag); else; H = ref(vp,Ns,grad_flags,jacobian_flag); end
+    return;
+end
 vpt = vp;
 if g
     vpt.optimize_mu = logical(grad_flags(1)); vpt.optimize_sigma = logical(grad_flags(2));
     vpt.optimize_lambda = logical(grad_flags(3)); vpt.optimize_weights = logical(grad_flags(4));
 end
 [theta,vpt] = get_vptheta(vpt);                % misc/get_vptheta.m: the rescaled vp, so that theta and the fixed groups agree
-epsblk = [];
-if strcmp(getenv('VBMC_HIP_PARITY'),'1')
+% random numbers: exactly the reference's K blocks (:53) in parity mode and nothing else; one randi for the device stream otherwise
+epsblk = []; seed = 0;
+if vbmc_hip_state('parity')
     Nse = ceil(Ns/2)*2;
     epsblk = zeros(vp.D,Nse/2,vp.K);
     for j = 1:vp.K; epsblk(:,:,j) = reshape(randn(vp.D,1,Nse/2),[vp.D,Nse/2]); end
+else
+    seed = randi(2^31-1);
 end
 try
-    [~,~,~,H,~,dH] = vbmc_hip_mex('elbo',uint64(0),theta(:),vpt,Ns,double(g),0,0,0,[],epsblk,randi(2^31-1),1);
+    [~,~,~,H,~,dH] = vbmc_hip_mex('elbo',uint64(0),theta(:),vpt,Ns,double(g),0,0,0,[],epsblk,seed,1);
 catch err
-    if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+    if ~strcmp(err.identifier,'vbmc_hip:unsupported') || ~isempty(epsblk); rethrow(err); end    % after parity draws: no second pass
     ref = vbmc_hip_reference('entmc_vbmc');
     if nargout > 1; [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag); else; H = ref(vp,Ns,grad_flags,jacobian_flag); end
     return;

@@ -6,9 +6,11 @@ function [F,dF,G,H,varF,dH,varGss,varG,varH,I_sk,J_sjk] = negelcbo_vbmc(theta,be
 % outside the accelerated path (unsupported mean function, weights-only optimisation, K > 256,
 % ...) falls through to the reference implementation found further down the path.
 %
-% MC draws: with VBMC_HIP_PARITY=1 in the environment the K blocks randn(D,1,Ns/2) are drawn here, in
-% the reference's order (ent/entmc_vbmc.m:53), so MATLAB's global stream advances identically and the
-% result matches the reference to fp64 round-off; otherwise a device Philox stream is used.
+% Random numbers.  The reference draws K blocks randn(D,1,Ns/2) per call when Ns > 0 (ent/entmc_vbmc.m:53) and nothing
+% when Ns == 0 (entlb_vbmc, misc/negelcbo_vbmc.m:104-110).  VBMC_HIP_PARITY=1: exactly those blocks are drawn here, in
+% that order, and handed to the device (eps_mode 1) -- no other draw, so MATLAB's global stream advances as in the
+% reference and the result matches it to fp64 round-off.  Otherwise (device Philox stream, eps_mode 0) ONE randi seeds the
+% device stream of a call with Ns > 0; a call with Ns == 0 draws nothing in either mode.
 if nargin < 5 || isempty(Ns); Ns = 0; end
 if nargin < 6 || isempty(compute_grad); compute_grad = nargout > 1; end
 if nargin < 7; compute_var = []; end
@@ -19,23 +21,41 @@ if isempty(beta) || ~isfinite(beta); beta = 0; end
 if isempty(compute_var); compute_var = beta ~= 0 || nargout > 4; end
 separate_K = nargout > 9;
 
+if vbmc_hip_state('recording')      % matlab/vpsieve_vbmc.m: note the candidate, evaluate the whole batch later
+    vbmc_hip_state('record_push',struct('theta',theta(:),'vp',vp,'Ns',Ns,'compute_var',compute_var,'thetabnd',thetabnd));
+    F = 0; dF = []; G = 0; H = 0; varF = 0; dH = []; varGss = 0; varG = 0; varH = 0; I_sk = []; J_sjk = [];
+    return;
+end
+
 onlyweights = vp.optimize_weights && ~vp.optimize_mu && ~vp.optimize_sigma && ~vp.optimize_lambda;
+epsblk = []; seed = 0;
+drawn = false;                                  % has this call consumed random numbers already?
 try
     if onlyweights; error('vbmc_hip:unsupported','weights-only branch stays on the host'); end
-    h = vbmc_hip_gp_handle(gp);                 % cached upload, keyed on the gp struct (see INTEGRATION.md)
-    epsblk = [];
-    if Ns > 0 && strcmp(getenv('VBMC_HIP_PARITY'),'1')
-        Nse = ceil(Ns/2)*2;
-        epsblk = zeros(vp.D,Nse/2,vp.K);
-        for j = 1:vp.K; epsblk(:,:,j) = reshape(randn(vp.D,1,Nse/2),[vp.D,Nse/2]); end
+    if ~vbmc_hip_supported(gp,vp,compute_var)   % decided from shapes and model ids, BEFORE any random number is drawn
+        error('vbmc_hip:unsupported','outside the accelerated path');
     end
-    seed = randi(2^31-1);
+    h = vbmc_hip_gp_handle(gp);                 % cached upload, keyed on the gp struct (see INTEGRATION.md)
+    if Ns > 0
+        if vbmc_hip_state('parity')
+            Nse = ceil(Ns/2)*2;
+            epsblk = zeros(vp.D,Nse/2,vp.K);
+            for j = 1:vp.K; epsblk(:,:,j) = reshape(randn(vp.D,1,Nse/2),[vp.D,Nse/2]); end
+        else
+            seed = randi(2^31-1);
+        end
+        drawn = true;
+    end
     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo',h,theta(:),vp,Ns,double(compute_grad), ...
         double(compute_var),double(separate_K),beta,thetabnd,epsblk,seed,numel(gp.post));
     varH = 0;
     if compute_var; varF = varG + varH; else; varF = 0; varG = 0; varGss = 0; end
 catch err
     if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+    if drawn && vbmc_hip_state('parity')
+        % the K blocks are consumed already: the reference would draw them again and leave the stream K blocks ahead
+        error('vbmc_hip:parity','negelcbo_vbmc: the device refused a call after its random draws (%s); parity with the reference stream is lost.',err.message);
+    end
     ref = vbmc_hip_reference('negelcbo_vbmc');  % next negelcbo_vbmc on the path (which -all)
     outs = cell(1,max(nargout,1));
     [outs{:}] = ref(theta,beta,vp,gp,Ns,compute_grad,compute_var,false,thetabnd,0);

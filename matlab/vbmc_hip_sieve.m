@@ -1,36 +1,51 @@
-function nelcbo_fill = vbmc_hip_sieve(vp0_vec,gp,NSentKFast,compute_var,elcbo_beta,thetabnd)
-%VBMC_HIP_SIEVE All sieve candidates in ONE batched device pass.
-%
-% Replaces the sequential loop of misc/vpsieve_vbmc.m:74-78
-%     for iOpt = 1:Nopts
-%         [theta0,vp0_vec(iOpt)] = get_vptheta(vp0_vec(iOpt), ...);
-%         [nelbo_tmp,~,~,~,varF_tmp] = negelcbo_vbmc(theta0,0,vp0_vec(iOpt),gp,NSentKFast,0,compute_var,...,thetabnd);
-%         nelcbo_fill(iOpt) = nelbo_tmp + elcbo_beta*sqrt(varF_tmp);
-%     end
-% by   nelcbo_fill = vbmc_hip_sieve(vp0_vec,gp,NSentKFast,compute_var,elcbo_beta,thetabnd);
-% The caller keeps its own [~,vp0_ord] = sort(nelcbo_fill,'ascend') (:82), so the order is index-identical.
-% Candidates must share K and the optimize_* flags (they do: vbinit_vbmc builds them from one vp);
-% non-optimised groups that differ between candidates are evaluated in sub-batches.
-R = numel(vp0_vec);
-nelcbo_fill = zeros(1,R);
-T = numel(get_vptheta(vp0_vec(1)));
+function score = vbmc_hip_sieve(calls,gp,elcbo_beta)
+%VBMC_HIP_SIEVE The recorded sieve candidates in ONE batched device pass.
+%   SCORE = VBMC_HIP_SIEVE(CALLS,GP,ELCBO_BETA): CALLS is the cell array the negelcbo_vbmc shim recorded while the
+%   reference's misc/vpsieve_vbmc.m:74-78 ran (one struct per candidate: theta, vp, Ns, compute_var, thetabnd);
+%   SCORE(i) = nelbo_i + ELCBO_BETA*sqrt(varF_i), what the reference's loop would have stored in nelcbo_fill(i).
+% Candidates share K and the optimize_* flags (vbinit_vbmc builds them from one vp); those whose NON-optimised groups differ
+% go in separate sub-batches (those groups are not part of theta).  A candidate with a non-finite parameter is not sent
+% (the library validates the whole batch): its score is NaN, as the reference's arithmetic would give, and sorts last.
+% If the device refuses a sub-batch (vbmc_hip:unsupported) its members are evaluated one by one through the
+% negelcbo_vbmc shim, which falls through to the reference on its own.
+R = numel(calls);
+score = NaN(1,R);
+c1 = calls{1};
+T = numel(c1.theta);
 Theta = zeros(T,R);
-key = cell(1,R);
+label = cell(1,R);
 for i = 1:R
-    [Theta(:,i),vp0_vec(i)] = get_vptheta(vp0_vec(i));
-    v = vp0_vec(i); fx = [];
-    if ~v.optimize_mu; fx = [fx; v.mu(:)]; end %#ok<AGROW>
-    if ~v.optimize_sigma; fx = [fx; v.sigma(:)]; end %#ok<AGROW>
-    if ~v.optimize_lambda; fx = [fx; v.lambda(:)]; end %#ok<AGROW>
-    if ~v.optimize_weights; fx = [fx; v.w(:)]; end %#ok<AGROW>
-    key{i} = sprintf('%.17g,',fx);
+    Theta(:,i) = calls{i}.theta;
+    label{i} = fixed_label(calls{i}.vp);
 end
+finite = all(isfinite(Theta),1);
+[~,~,grp] = unique(label,'stable');
 h = vbmc_hip_gp_handle(gp);
-[~,~,grp] = unique(key,'stable');
 for g = 1:max(grp)
-    idx = find(grp == g);
-    [F,~,varG] = vbmc_hip_mex('elbo_batch',h,Theta(:,idx),vp0_vec(idx(1)),NSentKFast,0,double(compute_var), ...
-        0,thetabnd,randi(2^31-1));
-    if compute_var; nelcbo_fill(idx) = F + elcbo_beta*sqrt(varG); else; nelcbo_fill(idx) = F; end
+    members = find(grp(:)' == g & finite);
+    if isempty(members); continue; end
+    seed = 0;
+    if c1.Ns > 0; seed = randi(2^31-1); end                           % device stream of this sub-batch
+    try
+        [F,~,varG] = vbmc_hip_mex('elbo_batch',h,Theta(:,members),calls{members(1)}.vp,c1.Ns,0,double(c1.compute_var), ...
+            0,c1.thetabnd,seed);
+        if ~c1.compute_var; varG = zeros(size(F)); end
+        score(members) = F + elcbo_beta*sqrt(varG);
+    catch err
+        if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+        for i = members
+            [f,~,~,~,v] = negelcbo_vbmc(Theta(:,i),0,calls{i}.vp,gp,c1.Ns,0,c1.compute_var,0,c1.thetabnd);
+            score(i) = f + elcbo_beta*sqrt(v);
+        end
+    end
 end
+end
+
+function s = fixed_label(v)
+fx = [];
+if ~v.optimize_mu; fx = [fx; v.mu(:)]; end
+if ~v.optimize_sigma; fx = [fx; v.sigma(:)]; end
+if ~v.optimize_lambda; fx = [fx; v.lambda(:)]; end
+if ~v.optimize_weights; fx = [fx; v.w(:)]; end
+s = sprintf('%.17g,',fx);
 end

@@ -3,183 +3,174 @@ function [vp,varss,pruned] = vpoptimize_vbmc(Nfastopts,Nslowopts,vp,gp,K,optimSt
 % lock-step ENTIRELY on an MI355X (vbmc_hip_mex 'adam') and their 2*Nslowopts full-ELCBO evaluations in one batched pass.
 %
 % Same signature and defaulting as the reference (misc/vpoptimize_vbmc.m:1).  Written from the batched host mirror
-% vbmc_amd/optimize.py:vpoptimize_vbmc: (1) batched sieve (matlab/vpsieve_vbmc.m), (2) the starting points picked by
-% candidate type, (3) all chains through ONE on-device Adam loop (utils/fminadam.m per chain, including the
-% 20-iteration stopping test), (4) one batched evaluation of the full ELCBO (fine MC entropy, full variance,
-% per-component terms) at every chain's best midpoint and endpoint, (5) the best slot by ELCBO, (6) component pruning,
-% one evaluation at a time because each depends on the last.
+% vbmc_amd/optimize.py:vpoptimize_vbmc (tested against a sequential restatement of the reference on the device's own
+% random streams, tests/test_gpu_vpoptimize.py):
+%   (1) batched sieve (matlab/vpsieve_vbmc.m), (2) one starting point per chain by candidate type, (3) all chains through
+%   ONE on-device Adam loop (utils/fminadam.m per chain, including the 20-iteration stopping test), (4) one batched
+%   evaluation of the full ELCBO (fine Monte Carlo entropy, full variance, per-component terms) at every chain's best
+%   midpoint and endpoint, (5) the best of them, (6) component pruning (matlab/vbmc_hip_prune.m), (7) vp.stats.
 %
-% Falls through to the reference further down the path, BEFORE any random number is drawn, for everything outside that
-% path: deterministic entropy (NSentK = 0: fminunc), ELCBOWeight ~= 0 or StochasticOptimizer ~= 'adam' (CMA-ES),
-% unsupported surrogates (vbmc_hip_supported).
-if nargin < 5 || isempty(K); K = vp.K; end
-if nargin < 6; optimState = []; end
-if nargin < 7; options = []; end
-if nargin < 8 || isempty(prnt); prnt = 0; end
-
-fallthrough = isempty(options);
-if ~fallthrough
-    if ~isfield(optimState,'delta'); optimState.delta = 0; end
-    if ~isfield(optimState,'EntropySwitch'); optimState.EntropySwitch = false; end
-    if ~isfield(optimState,'Neff'); optimState.Neff = size(gp.X,1); end
-    vpchk = vp; vpchk.K = K; vpchk.delta = optimState.delta;
-    NSentK = ceil(evaloption_vbmc(options.NSent,K)/K);
-    if optimState.EntropySwitch || K == 1; NSentK = 0; end
-    elcbo_beta = evaloption_vbmc(options.ELCBOWeight,optimState.Neff);
-    fallthrough = NSentK == 0 || elcbo_beta ~= 0 || ~strcmpi(options.StochasticOptimizer,'adam') ...
-        || ~vbmc_hip_supported(gp,vpchk);
-end
-if fallthrough
+% The whole call goes to the reference further down the path, BEFORE any random number is drawn, when
+%   * VBMC_HIP_PARITY=1 -- the reference's own control flow then runs with only the leaf evaluations on the device (the
+%     negelcbo_vbmc shim fed with MATLAB's randn blocks, the reference's host-loop fminadam), so the global random stream
+%     is consumed exactly as in an unmodified run;
+%   * the call is outside this path: deterministic entropy (NSentK = 0: fminunc), ELCBOWeight ~= 0 or StochasticOptimizer
+%     other than 'adam' (CMA-ES), unsupported surrogates (vbmc_hip_supported), no options.
+if nargin < 8; prnt = []; if nargin < 7; options = []; if nargin < 6; optimState = []; if nargin < 5; K = []; end; end; end; end
+if ~inside_path(vp,gp,K,optimState,options)
     ref = vbmc_hip_reference('vpoptimize_vbmc');
     [vp,varss,pruned] = ref(Nfastopts,Nslowopts,vp,gp,K,optimState,options,prnt);
     return;
 end
-if ~isfield(optimState,'Warmup'); optimState.Warmup = ~vp.optimize_weights; end
-if ~isfield(optimState,'temperature'); optimState.temperature = 1; end
+if isempty(K); K = vp.K; end
+warm = ~vp.optimize_weights;
+if isfield(optimState,'Warmup'); warm = optimState.Warmup; end
+temperature = 1;
+if isfield(optimState,'temperature'); temperature = optimState.temperature; end
 
-% (1) batched sieve
-[vp0_vec,vp0_type,elcbo_beta,compute_var,NSentK] = vpsieve_vbmc(Nfastopts,Nslowopts,vp,gp,optimState,options,K);
-[vp,thetabnd] = vpbounds(vp,gp,options,K);
+% (1) the sieve: candidates in ascending order of their quick ELCBO estimate, with their types
+[cand,ctype,elcbo_beta,compute_var,NSentK] = vpsieve_vbmc(Nfastopts,Nslowopts,vp,gp,optimState,options,K);
+[vp,bnd] = vpbounds(vp,gp,options,K);                                 % soft bounds of the optimisation (misc/vpbounds.m)
 
-% (2) starting points by candidate type
-for iOpt = 1:Nslowopts
-    if Nslowopts == 1
-        idx = 1;
-    elseif Nslowopts == 2
-        if iOpt == 1; idx = find(vp0_type == 1,1); else; idx = find(vp0_type == 2 | vp0_type == 3,1); end
-    else
-        idx = find(vp0_type == (mod(iOpt-1,3)+1),1);
-    end
-    starts(iOpt) = rescale_params(vp0_vec(idx)); %#ok<AGROW>
-    vp0_type(idx) = []; vp0_vec(idx) = [];
-    Theta0(:,iOpt) = get_vptheta(starts(iOpt)); %#ok<AGROW>
+% (2) chain c starts from the best candidate not taken yet whose type suits it: any type for a single chain; type 1, then
+% "not type 1" for two chains; types 1,2,3,1,... for more (the selection of :53-61 with a mask instead of deletions)
+taken = false(1,numel(cand));
+ctype = ctype(:)';
+want = mod((1:Nslowopts)-1,3) + 1;
+one = Nslowopts == 1; two = Nslowopts == 2;
+for c = 1:Nslowopts
+    suits = one | (two & c == 1 & ctype == 1) | (two & c == 2 & (ctype == 2 | ctype == 3)) | (~one & ~two & ctype == want(c));
+    pick = find(suits & ~taken,1);
+    if isempty(pick); error('vbmc_hip:starts','vpoptimize_vbmc: no sieve candidate of the type chain %d starts from.',c); end
+    taken(pick) = true;
+    start(c) = rescale_params(cand(pick)); %#ok<AGROW>
+    Theta0(:,c) = get_vptheta(start(c)); %#ok<AGROW>
 end
 T = size(Theta0,1);
 
-% (3) all chains in one on-device Adam loop per group of equal non-optimised parameters (one group in a default run)
-master_stepsize.min = min(options.SGDStepSize,0.001);
-if optimState.Warmup || ~vp.optimize_weights
-    scaling_factor = min(0.1,options.SGDStepSize*10);
-else
-    scaling_factor = min(0.1,options.SGDStepSize);
-end
-master_stepsize.max = max(master_stepsize.min,scaling_factor);
-master_stepsize.decay = 200;
-MaxIter = min(options.MaxIterStochastic,1e4);
-grp = fixed_groups(starts);
+% (3) the Adam loops on the device, one batch per group of chains whose NON-optimised parameters agree (one group in a
+% default run).  Step sizes as :108-125: floor min(SGDStepSize,1e-3); ceiling SGDStepSize (x10 during warm-up), at most 0.1.
+lo = min(options.SGDStepSize,0.001);
+if warm || ~vp.optimize_weights; hi = options.SGDStepSize*10; else; hi = options.SGDStepSize; end
+steps = [lo, max(lo,min(0.1,hi)), 200];
+maxit = min(1e4,options.MaxIterStochastic);
+grp = groups_of(start);
 h = vbmc_hip_gp_handle(gp);
-ThetaOpt = zeros(T,Nslowopts);
+ThetaEnd = zeros(T,Nslowopts);
 ThetaMid = zeros(T,Nslowopts);
 for g = 1:max(grp)
-    members = find(grp == g);
-    [x,~,iters,xtab,ftab] = vbmc_hip_mex('adam',h,Theta0(:,members),starts(members(1)),NSentK,double(compute_var), ...
-        elcbo_beta,thetabnd,randi(2^31-1),options.TolFunStochastic,MaxIter, ...
-        [master_stepsize.min master_stepsize.max master_stepsize.decay]);
-    ThetaOpt(:,members) = x;
-    for r = 1:numel(members)
-        [~,idx_mid] = min(ftab(1:double(iters(r)),r));      % best midpoint of the chain
-        ThetaMid(:,members(r)) = xtab(:,idx_mid,r);
-    end
-end
-
-% (4) full ELCBO at midpoints and endpoints: slots 2*iOpt-1 (midpoint, only with ELCBOmidpoint) and 2*iOpt (endpoint)
-Nsgp = numel(gp.post);
-NSentFineK = ceil(evaloption_vbmc(options.NSentFine,K)/K);
-computevar_flag = ~(isfield(options,'SkipELBOVariance') && options.SkipELBOVariance);
-nslot = 2*Nslowopts;
-st.nelbo = Inf(1,nslot); st.nelcbo = Inf(1,nslot);
-st.G = NaN(1,nslot); st.H = NaN(1,nslot); st.varF = NaN(1,nslot); st.varss = NaN(1,nslot);
-st.theta = NaN(nslot,T); st.I_sk = NaN(nslot,Nsgp,K); st.J_sjk = NaN(nslot,Nsgp,K,K);
-slot = []; chain = []; Th = zeros(T,0);
-for iOpt = 1:Nslowopts
-    if options.ELCBOmidpoint
-        slot(end+1) = 2*iOpt-1; chain(end+1) = iOpt; Th(:,end+1) = ThetaMid(:,iOpt); %#ok<AGROW>
-    end
-    slot(end+1) = 2*iOpt; chain(end+1) = iOpt; Th(:,end+1) = ThetaOpt(:,iOpt); %#ok<AGROW>
-end
-for g = 1:max(grp)
-    sel = find(grp(chain) == g);
-    [F,~,varG,G,H,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo_batch',h,Th(:,sel),starts(chain(sel(1))),NSentFineK,0, ...
-        double(computevar_flag),0,[],randi(2^31-1),1,Nsgp);
-    if ~computevar_flag; varG = zeros(size(F)); varGss = zeros(size(F)); J_sjk = zeros(Nsgp,K,K,numel(sel)); end
-    for q = 1:numel(sel)
-        s = slot(sel(q));
-        st.nelbo(s) = F(q); st.G(s) = G(q); st.H(s) = H(q); st.varF(s) = varG(q); st.varss(s) = varGss(q);
-        st.nelcbo(s) = F(q) + elcbo_beta*sqrt(varG(q));
-        st.theta(s,:) = Th(:,sel(q))';
-        st.I_sk(s,:,:) = I_sk(:,:,q);
-        st.J_sjk(s,:,:,:) = J_sjk(:,:,:,q);
-    end
-end
-
-% (5) best slot
-[~,idx] = min(st.nelcbo);
-elbo = -st.nelbo(idx);
-elbo_sd = sqrt(st.varF(idx));
-G = st.G(idx); H = st.H(idx); varss = st.varss(idx); varG = st.varF(idx); varH = 0;
-I_sk = zeros(Nsgp,K); J_sjk = zeros(Nsgp,K,K);
-I_sk(:,:) = st.I_sk(idx,:,:);
-J_sjk(:,:,:) = st.J_sjk(idx,:,:,:);
-vp = rescale_params(starts(ceil(idx/2)),st.theta(idx,:));
-vp.temperature = optimState.temperature;
-
-% (6) pruning of components with negligible weight: one full-ELCBO evaluation (the shimmed negelcbo_vbmc) per attempt
-pruned = 0;
-if vp.optimize_weights
-    alreadychecked = false(1,vp.K);
-    while any(vp.w < options.TolWeight & ~alreadychecked)
-        vp_pruned = vp;
-        cand = find(vp_pruned.w < options.TolWeight & ~alreadychecked);
-        idx = cand(randi(numel(cand)));
-        vp_pruned.w(idx) = [];
-        if isfield(vp_pruned,'eta'); vp_pruned.eta(idx) = []; end
-        vp_pruned.sigma(idx) = [];
-        vp_pruned.mu(:,idx) = [];
-        vp_pruned.K = vp_pruned.K - 1;
-        [theta_pruned,vp_pruned] = get_vptheta(vp_pruned,vp_pruned.optimize_mu,vp_pruned.optimize_sigma, ...
-            vp_pruned.optimize_lambda,vp_pruned.optimize_weights);
-        NSp = ceil(evaloption_vbmc(options.NSentFine,vp_pruned.K)/vp_pruned.K);
-        [nelbo_p,~,G_p,H_p,varF_p,~,varss_p,varG_p,varH_p] = negelcbo_vbmc(theta_pruned(:)',0,vp_pruned,gp,NSp,0,computevar_flag,0,[],0);
-        elbo_pruned = -nelbo_p;
-        elbo_pruned_sd = sqrt(varF_p);
-        delta_elcbo = abs((elbo_pruned - options.ELCBOImproWeight*elbo_pruned_sd) - (elbo - options.ELCBOImproWeight*elbo_sd));
-        PruningThreshold = options.TolImprovement*evaloption_vbmc(options.PruningThresholdMultiplier,K);
-        if delta_elcbo < PruningThreshold
-            vp = vp_pruned;
-            elbo = elbo_pruned; elbo_sd = elbo_pruned_sd;
-            G = G_p; H = H_p; varss = varss_p; varG = varG_p; varH = varH_p;
-            pruned = pruned + 1;
-            alreadychecked(idx) = [];
-            I_sk(:,idx) = [];
-            J_sjk(:,:,idx) = [];
-        else
-            alreadychecked(idx) = true;
+    m = find(grp == g);
+    try
+        [x,~,iters,xtab,ftab] = vbmc_hip_mex('adam',h,Theta0(:,m),start(m(1)),NSentK,double(compute_var),elcbo_beta, ...
+            bnd,randi(2^31-1),options.TolFunStochastic,maxit,steps);
+        ThetaEnd(:,m) = x;
+        for r = 1:numel(m)
+            [~,at] = min(ftab(1:double(iters(r)),r));                  % best midpoint of the chain (:133)
+            ThetaMid(:,m(r)) = xtab(:,at,r);
+        end
+    catch err
+        if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+        % refused on the device: the user's own host-loop fminadam over the shimmed objective (which falls through by itself)
+        ms = struct('min',steps(1),'max',steps(2),'decay',steps(3));
+        for c = m
+            fun = @(t) negelcbo_vbmc(t,elcbo_beta,start(c),gp,NSentK,1,compute_var,0,bnd,0);
+            [xo,~,xl,fl] = fminadam(fun,Theta0(:,c)',[],[],options.TolFunStochastic,maxit,ms);
+            ThetaEnd(:,c) = xo(:);
+            [~,at] = min(fl);
+            ThetaMid(:,c) = xl(at,:)';
         end
     end
 end
 
-vp.stats.elbo = elbo;
-vp.stats.elbo_sd = elbo_sd;
-vp.stats.elogjoint = G;
-vp.stats.elogjoint_sd = sqrt(varG);
-vp.stats.entropy = H;
-vp.stats.entropy_sd = sqrt(varH);
-vp.stats.stable = false;
-vp.stats.I_sk = I_sk;
-vp.stats.J_sjk = J_sjk;
+% (4) full ELCBO at midpoints (slot 2c-1, only with ELCBOmidpoint) and endpoints (slot 2c).  Empty slots keep nelcbo = Inf
+% (:33); a point with a non-finite parameter (a diverged chain) is not sent -- the library validates the whole batch -- and
+% keeps NaN, which is what the reference's arithmetic gives it and what its min() skips.
+S = numel(gp.post);
+Nfine = ceil(evaloption_vbmc(options.NSentFine,K)/K);
+with_variance = ~(isfield(options,'SkipELBOVariance') && options.SkipELBOVariance);
+nslot = 2*Nslowopts;
+res = struct('nelbo',Inf(1,nslot),'nelcbo',Inf(1,nslot),'G',NaN(1,nslot),'H',NaN(1,nslot),'varF',NaN(1,nslot), ...
+    'varss',NaN(1,nslot),'theta',NaN(T,nslot),'I_sk',NaN(S,K,nslot),'J_sjk',NaN(S,K,K,nslot));
+slot = zeros(1,0); chain = zeros(1,0);
+for c = 1:Nslowopts
+    if options.ELCBOmidpoint
+        slot(end+1) = 2*c-1; chain(end+1) = c; res.theta(:,2*c-1) = ThetaMid(:,c); %#ok<AGROW>
+    end
+    slot(end+1) = 2*c; chain(end+1) = c; res.theta(:,2*c) = ThetaEnd(:,c); %#ok<AGROW>
+end
+for g = 1:max(grp)
+    sel = find(grp(chain) == g);
+    bad = ~all(isfinite(res.theta(:,slot(sel))),1);
+    res.nelbo(slot(sel(bad))) = NaN; res.nelcbo(slot(sel(bad))) = NaN;
+    sel = sel(~bad);
+    if isempty(sel); continue; end
+    vpg = start(chain(sel(1)));
+    try
+        [F,~,varG,G,H,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo_batch',h,res.theta(:,slot(sel)),vpg,Nfine,0, ...
+            double(with_variance),0,[],randi(2^31-1),1,S);
+        if ~with_variance; varG = zeros(size(F)); varGss = zeros(size(F)); J_sjk = zeros(S,K,K,numel(sel)); end
+        for q = 1:numel(sel)
+            s = slot(sel(q));
+            res.nelbo(s) = F(q); res.G(s) = G(q); res.H(s) = H(q); res.varF(s) = varG(q); res.varss(s) = varGss(q);
+            res.I_sk(:,:,s) = I_sk(:,:,q);
+            res.J_sjk(:,:,:,s) = J_sjk(:,:,:,q);
+        end
+    catch err
+        if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+        for q = 1:numel(sel)                      % slot by slot through the shimmed objective (falls through on its own)
+            s = slot(sel(q));
+            [nF,~,G1,H1,vF,~,vss,~,~,I1,J1] = negelcbo_vbmc(res.theta(:,s)',0,vpg,gp,Nfine,0,with_variance,0,[],0);
+            res.nelbo(s) = nF; res.G(s) = G1; res.H(s) = H1; res.varF(s) = vF; res.varss(s) = vss;
+            res.I_sk(:,:,s) = I1;
+            if isempty(J1); res.J_sjk(:,:,:,s) = 0; else; res.J_sjk(:,:,:,s) = J1; end
+        end
+    end
+    res.nelcbo(slot(sel)) = res.nelbo(slot(sel)) + elcbo_beta*sqrt(res.varF(slot(sel)));
 end
 
-function grp = fixed_groups(vps)
+% (5) the best of them (first minimum; NaN skipped)
+[~,b] = min(res.nelcbo);
+best = struct('elbo',-res.nelbo(b),'elbo_sd',sqrt(res.varF(b)),'G',res.G(b),'H',res.H(b),'varss',res.varss(b), ...
+    'varG',res.varF(b),'varH',0,'I_sk',res.I_sk(:,:,b),'J_sjk',res.J_sjk(:,:,:,b));
+vp = rescale_params(start(ceil(b/2)),res.theta(:,b)');
+vp.temperature = temperature;
+
+% (6) pruning
+[vp,best,pruned] = vbmc_hip_prune(vp,gp,options,K,best,with_variance);
+varss = best.varss;
+
+% (7) the statistics of the solution, fields in the reference's order (:244-252)
+names = {'elbo','elbo_sd','elogjoint','elogjoint_sd','entropy','entropy_sd','stable','I_sk','J_sjk'};
+vals = {best.elbo,best.elbo_sd,best.G,sqrt(best.varG),best.H,sqrt(best.varH),false,best.I_sk,best.J_sjk};
+for q = 1:numel(names); vp.stats.(names{q}) = vals{q}; end
+end
+
+function ok = inside_path(vp,gp,K,optimState,options)
+ok = false;
+if isempty(options) || vbmc_hip_state('parity'); return; end
+if isempty(K); K = vp.K; end
+probe = vp; probe.K = K; probe.delta = 0;
+if isfield(optimState,'delta'); probe.delta = optimState.delta; end
+Neff = size(gp.X,1);
+if isfield(optimState,'Neff'); Neff = optimState.Neff; end
+deterministic = K == 1 || (isfield(optimState,'EntropySwitch') && optimState.EntropySwitch) ...
+    || ceil(evaloption_vbmc(options.NSent,K)/K) == 0;
+with_variance = ~(isfield(options,'SkipELBOVariance') && options.SkipELBOVariance);
+ok = ~deterministic && evaloption_vbmc(options.ELCBOWeight,Neff) == 0 && strcmpi(options.StochasticOptimizer,'adam') ...
+    && vbmc_hip_supported(gp,probe,with_variance);
+end
+
+function grp = groups_of(vps)
 % chains whose NON-optimised parameter groups are equal share a batch (those groups are not part of theta)
-key = cell(1,numel(vps));
+label = cell(1,numel(vps));
 for i = 1:numel(vps)
     v = vps(i); fx = [];
     if ~v.optimize_mu; fx = [fx; v.mu(:)]; end %#ok<AGROW>
     if ~v.optimize_sigma; fx = [fx; v.sigma(:)]; end %#ok<AGROW>
     if ~v.optimize_lambda; fx = [fx; v.lambda(:)]; end %#ok<AGROW>
     if ~v.optimize_weights; fx = [fx; v.w(:)]; end %#ok<AGROW>
-    key{i} = sprintf('%.17g,',fx);
+    label{i} = sprintf('%.17g,',fx);
 end
-[~,~,grp] = unique(key,'stable');
+[~,~,grp] = unique(label,'stable');
 grp = grp(:)';
 end

@@ -103,3 +103,25 @@ def test_pipeline_misuse_is_refused(va):
     obj.submit(batches[0], seed=1, slot=0)
     F2, _ = obj.collect(0)
     assert np.array_equal(F2, F)
+
+
+def test_collect_with_another_layout_is_refused(va):
+    """collecting with args whose optimize flags (a smaller T) or compute_grad differ from the submitted ones would
+    copy plan.T doubles per restart into the caller's shorter arrays.  Refused; the slot stays collectable with the right args."""
+    p, gp, vp, batches = setup(va, 7, 3, 25, 4, 2, 3)
+    T = batches[0].shape[0]
+    obj = va.PreparedObjective(T, 3, 0, vp, gp, 60, 0, None)
+    ctx = va.default_engine().ctx
+    obj.submit(batches[0], seed=4, slot=1)
+    a, _, _ = obj._slot(1)
+    b = type(a).from_buffer_copy(a)
+    b.optimize[3] = 0                       # without the eta block: T - K
+    with pytest.raises(va.VbmcHipError, match="differ from the submitted"):
+        ctx.check(ctx.lib.vbmc_elbo_collect(ctx.h, C.byref(b), 1))
+    b = type(a).from_buffer_copy(a)
+    b.compute_grad = 0
+    with pytest.raises(va.VbmcHipError, match="differ from the submitted"):
+        ctx.check(ctx.lib.vbmc_elbo_collect(ctx.h, C.byref(b), 1))
+    F, dF = obj.collect(1)
+    ref = va.negelcbo_batch(batches[0], 0, vp, gp, 60, True, 0, seed=4)
+    assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])

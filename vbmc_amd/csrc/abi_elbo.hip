@@ -1094,8 +1094,14 @@ extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const 
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
   if (s_) { (void)hipStreamSynchronize(ctx->stream); return s_; }   // nothing of a failed submit stays in flight
-  HIP_TRY(ctx, hipEventRecord(ctx->slot_ev[slot], ctx->stream));
   ctx->slot_busy[slot] = true;
+  hipError_t e_ = hipEventRecord(ctx->slot_ev[slot], ctx->stream);
+  if (e_ != hipSuccess) {   // the pass is enqueued but cannot be waited for through the event: drain it and give the slot back
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->slot_busy[slot] = false;
+    return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_submit: hipEventRecord: %s", hipGetErrorString(e_));
+  }
   return VBMC_OK;
 }
 
@@ -1104,8 +1110,12 @@ extern "C" vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* a,
   if (!a || slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: null args / slot not 0 or 1");
   if (!ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: nothing submitted in slot %d", slot);
   const SlotPlan* sp = (const SlotPlan*)ctx->slot_plan[slot];
-  if (a->D != sp->P.dm.D || a->K != sp->P.dm.K || a->R != sp->P.dm.R)
-    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: args differ from the submitted ones (D, K, R)");
+  // elbo_unpack copies T = plan.T doubles per restart into the caller's arrays: the layout must be the submitted one
+  int T_now = 0;
+  { const int n[4] = {a->D * a->K, a->K, a->D, a->K}; for (int g = 0; g < 4; ++g) if (a->optimize[g]) T_now += n[g]; }
+  if (a->D != sp->P.dm.D || a->K != sp->P.dm.K || a->R != sp->P.dm.R || T_now != sp->P.dm.T ||
+      (a->compute_grad ? 1 : 0) != sp->P.compute_grad)
+    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: args differ from the submitted ones (D, K, R, optimize flags, compute_grad)");
   ctx->slot_busy[slot] = false;
   hipError_t e_ = hipEventSynchronize(ctx->slot_ev[slot]);
   if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_collect: %s", hipGetErrorString(e_)); }
