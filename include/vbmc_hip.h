@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VBMC_ABI_VERSION 2
+#define VBMC_ABI_VERSION 3
 
 typedef int vbmc_status;
 enum {
@@ -241,6 +241,10 @@ typedef struct vbmc_elbo_args {
                               * THIS device once.  W > 1: as many as fill W devices -- the chunking vbmc_elbo_shard_* use for a
                               * world of W ranks, so that an unsharded evaluation with chunk_world = W is their bit-exact
                               * reference (the chunk count only moves the summation order of the entropy partials) */
+  int32_t restart_offset;    /* eps_mode 0: the device stream of restart r (column r of theta) is keyed by                    */
+  int32_t restart_stride;    /* restart_offset + r * restart_stride (stride 0 is read as 1).  0 / 1: the position in this      */
+                             /* batch.  A batch dealt over G devices (vbmc_elbo_batch_multi: device g gets restarts g, g+G,   */
+                             /* ...) passes g / G, so that every restart draws what it would draw in the undivided batch      */
 } vbmc_elbo_args;
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
@@ -285,6 +289,55 @@ vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* args, int slo
 vbmc_status vbmc_elbo_shard_size(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int world, size_t* n_doubles);
 vbmc_status vbmc_elbo_shard_begin(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int rank, int world, double* d_send);
 vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int world, const double* d_gathered);
+
+/* ---- more than one GPU: the communicator inside the library -----------------------------------------------------------
+ * The path shards over the independent restarts of the sieve / the optimiser (misc/vpsieve_vbmc.m:74-78,
+ * misc/vpoptimize_vbmc.m:49): rank g of G evaluates restarts g, g + G, g + 2G, ... against its own replica of the surrogate, and
+ * the ONE exchange is an all-gather of the restarts' ELCBO values (RCCL ncclAllGather, device to device over xGMI), after which
+ * every rank holds the identical vector and performs the identical stable sort (:82) -- index-identical order with no broadcast.
+ * RCCL is reached from inside the library (dlopen of librccl on first use), so that a host without a distributed runtime of its
+ * own -- the MATLAB process behind matlab/vbmc_hip_mex.cpp -- can use every GPU of a node.
+ *
+ *   vbmc_comm_create_all    ONE process drives ndev devices (devices == NULL: 0 .. ndev-1): creates a context per device and an
+ *                           RCCL rank per device (ncclCommInitAll).  vbmc_comm_ctx(c, i) is the context of local device i.
+ *   vbmc_comm_unique_id /   one process PER device (python -m torch.distributed.run, mpirun): rank 0 obtains the 128-byte id and
+ *   vbmc_comm_create_rank   hands it to the others by any means (a file, torch.distributed, MPI); every process then joins with its
+ *                           own context (ncclCommInitRank).  The context stays the caller's.
+ *   vbmc_allgather_f64      every local device contributes `count` doubles (d_send[i], device memory on local device i) and
+ *                           receives size * count doubles in rank order (d_recv[i]); enqueued on the contexts' streams inside
+ *                           ncclGroupStart / ncclGroupEnd, then synchronised.  All-gather, never all-reduce: the result is
+ *                           bit-identical to the one-GPU evaluation and identical on every rank.
+ *   vbmc_allgather_host_f64 the same for host blocks (send: local * count doubles, recv: size * count), staged through the
+ *                           communicator's own device blocks.
+ *   vbmc_gp_upload_all      vbmc_gp_upload on every local device (gps[local]): the surrogate is replicated, not sharded (25.6 MB
+ *                           at the headline shape against 288 GB of HBM per device).
+ *   vbmc_elbo_batch_multi   vbmc_elbo_batch for R restarts dealt over the ranks.  args is the UNDIVIDED batch (theta T x R, outputs
+ *                           sized for R), identical on every rank.  On return F and varG hold ALL R values on every rank (the
+ *                           all-gathered vectors as device memory of local device 0 received them); the other outputs are filled
+ *                           for the restarts this process evaluated (all of them for vbmc_comm_create_all) and left untouched
+ *                           elsewhere.  The device stream of restart r is keyed by its index r in the undivided batch
+ *                           (restart_offset / restart_stride), and each device computes its restarts with the same kernels in the same
+ *                           order of summation: every value is BIT-IDENTICAL to vbmc_elbo_batch of the whole batch on one
+ *                           device.  eps_mode 0, or one shared host block of draws (eps_mode 1 with eps_shared).
+ * Errors of these calls are reported by vbmc_comm_last_error.
+ */
+typedef struct vbmc_comm vbmc_comm;
+vbmc_status vbmc_comm_create_all(int ndev, const int* devices, vbmc_comm** out);
+vbmc_status vbmc_comm_unique_id(void* id128);
+vbmc_status vbmc_comm_create_rank(vbmc_ctx* ctx, int rank, int size, const void* id128, vbmc_comm** out);
+void vbmc_comm_destroy(vbmc_comm* comm);
+int vbmc_comm_size(const vbmc_comm* comm);    /* ranks of the communicator                         */
+int vbmc_comm_local(const vbmc_comm* comm);   /* devices this process drives                        */
+int vbmc_comm_rank(const vbmc_comm* comm);    /* rank of local device 0                             */
+vbmc_ctx* vbmc_comm_ctx(vbmc_comm* comm, int local);
+const char* vbmc_comm_last_error(const vbmc_comm* comm);
+vbmc_status vbmc_allgather_f64(vbmc_comm* comm, const double* const* d_send, double* const* d_recv, size_t count);
+vbmc_status vbmc_allgather_host_f64(vbmc_comm* comm, const double* send, double* recv, size_t count);
+vbmc_status vbmc_gp_upload_all(vbmc_comm* comm, int N, int D, int S, int Nhyp, int Ncov, int Nnoise, int meanfun,
+                               const double* X, const double* hyp, const double* alpha, const double* L, const double* sW1,
+                               const uint8_t* Lchol, vbmc_gp** gps);
+void vbmc_gp_free_all(vbmc_comm* comm, vbmc_gp** gps);
+vbmc_status vbmc_elbo_batch_multi(vbmc_comm* comm, const vbmc_gp* const* gps, const vbmc_elbo_args* args);
 
 /*
  * [x,f,xtab,ftab,iter] = fminadam(@(t) negelcbo_vbmc(t,beta,vp,gp,Ns,1,compute_var,~,thetabnd), x0, [], [],

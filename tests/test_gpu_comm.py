@@ -1,0 +1,131 @@
+"""GPU: the communicator inside the library (vbmc_comm_*, vbmc_elbo_batch_multi: RCCL reached from libvbmc_hip.so itself).
+
+On the one-GPU box: a one-rank communicator (ncclCommInitAll / ncclCommInitRank with world 1, a real ncclAllGather on the
+context's stream) must return the bits of vbmc_elbo_batch; and the piece that makes a DEALT batch equal the undivided one --
+the device stream of restart r keyed by its index in the whole batch (restart_offset / restart_stride) -- is checked by
+evaluating the shares of G = 2, 3, 8 emulated ranks one after the other on the same device.  With two or more devices the same
+test runs the real thing (skipped otherwise)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vbmc_ref as R
+from tests._cases import synth_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vbmc_amd
+
+    return vbmc_amd
+
+
+def setup(seed, D, N, K, S, Rn):
+    p = synth_problem(seed, D, N, K, S)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"])
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    Th = np.asfortranarray(theta[:, None] + 0.05 * np.random.default_rng(seed).standard_normal((theta.size, Rn)))
+    return gp, vp, Th
+
+
+def test_dealt_shares_equal_the_undivided_batch(va):
+    """Rank g's share (restarts g, g + G, ...) evaluated as its own batch with restart_offset = g, restart_stride = G gives,
+    column for column, the bits of the undivided batch -- Monte-Carlo entropy on the device stream included."""
+    from vbmc_amd.elbo import _build_args, default_engine
+    from vbmc_amd._lib import ptr
+
+    gp, vp, Th = setup(11, 5, 40, 7, 3, 13)
+    eng = default_engine()
+    whole = va.negelcbo_batch(Th, 0, vp, gp, 50, True, 0, seed=21)
+    for G in (2, 3, 8):
+        for g in range(G):
+            cols = np.arange(Th.shape[1])[g::G]
+            sub = np.asfortranarray(Th[:, cols])
+            a, keep, _ = _build_args(sub, 0, vp, gp, 50, True, 0, None, False, None, None, False, 21, eng)
+            a.restart_offset, a.restart_stride = g, G
+            F = np.empty(cols.size); dF = np.empty((Th.shape[0], cols.size), order="F"); H = np.empty(cols.size)
+            a.F, a.dF, a.H = ptr(F), ptr(dF), ptr(H)
+            dgp = eng.device_gp(gp)
+            eng.ctx.check(eng.ctx.lib.vbmc_elbo_batch(eng.ctx.h, dgp.h, C.byref(a)))
+            assert np.array_equal(F, whole["F"][cols]) and np.array_equal(H, whole["H"][cols])
+            assert np.array_equal(dF, whole["dF"][:, cols])
+    # and the default (0 / 0) is the plain batch
+    a, keep, _ = _build_args(Th, 0, vp, gp, 50, False, 0, None, False, None, None, False, 21, eng)
+    F = np.empty(Th.shape[1]); a.F = ptr(F)
+    eng.ctx.check(eng.ctx.lib.vbmc_elbo_batch(eng.ctx.h, eng.device_gp(gp).h, C.byref(a)))
+    assert np.array_equal(F, whole["F"])
+
+
+def _check_multi(va, comm, with_var):
+    gp, vp, Th = setup(12, 4, 35, 6, 2, 9)
+    gps = comm.upload_gp(gp, need_L=with_var)
+    try:
+        for Ns, grad, cv in ((0, False, 1 if with_var else 0), (40, True, 0), (40, False, 1 if with_var else 0)):
+            ref = va.negelcbo_batch(Th, 0, vp, gp, Ns, grad, cv, seed=5)
+            out = comm.negelcbo_batch(Th, 0, vp, gps, Ns, grad, cv, seed=5)
+            assert np.array_equal(out["F"], ref["F"]), (Ns, grad, cv)
+            assert np.array_equal(out["varG"], ref["varG"])
+            mine = np.arange(Th.shape[1])                    # create_all: every restart is local
+            assert np.array_equal(out["G"][mine], ref["G"]) and np.array_equal(out["H"][mine], ref["H"])
+            if grad:
+                assert np.array_equal(out["dF"], ref["dF"]) and np.array_equal(out["dH"], ref["dH"])
+        if with_var:
+            ref = va.negelcbo_batch(Th, 0, vp, gp, 30, False, 1, separate_K=True, seed=6)
+            out = comm.negelcbo_batch(Th, 0, vp, gps, 30, False, 1, separate_K=True, seed=6, S=2)
+            assert np.array_equal(out["I_sk"], ref["I_sk"]) and np.array_equal(out["J_sjk"], ref["J_sjk"])
+    finally:
+        comm.free_gp(gps)
+
+
+def test_one_rank_communicator_is_bit_identical(va):
+    """ncclCommInitAll over ONE device: the whole vbmc_elbo_batch_multi path (deal, pick kernel, ncclAllGather inside a group
+    on the context's stream, gathered read-back) against vbmc_elbo_batch."""
+    from vbmc_amd.multi import Comm
+
+    comm = Comm.create_all(1)
+    assert (comm.size, comm.local, comm.rank) == (1, 1, 0)
+    v = np.arange(5.0)
+    assert np.array_equal(comm.allgather_host(v), v.reshape(1, 5))
+    _check_multi(va, comm, with_var=True)
+    # more ranks than restarts is fine too (R = 1 here: nothing to deal); refusals name their reason
+    gp, vp, Th = setup(13, 3, 30, 4, 2, 1)
+    gps = comm.upload_gp(gp)
+    out = comm.negelcbo_batch(Th, 0, vp, gps, 20, True, 0, seed=3)
+    assert np.array_equal(out["F"], va.negelcbo_batch(Th, 0, vp, gp, 20, True, 0, seed=3)["F"])
+    comm.free_gp(gps)
+    comm.close()
+
+
+def test_rank_form_with_a_unique_id(va):
+    """ncclGetUniqueId + ncclCommInitRank (the one-process-per-GPU form bench.py uses), world 1 on this box, on the default
+    engine's own context."""
+    from vbmc_amd.multi import Comm
+
+    ctx = va.default_engine().ctx
+    comm = Comm.create_rank(ctx, 0, 1, Comm.unique_id())
+    assert comm.size == 1 and comm.local == 1
+    _check_multi(va, comm, with_var=False)
+    r = comm.allgather_host(np.array([1.5, -2.0]))
+    assert r.shape == (1, 2) and r[0, 1] == -2.0
+    comm.close()
+
+
+def test_all_devices_of_the_node(va):
+    """With >= 2 gfx950 devices: ONE process drives them all; every value equals the one-device batch."""
+    import torch
+    from vbmc_amd.multi import Comm
+
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one device on this box: the multi-device form is exercised with emulated ranks above")
+    comm = Comm.create_all(n)
+    assert comm.size == n and comm.local == n
+    _check_multi(va, comm, with_var=True)
+    blocks = np.arange(3.0 * n).reshape(n, 3)
+    assert np.array_equal(comm.allgather_host(blocks), blocks)
+    comm.close()

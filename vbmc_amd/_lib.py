@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VBMC_HIP_LIB: an alternative build of the SAME library (kernel A/B experiments, tools/ent_experiments.py)
 LIB_PATH = os.environ.get("VBMC_HIP_LIB") or os.path.join(_HERE, "lib", "libvbmc_hip.so")
 
-ABI_VERSION = 2   # include/vbmc_hip.h: VBMC_ABI_VERSION
+ABI_VERSION = 3   # include/vbmc_hip.h: VBMC_ABI_VERSION
 VBMC_OK, VBMC_ERR_INVALID, VBMC_ERR_NO_DEVICE, VBMC_ERR_HIP, VBMC_ERR_UNSUPPORTED, VBMC_ERR_NOT_POSDEF = range(6)
 _STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "UNSUPPORTED", 5: "NOT_POSDEF"}
 
@@ -54,6 +54,7 @@ class ElboArgs(C.Structure):
         ("varG", _dp), ("varGss", _dp), ("I_sk", _dp), ("J_sjk", _dp),
         ("G_s", _dp), ("varG_s", _dp),
         ("chunk_world", C.c_int32),
+        ("restart_offset", C.c_int32), ("restart_stride", C.c_int32),
     ]
 
 
@@ -117,6 +118,27 @@ def load():
     lib.vbmc_gp_nlz.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
     lib.vbmc_test_exp.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
     lib.vbmc_sq_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
+    # the communicator inside the library (abi_comm.hip)
+    vpp = C.POINTER(vp)
+    lib.vbmc_comm_create_all.argtypes = [C.c_int, C.POINTER(C.c_int), vpp]
+    lib.vbmc_comm_unique_id.argtypes = [C.c_char_p]
+    lib.vbmc_comm_create_rank.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, vpp]
+    lib.vbmc_comm_destroy.argtypes = [vp]
+    lib.vbmc_comm_destroy.restype = None
+    for name in ("vbmc_comm_size", "vbmc_comm_local", "vbmc_comm_rank"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = C.c_int
+    lib.vbmc_comm_ctx.argtypes = [vp, C.c_int]
+    lib.vbmc_comm_ctx.restype = vp
+    lib.vbmc_comm_last_error.argtypes = [vp]
+    lib.vbmc_comm_last_error.restype = C.c_char_p
+    lib.vbmc_allgather_f64.argtypes = [vp, vpp, vpp, C.c_size_t]
+    lib.vbmc_allgather_host_f64.argtypes = [vp, _dp, _dp, C.c_size_t]
+    lib.vbmc_gp_upload_all.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_uint8), vpp]
+    lib.vbmc_gp_free_all.argtypes = [vp, vpp]
+    lib.vbmc_gp_free_all.restype = None
+    lib.vbmc_elbo_batch_multi.argtypes = [vp, vpp, C.POINTER(ElboArgs)]
     for name in DECLARED_OPTIONAL:
         if hasattr(lib, name):
             pass

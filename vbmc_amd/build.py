@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-MAIN_DEPS = ["vbmc_hip.hip", "abi_elbo.hip", "abi_gp.hip", "common.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "elbo_kernels.h", "trsm_mfma.h",
+MAIN_DEPS = ["vbmc_hip.hip", "abi_elbo.hip", "abi_gp.hip", "abi_comm.hip", "common.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "elbo_kernels.h", "trsm_mfma.h",
              "var_kernels.h", "gp_kernels.h", "chol_mfma.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
 MFMA_DEPS = ["ent_mfma_inst.hip", "entropy_mfma.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h"]
 QS_RANGE = range(1, 10)
@@ -54,7 +54,7 @@ def build(force=False, verbose=True):
             list(ex.map(lambda c: _run(c, verbose), jobs))
     lib = os.path.join(LIBDIR, "libvbmc_hip.so")
     if force or jobs or _newer(lib, objs):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib], verbose)
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", lib], verbose)
     mb_src = os.path.join(ROOT, "tools", "microbench.hip")
     mb = os.path.join(LIBDIR, "microbench")
     if os.path.exists(mb_src) and (force or _newer(mb, [mb_src, os.path.join(CSRC, "device_math.h")])):

@@ -434,6 +434,7 @@ struct ElboPlan {
   bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false, tri_gemm = false;
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
+  int r0 = 0, rstride = 1;   // device-RNG key of restart r: r0 + r * rstride (vbmc_elbo_args.restart_offset / restart_stride)
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0, n_sepk = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
   double *d_ljbar = nullptr;
@@ -492,6 +493,8 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
 
   int M = a->Ns;
   if (M < 0) return set_err(ctx, VBMC_ERR_INVALID, "Ns must be >= 0");
+  if (a->restart_offset < 0 || a->restart_stride < 0) return set_err(ctx, VBMC_ERR_INVALID, "restart_offset / restart_stride must be >= 0");
+  P.r0 = a->restart_offset; P.rstride = a->restart_stride > 0 ? a->restart_stride : 1;
   M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
   const int Mh = P.Mh = M / 2;
   P.mc = M > 0;
@@ -799,7 +802,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     // sharded: this rank's chunks [c0, c0 + nc) of the unsharded chunking, written to slots 0 .. nc-1 of a perC-slot record
     ea.part = sh.mode == 1 ? sh.send + shard_lj_doubles(P, sh.world) : P.d_part;
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
-    ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff;
+    ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff; ea.r0 = P.r0; ea.rstride = P.rstride;
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     if (sh.mode == 2 || nc <= 0) {
     } else if (P.use_mfma) {

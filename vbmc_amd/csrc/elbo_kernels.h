@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(WAVE) k_entropy(EntArgs a) {
 #pragma unroll
       for (int q4 = 0; q4 < (DT + 3) / 4; ++q4) {
         double z4[4];
-        vb_normal4(a.seed, (unsigned)b, (unsigned)j, (unsigned)r, (unsigned)q4, z4);
+        vb_normal4(a.seed, (unsigned)b, (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q4, z4);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           int d = q4 * 4 + t;

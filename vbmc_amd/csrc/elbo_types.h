@@ -47,5 +47,7 @@ struct EntArgs {
   int D, K, Mh, C, tiles_per_chunk, ncol;
   int c0;                // first chunk of this launch (blockIdx.x + c0 is the chunk index; 0 unless the chunks are sharded over ranks)
   unsigned long long seed;
+  int r0, rstride;       // the device-RNG stream of restart r is keyed by r0 + r * rstride: the restart's index in the WHOLE batch when
+                         // the batch is dealt over several devices (vbmc_elbo_batch_multi: r0 = g, rstride = G); 0, 1 otherwise
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
 };

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(WAVE * HV, ((KT <= 2 && QS <= 4) ? 3 : 2)) k_e
 #ifdef VBMC_EXP_NORNG
         if (q < (D + 3) / 4) { z4[0] = 1e-3 * (double)((b0 + li) & 1023) - 0.5; z4[1] = 0.25 * z4[0]; z4[2] = -z4[0]; z4[3] = 0.5 - z4[1]; }
 #else
-        if (q < (D + 3) / 4) vb_normal4(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)r, (unsigned)q, z4);
+        if (q < (D + 3) / 4) vb_normal4(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q, z4);
 #endif
 #pragma unroll
         for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = (bv && 4 * q + t < D) ? z4[t] : 0.0;
