@@ -26,6 +26,17 @@
 //     [acq,fbar,vtot] = vbmc_hip_mex('acq_iqr', h, his, Xs, gplengthscale, X_rescaled, sn2new, var_regularized, TolGPVar)
 //     [nlZ,dnlZ] = vbmc_hip_mex('gp_nlz', Hyp /*Nhyp x B*/, X, y, s2, meanfun, noisefun)   (gplite_nlZ for B vectors)
 //     C = vbmc_hip_mex('sq_dist', a, b)
+// Every GPU of the node from ONE MATLAB process (the communicator inside the library, include/vbmc_hip.h):
+//     n  = vbmc_hip_mex('comm_open', ndev)                 -> must be the first command of the session: a context and an RCCL rank
+//                                                             per device; the single-device commands then run on device 0.
+//                                                             VBMC_HIP_DEVICES=ndev in the environment does the same implicitly.
+//     n  = vbmc_hip_mex('comm_size')                       -> devices of the session (1 without a communicator)
+//     hs = vbmc_hip_mex('gp_upload_all', gpstruct)         -> 1 x n uint64 handles, one replica per device (hs(1): device 0)
+//          vbmc_hip_mex('gp_free_all', hs)
+//     [F,dF,varG,G,H,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo_batch_multi', hs, Theta, vp, Ns, compute_grad, compute_var, beta,
+//                                thetabnd_or_empty, seed, separate_K, numel(gp.post))
+//                                ('elbo_batch' with the R candidates dealt r = g (mod n) over the devices and their ELCBO values
+//                                 all-gathered over xGMI; every value bit-identical to 'elbo_batch' on one device)
 //
 // Errors: mexErrMsgIdAndTxt long-jumps out of the MEX function without running C++ destructors, so it is called from
 // exactly one place -- mexFunction itself, which owns no C++ object -- after dispatch() has RETURNED (all its
@@ -42,8 +53,10 @@
 #include "vbmc_hip.h"
 
 static vbmc_ctx* g_ctx = nullptr;
+static vbmc_comm* g_comm = nullptr;   // 'comm_open': owns one context per device; g_ctx is then its device-0 context
 
 static void at_exit() {
+  if (g_comm) { vbmc_comm_destroy(g_comm); g_comm = nullptr; g_ctx = nullptr; }
   if (g_ctx) { vbmc_ctx_destroy(g_ctx); g_ctx = nullptr; }
 }
 
@@ -73,8 +86,24 @@ static int fail(vbmc_status st) {
   return raise("vbmc_hip:error", msg);
 }
 
+// status of a communicator call -> pending MATLAB error
+static int fail_comm(vbmc_status st) {
+  const char* msg = g_comm ? vbmc_comm_last_error(g_comm) : "no communicator";
+  return raise(st == VBMC_ERR_UNSUPPORTED ? "vbmc_hip:unsupported" : "vbmc_hip:error", msg);
+}
+
 static int ensure_ctx(int device) {
   if (g_ctx) return 0;
+  // VBMC_HIP_DEVICES=n (n >= 2) in the environment: the session opens on n devices, as 'comm_open' n would
+  const char* nd = getenv("VBMC_HIP_DEVICES");
+  if (nd && atoi(nd) >= 2) {
+    vbmc_status st = vbmc_comm_create_all(atoi(nd), nullptr, &g_comm);
+    if (st != VBMC_OK) { g_comm = nullptr; return raise("vbmc_hip:nodevice", "libvbmc_hip: VBMC_HIP_DEVICES asks for more gfx950 devices than could be opened (or librccl is missing)"); }
+    g_ctx = vbmc_comm_ctx(g_comm, 0);
+    mexLock();
+    mexAtExit(at_exit);
+    return 0;
+  }
   vbmc_status st = vbmc_ctx_create(device, nullptr, &g_ctx);
   if (st != VBMC_OK) return raise("vbmc_hip:nodevice", "libvbmc_hip: no gfx950 (MI355X) device available");
   mexLock();
@@ -110,6 +139,37 @@ static void fill_vp_args(vbmc_elbo_args& a, const mxArray* vp, const mxArray* tb
   { const char* sc = getenv("VBMC_HIP_SPARSE_CUTOFF"); a.sparse_cutoff = sc ? atof(sc) : 0.0; }
 }
 
+// gp struct (gplite_post.m:94-157) -> the flat arrays of vbmc_gp_upload; returns the sizes
+struct GpArrays {
+  int N = 0, D = 0, S = 0, Nhyp = 0, Ncov = 0, Nnoise = 0, meanfun = 0;
+  const double* X = nullptr;
+  std::vector<double> hyp, alpha, L, sW1, mult;
+  std::vector<uint8_t> lch;
+  int32_t nf[3] = {1, 0, 0};
+};
+static void read_gp(const mxArray* gp, GpArrays& g) {
+  const mxArray* X = field(gp, "X");
+  const mxArray* post = field(gp, "post");
+  g.N = (int)mxGetM(X); g.D = (int)mxGetN(X); g.S = (int)mxGetNumberOfElements(post);
+  g.Nhyp = (int)mxGetNumberOfElements(mxGetField(post, 0, "hyp"));
+  g.X = mxGetDoubles(X);
+  const int N = g.N, S = g.S, Nhyp = g.Nhyp;
+  g.hyp.resize((size_t)Nhyp * S); g.alpha.resize((size_t)N * S); g.L.resize((size_t)N * N * S); g.sW1.resize(S); g.mult.resize(S);
+  g.lch.resize(S);
+  for (int s = 0; s < S; ++s) {
+    memcpy(&g.hyp[(size_t)s * Nhyp], mxGetDoubles(mxGetField(post, s, "hyp")), Nhyp * sizeof(double));
+    memcpy(&g.alpha[(size_t)s * N], mxGetDoubles(mxGetField(post, s, "alpha")), N * sizeof(double));
+    memcpy(&g.L[(size_t)s * N * N], mxGetDoubles(mxGetField(post, s, "L")), (size_t)N * N * sizeof(double));
+    g.sW1[s] = mxGetDoubles(mxGetField(post, s, "sW"))[0];
+    g.mult[s] = mxGetScalar(mxGetField(post, s, "sn2_mult"));
+    g.lch[s] = mxIsLogicalScalarTrue(mxGetField(post, s, "Lchol")) ? 1 : 0;
+  }
+  const mxArray* nfa = field(gp, "noisefun");
+  for (int i = 0; nfa && i < 3 && i < (int)mxGetNumberOfElements(nfa); ++i) g.nf[i] = (int32_t)mxGetDoubles(nfa)[i];
+  g.Ncov = (int)scalar_field(gp, "Ncov", g.D + 1); g.Nnoise = (int)scalar_field(gp, "Nnoise", 1);
+  g.meanfun = (int)scalar_field(gp, "meanfun", 4);
+}
+
 // Every command; returns 0 on success, nonzero with g_err_id / g_err_msg set.  All C++ objects live in here.
 static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (nrhs < 1 || !mxIsChar(prhs[0])) return raise("vbmc_hip:usage", "first argument must be a command string");
@@ -117,36 +177,54 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
   mxGetString(prhs[0], cmd, sizeof cmd);
 
   if (!strcmp(cmd, "open")) return ensure_ctx(nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0);
+  if (!strcmp(cmd, "comm_open")) {
+    if (g_comm || g_ctx) return raise("vbmc_hip:usage", "comm_open must be the first command of the session");
+    const int ndev = nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 1;
+    vbmc_status st = vbmc_comm_create_all(ndev, nullptr, &g_comm);
+    if (st != VBMC_OK) { g_comm = nullptr; return raise("vbmc_hip:nodevice", "libvbmc_hip: could not open the requested gfx950 devices / librccl"); }
+    g_ctx = vbmc_comm_ctx(g_comm, 0);
+    mexLock();
+    mexAtExit(at_exit);
+    plhs[0] = mxCreateDoubleMatrix(1, 1, mxREAL);
+    mxGetDoubles(plhs[0])[0] = vbmc_comm_size(g_comm);
+    return 0;
+  }
   if (ensure_ctx(0)) return 1;
 
   if (!strcmp(cmd, "gp_upload")) {
-    const mxArray* gp = prhs[1];
-    const mxArray* X = field(gp, "X");
-    const mxArray* post = field(gp, "post");
-    const int N = (int)mxGetM(X), D = (int)mxGetN(X), S = (int)mxGetNumberOfElements(post);
-    const int Nhyp = (int)mxGetNumberOfElements(mxGetField(post, 0, "hyp"));
-    std::vector<double> hyp((size_t)Nhyp * S), alpha((size_t)N * S), L((size_t)N * N * S), sW1(S), mult(S);
-    std::vector<uint8_t> lch(S);
-    for (int s = 0; s < S; ++s) {
-      memcpy(&hyp[(size_t)s * Nhyp], mxGetDoubles(mxGetField(post, s, "hyp")), Nhyp * sizeof(double));
-      memcpy(&alpha[(size_t)s * N], mxGetDoubles(mxGetField(post, s, "alpha")), N * sizeof(double));
-      memcpy(&L[(size_t)s * N * N], mxGetDoubles(mxGetField(post, s, "L")), (size_t)N * N * sizeof(double));
-      sW1[s] = mxGetDoubles(mxGetField(post, s, "sW"))[0];
-      mult[s] = mxGetScalar(mxGetField(post, s, "sn2_mult"));
-      lch[s] = mxIsLogicalScalarTrue(mxGetField(post, s, "Lchol")) ? 1 : 0;
-    }
-    int32_t nf[3] = {1, 0, 0};
-    const mxArray* nfa = field(gp, "noisefun");
-    for (int i = 0; nfa && i < 3 && i < (int)mxGetNumberOfElements(nfa); ++i) nf[i] = (int32_t)mxGetDoubles(nfa)[i];
+    GpArrays g;
+    read_gp(prhs[1], g);
     vbmc_gp* h = nullptr;
-    vbmc_status st = vbmc_gp_upload(g_ctx, N, D, S, Nhyp, (int)scalar_field(gp, "Ncov", D + 1), (int)scalar_field(gp, "Nnoise", 1),
-                                    (int)scalar_field(gp, "meanfun", 4), mxGetDoubles(X), hyp.data(), alpha.data(), L.data(),
-                                    sW1.data(), lch.data(), &h);
-    if (st == VBMC_OK) st = vbmc_gp_set_noise(g_ctx, h, nf, mult.data());
-    hyp = {}; alpha = {}; L = {};
+    vbmc_status st = vbmc_gp_upload(g_ctx, g.N, g.D, g.S, g.Nhyp, g.Ncov, g.Nnoise, g.meanfun, g.X, g.hyp.data(), g.alpha.data(),
+                                    g.L.data(), g.sW1.data(), g.lch.data(), &h);
+    if (st == VBMC_OK) st = vbmc_gp_set_noise(g_ctx, h, g.nf, g.mult.data());
     if (st != VBMC_OK) return fail(st);
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
     *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+    return 0;
+  }
+  if (!strcmp(cmd, "comm_size")) { plhs[0] = mxCreateDoubleMatrix(1, 1, mxREAL); mxGetDoubles(plhs[0])[0] = g_comm ? vbmc_comm_size(g_comm) : 1; return 0; }
+  if (!strcmp(cmd, "gp_upload_all")) {
+    if (!g_comm) return raise("vbmc_hip:usage", "gp_upload_all needs 'comm_open' first");
+    GpArrays g;
+    read_gp(prhs[1], g);
+    const int n = vbmc_comm_local(g_comm);
+    std::vector<vbmc_gp*> hs(n, nullptr);
+    vbmc_status st = vbmc_gp_upload_all(g_comm, g.N, g.D, g.S, g.Nhyp, g.Ncov, g.Nnoise, g.meanfun, g.X, g.hyp.data(), g.alpha.data(),
+                                        g.L.data(), g.sW1.data(), g.lch.data(), hs.data());
+    if (st != VBMC_OK) return fail_comm(st);
+    for (int i = 0; i < n && st == VBMC_OK; ++i) st = vbmc_gp_set_noise(vbmc_comm_ctx(g_comm, i), hs[i], g.nf, g.mult.data());
+    if (st != VBMC_OK) { vbmc_gp_free_all(g_comm, hs.data()); return raise("vbmc_hip:error", "vbmc_gp_set_noise failed on a replica"); }
+    plhs[0] = mxCreateNumericMatrix(1, n, mxUINT64_CLASS, mxREAL);
+    for (int i = 0; i < n; ++i) ((uint64_t*)mxGetData(plhs[0]))[i] = (uint64_t)(uintptr_t)hs[i];
+    return 0;
+  }
+  if (!strcmp(cmd, "gp_free_all")) {
+    if (!g_comm) return 0;
+    const int n = vbmc_comm_local(g_comm);
+    std::vector<vbmc_gp*> hs(n, nullptr);
+    for (int i = 0; i < n && i < (int)mxGetNumberOfElements(prhs[1]); ++i) hs[i] = (vbmc_gp*)(uintptr_t)((uint64_t*)mxGetData(prhs[1]))[i];
+    vbmc_gp_free_all(g_comm, hs.data());
     return 0;
   }
   if (!strcmp(cmd, "gp_free")) { vbmc_gp_free(g_ctx, (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]))); return 0; }
@@ -195,10 +273,18 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     return 0;
   }
 
-  if (!strcmp(cmd, "elbo_batch")) {
+  const bool multi = !strcmp(cmd, "elbo_batch_multi");
+  if (multi && !g_comm) return raise("vbmc_hip:usage", "elbo_batch_multi needs 'comm_open' first");
+  if (multi || !strcmp(cmd, "elbo_batch")) {
     // (h, Theta, vp, Ns, compute_grad, compute_var, beta, thetabnd, seed): R = size(Theta,2) candidates that share
-    // vp's flags and its non-optimised groups; device MC stream keyed by (seed, r)
+    // vp's flags and its non-optimised groups; device MC stream keyed by (seed, r).  'elbo_batch_multi': h is the 1 x n handle
+    // vector of 'gp_upload_all' and the candidates are dealt over the n devices.
     vbmc_gp* h = (vbmc_gp*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[1]));
+    std::vector<const vbmc_gp*> hs;
+    if (multi) {
+      if ((int)mxGetNumberOfElements(prhs[1]) != vbmc_comm_local(g_comm)) return raise("vbmc_hip:usage", "elbo_batch_multi: one handle per device");
+      for (int i = 0; i < vbmc_comm_local(g_comm); ++i) hs.push_back((const vbmc_gp*)(uintptr_t)((uint64_t*)mxGetData(prhs[1]))[i]);
+    }
     const mxArray* Theta = prhs[2];
     vbmc_elbo_args a;
     std::vector<double> delta;
@@ -226,8 +312,13 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
       a.I_sk = mxGetDoubles(Isk);
       if (a.compute_var && nlhs > 7) { Jsjk = mxCreateNumericArray(4, d4, mxDOUBLE_CLASS, mxREAL); a.J_sjk = mxGetDoubles(Jsjk); }
     }
-    vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
-    if (st != VBMC_OK) return fail(st);
+    if (multi) {
+      vbmc_status st = vbmc_elbo_batch_multi(g_comm, hs.data(), &a);
+      if (st != VBMC_OK) return fail_comm(st);
+    } else {
+      vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
+      if (st != VBMC_OK) return fail(st);
+    }
     mxArray* outs[8] = {F, dF, vG, G, H, vss, Isk, Jsjk};
     for (int i = 0; i < 8 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
     return 0;

@@ -6,6 +6,8 @@ function score = vbmc_hip_sieve(calls,gp,elcbo_beta)
 % Candidates share K and the optimize_* flags (vbinit_vbmc builds them from one vp); those whose NON-optimised groups differ
 % go in separate sub-batches (those groups are not part of theta).  A candidate with a non-finite parameter is not sent
 % (the library validates the whole batch): its score is NaN, as the reference's arithmetic would give, and sorts last.
+% In a multi-device session the candidates of a sub-batch are dealt over the devices (r = g mod n) and their values
+% all-gathered over xGMI inside the library ('elbo_batch_multi'): bit-identical to the one-device pass.
 % If the device refuses a sub-batch (vbmc_hip:unsupported) its members are evaluated one by one through the
 % negelcbo_vbmc shim, which falls through to the reference on its own.
 R = numel(calls);
@@ -20,14 +22,15 @@ for i = 1:R
 end
 finite = all(isfinite(Theta),1);
 [~,~,grp] = unique(label,'stable');
-h = vbmc_hip_gp_handle(gp);
+ndev = vbmc_hip_mex('comm_size');                                      % > 1: VBMC_HIP_DEVICES / 'comm_open' (every GPU of the node)
+if ndev > 1; h = vbmc_hip_gp_handle(gp,'all'); batch = 'elbo_batch_multi'; else; h = vbmc_hip_gp_handle(gp); batch = 'elbo_batch'; end
 for g = 1:max(grp)
     members = find(grp(:)' == g & finite);
     if isempty(members); continue; end
     seed = 0;
     if c1.Ns > 0; seed = randi(2^31-1); end                           % device stream of this sub-batch
     try
-        [F,~,varG] = vbmc_hip_mex('elbo_batch',h,Theta(:,members),calls{members(1)}.vp,c1.Ns,0,double(c1.compute_var), ...
+        [F,~,varG] = vbmc_hip_mex(batch,h,Theta(:,members),calls{members(1)}.vp,c1.Ns,0,double(c1.compute_var), ...
             0,c1.thetabnd,seed);
         if ~c1.compute_var; varG = zeros(size(F)); end
         score(members) = F + elcbo_beta*sqrt(varG);

@@ -255,3 +255,40 @@ def test_errors_cross_the_boundary_as_matlab_ids(mex):
     assert e.value.identifier == "vbmc_hip:usage"
     mex.call(0, "gp_free", hh)
     assert mex.live_arrays() == 0
+
+
+def test_multi_device_session_commands(mex, va):
+    """'comm_open' (must precede every other command: here after `clear mex`), 'comm_size', 'gp_upload_all',
+    'elbo_batch_multi', 'gp_free_all' as matlab/vbmc_hip_sieve.m / vbmc_hip_gp_handle.m use them; one device on this box, so
+    the communicator has one rank -- the values must be those of 'elbo_batch'."""
+    from tests._mex import MexError
+
+    with pytest.raises(MexError) as e:
+        mex.call(1, "comm_open", 1)                     # a context exists already
+    assert e.value.identifier == "vbmc_hip:usage"
+    with pytest.raises(MexError) as e:
+        mex.call(1, "gp_upload_all", {"X": np.zeros((1, 1))})
+    assert e.value.identifier == "vbmc_hip:usage"
+    assert mex.call(1, "comm_size")[0][0, 0] == 1
+    mex.close()                                          # clear mex: the mexAtExit handler destroys the context
+    assert mex.call(1, "comm_open", 1)[0][0, 0] == 1
+    assert mex.call(1, "comm_size")[0][0, 0] == 1
+    p, gp, vp, theta = make(seed=10)
+    rng = np.random.default_rng(7)
+    Th = np.asfortranarray(theta[:, None] + 0.05 * rng.standard_normal((theta.size, 7)))
+    tb = bounds(vp, theta, rng)
+    tbp = {k: (np.asarray(v).reshape(-1) if k in ("lb", "ub") else v) for k, v in tb.items()}
+    hs = mex.call(1, "gp_upload_all", gp_struct(gp))[0]
+    assert hs.dtype == np.uint64 and hs.shape == (1, 1)
+    F, dF, varG = mex.call(3, "elbo_batch_multi", hs, Th, vp_struct(vp), 30, 0, 1, 0, tb, 77)
+    ref = va.negelcbo_batch(Th, 0, vp, gp, 30, False, 1, tbp, seed=77)
+    same(F[0], ref["F"]); same(varG[0], ref["varG"])
+    F, dF = mex.call(2, "elbo_batch_multi", hs, Th, vp_struct(vp), 30, 1, 0, 0, tb, 78)
+    ref = va.negelcbo_batch(Th, 0, vp, gp, 30, True, 0, tbp, seed=78)
+    same(F[0], ref["F"]); same(dF, ref["dF"])
+    # the single-device commands run on device 0 of the session with the first handle
+    (F1,) = mex.call(1, "elbo_batch", np.uint64(hs[0, 0]), Th, vp_struct(vp), 30, 0, 0, 0, tb, 78)
+    same(F1[0], ref["F"])
+    mex.call(0, "gp_free_all", hs)
+    mex.close()
+    mex.call(0, "open", 0)                               # leave a plain session behind for the fixture's teardown
