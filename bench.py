@@ -36,18 +36,24 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6  # dense fp64 peak of MI355X, MFMA f64 = vector f64 (256 CU x 128 flop/clk x 2.4 GHz); see DESIGN.md
 
 
-def synth_inputs(seed, D, N, K, S):
-    """Synthetic GP + VP of the headline shape: lumpy 12-component target."""
+def synth_inputs(seed, D, N, K, S, target="lumpy", noisy=False):
+    """Synthetic GP + VP of the headline shape: lumpy 12-component target (configs[2..4]) or the multivariate
+    Student-t log-density of configs[1] (nu = 5, scale diag(1:D)/D); `noisy` adds N(0,1) observation noise (configs[4])."""
     rng = np.random.default_rng(seed)
     X = 1.5 * rng.standard_normal((N, D))
-    nc = 12
-    mus = rng.uniform(-2, 2, size=(nc, D))
-    sig = rng.uniform(0.3, 1.0, size=nc)
-    wts = rng.dirichlet(np.ones(nc))
-    lp = np.stack([np.log(wts[i]) - 0.5 * np.sum(((X - mus[i]) / sig[i]) ** 2, axis=1) - D * np.log(sig[i])
-                   - 0.5 * D * np.log(2 * np.pi) for i in range(nc)])
-    mx = lp.max(axis=0)
-    y = mx + np.log(np.sum(np.exp(lp - mx), axis=0))
+    if target == "student":
+        y = -0.5 * (5.0 + D) * np.log1p(np.sum((X / (np.arange(1, D + 1) / D)) ** 2, axis=1) / 5.0)
+    else:
+        nc = 12
+        mus = rng.uniform(-2, 2, size=(nc, D))
+        sig = rng.uniform(0.3, 1.0, size=nc)
+        wts = rng.dirichlet(np.ones(nc))
+        lp = np.stack([np.log(wts[i]) - 0.5 * np.sum(((X - mus[i]) / sig[i]) ** 2, axis=1) - D * np.log(sig[i])
+                       - 0.5 * D * np.log(2 * np.pi) for i in range(nc)])
+        mx = lp.max(axis=0)
+        y = mx + np.log(np.sum(np.exp(lp - mx), axis=0))
+    if noisy:
+        y = y + rng.standard_normal(N)
     hyp = np.zeros((D + 2 + 2 * D + 1, S))
     for s in range(S):
         hyp[:D, s] = np.log(0.8) + 0.2 * rng.standard_normal(D)
@@ -275,6 +281,34 @@ def main():
     # and buffers resolved once; every step still moves theta H2D and (F, dF) D2H
     objective = vbmc_amd.PreparedObjective(T, Rr, 0, vp, gp, Ns, 0, None, engine=eng)
 
+    # N > 1: the restarts of ALL ranks form one batch of world x R candidates, identical on every rank, dealt r = g (mod world) by
+    # the library (vbmc_elbo_batch_multi): rank g evaluates its R restarts and the ELCBO values of all world x R are all-gathered
+    # device to device by RCCL reached from inside libvbmc_hip.so (no host hop, no torch tensor on the data path; torch.distributed
+    # only carries the 128-byte RCCL id at start-up and the timing rows at the end).  VBMC_BENCH_EXCHANGE=torch forces the round-2
+    # path (torch.distributed all_gather_into_tensor of the host vector) for A/B runs; it is also the fall-back if librccl cannot be
+    # opened from the library.
+    comm, gps_all, thetas_all, exchange = None, None, None, None
+    if world > 1 and not args.shard_s:
+        exchange = "torch.distributed all_gather_into_tensor"
+        # (gloo = ranks sharing one device for a functional check: RCCL refuses two ranks on a device)
+        if os.environ.get("VBMC_BENCH_EXCHANGE", "library") != "torch" and backend == "nccl":
+            try:
+                from vbmc_amd.multi import Comm
+
+                comm = Comm.from_torch(eng.ctx)
+                gps_all = comm.upload_gp(gp)
+                thetas_all = np.asfortranarray(theta0[:, None] + 0.05 * np.random.default_rng(100).standard_normal((T, Rr * world)))
+                exchange = "ncclAllGather inside libvbmc_hip.so (vbmc_elbo_batch_multi)"
+            except Exception as e:  # noqa: BLE001
+                comm = None
+                exchange += " (library communicator unavailable: %s)" % str(e)[:120]
+
+    def multi_step(i, batch):
+        o = comm.negelcbo_batch(batch, 0, vp, gps_all, Ns, True, 0, seed=i, outputs=("F", "dF"))
+        np.argsort(o["F"], kind="stable")     # every rank: the identical sieve order (misc/vpsieve_vbmc.m:82)
+        mine = np.arange(batch.shape[1])[rank::world]
+        return {"F": o["F"], "dF": o["dF"][:, mine]}
+
     shard_ex = None
     if args.shard_s and world > 1:
         from vbmc_amd.dist import ShardExchange
@@ -286,6 +320,8 @@ def main():
         if shard_ex is not None:
             o = vbmc_amd.negelcbo_shard(thetas, 0, vp, gp, Ns, True, None, rank=rank, world=world, exchange=shard_ex, seed=i, engine=eng)
             return {"F": o["F"], "dF": o["dF"]}, None
+        if comm is not None:
+            return multi_step(i, thetas_all), None
         F_, dF_ = objective(thetas, seed=(rank << 32) + i)
         out = {"F": F_, "dF": dF_}
         if world > 1:
@@ -300,7 +336,7 @@ def main():
     # vbmc_elbo_collect, two batches in flight: the host stages theta of step i + 1 while the device works on step i.  Every
     # step still moves its theta H2D, runs the full pass and moves (F, dF) D2H, and every step's results are consumed (the
     # all-gather + sort of the sieve when world > 1) before the timed region ends.  --sync-steps: one blocking call per step.
-    pipelined = shard_ex is None and not args.sync_steps
+    pipelined = shard_ex is None and comm is None and not args.sync_steps
 
     def finish(slot):
         F_, dF_ = objective.collect(slot)
@@ -339,6 +375,27 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # ---- strong scaling (BASELINE configs[3]: the SAME 64 restarts over the GPUs): R restarts in total, R / world per rank
+    strong = None
+    if comm is not None and Rr >= world:
+        batch = np.ascontiguousarray(thetas_all[:, :Rr], dtype=np.float64)
+        batch = np.asfortranarray(batch)
+        for i in range(3):
+            multi_step(5000 + i, batch)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            multi_step(6000 + i, batch)
+        torch.cuda.synchronize()
+        dist.barrier()
+        strong_s = time.perf_counter() - t1
+        ts = torch.tensor([strong_s], dtype=torch.float64, device=cdev)
+        alls = torch.empty(world, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(alls, ts)
+        strong_s = float(alls.max())
+        strong = {"value": Rr * args.steps / strong_s, "unit": "evals/s", "scaling": "strong", "restarts_total": Rr,
+                  "restarts_per_gpu": Rr / world, "ms_per_step": 1e3 * strong_s / args.steps, "steps": args.steps}
     rank_rows = [[float(rank), float(gpu), elapsed]]
     if world > 1:
         mine = torch.tensor(rank_rows[0], dtype=torch.float64, device=cdev)
@@ -502,6 +559,52 @@ def main():
                 aux[name] = v
         aux["gplite_pred_8192_gflop"] = S * 8192.0 * N * N / 1e9    # S N* N^2 flops: two per multiply-add of the triangle inv(L') (sW Ks)
 
+    def shape_leg(D_, N_, K_, Ns_, S_, R_, target, noisy, nsteps):
+        """another BASELINE configuration on this GPU, same stepping as the headline (pipelined independent batches), with the
+        HIP-event duration of its entropy kernel and the fraction of the fp64 peak that makes"""
+        inp_ = synth_inputs(0, D_, N_, K_, S_, target, noisy)
+        s2_ = np.ones(N_) if noisy else None
+        gp_ = vbmc_amd.gplite_post(inp_["hyp"], inp_["X"], inp_["y"], 1, 4, (1, 1, 0) if noisy else (1, 0, 0), s2_, need_L=False, engine=eng)
+        vp_ = vbmc_amd.make_vp(inp_["mu"], inp_["sigma"], inp_["lam"], eta=inp_["eta"])
+        vp_["w"] = np.exp(inp_["eta"]) / np.sum(np.exp(inp_["eta"]))
+        th0 = np.concatenate([inp_["mu"].reshape(-1, order="F"), np.log(inp_["sigma"]), np.log(inp_["lam"]), inp_["eta"]])
+        th = np.asfortranarray(th0[:, None] + 0.05 * np.random.default_rng(100).standard_normal((th0.size, R_)))
+        obj = vbmc_amd.PreparedObjective(th0.size, R_, 0, vp_, gp_, Ns_, 0, None, engine=eng)
+        for _ in obj.stream([th] * 3, seeds=[1, 2, 3]):
+            pass
+        t1 = time.perf_counter()
+        for F_, dF_ in obj.stream([th] * nsteps, seeds=list(range(10, 10 + nsteps))):
+            pass
+        dt_ = time.perf_counter() - t1
+        assert np.all(np.isfinite(F_)) and np.all(np.isfinite(dF_))
+        eng.ctx.set_profiling(True)
+        ems = []
+        for i in range(5):
+            vbmc_amd.negelcbo_batch(th, 0, vp_, gp_, Ns_, True, 0, seed=50 + i, engine=eng, outputs=("F", "dF"))
+            ems.append(eng.ctx.last_kernel_ms()[0])
+        eng.ctx.set_profiling(False)
+        M_ = Ns_ + (Ns_ % 2)
+        f_ent, _, _ = algorithmic_flops(D_, K_, M_, S_, N_)
+        ach = R_ * f_ent / (float(np.mean(ems)) * 1e-3) / 1e12
+        return {"workload": "D=%d N=%d K=%d Ns=%d/component S=%d, R=%d, %s target%s" % (D_, N_, K_, Ns_, S_, R_, target, ", noisy (s2 = 1)" if noisy else ""),
+                "evals_per_s": R_ * nsteps / dt_, "ms_per_step": 1e3 * dt_ / nsteps, "kernel": entropy_kernel_label(D_, K_),
+                "entropy_kernel_ms": float(np.mean(ems)), "achieved_TFLOPs": ach, "frac": ach / FP64_PEAK_TFLOPS}
+
+    def small_batch_leg():
+        """BASELINE configs[3] is the SAME 64 restarts over 8 GPUs: 64 / G per device.  The rate of one device at R = 32, 16, 8 says
+        what G = 2, 4, 8 devices can reach before a node is there (strong-scaling bound: G x rate(64 / G) / rate(64))."""
+        out_ = {}
+        for Rc in (32, 16, 8):
+            obj = vbmc_amd.PreparedObjective(T, Rc, 0, vp, gp, Ns, 0, None, engine=eng)
+            th = np.asfortranarray(thetas[:, :Rc])
+            for _ in obj.stream([th] * 4, seeds=[1, 2, 3, 4]):
+                pass
+            t1 = time.perf_counter()
+            for _ in obj.stream([th] * 20, seeds=list(range(10, 30))):
+                pass
+            out_["restarts_%d_evals_per_s" % Rc] = Rc * 20 / (time.perf_counter() - t1)
+        return out_
+
     def sync_leg():
         """the same steps as one blocking call each (round 1's stepping): what a DEPENDENT sequence of batches gets"""
         n = max(5, min(args.steps, 20))
@@ -527,6 +630,14 @@ def main():
         if v is not None:
             aux["eps_streamed"] = v
         gp_legs(aux)
+        aux.update(leg("aux.small_batches", small_batch_leg) or {})
+        if (D, N, K, Ns, S) == (10, 400, 50, 10000, 20):     # the other single-GPU configurations of BASELINE.json, beside the headline
+            v = leg("aux.config1", lambda: shape_leg(6, 200, 10, 1000, 8, 64, "student", False, 20))
+            if v is not None:
+                aux["config1"] = v
+            v = leg("aux.config4", lambda: shape_leg(20, 800, 100, 20000, 20, 16, "lumpy", True, 6))
+            if v is not None:
+                aux["config4"] = v
         extra["aux"] = aux
     elif rank == 0 and args.eps_stream:
         extra["eps_streamed"] = leg("eps_streamed", eps_leg)
@@ -549,7 +660,8 @@ def main():
                                    "value+gradient, beta=0, no variance" % (3 if world > 1 else 2, D, N, K, Ns, S, Rr),
                        "restarts_per_gpu": Rr,
                        "parallelism": ("hyper-sample x sample-chunk sharded x%d (one batch of %d), all-gather of the partial records" % (world, Rr))
-                       if shard_ex is not None else "restart-sharded x%d, all-gather of ELCBO" % world,
+                       if shard_ex is not None else ("restart-sharded x%d (restart r on rank r mod %d), all-gather of ELCBO" % (world, world)
+                                                     if world > 1 else "one GPU"),
                        "stepping": ("pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, two in flight; every step moves "
                                     "its theta H2D and its (F, dF) D2H" if pipelined else "one blocking vbmc_elbo_batch call per step")},
             "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if world > 1 else None),
@@ -557,6 +669,9 @@ def main():
             "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if world > 1:
+            line["exchange"] = exchange
+            line["strong"] = strong
         line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
