@@ -13,11 +13,39 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
+def _host_stamp():
+    """The Makefile compiles with -march=native: a library built on another machine (the development container's build travels
+    to the GPU box with the snapshot) may use instructions this host lacks, and would be the wrong baseline anyway.  The stamp is
+    the CPU model and its flag set."""
+    import hashlib
+
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [ln for ln in txt.split("\n") if ln.startswith(("model name", "flags"))][:2]
+        return hashlib.sha256("\n".join(keep).encode()).hexdigest()[:16]
+    except OSError:
+        return "unknown"
+
+
+def ensure_built():
+    """Build (or rebuild, when the existing build was made on a different CPU) the two libraries for THIS host."""
+    build = os.path.join(_HERE, "_build")
+    stamp_file = os.path.join(build, "host_stamp")
+    stamp = _host_stamp()
+    have = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
+    libs = [os.path.join(build, n) for n in ("liboracle.so", "liboracle_omp.so")]
+    src = os.path.join(_HERE, "vbmc_oracle.c")
+    stale = have != stamp or not all(os.path.exists(p) and os.path.getmtime(p) >= os.path.getmtime(src) for p in libs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
+        with open(stamp_file, "w") as f:
+            f.write(stamp)
+
+
 def load(openmp=False):
     name = "liboracle_omp.so" if openmp else "liboracle.so"
     path = os.path.join(_HERE, "_build", name)
-    if not os.path.exists(path):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+    ensure_built()
     lib = C.CDLL(path)
     lib.oracle_num_threads.restype = C.c_int
     if openmp:
