@@ -111,6 +111,8 @@ static int ensure_ctx(int device) {
   return 0;
 }
 
+// device handles travel as uint64 scalars; anything else (a double that lost its class on the way) must not be dereferenced
+static bool is_handle(const mxArray* a) { return a && mxGetClassID(a) == mxUINT64_CLASS && mxGetNumberOfElements(a) >= 1; }
 static const double* dbl(const mxArray* a) { return (a && !mxIsEmpty(a)) ? mxGetDoubles(a) : nullptr; }
 static const mxArray* field(const mxArray* s, const char* name) { return mxGetField(s, 0, name); }
 static double scalar_field(const mxArray* s, const char* name, double dflt) {
@@ -190,6 +192,13 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     return 0;
   }
   if (ensure_ctx(0)) return 1;
+  {  // commands whose first argument is a device handle (the IQR evaluation takes two)
+    const char* with_handle[] = {"gp_free", "elbo", "elbo_batch", "elbo_batch_multi", "adam", "gp_rank1", "acq", "is_create", "is_free",
+                                 "acq_iqr", "gp_pred", "gp_free_all"};
+    for (const char* w : with_handle)
+      if (!strcmp(cmd, w) && (nrhs < 2 || !is_handle(prhs[1]) || (!strcmp(cmd, "acq_iqr") && (nrhs < 3 || !is_handle(prhs[2])))))
+        return raise("vbmc_hip:usage", "this command takes a uint64 device handle as its first argument");
+  }
 
   if (!strcmp(cmd, "gp_upload")) {
     GpArrays g;

@@ -89,6 +89,8 @@ class Mex:
         if isinstance(v, np.uint64):
             return self._numeric(np.array([[v]], dtype=np.uint64), mxUINT64)
         a = np.asarray(v)
+        if a.dtype == np.uint64:                      # handle vectors keep their class, as in MATLAB
+            return self._numeric(a.reshape(1, -1) if a.ndim < 2 else a, mxUINT64)
         if a.dtype == np.bool_ and a.size == 1:
             return L.mxCreateLogicalScalar(bool(a.reshape(-1)[0]))
         a = np.asarray(a, dtype=np.float64)

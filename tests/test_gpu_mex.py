@@ -57,8 +57,13 @@ def vp_struct(vp):
 
 
 def bounds(vp, theta, rng):
-    T = theta.size
-    return {"lb": (theta - np.abs(rng.standard_normal(T)) * 0.3).reshape(-1, 1), "ub": (theta + np.abs(rng.standard_normal(T)) * 0.3 - 0.1).reshape(-1, 1),
+    """thetabnd of misc/vpbounds.m: bounds on the EXTENDED vector [mu(:); ln sigma_k + ln lambda_d (D x K); eta], a few violated."""
+    D, K = vp["D"], vp["K"]
+    ext = np.concatenate([vp["mu"].reshape(-1, order="F"), (np.log(vp["sigma"])[None, :] + np.log(vp["lambda"])[:, None]).reshape(-1, order="F"),
+                          vp["eta"]])
+    n = ext.size
+    assert n == 2 * D * K + K
+    return {"lb": (ext - np.abs(rng.standard_normal(n)) * 0.3).reshape(-1, 1), "ub": (ext + np.abs(rng.standard_normal(n)) * 0.3 - 0.1).reshape(-1, 1),
             "TolCon": 0.01, "WeightThreshold": 0.15, "WeightPenalty": 0.3}
 
 
@@ -82,16 +87,22 @@ def test_elbo_with_host_draws_all_twelve_outputs(mex, va):
     h = mex.call(1, "gp_upload", gp_struct(gp))[0]
     assert h.dtype == np.uint64 and h.shape == (1, 1)
     hh = np.uint64(h[0, 0])
-    out = mex.call(12, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 2, 1, 0.7, tb, eps_m, 0, S)
-    F, dF, G, H, varG, dH, varGss, I_sk, J_sjk, dG, G_s, varG_s = out
     tbp = {k: (np.asarray(v).reshape(-1) if k in ("lb", "ub") else v) for k, v in tb.items()}
-    ref = va.negelcbo_batch(theta, 0.7, vp, gp, Ns, True, 2, tbp, separate_K=True, eps=eps, eps_shared=True,
-                            outputs=("F", "dF", "G", "H", "dG", "dH", "varG", "varGss", "I_sk", "J_sjk", "G_s", "varG_s"))
-    assert F.shape == (1, 1) and dF.shape == (theta.size, 1) and I_sk.shape == (S, K) and J_sjk.shape == (S, K, K)
-    assert G_s.shape == (1, S) and varG_s.shape == (1, S)
+    # (a) value + gradient with the diagonal variance and its gradient (beta ~= 0 needs compute_var = 2), bounds, host draws
+    out = mex.call(10, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 2, 0, 0.7, tb, eps_m, 0, S)
+    F, dF, G, H, varG, dH, varGss, I_sk, J_sjk, dG = out
+    ref = va.negelcbo_batch(theta, 0.7, vp, gp, Ns, True, 2, tbp, eps=eps, eps_shared=True)
+    assert F.shape == (1, 1) and dF.shape == (theta.size, 1) and I_sk.size == 0 and J_sjk.size == 0
     same(F[0, 0], ref["F"][0]); same(G[0, 0], ref["G"][0]); same(H[0, 0], ref["H"][0])
     same(varG[0, 0], ref["varG"][0]); same(varGss[0, 0], ref["varGss"][0])
     same(dF[:, 0], ref["dF"][:, 0]); same(dH[:, 0], ref["dH"][:, 0]); same(dG[:, 0], ref["dG"][:, 0])
+    # (b) value only with the full variance, the per-component terms (separate_K) and the per-hyper-sample outputs: 12 outputs
+    out = mex.call(12, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), Ns, 0, 1, 1, 0, None, eps_m, 0, S)
+    F, dF, G, H, varG, dH, varGss, I_sk, J_sjk, dG, G_s, varG_s = out
+    ref = va.negelcbo_batch(theta, 0, vp, gp, Ns, False, 1, None, separate_K=True, eps=eps, eps_shared=True,
+                            outputs=("F", "G", "H", "varG", "varGss", "I_sk", "J_sjk", "G_s", "varG_s"))
+    assert dF.size == 0 and I_sk.shape == (S, K) and J_sjk.shape == (S, K, K) and G_s.shape == (1, S) and varG_s.shape == (1, S)
+    same(F[0, 0], ref["F"][0]); same(G[0, 0], ref["G"][0]); same(H[0, 0], ref["H"][0]); same(varG[0, 0], ref["varG"][0])
     same(I_sk, ref["I_sk"][:, :, 0]); same(J_sjk, ref["J_sjk"][:, :, :, 0])
     same(G_s[0], ref["G_s"][:, 0]); same(varG_s[0], ref["varG_s"][:, 0])
     # value only, one output, no bounds, device RNG keyed by the seed argument
@@ -212,7 +223,7 @@ def test_acquisition_commands(mex, va):
     rng = np.random.default_rng(5)
     Xs = np.asfortranarray(rng.standard_normal((50, D)))
     gl = np.exp(0.1 * rng.standard_normal(D))
-    gp2 = dict(gp, X_rescaled=gp["X"] / gl[None, :], sn2new=np.array([np.exp(2 * q["hyp"][gp["Ncov"]]) for q in gp["post"]]))
+    gp2 = dict(gp, X_rescaled=gp["X"] / gl[None, :], sn2new=0.02 + 0.05 * rng.random(gp["X"].shape[0]))      # noise at the training points (N)
     Xa = np.asfortranarray(rng.standard_normal((24, D)))
     st = {"ymax": float(np.max(gp["y"])), "VarianceRegularizedAcqFcn": True, "TolGPVar": 1e-4, "gplengthscale": gl,
           "ActiveImportanceSampling": {"Xa": Xa}}
@@ -250,6 +261,9 @@ def test_errors_cross_the_boundary_as_matlab_ids(mex):
     with pytest.raises(MexError) as e:
         mex.call(1, "elbo", hh, th.reshape(-1, 1), vp_struct(vp), 10, 0, 0, 0, 0, None, None, 1, 3)
     assert e.value.identifier == "vbmc_hip:error" and "non-finite" in e.value.message
+    with pytest.raises(MexError) as e:                   # a handle that lost its class (a double) is refused, not dereferenced
+        mex.call(1, "elbo", float(hh), theta.reshape(-1, 1), vp_struct(vp), 10, 0, 0, 0, 0, None, None, 1, 3)
+    assert e.value.identifier == "vbmc_hip:usage"
     with pytest.raises(MexError) as e:
         mex.call(1, "no_such_command")
     assert e.value.identifier == "vbmc_hip:usage"
