@@ -21,6 +21,11 @@ VARIANTS = {"base": [], "norng": ["-DVBMC_EXP_NORNG"], "noexp": ["-DVBMC_EXP_NOE
 
 
 def build(qs=3):
+    only = os.environ.get("VBMC_EXP_ONLY")          # comma-separated subset of the variants
+    if only:
+        for k in list(VARIANTS):
+            if k not in only.split(","):
+                del VARIANTS[k]
     os.makedirs(EXP, exist_ok=True)
     others = [os.path.join(OBJ, "vbmc_hip.o")] + [os.path.join(OBJ, "ent_mfma_qs%d.o" % q) for q in range(1, 10) if q != qs]
     procs = []
