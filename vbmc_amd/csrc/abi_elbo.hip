@@ -713,8 +713,12 @@ __global__ void __launch_bounds__(256) k_shard_scatter(int R, int S, int K, int 
   }
 }
 
+// pend / pend_iter: the Adam update of iteration pend_iter rides on this pass's k_prep.  fuse / fuse_iter: this pass's
+// finalize kernel applies the Adam update of iteration fuse_iter and unpacks the new theta for the NEXT pass, which is then
+// enqueued with skip_prep (the on-device optimiser loop: one launch per iteration less, vbmc_adam_batch).
 static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan& P, unsigned long long seed,
-                                const AdamState* pend = nullptr, int pend_iter = 0, const ShardSpec* shp = nullptr) {
+                                const AdamState* pend = nullptr, int pend_iter = 0, const ShardSpec* shp = nullptr,
+                                const AdamState* fuse = nullptr, int fuse_iter = 0, bool skip_prep = false) {
   const ElboDims& dm = P.dm;
   const int D = dm.D, K = dm.K, R = dm.R, S = dm.S, T = dm.T;
   const int dt = P.dt;
@@ -729,9 +733,11 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const size_t prep_lds = ((size_t)D * K + 3 * K + D + 8) * sizeof(double);
   if (prep_lds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-  hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), prep_lds, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
-                     pend ? pend_iter : 0, (const double*)P.d_out);
-  LAUNCH_CHECK(ctx, "k_prep");
+  if (!skip_prep) {
+    hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), prep_lds, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
+                       pend ? pend_iter : 0, (const double*)P.d_out);
+    LAUNCH_CHECK(ctx, "k_prep");
+  }
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
   const bool fork = sh.mode == 0 && ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
@@ -902,9 +908,18 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     fa.stage = 0;
     if (lds + stage_vp <= 96 * 1024) { fa.stage |= 2; lds += stage_vp; }
     if (lds + stage_rec <= 96 * 1024) { fa.stage |= 1; lds += stage_rec; }
-    if (lds > 64 * 1024)
+    // k_finalize_ws: the wave-specialised form (one barrier instead of ~18; round 3); VBMC_FIN=seq keeps the sequential kernel
+    // for A/B runs.  Only the wave-specialised kernel carries the fused Adam update + unpacking of the next iteration.
+    static const bool fin_seq = [] { const char* e = getenv("VBMC_FIN"); return e && !strcmp(e, "seq"); }();
+    if (fuse && !fin_seq) {
+      fa.next_iter = fuse_iter; fa.next_A = *fuse; fa.next_theta = P.d_theta; fa.next_vpfix = P.d_fix; fa.next_vpd = P.d_vpd; fa.next_entp = P.d_entp;
+    }
+    if (lds > 64 * 1024) {
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (fin_seq) hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+    else hipLaunchKernelGGL(k_finalize_ws, dim3(R), dim3(FIN_THREADS), lds, st, fa);
     LAUNCH_CHECK(ctx, "k_finalize");
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -1243,14 +1258,25 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   HIP_TRY(ctx, hipMemsetAsync(A.done, 0, (size_t)R * sizeof(int), st));
   std::vector<int> done(R, 0);
   int iter = 0;
-  bool pending = false;   // the update of iteration iter - 1 rides on this iteration's k_prep
+  // Where the NEXT iteration follows without a stopping test in between, this iteration's finalize kernel applies the Adam update
+  // and unpacks the new theta itself (k_finalize_ws: fused), and the next pass starts at its log-joint kernel; before a stopping
+  // test (every 20 iterations from the 40th, utils/fminadam.m:65) and at the end the update is a launch of its own.
+  static const bool fusable = [] { const char* e = getenv("VBMC_FIN"); return !(e && !strcmp(e, "seq")) && !(getenv("VBMC_ADAM_FUSE") && !strcmp(getenv("VBMC_ADAM_FUSE"), "0")); }();
+  bool prepped = false;   // the previous pass has already applied its update and unpacked theta for this one
+  bool pending = false;   // (round-2 schedule) the update of iteration iter - 1 rides on this iteration's k_prep
   for (iter = 1; iter <= MaxIter; ++iter) {
-    { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, pending ? &A : nullptr, iter - 1); if (s_) return s_; }
-    pending = true;
     const bool check = iter % 20 == 0 && iter >= 40;
-    if (check || iter == MaxIter) {   // the stopping test and the final read-back need this iteration's update now
-      hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
-      pending = false;
+    const bool last = check || iter == MaxIter;
+    const bool fuse = fusable && !last;
+    if (fusable) {
+      { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, nullptr, 0, nullptr, fuse ? &A : nullptr, iter, prepped); if (s_) return s_; }
+      prepped = fuse;
+      // the stopping test and the final read-back need this iteration's update now; the next pass unpacks theta itself
+      if (!fuse) hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
+    } else {   // round-2 schedule (A/B runs): the update of iteration iter - 1 rides on this iteration's k_prep
+      { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, pending ? &A : nullptr, iter - 1); if (s_) return s_; }
+      pending = true;
+      if (last) { hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out); pending = false; }
     }
     if (check) {
       hipLaunchKernelGGL(k_adam_check, dim3(R), dim3(256), 0, st, A, iter);

@@ -67,17 +67,13 @@ __device__ inline void adam_update_chain(const AdamState& A, int iter, double* _
 // k_prep: unpack theta exactly as misc/negelcbo_vbmc.m:33-48 does.  Inside the on-device optimiser loop the Adam update
 // of the previous iteration (adam_iter > 0) is applied first by the same workgroup, which saves one launch per iteration.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ theta,
-                                              const double* __restrict__ vpfix,  // mu sigma lambda w (fixed vp) packed
-                                              double* __restrict__ vpd, double* __restrict__ entp, AdamState A, int adam_iter,
-                                              const double* __restrict__ prev_out) {
-  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+// the body of k_prep for restart r, by whichever workgroup calls it (k_prep, or k_finalize_ws for the NEXT iteration of the
+// on-device optimiser loop); sh: dynamic LDS of D K + 3 K + D doubles + one per wave
+__device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ theta, const double* __restrict__ vpfix,
+                                 double* __restrict__ vpd, double* __restrict__ entp, int r, double* sh) {
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int D = dm.D, K = dm.K;
   VpLayout L{D, K};
-  if (adam_iter > 0) {
-    adam_update_chain(A, adam_iter, theta, prev_out, r);
-    __syncthreads();
-  }
   const double* th = theta + (size_t)r * dm.T;
   double* v = vpd + (size_t)r * L.stride();
   const double* fmu = vpfix;
@@ -85,7 +81,6 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
   const double* flam = fsig + K;
   const double* fw = flam + D;
   // the unpacked record is kept in LDS as well, so that the later phases do not wait for their own global writes
-  extern __shared__ double sh[];
   double* s_mu = sh;               // D x K
   double* s_sig = s_mu + D * K;    // K
   double* s_lnsig = s_sig + K;     // K
@@ -132,6 +127,18 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
     else val = s_w[k] / (sg * sg);
     ep[i] = val;
   }
+}
+
+__global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ theta,
+                                              const double* __restrict__ vpfix,  // mu sigma lambda w (fixed vp) packed
+                                              double* __restrict__ vpd, double* __restrict__ entp, AdamState A, int adam_iter,
+                                              const double* __restrict__ prev_out) {
+  extern __shared__ double sh[];
+  if (adam_iter > 0) {
+    adam_update_chain(A, adam_iter, theta, prev_out, blockIdx.x);
+    __syncthreads();
+  }
+  prep_body(dm, theta, vpfix, vpd, entp, blockIdx.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -776,6 +783,15 @@ struct FinArgs {
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* big;            // null, or R x (3T + DK) doubles of global scratch for dG | dH | dP | gsc when they exceed the LDS
   double* out;            // R x (OUT_HDR + 3T)
+  // on-device optimiser loop (k_finalize_ws): after this iteration's results, the same workgroup applies the Adam update
+  // (next_iter > 0: utils/fminadam.m:48-61 for iteration next_iter) and unpacks the NEW theta for the next iteration (k_prep's
+  // body) -- one launch per iteration less, and the next iteration's first kernel starts from records that are already there
+  int next_iter;
+  AdamState next_A;
+  double* next_theta;
+  const double* next_vpfix;
+  double* next_vpd;
+  double* next_entp;
 };
 
 #define FIN_THREADS 1024
@@ -1040,5 +1056,272 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize(FinArgs a) {
       o[OUT_HDR + T + i] = dG[i];
       o[OUT_HDR + 2 * T + i] = dH[i];
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize_ws: the same arithmetic as k_finalize, organised for LATENCY (round 3).  k_finalize runs its sections one after the
+// other with every thread of the workgroup and a workgroup barrier (or a two-barrier block sum) between them: ~18 barriers of
+// 1024 threads, 16 us for one restart -- the second-longest kernel of a single Adam chain.  Here every section is ONE WAVE's
+// task: the inputs are staged in LDS once, each wave computes the outputs of its task from them with wave-level sums only
+// (the few scalars a task needs from another section -- G, the entropy means, the weight-gradient dot product -- it
+// recomputes itself: O(K) or O(K^2 / 64) work), and the waves meet at ONE barrier before the assembly.  Sums over components
+// run over the 64 lanes of a wave in a fixed order (butterfly), so results stay run-to-run identical; they differ from
+// k_finalize's in the last bits only where the order of a sum differs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
+  extern __shared__ double lds[];
+  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+  const ElboDims& dm = a.dm;
+  const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
+  VpLayout L{D, K};
+  const double* v = a.vpd + (size_t)r * L.stride();
+  const double* bnd = a.bnd;
+  double* red = lds;           // nt   (unused here; same layout as k_finalize so that the host sizes one LDS block)
+  double* Ibar = red + nt;     // K    (unused)
+  double* Hj = Ibar + K;       // K    (unused)
+  double* wraw = Hj + K;       // K    raw w-gradient of H (task 5's own scratch)
+  double* bigr = a.big ? a.big + (size_t)r * (3 * (size_t)T + (size_t)D * K) : nullptr;
+  double* dG = bigr ? bigr : wraw + K;       // T (packed)
+  double* dH = dG + T;         // T
+  double* dP = dH + T;         // T   penalty gradient
+  double* scal = bigr ? wraw + K : dP + T;   // 8 scalars: G, H, three partial penalties
+  double* gsc = bigr ? dP + T : scal + 8;    // D x K   soft-bound gradient of the lnscale block per (d, k)  (task 7's own scratch)
+  double* stg = bigr ? scal + 8 : gsc + D * K;
+  if (a.stage & 2) {
+    stage_copy(stg, v, L.stride(), tid, nt);
+    v = stg;
+    stg += L.stride();
+    if (a.has_bnd) {
+      const int next_mu = dm.opt[0] ? D * K : 0;
+      const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
+      stage_copy(stg, a.bnd, 2 * Text, tid, nt);
+      bnd = stg;
+      stg += 2 * Text;
+    }
+  }
+  const double* w = v + L.w();
+  const double* sigma = v + L.sigma();
+  const double* lam = v + L.lambda();
+  double* o = a.out + (size_t)r * (OUT_HDR + 3 * T);
+  const int LJS = 2 * D + 2;
+  const double invS = 1.0 / S;
+  const double* lb = a.ljbar + (size_t)r * K * LJS;
+  const double* pe = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;   // (C = 1: reduced records)
+  if (a.stage & 1) {
+    double* lbL = stg;
+    double* peL = lbL + K * LJS;
+    stage_copy(lbL, lb, K * LJS, tid, nt);
+    if (pe) stage_copy(peL, pe, K * a.C * a.ncol, tid, nt);
+    lb = lbL;
+    if (pe) pe = peL;
+  }
+  for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
+  if (tid < 8) scal[tid] = 0.0;
+  __syncthreads();
+
+  const bool grad = a.want_grad != 0;
+  const double lognf = v[L.lognf()];
+  const double invM = a.entpart ? 1.0 / (2.0 * a.M) : 0.0;
+  const int ncol = a.ncol;
+  const double* eb = a.entpart ? nullptr : a.entlb + (size_t)r * (1 + D * K + 2 * K + D);
+  const int next_mu = dm.opt[0] ? D * K : 0;
+  const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
+  const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
+  const double* blo = bnd;
+  const double* bup = bnd ? bnd + Text : nullptr;
+
+  for (int task = wave; task < 9; task += nw) {
+    switch (task) {
+      case 0: {   // G (:203,:400), the sigma / lambda / eta blocks of its gradient (:356,:362,:366-368)
+        double part = 0.0;
+        for (int k = lane; k < K; k += 64) part += w[k] * (lb[(size_t)k * LJS] * invS);
+        const double G = wave_sum(part);
+        if (lane == 0) scal[0] = G;
+        if (grad) {
+          if (dm.opt[1])
+            for (int k = lane; k < K; k += 64) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * sigma[k] * invS;
+          if (dm.opt[3])
+            for (int k = lane; k < K; k += 64) { const double Ib = lb[(size_t)k * LJS] * invS; dG[dm.off_eta + k] = w[k] * Ib - w[k] * G; }
+          if (dm.opt[2])
+            for (int d = 0; d < D; ++d) {
+              double acc = 0.0;
+              for (int k = lane; k < K; k += 64) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
+              acc = wave_sum(acc);
+              if (lane == 0) dG[dm.off_lambda + d] = acc * lam[d] * invS;
+            }
+        }
+      } break;
+      case 1:     // mu block of dG
+        if (grad && dm.opt[0])
+          for (int p = lane; p < D * K; p += 64) dG[dm.off_mu + p] = lb[(size_t)(p / D) * LJS + 1 + p % D] * invS;
+        break;
+      case 2: {   // H (:67) and the sigma block of its gradient (:88,:113)
+        if (pe) {
+          double part = 0.0;
+          for (int j = lane; j < K; j += 64) part -= w[j] * (lognf + pe[(size_t)j * ncol] * invM);
+          const double H = wave_sum(part);
+          if (lane == 0) scal[1] = H;
+          if (grad && dm.opt[1])
+            for (int j = lane; j < K; j += 64) dH[dm.off_sigma + j] = w[j] * pe[(size_t)j * ncol + 1 + D] * invM * sigma[j];
+        } else {
+          if (lane == 0) scal[1] = eb[0];
+          if (grad && dm.opt[1]) for (int k = lane; k < K; k += 64) dH[dm.off_sigma + k] = eb[1 + D * K + k];
+        }
+      } break;
+      case 3:     // mu block of dH (:82)
+        if (grad && dm.opt[0]) {
+          if (pe)
+            for (int p = lane; p < D * K; p += 64) {
+              const int d = p % D, j = p / D;
+              dH[dm.off_mu + p] = w[j] * pe[(size_t)j * ncol + 1 + d] * invM / lam[d];
+            }
+          else
+            for (int p = lane; p < D * K; p += 64) dH[dm.off_mu + p] = eb[1 + p];
+        }
+        break;
+      case 4:     // lambda block of dH (:93; the /lambda of lsum cancels the *lambda of :107)
+        if (grad && dm.opt[2]) {
+          if (pe)
+            for (int d = 0; d < D; ++d) {
+              double acc = 0.0;
+              for (int j = lane; j < K; j += 64) acc += w[j] * sigma[j] * pe[(size_t)j * ncol + 2 + D + d] * invM;
+              acc = wave_sum(acc);
+              if (lane == 0) dH[dm.off_lambda + d] = acc;
+            }
+          else
+            for (int d = lane; d < D; d += 64) dH[dm.off_lambda + d] = eb[1 + D * K + K + d];
+        }
+        break;
+      case 5:     // eta block of dH: raw weight gradient (:97-100), then the softmax Jacobian (:121-123)
+        if (grad && dm.opt[3]) {
+          double dpart = 0.0;
+          for (int l0 = 0; l0 < K; l0 += 64) {
+            const int l = l0 + lane;
+            double wr = 0.0;
+            if (l < K) {
+              if (pe) {
+                double acc = 0.0;
+                for (int j = 0; j < K; ++j) acc += w[j] * pe[(size_t)j * ncol + 2 + 2 * D + l] * invM;   // lane <-> l: no cross-lane sum
+                wr = -(lognf + pe[(size_t)l * ncol] * invM) - acc;
+              } else {
+                wr = eb[1 + D * K + K + D + l];
+              }
+              wraw[l] = wr;
+              dpart += w[l] * wr;
+            }
+          }
+          const double dot = wave_sum(dpart);
+          wave_fence();
+          for (int l = lane; l < K; l += 64) dH[dm.off_eta + l] = w[l] * wraw[l] - w[l] * dot;
+        }
+        break;
+      case 6:     // soft bounds, mu block (vpbndloss.m, softbndloss.m)
+        if (a.has_bnd && dm.opt[0]) {
+          double part = 0.0;
+          for (int p = lane; p < D * K; p += 64) {
+            const double x = v[L.mu() + p], l = blo[p], u = bup[p], ell = (u - l) * a.TolCon;
+            double g = 0.0;
+            if (x < l) { const double t = (l - x) / ell; part += 0.5 * t * t; g += (x - l) / (ell * ell); }
+            if (x > u) { const double t = (x - u) / ell; part += 0.5 * t * t; g += (x - u) / (ell * ell); }
+            dP[dm.off_mu + p] = g;
+          }
+          part = wave_sum(part);
+          if (lane == 0) scal[2] = part;
+        }
+        break;
+      case 7:     // soft bounds, lnscale block D x K: ln sigma_k + ln lambda_d (vpbndloss.m:36); gradient summed over d / k
+        if (a.has_bnd && has_sc) {
+          double part = 0.0;
+          for (int p = lane; p < D * K; p += 64) {
+            const int d = p % D, k = p / D;
+            const double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
+            const double l = blo[next_mu + p], u = bup[next_mu + p], ell = (u - l) * a.TolCon;
+            double g = 0.0;
+            if (x < l) { const double t = (l - x) / ell; part += 0.5 * t * t; g += (x - l) / (ell * ell); }
+            if (x > u) { const double t = (x - u) / ell; part += 0.5 * t * t; g += (x - u) / (ell * ell); }
+            gsc[p] = g;
+          }
+          part = wave_sum(part);
+          if (lane == 0) scal[3] = part;
+          wave_fence();
+          if (grad) {
+            if (dm.opt[1])
+              for (int k = lane; k < K; k += 64) {
+                double acc = 0.0;
+                for (int d = 0; d < D; ++d) acc += gsc[d + D * k];
+                dP[dm.off_sigma + k] = acc;
+              }
+            if (dm.opt[2])
+              for (int d = lane; d < D; d += 64) {
+                double acc = 0.0;
+                for (int k = 0; k < K; ++k) acc += gsc[d + D * k];
+                dP[dm.off_lambda + d] = acc;
+              }
+          }
+        }
+        break;
+      case 8:     // soft bounds on eta and the weight-size penalty (negelcbo_vbmc.m:146-162)
+        if (a.has_bnd && dm.opt[3]) {
+          const int o3 = next_mu + has_sc * D * K;
+          double part = 0.0, pd = 0.0;
+          for (int k = lane; k < K; k += 64) {
+            const double x = v[L.eta() + k], l = blo[o3 + k], u = bup[o3 + k], ell = (u - l) * a.TolCon;
+            if (x < l) { const double t = (l - x) / ell; part += 0.5 * t * t; }
+            if (x > u) { const double t = (x - u) / ell; part += 0.5 * t * t; }
+            part += a.WeightPenalty * ((w[k] < a.WeightThreshold) ? w[k] : a.WeightThreshold);
+            pd += (w[k] < a.WeightThreshold) ? w[k] * a.WeightPenalty : 0.0;
+          }
+          part = wave_sum(part);
+          const double dot = wave_sum(pd);
+          if (lane == 0) scal[4] = part;
+          if (grad)
+            for (int k = lane; k < K; k += 64) {
+              const double x = v[L.eta() + k], l = blo[o3 + k], u = bup[o3 + k], ell = (u - l) * a.TolCon;
+              double g = 0.0;
+              if (x < l) g += (x - l) / (ell * ell);
+              if (x > u) g += (x - u) / (ell * ell);
+              const double gk = (w[k] < a.WeightThreshold) ? a.WeightPenalty : 0.0;
+              dP[dm.off_eta + k] = g + (w[k] * gk - w[k] * dot);
+            }
+        }
+        break;
+      default: break;
+    }
+  }
+  __syncthreads();
+  // ---- assemble
+  double varG = 0.0, varGss = 0.0;
+  const double* vr = a.var ? a.var + (size_t)r * a.var_stride : nullptr;
+  if (vr) { varG = vr[0]; varGss = vr[1]; }
+  if (tid == 0) {
+    const double G = scal[0], H = scal[1];
+    double F = -G - H;                                  // :116
+    if (a.beta != 0.0) F += a.beta * sqrt(varG);        // :127 (varH = 0)
+    F += (scal[2] + scal[3]) + scal[4];
+    o[0] = F; o[1] = G; o[2] = H; o[3] = varG; o[4] = varGss;
+  }
+  if (grad) {
+    for (int i = tid; i < T; i += nt) {
+      double g = -dG[i] - dH[i];                        // :117
+      if (a.beta != 0.0 && vr) g += 0.5 * a.beta * vr[2 + i] / sqrt(varG);  // :129
+      o[OUT_HDR + i] = g + dP[i];
+      o[OUT_HDR + T + i] = dG[i];
+      o[OUT_HDR + 2 * T + i] = dH[i];
+    }
+  }
+  // ---- on-device optimiser loop: this iteration's Adam update and the unpacking of the new theta, by the same workgroup
+  if (a.next_iter > 0) {
+    __syncthreads();                                     // the gradient in `o` was written by other threads of this workgroup
+    adam_update_chain(a.next_A, a.next_iter, a.next_theta, a.out, r);
+    __syncthreads();
+    prep_body(dm, a.next_theta, a.next_vpfix, a.next_vpd, a.next_entp, r, lds);
   }
 }
