@@ -71,7 +71,14 @@ __device__ inline void adam_update_chain(const AdamState& A, int iter, double* _
 // on-device optimiser loop); sh: dynamic LDS of D K + 3 K + D doubles + one per wave
 __device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ theta, const double* __restrict__ vpfix,
                                  double* __restrict__ vpd, double* __restrict__ entp, int r, double* sh) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  // Latency form (round 3): no workgroup barrier and no LDS.  The two sums every element needs -- sum_k exp(eta_k) of the
+  // softmax (:45-47) and sum_d log lambda_d of the normalisation constant -- are computed by EVERY wave for itself (K / 64
+  // exponentials per lane and one butterfly: less than a barrier costs), in an order that does not depend on the number of
+  // threads, so k_prep (256 threads) and the fused call at the end of k_finalize_ws (1024) give the same bits.  Every output
+  // element is then a function of theta alone; the packed entropy parameters recompute the exponentials they need
+  // instead of waiting for another thread's result.
+  (void)sh;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
   const int D = dm.D, K = dm.K;
   VpLayout L{D, K};
   const double* th = theta + (size_t)r * dm.T;
@@ -80,51 +87,44 @@ __device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ 
   const double* fsig = vpfix + D * K;
   const double* flam = fsig + K;
   const double* fw = flam + D;
-  // the unpacked record is kept in LDS as well, so that the later phases do not wait for their own global writes
-  double* s_mu = sh;               // D x K
-  double* s_sig = s_mu + D * K;    // K
-  double* s_lnsig = s_sig + K;     // K
-  double* s_lam = s_lnsig + K;     // D
-  double* s_w = s_lam + D;         // K
-  double* red = s_w + K;           // one double per wave
-  for (int i = tid; i < D * K; i += nt) { double m = dm.opt[0] ? th[dm.off_mu + i] : fmu[i]; s_mu[i] = m; v[L.mu() + i] = m; }
-  double pe_ = 0.0, pl_ = 0.0;
+  double s_sum = 0.0, sum_loglam = 0.0;
+  if (dm.opt[3]) {
+    for (int k = lane; k < K; k += 64) s_sum += exp(th[dm.off_eta + k]);
+    s_sum = wave_sum(s_sum);
+  }
+  for (int d = lane; d < D; d += 64) sum_loglam += dm.opt[2] ? th[dm.off_lambda + d] : log(flam[d]);   // log(exp(x)) = x (:41)
+  sum_loglam = wave_sum(sum_loglam);
+  auto mu_of = [&](int i) { return dm.opt[0] ? th[dm.off_mu + i] : fmu[i]; };
+  auto lnsig_of = [&](int k) { return dm.opt[1] ? th[dm.off_sigma + k] : log(fsig[k]); };
+  auto sig_of = [&](int k) { return dm.opt[1] ? exp(th[dm.off_sigma + k]) : fsig[k]; };   // vp.sigma = exp(theta) (:40)
+  auto lam_of = [&](int d) { return dm.opt[2] ? exp(th[dm.off_lambda + d]) : flam[d]; };
+  auto w_of = [&](int k) { return dm.opt[3] ? exp(th[dm.off_eta + k]) / s_sum : fw[k]; };   // no max-shift (:45-47)
+  for (int i = tid; i < D * K; i += nt) v[L.mu() + i] = mu_of(i);
   for (int k = tid; k < K; k += nt) {
-    double ls = dm.opt[1] ? th[dm.off_sigma + k] : log(fsig[k]);
-    double sg = dm.opt[1] ? exp(ls) : fsig[k];  // vp.sigma = exp(theta) (:40)
-    v[L.lnsigma() + k] = ls; s_lnsig[k] = ls;
-    v[L.sigma() + k] = sg; s_sig[k] = sg;
-    if (dm.opt[3]) pe_ += exp(th[dm.off_eta + k]);
+    v[L.lnsigma() + k] = lnsig_of(k);
+    v[L.sigma() + k] = sig_of(k);
+    v[L.eta() + k] = dm.opt[3] ? th[dm.off_eta + k] : log(fw[k]);
+    v[L.w() + k] = w_of(k);
   }
   for (int d = tid; d < D; d += nt) {
-    double ll = dm.opt[2] ? th[dm.off_lambda + d] : log(flam[d]);
-    double lm = dm.opt[2] ? exp(ll) : flam[d];
-    v[L.lnlambda() + d] = ll;
-    v[L.lambda() + d] = lm; s_lam[d] = lm;
-    pl_ += log(lm);
+    v[L.lnlambda() + d] = dm.opt[2] ? th[dm.off_lambda + d] : log(flam[d]);
+    v[L.lambda() + d] = lam_of(d);
   }
-  // vp.w = exp(eta)/sum(exp(eta)), no max-shift (:45-47); log nf = -D/2 log(2 pi) - sum log lambda
-  const double s_sum = block_sum(pe_, red);
-  const double sum_loglam = block_sum(pl_, red);
   if (tid == 0) v[L.lognf()] = -0.5 * D * 1.8378770664093454835606594728112 - sum_loglam;
-  for (int k = tid; k < K; k += nt) {
-    double eta = dm.opt[3] ? th[dm.off_eta + k] : log(fw[k]);
-    double wk = dm.opt[3] ? exp(eta) / s_sum : fw[k];
-    v[L.eta() + k] = eta;
-    v[L.w() + k] = wk; s_w[k] = wk;
-  }
-  __syncthreads();
-  // packed entropy parameters
+  // packed entropy parameters [m_dk = mu_dk / lambda_d (D), -1/(2 sigma_k^2), -D ln sigma_k, w_k, w_k / sigma_k^2]
   double* ep = entp + (size_t)r * K * (D + ENTP_EXTRA);
-  for (int i = tid; i < K * (D + ENTP_EXTRA); i += nt) {
-    int k = i / (D + ENTP_EXTRA), c = i % (D + ENTP_EXTRA);
-    double sg = s_sig[k];
+  const int PS = D + ENTP_EXTRA;
+  for (int i = tid; i < K * PS; i += nt) {
+    const int k = i / PS, c = i - k * PS;
     double val;
-    if (c < D) val = s_mu[c + D * k] / s_lam[c];
-    else if (c == D) val = -0.5 / (sg * sg);
-    else if (c == D + 1) val = -(double)D * s_lnsig[k];
-    else if (c == D + 2) val = s_w[k];
-    else val = s_w[k] / (sg * sg);
+    if (c < D) val = mu_of(c + D * k) / lam_of(c);
+    else {
+      const double sg = sig_of(k);
+      if (c == D) val = -0.5 / (sg * sg);
+      else if (c == D + 1) val = -(double)D * lnsig_of(k);
+      else if (c == D + 2) val = w_of(k);
+      else val = w_of(k) / (sg * sg);
+    }
     ep[i] = val;
   }
 }
