@@ -347,11 +347,14 @@ vbmc_status vbmc_elbo_batch_multi(vbmc_comm* comm, const vbmc_gp* const* gps, co
  * random-walk stopping test (:65-81); the host only polls R flags on those iterations.  args->theta
  * holds the R starting points x0 (T x R); args->seed + iter keys the MC draws of iteration iter
  * (eps_mode must be 0).  Outputs (any may be NULL): x T x R (mean of the last 20 iterates, :96),
- * f R (:97), iters R, xtab T x MaxIter x R and ftab MaxIter x R (first iters(r) entries filled).
+ * f R (:97), iters R, xtab T x MaxIter x R and ftab MaxIter x R (first iters(r) entries filled), xmid T x R: per chain the
+ * iterate with the smallest recorded objective, theta_lst(idx_mid,:) with [~,idx_mid] = min(fval_lst) of
+ * misc/vpoptimize_vbmc.m:133 -- the one thing that caller reads from the tables, so that it need not ask for them (T x MaxIter x R
+ * doubles with MaxIter = 1e4).
  */
 vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, double TolFun, int MaxIter,
                             double step_min, double step_max, double step_decay, double* x, double* f, int32_t* iters,
-                            double* xtab, double* ftab);
+                            double* xtab, double* ftab, double* xmid);
 
 /* Writes the exact standard-normal block eps (D x Ns/2 x K x R) that eps_mode 0 consumes for
  * `seed`, so that a host oracle can be fed the same draws (test hook; entmc_vbmc.m:53). */

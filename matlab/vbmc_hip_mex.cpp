@@ -15,9 +15,10 @@
 //                                thetabnd_or_empty, seed, separate_K, numel(gp.post))
 //                                (the R candidates of vpsieve_vbmc.m:74-78, or the 2*Nslowopts eval_fullelcbo calls of
 //                                 vpoptimize_vbmc.m:134,165, in one pass; I_sk is S x K x R, J_sjk S x K x K x R)
-//     [x,f,iters,xtab,ftab] = vbmc_hip_mex('adam', h, Theta0 /*T x R*/, vp, Ns, compute_var, beta, thetabnd_or_empty, seed,
-//                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device; xtab is
-//                                T x MaxIter x R, ftab MaxIter x R, the first iters(r) entries of chain r filled)
+//     [x,f,iters,xmid,xtab,ftab] = vbmc_hip_mex('adam', h, Theta0 /*T x R*/, vp, Ns, compute_var, beta, thetabnd_or_empty, seed,
+//                                TolFun, MaxIter, [step_min step_max step_decay])   (fminadam.m on the device; xmid T x R: each
+//                                chain's iterate of smallest recorded objective, vpoptimize_vbmc.m:133; the tables only on
+//                                request: xtab T x MaxIter x R, ftab MaxIter x R, the first iters(r) entries of chain r filled)
 //     [alpha,L,sW,sn2_mult,Lchol,h] = vbmc_hip_mex('gp_post', hyp, X, y, s2, meanfun, noisefun)
 //     [ymu,ys2,fmu,fs2] = vbmc_hip_mex('gp_pred', h, Xstar, s2star, ssflag)
 //     [acq,fbar,vtot] = vbmc_hip_mex('acq', h, Xs, acq_id, vp, ymax, var_regularized, TolGPVar, gplengthscale, X_rescaled, sn2new)
@@ -351,17 +352,20 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     for (int i = 0; nrhs > 11 && i < 3 && i < (int)mxGetNumberOfElements(prhs[11]); ++i) step[i] = mxGetDoubles(prhs[11])[i];
     mxArray *x = mxCreateDoubleMatrix(T, a.R, mxREAL), *f = mxCreateDoubleMatrix(1, a.R, mxREAL);
     mxArray* it = mxCreateNumericMatrix(1, a.R, mxINT32_CLASS, mxREAL);
-    mxArray *xtab = nullptr, *ftab = nullptr;
-    if (nlhs > 3) { mwSize d3[3] = {(mwSize)T, (mwSize)MaxIter, (mwSize)a.R}; xtab = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL); }
-    if (nlhs > 4) ftab = mxCreateDoubleMatrix(MaxIter, a.R, mxREAL);
+    mxArray *xmid = nullptr, *xtab = nullptr, *ftab = nullptr;
+    if (nlhs > 3) xmid = mxCreateDoubleMatrix(T, a.R, mxREAL);
+    if (nlhs > 4) { mwSize d3[3] = {(mwSize)T, (mwSize)MaxIter, (mwSize)a.R}; xtab = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL); }
+    if (nlhs > 5) ftab = mxCreateDoubleMatrix(MaxIter, a.R, mxREAL);
     vbmc_status st = vbmc_adam_batch(g_ctx, h, &a, TolFun, MaxIter, step[0], step[1], step[2], mxGetDoubles(x), mxGetDoubles(f),
-                                     (int32_t*)mxGetData(it), xtab ? mxGetDoubles(xtab) : nullptr, ftab ? mxGetDoubles(ftab) : nullptr);
+                                     (int32_t*)mxGetData(it), xtab ? mxGetDoubles(xtab) : nullptr, ftab ? mxGetDoubles(ftab) : nullptr,
+                                     xmid ? mxGetDoubles(xmid) : nullptr);
     if (st != VBMC_OK) return fail(st);
     plhs[0] = x;
     if (nlhs > 1) plhs[1] = f;
     if (nlhs > 2) plhs[2] = it;
-    if (nlhs > 3) plhs[3] = xtab;
-    if (nlhs > 4) plhs[4] = ftab;
+    if (nlhs > 3) plhs[3] = xmid;
+    if (nlhs > 4) plhs[4] = xtab;
+    if (nlhs > 5) plhs[5] = ftab;
     return 0;
   }
 

@@ -61,13 +61,12 @@ ThetaMid = zeros(T,Nslowopts);
 for g = 1:max(grp)
     m = find(grp == g);
     try
-        [x,~,iters,xtab,ftab] = vbmc_hip_mex('adam',h,Theta0(:,m),start(m(1)),NSentK,double(compute_var),elcbo_beta, ...
+        % xmid: each chain's iterate of smallest recorded objective (the best midpoint, :133), picked inside the library -- the
+        % T x MaxIter x R iterate table never crosses into MATLAB
+        [x,~,~,xmid] = vbmc_hip_mex('adam',h,Theta0(:,m),start(m(1)),NSentK,double(compute_var),elcbo_beta, ...
             bnd,randi(2^31-1),options.TolFunStochastic,maxit,steps);
         ThetaEnd(:,m) = x;
-        for r = 1:numel(m)
-            [~,at] = min(ftab(1:double(iters(r)),r));                  % best midpoint of the chain (:133)
-            ThetaMid(:,m(r)) = xtab(:,at,r);
-        end
+        ThetaMid(:,m) = xmid;
     catch err
         if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
         % refused on the device: the user's own host-loop fminadam over the shimmed objective (which falls through by itself)

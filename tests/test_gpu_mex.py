@@ -150,13 +150,21 @@ def test_adam_tables(mex, va):
     tbp = {k: (np.asarray(v).reshape(-1) if k in ("lb", "ub") else v) for k, v in tb.items()}
     hh = np.uint64(mex.call(1, "gp_upload", gp_struct(gp))[0][0, 0])
     MaxIter = 60
-    x, f, it, xtab, ftab = mex.call(5, "adam", hh, Th, vp_struct(vp), 20, 0, 0, tb, 11, 0.001, MaxIter, np.array([0.001, 0.05, 200.0]))
+    x, f, it, xmid, xtab, ftab = mex.call(6, "adam", hh, Th, vp_struct(vp), 20, 0, 0, tb, 11, 0.001, MaxIter, np.array([0.001, 0.05, 200.0]))
     xr, fr, xt, ft, itr = va.fminadam_device(Th, 0, vp, gp, 20, tbp, TolFun=0.001, MaxIter=MaxIter,
                                              master_stepsize={"min": 0.001, "max": 0.05, "decay": 200.0}, seed=11)
     assert it.dtype == np.int32 and xtab.shape == (theta.size, MaxIter, 2) and ftab.shape == (MaxIter, 2)
     same(x, xr); same(f[0], fr); assert list(it[0]) == list(itr)
     for r in range(2):
         same(xtab[:, : itr[r], r], xt[r]); same(ftab[: itr[r], r], ft[r])
+        same(xmid[:, r], xt[r][:, int(np.argmin(ft[r]))])            # the best midpoint, picked inside the library
+    # the form matlab/vpoptimize_vbmc.m uses: four outputs, no tables
+    x4, _, _, xmid4 = mex.call(4, "adam", hh, Th, vp_struct(vp), 20, 0, 0, tb, 11, 0.001, MaxIter, np.array([0.001, 0.05, 200.0]))
+    same(x4, xr); same(xmid4, xmid)
+    xq, fq, xmq, none, itq = va.fminadam_device(Th, 0, vp, gp, 20, tbp, TolFun=0.001, MaxIter=MaxIter,
+                                                master_stepsize={"min": 0.001, "max": 0.05, "decay": 200.0}, seed=11, tables=False)
+    assert none is None
+    same(xq, xr); same(xmq, xmid)
     mex.call(0, "gp_free", hh)
 
 

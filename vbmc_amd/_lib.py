@@ -90,7 +90,7 @@ def load():
     lib.vbmc_elbo_submit.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int]
     lib.vbmc_elbo_collect.argtypes = [vp, C.POINTER(ElboArgs), C.c_int]
     lib.vbmc_adam_batch.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
-                                    _dp, _dp, C.POINTER(C.c_int32), _dp, _dp]
+                                    _dp, _dp, C.POINTER(C.c_int32), _dp, _dp, _dp]
     lib.vbmc_elbo_shard_size.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, C.POINTER(C.c_size_t)]
     lib.vbmc_elbo_shard_begin.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, C.c_int, vp]
     lib.vbmc_elbo_shard_finish.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int, vp]

@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(256) k_adam_check(AdamState A, int iter) {
 
 extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, double TolFun, int MaxIter,
                                        double step_min, double step_max, double step_decay, double* x_out, double* f_out,
-                                       int32_t* iters_out, double* xtab_out, double* ftab_out) {
+                                       int32_t* iters_out, double* xtab_out, double* ftab_out, double* xmid_out) {
   if (!ctx) return VBMC_ERR_INVALID;
   if (!a || !a->compute_grad) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_adam_batch needs compute_grad = 1");
   if (MaxIter < 1) return set_err(ctx, VBMC_ERR_INVALID, "MaxIter must be >= 1");
@@ -1289,26 +1289,40 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   }
   if (iter > MaxIter) iter = MaxIter;
   HIP_TRY(ctx, hipGetLastError());
-  // outputs: x = mean of the last 20 iterates, f = mean of the last 20 values (fminadam.m:96-97)
-  std::vector<double> xt(nx), ft(nf);
-  HIP_TRY(ctx, hipMemcpyAsync(xt.data(), A.xtab, nx * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ft.data(), A.ftab, nf * sizeof(double), hipMemcpyDeviceToHost, st));
+  // outputs: x = mean of the last 20 iterates, f = mean of the last 20 values (fminadam.m:96-97).  Only the iterations that were
+  // run come back: `iter` rows of each chain's table (a strided copy), not the MaxIter the table was sized for -- with
+  // MaxIter = 1e4 and chains that stop after a few hundred iterations that is the difference between megabytes and hundreds of them
+  const size_t nit = (size_t)iter;
+  std::vector<double> xt(nit * T * R), ft(nit * R);
+  HIP_TRY(ctx, hipMemcpy2DAsync(xt.data(), nit * T * sizeof(double), A.xtab, (size_t)MaxIter * T * sizeof(double), nit * T * sizeof(double), R,
+                                hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpy2DAsync(ft.data(), nit * sizeof(double), A.ftab, (size_t)MaxIter * sizeof(double), nit * sizeof(double), R,
+                                hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(done.data(), A.done, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   for (int r = 0; r < R; ++r) {
     const int it = done[r] ? done[r] : iter;
     const int nb = it < 20 ? it : 20;
+    const double* xr = xt.data() + (size_t)r * nit * T;
+    const double* fr = ft.data() + (size_t)r * nit;
     if (iters_out) iters_out[r] = it;
     for (int i = 0; i < T; ++i) {
       double acc = 0.0;
-      for (int t = it - nb; t < it; ++t) acc += xt[((size_t)r * MaxIter + t) * T + i];
+      for (int t = it - nb; t < it; ++t) acc += xr[(size_t)t * T + i];
       if (x_out) x_out[(size_t)r * T + i] = acc / nb;
     }
     double fa = 0.0;
-    for (int t = it - nb; t < it; ++t) fa += ft[(size_t)r * MaxIter + t];
+    for (int t = it - nb; t < it; ++t) fa += fr[t];
     if (f_out) f_out[r] = fa / nb;
-    if (xtab_out) memcpy(xtab_out + (size_t)r * MaxIter * T, xt.data() + (size_t)r * MaxIter * T, (size_t)it * T * sizeof(double));
-    if (ftab_out) memcpy(ftab_out + (size_t)r * MaxIter, ft.data() + (size_t)r * MaxIter, (size_t)it * sizeof(double));
+    if (xmid_out) {   // the iterate with the smallest recorded objective: [~,idx_mid] = min(fval_lst) (misc/vpoptimize_vbmc.m:133; first minimum, NaN skipped)
+      int best = 0;
+      bool have = false;
+      for (int t = 0; t < it; ++t)
+        if (!std::isnan(fr[t]) && (!have || fr[t] < fr[best])) { best = t; have = true; }
+      memcpy(xmid_out + (size_t)r * T, xr + (size_t)best * T, (size_t)T * sizeof(double));
+    }
+    if (xtab_out) memcpy(xtab_out + (size_t)r * MaxIter * T, xr, (size_t)it * T * sizeof(double));
+    if (ftab_out) memcpy(ftab_out + (size_t)r * MaxIter, fr, (size_t)it * sizeof(double));
   }
   return VBMC_OK;
 }

@@ -149,12 +149,14 @@ def _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, s
 
 
 def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10000, master_stepsize=None, *,
-                    compute_var=0, seed=0, engine=None, sparse_cutoff=0.0):
+                    compute_var=0, seed=0, engine=None, sparse_cutoff=0.0, tables=True):
     """fminadam (utils/fminadam.m) with the objective negelcbo_vbmc(., beta, vp, gp, Ns, 1, compute_var, ~, thetabnd)
     run entirely on the device for R chains in lock-step (x0: (T, R) or (T,)).
 
     Returns (x, f, xtab, ftab, iters): x (T, R) mean of the last 20 iterates, f (R,), xtab list of (T, iters_r)
-    arrays, ftab list of (iters_r,) arrays, iters (R,) -- the reference's five outputs per chain."""
+    arrays, ftab list of (iters_r,) arrays, iters (R,) -- the reference's five outputs per chain.
+    tables=False: the iterate tables stay on the device; (x, f, xmid, None, iters) with xmid (T, R) = each chain's iterate of
+    smallest recorded objective (what misc/vpoptimize_vbmc.m:133 reads from the tables)."""
     engine = engine or default_engine()
     ctx = engine.ctx
     ms = {"max": 0.1, "min": 0.001, "decay": 200.0}
@@ -170,12 +172,15 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
     x = np.zeros((T, R), order="F")
     f = np.zeros(R)
     iters = np.zeros(R, dtype=np.int32)
-    xtab = np.zeros((R, MaxIter, T))   # C order == T x MaxIter x R column-major
-    ftab = np.zeros((R, MaxIter))
+    xtab = np.zeros((R, MaxIter, T)) if tables else None   # C order == T x MaxIter x R column-major
+    ftab = np.zeros((R, MaxIter)) if tables else None
+    xmid = np.zeros((T, R), order="F")
     dgp = engine.device_gp(gp, need_L=int(compute_var or 0) != 0)
     ctx.check(ctx.lib.vbmc_adam_batch(ctx.h, dgp.h, C.byref(a), float(TolFun), MaxIter, float(ms["min"]), float(ms["max"]),
                                        float(ms["decay"]), ptr(x), ptr(f), iters.ctypes.data_as(C.POINTER(C.c_int32)),
-                                       ptr(xtab), ptr(ftab)))
+                                       ptr(xtab), ptr(ftab), ptr(xmid)))
+    if not tables:
+        return x, f, xmid, None, iters
     return x, f, [xtab[r, : iters[r]].T.copy() for r in range(R)], [ftab[r, : iters[r]].copy() for r in range(R)], iters
 
 

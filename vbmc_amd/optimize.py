@@ -546,9 +546,11 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
             X0 = np.asfortranarray(np.stack([theta0s[i] for i in members], axis=1))
             sd = sbase + (1 << 16) + (gi << 12)
             vpg = starts[members[0]]
-            if device_adam:  # the whole Adam loop on the device (vbmc_adam_batch), no host round trip per evaluation
-                xo, _, xt, ft, its = fminadam_device(X0, elcbo_beta, vpg, gp, NSentK, thetabnd, options["TolFunStochastic"], MaxIter, ms,
-                                                     seed=sd, engine=engine)
+            xmid = None
+            if device_adam:  # the whole Adam loop on the device (vbmc_adam_batch), no host round trip per evaluation; the best midpoint
+                # of each chain (:133) is picked inside the library, the iterate tables (T x MaxIter x R) stay on the device
+                xo, _, xmid, _, its = fminadam_device(X0, elcbo_beta, vpg, gp, NSentK, thetabnd, options["TolFunStochastic"], MaxIter, ms,
+                                                      seed=sd, engine=engine, tables=False)
             else:
                 def fun_batch(X, it, vpg=vpg, sd=sd):
                     r = negelcbo_batch(X, elcbo_beta, vpg, gp, NSentK, True, 0, thetabnd, seed=sd + it, engine=engine, outputs=("F", "dF"))
@@ -558,7 +560,7 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
             for r, i in enumerate(members):
                 thetaopt[i] = xo[:, r].copy()
                 if options["ELCBOmidpoint"]:
-                    theta_mid[i] = xt[r][:, int(np.argmin(ft[r]))].copy()   # :133 [~,idx_mid] = min(fval_lst)
+                    theta_mid[i] = (xmid[:, r] if xmid is not None else xt[r][:, int(np.argmin(ft[r]))]).copy()   # :133 [~,idx_mid] = min(fval_lst)
                 if trace is not None:
                     trace.append({"kind": "adam", "slot": i, "seed": sd, "r": r, "R": len(members), "K": K, "Ns": NSentK, "iters": int(its[r])})
     else:
