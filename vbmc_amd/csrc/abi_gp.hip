@@ -12,8 +12,10 @@ namespace {
 struct TmpBuf {   // a pooled device block (common.h pool_get/pool_put), returned to the context's pool on scope exit
   void* p = nullptr;
   vbmc_ctx* owner = nullptr;
-  ~TmpBuf() { if (p) pool_put(owner, p); }
+  bool is_view = false;   // a window into another block (the packed input block of gp_factorize): nothing to return
+  ~TmpBuf() { if (p && !is_view) pool_put(owner, p); }
   hipError_t alloc(vbmc_ctx* ctx, size_t bytes) { owner = ctx; return pool_get(ctx, bytes, &p); }
+  void view(void* q) { p = q; is_view = true; }
   template <typename T> T* as() { return (T*)p; }
 };
 
@@ -90,14 +92,18 @@ struct GpFactor {
   std::vector<unsigned char> lch, failed;           // Lchol flag; 1 = Cholesky still failing after 10 retries
   bool any_inv = false;
   size_t tlds = 0;
-  TmpBuf dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dones, dninv, dal, dfinv;
+  double* pin_out = nullptr;
+  int* pin_pf = nullptr;        // optimistic first try: the Cholesky's failure flags land here (pinned) and are read at the caller's own synchronisation
+  bool unchecked = false;
+  bool alpha_event = false;    // alpha is being computed on the second stream: wait for ctx->ev_join before reading it
+  TmpBuf dIn, dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dones, dninv, dal, dfinv;   // dIn: the packed inputs (dX .. dninv are windows)
 };
 
 // fail_is_error: vbmc_gp_post refuses a matrix that is still not positive definite after the retries;
 // vbmc_gp_nlz marks that hyper-parameter vector as failed (NaN result, gplite_train.m:542-546) and goes on.
 vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
                          const double* X, const double* y, const double* s2, const double* hyp, bool fail_is_error,
-                         GpFactor& f) {
+                         GpFactor& f, size_t pin_extra_doubles = 0, bool optimistic = false, bool alpha_aside = false) {
   if (N <= 0 || D <= 0 || S <= 0 || !X || !y || !hyp || !noisefun)
     return set_err(ctx, VBMC_ERR_INVALID, "%s: bad arguments", who);
   if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
@@ -133,29 +139,40 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     scal[s * 4 + 0] = lch[s] ? mn : 1.0;  // sn2div
     scal[s * 4 + 1] = 1.0;                // sn2_mult
     scal[s * 4 + 2] = lch[s];
-    scal[s * 4 + 3] = 1.0;                // sl (set after the retry loop)
+    scal[s * 4 + 3] = lch[s] ? scal[s * 4 + 0] : 1.0;   // sl = sn2div * sn2_mult (:82,:96); rewritten below if a retry inflates the noise
   }
   TmpBuf &dX = f.dX, &dy = f.dy, &dhyp = f.dhyp, &dXc = f.dXc, &daa = f.daa, &dsn2 = f.dsn2, &dscal = f.dscal, &dact = f.dact,
          &dA = f.dA, &dpf = f.dpf, &dr = f.dr, &dones = f.dones, &dninv = f.dninv;
-  HIP_TRY(ctx, dX.alloc(ctx, (size_t)N * D * 8));
-  HIP_TRY(ctx, dy.alloc(ctx, (size_t)N * 8));
-  HIP_TRY(ctx, dhyp.alloc(ctx, (size_t)Nhyp * S * 8));
+  // Inputs: ONE pinned block [X | y | hyp | sn2 | scal | ones needinv active], one asynchronous copy.  (Round 2 issued eight
+  // hipMemcpyAsync from pageable memory -- each of them staged and waited for by the runtime, ~100 us of host time in a call whose
+  // kernels take 0.36 ms.)
+  const size_t nX = (size_t)N * D, nH = (size_t)Nhyp * S, nS = (size_t)S * N, nC = (size_t)S * 4;
+  const size_t in_doubles = nX + N + nH + nS + nC + (3 * (size_t)S + 7) / 8;
+  { vbmc_status s_ = ensure_pin(ctx, (in_doubles + pin_extra_doubles) * 8 + (size_t)S * sizeof(int) + 8); if (s_) return s_; }
+  double* hin = (double*)ctx->pin;
+  f.pin_out = hin + in_doubles;      // the caller's results come back through the same pinned block (pin_extra_doubles of it)
+  f.pin_pf = (int*)(hin + in_doubles + pin_extra_doubles);
+  memcpy(hin, X, nX * 8);
+  memcpy(hin + nX, y, (size_t)N * 8);
+  memcpy(hin + nX + N, hyp, nH * 8);
+  memcpy(hin + nX + N + nH, sn2all.data(), nS * 8);
+  memcpy(hin + nX + N + nH + nS, scal.data(), nC * 8);
+  unsigned char* hb = (unsigned char*)(hin + nX + N + nH + nS + nC);
+  memcpy(hb, ones.data(), S); memcpy(hb + S, needinv.data(), S); memcpy(hb + 2 * S, active.data(), S);
+  TmpBuf& dIn = f.dIn;
+  HIP_TRY(ctx, dIn.alloc(ctx, in_doubles * 8));
+  {
+    double* din = dIn.as<double>();
+    dX.view(din); dy.view(din + nX); dhyp.view(din + nX + N); dsn2.view(din + nX + N + nH); dscal.view(din + nX + N + nH + nS);
+    unsigned char* db = (unsigned char*)(din + nX + N + nH + nS + nC);
+    dones.view(db); dninv.view(db + S); dact.view(db + 2 * S);
+  }
   HIP_TRY(ctx, dXc.alloc(ctx, (size_t)S * N * D * 8));
   HIP_TRY(ctx, daa.alloc(ctx, (size_t)S * N * 8));
-  HIP_TRY(ctx, dsn2.alloc(ctx, (size_t)S * N * 8));
-  HIP_TRY(ctx, dscal.alloc(ctx, (size_t)S * 4 * 8));
-  HIP_TRY(ctx, dact.alloc(ctx, S));
-  HIP_TRY(ctx, dones.alloc(ctx, S));
-  HIP_TRY(ctx, dninv.alloc(ctx, S));
   HIP_TRY(ctx, dA.alloc(ctx, (size_t)S * N * N * 8));
   HIP_TRY(ctx, dpf.alloc(ctx, (size_t)S * sizeof(int)));
   HIP_TRY(ctx, dr.alloc(ctx, (size_t)S * N * 8));
-  HIP_TRY(ctx, hipMemcpyAsync(dX.p, X, (size_t)N * D * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(dy.p, y, (size_t)N * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(dhyp.p, hyp, (size_t)Nhyp * S * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(dsn2.p, sn2all.data(), (size_t)S * N * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(dones.p, ones.data(), S, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(dninv.p, needinv.data(), S, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(dIn.p, hin, in_doubles * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>());
 
   // jittered Cholesky: up to 10 tries, noise multiplier x10 per failure (gplite_core.m:77-80,91-94)
@@ -163,20 +180,33 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   TmpBuf dPg;
   if (chol2_needs_gpanel(N)) HIP_TRY(ctx, dPg.alloc(ctx, (size_t)S * 16 * (size_t)(((N + 15) >> 4) << 4) * 8));
   std::vector<int> pf(S);
-  bool pending = true;
+  bool pending = true, retried = false;
   for (int iter = 0; iter < 10 && pending; ++iter) {
-    HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dact.p, active.data(), S, hipMemcpyHostToDevice, st));
+    if (iter > 0) {   // (the first try's copies are part of the packed block)
+      HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipMemcpyAsync(dact.p, active.data(), S, hipMemcpyHostToDevice, st));
+    }
     DISPATCH_GPDT(D, hipLaunchKernelGGL((k_gp_build<DT>), dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D,
                                         Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(), dsn2.as<double>(), dscal.as<double>(),
                                         dact.as<unsigned char>(), dA.as<double>()));
     HIP_TRY(ctx, chol2_launch(N, S, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>(), dPg.p ? dPg.as<double>() : nullptr, st));
+    if (optimistic) {
+      // Almost every factorisation succeeds at the first try (the retries exist for hyper-parameter vectors at the edge of the
+      // prior).  The flags are copied to pinned memory and NOT waited for: everything downstream is enqueued as if the try had
+      // succeeded, the caller looks at the flags at its own final synchronisation (gp_factor_ok) and, if one is set, repeats the
+      // call with the retry loop -- one host round trip (25 us of an otherwise idle device) less per call
+      HIP_TRY(ctx, hipMemcpyAsync(f.pin_pf, dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
+      f.unchecked = true;
+      std::fill(active.begin(), active.end(), 0);
+      pending = false;
+      break;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(pf.data(), dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     pending = false;
     for (int s = 0; s < S; ++s) {
       if (!active[s]) continue;
-      if (pf[s] > 0) { scal[s * 4 + 1] *= 10.0; pending = true; }  // sn2_mult = sn2_mult*10
+      if (pf[s] > 0) { scal[s * 4 + 1] *= 10.0; pending = true; retried = true; }  // sn2_mult = sn2_mult*10
       else active[s] = 0;
     }
   }
@@ -186,40 +216,75 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
       return set_err(ctx, VBMC_ERR_NOT_POSDEF, "gplite_core: Cholesky failed after 10 noise-inflation retries");
     for (int s = 0; s < S; ++s) f.failed[s] = active[s];
   }
-  for (int s = 0; s < S; ++s) scal[s * 4 + 3] = lch[s] ? scal[s * 4 + 0] * scal[s * 4 + 1] : 1.0;  // sl (:82,:96)
-  HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
+  if (retried) {   // (without a retry the packed block already carries sl)
+    for (int s = 0; s < S; ++s) scal[s * 4 + 3] = lch[s] ? scal[s * 4 + 0] * scal[s * 4 + 1] : 1.0;  // sl (:82,:96)
+    HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
+  }
 
-  // alpha = L\(L'\(y-m)) / sl  (:102)
+  // alpha = L\(L'\(y-m)) / sl  (:102).  alpha_aside (vbmc_gp_nlz with a gradient, few matrices): the solve runs on the context's
+  // second stream while the caller inverts the factor on the first -- two latency-bound kernels of 56 and 115 us that do not
+  // depend on each other; the caller waits for ctx->ev_join before it reads alpha.
   const int moff = Ncov + Nnoise;
-  hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
-                     dhyp.as<double>(), dr.as<double>());
   f.cw = trsm_cw_for(N);
   f.tlds = TRSM_LDS_BYTES_CW(N, f.cw);
   TmpBuf &dal = f.dal, &dfinv = f.dfinv;
   HIP_TRY(ctx, dal.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
   hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, st, N, dA.as<double>(), dones.as<unsigned char>(), dfinv.as<double>());
+  hipStream_t sa = st;
+  f.alpha_event = false;
+  if (alpha_aside && ctx->aux && ctx->ev_fork && ctx->ev_join) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    sa = ctx->aux;
+    f.alpha_event = true;
+  }
+  hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, sa, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
+                     dhyp.as<double>(), dr.as<double>());
   if (N <= ASOLVE1_THREADS)
-    hipLaunchKernelGGL(k_alpha_solve1, dim3(S), dim3(ASOLVE1_THREADS), 0, st, N, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(),
+    hipLaunchKernelGGL(k_alpha_solve1, dim3(S), dim3(ASOLVE1_THREADS), 0, sa, N, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(),
                        dr.as<double>(), dal.as<double>());
   else
-    hipLaunchKernelGGL(k_alpha_solve, dim3(S), dim3(ASOLVE_THREADS), (size_t)((TRSM_NBLK(N) << 4) + 16) * sizeof(double), st, N, dA.as<double>(),
+    hipLaunchKernelGGL(k_alpha_solve, dim3(S), dim3(ASOLVE_THREADS), (size_t)((TRSM_NBLK(N) << 4) + 16) * sizeof(double), sa, N, dA.as<double>(),
                        dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
-  hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, st, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
+  hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, sa, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
+  if (f.alpha_event) HIP_TRY(ctx, hipEventRecord(ctx->ev_join, sa));
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;
 }
 
+// after the caller's synchronisation: did the optimistic first try succeed for every matrix?
+bool gp_factor_ok(const GpFactor& f, int S) {
+  if (!f.unchecked) return true;
+  for (int s = 0; s < S; ++s)
+    if (f.pin_pf[s] > 0) return false;
+  return true;
+}
+
 }  // namespace
 
+static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
+                                const double* X, const double* y, const double* s2, const double* hyp,
+                                double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
+                                vbmc_gp** gp_out, bool optimistic);
+#define VBMC_INTERNAL_RETRY 1000
 extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
                                     const double* X, const double* y, const double* s2, const double* hyp,
                                     double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
                                     vbmc_gp** gp_out) {
+  vbmc_status st = gp_post_impl(ctx, N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, alpha, L, sW, sn2_mult, Lchol, gp_out, true);
+  if (st == VBMC_INTERNAL_RETRY) st = gp_post_impl(ctx, N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, alpha, L, sW, sn2_mult, Lchol, gp_out, false);
+  return st;
+}
+
+static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
+                                const double* X, const double* y, const double* s2, const double* hyp,
+                                double* alpha, double* L, double* sW, double* sn2_mult, uint8_t* Lchol,
+                                vbmc_gp** gp_out, bool optimistic) {
   if (!ctx) return VBMC_ERR_INVALID;
   if (gp_out) *gp_out = nullptr;
   GpFactor f;
-  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_post", N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, true, f); if (s_ != VBMC_OK) return s_; }
+  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_post", N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, true, f, (size_t)S * N, optimistic); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int Ncov = f.Ncov, Nnoise = f.Nnoise;
   const bool any_inv = f.any_inv;
@@ -228,8 +293,8 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
   std::vector<unsigned char>& lch = f.lch;
   TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dXi;
 
-  std::vector<double> alh((size_t)S * N);
-  HIP_TRY(ctx, hipMemcpyAsync(alh.data(), dal.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
+  double* alh = f.pin_out;   // pinned: the copy is asynchronous, one synchronisation below
+  HIP_TRY(ctx, hipMemcpyAsync(alh, dal.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
   const bool wantL = L != nullptr || gp_out != nullptr;
   if (wantL && any_inv) {
     // pL = -L\(L'\eye(N)) for low-noise samples (:98); the sign is applied where the matrix is consumed
@@ -251,6 +316,7 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
     }
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (!gp_factor_ok(f, S)) return VBMC_INTERNAL_RETRY;     // a first try failed: once more with the noise-inflation loop
   if (L && any_inv)
     for (int s = 0; s < S; ++s)
       if (!lch[s]) for (size_t i = 0; i < (size_t)N * N; ++i) L[(size_t)s * N * N + i] = -L[(size_t)s * N * N + i];
@@ -260,13 +326,13 @@ extern "C" vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp
     mult[s] = scal[s * 4 + 1];
     sW1[s] = 1.0 / std::sqrt(sn2min[s] * mult[s]);  // post.sW = ones(N,1)./sqrt(min(sn2)*sn2_mult)  (:281)
   }
-  if (alpha) memcpy(alpha, alh.data(), (size_t)S * N * 8);
+  if (alpha) memcpy(alpha, alh, (size_t)S * N * 8);
   if (sW) for (int s = 0; s < S; ++s) for (int n = 0; n < N; ++n) sW[(size_t)s * N + n] = sW1[s];
   if (sn2_mult) memcpy(sn2_mult, mult.data(), S * 8);
   if (Lchol) memcpy(Lchol, lch.data(), S);
   if (gp_out) {
     // the device-resident posterior is assembled from the device buffers (no round trip of the S N x N matrices)
-    vbmc_status st2 = gp_upload_impl(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alh.data(), nullptr, dA.as<double>(),
+    vbmc_status st2 = gp_upload_impl(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alh, nullptr, dA.as<double>(),
                                      any_inv ? dXi.as<double>() : nullptr, sW1.data(), lch.data(), gp_out);
     if (st2 != VBMC_OK) return st2;
     st2 = vbmc_gp_set_noise(ctx, *gp_out, noisefun, mult.data());
@@ -294,9 +360,20 @@ void noise_grad(const int32_t nf[3], const double* hn, int N, const double* y, c
 }
 }  // namespace
 
+static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int meanfun, const int32_t noisefun[3], const double* X,
+                               const double* y, const double* s2, const double* hyp, int compute_grad, double* nlZ, double* dnlZ,
+                               bool optimistic);
 extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int meanfun, const int32_t noisefun[3],
                                    const double* X, const double* y, const double* s2, const double* hyp, int compute_grad,
                                    double* nlZ, double* dnlZ) {
+  vbmc_status st = gp_nlz_impl(ctx, N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, compute_grad, nlZ, dnlZ, true);
+  if (st == VBMC_INTERNAL_RETRY) st = gp_nlz_impl(ctx, N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, compute_grad, nlZ, dnlZ, false);
+  return st;
+}
+
+static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int meanfun, const int32_t noisefun[3], const double* X,
+                               const double* y, const double* s2, const double* hyp, int compute_grad, double* nlZ, double* dnlZ,
+                               bool optimistic) {
   if (!ctx) return VBMC_ERR_INVALID;
   if (!nlZ || (compute_grad && !dnlZ)) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_nlz: null output");
   {
@@ -314,30 +391,42 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
     }
   }
   GpFactor f;
-  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f); if (s_ != VBMC_OK) return s_; }
+  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f, (size_t)B * (1 + Nhyp) + (compute_grad ? (size_t)B * std::max(noise_nhyp(noisefun), 1) * N : 0), optimistic, compute_grad && B <= 16); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int Nnoise = f.Nnoise, Nmean = f.Nmean, moff = f.Ncov + f.Nnoise;
-  TmpBuf dnlz, dKi, dds, dpart, dg;
+  TmpBuf dnlz, dKi, dds, dpart, dg, dTT;
   HIP_TRY(ctx, dnlz.alloc(ctx, (size_t)B * 8));
-  hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
-                     f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz.as<double>());
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(nlZ, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
-  if (compute_grad) {
-    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
-    // identity (k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores (k_syrk_tt);
-    // only the upper triangle is formed -- the part k_nlz_grad reads
-    TmpBuf dTT;
+  if (f.alpha_event) {
+    // the inverse of the factor first (it does not need alpha), then join the second stream
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
     HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
     HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
     hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
                        dKi.as<double>());
-    std::vector<double> dsn2h((size_t)B * std::max(Nnoise, 1) * N);
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  }
+  hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
+                     f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
+  if (compute_grad) {
+    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
+    // identity (k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores (k_syrk_tt);
+    // only the upper triangle is formed -- the part k_nlz_grad reads
+    if (!f.alpha_event) {
+      HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
+      HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
+      HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
+      hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
+                         dKi.as<double>());
+    }
+    // the noise-model derivatives (host, O(B Nnoise N)) go up through the pinned block as well: an asynchronous copy
+    const size_t nds = (size_t)B * std::max(Nnoise, 1) * N;
+    double* dsn2h = f.pin_out + (size_t)B * (1 + Nhyp);
     for (int b = 0; b < B; ++b)
-      noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h.data() + (size_t)b * Nnoise * N);
-    HIP_TRY(ctx, dds.alloc(ctx, dsn2h.size() * 8));
-    HIP_TRY(ctx, hipMemcpyAsync(dds.p, dsn2h.data(), dsn2h.size() * 8, hipMemcpyHostToDevice, st));
+      noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h + (size_t)b * Nnoise * N);
+    HIP_TRY(ctx, dds.alloc(ctx, nds * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(dds.p, dsn2h, nds * 8, hipMemcpyHostToDevice, st));
     const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
     HIP_TRY(ctx, dpart.alloc(ctx, (size_t)B * ntile * P * 8));
     HIP_TRY(ctx, dg.alloc(ctx, (size_t)B * Nhyp * 8));
@@ -347,9 +436,12 @@ extern "C" vbmc_status vbmc_gp_nlz(vbmc_ctx* ctx, int N, int D, int B, int Nhyp,
     hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
                        f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg.as<double>());
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(dnlZ, dg.p, (size_t)B * Nhyp * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f.pin_out + B, dg.p, (size_t)B * Nhyp * 8, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (!gp_factor_ok(f, B)) return VBMC_INTERNAL_RETRY;
+  memcpy(nlZ, f.pin_out, (size_t)B * 8);
+  if (compute_grad) memcpy(dnlZ, f.pin_out + B, (size_t)B * Nhyp * 8);
   // a matrix still not positive definite after the retries: MATLAB errors downstream and the caller maps it to NaN
   // (gplite_train.m:542-546)
   const double qnan = std::numeric_limits<double>::quiet_NaN();
