@@ -624,10 +624,15 @@ def fl(x):
     return float(x)
 
 
-def make_case(seed, D, K, N, S, Mh, meanfun):
+def make_case(seed, D, K, N, S, Mh, meanfun, target="quad"):
     rng = np.random.default_rng(seed)
     X = 1.5 * rng.standard_normal((N, D))
-    y = -0.5 * np.sum((X / 1.3) ** 2, axis=1) + 0.3 * np.sin(X[:, 0]) + 0.05 * rng.standard_normal(N)
+    if target == "rosenbrock":
+        # BASELINE configs[0]: the reference's own test target, rosenbrock_test.m:7 (noise-free form):
+        #   y = -sum((x(:,1:end-1).^2 - x(:,2:end)).^2 + (x(:,1:end-1) - 1).^2/100, 2)
+        y = -np.sum((X[:, :-1] ** 2 - X[:, 1:]) ** 2 + (X[:, :-1] - 1.0) ** 2 / 100.0, axis=1)
+    else:
+        y = -0.5 * np.sum((X / 1.3) ** 2, axis=1) + 0.3 * np.sin(X[:, 0]) + 0.05 * rng.standard_normal(N)
     nmean = {0: 0, 1: 1, 4: 2 * D + 1}[meanfun]
     hyp = np.zeros((D + 2 + nmean, S))
     for s in range(S):
@@ -647,8 +652,11 @@ def make_case(seed, D, K, N, S, Mh, meanfun):
     w = np.exp(eta) / np.sum(np.exp(eta))
     eps = rng.standard_normal((K, Mh, D))
     Xstar = 1.5 * rng.standard_normal((5, D))
-    return dict(seed=seed, D=D, K=K, N=N, S=S, Mh=Mh, meanfun=meanfun, X=X, y=y, hyp=hyp, mu=mu, sigma=sigma,
-                lam=lam, eta=eta, w=w, eps=eps, Xstar=Xstar)
+    c = dict(seed=seed, D=D, K=K, N=N, S=S, Mh=Mh, meanfun=meanfun, X=X, y=y, hyp=hyp, mu=mu, sigma=sigma,
+             lam=lam, eta=eta, w=w, eps=eps, Xstar=Xstar)
+    if target != "quad":
+        c["target"] = target
+    return c
 
 
 def run_case(c):
@@ -692,6 +700,9 @@ CASES = [
     dict(seed=12, D=3, K=4, N=12, S=3, Mh=6, meanfun=4),
     dict(seed=13, D=1, K=3, N=8, S=2, Mh=10, meanfun=1),
     dict(seed=14, D=4, K=3, N=10, S=2, Mh=4, meanfun=0),
+    # BASELINE configs[0]: the Rosenbrock target of the reference's rosenbrock_test.m as the GP's training data, D = 2, K = 2
+    # mixture, Ns = 100 (Mh = 50 antithetic pairs), one hyper-parameter sample
+    dict(seed=15, D=2, K=2, N=20, S=1, Mh=50, meanfun=4, target="rosenbrock"),
 ]
 
 
@@ -803,10 +814,12 @@ def main_acq():
         print("wrote", path, os.path.getsize(path), "bytes", file=sys.stderr)
 
 
-def main():
+def main(only=None):
     outdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     for i, spec in enumerate(CASES):
+        if only is not None and i not in only:
+            continue
         c = make_case(**spec)
         out = run_case(c)
         rec = {"generator": "oracle/mp_golden.py (mpmath %s, dps=%d)" % (mp.__version__, mp.mp.dps),
@@ -833,7 +846,9 @@ def main_nlz():
 
 
 if __name__ == "__main__":
-    if "nlz" in sys.argv[1:]:
+    if "rosenbrock" in sys.argv[1:]:
+        main(only=[i for i, c in enumerate(CASES) if c.get("target") == "rosenbrock"])   # only mp_case4.json (BASELINE configs[0])
+    elif "nlz" in sys.argv[1:]:
         main_nlz()      # only the marginal-likelihood fixtures
     elif "pred" in sys.argv[1:]:
         main_pred()

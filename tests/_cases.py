@@ -117,6 +117,8 @@ def synth_problem(seed, D, N, K, S, meanfun=4, noisy=False, target="lumpy"):
         ])
         mx = lp.max(axis=0)
         y = mx + np.log(np.sum(np.exp(lp - mx), axis=0))
+    elif target == "rosenbrock":   # BASELINE configs[0]: the reference's own test target (rosenbrock_test.m:7, noise-free form)
+        y = -np.sum((X[:, :-1] ** 2 - X[:, 1:]) ** 2 + (X[:, :-1] - 1.0) ** 2 / 100.0, axis=1)
     else:  # multivariate Student-t, nu = 5, scale diag(1:D)/D
         nu = 5.0
         sc = np.arange(1, D + 1) / D

@@ -62,7 +62,7 @@ def test_golden_vectors(va, path):
 
 CONFIGS = [
     # name, D, N, K, S, Ns, target
-    ("C1-rosenbrock-shape", 2, 30, 2, 1, 100, "lumpy"),
+    ("C1-rosenbrock", 2, 30, 2, 1, 100, "rosenbrock"),      # BASELINE configs[0]: D = 2, K = 2, Ns = 100, one hyper-sample, Rosenbrock target
     ("C2-student", 6, 200, 10, 8, 1000, "student"),
     ("small-odd", 3, 17, 5, 2, 37, "lumpy"),
     ("D10", 10, 120, 12, 4, 200, "lumpy"),

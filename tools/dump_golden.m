@@ -5,9 +5,13 @@ function dump_golden(repo_root, vbmc_root)
 %
 % For every tests/golden/mp_case*.json, mp_nlz_case*.json, mp_pred_case*.json, mp_pen_case*.json and mp_acq_case*.json this runs the reference's own functions
 % (gplite_post, gplite_pred, gplogjoint, entmc_vbmc, entlb_vbmc, gplite_nlZ, vpbndloss, negelcbo_vbmc, acqf/acqflog/acqus/acqfsn2/acqviqr_vbmc) on the stored
-% inputs and writes tests/golden/matlab_case*.json / matlab_nlz_case*.json / matlab_pred_case*.json / matlab_acq_case*.json next to them.  tools/compare_matlab_golden.py then
-% compares those files with the mpmath vectors (and thereby with the oracle and the HIP path, which are pinned to
-% the mpmath vectors by the test-suite).  Nothing here is needed by CI: the development container has no MATLAB,
+% inputs and writes tests/golden/matlab/matlab_case*.json / matlab_nlz_case*.json / matlab_pred_case*.json / matlab_pen_case*.json /
+% matlab_acq_case*.json (mp_case4.json is BASELINE configs[0]: the GP trained on the reference's own rosenbrock_test target).
+% tools/compare_matlab_golden.py then compares those files with the mpmath vectors (and thereby with the oracle and the HIP path,
+% which are pinned to the mpmath vectors by the test-suite); COMMITTING the tests/golden/matlab/ folder turns the suite's
+% "oracle pinned-by-MATLAB: absent" into "present" (tests/test_matlab_pin.py checks every entry on every run).
+%
+% The one command:   matlab -batch "dump_golden('/path/to/this/repo','/path/to/vbmc')" && python tools/compare_matlab_golden.py  Nothing here is needed by CI: the development container has no MATLAB,
 % which is exactly why the oracle is documented as "parity unpinned by the reference" -- this script is how a
 % maintainer WITH MATLAB closes that gap.
 %
@@ -15,6 +19,8 @@ function dump_golden(repo_root, vbmc_root)
 % draws the script puts a temporary randn.m in front of the built-in that pops pre-loaded blocks (restored afterwards).
 addpath(vbmc_root); vbmc('all');                                   % adds acq, ent, gplite, misc, shared, utils (vbmc.m:1056-1078)
 gold = fullfile(repo_root,'tests','golden');
+outdir = fullfile(gold,'matlab');
+if ~exist(outdir,'dir'); mkdir(outdir); end
 files = dir(fullfile(gold,'mp_case*.json'));
 shadow = tempname; mkdir(shadow);
 fid = fopen(fullfile(shadow,'randn.m'),'w');
@@ -49,7 +55,7 @@ for f = 1:numel(files)
     out.G_s = Fs(:)'; out.dG_s = dFs'; out.I_sk = I_sk; out.J_sjk = J_sjk; out.varG_s_full = varF1(:)';
     [~,~,varF2] = gplogjoint(vp,gp,[0 0 0 0],0,1,2,0);
     out.varG_s_diag = varF2(:)';
-    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+    write_json(fullfile(outdir,strrep(files(f).name,'mp_','matlab_')),out);
 end
 files = dir(fullfile(gold,'mp_nlz_case*.json'));
 for f = 1:numel(files)
@@ -63,7 +69,7 @@ for f = 1:numel(files)
         [out.nlZ(s),g] = gplite_nlZ(hyp(:,s),gp,[]);
         out.dnlZ(s,:) = g(:)';
     end
-    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+    write_json(fullfile(outdir,strrep(files(f).name,'mp_','matlab_')),out);
 end
 % prediction with the general noise models (gplite_noisefun.m:176-210), ystar / s2star and the log predictive density
 files = dir(fullfile(gold,'mp_pred_case*.json'));
@@ -81,7 +87,7 @@ for f = 1:numel(files)
         out.alpha(s,:) = gp.post(s).alpha';
         out.min_sn2(s) = 1/gp.post(s).sW(1)^2/gp.post(s).sn2_mult;     % gplite_core.m:281
     end
-    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+    write_json(fullfile(outdir,strrep(files(f).name,'mp_','matlab_')),out);
 end
 % soft-bound and weight penalties (misc/vpbndloss.m, utils/softbndloss.m, misc/negelcbo_vbmc.m:146-162): vpbndloss directly, the
 % weight penalty as negelcbo_vbmc adds it (difference of the calls with and without thetabnd on a one-point surrogate, no entropy
@@ -100,7 +106,7 @@ for f = 1:numel(files)
     [F1,dF1] = negelcbo_vbmc(theta,0,vp,gp1,0,1,0,0,tb);
     [F0,dF0] = negelcbo_vbmc(theta,0,vp,gp1,0,1,0,0,[]);
     out = struct('L_bnd',Lb,'dL_bnd',dLb(:)','L_w',(F1-F0)-Lb,'dL_w',(dF1(:)-dF0(:))'-dLb(:)');
-    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+    write_json(fullfile(outdir,strrep(files(f).name,'mp_','matlab_')),out);
 end
 % acquisition functions (acq/acqf_vbmc.m, acqflog_vbmc.m, acqus_vbmc.m, acqfsn2_vbmc.m, acqviqr_vbmc.m) on the stored points, called
 % directly with the statistics acqwrapper_vbmc.m:17-29 forms (the wrapper itself needs vp.trinfo / warpvars_vbmc)
@@ -135,7 +141,7 @@ for f = 1:numel(files)
     out.acqus = acqus_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
     out.acqfsn2 = acqfsn2_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
     out.acqviqr = acqviqr_vbmc(Xs,vp,gp,optimState,fmu,fs2,fbar,vtot)';
-    write_json(fullfile(gold,strrep(files(f).name,'mp_','matlab_')),out);
+    write_json(fullfile(outdir,strrep(files(f).name,'mp_','matlab_')),out);
 end
 end
 
