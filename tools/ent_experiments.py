@@ -17,6 +17,8 @@ VARIANTS = {"base": [], "norng": ["-DVBMC_EXP_NORNG"], "noexp": ["-DVBMC_EXP_NOE
             "nomfma": ["-DVBMC_EXP_NOS", "-DVBMC_EXP_NOPV"],
             "novalu": ["-DVBMC_EXP_NORNG", "-DVBMC_EXP_NOEXP", "-DVBMC_EXP_NOEPI", "-DVBMC_EXP_NOW"],
             "stag": ["-DVBMC_STAG"], "now_stag": ["-DVBMC_EXP_NOW", "-DVBMC_STAG"],   # the staggered two-sign schedule at four k-tiles too
+            # two waves per SIMD (256 VGPRs, no spills) for every two-k-tile kernel with a component tail
+            "x_w2": ["-DVBMC_ENT_WAVES(KT_,QS_,TL_)=((((KT_)<=2&&(QS_)<=4)&&!((KT_)==2&&(TL_)))?3:2)"],
             "bare": ["-DVBMC_EXP_NORNG", "-DVBMC_EXP_NOEXP", "-DVBMC_EXP_NOEPI", "-DVBMC_EXP_NOW", "-DVBMC_EXP_NOS", "-DVBMC_EXP_NOPV"]}
 
 
@@ -49,7 +51,7 @@ def one(R, Ns):
     import vbmc_amd
     from bench import synth_inputs
 
-    D, N, K, S = 10, 400, 50, 20
+    D, N, K, S = 10, 400, int(os.environ.get('EXP_K', '50')), 20
     inp = synth_inputs(0, D, N, K, S)
     eng = vbmc_amd.Engine(0)
     gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)
