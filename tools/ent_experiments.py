@@ -18,7 +18,7 @@ VARIANTS = {"base": [], "norng": ["-DVBMC_EXP_NORNG"], "noexp": ["-DVBMC_EXP_NOE
             "novalu": ["-DVBMC_EXP_NORNG", "-DVBMC_EXP_NOEXP", "-DVBMC_EXP_NOEPI", "-DVBMC_EXP_NOW"],
             "stag": ["-DVBMC_STAG"], "now_stag": ["-DVBMC_EXP_NOW", "-DVBMC_STAG"],   # the staggered two-sign schedule at four k-tiles too
             # two waves per SIMD (256 VGPRs, no spills) for every two-k-tile kernel with a component tail
-            "x_w2": ["-DVBMC_ENT_WAVES(KT_,QS_,TL_)=((((KT_)<=2&&(QS_)<=4)&&!((KT_)==2&&(TL_)))?3:2)"],
+            "x_w2": ["-DVBMC_ENT_WAVES(KT_,QS_,TL_,HV_)=((((KT_)<=2&&(QS_)<=4)&&!((KT_)==2&&(TL_)))?3:2)"],
             "bare": ["-DVBMC_EXP_NORNG", "-DVBMC_EXP_NOEXP", "-DVBMC_EXP_NOEPI", "-DVBMC_EXP_NOW", "-DVBMC_EXP_NOS", "-DVBMC_EXP_NOPV"]}
 
 

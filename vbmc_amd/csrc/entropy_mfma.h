@@ -111,11 +111,12 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
-// tools/ent_experiments.py x_w2 at D = 10), so that one instantiation moved.
+// tools/ent_experiments.py x_w2 at D = 10), so that one instantiation moved (single-wave workgroups only: the multi-wave ones
+// were not re-measured).
 #ifndef VBMC_ENT_WAVES
-#define VBMC_ENT_WAVES(KT_, QS_, TL_) ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2)) ? 3 : 2)
+#define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2)
 #endif
-__global__ void __launch_bounds__(WAVE * HV, VBMC_ENT_WAVES(KT, QS, TL)) k_entropy_mfma(EntArgs a) {
+__global__ void __launch_bounds__(WAVE * HV, VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
   static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
   constexpr int TLN = TL > 0 ? TL : 1;     // tail values per lane: tail component 4u + lg, u < TL (the layout of a k-tile's register u)
