@@ -7,7 +7,7 @@ tag=${1:-px}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $out/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -4 > $out/pytest_gpu.txt   # (RCCL prints a banner after pytest's last line)
 python bench.py --extras 2> $out/bench_stderr.txt | tail -1 > $out/bench.json
 python tools/bench_aux.py 2>/dev/null | tail -1 > $out/bench_aux.json
 vbmc_amd/lib/microbench > $out/microbench.json 2>&1
