@@ -245,6 +245,12 @@ typedef struct vbmc_elbo_args {
   int32_t restart_stride;    /* restart_offset + r * restart_stride (stride 0 is read as 1).  0 / 1: the position in this      */
                              /* batch.  A batch dealt over G devices (vbmc_elbo_batch_multi: device g gets restarts g, g+G,   */
                              /* ...) passes g / G, so that every restart draws what it would draw in the undivided batch      */
+  int32_t no_jacobian;       /* 1: gradients with respect to sigma, lambda and the weights w themselves -- the JACOBIAN_FLAG = 0  */
+                             /* form of gplogjoint / entmc_vbmc / entlb_vbmc (misc/gplogjoint.m:352-373, ent/entmc_vbmc.m:110-125, */
+                             /* ent/entlb_vbmc.m:132-143) -- instead of log sigma, log lambda, eta.  Stand-alone forms only: no soft  */
+                             /* bounds (bnd_lb NULL), no variance gradient.  0 (default): the transformed gradients negelcbo uses   */
+  double* dvarG;             /* T x R  gradient of the diagonal variance of the expected log joint, gplogjoint's 4th output     */
+                             /* (compute_var = 2 with compute_grad; misc/gplogjoint.m:375-413), or NULL                          */
 } vbmc_elbo_args;
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);

@@ -4,7 +4,7 @@ function [H,dH] = entmc_vbmc(vp,Ns,grad_flags,jacobian_flag)
 % Same signature and defaulting as the reference (ent/entmc_vbmc.m:1-14).  The device path evaluates the
 % entropy term alone (vbmc_elbo_batch with a NULL surrogate, include/vbmc_hip.h) and returns the gradient for
 % the flagged groups in the order [mu(:); log sigma; log lambda; eta] with the Jacobians applied
-% (:110-125).  JACOBIAN_FLAG = 0 with gradients goes to the reference further down the path.
+% (:110-125), or without them for JACOBIAN_FLAG = 0 (gradients with respect to sigma, lambda and w themselves).
 % VBMC_HIP_PARITY=1: the K blocks randn(D,1,Ns/2) are drawn here in the reference's order (:53), and nothing else is drawn.
 % K > 256 (the library's limit) goes to the reference before any draw.
 if nargin < 2 || isempty(Ns); Ns = 10; end
@@ -12,11 +12,6 @@ if nargout < 2; grad_flags = false; elseif nargin < 3 || isempty(grad_flags); gr
 if isscalar(grad_flags); grad_flags = ones(1,4)*grad_flags; end
 if nargin < 4 || isempty(jacobian_flag); jacobian_flag = true; end
 g = any(grad_flags);
-if g && ~jacobian_flag
-    ref = vbmc_hip_reference('entmc_vbmc');
-    [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag);
-    return;
-end
 if vp.K > 256 || vp.D > 32
     ref = vbmc_hip_reference('entmc_vbmc');
     if nargout > 1; [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag); else; H = ref(vp,Ns,grad_flags,jacobian_flag); end
@@ -38,7 +33,7 @@ else
     seed = randi(2^31-1);
 end
 try
-    [~,~,~,H,~,dH] = vbmc_hip_mex('elbo',uint64(0),theta(:),vpt,Ns,double(g),0,0,0,[],epsblk,seed,1);
+    [~,~,~,H,~,dH] = vbmc_hip_mex('elbo',uint64(0),theta(:),vpt,Ns,double(g),0,0,0,[],epsblk,seed,1,double(~jacobian_flag));
 catch err
     if ~strcmp(err.identifier,'vbmc_hip:unsupported') || ~isempty(epsblk); rethrow(err); end    % after parity draws: no second pass
     ref = vbmc_hip_reference('entmc_vbmc');

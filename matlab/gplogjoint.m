@@ -2,11 +2,11 @@ function [F,dF,varF,dvarF,varss,I_sk,J_sjk] = gplogjoint(vp,gp,grad_flags,avg_fl
 %GPLOGJOINT Drop-in shim: expected log joint (Bayesian quadrature) on an MI355X through vbmc_hip_mex.
 %
 % Same signature and defaulting as the reference (misc/gplogjoint.m:1-30).  Accelerated: (a) averaged over
-% hyper-parameter samples (AVG_FLAG = 1) with Jacobian-transformed gradients (JACOBIAN_FLAG) for exactly the
+% hyper-parameter samples (AVG_FLAG = 1) with Jacobian-transformed or (JACOBIAN_FLAG = 0) untransformed gradients for exactly the
 % parameter groups VP optimises; (b) per-hyper-sample values WITHOUT gradients (AVG_FLAG = 0: F and VARF are
 % 1-by-Ns, VARSS = 0) -- the forms private/activesample_vbmc.m:155 ([~,~,varF] = gplogjoint(vp,gp,0,0,0,1)) and
-% misc/vpoptimizeweights_vbmc.m:42 ([~,~,~,~,~,I_sk,J_sjk] = gplogjoint(vp,gp,0,0,0,1,1)) use.  No gradient of the
-% variance as a separate output.  Other call forms go to the reference further down the path.
+% misc/vpoptimizeweights_vbmc.m:42 ([~,~,~,~,~,I_sk,J_sjk] = gplogjoint(vp,gp,0,0,0,1,1)) use; (c) DVARF, the gradient of the
+% diagonal variance (COMPUTE_VAR = 2, with the Jacobians).  Other call forms go to the reference further down the path.
 if nargin < 3; grad_flags = []; end
 if nargin < 4 || isempty(avg_flag); avg_flag = true; end
 if nargin < 5 || isempty(jacobian_flag); jacobian_flag = true; end
@@ -22,7 +22,8 @@ if compute_vargrad && compute_var ~= 2
 end
 
 vpflags = [vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambda, vp.optimize_weights];
-supported = (avg_flag || ~any(grad_flags)) && (jacobian_flag || ~any(grad_flags)) && ~compute_vargrad && any(gp.meanfun == [0 1 4]) ...
+supported = (avg_flag || ~any(grad_flags)) && (~compute_vargrad || jacobian_flag) && any(gp.meanfun == [0 1 4]) ...
+    && ~(separate_K && any(grad_flags)) ...
     && (~any(grad_flags) || isequal(logical(grad_flags(:)'),logical(vpflags))) ...
     && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) && (~vp.optimize_weights || isfield(vp,'eta'));
 if ~supported
@@ -37,15 +38,20 @@ end
 h = vbmc_hip_gp_handle(gp);
 g = any(grad_flags);
 if avg_flag || numel(gp.post) == 1
-    [~,~,F,~,varF,~,varss,I_sk,J_sjk,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,double(g), ...
-        double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+    dvarF = [];
+    if compute_vargrad
+        [~,~,F,~,varF,~,varss,I_sk,J_sjk,dF,~,~,dvarF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,1, ...
+            2,double(separate_K),0,[],[],0,numel(gp.post));
+    else
+        [~,~,F,~,varF,~,varss,I_sk,J_sjk,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,double(g), ...
+            double(compute_var),double(separate_K),0,[],[],0,numel(gp.post),double(~jacobian_flag));
+    end
     if ~avg_flag; varss = 0; end
 else                                            % misc/gplogjoint.m:398-399: no averaging, varss stays 0
     [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0, ...
         double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
-    varss = 0;
+    varss = 0; dvarF = [];
 end
 if ~g; dF = []; end
-dvarF = [];
 if ~compute_var; varF = []; varss = []; end
 end

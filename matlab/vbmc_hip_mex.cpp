@@ -9,8 +9,10 @@
 //     h  = vbmc_hip_mex('gp_upload', gpstruct)             -> uint64 handle of a device-resident gp.post
 //          vbmc_hip_mex('gp_free', h)
 //     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk,dG,G_s,varG_s] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
-//                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty, seed, numel(gp.post))
-//                                     (G_s, varG_s: the per-hyper-sample outputs of gplogjoint(...,avg_flag = 0))
+//                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty, seed, numel(gp.post), no_jacobian)
+//                                     (G_s, varG_s: the per-hyper-sample outputs of gplogjoint(...,avg_flag = 0); no_jacobian,
+//                                     optional: 1 = gradients with respect to sigma, lambda, w themselves, the JACOBIAN_FLAG = 0
+//                                     form of entmc_vbmc / entlb_vbmc / gplogjoint)
 //     [F,dF,varG,G,H,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo_batch', h, Theta /*T x R*/, vp, Ns, compute_grad, compute_var, beta,
 //                                thetabnd_or_empty, seed, separate_K, numel(gp.post))
 //                                (the R candidates of vpsieve_vbmc.m:74-78, or the 2*Nslowopts eval_fullelcbo calls of
@@ -254,6 +256,7 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     const mxArray* eps = nrhs > 10 ? prhs[10] : nullptr;  // D x Ns/2 x K block drawn by the shim with randn, or []
     if (eps && !mxIsEmpty(eps)) { a.eps_mode = 1; a.eps = mxGetDoubles(eps); a.eps_shared = 1; }
     else { a.eps_mode = 0; a.seed = (uint64_t)(nrhs > 11 ? mxGetScalar(prhs[11]) : 0); }
+    a.no_jacobian = (nrhs > 13 && !mxIsEmpty(prhs[13])) ? (mxGetScalar(prhs[13]) != 0) : 0;
     const size_t T = mxGetNumberOfElements(theta);
     mxArray *F = mxCreateDoubleMatrix(1, 1, mxREAL), *dF = mxCreateDoubleMatrix(a.compute_grad ? T : 0, a.compute_grad ? 1 : 0, mxREAL);
     mxArray *G = mxCreateDoubleMatrix(1, 1, mxREAL), *H = mxCreateDoubleMatrix(1, 1, mxREAL), *vG = mxCreateDoubleMatrix(1, 1, mxREAL);
@@ -276,10 +279,12 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
       a.G_s = mxGetDoubles(Gs);
       if (nlhs > 11 && a.compute_var) { vGs = mxCreateDoubleMatrix(1, S, mxREAL); a.varG_s = mxGetDoubles(vGs); }
     }
+    mxArray* dvG = nullptr;         // 13th output: gradient of the diagonal variance (dvarF of misc/gplogjoint.m:27)
+    if (nlhs > 12 && a.compute_grad && a.compute_var == 2) { dvG = mxCreateDoubleMatrix(T, 1, mxREAL); a.dvarG = mxGetDoubles(dvG); }
     vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
     if (st != VBMC_OK) return fail(st);  // MATLAB frees the mxArrays created above on error
-    mxArray* outs[12] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs};
-    for (int i = 0; i < 12 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    mxArray* outs[13] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs, dvG};
+    for (int i = 0; i < 13 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
     return 0;
   }
 

@@ -10,6 +10,7 @@ import pytest
 
 from oracle import vbmc_ref as R
 from tests._cases import synth_problem
+from tests._mex import MexError
 
 pytestmark = pytest.mark.gpu
 
@@ -112,6 +113,22 @@ def test_elbo_with_host_draws_all_twelve_outputs(mex, va):
     o = mex.call(6, "elbo", np.uint64(0), theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 0, 0, 0, None, eps_m, 0, 1)
     re = va.negelcbo_batch(theta, 0, vp, None, Ns, True, 0, eps=eps, eps_shared=True)
     same(o[3][0, 0], re["H"][0]); same(o[5][:, 0], re["dH"][:, 0])
+    # 14th argument: JACOBIAN_FLAG = 0 as the stand-alone shims pass it (matlab/entmc_vbmc.m, matlab/gplogjoint.m)
+    o = mex.call(6, "elbo", np.uint64(0), theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 0, 0, 0, None, eps_m, 0, 1, 1)
+    rn = va.negelcbo_batch(theta, 0, vp, None, Ns, True, 0, eps=eps, eps_shared=True, jacobian_flag=False)
+    same(o[3][0, 0], rn["H"][0]); same(o[5][:, 0], rn["dH"][:, 0])
+    assert np.max(np.abs(rn["dH"][:, 0] - re["dH"][:, 0])) > 1e-8
+    o = mex.call(10, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), 0, 1, 0, 0, 0, None, None, 0, S, 1)
+    rn = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 0, jacobian_flag=False)
+    same(o[2][0, 0], rn["G"][0]); same(o[9][:, 0], rn["dG"][:, 0])
+    # 13th output: the gradient of the diagonal variance (matlab/gplogjoint.m, dvarF)
+    o = mex.call(13, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), 0, 1, 2, 0, 0, None, None, 0, S)
+    rv = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 2, outputs=("F", "dF", "G", "dG", "varG", "dvarG"))
+    same(o[4][0, 0], rv["varG"][0]); same(o[12][:, 0], rv["dvarG"][:, 0])
+    assert np.max(np.abs(o[12])) > 0
+    with pytest.raises(MexError) as e:                            # the Jacobian of the soft bounds is part of the penalty's gradient
+        mex.call(2, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 0, 0, 0, tb, eps_m, 0, S, 1)
+    assert e.value.identifier in ("vbmc_hip:error", "vbmc_hip:unsupported")
     mex.call(0, "gp_free", hh)
 
 

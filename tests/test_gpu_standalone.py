@@ -69,10 +69,6 @@ def test_entropy_defaults_and_refusals(va):
     exact = 0.5 * 3 * (1 + np.log(2 * np.pi)) + 3 * np.log(vp1["sigma"][0]) + np.sum(np.log(vp1["lambda"]))
     assert relerr(va.entlb_vbmc(vp1, nargout=1), exact) < 1e-12
     assert abs(va.entmc_vbmc(vp1, 20000, nargout=1, seed=3) - exact) < 0.05
-    with pytest.raises(va.VbmcUnsupported):
-        va.entmc_vbmc(vp, 10, True, False)   # untransformed gradients stay with the reference
-    with pytest.raises(va.VbmcUnsupported):
-        va.entlb_vbmc(vp, True, False)
     # the ABI refuses variance outputs without a surrogate
     theta, _ = va.get_vptheta(vp)
     with pytest.raises(ValueError):
@@ -109,9 +105,45 @@ def test_gplogjoint_refusals(va):
     with pytest.raises(va.VbmcUnsupported):
         va.gplogjoint(vp, gp, True, False, nargout=2)            # avg_flag = 0
     with pytest.raises(va.VbmcUnsupported):
-        va.gplogjoint(vp, gp, True, True, False, nargout=2)      # jacobian_flag = 0
+        va.gplogjoint(vp, gp, True, True, False, 2, nargout=4)   # dvarF without the Jacobians
     with pytest.raises(ValueError, match="FullVarianceGradient"):
         va.gplogjoint(vp, gp, True, True, True, 1, nargout=4)    # gplogjoint.m:27-30
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+def test_untransformed_gradients(va, flags):
+    """JACOBIAN_FLAG = 0 (round 3: on the device): gradients with respect to sigma, lambda and the weights w themselves --
+    misc/gplogjoint.m:352-373, ent/entmc_vbmc.m:110-125 and ent/entlb_vbmc.m:132-143 skipped -- for every subset of the groups."""
+    p, gp, vp = make(21, 4, 30, 6, 2)
+    Ns = 60
+    eps = p["rng"].standard_normal((vp["K"], Ns // 2, vp["D"]))
+    H, dH = va.entmc_vbmc(vp, Ns, flags, False, eps=eps)
+    Ho, dHo = R.entmc_vbmc(vp, Ns, flags, False, eps=eps)
+    assert relerr(H, Ho) < 1e-10 and relerr(dH, np.asarray(dHo).reshape(-1)) < 1e-9
+    H, dH = va.entlb_vbmc(vp, flags, False)
+    Ho, dHo = R.entlb_vbmc(vp, flags, False)[:2]
+    assert relerr(H, Ho) < 1e-10 and relerr(dH, np.asarray(dHo).reshape(-1)) < 1e-9
+    F, dF = va.gplogjoint(vp, gp, flags, True, False, nargout=2)
+    o = R.gplogjoint(vp, gp, flags, True, False, 0)
+    assert relerr(F, o["F"]) < 1e-10 and relerr(dF, np.asarray(o["dF"]).reshape(-1)) < 1e-9
+    # and they differ from the transformed ones wherever a Jacobian acts (every group but mu)
+    if any(flags[1:]):
+        _, dFj = va.gplogjoint(vp, gp, flags, True, True, nargout=2)
+        assert np.max(np.abs(dFj - dF)) > 1e-6
+
+
+@pytest.mark.parametrize("flags", [(1, 1, 1, 1), (1, 0, 1, 0), (0, 1, 0, 1)])
+def test_gplogjoint_variance_gradient_output(va, flags):
+    """[F,dF,varF,dvarF] = gplogjoint(vp,gp,grad_flags,1,1,2): the gradient of the diagonal variance as the 4th output
+    (misc/gplogjoint.m:27,375-413; round 3: vbmc_elbo_args.dvarG)."""
+    p, gp, vp = make(22, 3, 28, 5, 3)
+    F, dF, varF, dvarF = va.gplogjoint(vp, gp, flags, True, True, 2, nargout=4)
+    o = R.gplogjoint(vp, gp, flags, True, True, 2, compute_vargrad=True)
+    assert relerr(F, o["F"]) < 1e-10 and relerr(dF, np.asarray(o["dF"]).reshape(-1)) < 1e-9
+    assert relerr(varF, o["varF"]) < 1e-8
+    ref = np.asarray(o["dvarF"]).reshape(-1)
+    assert dvarF.shape == ref.shape
+    assert np.max(np.abs(dvarF - ref)) < 1e-7 * max(1e-30, np.max(np.abs(ref)))
 
 
 @pytest.mark.parametrize("cfg", [(4, 50, 6, 5), (3, 30, 3, 1), (10, 120, 20, 8)])

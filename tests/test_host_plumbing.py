@@ -112,10 +112,8 @@ def test_vbmc_rnd_moments_and_balanced_split():
 def test_grad_flag_defaulting_of_the_standalone_wrappers():
     """entmc_vbmc / entlb_vbmc / gplogjoint resolve grad_flags like the reference (ent/entmc_vbmc.m:5-11,
     misc/gplogjoint.m:17-23): no second output -> no gradient, omitted flags -> all four groups, a scalar flag is
-    broadcast; theta then holds exactly the flagged groups, and untransformed gradients are refused.  Host logic only."""
+    broadcast; theta then holds exactly the flagged groups, with or without the Jacobians.  Host logic only."""
     from vbmc_amd.elbo import _with_grad_groups
-    from vbmc_amd import VbmcUnsupported
-
     rng = np.random.default_rng(0)
     D, K = 3, 4
     vp = vpm.make_vp(rng.standard_normal((D, K)), np.exp(rng.standard_normal(K)), np.ones(D), eta=rng.standard_normal(K))
@@ -129,8 +127,8 @@ def test_grad_flag_defaulting_of_the_standalone_wrappers():
     assert th.size == 2 * K
     vpt, th, g = _with_grad_groups(vp, True, 2, True, "entlb_vbmc")
     assert g and th.size == D * K + K + D + K
-    with pytest.raises(VbmcUnsupported):
-        _with_grad_groups(vp, True, 2, False, "entlb_vbmc")
+    vpt, th, g = _with_grad_groups(vp, True, 2, False, "entlb_vbmc")   # JACOBIAN_FLAG = 0: same theta, the device drops the Jacobians
+    assert g and th.size == D * K + K + D + K
     assert vp["optimize_mu"] and vp["optimize_weights"]            # the caller's vp is not modified
 
 

@@ -55,6 +55,8 @@ class ElboArgs(C.Structure):
         ("G_s", _dp), ("varG_s", _dp),
         ("chunk_world", C.c_int32),
         ("restart_offset", C.c_int32), ("restart_stride", C.c_int32),
+        ("no_jacobian", C.c_int32),
+        ("dvarG", _dp),
     ]
 
 

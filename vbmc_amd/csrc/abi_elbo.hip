@@ -434,6 +434,7 @@ struct ElboPlan {
   bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false, tri_gemm = false;
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
+  int no_jacobian = 0;
   int r0 = 0, rstride = 1;   // device-RNG key of restart r: r0 + r * rstride (vbmc_elbo_args.restart_offset / restart_stride)
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0, n_sepk = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
@@ -494,6 +495,12 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   int M = a->Ns;
   if (M < 0) return set_err(ctx, VBMC_ERR_INVALID, "Ns must be >= 0");
   if (a->restart_offset < 0 || a->restart_stride < 0) return set_err(ctx, VBMC_ERR_INVALID, "restart_offset / restart_stride must be >= 0");
+  if (a->no_jacobian && compute_grad) {
+    if (a->bnd_lb) return set_err(ctx, VBMC_ERR_INVALID, "no_jacobian (JACOBIAN_FLAG = 0) is a form of the stand-alone functions: no soft bounds");
+    if (compute_var == 2) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "the variance gradient without the Jacobians (JACOBIAN_FLAG = 0 with compute_var = 2) is not accelerated");
+  }
+  if (a->dvarG && !(compute_grad && compute_var == 2)) return set_err(ctx, VBMC_ERR_INVALID, "dvarG needs compute_grad with compute_var = 2");
+  P.no_jacobian = a->no_jacobian && compute_grad ? 1 : 0;
   P.r0 = a->restart_offset; P.rstride = a->restart_stride > 0 ? a->restart_stride : 1;
   M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
   const int Mh = P.Mh = M / 2;
@@ -897,7 +904,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.vpd = P.d_vpd; fa.theta = P.d_theta; fa.ljbar = P.d_ljbar; fa.var = P.d_var; fa.var_stride = P.d_var ? P.var_stride : 0;
   fa.bnd = P.d_bnd; fa.has_bnd = P.has_bnd ? 1 : 0;
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
-  fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out;
+  fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out; fa.no_jacobian = P.no_jacobian;
   {
     size_t lds = (FIN_THREADS + 3 * (size_t)K + (P.fin_big ? 0 : (size_t)D * K + 3 * (size_t)T) + 8) * sizeof(double);
     fa.big = P.d_finbig;
@@ -918,7 +925,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (fin_seq) hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+    if (fin_seq && !P.no_jacobian) hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);   // (the untransformed gradients exist in k_finalize_ws only)
     else hipLaunchKernelGGL(k_finalize_ws, dim3(R), dim3(FIN_THREADS), lds, st, fa);
     LAUNCH_CHECK(ctx, "k_finalize");
   }
@@ -1040,6 +1047,11 @@ static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbm
     if (P.mc && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ent_ms = ms;
   }
   elbo_unpack(P, a, hout);
+  if (a->dvarG && P.vgrad && P.d_var) {   // gplogjoint's dvarF: behind the two variance scalars of each restart's record
+    HIP_TRY(ctx, hipMemcpy2DAsync(a->dvarG, (size_t)dm.T * sizeof(double), P.d_var + 2, (size_t)P.var_stride * sizeof(double),
+                                  (size_t)dm.T * sizeof(double), R, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
   if (packed) {
     if (a->I_sk) memcpy(a->I_sk, hI, (size_t)R * S * K * sizeof(double));
     if (wantJ) memcpy(a->J_sjk, hJ, (size_t)R * S * K * K * sizeof(double));

@@ -780,6 +780,7 @@ struct FinArgs {
   const double* bnd;      // lb[Text] ub[Text] or null
   double TolCon, WeightThreshold, WeightPenalty, beta;
   int M, C, ncol, want_grad, has_bnd, var_stride;
+  int no_jacobian;        // 1: gradients with respect to sigma, lambda, w themselves (JACOBIAN_FLAG = 0 of the stand-alone forms; k_finalize_ws only)
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* big;            // null, or R x (3T + DK) doubles of global scratch for dG | dH | dP | gsc when they exceed the LDS
   double* out;            // R x (OUT_HDR + 3T)
@@ -1128,6 +1129,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   __syncthreads();
 
   const bool grad = a.want_grad != 0;
+  const bool jac = a.no_jacobian == 0;   // the Jacobians of sigma = exp(.), lambda = exp(.), w = softmax(eta) (gplogjoint.m:352-373, entmc_vbmc.m:110-125)
   const double lognf = v[L.lognf()];
   const double invM = a.entpart ? 1.0 / (2.0 * a.M) : 0.0;
   const int ncol = a.ncol;
@@ -1147,15 +1149,15 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
         if (lane == 0) scal[0] = G;
         if (grad) {
           if (dm.opt[1])
-            for (int k = lane; k < K; k += 64) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * sigma[k] * invS;
+            for (int k = lane; k < K; k += 64) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * (jac ? sigma[k] : 1.0) * invS;
           if (dm.opt[3])
-            for (int k = lane; k < K; k += 64) { const double Ib = lb[(size_t)k * LJS] * invS; dG[dm.off_eta + k] = w[k] * Ib - w[k] * G; }
+            for (int k = lane; k < K; k += 64) { const double Ib = lb[(size_t)k * LJS] * invS; dG[dm.off_eta + k] = jac ? w[k] * Ib - w[k] * G : Ib; }
           if (dm.opt[2])
             for (int d = 0; d < D; ++d) {
               double acc = 0.0;
               for (int k = lane; k < K; k += 64) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
               acc = wave_sum(acc);
-              if (lane == 0) dG[dm.off_lambda + d] = acc * lam[d] * invS;
+              if (lane == 0) dG[dm.off_lambda + d] = acc * (jac ? lam[d] : 1.0) * invS;
             }
         }
       } break;
@@ -1170,10 +1172,11 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
           const double H = wave_sum(part);
           if (lane == 0) scal[1] = H;
           if (grad && dm.opt[1])
-            for (int j = lane; j < K; j += 64) dH[dm.off_sigma + j] = w[j] * pe[(size_t)j * ncol + 1 + D] * invM * sigma[j];
+            for (int j = lane; j < K; j += 64) dH[dm.off_sigma + j] = w[j] * pe[(size_t)j * ncol + 1 + D] * invM * (jac ? sigma[j] : 1.0);
         } else {
           if (lane == 0) scal[1] = eb[0];
-          if (grad && dm.opt[1]) for (int k = lane; k < K; k += 64) dH[dm.off_sigma + k] = eb[1 + D * K + k];
+          // k_entlb's sigma and lambda blocks carry their Jacobians (entlb_vbmc.m:132-137): divided back out for JACOBIAN_FLAG = 0
+          if (grad && dm.opt[1]) for (int k = lane; k < K; k += 64) dH[dm.off_sigma + k] = jac ? eb[1 + D * K + k] : eb[1 + D * K + k] / sigma[k];
         }
       } break;
       case 3:     // mu block of dH (:82)
@@ -1194,10 +1197,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
               double acc = 0.0;
               for (int j = lane; j < K; j += 64) acc += w[j] * sigma[j] * pe[(size_t)j * ncol + 2 + D + d] * invM;
               acc = wave_sum(acc);
-              if (lane == 0) dH[dm.off_lambda + d] = acc;
+              if (lane == 0) dH[dm.off_lambda + d] = jac ? acc : acc / lam[d];      // (:116-118)
             }
           else
-            for (int d = lane; d < D; d += 64) dH[dm.off_lambda + d] = eb[1 + D * K + K + d];
+            for (int d = lane; d < D; d += 64) dH[dm.off_lambda + d] = jac ? eb[1 + D * K + K + d] : eb[1 + D * K + K + d] / lam[d];
         }
         break;
       case 5:     // eta block of dH: raw weight gradient (:97-100), then the softmax Jacobian (:121-123)
@@ -1220,7 +1223,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
           }
           const double dot = wave_sum(dpart);
           wave_fence();
-          for (int l = lane; l < K; l += 64) dH[dm.off_eta + l] = w[l] * wraw[l] - w[l] * dot;
+          for (int l = lane; l < K; l += 64) dH[dm.off_eta + l] = jac ? w[l] * wraw[l] - w[l] * dot : wraw[l];
         }
         break;
       case 6:     // soft bounds, mu block (vpbndloss.m, softbndloss.m)

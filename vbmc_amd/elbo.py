@@ -186,7 +186,7 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
 
 def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
                    separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
-                   sparse_cutoff=0.0, outputs=None, chunk_world=0):
+                   sparse_cutoff=0.0, outputs=None, chunk_world=0, jacobian_flag=True):
     """R evaluations of negelcbo_vbmc in one device pass.
 
     outputs: None = everything below; a subset such as ("F", "dF") -- what the optimiser loop reads,
@@ -198,6 +198,8 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     reference's randn stream (entmc_vbmc.m:53); None -> device Philox stream keyed by ``seed``.
     sparse_cutoff: 0 dense; c > 0 skips 16-component tiles whose terms are provably < exp(-c) of q(x).
     chunk_world: W > 1 chunks the MC samples as negelcbo_shard does for a world of W ranks (its bit-exact 1-GPU reference).
+    jacobian_flag=False: gradients with respect to sigma, lambda, w themselves (the JACOBIAN_FLAG = 0 form of the stand-alone
+    functions; no soft bounds, no variance gradient).  outputs may name "dvarG" (T, R) with compute_var = 2 and a gradient.
     """
     engine = engine or default_engine()
     ctx = engine.ctx
@@ -208,6 +210,7 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     D, K = int(vp["D"]), int(vp["K"])
     a, keep, compute_var = _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps,
                                        eps_device_ptr, eps_shared, seed, engine, sparse_cutoff, chunk_world)
+    a.no_jacobian = 0 if jacobian_flag else 1
     if gp is None:   # entropy only (entmc_vbmc / entlb_vbmc on their own): the ABI takes a NULL surrogate
         if compute_var or separate_K:
             raise ValueError("an entropy-only evaluation has no variance or per-component outputs")
@@ -233,6 +236,8 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
         a.dH = outbuf("dH", (T, R))
     a.varG = outbuf("varG", (R,))
     a.varGss = outbuf("varGss", (R,))
+    if outputs is not None and "dvarG" in outputs and compute_grad and compute_var == 2:
+        a.dvarG = outbuf("dvarG", (T, R))
     if separate_K:
         a.I_sk = outbuf("I_sk", (S, K, R))
         if compute_var:
@@ -287,9 +292,6 @@ def _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, who):
         grad_flags = True
     gf = np.broadcast_to(np.asarray(grad_flags, dtype=bool).reshape(-1), (4,)) if np.size(grad_flags) == 1 \
         else np.asarray(grad_flags, dtype=bool).reshape(4)
-    if gf.any() and not jacobian_flag:
-        raise VbmcUnsupported(-1, who + ": gradients without the Jacobian of the parameter transformation (jacobian_flag = 0) "
-                              "are not accelerated")
     vpt = dict(vp)
     if gf.any():
         for name, f in zip(("optimize_mu", "optimize_sigma", "optimize_lambda", "optimize_weights"), gf):
@@ -308,7 +310,7 @@ def entmc_vbmc(vp, Ns=10, grad_flags=None, jacobian_flag=True, nargout=2, *, eps
         Ns = 10   # :4
     vpt, theta, g = _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, "entmc_vbmc")
     r = negelcbo_batch(theta, 0.0, vpt, None, int(Ns), g, 0, None, eps=eps, seed=seed, engine=engine,
-                       outputs=("H", "dH") if g else ("H",))
+                       outputs=("H", "dH") if g else ("H",), jacobian_flag=bool(jacobian_flag))
     H = float(r["H"][0])
     return (H, r["dH"][:, 0].copy() if g else np.zeros(0)) if nargout > 1 else H
 
@@ -316,7 +318,8 @@ def entmc_vbmc(vp, Ns=10, grad_flags=None, jacobian_flag=True, nargout=2, *, eps
 def entlb_vbmc(vp, grad_flags=None, jacobian_flag=True, nargout=2, *, engine=None):
     """[H,dH] = entlb_vbmc(vp,grad_flags,jacobian_flag)  (ent/entlb_vbmc.m:1): deterministic entropy lower bound."""
     vpt, theta, g = _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, "entlb_vbmc")
-    r = negelcbo_batch(theta, 0.0, vpt, None, 0, g, 0, None, engine=engine, outputs=("H", "dH") if g else ("H",))
+    r = negelcbo_batch(theta, 0.0, vpt, None, 0, g, 0, None, engine=engine, outputs=("H", "dH") if g else ("H",),
+                       jacobian_flag=bool(jacobian_flag))
     H = float(r["H"][0])
     return (H, r["dH"][:, 0].copy() if g else np.zeros(0)) if nargout > 1 else H
 
@@ -327,37 +330,40 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
     (misc/gplogjoint.m:1-30).  Accelerated call forms: averaged over the hyper-parameter samples (avg_flag = 1) with
     transformed gradients (jacobian_flag), and per-hyper-sample values without gradients (avg_flag = 0: F and varF are
     length-S vectors, varss = 0 -- the forms of private/activesample_vbmc.m:155 and misc/vpoptimizeweights_vbmc.m:42);
-    the gradient of the variance is not a separate output of the device path (dvarF is returned as None unless asked for
-    together with gradients, which is refused like the other unsupported forms)."""
+    untransformed gradients (jacobian_flag = 0: with respect to sigma, lambda and w themselves, :352-373 skipped), and dvarF --
+    the gradient of the diagonal variance (compute_var = 2, nargout >= 4; :375-413).  Not accelerated: per-hyper-sample gradients
+    (avg_flag = 0 with grad_flags; no caller in VBMC) and dvarF with jacobian_flag = 0."""
     if separate_K is None:
         separate_K = nargout > 5            # :13
     if compute_var is None:
         compute_var = nargout > 2           # :14
     compute_var = int(compute_var)
     vpt, theta, g = _with_grad_groups(vp, grad_flags, nargout, jacobian_flag, "gplogjoint")
-    if nargout > 3 and compute_var and g:
+    want_dvar = nargout > 3 and compute_var and g      # compute_vargrad (:27)
+    if want_dvar:
         if compute_var != 2:                # :27-30
             raise ValueError("gplogjoint:FullVarianceGradient Computation of gradient of log joint variance is currently "
                              "available only for diagonal approximation of the variance.")
-        raise VbmcUnsupported(-1, "gplogjoint: dvarF as a separate output is not accelerated")
+        if not jacobian_flag:
+            raise VbmcUnsupported(-1, "gplogjoint: the variance gradient without the Jacobians (jacobian_flag = 0) is not accelerated")
     if not avg_flag and g:
         raise VbmcUnsupported(-1, "gplogjoint: per-hyper-sample gradients (avg_flag = 0 with grad_flags) are not accelerated")
     if separate_K and g:
         raise VbmcUnsupported(-1, "gplogjoint: per-component outputs together with gradients are not accelerated")
-    want = ["G"] + (["dG"] if g else []) + (["varG", "varGss"] if compute_var else [])
+    want = ["G"] + (["dG"] if g else []) + (["varG", "varGss"] if compute_var else []) + (["dvarG"] if want_dvar else [])
     if separate_K:
         want += ["I_sk"] + (["J_sjk"] if compute_var else [])
     if not avg_flag:
         want += ["G_s"] + (["varG_s"] if compute_var else [])
     r = negelcbo_batch(theta, 0.0, vpt, gp, 0, g, compute_var, None, separate_K=bool(separate_K), engine=engine,
-                       outputs=tuple(want))
+                       outputs=tuple(want), jacobian_flag=bool(jacobian_flag))
     if not avg_flag and r["G_s"].shape[0] > 1:     # :399: no averaging -> F, varF are 1 x S; varss stays 0 (:398)
         outs = (r["G_s"][:, 0].copy(), np.zeros(0), r["varG_s"][:, 0].copy() if compute_var else None, None, 0.0,
                 r["I_sk"][:, :, 0].copy() if separate_K else None,
                 r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
         return outs[0] if nargout <= 1 else outs[:nargout]
     outs = (float(r["G"][0]), r["dG"][:, 0].copy() if g else np.zeros(0),
-            float(r["varG"][0]) if compute_var else None, None,
+            float(r["varG"][0]) if compute_var else None, r["dvarG"][:, 0].copy() if want_dvar else None,
             (float(r["varGss"][0]) if avg_flag else 0.0) if compute_var else None,
             r["I_sk"][:, :, 0].copy() if separate_K else None,
             r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
