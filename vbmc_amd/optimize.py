@@ -475,7 +475,8 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
     Branches: NSentK > 0 with ELCBOWeight = 0 -> Adam (:108-135).  ELCBOWeight ~= 0 -> the reference has no gradient of the
     full variance and switches to CMA-ES on the value (:38-46,137-160): mirrored with cmaes_batched, each generation one
     batched value-only pass with compute_var = 1.  NSentK = 0 (deterministic entropy: EntropySwitch or K = 1) -> the reference
-    calls fminunc from MATLAB's Optimization Toolbox (:73-81); SciPy's BFGS drives the same device objective here.
+    calls fminunc from MATLAB's Optimization Toolbox (:73-81); SciPy's BFGS drives the same device objective here, with the
+    device gradient or (ELCBOWeight ~= 0) forward differences whose T + 1 points are one batched pass.
 
     Device-stream schedule (``seed`` = s; tests replay it through ``trace``): sieve s; Adam iteration it of chain group g
     (s << 20) + (1 << 16) + (g << 12) + it; eval_fullelcbo batch (s << 20) + (2 << 16); pruning evaluation number c
@@ -495,9 +496,8 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
         # deterministic entropy (EntropySwitch or K = 1, :73-106): the reference calls fminunc (MATLAB's Optimization Toolbox,
         # quasi-Newton BFGS, TolFun = DetEntTolOpt, MaxFunEvals = 50 (D + 2)); here SciPy's BFGS stands in its place, one
         # device evaluation (value + gradient, entlb_vbmc entropy) per objective call
-        if not gradient_available:
-            raise NotImplementedError("vpoptimize_vbmc: deterministic entropy with ELCBOWeight ~= 0 runs fminunc on finite differences "
-                                      "(misc/vpoptimize_vbmc.m:43-46,80): not mirrored")
+        # With ELCBOWeight ~= 0 (no gradient of the full variance, :38-46) fminunc differences the value (GradObj off, forward
+        # differences): the T + 1 points of one difference gradient are ONE batched value-only device pass here.
         optimizer = "bfgs"
     if optimizer not in ("adam", "cmaes", "bfgs"):
         raise ValueError("vbmc:VPoptimize Unknown stochastic optimizer.")
@@ -527,15 +527,30 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
         from scipy.optimize import minimize
 
         for i, vp0 in enumerate(starts):
-            def fun(th, vp0=vp0):
-                r = negelcbo_batch(np.asarray(th, dtype=np.float64), elcbo_beta, vp0, gp, 0, True, 0, thetabnd, engine=engine, outputs=("F", "dF"))
-                return float(r["F"][0]), r["dF"][:, 0].copy()
+            nev = [0]
 
-            res = minimize(fun, theta0s[i], jac=True, method="BFGS",
-                           options={"gtol": options["DetEntTolOpt"], "maxiter": 50 * (D + 2)})
+            def fun(th, vp0=vp0):
+                th = np.asarray(th, dtype=np.float64)
+                if gradient_available:
+                    nev[0] += 1
+                    r = negelcbo_batch(th, elcbo_beta, vp0, gp, 0, True, 0, thetabnd, engine=engine, outputs=("F", "dF"))
+                    return float(r["F"][0]), r["dF"][:, 0].copy()
+                # fminunc's forward differences: step sqrt(eps) * max(|x|, TypicalX = 1), signed like x
+                h = np.sqrt(np.finfo(np.float64).eps) * np.where(th < 0, -1.0, 1.0) * np.maximum(np.abs(th), 1.0)
+                X = np.repeat(th[:, None], th.size + 1, axis=1)
+                X[np.arange(th.size), np.arange(1, th.size + 1)] += h
+                h = X[np.arange(th.size), np.arange(1, th.size + 1)] - th        # the step actually taken in floating point
+                nev[0] += th.size + 1
+                F = negelcbo_batch(np.asfortranarray(X), elcbo_beta, vp0, gp, 0, False, int(bool(compute_var)), thetabnd, engine=engine,
+                                   outputs=("F",))["F"]
+                return float(F[0]), (F[1:] - F[0]) / h
+
+            # MaxFunEvals = 50 (D + 2) counts every differenced point in fminunc (:76): the iteration cap follows from it
+            maxit = 50 * (D + 2) if gradient_available else max(2, (50 * (D + 2)) // (theta0s[i].size + 1))
+            res = minimize(fun, theta0s[i], jac=True, method="BFGS", options={"gtol": options["DetEntTolOpt"], "maxiter": maxit})
             thetaopt[i] = np.asarray(res.x, dtype=np.float64)
             if trace is not None:
-                trace.append({"kind": "bfgs", "slot": i, "nfev": int(res.nfev), "fun": float(res.fun)})
+                trace.append({"kind": "bfgs", "slot": i, "nfev": int(nev[0]), "fun": float(res.fun), "fd": not gradient_available})
     elif optimizer == "adam":
         ms = {"min": min(options["SGDStepSize"], 0.001)}
         scaling = min(0.1, options["SGDStepSize"] * 10) if (optimState["Warmup"] or not vp["optimize_weights"]) else min(0.1, options["SGDStepSize"])
