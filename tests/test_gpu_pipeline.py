@@ -125,3 +125,32 @@ def test_collect_with_another_layout_is_refused(va):
     F, dF = obj.collect(1)
     ref = va.negelcbo_batch(batches[0], 0, vp, gp, 60, True, 0, seed=4)
     assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])
+
+
+def test_log_joint_role_of_the_entropy_launch_matches_the_separate_kernel():
+    """Small grids (S R < half the compute units, value + gradient, no per-hyper-sample outputs): the expected log joint runs as
+    extra single-wave workgroups of the MFMA entropy kernel's launch (entropy_mfma.h CO = true).
+    The role is on in this process (VBMC_LJ_CO unset); asking for the per-component records (separate_K) or for the variance
+    routes the SAME evaluation through the separate k_logjoint launch: G and its gradient agree to summation order, and the
+    role's answer is pinned by the oracle like every other."""
+    import vbmc_amd as va
+    from oracle import vbmc_ref as R
+    from tests._cases import synth_problem
+
+    for (D, N, K, S, Ns, nR, seed) in [(10, 400, 50, 20, 56, 1, 3), (4, 70, 17, 3, 40, 2, 4), (14, 130, 36, 5, 24, 1, 5), (2, 30, 2, 1, 100, 3, 6),
+                                       (7, 64, 21, 6, 30, 1, 7)]:
+        p = synth_problem(seed, D, N, K, S)
+        gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=p["meanfun"])
+        vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+        vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+        theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+        th = np.asfortranarray(theta[:, None] + 0.03 * np.random.default_rng(seed).standard_normal((theta.size, nR)))
+        co = va.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=11, outputs=("F", "G", "dG", "H", "dH"))
+        sep = va.negelcbo_batch(th, 0, vp, gp, Ns, True, 2, seed=11, outputs=("F", "G", "dG", "H", "dH", "varG"))   # variance: separate launch
+        assert np.array_equal(co["H"], sep["H"]) and np.array_equal(co["dH"], sep["dH"])       # same entropy kernel body, same stream
+        assert np.allclose(co["G"], sep["G"], rtol=1e-13, atol=0)
+        assert np.max(np.abs(co["dG"] - sep["dG"])) <= 1e-12 * np.max(np.abs(sep["dG"]))
+        for r in range(nR):
+            o = R.negelcbo_vbmc(th[:, r], 0, vp, gp, 0, True, 0)
+            assert abs(co["G"][r] - o["G"]) <= 1e-10 * abs(o["G"])
+            assert np.max(np.abs(co["dG"][:, r] - np.asarray(o["dG"]).reshape(-1))) <= 1e-9 * np.max(np.abs(o["dG"]))

@@ -16,9 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-MAIN_DEPS = ["vbmc_hip.hip", "abi_elbo.hip", "abi_gp.hip", "abi_comm.hip", "common.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "elbo_kernels.h", "trsm_mfma.h",
+MAIN_DEPS = ["vbmc_hip.hip", "abi_elbo.hip", "abi_gp.hip", "abi_comm.hip", "common.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "elbo_kernels.h", "logjoint_body.h", "trsm_mfma.h",
              "var_kernels.h", "gp_kernels.h", "chol_mfma.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
-MFMA_DEPS = ["ent_mfma_inst.hip", "entropy_mfma.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h"]
+MFMA_DEPS = ["ent_mfma_inst.hip", "entropy_mfma.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "logjoint_body.h"]
 QS_RANGE = range(1, 10)
 
 

@@ -435,6 +435,7 @@ struct ElboPlan {
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   int no_jacobian = 0;
+  bool lj_records = false;   // the caller reads per-hyper-sample log-joint records (separate_K, G_s / varG_s, the variance kernels)
   int r0 = 0, rstride = 1;   // device-RNG key of restart r: r0 + r * rstride (vbmc_elbo_args.restart_offset / restart_stride)
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0, n_sepk = 0;
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
@@ -564,7 +565,12 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   { vbmc_status s_ = ensure(ctx, ctx->prep, (size_t)R * VL.stride() * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->entp, (size_t)R * K * (D + ENTP_EXTRA) * sizeof(double)); if (s_) return s_; }
   const int LJS = 2 * D + 2;
-  { vbmc_status s_ = ensure(ctx, ctx->ljpart, ((size_t)R * S * K * LJS + (size_t)R * K * LJS) * sizeof(double)); if (s_) return s_; }
+  // (LJ_CO_SPLIT records per hyper-sample where the log joint may run as a role of the entropy launch: small grids only, see elbo_enqueue)
+  // (also set when the caller asks for the numbers a SHARDED evaluation gives -- chunk_world: the sharded path adds the log-joint
+  // records per hyper-sample, so the unsharded evaluation it is compared with bit for bit must too)
+  P.lj_records = a->separate_K || a->G_s || a->varG_s || compute_var != 0 || chunk_world > 0 || a->chunk_world > 1;
+  const size_t ljrec = (size_t)R * S * K * LJS * (((long long)S * R < ctx->num_cu / 2 && !P.lj_records) ? LJ_CO_SPLIT : 1);
+  { vbmc_status s_ = ensure(ctx, ctx->ljpart, (ljrec + (size_t)R * K * LJS) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->out, P.out_n * sizeof(double)); if (s_) return s_; }
   {
     const size_t nbig = P.fin_big ? (size_t)R * (3 * (size_t)T + (size_t)D * K) : 0;
@@ -578,7 +584,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   P.d_vpd = (double*)ctx->prep.p;
   P.d_entp = (double*)ctx->entp.p;
   P.d_lj = (double*)ctx->ljpart.p;
-  P.d_ljbar = P.d_lj + (size_t)R * S * K * LJS;
+  P.d_ljbar = P.d_lj + ljrec;
   P.d_out = (double*)ctx->out.p;
 
   if (P.mc) {
@@ -748,18 +754,25 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
   const bool fork = sh.mode == 0 && ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
+  // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
+  const char* ljf = getenv("VBMC_LJ_KERNEL");
+  // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
+  // kernel has the lower latency
+  const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
+  const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
+  // Small grids (a single chain, a handful of restarts): the VALU log joint runs as a ROLE of the entropy launch (single-wave
+  // workgroups ahead of the entropy ones, entropy_mfma.h CO = true) -- two dependent-chain-bound kernels side by side instead of
+  // one after the other, one launch less.  Its records are per (hyper-sample, split of the training set); the reduction over
+  // hyper-samples adds the splits.  VBMC_LJ_CO=0 keeps the separate launch (A/B runs, tests).
+  static const bool co_off = [] { const char* e = getenv("VBMC_LJ_CO"); return e && !strcmp(e, "0"); }();
+  const bool co = !co_off && sh.mode == 0 && !fork && !lj_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && !(P.cutoff > 0.0) &&
+                  P.compute_grad && !P.lj_records && (long long)S * R < ctx->num_cu / 2;
   auto enqueue_logjoint = [&](hipStream_t ls) -> vbmc_status {
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ls));
-    {
-      // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
-      const char* ljf = getenv("VBMC_LJ_KERNEL");
-      // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
-      // kernel has the lower latency
-      const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
+    if (!co) {
       // VALU kernel: four waves per cell (training set split, lower latency) while the grid is small, one wave per cell (no
       // replicated per-wave setup) once there are enough cells to fill the chip several times over
       const bool lj_split = dm.N > 64 && (long long)((K + 3) / 4) * S * R < 8LL * ctx->num_cu;
-      const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
       DISPATCH_DT(dt, {
         constexpr int NCT = (2 * DT + 1 + 15) / 16;
         const int nw = (K + 15) / 16;
@@ -816,10 +829,19 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     ea.part = sh.mode == 1 ? sh.send + shard_lj_doubles(P, sh.world) : P.d_part;
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff; ea.r0 = P.r0; ea.rstride = P.rstride;
+    int co_rows = 0;
+    if (co) {
+      LjCo& lc = ea.lj;
+      lc.nsplit = dm.N > 64 ? LJ_CO_SPLIT : 1;
+      lc.nwg = ((K + 3) / 4) * S * lc.nsplit;
+      lc.rows = co_rows = (lc.nwg + nc - 1) / nc;
+      lc.want_grad = P.compute_grad;
+      lc.dm = dm; lc.X = gp->X; lc.alpha = gp->alpha; lc.gpc = gp->gpc; lc.delta2 = P.d_delta2; lc.lj = P.d_lj;
+    }
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     if (sh.mode == 2 || nc <= 0) {
     } else if (P.use_mfma) {
-      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(nc, K, R), st, ea);
+      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(nc, K + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
     } else {
       const size_t lds = P.ent_lds;
@@ -837,7 +859,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
                          P.d_part, P.d_red);
     else
       hipLaunchKernelGGL(k_reduce_both, dim3(K, R, 2), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
-                         P.d_part, P.d_red, S, 2 * D + 2, P.d_lj, P.d_ljbar);
+                         P.d_part, P.d_red, co ? S * ea.lj.nsplit : S, 2 * D + 2, P.d_lj, P.d_ljbar);
     LAUNCH_CHECK(ctx, "k_ent_reduce / k_reduce_both");
     fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {

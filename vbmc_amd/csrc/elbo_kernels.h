@@ -17,6 +17,7 @@
 #include "common.h"
 #include "device_math.h"
 #include "elbo_types.h"
+#include "logjoint_body.h"
 
 // Sum over the workgroup (blockDim.x a multiple of 64; `red` holds at least one double per wave): a fixed-order butterfly
 // inside each wave, then the wave totals in wave order -- two barriers instead of a log2(blockDim) LDS tree.
@@ -142,20 +143,13 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_logjoint: misc/gplogjoint.m:162-271.  One wave = four (component k, hyper-sample s) cells: lane
-// (kq = lane>>4, ni = lane&15) strides over the training points n = ni, ni+16, ... for component
-// k = 4*blockIdx.x + kq.  The per-dimension constants tau_d, log tau_d are computed once by the lane
-// with ni = d (and d+16) and broadcast inside the 16-lane row; the 2D+2 sums are reduced over the
-// 16 lanes of a row only (4 butterfly steps, each shuffle serving four cells).
+// k_logjoint: misc/gplogjoint.m:162-271 (body: logjoint_body.h).  One workgroup = four (component k, hyper-sample s) cells;
+// with LJ_MAXW waves each wave takes every LJ_MAXW-th 16-point slab of the training set.
 // partial layout LJ[r][s][k][2D+2] = I_k, w_k*dmu[D], w_k*dsigma (no Jacobian), w_k*dlambda[D]
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double row16_sum(double v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
-
-#define LJ_MAXW 4   // waves per workgroup of k_logjoint: each takes every LJ_MAXW-th 16-point slab of the training set
+#ifndef LJ_MAXW
+#define LJ_MAXW 4   // waves per workgroup of k_logjoint (eight: 59 vs 52 us per single-chain Adam iteration, round 3)
+#endif
 
 template <int DT>
 __global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const double* __restrict__ vpd,
@@ -167,136 +161,18 @@ __global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const 
   constexpr int NC = 2 * DT + 2;                 // I, M[DT], S, L[DT]
   __shared__ double TAB[VB_EXP_TAB_N];
   __shared__ double PART[LJ_MAXW][4][NC];        // per wave and component: the 16-lane row sums
-  const int s = blockIdx.y, r = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
-  const int ni = lane & 15, kq = lane >> 4, rowbase = lane & 48;
-  const int D = dm.D, K = dm.K, N = dm.N;
-  const int kk = 4 * blockIdx.x + kq;
-  const bool kvalid = kk < K;
-  const int k = kvalid ? kk : K - 1;
+  const int s = blockIdx.y, r = blockIdx.z, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
   for (int t = threadIdx.x; t < VB_EXP_TAB_N; t += blockDim.x) TAB[t] = c_exp2_tab[t];
-  VpLayout L{D, K};
+  VpLayout L{dm.D, dm.K};
   const double* v = vpd + (size_t)r * L.stride();
-  const double* g = gpc + (size_t)s * GPC_STRIDE(D);
-  const double sig = v[L.sigma() + k];
-  const double wk = v[L.w() + k];
-  // lane ni owns dimensions d = ni and ni + 16
-  double my_lam[2] = {0.0, 0.0}, my_mu[2] = {0.0, 0.0}, my_itau[2] = {0.0, 0.0};
-  double my_logtau = 0.0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int d = ni + 16 * h;
-    if (d < D && (h == 0 || DT > 16)) {
-      my_lam[h] = v[L.lambda() + d];
-      my_mu[h] = v[L.mu() + d + D * k];
-      double tau = sqrt(sig * sig * my_lam[h] * my_lam[h] + g[d] + delta2[d]);  // :164
-      my_logtau += log(tau);
-      my_itau[h] = 1.0 / tau;
-    }
-  }
-  const double sumlogtau = row16_sum(my_logtau);
-  double mu[DT], itau[DT], c1[DT], c2[DT], c3[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    const int src = rowbase | (d & 15), h = d >> 4;
-    const double lam_d = __shfl(my_lam[h], src, 64);
-    mu[d] = __shfl(my_mu[h], src, 64);
-    itau[d] = __shfl(my_itau[h], src, 64);     // zero for padded dimensions: they vanish below
-    const double li = lam_d * itau[d], si = sig * itau[d];
-    c1[d] = -itau[d];                          // dz_dmu factor      (:207)
-    c2[d] = li * li;                           // dz_dsigma factor   (:228)
-    c3[d] = si * si * lam_d;                   // dz_dlambda factor  (:249)
-  }
-  const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
-  __syncthreads();
-  double accI = 0.0, accS = 0.0;
-  double accM[DT], accL[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d) { accM[d] = 0.0; accL[d] = 0.0; }
-  const double* al = alpha + (size_t)s * N;
-  // the loads of the next slab are issued before the arithmetic of the current one (a single chain is bound by this
-  // kernel's memory latency, not its flops)
-  const int step = 16 * NW;
-  int n = ni + 16 * wv;
-  double xc[DT], ac = 0.0;
-#pragma unroll
-  for (int d = 0; d < DT; ++d) xc[d] = (d < D && n < N) ? X[n + (size_t)N * d] : 0.0;
-  if (n < N) ac = al[n];
-  while (n < N) {
-    const int nn = n + step;
-    double xn[DT], an = 0.0;
-#pragma unroll
-    for (int d = 0; d < DT; ++d) xn[d] = (d < D && nn < N) ? X[nn + (size_t)N * d] : 0.0;
-    if (nn < N) an = al[nn];
-    double dl[DT];
-    double a2 = 0.0;
-#pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      dl[d] = (mu[d] - xc[d]) * itau[d];  // delta_k :167
-      a2 = fma(dl[d], dl[d], a2);
-    }
-    double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);  // z_k :168
-    double za = z * ac;
-    accI += za;
-    if (want_grad) {
-      double ssum = 0.0;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        double q = fma(dl[d], dl[d], -1.0);
-        accM[d] = fma(dl[d] * c1[d], za, accM[d]);  // dz_dmu*alpha :207-208
-        ssum = fma(c2[d], q, ssum);                  // :228
-        accL[d] = fma(c3[d] * q, za, accL[d]);       // :249-250
-      }
-      accS = fma(ssum * sig, za, accS);
-    }
-#pragma unroll
-    for (int d = 0; d < DT; ++d) xc[d] = xn[d];
-    ac = an;
-    n = nn;
-  }
-  accI = row16_sum(accI);
-  if (want_grad) {
-    accS = row16_sum(accS);
-#pragma unroll
-    for (int d = 0; d < DT; ++d) { accM[d] = row16_sum(accM[d]); accL[d] = row16_sum(accL[d]); }
-  }
-  if (ni == 0) {
-    double* pp = PART[wv][kq];
-    pp[0] = accI;
-    if (want_grad) {
-      pp[1 + DT] = accS;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) { pp[1 + d] = accM[d]; pp[2 + DT + d] = accL[d]; }
-    }
-  }
+  const double* g = gpc + (size_t)s * GPC_STRIDE(dm.D);
+  lj_wave_sums<DT>(dm, v, X, alpha + (size_t)s * dm.N, g, delta2, TAB, blockIdx.x, wv, NW, want_grad, &PART[wv][0][0],
+                   [] { __syncthreads(); });
   __syncthreads();
   // ---- epilogue by wave 0, one lane per output column of its component; wave partials added in wave order
-  if (wv != 0 || !kvalid) return;
-  double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
-  const int ncol = want_grad ? 2 * D + 2 : 1;
-  for (int c = ni; c < ncol; c += 16) {
-    // column c of the output record <-> slot of PART (padded to DT)
-    const int d = (c >= 1 && c <= D) ? c - 1 : (c >= D + 2 ? c - D - 2 : 0);
-    const int slot = c == 0 ? 0 : (c <= D ? c : (c == D + 1 ? 1 + DT : 2 + DT + d));
-    double acc = PART[0][kq][slot];
-    for (int w2 = 1; w2 < NW; ++w2) acc += PART[w2][kq][slot];
-    // mean-function terms; iom2 = 0 and xm = 0 for meanfun 0/1 so they vanish  :169-174
-    if (c == 0 || c == D + 1) {
-      double nu = 0.0, sl2 = 0.0;
-      for (int e = 0; e < D; ++e) {
-        double xm = g[D + e], iom2 = g[2 * D + e];
-        double lam_e = v[L.lambda() + e], mu_e = v[L.mu() + e + D * k];
-        nu += iom2 * (mu_e * mu_e + sig * sig * lam_e * lam_e - 2.0 * mu_e * xm + xm * xm + delta2[e]);
-        sl2 += iom2 * lam_e * lam_e;
-      }
-      o[c] = c == 0 ? acc + g[3 * D + 1] + (-0.5 * nu)          // I_k
-                    : wk * acc - wk * sig * sl2;                 // :229-231
-    } else {
-      const double xm = g[D + d], iom2 = g[2 * D + d];
-      const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
-      o[c] = c <= D ? wk * acc - wk * iom2 * (mu_d - xm)                   // :208-210
-                    : wk * acc - wk * sig * sig * iom2 * lam_d;            // :250-252
-    }
-  }
+  if (wv != 0) return;
+  lj_write_record<DT>(dm, v, g, delta2, &PART[0][0][0], NW, 4 * NC, blockIdx.x, want_grad, true,
+                      lj + ((size_t)r * dm.S + s) * dm.K * (2 * dm.D + 2));
 }
 
 // ------------------------------------------------------------------------------------------

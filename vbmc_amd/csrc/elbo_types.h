@@ -35,6 +35,17 @@ struct ElboDims {
 };
 
 
+#define LJ_CO_SPLIT 4   // splits of the training set per cell group in the log-joint role (one single-wave workgroup each)
+// The log-joint role of the MFMA entropy kernel's launch (logjoint_body.h: lj_co_role; entropy_mfma.h, CO = true)
+struct LjCo {
+  int rows;              // grid rows (blockIdx.y) taken by the role, ahead of the entropy kernel's K; 0: no role
+  int nwg;               // role workgroups per restart = G4 * S * nsplit
+  int nsplit, want_grad;
+  ElboDims dm;
+  const double *X, *alpha, *gpc, *delta2;
+  double* lj;
+};
+
 // k_entropy / k_entropy_mfma arguments.
 // partial layout PE[r][j][c][NCOL]: sum log q | G[D] | SG | LG[D] | W[K]   (NCOL = 1 if !GRAD); c = blockIdx.x is the
 // slot in the output record (C slots per (r, j)), c0 + blockIdx.x the chunk of samples it covers
@@ -50,4 +61,5 @@ struct EntArgs {
   int r0, rstride;       // the device-RNG stream of restart r is keyed by r0 + r * rstride: the restart's index in the WHOLE batch when
                          // the batch is dealt over several devices (vbmc_elbo_batch_multi: r0 = g, rstride = G); 0, 1 otherwise
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
+  LjCo lj;               // CO kernels only: the expected log joint as extra workgroups of this launch (lj.rows = 0: none)
 };

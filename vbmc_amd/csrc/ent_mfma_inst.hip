@@ -22,6 +22,12 @@ static void launch_kt(int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
     if (grad) (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, true, false, HV, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     else (void)hipFuncSetAttribute((const void*)k_entropy_mfma<QS_VALUE, KT, false, false, HV, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
+  if constexpr (HV == 1 && QS_VALUE <= 4) {
+    if (ea.lj.rows > 0) {   // the launch carries the log-joint role (gradient kernels, dense): the caller checked vbmc_ent_mfma_has_co
+      hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, true>), grid, dim3(WAVE), lds, st, ea);
+      return;
+    }
+  }
   if (ea.cutoff > 0.0 && HV == 1 && !TL) {  // opt-in block-sparse variant (single-wave kernels only, no component tail)
     if (grad) hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, true, true, 1>), grid, dim3(WAVE), lds, st, ea);
     else hipLaunchKernelGGL((k_entropy_mfma<QS_VALUE, KT, false, true, 1>), grid, dim3(WAVE), lds, st, ea);

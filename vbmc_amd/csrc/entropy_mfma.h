@@ -32,6 +32,7 @@
 #include "device_math.h"
 #include "elbo_types.h"
 #include "exp2_tab1k.h"
+#include "logjoint_body.h"
 
 typedef double mf4 __attribute__((ext_vector_type(4)));
 
@@ -107,7 +108,12 @@ __device__ __forceinline__ void ent_sync_wg() {
 // TAIL they live in the lane layout (sample li, tail component lg) -- one value per lane: the linear part of the exponent is D
 // FMAs per tile from two LDS rows (the sample's draws, the component's coefficients), one exp per sign, and the lane's value IS
 // the A operand of one PV MFMA (component index = inner index lg), its weight-gradient term one lane-local FMA.
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0>
+// CO = true (single-wave workgroups, D <= 16): the launch carries the expected log joint as well -- its first a.lj.rows grid rows are
+// single-wave log-joint workgroups (logjoint_body.h: lj_co_role), the entropy workgroups follow.  For a single chain (one restart, a
+// few dozen samples per component) both kernels are bound by their own dependent chains, not by the chip: side by side an Adam
+// iteration loses the shorter of the two (round 3).  These kernels are built for two waves per SIMD whatever the entropy body needs:
+// the grids they serve do not fill the chip anyway, and the log-joint body keeps 6 x 4 QS values per lane in registers.
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
@@ -116,7 +122,8 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0>
 #ifndef VBMC_ENT_WAVES
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2)
 #endif
-__global__ void __launch_bounds__(WAVE * HV, VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+__global__ void __launch_bounds__(WAVE * HV, CO ? 2 : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+  static_assert(!CO || (HV == 1 && QS <= 4 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 16");
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
   static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
   constexpr int TLN = TL > 0 ? TL : 1;     // tail values per lane: tail component 4u + lg, u < TL (the layout of a k-tile's register u)
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(WAVE * HV, VBMC_ENT_WAVES(KT, QS, TL, HV)) k_e
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   const int tid = threadIdx.x, hv = HV == 1 ? 0 : tid >> 6, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
-  const int c = blockIdx.x, j = blockIdx.y, r = blockIdx.z;
+  const int c = blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
   double* Et = Et_all[0];
   double* RQ = RQ_all[hv];
@@ -155,6 +162,12 @@ __global__ void __launch_bounds__(WAVE * HV, VBMC_ENT_WAVES(KT, QS, TL, HV)) k_e
   // stage this restart's packed parameter block [k][m_1..m_D, h, cK, w, wi] in LDS with coalesced loads;
   // the per-lane operand fragments below are gathered from LDS, not from global memory
   extern __shared__ double PB[];
+  if (CO) {   // workgroup-uniform: the first a.lj.rows grid rows are the log-joint role (>= 8 KB of dynamic LDS: table + rows fit)
+    if ((int)blockIdx.y < a.lj.rows) {
+      lj_co_role<4 * QS>(a.lj, a.vpd, PB);
+      return;
+    }
+  }
   // The parameter block is needed only while the operand fragments are built; afterwards its LDS holds the exp table
   // 2^(j/1024) (8 KB) and, behind it, the PV exchange buffers of multi-wave workgroups [sign][wave][YXN] (the launcher sizes the
   // dynamic LDS for the larger of the two uses)

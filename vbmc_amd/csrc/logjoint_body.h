@@ -1,0 +1,204 @@
+// The body of the VALU expected-log-joint kernel (misc/gplogjoint.m:162-271), shared by k_logjoint (elbo_kernels.h: a workgroup of
+// one or LJ_MAXW waves per group of four components and hyper-sample) and by the log-joint ROLE of the MFMA entropy kernel
+// (entropy_mfma.h, CO = true: single-wave workgroups of the SAME launch, so that a single chain's two independent kernels run side
+// by side instead of one after the other).
+#pragma once
+#include "device_math.h"
+#include "elbo_types.h"
+
+// One wave = four (component k, hyper-sample s) cells: lane (kq = lane>>4, ni = lane&15) strides over the training points
+// n = ni + 16 (wv + NW i) for component k = 4 kgroup + kq.  The per-dimension constants tau_d, log tau_d are computed once by the
+// lane with ni = d (and d+16) and broadcast inside the 16-lane row; the 2D+1 sums are reduced over the 16 lanes of a row only
+// (4 butterfly steps, each shuffle serving four cells).
+// record layout [2D+2] = I_k, w_k*dmu[D], w_k*dsigma (no Jacobian), w_k*dlambda[D]
+__device__ __forceinline__ double row16_sum(double v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// The sums of one wave over its share of the training set -> pp[kq][NC] (LDS rows of this wave, NC = 2 DT + 2: I, M[DT], S, L[DT]).
+// `tab_ready()` is called once, after the set-up arithmetic and before the first exponential: the point where the exp table in
+// LDS must be complete (a workgroup barrier in k_logjoint, a wave-level fence in the role).
+template <int DT, class TabReady>
+__device__ __forceinline__ void lj_wave_sums(const ElboDims& dm, const double* __restrict__ v, const double* __restrict__ X,
+                                             const double* __restrict__ al, const double* __restrict__ g,
+                                             const double* __restrict__ delta2, const double* TAB, int kgroup, int wv, int NW,
+                                             int want_grad, double* pp_wave, TabReady tab_ready) {
+  constexpr int NC = 2 * DT + 2;
+  const int lane = threadIdx.x & 63;
+  const int ni = lane & 15, kq = lane >> 4, rowbase = lane & 48;
+  const int D = dm.D, K = dm.K, N = dm.N;
+  const int kk = 4 * kgroup + kq;
+  const int k = kk < K ? kk : K - 1;
+  VpLayout L{D, K};
+  const double sig = v[L.sigma() + k];
+  // lane ni owns dimensions d = ni and ni + 16
+  double my_lam[2] = {0.0, 0.0}, my_mu[2] = {0.0, 0.0}, my_itau[2] = {0.0, 0.0};
+  double my_logtau = 0.0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int d = ni + 16 * h;
+    if (d < D && (h == 0 || DT > 16)) {
+      my_lam[h] = v[L.lambda() + d];
+      my_mu[h] = v[L.mu() + d + D * k];
+      double tau = sqrt(sig * sig * my_lam[h] * my_lam[h] + g[d] + delta2[d]);  // :164
+      my_logtau += log(tau);
+      my_itau[h] = 1.0 / tau;
+    }
+  }
+  const double sumlogtau = row16_sum(my_logtau);
+  double mu[DT], itau[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    const int src = rowbase | (d & 15), h = d >> 4;
+    mu[d] = __shfl(my_mu[h], src, 64);
+    itau[d] = __shfl(my_itau[h], src, 64);     // zero for padded dimensions: they vanish below
+  }
+  const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
+  tab_ready();
+  // The three gradient sums of :207-250 are  dz_dmu = -1/tau_d * A_d,  dz_dlambda = sigma^2 lambda_d / tau_d^2 * Q_d  and
+  // dz_dsigma = sigma sum_d lambda_d^2 / tau_d^2 * Q_d  with only TWO sums over the training set per dimension,
+  // A_d = sum_n delta_d z alpha  and  Q_d = sum_n (delta_d^2 - 1) z alpha: the factors do not depend on n and are applied once,
+  // after the row sums (round 3: half the FMAs of the loop and 3 DT fewer live registers)
+  double accI = 0.0;
+  double accA[DT], accQ[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { accA[d] = 0.0; accQ[d] = 0.0; }
+  // the loads of the next slab are issued before the arithmetic of the current one (a single chain is bound by this
+  // kernel's memory latency, not its flops)
+  const int step = 16 * NW;
+  int n = ni + 16 * wv;
+  double xc[DT], ac = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) xc[d] = (d < D && n < N) ? X[n + (size_t)N * d] : 0.0;
+  if (n < N) ac = al[n];
+  while (n < N) {
+    const int nn = n + step;
+    double xn[DT], an = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) xn[d] = (d < D && nn < N) ? X[nn + (size_t)N * d] : 0.0;
+    if (nn < N) an = al[nn];
+    double dl[DT];
+    double a2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      dl[d] = (mu[d] - xc[d]) * itau[d];  // delta_k :167
+      a2 = fma(dl[d], dl[d], a2);
+    }
+    double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);  // z_k :168
+    double za = z * ac;
+    accI += za;
+    if (want_grad) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        accA[d] = fma(dl[d], za, accA[d]);                        // :207-208 without its factor
+        accQ[d] = fma(fma(dl[d], dl[d], -1.0), za, accQ[d]);      // :228, :249-250 without theirs
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) xc[d] = xn[d];
+    ac = an;
+    n = nn;
+  }
+  accI = row16_sum(accI);
+  if (want_grad) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { accA[d] = row16_sum(accA[d]); accQ[d] = row16_sum(accQ[d]); }
+  }
+  double accS = 0.0;
+  double* pp = pp_wave + kq * NC;
+  if (want_grad) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const double lam_d = __shfl(my_lam[d >> 4], rowbase | (d & 15), 64);
+      const double li = lam_d * itau[d], si = sig * itau[d];
+      accS = fma(li * li, accQ[d], accS);                                  // dz_dsigma factor   (:228)
+      if (ni == 0) {
+        pp[1 + d] = -itau[d] * accA[d];                                    // dz_dmu factor      (:207)
+        pp[2 + DT + d] = si * si * lam_d * accQ[d];                        // dz_dlambda factor  (:249)
+      }
+    }
+  }
+  if (ni == 0) {
+    pp[0] = accI;
+    if (want_grad) pp[1 + DT] = sig * accS;
+  }
+}
+
+// Output record of component k = 4 kgroup + kq from `nrows` rows of wave sums (row stride `rstride` doubles, added in row order),
+// one lane per output column.  with_const: the closed-form mean-function terms of :169-174 / :208-210 / :229-231 / :250-252 that do
+// not depend on the training set are added (exactly one of the records that are later summed carries them).
+template <int DT>
+__device__ __forceinline__ void lj_write_record(const ElboDims& dm, const double* __restrict__ v, const double* __restrict__ g,
+                                                const double* __restrict__ delta2, const double* pp0, int nrows, int rstride,
+                                                int kgroup, int want_grad, bool with_const, double* __restrict__ o_s /* [K][2D+2] of (r, s) */) {
+  constexpr int NC = 2 * DT + 2;
+  const int lane = threadIdx.x & 63;
+  const int ni = lane & 15, kq = lane >> 4;
+  const int D = dm.D, K = dm.K;
+  const int k = 4 * kgroup + kq;
+  if (k >= K) return;
+  VpLayout L{D, K};
+  const double sig = v[L.sigma() + k];
+  const double wk = v[L.w() + k];
+  double* o = o_s + (size_t)k * (2 * D + 2);
+  const int ncol = want_grad ? 2 * D + 2 : 1;
+  for (int c = ni; c < ncol; c += 16) {
+    // column c of the output record <-> slot of the row (padded to DT)
+    const int d = (c >= 1 && c <= D) ? c - 1 : (c >= D + 2 ? c - D - 2 : 0);
+    const int slot = c == 0 ? 0 : (c <= D ? c : (c == D + 1 ? 1 + DT : 2 + DT + d));
+    double acc = pp0[kq * NC + slot];
+    for (int w2 = 1; w2 < nrows; ++w2) acc += pp0[(size_t)w2 * rstride + kq * NC + slot];
+    if (!with_const) {
+      o[c] = c == 0 ? acc : wk * acc;
+      continue;
+    }
+    // mean-function terms; iom2 = 0 and xm = 0 for meanfun 0/1 so they vanish  :169-174
+    if (c == 0 || c == D + 1) {
+      double nu = 0.0, sl2 = 0.0;
+      for (int e = 0; e < D; ++e) {
+        double xm = g[D + e], iom2 = g[2 * D + e];
+        double lam_e = v[L.lambda() + e], mu_e = v[L.mu() + e + D * k];
+        nu += iom2 * (mu_e * mu_e + sig * sig * lam_e * lam_e - 2.0 * mu_e * xm + xm * xm + delta2[e]);
+        sl2 += iom2 * lam_e * lam_e;
+      }
+      o[c] = c == 0 ? acc + g[3 * D + 1] + (-0.5 * nu)          // I_k
+                    : wk * acc - wk * sig * sl2;                 // :229-231
+    } else {
+      const double xm = g[D + d], iom2 = g[2 * D + d];
+      const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
+      o[c] = c <= D ? wk * acc - wk * iom2 * (mu_d - xm)                   // :208-210
+                    : wk * acc - wk * sig * sig * iom2 * lam_d;            // :250-252
+    }
+  }
+}
+
+// The log-joint role of a single-wave workgroup (entropy_mfma.h, CO kernels): workgroup `w` of the role handles the cell group
+// kgroup = w mod G4, split sp = (w / G4) mod nsplit of the training set, hyper-sample s = w / (G4 nsplit), and writes ITS OWN record
+// lj[r][s nsplit + sp][k][2D+2] -- the reduction over hyper-samples (k_reduce_both with S nsplit "samples") adds the splits, the
+// record of split 0 carries the closed-form terms.  lds: >= 256 + 4 (2 DT + 2) doubles (exp table, then this wave's rows).
+template <int DT>
+__device__ __forceinline__ void lj_co_role(const LjCo& a, const double* __restrict__ vpd, double* lds) {
+  constexpr int NC = 2 * DT + 2;
+  const int w = blockIdx.y * gridDim.x + blockIdx.x, r = blockIdx.z, lane = threadIdx.x & 63;
+  if (w >= a.nwg) return;
+  const ElboDims& dm = a.dm;
+  const int D = dm.D, K = dm.K, G4 = (K + 3) / 4;
+  const int kgroup = w % G4, t = w / G4, sp = t % a.nsplit, s = t / a.nsplit;
+  double* TAB = lds;
+  double* pp = lds + VB_EXP_TAB_N;
+  for (int i = lane; i < VB_EXP_TAB_N; i += 64) TAB[i] = c_exp2_tab[i];
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double* g = a.gpc + (size_t)s * GPC_STRIDE(D);
+  auto fence = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  lj_wave_sums<DT>(dm, v, a.X, a.alpha + (size_t)s * dm.N, g, a.delta2, TAB, kgroup, sp, a.nsplit, a.want_grad, pp, fence);
+  fence();
+  double* o_s = a.lj + ((size_t)r * dm.S * a.nsplit + (size_t)s * a.nsplit + sp) * K * (2 * D + 2);
+  lj_write_record<DT>(dm, v, g, a.delta2, pp, 1, 0, kgroup, a.want_grad, sp == 0, o_s);
+}
