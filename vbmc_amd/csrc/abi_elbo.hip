@@ -766,7 +766,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // hyper-samples adds the splits.  VBMC_LJ_CO=0 keeps the separate launch (A/B runs, tests).
   static const bool co_off = [] { const char* e = getenv("VBMC_LJ_CO"); return e && !strcmp(e, "0"); }();
   const bool co = !co_off && sh.mode == 0 && !fork && !lj_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && !(P.cutoff > 0.0) &&
-                  P.compute_grad && !P.lj_records && (long long)S * R < ctx->num_cu / 2;
+                  P.compute_grad && !P.lj_records && (long long)S * R < ctx->num_cu / 2 && (long long)S * R * P.rstride < ctx->num_cu / 2;   // (the undivided batch's choice when the restarts are dealt over devices)
   auto enqueue_logjoint = [&](hipStream_t ls) -> vbmc_status {
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ls));
     if (!co) {
@@ -832,7 +832,14 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     int co_rows = 0;
     if (co) {
       LjCo& lc = ea.lj;
-      lc.nsplit = dm.N > 64 ? LJ_CO_SPLIT : 1;
+      // splits of the training set per cell group: per-workgroup set-up (exp table, tau / log tau) against the length of the dependent
+      // loop over the training set.  Single chain at the headline shape (260 cell groups, 25 slabs of 16 points), us per Adam
+      // iteration: 1 split 46.6, 2: 41.1, 3: 41.2, 4: 43.0, 6: 45.4, 8: 52.2 (more workgroups than wave slots) -> about 640 role workgroups per restart
+      {
+        const long long cells = (long long)((K + 3) / 4) * S;   // per restart: a restart's bits do not depend on the batch it is in
+        const int slabs = (dm.N + 15) / 16;
+        lc.nsplit = (int)std::max<long long>(1, std::min<long long>(std::min(LJ_CO_SPLIT, slabs), (640 + cells / 2) / cells));
+      }
       lc.nwg = ((K + 3) / 4) * S * lc.nsplit;
       lc.rows = co_rows = (lc.nwg + nc - 1) / nc;
       lc.want_grad = P.compute_grad;

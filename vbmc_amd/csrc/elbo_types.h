@@ -35,7 +35,7 @@ struct ElboDims {
 };
 
 
-#define LJ_CO_SPLIT 4   // splits of the training set per cell group in the log-joint role (one single-wave workgroup each)
+#define LJ_CO_SPLIT 8   // most splits of the training set per cell group in the log-joint role (one single-wave workgroup each; buffer sizing)
 // The log-joint role of the MFMA entropy kernel's launch (logjoint_body.h: lj_co_role; entropy_mfma.h, CO = true)
 struct LjCo {
   int rows;              // grid rows (blockIdx.y) taken by the role, ahead of the entropy kernel's K; 0: no role
