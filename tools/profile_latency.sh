@@ -13,15 +13,19 @@ echo "Un-profiled, 200 iterations after 40 warm-up iterations (\`tools/prof_adam
 echo
 echo "| schedule | Ns per component | us per iteration |"
 echo "|---|---|---|"
-for f in seq ws; do for ns in 28 10000; do
-  v=$(VBMC_FIN=$f PROF_NS=$ns timeout 120 python tools/prof_adam.py 2>&1 | tail -1 | sed 's/us\/iter //')
-  [ $f = seq ] && name="round 2 (\`VBMC_FIN=seq\`: k_prep+Adam, k_logjoint, entropy, k_reduce_both, k_finalize)" || name="round 3 (k_logjoint, entropy, k_reduce_both, k_finalize_ws + Adam + unpacking)"
+for f in seq:0 ws:0 ws:1; do for ns in 28 10000; do
+  v=$(VBMC_FIN=${f%:*} VBMC_LJ_CO=${f#*:} PROF_NS=$ns timeout 120 python tools/prof_adam.py 2>&1 | tail -1 | sed 's/us\/iter //')
+  case $f in
+    seq:0) name="round 2 (\`VBMC_FIN=seq VBMC_LJ_CO=0\`: k_prep+Adam, k_logjoint, entropy, k_reduce_both, k_finalize)";;
+    ws:0) name="round 3, first half (\`VBMC_LJ_CO=0\`: k_logjoint, entropy, k_reduce_both, k_finalize_ws + Adam + unpacking)";;
+    *) name="round 3 (entropy launch with the log-joint role, k_reduce_both, k_finalize_ws + Adam + unpacking)";;
+  esac
   echo "| $name | $ns | $v |"
 done; done
-for f in seq ws; do for ns in 28 10000; do
-  VBMC_FIN=$f PROF_NS=$ns rocprofv3 --kernel-trace -d $out/t -o p -- python tools/prof_adam.py > /dev/null 2>&1
+for f in seq:0 ws:0 ws:1; do for ns in 28 10000; do
+  VBMC_FIN=${f%:*} VBMC_LJ_CO=${f#*:} PROF_NS=$ns rocprofv3 --kernel-trace -d $out/t -o p -- python tools/prof_adam.py > /dev/null 2>&1
   db=$(find $out/t -name '*.db' | head -1)
-  echo; echo "## Kernel trace, VBMC_FIN=$f, Ns = $ns (rocprofv3 --kernel-trace; the profiler adds ~8 us per iteration to the wall time)"; echo
+  echo; echo "## Kernel trace, VBMC_FIN=${f%:*} VBMC_LJ_CO=${f#*:}, Ns = $ns (rocprofv3 --kernel-trace; the profiler adds ~5-8 us per iteration to the wall time)"; echo
   python tools/rocpd_summary.py $db | head -9 | cut -c1-170
   echo; echo "Last iterations:"; echo
   python tools/rocpd_timeline.py $db 16 | cut -c1-120 | head -14
