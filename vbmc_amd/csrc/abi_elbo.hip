@@ -1299,6 +1299,11 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   HIP_TRY(ctx, hipMemsetAsync(A.done, 0, (size_t)R * sizeof(int), st));
   std::vector<int> done(R, 0);
   int iter = 0;
+  // the factors of iteration `it`'s update (utils/fminadam.m:53-57), handed to the kernels with the state
+  auto adam_set_iter = [&](AdamState& S_, int it) {
+    S_.c1 = 1.0 - std::pow(0.9, (double)it); S_.c2 = 1.0 - std::pow(0.999, (double)it);
+    S_.step = step_min + (step_max - step_min) * std::exp(-(double)it / step_decay);
+  };
   // Where the NEXT iteration follows without a stopping test in between, this iteration's finalize kernel applies the Adam update
   // and unpacks the new theta itself (k_finalize_ws: fused), and the next pass starts at its log-joint kernel; before a stopping
   // test (every 20 iterations from the 40th, utils/fminadam.m:65) and at the end the update is a launch of its own.
@@ -1309,13 +1314,16 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     const bool check = iter % 20 == 0 && iter >= 40;
     const bool last = check || iter == MaxIter;
     const bool fuse = fusable && !last;
+    adam_set_iter(A, iter);
     if (fusable) {
       { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, nullptr, 0, nullptr, fuse ? &A : nullptr, iter, prepped); if (s_) return s_; }
       prepped = fuse;
       // the stopping test and the final read-back need this iteration's update now; the next pass unpacks theta itself
       if (!fuse) hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
     } else {   // round-2 schedule (A/B runs): the update of iteration iter - 1 rides on this iteration's k_prep
-      { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, pending ? &A : nullptr, iter - 1); if (s_) return s_; }
+      AdamState Ap = A;
+      if (pending) adam_set_iter(Ap, iter - 1);
+      { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, pending ? &Ap : nullptr, iter - 1); if (s_) return s_; }
       pending = true;
       if (last) { hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out); pending = false; }
     }

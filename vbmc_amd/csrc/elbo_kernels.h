@@ -40,28 +40,33 @@ struct AdamState {
   int* done;                    // R: 0 = running, otherwise the iteration at which the chain stopped
   int T, R, MaxIter;
   double step_min, step_max, step_decay, TolFun;
+  // factors of the update this launch applies (functions of the iteration alone: set by the host per launch, adam_set_iter in
+  // abi_elbo.hip -- two pow and an exp per thread on the critical path of a single chain otherwise)
+  double c1, c2, step;          // 1 - 0.9^iter, 1 - 0.999^iter (fminadam.m:53-54), step size (:56-57)
 };
+
+// one element of the update (utils/fminadam.m:51-59): g = dF_i of this iteration; returns the new x_i
+__device__ __forceinline__ double adam_elem(const AdamState& A, int iter, int r, int i, double g, double* __restrict__ x) {
+  const int T = A.T;
+  const double b1 = 0.9, b2 = 0.999, fudge = 1.4901161193847656e-08;  // sqrt(eps)  (fminadam.m:20-22)
+  double m = b1 * A.m[(size_t)r * T + i] + (1.0 - b1) * g;      // :51
+  double v = b2 * A.v[(size_t)r * T + i] + (1.0 - b2) * g * g;  // :52
+  A.m[(size_t)r * T + i] = m;
+  A.v[(size_t)r * T + i] = v;
+  const double mhat = m / A.c1, vhat = v / A.c2;
+  const double xn = x[(size_t)r * T + i] - A.step * mhat / (sqrt(vhat) + fudge);  // :59 (LB/UB are [] at the call site)
+  x[(size_t)r * T + i] = xn;
+  A.xtab[((size_t)r * A.MaxIter + (iter - 1)) * T + i] = xn;
+  return xn;
+}
 
 __device__ inline void adam_update_chain(const AdamState& A, int iter, double* __restrict__ x /*T x R*/,
                                          const double* __restrict__ out /*R x (5+3T)*/, int r) {
   if (A.done[r]) return;
   const int T = A.T;
   const double* o = out + (size_t)r * (OUT_HDR + 3 * T);
-  const double b1 = 0.9, b2 = 0.999, fudge = 1.4901161193847656e-08;  // sqrt(eps)  (fminadam.m:20-22)
-  const double c1 = 1.0 - pow(b1, (double)iter), c2 = 1.0 - pow(b2, (double)iter);
-  const double step = A.step_min + (A.step_max - A.step_min) * exp(-(double)iter / A.step_decay);  // :56-57
   if (threadIdx.x == 0) A.ftab[(size_t)r * A.MaxIter + (iter - 1)] = o[0];
-  for (int i = threadIdx.x; i < T; i += blockDim.x) {
-    const double g = o[OUT_HDR + i];
-    double m = b1 * A.m[(size_t)r * T + i] + (1.0 - b1) * g;      // :51
-    double v = b2 * A.v[(size_t)r * T + i] + (1.0 - b2) * g * g;  // :52
-    A.m[(size_t)r * T + i] = m;
-    A.v[(size_t)r * T + i] = v;
-    const double mhat = m / c1, vhat = v / c2;
-    const double xn = x[(size_t)r * T + i] - step * mhat / (sqrt(vhat) + fudge);  // :59 (LB/UB are [] at the call site)
-    x[(size_t)r * T + i] = xn;
-    A.xtab[((size_t)r * A.MaxIter + (iter - 1)) * T + i] = xn;
-  }
+  for (int i = threadIdx.x; i < T; i += blockDim.x) adam_elem(A, iter, r, i, o[OUT_HDR + i], x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -71,7 +76,8 @@ __device__ inline void adam_update_chain(const AdamState& A, int iter, double* _
 // the body of k_prep for restart r, by whichever workgroup calls it (k_prep, or k_finalize_ws for the NEXT iteration of the
 // on-device optimiser loop); sh: dynamic LDS of D K + 3 K + D doubles + one per wave
 __device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ theta, const double* __restrict__ vpfix,
-                                 double* __restrict__ vpd, double* __restrict__ entp, int r, double* sh) {
+                                 double* __restrict__ vpd, double* __restrict__ entp, int r, double* sh,
+                                 const double* th_row = nullptr /* restart r's theta where the caller already holds it (LDS) */) {
   // Latency form (round 3): no workgroup barrier and no LDS.  The two sums every element needs -- sum_k exp(eta_k) of the
   // softmax (:45-47) and sum_d log lambda_d of the normalisation constant -- are computed by EVERY wave for itself (K / 64
   // exponentials per lane and one butterfly: less than a barrier costs), in an order that does not depend on the number of
@@ -82,7 +88,7 @@ __device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ 
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
   const int D = dm.D, K = dm.K;
   VpLayout L{D, K};
-  const double* th = theta + (size_t)r * dm.T;
+  const double* th = th_row ? th_row : theta + (size_t)r * dm.T;
   double* v = vpd + (size_t)r * L.stride();
   const double* fmu = vpfix;
   const double* fsig = vpfix + D * K;
@@ -1187,20 +1193,41 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
     F += (scal[2] + scal[3]) + scal[4];
     o[0] = F; o[1] = G; o[2] = H; o[3] = varG; o[4] = varGss;
   }
+  // ---- on-device optimiser loop: this iteration's Adam update and the unpacking of the new theta, by the same workgroup.  Every
+  // thread updates the elements whose gradient it has just assembled (no barrier, no trip through global memory in between); the
+  // new theta reaches the unpacking through LDS (xl: the gradient blocks are dead once every thread has assembled its elements)
+  const bool adam = a.next_iter > 0 && grad;
+  const bool running = adam && a.next_A.done[r] == 0;
+  double xn_keep[4];                                     // T <= 4 * 1024 elements per restart pass through here (else: global)
+  const bool keep = adam && T <= 4 * nt;
+  if (running && tid == 0) a.next_A.ftab[(size_t)r * a.next_A.MaxIter + (a.next_iter - 1)] = o[0];
   if (grad) {
-    for (int i = tid; i < T; i += nt) {
+    auto elem = [&](int i) -> double {
       double g = -dG[i] - dH[i];                        // :117
       if (a.beta != 0.0 && vr) g += 0.5 * a.beta * vr[2 + i] / sqrt(varG);  // :129
-      o[OUT_HDR + i] = g + dP[i];
+      const double gF = g + dP[i];
+      o[OUT_HDR + i] = gF;
       o[OUT_HDR + T + i] = dG[i];
       o[OUT_HDR + 2 * T + i] = dH[i];
+      if (!adam) return 0.0;
+      return running ? adam_elem(a.next_A, a.next_iter, r, i, gF, a.next_theta) : a.next_theta[(size_t)r * T + i];
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * nt;
+      xn_keep[u] = i < T ? elem(i) : 0.0;
     }
+    for (int i = tid + 4 * nt; i < T; i += nt) elem(i);
   }
-  // ---- on-device optimiser loop: this iteration's Adam update and the unpacking of the new theta, by the same workgroup
-  if (a.next_iter > 0) {
-    __syncthreads();                                     // the gradient in `o` was written by other threads of this workgroup
-    adam_update_chain(a.next_A, a.next_iter, a.next_theta, a.out, r);
-    __syncthreads();
-    prep_body(dm, a.next_theta, a.next_vpfix, a.next_vpd, a.next_entp, r, lds);
+  if (adam) {
+    __syncthreads();                                     // every thread is done with dG / dH / dP: their LDS becomes theta's
+    double* xl = lds;
+    if (keep) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tid + u * nt < T) xl[tid + u * nt] = xn_keep[u];
+      __syncthreads();
+    }
+    prep_body(dm, a.next_theta, a.next_vpfix, a.next_vpd, a.next_entp, r, lds, keep ? xl : nullptr);
   }
 }
