@@ -612,7 +612,7 @@ def acq_function(name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot):
 
 
 def acq_is_precompute(gp, Xa):
-    """private/activeimportancesampling_vbmc.m:248-276 (Step 3): cross-kernel of the importance points with the
+    r"""private/activeimportancesampling_vbmc.m:248-276 (Step 3): cross-kernel of the importance points with the
     training inputs and Ctmp = (L\(L'\Kax'))/sn2_eff (Lchol) or L*Kax' per hyper-sample.  Xa: Na x D, or
     Na x D x S for per-hyper-sample inputs.  Returns (Kax_mat Na x N x S, Ctmp_mat N x Na x S)."""
     X = gp["X"]
@@ -638,6 +638,59 @@ def acq_is_precompute(gp, Xa):
 
 
 ACQ_U = 0.6745  # norminv(0.75), acqviqr_vbmc.m:4 / acqimiqr_vbmc.m:4
+
+
+def acq_islogf(name, which, vlnpdf, fmu, fs2):
+    """acqfun('islogf1' | 'islogf2' | 'islogf', vlnpdf, [], [], fmu, fs2): acq/acqviqr_vbmc.m:13-30 (name 'acqviqr') and
+    acq/acqimiqr_vbmc.m:12-27 ('acqimiqr').  fmu, fs2: Na x S."""
+    fs2 = np.asarray(fs2, dtype=np.float64)
+    out = np.zeros_like(fs2)
+    for i in range(fs2.shape[0]):
+        for s in range(fs2.shape[1]):
+            fs = math.sqrt(fs2[i, s])
+            added = ACQ_U * fs + math.log1p(-math.exp(-2 * ACQ_U * fs))
+            if name == "acqviqr":
+                fixed = 0.0 if which == "islogf1" else float(np.asarray(vlnpdf).reshape(-1)[i])      # :19 zeros(size(fs2)); :29 vp + ...
+            else:
+                fixed = float(np.asarray(fmu)[i, s])                                                  # acqimiqr :16, :26
+            out[i, s] = fixed if which == "islogf1" else (added if which == "islogf2" else fixed + added)
+    return out
+
+
+def activesample_proposalpdf(Xa, gp, vp_is, w_vp, rect_delta, name, vp, isamplevp_flag):
+    """[lnw,fs2] = activesample_proposalpdf(Xa,gp,vp_is,w_vp,rect_delta,acqfun,vp,isamplevp_flag)
+    (private/activeimportancesampling_vbmc.m:301-340), point by point.  Returns lnw (Na x S) and fs2 (Na x S)."""
+    X = gp["X"]
+    N, D = X.shape
+    Xa = np.asarray(Xa, dtype=np.float64)
+    Na = Xa.shape[0]
+    pr = gplite_pred(gp, Xa, None, None, True)                                      # :307
+    S = len(gp["post"])
+    fmu = np.asarray(pr[2]).reshape(Na, S)
+    fs2 = np.asarray(pr[3]).reshape(Na, S)
+    templ = np.full((Na, 1 + N), -np.inf)
+    if w_vp > 0:                                                                     # :313-318
+        with np.errstate(divide="ignore"):
+            templ[:, 0] = np.log(vbmc_pdf_transformed(vp_is, Xa)) + math.log(w_vp)
+    if isamplevp_flag:                                                               # :321-326
+        with np.errstate(divide="ignore"):
+            vln = np.maximum(np.log(np.maximum(vbmc_pdf_transformed(vp, Xa), 0.0)), math.log(REALMIN))
+        lny = acq_islogf(name, "islogf1", vln, fmu, fs2)
+    else:
+        lny = acq_islogf(name, "islogf1", None, fmu, fs2)
+    if w_vp < 1:                                                                     # :329-336
+        VV = float(np.prod(2 * rect_delta))
+        for ii in range(N):
+            for a in range(Na):
+                inside = bool(np.all(np.abs(Xa[a] - X[ii]) < rect_delta))
+                templ[a, ii + 1] = math.log(inside / VV / N * (1 - w_vp)) if inside else -np.inf
+        mmax = np.max(templ, axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):      # a point outside every component: exp(-Inf - -Inf) = NaN, as in MATLAB (:338)
+            lpdf = np.log(np.sum(np.exp(templ - mmax[:, None]), axis=1))
+        lnw = lny - (lpdf + mmax)[:, None]
+    else:
+        lnw = lny - templ[:, 0:1]
+    return lnw, fs2
 
 
 def acq_iqr(name, Xs, vp, gp, optimState, fmu, fs2, fbar, vtot):

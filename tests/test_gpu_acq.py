@@ -171,3 +171,70 @@ def test_acquisition_golden_vectors(va, path):
         tol = 1e-8 if name == "acqviqr" else 1e-9
         assert np.max(np.abs(acq - exp[name]) / np.maximum(1e-300, np.abs(exp[name]))) < tol, (name, acq, exp[name])
         assert np.max(np.abs(fbar - exp["fbar"])) < 1e-10 and np.max(np.abs(vtot - exp["vtot"]) / exp["vtot"]) < 1e-9
+
+
+def test_proposal_weights_match_the_oracle(va):
+    """activesample_proposalpdf (private/activeimportancesampling_vbmc.m:301-340): log weights of points drawn from the smoothed
+    variational posterior and from the box-uniforms, GP prediction on the device, against the oracle's point-by-point form --
+    both acquisition functions, with and without the variational density in the base, pure-VP / pure-box / mixed proposals."""
+    from vbmc_amd.acq import _proposal_lnw
+
+    gp, vp, Xs, st, rng = setup(23, 3, 40, 4, 3)
+    D, K, S_ = 3, 4, 3
+    X = gp["X"]
+    rect = 2 * np.std(X, axis=0, ddof=1)
+    sc = (0.05, 0.2, 1.0)
+    vp_is = dict(vp, K=4 * K, w=np.tile(vp["w"], 4) / 4, mu=np.tile(vp["mu"], (1, 4)),
+                 sigma=np.concatenate([vp["sigma"]] + [np.sqrt(vp["sigma"] ** 2 + c * c) for c in sc]))
+    Xa = np.concatenate([X[rng.integers(0, 40, 12)] + (2 * rng.random((12, D)) - 1) * rect, 1.2 * rng.standard_normal((10, D)),
+                         50.0 + rng.standard_normal((2, D))], axis=0)      # the last two: outside every box
+    eng = va.default_engine()
+    for name, oname in (("acqimiqr_vbmc", "acqimiqr"), ("acqviqr_vbmc", "acqviqr")):
+        for w_vp in (0.5, 1.0, 0.0):
+            for isvp in (False, True):
+                lw, f2 = _proposal_lnw(Xa, gp, vp_is, w_vp, rect, name, vp, isvp, eng)
+                lo, f2o = R.activesample_proposalpdf(Xa, gp, vp_is, w_vp, rect, oname, vp, isvp)
+                assert relerr(f2, f2o) < 1e-9
+                fin = np.isfinite(lo)            # (a point outside every box and far from the mixture has density 0: NaN / Inf weights on
+                assert np.array_equal(fin, np.isfinite(lw))      # both sides, which :146 then turns into -Inf)
+                assert fin.sum() >= 22 * S_ and np.max(np.abs(lw[fin] - lo[fin])) < 1e-8 * max(1.0, np.max(np.abs(lo[fin])))
+
+
+def test_imiqr_end_to_end_through_the_mirror(va):
+    """activeimportancesampling_vbmc for acqimiqr_vbmc (round 3: importance sampling-resampling + MCMC per GP hyper-sample with every
+    log-density evaluation a batched device prediction) -> acqwrapper_vbmc(acqimiqr).  The sampler is a stand-in for
+    utils/eissample_lite.m, so what is checked is what the reference's OUTPUT must satisfy: shapes (Xa Na x D x S, lnw S x Na),
+    every point inside the sampler's box, lnw = islogf1 - log p of the chain's own target (recomputed with the ORACLE's prediction),
+    chains that sit where their target has mass (mean log density of the samples far above that of the box's uniform points), and the
+    acquisition sweep on that state equal to the oracle's on the same state."""
+    D, N, K, S = 3, 60, 4, 3
+    gp, vp, Xs, st, rng = setup(29, D, N, K, S)
+    gl = np.exp(np.mean(np.stack([q["hyp"][:D] for q in gp["post"]], axis=1), axis=1))
+    gp = dict(gp, X_rescaled=gp["X"] / gl[None, :], sn2new=np.full(N, 0.05))
+    opts = {"ActiveImportanceSamplingMCMCSamples": 48, "ActiveImportanceSamplingVPSamples": 40, "ActiveImportanceSamplingBoxSamples": 40}
+    ais = va.activeimportancesampling_vbmc(vp, gp, "acqimiqr_vbmc", None, opts, rng=np.random.default_rng(4))
+    Xa, lnw = ais["Xa"], ais["lnw"]
+    assert Xa.shape == (48, D, S) and lnw.shape == (S, 48) and ais["fs2a"].shape == (48, S)
+    X = gp["X"]
+    diam = X.max(axis=0) - X.min(axis=0)
+    assert np.all(Xa >= (X.min(axis=0) - 0.5 * diam)[None, :, None]) and np.all(Xa <= (X.max(axis=0) + 0.5 * diam)[None, :, None])
+    u = 0.6745
+    uni = (X.min(axis=0) - 0.5 * diam) + rng.random((400, D)) * 2 * diam
+    for s in range(S):
+        pr = R.gplite_pred(gp, Xa[:, :, s], None, None, True)
+        fmu = np.asarray(pr[2]).reshape(48, S)[:, s]
+        fs = np.sqrt(np.asarray(pr[3]).reshape(48, S)[:, s])
+        logp = fmu + u * fs + np.log1p(-np.exp(-2 * u * fs))            # acq/acqimiqr_vbmc.m:24-27
+        assert np.max(np.abs(lnw[s] - (fmu - logp))) < 1e-7 * max(1.0, np.max(np.abs(logp)))
+        pu = R.gplite_pred(gp, uni, None, None, True)
+        fu = np.asarray(pu[2]).reshape(400, S)[:, s]
+        su = np.sqrt(np.asarray(pu[3]).reshape(400, S)[:, s])
+        assert np.mean(logp) > np.mean(fu + u * su + np.log1p(-np.exp(-2 * u * su))) + 1.0
+    st = dict(st, gplengthscale=gl, VarianceRegularizedAcqFcn=False, ActiveImportanceSampling=ais)
+    acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqimiqr_vbmc", None)
+    Kax, Ct = R.acq_is_precompute(gp, Xa)
+    st_o = dict(st, ActiveImportanceSampling={"Xa": Xa, "Kax_mat": Kax, "Ctmp_mat": Ct, "fs2a": ais["fs2a"], "lnw": lnw})
+    ref, _, _ = R.acqwrapper_vbmc(Xs, vp, gp, st_o, "acqimiqr")
+    assert np.max(np.abs(acq - ref)) < 1e-8 * max(1.0, np.max(np.abs(ref)))
+    assert int(np.argmin(acq)) == int(np.argmin(ref))
+    assert ais["funccount"] > 0

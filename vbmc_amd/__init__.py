@@ -12,6 +12,6 @@ from .vp import get_vptheta, make_vp, rescale_params, vpbounds  # noqa: F401
 from .elbo import (Engine, PreparedObjective, default_engine, entlb_vbmc, entmc_vbmc, fminadam_device, gplogjoint,  # noqa: F401
                    negelcbo_batch, negelcbo_shard, negelcbo_vbmc)
 from .gplite import gplite_hypprior, gplite_nlZ, gplite_post, gplite_post_rank1, gplite_pred, sq_dist  # noqa: F401,E402
-from .acq import acq_info, acqwrapper_vbmc, activeimportancesampling_vbmc, vbmc_rnd  # noqa: F401,E402
+from .acq import acq_info, acqwrapper_vbmc, activeimportancesampling_vbmc, ensemble_slice_sample, vbmc_rnd  # noqa: F401,E402
 from .optimize import (eval_fullelcbo, fminadam, gethpd_vbmc, sieve_evaluate, vbinit_vbmc, vpoptimize_vbmc,  # noqa: F401,E402
                        vpsieve_vbmc)

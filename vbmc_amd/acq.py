@@ -189,20 +189,283 @@ def vbmc_rnd(vp, N, origflag=False, balanceflag=False, *, rng=None):
     return X, I
 
 
-def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *, rng=None, engine=None):
-    """ActiveImportanceSampling = activeimportancesampling_vbmc(vp,gp,acqfun,acqinfo,options) for the branch VBMC takes
-    with acqviqr_vbmc (variational_importance_sampling: private/activeimportancesampling_vbmc.m:36-52,92-100 and the
-    Step-3 precomputation :248-276): Na draws from the variational posterior, lnw = 0, and -- on the device, inside
-    vbmc_acq_is_create at the first acquisition call -- fs2a = gplite_pred at the draws and Ctmp = (L\\(L'\\Kax'))/sn2_eff.
-    The MCMC refinement (:54-90, only for acqimiqr-style functions or a tiny effective sample size) is not mirrored."""
-    info = acqInfo or acq_info(acqFun)
-    if not info.get("variational_importance_sampling", False):
-        raise VbmcUnsupported(-1, "activeimportancesampling_vbmc: only the variational (VIQR) branch is mirrored")
-    opts = dict(options or {})
-    na = opts.get("ActiveImportanceSamplingMCMCSamples", 100)          # vbmc.m:337 default '100'
-    Na = int(np.ceil(na(int(vp["K"]), int(vp["D"])) if callable(na) else na))
-    if Na <= 0:
-        raise ValueError("OPTIONS.ActiveImportanceSamplingMCMCSamples should be (or evaluate to) a positive integer.")
-    Xa, _ = vbmc_rnd(vp, Na, False, rng=rng)
+_U_IQR = 0.6745   # norminv(0.75), acq/acqviqr_vbmc.m:4, acq/acqimiqr_vbmc.m:4
+
+
+def _islogf(name, which, vlnpdf, fmu, fs2):
+    """acqfun('islogf1' | 'islogf2' | 'islogf', vlnpdf, [], [], fmu, fs2) of the two importance-sampled acquisition functions
+    (acq/acqviqr_vbmc.m:13-30, acq/acqimiqr_vbmc.m:12-27): the log base density of the importance sampler, split into the part
+    that is fixed per point (1) and the part added per GP hyper-sample (2)."""
+    fs = np.sqrt(fs2)
+    added = _U_IQR * fs + np.log1p(-np.exp(-2 * _U_IQR * fs))
+    if which == "islogf2":
+        return added
+    fixed = fmu if name == "acqimiqr_vbmc" else (np.zeros_like(fs2) if which == "islogf1" else np.asarray(vlnpdf).reshape(-1, 1))
+    return fixed if which == "islogf1" else fixed + added
+
+
+def _vbmc_lnpdf(vp, X):
+    """log vbmc_pdf(vp,X,0,1) in the transformed space (vbmc_pdf.m:38-71 with logflag): Gaussian mixture, host side (Na x K)."""
+    X = np.asarray(X, dtype=np.float64)
+    D, K = int(vp["D"]), int(vp["K"])
+    mu = np.asarray(vp["mu"], dtype=np.float64).reshape(D, K)
+    sigma = np.asarray(vp["sigma"], dtype=np.float64).reshape(K)
+    lam = np.asarray(vp["lambda"], dtype=np.float64).reshape(D)
+    w = np.asarray(vp["w"], dtype=np.float64).reshape(K)
+    z = (X[:, None, :] - mu.T[None, :, :]) / (lam[None, None, :] * sigma[None, :, None])
+    lp = np.log(w)[None, :] - 0.5 * np.sum(z * z, axis=2) - D * np.log(sigma)[None, :] - np.sum(np.log(lam)) - 0.5 * D * np.log(2 * np.pi)
+    m = np.max(lp, axis=1, keepdims=True)
+    out = (m + np.log(np.sum(np.exp(lp - m), axis=1, keepdims=True))).reshape(-1)
+    # the reference forms the density and then takes its log (vbmc_pdf.m:71,117): below the smallest double it is log(0) = -Inf
+    return np.where(out < np.log(5e-324), -np.inf, out)
+
+
+def _proposal_lnw(Xa, gp, vp_is, w_vp, rect_delta, name, vp, isamplevp, engine):
+    """[lnw, fs2] = activesample_proposalpdf(...) (private/activeimportancesampling_vbmc.m:301-340): log importance weights of
+    points drawn from the mixture of the smoothed variational posterior and of box-uniforms centred on the training inputs.
+    The GP prediction at the points runs on the device; the two proposal densities are O(Na (K + N) D) on the host."""
+    X = np.asarray(gp["X"], dtype=np.float64)
+    N, D = X.shape
+    _, _, fmu, fs2 = gplite_pred_device(gp, Xa, engine)
+    logs = []
+    if w_vp > 0:
+        logs.append(_vbmc_lnpdf(vp_is, Xa) + np.log(w_vp))                                            # :313-315
+    vln = np.maximum(_vbmc_lnpdf(vp, Xa), np.log(np.finfo(np.float64).tiny)) if isamplevp else None  # :321-323
+    lny = _islogf(name, "islogf1", vln, fmu, fs2)
+    if w_vp < 1:                                                                                     # :328-336
+        VV = np.prod(2 * rect_delta)
+        inside = np.all(np.abs(Xa[:, None, :] - X[None, :, :]) < rect_delta[None, None, :], axis=2)   # Na x N
+        with np.errstate(divide="ignore"):
+            logs.append(np.log(np.sum(inside, axis=1) / VV / N * (1 - w_vp)))
+    T = np.stack(logs, axis=1)
+    m = np.max(T, axis=1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lpdf = (m + np.log(np.sum(np.exp(T - m), axis=1, keepdims=True)))
+    return lny - lpdf, fs2                                                                           # Na x S each
+
+
+def gplite_pred_device(gp, Xs, engine):
+    """[~,~,fmu,fs2] = gplite_pred(gp,Xs,[],[],1,0) per hyper-sample (Nstar x S) on the device."""
+    from .gplite import gplite_pred
+
+    out = gplite_pred(gp, Xs, None, None, True, False, 4, engine=engine)
     S = len(gp["post"])
-    return {"Xa": Xa, "lnw": np.zeros((S, Na))}        # fs2a / Ctmp_mat are produced on the device from Xa
+    return tuple(np.asarray(o).reshape(np.asarray(Xs).shape[0], S) for o in out)
+
+
+def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_factor=1.0, rng=None, max_steps=20, max_shrink=60):
+    """Ensemble slice sampling for E independent targets at once, every log-density evaluation ONE batched call.
+
+    Stands where the reference calls utils/eissample_lite.m (third-party, 1329 lines, not restated) with its default
+    transition operator (transSliceSampleRD with an ensemble, eissample_lite.m:212,956-962): a walker moves by one-dimensional
+    slice sampling (stepping out, shrinkage) along the difference of two other walkers of its ensemble.  The reference moves one
+    walker per iteration; here the two halves of every ensemble take turns and all walkers of a half -- of ALL E ensembles -- move
+    together, each along the difference of two walkers of the complementary half, so that a move costs a handful of batched
+    evaluations of E W / 2 points instead of that many sequential ones.
+
+    logp(X, e): X (M x D) points, e (M,) the ensemble each belongs to -> (M,) log densities (-inf outside the support).
+    x0: E x W x D starting walkers.  Returns (samples E x N x D, logp E x N): after ``burnin`` recorded moves per ensemble have
+    been discarded every thin-th moved walker is recorded, as eissample_lite counts them (:386, one sample per walker move)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    x = np.array(x0, dtype=np.float64, copy=True)
+    E, W, D = x.shape
+    assert W >= 4 and W % 2 == 0, "two halves of at least two walkers"
+    LB = np.broadcast_to(np.asarray(LB, dtype=np.float64), (D,))
+    UB = np.broadcast_to(np.asarray(UB, dtype=np.float64), (D,))
+    burnin = int(np.ceil(thin * N / 2)) if burnin is None else int(burnin)     # get_mcmcopts, activeimportancesampling_vbmc.m:372-376
+    ens = np.repeat(np.arange(E), W)
+    count = [0]          # evaluations of the target (proposals outside the bounds cost none)
+
+    def lp_of(P, e):
+        ok = np.all((P >= LB) & (P <= UB), axis=1)
+        out = np.full(P.shape[0], -np.inf)
+        if np.any(ok):
+            out[ok] = logp(P[ok], e[ok])
+            count[0] += int(np.sum(ok))
+        return out
+
+    lp = lp_of(x.reshape(E * W, D), ens).reshape(E, W)
+    if not np.all(np.isfinite(lp)):
+        raise ValueError("ensemble_slice_sample: a starting point has zero density")
+    H = W // 2
+    halves = (np.arange(0, H), np.arange(H, W))
+    total = burnin + N * thin
+    out_x = np.empty((E, N, D))
+    out_lp = np.empty((E, N))
+    moved = 0            # walker moves per ensemble so far
+    nrec = 0
+    while nrec < N:
+        for h in (0, 1):
+            mine, other = halves[h], halves[1 - h]
+            M = E * H
+            xc = x[:, mine, :].reshape(M, D)
+            lc = lp[:, mine].reshape(M)
+            ee = np.repeat(np.arange(E), H)
+            # direction: difference of two distinct walkers of the complementary half (eissample_lite.m:956-960)
+            a = rng.integers(0, H, size=M)
+            b = (a + 1 + rng.integers(0, H - 1, size=M)) % H
+            xo = x[:, other, :]
+            V = (xo[ee, b] - xo[ee, a]) * sigma_factor
+            y = lc + np.log(rng.random(M))                       # slice level
+            L = -rng.random(M)
+            Rr = L + 1.0
+            # stepping out, both ends in lock-step; a finished end stops costing evaluations
+            growL = np.ones(M, dtype=bool)
+            growR = np.ones(M, dtype=bool)
+            for _ in range(max_steps):
+                if not (np.any(growL) or np.any(growR)):
+                    break
+                idx = np.concatenate([np.nonzero(growL)[0], np.nonzero(growR)[0]])
+                t = np.concatenate([L[growL], Rr[growR]])
+                val = lp_of(xc[idx] + t[:, None] * V[idx], ee[idx])
+                nl = int(np.sum(growL))
+                il, ir = idx[:nl], idx[nl:]
+                keepL = val[:nl] > y[il]
+                keepR = val[nl:] > y[ir]
+                L[il[keepL]] -= 1.0
+                Rr[ir[keepR]] += 1.0
+                growL[il[~keepL]] = False
+                growR[ir[~keepR]] = False
+            # shrinkage
+            todo = np.ones(M, dtype=bool)
+            xn = xc.copy()
+            ln = lc.copy()
+            for _ in range(max_shrink):
+                if not np.any(todo):
+                    break
+                idx = np.nonzero(todo)[0]
+                t = L[idx] + rng.random(idx.size) * (Rr[idx] - L[idx])
+                P = xc[idx] + t[:, None] * V[idx]
+                val = lp_of(P, ee[idx])
+                acc = val > y[idx]
+                xn[idx[acc]] = P[acc]
+                ln[idx[acc]] = val[acc]
+                todo[idx[acc]] = False
+                rej = idx[~acc]
+                tr = t[~acc]
+                neg = tr < 0
+                L[rej[neg]] = tr[neg]
+                Rr[rej[~neg]] = tr[~neg]
+            # (a walker whose slice collapsed stays where it is: eissample_lite's exitflag -5 case)
+            x[:, mine, :] = xn.reshape(E, H, D)
+            lp[:, mine] = ln.reshape(E, H)
+            for j in range(H):
+                moved += 1
+                if moved > burnin and (moved - burnin) % thin == 0 and nrec < N:
+                    out_x[:, nrec, :] = x[:, mine[j], :]
+                    out_lp[:, nrec] = lp[:, mine[j]]
+                    nrec += 1
+            if moved >= total and nrec >= N:
+                break
+    ensemble_slice_sample.last_funccount = count[0]
+    return out_x, out_lp
+
+
+def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *, rng=None, engine=None):
+    """ActiveImportanceSampling = activeimportancesampling_vbmc(vp,gp,acqfun,acqinfo,options)
+    (private/activeimportancesampling_vbmc.m).
+
+    acqviqr_vbmc (variational_importance_sampling, :36-52,92-100): Na draws from the variational posterior, lnw = 0.
+    acqimiqr_vbmc (round 3; :103-246): importance sampling-resampling from the smoothed variational posterior and box-uniforms
+    around the training inputs (Step 1), then, per GP hyper-sample, MCMC on the log base density fmu + u fs + log1p(-exp(-2 u fs))
+    started from a weighted resample of those points (Step 2) -- all hyper-samples' ensembles advance together, every
+    log-density evaluation is one batched GP prediction on the device (the reference predicts one point at a time,
+    log_isbasefun :343-353), the transition operator is ensemble_slice_sample above.  Xa is then Na x D x S and lnw S x Na.
+    Step 3 (fs2a, Kax, Ctmp) happens on the device inside vbmc_acq_is_create at the first acquisition call."""
+    info = acqInfo or acq_info(acqFun)
+    name = info.get("name") or (acqFun if isinstance(acqFun, str) else acqFun.__name__).lstrip("@")
+    engine = engine or default_engine()
+    rng = np.random.default_rng(0) if rng is None else rng
+    opts = dict(options or {})
+    K, D = int(vp["K"]), int(vp["D"])
+
+    def evalopt(v, default):
+        v = opts.get(v, default)
+        return int(np.ceil(v(K, D) if callable(v) else v))
+
+    S = len(gp["post"])
+    if info.get("variational_importance_sampling", False):
+        Na = evalopt("ActiveImportanceSamplingMCMCSamples", 100)          # vbmc.m:337 default '100'
+        if Na <= 0:
+            raise ValueError("OPTIONS.ActiveImportanceSamplingMCMCSamples should be (or evaluate to) a positive integer.")
+        Xa, _ = vbmc_rnd(vp, Na, False, rng=rng)
+        return {"Xa": Xa, "lnw": np.zeros((S, Na))}        # fs2a / Ctmp_mat are produced on the device from Xa
+    if delta_positive(vp):
+        raise VbmcUnsupported(-1, "vp.delta > 0 is not accelerated")
+    isamplevp = bool(info.get("importance_sampling_vp", False))
+    X = np.asarray(gp["X"], dtype=np.float64)
+    # ---- Step 1: importance sampling-resampling (:103-151)
+    Nvp = evalopt("ActiveImportanceSamplingVPSamples", 100)
+    Nbox = evalopt("ActiveImportanceSamplingBoxSamples", 100)
+    if Nvp + Nbox <= 0:
+        raise ValueError("activeimportancesampling_vbmc: no importance samples requested")
+    w_vp = Nvp / (Nvp + Nbox)
+    rect_delta = 2 * np.std(X, axis=0, ddof=1)
+    lnw_l, Xa_l, fs2_l = [], [], []
+    vp_is = None
+    if Nvp > 0:
+        mu = np.asarray(vp["mu"], dtype=np.float64).reshape(D, K)
+        sig = np.asarray(vp["sigma"], dtype=np.float64).reshape(K)
+        w = np.asarray(vp["w"], dtype=np.float64).reshape(K)
+        sc = (0.05, 0.2, 1.0)                                                                        # :114
+        vp_is = dict(vp, K=K * (1 + len(sc)), w=np.tile(w, 1 + len(sc)) / (1 + len(sc)), mu=np.tile(mu, (1, 1 + len(sc))),
+                     sigma=np.concatenate([sig] + [np.sqrt(sig ** 2 + c * c) for c in sc]))
+        Xv, _ = vbmc_rnd(vp_is, Nvp, False, rng=rng)
+        lw, f2 = _proposal_lnw(Xv, gp, vp_is, w_vp, rect_delta, name, vp, isamplevp, engine)
+        lnw_l.append(lw); Xa_l.append(Xv); fs2_l.append(f2)
+    if Nbox > 0:
+        jj = rng.integers(0, X.shape[0], size=Nbox)
+        Xb = X[jj] + (2 * rng.random((Nbox, D)) - 1) * rect_delta[None, :]                            # :138-139
+        lw, f2 = _proposal_lnw(Xb, gp, vp_is, w_vp, rect_delta, name, vp, isamplevp, engine)
+        lnw_l.append(lw); Xa_l.append(Xb); fs2_l.append(f2)
+    Xa1 = np.concatenate(Xa_l, axis=0)
+    lnw1 = np.concatenate(lnw_l, axis=0).T                    # S x Na
+    lnw1 = np.where(np.isfinite(lnw1), lnw1, -np.inf)          # :146
+    fs2a1 = np.concatenate(fs2_l, axis=0)
+    Nm = evalopt("ActiveImportanceSamplingMCMCSamples", 100)
+    if Nm <= 0:
+        return {"Xa": Xa1, "lnw": lnw1, "fs2a": fs2a1}
+    # ---- Step 2: MCMC per GP hyper-sample (:155-246), all S ensembles in lock-step
+    thin = max(1, evalopt("ActiveImportanceSamplingMCMCThin", 1))
+    burnin = int(np.ceil(thin * Nm / 2))
+    W = 2 * (D + 1)
+    diam = np.max(X, axis=0) - np.min(X, axis=0)
+    LB = np.min(X, axis=0) - 0.5 * diam                                                              # :25-28
+    UB = np.max(X, axis=0) + 0.5 * diam
+    _, _, fmu1, fs21 = gplite_pred_device(gp, Xa1, engine)
+    x0 = np.empty((S, W, D))
+    for s in range(S):                                                                                # :196-205 resampling without replacement
+        lw = lnw1[s] + _islogf(name, "islogf2", None, fmu1[:, s:s + 1], fs21[:, s:s + 1]).reshape(-1)
+        ww = np.exp(lw - np.max(lw))
+        for i in range(W):
+            if not np.sum(ww) > 0:
+                ww = np.ones_like(ww)
+            idx = int(np.searchsorted(np.cumsum(ww), rng.random() * np.sum(ww), side="right"))         # catrnd (:385-410)
+            idx = min(idx, ww.size - 1)
+            ww[idx] = 0.0
+            x0[s, i] = np.clip(Xa1[idx], LB, UB)
+
+    def logp(P, e):                                                                                   # log_isbasefun :343-353
+        _, _, fm, f2 = gplite_pred_device(gp, P, engine)
+        r = np.arange(P.shape[0])
+        vln = np.maximum(_vbmc_lnpdf(vp, P), np.log(np.finfo(np.float64).tiny)) if isamplevp else None
+        v = _islogf(name, "islogf", vln, fm[r, e].reshape(-1, 1), f2[r, e].reshape(-1, 1)).reshape(-1)
+        return np.where(np.isfinite(v), v, -np.inf)
+
+    Xs, lps = ensemble_slice_sample(logp, x0, Nm, LB, UB, thin=thin, burnin=burnin, rng=rng)
+    Xa = np.transpose(Xs, (1, 2, 0)).copy()                       # Na x D x S
+    lnw = np.empty((S, Nm))
+    fs2a = np.empty((Nm, S))
+    _, _, fm_all, f2_all = gplite_pred_device(gp, Xs.reshape(S * Nm, D), engine)
+    for s in range(S):                                            # :209-221: lnw = islogf1 - log p of the chain's target
+        fm = fm_all[s * Nm:(s + 1) * Nm, s:s + 1]
+        f2 = f2_all[s * Nm:(s + 1) * Nm, s:s + 1]
+        vln = np.maximum(_vbmc_lnpdf(vp, Xs[s]), np.log(np.finfo(np.float64).tiny)) if isamplevp else None
+        lnw[s] = _islogf(name, "islogf1", vln, fm, f2).reshape(-1) - lps[s]
+        fs2a[:, s] = f2.reshape(-1)
+    return {"Xa": Xa, "lnw": lnw, "fs2a": fs2a, "funccount": getattr(ensemble_slice_sample, "last_funccount", None)}
+
+
+def delta_positive(vp):
+    d = vp.get("delta")
+    return d is not None and bool(np.any(np.asarray(d) > 0))
