@@ -323,6 +323,10 @@ int vbmc_launch_ent_mfma_qs9(int, int, int, unsigned, unsigned, unsigned, void*,
 // coupling) -- EXCEPT where the two-wave kernel with four k-tiles per wave and a wide operand (D >= 15) spills its way down:
 // there four waves with two k-tiles each fit their registers (D = 24, K = 128: 3.4 vs 5.7 ms; D = 20, K = 128: 3.9 vs 5.0;
 // D = 20, K = 100 the other way: 50 vs 57 ms at configs[4]).
+// K <= 64: one wave per workgroup, except (round 3, tools/hv_small_sweep.py -> profiles/r03_hv_small.md) where the one-wave kernel with
+// four k-tiles and a wide operand spills its way down: K = 57..64 from D = 15 on (two waves with two k-tiles each: 9-13 % faster, 36 %
+// at D = 32) and K = 53..56 at D >= 31.  Everywhere else the split costs 25-85 % (PV exchange + a barrier per sign).
+static int ent_hv_small(int qs, int K) { return ((qs >= 5 && K > 56) || (qs >= 9 && K > 52)) ? 2 : 1; }
 static int ent_hv_mid(int qs, int K) { return (K > 96 && (qs >= 7 || (qs >= 5 && K > 112))) ? 4 : 2; }
 static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
@@ -342,9 +346,11 @@ static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipSt
 // the block-sparse mode (cutoff > 0) always does.
 static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_out, int* hv_out) {
   const int qs = (D + 2 + 3) / 4;
-  int hv = K <= 64 ? 1 : (K <= 128 ? ent_hv_mid(qs, K) : 4);
+  int hv = K <= 64 ? ent_hv_small(qs, K) : (K <= 128 ? ent_hv_mid(qs, K) : 4);
   if (K > 64 && K <= 128)
     if (const char* f = getenv("VBMC_ENT_HV")) { const int v = atoi(f); if (v == 2 || v == 4) hv = v; }
+  if (K > 32 && K <= 64)
+    if (const char* f = getenv("VBMC_ENT_HV")) { const int v = atoi(f); if (v == 1 || v == 2) hv = v; }
   int kt = (((K + hv - 1) / hv) + 15) / 16;
   static const bool tail_on = [] { const char* e = getenv("VBMC_ENT_TAIL"); return !(e && !strcmp(e, "0")); }();
   {
@@ -361,7 +367,7 @@ static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_
     }
   }
   *qs_out = qs; *kt_out = kt; *hv_out = hv;
-  return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 3) && !(hv == 4 && kt < 2) && !(hv > 16 && kt > 3);
+  return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 2) && !(hv == 4 && kt < 2) && !(hv > 16 && kt > 3);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, 
     case 544 + 3: launch_kt<3, 2, 2>(grad, grid, st, *ea); return 0;   //            106..112
     case 576 + 2: launch_kt<2, 4, 2>(grad, grid, st, *ea); return 0;   // four waves: K = 146..160
     case 576 + 3: launch_kt<3, 4, 2>(grad, grid, st, *ea); return 0;   //             210..224
+    case 32 + 2: launch_kt<2, 2>(grad, grid, st, *ea); return 0;   // 32 < K <= 64 at D >= 17, two waves (round 3: the one-wave kernels spill there)
     case 32 + 3: launch_kt<3, 2>(grad, grid, st, *ea); return 0;   // 64 < K <= 96, two waves
     case 32 + 4: launch_kt<4, 2>(grad, grid, st, *ea); return 0;   // 96 < K <= 128
     case 64 + 2: launch_kt<2, 4>(grad, grid, st, *ea); return 0;   // 64 < K <= 128, four waves
