@@ -318,15 +318,25 @@ int vbmc_launch_ent_mfma_qs6(int, int, int, unsigned, unsigned, unsigned, void*,
 int vbmc_launch_ent_mfma_qs7(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 int vbmc_launch_ent_mfma_qs8(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
 int vbmc_launch_ent_mfma_qs9(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs1(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs2(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs3(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs4(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs5(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs6(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs7(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs8(int, int, int, const EntArgs*);
+int vbmc_occupancy_ent_mfma_qs9(int, int, int, const EntArgs*);
 }
 // Waves per workgroup for 64 < K <= 128 (tools/tune_sweep.py, round 2): two -- four are 10-30 % slower (more exchange and barrier
 // coupling) -- EXCEPT where the two-wave kernel with four k-tiles per wave and a wide operand (D >= 15) spills its way down:
 // there four waves with two k-tiles each fit their registers (D = 24, K = 128: 3.4 vs 5.7 ms; D = 20, K = 128: 3.9 vs 5.0;
 // D = 20, K = 100 the other way: 50 vs 57 ms at configs[4]).
 // K <= 64: one wave per workgroup, except (round 3, tools/hv_small_sweep.py -> profiles/r03_hv_small.md) where the one-wave kernel with
-// four k-tiles and a wide operand spills its way down: K = 57..64 from D = 15 on (two waves with two k-tiles each: 9-13 % faster, 36 %
-// at D = 32) and K = 53..56 at D >= 31.  Everywhere else the split costs 25-85 % (PV exchange + a barrier per sign).
-static int ent_hv_small(int qs, int K) { return ((qs >= 5 && K > 56) || (qs >= 9 && K > 52)) ? 2 : 1; }
+// four k-tiles and the widest operands spills its way down: K = 53..64 at D >= 31 (two waves with two k-tiles each: 26-33 % faster) and
+// K = 53..56 at D = 23..26 (15 %).  Everywhere else the split is neutral (K = 64 at D = 16..20: 2-5 %) or costs 25-85 % (PV exchange + a
+// barrier per sign), so one wave stays.
+static int ent_hv_small(int qs, int K) { return ((qs >= 9 && K > 52) || (qs == 7 && K > 52 && K <= 56)) ? 2 : 1; }
 static int ent_hv_mid(int qs, int K) { return (K > 96 && (qs >= 7 || (qs >= 5 && K > 112))) ? 4 : 2; }
 static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
@@ -335,6 +345,23 @@ static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipSt
                               vbmc_launch_ent_mfma_qs7, vbmc_launch_ent_mfma_qs8, vbmc_launch_ent_mfma_qs9};
   if (qs < 1 || qs > 9) return false;
   return fns[qs - 1](kt, grad ? 1 : 0, hv, g.x, g.y, g.z, (void*)st, &ea) == 0;
+}
+// workgroups of the chosen instantiation per compute unit (registers and LDS: hipOccupancyMaxActiveBlocksPerMultiprocessor), cached
+static int entropy_mfma_occupancy(int qs, int kt, int hv, bool grad, const EntArgs& ea) {
+  typedef int (*fn_t)(int, int, int, const EntArgs*);
+  static const fn_t fns[9] = {vbmc_occupancy_ent_mfma_qs1, vbmc_occupancy_ent_mfma_qs2, vbmc_occupancy_ent_mfma_qs3,
+                              vbmc_occupancy_ent_mfma_qs4, vbmc_occupancy_ent_mfma_qs5, vbmc_occupancy_ent_mfma_qs6,
+                              vbmc_occupancy_ent_mfma_qs7, vbmc_occupancy_ent_mfma_qs8, vbmc_occupancy_ent_mfma_qs9};
+  if (qs < 1 || qs > 9) return -1;
+  struct Key { int qs, kt, hv, grad, co, sparse, ldsk; };
+  static std::vector<std::pair<Key, int>> cache;
+  const Key k{qs, kt, hv, grad ? 1 : 0, ea.lj.rows > 0 ? 1 : 0, ea.cutoff > 0.0 ? 1 : 0, ea.K * (ea.D + ENTP_EXTRA)};
+  for (const auto& c : cache)
+    if (c.first.qs == k.qs && c.first.kt == k.kt && c.first.hv == k.hv && c.first.grad == k.grad && c.first.co == k.co &&
+        c.first.sparse == k.sparse && c.first.ldsk == k.ldsk) return c.second;
+  const int nb = fns[qs - 1](kt, grad ? 1 : 0, hv, &ea);
+  cache.push_back({k, nb});
+  return nb;
 }
 // K <= 64: one wave per (chunk, component, restart) with kt = ceil(K/16) k-tiles; larger mixtures split their components
 // over the hv = 2 or 4 waves of a workgroup, kt = ceil(ceil(K/hv)/16) <= 4: two waves up to K = 128, four up to K = 256.
@@ -452,6 +479,17 @@ struct ElboPlan {
   long long eps_stride_r = 0;
   double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0, cutoff = 0.0;
 };
+
+// Does the expected log joint run as a role of the MFMA entropy launch (entropy_mfma.h CO = true; see elbo_enqueue)?  The part of the
+// answer that elbo_plan needs too (the chunk model asks for the occupancy of the kernel that will run).
+static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
+  static const bool co_off = [] { const char* e = getenv("VBMC_LJ_CO"); return e && !strcmp(e, "0"); }();
+  const char* ljf = getenv("VBMC_LJ_KERNEL");
+  const long long SR = (long long)P.dm.S * P.dm.R;
+  const bool lj_force_mfma = ljf && !strcmp(ljf, "mfma");
+  return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && !(P.cutoff > 0.0) && P.compute_grad &&
+         !P.lj_records && SR < ctx->num_cu / 2 && SR * P.rstride < ctx->num_cu / 2;   // (the undivided batch's choice when the restarts are dealt over devices)
+}
 
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
 #define VAR_FINAL_LDS(S_, K_, Tg_) ((VARFIN_THREADS + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
@@ -603,7 +641,18 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     // i.e. whole rounds of resident waves, with the per-wave setup worth ~1.5 tiles
     {
       const int cw = chunk_world > 0 ? chunk_world : (a->chunk_world > 1 ? a->chunk_world : 1);   // sharded over cw devices
-      const long long slots = (long long)ctx->num_cu * (P.use_mfma ? 8 : 5) * cw;
+      // resident waves: what the chosen instantiation really holds per compute unit (registers AND LDS; round 3 -- rounds 1-2 assumed two
+      // waves per SIMD for every MFMA kernel, which under-filled the chip for the small kernels that hold three or four)
+      int waves_per_cu = P.use_mfma ? 8 : 5;
+      if (P.use_mfma) {
+        EntArgs q{};
+        q.D = D; q.K = K; q.cutoff = P.cutoff; q.lj.rows = lj_co_shape(ctx, P) ? 1 : 0;
+        const int nb = entropy_mfma_occupancy(P.qs, P.kt, P.hv, compute_grad != 0, q);
+        if (nb > 0) waves_per_cu = nb * (P.hv & 15);
+      }
+      static const bool occ_off = [] { const char* e = getenv("VBMC_ENT_OCC"); return e && !strcmp(e, "0"); }();   // A/B: the old constant
+      if (occ_off) waves_per_cu = P.use_mfma ? 8 : 5;
+      const long long slots = (long long)ctx->num_cu * waves_per_cu * cw;
       const long long kr = (long long)K * R * (P.use_mfma ? (P.hv & 15) : 1);   // waves per chunk index (hv + 16 TL: with a component tail)
       const double setup = 1.5;   // measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
       double best = 1e300;
@@ -770,9 +819,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // workgroups ahead of the entropy ones, entropy_mfma.h CO = true) -- two dependent-chain-bound kernels side by side instead of
   // one after the other, one launch less.  Its records are per (hyper-sample, split of the training set); the reduction over
   // hyper-samples adds the splits.  VBMC_LJ_CO=0 keeps the separate launch (A/B runs, tests).
-  static const bool co_off = [] { const char* e = getenv("VBMC_LJ_CO"); return e && !strcmp(e, "0"); }();
-  const bool co = !co_off && sh.mode == 0 && !fork && !lj_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && !(P.cutoff > 0.0) &&
-                  P.compute_grad && !P.lj_records && (long long)S * R < ctx->num_cu / 2 && (long long)S * R * P.rstride < ctx->num_cu / 2;   // (the undivided batch's choice when the restarts are dealt over devices)
+  const bool co = sh.mode == 0 && !fork && !lj_mfma && lj_co_shape(ctx, P);
   auto enqueue_logjoint = [&](hipStream_t ls) -> vbmc_status {
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ls));
     if (!co) {
