@@ -50,13 +50,13 @@ def main():
     libs = sorted(f for f in os.listdir(tune) if f.endswith(".so"))
     res = {}
     for lib in libs:
-        for hv in (("",) if SMALL else ("", "4")):
+        for hv in (("",) if SMALL else ("", "2", "4")):
             env = dict(os.environ, VBMC_HIP_LIB=os.path.join(tune, lib), TUNE_SMALL="1" if SMALL else "0")
             if hv:
                 env["VBMC_ENT_HV"] = hv
             o = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
             line = [ln for ln in o.stdout.splitlines() if ln.startswith("{")]
-            res[lib[4:-3] + ("/hv4" if hv else "")] = json.loads(line[-1]) if line else {"error": o.stderr[-300:]}
+            res[lib[4:-3] + ("/hv" + hv if hv else "")] = json.loads(line[-1]) if line else {"error": o.stderr[-300:]}
     names = list(res)
     print("shape(D,K)  Ns   " + "  ".join("%8s" % n for n in names))
     for D, K in SHAPES:

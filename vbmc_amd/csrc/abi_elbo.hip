@@ -649,6 +649,10 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
         q.D = D; q.K = K; q.cutoff = P.cutoff; q.lj.rows = lj_co_shape(ctx, P) ? 1 : 0;
         const int nb = entropy_mfma_occupancy(P.qs, P.kt, P.hv, compute_grad != 0, q);
         if (nb > 0) waves_per_cu = nb * (P.hv & 15);
+        // wide operands (D >= 15): the kernels that COULD hold more than eight waves (one k-tile) do not gain from shorter chunks -- their
+        // per-wave set-up grows with D (D = 20, K = 8: 0.27 -> 0.37 ms with twelve assumed) -- while the ones that hold fewer (LDS: seven)
+        // are where the correction pays (D = 28, K = 40: 1.36 -> 1.10 ms): profiles/r03_shape_sweep.md
+        if (P.qs >= 5 && waves_per_cu > 8) waves_per_cu = 8;
       }
       static const bool occ_off = [] { const char* e = getenv("VBMC_ENT_OCC"); return e && !strcmp(e, "0"); }();   // A/B: the old constant
       if (occ_off) waves_per_cu = P.use_mfma ? 8 : 5;
@@ -669,6 +673,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
         const int c = atoi(fc);
         if (c >= 1 && c <= ntile) bestC = c;
       }
+      if (getenv("VBMC_DEBUG_OCC")) fprintf(stderr, "chunks: D %d K %d R %d qs %d kt %d hv %d waves/CU %d slots %lld kr %lld ntile %d -> C %d\n", D, K, R, P.qs, P.kt, P.hv, waves_per_cu, slots, kr, ntile, bestC);
       P.tpc = (ntile + bestC - 1) / bestC;
       P.C = (ntile + P.tpc - 1) / P.tpc;
     }
