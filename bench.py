@@ -474,6 +474,16 @@ def main():
             t1 = time.perf_counter()
             _, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vp, gp, Ns, None, 0.0, 200, seed=6, engine=eng)
             out_["device_adam_R%d_evals_per_s" % Rc] = float(np.sum(its)) / (time.perf_counter() - t1)
+        # ... and at the sample count VBMC itself runs its chains with (NSent = 100 K^(2/3): 28 per component at K = 50,
+        # misc/vpsieve_vbmc.m:28 with the defaults of vbmc.m), soft bounds as misc/vpoptimize_vbmc.m passes them
+        ns_v = int(np.ceil(100 * K ** (2.0 / 3.0) / K))
+        vpb, tb = vbmc_amd.vpbounds(vp, {"X": inp["X"], "y": inp["y"]}, {"TolConLoss": 0.01, "TolWeight": 1e-2, "WeightPenalty": 0.1, "TolLength": 1e-6}, K)
+        x0 = thetas[:, :1].copy()
+        vbmc_amd.fminadam_device(x0, 0, vpb, gp, ns_v, tb, 0.0, 40, seed=5, engine=eng)
+        t1 = time.perf_counter()
+        _, _, _, _, its = vbmc_amd.fminadam_device(x0, 0, vpb, gp, ns_v, tb, 0.0, 200, seed=6, engine=eng)
+        dt_ = time.perf_counter() - t1
+        out_["device_adam_R1_vbmc_Ns"] = {"Ns_per_component": ns_v, "evals_per_s": float(np.sum(its)) / dt_, "us_per_iteration": 1e6 * dt_ / float(np.sum(its))}
         return out_
 
     def extras_leg():
