@@ -8,7 +8,7 @@ import vbmc_amd  # noqa: E402
 from bench import synth_inputs  # noqa: E402
 
 import os
-D, N, K, S, Ns = 10, 400, 50, 20, int(os.environ.get("PROF_NS", "10000"))
+D, N, K, S, Ns = int(os.environ.get("PROF_D", "10")), 400, int(os.environ.get("PROF_K", "50")), 20, int(os.environ.get("PROF_NS", "10000"))
 inp = synth_inputs(0, D, N, K, S)
 eng = vbmc_amd.Engine(0)
 gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)

@@ -487,7 +487,7 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
   const char* ljf = getenv("VBMC_LJ_KERNEL");
   const long long SR = (long long)P.dm.S * P.dm.R;
   const bool lj_force_mfma = ljf && !strcmp(ljf, "mfma");
-  return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && !(P.cutoff > 0.0) && P.compute_grad &&
+  return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 8 && !(P.cutoff > 0.0) && P.compute_grad &&
          !P.lj_records && SR < ctx->num_cu / 2 && SR * P.rstride < ctx->num_cu / 2;   // (the undivided batch's choice when the restarts are dealt over devices)
 }
 

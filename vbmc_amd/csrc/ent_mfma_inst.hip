@@ -21,7 +21,7 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
   if (HV > 1) after += (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double);
   if (after > lds) lds = after;
   const void* fn = nullptr;
-  if constexpr (HV == 1 && QS_VALUE <= 4) {
+  if constexpr (HV == 1 && QS_VALUE <= 8) {
     // the launch carries the log-joint role (gradient kernels, dense): the caller checked the shape
     if (ea.lj.rows > 0) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, true>;
   }

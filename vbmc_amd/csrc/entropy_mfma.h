@@ -108,11 +108,12 @@ __device__ __forceinline__ void ent_sync_wg() {
 // TAIL they live in the lane layout (sample li, tail component lg) -- one value per lane: the linear part of the exponent is D
 // FMAs per tile from two LDS rows (the sample's draws, the component's coefficients), one exp per sign, and the lane's value IS
 // the A operand of one PV MFMA (component index = inner index lg), its weight-gradient term one lane-local FMA.
-// CO = true (single-wave workgroups, D <= 16): the launch carries the expected log joint as well -- its first a.lj.rows grid rows are
+// CO = true (single-wave workgroups, D <= 30): the launch carries the expected log joint as well -- its first a.lj.rows grid rows are
 // single-wave log-joint workgroups (logjoint_body.h: lj_co_role), the entropy workgroups follow.  For a single chain (one restart, a
 // few dozen samples per component) both kernels are bound by their own dependent chains, not by the chip: side by side an Adam
-// iteration loses the shorter of the two (round 3).  These kernels are built for two waves per SIMD whatever the entropy body needs:
-// the grids they serve do not fill the chip anyway, and the log-joint body keeps 6 x 4 QS values per lane in registers.
+// iteration loses the shorter of the two (round 3).  These kernels are built for two waves per SIMD whatever the entropy body needs
+// (ONE from D = 15 on): the grids they serve do not fill the chip anyway, and the log-joint body keeps 6 x 4 QS values per lane in
+// registers (185 VGPRs at QS = 3, beyond 256 from QS = 6 on, where the accumulation registers take the overflow).
 template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
@@ -122,8 +123,8 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
 #ifndef VBMC_ENT_WAVES
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2)
 #endif
-__global__ void __launch_bounds__(WAVE * HV, CO ? 2 : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
-  static_assert(!CO || (HV == 1 && QS <= 4 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 16");
+__global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+  static_assert(!CO || (HV == 1 && QS <= 8 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 30");
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
   static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
   constexpr int TLN = TL > 0 ? TL : 1;     // tail values per lane: tail component 4u + lg, u < TL (the layout of a k-tile's register u)
