@@ -487,8 +487,13 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
   const char* ljf = getenv("VBMC_LJ_KERNEL");
   const long long SR = (long long)P.dm.S * P.dm.R;
   const bool lj_force_mfma = ljf && !strcmp(ljf, "mfma");
+  // ... and only where the ENTROPY launch is small too (K R waves per sample chunk: a single chain has 50, a batch of restarts over one
+  // hyper-sample -- or an entropy-only evaluation, whose surrogate is a one-point stand-in -- can fill the chip by itself and wants the
+  // kernels built for occupancy, not these)
+  const long long KR = (long long)P.dm.K * P.dm.R * P.rstride;
   return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 8 && !(P.cutoff > 0.0) && P.compute_grad &&
-         !P.lj_records && SR < ctx->num_cu / 2 && SR * P.rstride < ctx->num_cu / 2;   // (the undivided batch's choice when the restarts are dealt over devices)
+         !P.lj_records && SR < ctx->num_cu / 2 && SR * P.rstride < ctx->num_cu / 2 &&   // (the undivided batch's choice when the restarts are dealt over devices)
+         KR < 2 * ctx->num_cu && P.dm.N > 1;
 }
 
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
