@@ -26,7 +26,7 @@ def grab(txt, kern, ctr):
     return float(re.search(r"- %s = ([0-9.e+]+)" % ctr, seg).group(1))
 
 
-kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1>(EntArgs)`"   # the headline instantiation: QS 3, three k-tiles + component tail
+kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1, false>(EntArgs)`"   # the headline instantiation: QS 3, three k-tiles + component tail
 fetch, write = grab(pa, kern, "FETCH_SIZE"), grab(pb, kern, "WRITE_SIZE")
 hbm = int(round(fetch * 1024 * 2 + write * 1024))
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
