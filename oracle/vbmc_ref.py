@@ -11,6 +11,8 @@ function-level golden vectors for this path and neither
 MATLAB nor Octave exists in the build container, so the reference cannot be run
 to generate vectors.  What pins this restatement instead is committed under
 ``tests/golden/`` and exercised by ``tests/test_oracle_*.py``:
+  * the reference's only known answers -- test/runtest_vbmc.m: |ELBO - lnZ| < 0.5 and RMSE of the posterior mean < 0.5 on its
+    test density 1 -- required of this module's whole pipeline from the GP fit on (``tests/test_oracle_known_answers.py``),
   * 50-digit mpmath re-evaluation of the same formulas (``oracle/mp_golden.py``),
   * closed forms (K=1 entropy, alpha=0 log-joint, identical-component bounds),
   * finite differences where the reference's gradient is an exact derivative
