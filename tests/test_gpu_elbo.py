@@ -97,15 +97,20 @@ CONFIGS = [
     # neighbours without a tail: K mod 16 = 0 and 9
     ("K48-D10", 10, 40, 48, 2, 40, "lumpy"),
     ("K57-D10", 10, 40, 57, 2, 40, "lumpy"),
-    # round 3: K = 53..64 at D >= 31 and K = 53..56 at D = 23..26 run on TWO waves with two k-tiles each (ent_hv_small, abi_elbo.hip),
-    # the last wave possibly short (K = 59: 30 + 29); their neighbours stay on one wave
+    # round 3: K = 57..64 at D >= 31 run on TWO waves with two k-tiles each (ent_hv_small, abi_elbo.hip), the last wave possibly short
+    # (K = 59: 30 + 29); one-wave kernels with four k-tiles from D = 15 on, and with three from D = 27 on, are built for ONE wave per
+    # SIMD (VBMC_ENT_ONE_WAVE, entropy_mfma.h)
     ("hv2-K64-D32", 32, 36, 64, 1, 32, "lumpy"),
     ("hv2-K59-D31", 31, 36, 59, 1, 32, "lumpy"),
-    ("hv2-K54-D32", 32, 36, 54, 1, 32, "lumpy"),
-    ("hv2-K55-D24", 24, 40, 55, 1, 32, "lumpy"),
-    ("hv1-K64-D20", 20, 40, 64, 1, 34, "lumpy"),
-    ("hv1-K57-D28", 28, 40, 57, 1, 32, "lumpy"),
-    ("hv1-K59-D16", 16, 40, 59, 2, 36, "lumpy"),
+    ("w1-K54-D32", 32, 36, 54, 1, 32, "lumpy"),
+    ("w1-K55-D24", 24, 40, 55, 1, 32, "lumpy"),
+    ("w1-K64-D20", 20, 40, 64, 1, 34, "lumpy"),
+    ("w1-K57-D28", 28, 40, 57, 1, 32, "lumpy"),
+    ("w1-K59-D16", 16, 40, 59, 2, 36, "lumpy"),
+    ("w1-K48-D28", 28, 40, 48, 1, 32, "lumpy"),
+    # ... and so are the four-wave kernels with four k-tiles per wave from D = 23 on and with three at D >= 31 (K = 193..256)
+    ("w1-hv4-K230-D24", 24, 30, 230, 1, 32, "lumpy"),
+    ("w1-hv4-K200-D31", 31, 30, 200, 1, 32, "lumpy"),
 ]
 
 

@@ -50,7 +50,7 @@ def main():
     libs = sorted(f for f in os.listdir(tune) if f.endswith(".so"))
     res = {}
     for lib in libs:
-        for hv in (("",) if SMALL else ("", "2", "4")):
+        for hv in (("",) if (SMALL or os.environ.get("TUNE_NO_HV")) else ("", "2", "4")):
             env = dict(os.environ, VBMC_HIP_LIB=os.path.join(tune, lib), TUNE_SMALL="1" if SMALL else "0")
             if hv:
                 env["VBMC_ENT_HV"] = hv

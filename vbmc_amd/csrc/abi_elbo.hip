@@ -332,11 +332,10 @@ int vbmc_occupancy_ent_mfma_qs9(int, int, int, const EntArgs*);
 // coupling) -- EXCEPT where the two-wave kernel with four k-tiles per wave and a wide operand (D >= 15) spills its way down:
 // there four waves with two k-tiles each fit their registers (D = 24, K = 128: 3.4 vs 5.7 ms; D = 20, K = 128: 3.9 vs 5.0;
 // D = 20, K = 100 the other way: 50 vs 57 ms at configs[4]).
-// K <= 64: one wave per workgroup, except (round 3, tools/hv_small_sweep.py -> profiles/r03_hv_small.md) where the one-wave kernel with
-// four k-tiles and the widest operands spills its way down: K = 53..64 at D >= 31 (two waves with two k-tiles each: 26-33 % faster) and
-// K = 53..56 at D = 23..26 (15 %).  Everywhere else the split is neutral (K = 64 at D = 16..20: 2-5 %) or costs 25-85 % (PV exchange + a
-// barrier per sign), so one wave stays.
-static int ent_hv_small(int qs, int K) { return ((qs >= 9 && K > 52) || (qs == 7 && K > 52 && K <= 56)) ? 2 : 1; }
+// K <= 64: one wave per workgroup.  Round 3 (tools/hv_small_sweep.py -> profiles/r03_hv_small.md) tried two waves with two k-tiles
+// each where the one-wave kernel with four k-tiles spills: once those kernels were rebuilt for ONE wave per SIMD (512 registers,
+// VBMC_ENT_ONE_WAVE in entropy_mfma.h: 11-23 % faster) the split only wins at K = 57..64 for D >= 31 (6 %) and costs 6-85 % everywhere else.
+static int ent_hv_small(int qs, int K) { return (qs >= 9 && K > 56) ? 2 : 1; }
 static int ent_hv_mid(int qs, int K) { return (K > 96 && (qs >= 7 || (qs >= 5 && K > 112))) ? 4 : 2; }
 static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);

@@ -120,8 +120,20 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
 // tools/ent_experiments.py x_w2 at D = 10), so that one instantiation moved (single-wave workgroups only: the multi-wave ones
 // were not re-measured).
+#ifdef VBMC_ENT_WAVES_ALL      // A/B builds (tools/tune_build.py): every instantiation for this many waves per SIMD
+#define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) VBMC_ENT_WAVES_ALL
+#endif
 #ifndef VBMC_ENT_WAVES
-#define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2)
+// ONE wave per SIMD (512 registers: nothing spills) where the two-wave build spills so much that losing the second wave's latency
+// hiding is the smaller evil (round 3, tools/tune_build.py w1:-DVBMC_ENT_WAVES_ALL=1 against the policy over 112 shapes,
+// profiles/r03_shape_sweep.md): four k-tiles on one wave from D = 15 on (K = 53..64: 11-23 % faster), three k-tiles from D = 27 on
+// (7-23 %), four-wave workgroups with four k-tiles from D = 23 on and with three at D >= 31 (K = 193..256: 27-49 %).  Everywhere
+// else one wave per SIMD costs 2-49 %.
+#define VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) \
+  (((HV_) == 1 && (KT_) == 4 && (QS_) >= 5) || ((HV_) == 1 && (KT_) == 3 && (QS_) >= 8) || ((HV_) == 4 && (KT_) == 4 && (QS_) >= 7) || \
+   ((HV_) == 4 && (KT_) == 3 && (QS_) >= 9))
+#define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) \
+  (VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) ? 1 : ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2))
 #endif
 __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
   static_assert(!CO || (HV == 1 && QS <= 8 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 30");
