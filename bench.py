@@ -224,6 +224,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("VBMC_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for single-GPU smoke tests
+    # the N > 1 code path: process group, library communicator, all-gather per step, strong leg.  VBMC_BENCH_FORCE_COMM=1 takes it with
+    # ONE rank too (under torch.distributed.run --nproc-per-node 1): the only way to execute it on a one-GPU box (tests/test_gpu_comm.py)
+    multi = world > 1 or (os.environ.get("VBMC_BENCH_FORCE_COMM") == "1" and "RANK" in os.environ)
     if args.gpus != world and rank == 0:
         print("bench.py: --gpus %d but the launcher created WORLD_SIZE=%d ranks; reporting the %d ranks that exist"
               % (args.gpus, world, world), file=sys.stderr)
@@ -232,7 +235,7 @@ def main():
     gpu = local_rank % ndev   # fewer devices than ranks (a 1-GPU box): ranks share a device -- gloo only, RCCL refuses duplicates
     if ndev_real:
         torch.cuda.set_device(gpu)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             if world > ndev_real:
@@ -246,7 +249,7 @@ def main():
 
     if args.check_launch:
         me = torch.tensor([rank, os.getpid(), gpu if ndev_real else -1], dtype=torch.int64, device=cdev)
-        if world > 1:
+        if multi:
             allr = torch.empty(world * 3, dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(allr, me)
             dist.barrier()
@@ -257,7 +260,7 @@ def main():
             print(json.dumps({"check_launch": True, "n_gpus": world, "backend": backend if world > 1 else None,
                               "spawned_by_bench": os.environ.get("VBMC_BENCH_SPAWNED") == "1",
                               "ranks": [{"rank": int(a), "pid": int(b), "device": int(c)} for a, b, c in rows]}), flush=True)
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -275,7 +278,7 @@ def main():
     rng = np.random.default_rng(100 + rank)
     thetas = np.asfortranarray(theta0[:, None] + 0.05 * rng.standard_normal((T, Rr)))  # R jittered restarts
     eng.device_gp(gp)  # one-off upload (already resident after gplite_post), outside the timed region
-    gathered = torch.empty(world * Rr, dtype=torch.float64, device=cdev) if world > 1 else None
+    gathered = torch.empty(world * Rr, dtype=torch.float64, device=cdev) if multi else None
 
     # the optimiser-loop objective [F,dF] = negelcbo_vbmc(theta,0,vp,gp,Ns,1,0) as the closure vpoptimize_vbmc.m:71 builds: vp, gp, flags
     # and buffers resolved once; every step still moves theta H2D and (F, dF) D2H
@@ -288,7 +291,7 @@ def main():
     # path (torch.distributed all_gather_into_tensor of the host vector) for A/B runs; it is also the fall-back if librccl cannot be
     # opened from the library.
     comm, gps_all, thetas_all, exchange = None, None, None, None
-    if world > 1 and not args.shard_s:
+    if multi and not args.shard_s:
         exchange = "torch.distributed all_gather_into_tensor"
         # (gloo = ranks sharing one device for a functional check: RCCL refuses two ranks on a device)
         if os.environ.get("VBMC_BENCH_EXCHANGE", "library") != "torch" and backend == "nccl":
@@ -310,7 +313,7 @@ def main():
         return {"F": o["F"], "dF": o["dF"][:, mine]}
 
     shard_ex = None
-    if args.shard_s and world > 1:
+    if args.shard_s and multi:
         from vbmc_amd.dist import ShardExchange
 
         thetas = np.asfortranarray(theta0[:, None] + 0.05 * np.random.default_rng(100).standard_normal((T, Rr)))  # the SAME batch on every rank
@@ -324,7 +327,7 @@ def main():
             return multi_step(i, thetas_all), None
         F_, dF_ = objective(thetas, seed=(rank << 32) + i)
         out = {"F": F_, "dF": dF_}
-        if world > 1:
+        if multi:
             f = torch.from_numpy(out["F"]).to(cdev)
             dist.all_gather_into_tensor(gathered, f)
             order = torch.argsort(gathered, stable=True)  # every rank: identical sieve order
@@ -341,7 +344,7 @@ def main():
     def finish(slot):
         F_, dF_ = objective.collect(slot)
         o = {"F": F_, "dF": dF_}
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(gathered, torch.from_numpy(F_).to(cdev))
             torch.argsort(gathered, stable=True)  # every rank: identical sieve order
         return o
@@ -366,13 +369,13 @@ def main():
     # fresh box: one 7 ms step among twenty)
     run_steps(0, 8)
     run_steps(0, args.warmup)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     # ---- strong scaling (BASELINE configs[3]: the SAME 64 restarts over the GPUs): R restarts in total, R / world per rank
@@ -397,7 +400,7 @@ def main():
         strong = {"value": Rr * args.steps / strong_s, "unit": "evals/s", "scaling": "strong", "restarts_total": Rr,
                   "restarts_per_gpu": Rr / world, "ms_per_step": 1e3 * strong_s / args.steps, "steps": args.steps}
     rank_rows = [[float(rank), float(gpu), elapsed]]
-    if world > 1:
+    if multi:
         mine = torch.tensor(rank_rows[0], dtype=torch.float64, device=cdev)
         allr = torch.empty(world * 3, dtype=torch.float64, device=cdev)
         dist.all_gather_into_tensor(allr, mine)
@@ -674,17 +677,17 @@ def main():
                                                      if world > 1 else "one GPU"),
                        "stepping": ("pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, two in flight; every step moves "
                                     "its theta H2D and its (F, dF) D2H" if pipelined else "one blocking vbmc_elbo_batch call per step")},
-            "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if world > 1 else None),
-            "world_size_observed": (dist.get_world_size() if world > 1 else 1),
+            "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if multi else None),
+            "world_size_observed": (dist.get_world_size() if multi else 1),
             "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if world > 1:
+        if multi:
             line["exchange"] = exchange
             line["strong"] = strong
         line.update(extra)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

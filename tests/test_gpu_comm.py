@@ -131,3 +131,26 @@ def test_all_devices_of_the_node(va):
     blocks = np.arange(3.0 * n).reshape(n, 3)
     assert np.array_equal(comm.allgather_host(blocks), blocks)
     comm.close()
+
+
+def test_bench_multi_gpu_code_path_with_one_rank(va):
+    """bench.py's N > 1 path -- process group over RCCL, the 128-byte id broadcast through it (Comm.from_torch), the surrogate uploaded
+    through the communicator, vbmc_elbo_batch_multi + ncclAllGather inside the library every step, the strong-scaling leg, the timing
+    rows gathered at the end -- executed under torch.distributed.run with ONE rank (VBMC_BENCH_FORCE_COMM=1): all a one-GPU box can
+    run of what the driver launches on eight."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBMC_BENCH_FORCE_COMM="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-aux",
+                        "--no-cpu-baseline", "--restarts", "8"], capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["world_size_observed"] == 1
+    assert "ncclAllGather inside libvbmc_hip.so" in d["exchange"], d["exchange"]
+    assert d["strong"]["restarts_total"] == 8 and d["strong"]["value"] > 0
