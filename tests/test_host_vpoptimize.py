@@ -15,7 +15,9 @@ def _stream(D):
     return stream
 
 
-def _fake_batch(D):
+def _fake_batch(D, gp_any=None):
+    """negelcbo_batch made of the oracle; gp = None (entropy-only evaluation: vpoptimize_vbmc's pruning attempts take the expected
+    log joint from the cached per-component terms) evaluates with ``gp_any`` and hands back the entropy alone."""
     stream = _stream(D)
 
     def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *, separate_K=False,
@@ -25,6 +27,8 @@ def _fake_batch(D):
             thetas = thetas[:, None]
         T, Rn = thetas.shape
         K = vp["K"]
+        if gp is None:
+            gp = gp_any
         out = {k: [] for k in ("F", "dF", "G", "H", "varG", "varGss", "I_sk", "J_sjk")}
         for r in range(Rn):
             eps = stream(seed, r, Rn, K, Ns) if Ns > 0 else None
@@ -56,7 +60,7 @@ def test_vpoptimize_host_logic_matches_sequential_reference(monkeypatch, nslow, 
 
     p, gp, vp = vpopt_problem()
     D = vp["D"]
-    monkeypatch.setattr(opt, "negelcbo_batch", _fake_batch(D))
+    monkeypatch.setattr(opt, "negelcbo_batch", _fake_batch(D, gp))
     opts = dict(OPTS, ELCBOmidpoint=midpoint)
     trace = []
     vpa, varss_a, pruned_a = opt.vpoptimize_vbmc(12, nslow, vp, gp, options=opts, rng=np.random.default_rng(3), seed=5,

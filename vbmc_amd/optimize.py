@@ -312,6 +312,26 @@ def eval_fullelcbo_batch(thetas, vps, gp, beta, options, *, seed=0, engine=None,
     return stats
 
 
+def _stats_from_cache(I_sk, J_sjk, w):
+    """G, varG, varss of a mixture from the per-component terms I_sk (S x K) and J_sjk (S x K x K, full variance) and ITS weights:
+    misc/gplogjoint.m:204,329-332,350 (the sums over components) and :399-413 (the statistics over hyper-samples); cf. the
+    reference's misc/gplogjoint_weights.m:47-58, which recombines the same cached arrays."""
+    S = I_sk.shape[0]
+    F = I_sk @ w
+    d = np.einsum("skk->sk", J_sjk)
+    varF = np.sum(w ** 2 * np.maximum(EPS, d), axis=1) + (np.einsum("sjk,j,k->s", J_sjk, w, w) - np.sum(w ** 2 * d, axis=1))
+    varF = np.maximum(varF, EPS)
+    varss = 0.0
+    if S > 1:
+        Fbar = float(np.sum(F) / S)
+        varFss = float(np.sum((F - Fbar) ** 2) / (S - 1))
+        varss = varFss + float(np.std(varF, ddof=1))
+        G, varG = Fbar, float(np.sum(varF) / S + varFss)
+    else:
+        G, varG = float(F[0]), float(varF[0])
+    return {"G": G, "varF": varG, "varG": varG, "varss": varss, "I_sk": I_sk.copy(), "J_sjk": J_sjk.copy()}
+
+
 def eval_fullelcbo(theta, vp, gp, beta, options, *, seed=0, engine=None):
     """eval_fullelcbo (misc/vpoptimize_vbmc.m:257-305) for one theta."""
     return eval_fullelcbo_batch([theta], [vp], gp, beta, options, seed=seed, engine=engine)[0]
@@ -640,6 +660,10 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
     if vp["optimize_weights"]:
         alreadychecked = np.zeros(vp["K"], dtype=bool)
         count = 0
+        # square copies of the per-component terms for the recombination below (the reported J_sjk loses only its third dimension on
+        # a removal, as the reference's does, :233)
+        Ic = I_sk.copy()
+        Jc = J_sjk.copy() if (J_sjk is not None and not options.get("SkipELBOVariance")) else None
         while np.any((vp["w"] < options["TolWeight"]) & ~alreadychecked):
             cand = np.nonzero((vp["w"] < options["TolWeight"]) & ~alreadychecked)[0]
             idx = int(cand[int(rng.integers(cand.size))])          # idx(randi(numel(idx)))
@@ -652,8 +676,24 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
             vpp["K"] = vpp["K"] - 1
             theta_p, vpp = get_vptheta(vpp)
             count += 1
-            sp = eval_fullelcbo_batch([theta_p], [vpp], gp, elcbo_beta, options, seed=sbase + (3 << 16) + count, engine=engine,
-                                      trace=trace, kind="prune", labels=[count])[0]
+            if Jc is not None and not options.get("VBMCHipPruneFullEval"):
+                # The expected log joint of the candidate and its variance are functions of the per-component terms the last full
+                # evaluation already returned -- I_sk and J_sjk of the components that stay, with the candidate's weights: the reference's
+                # own misc/gplogjoint_weights.m recombines them the same way -- so only the Monte-Carlo entropy needs the device
+                # (same stream as the full evaluation would draw: same seed, same kernel).  0.28 -> 0.08 ms per attempt (round 3).
+                keepk = np.delete(np.arange(Ic.shape[1]), idx)
+                sp = _stats_from_cache(Ic[:, keepk], Jc[:, keepk][:, :, keepk], np.asarray(vpp["w"], dtype=np.float64).reshape(-1))
+                NSentFineK = int(math.ceil(evaloption(options["NSentFine"], vpp["K"]) / vpp["K"]))
+                sd = sbase + (3 << 16) + count
+                Hn = float(negelcbo_batch(np.asarray(theta_p, dtype=np.float64).reshape(-1, 1), 0, vpp, None, NSentFineK, False, 0, None,
+                                          seed=sd, engine=engine, outputs=("H",))["H"][0])
+                sp.update(H=Hn, nelbo=-sp["G"] - Hn, varH=0.0, theta=np.asarray(theta_p, dtype=np.float64).reshape(-1).copy())
+                sp["nelcbo"] = sp["nelbo"] + elcbo_beta * math.sqrt(sp["varF"])
+                if trace is not None:
+                    trace.append({"kind": "prune", "slot": count, "seed": sd, "r": 0, "R": 1, "K": vpp["K"], "Ns": NSentFineK})
+            else:
+                sp = eval_fullelcbo_batch([theta_p], [vpp], gp, elcbo_beta, options, seed=sbase + (3 << 16) + count, engine=engine,
+                                          trace=trace, kind="prune", labels=[count])[0]
             elbo_p, elbo_p_sd = -sp["nelbo"], math.sqrt(sp["varF"])
             delta_elcbo = abs((elbo_p - options["ELCBOImproWeight"] * elbo_p_sd) - (elbo - options["ELCBOImproWeight"] * elbo_sd))
             thr = options["TolImprovement"] * evaloption(options["PruningThresholdMultiplier"], K)
@@ -662,6 +702,9 @@ def vpoptimize_vbmc(Nfastopts, Nslowopts, vp, gp, K=None, optimState=None, optio
                 elbo, elbo_sd = elbo_p, elbo_p_sd
                 G, H, varss, varG, varH = sp["G"], sp["H"], sp["varss"], sp["varG"], sp["varH"]
                 pruned += 1
+                if Jc is not None:
+                    keepk = np.delete(np.arange(Ic.shape[1]), idx)
+                    Ic, Jc = Ic[:, keepk], Jc[:, keepk][:, :, keepk]
                 alreadychecked = np.delete(alreadychecked, idx)
                 I_sk = np.delete(I_sk, idx, axis=1)                 # I_sk(:,idx) = []
                 if J_sjk is not None:
