@@ -2,6 +2,7 @@
 // Host side: argument validation, device scratch, launches, one packed D2H per call.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 #include "elbo_kernels.h"
 #include "var_kernels.h"
@@ -354,6 +355,8 @@ static int entropy_mfma_occupancy(int qs, int kt, int hv, bool grad, const EntAr
   if (qs < 1 || qs > 9) return -1;
   struct Key { int qs, kt, hv, grad, co, sparse, ldsk; };
   static std::vector<std::pair<Key, int>> cache;
+  static std::mutex mu;                           // contexts of several host threads share the table
+  std::lock_guard<std::mutex> lock(mu);
   const Key k{qs, kt, hv, grad ? 1 : 0, ea.lj.rows > 0 ? 1 : 0, ea.cutoff > 0.0 ? 1 : 0, ea.K * (ea.D + ENTP_EXTRA)};
   for (const auto& c : cache)
     if (c.first.qs == k.qs && c.first.kt == k.kt && c.first.hv == k.hv && c.first.grad == k.grad && c.first.co == k.co &&
