@@ -46,10 +46,10 @@ def test_ensemble_slice_sampler_respects_hard_bounds_and_counts_moves():
         return np.zeros(X.shape[0])
 
     x0 = 0.25 + 0.5 * rng.random((2, 6, 2))
-    Xs, lps = ensemble_slice_sample(logp, x0, 50, np.zeros(2), np.ones(2), thin=3, burnin=20, rng=rng)
+    Xs, lps, info = ensemble_slice_sample(logp, x0, 50, np.zeros(2), np.ones(2), thin=3, burnin=20, rng=rng, return_info=True)
     assert Xs.shape == (2, 50, 2) and np.all((Xs >= 0) & (Xs <= 1)) and np.all(lps == 0)
     assert np.std(Xs[0][:, 0]) > 0.15                      # it moves: a uniform on [0, 1] has 0.29
-    assert ensemble_slice_sample.last_funccount == calls["n"]   # out-of-bounds proposals are rejected without an evaluation
+    assert info["funccount"] == calls["n"]   # out-of-bounds proposals are rejected without an evaluation
 
 
 def test_islogf_and_lnpdf_match_the_oracle():

@@ -253,7 +253,8 @@ def gplite_pred_device(gp, Xs, engine):
     return tuple(np.asarray(o).reshape(np.asarray(Xs).shape[0], S) for o in out)
 
 
-def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_factor=1.0, rng=None, max_steps=20, max_shrink=60):
+def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_factor=1.0, rng=None, max_steps=20, max_shrink=60,
+                          return_info=False):
     """Ensemble slice sampling for E independent targets at once, every log-density evaluation ONE batched call.
 
     Stands where the reference calls utils/eissample_lite.m (third-party, 1329 lines, not restated) with its default
@@ -265,7 +266,8 @@ def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_fac
 
     logp(X, e): X (M x D) points, e (M,) the ensemble each belongs to -> (M,) log densities (-inf outside the support).
     x0: E x W x D starting walkers.  Returns (samples E x N x D, logp E x N): after ``burnin`` recorded moves per ensemble have
-    been discarded every thin-th moved walker is recorded, as eissample_lite counts them (:386, one sample per walker move)."""
+    been discarded every thin-th moved walker is recorded, as eissample_lite counts them (:386, one sample per walker move).
+    return_info=True adds a dict with ``funccount``, the evaluations of the target (proposals outside the bounds cost none)."""
     rng = np.random.default_rng(0) if rng is None else rng
     x = np.array(x0, dtype=np.float64, copy=True)
     E, W, D = x.shape
@@ -357,8 +359,7 @@ def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_fac
                     nrec += 1
             if moved >= total and nrec >= N:
                 break
-    ensemble_slice_sample.last_funccount = count[0]
-    return out_x, out_lp
+    return (out_x, out_lp, {"funccount": count[0]}) if return_info else (out_x, out_lp)
 
 
 def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *, rng=None, engine=None):
@@ -452,7 +453,7 @@ def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *,
         v = _islogf(name, "islogf", vln, fm[r, e].reshape(-1, 1), f2[r, e].reshape(-1, 1)).reshape(-1)
         return np.where(np.isfinite(v), v, -np.inf)
 
-    Xs, lps = ensemble_slice_sample(logp, x0, Nm, LB, UB, thin=thin, burnin=burnin, rng=rng)
+    Xs, lps, info_s = ensemble_slice_sample(logp, x0, Nm, LB, UB, thin=thin, burnin=burnin, rng=rng, return_info=True)
     Xa = np.transpose(Xs, (1, 2, 0)).copy()                       # Na x D x S
     lnw = np.empty((S, Nm))
     fs2a = np.empty((Nm, S))
@@ -463,7 +464,7 @@ def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *,
         vln = np.maximum(_vbmc_lnpdf(vp, Xs[s]), np.log(np.finfo(np.float64).tiny)) if isamplevp else None
         lnw[s] = _islogf(name, "islogf1", vln, fm, f2).reshape(-1) - lps[s]
         fs2a[:, s] = f2.reshape(-1)
-    return {"Xa": Xa, "lnw": lnw, "fs2a": fs2a, "funccount": getattr(ensemble_slice_sample, "last_funccount", None)}
+    return {"Xa": Xa, "lnw": lnw, "fs2a": fs2a, "funccount": info_s["funccount"]}
 
 
 def delta_positive(vp):
