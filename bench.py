@@ -562,6 +562,10 @@ def main():
             ("entlb_sieve_R250_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta0[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)),
             ("acqwrapper_acqf_8192_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None, engine=eng), 3)),
             ("acqwrapper_acqviqr_8192_Na100_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.acqwrapper_vbmc(Xs, vp, gpn, stv, False, "acqviqr_vbmc", None, engine=eng), 3)),
+            # the importance-point sampler behind acqimiqr_vbmc (private/activeimportancesampling_vbmc.m:103-246): resampling + MCMC for
+            # every hyper-sample, VBMC's default 100 + 100 + 100 points, all ensembles in lock-step with batched device predictions
+            ("activeimportancesampling_imiqr_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.activeimportancesampling_vbmc(
+                vp, gpn, "acqimiqr_vbmc", None, {}, rng=np.random.default_rng(7), engine=eng), 3)),
         ]
         for B in (1, 64, 256):
             H = np.tile(inp["hyp"], (1, (B + S - 1) // S))[:, :B] + 0.01 * np.random.default_rng(1).standard_normal((inp["hyp"].shape[0], B))
