@@ -7,10 +7,15 @@ from vbmc_amd.acq import _islogf, _vbmc_lnpdf, ensemble_slice_sample
 from oracle import vbmc_ref as R
 
 
-def test_ensemble_slice_sampler_recovers_correlated_gaussians():
+import pytest
+
+
+@pytest.mark.parametrize("spec", [3, 1])
+def test_ensemble_slice_sampler_recovers_correlated_gaussians(spec):
     """Three targets at once (one ensemble each), each a correlated 3-D Gaussian with its own mean / covariance, inside a wide box:
     first and second moments of 3000 recorded samples per target (thin 2) within Monte-Carlo error of the truth, the recorded
-    log densities are the target's own, every sample inside the bounds."""
+    log densities are the target's own, every sample inside the bounds -- with the stepping-out steps / shrinkage proposals evaluated
+    three per batched call (the default) and one at a time (the textbook procedure)."""
     rng = np.random.default_rng(5)
     D, E, W = 3, 3, 8
     means = rng.standard_normal((E, D))
@@ -23,7 +28,7 @@ def test_ensemble_slice_sampler_recovers_correlated_gaussians():
 
     x0 = means[:, None, :] + 0.5 * rng.standard_normal((E, W, D))
     N = 3000
-    Xs, lps = ensemble_slice_sample(logp, x0, N, -20 * np.ones(D), 20 * np.ones(D), thin=2, burnin=400, rng=rng)
+    Xs, lps = ensemble_slice_sample(logp, x0, N, -20 * np.ones(D), 20 * np.ones(D), thin=2, burnin=400, rng=rng, spec=spec)
     assert Xs.shape == (E, N, D) and lps.shape == (E, N)
     assert np.all(np.abs(Xs) <= 20)
     for e in range(E):

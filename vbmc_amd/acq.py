@@ -254,7 +254,7 @@ def gplite_pred_device(gp, Xs, engine):
 
 
 def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_factor=1.0, rng=None, max_steps=20, max_shrink=60,
-                          return_info=False):
+                          spec=3, return_info=False):
     """Ensemble slice sampling for E independent targets at once, every log-density evaluation ONE batched call.
 
     Stands where the reference calls utils/eissample_lite.m (third-party, 1329 lines, not restated) with its default
@@ -267,6 +267,7 @@ def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_fac
     logp(X, e): X (M x D) points, e (M,) the ensemble each belongs to -> (M,) log densities (-inf outside the support).
     x0: E x W x D starting walkers.  Returns (samples E x N x D, logp E x N): after ``burnin`` recorded moves per ensemble have
     been discarded every thin-th moved walker is recorded, as eissample_lite counts them (:386, one sample per walker move).
+    ``spec``: steps of the stepping-out / proposals of the shrinkage evaluated per batched call (1: the textbook one at a time).
     return_info=True adds a dict with ``funccount``, the evaluations of the target (proposals outside the bounds cost none)."""
     rng = np.random.default_rng(0) if rng is None else rng
     x = np.array(x0, dtype=np.float64, copy=True)
@@ -311,43 +312,69 @@ def ensemble_slice_sample(logp, x0, N, LB, UB, *, thin=1, burnin=None, sigma_fac
             y = lc + np.log(rng.random(M))                       # slice level
             L = -rng.random(M)
             Rr = L + 1.0
-            # stepping out, both ends in lock-step; a finished end stops costing evaluations
+            # Stepping out, both ends in lock-step.  The ends are tested `spec` steps at a time in ONE batched evaluation (an end
+            # stops at the first step that falls below the slice level; the steps behind it were evaluated for nothing, which is
+            # cheap, while a call is not: each is a device round trip): same interval as the one-step-at-a-time procedure.
             growL = np.ones(M, dtype=bool)
             growR = np.ones(M, dtype=bool)
-            for _ in range(max_steps):
-                if not (np.any(growL) or np.any(growR)):
-                    break
-                idx = np.concatenate([np.nonzero(growL)[0], np.nonzero(growR)[0]])
-                t = np.concatenate([L[growL], Rr[growR]])
+            steps = 0
+            while steps < max_steps and (np.any(growL) or np.any(growR)):
+                ns = min(spec, max_steps - steps)
+                il, ir = np.nonzero(growL)[0], np.nonzero(growR)[0]
+                off = np.arange(ns, dtype=np.float64)
+                tL = (L[il][:, None] - off[None, :]).reshape(-1)          # L, L - 1, ... of every growing left end
+                tR = (Rr[ir][:, None] + off[None, :]).reshape(-1)
+                idx = np.concatenate([np.repeat(il, ns), np.repeat(ir, ns)])
+                t = np.concatenate([tL, tR])
                 val = lp_of(xc[idx] + t[:, None] * V[idx], ee[idx])
-                nl = int(np.sum(growL))
-                il, ir = idx[:nl], idx[nl:]
-                keepL = val[:nl] > y[il]
-                keepR = val[nl:] > y[ir]
-                L[il[keepL]] -= 1.0
-                Rr[ir[keepR]] += 1.0
-                growL[il[~keepL]] = False
-                growR[ir[~keepR]] = False
-            # shrinkage
+                okL = (val[: il.size * ns] > np.repeat(y[il], ns)).reshape(il.size, ns)
+                okR = (val[il.size * ns:] > np.repeat(y[ir], ns)).reshape(ir.size, ns)
+                nL = np.where(np.all(okL, axis=1), ns, np.argmin(okL, axis=1))     # leading steps inside the slice
+                nR = np.where(np.all(okR, axis=1), ns, np.argmin(okR, axis=1))
+                L[il] -= nL
+                Rr[ir] += nR
+                growL[il[nL < ns]] = False
+                growR[ir[nR < ns]] = False
+                steps += ns
+            # Shrinkage, `spec` proposals per batched evaluation: proposal q + 1 is drawn from the interval as it would be after the
+            # rejection of proposal q, which depends on where proposal q fell, not on its density -- so the chain of proposals can be
+            # laid out before any of them is evaluated; the first one inside the slice is accepted, the interval shrinks by the
+            # rejected ones in front of it.
             todo = np.ones(M, dtype=bool)
             xn = xc.copy()
             ln = lc.copy()
-            for _ in range(max_shrink):
-                if not np.any(todo):
-                    break
+            shr = 0
+            while shr < max_shrink and np.any(todo):
+                ns = min(spec, max_shrink - shr)
                 idx = np.nonzero(todo)[0]
-                t = L[idx] + rng.random(idx.size) * (Rr[idx] - L[idx])
-                P = xc[idx] + t[:, None] * V[idx]
-                val = lp_of(P, ee[idx])
-                acc = val > y[idx]
-                xn[idx[acc]] = P[acc]
-                ln[idx[acc]] = val[acc]
-                todo[idx[acc]] = False
-                rej = idx[~acc]
-                tr = t[~acc]
-                neg = tr < 0
-                L[rej[neg]] = tr[neg]
-                Rr[rej[~neg]] = tr[~neg]
+                n = idx.size
+                Lq, Rq = L[idx].copy(), Rr[idx].copy()
+                T = np.empty((n, ns))
+                Ls, Rs = np.empty((n, ns)), np.empty((n, ns))             # the interval AFTER rejecting proposals 0..q
+                for q in range(ns):
+                    tq = Lq + rng.random(n) * (Rq - Lq)
+                    T[:, q] = tq
+                    neg = tq < 0
+                    Lq = np.where(neg, tq, Lq)
+                    Rq = np.where(neg, Rq, tq)
+                    Ls[:, q], Rs[:, q] = Lq, Rq
+                rep = np.repeat(idx, ns)
+                P = xc[rep] + T.reshape(-1)[:, None] * V[rep]
+                val = lp_of(P, ee[rep]).reshape(n, ns)
+                ok = val > y[idx][:, None]
+                anyok = np.any(ok, axis=1)
+                first = np.argmax(ok, axis=1)                               # first accepted proposal (0 if none: masked below)
+                acc = idx[anyok]
+                fa = first[anyok]
+                Pm = P.reshape(n, ns, D)
+                xn[acc] = Pm[anyok, fa]
+                ln[acc] = val[anyok, fa]
+                todo[acc] = False
+                # intervals: all ns proposals rejected -> after the last; (accepted ones no longer matter)
+                rej = idx[~anyok]
+                L[rej] = Ls[~anyok, ns - 1]
+                Rr[rej] = Rs[~anyok, ns - 1]
+                shr += ns
             # (a walker whose slice collapsed stays where it is: eissample_lite's exitflag -5 case)
             x[:, mine, :] = xn.reshape(E, H, D)
             lp[:, mine] = ln.reshape(E, H)
