@@ -223,6 +223,24 @@ def test_device_rng_stream_is_reproducible_and_standard_normal(va):
     assert out2["H"][0] != out["H"][0]
 
 
+@pytest.mark.parametrize("D", [2, 3, 4, 5, 7, 11, 15, 19])
+def test_device_rng_stream_parity_in_every_padding_class(va, D):
+    """The device-RNG tile carries draws in the padded dimensions and in the samples beyond Mh (round 4: no selects on the way into
+    LDS): every D mod 4 -- D = 4 QS - 5 pads the whole last dim-block and a slot of the one before -- and sample counts whose
+    last tile is partial, with and without the gradient, against the oracle on the dumped stream (ent/entmc_vbmc.m:49-104)."""
+    K = 3
+    p, gp, vp, theta = problem(40 + D, D, 30, K, 2)
+    eng = va.default_engine()
+    for Ns, seed in ((46, 5), (32, 6), (70, 7)):        # Mh = 23, 16, 35
+        eps = eng.ctx.rng_dump(D, K, 1, Ns, seed)[0]
+        ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+        out = va.negelcbo_batch(theta[:, None], 0, vp, gp, Ns, True, 0, seed=seed)
+        assert relerr(out["H"][0], ref["H"]) < RT_VAL
+        assert relerr(out["dF"][:, 0], ref["dF"]) < RT_GRAD
+        val = va.negelcbo_batch(theta[:, None], 0, vp, gp, Ns, False, 0, seed=seed)
+        assert relerr(val["H"][0], ref["H"]) < RT_VAL
+
+
 def test_entropy_mc_converges_to_closed_form(va):
     """K = 1: entmc -> 0.5 D (1 + log 2 pi) + D log sigma + sum log lambda (entlb_vbmc.m:34)."""
     p, gp, vp, theta = problem(7, 4, 30, 1, 1)

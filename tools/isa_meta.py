@@ -44,7 +44,7 @@ def main():
               % (t.group(2), ("+tail" if t.group(6) == "1" else "+tail8" if t.group(6) == "2" else ""), ("+lj" if t.group(7) == "1" else ""), t.group(3), t.group(4), t.group(5), v, a, g(r"\.sgpr_count"), g(r"\.vgpr_spill_count"), g(r"\.sgpr_spill_count"),
                  g(r"\.private_segment_fixed_size"), g(r"\.group_segment_fixed_size"), min(8, 512 // max(tot, 1))))
     # instruction mix of the dense gradient kernel with three k-tiles + component tail (K = 49..52: the headline instantiation at QS = 3)
-    key = "_Z14k_entropy_mfmaILi%dELi3ELb1ELb0ELi1ELi1ELb0EEv7EntArgs" % qs
+    key = "_Z14k_entropy_mfmaILi%dELi3ELb1ELb0ELi1ELi1ELb0ELi1EEv7EntArgs" % qs
     i = asm.find(key + ":")
     if i >= 0:
         body = asm[i: asm.find(".Lfunc_end", i)]

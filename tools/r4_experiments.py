@@ -1,0 +1,117 @@
+"""Round-4 experiments on the headline entropy kernel (k_entropy_mfma<3,3,...>, D = 10, K = 50): library variants built with
+extra -D flags on the QS = 3 translation unit, each timed under a list of environment settings, with a parity check against
+the base library on the same device stream (same seed: F and dF must agree to the summation-order level).
+
+    python tools/r4_experiments.py build            (here: cross-compiles vbmc_amd/lib/exp/libvbmc_hip_<name>.so)
+    python tools/r4_experiments.py run [R] [Ns]     (GPU box)
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP = os.path.join(ROOT, "vbmc_amd", "lib", "exp")
+OBJ = os.path.join(ROOT, "vbmc_amd", "lib", "obj")
+# name -> (compile flags, [environment settings to time it under])
+VARIANTS = {
+    "head": (["@HEAD"], [{}]),     # git HEAD's entropy translation unit (tools/r4_experiments.py build: from /tmp/head_src)
+    "nous": (["-DVBMC_RNG_INLINE", "-DVBMC_NO_US"], [{}]),
+    "us": (["-DVBMC_RNG_INLINE"], [{}]),
+    "us_pv1": (["-DVBMC_RNG_INLINE", "-DVBMC_TUNE_PV1"], [{}]),
+    "us_quad": (["-DVBMC_RNG_INLINE", "-DVBMC_EXP_QUAD"], [{}]),
+}
+
+
+def build(qs=3):
+    only = os.environ.get("VBMC_EXP_ONLY")
+    names = [k for k in VARIANTS if (not only or k in only.split(","))]
+    os.makedirs(EXP, exist_ok=True)
+    others = [os.path.join(OBJ, "vbmc_hip.o")] + [os.path.join(OBJ, "ent_mfma_qs%d.o" % q) for q in range(1, 10) if q != qs]
+    procs = []
+    for name in names:
+        flags = [f for f in VARIANTS[name][0] if f != "@HEAD"]
+        src = os.path.join("/tmp/head_src" if "@HEAD" in VARIANTS[name][0] else ROOT, "vbmc_amd", "csrc", "ent_mfma_inst.hip")
+        o = os.path.join(EXP, "ent_%s.o" % name)
+        procs.append((name, o, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+                                                 "-Wno-pass-failed", "-DQS_VALUE=%d" % qs] + flags +
+                                                ["-c", src, "-o", o])))
+    for name, o, p in procs:
+        assert p.wait() == 0, name
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", o] + others +
+                              ["-ldl", "-o", os.path.join(EXP, "libvbmc_hip_%s.so" % name)])
+        os.remove(o)
+    print("built", names)
+
+
+def one(R, Ns, dump):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    import vbmc_amd
+    from bench import synth_inputs
+
+    D, N, K, S = int(os.environ.get("EXP_D", "10")), 400, int(os.environ.get("EXP_K", "50")), 20
+    inp = synth_inputs(0, D, N, K, S)
+    eng = vbmc_amd.Engine(0)
+    gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)
+    vp = vbmc_amd.make_vp(inp["mu"], inp["sigma"], inp["lam"], eta=inp["eta"])
+    vp["w"] = np.exp(inp["eta"]) / np.sum(np.exp(inp["eta"]))
+    theta0 = np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]), np.log(inp["lam"]), inp["eta"]])
+    th = np.asfortranarray(theta0[:, None] + 0.05 * np.random.default_rng(100).standard_normal((theta0.size, R)))
+    out = None
+    for i in range(3):
+        out = vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=7, engine=eng, outputs=("F", "dF", "H", "dH"))
+    if dump:
+        np.savez(dump, F=out["F"], dF=out["dF"], H=out["H"], dH=out["dH"])
+    eng.ctx.set_profiling(True)
+    ms = []
+    for i in range(10):
+        vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=10 + i, engine=eng, outputs=("F",))
+        ms.append(eng.ctx.last_kernel_ms()[0])
+    print(json.dumps({"ms": float(np.median(ms)), "min": float(np.min(ms))}))
+
+
+def run(R, Ns):
+    import numpy as np
+
+    tmp = os.path.join(ROOT, "gpurun_out", "r4exp")
+    os.makedirs(tmp, exist_ok=True)
+    res = []
+    ref = None
+    for name, (_, envs) in VARIANTS.items():
+        lib = os.path.join(EXP, "libvbmc_hip_%s.so" % name)
+        if not os.path.exists(lib):
+            continue
+        for e in envs:
+            tag = name + "".join(" %s=%s" % kv for kv in e.items())
+            dump = os.path.join(tmp, "out_%d.npz" % len(res))
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(R), str(Ns), dump],
+                                 env=dict(os.environ, VBMC_HIP_LIB=lib, **e), capture_output=True, text=True)
+            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+            if not line:
+                res.append((tag, None, out.stderr[-400:]))
+                continue
+            ms = json.loads(line[-1])
+            z = np.load(dump)
+            if ref is None:
+                ref = z
+            def rel(a, b):
+                return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
+            res.append((tag, ms, "dH %.1e dHgrad %.1e" % (rel(z["H"], ref["H"]), rel(z["dH"], ref["dH"]))))
+    base = res[0][1]["ms"] if res and res[0][1] else None
+    for tag, ms, note in res:
+        if ms is None:
+            print("%-28s FAILED %s" % (tag, note))
+        else:
+            print("%-28s %.3f ms (min %.3f) %+6.1f %%   %s" % (tag, ms["ms"], ms["min"], 100 * (ms["ms"] - base) / base if base else 0.0, note))
+
+
+if __name__ == "__main__":
+    cmd = sys.argv[1] if len(sys.argv) > 1 else "build"
+    if cmd == "build":
+        build()
+    elif cmd == "one":
+        one(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
+    else:
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 64, int(sys.argv[3]) if len(sys.argv) > 3 else 10000)

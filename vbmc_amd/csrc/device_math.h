@@ -170,6 +170,26 @@ __device__ __forceinline__ vb_d4 vb_exp_tab4(vb_d4 x, const double* __restrict__
 #define VB_EXP_TAB1K_SCALE 1477.3197218702985291365628   // 1024 / ln 2
 __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restrict__ tab) {
   const double c = 0.693147180559945309417232 / 1024;
+#ifdef VBMC_EXP_MAGIC
+  // A/B variant: rint by the magic-number addition (three full-rate adds instead of v_rndne + v_cvt + v_sub, two of them quarter-rate);
+  // the integer sits in the low mantissa bits of t: table index = low 10 bits, binary exponent = bits 10..41 (one v_alignbit).
+  // Valid for |y| < 2^41 only (no saturation).
+  {
+    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+    const double t = y + MAGIC;
+    const int lo = __double2loint(t), hi = __double2hiint(t);
+    const double r = y - (t - MAGIC);
+    const double T = tab[lo & (VB_EXP_TAB1K_N - 1)];
+#ifdef VBMC_EXP_QUAD
+    const double u = fma(r, c * c / 2, c);
+#else
+    double u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96);
+    u = fma(r, u, c);
+#endif
+    const double Tr = T * r;
+    return ldexp(fma(Tr, u, T), (int)__builtin_amdgcn_alignbit((unsigned)hi, (unsigned)lo, 10));
+  }
+#endif
   const double nr = __builtin_rint(y);
   // the conversion must SATURATE for |y| >= 2^31 (that is what makes a clamp unnecessary): the hardware instruction does, a
   // C++ cast of an out-of-range value is undefined -- hence the instruction itself
@@ -179,8 +199,12 @@ __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restric
   const double T = tab[ni & (VB_EXP_TAB1K_N - 1)];
   // the dropped quartic term (c r')^4/24 is economised into the quadratic one (r'^4 ~ r'^2/4 - 1/128 on [-1/2, 1/2]:
   // Chebyshev), which leaves a remainder of c^4/24/64 = 1.4e-16 instead of 5.4e-16 at no cost
+#ifdef VBMC_EXP_QUAD
+  const double u = fma(r, c * c / 2, c);     // A/B variant: quadratic (relative error (c/2)^3/6 = 6.5e-12)
+#else
   double u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96);
   u = fma(r, u, c);
+#endif
   const double Tr = T * r;
   return ldexp(fma(Tr, u, T), ni >> 10);
 }
@@ -219,8 +243,12 @@ __device__ __forceinline__ void philox4x32(unsigned c[4], unsigned k0, unsigned 
 // Four standard normals for (sample b, component j, restart r, dim-block q4) under `seed`.
 // Box-Muller on 24-bit uniforms in fp32 (the draws only need to be N(0,1) to MC accuracy; they
 // are then *defined* as the fp64 values returned here, which vbmc_rng_dump reproduces bit for
-// bit -- hence noinline: one body, identical code in every caller; the four values come back in registers).
-__device__ __noinline__ vb_d4 vb_normal4v(unsigned long long seed, unsigned b, unsigned j, unsigned r, unsigned q4) {
+// bit.  ONE body (vb_normal4i): integer arithmetic, exactly rounded fp32 operations none of which the compiler may
+// contract or reassociate (an add followed by a multiply, single multiplies), and the hardware transcendentals -- so
+// every inlined copy computes the same bits; the out-of-line vb_normal4v is that body behind a call (the dump kernel and the
+// kernels that are short of registers use it).  Inlined into the MFMA entropy kernel (round 4) the key schedule and the
+// first round's product with the (uniform) restart index run on the scalar unit and the call's argument / result moves go away.
+__device__ __forceinline__ vb_d4 vb_normal4i(unsigned long long seed, unsigned b, unsigned j, unsigned r, unsigned q4) {
   vb_d4 z;
   unsigned c[4] = {b, j, r, q4};
   philox4x32(c, (unsigned)seed, (unsigned)(seed >> 32));
@@ -235,6 +263,9 @@ __device__ __noinline__ vb_d4 vb_normal4v(unsigned long long seed, unsigned b, u
     z[2 * h + 1] = (double)(rad * sn);
   }
   return z;
+}
+__device__ __noinline__ vb_d4 vb_normal4v(unsigned long long seed, unsigned b, unsigned j, unsigned r, unsigned q4) {
+  return vb_normal4i(seed, b, j, r, q4);
 }
 __device__ __forceinline__ void vb_normal4(unsigned long long seed, unsigned b, unsigned j, unsigned r, unsigned q4, double z[4]) {
   const vb_d4 v = vb_normal4v(seed, b, j, r, q4);

@@ -6,10 +6,13 @@
 #ifndef QS_VALUE
 #error "compile with -DQS_VALUE=<1..9>"
 #endif
+#ifndef VBMC_ENT_CW
+#define VBMC_ENT_CW 0     // > 1: chunk-wave workgroups (entropy_mfma.h, CW) for the instantiations listed in launch_kt
+#endif
 #define CAT2(a, b) a##b
 #define CAT(a, b) CAT2(a, b)
 
-// mode 0: launch.  mode 1: no launch -- returns the number of workgroups of this instantiation one compute unit holds at the launch's
+// mode 0: launch.  mode 2: the chunk waves per workgroup of the kernel that would run.  mode 1: no launch -- returns the number of workgroups of this instantiation one compute unit holds at the launch's
 // dynamic LDS size (hipOccupancyMaxActiveBlocksPerMultiprocessor: registers AND LDS), for the chunk model of elbo_plan.
 template <int KT, int HV, int TL = 0>
 static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
@@ -25,6 +28,10 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
     // the launch carries the log-joint role (gradient kernels, dense): the caller checked the shape
     if (ea.lj.rows > 0) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, true>;
   }
+  int cwv = 1;   // chunk waves per workgroup of the chosen kernel
+  if constexpr (VBMC_ENT_CW > 1 && HV == 1 && KT == 3 && TL == 1) {
+    if (!fn && grad && !(ea.cutoff > 0.0)) { fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, VBMC_ENT_CW>; cwv = VBMC_ENT_CW; }
+  }
   if (!fn) {
     if (ea.cutoff > 0.0 && HV == 1 && !TL) {  // opt-in block-sparse variant (single-wave kernels only, no component tail)
       if constexpr (HV == 1 && TL == 0)
@@ -34,13 +41,15 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
     }
   }
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int threads = (ea.cutoff > 0.0 && HV == 1 && !TL) ? WAVE : WAVE * HV;
+  const int threads = (ea.cutoff > 0.0 && HV == 1 && !TL) ? WAVE : WAVE * HV * cwv;
+  if (mode == 2) return cwv;
   if (mode == 1) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return nb;
+    return nb * cwv;   // in single-wave-workgroup equivalents
   }
   EntArgs arg = ea;
+  if (cwv > 1) grid.x = (grid.x + cwv - 1) / cwv;
   void* args[] = {(void*)&arg};
   (void)hipLaunchKernel(fn, grid, dim3(threads), args, lds, st);
   return 0;
@@ -75,7 +84,7 @@ static int dispatch(int mode, int kt, int grad, int hv, dim3 grid, hipStream_t s
     case 64 + 2: return launch_kt<2, 4>(mode, grad, grid, st, *ea);   // 64 < K <= 128, four waves
     case 64 + 3: return launch_kt<3, 4>(mode, grad, grid, st, *ea);   // 128 < K <= 192
     case 64 + 4: return launch_kt<4, 4>(mode, grad, grid, st, *ea);   // 192 < K <= 256
-    default: return mode == 1 ? -1 : 1;
+    default: return mode != 0 ? -1 : 1;
   }
 }
 
@@ -88,3 +97,14 @@ extern "C" int CAT(vbmc_launch_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, 
 extern "C" int CAT(vbmc_occupancy_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, const EntArgs* ea) {
   return dispatch(1, kt, grad, hv, dim3(1, 1, 1), nullptr, ea);
 }
+
+// chunk waves per workgroup (entropy_mfma.h, CW) of the instantiation that would run; -1: no such kernel
+extern "C" int CAT(vbmc_cw_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, const EntArgs* ea) {
+  return dispatch(2, kt, grad, hv, dim3(1, 1, 1), nullptr, ea);
+}
+
+#ifdef VBMC_EXP_CLK
+extern "C" int CAT(vbmc_dbg_ent_read_qs, QS_VALUE)(unsigned long long* out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ent_dbg), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -35,6 +35,22 @@
 #include "logjoint_body.h"
 
 typedef double mf4 __attribute__((ext_vector_type(4)));
+// how the tile body learns whether its tile can hold samples beyond Mh: a run-time test, or compiled in (see VBMC_ENT_SPLIT)
+struct EntTileAny { static constexpr bool rt = false, val = true; };     // one body for every tile: the selects are always there (a run-time test of
+                                                                          // the tile gets if-converted into twice as many)
+struct EntTileFull { static constexpr bool rt = false, val = false; };
+struct EntTilePartial { static constexpr bool rt = false, val = true; };
+#ifdef VBMC_ENT_NOSPLIT          // A/B builds: one body everywhere
+#define VBMC_ENT_SPLIT(KT_, QS_, TL_, HV_, CW_) false
+#endif
+#ifndef VBMC_ENT_SPLIT
+#define VBMC_ENT_SPLIT(KT_, QS_, TL_, HV_, CW_) ((HV_) == 1)
+#endif
+
+#ifdef VBMC_EXP_CLK   // timeline experiment (tools/r4_timeline.py): per wave [entry, loop start, loop end, exit] on the 100 MHz counter + HW_ID + XCC_ID
+#define VBMC_DBG_WAVES 32768
+__device__ unsigned long long g_ent_dbg[6 * VBMC_DBG_WAVES];
+#endif
 
 // Phase switches for timing experiments (tools/ent_experiments.py builds variants of the library with -DVBMC_EXP_NO...;
 // results are then meaningless -- only the kernel duration is read).  All true in the product build.
@@ -114,7 +130,7 @@ __device__ __forceinline__ void ent_sync_wg() {
 // iteration loses the shorter of the two (round 3).  These kernels are built for two waves per SIMD whatever the entropy body needs
 // (ONE from D = 15 on): the grids they serve do not fill the chip anyway, and the log-joint body keeps 6 x 4 QS values per lane in
 // registers (185 VGPRs at QS = 3, beyond 256 from QS = 6 on, where the accumulation registers take the overflow).
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false>
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, int CW = 1>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
@@ -123,19 +139,24 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
 #ifdef VBMC_ENT_WAVES_ALL      // A/B builds (tools/tune_build.py): every instantiation for this many waves per SIMD
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) VBMC_ENT_WAVES_ALL
 #endif
+#ifndef VBMC_ENT_CW_WAVES
+#define VBMC_ENT_CW_WAVES 3     // waves per SIMD the chunk-wave kernels (CW > 1) are built for
+#endif
 #ifndef VBMC_ENT_WAVES
 // ONE wave per SIMD (512 registers: nothing spills) where the two-wave build spills so much that losing the second wave's latency
 // hiding is the smaller evil (round 3, tools/tune_build.py w1:-DVBMC_ENT_WAVES_ALL=1 against the policy over 112 shapes,
 // profiles/r03_shape_sweep.md): four k-tiles on one wave from D = 15 on (K = 53..64: 11-23 % faster), three k-tiles from D = 27 on
-// (7-23 %), four-wave workgroups with four k-tiles from D = 23 on and with three at D >= 31 (K = 193..256: 27-49 %).  Everywhere
+// (7-23 %), four-wave workgroups with four k-tiles from D = 23 on (round 4: from D = 15 on -- the 154 VGPRs the two-wave build spills at
+// D = 15..22 cost more since the round-4 changes: K = 256, D = 20: 19.1 -> 15.9 ms) and with three at D >= 31 (K = 193..256: 27-49 %).  Everywhere
 // else one wave per SIMD costs 2-49 %.
 #define VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) \
-  (((HV_) == 1 && (KT_) == 4 && (QS_) >= 5) || ((HV_) == 1 && (KT_) == 3 && (QS_) >= 8) || ((HV_) == 4 && (KT_) == 4 && (QS_) >= 7) || \
+  (((HV_) == 1 && (KT_) == 4 && (QS_) >= 5) || ((HV_) == 1 && (KT_) == 3 && (QS_) >= 8) || ((HV_) == 4 && (KT_) == 4 && (QS_) >= 5) || \
    ((HV_) == 4 && (KT_) == 3 && (QS_) >= 9))
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) \
   (VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) ? 1 : ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2))
 #endif
-__global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+__global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV))) k_entropy_mfma(EntArgs a) {
+  static_assert(CW == 1 || (HV == 1 && !CO && !SPARSE && GRAD), "chunk-wave workgroups exist for the dense single-wave gradient kernels");
   static_assert(!CO || (HV == 1 && QS <= 8 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 30");
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4), "larger mixtures are split over the waves of a workgroup (HV = 2, 4)");
   static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
@@ -145,8 +166,8 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
   constexpr int QL = QS;                   // MFMAs of the linear part of the S-step (inner index c = 4q + lg < D, zero operands beyond D: for
                                            // D mod 4 in {3, 0} the last one multiplies zeros -- a compile-time count keeps the KT chains branch-free)
-  __shared__ double Et_all[1][16 * DP];    // eps tile [i][d], staged by wave 0 and shared by the waves of the workgroup
-  __shared__ double RQ_all[HV][16];        // q'_i then 1/q'_i
+  __shared__ double Et_all[CW][16 * DP];   // eps tile [i][d], staged by wave 0 and shared by the HV waves of the workgroup (one per chunk wave)
+  __shared__ double RQ_all[HV * CW][16];   // q'_i then 1/q'_i
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
   constexpr int YXN = NPV * 4 * WAVE;      // doubles per (sign, wave) slot of the PV exchange (in the dynamic LDS, see PB)
@@ -156,15 +177,35 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   // Two-wave workgroups (K > 64) keep the plain per-sign S-step with everything in registers: their LDS already holds the PV
   // exchange buffers and a larger parameter block, and 32 KB more would halve the resident waves.
   constexpr bool EO = HV == 1;
+  // US (round 4): the LDS tile holds u' = eps sigma_j, not eps -- every reader wanted the product (S-step operand, tail, gradient
+  // epilogue: a multiply per use), the own exponent comes from |u'|^2 as well
+#ifdef VBMC_NO_US
+  constexpr bool US = false;
+#else
+  constexpr bool US = EO;
+#endif
   constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
-  const int tid = threadIdx.x, hv = HV == 1 ? 0 : tid >> 6, lane = tid & 63;
+  // CW > 1 (chunk waves): the CW waves of a workgroup work on the SAME (component j, restart r) and on CW consecutive sample chunks,
+  // each on its own -- no barrier in the tile loop -- but they share what depends on (j, r) only: the exp table, the PV operands and,
+  // new here, the S-step operands (SAL: read from LDS right before the MFMA that consumes them, 2 KT QL VGPRs less).  The second
+  // sign's exponents wait in a private LDS block instead of registers (NML: 8 KT VGPRs less).  Together that is what the 168-VGPR
+  // budget of THREE waves per SIMD needs, and the shared table is what lets twelve waves' LDS fit a compute unit.
+  constexpr bool SAL = CW > 1, NML = CW > 1;
+  __shared__ double SAS_all[SAL ? KT * QL * WAVE : 1];
+  __shared__ double NMS_all[CW][NML ? KT * 4 * WAVE : 1];
+#ifdef VBMC_EXP_CLK
+  const unsigned long long wckE = wall_clock64();
+#endif
+  const int tid = threadIdx.x, wv = tid >> 6, hv = HV == 1 ? 0 : wv, cwi = CW == 1 ? 0 : wv, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
-  const int c = blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = blockIdx.z;
+  const int c = CW == 1 ? (int)blockIdx.x : (int)blockIdx.x * CW + cwi, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
-  double* Et = Et_all[0];
-  double* RQ = RQ_all[hv];
+  double* Et = Et_all[cwi];
+  double* RQ = RQ_all[wv];
+  double* SAS = SAS_all;
+  double* NMS = NMS_all[cwi];
   double* BND = BND_all[hv];
   double* VBS = VBS_all[hv];
   double* BTL = BTL_all[hv];
@@ -190,7 +231,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
     // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
     // single chain) this setup is a quarter of the kernel
     const double* gsrc = a.entp + (size_t)r * K * PSg;
-    constexpr int NT = WAVE * HV;
+    constexpr int NT = WAVE * HV * CW;
     const int n = K * PSg;
     int idx = tid;
     for (; idx + 7 * NT < n; idx += 8 * NT) {
@@ -222,7 +263,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   // ---- mixture-side operand fragments (registers, built once).  The S-step operands carry the factor 1024/ln2 of the exp's
   // range reduction (device_math.h: vb_exp_tab1k): the MFMAs deliver E * 1024/ln2
   constexpr double ESC = VB_EXP_TAB1K_SCALE;
-  double SA[KT][QL];          // S-step "A" operand, linear part: comp 16kt + li, inner c = 4q + lg < D
+  double SA[SAL ? 1 : KT][QL];  // S-step "A" operand, linear part: comp 16kt + li, inner c = 4q + lg < D   (in LDS when SAL)
   double SC[KT];              // S-step "A" operand, even part: inner index lg = 0 (coefficient of |u'|^2), 1 (constant), 2, 3 (zero)
   double VB[VBL ? 1 : KT][4][NPV];   // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD; in LDS when VBL)
   double WF[KT][4];           // w_k for comp 16kt + 4r + lg                                  (!GRAD)
@@ -246,7 +287,9 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
     for (int q = 0; q < QL; ++q) {
       const int cc = 4 * q + lg;
       if (EO) {
-        SA[kt][q] = (kv && cc < D) ? ESC * (-2.0 * h * (pk[cc] - pj[cc])) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+        const double sav = (kv && cc < D) ? ESC * (-2.0 * h * (pk[cc] - pj[cc])) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+        if (SAL) { if (cwi == 0) SAS[(kt * QL + q) * WAVE + lane] = sav; }
+        else SA[SAL ? 0 : kt][q] = sav;
       } else {   // plain S-step: linear and even columns in one (D + 2)-column operand, QS MFMAs per sign
         double v;
         if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;
@@ -254,7 +297,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
         else if (cc == D) v = h + hj_neg;
         else if (cc == D + 1) v = fma(h, m2, pk[D + 1]) - cKj;
         else v = 0.0;
-        SA[kt][q] = ESC * v;
+        SA[SAL ? 0 : kt][q] = ESC * v;
       }
     }
     // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2) is folded into the two even columns: accumulators start at 0
@@ -266,6 +309,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       const bool kv2 = k2 < Kw;
       const double* p2 = gp + (size_t)(kv2 ? kbase + k2 : 0) * PSg;
       if (GRAD) {
+        if (CW > 1 && cwi != 0) continue;   // the shared PV operands are written by the first chunk wave
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
           const int col = 16 * pv + li;
@@ -305,7 +349,8 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       for (int d = 0; d < D; ++d) { double t = pq[d] - pj[d]; m2 = fma(t, t, m2); }
       tC0[u] = kvq ? ESC * (h + hj_neg) : 0.0;
       tC1[u] = ESC * (kvq ? fma(h, m2, pq[D + 1]) - cKj : -1.0e6);            // absent component: exp -> 0
-      for (int d = li; d < DP; d += 16) BTL[tq * DP + d] = (kvq && d < D) ? ESC * (-2.0 * h * (pq[d] - pj[d])) : 0.0;
+      if (CW == 1 || cwi == 0)
+        for (int d = li; d < DP; d += 16) BTL[tq * DP + d] = (kvq && d < D) ? ESC * (-2.0 * h * (pq[d] - pj[d])) : 0.0;
       if (GRAD) {
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {     // PV "B" operand: inner index lg <-> tail component 4u + lg, column 16 pv + li
@@ -327,15 +372,18 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   // ---- the parameter block is dead: its LDS becomes the exp table
   __syncthreads();
   {
-    constexpr int NTB = VB_EXP_TAB1K_N / (WAVE * HV);
+    constexpr int NTH = WAVE * HV * CW;
+    constexpr int NTB = (VB_EXP_TAB1K_N + NTH - 1) / NTH;
     double tt[NTB];
 #pragma unroll
-    for (int u = 0; u < NTB; ++u) tt[u] = c_exp2_tab1k[tid + u * WAVE * HV];
+    for (int u = 0; u < NTB; ++u) tt[u] = c_exp2_tab1k[min(tid + u * NTH, VB_EXP_TAB1K_N - 1)];
 #pragma unroll
-    for (int u = 0; u < NTB; ++u) TAB[tid + u * WAVE * HV] = tt[u];
+    for (int u = 0; u < NTB; ++u) if (VB_EXP_TAB1K_N % NTH == 0 || tid + u * NTH < VB_EXP_TAB1K_N) TAB[tid + u * NTH] = tt[u];
   }
   __syncthreads();
+  if (CW > 1 && c >= a.C) return;   // a chunk wave beyond the last chunk (C not a multiple of CW): no barrier follows
 
+#define SAV(kt_, q_) (SAL ? SAS[((kt_) * QL + (q_)) * WAVE + lane] : SA[SAL ? 0 : (kt_)][q_])
 #define VBV(kt_, rr_, pv_) (VBL ? VBS[(((kt_) * 4 + (rr_)) * NPV + (pv_)) * WAVE + lane] : VB[VBL ? 0 : (kt_)][rr_][pv_])
   double accH = 0.0, accG[NPV], accLG[NPV];
   double pm = 1.0;            // running product of mantissas of q'
@@ -348,12 +396,23 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = 0.0;
 
+#ifdef VBMC_EXP_CLK   // timing experiment: shader-clock ticks (s_memtime) against the constant 100 MHz counter over one wave's tile loop
+  const unsigned long long wck0 = wall_clock64();
+#endif
   const int ntile = (a.Mh + 15) >> 4;
+  const double sfm0 = lg == 0 ? 1.0 : 0.0, sfm1 = lg == 1 ? 1.0 : 0.0;   // sample-side operand of the even S-step product (EO)
+  const int emask = (4 * (QS - 1) + lg < D) ? -1 : 0;   // this lane's slot of the last dim-block: a dimension (all ones) or padding (zero)
+  const int emask2 = (QS >= 2 && 4 * (QS - 2) + lg < D) ? -1 : 0;   // ... and of the one before
   const int t0 = (c + a.c0) * a.tiles_per_chunk;
   const int t1 = min(t0 + a.tiles_per_chunk, ntile);
   const double* epsr = a.eps ? a.eps + (size_t)r * a.eps_stride_r + (size_t)j * a.Mh * D : nullptr;
 
-  for (int tile = t0; tile < t1; ++tile) {
+  // The tile body, compiled twice where it pays (VBMC_ENT_SPLIT): once for the full tiles -- no sample-validity selects at all: a
+  // v_cndmask_b32 costs four fp64 operations on this chip (tools/valu_rate.hip), and written as rare uniform branches inside one body
+  // they cost registers the staggered schedule does not have -- and once for the single tile of a component that can hold samples
+  // beyond Mh (its last).  Elsewhere one body with the run-time test.
+  auto tile_body = [&](const int tile, auto pkind) __attribute__((always_inline)) {
+    using PK = decltype(pkind);
     const int b0 = tile * 16;
     // ---- stage the 16 x D eps tile in LDS (zeros for padded dims / samples beyond Mh)
     ent_sync_wg<HV>();
@@ -362,20 +421,36 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
     } else if (epsr) {
       for (int idx = lane; idx < 16 * DP; idx += WAVE) {
         const int i = idx / DP, d = idx - i * DP;
-        Et[idx] = (d < D && b0 + i < a.Mh) ? epsr[(size_t)(b0 + i) * D + d] : 0.0;
+        Et[idx] = (d < D && b0 + i < a.Mh) ? (US ? sigj * epsr[(size_t)(b0 + i) * D + d] : epsr[(size_t)(b0 + i) * D + d]) : 0.0;
       }
     } else {
-      const bool bv = b0 + li < a.Mh;
+      // no select on the way into the tile (v_cndmask_b32 costs four fp64 operations on this chip: tools/valu_rate.hip): draws
+      // land in the padded dimensions and in the samples beyond Mh too; the padded dimensions are masked where they could matter
+      // (ev below: one multiply; every other reader has zero coefficients beyond D or checks d < D), the samples beyond Mh by
+      // svalid in the per-sample scalars (their densities are those of ordinary draws: finite)
 #pragma unroll
       for (int q = lg; q < QS; q += 4) {
         double z4[4] = {0.0, 0.0, 0.0, 0.0};
 #ifdef VBMC_EXP_NORNG
         if (q < (D + 3) / 4) { z4[0] = 1e-3 * (double)((b0 + li) & 1023) - 0.5; z4[1] = 0.25 * z4[0]; z4[2] = -z4[0]; z4[3] = 0.5 - z4[1]; }
 #else
+        // inlined (round 4: -2.5 % at the headline shape -- no call, no wait for every outstanding memory operation at its entry, scalar key
+        // schedule) except in the two instantiations where the inlined body costs registers the kernel does not have (tools/tune_sweep.py:
+        // D = 18, K = 80: +6 %, D = 24, K = 96: +11 %); -DVBMC_RNG_CALL: the out-of-line body everywhere (A/B builds)
+#ifndef VBMC_RNG_CALL
+#define VBMC_RNG_CALL_FOR(KT_, QS_, TL_, HV_) ((HV_) == 2 && (((KT_) == 2 && (TL_) == 2 && (QS_) == 5) || ((KT_) == 3 && (TL_) == 0 && (QS_) == 7)))
+#else
+#define VBMC_RNG_CALL_FOR(KT_, QS_, TL_, HV_) true
+#endif
+        if constexpr (!VBMC_RNG_CALL_FOR(KT, QS, TL, HV)) {
+        if (q < (D + 3) / 4) { const vb_d4 zz = vb_normal4i(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q); z4[0] = zz[0]; z4[1] = zz[1]; z4[2] = zz[2]; z4[3] = zz[3]; }
+        } else {
         if (q < (D + 3) / 4) vb_normal4(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q, z4);
+        }
+#undef VBMC_RNG_CALL_FOR
 #endif
 #pragma unroll
-        for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = (bv && 4 * q + t < D) ? z4[t] : 0.0;
+        for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = US ? sigj * z4[t] : z4[t];
       }
     }
     ent_sync_wg<HV>();
@@ -385,13 +460,21 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
       ev[q] = Et[li * DP + 4 * q + lg];   // zero beyond D
+      // (device-RNG tiles carry draws in the padded dimensions: D = 4 QS - 5 .. 4 QS - 2, so the padding is the tail of the last dim-block
+      // and, for D = 4 QS - 5, the whole of it plus the last slot of the one before)
+      if (q == QS - 1) ev[q] = __hiloint2double(__double2hiint(ev[q]) & emask, __double2loint(ev[q]) & emask);
+      if (QS >= 2 && q == QS - 2) ev[q] = __hiloint2double(__double2hiint(ev[q]) & emask2, __double2loint(ev[q]) & emask2);
       e2 = fma(ev[q], ev[q], e2);
     }
     e2 += __shfl_xor(e2, 16, 64);
     e2 += __shfl_xor(e2, 32, 64);
-    const double shift = cKj - 0.5 * e2;        // exponent of the sample's own component
-    const double u2 = sigj * sigj * e2;         // |u'_i|^2
+    // US: the sum above is |u'_i|^2 already
+    double shift = US ? fma(-e2, hj_neg, cKj) : cKj - 0.5 * e2;              // exponent of the sample's own component: cK_j - |eps_i|^2 / 2
+    const double u2 = US ? e2 : sigj * sigj * e2;                            // |u'_i|^2
+    if (US && SPARSE) e2 *= 2.0 * hj_neg;                                    // |eps_i|^2 for the bound below
+    constexpr bool partial = PK::val;   // can this tile hold samples beyond Mh?  (only the last tile of a component can)
     const bool svalid = b0 + li < a.Mh;
+    if (partial) shift = svalid ? shift : 0.0;
     // ---- block-sparse mode: which k-tiles can contribute more than exp(-cutoff) * q to any sample of this tile?
     // n_ik / q'_i <= exp(cK_k - cK_j - (max(0, |m'_k| - |u'_i|))^2 / (2 sigma_k^2) + |u'_i|^2 / (2 sigma_j^2)) / w_j
     unsigned act = FULL_MASK;
@@ -412,23 +495,29 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
     }
 
     // ---- S-step, once per tile for both signs
-    mf4 n[KT], nm[EO ? KT : 1];
+    mf4 n[KT], nm[(EO && !NML) ? KT : 1];
     if (EO) {
-      const double sfc = lg == 0 ? u2 : (lg == 1 ? 1.0 : 0.0);
+      const double sfc = fma(u2, sfm0, sfm1);   // [|u'|^2, 1, 0, 0] over the lane groups, exactly, without the two selects
       double sfl[QL];
 #pragma unroll
-      for (int q = 0; q < QL; ++q) sfl[q] = ev[q] * sigj;       // u'_ic (zero beyond D)
+      for (int q = 0; q < QL; ++q) sfl[q] = US ? ev[q] : ev[q] * sigj;       // u'_ic (zero beyond D)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
-        nm[EO ? kt : 0] = (mf4){0.0, 0.0, 0.0, 0.0};
+        if (!NML) nm[(EO && !NML) ? kt : 0] = (mf4){0.0, 0.0, 0.0, 0.0};
         if (!SP || ((act >> kt) & 1u)) {
-          const mf4 cacc = X_S ? __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0) : (mf4){SC[kt] * sfc, sfl[0], SA[kt][0], -1.0};
+          const mf4 cacc = X_S ? __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0) : (mf4){SC[kt] * sfc, sfl[0], SAV(kt, 0), -1.0};
           n[kt] = cacc;
 #pragma unroll
           for (int q = 0; q < QL; ++q)
-            if (X_S) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sfl[q], n[kt], 0, 0, 0);
-          nm[EO ? kt : 0] = 2.0 * cacc - n[kt];
+            if (X_S) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SAV(kt, q), sfl[q], n[kt], 0, 0, 0);
+          if (NML) {
+            const mf4 e2nd = 2.0 * cacc - n[kt];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) NMS[(kt * 4 + rr) * WAVE + lane] = e2nd[rr];
+          } else {
+            nm[(EO && !NML) ? kt : 0] = 2.0 * cacc - n[kt];
+          }
         }
       }
     }
@@ -443,7 +532,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
         double lt = 0.0;
 #pragma unroll
         for (int d = 0; d < DP; ++d) lt = fma(BTL[(4 * u + lg) * DP + d], Et[li * DP + d], lt);    // zero beyond D on both sides
-        lt *= sigj;
+        if (!US) lt *= sigj;
         const double ct = fma(tC0[u], u2, tC1[u]);
         ntl[u] = ct + lt;
         ntm[u] = ct - lt;
@@ -481,7 +570,9 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
     // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
     // (NPV >= 2: the column blocks are independent chains already, one set is enough -- 16 VGPRs less.)
     auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg, const double (&tn)[TLN]) {
-#ifdef VBMC_TUNE_PV2
+#if defined(VBMC_TUNE_PV1)
+      constexpr bool TWO = false;     // A/B: one accumulator set even with a single column block
+#elif defined(VBMC_TUNE_PV2)
       constexpr bool TWO = (VBMC_TUNE_PV2) != 0 || NPV == 1;
 #else
       constexpr bool TWO = NPV == 1;
@@ -545,11 +636,15 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       ent_sync<HV>();   // RQ is private to the wave
     };
     auto get_rq = [&]() -> double {
-      const double qs_ = svalid ? RQ[li] : 1.0;
-      const double rqs = svalid ? vb_rcp(qs_) : 0.0;
+      double qs_ = RQ[li];
+      double rqs = vb_rcp(qs_);
+      if (partial) {
+        qs_ = svalid ? qs_ : 1.0;
+        rqs = svalid ? rqs : 0.0;
+      }
       pm *= __builtin_amdgcn_frexp_mant(qs_);   // sum log q' = ln2 * sum exp + log(prod mant)
       pe += __builtin_amdgcn_frexp_exp(qs_);
-      if (svalid) accH += shift;
+      accH += shift;
       return rqs;
     };
     auto wacc = [&](mf4 (&x)[KT], double rqs, const double (&tn)[TLN]) {
@@ -570,7 +665,8 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       ent_sync<HV>();
     };
     // gradient pieces in the PV output layout
-    auto gradpieces = [&](mf4 (&Y)[NPV], double ssig) {
+    auto gradpieces = [&](mf4 (&Y)[NPV], double ssig, auto sgc) {   // sgc: the sign as a compile-time +1 / -1 (US: no multiply), or 0: ssig at run time
+      constexpr int SG = decltype(sgc)::value;
       const int base = lane & 48;
 #pragma unroll
       for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
@@ -582,7 +678,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
           if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
           const int d = 16 * pv + li - 2;
           if (d >= 0 && d < D) {
-            const double t = ssig * Et[i * DP + d];              // u'_id = +-eps_id sigma_j
+            const double t = (US && SG > 0) ? Et[i * DP + d] : ((US && SG < 0) ? -Et[i * DP + d] : ssig * Et[i * DP + d]);   // u'_id = +-eps_id sigma_j
             const double gd = (t * Av - Y[pv][rr]) * rq;         // lambda_d lsum_d / q  (:77-79)
             accG[pv] += gd;                                      // -> mu_grad (:82)
             accLG[pv] = fma(t, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93), times sigma_j (divided out at the end)
@@ -591,18 +687,21 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       }
       ent_sync<HV>();
     };
-    // fold the mantissa product before it can underflow (0.5^256 = 8.6e-78)
+    // renormalise the mantissa product before it can underflow (0.5^256 = 8.6e-78): its exponent joins the exponent sum.  (Round 4:
+    // this used to take the logarithm here -- two instructions now instead of a library log in the tile loop, whose polynomial
+    // constants sat in twelve VGPRs of a kernel that has none to spare.)
     auto fold = [&]() {
       if (++pcnt == 256) {
-        accH += log(pm) + 0.693147180559945309417 * (double)pe;
-        pm = 1.0; pe = 0; pcnt = 0;
+        pe += __builtin_amdgcn_frexp_exp(pm);
+        pm = __builtin_amdgcn_frexp_mant(pm);
+        pcnt = 0;
       }
     };
     using I0 = std::integral_constant<int, 0>;
     using IH = std::integral_constant<int, (KT + 1) / 2>;
     using IK = std::integral_constant<int, KT>;
 
-    if constexpr (EO && GRAD && VBMC_STAG_FOR(KT, QS, TL)) {
+    if constexpr (EO && GRAD && CW == 1 && VBMC_STAG_FOR(KT, QS, TL)) {
       // Both signs in straight-line code, staggered: the second sign's exponentials (independent of everything the first
       // sign's per-sample chain waits for -- the q' exchange through LDS, the reciprocal, the 1/q' exchange) are issued
       // inside that chain, so this wave keeps the pipe busy across its own latencies instead of leaving them to the one
@@ -618,20 +717,20 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       exps(nm, IH{}, IK{});
       texp(ntm);
       wacc(n, rqs, ntl);
-      gradpieces(Y, sigj);
+      gradpieces(Y, sigj, std::integral_constant<int, 1>{});
       fold();
       pvstep(nm, Y, 1, ntm);
       put_q(Y);
       const double rqs2 = get_rq();
       wacc(nm, rqs2, ntm);
       put_rq(rqs2);
-      gradpieces(Y, -sigj);
+      gradpieces(Y, -sigj, std::integral_constant<int, -1>{});
       fold();
     } else {
       // one loop body for both signs; the second sign's exponents are MOVED into n on the back edge -- written as a
       // conditional at the loop head the compiler turns them into 32 selects per sign
       int sg = 0;
-      double ssig = sigj;          // +-sigma_j
+      double ssig = US ? 1.0 : sigj;          // +-sigma_j (US: +-1, the tile holds the product)
 #pragma unroll 1
       for (;;) {
         if (!EO) {   // plain S-step of this sign: KT independent accumulator chains
@@ -652,7 +751,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
           for (int kt = 0; kt < KT; ++kt) {
             n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
+            for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[SAL ? 0 : kt][q], sf[q], n[kt], 0, 0, 0);
           }
         }
         exps(n, I0{}, IK{});
@@ -664,7 +763,7 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
           const double rqs = get_rq();
           wacc(n, rqs, ntl);
           put_rq(rqs);
-          gradpieces(Y, ssig);
+          gradpieces(Y, ssig, std::integral_constant<int, 0>{});
         } else {
           double qp = 0.0;
 #pragma unroll
@@ -684,24 +783,42 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
 #pragma unroll
             for (int w = 1; w < HV; ++w) qp += YX[(sg * HV + w) * YXN + lane];
           }
-          const double qs_ = svalid ? qp : 1.0;
+          double qs_ = qp;
+          if (partial) qs_ = svalid ? qp : 1.0;
           pm *= __builtin_amdgcn_frexp_mant(qs_);
           pe += __builtin_amdgcn_frexp_exp(qs_);
-          if (svalid) accH += shift;
+          accH += shift;
         }
         fold();
         if (sg) break;
         sg = 1;
-        ssig = -sigj;
+        ssig = US ? -1.0 : -sigj;
         if (EO) {
 #pragma unroll
-          for (int kt = 0; kt < KT; ++kt) n[kt] = nm[EO ? kt : 0];
+          for (int kt = 0; kt < KT; ++kt) {
+            if (NML) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) n[kt][rr] = NMS[(kt * 4 + rr) * WAVE + lane];
+            } else {
+              n[kt] = nm[(EO && !NML) ? kt : 0];
+            }
+          }
         }
 #pragma unroll
         for (int u = 0; u < TLN; ++u) ntl[u] = ntm[u];
       }
     }
+  };
+  if constexpr (VBMC_ENT_SPLIT(KT, QS, TL, HV, CW)) {
+    const int tf = min(t1, a.Mh >> 4);        // tiles [t0, tf) hold 16 samples each
+    for (int tile = t0; tile < tf; ++tile) tile_body(tile, EntTileFull{});
+    if (tf < t1) tile_body(tf, EntTilePartial{});
+  } else {
+    for (int tile = t0; tile < t1; ++tile) tile_body(tile, EntTileAny{});
   }
+#ifdef VBMC_EXP_CLK
+  const unsigned long long wck1 = wall_clock64();
+#endif
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
   if (lg != 0) accH = 0.0;   // the four lanes of a sample hold identical copies: count one
 
@@ -753,5 +870,16 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       }
     }
   }
+#ifdef VBMC_EXP_CLK
+  if (lane == 0) {
+    const size_t w = ((size_t)r * K + j) * a.C + c;
+    if (w < VBMC_DBG_WAVES) {
+      g_ent_dbg[6 * w + 0] = wckE; g_ent_dbg[6 * w + 1] = wck0; g_ent_dbg[6 * w + 2] = wck1; g_ent_dbg[6 * w + 3] = wall_clock64();
+      g_ent_dbg[6 * w + 4] = __builtin_amdgcn_s_getreg(63492);    // HW_ID
+      g_ent_dbg[6 * w + 5] = __builtin_amdgcn_s_getreg(63508);    // XCC_ID
+    }
+  }
+#endif
 #undef VBV
+#undef SAV
 }
