@@ -99,6 +99,7 @@ def cpu_baseline(inp, gp, D, K, Ns_full, budget_s=20.0):
 
     out = {}
     for omp in (False, True):
+        run(2, omp)                          # untimed: the first call into the port loads (or rebuilds, -march=native) the library
         t_lj = run(2, omp)                   # entropy negligible: K*2 samples
         Ns1 = 400
         t1 = run(Ns1, omp) - t_lj
@@ -117,6 +118,36 @@ def cpu_baseline(inp, gp, D, K, Ns_full, budget_s=20.0):
             "sample": "C port of the MATLAB loop nest (oracle/vbmc_oracle.c), 1 thread: median of %d evaluations at Ns=%d of %d per "
                       "component, %.2fs each; entropy part scaled linearly in Ns, log-joint part (%.3fs) timed in full" % (nrep, Ns2, Ns_full, t2, t_lj),
             "all_cores": {"value": vo[0], "cores": int(lib.oracle_num_threads()), "sample": "same port with OpenMP, median of %d evaluations at Ns=%d" % (vo[4], vo[1])}}
+
+
+def interpreted_baseline(D, K, Ns_full, budget_s=20.0):
+    """"if matlab or octave is discovered on the GPU box at bench time, additionally time the build's own .m restatement".
+    tools/cpu_ref_entmc.m is that restatement (written from the formulas of ent/entmc_vbmc.m:28-128, vectorised over samples the way
+    the reference is); it is run at a reduced sample count inside a time budget and scaled linearly in Ns.  Returns {"found": None}
+    when neither interpreter is on the PATH -- the usual case: the image ships neither."""
+    import shutil
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = os.path.join(here, "tools", "cpu_ref_entmc.m")
+    for exe, argv in (("matlab", ["-batch"]), ("octave-cli", ["--no-gui", "--quiet", "--eval"]), ("octave", ["--no-gui", "--quiet", "--eval"])):
+        path = shutil.which(exe)
+        if not path:
+            continue
+        Ns1 = 400
+        cmd = "addpath('%s'); cpu_ref_entmc(%d, %d, %d, %g);" % (os.path.join(here, "tools"), D, K, Ns1, budget_s / 2)
+        try:
+            r = subprocess.run([path] + argv + [cmd], capture_output=True, text=True, timeout=6 * budget_s)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("ENTMC_SECONDS_PER_EVAL")]
+            if r.returncode != 0 or not line:
+                return {"found": exe, "error": (r.stderr or r.stdout)[-300:]}
+            sec = float(line[-1].split()[1]) * (Ns_full / Ns1)
+            return {"found": exe, "value": 1.0 / sec, "unit": "evals/s (entropy + gradient only)", "kind": "port, interpreted",
+                    "sample": "tools/cpu_ref_entmc.m (the build's own restatement of ent/entmc_vbmc.m, not the reference's file) at Ns=%d of %d per "
+                              "component, scaled linearly in Ns" % (Ns1, Ns_full)}
+        except Exception as e:  # noqa: BLE001
+            return {"found": exe, "error": str(e)[:300]}
+    return {"found": None, "note": "neither matlab nor octave on the PATH of this host: no interpreted baseline (tools/cpu_ref_entmc.m is what would run)"}
 
 
 def _free_port():
@@ -306,11 +337,35 @@ def main():
                 comm = None
                 exchange += " (library communicator unavailable: %s)" % str(e)[:120]
 
-    def multi_step(i, batch):
-        o = comm.negelcbo_batch(batch, 0, vp, gps_all, Ns, True, 0, seed=i, outputs=("F", "dF"))
-        np.argsort(o["F"], kind="stable")     # every rank: the identical sieve order (misc/vpsieve_vbmc.m:82)
-        mine = np.arange(batch.shape[1])[rank::world]
-        return {"F": o["F"], "dF": o["dF"][:, mine]}
+    # the N > 1 objective with everything resolved once (vbmc_amd.multi.PreparedMulti: the argument struct, the per-device sub-plans'
+    # staging and the exchange blocks live across calls); pipelined like the one-GPU step: vbmc_elbo_multi_submit / _collect, two
+    # batches in flight
+    po_multi = comm.prepare(T, Rr * world, 0, vp, gps_all, Ns) if comm is not None else None
+
+    def multi_finish(po, slot, ncols):
+        F_, dF_ = po.collect(slot)
+        np.argsort(F_, kind="stable")         # every rank: the identical sieve order (misc/vpsieve_vbmc.m:82)
+        mine = np.arange(ncols)[rank::world]
+        return {"F": F_, "dF": dF_[:, mine]}
+
+    def multi_step(i, batch, po=None):
+        po = po or po_multi
+        po.submit(batch, seed=i, slot=0)
+        return multi_finish(po, 0, batch.shape[1])
+
+    def multi_run(po, batch, i0, n, pipe):
+        o, pend = None, []
+        for i in range(n):
+            if not pipe:
+                o = multi_step(i0 + i, batch, po)
+                continue
+            po.submit(batch, seed=i0 + i, slot=i & 1)
+            pend.append(i & 1)
+            if len(pend) == 2:
+                o = multi_finish(po, pend.pop(0), batch.shape[1])
+        while pend:
+            o = multi_finish(po, pend.pop(0), batch.shape[1])
+        return o
 
     shard_ex = None
     if args.shard_s and multi:
@@ -339,7 +394,7 @@ def main():
     # vbmc_elbo_collect, two batches in flight: the host stages theta of step i + 1 while the device works on step i.  Every
     # step still moves its theta H2D, runs the full pass and moves (F, dF) D2H, and every step's results are consumed (the
     # all-gather + sort of the sieve when world > 1) before the timed region ends.  --sync-steps: one blocking call per step.
-    pipelined = shard_ex is None and comm is None and not args.sync_steps
+    pipelined = shard_ex is None and not args.sync_steps
 
     def finish(slot):
         F_, dF_ = objective.collect(slot)
@@ -351,6 +406,8 @@ def main():
 
     def run_steps(i0, n):
         o, pend = None, []
+        if comm is not None:
+            return multi_run(po_multi, thetas_all, i0, n, pipelined)
         if not pipelined:
             for i in range(n):
                 o, _ = step(i0 + i)
@@ -367,7 +424,8 @@ def main():
     # untimed: a fresh box runs its first launches with cold code pages, first-touch pinned blocks and ramping clocks; a few steps
     # beyond the caller's --warmup keep a single slow step of that kind out of the timed region (observed once in ~25 runs on a
     # fresh box: one 7 ms step among twenty)
-    run_steps(0, 8)
+    WARM_EXTRA = 8                # reported as warmup_untimed_extra
+    run_steps(0, WARM_EXTRA)
     run_steps(0, args.warmup)
     if multi:
         dist.barrier()
@@ -383,13 +441,12 @@ def main():
     if comm is not None and Rr >= world:
         batch = np.ascontiguousarray(thetas_all[:, :Rr], dtype=np.float64)
         batch = np.asfortranarray(batch)
-        for i in range(3):
-            multi_step(5000 + i, batch)
+        po_strong = comm.prepare(T, Rr, 0, vp, gps_all, Ns)
+        multi_run(po_strong, batch, 5000, 4, pipelined)
         dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(args.steps):
-            multi_step(6000 + i, batch)
+        multi_run(po_strong, batch, 6000, args.steps, pipelined)
         torch.cuda.synchronize()
         dist.barrier()
         strong_s = time.perf_counter() - t1
@@ -611,7 +668,8 @@ def main():
         """BASELINE configs[3] is the SAME 64 restarts over 8 GPUs: 64 / G per device.  The rate of one device at R = 32, 16, 8 says
         what G = 2, 4, 8 devices can reach before a node is there (strong-scaling bound: G x rate(64 / G) / rate(64))."""
         out_ = {}
-        for Rc in (32, 16, 8):
+        f_ent, _, _ = algorithmic_flops(D, K, M, S, N)
+        for Rc in (32, 16, 8, 4, 2, 1):
             obj = vbmc_amd.PreparedObjective(T, Rc, 0, vp, gp, Ns, 0, None, engine=eng)
             th = np.asfortranarray(thetas[:, :Rc])
             for _ in obj.stream([th] * 4, seeds=[1, 2, 3, 4]):
@@ -619,7 +677,69 @@ def main():
             t1 = time.perf_counter()
             for _ in obj.stream([th] * 20, seeds=list(range(10, 30))):
                 pass
-            out_["restarts_%d_evals_per_s" % Rc] = Rc * 20 / (time.perf_counter() - t1)
+            dt_ = time.perf_counter() - t1
+            out_["restarts_%d_evals_per_s" % Rc] = Rc * 20 / dt_
+            eng.ctx.set_profiling(True)
+            ems = []
+            for i in range(5):
+                obj(th, seed=40 + i)
+                ems.append(eng.ctx.last_kernel_ms()[0])
+            eng.ctx.set_profiling(False)
+            out_["restarts_%d" % Rc] = {"ms_per_step": 1e3 * dt_ / 20, "entropy_kernel_ms": float(np.median(ems)),
+                                        "frac": Rc * f_ent / (float(np.median(ems)) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        return out_
+
+    def comm_one_rank_leg():
+        """The N > 1 step's own cost on ONE device: the same R = 64 and R = 8 steps through a one-rank communicator -- Comm.create_all(1):
+        a real ncclAllGather on the context's stream, k_comm_pick, the gathered read-back -- pipelined like the headline step, beside
+        the plain PreparedObjective step of the same R on the same context.  What the strong-scaling prediction 8 x rate(R = 8) /
+        rate(R = 64) has to be discounted by before a node is there."""
+        from vbmc_amd.multi import Comm
+
+        out_ = {}
+        comm1 = Comm.create_all(1)
+        try:
+            gps1 = comm1.upload_gp(gp)
+            for Rc in (64, 8):
+                if Rc > thetas.shape[1]:
+                    continue
+                th = np.asfortranarray(thetas[:, :Rc])
+                po = comm1.prepare(T, Rc, 0, vp, gps1, Ns)
+                obj = vbmc_amd.PreparedObjective(T, Rc, 0, vp, gp, Ns, 0, None, engine=eng)
+
+                def run_comm(n, i0):
+                    pend = []
+                    for i in range(n):
+                        po.submit(th, seed=i0 + i, slot=i & 1)
+                        pend.append(i & 1)
+                        if len(pend) == 2:
+                            F_, _ = po.collect(pend.pop(0))
+                            np.argsort(F_, kind="stable")
+                    while pend:
+                        F_, _ = po.collect(pend.pop(0))
+                        np.argsort(F_, kind="stable")
+
+                def run_plain(n, i0):
+                    for _ in obj.stream([th] * n, seeds=list(range(i0, i0 + n))):
+                        pass
+
+                nst = 20 if Rc >= 32 else 40
+                res = {}
+                for name, fn in (("plain", run_plain), ("comm", run_comm)):
+                    fn(4, 1)
+                    ts = []
+                    for rep_ in range(3):
+                        t1 = time.perf_counter()
+                        fn(nst, 100 * (rep_ + 1))
+                        ts.append((time.perf_counter() - t1) / nst)
+                    res[name] = 1e3 * float(np.median(ts))
+                out_["R%d" % Rc] = {"plain_ms_per_step": res["plain"], "comm_ms_per_step": res["comm"],
+                                    "overhead_pct": 100.0 * (res["comm"] - res["plain"]) / res["plain"],
+                                    "comm_evals_per_s": Rc / (res["comm"] * 1e-3)}
+            comm1.free_gp(gps1)
+        finally:
+            comm1.close()
+        out_["path"] = "Comm.create_all(1): vbmc_elbo_multi_submit / _collect, ncclAllGather of [F | varG] on the context's stream, two batches in flight"
         return out_
 
     def sync_leg():
@@ -648,6 +768,9 @@ def main():
             aux["eps_streamed"] = v
         gp_legs(aux)
         aux.update(leg("aux.small_batches", small_batch_leg) or {})
+        v = leg("aux.comm_one_rank", comm_one_rank_leg)
+        if v is not None:
+            aux["comm_one_rank"] = v
         if (D, N, K, Ns, S) == (10, 400, 50, 10000, 20):     # the other single-GPU configurations of BASELINE.json, beside the headline
             v = leg("aux.config1", lambda: shape_leg(6, 200, 10, 1000, 8, 64, "student", False, 20))
             if v is not None:
@@ -662,6 +785,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = leg("cpu_baseline", lambda: cpu_baseline(inp, gp, D, K, Ns))
+        if cpu is not None:
+            cpu["interpreted"] = leg("cpu_baseline.interpreted", lambda: interpreted_baseline(D, K, Ns))
     if leg_errors:
         extra["leg_errors"] = leg_errors
 
@@ -671,6 +796,7 @@ def main():
             "metric": "ELBO+grad evals/sec (Ns=1e4, K=50, D=10, N=400)" if (D, N, K, Ns) == (10, 400, 50, 10000)
             else "ELBO+grad evals/sec (Ns=%d, K=%d, D=%d, N=%d)" % (Ns, K, D, N),
             "value": evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_untimed_extra": WARM_EXTRA,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if shard_ex is not None else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (seeded lumpy 12-component target, SURVEY 8d); device Philox MC draws",
             "config": {"workload": "BASELINE configs[%d]: D=%d N=%d K=%d Ns=%d/component S=%d, R=%d restarts batched per GPU per step, "
@@ -679,8 +805,10 @@ def main():
                        "parallelism": ("hyper-sample x sample-chunk sharded x%d (one batch of %d), all-gather of the partial records" % (world, Rr))
                        if shard_ex is not None else ("restart-sharded x%d (restart r on rank r mod %d), all-gather of ELCBO" % (world, world)
                                                      if world > 1 else "one GPU"),
-                       "stepping": ("pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, two in flight; every step moves "
-                                    "its theta H2D and its (F, dF) D2H" if pipelined else "one blocking vbmc_elbo_batch call per step")},
+                       "stepping": (("pipelined: independent batches through vbmc_elbo_multi_submit / vbmc_elbo_multi_collect (the restarts dealt over "
+                                     "the ranks, ncclAllGather of the ELCBO values inside the library), two in flight" if comm is not None else
+                                     "pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, two in flight") +
+                                    "; every step moves its theta H2D and its (F, dF) D2H" if pipelined else "one blocking call per step")},
             "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if multi else None),
             "world_size_observed": (dist.get_world_size() if multi else 1),
             "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],

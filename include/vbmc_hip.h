@@ -322,9 +322,14 @@ vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_
  *                           all-gathered vectors as device memory of local device 0 received them); the other outputs are filled
  *                           for the restarts this process evaluated (all of them for vbmc_comm_create_all) and left untouched
  *                           elsewhere.  The device stream of restart r is keyed by its index r in the undivided batch
- *                           (restart_offset / restart_stride), and each device computes its restarts with the same kernels in the same
- *                           order of summation: every value is BIT-IDENTICAL to vbmc_elbo_batch of the whole batch on one
- *                           device.  eps_mode 0, or one shared host block of draws (eps_mode 1 with eps_shared).
+ *                           (restart_offset / restart_stride): every rank evaluates exactly the Monte-Carlo estimator the one-device
+ *                           batch evaluates, sample for sample.  The values agree with vbmc_elbo_batch of the whole batch on one
+ *                           device to the order of summation (relative 1e-13): launch shapes -- the number of sample chunks per
+ *                           component, which sets the order in which the entropy partials are added -- are chosen for the restarts a
+ *                           device actually holds, which is what strong scaling needs (8 restarts per device want other chunks than
+ *                           64).  Where the two launches coincide (small batches: every test shape of tests/test_gpu_comm.py) the
+ *                           values are bit-identical.  All RANKS of one call always see the identical gathered vectors, hence the
+ *                           identical sieve order.  eps_mode 0, or one shared host block of draws (eps_mode 1 with eps_shared).
  * Errors of these calls are reported by vbmc_comm_last_error.
  */
 typedef struct vbmc_comm vbmc_comm;
@@ -344,6 +349,16 @@ vbmc_status vbmc_gp_upload_all(vbmc_comm* comm, int N, int D, int S, int Nhyp, i
                                const uint8_t* Lchol, vbmc_gp** gps);
 void vbmc_gp_free_all(vbmc_comm* comm, vbmc_gp** gps);
 vbmc_status vbmc_elbo_batch_multi(vbmc_comm* comm, const vbmc_gp* const* gps, const vbmc_elbo_args* args);
+/* The pipelined form of vbmc_elbo_batch_multi for streams of INDEPENDENT batches (the candidates of misc/vpsieve_vbmc.m:74-78), as
+ * vbmc_elbo_submit / vbmc_elbo_collect are for one device: submit stages this process's restarts, enqueues the passes, the one
+ * ncclAllGather and the copy of the gathered vectors to pinned host memory and returns; collect waits and fills the caller's arrays
+ * (same contents as vbmc_elbo_batch_multi).  slot = 0 or 1: two batches in flight.  Device RNG (eps_mode 0), no per-component or
+ * per-hyper-sample outputs.  A steady-state call allocates nothing: the per-device argument structs, staging vectors, exchange
+ * blocks and the pinned landing block live in the communicator's slot.  A failure local to one rank (resource error, missing
+ * surrogate) is reported AFTER the rank has entered the collective with an all-NaN block, so that the other ranks are never left
+ * waiting (vbmc_elbo_batch_multi does the same). */
+vbmc_status vbmc_elbo_multi_submit(vbmc_comm* comm, const vbmc_gp* const* gps, const vbmc_elbo_args* args, int slot);
+vbmc_status vbmc_elbo_multi_collect(vbmc_comm* comm, const vbmc_elbo_args* args, int slot);
 
 /*
  * [x,f,xtab,ftab,iter] = fminadam(@(t) negelcbo_vbmc(t,beta,vp,gp,Ns,1,compute_var,~,thetabnd), x0, [], [],

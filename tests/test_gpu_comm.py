@@ -103,6 +103,92 @@ def test_one_rank_communicator_is_bit_identical(va):
     comm.close()
 
 
+def test_pipelined_multi_equals_the_blocking_call(va):
+    """vbmc_elbo_multi_submit / vbmc_elbo_multi_collect (Comm.prepare): two batches in flight through a one-rank communicator give,
+    batch for batch, the bits of the blocking vbmc_elbo_batch_multi and of the one-device vbmc_elbo_batch; a second submit into a busy
+    slot and a collect of an empty one are refused by name."""
+    from vbmc_amd.multi import Comm
+    from vbmc_amd._lib import VbmcHipError
+
+    comm = Comm.create_all(1)
+    gp, vp, Th = setup(14, 5, 40, 6, 3, 10)
+    gps = comm.upload_gp(gp)
+    T, Rn = Th.shape
+    po = comm.prepare(T, Rn, 0, vp, gps, 48)
+    batches = [np.asfortranarray(Th + 0.01 * i) for i in range(5)]
+    refs = [va.negelcbo_batch(b, 0, vp, gp, 48, True, 0, seed=100 + i) for i, b in enumerate(batches)]
+    got, pend = [], []
+    for i, b in enumerate(batches):
+        po.submit(b, seed=100 + i, slot=i & 1)
+        pend.append(i & 1)
+        if len(pend) == 2:
+            F, dF = po.collect(pend.pop(0))
+            got.append((F.copy(), dF.copy()))
+    while pend:
+        F, dF = po.collect(pend.pop(0))
+        got.append((F.copy(), dF.copy()))
+    for (F, dF), ref in zip(got, refs):
+        assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])
+    F, dF = po(batches[2], seed=102)                       # the blocking form of the same prepared objective
+    assert np.array_equal(F, refs[2]["F"]) and np.array_equal(dF, refs[2]["dF"])
+    po.submit(batches[0], seed=1, slot=0)
+    with pytest.raises(VbmcHipError, match="holds an uncollected"):
+        po.submit(batches[1], seed=2, slot=0)
+    po.collect(0)
+    with pytest.raises(VbmcHipError, match="nothing submitted"):
+        po.collect(1)
+    comm.free_gp(gps)
+    comm.close()
+
+
+def test_dealt_shares_at_a_shape_where_the_launches_differ(va):
+    """A batch large enough that the share of one of G = 8 ranks is launched differently from the undivided batch (the number of sample
+    chunks per component follows the restarts a device holds: strong scaling wants that).  Every rank still evaluates the estimator of
+    the undivided batch sample for sample, so the values agree to the order of summation -- 1e-12 here, against the 1e-6 the path
+    promises -- and the sieve order of well-separated candidates is the same."""
+    from vbmc_amd.elbo import _build_args, default_engine
+    from vbmc_amd._lib import ptr
+
+    gp, vp, Th = setup(15, 10, 60, 50, 4, 64)
+    eng = default_engine()
+    Ns = 2000
+    whole = va.negelcbo_batch(Th, 0, vp, gp, Ns, True, 0, seed=31)
+    G = 8
+    F_all = np.empty(Th.shape[1])
+    worst = 0.0
+    for g in range(G):
+        cols = np.arange(Th.shape[1])[g::G]
+        sub = np.asfortranarray(Th[:, cols])
+        a, keep, _ = _build_args(sub, 0, vp, gp, Ns, True, 0, None, False, None, None, False, 31, eng)
+        a.restart_offset, a.restart_stride = g, G
+        F = np.empty(cols.size); dF = np.empty((Th.shape[0], cols.size), order="F")
+        a.F, a.dF = ptr(F), ptr(dF)
+        eng.ctx.check(eng.ctx.lib.vbmc_elbo_batch(eng.ctx.h, eng.device_gp(gp).h, C.byref(a)))
+        F_all[cols] = F
+        worst = max(worst, float(np.max(np.abs(F - whole["F"][cols]) / np.maximum(1.0, np.abs(whole["F"][cols])))),
+                    float(np.max(np.abs(dF - whole["dF"][:, cols])) / max(1.0, float(np.max(np.abs(whole["dF"]))))))
+    assert worst < 1e-12, worst
+    assert np.array_equal(np.argsort(F_all, kind="stable"), np.argsort(whole["F"], kind="stable"))
+
+
+def test_a_host_without_rccl_reports_instead_of_crashing():
+    """with librccl unloadable every communicator entry point must return VBMC_ERR_HIP with a message (the first version built
+    the message from two dlerror() calls, the second of which returns NULL).  A fresh process, RCCL disabled by the test hook."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from vbmc_amd.multi import Comm\n"
+            "from vbmc_amd._lib import VbmcHipError\n"
+            "for f in (lambda: Comm.create_all(1), Comm.unique_id):\n"
+            "    try:\n        f(); print('NO ERROR')\n    except VbmcHipError as e:\n        print('refused:', e)\n") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VBMC_RCCL_DISABLE="1"), capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    assert r.stdout.count("refused:") == 2 and "NO ERROR" not in r.stdout, r.stdout
+
+
 def test_rank_form_with_a_unique_id(va):
     """ncclGetUniqueId + ncclCommInitRank (the one-process-per-GPU form bench.py uses), world 1 on this box, on the default
     engine's own context."""

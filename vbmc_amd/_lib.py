@@ -141,6 +141,8 @@ def load():
     lib.vbmc_gp_free_all.argtypes = [vp, vpp]
     lib.vbmc_gp_free_all.restype = None
     lib.vbmc_elbo_batch_multi.argtypes = [vp, vpp, C.POINTER(ElboArgs)]
+    lib.vbmc_elbo_multi_submit.argtypes = [vp, vpp, C.POINTER(ElboArgs), C.c_int]
+    lib.vbmc_elbo_multi_collect.argtypes = [vp, C.POINTER(ElboArgs), C.c_int]
     for name in DECLARED_OPTIONAL:
         if hasattr(lib, name):
             pass

@@ -37,6 +37,9 @@ RcclApi* rccl_api(std::string& err) {
   if (api.handle) return &api;
   if (tried) { err = "librccl could not be loaded"; return nullptr; }
   tried = true;
+  if (const char* f = getenv("VBMC_RCCL_DISABLE")) {   // tests: a host without librccl (every comm entry point must report, not crash)
+    if (f[0] == '1') { err = "dlopen(librccl): disabled by VBMC_RCCL_DISABLE"; return nullptr; }
+  }
   // a copy this process holds already (PyTorch's) first, then ROCm's
   const char* held[] = {"librccl.so.1", "librccl.so"};
   for (const char* n : held)
@@ -44,7 +47,11 @@ RcclApi* rccl_api(std::string& err) {
   const char* fresh[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
   for (const char* n : fresh)
     if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-  if (!api.handle) { err = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return nullptr; }
+  if (!api.handle) {
+    const char* e = dlerror();      // once: the call returns the message AND clears it
+    err = std::string("dlopen(librccl): ") + (e ? e : "not found");
+    return nullptr;
+  }
 #define VB_SYM(name)                                                      \
   api.name = (decltype(api.name))dlsym(api.handle, "nccl" #name);         \
   if (!api.name) { err = "librccl lacks nccl" #name; api.handle = nullptr; return nullptr; }
@@ -67,6 +74,20 @@ struct vbmc_comm {
   size_t cap = 0;
   RcclApi* api = nullptr;
   std::string err;
+  // pipelined form (vbmc_elbo_multi_submit / _collect): per slot its own exchange blocks, a pinned landing block for the gathered
+  // vectors and what collect needs to know about the submitted batch
+  struct Slot {
+    bool busy = false;
+    int R = 0, T = 0, P = 0;
+    std::vector<int> n;                       // restarts of local device i in the submitted batch
+    std::vector<vbmc_status> st;              // ... and how its submit went
+    std::vector<std::vector<double>> theta;   // its columns of theta, gathered (capacity kept between calls)
+    std::vector<vbmc_elbo_args> sub;
+    std::vector<double*> d_send, d_recv;
+    size_t cap = 0;
+    double* h_gather = nullptr;
+    size_t h_cap = 0;
+  } slot[2];
 };
 
 static vbmc_status comm_err(vbmc_comm* c, vbmc_status st, const char* fmt, ...) {
@@ -118,8 +139,14 @@ extern "C" void vbmc_comm_destroy(vbmc_comm* c) {
     if (i < (int)c->comm.size() && c->comm[i] && c->api) (void)c->api->CommDestroy(c->comm[i]);
     if (c->d_send[i]) (void)hipFree(c->d_send[i]);
     if (c->d_recv[i]) (void)hipFree(c->d_recv[i]);
+    for (auto& sl : c->slot) {
+      if (i < (int)sl.d_send.size() && sl.d_send[i]) (void)hipFree(sl.d_send[i]);
+      if (i < (int)sl.d_recv.size() && sl.d_recv[i]) (void)hipFree(sl.d_recv[i]);
+    }
     if (c->own_ctx && c->ctx[i]) vbmc_ctx_destroy(c->ctx[i]);
   }
+  for (auto& sl : c->slot)
+    if (sl.h_gather) (void)hipHostFree(sl.h_gather);
   delete c;
 }
 
@@ -262,8 +289,12 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
   if (R < 1 || K < 1 || D < 1) return comm_err(c, VBMC_ERR_INVALID, "D, K, R must be positive");
   int T = 0;
   { const int n[4] = {D * K, K, D, K}; for (int g = 0; g < 4; ++g) if (a->optimize[g]) T += n[g]; }
+  if (T > 0 && !a->theta) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_batch_multi: theta is null");
   const int P = (R + G - 1) / G;                    // restarts per rank, padded
   { vbmc_status s_ = comm_reserve(c, 2 * (size_t)P); if (s_) return s_; }
+  // A failure that is local to one rank (a resource error, a missing surrogate) must not leave the other ranks waiting in the
+  // collective: the rank still enters it, contributing an all-NaN block, and reports its error after the exchange.
+  vbmc_status local_fail = VBMC_OK;
 
   struct Local {
     int n = 0, S = 0;
@@ -284,7 +315,12 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
       COMM_HIP(c, hipGetLastError());
       continue;
     }
-    if (!gps[i]) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_batch_multi: no surrogate for local device %d", i);
+    if (!gps[i]) {
+      local_fail = comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_batch_multi: no surrogate for local device %d", i);
+      L.n = 0;
+      hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, 0, P, (size_t)1, (const double*)nullptr, c->d_send[i]);
+      continue;
+    }
     L.S = gps[i]->S;
     L.sub = *a;
     L.sub.R = L.n;
@@ -305,9 +341,10 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
     vbmc_status st = elbo_plan(ctx, gps[i], &L.sub, L.plan);
     if (!st) st = elbo_enqueue(ctx, gps[i], L.plan, a->seed);
     if (st) {
-      comm_err(c, st, "device %d: %s", ctx->device, vbmc_last_error(ctx));
-      for (int j = 0; j <= i; ++j) { (void)hipSetDevice(c->ctx[j]->device); (void)hipStreamSynchronize(c->ctx[j]->stream); }
-      return st;     // (a multi-process caller must make the same call on every rank: a refusal is a function of the args alone)
+      local_fail = comm_err(c, st, "device %d: %s", ctx->device, vbmc_last_error(ctx));
+      L.n = 0;
+      hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, 0, P, (size_t)1, (const double*)nullptr, c->d_send[i]);
+      continue;
     }
     const size_t OS = OUT_HDR + 3 * (size_t)T;
     hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, L.n, P, OS, (const double*)L.plan.d_out, c->d_send[i]);
@@ -315,6 +352,12 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
   }
   // ---- the exchange: [F | varG] of every rank to every rank, on the streams the passes run on
   { vbmc_status s_ = comm_allgather_enqueue(c, c->d_send.data(), c->d_recv.data(), 2 * (size_t)P); if (s_) return s_; }
+  if (local_fail) {
+    const std::string keep = c->err;
+    for (int i = 0; i < c->n; ++i) { (void)hipSetDevice(c->ctx[i]->device); (void)hipStreamSynchronize(c->ctx[i]->stream); }
+    c->err = keep;
+    return local_fail;
+  }
   // ---- results of the local restarts (synchronises each device), then the gathered vectors from local device 0
   for (int i = 0; i < c->n; ++i) {
     Local& L = loc[i];
@@ -343,6 +386,143 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
     const int g = r % G, q = r / G;
     if (a->F) a->F[r] = gathered[(size_t)g * 2 * P + q];
     if (a->varG) a->varG[r] = gathered[(size_t)g * 2 * P + P + q];
+  }
+  return VBMC_OK;
+}
+
+
+// ---- pipelined form: streams of INDEPENDENT batches dealt over the ranks (the sieve's candidates, misc/vpsieve_vbmc.m:74-78;
+// bench.py's N > 1 step).  vbmc_elbo_multi_submit stages this process's restarts, enqueues the passes, the pick of (F, varG), ONE
+// ncclAllGather and the copy of the gathered vectors into pinned memory -- and returns; vbmc_elbo_multi_collect waits for them.
+// Two slots: the host stages batch i + 1 while the devices work on batch i.  Everything a call needs beyond the batch itself (the
+// per-device argument structs, the staging vectors, the exchange blocks, the pinned landing block) lives in the communicator's slot
+// and is sized once: a steady-state call allocates nothing.
+static vbmc_status comm_slot_reserve(vbmc_comm* c, vbmc_comm::Slot& sl, size_t count) {
+  if (sl.d_send.empty()) { sl.d_send.assign(c->n, nullptr); sl.d_recv.assign(c->n, nullptr); }
+  if (count > sl.cap) {
+    const size_t cap = std::max<size_t>(count + count / 2, 256);
+    for (int i = 0; i < c->n; ++i) {
+      COMM_HIP(c, hipSetDevice(c->ctx[i]->device));
+      COMM_HIP(c, hipStreamSynchronize(c->ctx[i]->stream));
+      if (sl.d_send[i]) COMM_HIP(c, hipFree(sl.d_send[i]));
+      if (sl.d_recv[i]) COMM_HIP(c, hipFree(sl.d_recv[i]));
+      sl.d_send[i] = sl.d_recv[i] = nullptr;
+      COMM_HIP(c, hipMalloc((void**)&sl.d_send[i], cap * sizeof(double)));
+      COMM_HIP(c, hipMalloc((void**)&sl.d_recv[i], cap * c->world * sizeof(double)));
+    }
+    sl.cap = cap;
+  }
+  const size_t hneed = count * c->world;
+  if (hneed > sl.h_cap) {
+    if (sl.h_gather) { COMM_HIP(c, hipHostFree(sl.h_gather)); sl.h_gather = nullptr; }
+    COMM_HIP(c, hipHostMalloc((void**)&sl.h_gather, (hneed + hneed / 2) * sizeof(double), hipHostMallocDefault));
+    sl.h_cap = hneed + hneed / 2;
+  }
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const* gps, const vbmc_elbo_args* a, int slot) {
+  if (!c) return VBMC_ERR_INVALID;
+  if (!gps || !a) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: null surrogates / args");
+  if (slot < 0 || slot > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot must be 0 or 1");
+  if (a->struct_size != sizeof(vbmc_elbo_args)) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size (ABI mismatch)");
+  if (a->eps_mode != 0) return comm_err(c, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_multi_submit: device RNG (eps_mode 0) only");
+  if (a->restart_offset != 0 || a->restart_stride > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit deals the restarts itself");
+  vbmc_comm::Slot& sl = c->slot[slot];
+  if (sl.busy) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot %d holds an uncollected batch", slot);
+  const int G = c->world, R = a->R, K = a->K, D = a->D;
+  if (R < 1 || K < 1 || D < 1) return comm_err(c, VBMC_ERR_INVALID, "D, K, R must be positive");
+  int T = 0;
+  { const int n[4] = {D * K, K, D, K}; for (int g = 0; g < 4; ++g) if (a->optimize[g]) T += n[g]; }
+  if (T > 0 && !a->theta) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: theta is null");
+  const int P = (R + G - 1) / G;
+  { vbmc_status s_ = comm_slot_reserve(c, sl, 2 * (size_t)P); if (s_) return s_; }
+  sl.R = R; sl.T = T; sl.P = P;
+  sl.n.assign(c->n, 0); sl.st.assign(c->n, VBMC_OK);
+  if ((int)sl.theta.size() != c->n) { sl.theta.resize(c->n); sl.sub.resize(c->n); }
+  vbmc_status local_fail = VBMC_OK;
+  for (int i = 0; i < c->n; ++i) {
+    const int g = c->rank0 + i;
+    vbmc_ctx* ctx = c->ctx[i];
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    int n = g < R ? (R - g + G - 1) / G : 0;
+    vbmc_status st = VBMC_OK;
+    if (n > 0 && !gps[i]) st = comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: no surrogate for local device %d", i);
+    if (n > 0 && !st) {
+      vbmc_elbo_args& sub = sl.sub[i];
+      sub = *a;
+      sub.R = n;
+      sub.restart_offset = g; sub.restart_stride = G;
+      std::vector<double>& th = sl.theta[i];
+      if (th.size() < (size_t)T * n) th.resize((size_t)T * n);
+      for (int q = 0; q < n; ++q) memcpy(&th[(size_t)q * T], a->theta + (size_t)(g + (size_t)q * G) * T, T * sizeof(double));
+      sub.theta = th.data();
+      st = elbo_submit_core(ctx, gps[i], &sub, slot, "vbmc_elbo_multi_submit");
+      if (st) comm_err(c, st, "device %d: %s", ctx->device, vbmc_last_error(ctx));
+    }
+    if (st) { local_fail = st; n = 0; }      // the rank still enters the collective: an all-NaN block (lock-step with the others)
+    sl.n[i] = n; sl.st[i] = st;
+    const size_t OS = OUT_HDR + 3 * (size_t)T;
+    const double* dout = n > 0 ? (const double*)((const SlotPlan*)ctx->slot_plan[slot])->P.d_out : nullptr;
+    hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, n, P, n > 0 ? OS : (size_t)1, dout, sl.d_send[i]);
+    COMM_HIP(c, hipGetLastError());
+  }
+  const std::string keep = c->err;
+  { vbmc_status s_ = comm_allgather_enqueue(c, sl.d_send.data(), sl.d_recv.data(), 2 * (size_t)P); if (s_) return s_; }
+  COMM_HIP(c, hipSetDevice(c->ctx[0]->device));
+  COMM_HIP(c, hipMemcpyAsync(sl.h_gather, sl.d_recv[0], 2 * (size_t)P * G * sizeof(double), hipMemcpyDeviceToHost, c->ctx[0]->stream));
+  for (int i = 0; i < c->n; ++i) {
+    vbmc_ctx* ctx = c->ctx[i];
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    if (sl.n[i] > 0) {
+      vbmc_status s_ = elbo_submit_mark(ctx, slot, "vbmc_elbo_multi_submit");
+      if (s_) return comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(ctx));
+    }
+  }
+  if (local_fail) {     // the exchange is enqueued (the other ranks are not left waiting); drain and report
+    for (int i = 0; i < c->n; ++i) {
+      (void)hipSetDevice(c->ctx[i]->device);
+      (void)hipStreamSynchronize(c->ctx[i]->stream);
+      c->ctx[i]->slot_busy[slot] = false;
+    }
+    c->err = keep;
+    return local_fail;
+  }
+  sl.busy = true;
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_multi_collect(vbmc_comm* c, const vbmc_elbo_args* a, int slot) {
+  if (!c) return VBMC_ERR_INVALID;
+  if (!a || slot < 0 || slot > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_collect: null args / slot not 0 or 1");
+  vbmc_comm::Slot& sl = c->slot[slot];
+  if (!sl.busy) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_collect: nothing submitted in slot %d", slot);
+  int T = 0;
+  { const int n[4] = {a->D * a->K, a->K, a->D, a->K}; for (int g = 0; g < 4; ++g) if (a->optimize[g]) T += n[g]; }
+  if (a->R != sl.R || T != sl.T) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_collect: args differ from the submitted ones (R, optimize flags)");
+  sl.busy = false;
+  const int G = c->world, R = sl.R, P = sl.P;
+  vbmc_status fail = VBMC_OK;
+  for (int i = 0; i < c->n; ++i) {
+    vbmc_ctx* ctx = c->ctx[i];
+    COMM_HIP(c, hipSetDevice(ctx->device));
+    if (sl.n[i] > 0) {
+      const SlotPlan* sp = nullptr;
+      vbmc_status s_ = elbo_collect_core(ctx, &sl.sub[i], slot, &sp, "vbmc_elbo_multi_collect");
+      if (s_) { fail = comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(ctx)); continue; }
+      vbmc_elbo_args view = *a;            // the caller's arrays; F and varG come from the gathered vectors below
+      view.F = nullptr; view.varG = nullptr;
+      elbo_unpack(sp->P, &view, sp->hout, c->rank0 + i, G);
+    } else {
+      COMM_HIP(c, hipStreamSynchronize(ctx->stream));     // a device without restarts still took part in the exchange
+    }
+  }
+  if (c->n > 0 && sl.n[0] == 0) COMM_HIP(c, hipStreamSynchronize(c->ctx[0]->stream));
+  if (fail) return fail;
+  for (int r = 0; r < R; ++r) {
+    const int g = r % G, q = r / G;
+    if (a->F) a->F[r] = sl.h_gather[(size_t)g * 2 * P + q];
+    if (a->varG) a->varG[r] = sl.h_gather[(size_t)g * 2 * P + P + q];
   }
   return VBMC_OK;
 }

@@ -1067,21 +1067,23 @@ static vbmc_status elbo_enqueue_readback(vbmc_ctx* ctx, const ElboPlan& P, const
   return VBMC_OK;
 }
 
-// ... and, once it has landed, its unpacking into the caller's arrays
-static void elbo_unpack(const ElboPlan& P, const vbmc_elbo_args* a, const double* hout) {
+// ... and, once it has landed, its unpacking into the caller's arrays (restart q of the pass is column col0 + q * cstride there:
+// 0, 1 for a batch of its own; g, G for the share of rank g of a batch dealt over G ranks)
+static void elbo_unpack(const ElboPlan& P, const vbmc_elbo_args* a, const double* hout, int col0 = 0, int cstride = 1) {
   const int R = P.dm.R, T = P.dm.T;
   const size_t OS = OUT_HDR + 3 * (size_t)T;
-  for (int r = 0; r < R; ++r) {
-    const double* o = hout + (size_t)r * OS;
+  for (int q = 0; q < R; ++q) {
+    const double* o = hout + (size_t)q * OS;
+    const size_t r = (size_t)col0 + (size_t)q * cstride;
     if (a->F) a->F[r] = o[0];
     if (a->G) a->G[r] = o[1];
     if (a->H) a->H[r] = o[2];
     if (a->varG) a->varG[r] = o[3];
     if (a->varGss) a->varGss[r] = o[4];
     if (P.compute_grad) {
-      if (a->dF) memcpy(a->dF + (size_t)r * T, o + OUT_HDR, T * sizeof(double));
-      if (a->dG) memcpy(a->dG + (size_t)r * T, o + OUT_HDR + T, T * sizeof(double));
-      if (a->dH) memcpy(a->dH + (size_t)r * T, o + OUT_HDR + 2 * T, T * sizeof(double));
+      if (a->dF) memcpy(a->dF + r * T, o + OUT_HDR, T * sizeof(double));
+      if (a->dG) memcpy(a->dG + r * T, o + OUT_HDR + T, T * sizeof(double));
+      if (a->dH) memcpy(a->dH + r * T, o + OUT_HDR + 2 * T, T * sizeof(double));
     }
   }
 }
@@ -1187,17 +1189,18 @@ struct SlotPlan {
 };
 static void elbo_plan_free(void* plan) { delete (SlotPlan*)plan; }
 
-extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot) {
-  if (!ctx) return VBMC_ERR_INVALID;
-  if (!a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: null args");
-  if (slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slot must be 0 or 1");
-  if (ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slot %d holds an uncollected pass", slot);
+// stage + enqueue + read-back of one batch into `slot` of the context, WITHOUT the event that marks its end (the caller may append work
+// of its own to the stream first: the exchange of vbmc_elbo_multi_submit)
+static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot, const char* who) {
+  if (!a) return set_err(ctx, VBMC_ERR_INVALID, "%s: null args", who);
+  if (slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot must be 0 or 1", who);
+  if (ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot %d holds an uncollected pass", who, slot);
   if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_submit: per-component / per-hyper-sample outputs only through vbmc_elbo_batch");
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "%s: per-component / per-hyper-sample outputs only through vbmc_elbo_batch", who);
   if (a->eps_mode == 1)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_submit: host-resident draws (eps_mode 1) only through vbmc_elbo_batch");
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "%s: host-resident draws (eps_mode 1) only through vbmc_elbo_batch", who);
   if (!gp) {
-    if (a->compute_var != 0) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: an entropy-only call (gp == NULL) has no variance");
+    if (a->compute_var != 0) return set_err(ctx, VBMC_ERR_INVALID, "%s: an entropy-only call (gp == NULL) has no variance", who);
     vbmc_status s_ = null_gp_for(ctx, a->D, &gp);
     if (s_) return s_;
   }
@@ -1218,31 +1221,49 @@ extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const 
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
   if (s_) { (void)hipStreamSynchronize(ctx->stream); return s_; }   // nothing of a failed submit stays in flight
+  return VBMC_OK;
+}
+// ... and the event: the slot is busy from here on
+static vbmc_status elbo_submit_mark(vbmc_ctx* ctx, int slot, const char* who) {
   ctx->slot_busy[slot] = true;
   hipError_t e_ = hipEventRecord(ctx->slot_ev[slot], ctx->stream);
   if (e_ != hipSuccess) {   // the pass is enqueued but cannot be waited for through the event: drain it and give the slot back
     (void)hipGetLastError();
     (void)hipStreamSynchronize(ctx->stream);
     ctx->slot_busy[slot] = false;
-    return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_submit: hipEventRecord: %s", hipGetErrorString(e_));
+    return set_err(ctx, VBMC_ERR_HIP, "%s: hipEventRecord: %s", who, hipGetErrorString(e_));
   }
   return VBMC_OK;
 }
 
-extern "C" vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot) {
+extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot) {
   if (!ctx) return VBMC_ERR_INVALID;
-  if (!a || slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: null args / slot not 0 or 1");
-  if (!ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: nothing submitted in slot %d", slot);
+  { vbmc_status s_ = elbo_submit_core(ctx, gp, a, slot, "vbmc_elbo_submit"); if (s_) return s_; }
+  return elbo_submit_mark(ctx, slot, "vbmc_elbo_submit");
+}
+
+// waits for the pass submitted in `slot`; *sp_out: its plan and the pinned block its results landed in
+static vbmc_status elbo_collect_core(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, const SlotPlan** sp_out, const char* who) {
+  if (!a || slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "%s: null args / slot not 0 or 1", who);
+  if (!ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "%s: nothing submitted in slot %d", who, slot);
   const SlotPlan* sp = (const SlotPlan*)ctx->slot_plan[slot];
   // elbo_unpack copies T = plan.T doubles per restart into the caller's arrays: the layout must be the submitted one
   int T_now = 0;
   { const int n[4] = {a->D * a->K, a->K, a->D, a->K}; for (int g = 0; g < 4; ++g) if (a->optimize[g]) T_now += n[g]; }
   if (a->D != sp->P.dm.D || a->K != sp->P.dm.K || a->R != sp->P.dm.R || T_now != sp->P.dm.T ||
       (a->compute_grad ? 1 : 0) != sp->P.compute_grad)
-    return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: args differ from the submitted ones (D, K, R, optimize flags, compute_grad)");
+    return set_err(ctx, VBMC_ERR_INVALID, "%s: args differ from the submitted ones (D, K, R, optimize flags, compute_grad)", who);
   ctx->slot_busy[slot] = false;
   hipError_t e_ = hipEventSynchronize(ctx->slot_ev[slot]);
-  if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_collect: %s", hipGetErrorString(e_)); }
+  if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "%s: %s", who, hipGetErrorString(e_)); }
+  *sp_out = sp;
+  return VBMC_OK;
+}
+
+extern "C" vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  const SlotPlan* sp = nullptr;
+  { vbmc_status s_ = elbo_collect_core(ctx, a, slot, &sp, "vbmc_elbo_collect"); if (s_) return s_; }
   elbo_unpack(sp->P, a, sp->hout);
   return VBMC_OK;
 }

@@ -8,8 +8,13 @@ points a MATLAB host binds through matlab/vbmc_hip_mex.cpp ('comm_open', 'elbo_b
     gps = comm.upload_gp(gp)                  # a replica of the surrogate on every local device
     out = comm.negelcbo_batch(thetas, 0, vp, gps, Ns, ...)    # the R restarts dealt r = g (mod G); F / varG all-gathered
 
-The restart axis (misc/vpsieve_vbmc.m:74-78, misc/vpoptimize_vbmc.m:49) is the one the path shards over; every value
-is bit-identical to the one-GPU batch (tests/test_gpu_comm.py)."""
+    po = comm.prepare(T, R, 0, vp, gps, Ns)   # the same objective with everything resolved once; po(thetas, seed) blocks,
+    po.submit(thetas, seed, slot); F, dF = po.collect(slot)   # ... or two batches in flight (vbmc_elbo_multi_submit / _collect)
+
+The restart axis (misc/vpsieve_vbmc.m:74-78, misc/vpoptimize_vbmc.m:49) is the one the path shards over.  Every rank
+evaluates the estimator the one-GPU batch evaluates, sample for sample (the device stream of a restart is keyed by its index in the
+undivided batch); the values agree with the one-GPU batch to the order of summation (1e-13) -- bit for bit where the per-device
+launch shapes coincide, as in every shape of tests/test_gpu_comm.py -- and all ranks of a call see the identical vectors."""
 from __future__ import annotations
 
 import ctypes as C
@@ -153,3 +158,54 @@ class Comm:
                 a.J_sjk = buf("J_sjk", (S, K, K, R))
         self.check(self.lib.vbmc_elbo_batch_multi(self.h, gps, C.byref(a)))
         return out
+
+
+    def prepare(self, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None):
+        """The batched objective for a stream of batches of the same shape, resolved once (PreparedMulti)."""
+        return PreparedMulti(self, T, R, beta, vp, gps, Ns, compute_var, thetabnd)
+
+
+class PreparedMulti:
+    """negelcbo_vbmc(theta, beta, vp, gp, Ns, 1, compute_var, 0, thetabnd) for batches (T, R) dealt over the communicator's ranks
+    (the multi-GPU sibling of vbmc_amd.elbo.PreparedObjective): the argument struct, the fixed vp groups, the bounds and the output
+    buffers are built once; a call copies the new thetas into place.  __call__ blocks (vbmc_elbo_batch_multi); submit / collect keep
+    two batches in flight (vbmc_elbo_multi_submit / vbmc_elbo_multi_collect): F of ALL R restarts, dF of the restarts this process
+    evaluated (NaN elsewhere)."""
+
+    def __init__(self, comm, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None):
+        self.comm, self.gps = comm, gps
+        self.theta = np.zeros((T, R), order="F")
+        self.args, self._keep, _ = _build_args(self.theta, beta, vp, None, Ns, True, compute_var, thetabnd, False, None, None, False, 0, None)
+        self._slots = {}
+        self.F, self.dF = self._buffers(self.args)
+
+    def _buffers(self, a):
+        T, R = self.theta.shape
+        F = np.full(R, np.nan)
+        dF = np.full((T, R), np.nan, order="F")
+        a.F, a.dF = ptr(F), ptr(dF)
+        return F, dF
+
+    def _slot(self, slot):
+        if slot not in self._slots:
+            a = type(self.args).from_buffer_copy(self.args)
+            F, dF = self._buffers(a)
+            self._slots[slot] = (a, F, dF)
+        return self._slots[slot]
+
+    def __call__(self, thetas, seed=0):
+        np.copyto(self.theta, np.asarray(thetas, dtype=np.float64).reshape(self.theta.shape, order="F"))
+        self.args.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.comm.check(self.comm.lib.vbmc_elbo_batch_multi(self.comm.h, self.gps, C.byref(self.args)))
+        return self.F, self.dF
+
+    def submit(self, thetas, seed=0, slot=0):
+        a, _, _ = self._slot(slot)
+        np.copyto(self.theta, np.asarray(thetas, dtype=np.float64).reshape(self.theta.shape, order="F"))   # copied by the library before it returns
+        a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.comm.check(self.comm.lib.vbmc_elbo_multi_submit(self.comm.h, self.gps, C.byref(a), int(slot)))
+
+    def collect(self, slot=0):
+        a, F, dF = self._slot(slot)
+        self.comm.check(self.comm.lib.vbmc_elbo_multi_collect(self.comm.h, C.byref(a), int(slot)))
+        return F, dF
