@@ -60,7 +60,9 @@ def test_headline_translation_unit_compiles_cold_on_the_target_and_runs(tmp_path
                      "vgpr_spill": g(r"\.vgpr_spill_count"), "lds": g(r"\.group_segment_fixed_size")}
     assert found, "headline instantiation k_entropy_mfma<3,3,true,false,1,1> not in the fresh object"
     assert found["vgpr"] <= 256 and found["agpr"] == 0 and found["scratch"] == 0 and found["vgpr_spill"] == 0, found
-    assert found["vgpr"] == 234, found                    # DESIGN.md section 4 / profiles/isa_meta_qs3.txt (round 4; 252 through round 3)
+    # the figure DESIGN.md section 4 quotes is the one committed in profiles/isa_meta_qs3.txt (tools/isa_meta.py): the cold build must give it
+    meta_line = [ln for ln in open(os.path.join(ROOT, "profiles", "isa_meta_qs3.txt")) if ln.startswith("KT=3+tail grad=1 sparse=0 HV=1:")][0]
+    assert found["vgpr"] == int(re.search(r"vgpr (\d+)", meta_line).group(1)), (found, meta_line)
     # a library with the fresh object in place of the shipped one
     objs = [os.path.join(OBJ, "vbmc_hip.o")] + [obj if q == 3 else os.path.join(OBJ, "ent_mfma_qs%d.o" % q) for q in range(1, 10)]
     lib = str(tmp_path / "libvbmc_hip_cold.so")

@@ -16,10 +16,8 @@ OBJ = os.path.join(ROOT, "vbmc_amd", "lib", "obj")
 # name -> (compile flags, [environment settings to time it under])
 VARIANTS = {
     "head": (["@HEAD"], [{}]),     # git HEAD's entropy translation unit (tools/r4_experiments.py build: from /tmp/head_src)
-    "nous": (["-DVBMC_RNG_INLINE", "-DVBMC_NO_US"], [{}]),
-    "us": (["-DVBMC_RNG_INLINE"], [{}]),
-    "us_pv1": (["-DVBMC_RNG_INLINE", "-DVBMC_TUNE_PV1"], [{}]),
-    "us_quad": (["-DVBMC_RNG_INLINE", "-DVBMC_EXP_QUAD"], [{}]),
+    "noepf": (["-DVBMC_NO_EPF"], [{}]),
+    "epf": ([], [{}]),
 }
 
 
@@ -48,6 +46,11 @@ def one(R, Ns, dump):
     sys.path.insert(0, ROOT)
     import numpy as np
 
+    if os.environ.get("EXP_EPS") == "1":
+        import torch                       # before the library: the two HIP runtimes must come up in this order (as in bench.py)
+
+        torch.cuda.init()
+
     import vbmc_amd
     from bench import synth_inputs
 
@@ -69,7 +72,23 @@ def one(R, Ns, dump):
     for i in range(10):
         vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=10 + i, engine=eng, outputs=("F",))
         ms.append(eng.ctx.last_kernel_ms()[0])
-    print(json.dumps({"ms": float(np.median(ms)), "min": float(np.min(ms))}))
+    res = {"ms": float(np.median(ms)), "min": float(np.min(ms))}
+    if os.environ.get("EXP_EPS") == "1":      # parity mode too: every restart its own block of draws, resident on the device
+        import torch
+
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(1)
+        eps_d = torch.randn((R, K, (Ns + 1) // 2, D), dtype=torch.float64, device="cuda:0", generator=g)
+        torch.cuda.synchronize()
+        kw = dict(eps_device_ptr=eps_d.data_ptr(), eps_shared=False, engine=eng, outputs=("F",))
+        for _ in range(2):
+            vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, **kw)
+        ms2 = []
+        for i in range(8):
+            vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, **kw)
+            ms2.append(eng.ctx.last_kernel_ms()[0])
+        res["eps_ms"] = float(np.median(ms2))
+    print(json.dumps(res))
 
 
 def run(R, Ns):
@@ -104,7 +123,8 @@ def run(R, Ns):
         if ms is None:
             print("%-28s FAILED %s" % (tag, note))
         else:
-            print("%-28s %.3f ms (min %.3f) %+6.1f %%   %s" % (tag, ms["ms"], ms["min"], 100 * (ms["ms"] - base) / base if base else 0.0, note))
+            print("%-28s %.3f ms (min %.3f) %+6.1f %%   %s%s" % (tag, ms["ms"], ms["min"], 100 * (ms["ms"] - base) / base if base else 0.0, note,
+                                                             ("   eps-from-memory %.3f ms" % ms["eps_ms"]) if "eps_ms" in ms else ""))
 
 
 if __name__ == "__main__":

@@ -868,9 +868,16 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     LAUNCH_CHECK(ctx, "k_lj_reduce");
     return VBMC_OK;
   };
+  // A/B (round 4): VBMC_LJ_FIRST=1 queues the log joint on the auxiliary stream BEFORE the entropy kernel is queued on the main one
+  static const bool lj_first = [] { const char* e = getenv("VBMC_LJ_FIRST"); return e && !strcmp(e, "1"); }();
   if (fork) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    if (lj_first) {
+      vbmc_status s_ = enqueue_logjoint(ctx->aux);
+      if (s_) return s_;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    }
   } else if (sh.mode != 2) {
     vbmc_status s_ = enqueue_logjoint(st);
     if (s_) return s_;
@@ -945,9 +952,11 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   }
 
   if (fork) {   // the entropy kernel is already queued on the main stream: the log joint fills in around it
-    vbmc_status s_ = enqueue_logjoint(ctx->aux);
-    if (s_) return s_;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    if (!lj_first) {
+      vbmc_status s_ = enqueue_logjoint(ctx->aux);
+      if (s_) return s_;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    }
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   }
 

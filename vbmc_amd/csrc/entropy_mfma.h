@@ -406,6 +406,26 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   const int t0 = (c + a.c0) * a.tiles_per_chunk;
   const int t1 = min(t0 + a.tiles_per_chunk, ntile);
   const double* epsr = a.eps ? a.eps + (size_t)r * a.eps_stride_r + (size_t)j * a.Mh * D : nullptr;
+  // Parity mode (draws from memory: ent/entmc_vbmc.m:53-55 with the caller's randn stream): the tile of draws is loaded ONE TILE AHEAD
+  // into QS registers per lane (round 4) -- issued right after the current tile went to LDS, waited for at the next tile's start, a whole
+  // tile of arithmetic later -- instead of a load-and-wait at the head of every tile.  Where the registers are there (EPF); the same
+  // kernel serves the device-RNG mode, so the registers are spent in both.
+#ifdef VBMC_NO_EPF
+  constexpr bool EPF = false;
+#else
+  constexpr bool EPF = HV == 1 && QS <= 4 && KT <= 3 && !SPARSE;
+#endif
+  double epre[EPF ? QS : 1];
+  auto eps_fetch = [&](const int tile) {
+#pragma unroll
+    for (int u = 0; u < (EPF ? QS : 0); ++u) {
+      const int idx = lane + u * WAVE, i = idx / DP, d = idx - i * DP;     // (16 DP = 64 QS slots: every lane has exactly QS)
+      double v = 0.0;
+      if (tile < t1 && d < D && tile * 16 + i < a.Mh) v = epsr[(size_t)(tile * 16 + i) * D + d];
+      epre[u] = v;
+    }
+  };
+  if (EPF && epsr) eps_fetch(t0);
 
   // The tile body, compiled twice where it pays (VBMC_ENT_SPLIT): once for the full tiles -- no sample-validity selects at all: a
   // v_cndmask_b32 costs four fp64 operations on this chip (tools/valu_rate.hip), and written as rare uniform branches inside one body
@@ -418,6 +438,10 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     ent_sync_wg<HV>();
     if (HV > 1 && hv != 0) {
       // wave 0 stages (and, in device-RNG mode, draws) the tile for both
+    } else if (EPF && epsr) {
+#pragma unroll
+      for (int u = 0; u < (EPF ? QS : 0); ++u) Et[lane + u * WAVE] = US ? sigj * epre[u] : epre[u];
+      eps_fetch(tile + 1);
     } else if (epsr) {
       for (int idx = lane; idx < 16 * DP; idx += WAVE) {
         const int i = idx / DP, d = idx - i * DP;
