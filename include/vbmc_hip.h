@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VBMC_ABI_VERSION 3
+#define VBMC_ABI_VERSION 4
 
 typedef int vbmc_status;
 enum {
@@ -251,6 +251,9 @@ typedef struct vbmc_elbo_args {
                              /* bounds (bnd_lb NULL), no variance gradient.  0 (default): the transformed gradients negelcbo uses   */
   double* dvarG;             /* T x R  gradient of the diagonal variance of the expected log joint, gplogjoint's 4th output     */
                              /* (compute_var = 2 with compute_grad; misc/gplogjoint.m:375-413), or NULL                          */
+  double* dG_s;              /* T x S x R  gradient of the expected log joint PER hyper-sample: gplogjoint's dF with avg_flag = 0  */
+                             /* (misc/gplogjoint.m:206-271 per s, Jacobians :352-373, the averaging of :411 skipped); needs      */
+                             /* compute_grad; honours no_jacobian.  ABI version 4.  NULL: not wanted                               */
 } vbmc_elbo_args;
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);

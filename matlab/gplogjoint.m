@@ -3,10 +3,11 @@ function [F,dF,varF,dvarF,varss,I_sk,J_sjk] = gplogjoint(vp,gp,grad_flags,avg_fl
 %
 % Same signature and defaulting as the reference (misc/gplogjoint.m:1-30).  Accelerated: (a) averaged over
 % hyper-parameter samples (AVG_FLAG = 1) with Jacobian-transformed or (JACOBIAN_FLAG = 0) untransformed gradients for exactly the
-% parameter groups VP optimises; (b) per-hyper-sample values WITHOUT gradients (AVG_FLAG = 0: F and VARF are
-% 1-by-Ns, VARSS = 0) -- the forms private/activesample_vbmc.m:155 ([~,~,varF] = gplogjoint(vp,gp,0,0,0,1)) and
+% parameter groups VP optimises; (b) per-hyper-sample values (AVG_FLAG = 0: F and VARF are 1-by-Ns, DF is T-by-Ns, VARSS = 0) --
+% the forms private/activesample_vbmc.m:155 ([~,~,varF] = gplogjoint(vp,gp,0,0,0,1)) and
 % misc/vpoptimizeweights_vbmc.m:42 ([~,~,~,~,~,I_sk,J_sjk] = gplogjoint(vp,gp,0,0,0,1,1)) use; (c) DVARF, the gradient of the
-% diagonal variance (COMPUTE_VAR = 2, with the Jacobians).  Other call forms go to the reference further down the path.
+% diagonal variance (COMPUTE_VAR = 2, with the Jacobians, averaged form); (d) per-component outputs together with gradients (two
+% passes).  Other call forms go to the reference further down the path.
 if nargin < 3; grad_flags = []; end
 if nargin < 4 || isempty(avg_flag); avg_flag = true; end
 if nargin < 5 || isempty(jacobian_flag); jacobian_flag = true; end
@@ -22,8 +23,7 @@ if compute_vargrad && compute_var ~= 2
 end
 
 vpflags = [vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambda, vp.optimize_weights];
-supported = (avg_flag || ~any(grad_flags)) && (~compute_vargrad || jacobian_flag) && any(gp.meanfun == [0 1 4]) ...
-    && ~(separate_K && any(grad_flags)) ...
+supported = (avg_flag || ~compute_vargrad) && (~compute_vargrad || jacobian_flag) && any(gp.meanfun == [0 1 4]) ...
     && (~any(grad_flags) || isequal(logical(grad_flags(:)'),logical(vpflags))) ...
     && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) && (~vp.optimize_weights || isfield(vp,'eta'));
 if ~supported
@@ -37,6 +37,8 @@ end
 [theta,vp] = get_vptheta(vp);                  % misc/get_vptheta.m: the rescaled vp, so that theta and the fixed groups agree
 h = vbmc_hip_gp_handle(gp);
 g = any(grad_flags);
+sepK2 = separate_K && g;               % the objective's entry point refuses the combination (negelcbo_vbmc.m:57-59): a pass of its own
+if sepK2; separate_K = false; end
 if avg_flag || numel(gp.post) == 1
     dvarF = [];
     if compute_vargrad
@@ -48,9 +50,17 @@ if avg_flag || numel(gp.post) == 1
     end
     if ~avg_flag; varss = 0; end
 else                                            % misc/gplogjoint.m:398-399: no averaging, varss stays 0
-    [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0, ...
-        double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+    if g
+        [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF,~,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,1, ...
+            double(compute_var),0,0,[],[],0,numel(gp.post),double(~jacobian_flag));
+    else
+        [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0, ...
+            double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
+    end
     varss = 0; dvarF = [];
+end
+if sepK2
+    [~,~,~,~,~,~,~,I_sk,J_sjk] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0,double(compute_var),1,0,[],[],0,numel(gp.post));
 end
 if ~g; dF = []; end
 if ~compute_var; varF = []; varss = []; end

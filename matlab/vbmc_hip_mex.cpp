@@ -8,9 +8,9 @@
 //     vbmc_hip_mex('open', device)                         -> (context kept in a persistent, mexLock'ed)
 //     h  = vbmc_hip_mex('gp_upload', gpstruct)             -> uint64 handle of a device-resident gp.post
 //          vbmc_hip_mex('gp_free', h)
-//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk,dG,G_s,varG_s] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
+//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk,dG,G_s,varG_s,dvarG,dG_s] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
 //                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty, seed, numel(gp.post), no_jacobian)
-//                                     (G_s, varG_s: the per-hyper-sample outputs of gplogjoint(...,avg_flag = 0); no_jacobian,
+//                                     (G_s, varG_s, dG_s (T x S): the per-hyper-sample outputs of gplogjoint(...,avg_flag = 0); no_jacobian,
 //                                     optional: 1 = gradients with respect to sigma, lambda, w themselves, the JACOBIAN_FLAG = 0
 //                                     form of entmc_vbmc / entlb_vbmc / gplogjoint)
 //     [F,dF,varG,G,H,varGss,I_sk,J_sjk] = vbmc_hip_mex('elbo_batch', h, Theta /*T x R*/, vp, Ns, compute_grad, compute_var, beta,
@@ -281,10 +281,16 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     }
     mxArray* dvG = nullptr;         // 13th output: gradient of the diagonal variance (dvarF of misc/gplogjoint.m:27)
     if (nlhs > 12 && a.compute_grad && a.compute_var == 2) { dvG = mxCreateDoubleMatrix(T, 1, mxREAL); a.dvarG = mxGetDoubles(dvG); }
+    mxArray* dGs = nullptr;         // 14th output: the gradient per hyper-sample, T x S (gplogjoint's dF with avg_flag = 0, misc/gplogjoint.m:411 skipped)
+    if (nlhs > 13 && a.compute_grad && nrhs > 12) {
+      const int S = (int)mxGetScalar(prhs[12]);
+      dGs = mxCreateDoubleMatrix(T, S, mxREAL);
+      a.dG_s = mxGetDoubles(dGs);
+    }
     vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
     if (st != VBMC_OK) return fail(st);  // MATLAB frees the mxArrays created above on error
-    mxArray* outs[13] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs, dvG};
-    for (int i = 0; i < 13 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    mxArray* outs[14] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs, dvG, dGs};
+    for (int i = 0; i < 14 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
     return 0;
   }
 

@@ -126,6 +126,11 @@ def test_elbo_with_host_draws_all_twelve_outputs(mex, va):
     rv = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 2, outputs=("F", "dF", "G", "dG", "varG", "dvarG"))
     same(o[4][0, 0], rv["varG"][0]); same(o[12][:, 0], rv["dvarG"][:, 0])
     assert np.max(np.abs(o[12])) > 0
+    # 14th output: the gradient per hyper-sample, T x S (gplogjoint with avg_flag = 0 and grad_flags; round 4)
+    o = mex.call(14, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), 0, 1, 0, 0, 0, None, None, 0, S)
+    rs = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 0, outputs=("G", "dG", "G_s", "dG_s"))
+    same(o[10][0, :], rs["G_s"][:, 0]); same(o[13], rs["dG_s"][:, :, 0])
+    assert o[13].shape == (theta.size, S) and np.max(np.abs(np.mean(o[13], axis=1) - rs["dG"][:, 0])) < 1e-12 * max(1.0, np.max(np.abs(rs["dG"])))
     with pytest.raises(MexError) as e:                            # the Jacobian of the soft bounds is part of the penalty's gradient
         mex.call(2, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 0, 0, 0, tb, eps_m, 0, S, 1)
     assert e.value.identifier in ("vbmc_hip:error", "vbmc_hip:unsupported")

@@ -103,7 +103,7 @@ def test_gplogjoint_variance_and_components(va, cv):
 def test_gplogjoint_refusals(va):
     p, gp, vp = make(8, 3, 20, 4, 2)
     with pytest.raises(va.VbmcUnsupported):
-        va.gplogjoint(vp, gp, True, False, nargout=2)            # avg_flag = 0
+        va.gplogjoint(vp, gp, True, False, True, 2, nargout=4)   # per-hyper-sample variance gradient
     with pytest.raises(va.VbmcUnsupported):
         va.gplogjoint(vp, gp, True, True, False, 2, nargout=4)   # dvarF without the Jacobians
     with pytest.raises(ValueError, match="FullVarianceGradient"):
@@ -176,8 +176,46 @@ def test_gplogjoint_per_hyper_sample_outputs(va, cfg):
         vss = np.var(Fs, ddof=1)
         assert abs(np.mean(vs) + vss - varFa) < 1e-9 * max(1.0, abs(varFa))
         assert abs(vss + np.std(vs, ddof=1) - varss) < 1e-9 * max(1.0, abs(varss))
-    with pytest.raises(va.VbmcUnsupported):
-        va.gplogjoint(vp, gp, 1, 0, 1, 0, nargout=2)    # per-sample gradients: not accelerated, the shim falls through
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+@pytest.mark.parametrize("jac", [True, False])
+def test_gplogjoint_per_hyper_sample_gradients(va, flags, jac):
+    """avg_flag = 0 WITH grad_flags (round 4, vbmc_elbo_args.dG_s): dF is T x S -- the per-sample gradients of misc/gplogjoint.m:206-271 with
+    the Jacobians of :352-373 (or without: jacobian_flag = 0) and the averaging of :411 skipped -- for every grad_flags subset; their mean
+    over the hyper-samples is the averaged call's dF."""
+    p, gp, vp = make(19, 5, 45, 7, 4)
+    ref = R.gplogjoint(vp, gp, flags, False, jac, 0)
+    F, dF = va.gplogjoint(vp, gp, flags, False, jac, nargout=2)
+    assert np.shape(F) == (4,) and relerr(F, ref["F"]) < 1e-10
+    assert dF.shape == np.asarray(ref["dF"]).shape == (dF.shape[0], 4)
+    assert relerr(dF, ref["dF"]) < 1e-9
+    Fa, dFa = va.gplogjoint(vp, gp, flags, True, jac, nargout=2)
+    assert relerr(np.mean(dF, axis=1), dFa) < 1e-12
+    if not jac:
+        return       # (the diagonal variance with a gradient brings the variance gradient's Jacobians along: refused without them)
+    # with the variance: F, varF per sample beside the gradients
+    F2, dF2, varF2 = va.gplogjoint(vp, gp, flags, False, jac, 2, nargout=3)
+    ref2 = R.gplogjoint(vp, gp, flags, False, jac, 2)
+    assert relerr(dF2, ref2["dF"]) < 1e-9 and np.max(np.abs(np.asarray(varF2) - ref2["varF"])) < 1e-7 * max(1.0, np.max(np.abs(ref2["varF"])))
+
+
+@pytest.mark.parametrize("cv", [0, 1, 2])
+def test_gplogjoint_components_together_with_gradients(va, cv):
+    """separate_K WITH grad_flags (round 4): negelcbo_vbmc refuses the combination (misc/negelcbo_vbmc.m:57-59), gplogjoint itself does not
+    (misc/gplogjoint.m:13): F, dF, varF, I_sk, J_sjk of one call against the oracle."""
+    p, gp, vp = make(21, 4, 40, 6, 3)
+    o = R.gplogjoint(vp, gp, (1, 1, 1, 1), True, True, cv, separate_K=True)
+    if cv == 1:      # seven outputs with a gradient ask for dvarF: the full variance has none (misc/gplogjoint.m:27-30)
+        with pytest.raises(ValueError, match="FullVarianceGradient"):
+            va.gplogjoint(vp, gp, (1, 1, 1, 1), True, True, cv, True, nargout=7)
+        return
+    out = va.gplogjoint(vp, gp, (1, 1, 1, 1), True, True, cv, True, nargout=7)
+    assert relerr(out[0], o["F"]) < 1e-10 and relerr(out[1], np.asarray(o["dF"]).reshape(-1)) < 1e-9
+    assert relerr(out[5], o["I_sk"]) < 1e-10
+    if cv:
+        assert relerr(out[2], o["varF"]) < 1e-8
+        assert np.max(np.abs(out[6] - o["J_sjk"])) < 1e-7 * max(1.0, np.max(np.abs(o["J_sjk"])))
 
 
 def test_gplogjoint_per_hyper_sample_outputs_against_mpmath_vectors(va):

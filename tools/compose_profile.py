@@ -18,6 +18,12 @@ from bench import kernel_source_hash  # noqa: E402  (code-only hash: comments an
 tag, changes = sys.argv[1], sys.argv[2]
 o = "gpurun_out/%s/" % tag
 rd = lambda f: open(o + f).read().strip()  # noqa: E731
+
+
+def last_json(txt):
+    """the JSON line of a bench run's stdout (RCCL prints a banner after it when the process exits)"""
+    return [ln for ln in txt.splitlines() if ln.startswith("{")][-1]
+
 pa, pb = rd("pmc_a.md"), rd("pmc_b.md")
 
 
@@ -26,7 +32,7 @@ def grab(txt, kern, ctr):
     return float(re.search(r"- %s = ([0-9.e+]+)" % ctr, seg).group(1))
 
 
-kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1, false>(EntArgs)`"   # the headline instantiation: QS 3, three k-tiles + component tail
+kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1, false"   # the headline instantiation: QS 3, three k-tiles + component tail (round 4: one more template argument follows)
 fetch, write = grab(pa, kern, "FETCH_SIZE"), grab(pb, kern, "WRITE_SIZE")
 hbm = int(round(fetch * 1024 * 2 + write * 1024))
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
@@ -39,13 +45,41 @@ json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_ent
 busy, act = grab(pa, kern, "SQ_VALU_MFMA_BUSY_CYCLES"), grab(pa, kern, "SQ_ACTIVE_INST_VALU")
 n_mfma, n_valu = grab(pa, kern, "SQ_INSTS_MFMA"), grab(pa, kern, "SQ_INSTS_VALU")
 TS = 64 * 50 * 313 * 2.0     # tile-signs per launch at the headline shape: R x K x ceil(5000 / 16) tiles x 2 signs
-b = json.loads(rd("bench.json"))
+b = json.loads(last_json(rd("bench.json")))
 b.update(b.get("aux", {}))   # round 2: the auxiliary legs are nested under "aux"
-bt = json.loads(rd("bench_traced.json").splitlines()[-1])
-aux = json.loads(rd("bench_aux.json"))
+bt = json.loads(last_json(rd("bench_traced.json")))
+aux = json.loads(last_json(rd("bench_aux.json")))
 r = b["roofline"]
 mf, va = busy / 1024 / 2.4e9 * 1e3, act * 4 / 1024 / 2.4e9 * 1e3
 isa = rd("isa_meta.txt") if os.path.exists(o + "isa_meta.txt") else "(not collected)"
+pc = rd("pmc_c.md") if os.path.exists(o + "pmc_c.md") else None
+lane_txt, cfg_txt = "", ""
+if pc:
+    thr, actc = grab(pc, kern, "SQ_THREAD_CYCLES_VALU"), grab(pc, kern, "SQ_ACTIVE_INST_VALU")
+    coex = grab(pc, kern, "SQ_VALU_MFMA_COEXEC_CYCLES")
+    lane_txt = f"""
+## PMC per launch, pass C (round 4: VALU lane utilisation, instruction classes)
+
+{pc}
+
+VALU lane utilisation of the headline kernel = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = {thr:.4g} / (64 x {actc:.4g}) =
+**{thr / (64 * actc):.3f}** (1.0 = every VALU instruction runs with all 64 lanes enabled); MFMA / VALU co-execution
+(`SQ_VALU_MFMA_COEXEC_CYCLES`) {coex:.4g} cycles against {busy:.4g} MFMA-busy cycles.
+"""
+for name, label in (("c1", "BASELINE configs[1]: D=6 N=200 K=10 Ns=1000 S=8, R=64"), ("c4", "BASELINE configs[4]: D=20 N=800 K=100 Ns=20000 S=20, R=16")):
+    if os.path.exists(o + "kernel_trace_%s.md" % name):
+        bl = last_json(rd("bench_%s.json" % name))
+        cfg_txt += f"""
+## {label}: `rocprofv3 --kernel-trace --stats` and one `--pmc` pass of `python bench.py <shape flags> --no-cpu-baseline --no-aux`
+
+```
+{bl[:1500]}
+```
+
+{rd('kernel_trace_%s.md' % name)}
+
+{rd('pmc_%s.md' % name)}
+"""
 txt = f"""# Round {int(RND[1:])}, profile {tag[1:]}
 
 Produced by `bash tools/profile_round.sh {tag}` on the MI355X box (`cd /tmp && export TMPDIR=/tmp` first): full GPU
@@ -66,7 +100,7 @@ which its workgroups were fitted into the entropy kernel's idle slots (alone it 
 ## Bench line of the kernel-trace run
 
 ```
-{rd('bench_traced.json').splitlines()[-1]}
+{last_json(rd('bench_traced.json'))}
 ```
 
 ## Kernel trace (tools/rocpd_summary.py; 28 ELBO launches = 3 warm-up + 20 timed + 5 roofline-leg; k_chol / k_gp_* / k_alpha_solve = the one-off gplite_post that builds the synthetic GP posterior, outside the timed region)
@@ -90,6 +124,7 @@ count (VERDICT r1 asked: 128 there vs 255 claimed); the authoritative figures ar
 
 {pb}
 
+{lane_txt}{cfg_txt}
 ## Other device paths at the C3 GP shape (`tools/bench_aux.py`, wall time per call incl. H2D/D2H)
 
 ```
@@ -123,7 +158,7 @@ count (VERDICT r1 asked: 128 there vs 255 claimed); the authoritative figures ar
 * GP side (`tools/bench_aux.py`): `gplite_post` (S = 20, N = 400) {aux['gplite_post_ms']:.1f} ms; `gplite_pred` 8192 x 20: {aux['gplite_pred_8192_ms']:.2f} ms wall;
   acquisition sweep on 8192 points: `acqf` {aux['acqwrapper_acqf_8192_ms']:.2f} ms, VIQR with 100 importance points {aux['acqwrapper_acqviqr_8192_Na100_ms']:.2f} ms;
   `eval_fullelcbo` {aux['eval_fullelcbo_ms']:.2f} ms; value-only `entlb` sieve of 250 candidates {aux['entlb_sieve_R250_ms']:.2f} ms;
-  `gplite_nlZ`+gradient {aux['nlz_grad_B1_evals_per_s']:.0f} / {aux['nlz_grad_B16_evals_per_s'] / 1e3:.1f} k / {aux['nlz_grad_B64_evals_per_s'] / 1e3:.1f} k / {aux['nlz_grad_B256_evals_per_s'] / 1e3:.1f} k evals/s at B = 1 / 16 / 64 / 256.
+  `gplite_nlZ`+gradient {aux.get('nlz_grad_B1_evals_per_s', 0):.0f} / {aux.get('nlz_grad_B16_evals_per_s', 0) / 1e3:.1f} k / {aux.get('nlz_grad_B64_evals_per_s', 0) / 1e3:.1f} k / {aux.get('nlz_grad_B256_evals_per_s', 0) / 1e3:.1f} k evals/s at B = 1 / 16 / 64 / 256.
 """
 open("profiles/%s_%s_summary.md" % (RND, tag), "w").write(txt)
 print("wrote profiles/%s_%s_summary.md" % (RND, tag), len(txt))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VBMC_HIP_LIB: an alternative build of the SAME library (kernel A/B experiments, tools/ent_experiments.py)
 LIB_PATH = os.environ.get("VBMC_HIP_LIB") or os.path.join(_HERE, "lib", "libvbmc_hip.so")
 
-ABI_VERSION = 3   # include/vbmc_hip.h: VBMC_ABI_VERSION
+ABI_VERSION = 4   # include/vbmc_hip.h: VBMC_ABI_VERSION
 VBMC_OK, VBMC_ERR_INVALID, VBMC_ERR_NO_DEVICE, VBMC_ERR_HIP, VBMC_ERR_UNSUPPORTED, VBMC_ERR_NOT_POSDEF = range(6)
 _STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "UNSUPPORTED", 5: "NOT_POSDEF"}
 
@@ -57,6 +57,7 @@ class ElboArgs(C.Structure):
         ("restart_offset", C.c_int32), ("restart_stride", C.c_int32),
         ("no_jacobian", C.c_int32),
         ("dvarG", _dp),
+        ("dG_s", _dp),
     ]
 
 

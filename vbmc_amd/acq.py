@@ -196,8 +196,8 @@ def _islogf(name, which, vlnpdf, fmu, fs2):
     """acqfun('islogf1' | 'islogf2' | 'islogf', vlnpdf, [], [], fmu, fs2) of the two importance-sampled acquisition functions
     (acq/acqviqr_vbmc.m:13-30, acq/acqimiqr_vbmc.m:12-27): the log base density of the importance sampler, split into the part
     that is fixed per point (1) and the part added per GP hyper-sample (2)."""
-    fs = np.sqrt(fs2)
-    added = _U_IQR * fs + np.log1p(-np.exp(-2 * _U_IQR * fs))
+    fs = np.sqrt(np.maximum(fs2, np.finfo(np.float64).tiny))     # (a degenerate hyper-sample -- fs2 <= 0 by rounding -- degrades to a tiny
+    added = _U_IQR * fs + np.log1p(-np.exp(-2 * _U_IQR * fs))    # density instead of a NaN that aborts the whole set-up)
     if which == "islogf2":
         return added
     fixed = fmu if name == "acqimiqr_vbmc" else (np.zeros_like(fs2) if which == "islogf1" else np.asarray(vlnpdf).reshape(-1, 1))
@@ -245,7 +245,7 @@ def _proposal_lnw(Xa, gp, vp_is, w_vp, rect_delta, name, vp, isamplevp, engine):
 
 
 def gplite_pred_device(gp, Xs, engine):
-    """[~,~,fmu,fs2] = gplite_pred(gp,Xs,[],[],1,0) per hyper-sample (Nstar x S) on the device."""
+    """[ymu,ys2,fmu,fs2] = gplite_pred(gp,Xs,[],[],1,0) per hyper-sample (Nstar x S) on the device."""
     from .gplite import gplite_pred
 
     out = gplite_pred(gp, Xs, None, None, True, False, 4, engine=engine)
@@ -474,12 +474,23 @@ def activeimportancesampling_vbmc(vp, gp, acqFun, acqInfo=None, options=None, *,
             x0[s, i] = np.clip(Xa1[idx], LB, UB)
 
     def logp(P, e):                                                                                   # log_isbasefun :343-353
-        _, _, fm, f2 = gplite_pred_device(gp, P, engine)
+        # (:346 reads the FIRST two outputs of gplite_pred -- ymu, ys2: the predictive variance with the observation noise -- not the
+        # latent fmu, fs2 the proposals above use)
+        fm, f2, _, _ = gplite_pred_device(gp, P, engine)
         r = np.arange(P.shape[0])
         vln = np.maximum(_vbmc_lnpdf(vp, P), np.log(np.finfo(np.float64).tiny)) if isamplevp else None
         v = _islogf(name, "islogf", vln, fm[r, e].reshape(-1, 1), f2[r, e].reshape(-1, 1)).reshape(-1)
         return np.where(np.isfinite(v), v, -np.inf)
 
+    # a walker that starts at zero density (a clipped point, a duplicate drawn after the weights ran out) is replaced by a training input
+    # inside the box -- the sampler would refuse it, and one degenerate hyper-sample must not abort the acquisition set-up
+    lp0 = logp(x0.reshape(S * W, D), np.repeat(np.arange(S), W)).reshape(S, W)
+    inside = X[np.all((X >= LB) & (X <= UB), axis=1)]
+    for s, i in zip(*np.nonzero(~np.isfinite(lp0))):
+        for cand in inside[rng.permutation(inside.shape[0])[:16]]:
+            if np.isfinite(logp(cand[None, :], np.array([s]))[0]):
+                x0[s, i] = cand
+                break
     Xs, lps, info_s = ensemble_slice_sample(logp, x0, Nm, LB, UB, thin=thin, burnin=burnin, rng=rng, return_info=True)
     Xa = np.transpose(Xs, (1, 2, 0)).copy()                       # Na x D x S
     lnw = np.empty((S, Nm))

@@ -552,6 +552,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     if (compute_var == 2) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "the variance gradient without the Jacobians (JACOBIAN_FLAG = 0 with compute_var = 2) is not accelerated");
   }
   if (a->dvarG && !(compute_grad && compute_var == 2)) return set_err(ctx, VBMC_ERR_INVALID, "dvarG needs compute_grad with compute_var = 2");
+  if (a->dG_s && !compute_grad) return set_err(ctx, VBMC_ERR_INVALID, "dG_s (per-hyper-sample gradients) needs compute_grad");
   P.no_jacobian = a->no_jacobian && compute_grad ? 1 : 0;
   P.r0 = a->restart_offset; P.rstride = a->restart_stride > 0 ? a->restart_stride : 1;
   M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
@@ -619,7 +620,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   // (LJ_CO_SPLIT records per hyper-sample where the log joint may run as a role of the entropy launch: small grids only, see elbo_enqueue)
   // (also set when the caller asks for the numbers a SHARDED evaluation gives -- chunk_world: the sharded path adds the log-joint
   // records per hyper-sample, so the unsharded evaluation it is compared with bit for bit must too)
-  P.lj_records = a->separate_K || a->G_s || a->varG_s || compute_var != 0 || chunk_world > 0 || a->chunk_world > 1;
+  P.lj_records = a->separate_K || a->G_s || a->varG_s || a->dG_s || compute_var != 0 || chunk_world > 0 || a->chunk_world > 1;
   const size_t ljrec = (size_t)R * S * K * LJS * (((long long)S * R < ctx->num_cu / 2 && !P.lj_records) ? LJ_CO_SPLIT : 1);
   { vbmc_status s_ = ensure(ctx, ctx->ljpart, (ljrec + (size_t)R * K * LJS) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->out, P.out_n * sizeof(double)); if (s_) return s_; }
@@ -1139,11 +1140,24 @@ static vbmc_status elbo_read_results(vbmc_ctx* ctx, const ElboPlan& P, const vbm
     hipError_t e_ = hipMemcpyAsync(psh.data(), d_ps, psh.size() * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e_ != hipSuccess) { pool_put(ctx, d_ps); return set_err(ctx, VBMC_ERR_HIP, "per-sample read-back: %s", hipGetErrorString(e_)); }
   }
+  std::vector<double> dgsh;
+  double* d_dgs = nullptr;
+  if (a->dG_s) {               // gplogjoint's dF with avg_flag = 0: T x S per restart
+    const size_t n = (size_t)dm.T * S * R;
+    hipError_t e0 = pool_get(ctx, n * sizeof(double), (void**)&d_dgs);
+    if (e0 != hipSuccess) { if (d_ps) pool_put(ctx, d_ps); return set_err(ctx, VBMC_ERR_HIP, "per-sample gradient block: %s", hipGetErrorString(e0)); }
+    hipLaunchKernelGGL(k_per_sample_grad, dim3(S, R), dim3(256), 0, st, dm, P.d_vpd, P.d_lj, P.no_jacobian, d_dgs);
+    dgsh.resize(n);
+    hipError_t e_ = hipMemcpyAsync(dgsh.data(), d_dgs, n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e_ != hipSuccess) { pool_put(ctx, d_dgs); if (d_ps) pool_put(ctx, d_ps); return set_err(ctx, VBMC_ERR_HIP, "per-sample gradient read-back: %s", hipGetErrorString(e_)); }
+  }
   {
     hipError_t e_ = hipStreamSynchronize(st);
+    if (d_dgs) pool_put(ctx, d_dgs);
     if (d_ps) pool_put(ctx, d_ps);
     if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_batch: %s", hipGetErrorString(e_)); }
   }
+  if (a->dG_s) memcpy(a->dG_s, dgsh.data(), dgsh.size() * sizeof(double));
   if (a->G_s) memcpy(a->G_s, psh.data(), (size_t)S * R * sizeof(double));
   if (a->varG_s) memcpy(a->varG_s, psh.data() + (size_t)S * R, (size_t)S * R * sizeof(double));
   if (ctx->profiling) {
@@ -1204,7 +1218,7 @@ static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc
   if (!a) return set_err(ctx, VBMC_ERR_INVALID, "%s: null args", who);
   if (slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot must be 0 or 1", who);
   if (ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot %d holds an uncollected pass", who, slot);
-  if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s)
+  if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s || a->dG_s)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "%s: per-component / per-hyper-sample outputs only through vbmc_elbo_batch", who);
   if (a->eps_mode == 1)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "%s: host-resident draws (eps_mode 1) only through vbmc_elbo_batch", who);

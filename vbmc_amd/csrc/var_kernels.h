@@ -354,6 +354,45 @@ __global__ void __launch_bounds__(64) k_per_sample(ElboDims dm, const double* __
 }
 
 // ------------------------------------------------------------------------------------------
+// k_per_sample_grad: gplogjoint's dF with avg_flag = 0 -- the gradient of F(s) for every hyper-sample on its own, T x S per restart
+// (misc/gplogjoint.m:206-271 hold the per-sample pieces; :352-373 the Jacobians; the averaging of :411 is what is skipped).  The
+// per-(s, k) records carry I_k | w_k dI_k/dmu (D) | w_k dI_k/dsigma | w_k dI_k/dlambda (D): mu and sigma blocks are copies (times
+// sigma_k for log sigma), lambda sums over the components (times lambda_d for log lambda), the weight gradient is I_k itself, through
+// the softmax Jacobian diag(w) - w w' for eta (:366-368): w_k (I_k - F(s)).  One workgroup per (hyper-sample, restart).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_per_sample_grad(ElboDims dm, const double* __restrict__ vpd, const double* __restrict__ lj,
+                                                         int no_jacobian, double* __restrict__ dGs) {
+  const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+  const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
+  VpLayout L{D, K};
+  const double* v = vpd + (size_t)r * L.stride();
+  const double *w = v + L.w(), *sigma = v + L.sigma(), *lam = v + L.lambda();
+  const int LJS = 2 * D + 2;
+  const double* l = lj + ((size_t)r * S + s) * K * LJS;
+  double* o = dGs + ((size_t)r * S + s) * T;
+  const bool jac = no_jacobian == 0;
+  __shared__ double Fs;
+  if (tid == 0) {
+    double F = 0.0;
+    for (int k = 0; k < K; ++k) F += w[k] * l[(size_t)k * LJS];     // :203, the order of k_per_sample
+    Fs = F;
+  }
+  __syncthreads();
+  if (dm.opt[0])
+    for (int p = tid; p < D * K; p += nt) o[dm.off_mu + p] = l[(size_t)(p / D) * LJS + 1 + p % D];
+  if (dm.opt[1])
+    for (int k = tid; k < K; k += nt) o[dm.off_sigma + k] = l[(size_t)k * LJS + 1 + D] * (jac ? sigma[k] : 1.0);        // :356
+  if (dm.opt[2])
+    for (int d = tid; d < D; d += nt) {
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) acc += l[(size_t)k * LJS + 2 + D + d];                                               // :250
+      o[dm.off_lambda + d] = acc * (jac ? lam[d] : 1.0);                                                                // :362
+    }
+  if (dm.opt[3])
+    for (int k = tid; k < K; k += nt) o[dm.off_eta + k] = jac ? w[k] * l[(size_t)k * LJS] - w[k] * Fs : l[(size_t)k * LJS];   // :366-368
+}
+
+// ------------------------------------------------------------------------------------------
 // k_var_final: one workgroup per restart.  out VR[r] = varG, varGss, dvarG[T]
 // ------------------------------------------------------------------------------------------
 struct VarFinArgs {

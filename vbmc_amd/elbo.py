@@ -247,6 +247,8 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
             a.G_s = outbuf("G_s", (S, R))
         if "varG_s" in outputs and compute_var:
             a.varG_s = outbuf("varG_s", (S, R))
+        if "dG_s" in outputs and compute_grad:
+            a.dG_s = outbuf("dG_s", (T, S, R))
     ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, dgp_h, C.byref(a)))
     return out
 
@@ -330,9 +332,10 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
     (misc/gplogjoint.m:1-30).  Accelerated call forms: averaged over the hyper-parameter samples (avg_flag = 1) with
     transformed gradients (jacobian_flag), and per-hyper-sample values without gradients (avg_flag = 0: F and varF are
     length-S vectors, varss = 0 -- the forms of private/activesample_vbmc.m:155 and misc/vpoptimizeweights_vbmc.m:42);
-    untransformed gradients (jacobian_flag = 0: with respect to sigma, lambda and w themselves, :352-373 skipped), and dvarF --
-    the gradient of the diagonal variance (compute_var = 2, nargout >= 4; :375-413).  Not accelerated: per-hyper-sample gradients
-    (avg_flag = 0 with grad_flags; no caller in VBMC) and dvarF with jacobian_flag = 0."""
+    untransformed gradients (jacobian_flag = 0: with respect to sigma, lambda and w themselves, :352-373 skipped), dvarF --
+    the gradient of the diagonal variance (compute_var = 2, nargout >= 4; :375-413) -- and, round 4, per-hyper-sample gradients
+    (avg_flag = 0 with grad_flags: dF is T x S, :411 skipped; vbmc_elbo_args.dG_s) and per-component outputs together with gradients
+    (separate_K with grad_flags: two passes).  Not accelerated: dvarF with jacobian_flag = 0 or with avg_flag = 0."""
     if separate_K is None:
         separate_K = nargout > 5            # :13
     if compute_var is None:
@@ -346,19 +349,25 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
                              "available only for diagonal approximation of the variance.")
         if not jacobian_flag:
             raise VbmcUnsupported(-1, "gplogjoint: the variance gradient without the Jacobians (jacobian_flag = 0) is not accelerated")
-    if not avg_flag and g:
-        raise VbmcUnsupported(-1, "gplogjoint: per-hyper-sample gradients (avg_flag = 0 with grad_flags) are not accelerated")
-    if separate_K and g:
-        raise VbmcUnsupported(-1, "gplogjoint: per-component outputs together with gradients are not accelerated")
+    if not avg_flag and want_dvar:
+        raise VbmcUnsupported(-1, "gplogjoint: the per-hyper-sample variance gradient (avg_flag = 0 with nargout >= 4) is not accelerated")
     want = ["G"] + (["dG"] if g else []) + (["varG", "varGss"] if compute_var else []) + (["dvarG"] if want_dvar else [])
-    if separate_K:
-        want += ["I_sk"] + (["J_sjk"] if compute_var else [])
     if not avg_flag:
-        want += ["G_s"] + (["varG_s"] if compute_var else [])
-    r = negelcbo_batch(theta, 0.0, vpt, gp, 0, g, compute_var, None, separate_K=bool(separate_K), engine=engine,
+        want += ["G_s"] + (["varG_s"] if compute_var else []) + (["dG_s"] if g else [])
+    sep = None
+    if separate_K and g:
+        # per-component outputs TOGETHER with gradients (round 4): the objective's entry point refuses the combination as
+        # negelcbo_vbmc.m:57-59 does, so the stand-alone form takes two passes -- I_sk / J_sjk do not depend on the gradient request
+        sep = negelcbo_batch(theta, 0.0, vpt, gp, 0, False, compute_var, None, separate_K=True, engine=engine,
+                             outputs=("I_sk",) + (("J_sjk",) if compute_var else ()), jacobian_flag=bool(jacobian_flag))
+    elif separate_K:
+        want += ["I_sk"] + (["J_sjk"] if compute_var else [])
+    r = negelcbo_batch(theta, 0.0, vpt, gp, 0, g, compute_var, None, separate_K=bool(separate_K) and sep is None, engine=engine,
                        outputs=tuple(want), jacobian_flag=bool(jacobian_flag))
-    if not avg_flag and r["G_s"].shape[0] > 1:     # :399: no averaging -> F, varF are 1 x S; varss stays 0 (:398)
-        outs = (r["G_s"][:, 0].copy(), np.zeros(0), r["varG_s"][:, 0].copy() if compute_var else None, None, 0.0,
+    if sep is not None:
+        r.update(sep)
+    if not avg_flag and r["G_s"].shape[0] > 1:     # :399: no averaging -> F, varF are 1 x S, dF is T x S; varss stays 0 (:398)
+        outs = (r["G_s"][:, 0].copy(), r["dG_s"][:, :, 0].copy() if g else np.zeros(0), r["varG_s"][:, 0].copy() if compute_var else None, None, 0.0,
                 r["I_sk"][:, :, 0].copy() if separate_K else None,
                 r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
         return outs[0] if nargout <= 1 else outs[:nargout]
