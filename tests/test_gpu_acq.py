@@ -223,12 +223,15 @@ def test_imiqr_end_to_end_through_the_mirror(va):
     for s in range(S):
         pr = R.gplite_pred(gp, Xa[:, :, s], None, None, True)
         fmu = np.asarray(pr[2]).reshape(48, S)[:, s]
-        fs = np.sqrt(np.asarray(pr[3]).reshape(48, S)[:, s])
-        logp = fmu + u * fs + np.log1p(-np.exp(-2 * u * fs))            # acq/acqimiqr_vbmc.m:24-27
+        # the chain's target (log_isbasefun, private/activeimportancesampling_vbmc.m:343-353) reads the FIRST two outputs of gplite_pred:
+        # ymu and ys2, the predictive variance with the observation noise; the weight's numerator islogf1 the latent mean (:209-221)
+        ym = np.asarray(pr[0]).reshape(48, S)[:, s]
+        fs = np.sqrt(np.asarray(pr[1]).reshape(48, S)[:, s])
+        logp = ym + u * fs + np.log1p(-np.exp(-2 * u * fs))             # acq/acqimiqr_vbmc.m:24-27
         assert np.max(np.abs(lnw[s] - (fmu - logp))) < 1e-7 * max(1.0, np.max(np.abs(logp)))
         pu = R.gplite_pred(gp, uni, None, None, True)
-        fu = np.asarray(pu[2]).reshape(400, S)[:, s]
-        su = np.sqrt(np.asarray(pu[3]).reshape(400, S)[:, s])
+        fu = np.asarray(pu[0]).reshape(400, S)[:, s]
+        su = np.sqrt(np.asarray(pu[1]).reshape(400, S)[:, s])
         assert np.mean(logp) > np.mean(fu + u * su + np.log1p(-np.exp(-2 * u * su))) + 1.0
     st = dict(st, gplengthscale=gl, VarianceRegularizedAcqFcn=False, ActiveImportanceSampling=ais)
     acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqimiqr_vbmc", None)

@@ -827,7 +827,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
   // kernel has the lower latency
   const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
-  const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu / 2) && !(ljf && !strcmp(ljf, "valu"));
+  // (round 4: from S R = one workgroup per compute unit on -- below, the finer-grained VALU kernel is the faster one: R = 8 at the headline
+  // shape, 160 (hyper-sample, restart) workgroups: 56 us against 34 alone, the step 0.394 -> 0.360 ms; equal at R = 16, 142 against 174 us at R = 64)
+  const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu) && !(ljf && !strcmp(ljf, "valu"));
   // Small grids (a single chain, a handful of restarts): the VALU log joint runs as a ROLE of the entropy launch (single-wave
   // workgroups ahead of the entropy ones, entropy_mfma.h CO = true) -- two dependent-chain-bound kernels side by side instead of
   // one after the other, one launch less.  Its records are per (hyper-sample, split of the training set); the reduction over
