@@ -17,7 +17,7 @@ def one():
     import vbmc_amd
     from bench import synth_inputs
 
-    D, N, K, S, Ns = 10, 400, 50, 20, 10000
+    D, N, K, S, Ns = 10, 400, 50, 20, int(os.environ.get("AB_NS", "10000"))
     inp = synth_inputs(0, D, N, K, S)
     eng = vbmc_amd.Engine(0)
     gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)

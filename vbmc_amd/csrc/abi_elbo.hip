@@ -495,7 +495,12 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
   const long long KR = (long long)P.dm.K * P.dm.R * P.rstride;
   return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 8 && !(P.cutoff > 0.0) && P.compute_grad &&
          !P.lj_records && SR < ctx->num_cu / 2 && SR * P.rstride < ctx->num_cu / 2 &&   // (the undivided batch's choice when the restarts are dealt over devices)
-         KR < 2 * ctx->num_cu && P.dm.N > 1;
+         KR < 2 * ctx->num_cu && P.dm.N > 1 &&
+         // (round 4) ... and small in WORK, not only in width: with many sample tiles per wave (Ns = 1e4 per component: 313 tiles per
+         // (component, restart)) the role's workgroups delay an entropy launch that fills the chip by itself -- R = 4 at the headline
+         // shape: 0.242 ms with the role, 0.221 without; equal at R = 2 -- while at the optimiser's own sample counts (Ns = 28..400)
+         // the role wins by 13-24 % for R <= 4.  The bound: sixteen sample tiles per resident wave slot.
+         KR * ((P.Mh + 15) / 16) <= 16LL * 8 * ctx->num_cu;
 }
 
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
