@@ -150,6 +150,19 @@ def interpreted_baseline(D, K, Ns_full, budget_s=20.0):
     return {"found": None, "note": "neither matlab nor octave on the PATH of this host: no interpreted baseline (tools/cpu_ref_entmc.m is what would run)"}
 
 
+def newest_profile_with(marker):
+    """the newest profiles/rNN_*_summary.md that holds a section for `marker` (e.g. "configs[4]"), or None"""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    best = None
+    try:
+        for f in sorted(os.listdir(here)):
+            if f.endswith("_summary.md") and marker in open(os.path.join(here, f), errors="replace").read():
+                best = "profiles/" + f
+    except OSError:
+        pass
+    return best
+
+
 def _free_port():
     import socket
 
@@ -662,7 +675,9 @@ def main():
         ach = R_ * f_ent / (float(np.mean(ems)) * 1e-3) / 1e12
         return {"workload": "D=%d N=%d K=%d Ns=%d/component S=%d, R=%d, %s target%s" % (D_, N_, K_, Ns_, S_, R_, target, ", noisy (s2 = 1)" if noisy else ""),
                 "evals_per_s": R_ * nsteps / dt_, "ms_per_step": 1e3 * dt_ / nsteps, "kernel": entropy_kernel_label(D_, K_),
-                "entropy_kernel_ms": float(np.mean(ems)), "achieved_TFLOPs": ach, "frac": ach / FP64_PEAK_TFLOPS}
+                "entropy_kernel_ms": float(np.mean(ems)), "achieved_TFLOPs": ach, "frac": ach / FP64_PEAK_TFLOPS,
+                # rocprofv3 evidence for this configuration (kernel trace + one PMC pass of this command line), newest committed summary
+                "profile": newest_profile_with("configs[%d]" % (1 if D_ == 6 else 4))}
 
     def small_batch_leg():
         """BASELINE configs[3] is the SAME 64 restarts over 8 GPUs: 64 / G per device.  The rate of one device at R = 32, 16, 8 says
