@@ -7,7 +7,8 @@ function score = vbmc_hip_sieve(calls,gp,elcbo_beta)
 % go in separate sub-batches (those groups are not part of theta).  A candidate with a non-finite parameter is not sent
 % (the library validates the whole batch): its score is NaN, as the reference's arithmetic would give, and sorts last.
 % In a multi-device session the candidates of a sub-batch are dealt over the devices (r = g mod n) and their values
-% all-gathered over xGMI inside the library ('elbo_batch_multi'): bit-identical to the one-device pass.
+% all-gathered over xGMI inside the library ('elbo_batch_multi'): the estimator of the one-device pass sample for sample, equal to
+% it to the order of summation (1e-13), identical on every device of the session.
 % If the device refuses a sub-batch (vbmc_hip:unsupported) its members are evaluated one by one through the
 % negelcbo_vbmc shim, which falls through to the reference on its own.
 R = numel(calls);
