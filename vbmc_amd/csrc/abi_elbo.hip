@@ -336,7 +336,7 @@ int vbmc_occupancy_ent_mfma_qs9(int, int, int, const EntArgs*);
 // K <= 64: one wave per workgroup.  Round 3 (tools/hv_small_sweep.py -> profiles/r03_hv_small.md) tried two waves with two k-tiles
 // each where the one-wave kernel with four k-tiles spills: once those kernels were rebuilt for ONE wave per SIMD (512 registers,
 // VBMC_ENT_ONE_WAVE in entropy_mfma.h: 11-23 % faster) the split only wins at K = 57..64 for D >= 31 (6 %) and costs 6-85 % everywhere else.
-static int ent_hv_small(int qs, int K) { return (qs >= 9 && K > 56) ? 2 : 1; }
+static int ent_hv_small(int qs, int K) { return (qs >= 9 && K > 52) ? 2 : 1; }   // (round 4, with the shared even part in the two-wave kernels: K = 53..56 at D >= 31 too, 0.77 of the one-wave time)
 static int ent_hv_mid(int qs, int K) { return (K > 96 && (qs >= 7 || (qs >= 5 && K > 112))) ? 4 : 2; }
 static bool launch_entropy_mfma(int qs, int kt, int hv, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);

@@ -21,7 +21,7 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
   constexpr int NPV_ = (4 * QS_VALUE + 15) / 16;
   size_t lds = (size_t)ea.K * (ea.D + ENTP_EXTRA) * sizeof(double);
   size_t after = (size_t)VB_EXP_TAB1K_N * sizeof(double);          // the exp table takes the block's place once the operands are built
-  if (HV > 1) after += (size_t)2 * HV * NPV_ * 4 * WAVE * sizeof(double);
+  if (HV > 1) after += (size_t)(VBMC_ENT_EO(HV) ? 1 : 2) * HV * NPV_ * 4 * WAVE * sizeof(double);   // PV exchange: per sign, or one for both (entropy_mfma.h: YXSB)
   if (after > lds) lds = after;
   const void* fn = nullptr;
   if constexpr (HV == 1 && QS_VALUE <= 8) {

@@ -139,6 +139,17 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
 #ifdef VBMC_ENT_WAVES_ALL      // A/B builds (tools/tune_build.py): every instantiation for this many waves per SIMD
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) VBMC_ENT_WAVES_ALL
 #endif
+// Which workgroup shapes share the even part of the exponent between the antithetic pair (EO: 4 instead of 2 QS S-step MFMAs per k-tile and
+// tile).  Single-wave workgroups since round 2; round 4: two- and four-wave workgroups (64 < K <= 256) too -- the second sign's exponents are
+// parked in LDS (NML) and the PV exchange is single-buffered to pay for that LDS: up to -35 % at D >= 20 (tools/tune_sweep.py, r04_experiments.md
+// section 10), BASELINE configs[4] 9.75 -> 8.5 ms.  -DVBMC_NO_EO2 / -DVBMC_NO_EO4: round 3's plain per-sign S-step there (A/B builds).
+#ifdef VBMC_NO_EO2
+#define VBMC_ENT_EO(HV_) ((HV_) == 1)
+#elif defined(VBMC_NO_EO4)
+#define VBMC_ENT_EO(HV_) ((HV_) == 1 || (HV_) == 2)
+#else
+#define VBMC_ENT_EO(HV_) true
+#endif
 #ifndef VBMC_ENT_CW_WAVES
 #define VBMC_ENT_CW_WAVES 3     // waves per SIMD the chunk-wave kernels (CW > 1) are built for
 #endif
@@ -176,7 +187,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // EO: the even / odd split of the S-step below (needs 32 more VGPRs for the second sign's exponents, paid for by VBL).
   // Two-wave workgroups (K > 64) keep the plain per-sign S-step with everything in registers: their LDS already holds the PV
   // exchange buffers and a larger parameter block, and 32 KB more would halve the resident waves.
-  constexpr bool EO = HV == 1;
+  constexpr bool EO = VBMC_ENT_EO(HV);
+  constexpr bool YXSB = HV > 1 && EO;   // one PV exchange buffer for both signs (a barrier more per tile): the LDS it frees holds the parked exponents
   // US (round 4): the LDS tile holds u' = eps sigma_j, not eps -- every reader wanted the product (S-step operand, tail, gradient
   // epilogue: a multiply per use), the own exponent comes from |u'|^2 as well
 #ifdef VBMC_NO_US
@@ -184,7 +196,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #else
   constexpr bool US = EO;
 #endif
-  constexpr bool VBL = GRAD && EO && (KT >= 3 || NPV >= 2);
+  constexpr bool VBL = GRAD && HV == 1 && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   // CW > 1 (chunk waves): the CW waves of a workgroup work on the SAME (component j, restart r) and on CW consecutive sample chunks,
@@ -192,9 +204,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // new here, the S-step operands (SAL: read from LDS right before the MFMA that consumes them, 2 KT QL VGPRs less).  The second
   // sign's exponents wait in a private LDS block instead of registers (NML: 8 KT VGPRs less).  Together that is what the 168-VGPR
   // budget of THREE waves per SIMD needs, and the shared table is what lets twelve waves' LDS fit a compute unit.
-  constexpr bool SAL = CW > 1, NML = CW > 1;
+  constexpr bool SAL = CW > 1, NML = CW > 1 || (HV > 1 && EO);   // (two-wave workgroups with the shared even part park them too: their registers are spoken for)
   __shared__ double SAS_all[SAL ? KT * QL * WAVE : 1];
-  __shared__ double NMS_all[CW][NML ? KT * 4 * WAVE : 1];
+  __shared__ double NMS_all[HV * CW][NML ? KT * 4 * WAVE : 1];
 #ifdef VBMC_EXP_CLK
   const unsigned long long wckE = wall_clock64();
 #endif
@@ -205,7 +217,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   double* Et = Et_all[cwi];
   double* RQ = RQ_all[wv];
   double* SAS = SAS_all;
-  double* NMS = NMS_all[cwi];
+  double* NMS = NMS_all[wv];
   double* BND = BND_all[hv];
   double* VBS = VBS_all[hv];
   double* BTL = BTL_all[hv];
@@ -634,19 +646,20 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
         if (TWO) Y[pv] += Yb;
       }
       if (HV > 1) {
+        if (YXSB && sg == 1) __syncthreads();     // every wave has read the first sign's partials
         // all shares of the mixture: the partial q', A', B' of every wave, added in wave order
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) YX[(sg * HV + hv) * YXN + (pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
+          for (int rr = 0; rr < 4; ++rr) YX[((YXSB ? 0 : sg) * HV + hv) * YXN + (pv * 4 + rr) * WAVE + lane] = Y[pv][rr];
         __syncthreads();
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            double t = YX[(sg * HV + 0) * YXN + (pv * 4 + rr) * WAVE + lane];
+            double t = YX[((YXSB ? 0 : sg) * HV + 0) * YXN + (pv * 4 + rr) * WAVE + lane];
 #pragma unroll
-            for (int w = 1; w < HV; ++w) t += YX[(sg * HV + w) * YXN + (pv * 4 + rr) * WAVE + lane];
+            for (int w = 1; w < HV; ++w) t += YX[((YXSB ? 0 : sg) * HV + w) * YXN + (pv * 4 + rr) * WAVE + lane];
             Y[pv][rr] = t;
           }
       }
@@ -725,7 +738,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     using IH = std::integral_constant<int, (KT + 1) / 2>;
     using IK = std::integral_constant<int, KT>;
 
-    if constexpr (EO && GRAD && CW == 1 && VBMC_STAG_FOR(KT, QS, TL)) {
+    if constexpr (EO && GRAD && CW == 1 && HV == 1 && VBMC_STAG_FOR(KT, QS, TL)) {
       // Both signs in straight-line code, staggered: the second sign's exponentials (independent of everything the first
       // sign's per-sample chain waits for -- the q' exchange through LDS, the reciprocal, the 1/q' exchange) are issued
       // inside that chain, so this wave keeps the pipe busy across its own latencies instead of leaving them to the one
@@ -801,11 +814,12 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
           qp += __shfl_xor(qp, 16, 64);
           qp += __shfl_xor(qp, 32, 64);
           if (HV > 1) {
-            YX[(sg * HV + hv) * YXN + lane] = qp;
+            if (YXSB && sg == 1) __syncthreads();
+            YX[((YXSB ? 0 : sg) * HV + hv) * YXN + lane] = qp;
             __syncthreads();
-            qp = YX[(sg * HV + 0) * YXN + lane];
+            qp = YX[((YXSB ? 0 : sg) * HV + 0) * YXN + lane];
 #pragma unroll
-            for (int w = 1; w < HV; ++w) qp += YX[(sg * HV + w) * YXN + lane];
+            for (int w = 1; w < HV; ++w) qp += YX[((YXSB ? 0 : sg) * HV + w) * YXN + lane];
           }
           double qs_ = qp;
           if (partial) qs_ = svalid ? qp : 1.0;
