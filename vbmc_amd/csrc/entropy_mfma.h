@@ -157,11 +157,11 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
 // ONE wave per SIMD (512 registers: nothing spills) where the two-wave build spills so much that losing the second wave's latency
 // hiding is the smaller evil (round 3, tools/tune_build.py w1:-DVBMC_ENT_WAVES_ALL=1 against the policy over 112 shapes,
 // profiles/r03_shape_sweep.md): four k-tiles on one wave from D = 15 on (K = 53..64: 11-23 % faster), three k-tiles from D = 27 on
-// (7-23 %), four-wave workgroups with four k-tiles from D = 23 on (round 4: from D = 15 on -- the 154 VGPRs the two-wave build spills at
-// D = 15..22 cost more since the round-4 changes: K = 256, D = 20: 19.1 -> 15.9 ms) and with three at D >= 31 (K = 193..256: 27-49 %).  Everywhere
+// (7-23 %), four-wave workgroups with four k-tiles from D = 23 on (round 4: from D = 19 on -- K = 256, D = 20: 16.9 ms
+// at two waves, 13.8 at one, with the shared even part in these kernels; D = 18: 12.3 against 13.1 the other way) and with three at D >= 31 (K = 193..256: 27-49 %).  Everywhere
 // else one wave per SIMD costs 2-49 %.
 #define VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) \
-  (((HV_) == 1 && (KT_) == 4 && (QS_) >= 5) || ((HV_) == 1 && (KT_) == 3 && (QS_) >= 8) || ((HV_) == 4 && (KT_) == 4 && (QS_) >= 5) || \
+  (((HV_) == 1 && (KT_) == 4 && (QS_) >= 5) || ((HV_) == 1 && (KT_) == 3 && (QS_) >= 8) || ((HV_) == 4 && (KT_) == 4 && (QS_) >= 6) || \
    ((HV_) == 4 && (KT_) == 3 && (QS_) >= 9))
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) \
   (VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) ? 1 : ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2))
