@@ -185,8 +185,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // PV "B" operands of large mixtures live in LDS (lane-contiguous: conflict-free ds_read_b64 right before the MFMA that
   // consumes them) -- the 32 VGPRs they would occupy hold the second sign's exponents instead (see the S-step)
   // EO: the even / odd split of the S-step below (needs 32 more VGPRs for the second sign's exponents, paid for by VBL).
-  // Two-wave workgroups (K > 64) keep the plain per-sign S-step with everything in registers: their LDS already holds the PV
-  // exchange buffers and a larger parameter block, and 32 KB more would halve the resident waves.
+  // Multi-wave workgroups (K > 64) kept the plain per-sign S-step through round 3 (their LDS already holds the PV exchange buffers and a
+  // larger parameter block, and 32 KB of PV operands more would halve the resident waves); since round 4 they share the even part as
+  // well, with the second sign's exponents parked in LDS (NML) and the PV exchange single-buffered (YXSB) -- see VBMC_ENT_EO.
   constexpr bool EO = VBMC_ENT_EO(HV);
   constexpr bool YXSB = HV > 1 && EO;   // one PV exchange buffer for both signs (a barrier more per tile): the LDS it frees holds the parked exponents
   // US (round 4): the LDS tile holds u' = eps sigma_j, not eps -- every reader wanted the product (S-step operand, tail, gradient
