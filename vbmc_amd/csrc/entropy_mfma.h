@@ -86,7 +86,8 @@ constexpr bool X_W = true;
 #elif defined(VBMC_NO_STAG)
 #define VBMC_STAG_FOR(KT_, QS_, TL_) false
 #else
-#define VBMC_STAG_FOR(KT_, QS_, TL_) ((KT_) == 1 || ((KT_) == 3 && (QS_) <= ((TL_) ? 5 : 8)))
+// Round 4 (the in-loop log's twelve constant registers are gone): four k-tiles (-0.6..-2.5 %) and two k-tiles from D = 19 on (-1.8..-3.7 %) too.
+#define VBMC_STAG_FOR(KT_, QS_, TL_) ((KT_) == 1 || (KT_) == 4 || ((KT_) == 2 && (QS_) >= 6) || ((KT_) == 3 && (QS_) <= ((TL_) ? 5 : 8)))
 #endif
 #ifdef VBMC_EXP_NOS
 constexpr bool X_S = false;
