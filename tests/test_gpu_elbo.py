@@ -241,6 +241,23 @@ def test_device_rng_stream_parity_in_every_padding_class(va, D):
         assert relerr(val["H"][0], ref["H"]) < RT_VAL
 
 
+@pytest.mark.parametrize("D,K", [(5, 70), (7, 100), (6, 130), (9, 200), (3, 256)])
+def test_device_rng_stream_parity_multi_wave_workgroups(va, D, K):
+    """K > 64: two- and four-wave workgroups (wave 0 draws and stages the tile for all; round 4: the tile holds eps sigma_j there too and
+    the antithetic pair shares the even part of the exponent, the second sign's exponents parked in LDS) on the device stream, partial
+    last tile included, against the oracle on the dumped stream (ent/entmc_vbmc.m:49-104)."""
+    p, gp, vp, theta = problem(60 + D, D, 25, K, 2)
+    eng = va.default_engine()
+    for Ns, seed in ((38, 3), (64, 4)):                 # Mh = 19 (partial tile), 32
+        eps = eng.ctx.rng_dump(D, K, 1, Ns, seed)[0]
+        ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, eps=eps)
+        out = va.negelcbo_batch(theta[:, None], 0, vp, gp, Ns, True, 0, seed=seed)
+        assert relerr(out["H"][0], ref["H"]) < RT_VAL
+        assert relerr(out["dF"][:, 0], ref["dF"]) < RT_GRAD
+        val = va.negelcbo_batch(theta[:, None], 0, vp, gp, Ns, False, 0, seed=seed)
+        assert relerr(val["H"][0], ref["H"]) < RT_VAL
+
+
 def test_entropy_mc_converges_to_closed_form(va):
     """K = 1: entmc -> 0.5 D (1 + log 2 pi) + D log sigma + sum log lambda (entlb_vbmc.m:34)."""
     p, gp, vp, theta = problem(7, 4, 30, 1, 1)
