@@ -372,9 +372,9 @@ def main():
             if not pipe:
                 o = multi_step(i0 + i, batch, po)
                 continue
-            po.submit(batch, seed=i0 + i, slot=i & 1)
-            pend.append(i & 1)
-            if len(pend) == 2:
+            po.submit(batch, seed=i0 + i, slot=i % DEPTH)
+            pend.append(i % DEPTH)
+            if len(pend) == DEPTH:
                 o = multi_finish(po, pend.pop(0), batch.shape[1])
         while pend:
             o = multi_finish(po, pend.pop(0), batch.shape[1])
@@ -404,10 +404,11 @@ def main():
 
     # The steps are independent batches (the sieve's candidates, misc/vpsieve_vbmc.m:74-78: batch i + 1 does not depend on the
     # result of batch i), so by default they go through the pipelined form of the same ABI call -- vbmc_elbo_submit /
-    # vbmc_elbo_collect, two batches in flight: the host stages theta of step i + 1 while the device works on step i.  Every
+    # vbmc_elbo_collect, four batches in flight on two streams: the host stages theta of step i + 1 while the device works on step i.  Every
     # step still moves its theta H2D, runs the full pass and moves (F, dF) D2H, and every step's results are consumed (the
     # all-gather + sort of the sieve when world > 1) before the timed region ends.  --sync-steps: one blocking call per step.
     pipelined = shard_ex is None and not args.sync_steps
+    DEPTH = 2 if os.environ.get("VBMC_SLOT_STREAMS") == "0" else 4      # batches in flight: four slots on two streams (include/vbmc_hip.h, vbmc_elbo_submit)
 
     def finish(slot):
         F_, dF_ = objective.collect(slot)
@@ -426,9 +427,9 @@ def main():
                 o, _ = step(i0 + i)
             return o
         for i in range(n):
-            objective.submit(thetas, seed=(rank << 32) + i0 + i, slot=i & 1)
-            pend.append(i & 1)
-            if len(pend) == 2:
+            objective.submit(thetas, seed=(rank << 32) + i0 + i, slot=i % DEPTH)
+            pend.append(i % DEPTH)
+            if len(pend) == DEPTH:
                 o = finish(pend.pop(0))
         while pend:
             o = finish(pend.pop(0))
@@ -725,9 +726,9 @@ def main():
                 def run_comm(n, i0):
                     pend = []
                     for i in range(n):
-                        po.submit(th, seed=i0 + i, slot=i & 1)
-                        pend.append(i & 1)
-                        if len(pend) == 2:
+                        po.submit(th, seed=i0 + i, slot=i & 3)
+                        pend.append(i & 3)
+                        if len(pend) == 4:
                             F_, _ = po.collect(pend.pop(0))
                             np.argsort(F_, kind="stable")
                     while pend:
@@ -754,7 +755,7 @@ def main():
             comm1.free_gp(gps1)
         finally:
             comm1.close()
-        out_["path"] = "Comm.create_all(1): vbmc_elbo_multi_submit / _collect, ncclAllGather of [F | varG] on the context's stream, two batches in flight"
+        out_["path"] = "Comm.create_all(1): vbmc_elbo_multi_submit / _collect, ncclAllGather of [F | varG] on the context's stream, four batches in flight on two streams"
         return out_
 
     def sync_leg():
@@ -821,8 +822,8 @@ def main():
                        if shard_ex is not None else ("restart-sharded x%d (restart r on rank r mod %d), all-gather of ELCBO" % (world, world)
                                                      if world > 1 else "one GPU"),
                        "stepping": (("pipelined: independent batches through vbmc_elbo_multi_submit / vbmc_elbo_multi_collect (the restarts dealt over "
-                                     "the ranks, ncclAllGather of the ELCBO values inside the library), two in flight" if comm is not None else
-                                     "pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, two in flight") +
+                                     "the ranks, ncclAllGather of the ELCBO values inside the library), four in flight on two streams per device" if comm is not None else
+                                     "pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, four in flight on two streams") +
                                     "; every step moves its theta H2D and its (F, dF) D2H" if pipelined else "one blocking call per step")},
             "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if multi else None),
             "world_size_observed": (dist.get_world_size() if multi else 1),

@@ -265,7 +265,9 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  *   vbmc_elbo_submit   validates and stages the inputs of one batch in the slot's own pinned block, enqueues the H2D, the
  *                      kernels and the packed D2H on the context's stream and returns WITHOUT waiting;
  *   vbmc_elbo_collect  waits for that slot's pass and fills the outputs named in args (F, dF, G, H, dG, dH, varG, varGss).
- * Two slots (0 and 1): while the device works on one batch the host stages the next, so that the device never waits for the
+ * Four slots (0 .. 3; round 4: slot s runs on stream s & 1 of two streams the context creates for this purpose, two passes deep each --
+ * the head and tail of one pass overlap the last round of waves of another and a stream never runs dry while the host collects and
+ * re-submits; slots 2 and 3 exist for passes without a variance term): while the device works on one batch the host stages the next, so that the device never waits for the
  * host between batches.  Measured: 2.82 -> 2.77 ms per batch of 64 at the headline shape (the device is busy 98 % of a
  * blocking call already), 113 -> 103 us per single evaluation; the batches still execute one after the other on the
  * context's stream, so the chain of dependent kernels inside a small batch is not hidden.  Passes execute in submission order; each
@@ -355,7 +357,8 @@ vbmc_status vbmc_elbo_batch_multi(vbmc_comm* comm, const vbmc_gp* const* gps, co
 /* The pipelined form of vbmc_elbo_batch_multi for streams of INDEPENDENT batches (the candidates of misc/vpsieve_vbmc.m:74-78), as
  * vbmc_elbo_submit / vbmc_elbo_collect are for one device: submit stages this process's restarts, enqueues the passes, the one
  * ncclAllGather and the copy of the gathered vectors to pinned host memory and returns; collect waits and fills the caller's arrays
- * (same contents as vbmc_elbo_batch_multi).  slot = 0 or 1: two batches in flight.  Device RNG (eps_mode 0), no per-component or
+ * (same contents as vbmc_elbo_batch_multi).  slot = 0 .. 3: up to four batches in flight, on two streams per device (the exchange itself
+ * stays on each context's own stream, ordered after the pass).  Device RNG (eps_mode 0), no per-component or
  * per-hyper-sample outputs.  A steady-state call allocates nothing: the per-device argument structs, staging vectors, exchange
  * blocks and the pinned landing block live in the communicator's slot.  A failure local to one rank (resource error, missing
  * surrogate) is reported AFTER the rank has entered the collective with an all-NaN block, so that the other ranks are never left

@@ -84,10 +84,19 @@ def test_pipeline_misuse_is_refused(va):
     obj.submit(batches[0], seed=1, slot=0)
     with pytest.raises(va.VbmcHipError, match="uncollected"):
         obj.submit(batches[1], seed=2, slot=0)
-    with pytest.raises(va.VbmcHipError, match="slot must be 0 or 1"):
-        obj.submit(batches[1], seed=2, slot=2)
+    with pytest.raises(va.VbmcHipError, match="slot must be 0 .. 3"):
+        obj.submit(batches[1], seed=2, slot=4)
     F, dF = obj.collect(0)
+    F = F.copy()
     assert np.all(np.isfinite(F))
+    # round 4: four slots on two streams (slot s on stream s & 1, two passes deep): all four in flight at once, collected in any order,
+    # give the bits of the blocking call
+    refs = [va.negelcbo_batch(batches[i & 1], 0, vp, gp, 100, True, 0, seed=50 + i, outputs=("F", "dF")) for i in range(4)]
+    for i in range(4):
+        obj.submit(batches[i & 1], seed=50 + i, slot=i)
+    for i in (2, 0, 3, 1):
+        Fi, dFi = obj.collect(i)
+        assert np.array_equal(Fi, refs[i]["F"]) and np.array_equal(dFi, refs[i]["dF"])
     # per-component outputs are not offered through the pipelined form
     a, _, _ = obj._slot(0)
     b = type(a).from_buffer_copy(a)

@@ -87,7 +87,7 @@ struct vbmc_comm {
     size_t cap = 0;
     double* h_gather = nullptr;
     size_t h_cap = 0;
-  } slot[2];
+  } slot[VBMC_SLOTS];
 };
 
 static vbmc_status comm_err(vbmc_comm* c, vbmc_status st, const char* fmt, ...) {
@@ -424,7 +424,7 @@ static vbmc_status comm_slot_reserve(vbmc_comm* c, vbmc_comm::Slot& sl, size_t c
 extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const* gps, const vbmc_elbo_args* a, int slot) {
   if (!c) return VBMC_ERR_INVALID;
   if (!gps || !a) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: null surrogates / args");
-  if (slot < 0 || slot > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot must be 0 or 1");
+  if (slot < 0 || slot >= VBMC_SLOTS) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot must be 0 .. 3");
   if (a->struct_size != sizeof(vbmc_elbo_args)) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size (ABI mismatch)");
   if (a->eps_mode != 0) return comm_err(c, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_multi_submit: device RNG (eps_mode 0) only");
   if (a->restart_offset != 0 || a->restart_stride > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit deals the restarts itself");
@@ -457,15 +457,30 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
       if (th.size() < (size_t)T * n) th.resize((size_t)T * n);
       for (int q = 0; q < n; ++q) memcpy(&th[(size_t)q * T], a->theta + (size_t)(g + (size_t)q * G) * T, T * sizeof(double));
       sub.theta = th.data();
-      st = elbo_submit_core(ctx, gps[i], &sub, slot, "vbmc_elbo_multi_submit");
+      // the pass on the slot's own stream (abi_elbo.hip: slot_ctx); the pick and the exchange stay on the context's stream, ordered
+      // after the pass by an event -- consecutive collectives of one communicator on one stream, passes of consecutive batches overlapping
+      vbmc_ctx* sc = ctx;
+      int inner = slot;
+      if (slot_in_flight(ctx, slot)) st = set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot %d holds an uncollected pass", slot);
+      if (!st) st = slot_ctx(ctx, &sub, slot, &sc, &inner);
+      if (!st) st = slot_err(ctx, sc, elbo_submit_core(sc, gps[i], &sub, inner, "vbmc_elbo_multi_submit"));
+      if (!st) { ctx->slot_where[slot] = sc; ctx->slot_inner[slot] = inner; }
       if (st) comm_err(c, st, "device %d: %s", ctx->device, vbmc_last_error(ctx));
     }
     if (st) { local_fail = st; n = 0; }      // the rank still enters the collective: an all-NaN block (lock-step with the others)
     sl.n[i] = n; sl.st[i] = st;
     const size_t OS = OUT_HDR + 3 * (size_t)T;
-    const double* dout = n > 0 ? (const double*)((const SlotPlan*)ctx->slot_plan[slot])->P.d_out : nullptr;
-    hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ctx->stream, n, P, n > 0 ? OS : (size_t)1, dout, sl.d_send[i]);
+    const double* dout = n > 0 ? (const double*)((const SlotPlan*)ctx->slot_where[slot]->slot_plan[ctx->slot_inner[slot]])->P.d_out : nullptr;
+    // the pick runs on the stream the pass ran on (the result records are that stream's scratch: the next pass queued there overwrites
+    // them); the exchange on the context's own stream waits for it
+    vbmc_ctx* ps = (n > 0 && ctx->slot_where[slot]) ? ctx->slot_where[slot] : ctx;
+    hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ps->stream, n, P, n > 0 ? OS : (size_t)1, dout, sl.d_send[i]);
     COMM_HIP(c, hipGetLastError());
+    if (ps != ctx) {
+      if (!ctx->slot_yev[slot]) COMM_HIP(c, hipEventCreateWithFlags(&ctx->slot_yev[slot], hipEventDisableTiming));
+      COMM_HIP(c, hipEventRecord(ctx->slot_yev[slot], ps->stream));
+      COMM_HIP(c, hipStreamWaitEvent(ctx->stream, ctx->slot_yev[slot], 0));
+    }
   }
   const std::string keep = c->err;
   { vbmc_status s_ = comm_allgather_enqueue(c, sl.d_send.data(), sl.d_recv.data(), 2 * (size_t)P); if (s_) return s_; }
@@ -475,15 +490,23 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
     vbmc_ctx* ctx = c->ctx[i];
     COMM_HIP(c, hipSetDevice(ctx->device));
     if (sl.n[i] > 0) {
-      vbmc_status s_ = elbo_submit_mark(ctx, slot, "vbmc_elbo_multi_submit");
-      if (s_) return comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(ctx));
+      vbmc_ctx* sc = ctx->slot_where[slot];
+      vbmc_status s_ = elbo_submit_mark(sc, ctx->slot_inner[slot], "vbmc_elbo_multi_submit");
+      if (s_) return comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(sc));
+      if (sc != ctx) {     // the exchange (and, on local device 0, the copy of the gathered vectors) ends on the context's own stream
+        if (!ctx->slot_zev[slot]) COMM_HIP(c, hipEventCreateWithFlags(&ctx->slot_zev[slot], hipEventDisableTiming));
+        COMM_HIP(c, hipEventRecord(ctx->slot_zev[slot], ctx->stream));
+      }
     }
   }
   if (local_fail) {     // the exchange is enqueued (the other ranks are not left waiting); drain and report
     for (int i = 0; i < c->n; ++i) {
       (void)hipSetDevice(c->ctx[i]->device);
       (void)hipStreamSynchronize(c->ctx[i]->stream);
-      c->ctx[i]->slot_busy[slot] = false;
+      if (c->ctx[i]->slot_where[slot]) {
+        (void)hipStreamSynchronize(c->ctx[i]->slot_where[slot]->stream);
+        c->ctx[i]->slot_where[slot]->slot_busy[c->ctx[i]->slot_inner[slot]] = false;
+      }
     }
     c->err = keep;
     return local_fail;
@@ -494,7 +517,7 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
 
 extern "C" vbmc_status vbmc_elbo_multi_collect(vbmc_comm* c, const vbmc_elbo_args* a, int slot) {
   if (!c) return VBMC_ERR_INVALID;
-  if (!a || slot < 0 || slot > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_collect: null args / slot not 0 or 1");
+  if (!a || slot < 0 || slot >= VBMC_SLOTS) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_collect: null args / slot not 0 .. 3");
   vbmc_comm::Slot& sl = c->slot[slot];
   if (!sl.busy) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_collect: nothing submitted in slot %d", slot);
   int T = 0;
@@ -508,8 +531,13 @@ extern "C" vbmc_status vbmc_elbo_multi_collect(vbmc_comm* c, const vbmc_elbo_arg
     COMM_HIP(c, hipSetDevice(ctx->device));
     if (sl.n[i] > 0) {
       const SlotPlan* sp = nullptr;
-      vbmc_status s_ = elbo_collect_core(ctx, &sl.sub[i], slot, &sp, "vbmc_elbo_multi_collect");
-      if (s_) { fail = comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(ctx)); continue; }
+      vbmc_ctx* sc = ctx->slot_where[slot] ? ctx->slot_where[slot] : ctx;
+      vbmc_status s_ = elbo_collect_core(sc, &sl.sub[i], ctx->slot_where[slot] ? ctx->slot_inner[slot] : slot, &sp, "vbmc_elbo_multi_collect");
+      if (s_) { fail = comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(sc)); continue; }
+      if (sc != ctx) {
+        hipError_t e_ = hipEventSynchronize(ctx->slot_zev[slot]);
+        if (e_ != hipSuccess) { (void)hipGetLastError(); fail = comm_err(c, VBMC_ERR_HIP, "device %d: %s", ctx->device, hipGetErrorString(e_)); continue; }
+      }
       vbmc_elbo_args view = *a;            // the caller's arrays; F and varG come from the gathered vectors below
       view.F = nullptr; view.varG = nullptr;
       elbo_unpack(sp->P, &view, sp->hout, c->rank0 + i, G);

@@ -78,6 +78,13 @@ extern "C" void vbmc_ctx_destroy(vbmc_ctx* ctx) {
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (vbmc_ctx* sc : ctx->slot_sub)
+    if (sc) vbmc_ctx_destroy(sc);
+  for (int sl = 0; sl < VBMC_SLOTS; ++sl) {
+    if (ctx->slot_xev[sl]) (void)hipEventDestroy(ctx->slot_xev[sl]);
+    if (ctx->slot_yev[sl]) (void)hipEventDestroy(ctx->slot_yev[sl]);
+    if (ctx->slot_zev[sl]) (void)hipEventDestroy(ctx->slot_zev[sl]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -87,6 +94,8 @@ extern "C" const char* vbmc_last_error(const vbmc_ctx* ctx) { return ctx ? ctx->
 extern "C" vbmc_status vbmc_ctx_synchronize(vbmc_ctx* ctx) {
   if (!ctx) return VBMC_ERR_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (vbmc_ctx* sc : ctx->slot_sub)
+    if (sc) HIP_TRY(ctx, hipStreamSynchronize(sc->stream));
   return VBMC_OK;
 }
 
@@ -1266,10 +1275,54 @@ static vbmc_status elbo_submit_mark(vbmc_ctx* ctx, int slot, const char* who) {
   return VBMC_OK;
 }
 
+// The context (and its slot) a pass submitted into public slot `slot` runs on: child context slot & 1, its slot slot >> 1 (see
+// vbmc_ctx.slot_sub) for the optimiser-loop / sieve form of the call; this context itself, slots 0 and 1 only, for the variance forms
+// (their lazily built per-surrogate blocks live in the parent's pool) and under VBMC_SLOT_STREAMS=0 (A/B runs).  The child's stream is
+// ordered after everything enqueued on the parent's stream so far (a surrogate uploaded, draws produced there).
+static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vbmc_ctx** out, int* inner) {
+  static const bool off = [] { const char* e = getenv("VBMC_SLOT_STREAMS"); return e && !strcmp(e, "0"); }();
+  *out = ctx; *inner = slot;
+  if (slot < 0 || slot >= VBMC_SLOTS) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slot must be 0 .. %d", VBMC_SLOTS - 1);
+  if (off || ctx->is_sub || !a || a->compute_var != 0) {
+    if (slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slots 2 and 3 exist for passes without a variance term (and not under VBMC_SLOT_STREAMS=0)");
+    return VBMC_OK;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int ch = slot & 1;
+  if (!ctx->slot_sub[ch]) {
+    vbmc_ctx* sc = nullptr;
+    vbmc_status st = vbmc_ctx_create(ctx->device, nullptr, &sc);
+    if (st != VBMC_OK) return set_err(ctx, st, "vbmc_elbo_submit: no stream for slot %d", slot);
+    sc->is_sub = true;
+    ctx->slot_sub[ch] = sc;
+  }
+  if (!ctx->slot_xev[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_xev[slot], hipEventDisableTiming));
+  vbmc_ctx* sc = ctx->slot_sub[ch];
+  sc->profiling = false;
+  HIP_TRY(ctx, hipEventRecord(ctx->slot_xev[slot], ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(sc->stream, ctx->slot_xev[slot], 0));
+  *out = sc; *inner = slot >> 1;
+  return VBMC_OK;
+}
+// an error of the child context reported through the parent the caller holds
+static vbmc_status slot_err(vbmc_ctx* ctx, vbmc_ctx* sc, vbmc_status st) {
+  if (st != VBMC_OK && sc != ctx) ctx->err = sc->err;
+  return st;
+}
+static bool slot_in_flight(const vbmc_ctx* ctx, int slot) {
+  return slot >= 0 && slot < VBMC_SLOTS && ctx->slot_where[slot] && ctx->slot_where[slot]->slot_busy[ctx->slot_inner[slot]] &&
+         (ctx->slot_where[slot] != ctx || ctx->slot_inner[slot] == slot);
+}
+
 extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot) {
   if (!ctx) return VBMC_ERR_INVALID;
-  { vbmc_status s_ = elbo_submit_core(ctx, gp, a, slot, "vbmc_elbo_submit"); if (s_) return s_; }
-  return elbo_submit_mark(ctx, slot, "vbmc_elbo_submit");
+  if (slot_in_flight(ctx, slot)) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_submit: slot %d holds an uncollected pass", slot);
+  vbmc_ctx* sc = ctx;
+  int inner = slot;
+  { vbmc_status s_ = slot_ctx(ctx, a, slot, &sc, &inner); if (s_) return s_; }
+  { vbmc_status s_ = elbo_submit_core(sc, gp, a, inner, "vbmc_elbo_submit"); if (s_) return slot_err(ctx, sc, s_); }
+  ctx->slot_where[slot] = sc; ctx->slot_inner[slot] = inner;
+  return slot_err(ctx, sc, elbo_submit_mark(sc, inner, "vbmc_elbo_submit"));
 }
 
 // waits for the pass submitted in `slot`; *sp_out: its plan and the pinned block its results landed in
@@ -1293,7 +1346,10 @@ static vbmc_status elbo_collect_core(vbmc_ctx* ctx, const vbmc_elbo_args* a, int
 extern "C" vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot) {
   if (!ctx) return VBMC_ERR_INVALID;
   const SlotPlan* sp = nullptr;
-  { vbmc_status s_ = elbo_collect_core(ctx, a, slot, &sp, "vbmc_elbo_collect"); if (s_) return s_; }
+  if (slot < 0 || slot >= VBMC_SLOTS) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: slot must be 0 .. %d", VBMC_SLOTS - 1);
+  if (!slot_in_flight(ctx, slot)) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_collect: nothing submitted in slot %d", slot);
+  vbmc_ctx* sc = ctx->slot_where[slot];
+  { vbmc_status s_ = elbo_collect_core(sc, a, ctx->slot_inner[slot], &sp, "vbmc_elbo_collect"); if (s_) return slot_err(ctx, sc, s_); }
   elbo_unpack(sp->P, a, sp->hout);
   return VBMC_OK;
 }

@@ -55,6 +55,22 @@ struct vbmc_ctx {
   hipEvent_t slot_ev[2] = {nullptr, nullptr};
   void* slot_plan[2] = {nullptr, nullptr};     // ElboPlan*
   bool slot_busy[2] = {false, false};
+  // Round 4: FOUR slots on TWO streams.  Slot s runs on child context s & 1 (own stream, own scratch, created on first use) as that
+  // child's slot s >> 1 -- two passes queued per stream, two streams: the small kernels at the head and tail of one pass and the last round
+  // of waves of another share the chip instead of queuing behind each other, and a stream never runs dry while the host collects and
+  // re-submits (tools/r4_two_ctx.py: the headline step 2.45 -> 2.41 ms, eight restarts 0.358 -> 0.336, four 0.221 -> 0.183).
+  // slot_sub[]: the children; slot_where[s] / slot_inner[s]: the context and its slot the pass in flight was enqueued on (this context
+  // itself, slots 0 and 1 only, for the variance forms and under VBMC_SLOT_STREAMS=0); slot_xev[s] orders the child's stream after
+  // everything enqueued on this context's stream before the submit; slot_yev / slot_zev serve vbmc_elbo_multi_submit, whose exchange
+  // stays on this context's stream (ordered after the pass; its end).
+#define VBMC_SLOTS 4
+  vbmc_ctx* slot_sub[2] = {nullptr, nullptr};
+  vbmc_ctx* slot_where[VBMC_SLOTS] = {};
+  int slot_inner[VBMC_SLOTS] = {};
+  hipEvent_t slot_xev[VBMC_SLOTS] = {};
+  hipEvent_t slot_yev[VBMC_SLOTS] = {};
+  hipEvent_t slot_zev[VBMC_SLOTS] = {};
+  bool is_sub = false;
   // entropy-only evaluations (vbmc_elbo_batch with gp == NULL): a one-point surrogate with alpha = 0 and a zero mean
   // function per dimension, whose expected log joint is exactly 0
   vbmc_gp* null_gp[33] = {};

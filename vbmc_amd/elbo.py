@@ -433,12 +433,16 @@ class PreparedObjective:
         return F, dF
 
     def stream(self, batches, seeds=None):
-        """Generator over an iterable of theta batches (T x R each): yields (F, dF) copies in order, two batches in flight."""
+        """Generator over an iterable of theta batches (T x R each): yields (F, dF) copies in order, four batches in flight (two per
+        stream; two in all for the variance forms, which stay on the context's own stream)."""
         pending = []
+        import os
+
+        depth = 4 if int(self.args.compute_var) == 0 and os.environ.get("VBMC_SLOT_STREAMS") != "0" else 2
         for i, th in enumerate(batches):
-            self.submit(th, seed=(seeds[i] if seeds is not None else i), slot=i & 1)
-            pending.append(i & 1)
-            if len(pending) == 2:
+            self.submit(th, seed=(seeds[i] if seeds is not None else i), slot=i % depth)
+            pending.append(i % depth)
+            if len(pending) == depth:
                 F, dF = self.collect(pending.pop(0))
                 yield F.copy(), dF.copy()
         while pending:

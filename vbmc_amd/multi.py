@@ -9,7 +9,7 @@ points a MATLAB host binds through matlab/vbmc_hip_mex.cpp ('comm_open', 'elbo_b
     out = comm.negelcbo_batch(thetas, 0, vp, gps, Ns, ...)    # the R restarts dealt r = g (mod G); F / varG all-gathered
 
     po = comm.prepare(T, R, 0, vp, gps, Ns)   # the same objective with everything resolved once; po(thetas, seed) blocks,
-    po.submit(thetas, seed, slot); F, dF = po.collect(slot)   # ... or two batches in flight (vbmc_elbo_multi_submit / _collect)
+    po.submit(thetas, seed, slot); F, dF = po.collect(slot)   # ... or up to four batches in flight (vbmc_elbo_multi_submit / _collect)
 
 The restart axis (misc/vpsieve_vbmc.m:74-78, misc/vpoptimize_vbmc.m:49) is the one the path shards over.  Every rank
 evaluates the estimator the one-GPU batch evaluates, sample for sample (the device stream of a restart is keyed by its index in the
@@ -169,7 +169,7 @@ class PreparedMulti:
     """negelcbo_vbmc(theta, beta, vp, gp, Ns, 1, compute_var, 0, thetabnd) for batches (T, R) dealt over the communicator's ranks
     (the multi-GPU sibling of vbmc_amd.elbo.PreparedObjective): the argument struct, the fixed vp groups, the bounds and the output
     buffers are built once; a call copies the new thetas into place.  __call__ blocks (vbmc_elbo_batch_multi); submit / collect keep
-    two batches in flight (vbmc_elbo_multi_submit / vbmc_elbo_multi_collect): F of ALL R restarts, dF of the restarts this process
+    up to four batches in flight (slots 0 .. 3; vbmc_elbo_multi_submit / vbmc_elbo_multi_collect): F of ALL R restarts, dF of the restarts this process
     evaluated (NaN elsewhere)."""
 
     def __init__(self, comm, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None):
