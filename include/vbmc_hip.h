@@ -50,7 +50,11 @@ void vbmc_ctx_destroy(vbmc_ctx* ctx);
 const char* vbmc_last_error(const vbmc_ctx* ctx);
 vbmc_status vbmc_ctx_synchronize(vbmc_ctx* ctx);
 /* When enabled, HIP events bracket the dominant kernel (entropy MC) of every elbo call on the
- * context's stream; vbmc_ctx_last_kernel_ms returns its duration (bench.py roofline leg). */
+ * context's stream; vbmc_ctx_last_kernel_ms returns its duration (bench.py roofline leg).
+ * enable = 1: the call as it normally runs (a blocking call forks the expected log joint onto
+ * the context's second, low-priority stream, where it shares the chip with the dominant kernel
+ * and stretches its duration); enable = 2: nothing is forked beside it -- the duration of the
+ * kernel alone, the figure a roofline prices. */
 vbmc_status vbmc_ctx_set_profiling(vbmc_ctx* ctx, int enable);
 vbmc_status vbmc_ctx_last_kernel_ms(vbmc_ctx* ctx, double* ent_ms, double* logjoint_ms);
 

@@ -10,14 +10,23 @@ def main(path, n=40):
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = cur.execute("select %s, start, end from kernels order by start" % namecol).fetchall()[-n:]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = cur.execute("select %s, start, end, %s from kernels order by start" % (namecol, qcol)).fetchall()
+    try:      # memory copies, if traced (named by direction)
+        mc = [r[1] for r in cur.execute("pragma table_info(memory_copies)")]
+        if mc:
+            rows += [("copy:" + str(r[0]), r[1], r[2], -1) for r in cur.execute("select name, start, end from memory_copies").fetchall()]
+            rows.sort(key=lambda r: r[1])
+    except sqlite3.Error:
+        pass
+    rows = rows[-n:]
     t0 = rows[0][1]
     prev_end = None
-    print("| kernel | start us | end us | duration us | gap to the latest earlier end us |")
-    print("|---|---|---|---|---|")
-    for nm, s, e in rows:
+    print("| kernel | queue | start us | end us | duration us | gap to the latest earlier end us |")
+    print("|---|---|---|---|---|---|")
+    for nm, s, e, q in rows:
         gap = "" if prev_end is None else "%.1f" % ((s - prev_end) / 1e3)
-        print("| `%s` | %.1f | %.1f | %.1f | %s |" % (nm[:40], (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, gap))
+        print("| `%s` | %s | %.1f | %.1f | %.1f | %s |" % (nm[:40], q, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, gap))
         prev_end = e if prev_end is None else max(prev_end, e)
 
 

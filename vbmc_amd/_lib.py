@@ -10,6 +10,13 @@ import os
 
 import numpy as np
 
+# The pipelined step keeps several streams of one context busy at a time (the two pass streams behind the four slots, the exchange
+# stream of a communicator, the context's own and its forked log joint); the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
+# hardware queues (four by default), and two busy streams that share a queue run one after the other (profiles/r04_experiments.md
+# section 11: the R = 8 step 0.34 -> 0.51 ms when that happens).  The runtime reads the variable when it initialises, i.e. at the
+# first HIP call of the process: it is set here, before the library is loaded, and a value already in the environment is kept.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VBMC_HIP_LIB: an alternative build of the SAME library (kernel A/B experiments, tools/ent_experiments.py)
 LIB_PATH = os.environ.get("VBMC_HIP_LIB") or os.path.join(_HERE, "lib", "libvbmc_hip.so")
@@ -190,7 +197,8 @@ class Context:
         self.check(self.lib.vbmc_ctx_synchronize(self.h))
 
     def set_profiling(self, on=True):
-        self.check(self.lib.vbmc_ctx_set_profiling(self.h, 1 if on else 0))
+        """on = 2: the dominant kernel timed ALONE (the log joint is not forked beside it), see include/vbmc_hip.h"""
+        self.check(self.lib.vbmc_ctx_set_profiling(self.h, 2 if (on is not True and on == 2) else (1 if on else 0)))
 
     def last_kernel_ms(self):
         a, b = C.c_double(), C.c_double()

@@ -74,6 +74,10 @@ struct vbmc_comm {
   size_t cap = 0;
   RcclApi* api = nullptr;
   std::string err;
+  // the pipelined form's exchange stream per local device: the collectives of consecutive batches in issue order on ONE stream that
+  // holds nothing else (a pass on a slot stream is ordered after the context's stream, abi_elbo.hip: slot_ctx -- with the exchange on
+  // the context's stream every pass would queue behind the previous batch's exchange)
+  std::vector<hipStream_t> xs;
   // pipelined form (vbmc_elbo_multi_submit / _collect): per slot its own exchange blocks, a pinned landing block for the gathered
   // vectors and what collect needs to know about the submitted batch
   struct Slot {
@@ -84,6 +88,7 @@ struct vbmc_comm {
     std::vector<std::vector<double>> theta;   // its columns of theta, gathered (capacity kept between calls)
     std::vector<vbmc_elbo_args> sub;
     std::vector<double*> d_send, d_recv;
+    std::vector<hipStream_t> xst;             // the stream local device i's exchange was enqueued on
     size_t cap = 0;
     double* h_gather = nullptr;
     size_t h_cap = 0;
@@ -143,6 +148,7 @@ extern "C" void vbmc_comm_destroy(vbmc_comm* c) {
       if (i < (int)sl.d_send.size() && sl.d_send[i]) (void)hipFree(sl.d_send[i]);
       if (i < (int)sl.d_recv.size() && sl.d_recv[i]) (void)hipFree(sl.d_recv[i]);
     }
+    if (i < (int)c->xs.size() && c->xs[i]) { (void)hipStreamSynchronize(c->xs[i]); (void)hipStreamDestroy(c->xs[i]); }
     if (c->own_ctx && c->ctx[i]) vbmc_ctx_destroy(c->ctx[i]);
   }
   for (auto& sl : c->slot)
@@ -204,10 +210,11 @@ extern "C" vbmc_status vbmc_comm_create_rank(vbmc_ctx* ctx, int rank, int world,
 }
 
 // the collective itself: every local device contributes `count` doubles, every device receives world * count in rank order
-static vbmc_status comm_allgather_enqueue(vbmc_comm* c, const double* const* d_send, double* const* d_recv, size_t count) {
+static vbmc_status comm_allgather_enqueue(vbmc_comm* c, const double* const* d_send, double* const* d_recv, size_t count,
+                                          const hipStream_t* on = nullptr) {
   COMM_NCCL(c, c->api->GroupStart());
   for (int i = 0; i < c->n; ++i) {
-    ncclResult_t r = c->api->AllGather(d_send[i], d_recv[i], count, ncclDouble, c->comm[i], c->ctx[i]->stream);
+    ncclResult_t r = c->api->AllGather(d_send[i], d_recv[i], count, ncclDouble, c->comm[i], on ? on[i] : c->ctx[i]->stream);
     if (r != ncclSuccess) { (void)c->api->GroupEnd(); return comm_err(c, VBMC_ERR_HIP, "ncclAllGather: %s", c->api->GetErrorString(r)); }
   }
   COMM_NCCL(c, c->api->GroupEnd());
@@ -404,6 +411,7 @@ static vbmc_status comm_slot_reserve(vbmc_comm* c, vbmc_comm::Slot& sl, size_t c
     for (int i = 0; i < c->n; ++i) {
       COMM_HIP(c, hipSetDevice(c->ctx[i]->device));
       COMM_HIP(c, hipStreamSynchronize(c->ctx[i]->stream));
+      if (i < (int)c->xs.size() && c->xs[i]) COMM_HIP(c, hipStreamSynchronize(c->xs[i]));
       if (sl.d_send[i]) COMM_HIP(c, hipFree(sl.d_send[i]));
       if (sl.d_recv[i]) COMM_HIP(c, hipFree(sl.d_recv[i]));
       sl.d_send[i] = sl.d_recv[i] = nullptr;
@@ -440,6 +448,8 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
   sl.R = R; sl.T = T; sl.P = P;
   sl.n.assign(c->n, 0); sl.st.assign(c->n, VBMC_OK);
   if ((int)sl.theta.size() != c->n) { sl.theta.resize(c->n); sl.sub.resize(c->n); }
+  if ((int)c->xs.size() != c->n) c->xs.assign(c->n, nullptr);
+  sl.xst.assign(c->n, nullptr);
   vbmc_status local_fail = VBMC_OK;
   for (int i = 0; i < c->n; ++i) {
     const int g = c->rank0 + i;
@@ -457,8 +467,9 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
       if (th.size() < (size_t)T * n) th.resize((size_t)T * n);
       for (int q = 0; q < n; ++q) memcpy(&th[(size_t)q * T], a->theta + (size_t)(g + (size_t)q * G) * T, T * sizeof(double));
       sub.theta = th.data();
-      // the pass on the slot's own stream (abi_elbo.hip: slot_ctx); the pick and the exchange stay on the context's stream, ordered
-      // after the pass by an event -- consecutive collectives of one communicator on one stream, passes of consecutive batches overlapping
+      // the pass on the slot's own stream (abi_elbo.hip: slot_ctx), the pick after it on the same stream; the exchange on the
+      // communicator's exchange stream, ordered after the pick by an event: the collectives of one communicator in issue order on one
+      // stream, the passes of consecutive batches overlapping
       vbmc_ctx* sc = ctx;
       int inner = slot;
       if (slot_in_flight(ctx, slot)) st = set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot %d holds an uncollected pass", slot);
@@ -472,20 +483,34 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
     const size_t OS = OUT_HDR + 3 * (size_t)T;
     const double* dout = n > 0 ? (const double*)((const SlotPlan*)ctx->slot_where[slot]->slot_plan[ctx->slot_inner[slot]])->P.d_out : nullptr;
     // the pick runs on the stream the pass ran on (the result records are that stream's scratch: the next pass queued there overwrites
-    // them); the exchange on the context's own stream waits for it
+    // them)
     vbmc_ctx* ps = (n > 0 && ctx->slot_where[slot]) ? ctx->slot_where[slot] : ctx;
-    hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, ps->stream, n, P, n > 0 ? OS : (size_t)1, dout, sl.d_send[i]);
+    // VBMC_COMM_XS (A/B): 1 = the exchange stream (default), 2 = at high priority, 0 = no exchange stream: each exchange on the
+    // stream of its pass (the communicator then sees alternating streams)
+    static const int xs_mode = [] { const char* e = getenv("VBMC_COMM_XS"); return e ? atoi(e) : 1; }();
+    hipStream_t xst = ps->stream;
+    if (ps != ctx && xs_mode != 0) {
+      if (!c->xs[i]) {
+        int lo = 0, hi = 0;
+        COMM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        COMM_HIP(c, hipStreamCreateWithPriority(&c->xs[i], hipStreamNonBlocking, xs_mode == 2 ? hi : 0));
+      }
+      xst = c->xs[i];
+    }
+    if (n == 0 && c->xs[i]) xst = c->xs[i];     // a device without restarts: where this communicator's exchanges have been running
+    sl.xst[i] = xst;
+    hipLaunchKernelGGL(k_comm_pick, dim3((P + 63) / 64), dim3(64), 0, n > 0 ? ps->stream : xst, n, P, n > 0 ? OS : (size_t)1, dout, sl.d_send[i]);
     COMM_HIP(c, hipGetLastError());
-    if (ps != ctx) {
+    if (n > 0 && xst != ps->stream) {
       if (!ctx->slot_yev[slot]) COMM_HIP(c, hipEventCreateWithFlags(&ctx->slot_yev[slot], hipEventDisableTiming));
       COMM_HIP(c, hipEventRecord(ctx->slot_yev[slot], ps->stream));
-      COMM_HIP(c, hipStreamWaitEvent(ctx->stream, ctx->slot_yev[slot], 0));
+      COMM_HIP(c, hipStreamWaitEvent(xst, ctx->slot_yev[slot], 0));
     }
   }
   const std::string keep = c->err;
-  { vbmc_status s_ = comm_allgather_enqueue(c, sl.d_send.data(), sl.d_recv.data(), 2 * (size_t)P); if (s_) return s_; }
+  { vbmc_status s_ = comm_allgather_enqueue(c, sl.d_send.data(), sl.d_recv.data(), 2 * (size_t)P, sl.xst.data()); if (s_) return s_; }
   COMM_HIP(c, hipSetDevice(c->ctx[0]->device));
-  COMM_HIP(c, hipMemcpyAsync(sl.h_gather, sl.d_recv[0], 2 * (size_t)P * G * sizeof(double), hipMemcpyDeviceToHost, c->ctx[0]->stream));
+  COMM_HIP(c, hipMemcpyAsync(sl.h_gather, sl.d_recv[0], 2 * (size_t)P * G * sizeof(double), hipMemcpyDeviceToHost, sl.xst[0]));
   for (int i = 0; i < c->n; ++i) {
     vbmc_ctx* ctx = c->ctx[i];
     COMM_HIP(c, hipSetDevice(ctx->device));
@@ -493,9 +518,9 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
       vbmc_ctx* sc = ctx->slot_where[slot];
       vbmc_status s_ = elbo_submit_mark(sc, ctx->slot_inner[slot], "vbmc_elbo_multi_submit");
       if (s_) return comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(sc));
-      if (sc != ctx) {     // the exchange (and, on local device 0, the copy of the gathered vectors) ends on the context's own stream
+      if (sl.xst[i] != sc->stream) {     // the exchange (and, on local device 0, the copy of the gathered vectors) ends on the exchange stream
         if (!ctx->slot_zev[slot]) COMM_HIP(c, hipEventCreateWithFlags(&ctx->slot_zev[slot], hipEventDisableTiming));
-        COMM_HIP(c, hipEventRecord(ctx->slot_zev[slot], ctx->stream));
+        COMM_HIP(c, hipEventRecord(ctx->slot_zev[slot], sl.xst[i]));
       }
     }
   }
@@ -503,6 +528,7 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
     for (int i = 0; i < c->n; ++i) {
       (void)hipSetDevice(c->ctx[i]->device);
       (void)hipStreamSynchronize(c->ctx[i]->stream);
+      if (sl.xst[i]) (void)hipStreamSynchronize(sl.xst[i]);
       if (c->ctx[i]->slot_where[slot]) {
         (void)hipStreamSynchronize(c->ctx[i]->slot_where[slot]->stream);
         c->ctx[i]->slot_where[slot]->slot_busy[c->ctx[i]->slot_inner[slot]] = false;
@@ -534,7 +560,7 @@ extern "C" vbmc_status vbmc_elbo_multi_collect(vbmc_comm* c, const vbmc_elbo_arg
       vbmc_ctx* sc = ctx->slot_where[slot] ? ctx->slot_where[slot] : ctx;
       vbmc_status s_ = elbo_collect_core(sc, &sl.sub[i], ctx->slot_where[slot] ? ctx->slot_inner[slot] : slot, &sp, "vbmc_elbo_multi_collect");
       if (s_) { fail = comm_err(c, s_, "device %d: %s", ctx->device, vbmc_last_error(sc)); continue; }
-      if (sc != ctx) {
+      if (sl.xst[i] != sc->stream) {
         hipError_t e_ = hipEventSynchronize(ctx->slot_zev[slot]);
         if (e_ != hipSuccess) { (void)hipGetLastError(); fail = comm_err(c, VBMC_ERR_HIP, "device %d: %s", ctx->device, hipGetErrorString(e_)); continue; }
       }
@@ -542,10 +568,10 @@ extern "C" vbmc_status vbmc_elbo_multi_collect(vbmc_comm* c, const vbmc_elbo_arg
       view.F = nullptr; view.varG = nullptr;
       elbo_unpack(sp->P, &view, sp->hout, c->rank0 + i, G);
     } else {
-      COMM_HIP(c, hipStreamSynchronize(ctx->stream));     // a device without restarts still took part in the exchange
+      COMM_HIP(c, hipStreamSynchronize(sl.xst[i]));     // a device without restarts still took part in the exchange
     }
   }
-  if (c->n > 0 && sl.n[0] == 0) COMM_HIP(c, hipStreamSynchronize(c->ctx[0]->stream));
+  if (c->n > 0 && sl.n[0] == 0) COMM_HIP(c, hipStreamSynchronize(sl.xst[0]));
   if (fail) return fail;
   for (int r = 0; r < R; ++r) {
     const int g = r % G, q = r / G;

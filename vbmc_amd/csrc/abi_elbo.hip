@@ -36,12 +36,10 @@ extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out)
   for (auto& e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return VBMC_ERR_HIP; }
   {
-    int lo = 0, hi = 0;   // numerically larger = lower priority
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     const char* ov = getenv("VBMC_LJ_OVERLAP");   // "0": everything on one stream (A/B testing)
     ctx->overlap = !(ov && !strcmp(ov, "0"));
-    if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    // (the second stream itself on first use, common.h: ctx_aux -- a context that never forks holds one stream)
+    if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
       delete ctx;
       return VBMC_ERR_HIP;
@@ -102,6 +100,7 @@ extern "C" vbmc_status vbmc_ctx_synchronize(vbmc_ctx* ctx) {
 extern "C" vbmc_status vbmc_ctx_set_profiling(vbmc_ctx* ctx, int enable) {
   if (!ctx) return VBMC_ERR_INVALID;
   ctx->profiling = enable != 0;
+  ctx->prof_alone = enable == 2;
   return VBMC_OK;
 }
 
@@ -835,7 +834,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   }
 
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
-  const bool fork = sh.mode == 0 && ctx->overlap && P.mc && (long long)S * R >= ctx->num_cu / 2;   // a single chain: the fork / join events cost more than they hide
+  // ... and so does a pass on a slot stream: the pass on the other slot stream is what fills in around its entropy kernel, and a log
+  // joint forked off there is the last to be let onto the chip (profiles/r04_experiments.md section 11)
+  const bool fork = sh.mode == 0 && P.mc && (long long)S * R >= ctx->num_cu / 2 && !ctx->prof_alone && ctx_aux(ctx);   // a single chain: the fork / join events cost more than they hide
   // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
   const char* ljf = getenv("VBMC_LJ_KERNEL");
   // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
@@ -1294,6 +1295,8 @@ static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vb
     vbmc_status st = vbmc_ctx_create(ctx->device, nullptr, &sc);
     if (st != VBMC_OK) return set_err(ctx, st, "vbmc_elbo_submit: no stream for slot %d", slot);
     sc->is_sub = true;
+    static const bool sub_fork = [] { const char* e = getenv("VBMC_SUB_FORK"); return e && !strcmp(e, "1"); }();   // A/B (round 4)
+    if (!sub_fork) sc->overlap = false;     // no fork on a slot stream (elbo_enqueue): one stream per child, not two
     ctx->slot_sub[ch] = sc;
   }
   if (!ctx->slot_xev[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_xev[slot], hipEventDisableTiming));

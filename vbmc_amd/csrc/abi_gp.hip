@@ -233,7 +233,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, st, N, dA.as<double>(), dones.as<unsigned char>(), dfinv.as<double>());
   hipStream_t sa = st;
   f.alpha_event = false;
-  if (alpha_aside && ctx->aux && ctx->ev_fork && ctx->ev_join) {
+  if (alpha_aside && ctx->ev_fork && ctx->ev_join && ctx_aux(ctx)) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     sa = ctx->aux;

@@ -33,6 +33,7 @@ struct vbmc_ctx {
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
+  bool prof_alone = false;     // vbmc_ctx_set_profiling(ctx, 2): nothing forked beside the dominant kernel while it is timed
   void* bounce = nullptr;                       // (unused since round 2: see d2h_bounced)
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
   std::string err;
@@ -75,6 +76,23 @@ struct vbmc_ctx {
   // function per dimension, whose expected log joint is exactly 0
   vbmc_gp* null_gp[33] = {};
 };
+
+// The context's second stream (low priority: what is forked onto it fills in around the kernels of the first), created on first use:
+// a context that never forks -- the children behind the pipeline slots -- holds ONE stream.  The runtime maps streams onto a few
+// hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise), and two busy streams that share a queue run one after the other.
+static inline bool ctx_aux(vbmc_ctx* ctx) {
+  if (!ctx->overlap) return false;
+  if (ctx->aux) return true;
+  int lo = 0, hi = 0;   // numerically larger = lower priority
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, lo) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->aux = nullptr;
+    ctx->overlap = false;
+    return false;
+  }
+  return true;
+}
 
 static inline hipError_t pool_get(vbmc_ctx* ctx, size_t bytes, void** out) {
   if (bytes < 256) bytes = 256;
