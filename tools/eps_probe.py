@@ -21,29 +21,38 @@ theta0 = np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]),
 dev = torch.device("cuda:0")
 
 
-def run(R, mode):
+def setup(R, mode):
     th = np.asfortranarray(theta0[:, None] + 0.05 * np.random.default_rng(100).standard_normal((theta0.size, R)))
     kw = dict(engine=eng, outputs=("F", "dF"))
+    keep = None
     if mode != "rng":
         g = torch.Generator(device=dev)
         g.manual_seed(1)
         shape = (1 if mode == "shared" else R, K, Ns // 2, D)
-        eps_d = torch.randn(shape, dtype=torch.float64, device=dev, generator=g)
-        if mode == "zeros":
-            eps_d.zero_()
+        keep = torch.randn(shape, dtype=torch.float64, device=dev, generator=g)
         torch.cuda.synchronize()
-        kw.update(eps_device_ptr=eps_d.data_ptr(), eps_shared=(mode == "shared"))
-    for _ in range(2):
-        vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, **kw)
-    eng.ctx.set_profiling(True)
+        kw.update(eps_device_ptr=keep.data_ptr(), eps_shared=(mode == "shared"))
+    return th, kw, keep
+
+
+def measure(th, kw, n=6):
+    eng.ctx.set_profiling(2)
     ems = []
-    for _ in range(6):
+    for _ in range(n):
         vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, **kw)
         ems.append(eng.ctx.last_kernel_ms()[0])
     eng.ctx.set_profiling(False)
-    return float(np.median(ems))
+    return ems
 
 
 for R in (64, 8):
-    for mode in ("rng", "distinct", "shared"):
-        print("R=%d %-9s entropy kernel %.3f ms" % (R, mode, run(R, mode)), flush=True)
+    cases = {m: setup(R, m) for m in ("rng", "distinct", "shared")}
+    for m in cases:                       # warm: code pages, clocks
+        measure(*cases[m][:2], n=12)
+    ems = {m: [] for m in cases}
+    for rnd in range(4):                  # interleaved: the clocks drift over a run
+        for m in cases:
+            ems[m] += measure(*cases[m][:2])
+    for m in cases:
+        print("R=%d %-9s entropy kernel median %.3f min %.3f ms" % (R, m, float(np.median(ems[m])), float(np.min(ems[m]))), flush=True)
+    del cases
