@@ -14,7 +14,11 @@
 // ------------------------------------------------------------------------------------------
 extern "C" int vbmc_abi_version(void) { return VBMC_ABI_VERSION; }
 
-extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out) {
+// with_aux: the second stream is created WITH the context (a caller's context: its blocking calls fork the expected log joint onto it);
+// a child behind the pipeline slots never forks and holds one stream.  Created beside the first stream, not on first use: a
+// low-priority stream that comes into being after the slot streams no longer yields to the first stream's kernel (the blocking call
+// at the headline shape 2.50 -> 2.64 ms, tools/r4_blocking_probe.py).
+static vbmc_status ctx_create_impl(int device, void* stream, vbmc_ctx** out, bool with_aux) {
   if (!out) return VBMC_ERR_INVALID;
   *out = nullptr;
   int ndev = 0;
@@ -38,7 +42,9 @@ extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out)
   {
     const char* ov = getenv("VBMC_LJ_OVERLAP");   // "0": everything on one stream (A/B testing)
     ctx->overlap = !(ov && !strcmp(ov, "0"));
-    // (the second stream itself on first use, common.h: ctx_aux -- a context that never forks holds one stream)
+    if (!with_aux) ctx->overlap = false;
+    const char* ea = getenv("VBMC_AUX_EAGER");   // "0": on first use (A/B, round 4)
+    if (with_aux && !(ea && !strcmp(ea, "0"))) (void)ctx_aux(ctx);
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
       delete ctx;
@@ -48,6 +54,7 @@ extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out)
   *out = ctx;
   return VBMC_OK;
 }
+extern "C" vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out) { return ctx_create_impl(device, stream, out, true); }
 
 static void elbo_plan_free(void* plan);   // (ElboPlan is defined further down)
 
@@ -1292,18 +1299,24 @@ static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vb
   const int ch = slot & 1;
   if (!ctx->slot_sub[ch]) {
     vbmc_ctx* sc = nullptr;
-    vbmc_status st = vbmc_ctx_create(ctx->device, nullptr, &sc);
+    static const bool sub_fork = [] { const char* e = getenv("VBMC_SUB_FORK"); return e && !strcmp(e, "1"); }();   // A/B (round 4)
+    vbmc_status st = ctx_create_impl(ctx->device, nullptr, &sc, sub_fork);     // no fork on a slot stream (elbo_enqueue): one stream per child
     if (st != VBMC_OK) return set_err(ctx, st, "vbmc_elbo_submit: no stream for slot %d", slot);
     sc->is_sub = true;
-    static const bool sub_fork = [] { const char* e = getenv("VBMC_SUB_FORK"); return e && !strcmp(e, "1"); }();   // A/B (round 4)
-    if (!sub_fork) sc->overlap = false;     // no fork on a slot stream (elbo_enqueue): one stream per child, not two
     ctx->slot_sub[ch] = sc;
   }
   if (!ctx->slot_xev[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_xev[slot], hipEventDisableTiming));
   vbmc_ctx* sc = ctx->slot_sub[ch];
   sc->profiling = false;
-  HIP_TRY(ctx, hipEventRecord(ctx->slot_xev[slot], ctx->stream));
-  HIP_TRY(ctx, hipStreamWaitEvent(sc->stream, ctx->slot_xev[slot], 0));
+  // ... when there is anything: an event recorded on an idle stream and waited for on another is still a device-side dependency between
+  // two queues, 15-30 us per step where a step is that short (tools/r4_host_cost.py: one restart at VBMC's own sample count 58 -> 27 us
+  // per step, BASELINE configs[1] 89 -> 52).  VBMC_SLOT_XEV=1: always (A/B).
+  static const int xev_mode = [] { const char* e = getenv("VBMC_SLOT_XEV"); return e ? atoi(e) : 2; }();
+  if (xev_mode == 1 || (xev_mode == 2 && hipStreamQuery(ctx->stream) != hipSuccess)) {
+    (void)hipGetLastError();
+    HIP_TRY(ctx, hipEventRecord(ctx->slot_xev[slot], ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(sc->stream, ctx->slot_xev[slot], 0));
+  }
   *out = sc; *inner = slot >> 1;
   return VBMC_OK;
 }

@@ -77,9 +77,9 @@ struct vbmc_ctx {
   vbmc_gp* null_gp[33] = {};
 };
 
-// The context's second stream (low priority: what is forked onto it fills in around the kernels of the first), created on first use:
-// a context that never forks -- the children behind the pipeline slots -- holds ONE stream.  The runtime maps streams onto a few
-// hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise), and two busy streams that share a queue run one after the other.
+// The context's second stream (low priority: what is forked onto it fills in around the kernels of the first).  A context that never
+// forks -- the children behind the pipeline slots -- holds ONE stream (overlap = false).  The runtime maps streams onto a few hardware
+// queues (four unless GPU_MAX_HW_QUEUES says otherwise), and two busy streams that share a queue run one after the other.
 static inline bool ctx_aux(vbmc_ctx* ctx) {
   if (!ctx->overlap) return false;
   if (ctx->aux) return true;
