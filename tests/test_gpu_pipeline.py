@@ -163,3 +163,32 @@ def test_log_joint_role_of_the_entropy_launch_matches_the_separate_kernel():
             o = R.negelcbo_vbmc(th[:, r], 0, vp, gp, 0, True, 0)
             assert abs(co["G"][r] - o["G"]) <= 1e-10 * abs(o["G"])
             assert np.max(np.abs(co["dG"][:, r] - np.asarray(o["dG"]).reshape(-1))) <= 1e-9 * np.max(np.abs(o["dG"]))
+
+
+def test_slot_streams_are_placed_by_measurement_in_a_process_with_other_queues(va):
+    """abi_elbo.hip: stream_beside -- a fresh context in a process that already holds other hardware queues (torch streams here) creates
+    its slot streams by measuring which candidates dispatch beside each other (tools/stream_pipes.hip, tools/r4_place_check.py); the
+    results do not depend on it, and a second context goes through the same procedure."""
+    import torch
+
+    keep = []
+    for _ in range(3):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            keep.append(torch.zeros(8, device="cuda") + 1)
+        s.synchronize()
+        keep.append(s)
+    p, gp, vp, batches = setup(va, 11, 6, 60, 9, 3, 8)
+    T = batches[0].shape[0]
+    ref_obj = va.PreparedObjective(T, 8, 0, vp, gp, 400, 0, None)
+    ref = [tuple(x.copy() for x in ref_obj(th, seed=40 + i)) for i, th in enumerate(batches)]
+    for _ in range(2):
+        eng = va.Engine(0)
+        try:
+            gp2 = va.gplite_post(p["hyp"], p["X"], p["y"], 1, p["meanfun"], engine=eng)
+            obj = va.PreparedObjective(T, 8, 0, vp, gp2, 400, 0, None, engine=eng)
+            got = list(obj.stream(batches, seeds=[40 + i for i in range(len(batches))]))
+            for (F0, dF0), (F1, dF1) in zip(ref, got):
+                assert np.array_equal(F0, F1) and np.array_equal(dF0, dF1)
+        finally:
+            eng.close() if hasattr(eng, "close") else None

@@ -86,8 +86,9 @@ Produced by `bash tools/profile_round.sh {tag}` on the MI355X box (`cd /tmp && e
 test suite, `python bench.py --extras`, `tools/bench_aux.py`, `tools/microbench.hip`, then
 `rocprofv3 --kernel-trace --stats` and two separate `--pmc` passes of
 `python bench.py [--steps 3 --warmup 1] --no-cpu-baseline --no-aux` (the timed region of the default command; the auxiliary legs and the CPU baseline run after it); assembled by `tools/compose_profile.py`.  {changes}
-`k_logjoint_mfma` runs on the second, lower-priority stream beside the entropy kernel: its traced duration is the span over
-which its workgroups were fitted into the entropy kernel's idle slots (alone it takes 0.14 ms, `r01_p6_summary.md`).
+In a blocking call `k_logjoint_mfma` runs on the context's second, lower-priority stream beside the entropy kernel: its traced duration there
+is the span over which its workgroups were fitted into the entropy kernel's idle slots (alone it takes 0.14 ms); in the pipelined steps it runs
+at the head of its pass on the slot stream, beside the other pass's entropy kernel.
 
 `pytest tests -m gpu`: **{rd('pytest_gpu.txt').splitlines()[-1]}**.
 
@@ -103,9 +104,18 @@ which its workgroups were fitted into the entropy kernel's idle slots (alone it 
 {last_json(rd('bench_traced.json'))}
 ```
 
-## Kernel trace (tools/rocpd_summary.py; 28 ELBO launches = 3 warm-up + 20 timed + 5 roofline-leg; k_chol / k_gp_* / k_alpha_solve = the one-off gplite_post that builds the synthetic GP posterior, outside the timed region)
+## Kernel trace (tools/rocpd_summary.py; 82 ELBO launches = 11 warm-up + 20 timed + 21 of the --sync-steps leg + 30 roofline-leg; k_chol / k_gp_* / k_alpha_solve = the one-off gplite_post that builds the synthetic GP posterior, outside the timed region)
 
 {rd('kernel_trace.md')}
+
+### The dominant kernel's launches by phase of the command (tools/rocpd_launches.py)
+
+In the pipelined steps four batches are in flight on two streams: the entropy kernel of one batch shares the chip with the log joint and
+the small kernels of the next, so its span is longer than its work and the spans of consecutive launches overlap (their sum exceeds the wall
+time).  `roofline.kernel_ms` of the bench line is the last phase -- the kernel alone on the device, `vbmc_ctx_set_profiling(ctx, 2)` -- and
+that is the row it has to agree with.
+
+{rd('kernel_phases.md') if os.path.exists(o + 'kernel_phases.md') else '(not collected in this run)'}
 
 ## Registers / LDS / scratch of the entropy kernels from the compiler's own metadata (`tools/isa_meta.py 3`)
 

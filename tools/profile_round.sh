@@ -7,6 +7,14 @@ tag=${1:-px}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if [ "${ONLY_TRACE:-0}" = "1" ]; then
+  rocprofv3 --kernel-trace --stats -d $out/t -o p -- python bench.py --no-cpu-baseline --no-aux > $out/bench_traced.json 2> $out/trace_stderr.txt
+  python tools/rocpd_summary.py $(find $out/t -name '*.db' | head -1) > $out/kernel_trace.md
+  python tools/rocpd_launches.py $(find $out/t -name '*.db' | head -1) k_entropy_mfma "pipelined steps (8 + 3 warm-up, 20 timed):31" "blocking calls, log joint forked beside it (21 of the --sync-steps leg, 10 of the roofline leg):31" "roofline leg, kernel alone (the figure bench.py prices):20" > $out/kernel_phases.md
+  rm -rf $out/t
+  cat $out/kernel_phases.md
+  exit 0
+fi
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -4 > $out/pytest_gpu.txt   # (RCCL prints a banner after pytest's last line)
 python bench.py --extras 2> $out/bench_stderr.txt | grep '^{' | tail -1 > $out/bench.json   # (RCCL prints a banner after the line when the process exits)
 python tools/bench_aux.py 2>/dev/null | grep '^{' | tail -1 > $out/bench_aux.json
@@ -14,6 +22,9 @@ vbmc_amd/lib/microbench > $out/microbench.json 2>&1
 [ -f profiles/isa_meta_qs3.txt ] && cp profiles/isa_meta_qs3.txt $out/isa_meta.txt
 rocprofv3 --kernel-trace --stats -d $out/t -o p -- python bench.py --no-cpu-baseline --no-aux > $out/bench_traced.json 2> $out/trace_stderr.txt
 python tools/rocpd_summary.py $(find $out/t -name '*.db' | head -1) > $out/kernel_trace.md
+# the dominant kernel's launches by phase of the command: 8 + 3 warm-up and 20 timed steps (pipelined: four batches in flight on two streams, the
+# kernels of consecutive batches overlap), then 21 + 10 blocking calls (log joint forked beside the kernel) and 20 with the kernel alone
+python tools/rocpd_launches.py $(find $out/t -name '*.db' | head -1) k_entropy_mfma "pipelined steps (8 + 3 warm-up, 20 timed):31" "blocking calls, log joint forked beside it (21 of the --sync-steps leg, 10 of the roofline leg):31" "roofline leg, kernel alone (the figure bench.py prices):20" > $out/kernel_phases.md
 rm -rf $out/t
 rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $out/a -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aux > /dev/null 2> $out/pmc_a_stderr.txt
 python tools/pmc_summary.py $(find $out/a -name '*.db' | head -1) > $out/pmc_a.md

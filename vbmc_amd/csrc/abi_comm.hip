@@ -490,10 +490,14 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
     static const int xs_mode = [] { const char* e = getenv("VBMC_COMM_XS"); return e ? atoi(e) : 1; }();
     hipStream_t xst = ps->stream;
     if (ps != ctx && xs_mode != 0) {
-      if (!c->xs[i]) {
+      if (!c->xs[i]) {     // beside both slot streams (abi_elbo.hip: stream_beside); they exist and, for the first batch, are idle but for this pass
         int lo = 0, hi = 0;
         COMM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        COMM_HIP(c, hipStreamCreateWithPriority(&c->xs[i], hipStreamNonBlocking, xs_mode == 2 ? hi : 0));
+        hipStream_t both[2];
+        int nb = 0;
+        for (vbmc_ctx* sub : ctx->slot_sub) if (sub) both[nb++] = sub->stream;
+        c->xs[i] = stream_beside(ctx, both, nb, xs_mode == 2 ? hi : 0);
+        if (!c->xs[i]) return comm_err(c, VBMC_ERR_HIP, "vbmc_elbo_multi_submit: no exchange stream");
       }
       xst = c->xs[i];
     }

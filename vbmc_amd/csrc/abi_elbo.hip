@@ -1283,6 +1283,67 @@ static vbmc_status elbo_submit_mark(vbmc_ctx* ctx, int slot, const char* who) {
   return VBMC_OK;
 }
 
+// ---- where a new stream lands.  The runtime gives a stream a hardware queue, and the k-th hardware queue a process creates sits on
+// dispatch pipe k mod 4 (tools/stream_pipes.hip, profiles/r04_experiments.md section 11): a kernel of a stream on the SAME pipe as a
+// stream whose large grid is being handed out waits until the last workgroup of that grid is out -- for the entropy kernel ten
+// elevenths of its duration -- and one on the same queue until it has finished.  Which queues exist when the slot streams are created
+// is the process's history (torch, RCCL, other contexts), so the placement is measured: a candidate stream is kept if a one-wave
+// kernel on it finishes early in the life of a long, low-occupancy kernel on each of the streams it has to run beside.
+__global__ void k_place_probe(long long ticks) {
+  extern __shared__ char probe_lds[];
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) { }
+  if (ticks < 0) probe_lds[threadIdx.x] = 0;
+}
+// when the small kernel on `b` finished, as a fraction of the long kernel on `a` (both streams idle before); 2 on any error
+static double place_ratio(int num_cu, hipStream_t a, hipStream_t b) {
+  hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+  double best = 2.0;
+  bool ok = true;
+  for (auto& ev : e) ok = ok && hipEventCreate(&ev) == hipSuccess;
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+  const long long ticks = (long long)(15e-6 * khz * 1e3);     // 15 us per workgroup, three rounds of four one-wave workgroups per compute unit
+  for (int rep = 0; ok && rep < 2; ++rep) {
+    ok = ok && hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess;
+    ok = ok && hipEventRecord(e[0], a) == hipSuccess;
+    hipLaunchKernelGGL(k_place_probe, dim3(num_cu * 12), dim3(64), 36 * 1024, a, ticks);
+    hipLaunchKernelGGL(k_place_probe, dim3(1), dim3(64), 0, b, ticks / 50);
+    ok = ok && hipEventRecord(e[1], b) == hipSuccess && hipEventRecord(e[2], a) == hipSuccess;
+    ok = ok && hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess;
+    float ts = 0.f, tl = 0.f;
+    ok = ok && hipEventElapsedTime(&ts, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&tl, e[0], e[2]) == hipSuccess;
+    if (ok && tl > 0.f) best = std::min(best, (double)ts / tl);
+  }
+  for (auto& ev : e) if (ev) (void)hipEventDestroy(ev);
+  if (!ok) (void)hipGetLastError();
+  return ok ? best : 2.0;
+}
+// a new stream that dispatches beside every stream of `beside` (up to six candidates; the first one if none does); VBMC_PLACE=0: unchecked
+static hipStream_t stream_beside(vbmc_ctx* ctx, const hipStream_t* beside, int nb, int priority = 0) {
+  static const bool off = [] { const char* e = getenv("VBMC_PLACE"); return e && !strcmp(e, "0"); }();
+  static const bool dbg = [] { const char* e = getenv("VBMC_DEBUG_PLACE"); return e && !strcmp(e, "1"); }();
+  hipStream_t cand[6];
+  int nc = 0;
+  hipStream_t pick = nullptr;
+  while (nc < 6 && !pick) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) { (void)hipGetLastError(); break; }
+    cand[nc++] = s;
+    bool ok = true;
+    for (int i = 0; i < nb && ok && !off; ++i) {
+      const double r = place_ratio(ctx->num_cu, beside[i], s);
+      if (dbg) fprintf(stderr, "[vbmc place] candidate %d beside stream %d: %.2f\n", nc - 1, i, r);
+      ok = r < 0.35;
+    }
+    if (ok) pick = s;
+  }
+  if (!pick && nc) pick = cand[0];
+  for (int i = 0; i < nc; ++i)
+    if (cand[i] != pick) (void)hipStreamDestroy(cand[i]);
+  return pick;
+}
+
 // The context (and its slot) a pass submitted into public slot `slot` runs on: child context slot & 1, its slot slot >> 1 (see
 // vbmc_ctx.slot_sub) for the optimiser-loop / sieve form of the call; this context itself, slots 0 and 1 only, for the variance forms
 // (their lazily built per-surrogate blocks live in the parent's pool) and under VBMC_SLOT_STREAMS=0 (A/B runs).  The child's stream is
@@ -1297,13 +1358,20 @@ static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vb
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int ch = slot & 1;
-  if (!ctx->slot_sub[ch]) {
-    vbmc_ctx* sc = nullptr;
+  if (!ctx->slot_sub[0] || !ctx->slot_sub[1]) {     // both children at once, before anything runs on either: the second beside the first
     static const bool sub_fork = [] { const char* e = getenv("VBMC_SUB_FORK"); return e && !strcmp(e, "1"); }();   // A/B (round 4)
-    vbmc_status st = ctx_create_impl(ctx->device, nullptr, &sc, sub_fork);     // no fork on a slot stream (elbo_enqueue): one stream per child
-    if (st != VBMC_OK) return set_err(ctx, st, "vbmc_elbo_submit: no stream for slot %d", slot);
-    sc->is_sub = true;
-    ctx->slot_sub[ch] = sc;
+    for (int c2 = 0; c2 < 2; ++c2) {
+      if (ctx->slot_sub[c2]) continue;
+      hipStream_t other = ctx->slot_sub[1 - c2] ? ctx->slot_sub[1 - c2]->stream : nullptr;
+      hipStream_t s = stream_beside(ctx, &other, other ? 1 : 0);
+      if (!s) return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_submit: no stream for slot %d", slot);
+      vbmc_ctx* sc = nullptr;
+      vbmc_status st = ctx_create_impl(ctx->device, s, &sc, sub_fork);     // no fork on a slot stream (elbo_enqueue): one stream per child
+      if (st != VBMC_OK) { (void)hipStreamDestroy(s); return set_err(ctx, st, "vbmc_elbo_submit: no stream for slot %d", slot); }
+      sc->own_stream = true;
+      sc->is_sub = true;
+      ctx->slot_sub[c2] = sc;
+    }
   }
   if (!ctx->slot_xev[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->slot_xev[slot], hipEventDisableTiming));
   vbmc_ctx* sc = ctx->slot_sub[ch];
