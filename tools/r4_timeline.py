@@ -75,6 +75,16 @@ def main():
     # finishing time per SIMD
     fin = np.array([ex[simdk == k].max() for k in np.unique(simdk)])
     print("last exit per SIMD [ms]: min %.3f median %.3f max %.3f" % (fin.min() / 1e5, np.median(fin) / 1e5, fin.max() / 1e5))
+    # where do the slow waves sit?  loop duration by XCC, by the number of waves of this launch on the wave's SIMD, by chunk index
+    dur = (le - ls) / 100.0
+    print("loop us by XCC: " + "  ".join("%d: %.0f/%.0f" % (x, np.median(dur[xcc == x]), dur[xcc == x].max()) for x in np.unique(xcc)) + "   (median/max)")
+    inv = np.unique(simdk, return_inverse=True)[1]
+    wps = waves_per_simd[inv]
+    print("loop us by waves on the SIMD: " + "  ".join("%d waves: n=%d median %.0f p90 %.0f" % (k, (wps == k).sum(), np.median(dur[wps == k]), np.percentile(dur[wps == k], 90)) for k in np.unique(wps)))
+    cuk = simdk >> 2
+    wpc = np.bincount(np.unique(cuk, return_inverse=True)[1])[np.unique(cuk, return_inverse=True)[1]]
+    print("loop us by waves on the CU: " + "  ".join("%d: n=%d med %.0f" % (k, (wpc == k).sum(), np.median(dur[wpc == k])) for k in np.unique(wpc)))
+    print("entry time us percentiles 1/50/99: " + " ".join("%.1f" % v for v in np.percentile(ent, [1, 50, 99]) / 100.0))
     tiles = (Ns // 2 + 15) // 16
     print("tile-signs per wave-loop: ~%.1f; loop ticks(10ns)/tile-sign median %.2f" % (2.0 * tiles * K * R / len(a), np.median(le - ls) / (2.0 * tiles * K * R / len(a))))
 
