@@ -60,3 +60,30 @@ def test_gaussian_target_elbo_and_mean(va):
     assert abs(st["elbo"] - 0.0) < 0.5, st["elbo"]          # test/runtest_vbmc.m:87 (lnZ = 0 for a normalised density)
     assert rmse < 0.5, (post_mean, mu_t)                    # test/runtest_vbmc.m:9
     assert st["elbo_sd"] < 0.5 and np.isfinite(varss)
+
+
+def test_profiling_modes_time_the_dominant_kernel_and_leave_the_results_alone(va):
+    """vbmc_ctx_set_profiling (include/vbmc_hip.h): 1 = the call as it runs (a blocking call forks the log joint beside the kernel),
+    2 = the kernel alone; both report a positive duration and neither changes a bit of the results."""
+    import numpy as np
+
+    from tests._cases import synth_problem
+
+    p = synth_problem(5, 10, 200, 50, 8)
+    eng = va.Engine(0)
+    gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, p["meanfun"], engine=eng)
+    vp = va.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    th = np.asfortranarray(theta[:, None] + 0.05 * np.random.default_rng(5).standard_normal((theta.size, 32)))
+    outs = []
+    for mode in (False, 1, 2):
+        eng.ctx.set_profiling(mode)
+        o = va.negelcbo_batch(th, 0, vp, gp, 2000, True, 0, seed=9, engine=eng, outputs=("F", "dF"))
+        if mode:
+            ent_ms, lj_ms = eng.ctx.last_kernel_ms()
+            assert ent_ms > 0.0 and lj_ms > 0.0
+        outs.append((o["F"].copy(), o["dF"].copy()))
+    eng.ctx.set_profiling(False)
+    for F, dF in outs[1:]:
+        assert np.array_equal(F, outs[0][0]) and np.array_equal(dF, outs[0][1])

@@ -186,3 +186,18 @@ def test_build_dependency_lists_cover_every_included_source():
     mfma = {os.path.normpath(d) for d in B.MFMA_DEPS}
     assert closure("vbmc_hip.hip") <= main, sorted(closure("vbmc_hip.hip") - main)
     assert closure("ent_mfma_inst.hip") <= mfma, sorted(closure("ent_mfma_inst.hip") - mfma)
+
+
+def test_hardware_queue_default_is_set_before_the_runtime_and_never_overrides_the_environment():
+    """vbmc_amd/_lib.py: GPU_MAX_HW_QUEUES is raised to 8 at import (before the HIP runtime initialises) unless the environment already
+    holds a value (busy streams that share a hardware queue run one after the other)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import vbmc_amd._lib; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "3"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "3"
