@@ -493,6 +493,7 @@ struct ElboPlan {
   double *d_vpd = nullptr, *d_entp = nullptr, *d_lj = nullptr, *d_out = nullptr, *d_part = nullptr, *d_red = nullptr;
   double *d_Z = nullptr, *d_X = nullptr, *d_J = nullptr, *d_vg = nullptr, *d_var = nullptr;
   const double* d_eps = nullptr;
+  double* out_direct = nullptr;   // the pinned result block itself: the finalize kernel writes the records there (small pipelined passes)
   long long eps_stride_r = 0;
   double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0, cutoff = 0.0;
 };
@@ -1032,7 +1033,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.vpd = P.d_vpd; fa.theta = P.d_theta; fa.ljbar = P.d_ljbar; fa.var = P.d_var; fa.var_stride = P.d_var ? P.var_stride : 0;
   fa.bnd = P.d_bnd; fa.has_bnd = P.has_bnd ? 1 : 0;
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
-  fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.d_out; fa.no_jacobian = P.no_jacobian;
+  fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.out_direct ? P.out_direct : P.d_out; fa.no_jacobian = P.no_jacobian;
   {
     size_t lds = (FIN_THREADS + 3 * (size_t)K + (P.fin_big ? 0 : (size_t)D * K + 3 * (size_t)T) + 8) * sizeof(double);
     fa.big = P.d_finbig;
@@ -1238,7 +1239,8 @@ static void elbo_plan_free(void* plan) { delete (SlotPlan*)plan; }
 
 // stage + enqueue + read-back of one batch into `slot` of the context, WITHOUT the event that marks its end (the caller may append work
 // of its own to the stream first: the exchange of vbmc_elbo_multi_submit)
-static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot, const char* who) {
+static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int slot, const char* who,
+                                    bool allow_direct = false) {
   if (!a) return set_err(ctx, VBMC_ERR_INVALID, "%s: null args", who);
   if (slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot must be 0 or 1", who);
   if (ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot %d holds an uncollected pass", who, slot);
@@ -1260,11 +1262,17 @@ static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
   vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P);
-  if (!s_) s_ = elbo_enqueue(ctx, gp, sp->P, a->seed);
+  // Result blocks of at most 256 KB are written by the finalize kernel straight into the pinned block (no read-back launch: BASELINE
+  // configs[1] 52.1 -> 50.0 us per step, nothing elsewhere), only where nothing on the device reads the records afterwards (not under a
+  // communicator: k_comm_pick does).  VBMC_DIRECT_OUT=n: another bound in KB, 0 = never (A/B).  The mirror image -- the staging block read
+  // by the pass's first kernel instead of a copy launch -- was built and measured too: no gain (49.8 us), removed.
+  static const size_t direct_kb = [] { const char* e = getenv("VBMC_DIRECT_OUT"); return e ? (size_t)atol(e) : (size_t)256; }();
   if (!s_) {
     sp->hout = (double*)ctx->pin + sp->P.n_up;
-    s_ = elbo_enqueue_readback(ctx, sp->P, a, sp->hout);
+    if (allow_direct && direct_kb && sp->P.compute_var == 0 && sp->P.out_n * sizeof(double) <= direct_kb * 1024) sp->P.out_direct = sp->hout;
   }
+  if (!s_) s_ = elbo_enqueue(ctx, gp, sp->P, a->seed);
+  if (!s_ && !sp->P.out_direct) s_ = elbo_enqueue_readback(ctx, sp->P, a, sp->hout);
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
   if (s_) { (void)hipStreamSynchronize(ctx->stream); return s_; }   // nothing of a failed submit stays in flight
@@ -1404,7 +1412,7 @@ extern "C" vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const 
   vbmc_ctx* sc = ctx;
   int inner = slot;
   { vbmc_status s_ = slot_ctx(ctx, a, slot, &sc, &inner); if (s_) return s_; }
-  { vbmc_status s_ = elbo_submit_core(sc, gp, a, inner, "vbmc_elbo_submit"); if (s_) return slot_err(ctx, sc, s_); }
+  { vbmc_status s_ = elbo_submit_core(sc, gp, a, inner, "vbmc_elbo_submit", true); if (s_) return slot_err(ctx, sc, s_); }
   ctx->slot_where[slot] = sc; ctx->slot_inner[slot] = inner;
   return slot_err(ctx, sc, elbo_submit_mark(sc, inner, "vbmc_elbo_submit"));
 }
