@@ -927,6 +927,10 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     ea.part = sh.mode == 1 ? sh.send + shard_lj_doubles(P, sh.world) : P.d_part;
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff; ea.r0 = P.r0; ea.rstride = P.rstride;
+    {   // progress-ordered wave priorities (entropy_mfma.h); VBMC_ENT_PRIO=0: without (A/B)
+      static const int prio_env = [] { const char* e = getenv("VBMC_ENT_PRIO"); return e ? atoi(e) : 1; }();
+      ea.prio = prio_env;
+    }
     int co_rows = 0;
     if (co) {
       LjCo& lc = ea.lj;

@@ -57,6 +57,7 @@ struct EntArgs {
   double* part;
   int D, K, Mh, C, tiles_per_chunk, ncol;
   int c0;                // first chunk of this launch (blockIdx.x + c0 is the chunk index; 0 unless the chunks are sharded over ranks)
+  int prio;              // 1: a wave lowers its issue priority as it progresses (entropy_mfma.h: the one behind on a SIMD is served first)
   unsigned long long seed;
   int r0, rstride;       // the device-RNG stream of restart r is keyed by r0 + r * rstride: the restart's index in the WHOLE batch when
                          // the batch is dealt over several devices (vbmc_elbo_batch_multi: r0 = g, rstride = G); 0, 1 otherwise

@@ -851,7 +851,25 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   };
   if constexpr (VBMC_ENT_SPLIT(KT, QS, TL, HV, CW)) {
     const int tf = min(t1, a.Mh >> 4);        // tiles [t0, tf) hold 16 samples each
+#ifndef VBMC_ENT_NOPRIO
+    // A wave's issue priority falls as it progresses (s_setprio 3 -> 0 at the quarter points of its tiles): of two waves that share a
+    // SIMD the one BEHIND is served first.  At equal priority the arbiter keeps serving the older wave: with a single round of waves
+    // (8 restarts per device: 2000 waves on 2048 slots) one wave of each SIMD finished at 240 us, the other at 340, the last 100 us at
+    // the single-wave issue rate (tools/r4_timeline.py).  R = 8: 0.337 -> 0.327 ms per step (-3.1 %), R = 16: 0.644 -> 0.633, R = 32:
+    // 1.246 -> 1.234, R = 64 (eleven rounds: there is always a younger wave to take over) within 0.2 % either way; the same bits.
+    // Halves instead of quarters: a third of the gain.  EntArgs::prio = 0 (VBMC_ENT_PRIO=0) / -DVBMC_ENT_NOPRIO: without (A/B).
+    const bool pr = a.prio != 0;
+    const int q1 = pr ? t0 + (t1 - t0 + 3) / 4 : -1, q2 = pr ? t0 + (t1 - t0 + 1) / 2 : -1, q3 = pr ? t0 + (3 * (t1 - t0) + 3) / 4 : -1;
+    if (pr) __builtin_amdgcn_s_setprio(3);
+    for (int tile = t0; tile < tf; ++tile) {
+      if (tile == q1) __builtin_amdgcn_s_setprio(2);
+      if (tile == q2) __builtin_amdgcn_s_setprio(1);
+      if (tile == q3) __builtin_amdgcn_s_setprio(0);
+      tile_body(tile, EntTileFull{});
+    }
+#else
     for (int tile = t0; tile < tf; ++tile) tile_body(tile, EntTileFull{});
+#endif
     if (tf < t1) tile_body(tf, EntTilePartial{});
   } else {
     for (int tile = t0; tile < t1; ++tile) tile_body(tile, EntTileAny{});
