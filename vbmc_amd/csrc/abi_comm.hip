@@ -275,6 +275,7 @@ extern "C" void vbmc_gp_free_all(vbmc_comm* c, vbmc_gp** gps) {
 // F and varG of the n restarts of one device, out of its packed result records, into its exchange block [F (P) | varG (P)];
 // slots beyond n carry NaN
 __global__ void k_comm_pick(int n, int P, size_t OS, const double* __restrict__ out, double* __restrict__ send) {
+  VB_SMALL_PRIO();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);

@@ -425,10 +425,12 @@ static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_
 // launch costs ~10 us.  VBMC_COPY_ENGINE=1 restores the hipMemcpyAsync path (A/B runs); larger transfers always use it.
 #define COPY_KERNEL_MAX_BYTES ((size_t)4 << 20)
 __global__ void k_copy_f64(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
+  VB_SMALL_PRIO();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 // rows of `width` doubles, row r at src + r * stride -> dst + r * stride (same stride on both sides)
 __global__ void k_copy_rows_f64(int rows, size_t stride, size_t width, const double* __restrict__ src, double* __restrict__ dst) {
+  VB_SMALL_PRIO();
   for (int r = blockIdx.y; r < rows; r += gridDim.y)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += (size_t)gridDim.x * blockDim.x)
       dst[(size_t)r * stride + i] = src[(size_t)r * stride + i];

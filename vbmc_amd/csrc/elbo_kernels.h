@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
                                               const double* __restrict__ vpfix,  // mu sigma lambda w (fixed vp) packed
                                               double* __restrict__ vpd, double* __restrict__ entp, AdamState A, int adam_iter,
                                               const double* __restrict__ prev_out) {
+  VB_SMALL_PRIO();
   extern __shared__ double sh[];
   if (adam_iter > 0) {
     adam_update_chain(A, adam_iter, theta, prev_out, blockIdx.x);
@@ -164,6 +165,7 @@ __global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const 
                                                              const double* __restrict__ gpc,    // S x GPC_STRIDE
                                                              const double* __restrict__ delta2,  // D (delta.^2)
                                                              double* __restrict__ lj, int want_grad) {
+  VB_SMALL_PRIO();
   constexpr int NC = 2 * DT + 2;                 // I, M[DT], S, L[DT]
   __shared__ double TAB[VB_EXP_TAB_N];
   __shared__ double PART[LJ_MAXW][4][NC];        // per wave and component: the 16-lane row sums
@@ -201,6 +203,7 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
                                                         const double* __restrict__ gpc,     // S x GPC_STRIDE
                                                         const double* __restrict__ delta2,  // D (delta.^2)
                                                         double* __restrict__ lj) {
+  VB_SMALL_PRIO();
   constexpr int NCT = (2 * DT + 1 + 15) / 16;
   __shared__ double TAB[VB_EXP_TAB_N];
   __shared__ double XT[LJ_CH][DT];        // centred chunk of X, [n][d], zero beyond D / N
@@ -482,6 +485,7 @@ __global__ void k_rng_dump(int D, int K, int R, int Mh, unsigned long long seed,
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __restrict__ vpd,
                                                double* __restrict__ eb, int want_grad, double* __restrict__ gamma_g) {
+  VB_SMALL_PRIO();
   extern __shared__ double lds[];
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int D = dm.D, K = dm.K;
@@ -610,6 +614,7 @@ __device__ __forceinline__ void ent_reduce_body(int j, int r, int K, int C, int 
 
 __global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const double* __restrict__ part,
                                                     double* __restrict__ red) {
+  VB_SMALL_PRIO();
   ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red);
 }
 
@@ -636,12 +641,14 @@ __device__ __forceinline__ void lj_reduce_body(int k, int r, int S, int K, int L
 
 __global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const double* __restrict__ lj,
                                                   double* __restrict__ ljbar) {
+  VB_SMALL_PRIO();
   lj_reduce_body(blockIdx.x, blockIdx.y, S, K, LJS, lj, ljbar);
 }
 
 // both reductions in one launch (blockIdx.z = 0: entropy chunks, 1: hyper-samples) when they sit on the same stream
 __global__ void __launch_bounds__(256) k_reduce_both(int C, int ncol, const double* __restrict__ part, double* __restrict__ red,
                                                      int S, int LJS, const double* __restrict__ lj, double* __restrict__ ljbar) {
+  VB_SMALL_PRIO();
   if (blockIdx.z == 0) ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red);
   else lj_reduce_body(blockIdx.x, blockIdx.y, S, gridDim.x, LJS, lj, ljbar);
 }
@@ -692,6 +699,7 @@ __device__ __forceinline__ void stage_copy(double* __restrict__ dst, const doubl
 }
 
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize(FinArgs a) {
+  VB_SMALL_PRIO();
   extern __shared__ double lds[];
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const ElboDims& dm = a.dm;
@@ -959,6 +967,7 @@ __device__ __forceinline__ void wave_fence() {
 }
 
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
+  VB_SMALL_PRIO();
   extern __shared__ double lds[];
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;

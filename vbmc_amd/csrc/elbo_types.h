@@ -64,3 +64,13 @@ struct EntArgs {
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
   LjCo lj;               // CO kernels only: the expected log joint as extra workgroups of this launch (lj.rows = 0: none)
 };
+
+// The short kernels of a pass (copies, k_prep, the log joint, the reductions, the finalize kernel) ask for the highest issue priority: in
+// the pipelined step they share SIMDs with the other pass's entropy kernel, whose waves run at priorities 3 -> 0 (entropy_mfma.h), and
+// they are what the next pass waits for.  -DVBMC_NO_SMALL_PRIO: without (A/B).
+#ifndef VBMC_NO_SMALL_PRIO
+#define VB_SMALL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define VB_SMALL_PRIO() do { } while (0)
+#endif
+
