@@ -269,17 +269,20 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  *   vbmc_elbo_submit   validates and stages the inputs of one batch in the slot's own pinned block, enqueues the H2D, the
  *                      kernels and the packed D2H on the context's stream and returns WITHOUT waiting;
  *   vbmc_elbo_collect  waits for that slot's pass and fills the outputs named in args (F, dF, G, H, dG, dH, varG, varGss).
- * Four slots (0 .. 3; round 4: slot s runs on stream s & 1 of two streams the context creates for this purpose, two passes deep each --
- * the head and tail of one pass overlap the last round of waves of another and a stream never runs dry while the host collects and
- * re-submits; slots 2 and 3 exist for passes without a variance term): while the device works on one batch the host stages the next, so that the device never waits for the
- * host between batches.  Measured: 2.82 -> 2.77 ms per batch of 64 at the headline shape (the device is busy 98 % of a
- * blocking call already), 113 -> 103 us per single evaluation; the batches still execute one after the other on the
- * context's stream, so the chain of dependent kernels inside a small batch is not hidden.  Passes execute in submission order; each
+ * Four slots (0 .. 3; round 4: slot s runs on slot stream s & 1 of two streams the context creates at the first submit, two passes
+ * deep each -- the head and tail of one pass overlap the entropy kernel of another and a stream never runs dry while the host collects
+ * and re-submits; slots 2 and 3 exist for passes without a variance term; the variance forms run on the context's own stream, slots 0
+ * and 1).  The two slot streams are chosen among candidates that the runtime places on different hardware queues and dispatch pipes
+ * (measured at creation; set GPU_MAX_HW_QUEUES=8 in the environment before the first HIP call so that there are queues to choose from,
+ * see INTEGRATION.md), and a slot stream is ordered after whatever the context's own stream still holds at submit (a surrogate being
+ * uploaded, draws being produced).  While the device works on one batch the host stages the next, so that the device never waits for
+ * the host between batches.  Measured at the headline shape: 2.49 ms per blocking call of 64 restarts, 2.39-2.42 ms per pipelined batch;
+ * 0.37 / 0.33 ms for 8 restarts, 102 / 65 us for one.  Passes of one slot stream execute in submission order; each
  * slot must be collected before it is submitted again.  Results are bit-identical to vbmc_elbo_batch with the same args.
  * Not offered here: separate_K / I_sk / J_sjk / G_s / varG_s outputs and host-resident draws (eps_mode 1) -- their copies
  * go through pageable memory; use vbmc_elbo_batch.  The surrogate handle and the arrays named in args must stay valid until the
  * slot is collected (the inputs are copied at submit, the outputs are written at collect).  Other entry points of the same context may be called between a submit and
- * its collect (they queue behind it on the stream).
+ * its collect (they run on the context's own stream, beside the passes in flight).
  */
 vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int slot);
 vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* args, int slot);
