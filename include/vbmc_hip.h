@@ -282,7 +282,8 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * Not offered here: separate_K / I_sk / J_sjk / G_s / varG_s outputs and host-resident draws (eps_mode 1) -- their copies
  * go through pageable memory; use vbmc_elbo_batch.  The surrogate handle and the arrays named in args must stay valid until the
  * slot is collected (the inputs are copied at submit, the outputs are written at collect).  Other entry points of the same context may be called between a submit and
- * its collect (they run on the context's own stream, beside the passes in flight).
+ * its collect (they run on the context's own stream, beside the passes in flight) -- except those that change or free the surrogate
+ * a pass in flight reads (vbmc_gp_set_noise, vbmc_gp_free): collect first.
  */
 vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int slot);
 vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* args, int slot);
