@@ -872,7 +872,19 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #endif
     if (tf < t1) tile_body(tf, EntTilePartial{});
   } else {
+#ifndef VBMC_ENT_NOPRIO
+    const bool pr = a.prio != 0;     // (the waves of a multi-wave workgroup progress together: they hold the same priority at every barrier)
+    const int q1 = pr ? t0 + (t1 - t0 + 3) / 4 : -1, q2 = pr ? t0 + (t1 - t0 + 1) / 2 : -1, q3 = pr ? t0 + (3 * (t1 - t0) + 3) / 4 : -1;
+    if (pr) __builtin_amdgcn_s_setprio(3);
+    for (int tile = t0; tile < t1; ++tile) {
+      if (tile == q1) __builtin_amdgcn_s_setprio(2);
+      if (tile == q2) __builtin_amdgcn_s_setprio(1);
+      if (tile == q3) __builtin_amdgcn_s_setprio(0);
+      tile_body(tile, EntTileAny{});
+    }
+#else
     for (int tile = t0; tile < t1; ++tile) tile_body(tile, EntTileAny{});
+#endif
   }
 #ifdef VBMC_EXP_CLK
   const unsigned long long wck1 = wall_clock64();
