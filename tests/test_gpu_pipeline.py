@@ -98,7 +98,7 @@ def test_pipeline_misuse_is_refused(va):
         Fi, dFi = obj.collect(i)
         assert np.array_equal(Fi, refs[i]["F"]) and np.array_equal(dFi, refs[i]["dF"])
     # per-component outputs are not offered through the pipelined form
-    a, _, _ = obj._slot(0)
+    a = obj._slot(0)[0]
     b = type(a).from_buffer_copy(a)
     b.separate_K = 1
     b.compute_grad = 0
@@ -122,7 +122,7 @@ def test_collect_with_another_layout_is_refused(va):
     obj = va.PreparedObjective(T, 3, 0, vp, gp, 60, 0, None)
     ctx = va.default_engine().ctx
     obj.submit(batches[0], seed=4, slot=1)
-    a, _, _ = obj._slot(1)
+    a = obj._slot(1)[0]
     b = type(a).from_buffer_copy(a)
     b.optimize[3] = 0                       # without the eta block: T - K
     with pytest.raises(va.VbmcHipError, match="differ from the submitted"):
