@@ -858,7 +858,10 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     // the single-wave issue rate (tools/r4_timeline.py).  R = 8: 0.337 -> 0.327 ms per step (-3.1 %), R = 16: 0.644 -> 0.633, R = 32:
     // 1.246 -> 1.234, R = 64 (eleven rounds: there is always a younger wave to take over) within 0.2 % either way; the same bits.
     // Halves instead of quarters: a third of the gain.  EntArgs::prio = 0 (VBMC_ENT_PRIO=0) / -DVBMC_ENT_NOPRIO: without (A/B).
-    const bool pr = a.prio != 0;
+    // Not in the instantiations built for ONE wave per SIMD (nothing to arbitrate; the thresholds only cost scalar registers there: +0.5-1.1 %
+    // at D >= 20, K = 56..64 over the 112-shape sweep, against -3.2 % on average for the shapes of 8..64 components).
+    constexpr bool PRIO = CW > 1 || (CO ? QS <= 4 : VBMC_ENT_WAVES(KT, QS, TL, HV) > 1);
+    const bool pr = PRIO && a.prio != 0;
     const int q1 = pr ? t0 + (t1 - t0 + 3) / 4 : -1, q2 = pr ? t0 + (t1 - t0 + 1) / 2 : -1, q3 = pr ? t0 + (3 * (t1 - t0) + 3) / 4 : -1;
     if (pr) __builtin_amdgcn_s_setprio(3);
     for (int tile = t0; tile < tf; ++tile) {
@@ -872,19 +875,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #endif
     if (tf < t1) tile_body(tf, EntTilePartial{});
   } else {
-#ifndef VBMC_ENT_NOPRIO
-    const bool pr = a.prio != 0;     // (the waves of a multi-wave workgroup progress together: they hold the same priority at every barrier)
-    const int q1 = pr ? t0 + (t1 - t0 + 3) / 4 : -1, q2 = pr ? t0 + (t1 - t0 + 1) / 2 : -1, q3 = pr ? t0 + (3 * (t1 - t0) + 3) / 4 : -1;
-    if (pr) __builtin_amdgcn_s_setprio(3);
-    for (int tile = t0; tile < t1; ++tile) {
-      if (tile == q1) __builtin_amdgcn_s_setprio(2);
-      if (tile == q2) __builtin_amdgcn_s_setprio(1);
-      if (tile == q3) __builtin_amdgcn_s_setprio(0);
-      tile_body(tile, EntTileAny{});
-    }
-#else
+    // (no priorities here: in the multi-wave kernels the three thresholds cost scalar registers these instantiations do not have --
+    // BASELINE configs[4]: kernel alone 8.31 -> 8.64 ms with the code in place and switched off, 8.50 switched on)
     for (int tile = t0; tile < t1; ++tile) tile_body(tile, EntTileAny{});
-#endif
   }
 #ifdef VBMC_EXP_CLK
   const unsigned long long wck1 = wall_clock64();
