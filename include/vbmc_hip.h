@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VBMC_ABI_VERSION 4
+#define VBMC_ABI_VERSION 5
 
 typedef int vbmc_status;
 enum {
@@ -44,7 +44,10 @@ typedef struct vbmc_gp vbmc_gp;   /* device-resident gp.post(1..S) (gplite_post.
 
 /* ---- library / context ------------------------------------------------------------- */
 int vbmc_abi_version(void);
-/* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private one */
+/* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private one.  Side effect, once per process and only
+ * while the HIP runtime has not been initialised by anyone: setenv("GPU_MAX_HW_QUEUES", "8", no overwrite) -- the pipelined forms keep
+ * five streams busy and the runtime's default of four hardware queues serialises two of them (VBMC_HW_QUEUES=0: leave it alone,
+ * VBMC_HW_QUEUES=n: that many). */
 vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out);
 void vbmc_ctx_destroy(vbmc_ctx* ctx);
 const char* vbmc_last_error(const vbmc_ctx* ctx);
@@ -273,8 +276,9 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * deep each -- the head and tail of one pass overlap the entropy kernel of another and a stream never runs dry while the host collects
  * and re-submits; slots 2 and 3 exist for passes without a variance term; the variance forms run on the context's own stream, slots 0
  * and 1).  The two slot streams are chosen among candidates that the runtime places on different hardware queues and dispatch pipes
- * (measured at creation; set GPU_MAX_HW_QUEUES=8 in the environment before the first HIP call so that there are queues to choose from,
- * see INTEGRATION.md), and a slot stream is ordered after whatever the context's own stream still holds at submit (a surrogate being
+ * (measured at creation; vbmc_ctx_create raises GPU_MAX_HW_QUEUES to 8 ahead of its own first HIP call so that there are queues to choose
+ * from -- unless the environment holds a value, VBMC_HW_QUEUES=0 forbids it, or another HIP user initialised the runtime first: see
+ * INTEGRATION.md), and a slot stream is ordered after whatever the context's own stream still holds at submit (a surrogate being
  * uploaded, draws being produced).  While the device works on one batch the host stages the next, so that the device never waits for
  * the host between batches.  Measured at the headline shape: 2.49 ms per blocking call of 64 restarts, 2.39-2.42 ms per pipelined batch;
  * 0.37 / 0.33 ms for 8 restarts, 102 / 65 us for one.  Passes of one slot stream execute in submission order; each
@@ -283,10 +287,15 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * go through pageable memory; use vbmc_elbo_batch.  The surrogate handle and the arrays named in args must stay valid until the
  * slot is collected (the inputs are copied at submit, the outputs are written at collect).  Other entry points of the same context may be called between a submit and
  * its collect (they run on the context's own stream, beside the passes in flight) -- except those that change or free the surrogate
- * a pass in flight reads (vbmc_gp_set_noise, vbmc_gp_free): collect first.
+ * a pass in flight reads (vbmc_gp_set_noise, vbmc_gp_free): collect first.  (Round 5, ABI 5: those two now wait for the slot streams
+ * that hold a pass before they touch the surrogate -- the pass completes on the old data and stays collectable -- so a forgotten
+ * collect costs a synchronisation, not a read of recycled memory.)
+ *   vbmc_elbo_abandon  gives a slot back WITHOUT its results: waits for the pass in flight, if any, and clears the slot (a caller that
+ *                      will not collect: an exception between submit and collect, an abandoned generator).  VBMC_OK on an idle slot.
  */
 vbmc_status vbmc_elbo_submit(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args, int slot);
 vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* args, int slot);
+vbmc_status vbmc_elbo_abandon(vbmc_ctx* ctx, int slot);
 
 /*
  * ONE evaluation (or a batch with fewer restarts than GPUs) sharded over `world` ranks, one process per GPU, each with a
@@ -401,7 +410,8 @@ vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t s
  * labels the kernel it measures with it. */
 int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* tail);
 
-/* Test hook: y = exp(x) evaluated by the hot-loop device implementations (0: polynomial, 1: table). */
+/* Test hook: y = exp(x) evaluated by the hot-loop device implementations (0: polynomial, 1 / 2: 256-entry table with the two- /
+ * one-constant reduction, 3: the Monte-Carlo entropy kernel's exponential as built, 4 / 5: its cubic / quadratic form). */
 vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const double* x, double* y);
 
 /* Device-memory helpers for callers without their own allocator (MEX). */

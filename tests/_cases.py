@@ -152,6 +152,18 @@ def synth_problem(seed, D, N, K, S, meanfun=4, noisy=False, target="lumpy"):
                 mu=mu, sigma=sigma, lam=lam, eta=eta, rng=rng)
 
 
+def relerr(a, b, scale=None):
+    """max |a - b| relative to the LARGEST reference entry (round 5: no floor at 1 -- a quantity below 1 used to get an absolute test).
+    `scale`: an explicit yardstick for quantities that are differences of larger terms (say so at the call site); an all-zero reference
+    is compared absolutely."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if not a.size:
+        return 0.0
+    den = float(np.max(np.abs(b))) if scale is None else float(scale)
+    return float(np.max(np.abs(a - b)) / den) if den > 0.0 else float(np.max(np.abs(a - b)))
+
+
 def block_relerr(a, b, D, K, opt=(1, 1, 1, 1)):
     """Per-block relative error of a theta-shaped gradient [mu (D K) | log sigma (K) | log lambda (D) | eta (K)] (only the
     optimised groups present): each block against ITS OWN largest reference entry, so that a wrong small block (a lambda

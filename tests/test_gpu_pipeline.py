@@ -184,3 +184,38 @@ def test_slot_streams_are_placed_by_measurement_in_a_process_with_other_queues(v
                 assert np.array_equal(F0, F1) and np.array_equal(dF0, dF1)
         finally:
             eng.close() if hasattr(eng, "close") else None
+
+
+def test_abandoned_generator_and_surrogate_freed_under_a_pass_in_flight(va):
+    """(a) a stream() generator dropped half way leaves no slot busy (vbmc_elbo_abandon in its finally block) -- the next
+    stream() over the same objective runs; (b) a pooled surrogate freed, and its blocks handed out again to a new upload, while a pass
+    that reads it is still in flight on a slot stream: vbmc_gp_free waits for that stream first, so the pass completes on the OLD data
+    and collects the bits of the blocking call."""
+    p, gp, vp, batches = setup(va, 11, 10, 120, 50, 4, 16)
+    T = batches[0].shape[0]
+    obj = va.PreparedObjective(T, 16, 0, vp, gp, 2000, 0, None)
+    ref = [tuple(x.copy() for x in obj(th, seed=30 + i)) for i, th in enumerate(batches)]
+    g = obj.stream(batches, seeds=[30 + i for i in range(len(batches))])
+    F0, dF0 = next(g)                       # four submitted, one collected: three passes in flight
+    assert np.array_equal(F0, ref[0][0])
+    g.close()                               # GeneratorExit -> finally -> abandon
+    ctx = va.default_engine().ctx
+    for sl in range(4):
+        with pytest.raises(va.VbmcHipError, match="nothing submitted"):
+            obj.collect(sl)
+        obj.abandon(sl)                     # idle slot: a no-op
+    got = list(obj.stream(batches, seeds=[30 + i for i in range(len(batches))]))
+    for (F, dF), (Fr, dFr) in zip(got, ref):
+        assert np.array_equal(F, Fr) and np.array_equal(dF, dFr)
+    # (b)
+    eng = va.default_engine()
+    obj.submit(batches[1], seed=31, slot=0)
+    obj.submit(batches[2], seed=32, slot=1)
+    eng.invalidate()                                   # the engine's cache lets go of the surrogate ...
+    obj.dgp.close()                                    # ... and its blocks go back to the pool while two passes read them
+    gp2 = va.gplite_post(p["hyp"], p["X"] * 1.5 + 0.3, p["y"] - 2.0, 1, p["meanfun"])    # same sizes: the pool hands the same blocks out again
+    _ = va.negelcbo_batch(batches[0], 0, vp, gp2, 2000, True, 0, seed=1)
+    F1, dF1 = obj.collect(0)
+    F2, dF2 = obj.collect(1)
+    assert np.array_equal(F1, ref[1][0]) and np.array_equal(dF1, ref[1][1])
+    assert np.array_equal(F2, ref[2][0]) and np.array_equal(dF2, ref[2][1])

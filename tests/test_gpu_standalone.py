@@ -11,10 +11,7 @@ from tests._cases import synth_problem
 pytestmark = pytest.mark.gpu
 
 
-def relerr(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if a.size else 0.0
+from tests._cases import relerr  # noqa: E402  (relative to the largest reference entry; no floor)
 
 
 @pytest.fixture(scope="module")

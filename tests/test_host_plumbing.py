@@ -188,16 +188,25 @@ def test_build_dependency_lists_cover_every_included_source():
     assert closure("ent_mfma_inst.hip") <= mfma, sorted(closure("ent_mfma_inst.hip") - mfma)
 
 
-def test_hardware_queue_default_is_set_before_the_runtime_and_never_overrides_the_environment():
-    """vbmc_amd/_lib.py: GPU_MAX_HW_QUEUES is raised to 8 at import (before the HIP runtime initialises) unless the environment already
-    holds a value (busy streams that share a hardware queue run one after the other)."""
+def test_hardware_queue_default_is_set_by_the_library_and_never_overrides_the_environment():
+    """Round 5: GPU_MAX_HW_QUEUES is raised to 8 inside vbmc_ctx_create, ahead of the library's first HIP call (busy
+    streams that share a hardware queue run one after the other) -- the same for a ctypes, a MEX and a C host; a value already in the
+    environment is kept, VBMC_HW_QUEUES=0 leaves the variable alone, and importing vbmc_amd no longer touches the environment."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, sys; sys.path.insert(0, %r); import vbmc_amd._lib; print(os.environ.get('GPU_MAX_HW_QUEUES'))" % root
-    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
-    env["GPU_MAX_HW_QUEUES"] = "3"
-    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "3"
+    code = ("import os, sys, ctypes as C; sys.path.insert(0, %r); import vbmc_amd._lib as L; a = os.environ.get('GPU_MAX_HW_QUEUES');"
+            "lib = L.load(); h = C.c_void_p(); lib.vbmc_ctx_create(0, None, C.byref(h));"
+            "libc = C.CDLL(None); libc.getenv.restype = C.c_char_p; v = libc.getenv(b'GPU_MAX_HW_QUEUES');"
+            "print(a, v.decode() if v else None)") % root
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "VBMC_HW_QUEUES")}
+
+    def run(e):
+        return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True).stdout.strip()
+
+    assert run(env) == "None 8"
+    assert run(dict(env, GPU_MAX_HW_QUEUES="3")) == "3 3"
+    assert run(dict(env, VBMC_HW_QUEUES="0")) == "None None"
+    assert run(dict(env, VBMC_HW_QUEUES="6")) == "None 6"

@@ -1,9 +1,12 @@
-"""Round-4 experiments on the headline entropy kernel (k_entropy_mfma<3,3,...>, D = 10, K = 50): library variants built with
+"""A/B experiments on the headline entropy kernel (k_entropy_mfma<3,3,...>, D = 10, K = 50): library variants built with
 extra -D flags on the QS = 3 translation unit, each timed under a list of environment settings, with a parity check against
-the base library on the same device stream (same seed: F and dF must agree to the summation-order level).
+the first variant on the same device stream (same seed: H and dH must agree to the summation-order level).  (Round 4: tools/r4_experiments.py.)
 
-    python tools/r4_experiments.py build            (here: cross-compiles vbmc_amd/lib/exp/libvbmc_hip_<name>.so)
-    python tools/r4_experiments.py run [R] [Ns]     (GPU box)
+    python tools/ent_ab.py build            (here: cross-compiles vbmc_amd/lib/exp/libvbmc_hip_<name>.so)
+    python tools/ent_ab.py run [R] [Ns]     (GPU box; ENT_AB_REPS=n: every variant n times, interleaved, median reported)
+
+Variants: the table below, or ENT_AB="name:-Dflag,-Dflag;name2:...;head:@HEAD" (@HEAD: the entropy translation unit of the previous
+round's last commit, unpacked under /tmp/head_src by `git archive <commit> vbmc_amd/csrc include | tar -x -C /tmp/head_src`).
 """
 import json
 import os
@@ -15,10 +18,20 @@ EXP = os.path.join(ROOT, "vbmc_amd", "lib", "exp")
 OBJ = os.path.join(ROOT, "vbmc_amd", "lib", "obj")
 # name -> (compile flags, [environment settings to time it under])
 VARIANTS = {
-    "head": (["@HEAD"], [{}]),     # git HEAD's entropy translation unit (tools/r4_experiments.py build: from /tmp/head_src)
-    "noepf": (["-DVBMC_NO_EPF"], [{}]),
-    "epf": ([], [{}]),
+    "head": (["@HEAD"], [{}]),            # round 4's kernel
+    "r5": ([], [{}]),                     # the tree: quadratic exp + GP2 + ETZ + C2
+    "noc2": (["-DVBMC_NO_C2"], [{}]),
+    "cubic": (["-DVBMC_EXP_CUBIC"], [{}]),
+    "nogp2": (["-DVBMC_NO_GP2"], [{}]),
+    "evx": (["-DVBMC_EVX"], [{}]),
+    "noetz": (["-DVBMC_NO_ETZ"], [{}]),
+    "tablin": (["-DVBMC_EXP_TABLIN"], [{}]),   # diagnostic: the exp table read without bank conflicts (results meaningless)
 }
+if os.environ.get("ENT_AB"):
+    VARIANTS = {}
+    for item in os.environ["ENT_AB"].split(";"):
+        nm, _, fl = item.partition(":")
+        VARIANTS[nm.strip()] = ([f for f in fl.split(",") if f], [{}])
 
 
 def build(qs=3):
@@ -69,7 +82,9 @@ def one(R, Ns, dump):
         np.savez(dump, F=out["F"], dF=out["dF"], H=out["H"], dH=out["dH"])
     eng.ctx.set_profiling(True)
     ms = []
-    for i in range(10):
+    if os.environ.get("ENT_AB_ALONE", "1") == "1":
+        eng.ctx.set_profiling(2)       # nothing forked beside the kernel while it is timed (what bench.py's roofline leg prices)
+    for i in range(int(os.environ.get("ENT_AB_ITERS", "20"))):
         vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=10 + i, engine=eng, outputs=("F",))
         ms.append(eng.ctx.last_kernel_ms()[0])
     res = {"ms": float(np.median(ms)), "min": float(np.min(ms))}
@@ -94,37 +109,51 @@ def one(R, Ns, dump):
 def run(R, Ns):
     import numpy as np
 
-    tmp = os.path.join(ROOT, "gpurun_out", "r4exp")
+    tmp = os.path.join(ROOT, "gpurun_out", "entab")
     os.makedirs(tmp, exist_ok=True)
-    res = []
+    reps = int(os.environ.get("ENT_AB_REPS", "2"))
+    tags, runs, notes = [], {}, {}
     ref = None
-    for name, (_, envs) in VARIANTS.items():
-        lib = os.path.join(EXP, "libvbmc_hip_%s.so" % name)
-        if not os.path.exists(lib):
-            continue
-        for e in envs:
-            tag = name + "".join(" %s=%s" % kv for kv in e.items())
-            dump = os.path.join(tmp, "out_%d.npz" % len(res))
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(R), str(Ns), dump],
-                                 env=dict(os.environ, VBMC_HIP_LIB=lib, **e), capture_output=True, text=True)
-            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-            if not line:
-                res.append((tag, None, out.stderr[-400:]))
+    for rep in range(reps):
+        for name, (_, envs) in VARIANTS.items():
+            lib = os.path.join(EXP, "libvbmc_hip_%s.so" % name)
+            if not os.path.exists(lib):
                 continue
-            ms = json.loads(line[-1])
-            z = np.load(dump)
-            if ref is None:
-                ref = z
-            def rel(a, b):
-                return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
-            res.append((tag, ms, "dH %.1e dHgrad %.1e" % (rel(z["H"], ref["H"]), rel(z["dH"], ref["dH"]))))
-    base = res[0][1]["ms"] if res and res[0][1] else None
-    for tag, ms, note in res:
-        if ms is None:
-            print("%-28s FAILED %s" % (tag, note))
-        else:
-            print("%-28s %.3f ms (min %.3f) %+6.1f %%   %s%s" % (tag, ms["ms"], ms["min"], 100 * (ms["ms"] - base) / base if base else 0.0, note,
-                                                             ("   eps-from-memory %.3f ms" % ms["eps_ms"]) if "eps_ms" in ms else ""))
+            for e in envs:
+                tag = name + "".join(" %s=%s" % kv for kv in e.items())
+                dump = os.path.join(tmp, "out_%s_%d.npz" % (name, rep))
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(R), str(Ns), dump],
+                                     env=dict(os.environ, VBMC_HIP_LIB=lib, **e), capture_output=True, text=True)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                if tag not in tags:
+                    tags.append(tag)
+                if not line:
+                    notes[tag] = "FAILED " + out.stderr[-400:]
+                    continue
+                runs.setdefault(tag, []).append(json.loads(line[-1]))
+                z = np.load(dump)
+                if ref is None:
+                    ref = z
+
+                def rel(a, b):
+                    return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
+
+                notes[tag] = "dH %.1e dHgrad %.1e" % (rel(z["H"], ref["H"]), rel(z["dH"], ref["dH"]))
+    base = basemin = None
+    for tag in tags:
+        if tag not in runs:
+            print("%-28s %s" % (tag, notes.get(tag)))
+            continue
+        ms = float(np.median([r_["ms"] for r_ in runs[tag]]))
+        mn = float(np.min([r_["min"] for r_ in runs[tag]]))
+        if base is None:
+            base = ms
+        extra = ""
+        if "eps_ms" in runs[tag][0]:
+            extra = "   eps-from-memory %.3f ms" % float(np.median([r_["eps_ms"] for r_ in runs[tag]]))
+        if basemin is None:
+            basemin = mn
+        print("%-22s median %.3f ms %+5.1f %%   min %.3f ms %+5.1f %%   (runs %s)   %s%s" % (tag, ms, 100 * (ms - base) / base, mn, 100 * (mn - basemin) / basemin, " ".join("%.3f" % r_["ms"] for r_ in runs[tag]), notes[tag], extra))
 
 
 if __name__ == "__main__":

@@ -10,18 +10,15 @@ import os
 
 import numpy as np
 
-# The pipelined step keeps several streams of one context busy at a time (the two pass streams behind the four slots, the exchange
-# stream of a communicator, the context's own and its forked log joint); the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
-# hardware queues (four by default), and two busy streams that share a queue run one after the other (profiles/r04_experiments.md
-# section 11: the R = 8 step 0.34 -> 0.51 ms when that happens).  The runtime reads the variable when it initialises, i.e. at the
-# first HIP call of the process: it is set here, before the library is loaded, and a value already in the environment is kept.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES: raised by the library itself, inside vbmc_ctx_create ahead of its first HIP call -- round 5; importing this module no
+# longer touches the process environment.  An application that initialises another HIP user first -- bench.py imports torch -- sets it
+# itself.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VBMC_HIP_LIB: an alternative build of the SAME library (kernel A/B experiments, tools/ent_experiments.py)
 LIB_PATH = os.environ.get("VBMC_HIP_LIB") or os.path.join(_HERE, "lib", "libvbmc_hip.so")
 
-ABI_VERSION = 4   # include/vbmc_hip.h: VBMC_ABI_VERSION
+ABI_VERSION = 5   # include/vbmc_hip.h: VBMC_ABI_VERSION
 VBMC_OK, VBMC_ERR_INVALID, VBMC_ERR_NO_DEVICE, VBMC_ERR_HIP, VBMC_ERR_UNSUPPORTED, VBMC_ERR_NOT_POSDEF = range(6)
 _STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "UNSUPPORTED", 5: "NOT_POSDEF"}
 
@@ -97,6 +94,7 @@ def load():
     lib.vbmc_gp_free.argtypes = [vp, vp]
     lib.vbmc_gp_free.restype = None
     lib.vbmc_elbo_batch.argtypes = [vp, vp, C.POINTER(ElboArgs)]
+    lib.vbmc_elbo_abandon.argtypes = [vp, C.c_int]
     lib.vbmc_elbo_submit.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_int]
     lib.vbmc_elbo_collect.argtypes = [vp, C.POINTER(ElboArgs), C.c_int]
     lib.vbmc_adam_batch.argtypes = [vp, vp, C.POINTER(ElboArgs), C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,

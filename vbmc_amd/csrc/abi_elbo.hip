@@ -21,6 +21,17 @@ extern "C" int vbmc_abi_version(void) { return VBMC_ABI_VERSION; }
 static vbmc_status ctx_create_impl(int device, void* stream, vbmc_ctx** out, bool with_aux) {
   if (!out) return VBMC_ERR_INVALID;
   *out = nullptr;
+  // The pipelined step keeps up to five streams of a context busy (the two pass streams behind the four slots, the exchange stream of a
+  // communicator, the context's own and its forked log joint); the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+  // queues (four by default), and two busy streams that share a queue run one after the other (profiles/r04_experiments.md section 11:
+  // the R = 8 step 0.34 -> 0.51 ms when that happens).  The runtime reads the variable when it initialises -- at the first HIP call of the
+  // process -- so it is raised HERE, ahead of this function's own first HIP call, for every host alike (the MEX gateway, ctypes, a C
+  // caller).  A value already in the environment is kept; it has no effect when another HIP user (torch, say) initialised the runtime
+  // first -- the streams are then placed among the queues that exist (stream_beside) -- and VBMC_HW_QUEUES=0 leaves the variable alone.
+  {
+    const char* hq = getenv("VBMC_HW_QUEUES");
+    if (!(hq && !strcmp(hq, "0"))) (void)setenv("GPU_MAX_HW_QUEUES", hq && atoi(hq) > 0 ? hq : "8", 0);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VBMC_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev) return VBMC_ERR_NO_DEVICE;
@@ -264,6 +275,7 @@ extern "C" vbmc_status vbmc_gp_upload(vbmc_ctx* ctx, int N, int D, int S, int Nh
 
 extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
   if (!gp) return;
+  if (ctx && gp->pooled) ctx_drain_slots(ctx);   // a pass in flight on a slot stream may still read the blocks the pool is about to hand out again
   // pooled blocks go back to the context's pool; without a live context (destroyed first) they are already gone with it
   void* blocks[] = {gp->X, gp->alpha, gp->L, gp->gpc, gp->hyp, gp->d_sn2, gp->d_lchol, gp->d_mult, gp->d_finv, gp->d_tinv, gp->d_meanX};
   for (void* b : blocks) {
@@ -1310,13 +1322,13 @@ __global__ void k_place_probe(long long ticks) {
   if (ticks < 0) probe_lds[threadIdx.x] = 0;
 }
 // when the small kernel on `b` finished, as a fraction of the long kernel on `a` (both streams idle before); 2 on any error
-static double place_ratio(int num_cu, hipStream_t a, hipStream_t b) {
+static double place_ratio(int device, int num_cu, hipStream_t a, hipStream_t b) {
   hipEvent_t e[3] = {nullptr, nullptr, nullptr};
   double best = 2.0;
   bool ok = true;
   for (auto& ev : e) ok = ok && hipEventCreate(&ev) == hipSuccess;
   int khz = 100000;
-  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
   const long long ticks = (long long)(15e-6 * khz * 1e3);     // 15 us per workgroup, three rounds of four one-wave workgroups per compute unit
   for (int rep = 0; ok && rep < 2; ++rep) {
     ok = ok && hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess;
@@ -1346,7 +1358,7 @@ static hipStream_t stream_beside(vbmc_ctx* ctx, const hipStream_t* beside, int n
     cand[nc++] = s;
     bool ok = true;
     for (int i = 0; i < nb && ok && !off; ++i) {
-      const double r = place_ratio(ctx->num_cu, beside[i], s);
+      const double r = place_ratio(ctx->device, ctx->num_cu, beside[i], s);
       if (dbg) fprintf(stderr, "[vbmc place] candidate %d beside stream %d: %.2f\n", nc - 1, i, r);
       ok = r < 0.35;
     }
@@ -1449,6 +1461,20 @@ extern "C" vbmc_status vbmc_elbo_collect(vbmc_ctx* ctx, const vbmc_elbo_args* a,
   vbmc_ctx* sc = ctx->slot_where[slot];
   { vbmc_status s_ = elbo_collect_core(sc, a, ctx->slot_inner[slot], &sp, "vbmc_elbo_collect"); if (s_) return slot_err(ctx, sc, s_); }
   elbo_unpack(sp->P, a, sp->hout);
+  return VBMC_OK;
+}
+
+// gives a slot back without its results: waits for the pass in flight (if any) and clears the slot -- for a caller that will not collect
+// (an exception between submit and collect, an abandoned generator).  No-op on an idle slot.
+extern "C" vbmc_status vbmc_elbo_abandon(vbmc_ctx* ctx, int slot) {
+  if (!ctx) return VBMC_ERR_INVALID;
+  if (slot < 0 || slot >= VBMC_SLOTS) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_abandon: slot must be 0 .. %d", VBMC_SLOTS - 1);
+  if (!slot_in_flight(ctx, slot)) return VBMC_OK;
+  vbmc_ctx* sc = ctx->slot_where[slot];
+  const int inner = ctx->slot_inner[slot];
+  hipError_t e_ = sc->slot_ev[inner] ? hipEventSynchronize(sc->slot_ev[inner]) : hipStreamSynchronize(sc->stream);
+  sc->slot_busy[inner] = false;
+  if (e_ != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_abandon: %s", hipGetErrorString(e_)); }
   return VBMC_OK;
 }
 
@@ -1670,7 +1696,8 @@ __global__ void k_test_exp(int n, int variant, const double* __restrict__ x, dou
 
 // variant 3: vb_exp_tab1k, the entropy kernel's exp, on y = x * 1024/ln2 (in the kernel the factor sits in the MFMA operands)
 #include "exp2_tab1k.h"
-__global__ void k_test_exp1k(int n, const double* __restrict__ x, double* __restrict__ y) {
+// variant 3: as the entropy kernel is built (VB_EXP_TAB1K_QUAD), 4: the economised cubic, 5: the economised quadratic
+__global__ void k_test_exp1k(int n, int variant, const double* __restrict__ x, double* __restrict__ y) {
   __shared__ double tab[VB_EXP_TAB1K_N];
   for (int t = threadIdx.x; t < VB_EXP_TAB1K_N; t += blockDim.x) tab[t] = c_exp2_tab1k[t];
   __syncthreads();
@@ -1678,7 +1705,8 @@ __global__ void k_test_exp1k(int n, const double* __restrict__ x, double* __rest
   if (i < n) {
     double ys;   // a ROUNDED product, as the MFMA delivers it: the compiler must not contract it into the reduction's subtraction
     asm volatile("v_mul_f64 %0, %1, %2" : "=v"(ys) : "v"(x[i]), "v"(VB_EXP_TAB1K_SCALE));
-    y[i] = vb_exp_tab1k(ys, tab);
+    const bool quad = variant == 3 ? VB_EXP_TAB1K_QUAD : variant == 5;
+    y[i] = quad ? vb_exp_tab1k<true>(ys, tab) : vb_exp_tab1k<false>(ys, tab);
   }
 }
 
@@ -1688,7 +1716,8 @@ extern "C" vbmc_status vbmc_test_exp(vbmc_ctx* ctx, int n, int variant, const do
   { vbmc_status s_ = ensure(ctx, ctx->misc, 2 * (size_t)n * sizeof(double)); if (s_) return s_; }
   double* dx = (double*)ctx->misc.p;
   HIP_TRY(ctx, hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (variant == 3) hipLaunchKernelGGL(k_test_exp1k, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, dx, dx + n);
+  if (variant >= 3 && variant <= 5) hipLaunchKernelGGL(k_test_exp1k, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, variant, dx, dx + n);
+  else if (variant < 0 || variant > 5) return VBMC_ERR_INVALID;
   else hipLaunchKernelGGL(k_test_exp, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, variant, dx, dx + n);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(y, dx + n, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));

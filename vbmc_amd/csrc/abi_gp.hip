@@ -455,6 +455,7 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
 
 extern "C" vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32_t noisefun[3], const double* sn2_mult) {
   if (!ctx || !gp || !noisefun || !sn2_mult) return VBMC_ERR_INVALID;
+  if (gp->d_mult) ctx_drain_slots(ctx);    // a pass in flight on a slot stream may be reading the multipliers about to be overwritten
   for (int i = 0; i < 3; ++i) gp->noisefun[i] = noisefun[i];
   if (!gp->d_mult) HIP_TRY(ctx, gp->pooled ? pool_get(ctx, (size_t)gp->S * 8, (void**)&gp->d_mult) : hipMalloc((void**)&gp->d_mult, (size_t)gp->S * 8));
   HIP_TRY(ctx, hipMemcpy(gp->d_mult, sn2_mult, (size_t)gp->S * 8, hipMemcpyHostToDevice));

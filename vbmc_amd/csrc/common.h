@@ -94,6 +94,20 @@ static inline bool ctx_aux(vbmc_ctx* ctx) {
   return true;
 }
 
+// Passes submitted through the pipeline slots run on the child contexts' own streams, ordered after the parent's stream only at submit.
+// Whatever then changes or releases something such a pass may still read -- a pooled surrogate given back (vbmc_gp_free), its noise
+// model rewritten (vbmc_gp_set_noise), a rank-one update reusing pool blocks -- first waits for the child streams that hold a pass
+// (round 5, ADVICE r4: the header's "collect first" was the only protection).  The slots stay collectable.
+static inline void ctx_drain_slots(vbmc_ctx* ctx) {
+  if (!ctx) return;
+  for (int sl = 0; sl < VBMC_SLOTS; ++sl) {
+    vbmc_ctx* w = ctx->slot_where[sl];
+    if (w && w != ctx && w->slot_busy[ctx->slot_inner[sl]]) (void)hipStreamSynchronize(w->stream);
+  }
+  for (int sl = 0; sl < 2; ++sl)
+    if (ctx->slot_busy[sl]) { (void)hipStreamSynchronize(ctx->stream); break; }
+}
+
 static inline hipError_t pool_get(vbmc_ctx* ctx, size_t bytes, void** out) {
   if (bytes < 256) bytes = 256;
   int best = -1;

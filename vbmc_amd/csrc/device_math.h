@@ -168,6 +168,17 @@ __device__ __forceinline__ vb_d4 vb_exp_tab4(vb_d4 x, const double* __restrict__
 // Accuracy as vb_exp_tab<1> ("sum" mode): the argument's own rounding, |x| 1e-16, dominates.
 #define VB_EXP_TAB1K_N 1024
 #define VB_EXP_TAB1K_SCALE 1477.3197218702985291365628   // 1024 / ln 2
+// QUAD (round 5: what the entropy kernel runs; -DVBMC_EXP_CUBIC builds it with the cubic for A/B runs): the polynomial behind the table is
+// the economised QUADRATIC 1 + c r' (1 + c r'/2) -- one fused multiply-add fewer per value (10 VALU operations), relative error
+// (c/2)^3/24 = 1.6e-12 of every term, an odd function of r' to leading order, so that over the terms of a mixture density it averages out:
+// measured on the headline shape, H and dH move by 1.3e-16 and 2.2e-16 (profiles/r04_experiments.md section 2); the 50-digit vectors of
+// tests/golden stay at 1e-11, and the per-value bound is tests/test_gpu_elbo.py::test_device_exp_sum_mode_accuracy.
+#ifdef VBMC_EXP_CUBIC
+#define VB_EXP_TAB1K_QUAD false
+#else
+#define VB_EXP_TAB1K_QUAD true
+#endif
+template <bool QUAD = false>
 __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restrict__ tab) {
   const double c = 0.693147180559945309417232 / 1024;
 #ifdef VBMC_EXP_MAGIC
@@ -180,12 +191,9 @@ __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restric
     const int lo = __double2loint(t), hi = __double2hiint(t);
     const double r = y - (t - MAGIC);
     const double T = tab[lo & (VB_EXP_TAB1K_N - 1)];
-#ifdef VBMC_EXP_QUAD
-    const double u = fma(r, c * c / 2, c);
-#else
-    double u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96);
-    u = fma(r, u, c);
-#endif
+    double u;
+    if (QUAD) u = fma(r, c * c / 2, c + c * c * c / 32);
+    else { u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96); u = fma(r, u, c); }
     const double Tr = T * r;
     return ldexp(fma(Tr, u, T), (int)__builtin_amdgcn_alignbit((unsigned)hi, (unsigned)lo, 10));
   }
@@ -196,22 +204,28 @@ __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restric
   int ni;
   asm("v_cvt_i32_f64 %0, %1" : "=v"(ni) : "v"(nr));
   const double r = y - nr;
-  const double T = tab[ni & (VB_EXP_TAB1K_N - 1)];
-  // the dropped quartic term (c r')^4/24 is economised into the quadratic one (r'^4 ~ r'^2/4 - 1/128 on [-1/2, 1/2]:
-  // Chebyshev), which leaves a remainder of c^4/24/64 = 1.4e-16 instead of 5.4e-16 at no cost
-#ifdef VBMC_EXP_QUAD
-  const double u = fma(r, c * c / 2, c);     // A/B variant: quadratic (relative error (c/2)^3/6 = 6.5e-12)
+#ifdef VBMC_EXP_TABLIN   // diagnostic build (results meaningless): the table read without bank conflicts -- consecutive lanes read consecutive
+                         // entries; same instructions (the mask is a scalar register the compiler cannot see through)
+  int msk_;
+  asm("s_mov_b32 %0, 0" : "=s"(msk_));
+  const double T = (tab + (threadIdx.x & 63))[ni & msk_];
 #else
-  double u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96);
-  u = fma(r, u, c);
+  const double T = tab[ni & (VB_EXP_TAB1K_N - 1)];
 #endif
+  // cubic: the dropped quartic term (c r')^4/24 is economised into the quadratic one (r'^4 ~ r'^2/4 - 1/128 on [-1/2, 1/2]:
+  // Chebyshev), which leaves a remainder of c^4/24/64 = 1.4e-16 instead of 5.4e-16 at no cost.  Quadratic: the dropped cubic term
+  // (c r')^3/6 is economised into the linear one (r'^3 ~ 3 r'/16): remainder c^3/6/32 = 1.6e-12 instead of 6.5e-12
+  double u;
+  if (QUAD) u = fma(r, c * c / 2, c + c * c * c / 32);
+  else { u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96); u = fma(r, u, c); }
   const double Tr = T * r;
   return ldexp(fma(Tr, u, T), ni >> 10);
 }
+template <bool QUAD = false>
 __device__ __forceinline__ vb_d4 vb_exp_tab1k4(vb_d4 y, const double* __restrict__ tab) {
   vb_d4 e;
-  e[0] = vb_exp_tab1k(y[0], tab); e[1] = vb_exp_tab1k(y[1], tab);
-  e[2] = vb_exp_tab1k(y[2], tab); e[3] = vb_exp_tab1k(y[3], tab);
+  e[0] = vb_exp_tab1k<QUAD>(y[0], tab); e[1] = vb_exp_tab1k<QUAD>(y[1], tab);
+  e[2] = vb_exp_tab1k<QUAD>(y[2], tab); e[3] = vb_exp_tab1k<QUAD>(y[3], tab);
   return e;
 }
 

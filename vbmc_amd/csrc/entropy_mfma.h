@@ -96,6 +96,42 @@ constexpr bool X_S = true;
 #endif
 
 
+// Round 5 (profiles/r05_experiments.md), each with its A/B switch:
+//  GP2  the gradient epilogue without shuffles and without branches: the lanes of column 1 hand A'_i over with q'_i (same exec-masked
+//       store), the sample-layout lanes return 1/q'_i AND A'_i/q'_i, and the PV-layout lanes read the pair with one broadcast ds_read2 --
+//       no ds_bpermute (16 per tile), and no `d < D` predicate around the four sample rows (lanes of the padded columns compute values
+//       nobody stores): the compiler had made four basic blocks of them, each an exposed LDS round trip.   -DVBMC_NO_GP2: round 4's form
+//  EVX  (NOT adopted) the padded slots of the sample-side fragment zeroed by v_and_b32 with masks the compiler cannot see through, instead
+//       of the four v_cndmask_b32 it makes of the AND with a compare's 0 / -1 (19 cycles each in tools/valu_rate.hip's isolated chain):
+//       in the kernel the selects are FASTER -- by 0.8 % (minimum of four interleaved runs) to 2 % (median); an exec-masked v_mov_b64
+//       between two scalar writes of exec: +1.6 % (profiles/r05_experiments.md).                           -DVBMC_EVX: the and-form
+//  ETZ  dim-blocks that are all padding are zeroed once per wave, not once per tile (four v_mov_b64 per tile).   -DVBMC_NO_ETZ
+#ifdef VBMC_NO_GP2
+constexpr bool X_GP2 = false;
+#else
+constexpr bool X_GP2 = true;
+#endif
+#ifdef VBMC_EVX          // (A/B only: measured slower than the selects, see above)
+constexpr bool X_EVX = true;
+#else
+constexpr bool X_EVX = false;
+#endif
+#ifdef VBMC_NO_ETZ
+constexpr bool X_ETZ = false;
+#else
+constexpr bool X_ETZ = true;
+#endif
+//  C2   the even part of the exponent rides in the linear product: D + 2 <= 4 QS always, so the inner slots D and D + 1 of the last
+//       dim-block(s) are free -- they carry [|u'|^2, 1] against [h_k - h_j, const_k], and E+ = L + C comes out of QS MFMAs per k-tile
+//       instead of QS + 1.  The second sign still needs C by itself (E- = 2C - E+): 2C_ik = 2 c0_k |u'_i|^2 + 2 c1_k, one FMA per
+//       element from a pair table in LDS (one broadcast ds_read_b128 per element, immediate offsets, issued behind the MFMAs).
+//       Per tile -KT MFMA (27 ns each), +4 KT VALU.                                                  -DVBMC_NO_C2: round 4's S-step
+#ifdef VBMC_NO_C2
+constexpr bool X_C2 = false;
+#else
+constexpr bool X_C2 = true;
+#endif
+
 // Ordering point for LDS words that only ONE wave touches (lanes of a wave exchanging values through LDS): the hardware
 // executes a wave's LDS instructions in order, so no s_barrier and no full s_waitcnt drain is needed -- only the compiler must
 // keep the accesses in program order (wave-level fence).  The waves of a two-wave workgroup meet only at the eps staging and
@@ -179,7 +215,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   constexpr int QL = QS;                   // MFMAs of the linear part of the S-step (inner index c = 4q + lg < D, zero operands beyond D: for
                                            // D mod 4 in {3, 0} the last one multiplies zeros -- a compile-time count keeps the KT chains branch-free)
   __shared__ double Et_all[CW][16 * DP];   // eps tile [i][d], staged by wave 0 and shared by the HV waves of the workgroup (one per chunk wave)
-  __shared__ double RQ_all[HV * CW][16];   // q'_i then 1/q'_i
+  constexpr bool GP2 = X_GP2 && GRAD;
+  __shared__ double RQ_all[HV * CW][GP2 ? 32 : 16];   // q'_i then 1/q'_i  (GP2: and A'_i then A'_i/q'_i behind them)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
   constexpr int YXN = NPV * 4 * WAVE;      // doubles per (sign, wave) slot of the PV exchange (in the dynamic LDS, see PB)
@@ -200,6 +237,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #endif
   constexpr bool VBL = GRAD && HV == 1 && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
+  constexpr bool C2 = X_C2 && VBMC_ENT_EO(HV) && !SPARSE;
+  __shared__ __attribute__((aligned(16))) double SCP_all[HV][C2 ? KT * 16 * 2 : 2];   // C2: [component 16 kt + c][2 c0, 2 c1] of the even part
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   // CW > 1 (chunk waves): the CW waves of a workgroup work on the SAME (component j, restart r) and on CW consecutive sample chunks,
   // each on its own -- no barrier in the tile loop -- but they share what depends on (j, r) only: the exp table, the PV operands and,
@@ -223,6 +262,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   double* BND = BND_all[hv];
   double* VBS = VBS_all[hv];
   double* BTL = BTL_all[hv];
+  double* SCP = SCP_all[hv];
   const int Kh = (K + HV - 1) / HV;                    // components per wave
   const int kbase = hv * Kh;
   const int Kw = min(K, kbase + Kh) - kbase;           // this wave's components: kbase .. kbase + Kw - 1
@@ -301,7 +341,11 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     for (int q = 0; q < QL; ++q) {
       const int cc = 4 * q + lg;
       if (EO) {
-        const double sav = (kv && cc < D) ? ESC * (-2.0 * h * (pk[cc] - pj[cc])) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+        double sav = (kv && cc < D) ? ESC * (-2.0 * h * (pk[cc] - pj[cc])) : 0.0;   // m'_ck / sigma_k^2   (h = -1/(2 sigma^2))
+        if (C2) {   // the even part in the free inner slots D (coefficient of |u'|^2) and D + 1 (constant; padded component: exp -> 0)
+          if (cc == D) sav = kv ? ESC * (h + hj_neg) : 0.0;
+          if (cc == D + 1) sav = ESC * (kv ? fma(h, m2, pk[D + 1]) - cKj : -1.0e6);
+        }
         if (SAL) { if (cwi == 0) SAS[(kt * QL + q) * WAVE + lane] = sav; }
         else SA[SAL ? 0 : kt][q] = sav;
       } else {   // plain S-step: linear and even columns in one (D + 2)-column operand, QS MFMAs per sign
@@ -317,6 +361,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2) is folded into the two even columns: accumulators start at 0
     SC[kt] = ESC * (!kv ? (lg == 1 ? -1.0e6 : 0.0)                          // padded component: exp -> 0
                         : (lg == 0 ? h + hj_neg : (lg == 1 ? fma(h, m2, pk[D + 1]) - cKj : 0.0)));
+    if (C2 && lg < 2 && (CW == 1 || cwi == 0)) SCP[(16 * kt + li) * 2 + lg] = 2.0 * SC[kt];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int k2 = 16 * kt + 4 * rr + lg;
@@ -440,6 +485,18 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     }
   };
   if (EPF && epsr) eps_fetch(t0);
+  // (ETZ) the device-RNG path writes only the dim-blocks that hold a dimension: the others are zeroed here, once.  The first ordering point
+  // of the tile body lies between this and the first read.
+  if (X_ETZ && !epsr && (HV == 1 || hv == 0))
+    for (int idx = lane; idx < 16 * DP; idx += WAVE) Et[idx] = 0.0;
+  // (EVX) lanes whose slot of the last dim-block (and, for D = 4 QS - 5, of the one before) is padding, as wave masks in scalar registers
+  int evm1 = emask, evm2 = emask2;
+  if (X_EVX) { asm volatile("" : "+v"(evm1)); asm volatile("" : "+v"(evm2)); }
+  // (C2) the sample-side values of the even slots: slot D takes |u'_i|^2 (factor c2u), slot D + 1 the constant 1 (c2o); they sit in the last
+  // dim-block, or -- D = 4 QS - 5 -- slot D in the last slot of the one before
+  const double c2u1 = (4 * (QS - 1) + lg == D) ? 1.0 : 0.0, c2o1 = (4 * (QS - 1) + lg == D + 1) ? 1.0 : 0.0;
+  const double c2u2 = (QS >= 2 && 4 * (QS - 2) + lg == D) ? 1.0 : 0.0;
+  const bool c2prev = QS >= 2 && D == 4 * QS - 5;
 
   // The tile body, compiled twice where it pays (VBMC_ENT_SPLIT): once for the full tiles -- no sample-validity selects at all: a
   // v_cndmask_b32 costs four fp64 operations on this chip (tools/valu_rate.hip), and written as rare uniform branches inside one body
@@ -487,8 +544,10 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
         }
 #undef VBMC_RNG_CALL_FOR
 #endif
+        if (!X_ETZ || q < (D + 3) / 4) {     // (ETZ: an all-padding dim-block has been zero since the start of the wave)
 #pragma unroll
         for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = US ? sigj * z4[t] : z4[t];
+        }
       }
     }
     ent_sync_wg<HV>();
@@ -500,8 +559,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       ev[q] = Et[li * DP + 4 * q + lg];   // zero beyond D
       // (device-RNG tiles carry draws in the padded dimensions: D = 4 QS - 5 .. 4 QS - 2, so the padding is the tail of the last dim-block
       // and, for D = 4 QS - 5, the whole of it plus the last slot of the one before)
-      if (q == QS - 1) ev[q] = __hiloint2double(__double2hiint(ev[q]) & emask, __double2loint(ev[q]) & emask);
-      if (QS >= 2 && q == QS - 2) ev[q] = __hiloint2double(__double2hiint(ev[q]) & emask2, __double2loint(ev[q]) & emask2);
+      if (q == QS - 1) ev[q] = __hiloint2double(__double2hiint(ev[q]) & evm1, __double2loint(ev[q]) & evm1);
+      if (QS >= 2 && q == QS - 2) ev[q] = __hiloint2double(__double2hiint(ev[q]) & evm2, __double2loint(ev[q]) & evm2);
       e2 = fma(ev[q], ev[q], e2);
     }
     e2 += __shfl_xor(e2, 16, 64);
@@ -539,10 +598,30 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       double sfl[QL];
 #pragma unroll
       for (int q = 0; q < QL; ++q) sfl[q] = US ? ev[q] : ev[q] * sigj;       // u'_ic (zero beyond D)
+      if (C2) {
+        sfl[QL - 1] = fma(u2, c2u1, sfl[QL - 1] + c2o1);      // (the dimensions' lanes: + 0)
+        if (QS >= 2 && c2prev) sfl[QL >= 2 ? QL - 2 : 0] = fma(u2, c2u2, sfl[QL >= 2 ? QL - 2 : 0]);
+      }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
         if (!NML) nm[(EO && !NML) ? kt : 0] = (mf4){0.0, 0.0, 0.0, 0.0};
+        if (C2) {
+#pragma unroll
+          for (int q = 0; q < QL; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SAV(kt, q), sfl[q], n[kt], 0, 0, 0);
+          mf4 e2nd;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const double2 pr = *reinterpret_cast<const double2*>(SCP + (16 * kt + 4 * rr + lg) * 2);
+            e2nd[rr] = fma(pr.x, u2, pr.y) - n[kt][rr];
+          }
+          if (NML) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) NMS[(kt * 4 + rr) * WAVE + lane] = e2nd[rr];
+          } else {
+            nm[(EO && !NML) ? kt : 0] = e2nd;
+          }
+        } else
         if (!SP || ((act >> kt) & 1u)) {
           const mf4 cacc = X_S ? __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0) : (mf4){SC[kt] * sfc, sfl[0], SAV(kt, 0), -1.0};
           n[kt] = cacc;
@@ -584,25 +663,25 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #pragma unroll
       for (int kt = k0; kt < k1; ++kt) {
         if (kt < KT - 1) {
-          if (!SP || ((act >> kt) & 1u)) x[kt] = vb_exp_tab1k4(x[kt], TAB);
+          if (!SP || ((act >> kt) & 1u)) x[kt] = vb_exp_tab1k4<VB_EXP_TAB1K_QUAD>(x[kt], TAB);
           else x[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
         } else if (SP && !((act >> (KT - 1)) & 1u)) {
           x[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
         } else if (nr_last == 4) {
-          x[KT - 1] = vb_exp_tab1k4(x[KT - 1], TAB);
+          x[KT - 1] = vb_exp_tab1k4<VB_EXP_TAB1K_QUAD>(x[KT - 1], TAB);
         } else {  // registers whose four components are all padding stay exactly zero
           mf4 t = x[KT - 1];
           x[KT - 1] = (mf4){0.0, 0.0, 0.0, 0.0};
-          x[KT - 1][0] = vb_exp_tab1k(t[0], TAB);
-          if (nr_last > 1) x[KT - 1][1] = vb_exp_tab1k(t[1], TAB);
-          if (nr_last > 2) x[KT - 1][2] = vb_exp_tab1k(t[2], TAB);
+          x[KT - 1][0] = vb_exp_tab1k<VB_EXP_TAB1K_QUAD>(t[0], TAB);
+          if (nr_last > 1) x[KT - 1][1] = vb_exp_tab1k<VB_EXP_TAB1K_QUAD>(t[1], TAB);
+          if (nr_last > 2) x[KT - 1][2] = vb_exp_tab1k<VB_EXP_TAB1K_QUAD>(t[2], TAB);
         }
       }
     };
     auto texp = [&](double (&t)[TLN]) {
       if (TL && X_EXP) {
 #pragma unroll
-        for (int u = 0; u < TLN; ++u) t[u] = vb_exp_tab1k(t[u], TAB);
+        for (int u = 0; u < TLN; ++u) t[u] = vb_exp_tab1k<VB_EXP_TAB1K_QUAD>(t[u], TAB);
       }
     };
     // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
@@ -668,12 +747,13 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     };
     // per-sample scalars in the sample layout (lane <-> sample li): q' from column 0, through LDS
     auto put_q = [&](mf4 (&Y)[NPV]) {
-      if (li == 0) {
+      if (GP2 ? li < 2 : li == 0) {      // column 0: q'_i; GP2: column 1 too, A'_i
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) RQ[lg + 4 * rr] = Y[0][rr];
+        for (int rr = 0; rr < 4; ++rr) RQ[(GP2 ? 16 * li : 0) + lg + 4 * rr] = Y[0][rr];
       }
       ent_sync<HV>();   // RQ is private to the wave
     };
+    double arq = 0.0;   // GP2: A'_i / q'_i in the sample layout
     auto get_rq = [&]() -> double {
       double qs_ = RQ[li];
       double rqs = vb_rcp(qs_);
@@ -681,6 +761,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
         qs_ = svalid ? qs_ : 1.0;
         rqs = svalid ? rqs : 0.0;
       }
+      if (GP2) arq = RQ[GP2 ? 16 + li : 0] * rqs;
       pm *= __builtin_amdgcn_frexp_mant(qs_);   // sum log q' = ln2 * sum exp + log(prod mant)
       pe += __builtin_amdgcn_frexp_exp(qs_);
       accH += shift;
@@ -700,12 +781,30 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     };
     auto put_rq = [&](double rqs) {
       ent_sync<HV>();
-      if (lg == 0) RQ[li] = rqs;
+      if (lg == 0) { RQ[li] = rqs; if (GP2) RQ[GP2 ? 16 + li : 0] = arq; }
       ent_sync<HV>();
     };
     // gradient pieces in the PV output layout
     auto gradpieces = [&](mf4 (&Y)[NPV], double ssig, auto sgc) {   // sgc: the sign as a compile-time +1 / -1 (US: no multiply), or 0: ssig at run time
       constexpr int SG = decltype(sgc)::value;
+      if constexpr (GP2) {
+#pragma unroll
+        for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
+          const int i = lg + 4 * rr;
+          const double rq = RQ[i], ar = RQ[GP2 ? 16 + i : 0];     // one broadcast read of the pair
+#pragma unroll
+          for (int pv = 0; pv < NPV; ++pv) {
+            if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
+            const int d = min(max(16 * pv + li - 2, 0), DP - 1);   // columns that are no dimension read a valid slot and are never stored
+            const double t = (US && SG > 0) ? Et[i * DP + d] : ((US && SG < 0) ? -Et[i * DP + d] : ssig * Et[i * DP + d]);   // u'_id = +-eps_id sigma_j
+            const double gd = fma(t, ar, -(Y[pv][rr] * rq));     // lambda_d lsum_d / q = (u'_id A'_i - B'_id) / q'_i  (:77-79)
+            accG[pv] += gd;                                      // -> mu_grad (:82)
+            accLG[pv] = fma(t, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93), times sigma_j (divided out at the end)
+          }
+        }
+        ent_sync<HV>();
+        return;
+      }
       const int base = lane & 48;
 #pragma unroll
       for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {

@@ -445,15 +445,28 @@ class PreparedObjective:
         import os
 
         depth = 4 if int(self.args.compute_var) == 0 and os.environ.get("VBMC_SLOT_STREAMS") != "0" else 2
-        for i, th in enumerate(batches):
-            self.submit(th, seed=(seeds[i] if seeds is not None else i), slot=i % depth)
-            pending.append(i % depth)
-            if len(pending) == depth:
+        try:
+            for i, th in enumerate(batches):
+                self.submit(th, seed=(seeds[i] if seeds is not None else i), slot=i % depth)
+                pending.append(i % depth)
+                if len(pending) == depth:
+                    F, dF = self.collect(pending.pop(0))
+                    yield F.copy(), dF.copy()
+            while pending:
                 F, dF = self.collect(pending.pop(0))
                 yield F.copy(), dF.copy()
-        while pending:
-            F, dF = self.collect(pending.pop(0))
-            yield F.copy(), dF.copy()
+        finally:
+            # an abandoned generator, or an exception between a submit and its collect: no pass stays in flight behind a slot nobody
+            # will collect (vbmc_elbo_abandon waits for it and frees the slot)
+            for sl in pending:
+                self.abandon(sl)
+
+    def abandon(self, slot=0):
+        """Give ``slot`` back without its results (waits for the pass in flight, if any)."""
+        ctx = self.engine.ctx
+        st = ctx.lib.vbmc_elbo_abandon(ctx.h, int(slot))
+        if st:
+            ctx.check(st)
 
 
 def negelcbo_vbmc(theta, beta, vp, gp, Ns=0, compute_grad=None, compute_var=None, altent_flag=False, thetabnd=None,
