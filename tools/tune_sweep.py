@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = "small" in sys.argv[1:] or os.environ.get("TUNE_SMALL") == "1"
 SHAPES = ([(D, K) for K in (8, 16, 24, 32, 40, 48, 56, 64) for D in (2, 6, 10, 14, 20, 28)] if SMALL else
           [(D, K) for K in (48, 64, 80, 96, 112, 128, 192, 256) for D in (6, 10, 14, 18, 20, 24, 28, 32)])
+if os.environ.get("TUNE_KS"):      # another grid: TUNE_KS=20,36,52 TUNE_DS=6,10,14
+    SHAPES = [(D, K) for K in map(int, os.environ["TUNE_KS"].split(",")) for D in map(int, os.environ.get("TUNE_DS", "6,10,14,18,20,24,28,32").split(","))]
 
 
 def one():

@@ -430,7 +430,30 @@ static vbmc_status comm_slot_reserve(vbmc_comm* c, vbmc_comm::Slot& sl, size_t c
   return VBMC_OK;
 }
 
+static vbmc_status multi_submit_impl(vbmc_comm* c, const vbmc_gp* const* gps, const vbmc_elbo_args* a, int slot);
+//  whatever way the enqueue fails after passes went onto the slot streams -- a HIP call, the all-gather's own enqueue, the end
+// event -- nothing stays in flight behind a slot nobody will collect: the streams are drained and the slots given back before the error is
+// returned.  (A rank whose own EVALUATION fails still enters the collective with an all-NaN block, below; a rank whose runtime fails
+// cannot, and the others see the communicator's error.)
 extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const* gps, const vbmc_elbo_args* a, int slot) {
+  const vbmc_status st = multi_submit_impl(c, gps, a, slot);
+  if (st != VBMC_OK && c && slot >= 0 && slot < VBMC_SLOTS && !c->slot[slot].busy) {
+    const std::string keep = c->err;
+    for (int i = 0; i < c->n; ++i) {
+      vbmc_ctx* ctx = c->ctx[i];
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (i < (int)c->xs.size() && c->xs[i]) (void)hipStreamSynchronize(c->xs[i]);
+      vbmc_ctx* w = ctx->slot_where[slot];
+      if (w) { (void)hipStreamSynchronize(w->stream); w->slot_busy[ctx->slot_inner[slot]] = false; }
+    }
+    (void)hipGetLastError();
+    c->err = keep;
+  }
+  return st;
+}
+
+static vbmc_status multi_submit_impl(vbmc_comm* c, const vbmc_gp* const* gps, const vbmc_elbo_args* a, int slot) {
   if (!c) return VBMC_ERR_INVALID;
   if (!gps || !a) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: null surrogates / args");
   if (slot < 0 || slot >= VBMC_SLOTS) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_multi_submit: slot must be 0 .. 3");
@@ -497,10 +520,9 @@ extern "C" vbmc_status vbmc_elbo_multi_submit(vbmc_comm* c, const vbmc_gp* const
         hipStream_t both[2];
         int nb = 0;
         for (vbmc_ctx* sub : ctx->slot_sub) if (sub) both[nb++] = sub->stream;
-        c->xs[i] = stream_beside(ctx, both, nb, xs_mode == 2 ? hi : 0);
-        if (!c->xs[i]) return comm_err(c, VBMC_ERR_HIP, "vbmc_elbo_multi_submit: no exchange stream");
+        c->xs[i] = stream_beside(ctx, both, nb, xs_mode == 2 ? hi : 0);     // (none to be had: the exchange stays on the pass's stream)
       }
-      xst = c->xs[i];
+      if (c->xs[i]) xst = c->xs[i];
     }
     if (n == 0 && c->xs[i]) xst = c->xs[i];     // a device without restarts: where this communicator's exchanges have been running
     sl.xst[i] = xst;

@@ -32,6 +32,10 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
   if constexpr (VBMC_ENT_CW > 1 && HV == 1 && KT == 3 && TL == 1) {
     if (!fn && grad && !(ea.cutoff > 0.0)) { fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, VBMC_ENT_CW>; cwv = VBMC_ENT_CW; }
   }
+  // the device-RNG launch of a kernel that otherwise spends registers on the parity mode's prefetch (entropy_mfma.h: EM, EPF)
+  if constexpr (HV == 1 && QS_VALUE <= 4 && KT <= 3) {
+    if (!fn && grad && !ea.eps && !(ea.cutoff > 0.0)) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, 1, false>;
+  }
   if (!fn) {
     if (ea.cutoff > 0.0 && HV == 1 && !TL) {  // opt-in block-sparse variant (single-wave kernels only, no component tail)
       if constexpr (HV == 1 && TL == 0)

@@ -131,6 +131,28 @@ constexpr bool X_C2 = false;
 #else
 constexpr bool X_C2 = true;
 #endif
+// Where C2 and GP2 are used: everywhere except the instantiations where the sweep of every (k-tiles, tail, waves per workgroup) class
+// over D = 2..32 measured them slower than round 4's forms (tools/tune_sweep.py, variants noc2 / nogp2 of tools/tune_build.py against the
+// tree and against round 4's HEAD; profiles/r05_shape_sweep.md).  The losers are the register-bound kernels: the pair reads and the lane
+// constants of C2 tip them into spilling (D = 20, K = 112: 2.28 -> 2.90 ms; D = 18, K = 256: 10.6 -> 15.8; D = 28, K = 36: 0.74 -> 1.05),
+// and at three waves per SIMD with one k-tile the shuffles GP2 removes were hidden anyway.
+constexpr bool ent_c2_for(int KT, int QS, int TL, int HV) {
+  if (HV == 1) {
+    if (KT == 2) return !(TL == 1 && QS >= 6);
+    if (KT == 3) return QS <= 5 || (TL == 0 && QS != 7) || (TL == 1 && QS == 7);
+    if (KT == 4) return QS >= 5;
+    return true;
+  }
+  if (HV == 2) {
+    if (KT == 2) return TL != 2;
+    if (KT == 3) return !((TL == 1 && (QS == 5 || QS == 6)) || (TL == 2 && QS == 6));
+    return true;
+  }
+  if (KT == 2) return !((TL == 1 && QS >= 6) || (TL == 2 && QS >= 5));
+  if (KT == 3) return !(TL == 1 && QS == 7);
+  return QS != 5;
+}
+constexpr bool ent_gp2_for(int KT, int QS, int TL, int HV) { return !(HV == 1 && KT == 1 && TL == 0 && QS <= 3); }
 
 // Ordering point for LDS words that only ONE wave touches (lanes of a wave exchanging values through LDS): the hardware
 // executes a wave's LDS instructions in order, so no s_barrier and no full s_waitcnt drain is needed -- only the compiler must
@@ -167,7 +189,10 @@ __device__ __forceinline__ void ent_sync_wg() {
 // iteration loses the shorter of the two (round 3).  These kernels are built for two waves per SIMD whatever the entropy body needs
 // (ONE from D = 15 on): the grids they serve do not fill the chip anyway, and the log-joint body keeps 6 x 4 QS values per lane in
 // registers (185 VGPRs at QS = 3, beyond 256 from QS = 6 on, where the accumulation registers take the overflow).
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, int CW = 1>
+// EM (round 5): the instantiation reads its draws from memory (parity mode / eps_mode 2) -- it spends QS registers per lane on the tile
+// loaded one tile ahead (EPF below).  EM = false: the device-RNG launch of the same shape; those registers hold PV operands instead
+// (VBR).  Only the instantiations that prefetch exist twice (ent_mfma_inst.hip); everywhere else EM = true is the one kernel for both.
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, int CW = 1, bool EM = true>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
@@ -215,7 +240,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   constexpr int QL = QS;                   // MFMAs of the linear part of the S-step (inner index c = 4q + lg < D, zero operands beyond D: for
                                            // D mod 4 in {3, 0} the last one multiplies zeros -- a compile-time count keeps the KT chains branch-free)
   __shared__ double Et_all[CW][16 * DP];   // eps tile [i][d], staged by wave 0 and shared by the HV waves of the workgroup (one per chunk wave)
-  constexpr bool GP2 = X_GP2 && GRAD;
+  constexpr bool GP2 = X_GP2 && GRAD && ent_gp2_for(KT, QS, TL, HV);
   __shared__ double RQ_all[HV * CW][GP2 ? 32 : 16];   // q'_i then 1/q'_i  (GP2: and A'_i then A'_i/q'_i behind them)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
@@ -237,7 +262,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #endif
   constexpr bool VBL = GRAD && HV == 1 && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
-  constexpr bool C2 = X_C2 && VBMC_ENT_EO(HV) && !SPARSE;
+  constexpr bool C2 = X_C2 && VBMC_ENT_EO(HV) && !SPARSE && ent_c2_for(KT, QS, TL, HV);
   __shared__ __attribute__((aligned(16))) double SCP_all[HV][C2 ? KT * 16 * 2 : 2];   // C2: [component 16 kt + c][2 c0, 2 c1] of the even part
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   // CW > 1 (chunk waves): the CW waves of a workgroup work on the SAME (component j, restart r) and on CW consecutive sample chunks,
@@ -443,7 +468,19 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   if (CW > 1 && c >= a.C) return;   // a chunk wave beyond the last chunk (C not a multiple of CW): no barrier follows
 
 #define SAV(kt_, q_) (SAL ? SAS[((kt_) * QL + (q_)) * WAVE + lane] : SA[SAL ? 0 : (kt_)][q_])
-#define VBV(kt_, rr_, pv_) (VBL ? VBS[(((kt_) * 4 + (rr_)) * NPV + (pv_)) * WAVE + lane] : VB[VBL ? 0 : (kt_)][rr_][pv_])
+  // VBR (round 5): with the registers the gradient epilogue gave back (GP2) and one PV accumulator set (TWO below), PV operands of the
+  // three-k-tile kernels stay in registers again -- the LDS reads of the PV step were worth 2-3 % (profiles/r05_experiments.md: all
+  // twelve in registers -3.4 %, ten -2.5 %, with the parity-mode prefetch holding its QS registers): all of them in the device-RNG
+  // instantiation (EM = false), ten in the one that prefetches its draws.  -DVBMC_VBR=n (A/B): n for both; 0: all from LDS (round 4)
+#ifdef VBMC_VBR
+  constexpr int VBR = (VBL && NPV == 1 && CW == 1 && HV == 1 && KT == 3) ? (VBMC_VBR) : 0;
+#else
+  constexpr int VBR = (VBL && NPV == 1 && CW == 1 && HV == 1 && KT == 3 && !CO) ? ((EM && QS <= 4) ? (TL == 2 ? 4 : 10) : 12) : 0;
+#endif
+  double VBreg[VBR > 0 ? VBR : 1];
+#pragma unroll
+  for (int u = 0; u < VBR; ++u) VBreg[u] = VBS[u * WAVE + lane];
+#define VBV(kt_, rr_, pv_) (VBL ? (((kt_) * 4 + (rr_)) * NPV + (pv_) < VBR ? VBreg[(((kt_) * 4 + (rr_)) * NPV + (pv_)) < VBR ? (((kt_) * 4 + (rr_)) * NPV + (pv_)) : 0] : VBS[(((kt_) * 4 + (rr_)) * NPV + (pv_)) * WAVE + lane]) : VB[VBL ? 0 : (kt_)][rr_][pv_])
   double accH = 0.0, accG[NPV], accLG[NPV];
   double pm = 1.0;            // running product of mantissas of q'
   int pe = 0, pcnt = 0;       // running sum of exponents
@@ -472,7 +509,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #ifdef VBMC_NO_EPF
   constexpr bool EPF = false;
 #else
-  constexpr bool EPF = HV == 1 && QS <= 4 && KT <= 3 && !SPARSE;
+  constexpr bool EPF = EM && HV == 1 && QS <= 4 && KT <= 3 && !SPARSE;
 #endif
   double epre[EPF ? QS : 1];
   auto eps_fetch = [&](const int tile) {
@@ -496,7 +533,6 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // dim-block, or -- D = 4 QS - 5 -- slot D in the last slot of the one before
   const double c2u1 = (4 * (QS - 1) + lg == D) ? 1.0 : 0.0, c2o1 = (4 * (QS - 1) + lg == D + 1) ? 1.0 : 0.0;
   const double c2u2 = (QS >= 2 && 4 * (QS - 2) + lg == D) ? 1.0 : 0.0;
-  const bool c2prev = QS >= 2 && D == 4 * QS - 5;
 
   // The tile body, compiled twice where it pays (VBMC_ENT_SPLIT): once for the full tiles -- no sample-validity selects at all: a
   // v_cndmask_b32 costs four fp64 operations on this chip (tools/valu_rate.hip), and written as rare uniform branches inside one body
@@ -600,7 +636,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       for (int q = 0; q < QL; ++q) sfl[q] = US ? ev[q] : ev[q] * sigj;       // u'_ic (zero beyond D)
       if (C2) {
         sfl[QL - 1] = fma(u2, c2u1, sfl[QL - 1] + c2o1);      // (the dimensions' lanes: + 0)
-        if (QS >= 2 && c2prev) sfl[QL >= 2 ? QL - 2 : 0] = fma(u2, c2u2, sfl[QL >= 2 ? QL - 2 : 0]);
+        if (QS >= 2) sfl[QL >= 2 ? QL - 2 : 0] = fma(u2, c2u2, sfl[QL >= 2 ? QL - 2 : 0]);   // (c2u2 = 0 unless D = 4 QS - 5; unconditional: the
+                                                                                               //  compiler if-converts the test into two selects)
       }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
@@ -692,7 +729,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #elif defined(VBMC_TUNE_PV2)
       constexpr bool TWO = (VBMC_TUNE_PV2) != 0 || NPV == 1;
 #else
-      constexpr bool TWO = NPV == 1;
+      constexpr bool TWO = NPV == 1 && KT <= 2;     // (round 5: at three k-tiles and more the second set's eight registers are worth more as PV
+                                                    //  operands; the dependent MFMAs of one chain issue back to back anyway: 2.138 vs 2.140 ms)
 #endif
       mf4 Y2s[TWO ? NPV : 1];
       mf4 (&Y2)[TWO ? NPV : 1] = Y2s;
