@@ -9,6 +9,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// v + (v of lane ^ 16) / v + (v of lane ^ 32) on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows of one
+// operand with the even rows of the other, so with both operands = v the two results ARE the pair (v[lane], v[lane ^ 16]) in some order --
+// and a sum does not care which.  Two instructions per double and no trip through the LDS pipeline (__shfl_xor: two ds_bpermute_b32 and
+// their wait).  Bit-identical to v + __shfl_xor(v, 16 | 32, 64).
+__device__ __forceinline__ double xor_sum16(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double xor_sum32(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 // fp64 exp used in the hot loops.  Range reduction x = n ln2 + r, |r| <= ln2/2, degree-13 Taylor
 // polynomial in Horner form (|rel err| < 3e-16 before the final scaling), result scaled by
 // 2^n with v_ldexp_f64.  Underflows to 0 and overflows to +inf like exp(); a NaN argument is

@@ -599,8 +599,13 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       if (QS >= 2 && q == QS - 2) ev[q] = __hiloint2double(__double2hiint(ev[q]) & evm2, __double2loint(ev[q]) & evm2);
       e2 = fma(ev[q], ev[q], e2);
     }
+#ifdef VBMC_NO_PLS       // A/B: round 4's shuffles through the LDS pipeline
     e2 += __shfl_xor(e2, 16, 64);
     e2 += __shfl_xor(e2, 32, 64);
+#else
+    e2 = xor_sum16(e2);     // (PLS, round 5: on the VALU -- |u'|^2 heads the last MFMA group of the S-step and the second sign's exponents)
+    e2 = xor_sum32(e2);
+#endif
     // US: the sum above is |u'_i|^2 already
     double shift = US ? fma(-e2, hj_neg, cKj) : cKj - 0.5 * e2;              // exponent of the sample's own component: cK_j - |eps_i|^2 / 2
     const double u2 = US ? e2 : sigj * sigj * e2;                            // |u'_i|^2
@@ -792,6 +797,14 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       ent_sync<HV>();   // RQ is private to the wave
     };
     double arq = 0.0;   // GP2: A'_i / q'_i in the sample layout
+    // TQ (round 5): the second sign's gradient epilogue reuses the four u'_id the first sign read (-0.2 %; eight registers across the second
+    // sign's exponentials, so only in the headline class, where they are there).  -DVBMC_NO_TQ: both signs read (A/B)
+#ifndef VBMC_NO_TQ
+    constexpr bool TQ = GP2 && US && NPV == 1 && HV == 1 && CW == 1 && EO && KT == 3 && QS <= 3 && !CO && !EM && VBMC_STAG_FOR(KT, QS, TL);
+#else
+    constexpr bool TQ = false;
+#endif
+    double tq[TQ ? 4 : 1];
     auto get_rq = [&]() -> double {
       double qs_ = RQ[li];
       double rqs = vb_rcp(qs_);
@@ -834,7 +847,10 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
           for (int pv = 0; pv < NPV; ++pv) {
             if (HV > 1 && (pv % HV) != hv) continue;      // the waves share the column blocks of the gradient
             const int d = min(max(16 * pv + li - 2, 0), DP - 1);   // columns that are no dimension read a valid slot and are never stored
-            const double t = (US && SG > 0) ? Et[i * DP + d] : ((US && SG < 0) ? -Et[i * DP + d] : ssig * Et[i * DP + d]);   // u'_id = +-eps_id sigma_j
+            double tv;
+            if (TQ) { if (SG >= 0) tq[TQ ? rr : 0] = Et[i * DP + d]; tv = tq[TQ ? rr : 0]; }    // (TQ: the second sign reuses the first sign's reads)
+            else tv = Et[i * DP + d];
+            const double t = (US && SG > 0) ? tv : ((US && SG < 0) ? -tv : ssig * tv);   // u'_id = +-eps_id sigma_j
             const double gd = fma(t, ar, -(Y[pv][rr] * rq));     // lambda_d lsum_d / q = (u'_id A'_i - B'_id) / q'_i  (:77-79)
             accG[pv] += gd;                                      // -> mu_grad (:82)
             accLG[pv] = fma(t, gd, accLG[pv]);                   // -> sigma/lambda grads (:87-93), times sigma_j (divided out at the end)
