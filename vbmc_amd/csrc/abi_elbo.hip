@@ -1052,6 +1052,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   fa.bnd = P.d_bnd; fa.has_bnd = P.has_bnd ? 1 : 0;
   fa.TolCon = P.TolCon; fa.WeightThreshold = P.WeightThreshold; fa.WeightPenalty = P.WeightPenalty;
   fa.beta = P.beta; fa.want_grad = P.compute_grad; fa.out = P.out_direct ? P.out_direct : P.d_out; fa.no_jacobian = P.no_jacobian;
+  fa.invS = 1.0 / S; fa.invM = fa.M > 0 ? 1.0 / (2.0 * fa.M) : 0.0;
   {
     size_t lds = (FIN_THREADS + 3 * (size_t)K + (P.fin_big ? 0 : (size_t)D * K + 3 * (size_t)T) + 8) * sizeof(double);
     fa.big = P.d_finbig;
@@ -1070,10 +1071,12 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     }
     if (lds > 64 * 1024) {
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (fin_seq && !P.no_jacobian) hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);   // (the untransformed gradients exist in k_finalize_ws only)
-    else hipLaunchKernelGGL(k_finalize_ws, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+    else if (fa.stage == 3 && !fa.big) hipLaunchKernelGGL(k_finalize_ws<true>, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+    else hipLaunchKernelGGL(k_finalize_ws<false>, dim3(R), dim3(FIN_THREADS), lds, st, fa);
     LAUNCH_CHECK(ctx, "k_finalize");
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -1684,6 +1687,12 @@ extern "C" int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* t
   if (tail) *tail = h >> 4;
   return ok ? 1 : 0;
 }
+
+#ifdef VBMC_FIN_CLK
+extern "C" int vbmc_dbg_fin_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_dbg), 64 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // test hook: y[i] = exp(x[i]) with the hot-loop implementations (variant 0: vb_exp, 1: vb_exp_tab<0>, 2: vb_exp_tab<1>)
 __global__ void k_test_exp(int n, int variant, const double* __restrict__ x, double* __restrict__ y) {

@@ -75,6 +75,9 @@ __device__ inline void adam_update_chain(const AdamState& A, int iter, double* _
 // ------------------------------------------------------------------------------------------
 // the body of k_prep for restart r, by whichever workgroup calls it (k_prep, or k_finalize_ws for the NEXT iteration of the
 // on-device optimiser loop); sh: dynamic LDS of D K + 3 K + D doubles + one per wave
+// TH_LDS: th_row is given and lives in LDS (the fused call at the end of k_finalize_ws) -- a compile-time fact, so that the reads of theta
+// are ds_read and not flat_load (round 5)
+template <bool TH_LDS = false>
 __device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ theta, const double* __restrict__ vpfix,
                                  double* __restrict__ vpd, double* __restrict__ entp, int r, double* sh,
                                  const double* th_row = nullptr /* restart r's theta where the caller already holds it (LDS) */) {
@@ -88,7 +91,7 @@ __device__ inline void prep_body(const ElboDims& dm, const double* __restrict__ 
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
   const int D = dm.D, K = dm.K;
   VpLayout L{D, K};
-  const double* th = th_row ? th_row : theta + (size_t)r * dm.T;
+  const double* th = TH_LDS ? th_row : (th_row ? th_row : theta + (size_t)r * dm.T);
   double* v = vpd + (size_t)r * L.stride();
   const double* fmu = vpfix;
   const double* fsig = vpfix + D * K;
@@ -670,6 +673,7 @@ struct FinArgs {
   double TolCon, WeightThreshold, WeightPenalty, beta;
   int M, C, ncol, want_grad, has_bnd, var_stride;
   int no_jacobian;        // 1: gradients with respect to sigma, lambda, w themselves (JACOBIAN_FLAG = 0 of the stand-alone forms; k_finalize_ws only)
+  double invS, invM;      // 1 / S and 1 / (2 M) from the host (the same IEEE quotients; a division per thread in k_finalize_ws's preamble otherwise)
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* big;            // null, or R x (3T + DK) doubles of global scratch for dG | dH | dP | gsc when they exceed the LDS
   double* out;            // R x (OUT_HDR + 3T)
@@ -696,6 +700,24 @@ __device__ __forceinline__ void stage_copy(double* __restrict__ dst, const doubl
     for (int u = 0; u < 8; ++u) dst[i + u * nt] = t[u];
   }
   for (; i < n; i += nt) dst[i] = src[i];
+}
+
+// up to four blocks, every load of all of them issued before the first store (round 5: four calls of stage_copy were four -- with the
+// single-element tail loop up to a dozen -- round trips to memory one after the other: 3.3 us of k_finalize_ws's 15, tools/fin_timeline.py).
+// Blocks of at most 4 nt elements each; longer ones fall back to stage_copy.
+struct StageBlk { double* dst; const double* src; int n; };
+__device__ __forceinline__ void stage_copy4(const StageBlk (&b)[4], int tid, int nt) {
+  double t[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[q][u] = (b[q].n <= 4 * nt && tid + u * nt < b[q].n) ? b[q].src[tid + u * nt] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (b[q].n > 4 * nt) { stage_copy(b[q].dst, b[q].src, b[q].n, tid, nt); continue; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (tid + u * nt < b[q].n) b[q].dst[tid + u * nt] = t[q][u];
+  }
 }
 
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize(FinArgs a) {
@@ -966,8 +988,22 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef VBMC_FIN_CLK   // phase timeline of the finalize kernel (tools/fin_timeline.py): restart 0's workgroup stamps the 100 MHz counter
+__device__ unsigned long long g_fin_dbg[64];   // (in-loop iterations only: the Adam tail is part of the picture)
+#define FIN_STAMP(i_) do { if (a.next_iter > 0 && blockIdx.x == 0 && threadIdx.x == 0) g_fin_dbg[i_] = wall_clock64(); } while (0)
+#define FIN_STAMP_W(i_) do { if (a.next_iter > 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_fin_dbg[i_] = wall_clock64(); } while (0)
+#else
+#define FIN_STAMP(i_) do { } while (0)
+#define FIN_STAMP_W(i_) do { } while (0)
+#endif
+// FAST (round 5): everything staged (a.stage == 3) and nothing in the global fall-back block (a.big == null) -- the case of every shape but
+// the very largest.  Known at compile time, the records, the vp block, the bounds and the gradient vectors are LDS pointers and nothing
+// else: ds_read / ds_write instead of the flat_load / flat_store (130 + 78 of them, each waiting on BOTH memory counters) the compiler
+// must emit for a pointer that is global memory or LDS depending on a run-time flag.
+template <bool FAST>
 __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   VB_SMALL_PRIO();
+  FIN_STAMP(0);
   extern __shared__ double lds[];
   const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
@@ -980,21 +1016,23 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   double* Ibar = red + nt;     // K    (unused)
   double* Hj = Ibar + K;       // K    (unused)
   double* wraw = Hj + K;       // K    raw w-gradient of H (task 5's own scratch)
-  double* bigr = a.big ? a.big + (size_t)r * (3 * (size_t)T + (size_t)D * K) : nullptr;
+  double* bigr = (!FAST && a.big) ? a.big + (size_t)r * (3 * (size_t)T + (size_t)D * K) : nullptr;
   double* dG = bigr ? bigr : wraw + K;       // T (packed)
   double* dH = dG + T;         // T
   double* dP = dH + T;         // T   penalty gradient
   double* scal = bigr ? wraw + K : dP + T;   // 8 scalars: G, H, three partial penalties
   double* gsc = bigr ? dP + T : scal + 8;    // D x K   soft-bound gradient of the lnscale block per (d, k)  (task 7's own scratch)
   double* stg = bigr ? scal + 8 : gsc + D * K;
-  if (a.stage & 2) {
-    stage_copy(stg, v, L.stride(), tid, nt);
+  StageBlk sb[4] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+  if (FAST || (a.stage & 2)) {
+    sb[0] = StageBlk{stg, v, L.stride()};
     v = stg;
     stg += L.stride();
+    if (FAST) bnd = stg;          // (an LDS pointer whether or not there are bounds: never read without)
     if (a.has_bnd) {
       const int next_mu = dm.opt[0] ? D * K : 0;
       const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
-      stage_copy(stg, a.bnd, 2 * Text, tid, nt);
+      sb[1] = StageBlk{stg, a.bnd, 2 * Text};
       bnd = stg;
       stg += 2 * Text;
     }
@@ -1004,34 +1042,41 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   const double* lam = v + L.lambda();
   double* o = a.out + (size_t)r * (OUT_HDR + 3 * T);
   const int LJS = 2 * D + 2;
-  const double invS = 1.0 / S;
+  const double invS = a.invS;
   const double* lb = a.ljbar + (size_t)r * K * LJS;
   const double* pe = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;   // (C = 1: reduced records)
-  if (a.stage & 1) {
+  if (FAST || (a.stage & 1)) {
     double* lbL = stg;
     double* peL = lbL + K * LJS;
-    stage_copy(lbL, lb, K * LJS, tid, nt);
-    if (pe) stage_copy(peL, pe, K * a.C * a.ncol, tid, nt);
+    sb[2] = StageBlk{lbL, lb, K * LJS};
+    if (pe) sb[3] = StageBlk{peL, pe, K * a.C * a.ncol};
     lb = lbL;
     if (pe) pe = peL;
   }
+  stage_copy4(sb, tid, nt);      // (every load of the four blocks in flight before the first store)
   for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
   if (tid < 8) scal[tid] = 0.0;
   __syncthreads();
+  FIN_STAMP(1);
 
   const bool grad = a.want_grad != 0;
   const bool jac = a.no_jacobian == 0;   // the Jacobians of sigma = exp(.), lambda = exp(.), w = softmax(eta) (gplogjoint.m:352-373, entmc_vbmc.m:110-125)
   const double lognf = v[L.lognf()];
-  const double invM = a.entpart ? 1.0 / (2.0 * a.M) : 0.0;
+  const double invM = a.entpart ? a.invM : 0.0;
   const int ncol = a.ncol;
   const double* eb = a.entpart ? nullptr : a.entlb + (size_t)r * (1 + D * K + 2 * K + D);
   const int next_mu = dm.opt[0] ? D * K : 0;
   const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
   const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
   const double* blo = bnd;
-  const double* bup = bnd ? bnd + Text : nullptr;
+  const double* bup = (FAST || bnd) ? bnd + Text : nullptr;
 
-  for (int task = wave; task < 9; task += nw) {
+  // Eleven tasks (round 5; nine through round 4): the two lambda blocks that were D sequential 64-lane butterflies (tasks 0 and 4: 3.8 and
+  // 3.6 us of a 5.4 us phase, tools/fin_timeline.py) sum their K terms per lane (lane = dimension + 32 x half of the components) and meet in
+  // ONE exchange; the lambda sums of the lnscale bounds get a wave of their own and recompute their terms instead of reading the other
+  // wave's table; the K x K weight gradient issues its LDS reads eight at a time.
+  for (int task = wave; task < 11; task += nw) {
+    FIN_STAMP_W(16 + 2 * task);
     switch (task) {
       case 0: {   // G (:203,:400), the sigma / lambda / eta blocks of its gradient (:356,:362,:366-368)
         double part = 0.0;
@@ -1043,15 +1088,21 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
             for (int k = lane; k < K; k += 64) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * (jac ? sigma[k] : 1.0) * invS;
           if (dm.opt[3])
             for (int k = lane; k < K; k += 64) { const double Ib = lb[(size_t)k * LJS] * invS; dG[dm.off_eta + k] = jac ? w[k] * Ib - w[k] * G : Ib; }
-          if (dm.opt[2])
-            for (int d = 0; d < D; ++d) {
-              double acc = 0.0;
-              for (int k = lane; k < K; k += 64) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
-              acc = wave_sum(acc);
-              if (lane == 0) dG[dm.off_lambda + d] = acc * (jac ? lam[d] : 1.0) * invS;
-            }
         }
       } break;
+      case 9:     // lambda block of dG (:250,:362): lane <-> (dimension d = lane & 31, components of parity lane >> 5)
+        if (grad && dm.opt[2])
+          for (int d0 = 0; d0 < D; d0 += 32) {
+            const int d = d0 + (lane & 31);
+            double acc = 0.0;
+            if (d < D) {
+#pragma unroll 8
+              for (int k = lane >> 5; k < K; k += 2) acc += lb[(size_t)k * LJS + 2 + D + d];
+            }
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < 32 && d < D) dG[dm.off_lambda + d] = acc * (jac ? lam[d] : 1.0) * invS;
+          }
+        break;
       case 1:     // mu block of dG
         if (grad && dm.opt[0])
           for (int p = lane; p < D * K; p += 64) dG[dm.off_mu + p] = lb[(size_t)(p / D) * LJS + 1 + p % D] * invS;
@@ -1084,11 +1135,15 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
       case 4:     // lambda block of dH (:93; the /lambda of lsum cancels the *lambda of :107)
         if (grad && dm.opt[2]) {
           if (pe)
-            for (int d = 0; d < D; ++d) {
+            for (int d0 = 0; d0 < D; d0 += 32) {
+              const int d = d0 + (lane & 31);
               double acc = 0.0;
-              for (int j = lane; j < K; j += 64) acc += w[j] * sigma[j] * pe[(size_t)j * ncol + 2 + D + d] * invM;
-              acc = wave_sum(acc);
-              if (lane == 0) dH[dm.off_lambda + d] = jac ? acc : acc / lam[d];      // (:116-118)
+              if (d < D) {
+#pragma unroll 8
+                for (int j = lane >> 5; j < K; j += 2) acc += w[j] * sigma[j] * pe[(size_t)j * ncol + 2 + D + d] * invM;
+              }
+              acc += __shfl_xor(acc, 32, 64);
+              if (lane < 32 && d < D) dH[dm.off_lambda + d] = jac ? acc : acc / lam[d];      // (:116-118)
             }
           else
             for (int d = lane; d < D; d += 64) dH[dm.off_lambda + d] = jac ? eb[1 + D * K + K + d] : eb[1 + D * K + K + d] / lam[d];
@@ -1103,7 +1158,15 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
             if (l < K) {
               if (pe) {
                 double acc = 0.0;
-                for (int j = 0; j < K; ++j) acc += w[j] * pe[(size_t)j * ncol + 2 + 2 * D + l] * invM;   // lane <-> l: no cross-lane sum
+                int j = 0;
+                for (; j + 8 <= K; j += 8) {     // lane <-> l: no cross-lane sum; eight LDS reads in flight, summed in component order
+                  double t8[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) t8[u] = w[j + u] * pe[(size_t)(j + u) * ncol + 2 + 2 * D + l] * invM;
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) acc += t8[u];
+                }
+                for (; j < K; ++j) acc += w[j] * pe[(size_t)j * ncol + 2 + 2 * D + l] * invM;
                 wr = -(lognf + pe[(size_t)l * ncol] * invM) - acc;
               } else {
                 wr = eb[1 + D * K + K + D + l];
@@ -1153,14 +1216,28 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
                 for (int d = 0; d < D; ++d) acc += gsc[d + D * k];
                 dP[dm.off_sigma + k] = acc;
               }
-            if (dm.opt[2])
-              for (int d = lane; d < D; d += 64) {
-                double acc = 0.0;
-                for (int k = 0; k < K; ++k) acc += gsc[d + D * k];
-                dP[dm.off_lambda + d] = acc;
-              }
           }
         }
+        break;
+      case 10:    // ... its lambda sums: a wave of its own that recomputes the (rarely non-zero) terms, lane <-> (d, parity of k)
+        if (a.has_bnd && has_sc && grad && dm.opt[2])
+          for (int d0 = 0; d0 < D; d0 += 32) {
+            const int d = d0 + (lane & 31);
+            double acc = 0.0;
+            if (d < D) {
+              const double lnl = v[L.lnlambda() + d];
+              for (int k = lane >> 5; k < K; k += 2) {
+                const double x = v[L.lnsigma() + k] + lnl;
+                const double l = blo[next_mu + d + D * k], u = bup[next_mu + d + D * k], ell = (u - l) * a.TolCon;
+                double g = 0.0;
+                if (x < l) g += (x - l) / (ell * ell);
+                if (x > u) g += (x - u) / (ell * ell);
+                acc += g;
+              }
+            }
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < 32 && d < D) dP[dm.off_lambda + d] = acc;
+          }
         break;
       case 8:     // soft bounds on eta and the weight-size penalty (negelcbo_vbmc.m:146-162)
         if (a.has_bnd && dm.opt[3]) {
@@ -1189,8 +1266,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
         break;
       default: break;
     }
+    FIN_STAMP_W(17 + 2 * task);
   }
   __syncthreads();
+  FIN_STAMP(2);
   // ---- assemble
   double varG = 0.0, varGss = 0.0;
   const double* vr = a.var ? a.var + (size_t)r * a.var_stride : nullptr;
@@ -1228,6 +1307,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
     }
     for (int i = tid + 4 * nt; i < T; i += nt) elem(i);
   }
+  FIN_STAMP(3);
   if (adam) {
     __syncthreads();                                     // every thread is done with dG / dH / dP: their LDS becomes theta's
     double* xl = lds;
@@ -1237,6 +1317,9 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
         if (tid + u * nt < T) xl[tid + u * nt] = xn_keep[u];
       __syncthreads();
     }
-    prep_body(dm, a.next_theta, a.next_vpfix, a.next_vpd, a.next_entp, r, lds, keep ? xl : nullptr);
+    FIN_STAMP(4);
+    if (keep) prep_body<true>(dm, a.next_theta, a.next_vpfix, a.next_vpd, a.next_entp, r, lds, xl);
+    else prep_body<false>(dm, a.next_theta, a.next_vpfix, a.next_vpd, a.next_entp, r, lds, nullptr);
   }
+  FIN_STAMP(5);
 }
