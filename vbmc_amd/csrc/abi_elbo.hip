@@ -612,7 +612,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
   const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
   P.has_bnd = a->bnd_lb != nullptr && a->bnd_ub != nullptr;
-  const size_t n_bnd = P.has_bnd ? 2 * (size_t)Text : 0;
+  const size_t n_bnd = P.has_bnd ? 3 * (size_t)Text : 0;     // lb | ub | 1 / ((ub - lb) TolCon)^2  (round 5: the reciprocals from the host)
   const size_t n_up = P.n_up = n_theta + n_fix + n_delta + n_bnd;
   P.out_n = (size_t)R * (OUT_HDR + 3 * T);
   // pinned block: staged inputs | result records | (separate_K) I_sk and J_sjk in the caller's layouts, when they are small enough
@@ -634,6 +634,10 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   if (P.has_bnd) {
     memcpy(hdel + n_delta, a->bnd_lb, Text * sizeof(double));
     memcpy(hdel + n_delta + Text, a->bnd_ub, Text * sizeof(double));
+    // softbndloss.m's ell = (UB - LB) TolCon enters as 1 / ell^2: (x - LB) / ell^2 and ((LB - x) / ell)^2 = (LB - x)^2 / ell^2 -- two fp64
+    // divisions per bounded element in k_finalize_ws otherwise (44 division sequences, the longest of its tasks)
+    double* hinv = hdel + n_delta + 2 * (size_t)Text;
+    for (int i = 0; i < Text; ++i) { const double ell = (a->bnd_ub[i] - a->bnd_lb[i]) * a->TolCon; hinv[i] = 1.0 / (ell * ell); }
   }
   P.d_theta = (double*)ctx->theta.p;
   P.d_fix = P.d_theta + n_theta;
@@ -1059,7 +1063,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     const int next_mu = dm.opt[0] ? D * K : 0;
     const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
     const size_t stage_rec = ((size_t)K * (2 * D + 2) + (fa.entpart ? (size_t)K * fa.C * fa.ncol : 0)) * sizeof(double);
-    const size_t stage_vp = ((size_t)VpLayout{D, K}.stride() + (P.has_bnd ? 2 * (size_t)Text : 0)) * sizeof(double);
+    const size_t stage_vp = ((size_t)VpLayout{D, K}.stride() + (P.has_bnd ? 3 * (size_t)Text : 0)) * sizeof(double);
     fa.stage = 0;
     if (lds + stage_vp <= 96 * 1024) { fa.stage |= 2; lds += stage_vp; }
     if (lds + stage_rec <= 96 * 1024) { fa.stage |= 1; lds += stage_rec; }

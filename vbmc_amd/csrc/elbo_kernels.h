@@ -603,6 +603,15 @@ __device__ __forceinline__ void ent_reduce_body(int j, int r, int K, int C, int 
   for (int col = threadIdx.x; col < ncol; col += blockDim.x) {
     double acc = 0.0;
     int c = 0;
+    // (round 5) 32 loads in flight, then 8: every batch is one round trip to memory, and a single chain waits for each of them
+    // (k_reduce_both 4.9 -> 3.x us at VBMC's own sample count); the sum stays in chunk order
+    for (; c + 32 <= C; c += 32) {
+      double t[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) t[u] = p[(size_t)(c + u) * ncol + col];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += t[u];
+    }
     for (; c + 8 <= C; c += 8) {
       double v0 = p[(size_t)(c + 0) * ncol + col], v1 = p[(size_t)(c + 1) * ncol + col];
       double v2 = p[(size_t)(c + 2) * ncol + col], v3 = p[(size_t)(c + 3) * ncol + col];
@@ -630,6 +639,13 @@ __device__ __forceinline__ void lj_reduce_body(int k, int r, int S, int K, int L
     const double* p = lj + ((size_t)r * S * K + k) * LJS + col;
     const size_t st = (size_t)K * LJS;
     int s = 0;
+    for (; s + 32 <= S; s += 32) {   // (round 5) 32 loads in flight: one round trip where there were four; summed in sample order
+      double t[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) t[u] = p[(size_t)(s + u) * st];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += t[u];
+    }
     for (; s + 8 <= S; s += 8) {   // eight loads in flight; summed in sample order
       double t[8];
 #pragma unroll
@@ -1032,9 +1048,9 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
     if (a.has_bnd) {
       const int next_mu = dm.opt[0] ? D * K : 0;
       const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
-      sb[1] = StageBlk{stg, a.bnd, 2 * Text};
+      sb[1] = StageBlk{stg, a.bnd, 3 * Text};
       bnd = stg;
-      stg += 2 * Text;
+      stg += 3 * Text;
     }
   }
   const double* w = v + L.w();
@@ -1070,6 +1086,7 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
   const double* blo = bnd;
   const double* bup = (FAST || bnd) ? bnd + Text : nullptr;
+  const double* binv = (FAST || bnd) ? bnd + 2 * Text : nullptr;     // 1 / ell^2, ell = (ub - lb) TolCon (softbndloss.m), from the host
 
   // Eleven tasks (round 5; nine through round 4): the two lambda blocks that were D sequential 64-lane butterflies (tasks 0 and 4: 3.8 and
   // 3.6 us of a 5.4 us phase, tools/fin_timeline.py) sum their K terms per lane (lane = dimension + 32 x half of the components) and meet in
@@ -1184,10 +1201,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
         if (a.has_bnd && dm.opt[0]) {
           double part = 0.0;
           for (int p = lane; p < D * K; p += 64) {
-            const double x = v[L.mu() + p], l = blo[p], u = bup[p], ell = (u - l) * a.TolCon;
+            const double x = v[L.mu() + p], l = blo[p], u = bup[p], i2 = binv[p];
             double g = 0.0;
-            if (x < l) { const double t = (l - x) / ell; part += 0.5 * t * t; g += (x - l) / (ell * ell); }
-            if (x > u) { const double t = (x - u) / ell; part += 0.5 * t * t; g += (x - u) / (ell * ell); }
+            if (x < l) { const double t = x - l; part += 0.5 * t * t * i2; g += t * i2; }
+            if (x > u) { const double t = x - u; part += 0.5 * t * t * i2; g += t * i2; }
             dP[dm.off_mu + p] = g;
           }
           part = wave_sum(part);
@@ -1200,10 +1217,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
           for (int p = lane; p < D * K; p += 64) {
             const int d = p % D, k = p / D;
             const double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
-            const double l = blo[next_mu + p], u = bup[next_mu + p], ell = (u - l) * a.TolCon;
+            const double l = blo[next_mu + p], u = bup[next_mu + p], i2 = binv[next_mu + p];
             double g = 0.0;
-            if (x < l) { const double t = (l - x) / ell; part += 0.5 * t * t; g += (x - l) / (ell * ell); }
-            if (x > u) { const double t = (x - u) / ell; part += 0.5 * t * t; g += (x - u) / (ell * ell); }
+            if (x < l) { const double t = x - l; part += 0.5 * t * t * i2; g += t * i2; }
+            if (x > u) { const double t = x - u; part += 0.5 * t * t * i2; g += t * i2; }
             gsc[p] = g;
           }
           part = wave_sum(part);
@@ -1228,10 +1245,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
               const double lnl = v[L.lnlambda() + d];
               for (int k = lane >> 5; k < K; k += 2) {
                 const double x = v[L.lnsigma() + k] + lnl;
-                const double l = blo[next_mu + d + D * k], u = bup[next_mu + d + D * k], ell = (u - l) * a.TolCon;
+                const double l = blo[next_mu + d + D * k], u = bup[next_mu + d + D * k], i2 = binv[next_mu + d + D * k];
                 double g = 0.0;
-                if (x < l) g += (x - l) / (ell * ell);
-                if (x > u) g += (x - u) / (ell * ell);
+                if (x < l) g += (x - l) * i2;
+                if (x > u) g += (x - u) * i2;
                 acc += g;
               }
             }
@@ -1244,9 +1261,9 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
           const int o3 = next_mu + has_sc * D * K;
           double part = 0.0, pd = 0.0;
           for (int k = lane; k < K; k += 64) {
-            const double x = v[L.eta() + k], l = blo[o3 + k], u = bup[o3 + k], ell = (u - l) * a.TolCon;
-            if (x < l) { const double t = (l - x) / ell; part += 0.5 * t * t; }
-            if (x > u) { const double t = (x - u) / ell; part += 0.5 * t * t; }
+            const double x = v[L.eta() + k], l = blo[o3 + k], u = bup[o3 + k], i2 = binv[o3 + k];
+            if (x < l) { const double t = x - l; part += 0.5 * t * t * i2; }
+            if (x > u) { const double t = x - u; part += 0.5 * t * t * i2; }
             part += a.WeightPenalty * ((w[k] < a.WeightThreshold) ? w[k] : a.WeightThreshold);
             pd += (w[k] < a.WeightThreshold) ? w[k] * a.WeightPenalty : 0.0;
           }
@@ -1255,10 +1272,10 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
           if (lane == 0) scal[4] = part;
           if (grad)
             for (int k = lane; k < K; k += 64) {
-              const double x = v[L.eta() + k], l = blo[o3 + k], u = bup[o3 + k], ell = (u - l) * a.TolCon;
+              const double x = v[L.eta() + k], l = blo[o3 + k], u = bup[o3 + k], i2 = binv[o3 + k];
               double g = 0.0;
-              if (x < l) g += (x - l) / (ell * ell);
-              if (x > u) g += (x - u) / (ell * ell);
+              if (x < l) g += (x - l) * i2;
+              if (x > u) g += (x - u) * i2;
               const double gk = (w[k] < a.WeightThreshold) ? a.WeightPenalty : 0.0;
               dP[dm.off_eta + k] = g + (w[k] * gk - w[k] * dot);
             }

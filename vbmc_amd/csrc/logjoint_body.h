@@ -73,12 +73,21 @@ __device__ __forceinline__ void lj_wave_sums(const ElboDims& dm, const double* _
 #pragma unroll
   for (int d = 0; d < DT; ++d) xc[d] = (d < D && n < N) ? X[n + (size_t)N * d] : 0.0;
   if (n < N) ac = al[n];
-  while (n < N) {
-    const int nn = n + step;
-    double xn[DT], an = 0.0;
+  // (round 5) TWO slabs ahead: a slab's ~80 instructions of one wave are shorter than a load's round trip, so with one slab in flight the
+  // loop still waited for memory every trip (the role's dozen trips are most of its 14 us)
+  double xn[DT], an = 0.0;
+  {
+    const int n1 = n + step;
 #pragma unroll
-    for (int d = 0; d < DT; ++d) xn[d] = (d < D && nn < N) ? X[nn + (size_t)N * d] : 0.0;
-    if (nn < N) an = al[nn];
+    for (int d = 0; d < DT; ++d) xn[d] = (d < D && n1 < N) ? X[n1 + (size_t)N * d] : 0.0;
+    if (n1 < N) an = al[n1];
+  }
+  while (n < N) {
+    const int nn = n + step, n2 = nn + step;
+    double x2[DT], a2n = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) x2[d] = (d < D && n2 < N) ? X[n2 + (size_t)N * d] : 0.0;
+    if (n2 < N) a2n = al[n2];
     double dl[DT];
     double a2 = 0.0;
 #pragma unroll
@@ -97,8 +106,8 @@ __device__ __forceinline__ void lj_wave_sums(const ElboDims& dm, const double* _
       }
     }
 #pragma unroll
-    for (int d = 0; d < DT; ++d) xc[d] = xn[d];
-    ac = an;
+    for (int d = 0; d < DT; ++d) { xc[d] = xn[d]; xn[d] = x2[d]; }
+    ac = an; an = a2n;
     n = nn;
   }
   accI = row16_sum(accI);
