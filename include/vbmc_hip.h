@@ -255,12 +255,23 @@ typedef struct vbmc_elbo_args {
   int32_t no_jacobian;       /* 1: gradients with respect to sigma, lambda and the weights w themselves -- the JACOBIAN_FLAG = 0  */
                              /* form of gplogjoint / entmc_vbmc / entlb_vbmc (misc/gplogjoint.m:352-373, ent/entmc_vbmc.m:110-125, */
                              /* ent/entlb_vbmc.m:132-143) -- instead of log sigma, log lambda, eta.  Stand-alone forms only: no soft  */
-                             /* bounds (bnd_lb NULL), no variance gradient.  0 (default): the transformed gradients negelcbo uses   */
+                             /* bounds (bnd_lb NULL); the variance gradient follows suit (round 5: misc/gplogjoint.m:375-396          */
+                             /* skipped).  0 (default): the transformed gradients negelcbo uses                                     */
   double* dvarG;             /* T x R  gradient of the diagonal variance of the expected log joint, gplogjoint's 4th output     */
                              /* (compute_var = 2 with compute_grad; misc/gplogjoint.m:375-413), or NULL                          */
   double* dG_s;              /* T x S x R  gradient of the expected log joint PER hyper-sample: gplogjoint's dF with avg_flag = 0  */
                              /* (misc/gplogjoint.m:206-271 per s, Jacobians :352-373, the averaging of :411 skipped); needs      */
                              /* compute_grad; honours no_jacobian.  ABI version 4.  NULL: not wanted                               */
+  /* ---- ABI version 5 ---- */
+  double* dvarG_s;           /* T x S x R  gradient of the diagonal variance PER hyper-sample: gplogjoint's dvarF with avg_flag = 0   */
+                             /* (misc/gplogjoint.m:286-304 per s, Jacobians :375-396, the averaging of :407-409 skipped); needs      */
+                             /* compute_grad with compute_var = 2; honours no_jacobian.  NULL: not wanted                           */
+  int32_t plan_restarts;     /* 0: launch shapes follow THIS call's R.  P > 0: this call is a share of a batch of P restarts (dealt   */
+                             /* over devices: restart_offset / restart_stride): the sample chunking, the log-joint kernel and its     */
+                             /* splits are chosen as for a batch of P, so that every restart's results are BIT-IDENTICAL to the ones   */
+                             /* the undivided batch (R = P, plan_restarts 0 or P) computes -- the opt-in exact mode of                 */
+                             /* vbmc_elbo_batch_multi / vbmc_elbo_multi_submit, which pass the field through.  Costs throughput where   */
+                             /* a share is much smaller than the batch (launch shapes of a full chip on an eighth of the work).        */
 } vbmc_elbo_args;
 
 vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* args);
@@ -333,8 +344,10 @@ vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_
  *                           own context (ncclCommInitRank).  The context stays the caller's.
  *   vbmc_allgather_f64      every local device contributes `count` doubles (d_send[i], device memory on local device i) and
  *                           receives size * count doubles in rank order (d_recv[i]); enqueued on the contexts' streams inside
- *                           ncclGroupStart / ncclGroupEnd, then synchronised.  All-gather, never all-reduce: the result is
- *                           bit-identical to the one-GPU evaluation and identical on every rank.
+ *                           ncclGroupStart / ncclGroupEnd, then synchronised.  All-gather, never all-reduce: the exchange moves
+ *                           the values it is given without arithmetic, and every rank holds the identical vector afterwards
+ *                           (whether the VALUES equal the one-GPU batch's bit for bit is vbmc_elbo_batch_multi's business: see
+ *                           plan_restarts there).
  *   vbmc_allgather_host_f64 the same for host blocks (send: local * count doubles, recv: size * count), staged through the
  *                           communicator's own device blocks.
  *   vbmc_gp_upload_all      vbmc_gp_upload on every local device (gps[local]): the surrogate is replicated, not sharded (25.6 MB
@@ -349,9 +362,13 @@ vbmc_status vbmc_elbo_shard_finish(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_
  *                           device to the order of summation (relative 1e-13): launch shapes -- the number of sample chunks per
  *                           component, which sets the order in which the entropy partials are added -- are chosen for the restarts a
  *                           device actually holds, which is what strong scaling needs (8 restarts per device want other chunks than
- *                           64).  Where the two launches coincide (small batches: every test shape of tests/test_gpu_comm.py) the
- *                           values are bit-identical.  All RANKS of one call always see the identical gathered vectors, hence the
- *                           identical sieve order.  eps_mode 0, or one shared host block of draws (eps_mode 1 with eps_shared).
+ *                           64).  Where the two launches coincide (small batches) the values are bit-identical.  EXACT MODE (round
+ *                           5, opt-in): args.plan_restarts = R makes every device choose its launch shapes for the undivided batch
+ *                           -- then every value is BIT-IDENTICAL to vbmc_elbo_batch of the whole batch on one device, whatever the
+ *                           number of devices, and a sieve sorted on 1 GPU and on 8 orders even exact ties the same way
+ *                           (tests/test_gpu_comm.py: shares of 2 / 3 / 8 at a shape where the two modes choose different chunkings).
+ *                           All RANKS of one call always see the identical gathered vectors, hence the identical sieve order, in
+ *                           either mode.  eps_mode 0, or one shared host block of draws (eps_mode 1 with eps_shared).
  * Errors of these calls are reported by vbmc_comm_last_error.
  */
 typedef struct vbmc_comm vbmc_comm;

@@ -23,7 +23,7 @@ if compute_vargrad && compute_var ~= 2
 end
 
 vpflags = [vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambda, vp.optimize_weights];
-supported = (avg_flag || ~compute_vargrad) && (~compute_vargrad || jacobian_flag) && any(gp.meanfun == [0 1 4]) ...
+supported = any(gp.meanfun == [0 1 4]) ...         % (round 5: dvarF without the Jacobians and per hyper-sample are accelerated too)
     && (~any(grad_flags) || isequal(logical(grad_flags(:)'),logical(vpflags))) ...
     && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) && (~vp.optimize_weights || isfield(vp,'eta'));
 if ~supported
@@ -43,21 +43,25 @@ if avg_flag || numel(gp.post) == 1
     dvarF = [];
     if compute_vargrad
         [~,~,F,~,varF,~,varss,I_sk,J_sjk,dF,~,~,dvarF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,1, ...
-            2,double(separate_K),0,[],[],0,numel(gp.post));
+            2,double(separate_K),0,[],[],0,numel(gp.post),double(~jacobian_flag));
     else
         [~,~,F,~,varF,~,varss,I_sk,J_sjk,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,double(g), ...
             double(compute_var),double(separate_K),0,[],[],0,numel(gp.post),double(~jacobian_flag));
     end
     if ~avg_flag; varss = 0; end
 else                                            % misc/gplogjoint.m:398-399: no averaging, varss stays 0
-    if g
+    dvarF = [];
+    if compute_vargrad                          % per-hyper-sample variance gradient, T x S (misc/gplogjoint.m:375-396, :407-409 skipped)
+        [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF,~,dF,dvarF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,1, ...
+            2,0,0,[],[],0,numel(gp.post),double(~jacobian_flag));
+    elseif g
         [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF,~,dF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,1, ...
             double(compute_var),0,0,[],[],0,numel(gp.post),double(~jacobian_flag));
     else
         [~,~,~,~,~,~,~,I_sk,J_sjk,~,F,varF] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0, ...
             double(compute_var),double(separate_K),0,[],[],0,numel(gp.post));
     end
-    varss = 0; dvarF = [];
+    varss = 0;
 end
 if sepK2
     [~,~,~,~,~,~,~,I_sk,J_sjk] = vbmc_hip_mex('elbo',h,theta(:),vp,0,0,double(compute_var),1,0,[],[],0,numel(gp.post));

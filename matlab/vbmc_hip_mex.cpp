@@ -8,7 +8,7 @@
 //     vbmc_hip_mex('open', device)                         -> (context kept in a persistent, mexLock'ed)
 //     h  = vbmc_hip_mex('gp_upload', gpstruct)             -> uint64 handle of a device-resident gp.post
 //          vbmc_hip_mex('gp_free', h)
-//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk,dG,G_s,varG_s,dvarG,dG_s] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
+//     [F,dF,G,H,varG,dH,varGss,I_sk,J_sjk,dG,G_s,varG_s,dvarG,dG_s,dvarG_s] = vbmc_hip_mex('elbo', h, theta, vp, Ns, compute_grad,
 //                                     compute_var, separate_K, beta, thetabnd_or_empty, eps_or_empty, seed, numel(gp.post), no_jacobian)
 //                                     (G_s, varG_s, dG_s (T x S): the per-hyper-sample outputs of gplogjoint(...,avg_flag = 0); no_jacobian,
 //                                     optional: 1 = gradients with respect to sigma, lambda, w themselves, the JACOBIAN_FLAG = 0
@@ -287,10 +287,16 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
       dGs = mxCreateDoubleMatrix(T, S, mxREAL);
       a.dG_s = mxGetDoubles(dGs);
     }
+    mxArray* dvGs = nullptr;        // 15th output (ABI 5): the variance gradient per hyper-sample, T x S (gplogjoint's dvarF with avg_flag = 0, :407-409 skipped)
+    if (nlhs > 14 && a.compute_grad && a.compute_var == 2 && nrhs > 12) {
+      const int S = (int)mxGetScalar(prhs[12]);
+      dvGs = mxCreateDoubleMatrix(T, S, mxREAL);
+      a.dvarG_s = mxGetDoubles(dvGs);
+    }
     vbmc_status st = vbmc_elbo_batch(g_ctx, h, &a);
     if (st != VBMC_OK) return fail(st);  // MATLAB frees the mxArrays created above on error
-    mxArray* outs[14] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs, dvG, dGs};
-    for (int i = 0; i < 14 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
+    mxArray* outs[15] = {F, dF, G, H, vG, dH, vss, Isk, Jsjk, dG, Gs, vGs, dvG, dGs, dvGs};
+    for (int i = 0; i < 15 && (i < nlhs || i == 0); ++i) plhs[i] = outs[i] ? outs[i] : mxCreateDoubleMatrix(0, 0, mxREAL);
     return 0;
   }
 

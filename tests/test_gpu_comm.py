@@ -169,74 +169,83 @@ def test_dealt_shares_at_a_shape_where_the_launches_differ(va):
                     float(np.max(np.abs(dF - whole["dF"][:, cols])) / max(1.0, float(np.max(np.abs(whole["dF"]))))))
     assert worst < 1e-12, worst
     assert np.array_equal(np.argsort(F_all, kind="stable"), np.argsort(whole["F"], kind="stable"))
+    assert worst > 0.0        # (the shape was chosen for this: here the two launches DO differ -- the exact mode below is not vacuous)
+    # EXACT MODE (round 5, vbmc_elbo_args.plan_restarts = the undivided R): every share launches the undivided batch's shapes -- sample
+    # chunks, log-joint kernel and its splits -- so every column is bit-identical, for shares of 2, 3 and 8 ranks (64 % 3 != 0: a ragged deal)
+    for G2 in (8, 3, 2):
+        for g in range(G2):
+            cols = np.arange(Th.shape[1])[g::G2]
+            r = va.negelcbo_batch(np.asfortranarray(Th[:, cols]), 0, vp, gp, Ns, True, 0, seed=31, restart_offset=g, restart_stride=G2,
+                                  plan_restarts=Th.shape[1], outputs=("F", "dF", "H", "G"))
+            assert np.array_equal(r["F"], whole["F"][cols]) and np.array_equal(r["dF"], whole["dF"][:, cols])
+            assert np.array_equal(r["H"], whole["H"][cols]) and np.array_equal(r["G"], whole["G"][cols])
+    # plan_restarts below the share's own size is refused
+    with pytest.raises(va.VbmcHipError, match="plan_restarts"):
+        va.negelcbo_batch(Th, 0, vp, gp, Ns, True, 0, seed=31, plan_restarts=5)
 
 
-def test_a_host_without_rccl_reports_instead_of_crashing():
-    """with librccl unloadable every communicator entry point must return VBMC_ERR_HIP with a message (the first version built
-    the message from two dlerror() calls, the second of which returns NULL).  A fresh process, RCCL disabled by the test hook."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from vbmc_amd.multi import Comm\n"
-            "from vbmc_amd._lib import VbmcHipError\n"
-            "for f in (lambda: Comm.create_all(1), Comm.unique_id):\n"
-            "    try:\n        f(); print('NO ERROR')\n    except VbmcHipError as e:\n        print('refused:', e)\n") % root
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VBMC_RCCL_DISABLE="1"), capture_output=True, text=True, cwd=root, timeout=300)
-    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
-    assert r.stdout.count("refused:") == 2 and "NO ERROR" not in r.stdout, r.stdout
-
-
-def test_rank_form_with_a_unique_id(va):
-    """ncclGetUniqueId + ncclCommInitRank (the one-process-per-GPU form bench.py uses), world 1 on this box, on the default
-    engine's own context."""
+def test_exact_mode_through_the_communicator(va):
+    """The same through vbmc_elbo_batch_multi / vbmc_elbo_multi_submit with a one-rank communicator: exact = True passes plan_restarts
+    through and returns the plain batch's bits (one rank: trivially the same launch), and a variance pass hands varG back (ADVICE r4:
+    PreparedMulti accepted compute_var and never returned the gathered varG)."""
     from vbmc_amd.multi import Comm
 
-    ctx = va.default_engine().ctx
-    comm = Comm.create_rank(ctx, 0, 1, Comm.unique_id())
-    assert comm.size == 1 and comm.local == 1
-    _check_multi(va, comm, with_var=False)
-    r = comm.allgather_host(np.array([1.5, -2.0]))
-    assert r.shape == (1, 2) and r[0, 1] == -2.0
+    gp, vp, Th = setup(16, 6, 50, 12, 3, 16)
+    comm = Comm.create_all(1)
+    gps = comm.upload_gp(gp, need_L=True)
+    ref = va.negelcbo_batch(Th, 0, vp, gp, 400, True, 0, seed=9, outputs=("F", "dF"))
+    out = comm.negelcbo_batch(Th, 0, vp, gps, 400, True, 0, seed=9, outputs=("F", "dF"), exact=True)
+    assert np.array_equal(out["F"], ref["F"]) and np.array_equal(out["dF"], ref["dF"])
+    po = comm.prepare(Th.shape[0], Th.shape[1], 0, vp, gps, 400, exact=True)
+    po.submit(Th, seed=9, slot=2)
+    F, dF = po.collect(2)
+    assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])
+    refv = va.negelcbo_batch(Th, 1.0, vp, gp, 0, True, 2, outputs=("F", "dF", "varG"))
+    pv = comm.prepare(Th.shape[0], Th.shape[1], 1.0, vp, gps, 0, compute_var=2)
+    pv.submit(Th, seed=0, slot=1)
+    Fv, dFv, varGv = pv.collect(1)
+    assert np.array_equal(Fv, refv["F"]) and np.array_equal(varGv, refv["varG"]) and np.array_equal(dFv, refv["dF"])
+    with pytest.raises(ValueError, match="slots 0 and 1"):
+        pv.submit(Th, seed=0, slot=2)
+    comm.free_gp(gps)
     comm.close()
 
 
-def test_all_devices_of_the_node(va):
-    """With >= 2 gfx950 devices: ONE process drives them all; every value equals the one-device batch."""
-    import torch
+def test_two_ranks_on_this_box(va):
+    """more than ONE rank through the library's multi-device path on a one-GPU box.  RCCL itself cannot do it: with
+    the device listed twice ncclCommInitAll -- and, across two processes, ncclCommInitRank -- answers "invalid usage" ("Duplicate GPU
+    detected : rank 0 and rank 1 both on CUDA device": measured on the box in round 5, RCCL 2.27.7; there is no switch).  What CAN run
+    here is everything around the collective with two local ranks: vbmc_comm_create_all(2, {0, 0}) gives two contexts (own streams, own
+    slots) on device 0 and exchanges by event-ordered device-to-device copies instead of ncclAllGather (abi_comm.hip: local_copy) -- the
+    deal r = g (mod 2) of a RAGGED batch (R = 7: 4 + 3), k_comm_pick's NaN padding of the shorter share, the per-device argument
+    structs, vbmc_elbo_batch_multi and four vbmc_elbo_multi_submit / _collect batches in flight over two local devices, and the host
+    all-gather.  Every value must equal the one-device batch bit for bit (exact mode), on every slot, in any collect order."""
     from vbmc_amd.multi import Comm
 
-    n = torch.cuda.device_count()
-    if n < 2:
-        pytest.skip("one device on this box: the multi-device form is exercised with emulated ranks above")
-    comm = Comm.create_all(n)
-    assert comm.size == n and comm.local == n
-    _check_multi(va, comm, with_var=True)
-    blocks = np.arange(3.0 * n).reshape(n, 3)
-    assert np.array_equal(comm.allgather_host(blocks), blocks)
-    comm.close()
-
-
-def test_bench_multi_gpu_code_path_with_one_rank(va):
-    """bench.py's N > 1 path -- process group over RCCL, the 128-byte id broadcast through it (Comm.from_torch), the surrogate uploaded
-    through the communicator, vbmc_elbo_batch_multi + ncclAllGather inside the library every step, the strong-scaling leg, the timing
-    rows gathered at the end -- executed under torch.distributed.run with ONE rank (VBMC_BENCH_FORCE_COMM=1): all a one-GPU box can
-    run of what the driver launches on eight."""
-    import json
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VBMC_BENCH_FORCE_COMM="1", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-aux",
-                        "--no-cpu-baseline", "--restarts", "8"], capture_output=True, text=True, cwd=root, env=env, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["world_size_observed"] == 1
-    assert "ncclAllGather inside libvbmc_hip.so" in d["exchange"], d["exchange"]
-    assert d["strong"]["restarts_total"] == 8 and d["strong"]["value"] > 0
+    gp, vp, Th = setup(18, 5, 40, 9, 3, 7)
+    ref = va.negelcbo_batch(Th, 0, vp, gp, 120, True, 0, seed=4, outputs=("F", "dF"))
+    comm = Comm.create_all(devices=[0, 0])
+    assert comm.size == 2 and comm.local == 2
+    gps = comm.upload_gp(gp)
+    out = comm.negelcbo_batch(Th, 0, vp, gps, 120, True, 0, seed=4, outputs=("F", "dF"), exact=True)
+    assert np.array_equal(out["F"], ref["F"]) and np.array_equal(out["dF"], ref["dF"])
+    fast = comm.negelcbo_batch(Th, 0, vp, gps, 120, True, 0, seed=4, outputs=("F", "dF"))          # default mode: to the order of summation
+    assert np.max(np.abs(fast["F"] - ref["F"]) / np.abs(ref["F"])) < 1e-12
+    po = comm.prepare(Th.shape[0], Th.shape[1], 0, vp, gps, 120, exact=True)
+    for sl in (0, 1, 2, 3):
+        po.submit(Th, seed=4, slot=sl)
+    for sl in (3, 1, 0, 2):
+        F, dF = po.collect(sl)
+        assert np.array_equal(F, ref["F"]) and np.array_equal(dF, ref["dF"])
+    # three ranks, R = 7 again (3 + 2 + 2), and a batch smaller than the world (R = 2 on three ranks: one rank holds nothing)
+    comm3 = Comm.create_all(devices=[0, 0, 0])
+    gps3 = comm3.upload_gp(gp)
+    out3 = comm3.negelcbo_batch(Th, 0, vp, gps3, 120, True, 0, seed=4, outputs=("F", "dF"), exact=True)
+    assert np.array_equal(out3["F"], ref["F"]) and np.array_equal(out3["dF"], ref["dF"])
+    ref2 = va.negelcbo_batch(np.asfortranarray(Th[:, :2]), 0, vp, gp, 120, True, 0, seed=4, outputs=("F", "dF"))
+    out2 = comm3.negelcbo_batch(np.asfortranarray(Th[:, :2]), 0, vp, gps3, 120, True, 0, seed=4, outputs=("F", "dF"), exact=True)
+    assert np.array_equal(out2["F"], ref2["F"]) and np.array_equal(out2["dF"], ref2["dF"])
+    blocks = np.arange(9.0).reshape(3, 3)
+    assert np.array_equal(comm3.allgather_host(blocks), blocks)
+    comm3.free_gp(gps3); comm3.close()
+    comm.free_gp(gps); comm.close()

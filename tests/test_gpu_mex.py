@@ -130,6 +130,11 @@ def test_elbo_with_host_draws_all_twelve_outputs(mex, va):
     o = mex.call(14, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), 0, 1, 0, 0, 0, None, None, 0, S)
     rs = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 0, outputs=("G", "dG", "G_s", "dG_s"))
     same(o[10][0, :], rs["G_s"][:, 0]); same(o[13], rs["dG_s"][:, :, 0])
+    # 15th output (ABI 5): the variance gradient per hyper-sample, T x S, with and without the Jacobians (14th argument)
+    for nojac in (0, 1):
+        o = mex.call(15, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), 0, 1, 2, 0, 0, None, None, 0, S, nojac)
+        rs = va.negelcbo_batch(theta, 0, vp, gp, 0, True, 2, outputs=("G", "dG", "varG", "dvarG", "dvarG_s", "dG_s"), jacobian_flag=not nojac)
+        same(o[12][:, 0], rs["dvarG"][:, 0]); same(o[14], rs["dvarG_s"][:, :, 0]); same(o[13], rs["dG_s"][:, :, 0])
     assert o[13].shape == (theta.size, S) and np.max(np.abs(np.mean(o[13], axis=1) - rs["dG"][:, 0])) < 1e-12 * max(1.0, np.max(np.abs(rs["dG"])))
     with pytest.raises(MexError) as e:                            # the Jacobian of the soft bounds is part of the penalty's gradient
         mex.call(2, "elbo", hh, theta.reshape(-1, 1), vp_struct(vp), Ns, 1, 0, 0, 0, tb, eps_m, 0, S, 1)

@@ -99,10 +99,10 @@ def test_gplogjoint_variance_and_components(va, cv):
 
 def test_gplogjoint_refusals(va):
     p, gp, vp = make(8, 3, 20, 4, 2)
-    with pytest.raises(va.VbmcUnsupported):
-        va.gplogjoint(vp, gp, True, False, True, 2, nargout=4)   # per-hyper-sample variance gradient
-    with pytest.raises(va.VbmcUnsupported):
-        va.gplogjoint(vp, gp, True, True, False, 2, nargout=4)   # dvarF without the Jacobians
+    # (round 5: the per-hyper-sample variance gradient and dvarF without the Jacobians are accelerated now:
+    #  test_gplogjoint_variance_gradient_every_form)
+    assert va.gplogjoint(vp, gp, True, False, True, 2, nargout=4)[3].shape[1] == 2
+    assert va.gplogjoint(vp, gp, True, True, False, 2, nargout=4)[3].ndim == 1
     with pytest.raises(ValueError, match="FullVarianceGradient"):
         va.gplogjoint(vp, gp, True, True, True, 1, nargout=4)    # gplogjoint.m:27-30
 
@@ -189,12 +189,33 @@ def test_gplogjoint_per_hyper_sample_gradients(va, flags, jac):
     assert relerr(dF, ref["dF"]) < 1e-9
     Fa, dFa = va.gplogjoint(vp, gp, flags, True, jac, nargout=2)
     assert relerr(np.mean(dF, axis=1), dFa) < 1e-12
-    if not jac:
-        return       # (the diagonal variance with a gradient brings the variance gradient's Jacobians along: refused without them)
-    # with the variance: F, varF per sample beside the gradients
+    # with the variance: F, varF per sample beside the gradients -- with or without the Jacobians (round 5)
     F2, dF2, varF2 = va.gplogjoint(vp, gp, flags, False, jac, 2, nargout=3)
     ref2 = R.gplogjoint(vp, gp, flags, False, jac, 2)
     assert relerr(dF2, ref2["dF"]) < 1e-9 and np.max(np.abs(np.asarray(varF2) - ref2["varF"])) < 1e-7 * max(1.0, np.max(np.abs(ref2["varF"])))
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+@pytest.mark.parametrize("jac", [True, False])
+@pytest.mark.parametrize("avg", [True, False])
+def test_gplogjoint_variance_gradient_every_form(va, flags, jac, avg):
+    """Round 5: dvarF (compute_var = 2, nargout >= 4; misc/gplogjoint.m:286-304) in the two forms refused through round 4 -- without the
+    Jacobians (jacobian_flag = 0: :375-396 skipped) and per hyper-sample (avg_flag = 0: T x S, the averaging of :407-409 skipped;
+    vbmc_elbo_args.dvarG_s) -- and in the old one, for every grad_flags subset, against the oracle; the per-sample gradients average to
+    the averaged call's through :407-409."""
+    p, gp, vp = make(23, 5, 45, 7, 4)
+    ref = R.gplogjoint(vp, gp, flags, avg, jac, 2, compute_vargrad=True)
+    F, dF, varF, dvarF = va.gplogjoint(vp, gp, flags, avg, jac, 2, nargout=4)
+    assert relerr(F, ref["F"]) < 1e-10 and relerr(dF, np.asarray(ref["dF"])) < 1e-9
+    assert np.max(np.abs(np.asarray(varF) - ref["varF"])) < 1e-7 * max(1.0, np.max(np.abs(ref["varF"])))
+    assert np.shape(dvarF) == np.shape(ref["dvarF"])
+    assert relerr(dvarF, ref["dvarF"], scale=max(np.max(np.abs(ref["dvarF"])), 1e-6 * np.max(np.abs(ref["varF"])))) < 1e-6     # z' K^-1 z cancels against nf_kk
+    if not avg:
+        Fa, dFa, varFa, dvarFa = va.gplogjoint(vp, gp, flags, True, jac, 2, nargout=4)
+        Fs, dFs = np.asarray(F), np.asarray(dF)
+        S = Fs.size
+        dvv = 2.0 * np.sum(Fs[None, :] * dFs, axis=1) / (S - 1) - 2.0 * np.mean(Fs) * np.sum(dFs, axis=1) / (S - 1)      # :408
+        assert relerr(np.sum(dvarF, axis=1) / S + dvv, dvarFa, scale=max(np.max(np.abs(dvarFa)), 1e-12)) < 1e-9
 
 
 @pytest.mark.parametrize("cv", [0, 1, 2])

@@ -62,6 +62,8 @@ class ElboArgs(C.Structure):
         ("no_jacobian", C.c_int32),
         ("dvarG", _dp),
         ("dG_s", _dp),
+        ("dvarG_s", _dp),
+        ("plan_restarts", C.c_int32),
     ]
 
 

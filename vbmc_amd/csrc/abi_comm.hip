@@ -74,6 +74,12 @@ struct vbmc_comm {
   size_t cap = 0;
   RcclApi* api = nullptr;
   std::string err;
+  // Several ranks on ONE device (vbmc_comm_create_all with a device listed more than once: a multi-device run rehearsed on a one-device
+  // box, tests/test_gpu_comm.py).  RCCL refuses that ("Duplicate GPU detected"), in one process and across processes alike, so this form
+  // exchanges by device-to-device copies: rank j's block is ready at an event on its stream, every rank's stream waits for all of them
+  // and copies the blocks into its own receive buffer in rank order.  Same blocks, same order, no arithmetic: an all-gather.
+  bool local_copy = false;
+  std::vector<hipEvent_t> lc_ev;
   // the pipelined form's exchange stream per local device: the collectives of consecutive batches in issue order on ONE stream that
   // holds nothing else (a pass on a slot stream is ordered after the context's stream, abi_elbo.hip: slot_ctx -- with the exchange on
   // the context's stream every pass would queue behind the previous batch's exchange)
@@ -142,6 +148,7 @@ extern "C" void vbmc_comm_destroy(vbmc_comm* c) {
   for (int i = 0; i < c->n; ++i) {
     if (c->ctx[i]) { (void)hipSetDevice(c->ctx[i]->device); (void)hipStreamSynchronize(c->ctx[i]->stream); }
     if (i < (int)c->comm.size() && c->comm[i] && c->api) (void)c->api->CommDestroy(c->comm[i]);
+    if (i < (int)c->lc_ev.size() && c->lc_ev[i]) (void)hipEventDestroy(c->lc_ev[i]);
     if (c->d_send[i]) (void)hipFree(c->d_send[i]);
     if (c->d_recv[i]) (void)hipFree(c->d_recv[i]);
     for (auto& sl : c->slot) {
@@ -167,6 +174,20 @@ extern "C" vbmc_status vbmc_comm_create_all(int ndev, const int* devices, vbmc_c
   for (int i = 0; i < ndev; ++i) {
     vbmc_status st = vbmc_ctx_create(devs[i], nullptr, &c->ctx[i]);
     if (st != VBMC_OK) { vbmc_comm_destroy(c); return st; }
+  }
+  bool dup = false;
+  for (int i = 0; i < ndev; ++i)
+    for (int j = 0; j < i; ++j) dup = dup || devs[i] == devs[j];
+  if (dup) {      // more than one rank on a device: the copy exchange (see vbmc_comm::local_copy)
+    c->local_copy = true;
+    c->lc_ev.assign(ndev, nullptr);
+    for (int i = 0; i < ndev; ++i) {
+      if (hipSetDevice(devs[i]) != hipSuccess || hipEventCreateWithFlags(&c->lc_ev[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); vbmc_comm_destroy(c); return VBMC_ERR_HIP;
+      }
+    }
+    *out = c;
+    return VBMC_OK;
   }
   c->api = rccl_api(c->err);
   if (!c->api) { vbmc_comm_destroy(c); return VBMC_ERR_HIP; }
@@ -212,6 +233,21 @@ extern "C" vbmc_status vbmc_comm_create_rank(vbmc_ctx* ctx, int rank, int world,
 // the collective itself: every local device contributes `count` doubles, every device receives world * count in rank order
 static vbmc_status comm_allgather_enqueue(vbmc_comm* c, const double* const* d_send, double* const* d_recv, size_t count,
                                           const hipStream_t* on = nullptr) {
+  if (c->local_copy) {
+    for (int j = 0; j < c->n; ++j) {
+      COMM_HIP(c, hipSetDevice(c->ctx[j]->device));
+      COMM_HIP(c, hipEventRecord(c->lc_ev[j], on ? on[j] : c->ctx[j]->stream));
+    }
+    for (int i = 0; i < c->n; ++i) {
+      hipStream_t si = on ? on[i] : c->ctx[i]->stream;
+      COMM_HIP(c, hipSetDevice(c->ctx[i]->device));
+      for (int j = 0; j < c->n; ++j) {
+        if (j != i) COMM_HIP(c, hipStreamWaitEvent(si, c->lc_ev[j], 0));
+        COMM_HIP(c, hipMemcpyAsync(d_recv[i] + (size_t)j * count, d_send[j], count * sizeof(double), hipMemcpyDeviceToDevice, si));
+      }
+    }
+    return VBMC_OK;
+  }
   COMM_NCCL(c, c->api->GroupStart());
   for (int i = 0; i < c->n; ++i) {
     ncclResult_t r = c->api->AllGather(d_send[i], d_recv[i], count, ncclDouble, c->comm[i], on ? on[i] : c->ctx[i]->stream);

@@ -499,6 +499,8 @@ struct ElboPlan {
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   int no_jacobian = 0;
+  int Rp = 0;                // the restarts the launch shapes are chosen for: R, or the undivided batch's (vbmc_elbo_args.plan_restarts)
+  double* d_dvs = nullptr;   // per-hyper-sample variance gradient block (dvarG_s), pooled for the call
   bool lj_records = false;   // the caller reads per-hyper-sample log-joint records (separate_K, G_s / varG_s, the variance kernels)
   int r0 = 0, rstride = 1;   // device-RNG key of restart r: r0 + r * rstride (vbmc_elbo_args.restart_offset / restart_stride)
   size_t n_theta = 0, n_up = 0, out_n = 0, ent_lds = 0, tlds = 0, n_sepk = 0;
@@ -517,14 +519,15 @@ struct ElboPlan {
 static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
   static const bool co_off = [] { const char* e = getenv("VBMC_LJ_CO"); return e && !strcmp(e, "0"); }();
   const char* ljf = getenv("VBMC_LJ_KERNEL");
-  const long long SR = (long long)P.dm.S * P.dm.R;
+  const int Rp = P.Rp > 0 ? P.Rp : P.dm.R;        // (plan_restarts: the undivided batch decides)
+  const long long SR = (long long)P.dm.S * Rp;
   const bool lj_force_mfma = ljf && !strcmp(ljf, "mfma");
   // ... and only where the ENTROPY launch is small too (K R waves per sample chunk: a single chain has 50, a batch of restarts over one
   // hyper-sample -- or an entropy-only evaluation, whose surrogate is a one-point stand-in -- can fill the chip by itself and wants the
   // kernels built for occupancy, not these)
-  const long long KR = (long long)P.dm.K * P.dm.R * P.rstride;
+  const long long KR = (long long)P.dm.K * (P.Rp > P.dm.R ? P.Rp : (long long)P.dm.R * P.rstride);
   return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 8 && !(P.cutoff > 0.0) && P.compute_grad &&
-         !P.lj_records && SR < ctx->num_cu / 2 && SR * P.rstride < ctx->num_cu / 2 &&   // (the undivided batch's choice when the restarts are dealt over devices)
+         !P.lj_records && SR < ctx->num_cu / 2 && (P.Rp > P.dm.R || SR * P.rstride < ctx->num_cu / 2) &&   // (the undivided batch's choice when the restarts are dealt over devices)
          KR < 2 * ctx->num_cu && P.dm.N > 1 &&
          // (round 4) ... and small in WORK, not only in width: with many sample tiles per wave (Ns = 1e4 per component: 313 tiles per
          // (component, restart)) the role's workgroups delay an entropy launch that fills the chip by itself -- R = 4 at the headline
@@ -584,10 +587,12 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   if (a->restart_offset < 0 || a->restart_stride < 0) return set_err(ctx, VBMC_ERR_INVALID, "restart_offset / restart_stride must be >= 0");
   if (a->no_jacobian && compute_grad) {
     if (a->bnd_lb) return set_err(ctx, VBMC_ERR_INVALID, "no_jacobian (JACOBIAN_FLAG = 0) is a form of the stand-alone functions: no soft bounds");
-    if (compute_var == 2) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "the variance gradient without the Jacobians (JACOBIAN_FLAG = 0 with compute_var = 2) is not accelerated");
   }
   if (a->dvarG && !(compute_grad && compute_var == 2)) return set_err(ctx, VBMC_ERR_INVALID, "dvarG needs compute_grad with compute_var = 2");
   if (a->dG_s && !compute_grad) return set_err(ctx, VBMC_ERR_INVALID, "dG_s (per-hyper-sample gradients) needs compute_grad");
+  if (a->dvarG_s && !(compute_grad && compute_var == 2)) return set_err(ctx, VBMC_ERR_INVALID, "dvarG_s (per-hyper-sample variance gradients) needs compute_grad with compute_var = 2");
+  if (a->plan_restarts < 0 || (a->plan_restarts > 0 && a->plan_restarts < R)) return set_err(ctx, VBMC_ERR_INVALID, "plan_restarts must be 0 or the size (>= R) of the batch this call is a share of");
+  P.Rp = a->plan_restarts > 0 ? a->plan_restarts : R;
   P.no_jacobian = a->no_jacobian && compute_grad ? 1 : 0;
   P.r0 = a->restart_offset; P.rstride = a->restart_stride > 0 ? a->restart_stride : 1;
   M = ((M + 1) / 2) * 2;  // entmc_vbmc.m:45
@@ -660,7 +665,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   // (also set when the caller asks for the numbers a SHARDED evaluation gives -- chunk_world: the sharded path adds the log-joint
   // records per hyper-sample, so the unsharded evaluation it is compared with bit for bit must too)
   P.lj_records = a->separate_K || a->G_s || a->varG_s || a->dG_s || compute_var != 0 || chunk_world > 0 || a->chunk_world > 1;
-  const size_t ljrec = (size_t)R * S * K * LJS * (((long long)S * R < ctx->num_cu / 2 && !P.lj_records) ? LJ_CO_SPLIT : 1);
+  const size_t ljrec = (size_t)R * S * K * LJS * (((long long)S * std::min(R, P.Rp) < ctx->num_cu / 2 && !P.lj_records) ? LJ_CO_SPLIT : 1);
   { vbmc_status s_ = ensure(ctx, ctx->ljpart, (ljrec + (size_t)R * K * LJS) * sizeof(double)); if (s_) return s_; }
   { vbmc_status s_ = ensure(ctx, ctx->out, P.out_n * sizeof(double)); if (s_) return s_; }
   {
@@ -704,7 +709,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
       static const bool occ_off = [] { const char* e = getenv("VBMC_ENT_OCC"); return e && !strcmp(e, "0"); }();   // A/B: the old constant
       if (occ_off) waves_per_cu = P.use_mfma ? 8 : 5;
       const long long slots = (long long)ctx->num_cu * waves_per_cu * cw;
-      const long long kr = (long long)K * R * (P.use_mfma ? (P.hv & 15) : 1);   // waves per chunk index (hv + 16 TL: with a component tail)
+      const long long kr = (long long)K * P.Rp * (P.use_mfma ? (P.hv & 15) : 1);   // waves per chunk index (hv + 16 TL: with a component tail); Rp: R, or the undivided batch's (plan_restarts)
       const double setup = 1.5;   // measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
       double best = 1e300;
       int bestC = 1;
@@ -870,7 +875,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
   // (round 4: from S R = one workgroup per compute unit on -- below, the finer-grained VALU kernel is the faster one: R = 8 at the headline
   // shape, 160 (hyper-sample, restart) workgroups: 56 us against 34 alone, the step 0.394 -> 0.360 ms; equal at R = 16, 142 against 174 us at R = 64)
-  const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * R >= ctx->num_cu) && !(ljf && !strcmp(ljf, "valu"));
+  const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * P.Rp >= ctx->num_cu) && !(ljf && !strcmp(ljf, "valu"));
   // Small grids (a single chain, a handful of restarts): the VALU log joint runs as a ROLE of the entropy launch (single-wave
   // workgroups ahead of the entropy ones, entropy_mfma.h CO = true) -- two dependent-chain-bound kernels side by side instead of
   // one after the other, one launch less.  Its records are per (hyper-sample, split of the training set); the reduction over
@@ -881,7 +886,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     if (!co) {
       // VALU kernel: four waves per cell (training set split, lower latency) while the grid is small, one wave per cell (no
       // replicated per-wave setup) once there are enough cells to fill the chip several times over
-      const bool lj_split = dm.N > 64 && (long long)((K + 3) / 4) * S * R < 8LL * ctx->num_cu;
+      const bool lj_split = dm.N > 64 && (long long)((K + 3) / 4) * S * P.Rp < 8LL * ctx->num_cu;
       DISPATCH_DT(dt, {
         constexpr int NCT = (2 * DT + 1 + 15) / 16;
         const int nw = (K + 15) / 16;
@@ -1044,6 +1049,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     va.dm = dm; va.vpd = P.d_vpd; va.gpc = gp->gpc; va.delta2 = P.d_delta2; va.lj = P.d_lj; va.J = P.d_J;
     va.vg = P.vgrad ? P.d_vg : nullptr; va.compute_var = P.compute_var; va.want_grad = P.compute_grad; va.stride = P.var_stride;
     va.out = P.d_var;
+    va.no_jacobian = P.no_jacobian; va.dvs_out = P.d_dvs;
     const size_t vlds = VAR_FINAL_LDS(S, K, P.compute_grad ? T : 0);
     if (vlds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
@@ -1251,8 +1257,20 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   }
   ElboPlan P;
   { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
-  { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed); if (s_) return s_; }
-  return elbo_read_results(ctx, P, a);
+  const size_t ndvs = a->dvarG_s ? (size_t)P.dm.T * P.dm.S * P.dm.R : 0;    // gplogjoint's dvarF with avg_flag = 0: T x S per restart
+  if (ndvs) HIP_TRY(ctx, pool_get(ctx, ndvs * sizeof(double), (void**)&P.d_dvs));
+  vbmc_status st = elbo_enqueue(ctx, gp, P, a->seed);
+  if (!st) st = elbo_read_results(ctx, P, a);      // (waits for the stream)
+  if (P.d_dvs) {
+    if (!st) {
+      hipError_t e_ = hipMemcpy(a->dvarG_s, P.d_dvs, ndvs * sizeof(double), hipMemcpyDeviceToHost);
+      if (e_ != hipSuccess) { (void)hipGetLastError(); st = set_err(ctx, VBMC_ERR_HIP, "per-hyper-sample variance gradient read-back: %s", hipGetErrorString(e_)); }
+    } else {
+      (void)hipStreamSynchronize(ctx->stream);
+    }
+    pool_put(ctx, P.d_dvs);
+  }
+  return st;
 }
 
 // ---- pipelined form for streams of independent batches (include/vbmc_hip.h): submit enqueues and returns, collect waits
@@ -1269,7 +1287,7 @@ static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc
   if (!a) return set_err(ctx, VBMC_ERR_INVALID, "%s: null args", who);
   if (slot < 0 || slot > 1) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot must be 0 or 1", who);
   if (ctx->slot_busy[slot]) return set_err(ctx, VBMC_ERR_INVALID, "%s: slot %d holds an uncollected pass", who, slot);
-  if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s || a->dG_s)
+  if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s || a->dG_s || a->dvarG_s)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "%s: per-component / per-hyper-sample outputs only through vbmc_elbo_batch", who);
   if (a->eps_mode == 1)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "%s: host-resident draws (eps_mode 1) only through vbmc_elbo_batch", who);

@@ -405,6 +405,8 @@ struct VarFinArgs {
   const double* vg;   // R x S x K x (2D+1) or null
   int compute_var, want_grad, stride;
   double* out;
+  int no_jacobian;     // 1: the variance gradient with respect to sigma, lambda, w themselves (misc/gplogjoint.m:375-396 skipped)
+  double* dvs_out;     // null, or R x S x T: the per-hyper-sample variance gradient dvarF(:, s) (avg_flag = 0: :407-409 skipped)
 };
 
 #define VARFIN_THREADS 1024
@@ -435,6 +437,7 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
   const double* Jr = a.J + (size_t)r * S * K * K;
   double* o = a.out + (size_t)r * a.stride;
   const bool vgrad = a.want_grad && a.compute_var == 2;
+  const bool jac = a.no_jacobian == 0;
   for (int i = tid; i < T; i += nt) { acc1[i] = 0.0; acc2[i] = 0.0; acc3[i] = 0.0; }
   __syncthreads();
   // ---- per-hyper-sample F(s) and varF(s) (:203, :283, :329-332, :350): the S samples are independent, one WAVE each (16 at a
@@ -485,12 +488,12 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
       __syncthreads();
       // per-sample value gradient dF(:,s) after Jacobians (:352-373)
       if (dm.opt[0]) for (int p = tid; p < D * K; p += nt) dFs[dm.off_mu + p] = lj[((size_t)s * K + p / D) * LJS + 1 + p % D];
-      if (dm.opt[1]) for (int k = tid; k < K; k += nt) dFs[dm.off_sigma + k] = lj[((size_t)s * K + k) * LJS + 1 + D] * sigma[k];
+      if (dm.opt[1]) for (int k = tid; k < K; k += nt) dFs[dm.off_sigma + k] = lj[((size_t)s * K + k) * LJS + 1 + D] * (jac ? sigma[k] : 1.0);
       if (dm.opt[2])
         for (int d = tid; d < D; d += nt) {
           double ls = 0.0;
           for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
-          dFs[dm.off_lambda + d] = ls * lam[d];
+          dFs[dm.off_lambda + d] = ls * (jac ? lam[d] : 1.0);
         }
       // variance gradient pieces (:286-303)
       if (dm.opt[0])
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
       __syncthreads();
       if (dm.opt[1])
         for (int k = tid; k < K; k += nt)
-          dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * tmpK[k] * tmpK2[k] + vg[(size_t)k * (2 * D + 1) + D]) * sigma[k];  // :293, Jacobian :382
+          dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * tmpK[k] * tmpK2[k] + vg[(size_t)k * (2 * D + 1) + D]) * (jac ? sigma[k] : 1.0);  // :293, Jacobian :382
       if (dm.opt[2])
         for (int d = tid; d < D; d += nt) {
           double accd = 0.0;
@@ -520,7 +523,7 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
             double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
             accd -= 2.0 * w[k] * w[k] * (sigma[k] * sigma[k] * tmpK[k] * lam[d] / t2 + vg[(size_t)k * (2 * D + 1) + D + 1 + d]);  // :297
           }
-          dvs[dm.off_lambda + d] = accd * lam[d];  // Jacobian :386
+          dvs[dm.off_lambda + d] = accd * (jac ? lam[d] : 1.0);  // Jacobian :386
         }
       __syncthreads();
       if (dm.opt[3]) {
@@ -537,12 +540,13 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
         double d2 = block_sum(p2, red);
         for (int k = tid; k < K; k += nt) {
           double ik = lj[((size_t)s * K + k) * LJS];
-          dFs[dm.off_eta + k] = w[k] * ik - w[k] * d1;
-          dvs[dm.off_eta + k] = w[k] * tmpK[k] - w[k] * d2;
+          dFs[dm.off_eta + k] = jac ? w[k] * ik - w[k] * d1 : ik;
+          dvs[dm.off_eta + k] = jac ? w[k] * tmpK[k] - w[k] * d2 : tmpK[k];
         }
       }
       __syncthreads();
       double fsv = Fs[s];
+      if (a.dvs_out) for (int i = tid; i < T; i += nt) a.dvs_out[((size_t)r * S + s) * T + i] = dvs[i];
       for (int i = tid; i < T; i += nt) {
         acc1[i] += dvs[i];
         acc2[i] += fsv * dFs[i];

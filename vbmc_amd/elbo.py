@@ -186,7 +186,8 @@ def fminadam_device(x0, beta, vp, gp, Ns, thetabnd=None, TolFun=1e-3, MaxIter=10
 
 def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *,
                    separate_K=False, eps=None, eps_device_ptr=None, eps_shared=False, seed=0, engine=None,
-                   sparse_cutoff=0.0, outputs=None, chunk_world=0, jacobian_flag=True):
+                   sparse_cutoff=0.0, outputs=None, chunk_world=0, jacobian_flag=True, restart_offset=0, restart_stride=0,
+                   plan_restarts=0):
     """R evaluations of negelcbo_vbmc in one device pass.
 
     outputs: None = everything below; a subset such as ("F", "dF") -- what the optimiser loop reads,
@@ -199,7 +200,10 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     sparse_cutoff: 0 dense; c > 0 skips 16-component tiles whose terms are provably < exp(-c) of q(x).
     chunk_world: W > 1 chunks the MC samples as negelcbo_shard does for a world of W ranks (its bit-exact 1-GPU reference).
     jacobian_flag=False: gradients with respect to sigma, lambda, w themselves (the JACOBIAN_FLAG = 0 form of the stand-alone
-    functions; no soft bounds, no variance gradient).  outputs may name "dvarG" (T, R) with compute_var = 2 and a gradient.
+    functions; no soft bounds).  outputs may name "dvarG" (T, R) and "dvarG_s" (T, S, R) with compute_var = 2 and a gradient.
+    restart_offset / restart_stride / plan_restarts: this call is a SHARE of a larger batch (vbmc_elbo_args): the device stream of
+    column r is that of restart offset + r stride of the undivided batch, and with plan_restarts = its size the launch shapes are
+    the undivided batch's too -- every column bit-identical to the one-device evaluation of the whole batch.
     """
     engine = engine or default_engine()
     ctx = engine.ctx
@@ -211,6 +215,7 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
     a, keep, compute_var = _build_args(thetas, beta, vp, gp, Ns, compute_grad, compute_var, thetabnd, separate_K, eps,
                                        eps_device_ptr, eps_shared, seed, engine, sparse_cutoff, chunk_world)
     a.no_jacobian = 0 if jacobian_flag else 1
+    a.restart_offset, a.restart_stride, a.plan_restarts = int(restart_offset), int(restart_stride), int(plan_restarts)
     if gp is None:   # entropy only (entmc_vbmc / entlb_vbmc on their own): the ABI takes a NULL surrogate
         if compute_var or separate_K:
             raise ValueError("an entropy-only evaluation has no variance or per-component outputs")
@@ -249,6 +254,8 @@ def negelcbo_batch(thetas, beta, vp, gp, Ns=0, compute_grad=True, compute_var=No
             a.varG_s = outbuf("varG_s", (S, R))
         if "dG_s" in outputs and compute_grad:
             a.dG_s = outbuf("dG_s", (T, S, R))
+        if "dvarG_s" in outputs and compute_grad and compute_var == 2:
+            a.dvarG_s = outbuf("dvarG_s", (T, S, R))
     ctx.check(ctx.lib.vbmc_elbo_batch(ctx.h, dgp_h, C.byref(a)))
     return out
 
@@ -335,7 +342,8 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
     untransformed gradients (jacobian_flag = 0: with respect to sigma, lambda and w themselves, :352-373 skipped), dvarF --
     the gradient of the diagonal variance (compute_var = 2, nargout >= 4; :375-413) -- and, round 4, per-hyper-sample gradients
     (avg_flag = 0 with grad_flags: dF is T x S, :411 skipped; vbmc_elbo_args.dG_s) and per-component outputs together with gradients
-    (separate_K with grad_flags: two passes).  Not accelerated: dvarF with jacobian_flag = 0 or with avg_flag = 0."""
+    (separate_K with grad_flags: two passes); round 5: dvarF with jacobian_flag = 0 (:375-396 skipped) and per hyper-sample (avg_flag = 0:
+    T x S, :407-409 skipped; vbmc_elbo_args.dvarG_s) -- every call form of the reference's gplogjoint with mean functions 0 / 1 / 4."""
     if separate_K is None:
         separate_K = nargout > 5            # :13
     if compute_var is None:
@@ -347,13 +355,9 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
         if compute_var != 2:                # :27-30
             raise ValueError("gplogjoint:FullVarianceGradient Computation of gradient of log joint variance is currently "
                              "available only for diagonal approximation of the variance.")
-        if not jacobian_flag:
-            raise VbmcUnsupported(-1, "gplogjoint: the variance gradient without the Jacobians (jacobian_flag = 0) is not accelerated")
-    if not avg_flag and want_dvar:
-        raise VbmcUnsupported(-1, "gplogjoint: the per-hyper-sample variance gradient (avg_flag = 0 with nargout >= 4) is not accelerated")
     want = ["G"] + (["dG"] if g else []) + (["varG", "varGss"] if compute_var else []) + (["dvarG"] if want_dvar else [])
     if not avg_flag:
-        want += ["G_s"] + (["varG_s"] if compute_var else []) + (["dG_s"] if g else [])
+        want += ["G_s"] + (["varG_s"] if compute_var else []) + (["dG_s"] if g else []) + (["dvarG_s"] if want_dvar else [])
     sep = None
     if separate_K and g:
         # per-component outputs TOGETHER with gradients (round 4): the objective's entry point refuses the combination as
@@ -367,7 +371,8 @@ def gplogjoint(vp, gp, grad_flags=None, avg_flag=True, jacobian_flag=True, compu
     if sep is not None:
         r.update(sep)
     if not avg_flag and r["G_s"].shape[0] > 1:     # :399: no averaging -> F, varF are 1 x S, dF is T x S; varss stays 0 (:398)
-        outs = (r["G_s"][:, 0].copy(), r["dG_s"][:, :, 0].copy() if g else np.zeros(0), r["varG_s"][:, 0].copy() if compute_var else None, None, 0.0,
+        outs = (r["G_s"][:, 0].copy(), r["dG_s"][:, :, 0].copy() if g else np.zeros(0), r["varG_s"][:, 0].copy() if compute_var else None,
+                r["dvarG_s"][:, :, 0].copy() if want_dvar else None, 0.0,
                 r["I_sk"][:, :, 0].copy() if separate_K else None,
                 r["J_sjk"][:, :, :, 0].copy() if (separate_K and compute_var) else None)
         return outs[0] if nargout <= 1 else outs[:nargout]

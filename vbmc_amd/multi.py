@@ -13,8 +13,9 @@ points a MATLAB host binds through matlab/vbmc_hip_mex.cpp ('comm_open', 'elbo_b
 
 The restart axis (misc/vpsieve_vbmc.m:74-78, misc/vpoptimize_vbmc.m:49) is the one the path shards over.  Every rank
 evaluates the estimator the one-GPU batch evaluates, sample for sample (the device stream of a restart is keyed by its index in the
-undivided batch); the values agree with the one-GPU batch to the order of summation (1e-13) -- bit for bit where the per-device
-launch shapes coincide, as in every shape of tests/test_gpu_comm.py -- and all ranks of a call see the identical vectors."""
+undivided batch); by default the values agree with the one-GPU batch to the order of summation (1e-13) -- bit for bit where the
+per-device launch shapes coincide -- and all ranks of a call see the identical vectors; ``exact=True`` (round 5:
+vbmc_elbo_args.plan_restarts) makes every device launch the undivided batch's shapes: bit-identical to one device, always."""
 from __future__ import annotations
 
 import ctypes as C
@@ -126,10 +127,12 @@ class Comm:
 
     # ---- the batched objective dealt over the ranks
     def negelcbo_batch(self, thetas, beta, vp, gps, Ns=0, compute_grad=True, compute_var=None, thetabnd=None, *, separate_K=False,
-                       seed=0, S=None, outputs=None):
+                       seed=0, S=None, outputs=None, exact=False):
         """negelcbo_batch (vbmc_amd/elbo.py) for the UNDIVIDED batch thetas (T, R), identical on every rank: F and varG of all R
         restarts on every rank; the other outputs for the restarts this process evaluated (all of them with create_all), NaN
-        elsewhere."""
+        elsewhere.  exact=True (vbmc_elbo_args.plan_restarts = R): every device launches the shapes of the undivided batch, so
+        that the values are BIT-IDENTICAL to the one-device evaluation of the whole batch -- the sieve's order provably the same on
+        1 and on N devices -- at the price of launch shapes chosen for R restarts on a device that holds R / G of them."""
         thetas = f64(thetas)
         if thetas.ndim == 1:
             thetas = f64(thetas.reshape(-1, 1))
@@ -137,6 +140,7 @@ class Comm:
         K = int(vp["K"])
         a, keep, compute_var = _build_args(thetas, beta, vp, None, Ns, compute_grad, compute_var, thetabnd, separate_K, None, None, False,
                                            seed, None)
+        a.plan_restarts = R if exact else 0
         out = {}
 
         def buf(name, shape):
@@ -159,10 +163,9 @@ class Comm:
         self.check(self.lib.vbmc_elbo_batch_multi(self.h, gps, C.byref(a)))
         return out
 
-
-    def prepare(self, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None):
+    def prepare(self, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None, exact=False):
         """The batched objective for a stream of batches of the same shape, resolved once (PreparedMulti)."""
-        return PreparedMulti(self, T, R, beta, vp, gps, Ns, compute_var, thetabnd)
+        return PreparedMulti(self, T, R, beta, vp, gps, Ns, compute_var, thetabnd, exact)
 
 
 class PreparedMulti:
@@ -170,27 +173,37 @@ class PreparedMulti:
     (the multi-GPU sibling of vbmc_amd.elbo.PreparedObjective): the argument struct, the fixed vp groups, the bounds and the output
     buffers are built once; a call copies the new thetas into place.  __call__ blocks (vbmc_elbo_batch_multi); submit / collect keep
     up to four batches in flight (slots 0 .. 3; vbmc_elbo_multi_submit / vbmc_elbo_multi_collect): F of ALL R restarts, dF of the restarts this process
-    evaluated (NaN elsewhere)."""
+    evaluated (NaN elsewhere); with a variance term (compute_var != 0) also varG of ALL R restarts (``self.varG``; the third value
+    ``collect`` returns) -- those passes stay on the contexts' own streams, slots 0 and 1 only (include/vbmc_hip.h).
+    exact=True: vbmc_elbo_args.plan_restarts = R, bit-identical to the one-device batch (Comm.negelcbo_batch)."""
 
-    def __init__(self, comm, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None):
+    def __init__(self, comm, T, R, beta, vp, gps, Ns, compute_var=0, thetabnd=None, exact=False):
         self.comm, self.gps = comm, gps
         self.theta = np.zeros((T, R), order="F")
-        self.args, self._keep, _ = _build_args(self.theta, beta, vp, None, Ns, True, compute_var, thetabnd, False, None, None, False, 0, None)
+        self.args, self._keep, cv = _build_args(self.theta, beta, vp, None, Ns, True, compute_var, thetabnd, False, None, None, False, 0, None)
+        self.compute_var = int(cv)
+        self.args.plan_restarts = R if exact else 0
         self._slots = {}
-        self.F, self.dF = self._buffers(self.args)
+        self.F, self.dF, self.varG = self._buffers(self.args)
 
     def _buffers(self, a):
         T, R = self.theta.shape
         F = np.full(R, np.nan)
         dF = np.full((T, R), np.nan, order="F")
         a.F, a.dF = ptr(F), ptr(dF)
-        return F, dF
+        varG = None
+        if self.compute_var:           # (ADVICE r4: the library gathers [F | varG]; the buffer was never handed over)
+            varG = np.full(R, np.nan)
+            a.varG = ptr(varG)
+        return F, dF, varG
 
     def _slot(self, slot):
+        if self.compute_var and slot > 1:
+            raise ValueError("passes with a variance term run on the contexts' own streams: slots 0 and 1 only")
         if slot not in self._slots:
             a = type(self.args).from_buffer_copy(self.args)
-            F, dF = self._buffers(a)
-            self._slots[slot] = (a, F, dF)
+            F, dF, varG = self._buffers(a)
+            self._slots[slot] = (a, F, dF, varG)
         return self._slots[slot]
 
     def __call__(self, thetas, seed=0):
@@ -200,12 +213,12 @@ class PreparedMulti:
         return self.F, self.dF
 
     def submit(self, thetas, seed=0, slot=0):
-        a, _, _ = self._slot(slot)
+        a = self._slot(slot)[0]
         np.copyto(self.theta, np.asarray(thetas, dtype=np.float64).reshape(self.theta.shape, order="F"))   # copied by the library before it returns
         a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.comm.check(self.comm.lib.vbmc_elbo_multi_submit(self.comm.h, self.gps, C.byref(a), int(slot)))
 
     def collect(self, slot=0):
-        a, F, dF = self._slot(slot)
+        a, F, dF, varG = self._slot(slot)
         self.comm.check(self.comm.lib.vbmc_elbo_multi_collect(self.comm.h, C.byref(a), int(slot)))
-        return F, dF
+        return (F, dF, varG) if self.compute_var else (F, dF)
