@@ -273,6 +273,10 @@ def main():
     # the N > 1 code path: process group, library communicator, all-gather per step, strong leg.  VBMC_BENCH_FORCE_COMM=1 takes it with
     # ONE rank too (under torch.distributed.run --nproc-per-node 1): the only way to execute it on a one-GPU box (tests/test_gpu_comm.py)
     multi = world > 1 or (os.environ.get("VBMC_BENCH_FORCE_COMM") == "1" and "RANK" in os.environ)
+    if args.gpus != world and not args.check_launch:
+        # (round 5) a line whose n_gpus is not the N that was asked for is not a measurement of N GPUs: refuse
+        raise SystemExit("bench.py: --gpus %d but the launcher created WORLD_SIZE=%d ranks (rank %d): start it with --nproc-per-node %d"
+                         % (args.gpus, world, rank, args.gpus))
     if args.gpus != world and rank == 0:
         print("bench.py: --gpus %d but the launcher created WORLD_SIZE=%d ranks; reporting the %d ranks that exist"
               % (args.gpus, world, world), file=sys.stderr)
@@ -773,7 +777,9 @@ def main():
                     res[name] = 1e3 * float(np.median(ts))
                 out_["R%d" % Rc] = {"plain_ms_per_step": res["plain"], "comm_ms_per_step": res["comm"],
                                     "overhead_pct": 100.0 * (res["comm"] - res["plain"]) / res["plain"],
-                                    "comm_evals_per_s": Rc / (res["comm"] * 1e-3)}
+                                    "comm_evals_per_s": Rc / (res["comm"] * 1e-3),
+                                    # the N = 1 value of the multi-GPU code path against the plain line: within 3 %
+                                    "within_3pct_of_plain": bool(res["comm"] <= 1.03 * res["plain"])}
             comm1.free_gp(gps1)
         finally:
             comm1.close()
@@ -807,6 +813,8 @@ def main():
         gp_legs(aux)
         aux.update(leg("aux.small_batches", small_batch_leg) or {})
         v = leg("aux.comm_one_rank", comm_one_rank_leg)
+        if isinstance(v, dict) and isinstance(v.get("R64"), dict) and not v["R64"]["within_3pct_of_plain"]:
+            leg_errors["aux.comm_one_rank.assert"] = "the one-rank communicator step at R = 64 is %.1f %% slower than the plain step (> 3 %%)" % v["R64"]["overhead_pct"]
         if v is not None:
             aux["comm_one_rank"] = v
         if (D, N, K, Ns, S) == (10, 400, 50, 10000, 20):     # the other single-GPU configurations of BASELINE.json, beside the headline
@@ -828,6 +836,8 @@ def main():
     if leg_errors:
         extra["leg_errors"] = leg_errors
 
+    if multi:
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
     if rank == 0:
         evals = (1 if shard_ex is not None else world) * Rr * args.steps
         line = {
@@ -848,7 +858,7 @@ def main():
                                      "pipelined: independent batches through vbmc_elbo_submit / vbmc_elbo_collect, four in flight on two streams") +
                                     "; every step moves its theta H2D and its (F, dF) D2H" if pipelined else "one blocking call per step")},
             "backend": ({"nccl": "nccl (RCCL)"}.get(backend, backend) if multi else None),
-            "world_size_observed": (dist.get_world_size() if multi else 1),
+            "world_size_observed": (dist.get_world_size() if multi else 1),     # (== --gpus, asserted above and again here)
             "ranks": [{"rank": int(r[0]), "device": int(r[1]), "wall_s": r[2], "evals_per_s": Rr * args.steps / r[2]} for r in rank_rows],
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -41,11 +41,14 @@ def test_entlb_beyond_128_components(va, cfg):
     assert abs(H - Hr) < 1e-10 * max(1.0, abs(Hr))
 
 
+# Round 5: K = 300, 384, 400 -- beyond the 256 of four waves x 64 components: eight-wave workgroups (HV = 8, three or
+# four k-tiles per wave), Monte-Carlo entropy and the deterministic bound, with bounds and penalties
 @pytest.mark.parametrize("cfg", [(32, 40, 160, 2, 24), (32, 40, 150, 1, 0), (24, 30, 250, 1, 0), (28, 30, 190, 1, 12), (24, 30, 250, 1, 20),
-                                 (5, 40, 200, 2, 64), (10, 40, 129, 1, 40), (6, 30, 256, 1, 32)])
+                                 (5, 40, 200, 2, 64), (10, 40, 129, 1, 40), (6, 30, 256, 1, 32),
+                                 (10, 40, 300, 2, 40), (4, 30, 384, 1, 32), (6, 30, 400, 1, 24), (10, 40, 300, 1, 0), (18, 30, 300, 1, 20)])
 def test_mixtures_whose_finalize_record_exceeds_the_lds(va, cfg):
     D, N, K, S, Ns = cfg
-    assert 4 * D * K + 9 * K > 19400 or K > 128      # the old finalize-record limit, or the four-wave MFMA entropy kernel (K > 128)
+    assert 4 * D * K + 9 * K > 19400 or K > 128      # the old finalize-record limit, or the four- / eight-wave MFMA entropy kernels (K > 128)
     gp, vp, theta, tb = _problem(72, D, N, K, S)
     eps = np.random.default_rng(4).standard_normal((K, max(Ns, 2) // 2, D)) if Ns else None
     ref = R.negelcbo_vbmc(theta, 0, vp, gp, Ns, True, 0, thetabnd=tb, eps=eps)
@@ -66,7 +69,9 @@ def _big_gp(seed, D, N, S, noisy=False, low_noise=False):
     return p
 
 
-@pytest.mark.parametrize("cfg", [(6, 1500, 2, False), (4, 2200, 1, False), (5, 1300, 2, True)])
+# Round 5: N = 4500 -- beyond the 3872 of the four-column slab: two right-hand sides per wave (up to N = 6800; one up
+# to 10208), every GP / variance path.
+@pytest.mark.parametrize("cfg", [(6, 1500, 2, False), (4, 2200, 1, False), (5, 1300, 2, True), (3, 4500, 1, False)])
 def test_gp_post_pred_rank1_beyond_the_wide_slab(va, cfg):
     D, N, S, low = cfg
     p = _big_gp(81, D, N, S, low_noise=low)
@@ -101,8 +106,9 @@ def test_gp_post_pred_rank1_beyond_the_wide_slab(va, cfg):
             assert np.max(np.abs(a["L"] - b["L"])) < 1e-8 * np.max(np.abs(b["L"]))
 
 
-def test_variance_paths_and_nlz_beyond_the_wide_slab(va):
-    D, N, S, K = 5, 1300, 2, 6
+@pytest.mark.parametrize("N,S", [(1300, 2), (4500, 1)])
+def test_variance_paths_and_nlz_beyond_the_wide_slab(va, N, S):
+    D, K = 5, 6
     p = synth_problem(83, D, N, K, S)
     gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
     vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
@@ -123,6 +129,7 @@ def test_variance_paths_and_nlz_beyond_the_wide_slab(va):
     H = p["hyp"].copy()
     H[D + 1, :] = np.log(5e-2)
     nlz, dnlz = va.gplite_nlZ(H, gpd)
+    nlz, dnlz = np.atleast_1d(nlz), np.asarray(dnlz).reshape(H.shape[0], -1)      # (S = 1: a scalar and a vector)
     for b in range(S):
         rz, rg = R.gplite_nlZ(H[:, b], gpd)
         assert abs(nlz[b] - rz) < 1e-9 * max(1.0, abs(rz))

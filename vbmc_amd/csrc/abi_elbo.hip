@@ -402,7 +402,7 @@ static int entropy_mfma_occupancy(int qs, int kt, int hv, bool grad, const EntAr
 // the block-sparse mode (cutoff > 0) always does.
 static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_out, int* hv_out) {
   const int qs = (D + 2 + 3) / 4;
-  int hv = K <= 64 ? ent_hv_small(qs, K) : (K <= 128 ? ent_hv_mid(qs, K) : 4);
+  int hv = K <= 64 ? ent_hv_small(qs, K) : (K <= 128 ? ent_hv_mid(qs, K) : (K <= 256 ? 4 : 8));   // (round 5: eight waves for 256 < K <= 512, full k-tiles only)
   if (K > 64 && K <= 128)
     if (const char* f = getenv("VBMC_ENT_HV")) { const int v = atoi(f); if (v == 2 || v == 4) hv = v; }
   if (K > 32 && K <= 64)
@@ -417,13 +417,13 @@ static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_
     const int ktf = Kh / 16, rem = Kh % 16;
     const bool tail8_ok = ktf == 1 || (hv == 1 && ktf == 2 && (qs >= 5 || rem <= 6)) || (hv == 1 && ktf == 3 && qs <= 4) ||
                           (hv > 1 && ktf == 2) || (hv > 1 && ktf == 3 && qs >= 5);
-    if (tail_on && Kh > 16 && tl >= 1 && tl <= tail_max && (tl == 1 || (tl == 2 && tail8_ok)) && !(cutoff > 0.0) && !(hv > 1 && ktf < 2)) {
+    if (tail_on && hv != 8 && Kh > 16 && tl >= 1 && tl <= tail_max && (tl == 1 || (tl == 2 && tail8_ok)) && !(cutoff > 0.0) && !(hv > 1 && ktf < 2)) {
       kt = ktf;
       hv += 16 * tl;
     }
   }
   *qs_out = qs; *kt_out = kt; *hv_out = hv;
-  return qs >= 1 && qs <= 9 && K >= 1 && K <= 256 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 2) && !(hv == 4 && kt < 2) && !(hv > 16 && kt > 3);
+  return qs >= 1 && qs <= 9 && K >= 1 && K <= 512 && kt >= 1 && kt <= 4 && !(hv == 2 && kt < 2) && !(hv == 4 && kt < 2) && !(hv == 8 && kt < 3) && !(hv > 16 && kt > 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,7 +547,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   dm.D = a->D; dm.K = a->K; dm.R = a->R; dm.S = gp->S; dm.N = gp->N;
   if (dm.D != gp->D) return set_err(ctx, VBMC_ERR_INVALID, "vp.D = %d but gp has D = %d", dm.D, gp->D);
   if (dm.K <= 0 || dm.R <= 0) return set_err(ctx, VBMC_ERR_INVALID, "K and R must be positive");
-  if (dm.K > 256) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d > 256 not accelerated", dm.K);
+  if (dm.K > 512) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d > 512 not accelerated", dm.K);
   const int D = dm.D, K = dm.K, R = dm.R, S = dm.S;
   int T = 0;
   for (int g = 0; g < 4; ++g) dm.opt[g] = a->optimize[g] ? 1 : 0;
@@ -576,7 +576,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   if (compute_var != 0 && VAR_FINAL_LDS(S, K, compute_grad ? T : 0) > 160 * 1024)   // k_var_final: five T-vectors in LDS
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance gradient with %d variational parameters (> 4000) not accelerated", T);
   if (compute_var != 0 && trsm_cw_for(dm.N) == 0)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 3872 not accelerated", dm.N);
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 10208 not accelerated", dm.N);
   P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
   // theta must be finite (the device exp does not propagate NaN)
   for (size_t i = 0; i < (size_t)T * R; ++i)
@@ -701,6 +701,10 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
         q.D = D; q.K = K; q.cutoff = P.cutoff; q.lj.rows = lj_co_shape(ctx, P) ? 1 : 0;
         const int nb = entropy_mfma_occupancy(P.qs, P.kt, P.hv, compute_grad != 0, q);
         if (nb > 0) waves_per_cu = nb * (P.hv & 15);
+        // eight-wave workgroups (K > 256): the parameter block, the parked exponents of eight waves and the PV exchange can exceed the
+        // 160 KB of a compute unit at large D -- then no workgroup fits and the shape is refused below (the VALU kernel's LDS does not
+        // hold K > 256 either)
+        if (nb <= 0 && (P.hv & 15) == 8) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d: the eight-wave entropy kernel needs more than the 160 KiB of LDS", K, D);
         // wide operands (D >= 15): the kernels that COULD hold more than eight waves (one k-tile) do not gain from shorter chunks -- their
         // per-wave set-up grows with D (D = 20, K = 8: 0.27 -> 0.37 ms with twelve assumed) -- while the ones that hold fewer (LDS: seven)
         // are where the correction pays (D = 28, K = 40: 1.36 -> 1.10 ms): profiles/r03_shape_sweep.md

@@ -117,7 +117,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
                    fail_is_error ? "gplite_post" : "gplite_nlZ");
   // right-hand-side slabs of the triangular solves live in LDS: 16 columns wide up to N = 1136, narrower beyond (trsm_cw_for);
   // the Cholesky panel moves to a global scratch block when it no longer fits
-  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 3872 not accelerated", N);
+  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 10208 not accelerated", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 

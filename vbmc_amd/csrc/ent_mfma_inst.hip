@@ -88,6 +88,8 @@ static int dispatch(int mode, int kt, int grad, int hv, dim3 grid, hipStream_t s
     case 64 + 2: return launch_kt<2, 4>(mode, grad, grid, st, *ea);   // 64 < K <= 128, four waves
     case 64 + 3: return launch_kt<3, 4>(mode, grad, grid, st, *ea);   // 128 < K <= 192
     case 64 + 4: return launch_kt<4, 4>(mode, grad, grid, st, *ea);   // 192 < K <= 256
+    case 128 + 3: return launch_kt<3, 8>(mode, grad, grid, st, *ea);  // round 5: eight waves, 256 < K <= 384
+    case 128 + 4: return launch_kt<4, 8>(mode, grad, grid, st, *ea);  //                       384 < K <= 512
     default: return mode != 0 ? -1 : 1;
   }
 }

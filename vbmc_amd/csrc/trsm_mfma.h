@@ -17,8 +17,8 @@ typedef double tmf4 __attribute__((ext_vector_type(4)));
 #define TR_VS 17  // LDS row stride of the 16-column right-hand-side slab and of the panel buffer (16 columns + 1 pad)
 // Narrow slabs for large N: the slab of a wave holds CW = 16, 8 or 4 right-hand sides (row stride CW + 1), the MFMAs still
 // run 16 columns wide with zeros beyond CW.  16 columns fit the 160 KB of LDS up to N = 1136, 8 up to N = 2144, 4 up to
-// N = 3872 (VBMC's default MaxFunEvals = 50 (2 + D) reaches N = 1700 at D = 32): a fallback that trades matrix-core
-// utilisation for range, chosen per call by trsm_cw_for(N).
+// N = 3872 (VBMC's default MaxFunEvals = 50 (2 + D) reaches N = 1700 at D = 32), and -- round 5 -- 2 up to N = 6800, 1 up to
+// N = 10208: a fallback that trades matrix-core utilisation for range, chosen per call by trsm_cw_for(N).
 template <int CW>
 __device__ __forceinline__ double trsm_vld(const double* __restrict__ V, int row, int li) {
   return (CW == 16 || li < CW) ? V[row * (CW + 1) + (CW == 16 ? li : (li < CW ? li : 0))] : 0.0;
@@ -203,13 +203,17 @@ static inline int trsm_cw_for(int N) {
   if (TRSM_LDS_BYTES_CW(N, 16) <= 160 * 1024) return 16;
   if (TRSM_LDS_BYTES_CW(N, 8) <= 160 * 1024) return 8;
   if (TRSM_LDS_BYTES_CW(N, 4) <= 160 * 1024) return 4;
+  if (TRSM_LDS_BYTES_CW(N, 2) <= 160 * 1024) return 2;      // (round 5) up to N = 6800
+  if (TRSM_LDS_BYTES_CW(N, 1) <= 160 * 1024) return 1;      //           up to N = 10208: one right-hand side per wave
   return 0;
 }
 #define TRSM_DISPATCH_CW(cwv_, ...)                                 \
   switch (cwv_) {                                                   \
     case 16: { constexpr int CW = 16; __VA_ARGS__; } break;         \
     case 8: { constexpr int CW = 8; __VA_ARGS__; } break;           \
-    default: { constexpr int CW = 4; __VA_ARGS__; } break;          \
+    case 4: { constexpr int CW = 4; __VA_ARGS__; } break;           \
+    case 2: { constexpr int CW = 2; __VA_ARGS__; } break;           \
+    default: { constexpr int CW = 1; __VA_ARGS__; } break;          \
   }
 
 template <int CW>
