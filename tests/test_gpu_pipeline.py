@@ -167,7 +167,7 @@ def test_log_joint_role_of_the_entropy_launch_matches_the_separate_kernel():
 
 def test_slot_streams_are_placed_by_measurement_in_a_process_with_other_queues(va):
     """abi_elbo.hip: stream_beside -- a fresh context in a process that already holds other hardware queues (those of other contexts
-    here; tools/r4_place_check.py does it with torch streams) creates its slot streams by measuring which candidates dispatch beside each
+    here; tools/archive/r4_place_check.py does it with torch streams) creates its slot streams by measuring which candidates dispatch beside each
     other (tools/stream_pipes.hip); the results do not depend on it, and a second context goes through the same procedure."""
     keep = [va.Engine(0) for _ in range(3)]     # six more streams (a context's own and its second one each) ahead of the slot streams
     p, gp, vp, batches = setup(va, 11, 6, 60, 9, 3, 8)

@@ -17,7 +17,7 @@ extern "C" int vbmc_abi_version(void) { return VBMC_ABI_VERSION; }
 // with_aux: the second stream is created WITH the context (a caller's context: its blocking calls fork the expected log joint onto it);
 // a child behind the pipeline slots never forks and holds one stream.  Created beside the first stream, not on first use: a
 // low-priority stream that comes into being after the slot streams no longer yields to the first stream's kernel (the blocking call
-// at the headline shape 2.50 -> 2.64 ms, tools/r4_blocking_probe.py).
+// at the headline shape 2.50 -> 2.64 ms, tools/archive/r4_blocking_probe.py).
 static vbmc_status ctx_create_impl(int device, void* stream, vbmc_ctx** out, bool with_aux) {
   if (!out) return VBMC_ERR_INVALID;
   *out = nullptr;
@@ -1432,7 +1432,7 @@ static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vb
   vbmc_ctx* sc = ctx->slot_sub[ch];
   sc->profiling = false;
   // ... when there is anything: an event recorded on an idle stream and waited for on another is still a device-side dependency between
-  // two queues, 15-30 us per step where a step is that short (tools/r4_host_cost.py: one restart at VBMC's own sample count 58 -> 27 us
+  // two queues, 15-30 us per step where a step is that short (tools/archive/r4_host_cost.py: one restart at VBMC's own sample count 58 -> 27 us
   // per step, BASELINE configs[1] 89 -> 52).  VBMC_SLOT_XEV=1: always (A/B).
   static const int xev_mode = [] { const char* e = getenv("VBMC_SLOT_XEV"); return e ? atoi(e) : 2; }();
   if (xev_mode == 1 || (xev_mode == 2 && hipStreamQuery(ctx->stream) != hipSuccess)) {

@@ -59,7 +59,7 @@ struct vbmc_ctx {
   // Round 4: FOUR slots on TWO streams.  Slot s runs on child context s & 1 (own stream, own scratch, created on first use) as that
   // child's slot s >> 1 -- two passes queued per stream, two streams: the small kernels at the head and tail of one pass and the last round
   // of waves of another share the chip instead of queuing behind each other, and a stream never runs dry while the host collects and
-  // re-submits (tools/r4_two_ctx.py: the headline step 2.45 -> 2.41 ms, eight restarts 0.358 -> 0.336, four 0.221 -> 0.183).
+  // re-submits (tools/archive/r4_two_ctx.py: the headline step 2.45 -> 2.41 ms, eight restarts 0.358 -> 0.336, four 0.221 -> 0.183).
   // slot_sub[]: the children; slot_where[s] / slot_inner[s]: the context and its slot the pass in flight was enqueued on (this context
   // itself, slots 0 and 1 only, for the variance forms and under VBMC_SLOT_STREAMS=0); slot_xev[s] orders the child's stream after
   // everything enqueued on this context's stream before the submit; slot_yev / slot_zev serve vbmc_elbo_multi_submit, whose exchange

@@ -47,7 +47,7 @@ struct EntTilePartial { static constexpr bool rt = false, val = true; };
 #define VBMC_ENT_SPLIT(KT_, QS_, TL_, HV_, CW_) ((HV_) == 1)
 #endif
 
-#ifdef VBMC_EXP_CLK   // timeline experiment (tools/r4_timeline.py): per wave [entry, loop start, loop end, exit] on the 100 MHz counter + HW_ID + XCC_ID
+#ifdef VBMC_EXP_CLK   // timeline experiment (tools/archive/r4_timeline.py): per wave [entry, loop start, loop end, exit] on the 100 MHz counter + HW_ID + XCC_ID
 #define VBMC_DBG_WAVES 32768
 __device__ unsigned long long g_ent_dbg[6 * VBMC_DBG_WAVES];
 #endif
@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     // A wave's issue priority falls as it progresses (s_setprio 3 -> 0 at the quarter points of its tiles): of two waves that share a
     // SIMD the one BEHIND is served first.  At equal priority the arbiter keeps serving the older wave: with a single round of waves
     // (8 restarts per device: 2000 waves on 2048 slots) one wave of each SIMD finished at 240 us, the other at 340, the last 100 us at
-    // the single-wave issue rate (tools/r4_timeline.py).  R = 8: 0.337 -> 0.327 ms per step (-3.1 %), R = 16: 0.644 -> 0.633, R = 32:
+    // the single-wave issue rate (tools/archive/r4_timeline.py).  R = 8: 0.337 -> 0.327 ms per step (-3.1 %), R = 16: 0.644 -> 0.633, R = 32:
     // 1.246 -> 1.234, R = 64 (eleven rounds: there is always a younger wave to take over) within 0.2 % either way; the same bits.
     // Halves instead of quarters: a third of the gain.  EntArgs::prio = 0 (VBMC_ENT_PRIO=0) / -DVBMC_ENT_NOPRIO: without (A/B).
     // Not in the instantiations built for ONE wave per SIMD (nothing to arbitrate; the thresholds only cost scalar registers there: +0.5-1.1 %
