@@ -361,14 +361,20 @@ def test_kernel_instantiation_sweep(va, dk):
 
 def test_oversized_mixture_is_refused_cleanly(va):
     """Beyond the supported shapes the library answers with a clean VBMC_ERR_UNSUPPORTED (the shim falls through to the
-    reference), not with a failed launch: more than 256 components.  (A D x K record too large for k_finalize's LDS, entlb
-    beyond 128 components and the Monte-Carlo entropy of 128 < K <= 256 components are no longer refused:
-    tests/test_gpu_limits.py.)"""
-    p, gp, vp, theta = problem(5, 4, 40, 257, 1)
+    reference), not with a failed launch: more than 512 components (round 5; 256 through round 4).  (A D x K record too large for
+    k_finalize's LDS, entlb beyond 128 components, the Monte-Carlo entropy of 128 < K <= 256 components and -- eight-wave workgroups --
+    of 256 < K <= 512 are no longer refused: tests/test_gpu_limits.py.)"""
+    p, gp, vp, theta = problem(5, 4, 40, 513, 1)
     with pytest.raises(va.VbmcUnsupported):
         va.negelcbo_vbmc(theta, 0, vp, gp, 0, 1, 0)
     with pytest.raises(va.VbmcUnsupported):
         va.negelcbo_vbmc(theta, 0, vp, gp, 20, 1, 0)
+    # ... and 257 components, the old limit, evaluate
+    p, gp, vp, theta = problem(5, 4, 40, 257, 1)
+    eps = np.random.default_rng(2).standard_normal((257, 10, 4))
+    ref = R.negelcbo_vbmc(theta, 0, vp, gp, 20, True, 0, eps=eps)
+    F, dF = va.negelcbo_vbmc(theta, 0, vp, gp, 20, 1, 0, eps=eps)
+    assert relerr(F, ref["F"]) < RT_VAL and relerr(dF, ref["dF"]) < RT_GRAD
 
 
 def test_tiny_sigma_components_do_not_break_the_exp(va):

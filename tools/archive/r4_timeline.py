@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
@@ -19,7 +19,7 @@ def main():
     from bench import synth_inputs
     from vbmc_amd import _lib
 
-    D, N, K, S = 10, 400, int(os.environ.get("EXP_K", "50")), 20
+    D, N, K, S = int(os.environ.get("EXP_D", "10")), int(os.environ.get("EXP_N", "400")), int(os.environ.get("EXP_K", "50")), int(os.environ.get("EXP_S", "20"))
     inp = synth_inputs(0, D, N, K, S)
     eng = vbmc_amd.Engine(0)
     gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)
@@ -34,7 +34,7 @@ def main():
     lib = _lib.load()
     n = 6 * 32768
     buf = (ctypes.c_ulonglong * n)()
-    rc = lib.vbmc_dbg_ent_read_qs3(buf, ctypes.c_size_t(n))
+    rc = getattr(lib, "vbmc_dbg_ent_read_qs%d" % ((D + 2 + 3) // 4))(buf, ctypes.c_size_t(n))
     assert rc == 0, rc
     a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 6).astype(np.int64)
     a = a[a[:, 0] > 0]

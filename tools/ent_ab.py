@@ -159,7 +159,7 @@ def run(R, Ns):
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "build"
     if cmd == "build":
-        build()
+        build(int(os.environ.get("ENT_AB_QS", "3")))       # ENT_AB_QS=n: the translation unit of QS = n (D = 4 n - 5 .. 4 n - 2)
     elif cmd == "one":
         one(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     else:

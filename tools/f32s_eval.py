@@ -1,0 +1,105 @@
+"""BASELINE configs[4] ("fp32 vs fp64 tolerance stress") answered on the device: the entropy kernel's S-step on
+v_mfma_f32_16x16x4_f32 (an A/B build of the QS = 6 translation unit, -DVBMC_F32S; exponent in fp32, everything behind it in fp64) against
+the product (fp64 throughout), both against the compiled C port of the reference loop nest on the SAME dumped device stream, at the full
+configs[4] shape (D = 20, N = 800, K = 100, Ns = 2e4 per component, S = 20, noisy likelihood).
+
+    python tools/f32s_eval.py build      (here)           python tools/f32s_eval.py run      (GPU box; prints one JSON object)
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "vbmc_amd", "lib", "exp", "libvbmc_hip_f32s.so")
+
+
+def build():
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ent_ab.py"), "build"],
+                          env=dict(os.environ, ENT_AB="f32s:-DVBMC_F32S", ENT_AB_QS="6"))
+
+
+def one():
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    import vbmc_amd
+    from tests._cases import block_relerr, synth_problem
+
+    D, N, K, S, Ns = 20, 800, 100, 20, 20000
+    p = synth_problem(41, D, N, K, S, noisy=True)
+    scale = float(os.environ.get("F32S_MU_SCALE", "1"))     # < 1: the component means pulled together (an OVERLAPPING mixture)
+    p["mu"] = p["mu"] * scale
+    gp = vbmc_amd.gplite_post(p["hyp"], p["X"], p["y"], 1, 4, p["noisefun"], p["s2"])
+    vp = vbmc_amd.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]])
+    eng = vbmc_amd.default_engine()
+    a = vbmc_amd.negelcbo_batch(theta, 0, vp, gp, Ns, True, 0, seed=2024)
+    R = 16
+    th = np.asfortranarray(theta[:, None] + 0.02 * np.random.default_rng(1).standard_normal((theta.size, R)))
+    for _ in range(3):
+        vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=5, outputs=("F",))
+    eng.ctx.set_profiling(2)
+    ms = []
+    for i in range(8):
+        vbmc_amd.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=6 + i, outputs=("F",))
+        ms.append(eng.ctx.last_kernel_ms()[0])
+    from vbmc_amd import _lib
+
+    out = {"lib": os.path.basename(_lib.LIB_PATH), "F": float(a["F"][0]), "H": float(a["H"][0]), "G": float(a["G"][0]), "kernel_ms_R16": float(np.median(ms))}
+    if os.environ.get("F32S_REF") == "1":        # the reference values: C port (OpenMP) on the dumped device stream
+        from oracle import c_oracle
+
+        eps = eng.ctx.rng_dump(D, K, 1, Ns, 2024)[0]
+        alpha = np.stack([q["alpha"] for q in gp["post"]], axis=1)
+        F, dF, G, H = c_oracle.negelcbo(theta, p["X"], p["hyp"], alpha, eps, meanfun=4, Nnoise=1, openmp=True)
+        np.savez(os.environ["F32S_DUMP"] + "_ref.npz", F=F, dF=dF, G=G, H=H)
+    np.savez(os.environ["F32S_DUMP"] + ".npz", F=a["F"][0], dF=a["dF"][:, 0], H=a["H"][0], dH=a["dH"][:, 0])
+    print(json.dumps(out))
+
+
+def run():
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    from tests._cases import block_relerr
+
+    tmp = os.path.join(ROOT, "gpurun_out", "f32s")
+    os.makedirs(tmp, exist_ok=True)
+    all_res = {}
+    # the synthetic configs[4] mixture as bench.py builds it (D = 20: its components are ~30 sigma apart -- no cross term survives
+    # next to the own component's exact 1, so the two builds agree to the last bit), and the same mixture with the means pulled
+    # together by 20x and by 100x, where every sample sees many components
+    for scale in ("1", "0.05", "0.01"):
+        all_res["mu_scale_" + scale] = run_one(tmp, scale)
+    print(json.dumps(all_res))
+
+
+def run_one(tmp, scale):
+    import numpy as np
+    from tests._cases import block_relerr
+
+    res = {}
+    for name, lib, ref in (("fp64", None, "1"), ("fp32_exponent", LIB, "0")):
+        env = dict(os.environ, F32S_DUMP=os.path.join(tmp, name), F32S_REF=ref, F32S_MU_SCALE=scale)
+        if lib:
+            env["VBMC_HIP_LIB"] = lib
+        o = subprocess.run([sys.executable, os.path.abspath(__file__), "one"], env=env, capture_output=True, text=True)
+        line = [ln for ln in o.stdout.splitlines() if ln.startswith("{")]
+        assert line, o.stderr[-2000:]
+        res[name] = json.loads(line[-1])
+    r = np.load(os.path.join(tmp, "fp64_ref.npz"))
+    D, K = 20, 100
+    for name in ("fp64", "fp32_exponent"):
+        z = np.load(os.path.join(tmp, name + ".npz"))
+        res[name]["F_relerr_vs_c_port"] = float(abs(z["F"] - r["F"]) / abs(r["F"]))
+        res[name]["H_relerr_vs_c_port"] = float(abs(z["H"] - r["H"]) / abs(r["H"]))
+        res[name]["dF_block_relerr_vs_c_port"] = {k: float(v) for k, v in block_relerr(z["dF"], r["dF"], D, K).items()}
+    res["kernel"] = "k_entropy_mfma<QS=6,KT=3+tail2,grad,HV=2> at D=20 N=800 K=100 Ns=20000/component S=20, R=16; kernel timed alone (HIP events)"
+    res["speedup_pct"] = 100.0 * (res["fp64"]["kernel_ms_R16"] - res["fp32_exponent"]["kernel_ms_R16"]) / res["fp64"]["kernel_ms_R16"]
+    return res
+
+
+if __name__ == "__main__":
+    {"build": build, "one": one, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "build"]()

@@ -499,6 +499,7 @@ struct ElboPlan {
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   int no_jacobian = 0;
+  const double* h_up = nullptr;   // the staged upload block when the pass's first launch does the upload itself (k_prep_up)
   int Rp = 0;                // the restarts the launch shapes are chosen for: R, or the undivided batch's (vbmc_elbo_args.plan_restarts)
   double* d_dvs = nullptr;   // per-hyper-sample variance gradient block (dvarG_s), pooled for the call
   bool lj_records = false;   // the caller reads per-hyper-sample log-joint records (separate_K, G_s / varG_s, the variance kernels)
@@ -526,9 +527,12 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
   // hyper-sample -- or an entropy-only evaluation, whose surrogate is a one-point stand-in -- can fill the chip by itself and wants the
   // kernels built for occupancy, not these)
   const long long KR = (long long)P.dm.K * (P.Rp > P.dm.R ? P.Rp : (long long)P.dm.R * P.rstride);
+  // VBMC_LJ_CO_SR / VBMC_LJ_CO_KR (A/B, round 5): the two width limits in units of the chip's compute units (defaults 0.5 and 2)
+  static const double lim_sr = [] { const char* e = getenv("VBMC_LJ_CO_SR"); return e ? atof(e) : 0.5; }();
+  static const double lim_kr = [] { const char* e = getenv("VBMC_LJ_CO_KR"); return e ? atof(e) : 2.0; }();
   return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 8 && !(P.cutoff > 0.0) && P.compute_grad &&
-         !P.lj_records && SR < ctx->num_cu / 2 && (P.Rp > P.dm.R || SR * P.rstride < ctx->num_cu / 2) &&   // (the undivided batch's choice when the restarts are dealt over devices)
-         KR < 2 * ctx->num_cu && P.dm.N > 1 &&
+         !P.lj_records && SR < lim_sr * ctx->num_cu && (P.Rp > P.dm.R || SR * P.rstride < lim_sr * ctx->num_cu) &&   // (the undivided batch's choice when the restarts are dealt over devices)
+         KR < lim_kr * ctx->num_cu && P.dm.N > 1 &&
          // (round 4) ... and small in WORK, not only in width: with many sample tiles per wave (Ns = 1e4 per component: 313 tiles per
          // (component, restart)) the role's workgroups delay an entropy launch that fills the chip by itself -- R = 4 at the headline
          // shape: 0.242 ms with the role, 0.221 without; equal at R = 2 -- while at the optimiser's own sample counts (Ns = 28..400)
@@ -539,7 +543,9 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
 #define VAR_FINAL_LDS(S_, K_, Tg_) ((VARFIN_THREADS + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
-static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0) {
+// defer_upload: the caller goes straight on to elbo_enqueue with the pass's k_prep (vbmc_elbo_batch, the pipelined submit): the upload
+// is then done by that launch itself (k_prep_up) instead of a copy kernel of its own.
+static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0, bool defer_upload = false) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
   if (a->struct_size != sizeof(vbmc_elbo_args))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(vbmc_elbo_args));
@@ -648,7 +654,13 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   P.d_fix = P.d_theta + n_theta;
   P.d_delta2 = P.d_fix + n_fix;
   P.d_bnd = P.has_bnd ? P.d_delta2 + n_delta : nullptr;
-  if (copy_by_kernel(n_up * sizeof(double))) {
+  // (built and measured in round 5, NOT adopted: at BASELINE configs[1] the host's submit falls from 23.6 to 17.1 us with this and the
+  // folded reduction, but the step does not move (49.8 -> 51.2 us): the pass is bound by its two 30 us kernels on the device, and a
+  // workgroup that unpacks its restart from the pinned block pays a trip over the host link.  VBMC_PREP_UP=1 turns it on.)
+  static const bool up_fuse = [] { const char* e = getenv("VBMC_PREP_UP"); return e && !strcmp(e, "1"); }();
+  if (defer_upload && up_fuse && copy_by_kernel(n_up * sizeof(double)) && n_theta > 0) {
+    P.h_up = hp;          // k_prep_up copies and unpacks (elbo_enqueue)
+  } else if (copy_by_kernel(n_up * sizeof(double))) {
     hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((n_up + 255) / 256, 1024)), dim3(256), 0, st, n_up, (const double*)hp, P.d_theta);
     HIP_TRY(ctx, hipGetLastError());
   } else {
@@ -862,7 +874,14 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const size_t prep_lds = ((size_t)D * K + 3 * K + D + 8) * sizeof(double);
   if (prep_lds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-  if (!skip_prep) {
+  if (!skip_prep && P.h_up && !pend) {
+    hipLaunchKernelGGL(k_prep_up, dim3(R), dim3(256), prep_lds, st, dm, P.n_up, P.n_theta, P.h_up, P.d_theta, P.d_vpd, P.d_entp);
+    LAUNCH_CHECK(ctx, "k_prep_up");
+  } else if (!skip_prep) {
+    if (P.h_up) {      // (not reached: a deferred upload belongs to a plain pass)
+      hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((P.n_up + 255) / 256, 1024)), dim3(256), 0, st, P.n_up, P.h_up, P.d_theta);
+      LAUNCH_CHECK(ctx, "k_copy_f64");
+    }
     hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), prep_lds, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
                        pend ? pend_iter : 0, (const double*)P.d_out);
     LAUNCH_CHECK(ctx, "k_prep");
@@ -879,12 +898,17 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
   // (round 4: from S R = one workgroup per compute unit on -- below, the finer-grained VALU kernel is the faster one: R = 8 at the headline
   // shape, 160 (hyper-sample, restart) workgroups: 56 us against 34 alone, the step 0.394 -> 0.360 ms; equal at R = 16, 142 against 174 us at R = 64)
-  const bool lj_mfma = P.compute_grad && K <= 256 && (lj_force || (long long)S * P.Rp >= ctx->num_cu) && !(ljf && !strcmp(ljf, "valu"));
+  const bool co_shape = sh.mode == 0 && !fork && !lj_force && lj_co_shape(ctx, P);      // (the role takes precedence over the matrix-core kernel where its limits admit the batch)
+  // (round 5) ... and enough WAVES in each: with K <= 16 a workgroup of the matrix-core kernel is a single wave walking the whole training
+  // set, and the VALU kernel's four waves per cell group are faster until the batch is several chips wide (BASELINE configs[1], K = 10,
+  // S R = 512: 28.3 us against 19.9)
+  const bool lj_wide = K > 16 || (long long)S * P.Rp >= 4LL * ctx->num_cu;
+  const bool lj_mfma = !co_shape && P.compute_grad && K <= 256 && (lj_force || ((long long)S * P.Rp >= ctx->num_cu && lj_wide)) && !(ljf && !strcmp(ljf, "valu"));
   // Small grids (a single chain, a handful of restarts): the VALU log joint runs as a ROLE of the entropy launch (single-wave
   // workgroups ahead of the entropy ones, entropy_mfma.h CO = true) -- two dependent-chain-bound kernels side by side instead of
   // one after the other, one launch less.  Its records are per (hyper-sample, split of the training set); the reduction over
   // hyper-samples adds the splits.  VBMC_LJ_CO=0 keeps the separate launch (A/B runs, tests).
-  const bool co = sh.mode == 0 && !fork && !lj_mfma && lj_co_shape(ctx, P);
+  const bool co = co_shape && !lj_mfma;
   auto enqueue_logjoint = [&](hipStream_t ls) -> vbmc_status {
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ls));
     if (!co) {
@@ -946,6 +970,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
 
   // ---- entropy
   FinArgs fa{};
+  bool fin_fold = false;
   fa.dm = dm;
   if (P.mc) {
     EntArgs ea{};
@@ -968,6 +993,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         const long long cells = (long long)((K + 3) / 4) * S;   // per restart: a restart's bits do not depend on the batch it is in
         const int slabs = (dm.N + 15) / 16;
         lc.nsplit = (int)std::max<long long>(1, std::min<long long>(std::min(LJ_CO_SPLIT, slabs), (640 + cells / 2) / cells));
+        // (round 5) a BATCH wide enough that the record buffer holds one record per hyper-sample (elbo_plan: ljrec): one role workgroup per
+        // cell group -- the restarts supply the parallelism the splits supply to a single chain
+        if ((long long)S * std::min(R, P.Rp) >= ctx->num_cu / 2) lc.nsplit = 1;
       }
       lc.nwg = ((K + 3) / 4) * S * lc.nsplit;
       lc.rows = co_rows = (lc.nwg + nc - 1) / nc;
@@ -989,8 +1017,23 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     LAUNCH_CHECK(ctx, "the entropy kernel");
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     if (sh.mode == 1) return VBMC_OK;   // the records are in the send block; the exchange and the rest follow in mode 2
-    // chunk partials -> one record per (r, j), summed in chunk order
-    if (fork)
+    // chunk partials -> one record per (r, j), summed in chunk order.  (Round 5) FEW records -- at most sixteen log-joint records per
+    // component and sixteen sample chunks, a small mixture: BASELINE configs[1] -- and everything of the finalize kernel staged in LDS
+    // (its FAST instantiation): that kernel sums them while it stages, in the same order, and the launch is saved (fin_fold).
+    {
+      static const bool fold_off = [] { const char* e = getenv("VBMC_FIN_FOLD"); return !(e && !strcmp(e, "1")); }();     // (see VBMC_PREP_UP: measured, not adopted; "1" turns it on)
+      static const bool fin_seq0 = [] { const char* e = getenv("VBMC_FIN"); return e && !strcmp(e, "seq"); }();
+      const int Sraw = co ? S * ea.lj.nsplit : S, LJS0 = 2 * D + 2;
+      const int next_mu0 = dm.opt[0] ? D * K : 0;
+      const int Text0 = next_mu0 + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
+      const size_t need = (FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8 + (size_t)VpLayout{D, K}.stride() +
+                           (P.has_bnd ? 3 * (size_t)Text0 : 0) + (size_t)K * LJS0 + (size_t)K * P.ncol) * sizeof(double);
+      fin_fold = !fold_off && !fin_seq0 && !fork && sh.mode == 0 && !P.fin_big && !P.d_finbig && need <= 96 * 1024 && Sraw <= 16 && P.C <= 16 &&
+                 K * LJS0 <= 2048 && K * P.ncol <= 4096 && !fuse && !pend;
+      if (fin_fold) { fa.fold = 1; fa.S_raw = Sraw; fa.C_raw = P.C; fa.lj_raw = P.d_lj; fa.part_raw = P.d_part; }
+    }
+    if (fin_fold) {
+    } else if (fork)
       hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
                          P.d_part, P.d_red);
     else
@@ -1260,7 +1303,7 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     if (s_) return s_;
   }
   ElboPlan P;
-  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P, 0, true); if (s_) return s_; }
   const size_t ndvs = a->dvarG_s ? (size_t)P.dm.T * P.dm.S * P.dm.R : 0;    // gplogjoint's dvarF with avg_flag = 0: T x S per restart
   if (ndvs) HIP_TRY(ctx, pool_get(ctx, ndvs * sizeof(double), (void**)&P.d_dvs));
   vbmc_status st = elbo_enqueue(ctx, gp, P, a->seed);
@@ -1308,7 +1351,7 @@ static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc
   // the slot's own pinned block stands in for the context's while the inputs are staged and the copies are enqueued
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
-  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P);
+  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P, 0, true);
   // Result blocks of at most 256 KB are written by the finalize kernel straight into the pinned block (no read-back launch: BASELINE
   // configs[1] 52.1 -> 50.0 us per step, nothing elsewhere), only where nothing on the device reads the records afterwards (not under a
   // communicator: k_comm_pick does).  VBMC_DIRECT_OUT=n: another bound in KB, 0 = never (A/B).  The mirror image -- the staging block read

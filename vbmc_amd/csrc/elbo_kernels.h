@@ -152,6 +152,19 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
   prep_body(dm, theta, vpfix, vpd, entp, blockIdx.x, sh);
 }
 
+// k_prep_up (round 5): the upload of a pass and its unpacking in ONE launch.  The staged block (theta | fixed vp | delta^2 | bounds, in
+// the pass's pinned host block, mapped into the device's address space) is copied into device memory by all workgroups together -- the
+// kernels that follow read it there -- while each workgroup unpacks ITS restart straight from the pinned source (the device copy is
+// complete only at the end of the launch).  One launch less per pass: where a pass is seven short kernels (BASELINE configs[1]) the
+// launch and its first round trip are a sixth of it, and the host's submit is mostly launches.
+__global__ void __launch_bounds__(256) k_prep_up(ElboDims dm, size_t n_up, size_t n_theta, const double* __restrict__ hsrc,
+                                                 double* __restrict__ ddst, double* __restrict__ vpd, double* __restrict__ entp) {
+  VB_SMALL_PRIO();
+  extern __shared__ double sh[];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += (size_t)gridDim.x * blockDim.x) ddst[i] = hsrc[i];
+  prep_body(dm, hsrc, hsrc + n_theta, vpd, entp, blockIdx.x, sh);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_logjoint: misc/gplogjoint.m:162-271 (body: logjoint_body.h).  One workgroup = four (component k, hyper-sample s) cells;
 // with LJ_MAXW waves each wave takes every LJ_MAXW-th 16-point slab of the training set.
@@ -689,6 +702,12 @@ struct FinArgs {
   double TolCon, WeightThreshold, WeightPenalty, beta;
   int M, C, ncol, want_grad, has_bnd, var_stride;
   int no_jacobian;        // 1: gradients with respect to sigma, lambda, w themselves (JACOBIAN_FLAG = 0 of the stand-alone forms; k_finalize_ws only)
+  // fold (round 5, FAST instantiation only): the pass has FEW partial records (S' <= 16 log-joint records per component, C <= 16 sample
+  // chunks; small mixtures: BASELINE configs[1]) -- the finalize kernel sums them itself while it stages (same order as k_lj_reduce /
+  // k_ent_reduce: identical bits) and the pass does without the reduction launch
+  int fold, S_raw, C_raw;
+  const double* lj_raw;   // R x S' x K x (2D+2)
+  const double* part_raw; // R x K x C x ncol
   double invS, invM;      // 1 / S and 1 / (2 M) from the host (the same IEEE quotients; a division per thread in k_finalize_ws's preamble otherwise)
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* big;            // null, or R x (3T + DK) doubles of global scratch for dG | dH | dP | gsc when they exceed the LDS
@@ -1061,15 +1080,52 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   const double invS = a.invS;
   const double* lb = a.ljbar + (size_t)r * K * LJS;
   const double* pe = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;   // (C = 1: reduced records)
+  const bool fold = FAST && a.fold != 0;
   if (FAST || (a.stage & 1)) {
     double* lbL = stg;
     double* peL = lbL + K * LJS;
-    sb[2] = StageBlk{lbL, lb, K * LJS};
-    if (pe) sb[3] = StageBlk{peL, pe, K * a.C * a.ncol};
+    if (!fold) {
+      sb[2] = StageBlk{lbL, lb, K * LJS};
+      if (pe) sb[3] = StageBlk{peL, pe, K * a.C * a.ncol};
+    }
     lb = lbL;
     if (pe) pe = peL;
   }
   stage_copy4(sb, tid, nt);      // (every load of the four blocks in flight before the first store)
+  if (fold) {
+    // sum_s' lj_raw[r][s'][k][col] and sum_c part_raw[r][k][c][col], eight loads in flight, added in record order
+    double* lbL = const_cast<double*>(lb);
+    const double* src = a.lj_raw + (size_t)r * a.S_raw * K * LJS;
+    const size_t st_ = (size_t)K * LJS;
+    for (int i = tid; i < K * LJS; i += nt) {
+      double acc = 0.0;
+      for (int s0 = 0; s0 < a.S_raw; s0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = s0 + u < a.S_raw ? src[(size_t)(s0 + u) * st_ + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (s0 + u < a.S_raw) acc += t[u];
+      }
+      lbL[i] = acc;
+    }
+    if (pe) {
+      double* peL = const_cast<double*>(pe);
+      const double* ps = a.part_raw + (size_t)r * K * a.C_raw * a.ncol;
+      for (int i = tid; i < K * a.ncol; i += nt) {
+        const int j = i / a.ncol, col = i - j * a.ncol;
+        const double* pj = ps + (size_t)j * a.C_raw * a.ncol + col;
+        double acc = 0.0;
+        for (int c0 = 0; c0 < a.C_raw; c0 += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = c0 + u < a.C_raw ? pj[(size_t)(c0 + u) * a.ncol] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (c0 + u < a.C_raw) acc += t[u];
+        }
+        peL[i] = acc;
+      }
+    }
+  }
   for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
   if (tid < 8) scal[tid] = 0.0;
   __syncthreads();

@@ -131,6 +131,19 @@ constexpr bool X_C2 = false;
 #else
 constexpr bool X_C2 = true;
 #endif
+// F32S (A/B build only, -DVBMC_F32S; BASELINE configs[4]'s label "fp32 vs fp64 tolerance stress" answered on the device):
+// the S-step -- the exponents E = b_k . a_i -- on v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulation: half the matrix-pipe time of
+// the fp64 instruction), everything behind it (table exp, PV step, per-sample scalars, gradients) in fp64 as before.  Where the S-step is
+// round 4's form (no C2: the configs[4] instantiation among them).  The fp32 instruction leaves row 4 g + r in register r of lane group g
+// where the fp64 one leaves row 4 r + g: the component a register holds changes (ent_ci), nothing else.  Never the default: the measured
+// error and time are in profiles/r05_fp32_exponent.md.
+#ifdef VBMC_F32S
+constexpr bool X_F32S = true;
+#else
+constexpr bool X_F32S = false;
+#endif
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
 // Where C2 and GP2 are used: everywhere except the instantiations where the sweep of every (k-tiles, tail, waves per workgroup) class
 // over D = 2..32 measured them slower than round 4's forms (tools/tune_sweep.py, variants noc2 / nogp2 of tools/tune_build.py against the
 // tree and against round 4's HEAD; profiles/r05_shape_sweep.md).  The losers are the register-bound kernels: the pair reads and the lane
@@ -263,6 +276,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   constexpr bool VBL = GRAD && HV == 1 && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
   constexpr bool C2 = X_C2 && VBMC_ENT_EO(HV) && !SPARSE && ent_c2_for(KT, QS, TL, HV);
+  constexpr bool F32S = X_F32S && VBMC_ENT_EO(HV) && !C2 && !SPARSE && CW == 1;
+  // component (within the wave's share) held by accumulator register rr of this lane group in k-tile kt
+#define ENT_CI(kt_, rr_) (F32S ? 16 * (kt_) + 4 * lg + (rr_) : 16 * (kt_) + 4 * (rr_) + lg)
   __shared__ __attribute__((aligned(16))) double SCP_all[HV][C2 ? KT * 16 * 2 : 2];   // C2: [component 16 kt + c][2 c0, 2 c1] of the even part
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
   // CW > 1 (chunk waves): the CW waves of a workgroup work on the SAME (component j, restart r) and on CW consecutive sample chunks,
@@ -306,6 +322,14 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // dynamic LDS for the larger of the two uses)
   double* const TAB = PB;
   double* const YX = PB + VB_EXP_TAB1K_N;
+  // (round 5) the exp table's global loads and sigma_j leave at the kernel's entry, beside the parameter block's: three round trips to
+  // memory one after the other (block, sigma_j behind the barrier, table behind the operand build) were a third of the 9.7 us set-up
+  constexpr int NTH0 = WAVE * HV * CW;
+  constexpr int NTB0 = (VB_EXP_TAB1K_N + NTH0 - 1) / NTH0;
+  double tt[NTB0];
+#pragma unroll
+  for (int u = 0; u < NTB0; ++u) tt[u] = c_exp2_tab1k[min(tid + u * NTH0, VB_EXP_TAB1K_N - 1)];
+  const double sigj = a.vpd[(size_t)r * VpLayout{D, K}.stride() + VpLayout{D, K}.sigma() + j];
   {
     // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
     // single chain) this setup is a quarter of the kernel
@@ -331,11 +355,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   __syncthreads();
   const double* gp = PB;
   const double* pj = gp + (size_t)j * PSg;
-  VpLayout L{D, K};
-  const double sigj = a.vpd[(size_t)r * L.stride() + L.sigma() + j];
   const double cKj = pj[D + 1];
   const double hj_neg = 0.5 / (sigj * sigj);   // = -h_j bit for bit (k_prep computes h = -0.5/(sigma*sigma))
-  const int nr_last = TL ? 4 : max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
+  const int nr_last = (TL || F32S) ? 4 : max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
@@ -389,7 +411,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     if (C2 && lg < 2 && (CW == 1 || cwi == 0)) SCP[(16 * kt + li) * 2 + lg] = 2.0 * SC[kt];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int k2 = 16 * kt + 4 * rr + lg;
+      const int k2 = ENT_CI(kt, rr);
       const bool kv2 = k2 < Kw;
       const double* p2 = gp + (size_t)(kv2 ? kbase + k2 : 0) * PSg;
       if (GRAD) {
@@ -456,13 +478,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // ---- the parameter block is dead: its LDS becomes the exp table
   __syncthreads();
   {
-    constexpr int NTH = WAVE * HV * CW;
-    constexpr int NTB = (VB_EXP_TAB1K_N + NTH - 1) / NTH;
-    double tt[NTB];
 #pragma unroll
-    for (int u = 0; u < NTB; ++u) tt[u] = c_exp2_tab1k[min(tid + u * NTH, VB_EXP_TAB1K_N - 1)];
-#pragma unroll
-    for (int u = 0; u < NTB; ++u) if (VB_EXP_TAB1K_N % NTH == 0 || tid + u * NTH < VB_EXP_TAB1K_N) TAB[tid + u * NTH] = tt[u];
+    for (int u = 0; u < NTB0; ++u) if (VB_EXP_TAB1K_N % NTH0 == 0 || tid + u * NTH0 < VB_EXP_TAB1K_N) TAB[tid + u * NTH0] = tt[u];
   }
   __syncthreads();
   if (CW > 1 && c >= a.C) return;   // a chunk wave beyond the last chunk (C not a multiple of CW): no barrier follows
@@ -654,9 +671,25 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
           mf4 e2nd;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const double2 pr = *reinterpret_cast<const double2*>(SCP + (16 * kt + 4 * rr + lg) * 2);
+            const double2 pr = *reinterpret_cast<const double2*>(SCP + ENT_CI(kt, rr) * 2);
             e2nd[rr] = fma(pr.x, u2, pr.y) - n[kt][rr];
           }
+          if (NML) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) NMS[(kt * 4 + rr) * WAVE + lane] = e2nd[rr];
+          } else {
+            nm[(EO && !NML) ? kt : 0] = e2nd;
+          }
+        } else
+        if (F32S) {
+          const vf4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const vf4 c32 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)SC[kt], (float)sfc, z4, 0, 0, 0);
+          vf4 n32 = c32;
+#pragma unroll
+          for (int q = 0; q < QL; ++q) n32 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)SAV(kt, q), (float)sfl[q], n32, 0, 0, 0);
+          mf4 e2nd;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) { n[kt][rr] = (double)n32[rr]; e2nd[rr] = 2.0 * (double)c32[rr] - n[kt][rr]; }
           if (NML) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) NMS[(kt * 4 + rr) * WAVE + lane] = e2nd[rr];
@@ -1072,7 +1105,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
         double wv = Wacc[kt][rr];
         wv += __shfl_xor(wv, 1, 64); wv += __shfl_xor(wv, 2, 64);
         wv += __shfl_xor(wv, 4, 64); wv += __shfl_xor(wv, 8, 64);
-        const int k = 16 * kt + 4 * rr + lg;
+        const int k = ENT_CI(kt, rr);
         if (li == 0 && k < Kw) o[2 + 2 * D + kbase + k] = wv;
       }
     if (TL) {
@@ -1098,4 +1131,5 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #endif
 #undef VBV
 #undef SAV
+#undef ENT_CI
 }
