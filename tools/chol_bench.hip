@@ -64,9 +64,11 @@ __global__ void __launch_bounds__(512) k_tile_stream(int N, double* A, int mode,
   if (sum == 1.2345e300) out[0] = sum;
 }
 
+static double *g_dFinv = nullptr, *g_dpfd = nullptr, *g_drin = nullptr, *g_dzout = nullptr;   // variant 2: the by-products as well
 static hipError_t launch(int variant, int N, int S, double* dA, int* dpf, unsigned char* dact, double* dPg, hipStream_t st) {
   switch (variant) {
     case 1: return chol2_launch(N, S, dA, dpf, dact, dPg, st);
+    case 2: return chol2_launch(N, S, dA, dpf, dact, dPg, st, g_dFinv, g_dpfd, g_drin, g_dzout);
     default: return hipErrorInvalidValue;
   }
 }
@@ -123,6 +125,14 @@ int main(int argc, char** argv) {
   std::vector<unsigned char> ones(S, 1);
   CHECK(hipMemcpy(dact, ones.data(), S, hipMemcpyHostToDevice));
   for (int s = 0; s < S; ++s) CHECK(hipMemcpy(dA0 + s * NN, A.data(), NN * 8, hipMemcpyHostToDevice));
+  const int nblk = Np >> 4;
+  std::vector<double> rhs((size_t)S * N);
+  for (auto& v : rhs) v = rnd();
+  if (variant == 2) {
+    CHECK(hipMalloc(&g_dFinv, (size_t)S * nblk * 256 * 8)); CHECK(hipMalloc(&g_dpfd, S * 8));
+    CHECK(hipMalloc(&g_drin, (size_t)S * N * 8)); CHECK(hipMalloc(&g_dzout, (size_t)S * N * 8));
+    CHECK(hipMemcpy(g_drin, rhs.data(), (size_t)S * N * 8, hipMemcpyHostToDevice));
+  }
   hipStream_t st;
   CHECK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
@@ -154,6 +164,45 @@ int main(int argc, char** argv) {
         if (i <= j) worst = std::max(worst, std::fabs(v - r) / (std::fabs(r) + 1e-3));
         else lowmax = std::max(lowmax, std::fabs(v));
       }
+  }
+  double zworst = 0, fworst = 0, pfdbad = 0;
+  if (variant == 2) {
+    // by-products: z = R' \\ r against a long-double forward substitution with the host factor, the block inverses against
+    // a long-double inverse of the host factor's diagonal blocks, the failure indices as doubles
+    std::vector<double> z((size_t)S * N), fi((size_t)S * nblk * 256), pfd(S);
+    CHECK(hipMemcpy(z.data(), g_dzout, z.size() * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(fi.data(), g_dFinv, fi.size() * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(pfd.data(), g_dpfd, S * 8, hipMemcpyDeviceToHost));
+    for (int s = 0; s < S; ++s) {
+      pfdbad += std::fabs(pfd[s]);
+      std::vector<long double> zh(N);
+      double zmax = 0;
+      for (int i = 0; i < N; ++i) {
+        long double v = rhs[(size_t)s * N + i];
+        for (int t = 0; t < i; ++t) v -= (long double)R[t + (size_t)N * i] * zh[t];
+        zh[i] = v / R[i + (size_t)N * i];
+        zmax = std::max(zmax, (double)fabsl(zh[i]));
+      }
+      for (int i = 0; i < N; ++i) zworst = std::max(zworst, std::fabs(z[(size_t)s * N + i] - (double)zh[i]) / zmax);
+      for (int b = 0; b < nblk; ++b) {
+        const int b0 = b << 4;
+        for (int c = 0; c < 16; ++c) {        // column c of inv(R_bb'): R_bb' x = e_c
+          long double x[16];
+          for (int ii = 0; ii < 16; ++ii) {
+            long double t = ii == c ? 1.0L : 0.0L;
+            for (int jj = 0; jj < ii; ++jj) {
+              const double rji = (b0 + ii < N && b0 + jj < N) ? R[b0 + jj + (size_t)N * (b0 + ii)] : 0.0;
+              t -= (long double)rji * x[jj];
+            }
+            x[ii] = t / (b0 + ii < N ? R[b0 + ii + (size_t)N * (b0 + ii)] : 1.0);
+          }
+          for (int ii = 0; ii < 16; ++ii)
+            fworst = std::max(fworst, std::fabs(fi[((size_t)s * nblk + b) * 256 + ii * 16 + c] - (double)x[ii]) / (std::fabs((double)x[c]) + 1e-300));
+        }
+      }
+    }
+    printf("{\"by_products\": true, \"z_max_rel_err\": %.3e, \"finv_max_rel_err\": %.3e, \"pfd_sum\": %.1f, \"ok\": %s}\n", zworst, fworst, pfdbad,
+           (zworst < 1e-11 && fworst < 1e-9 && pfdbad == 0) ? "true" : "false");
   }
   // failure index: make the leading minor of order jf+1 indefinite
   const int jf = std::min(N - 1, (2 * N) / 3);

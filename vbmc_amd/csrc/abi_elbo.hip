@@ -156,6 +156,33 @@ extern "C" vbmc_status vbmc_memcpy_d2h(vbmc_ctx* ctx, void* dst, const void* src
 // ------------------------------------------------------------------------------------------
 // GP upload
 // ------------------------------------------------------------------------------------------
+// derived per-sample constants of a surrogate (gplogjoint.m:99-121): S x GPC_STRIDE(D)
+static void gp_constants(int D, int S, int Nhyp, int Ncov, int Nnoise, int meanfun, const double* hyp, double* gpc) {
+  for (int s = 0; s < S; ++s) {
+    const double* h = hyp + (size_t)s * Nhyp;
+    double* g = gpc + (size_t)s * GPC_STRIDE(D);
+    double sum_lnell = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double ell = std::exp(h[d]);
+      g[d] = ell * ell;
+      sum_lnell += h[d];
+    }
+    const int mo = Ncov + Nnoise;
+    for (int d = 0; d < D; ++d) {
+      if (meanfun == 4) {
+        g[D + d] = h[mo + 1 + d];
+        double om = std::exp(h[mo + D + 1 + d]);
+        g[2 * D + d] = 1.0 / (om * om);
+      } else {
+        g[D + d] = 0.0;
+        g[2 * D + d] = 0.0;
+      }
+    }
+    g[3 * D] = 2.0 * h[D] + sum_lnell;
+    g[3 * D + 1] = meanfun > 0 ? h[mo] : 0.0;
+  }
+}
+
 // L comes either from the host (L) or, for a posterior just computed on the device (vbmc_gp_post), from device memory:
 // dL_chol holds the Cholesky factors (all samples), dL_inv the solves L\(L'\I) of the low-noise samples (negated here).
 static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int Ncov, int Nnoise,
@@ -183,31 +210,8 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
     gp->sn2_eff[s] = 1.0 / (sW1[s] * sW1[s]);  // gplogjoint.m:160
     gp->Lchol[s] = Lchol ? Lchol[s] : 1;
   }
-  // derived per-sample constants (gplogjoint.m:99-121)
   std::vector<double> gpc((size_t)S * GPC_STRIDE(D));
-  for (int s = 0; s < S; ++s) {
-    const double* h = hyp + (size_t)s * Nhyp;
-    double* g = gpc.data() + (size_t)s * GPC_STRIDE(D);
-    double sum_lnell = 0.0;
-    for (int d = 0; d < D; ++d) {
-      double ell = std::exp(h[d]);
-      g[d] = ell * ell;
-      sum_lnell += h[d];
-    }
-    const int mo = Ncov + Nnoise;
-    for (int d = 0; d < D; ++d) {
-      if (meanfun == 4) {
-        g[D + d] = h[mo + 1 + d];
-        double om = std::exp(h[mo + D + 1 + d]);
-        g[2 * D + d] = 1.0 / (om * om);
-      } else {
-        g[D + d] = 0.0;
-        g[2 * D + d] = 0.0;
-      }
-    }
-    g[3 * D] = 2.0 * h[D] + sum_lnell;
-    g[3 * D + 1] = meanfun > 0 ? h[mo] : 0.0;
-  }
+  gp_constants(D, S, Nhyp, Ncov, Nnoise, meanfun, hyp, gpc.data());
   // device blocks of a surrogate come from the context's pool (hipMalloc / hipFree cost ~0.1 ms each and serialise the
   // device: an append or a re-upload per acquired point would pay for a dozen of them)
   gp->pooled = true;
@@ -277,7 +281,11 @@ extern "C" void vbmc_gp_free(vbmc_ctx* ctx, vbmc_gp* gp) {
   if (!gp) return;
   if (ctx && gp->pooled) ctx_drain_slots(ctx);   // a pass in flight on a slot stream may still read the blocks the pool is about to hand out again
   // pooled blocks go back to the context's pool; without a live context (destroyed first) they are already gone with it
-  void* blocks[] = {gp->X, gp->alpha, gp->L, gp->gpc, gp->hyp, gp->d_sn2, gp->d_lchol, gp->d_mult, gp->d_finv, gp->d_tinv, gp->d_meanX};
+  // in_views: X, hyp, gpc, d_sn2, d_lchol, d_mult, d_meanX are windows into blk_in (a posterior assembled by vbmc_gp_post from
+  // its own packed upload, abi_gp.hip)
+  void* blocks[] = {gp->in_views ? nullptr : gp->X, gp->alpha, gp->L, gp->in_views ? nullptr : gp->gpc, gp->in_views ? nullptr : gp->hyp,
+                    gp->in_views ? nullptr : gp->d_sn2, gp->in_views ? nullptr : gp->d_lchol, gp->in_views ? nullptr : gp->d_mult,
+                    gp->d_finv, gp->d_tinv, gp->in_views ? nullptr : gp->d_meanX, gp->blk_in};
   for (void* b : blocks) {
     if (!b) continue;
     if (gp->pooled) { if (ctx) pool_put(ctx, b); }

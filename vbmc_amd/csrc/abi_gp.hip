@@ -1,6 +1,7 @@
 // C-ABI entry points for the gplite GP surrogate: vbmc_sq_dist, vbmc_gp_post, vbmc_gp_pred
 // (include/vbmc_hip.h).  Host side: O(N) hyper-parameter transforms, the Cholesky jitter-retry
 // loop (gplite_core.m:77-80,91-94), launches, D2H of the posterior.
+#include <functional>
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -93,14 +94,25 @@ struct GpFactor {
   bool any_inv = false;
   size_t tlds = 0;
   double* pin_out = nullptr;
-  int* pin_pf = nullptr;        // optimistic first try: the Cholesky's failure flags land here (pinned) and are read at the caller's own synchronisation
+  // optimistic first try: the Cholesky's failure indices (as doubles, behind alpha on the device: d_pfd) are NOT waited for;
+  // the caller copies them out with its own results, points h_pfd at them and looks after its own synchronisation (gp_factor_ok)
+  double* d_pfd = nullptr;
+  const double* h_pfd = nullptr;
   bool unchecked = false;
   bool alpha_event = false;    // alpha is being computed on the second stream: wait for ctx->ev_join before reading it
-  TmpBuf dIn, dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dones, dninv, dal, dfinv;   // dIn: the packed inputs (dX .. dninv are windows)
+  // caller's extra inputs riding in the packed upload (set before gp_factorize): extra_in doubles, filled by fill_extra
+  size_t extra_in = 0;
+  std::function<void(double*)> fill_extra;
+  TmpBuf dIn, dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dz, dones, dninv, dal, dfinv, dExtra;   // dIn: the packed inputs (dX .. dninv, dExtra are windows)
 };
 
 // fail_is_error: vbmc_gp_post refuses a matrix that is still not positive definite after the retries;
 // vbmc_gp_nlz marks that hyper-parameter vector as failed (NaN result, gplite_train.m:542-546) and goes on.
+//
+// Device schedule (round 5): ONE upload of the packed inputs; k_gp_scale (scaled inputs, row norms AND the residual y - m);
+// k_gp_build; k_chol2, which also leaves the inverses of the diagonal blocks (the triangular solves' Finv) and the forward
+// solve z = R' \ (y - m) behind; the backward half of alpha's solve with the 1 / sl scaling folded in.  (Round 4: the
+// residual, the block inverses, the two-sided solve and the scaling were four more launches after the factorisation.)
 vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
                          const double* X, const double* y, const double* s2, const double* hyp, bool fail_is_error,
                          GpFactor& f, size_t pin_extra_doubles = 0, bool optimistic = false, bool alpha_aside = false) {
@@ -142,16 +154,16 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     scal[s * 4 + 3] = lch[s] ? scal[s * 4 + 0] : 1.0;   // sl = sn2div * sn2_mult (:82,:96); rewritten below if a retry inflates the noise
   }
   TmpBuf &dX = f.dX, &dy = f.dy, &dhyp = f.dhyp, &dXc = f.dXc, &daa = f.daa, &dsn2 = f.dsn2, &dscal = f.dscal, &dact = f.dact,
-         &dA = f.dA, &dpf = f.dpf, &dr = f.dr, &dones = f.dones, &dninv = f.dninv;
-  // Inputs: ONE pinned block [X | y | hyp | sn2 | scal | ones needinv active], one asynchronous copy.  (Round 2 issued eight
-  // hipMemcpyAsync from pageable memory -- each of them staged and waited for by the runtime, ~100 us of host time in a call whose
-  // kernels take 0.36 ms.)
+         &dA = f.dA, &dpf = f.dpf, &dr = f.dr, &dz = f.dz, &dones = f.dones, &dninv = f.dninv;
+  // Inputs: ONE pinned block [X | y | hyp | sn2 | scal | ones needinv active | caller's extras], one asynchronous copy.  (Round 2
+  // issued eight hipMemcpyAsync from pageable memory -- each of them staged and waited for by the runtime, ~100 us of host time
+  // in a call whose kernels take 0.36 ms.)
   const size_t nX = (size_t)N * D, nH = (size_t)Nhyp * S, nS = (size_t)S * N, nC = (size_t)S * 4;
-  const size_t in_doubles = nX + N + nH + nS + nC + (3 * (size_t)S + 7) / 8;
-  { vbmc_status s_ = ensure_pin(ctx, (in_doubles + pin_extra_doubles) * 8 + (size_t)S * sizeof(int) + 8); if (s_) return s_; }
+  const size_t nB = (3 * (size_t)S + 7) / 8;
+  const size_t in_doubles = nX + N + nH + nS + nC + nB + f.extra_in;
+  { vbmc_status s_ = ensure_pin(ctx, (in_doubles + pin_extra_doubles) * 8 + 8); if (s_) return s_; }
   double* hin = (double*)ctx->pin;
   f.pin_out = hin + in_doubles;      // the caller's results come back through the same pinned block (pin_extra_doubles of it)
-  f.pin_pf = (int*)(hin + in_doubles + pin_extra_doubles);
   memcpy(hin, X, nX * 8);
   memcpy(hin + nX, y, (size_t)N * 8);
   memcpy(hin + nX + N, hyp, nH * 8);
@@ -159,6 +171,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   memcpy(hin + nX + N + nH + nS, scal.data(), nC * 8);
   unsigned char* hb = (unsigned char*)(hin + nX + N + nH + nS + nC);
   memcpy(hb, ones.data(), S); memcpy(hb + S, needinv.data(), S); memcpy(hb + 2 * S, active.data(), S);
+  if (f.extra_in && f.fill_extra) f.fill_extra(hin + nX + N + nH + nS + nC + nB);
   TmpBuf& dIn = f.dIn;
   HIP_TRY(ctx, dIn.alloc(ctx, in_doubles * 8));
   {
@@ -166,19 +179,27 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     dX.view(din); dy.view(din + nX); dhyp.view(din + nX + N); dsn2.view(din + nX + N + nH); dscal.view(din + nX + N + nH + nS);
     unsigned char* db = (unsigned char*)(din + nX + N + nH + nS + nC);
     dones.view(db); dninv.view(db + S); dact.view(db + 2 * S);
+    f.dExtra.view(din + nX + N + nH + nS + nC + nB);
   }
+  TmpBuf &dal = f.dal, &dfinv = f.dfinv;
   HIP_TRY(ctx, dXc.alloc(ctx, (size_t)S * N * D * 8));
   HIP_TRY(ctx, daa.alloc(ctx, (size_t)S * N * 8));
   HIP_TRY(ctx, dA.alloc(ctx, (size_t)S * N * N * 8));
   HIP_TRY(ctx, dpf.alloc(ctx, (size_t)S * sizeof(int)));
   HIP_TRY(ctx, dr.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dz.alloc(ctx, (size_t)S * N * 8));
+  HIP_TRY(ctx, dal.alloc(ctx, ((size_t)S * N + S) * 8));       // alpha, and behind it the failure indices as doubles
+  HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
+  f.d_pfd = dal.as<double>() + (size_t)S * N;
+  const int moff = Ncov + Nnoise;
   HIP_TRY(ctx, hipMemcpyAsync(dIn.p, hin, in_doubles * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>());
+  hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
+                     moff, meanfun, dy.as<double>(), dr.as<double>());
 
   // jittered Cholesky: up to 10 tries, noise multiplier x10 per failure (gplite_core.m:77-80,91-94)
-  // the 16 x N panel of the Cholesky lives in LDS up to N = 1200, in a global scratch block beyond (chol_mfma.h)
+  // the 16 x N panel of the Cholesky lives in LDS up to N = 1120, in a global scratch block beyond (chol_mfma.h)
   TmpBuf dPg;
-  if (chol2_needs_gpanel(N)) HIP_TRY(ctx, dPg.alloc(ctx, (size_t)S * 16 * (size_t)(((N + 15) >> 4) << 4) * 8));
+  if (chol2_needs_gpanel(N, true)) HIP_TRY(ctx, dPg.alloc(ctx, (size_t)S * 16 * (size_t)(((N + 15) >> 4) << 4) * 8));
   std::vector<int> pf(S);
   bool pending = true, retried = false;
   for (int iter = 0; iter < 10 && pending; ++iter) {
@@ -189,13 +210,14 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     DISPATCH_GPDT(D, hipLaunchKernelGGL((k_gp_build<DT>), dim3((N + GPB_T - 1) / GPB_T, (N + GPB_T - 1) / GPB_T, S), dim3(256), 0, st, N, D,
                                         Nhyp, dhyp.as<double>(), dXc.as<double>(), daa.as<double>(), dsn2.as<double>(), dscal.as<double>(),
                                         dact.as<unsigned char>(), dA.as<double>()));
-    HIP_TRY(ctx, chol2_launch(N, S, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>(), dPg.p ? dPg.as<double>() : nullptr, st));
+    HIP_TRY(ctx, chol2_launch(N, S, dA.as<double>(), dpf.as<int>(), dact.as<unsigned char>(), dPg.p ? dPg.as<double>() : nullptr, st,
+                              dfinv.as<double>(), f.d_pfd, dr.as<double>(), dz.as<double>()));
     if (optimistic) {
       // Almost every factorisation succeeds at the first try (the retries exist for hyper-parameter vectors at the edge of the
-      // prior).  The flags are copied to pinned memory and NOT waited for: everything downstream is enqueued as if the try had
-      // succeeded, the caller looks at the flags at its own final synchronisation (gp_factor_ok) and, if one is set, repeats the
-      // call with the retry loop -- one host round trip (25 us of an otherwise idle device) less per call
-      HIP_TRY(ctx, hipMemcpyAsync(f.pin_pf, dpf.p, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, st));
+      // prior).  The flags are NOT waited for: everything downstream is enqueued as if the try had succeeded, they travel with
+      // the caller's results (d_pfd -> h_pfd) and the caller looks at them at its own final synchronisation (gp_factor_ok); if
+      // one is set it repeats the call with the retry loop -- one host round trip (25 us of an otherwise idle device) and one
+      // copy less per call
       f.unchecked = true;
       std::fill(active.begin(), active.end(), 0);
       pending = false;
@@ -221,16 +243,11 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     HIP_TRY(ctx, hipMemcpyAsync(dscal.p, scal.data(), (size_t)S * 4 * 8, hipMemcpyHostToDevice, st));
   }
 
-  // alpha = L\(L'\(y-m)) / sl  (:102).  alpha_aside (vbmc_gp_nlz with a gradient, few matrices): the solve runs on the context's
-  // second stream while the caller inverts the factor on the first -- two latency-bound kernels of 56 and 115 us that do not
-  // depend on each other; the caller waits for ctx->ev_join before it reads alpha.
-  const int moff = Ncov + Nnoise;
+  // alpha = L\(L'\(y-m)) / sl  (:102): the forward half came out of the factorisation (dz).  alpha_aside (vbmc_gp_nlz with a
+  // gradient, few matrices): the backward half runs on the context's second stream while the caller inverts the factor on the
+  // first -- two latency-bound kernels that do not depend on each other; the caller waits for ctx->ev_join before it reads alpha.
   f.cw = trsm_cw_for(N);
   f.tlds = TRSM_LDS_BYTES_CW(N, f.cw);
-  TmpBuf &dal = f.dal, &dfinv = f.dfinv;
-  HIP_TRY(ctx, dal.alloc(ctx, (size_t)S * N * 8));
-  HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
-  hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N), S), dim3(64), 0, st, N, dA.as<double>(), dones.as<unsigned char>(), dfinv.as<double>());
   hipStream_t sa = st;
   f.alpha_event = false;
   if (alpha_aside && ctx->ev_fork && ctx->ev_join && ctx_aux(ctx)) {
@@ -239,15 +256,12 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     sa = ctx->aux;
     f.alpha_event = true;
   }
-  hipLaunchKernelGGL(k_gp_resid, dim3(4, S), dim3(256), 0, sa, N, D, Nhyp, moff, meanfun, dX.as<double>(), dy.as<double>(),
-                     dhyp.as<double>(), dr.as<double>());
   if (N <= ASOLVE1_THREADS)
     hipLaunchKernelGGL(k_alpha_solve1, dim3(S), dim3(ASOLVE1_THREADS), 0, sa, N, dA.as<double>(), dfinv.as<double>(), dones.as<unsigned char>(),
-                       dr.as<double>(), dal.as<double>());
+                       dz.as<double>(), dal.as<double>(), 1, dscal.as<double>());
   else
     hipLaunchKernelGGL(k_alpha_solve, dim3(S), dim3(ASOLVE_THREADS), (size_t)((TRSM_NBLK(N) << 4) + 16) * sizeof(double), sa, N, dA.as<double>(),
-                       dfinv.as<double>(), dones.as<unsigned char>(), dr.as<double>(), dal.as<double>());
-  hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)(((size_t)S * N + 255) / 256)), dim3(256), 0, sa, (size_t)S * N, N, dscal.as<double>(), 3, dal.as<double>());
+                       dfinv.as<double>(), dones.as<unsigned char>(), dz.as<double>(), dal.as<double>(), 1, dscal.as<double>());
   if (f.alpha_event) HIP_TRY(ctx, hipEventRecord(ctx->ev_join, sa));
   HIP_TRY(ctx, hipGetLastError());
   return VBMC_OK;
@@ -256,8 +270,9 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
 // after the caller's synchronisation: did the optimistic first try succeed for every matrix?
 bool gp_factor_ok(const GpFactor& f, int S) {
   if (!f.unchecked) return true;
+  if (!f.h_pfd) return false;            // nobody brought the flags back: take the checked path
   for (int s = 0; s < S; ++s)
-    if (f.pin_pf[s] > 0) return false;
+    if (f.h_pfd[s] > 0.0) return false;
   return true;
 }
 
@@ -284,17 +299,40 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   if (!ctx) return VBMC_ERR_INVALID;
   if (gp_out) *gp_out = nullptr;
   GpFactor f;
-  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_post", N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, true, f, (size_t)S * N, optimistic); if (s_ != VBMC_OK) return s_; }
+  // Device-resident posterior, first (optimistic) try: what a vbmc_gp needs beyond the factorisation's own buffers -- the
+  // per-sample constants of the log joint, sn2_eff, the column means of X, the noise multipliers -- rides in the packed upload
+  // (they depend on the inputs only, the multipliers being 1 unless a retry inflates the noise), and the surrogate ADOPTS the
+  // device blocks of the factorisation: no second round of uploads, no copy of the S N x N factors, one synchronisation per call.
+  const bool resident = gp_out != nullptr && optimistic && D <= 32 && D > 0 && S > 0 && N > 0;
+  const size_t nG = resident ? (size_t)S * GPC_STRIDE(D) : 0;
+  std::vector<double> sW1(S > 0 ? S : 0), mult(S > 0 ? S : 0, 1.0);
+  if (resident) {
+    f.extra_in = nG + (size_t)S + (size_t)D + (size_t)S;            // gpc | sn2_eff | meanX | mult
+    f.fill_extra = [&](double* e) {
+      gp_constants(D, S, Nhyp, D + 1, noise_nhyp(noisefun), meanfun, hyp, e);
+      for (int s = 0; s < S; ++s) {
+        const double w = 1.0 / std::sqrt(f.sn2min[s]);               // post.sW(1) with sn2_mult = 1  (:281)
+        e[nG + s] = 1.0 / (w * w);                                   // gplogjoint.m:160
+        e[nG + S + D + s] = 1.0;
+      }
+      for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        for (int n = 0; n < N; ++n) acc += X[n + (size_t)N * d];
+        e[nG + S + d] = acc / N;
+      }
+    };
+  }
+  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_post", N, D, S, Nhyp, meanfun, noisefun, X, y, s2, hyp, true, f, (size_t)S * N + S, optimistic); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int Ncov = f.Ncov, Nnoise = f.Nnoise;
   const bool any_inv = f.any_inv;
-  const size_t tlds = f.tlds;
   std::vector<double>&scal = f.scal, &sn2min = f.sn2min;
   std::vector<unsigned char>& lch = f.lch;
   TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dXi;
 
-  double* alh = f.pin_out;   // pinned: the copy is asynchronous, one synchronisation below
-  HIP_TRY(ctx, hipMemcpyAsync(alh, dal.p, (size_t)S * N * 8, hipMemcpyDeviceToHost, st));
+  double* alh = f.pin_out;   // pinned: the copy is asynchronous, one synchronisation below; the failure indices ride behind alpha
+  HIP_TRY(ctx, hipMemcpyAsync(alh, dal.p, ((size_t)S * N + S) * 8, hipMemcpyDeviceToHost, st));
+  f.h_pfd = alh + (size_t)S * N;
   const bool wantL = L != nullptr || gp_out != nullptr;
   if (wantL && any_inv) {
     // pL = -L\(L'\eye(N)) for low-noise samples (:98); the sign is applied where the matrix is consumed
@@ -321,7 +359,6 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
     for (int s = 0; s < S; ++s)
       if (!lch[s]) for (size_t i = 0; i < (size_t)N * N; ++i) L[(size_t)s * N * N + i] = -L[(size_t)s * N * N + i];
 
-  std::vector<double> sW1(S), mult(S);
   for (int s = 0; s < S; ++s) {
     mult[s] = scal[s * 4 + 1];
     sW1[s] = 1.0 / std::sqrt(sn2min[s] * mult[s]);  // post.sW = ones(N,1)./sqrt(min(sn2)*sn2_mult)  (:281)
@@ -330,7 +367,25 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   if (sW) for (int s = 0; s < S; ++s) for (int n = 0; n < N; ++n) sW[(size_t)s * N + n] = sW1[s];
   if (sn2_mult) memcpy(sn2_mult, mult.data(), S * 8);
   if (Lchol) memcpy(Lchol, lch.data(), S);
-  if (gp_out) {
+  if (gp_out && resident && !any_inv) {
+    // adopt: the surrogate's device blocks ARE the factorisation's (every sample on the Cholesky branch: d_lchol = the ones)
+    vbmc_gp* gp = new vbmc_gp();
+    gp->N = N; gp->D = D; gp->S = S; gp->Nhyp = Nhyp; gp->Ncov = Ncov; gp->Nnoise = Nnoise; gp->meanfun = meanfun;
+    gp->hyp_host.assign(hyp, hyp + (size_t)Nhyp * S);
+    gp->sn2_eff.resize(S); gp->Lchol.assign(S, 1);
+    for (int s = 0; s < S; ++s) gp->sn2_eff[s] = 1.0 / (sW1[s] * sW1[s]);
+    gp->pooled = true; gp->in_views = true; gp->hasL = true;
+    gp->blk_in = f.dIn.p; f.dIn.p = nullptr;
+    gp->X = f.dX.as<double>(); gp->hyp = f.dhyp.as<double>(); gp->d_lchol = f.dones.as<unsigned char>();
+    double* e = f.dExtra.as<double>();
+    gp->gpc = e; gp->d_sn2 = e + nG; gp->d_meanX = e + nG + S; gp->d_mult = e + nG + S + D;
+    gp->alpha = dal.as<double>(); dal.p = nullptr;
+    gp->L = dA.as<double>(); dA.p = nullptr;
+    gp->d_finv = dfinv.as<double>(); dfinv.p = nullptr;
+    for (int i = 0; i < 3; ++i) gp->noisefun[i] = noisefun[i];
+    gp->has_noise = true;
+    *gp_out = gp;
+  } else if (gp_out) {
     // the device-resident posterior is assembled from the device buffers (no round trip of the S N x N matrices)
     vbmc_status st2 = gp_upload_impl(ctx, N, D, S, Nhyp, Ncov, Nnoise, meanfun, X, hyp, alh, nullptr, dA.as<double>(),
                                      any_inv ? dXi.as<double>() : nullptr, sW1.data(), lch.data(), gp_out);
@@ -391,57 +446,56 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
     }
   }
   GpFactor f;
-  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f, (size_t)B * (1 + Nhyp) + (compute_grad ? (size_t)B * std::max(noise_nhyp(noisefun), 1) * N : 0), optimistic, compute_grad && B <= 16); if (s_ != VBMC_OK) return s_; }
+  const int NnoiseH = noise_nhyp(noisefun);
+  // the noise-model derivatives (host, O(B Nnoise N)) ride in the packed upload
+  const size_t nds = compute_grad ? (size_t)B * std::max(NnoiseH, 1) * N : 0;
+  if (compute_grad && N > 0 && B > 0 && hyp && y) {
+    f.extra_in = nds;
+    f.fill_extra = [&](double* e) {
+      for (int b = 0; b < B; ++b)
+        noise_grad(noisefun, hyp + (size_t)b * Nhyp + D + 1, N, y, s2, NnoiseH, e + (size_t)b * NnoiseH * N);
+    };
+  }
+  // results: [nlZ B | failure indices B | dnlZ B x Nhyp], one block on the device, one copy back
+  const size_t nout = (size_t)B * (2 + (compute_grad ? Nhyp : 0));
+  { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f, nout, optimistic, compute_grad && B <= 16); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int Nnoise = f.Nnoise, Nmean = f.Nmean, moff = f.Ncov + f.Nnoise;
-  TmpBuf dnlz, dKi, dds, dpart, dg, dTT;
-  HIP_TRY(ctx, dnlz.alloc(ctx, (size_t)B * 8));
-  if (f.alpha_event) {
-    // the inverse of the factor first (it does not need alpha), then join the second stream
+  TmpBuf dout, dKi, dpart, dTT;
+  HIP_TRY(ctx, dout.alloc(ctx, nout * 8));
+  double* dnlz = dout.as<double>();
+  double* dg = dnlz + 2 * (size_t)B;
+  if (compute_grad) {
+    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
+    // identity (k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores (k_syrk_tt);
+    // only the upper triangle is formed -- the part k_nlz_grad reads.  Neither needs alpha: with alpha on the second stream
+    // (f.alpha_event) they run beside its solve, and the streams join here.
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
     HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
     HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
     hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
                        dKi.as<double>());
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   }
+  if (f.alpha_event) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
-                     f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz.as<double>());
+                     f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz, (const double*)f.d_pfd);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz.p, (size_t)B * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
   if (compute_grad) {
-    // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
-    // identity (k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores (k_syrk_tt);
-    // only the upper triangle is formed -- the part k_nlz_grad reads
-    if (!f.alpha_event) {
-      HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
-      HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
-      HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
-      hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
-                         dKi.as<double>());
-    }
-    // the noise-model derivatives (host, O(B Nnoise N)) go up through the pinned block as well: an asynchronous copy
-    const size_t nds = (size_t)B * std::max(Nnoise, 1) * N;
-    double* dsn2h = f.pin_out + (size_t)B * (1 + Nhyp);
-    for (int b = 0; b < B; ++b)
-      noise_grad(noisefun, hyp + (size_t)b * Nhyp + f.Ncov, N, y, s2, Nnoise, dsn2h + (size_t)b * Nnoise * N);
-    HIP_TRY(ctx, dds.alloc(ctx, nds * 8));
-    HIP_TRY(ctx, hipMemcpyAsync(dds.p, dsn2h, nds * 8, hipMemcpyHostToDevice, st));
     const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
     HIP_TRY(ctx, dpart.alloc(ctx, (size_t)B * ntile * P * 8));
-    HIP_TRY(ctx, dg.alloc(ctx, (size_t)B * Nhyp * 8));
     DISPATCH_GPDT(D, hipLaunchKernelGGL((k_nlz_grad<DT>), dim3(nt1, nt1, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(),
                                         f.dXc.as<double>(), f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(),
-                                        dds.as<double>(), dpart.as<double>()));
+                                        f.dExtra.as<double>(), dpart.as<double>()));
     hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
-                       f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg.as<double>());
+                       f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(f.pin_out + B, dg.p, (size_t)B * Nhyp * 8, hipMemcpyDeviceToHost, st));
   }
+  HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz, nout * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
+  f.h_pfd = f.pin_out + B;
   HIP_TRY(ctx, hipStreamSynchronize(st));
   if (!gp_factor_ok(f, B)) return VBMC_INTERNAL_RETRY;
   memcpy(nlZ, f.pin_out, (size_t)B * 8);
-  if (compute_grad) memcpy(dnlZ, f.pin_out + B, (size_t)B * Nhyp * 8);
+  if (compute_grad) memcpy(dnlZ, f.pin_out + 2 * (size_t)B, (size_t)B * Nhyp * 8);
   // a matrix still not positive definite after the retries: MATLAB errors downstream and the caller maps it to NaN
   // (gplite_train.m:542-546)
   const double qnan = std::numeric_limits<double>::quiet_NaN();

@@ -156,7 +156,9 @@ __device__ long long g_chol_la[8];
 
 template <bool GP, bool TWO>
 __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict__ Aall, int* __restrict__ pfail,
-                                                       const unsigned char* __restrict__ active, double* __restrict__ Pg) {
+                                                       const unsigned char* __restrict__ active, double* __restrict__ Pg,
+                                                       double* __restrict__ Finv, double* __restrict__ pfd,
+                                                       const double* __restrict__ rin, double* __restrict__ zout) {
   extern __shared__ __attribute__((aligned(32))) double lds_c2[];   // 32-byte vectors of the panel
   double* lds = lds_c2;
   const int s = blockIdx.x;
@@ -171,6 +173,45 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
   double* scr = lds + 4 * 16 * 17;        // 64 doubles (chol_diag_tile3)
   double* Pl = lds + CH2_LDS_FIXED;       // 16 x Np panel rows (LDS variant); TWO: a second panel behind it
   double* Pgl = GP ? Pg + (size_t)s * 16 * Np : nullptr;
+  // Right-hand side riding along (rin != null): z = R' \ r as a by-product -- r is one more column of the matrix: its row block
+  // takes the panel operation (z_b = inv(Rkk') r_b, with the same refinement step), the rest of it the trailing update
+  // (r -= P' z_b).  The vector lives behind the panel(s) in LDS; alpha = R \ z is then half of the two-sided solve.
+  double* rv = Pl + (GP ? 0 : (TWO ? 32 : 16) * Np);    // Np doubles
+  __shared__ double zb[16], zres[16];
+  const bool RHS = rin != nullptr;
+  if (RHS) for (int i = tid; i < Np; i += CH2_THREADS) rv[i] = i < N ? rin[(size_t)s * N + i] : 0.0;
+  // z_b for the block at kb from the tile in buffer `c_` (16 lanes of one wave; four short chains per product)
+  auto rhs_block = [&](int kb_, int c_) {
+    if (lane < 16) {
+      const double* Ri_ = RiB + c_ * 16 * 17;
+      const double* Dg_ = DgB + c_ * 16 * 17;
+      const int t = lane;
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a4[c & 3] = fma(Ri_[c * 17 + t], rv[kb_ + c], a4[c & 3]);
+      double z = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      zb[t] = z;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // refinement: res_t = r_t - sum_{u <= t} R[u][t] z_u,  z += inv(Rkk') res
+      double r4[4] = {rv[kb_ + t], 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) r4[u & 3] = fma(-(u <= t ? Dg_[u * 17 + t] : 0.0), zb[u], r4[u & 3]);
+      __builtin_amdgcn_wave_barrier();
+      zres[t] = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double c4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 16; ++c) c4[c & 3] = fma(Ri_[c * 17 + t], zres[c], c4[c & 3]);
+      z += (c4[0] + c4[1]) + (c4[2] + c4[3]);
+      __builtin_amdgcn_wave_barrier();
+      zb[t] = z;
+      if (kb_ + t < N) zout[(size_t)s * N + kb_ + t] = z;
+    }
+  };
   static_assert(!(GP && TWO), "the two-panel scheme keeps both panels in LDS");
   __shared__ int s_fail;
   __shared__ double DiB[2][16];
@@ -201,6 +242,15 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       if (ii < nbt && jj < nbt) Ad[(size_t)ii + (size_t)N * jj] = (ii <= jj) ? Dg[ii * 17 + jj] : 0.0;
     }
   };
+  // Finv (optional): the inverse of every diagonal block goes out in the layout the triangular solves read (trsm_mfma.h
+  // k_diag_inv: Finv[blk][ii][c] = inv(R_bb')[ii][c], row-major 16 x 16, identity beyond N) -- the factorisation has it anyway
+  double* Fo = Finv ? Finv + (size_t)s * (Np >> 4) * 256 : nullptr;
+  auto store_finv = [&](int blk, const double* Ri_) {
+    if (Fo) {
+#pragma unroll
+      for (int e = lane; e < 256; e += 64) Fo[(size_t)blk * 256 + e] = Ri_[(e & 15) * 17 + (e >> 4)];
+    }
+  };
   if (wave == 0) {
     const int nb = min(16, N);
     double X[4];
@@ -208,6 +258,7 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     chol_diag_tile3(X, DgB, DiB[0], scr, nb, 0, lane, &s_fail);
     chol_tile_inverse(DgB, DiB[0], RiB, lane);
     store_diag(A, nb, DgB);
+    store_finv(0, RiB);
   }
   __syncthreads();
   int cur = 0;
@@ -226,6 +277,7 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     const int pbuf = TWO ? ((kb >> 4) & 1) : 0;
     if (tid == 0) CHOL_STAMP(0, kb >> 4);
     // ---- panel: tile tj of the row block (16 x 16, rows kb.., columns t0 + 16 tj..) times inv(Rkk')
+    if (RHS && wave == CH2_W - 1) rhs_block(kb, cur);     // the wave with the fewest panel tiles
     {
       double av[4], rv[4];
       const double* Dgc = DgB + cur * 16 * 17;
@@ -311,12 +363,26 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       chol_tile_inverse(Dn, DiB[cur ^ 1], RiB + (cur ^ 1) * 16 * 17, lane);
       CH2_LSTAMP(4);
       store_diag(At, nb2, Dn);
+      store_finv(t0 >> 4, RiB + (cur ^ 1) * 16 * 17);
       CH2_LSTAMP(5);
       if (lane == 0) CHOL_STAMP(2, kb >> 4);
     }
     // Wave 0 (look-ahead) is a long chain of dependent fp64 VALU operations, and an fp64 MFMA of another wave on the same SIMD
     // blocks its issue: where the look-ahead is the critical path (small updates, A steps) wave 4, which shares SIMD 0 with it,
     // stays out of the update; a large update hides the look-ahead anyway and wants all four matrix pipes.
+    if (RHS && wave > 0) {
+      // the rest of the vector takes this step's panel: r[t0 + col] -= sum_t P[t][col] z_b[t]
+      for (int col = tid - 64; col < ntr; col += CH2_THREADS - 64) {
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const d4v pv = ldP4(pbuf, g, col);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a4[g] = fma(pv[q], zb[4 * q + g], a4[g]);
+        }
+        rv[t0 + col] -= (a4[0] + a4[1]) + (a4[2] + a4[3]);
+      }
+    }
     const bool idle4 = CH2_IDLE4 && !((!TWO || pbuf == 1) && npair > 48);
     const int UW = CH2_W - (idle4 ? 2 : 1);                              // waves that update
     const int uslot = (idle4 && wave > 4) ? wave - 2 : wave - 1;         // their index 0 .. UW - 1
@@ -438,7 +504,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     __syncthreads();
     if (tid == 0) CHOL_STAMP(3, kb >> 4);
   }
-  if (tid == 0) pfail[s] = s_fail;
+  if (RHS && wave == 0 && !s_fail) rhs_block(((N - 1) >> 4) << 4, cur);   // the last row block has no panel phase
+  if (tid == 0) { pfail[s] = s_fail; if (pfd) pfd[s] = (double)s_fail; }
   if (s_fail) return;
   // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
   for (int j = wave; j < N; j += CH2_W)
@@ -446,26 +513,41 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
 }
 
 // Launch on stream st: S matrices of order N in dA (N x N x S), pfail S ints, active S flags; Pg = S x 16 x Np doubles of
-// scratch, needed only when chol2_needs_gpanel(N).  Two panels in LDS up to N = 592, one up to N = 1200, global panel beyond.
-#define CHOL2_LDS_BYTES2(N) ((size_t)(CH2_LDS_FIXED + 32 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
-static inline bool chol2_needs_gpanel(int N) { return CHOL2_LDS_BYTES(N) > 159 * 1024; }   // + ~0.3 KB of static LDS
-static inline hipError_t chol2_launch(int N, int S, double* dA, int* dpf, const unsigned char* dact, double* dPg, hipStream_t st) {
-  if (chol2_needs_gpanel(N)) {
-    hipLaunchKernelGGL((k_chol2<true, false>), dim3(S), dim3(CH2_THREADS), (size_t)CH2_LDS_FIXED * sizeof(double), st, N, dA, dpf, dact, dPg);
-  } else if (CHOL2_LDS_BYTES2(N) > 159 * 1024) {
-    const size_t lds = CHOL2_LDS_BYTES(N);
+// scratch, needed only when chol2_needs_gpanel(N).  Two panels in LDS up to N = 592, one up to N = 1200, global panel beyond
+// (with a right-hand side riding along -- Np more doubles of LDS -- up to N = 576 / 1120).
+#define CHOL2_NP(N) ((size_t)((((N) + 15) >> 4) << 4))
+#define CHOL2_LDS_BYTES1(N, rhs) ((size_t)(CH2_LDS_FIXED + (16 + ((rhs) ? 1 : 0)) * CHOL2_NP(N)) * sizeof(double))
+#define CHOL2_LDS_BYTES2(N, rhs) ((size_t)(CH2_LDS_FIXED + (32 + ((rhs) ? 1 : 0)) * CHOL2_NP(N)) * sizeof(double))
+static inline bool chol2_needs_gpanel(int N, bool rhs = false) { return CHOL2_LDS_BYTES1(N, rhs) > 159 * 1024; }   // + ~0.5 KB of static LDS
+// dFinv (optional): S x nblk x 256 inverses of the diagonal blocks (what k_diag_inv would compute from the factor);
+// dpfd (optional): the failure indices once more as doubles (so that they can ride in a block of results);
+// drin / dzout (optional, both or neither): S x N right-hand sides r and the forward solves z = R' \ r
+static inline hipError_t chol2_launch(int N, int S, double* dA, int* dpf, const unsigned char* dact, double* dPg, hipStream_t st,
+                                      double* dFinv = nullptr, double* dpfd = nullptr, const double* drin = nullptr,
+                                      double* dzout = nullptr) {
+  const bool rhs = drin != nullptr;
+  if (rhs != (dzout != nullptr)) return hipErrorInvalidValue;
+  if (chol2_needs_gpanel(N, rhs)) {
+    const size_t lds = (size_t)(CH2_LDS_FIXED + (rhs ? CHOL2_NP(N) : 0)) * sizeof(double);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_chol2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_chol2<true, false>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, dPg, dFinv, dpfd, drin, dzout);
+  } else if (CHOL2_LDS_BYTES2(N, rhs) > 159 * 1024) {
+    const size_t lds = CHOL2_LDS_BYTES1(N, rhs);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)k_chol2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_chol2<false, false>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr);
+    hipLaunchKernelGGL((k_chol2<false, false>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr, dFinv, dpfd, drin, dzout);
   } else {
-    const size_t lds = CHOL2_LDS_BYTES2(N);
+    const size_t lds = CHOL2_LDS_BYTES2(N, rhs);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute((const void*)k_chol2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_chol2<false, true>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr);
+    hipLaunchKernelGGL((k_chol2<false, true>), dim3(S), dim3(CH2_THREADS), lds, st, N, dA, dpf, dact, (double*)nullptr, dFinv, dpfd, drin, dzout);
   }
   return hipGetLastError();
 }

@@ -160,6 +160,8 @@ struct vbmc_gp {
   double* d_finv = nullptr;   // S x nblk x 256: inverses of the 16 x 16 diagonal blocks of L' (trsm_mfma.h)
   mutable double* d_tinv = nullptr;  // S x N x N: inv(L') per Lchol sample (built on the first prediction, abi_gp.hip)
   double* d_meanX = nullptr;  // D  column means of X (sq_dist centring in gplite_pred)
+  void* blk_in = nullptr;     // in_views: the one pooled block X, hyp, gpc, d_sn2, d_lchol, d_mult and d_meanX are windows of
+  bool in_views = false;
   int noisefun[3] = {1, 0, 0};
   bool has_noise = false;
   std::vector<double> sn2_eff;

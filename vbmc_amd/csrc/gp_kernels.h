@@ -84,33 +84,61 @@ __device__ inline double gp_meanfun(int meanfun, int D, const double* hm, const 
 
 // A_s for the Cholesky.  Xc[s] holds the scaled, mean-centred inputs a = (X' ./ ell) - mean  (D x N),
 // aa[s][n] = |a_n|^2.  K = sf2 * exp(-max(aa_i + aa_j - 2 a_i.a_j, 0)/2)   (gplite_core.m:52-56)
+// rout != null: the residual r = y - m(X) of the same hyper-sample as well (gplite_core.m:58-65; what k_gp_resid computes).
 __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const double* __restrict__ X,
                                                   const double* __restrict__ hyp, double* __restrict__ Xc,
-                                                  double* __restrict__ aa) {
+                                                  double* __restrict__ aa, int moff, int meanfun, const double* __restrict__ y,
+                                                  double* __restrict__ rout) {
   const int s = blockIdx.y;
   const double* h = hyp + (size_t)s * Nhyp;
-  __shared__ double mean[32];
+  __shared__ double mean[32], sell[32], som[32];
   const int tid = threadIdx.x;
+  if (rout && meanfun == 4 && tid < D) som[tid] = exp(h[moff + D + 1 + tid]);
   {
-    // mean over n of X(n,d)/ell_d  (mean(a,2), sq_dist.m:36): 8 lanes per dimension, fixed-order butterfly
-    const int d = tid >> 3, sub = tid & 7;     // 256 threads = 32 dimensions x 8 lanes
-    double acc = 0.0;
-    if (d < D) {
+    // mean over n of X(n,d)/ell_d  (mean(a,2), sq_dist.m:36): one wave per dimension at a time, lanes along n with the loads
+    // of eight rows in flight, fixed-order butterfly.  (Round 5: the first version walked N / 8 dependent load + divide steps
+    // per lane and called exp(h[d]) for every element of the scaled copy -- 18 us of a 0.55 ms gplite_nlZ call.)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int d = wave; d < D; d += 4) {
       const double ell = exp(h[d]);
-      for (int n = sub; n < N; n += 8) acc += X[n + (size_t)N * d] / ell;
+      const double* xd = X + (size_t)N * d;
+      double acc = 0.0;
+      int n = lane;
+      for (; n + 7 * 64 < N; n += 8 * 64) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xd[n + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u] / ell;
+      }
+      for (; n < N; n += 64) acc += xd[n] / ell;
+      acc = wave_sum(acc);
+      if (lane == 0) { mean[d] = acc / N; sell[d] = ell; }
     }
-    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-    if (d < D && sub == 0) mean[d] = acc / N;
   }
   __syncthreads();
   for (int n = blockIdx.x * blockDim.x + tid; n < N; n += gridDim.x * blockDim.x) {
     double acc = 0.0;
     for (int d = 0; d < D; ++d) {
-      double v = X[n + (size_t)N * d] / exp(h[d]) - mean[d];
+      double v = X[n + (size_t)N * d] / sell[d] - mean[d];
       Xc[((size_t)s * N + n) * D + d] = v;
       acc = fma(v, v, acc);
     }
     aa[(size_t)s * N + n] = acc;
+    if (rout) {
+      const double* hm = h + moff;
+      double m = 0.0;
+      if (meanfun == 1) m = hm[0];
+      else if (meanfun == 4) {
+        double z2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double t = (X[n + (size_t)N * d] - hm[1 + d]) / som[d];
+          z2 = fma(t, t, z2);
+        }
+        m = hm[0] - 0.5 * z2;            // gplite_meanfun.m:425-431
+      }
+      rout[(size_t)s * N + n] = y[n] - m;
+    }
   }
 }
 
@@ -197,9 +225,10 @@ __device__ __forceinline__ double chol_readlane(double v, int l) {
 // (lanes along the long dimension, fixed-order butterfly), then wave 0 applies the precomputed inverse of the diagonal
 // block (k_diag_inv).  ~2 us per step instead of ~5 us for the 16-column MFMA slab solve with 15 zero columns.
 #define ASOLVE_THREADS 1024
+// skip_fwd != 0: Zin already holds R' \ z (the factorisation solved it on the way, chol_mfma.h): backward half only.
 __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                                 const unsigned char* __restrict__ on, const double* __restrict__ Zin,
-                                                                double* __restrict__ Xo) {
+                                                                double* __restrict__ Xo, int skip_fwd, const double* __restrict__ scal) {
   extern __shared__ double lds[];   // Np + 16
   const int s = blockIdx.x;
   if (!on[s]) return;
@@ -212,7 +241,7 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
   for (int i = tid; i < Np; i += ASOLVE_THREADS) v[i] = i < N ? Zin[(size_t)s * N + i] : 0.0;
   __syncthreads();
   // ---- forward: R' v = z
-  for (int bi = 0; bi < nblk; ++bi) {
+  for (int bi = skip_fwd ? nblk : 0; bi < nblk; ++bi) {
     const int b0 = bi << 4, c = b0 + wave;
     double dot = 0.0;
     if (c < N)
@@ -245,7 +274,8 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
     }
     __syncthreads();
   }
-  for (int i = tid; i < N; i += ASOLVE_THREADS) Xo[(size_t)s * N + i] = v[i];
+  const double sl = scal ? scal[s * 4 + 3] : 1.0;     // alpha = x / sl (gplite_core.m:102); no divisor, no division
+  for (int i = tid; i < N; i += ASOLVE_THREADS) Xo[(size_t)s * N + i] = scal ? v[i] / sl : v[i];
 }
 
 // The same solve for N <= ASOLVE1_THREADS, right-looking: thread e owns element e of the vector in a register.  Per 16-row block step the
@@ -257,7 +287,7 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
 #define ASOLVE1_THREADS 512
 __global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                                  const unsigned char* __restrict__ on, const double* __restrict__ Zin,
-                                                                 double* __restrict__ Xo) {
+                                                                 double* __restrict__ Xo, int skip_fwd, const double* __restrict__ scal) {
   __shared__ double xb[2][16], tb[16];
   const int s = blockIdx.x;
   if (!on[s]) return;
@@ -290,12 +320,14 @@ __global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const d
       for (int c = 0; c < 16; ++c) fi[c] = Fi[(size_t)(b + 1) * 256 + k * 16 + c];      // row k of (R_bb')^{-1}
     }
   };
+  if (!skip_fwd) {
   if (myblk == 0) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) fi[c] = Fi[k * 16 + c];
   }
   fetch_fwd(0);
-  for (int b = 0; b < nblk; ++b) {
+  }
+  for (int b = skip_fwd ? nblk : 0; b < nblk; ++b) {
     if (myblk == b) {                     // 16 lanes of one wave
       tb[k] = z;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -354,7 +386,7 @@ __global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const d
     z -= (p4[0] + p4[1]) + (p4[2] + p4[3]);
     fetch_bwd(b - 1);
   }
-  if (e < N) Xo[(size_t)s * N + e] = z;
+  if (e < N) Xo[(size_t)s * N + e] = scal ? z / scal[s * 4 + 3] : z;
 }
 
 // [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1, 1) (gplite_post.m:189) from the solves the append needs anyway:
@@ -791,9 +823,10 @@ __global__ void __launch_bounds__(256) k_nlz_value(int N, int D, int Nhyp, int m
                                                    const double* __restrict__ X, const double* __restrict__ y,
                                                    const double* __restrict__ hyp, const double* __restrict__ A,
                                                    const double* __restrict__ alpha, const double* __restrict__ scal,
-                                                   double* __restrict__ nlz) {
+                                                   double* __restrict__ nlz, const double* __restrict__ pfd) {
   __shared__ double red[256];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (pfd && tid == 0) nlz[gridDim.x + b] = pfd[b];     // the factorisation's failure index rides behind the values
   const double* hm = hyp + (size_t)b * Nhyp + moff;
   const double* Ab = A + (size_t)b * N * N;
   double quad = 0.0, ld = 0.0;
@@ -928,7 +961,13 @@ __global__ void __launch_bounds__(256) k_nlz_final(int N, int D, int Nhyp, int N
   double* g = dnlz + (size_t)b * Nhyp;
   if (tid < P) {
     double t = 0.0;
-    for (int jt = 0; jt < ntile; ++jt) t += part[((size_t)b * ntile + jt) * P + tid];
+    for (int jt = 0; jt < ntile; jt += 8) {          // tile order, eight loads in flight
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = jt + u < ntile ? part[((size_t)b * ntile + jt + u) * P + tid] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
     if (tid < D) g[tid] = t / 2.0;                 // sum(sum(Q.*K_temp))/2
     else if (tid == D) g[D] = t;                   // sum(sum(Q.*(2*K_mat)))/2
     else g[tid] = 0.5 * mult * t;                  // 0.5*sn2_mult*sum(dsn2(:,i).*dgQ)
