@@ -77,11 +77,13 @@ def test_nlz_batch_matches_oracle(va, cfg):
     assert f1 == nlZ[2] and np.array_equal(g1, dnlZ[:, 2])
 
 
-@pytest.mark.parametrize("N,D", [(16, 2), (17, 3), (48, 13), (81, 20), (70, 32), (1080, 6)])
+@pytest.mark.parametrize("N,D", [(16, 2), (17, 3), (48, 13), (81, 20), (70, 32), (1080, 6), (520, 5), (1001, 4), (1024, 3), (1030, 3)])
 def test_nlz_inverse_kernel_shapes(va, N, D):
     """Kinv = L\\(L'\\eye(N)) (gplite_core.m:240) is formed as T'T, T = inv(L') (k_tri_inverse + k_syrk_tt on 64 x 64 tiles):
     a single 16-block (N <= 16), N not a multiple of the tile sizes, D padded to the next kernel instantiation
-    (13 -> 16, 20 -> 24, 32), and N = 1080 near the LDS limit of the triangular-solve slab."""
+    (13 -> 16, 20 -> 24, 32), and N = 1080 near the LDS limit of the triangular-solve slab.  Round 5: the workgroup-per-slab
+    inverse (k_tri_inverse2) keeps 4 or 8 row blocks per wave in registers -- N = 520 and 1001 / 1024 take the 8-slot
+    instantiation (the last one at its limit of 64 blocks), N = 1030 falls back to the one-wave kernel."""
     rng = np.random.default_rng(N)
     gp, draw = make_gp(rng, N, D, 4, (1, 0, 0))
     H = np.stack([draw() for _ in range(2)], axis=1)

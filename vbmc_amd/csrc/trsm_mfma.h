@@ -12,6 +12,7 @@
 // (gplite/private/gplite_core.m:102) and the rank-1 update (gplite/gplite_post.m:227-229).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 typedef double tmf4 __attribute__((ext_vector_type(4)));
 #define TR_VS 17  // LDS row stride of the 16-column right-hand-side slab and of the panel buffer (16 columns + 1 pad)
@@ -308,11 +309,121 @@ __global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* 
   }
 }
 
+// The same inverse, latency-shaped (round 5): ONE WORKGROUP of TRI2_W waves per 16-column slab instead of one wave, right-looking.
+// The slab never touches LDS: wave w keeps the row blocks cb + w, cb + w + TRI2_W, ... of the right-hand side in accumulator
+// registers (acc[slot]).  Per 16-row block step b
+//   owner   (wave (b - cb) % TRI2_W): V_b = inv(R_bb') acc -- four MFMAs; register r of the accumulator layout is k-slice r of a
+//           B operand, so the product needs no exchange --, V_b to LDS (double-buffered by step parity) and to global memory;
+//   barrier (LDS only: the loads in flight for the next step are not waited for);
+//   update  every wave, for each of its row blocks i > b: acc_i -= R[b, i]' V_b, four MFMAs; the tile R[b, i] (one 32-byte load
+//           per lane: rows b0 + 4 lg .. + 3 of column i0 + li, the inner index permuted to match) was fetched a step ahead.
+// The chain per step is two MFMA quadruples and one LDS round trip (~0.3 us) where the one-wave kernel walked a growing
+// left-looking update behind every block (4.6 us per step at N = 400: 115 us for the first slab, the critical path of a
+// gplite_nlZ gradient for one hyper-parameter vector).  Up to TRI2_W * MAXS row blocks below the slab's own.
+#define TRI2_W 8
+template <int MAXS>
+__global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                              const unsigned char* __restrict__ lchol, double* __restrict__ T, int transposed) {
+  __shared__ double Vb[2][16 * 17];
+  const int cb = blockIdx.x, s = blockIdx.y;
+  if (!lchol[s]) return;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = (N + 15) >> 4, k0 = cb << 4;
+  const double* R = Lall + (size_t)s * N * N;
+  const double* Fi = Finv + (size_t)s * nblk * 256;
+  double* To = T + (size_t)s * N * N;
+  typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+  // rows above the slab's own block are zero, and are written as such
+  for (int e = tid; e < k0 * 16; e += 64 * TRI2_W) {
+    const int k = e >> 4, c = k0 + (e & 15);
+    if (c < N) To[transposed ? (size_t)k * N + c : (size_t)c * N + k] = 0.0;
+  }
+  tmf4 acc[MAXS], pre[MAXS];
+#pragma unroll
+  for (int sl = 0; sl < MAXS; ++sl) { acc[sl] = (tmf4){0.0, 0.0, 0.0, 0.0}; pre[sl] = (tmf4){0.0, 0.0, 0.0, 0.0}; }
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[0][r] = (4 * r + lg == li) ? 1.0 : 0.0;       // the identity block
+  }
+  // tiles R[b, i] of this wave's row blocks i > b (the A operand of the update, negated at use)
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+      const int i = cb + wave + TRI2_W * sl;                     // wave-uniform
+      const int col = (i << 4) + li;
+      tmf4 v = {0.0, 0.0, 0.0, 0.0};
+      if (i > b && i < nblk && col < N) {                        // rows b0 .. b0 + 15 exist: b < i <= nblk - 1
+        const d4u t = *reinterpret_cast<const d4u*>(R + (size_t)col * N + (b << 4) + 4 * lg);
+        v = (tmf4){t[0], t[1], t[2], t[3]};
+      }
+      pre[sl] = v;
+    }
+  };
+  double fv[4];      // this wave's next diagonal block inverse: A[i = li][k = 4u + lg] = Finv_b[li][4u + lg]
+  auto fetch_fv = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fv[u] = b < nblk ? Fi[(size_t)b * 256 + li * 16 + 4 * u + lg] : 0.0;
+  };
+  fetch_fv(cb + wave);
+  fetch(cb);
+  bool done = false;
+#pragma unroll
+  for (int sb = 0; sb < MAXS; ++sb) {
+    for (int ow = 0; ow < TRI2_W && !done; ++ow) {
+      const int b = cb + sb * TRI2_W + ow, b0 = b << 4;
+      if (b >= nblk) { done = true; break; }
+      double* Vw = Vb[ow & 1];                                   // TRI2_W is even: the parity of the step
+      if (wave == ow) {
+        tmf4 vb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], acc[sb][u], vb, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vw[(4 * r + lg) * 17 + li] = vb[r];
+        const int c = k0 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = b0 + 4 * r + lg;
+          if (k < N && c < N) To[transposed ? (size_t)k * N + c : (size_t)c * N + k] = vb[r];
+        }
+        fetch_fv(b + TRI2_W);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (b + 1 < nblk) {
+        double bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = Vw[(4 * lg + u) * 17 + li];
+#pragma unroll
+        for (int sl = sb; sl < MAXS; ++sl) {
+          const int i = cb + wave + TRI2_W * sl;
+          if (i > b && i < nblk) {                               // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[sl][u], bv[u], acc[sl], 0, 0, 0);
+          }
+        }
+        fetch(b + 1);
+      }
+    }
+  }
+}
+
 // T = inv(R') (transposed != 0: its transpose), see k_tri_inverse
 static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const double* Lall, const double* Finv,
                                             const unsigned char* lchol, double* T, int transposed) {
   const int cw = trsm_cw_for(N);
   if (cw == 0) return hipErrorInvalidValue;
+  // few slabs (a handful of matrices): the latency-shaped kernel; many: one wave per slab keeps every SIMD busy anyway
+  {
+    static const int force = getenv("VBMC_TRI2") ? atoi(getenv("VBMC_TRI2")) : -1;    // 0: never, 1: whenever it fits
+    const int nblk = TRSM_NBLK(N);
+    const bool fits = nblk <= TRI2_W * 8;
+    const bool want = force < 0 ? (size_t)S * nblk <= 1024 : force != 0;
+    if (fits && want) {
+      if (nblk <= TRI2_W * 4) hipLaunchKernelGGL((k_tri_inverse2<4>), dim3(nblk, S, 1), dim3(64 * TRI2_W), 0, st, N, S, Lall, Finv, lchol, T, transposed);
+      else hipLaunchKernelGGL((k_tri_inverse2<8>), dim3(nblk, S, 1), dim3(64 * TRI2_W), 0, st, N, S, Lall, Finv, lchol, T, transposed);
+      return hipGetLastError();
+    }
+  }
   TRSM_DISPATCH_CW(cw, {
     const size_t lds = TRSM_LDS_BYTES_CW(N, CW);
     if (lds > 64 * 1024) {
