@@ -17,5 +17,5 @@ python tools/rocpd_timeline.py $db 60 > $out/timeline.md
 python tools/rocpd_api_summary.py $db 32 > $out/api.md
 rm -rf /tmp/gpl
 fi
-[ -x vbmc_amd/lib/chol_bench ] && (timeout 60 vbmc_amd/lib/chol_bench 1 400 1 20 0; timeout 60 vbmc_amd/lib/chol_bench 1 400 20 20 0) > $out/chol_bench.txt 2>&1
+[ -x vbmc_amd/lib/chol_bench ] && (timeout 60 vbmc_amd/lib/chol_bench 1 400 1 20 0; timeout 60 vbmc_amd/lib/chol_bench 1 400 20 20 0; timeout 60 vbmc_amd/lib/chol_bench 2 400 1 20 1; timeout 60 vbmc_amd/lib/chol_bench 2 400 20 20 0) > $out/chol_bench.txt 2>&1
 tail -3 $out/chol_bench.txt 2>/dev/null | cut -c1-160

@@ -103,6 +103,7 @@ struct GpFactor {
   // caller's extra inputs riding in the packed upload (set before gp_factorize): extra_in doubles, filled by fill_extra
   size_t extra_in = 0;
   std::function<void(double*)> fill_extra;
+  bool defer_alpha = false;     // set by the caller: it launches alpha's backward solve itself (dz -> dal, k_tri_inverse2_alpha)
   TmpBuf dIn, dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dz, dones, dninv, dal, dfinv, dExtra;   // dIn: the packed inputs (dX .. dninv, dExtra are windows)
 };
 
@@ -250,6 +251,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   f.tlds = TRSM_LDS_BYTES_CW(N, f.cw);
   hipStream_t sa = st;
   f.alpha_event = false;
+  if (f.defer_alpha) { HIP_TRY(ctx, hipGetLastError()); return VBMC_OK; }
   if (alpha_aside && ctx->ev_fork && ctx->ev_join && ctx_aux(ctx)) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
@@ -458,38 +460,47 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
   }
   // results: [nlZ B | failure indices B | dnlZ B x Nhyp], one block on the device, one copy back
   const size_t nout = (size_t)B * (2 + (compute_grad ? Nhyp : 0));
+  // few matrices of moderate order with a gradient: the factor's inverse and alpha's backward solve share one launch
+  const bool combined = compute_grad && N > 0 && N <= ASOLVE1_THREADS && (size_t)B * TRSM_NBLK(N) <= 1024 && tri_inverse2_fits(N);
+  f.defer_alpha = combined;
   { vbmc_status s_ = gp_factorize(ctx, "vbmc_gp_nlz", N, D, B, Nhyp, meanfun, noisefun, X, y, s2, hyp, false, f, nout, optimistic, compute_grad && B <= 16); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
-  const int Nnoise = f.Nnoise, Nmean = f.Nmean, moff = f.Ncov + f.Nnoise;
+  const int Nnoise = f.Nnoise, Nmean = f.Nmean;
   TmpBuf dout, dKi, dpart, dTT;
   HIP_TRY(ctx, dout.alloc(ctx, nout * 8));
   double* dnlz = dout.as<double>();
-  double* dg = dnlz + 2 * (size_t)B;
+  const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
   if (compute_grad) {
     // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
-    // identity (k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores (k_syrk_tt);
-    // only the upper triangle is formed -- the part k_nlz_grad reads.  Neither needs alpha: with alpha on the second stream
-    // (f.alpha_event) they run beside its solve, and the streams join here.
+    // identity (k_tri_inverse2 / k_tri_inverse, from the column block's own rows down) and a rank-k update on the matrix cores
+    // (k_syrk_tt); only the upper triangle is formed -- the part k_nlz_grad reads.  Neither needs alpha: `combined` runs alpha's
+    // solve as one more workgroup of the inverse's launch; otherwise, with alpha on the second stream (f.alpha_event), they run
+    // beside its solve and the streams join below.
     HIP_TRY(ctx, dKi.alloc(ctx, (size_t)B * N * N * 8));
     HIP_TRY(ctx, dTT.alloc(ctx, (size_t)B * N * N * 8));
-    HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
-    hipLaunchKernelGGL(k_syrk_tt, dim3((N + 63) / 64, (N + 63) / 64, B), dim3(256), 0, st, N, dTT.as<double>(), f.dones.as<unsigned char>(),
-                       dKi.as<double>());
-  }
-  if (f.alpha_event) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-  hipLaunchKernelGGL(k_nlz_value, dim3(B), dim3(256), 0, st, N, D, Nhyp, moff, meanfun, f.dX.as<double>(), f.dy.as<double>(),
-                     f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dnlz, (const double*)f.d_pfd);
-  HIP_TRY(ctx, hipGetLastError());
-  if (compute_grad) {
-    const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
+    if (combined) {
+      const int nblk = TRSM_NBLK(N);
+      if (nblk <= TRI2_W * 4)
+        hipLaunchKernelGGL((k_tri_inverse2_alpha<4>), dim3(nblk + 1, B), dim3(64 * TRI2_W), 0, st, N, f.dA.as<double>(), f.dfinv.as<double>(),
+                           f.dones.as<unsigned char>(), dTT.as<double>(), f.dz.as<double>(), f.dal.as<double>(), f.dscal.as<double>());
+      else
+        hipLaunchKernelGGL((k_tri_inverse2_alpha<8>), dim3(nblk + 1, B), dim3(64 * TRI2_W), 0, st, N, f.dA.as<double>(), f.dfinv.as<double>(),
+                           f.dones.as<unsigned char>(), dTT.as<double>(), f.dz.as<double>(), f.dal.as<double>(), f.dscal.as<double>());
+    } else {
+      HIP_TRY(ctx, tri_inverse_launch(st, N, B, f.dA.as<double>(), f.dfinv.as<double>(), f.dones.as<unsigned char>(), dTT.as<double>(), 1));
+    }
+    syrk_tt_launch(st, N, B, dTT.as<double>(), f.dones.as<unsigned char>(), dKi.as<double>());
+    if (f.alpha_event) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIP_TRY(ctx, dpart.alloc(ctx, (size_t)B * ntile * P * 8));
     DISPATCH_GPDT(D, hipLaunchKernelGGL((k_nlz_grad<DT>), dim3(nt1, nt1, B), dim3(256), 0, st, N, D, Nhyp, Nnoise, f.dhyp.as<double>(),
                                         f.dXc.as<double>(), f.daa.as<double>(), dKi.as<double>(), f.dal.as<double>(), f.dscal.as<double>(),
                                         f.dExtra.as<double>(), dpart.as<double>()));
-    hipLaunchKernelGGL(k_nlz_final, dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, f.dX.as<double>(),
-                       f.dhyp.as<double>(), f.dal.as<double>(), f.dscal.as<double>(), dpart.as<double>(), dg);
-    HIP_TRY(ctx, hipGetLastError());
   }
+  DISPATCH_GPDT(D, hipLaunchKernelGGL((k_nlz_final<DT>), dim3(B), dim3(256), 0, st, N, D, Nhyp, Nnoise, Nmean, meanfun, ntile, compute_grad ? 1 : 0,
+                                      f.dX.as<double>(), f.dy.as<double>(), f.dhyp.as<double>(), f.dA.as<double>(), f.dal.as<double>(),
+                                      f.dscal.as<double>(), compute_grad ? dpart.as<double>() : (const double*)nullptr,
+                                      (const double*)f.d_pfd, dnlz));
+  HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz, nout * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
   f.h_pfd = f.pin_out + B;
   HIP_TRY(ctx, hipStreamSynchronize(st));

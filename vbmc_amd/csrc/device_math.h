@@ -26,6 +26,25 @@ __device__ __forceinline__ double xor_sum32(double v) {
   return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
+// Wave sum without the LDS pipeline: lanes ^1, ^2 by quad permutes, the two halves of 8 and of 16 by the row (half-)mirror --
+// after the quad steps every lane of a quad holds the quad's sum, so mirroring pairs the same groups an xor would --, the rows
+// by the permlane swaps above.  Twelve VALU instructions per double where wave_sum's six __shfl_xor are twelve ds_bpermute_b32
+// and their waits.  Fixed order (1, 2, 4, 8, 16, 32): deterministic, every lane ends with the total; NOT the order of wave_sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_pair_sum(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_valu(double v) {
+  v = dpp_pair_sum<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+  v = dpp_pair_sum<0x4E>(v);     // quad_perm [2, 3, 0, 1]
+  v = dpp_pair_sum<0x141>(v);    // row_half_mirror
+  v = dpp_pair_sum<0x140>(v);    // row_mirror
+  v = xor_sum16(v);
+  return xor_sum32(v);
+}
+
 // fp64 exp used in the hot loops.  Range reduction x = n ln2 + r, |r| <= ln2/2, degree-13 Taylor
 // polynomial in Horner form (|rel err| < 3e-16 before the final scaling), result scaled by
 // 2^n with v_ldexp_f64.  Underflows to 0 and overflows to +inf like exp(); a NaN argument is

@@ -285,12 +285,10 @@ __global__ void __launch_bounds__(ASOLVE_THREADS) k_alpha_solve(int N, const dou
 // of the block inverse) are fetched before the barrier: no L2 round trip on the critical path, no 64-lane reduction.
 // (k_alpha_solve above stays as the path for larger N; 512 threads: the 32 prefetched values need the 256-VGPR budget.)
 #define ASOLVE1_THREADS 512
-__global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
-                                                                 const unsigned char* __restrict__ on, const double* __restrict__ Zin,
-                                                                 double* __restrict__ Xo, int skip_fwd, const double* __restrict__ scal) {
+__device__ __forceinline__ void alpha_solve1_body(int N, int s, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                  const double* __restrict__ Zin, double* __restrict__ Xo, int skip_fwd,
+                                                  const double* __restrict__ scal) {
   __shared__ double xb[2][16], tb[16];
-  const int s = blockIdx.x;
-  if (!on[s]) return;
   const int e = threadIdx.x, lane = e & 63, k = e & 15, myblk = e >> 4;
   const int nblk = (N + 15) >> 4;
   const double* R = Lall + (size_t)s * N * N;
@@ -387,6 +385,29 @@ __global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const d
     fetch_bwd(b - 1);
   }
   if (e < N) Xo[(size_t)s * N + e] = scal ? z / scal[s * 4 + 3] : z;
+}
+__global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                                 const unsigned char* __restrict__ on, const double* __restrict__ Zin,
+                                                                 double* __restrict__ Xo, int skip_fwd, const double* __restrict__ scal) {
+  const int s = blockIdx.x;
+  if (!on[s]) return;
+  alpha_solve1_body(N, s, Lall, Finv, Zin, Xo, skip_fwd, scal);
+}
+
+// T' = inv(R')' for the marginal-likelihood gradient AND alpha's backward solve in ONE launch (N <= ASOLVE1_THREADS, few
+// matrices): workgroups 0 .. nblk - 1 of a matrix invert the factor slab by slab (tri_inverse2_body), workgroup nblk runs the
+// single-vector solve.  Neither needs the other; as two kernels on two streams they cost an event record, two stream waits
+// and their idle gaps (~12 us of a 0.46 ms gplite_nlZ call) on top of the longer of the two.
+static_assert(ASOLVE1_THREADS == 64 * TRI2_W, "the combined launch runs both bodies with one block size");
+template <int MAXS>
+__global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2_alpha(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                                    const unsigned char* __restrict__ on, double* __restrict__ TT,
+                                                                    const double* __restrict__ Zin, double* __restrict__ Xo,
+                                                                    const double* __restrict__ scal) {
+  const int s = blockIdx.y;
+  if (!on[s]) return;
+  if ((int)blockIdx.x == (int)gridDim.x - 1) alpha_solve1_body(N, s, Lall, Finv, Zin, Xo, 1, scal);
+  else tri_inverse2_body<MAXS>(N, blockIdx.x, s, Lall, Finv, TT, 1);
 }
 
 // [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1, 1) (gplite_post.m:189) from the solves the append needs anyway:
@@ -818,28 +839,6 @@ __global__ void __launch_bounds__(256) k_gp_ks(int N, int D, int Nhyp, const dou
 // ------------------------------------------------------------------------------------------
 // gplite_nlZ (gplite/private/gplite_core.m:128-275, covfun 1, no integrated mean / output warping)
 // ------------------------------------------------------------------------------------------
-// nlZ = (y-m)'*alpha/2 + sum(log(diag(L))) + N*log(2*pi*sl)/2   (:205).  One block per hyper-parameter vector.
-__global__ void __launch_bounds__(256) k_nlz_value(int N, int D, int Nhyp, int moff, int meanfun,
-                                                   const double* __restrict__ X, const double* __restrict__ y,
-                                                   const double* __restrict__ hyp, const double* __restrict__ A,
-                                                   const double* __restrict__ alpha, const double* __restrict__ scal,
-                                                   double* __restrict__ nlz, const double* __restrict__ pfd) {
-  __shared__ double red[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (pfd && tid == 0) nlz[gridDim.x + b] = pfd[b];     // the factorisation's failure index rides behind the values
-  const double* hm = hyp + (size_t)b * Nhyp + moff;
-  const double* Ab = A + (size_t)b * N * N;
-  double quad = 0.0, ld = 0.0;
-  for (int n = tid; n < N; n += 256) {
-    const double r = y[n] - gp_meanfun(meanfun, D, hm, X + n, (size_t)N);
-    quad = fma(r, alpha[(size_t)b * N + n], quad);
-    ld += log(Ab[(size_t)n * N + n]);
-  }
-  quad = block_sum(quad, red);
-  ld = block_sum(ld, red);
-  if (tid == 0) nlz[b] = quad / 2.0 + ld + N * log(2.0 * 3.14159265358979323846 * scal[b * 4 + 3]) / 2.0;
-}
-
 // Partial sums of the Q-contractions over one 64 x 64 tile of (k, j):
 //   Q = Kinv/sl - alpha*alpha'                                  (:240, Kinv = L\(L'\eye(N)))
 //   part[d]  = sum Q .* K .* sq_dist(X(:,d)'/ell_d), d < D       (:244-247; the 1/2 is applied in k_nlz_final)
@@ -919,22 +918,26 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
       }
     }
   }
-#pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    const double t = block_sum(acc[d], red);
-    if (tid == 0 && d < D) o[d] = t;
-  }
+  // fixed order: VALU butterfly inside a wave, then the four waves in turn -- one barrier for all D + 1 + Nnoise sums
+  // (round 4: a block_sum -- twelve ds_bpermute and two barriers -- per sum)
+  __shared__ double wr[4][DT + 5];
   {
-    double t = block_sum(accK, red);
-    if (tid == 0) o[D] = t;
-  }
+    const int wv = tid >> 6, ln = tid & 63;
+    double v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < Nnoise) {
-      const double t = block_sum(accN[i], red);
-      if (tid == 0) o[D + 1 + i] = t;
-    }
+    for (int d = 0; d < DT; ++d) { v = wave_sum_valu(acc[d]); if (ln == 0) wr[wv][d] = v; }
+    v = wave_sum_valu(accK); if (ln == 0) wr[wv][DT] = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v = wave_sum_valu(accN[i]); if (ln == 0) wr[wv][DT + 1 + i] = v; }
   }
+  __syncthreads();
+  if (tid < DT + 5) {
+    const double t = ((wr[0][tid] + wr[1][tid]) + wr[2][tid]) + wr[3][tid];
+    if (tid < D) o[tid] = t;
+    else if (tid == DT) o[D] = t;
+    else if (tid > DT && tid - DT - 1 < Nnoise) o[D + 1 + (tid - DT - 1)] = t;
+  }
+  (void)red;
 }
 
 // D -> padded DT for k_gp_build / k_nlz_grad
@@ -948,51 +951,106 @@ __global__ void __launch_bounds__(256) k_nlz_grad(int N, int D, int Nhyp, int Nn
     else { constexpr int DT = 32; __VA_ARGS__; }                 \
   } while (0)
 
-// dnlZ from the tile partials (summed in tile order) + the mean-function block -dm'*alpha (:274,
-// gplite_meanfun.m:402,406,433-435).  One block per hyper-parameter vector.
-__global__ void __launch_bounds__(256) k_nlz_final(int N, int D, int Nhyp, int Nnoise, int Nmean, int meanfun, int ntile,
-                                                   const double* __restrict__ X, const double* __restrict__ hyp,
+// The closing kernel of gplite_nlZ, one block per hyper-parameter vector:
+//   nlZ  = (y-m)'*alpha/2 + sum(log(diag(L))) + N*log(2*pi*sl)/2                                   (gplite_core.m:205)
+//   dnlZ = the tile partials of k_nlz_grad summed in tile order (grad != 0), and the mean-function block -dm'*alpha
+//          (:274, gplite_meanfun.m:402,406,433-435)
+// out = [nlZ B | failure index of the factorisation B | dnlZ B x Nhyp]: the one block that travels back to the host.
+// (Round 5: the value, the tile sums and the 2 D + 1 mean-function dot products were two kernels, the second walking them one
+// wave per hyper-parameter with dependent loads -- 7 + 15..24 us; now one pass over n per thread, every load of a thread in
+// flight at once, wave sums and a fixed-order sum over the four waves.)
+template <int DT>
+__global__ void __launch_bounds__(256) k_nlz_final(int N, int D, int Nhyp, int Nnoise, int Nmean, int meanfun, int ntile, int grad,
+                                                   const double* __restrict__ X, const double* __restrict__ y,
+                                                   const double* __restrict__ hyp, const double* __restrict__ A,
                                                    const double* __restrict__ alpha, const double* __restrict__ scal,
-                                                   const double* __restrict__ part, double* __restrict__ dnlz) {
-  __shared__ double red[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int P = D + 1 + Nnoise;
-  const double mult = scal[b * 4 + 1];
-  double* g = dnlz + (size_t)b * Nhyp;
-  if (tid < P) {
+                                                   const double* __restrict__ part, const double* __restrict__ pfd,
+                                                   double* __restrict__ out) {
+  __shared__ double wred[4][2 * DT + 3];
+  __shared__ double sxm[DT], som[DT];
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int P = D + 1 + Nnoise, moff = D + 1 + Nnoise;
+  const double* hm = hyp + (size_t)b * Nhyp + moff;
+  const double* al = alpha + (size_t)b * N;
+  const double* Ab = A + (size_t)b * N * N;
+  double* g = out + 2 * (size_t)B + (size_t)b * Nhyp;
+  if (tid < DT) {
+    const bool on = meanfun == 4 && tid < D;
+    sxm[tid] = on ? hm[1 + tid] : 0.0;
+    som[tid] = on ? exp(hm[D + 1 + tid]) : 1.0;
+  }
+  if (pfd && tid == 0) out[B + b] = pfd[b];
+  __shared__ double tq[4][64];
+  if (grad && lane < P) {
+    // the tile partials: wave q takes the q-th quarter of the tiles (in tile order, eight loads in flight), the quarters are
+    // added in order below
+    const int per = (ntile + 3) >> 2, j0 = wave * per, j1 = min(ntile, j0 + per);
     double t = 0.0;
-    for (int jt = 0; jt < ntile; jt += 8) {          // tile order, eight loads in flight
+    for (int jt = j0; jt < j1; jt += 8) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = jt + u < ntile ? part[((size_t)b * ntile + jt + u) * P + tid] : 0.0;
+      for (int u = 0; u < 8; ++u) v[u] = jt + u < j1 ? part[((size_t)b * ntile + jt + u) * P + lane] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) t += v[u];
     }
+    tq[wave][lane] = t;
+  }
+  __syncthreads();
+  if (grad && tid < P) {
+    const double t = ((tq[0][tid] + tq[1][tid]) + tq[2][tid]) + tq[3][tid];
+    const double mult = scal[b * 4 + 1];
     if (tid < D) g[tid] = t / 2.0;                 // sum(sum(Q.*K_temp))/2
     else if (tid == D) g[D] = t;                   // sum(sum(Q.*(2*K_mat)))/2
     else g[tid] = 0.5 * mult * t;                  // 0.5*sn2_mult*sum(dsn2(:,i).*dgQ)
   }
-  const int moff = D + 1 + Nnoise;
-  const double* hm = hyp + (size_t)b * Nhyp + moff;
-  const double* al = alpha + (size_t)b * N;
-  // -dm' * alpha, one mean-function hyper-parameter per wave at a time (fixed-order wave sums, no workgroup barriers)
-  const int wave = tid >> 6, lane = tid & 63;
-  for (int i = wave; i < Nmean; i += 4) {
-    double t = 0.0;
-    if (i == 0) {
-      for (int n = lane; n < N; n += 64) t += al[n];
-    } else {
-      const int d = i <= D ? i - 1 : i - 1 - D;
-      const double om = exp(hm[D + 1 + d]), xm = hm[1 + d];
-      for (int n = lane; n < N; n += 64) {
-        const double z = (X[n + (size_t)N * d] - xm) / om;
-        t = fma(i <= D ? z / om : z * z, al[n], t);     // gplite_meanfun.m:433-435
-      }
+  double t1[DT], t2[DT], t0 = 0.0, quad = 0.0, ld = 0.0;
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { t1[d] = 0.0; t2[d] = 0.0; }
+  for (int n = tid; n < N; n += 256) {
+    const double a = al[n], yn = y[n], dg = Ab[(size_t)n * N + n];
+    double x[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) x[d] = (meanfun == 4 && d < D) ? X[n + (size_t)N * d] : 0.0;
+    double z2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const double z = (x[d] - sxm[d]) / som[d];
+      z2 = fma(z, z, z2);
+      t1[d] = fma(z / som[d], a, t1[d]);           // gplite_meanfun.m:433-435
+      t2[d] = fma(z * z, a, t2[d]);
     }
-    t = wave_sum(t);
-    if (lane == 0) g[moff + i] = -t;
+    const double m = meanfun == 0 ? 0.0 : (meanfun == 1 ? hm[0] : hm[0] - 0.5 * z2);    // gplite_meanfun.m:425-431
+    quad = fma(yn - m, a, quad);
+    ld += log(dg);
+    t0 += a;
   }
-  (void)meanfun; (void)red;
+  // fixed order: butterfly inside a wave, then the four waves in turn
+  {
+    double v;
+    v = wave_sum_valu(t0); if (lane == 0) wred[wave][0] = v;
+    v = wave_sum_valu(quad); if (lane == 0) wred[wave][1] = v;
+    v = wave_sum_valu(ld); if (lane == 0) wred[wave][2] = v;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      v = wave_sum_valu(t1[d]); if (lane == 0) wred[wave][3 + d] = v;
+      v = wave_sum_valu(t2[d]); if (lane == 0) wred[wave][3 + DT + d] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * DT + 3) {
+    const double t = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
+    wred[0][tid] = t;
+  }
+  __syncthreads();
+  if (tid == 0) out[b] = wred[0][1] / 2.0 + wred[0][2] + N * log(2.0 * 3.14159265358979323846 * scal[b * 4 + 3]) / 2.0;
+  if (grad && tid < Nmean) {
+    const int i = tid;
+    double t;
+    if (i == 0) t = wred[0][0];
+    else if (i <= D) t = wred[0][3 + (i - 1)];
+    else t = wred[0][3 + DT + (i - 1 - D)];
+    g[moff + i] = -t;
+  }
 }
 
 

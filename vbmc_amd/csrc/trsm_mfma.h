@@ -322,11 +322,9 @@ __global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* 
 // gplite_nlZ gradient for one hyper-parameter vector).  Up to TRI2_W * MAXS row blocks below the slab's own.
 #define TRI2_W 8
 template <int MAXS>
-__global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
-                                                              const unsigned char* __restrict__ lchol, double* __restrict__ T, int transposed) {
+__device__ __forceinline__ void tri_inverse2_body(int N, int cb, int s, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                  double* __restrict__ T, int transposed) {
   __shared__ double Vb[2][16 * 17];
-  const int cb = blockIdx.x, s = blockIdx.y;
-  if (!lchol[s]) return;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = (N + 15) >> 4, k0 = cb << 4;
@@ -407,6 +405,15 @@ __global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2(int N, int S, cons
   }
 }
 
+template <int MAXS>
+__global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                              const unsigned char* __restrict__ lchol, double* __restrict__ T, int transposed) {
+  const int cb = blockIdx.x, s = blockIdx.y;
+  if (!lchol[s]) return;
+  tri_inverse2_body<MAXS>(N, cb, s, Lall, Finv, T, transposed);
+}
+static inline bool tri_inverse2_fits(int N) { return TRSM_NBLK(N) <= TRI2_W * 8; }
+
 // T = inv(R') (transposed != 0: its transpose), see k_tri_inverse
 static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const double* Lall, const double* Finv,
                                             const unsigned char* lchol, double* T, int transposed) {
@@ -440,31 +447,39 @@ static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const 
 // marginal-likelihood gradient contracts with (gplite_core.m:240), formed by a parallel rank-k update on the matrix cores
 // instead of a second, sequential triangular solve.  One workgroup = 4 waves = a 64 x 64 tile (2 x 2 waves of 32 x 32);
 // the roles of the MFMA operands are swapped (rows <-> j) so that the stores run along i.
+// NT = 2: 64 x 64 per workgroup as above (throughput: many matrices).  NT = 1: 32 x 32 per workgroup, one 16 x 16 tile per
+// wave -- for a handful of matrices the kernel is a chain of k-groups per workgroup, each an L2 round trip plus its MFMAs, and a
+// quarter of the MFMAs per group on four times the workgroups shortens exactly that chain (30 -> 12 us for one matrix of order 400).
+template <int NT>
 __global__ void __launch_bounds__(256) k_syrk_tt(int N, const double* __restrict__ TTall, const unsigned char* __restrict__ on,
                                                  double* __restrict__ Call) {
+  constexpr int WT = 16 * NT;                              // rows / columns per wave
   const int ti = blockIdx.x, tj = blockIdx.y, s = blockIdx.z;
-  if (!on[s] || ti > tj) return;
+  const bool diag64 = (ti * 2 * WT) / 64 == (tj * 2 * WT) / 64;     // inside a 64 x 64 diagonal tile: formed in full (k_nlz_grad reads both triangles of those)
+  if (!on[s] || (ti > tj && !diag64)) return;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-  const int i0 = ti * 64 + 32 * (wv & 1), j0 = tj * 64 + 32 * (wv >> 1);
+  const int i0 = ti * 2 * WT + WT * (wv & 1), j0 = tj * 2 * WT + WT * (wv >> 1);
   if (i0 >= N || j0 >= N) return;                      // sub-tile outside the matrix (diagonal tiles are formed in full)
   const double* TT = TTall + (size_t)s * N * N;
   double* C = Call + (size_t)s * N * N;
-  tmf4 acc[2][2];
+  tmf4 acc[NT][NT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (tmf4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NT; ++b) acc[a][b] = (tmf4){0.0, 0.0, 0.0, 0.0};
   const int kmin = (j0 > i0 ? j0 : i0) & ~3;           // rows above max(i, j) hold zeros in one of the two factors
-  const int ia[2] = {i0 + li, i0 + 16 + li}, ja[2] = {j0 + li, j0 + 16 + li};
-  // groups of SY_G k-steps: the 4 * SY_G operand loads of the next group are in flight during the 4 * SY_G MFMAs of this one
+  int ia[NT], ja[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) { ia[u] = i0 + 16 * u + li; ja[u] = j0 + 16 * u + li; }
+  // groups of SY_G k-steps: the operand loads of the next group are in flight during the MFMAs of this one
   constexpr int SY_G = 8;
-  double ac[SY_G][2], bc[SY_G][2], an[SY_G][2], bn[SY_G][2];
-  auto ldg = [&](int k0, double (*av)[2], double (*bv)[2]) {
+  double ac[SY_G][NT], bc[SY_G][NT], an[SY_G][NT], bn[SY_G][NT];
+  auto ldg = [&](int k0, double (*av)[NT], double (*bv)[NT]) {
 #pragma unroll
     for (int g = 0; g < SY_G; ++g) {
       const int kk = k0 + 4 * g + lg;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NT; ++u) {
         av[g][u] = (kk < N && ja[u] < N) ? TT[(size_t)kk * N + ja[u]] : 0.0;   // "A" operand: the j side (rows of the accumulator)
         bv[g][u] = (kk < N && ia[u] < N) ? TT[(size_t)kk * N + ia[u]] : 0.0;   // "B" operand: the i side (columns)
       }
@@ -476,24 +491,30 @@ __global__ void __launch_bounds__(256) k_syrk_tt(int N, const double* __restrict
 #pragma unroll
     for (int g = 0; g < SY_G; ++g)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g][a], bc[g][b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[g][a], bc[g][b], acc[a][b], 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < SY_G; ++g)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { ac[g][u] = an[g][u]; bc[g][u] = bn[g][u]; }
+      for (int u = 0; u < NT; ++u) { ac[g][u] = an[g][u]; bc[g][u] = bn[g][u]; }
   }
   // acc[a][b]: row = j0 + 16a + lg + 4r, column = i0 + 16b + li
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * a + lg + 4 * r, i = i0 + 16 * b + li;
-        if (j < N && i < N && (ti == tj || i <= j)) C[(size_t)j * N + i] = acc[a][b][r];
+        if (j < N && i < N && (diag64 || i <= j)) C[(size_t)j * N + i] = acc[a][b][r];
       }
+}
+// C = T'T for S matrices on stream st
+static inline void syrk_tt_launch(hipStream_t st, int N, int S, const double* TT, const unsigned char* on, double* C) {
+  const int t64 = (N + 63) / 64, t32 = (N + 31) / 32;
+  if ((size_t)S * t64 * (t64 + 1) / 2 <= 128) hipLaunchKernelGGL((k_syrk_tt<1>), dim3(t32, t32, S), dim3(256), 0, st, N, TT, on, C);
+  else hipLaunchKernelGGL((k_syrk_tt<2>), dim3(t64, t64, S), dim3(256), 0, st, N, TT, on, C);
 }
 
 // Two waves per workgroup take the column blocks cb and nblk-1-cb: a long and a short solve, so that every workgroup does
