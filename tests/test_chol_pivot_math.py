@@ -105,3 +105,93 @@ def test_blocked_cholesky_model_needs_the_refinement_step():
         assert e_plain > 20 * e_fix, (two, e_plain, e_fix)
     # and the two-panel order is the same factorisation up to rounding
     assert np.max(np.abs(_blocked_chol_model(K, True, True) - _blocked_chol_model(K, True, False))) < 1e-6 * np.max(np.abs(ref))
+
+
+# ------------------------------------------------------------------------------------------
+# Round 5: the diagonal tile as a blocked LDL' (chol_mfma.h: chol_diag_tile_fast) -- four columns at a time, the 4 x 4 diagonal
+# block eliminated on wave-uniform values with refined reciprocals (v_rcp_f64 + two Newton steps), the rows of the tile
+# against it, the rank-4 update as one MFMA, L = (L~ D) D^-1/2 at the end; the inverse of the factor by a blocked
+# substitution on the UNIT factor L~ (cross-block sums split over the four lane groups, the 4 x 4 diagonal coupling with
+# uniform coefficients), rows scaled by D^-1/2.  NumPy model of exactly that algebra.
+def _rcp2(d, seed_rel_err=2.0 ** -26):
+    y = (1.0 / d) * (1.0 + seed_rel_err)                  # stand-in for v_rcp_f64
+    for _ in range(2):
+        e = fma(-d, y, 1.0)
+        y = fma(y, e, y)
+    return y
+
+
+def _tile_ldl_model(T):
+    """returns (L, W): lower Cholesky factor of the 16 x 16 SPD tile T and W = inv(L), computed the way the kernel does"""
+    T = np.array(T, dtype=np.float64)
+    n = 16
+    Lt = np.zeros((n, n))          # unit lower factor L~ (strictly lower part)
+    U = np.zeros((n, n))           # U[i][s] = d_s * L~[i][s]
+    d = np.zeros(n)
+    for b in range(4):
+        c0 = 4 * b
+        a = T[c0:c0 + 4, c0:c0 + 4]
+        # uniform 4 x 4 LDL'
+        d0 = a[0, 0]; y0 = _rcp2(d0)
+        l10, l20, l30 = a[1, 0] * y0, a[2, 0] * y0, a[3, 0] * y0
+        d1 = fma(-l10, a[1, 0], a[1, 1]); y1 = _rcp2(d1)
+        u21 = fma(-l20, a[1, 0], a[2, 1]); u31 = fma(-l30, a[1, 0], a[3, 1])
+        l21, l31 = u21 * y1, u31 * y1
+        d2 = fma(-l21, u21, fma(-l20, a[2, 0], a[2, 2])); y2 = _rcp2(d2)
+        u32 = fma(-l31, u21, fma(-l30, a[2, 0], a[3, 2])); l32 = u32 * y2
+        d3 = fma(-l32, u32, fma(-l31, u31, fma(-l30, a[3, 0], a[3, 3]))); y3 = _rcp2(d3)
+        d[c0:c0 + 4] = d0, d1, d2, d3
+        # every row against the block
+        for i in range(c0, n):
+            w = T[i, c0:c0 + 4]
+            u0 = w[0]; l0 = u0 * y0
+            u1 = fma(-l0, a[1, 0], w[1]); l1 = u1 * y1
+            u2 = fma(-l1, u21, fma(-l0, a[2, 0], w[2])); l2 = u2 * y2
+            u3 = fma(-l2, u32, fma(-l1, u31, fma(-l0, a[3, 0], w[3]))); l3 = u3 * y3
+            U[i, c0:c0 + 4] = u0, u1, u2, u3
+            Lt[i, c0:c0 + 4] = l0, l1, l2, l3
+        # rank-4 update of the columns to the right (lower triangle)
+        for i in range(c0 + 4, n):
+            for j in range(c0 + 4, i + 1):
+                T[i, j] -= float(np.dot(Lt[i, c0:c0 + 4], U[j, c0:c0 + 4]))
+    ri = np.array([chol_sqrt_rsqrt(float(x), 2.0 ** -21)[1] for x in d])
+    rs = np.array([chol_sqrt_rsqrt(float(x), 2.0 ** -21)[0] for x in d])
+    L = np.tril(U * ri[None, :], -1) + np.diag(rs)
+    # inverse of the unit factor, blocks of four rows
+    M = np.zeros((n, n))
+    for c in range(n):
+        r = np.zeros(n)
+        for k in range(4):
+            s = np.zeros(4)
+            for g in range(4):                      # the four lane groups: u = 4 kk + g
+                part = np.zeros(4)
+                for kk in range(k):
+                    u = 4 * kk + g
+                    for p in range(4):
+                        part[p] = fma(Lt[4 * k + p, u], r[u], part[p])
+                s += part
+            bvec = [(1.0 if c == 4 * k + p else 0.0) - s[p] for p in range(4)]
+            q = 4 * k
+            r0 = bvec[0]
+            r1 = fma(-Lt[q + 1, q], r0, bvec[1])
+            r2 = fma(-Lt[q + 2, q + 1], r1, fma(-Lt[q + 2, q], r0, bvec[2]))
+            r3 = fma(-Lt[q + 3, q + 2], r2, fma(-Lt[q + 3, q + 1], r1, fma(-Lt[q + 3, q], r0, bvec[3])))
+            r[q:q + 4] = r0, r1, r2, r3
+        M[:, c] = r
+    W = ri[:, None] * M
+    return L, W
+
+
+def test_blocked_ldl_tile_model_factor_and_inverse():
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        G = rng.standard_normal((16, 40 if trial < 3 else 17))
+        T = G @ G.T / G.shape[1] + (0.05 if trial % 2 else 1e-3) * np.eye(16)
+        L, W = _tile_ldl_model(T)
+        Lref = np.linalg.cholesky(T)
+        scale = np.abs(Lref).max()
+        cond = np.linalg.cond(Lref)
+        assert np.abs(L - Lref).max() < 40 * cond * np.finfo(float).eps * scale, (trial, np.abs(L - Lref).max(), cond)
+        assert np.abs(L @ L.T - T).max() < 64 * np.finfo(float).eps * np.abs(T).max()
+        assert np.abs(W @ L - np.eye(16)).max() < 64 * cond * np.finfo(float).eps
+        assert np.abs(np.triu(W, 1)).max() == 0.0

@@ -245,6 +245,10 @@ int main(int argc, char** argv) {
                gs[8 * g + 4] - gs[8 * g + 3], g + 1 < gn ? gs[8 * (g + 1)] - gs[8 * g + 4] : 0);
     }
     {
+      long long tt[16];
+      CHECK(hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_chol_tt), sizeof(tt)));
+      printf("fast tile of the same look-ahead (shader cycles): block 0..3 (with the inverse of the block before) %lld %lld %lld %lld | inverse rows 12-15 %lld | roots, scaling, tile to LDS %lld\n",
+             tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5]);
       long long la[8];
       CHECK(hipMemcpyFromSymbol(la, HIP_SYMBOL(g_chol_la), sizeof(la)));
       printf("look-ahead of step 12 (shader cycles): load tile %lld | MFMA + tile to LDS %lld | factor %lld | invert %lld | store %lld\n", la[1] - la[0],

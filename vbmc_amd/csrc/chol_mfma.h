@@ -29,8 +29,18 @@
 #ifndef CH2_IDLE4
 #define CH2_IDLE4 1
 #endif
-// LDS doubles: 2 diagonal tiles + 2 inverses (16 x 17 each) + 64 of gather scratch for the tile factorisation + the panel
-#define CH2_LDS_FIXED (4 * 16 * 17 + 64)
+#ifndef CH2_FAST      // 0: the round-2 diagonal tile (pivot by pivot), stores on the look-ahead's own path
+#define CH2_FAST 1
+#endif
+#ifndef CH2_PREF      // the next diagonal tile fetched before the panel phase: measured, wave 0's four extra loads in front of its panel
+#define CH2_PREF 0    // tile cost the whole phase 0.5 us per step and saved 0.15 us of look-ahead (profiles/r05_chol.md) -- off
+#endif
+#ifndef CH2_DEFER     // the diagonal tile / block inverse stored in the NEXT step's panel phase instead of on the look-ahead's path
+#define CH2_DEFER CH2_FAST
+#endif
+// LDS doubles: 2 diagonal tiles + 2 inverses + the unit factor of the tile in flight (16 x 17 each) + 64 of gather scratch for the
+// tile factorisation + the panel
+#define CH2_LDS_FIXED (5 * 16 * 17 + 64)
 #define CHOL2_LDS_BYTES(N) ((size_t)(CH2_LDS_FIXED + 16 * (size_t)((((N) + 15) >> 4) << 4)) * sizeof(double))
 
 // sqrt(p) and 1/sqrt(p) from the v_rsq_f64 seed with two Goldschmidt steps and a final residual correction (the sequence of
@@ -138,6 +148,166 @@ __device__ __forceinline__ void chol_tile_inverse(const double* __restrict__ Dg,
   __builtin_amdgcn_wave_barrier();
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: the same tile as a blocked LDL' -- factor and inverse in ~1.6 us instead of 3.7 (chol_diag_tile3 + chol_tile_inverse
+// are a chain of 16 pivots, each a reciprocal-root refinement and two broadcasts behind the previous one, then a 16-step
+// substitution that issues 120 LDS reads per lane).  Per block of four columns (register b of the accumulator layout):
+//   uniform  the 4 x 4 diagonal block is read straight out of register b (entry (c0 + p, c0 + q) sits in lane c0 + p + 16 q) and
+//            eliminated on wave-uniform values: pivots d_s, reciprocals by v_rcp_f64 + two Newton steps (five operations
+//            where the reciprocal ROOT took twelve), multipliers -- no square root on the chain at all;
+//   rows     every lane takes its row of the block (LDS gather, beside the uniform chain) through the same elimination:
+//            u_is = d_s l_is and the unit-factor entry l_is;
+//   update   ONE MFMA with A = l (lane group g holds column c0 + g), B = u: L~ D L~' of the block, subtracted from the columns
+//            to the right;
+//   roots    sqrt(d_s), 1 / sqrt(d_s) (chol_sqrt_rsqrt, four independent chains per block, beside everything else):
+//            L[i][c0 + s] = u_is / sqrt(d_s).
+// The inverse W = inv(L) = D^-1/2 inv(L~) on the unit factor, four rows at a time: the sums over the earlier blocks split over
+// the four lane groups (u = 4 kk + g) and added by permlane swaps, the coupling inside the 4 x 4 diagonal block with uniform
+// coefficients -- a chain of ~12 operations per FOUR rows.
+// Anything unusual -- a pivot that is not a positive normal number of moderate size -- and the tile is redone by the careful
+// routine above from the saved input (returns false; the caller does that): the fast path carries no failure bookkeeping.
+#ifdef CHOL_TS   // harness only: shader-clock stamps inside the fast tile routine (look-ahead of step 12 of matrix 0)
+__device__ long long g_chol_tt[16];
+#define CH2_TSTAMP(slot) do { if (dbg) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if (lane == 0) g_chol_tt[slot] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CH2_TSTAMP(slot) do { } while (0)
+#endif
+__device__ __forceinline__ double chol_rcp2(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+// sqrt and reciprocal root without the tiny-pivot branch (the caller guarantees 2^-700 < p < 2^700)
+__device__ __forceinline__ void chol_sqrt_rsqrt_nb(double p, double& rs, double& ri) {
+  const double y = __builtin_amdgcn_rsq(p);
+  double g = p * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double d = fma(-g, g, p);
+  rs = fma(d, h, g);
+  ri = h + h;
+}
+__device__ __forceinline__ bool chol_diag_tile_fast(double (&X)[4], double* __restrict__ Dg, double* __restrict__ Di, double* __restrict__ Ri,
+                                                    double* __restrict__ scr, double* __restrict__ Lt, int lane, bool dbg = false) {
+  typedef double d4w __attribute__((ext_vector_type(4)));
+  const int li = lane & 15, lg = lane >> 4;
+  bool ok = true;
+  (void)dbg;
+  CH2_TSTAMP(0);
+  double rg[4] = {0.0, 0.0, 0.0, 0.0};          // inverse: M[4 kk + lg][c = li] of the blocks done so far
+  double ris_prev = 0.0, m10 = 0.0, m20 = 0.0, m30 = 0.0, m21 = 0.0, m31 = 0.0, m32 = 0.0;   // block b - 1: 1 / sqrt(d), unit-factor entries
+  // rows 4 k .. 4 k + 3 of the inverse: the sums over the earlier blocks split over the four lane groups (u = 4 kk + lg) and added by
+  // permlane swaps, the coupling inside the 4 x 4 diagonal block with the uniform unit-factor entries; Ri[c][t] = M[t][c] / sqrt(d_t)
+  auto inverse_block = [&](int k, double ris, double n10, double n20, double n30, double n21, double n31, double n32) {
+    const int q = 4 * k;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      if (kk < k) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) s4[p] = fma(Lt[(q + p) * 17 + 4 * kk + lg], rg[kk], s4[p]);
+      }
+    double bv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const double tot = k == 0 ? 0.0 : xor_sum32(xor_sum16(s4[p]));
+      bv[p] = (li == q + p ? 1.0 : 0.0) - tot;
+    }
+    const double r0 = bv[0];
+    const double r1 = fma(-n10, r0, bv[1]);
+    const double r2 = fma(-n21, r1, fma(-n20, r0, bv[2]));
+    const double r3 = fma(-n32, r2, fma(-n31, r1, fma(-n30, r0, bv[3])));
+    const double rsel = lg == 0 ? r0 : (lg == 1 ? r1 : (lg == 2 ? r2 : r3));
+    (void)ris;
+    return rsel;
+  };
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int c0 = 4 * b;
+    // the diagonal block, wave-uniform
+    const double a00 = chol_readlane(X[b], c0), a10 = chol_readlane(X[b], c0 + 1), a20 = chol_readlane(X[b], c0 + 2), a30 = chol_readlane(X[b], c0 + 3);
+    const double a11 = chol_readlane(X[b], c0 + 1 + 16), a21 = chol_readlane(X[b], c0 + 2 + 16), a31 = chol_readlane(X[b], c0 + 3 + 16);
+    const double a22 = chol_readlane(X[b], c0 + 2 + 32), a32 = chol_readlane(X[b], c0 + 3 + 32);
+    const double a33 = chol_readlane(X[b], c0 + 3 + 48);
+    // this lane's row of the block
+    scr[li * 4 + lg] = X[b];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const d4w wv = *reinterpret_cast<const d4w*>(scr + li * 4);
+    __builtin_amdgcn_wave_barrier();             // the next block's writes must not overtake these reads
+    // uniform elimination of the 4 x 4 block
+    const double d0 = a00, y0 = chol_rcp2(d0);
+    const double l10 = a10 * y0, l20 = a20 * y0, l30 = a30 * y0;
+    const double d1 = fma(-l10, a10, a11), y1 = chol_rcp2(d1);
+    const double u21 = fma(-l20, a10, a21), u31 = fma(-l30, a10, a31);
+    const double l21 = u21 * y1, l31 = u31 * y1;
+    const double d2 = fma(-l21, u21, fma(-l20, a20, a22)), y2 = chol_rcp2(d2);
+    const double u32 = fma(-l31, u21, fma(-l30, a20, a32)), l32 = u32 * y2;
+    const double d3 = fma(-l32, u32, fma(-l31, u31, fma(-l30, a30, a33))), y3 = chol_rcp2(d3);
+    // the rows (the rows of the block itself reproduce the uniform values: same operations)
+    const double u0 = wv[0], l0 = u0 * y0;
+    const double u1 = fma(-l0, a10, wv[1]), l1 = u1 * y1;
+    const double u2 = fma(-l1, u21, fma(-l0, a20, wv[2])), l2 = u2 * y2;
+    const double u3 = fma(-l2, u32, fma(-l1, u31, fma(-l0, a30, wv[3]))), l3 = u3 * y3;
+    const double lsel = lg == 0 ? l0 : (lg == 1 ? l1 : (lg == 2 ? l2 : l3));
+    const double usel = lg == 0 ? u0 : (lg == 1 ? u1 : (lg == 2 ? u2 : u3));
+    if (b < 3) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lsel, usel, acc, 0, 0, 0);
+#pragma unroll
+      for (int r = b + 1; r < 4; ++r) X[r] -= acc[r];
+    }
+    // the previous block's rows of the inverse, beside this block's chain
+    if (b > 0) rg[b - 1] = inverse_block(b - 1, ris_prev, m10, m20, m30, m21, m31, m32);
+    Lt[li * 17 + c0 + lg] = lsel;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // pivots to LDS (lane group g: d of column c0 + g); the roots of all sixteen are ONE chain after the loop
+    if (li == 0) Di[c0 + lg] = lg == 0 ? d0 : (lg == 1 ? d1 : (lg == 2 ? d2 : d3));
+    X[b] = usel;                                         // d_s L~[li][c0 + lg], scaled below
+    m10 = l10; m20 = l20; m30 = l30; m21 = l21; m31 = l31; m32 = l32;
+    CH2_TSTAMP(1 + b);
+  }
+  rg[3] = inverse_block(3, ris_prev, m10, m20, m30, m21, m31, m32);
+  CH2_TSTAMP(5);
+  // Roots: lane t < 16 takes pivot t -- sqrt and 1 / sqrt of all sixteen in one chain (the loop carried none), and the range test
+  // with them: anything but a positive normal number of moderate size sends the tile to the careful routine.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {
+    const double dt = Di[li];
+    ok = dt > 0x1p-200 && dt < 0x1p200;
+    double rs, ri;
+    chol_sqrt_rsqrt_nb(ok ? dt : 1.0, rs, ri);
+    __builtin_amdgcn_wave_barrier();
+    if (lg == 0) { Di[li] = ri; scr[li] = rs; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double rik = Di[4 * k + lg], rsk = scr[4 * k + lg];
+    X[k] = (li == 4 * k + lg) ? rsk : X[k] * rik;       // L[li][4k + lg] for li >= 4k + lg (rows above the diagonal are never read)
+    Ri[li * 17 + 4 * k + lg] = rik * rg[k];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Dg[(lg + 4 * r) * 17 + li] = X[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  CH2_TSTAMP(6);
+  return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
+
 #ifdef CHOL_TS   // harness only: shader-clock stamps inside the groups of wave 1 during the first full update (slot x group)
 __device__ long long g_chol_gs[8 * 64];
 __device__ int g_chol_gn;
@@ -153,6 +323,24 @@ __device__ long long g_chol_la[8];
 #define CH2_GSTAMP(slot) do { } while (0)
 #define CH2_LSTAMP(slot) do { } while (0)
 #endif
+
+// factor + invert one diagonal tile (wave-level): the fast path, the careful one when it declines
+__device__ __forceinline__ void chol_tile(double (&X)[4], double* __restrict__ Dg, double* __restrict__ Di, double* __restrict__ Ri,
+                                          double* __restrict__ scr, double* __restrict__ Lt, int nb, int kb, int lane, int* s_fail) {
+  if (CH2_FAST) {
+    double X0[4] = {X[0], X[1], X[2], X[3]};
+#ifdef CHOL_TS
+    const bool dbg = blockIdx.x == 0 && kb == 13 * 16;
+#else
+    const bool dbg = false;
+#endif
+    if (chol_diag_tile_fast(X, Dg, Di, Ri, scr, Lt, lane, dbg)) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = X0[r];
+  }
+  chol_diag_tile3(X, Dg, Di, scr, nb, kb, lane, s_fail);
+  chol_tile_inverse(Dg, Di, Ri, lane);
+}
 
 template <bool GP, bool TWO>
 __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict__ Aall, int* __restrict__ pfail,
@@ -170,7 +358,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
   double* A = Aall + (size_t)s * N * N;
   double* DgB = lds;                      // [2][16 x 17] diagonal tiles: this step's and the next one's
   double* RiB = lds + 2 * 16 * 17;        // [2][16 x 17] their inverses
-  double* scr = lds + 4 * 16 * 17;        // 64 doubles (chol_diag_tile3)
+  double* scr = lds + 4 * 16 * 17;        // 64 doubles (chol_diag_tile3 / chol_diag_tile_fast)
+  double* LtS = scr + 64;                 // 16 x 17: the unit factor of the tile in flight (chol_diag_tile_fast)
   double* Pl = lds + CH2_LDS_FIXED;       // 16 x Np panel rows (LDS variant); TWO: a second panel behind it
   double* Pgl = GP ? Pg + (size_t)s * 16 * Np : nullptr;
   // Right-hand side riding along (rin != null): z = R' \ r as a by-product -- r is one more column of the matrix: its row block
@@ -180,34 +369,37 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
   __shared__ double zb[16], zres[16];
   const bool RHS = rin != nullptr;
   if (RHS) for (int i = tid; i < Np; i += CH2_THREADS) rv[i] = i < N ? rin[(size_t)s * N + i] : 0.0;
-  // z_b for the block at kb from the tile in buffer `c_` (16 lanes of one wave; four short chains per product)
+  // z_b for the block at kb from the tile in buffer `c_`: one wave, lane (t = li, g = lg) takes the terms c = 4 j + g of row t's three
+  // 16-term products, the four groups are added by permlane swaps
   auto rhs_block = [&](int kb_, int c_) {
-    if (lane < 16) {
-      const double* Ri_ = RiB + c_ * 16 * 17;
-      const double* Dg_ = DgB + c_ * 16 * 17;
-      const int t = lane;
-      double a4[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* Ri_ = RiB + c_ * 16 * 17;
+    const double* Dg_ = DgB + c_ * 16 * 17;
+    const int t = li;
+    double a = 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a4[c & 3] = fma(Ri_[c * 17 + t], rv[kb_ + c], a4[c & 3]);
-      double z = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-      zb[t] = z;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // refinement: res_t = r_t - sum_{u <= t} R[u][t] z_u,  z += inv(Rkk') res
-      double r4[4] = {rv[kb_ + t], 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) a = fma(Ri_[(4 * j + lg) * 17 + t], rv[kb_ + 4 * j + lg], a);
+    double z = xor_sum32(xor_sum16(a));
+    if (lg == 0) zb[t] = z;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // refinement: res_t = r_t - sum_{u <= t} R[u][t] z_u,  z += inv(Rkk') res
+    double p = 0.0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) r4[u & 3] = fma(-(u <= t ? Dg_[u * 17 + t] : 0.0), zb[u], r4[u & 3]);
-      __builtin_amdgcn_wave_barrier();
-      zres[t] = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double c4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; ++j) {
+      const int u = 4 * j + lg;
+      p = fma(u <= t ? Dg_[u * 17 + t] : 0.0, zb[u], p);
+    }
+    const double res = rv[kb_ + t] - xor_sum32(xor_sum16(p));
+    if (lg == 0) zres[t] = res;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double c = 0.0;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) c4[c & 3] = fma(Ri_[c * 17 + t], zres[c], c4[c & 3]);
-      z += (c4[0] + c4[1]) + (c4[2] + c4[3]);
-      __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < 4; ++j) c = fma(Ri_[(4 * j + lg) * 17 + t], zres[4 * j + lg], c);
+    z += xor_sum32(xor_sum16(c));
+    if (lg == 0) {
       zb[t] = z;
       if (kb_ + t < N) zout[(size_t)s * N + kb_ + t] = z;
     }
@@ -255,10 +447,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     const int nb = min(16, N);
     double X[4];
     load_diag(A, nb, X);
-    chol_diag_tile3(X, DgB, DiB[0], scr, nb, 0, lane, &s_fail);
-    chol_tile_inverse(DgB, DiB[0], RiB, lane);
-    store_diag(A, nb, DgB);
-    store_finv(0, RiB);
+    chol_tile(X, DgB, DiB[0], RiB, scr, LtS, nb, 0, lane, &s_fail);
+    if (!CH2_DEFER) { store_diag(A, nb, DgB); store_finv(0, RiB); }
   }
   __syncthreads();
   int cur = 0;
@@ -277,7 +467,9 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     const int pbuf = TWO ? ((kb >> 4) & 1) : 0;
     if (tid == 0) CHOL_STAMP(0, kb >> 4);
     // ---- panel: tile tj of the row block (16 x 16, rows kb.., columns t0 + 16 tj..) times inv(Rkk')
-    if (RHS && wave == CH2_W - 1) rhs_block(kb, cur);     // the wave with the fewest panel tiles
+    // the next diagonal tile is complete up to this step's panel: wave 0 fetches it now, the L2 round trip hides behind the panel phase
+    double Xn[4] = {0.0, 0.0, 0.0, 0.0};
+    if (CH2_PREF && wave == 0) load_diag(A + (size_t)t0 + (size_t)N * t0, min(16, ntr), Xn);
     {
       double av[4], rv[4];
       const double* Dgc = DgB + cur * 16 * 17;
@@ -328,7 +520,16 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
         }
       }
     }
-    __syncthreads();
+    // behind this wave's panel tiles (their loads and stores are in flight): the right-hand side's block on the wave with the
+    // fewest tiles; this block's diagonal tile and its inverse go out here, off the look-ahead's path (the tile buffers hold
+    // them for a step)
+    if (RHS && wave == CH2_W - 1) rhs_block(kb, cur);
+    if (CH2_DEFER && wave == CH2_W - 2) { store_diag(A + (size_t)kb + (size_t)N * kb, nb, DgB + cur * 16 * 17); store_finv(kb >> 4, RiB + cur * 16 * 17); }
+    // Nothing this phase wrote to GLOBAL memory is read before the barrier at the end of the step (the row block of R, the diagonal
+    // tile, the block inverse and z are results; the panel the update reads is in LDS): an LDS-only barrier, so that the stores'
+    // acknowledgements (1-2 us) are waited for behind the update instead of in front of it.  (GP: the panel itself is in global memory.)
+    if (GP || !CH2_DEFER) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tid == 0) CHOL_STAMP(1, kb >> 4);
     // ---- trailing update.  Tile pair u = tj (tj + 1) / 2 + ti (ti <= tj) of the nt x nt tile triangle; transposed tiles so
     //      that lanes run along i (contiguous in the column-major matrix): lane (li, lg) register r holds
@@ -341,7 +542,10 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       double* Dn = DgB + (cur ^ 1) * 16 * 17;
       CH2_LSTAMP(0);
       double X[4];
-      load_diag(At, nb2, X);
+      if (CH2_PREF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[r] = Xn[r];
+      } else load_diag(At, nb2, X);
       CH2_LSTAMP(1);
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
       const d4v pa = ldP4(pbuf, lg, li);
@@ -358,12 +562,10 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
         if (li < nb2 && j < nb2 && li >= j) X[r] -= acc[r];     // the product is symmetric: either triangle of it will do
       }
       CH2_LSTAMP(2);
-      chol_diag_tile3(X, Dn, DiB[cur ^ 1], scr, nb2, t0, lane, &s_fail);
+      chol_tile(X, Dn, DiB[cur ^ 1], RiB + (cur ^ 1) * 16 * 17, scr, LtS, nb2, t0, lane, &s_fail);
       CH2_LSTAMP(3);
-      chol_tile_inverse(Dn, DiB[cur ^ 1], RiB + (cur ^ 1) * 16 * 17, lane);
       CH2_LSTAMP(4);
-      store_diag(At, nb2, Dn);
-      store_finv(t0 >> 4, RiB + (cur ^ 1) * 16 * 17);
+      if (!CH2_DEFER) { store_diag(At, nb2, Dn); store_finv(t0 >> 4, RiB + (cur ^ 1) * 16 * 17); }
       CH2_LSTAMP(5);
       if (lane == 0) CHOL_STAMP(2, kb >> 4);
     }
@@ -505,6 +707,11 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     if (tid == 0) CHOL_STAMP(3, kb >> 4);
   }
   if (RHS && wave == 0 && !s_fail) rhs_block(((N - 1) >> 4) << 4, cur);   // the last row block has no panel phase
+  if (CH2_DEFER && wave == 1 && !s_fail) {
+    const int kl = ((N - 1) >> 4) << 4;
+    store_diag(A + (size_t)kl + (size_t)N * kl, N - kl, DgB + cur * 16 * 17);
+    store_finv(kl >> 4, RiB + cur * 16 * 17);
+  }
   if (tid == 0) { pfail[s] = s_fail; if (pfd) pfd[s] = (double)s_fail; }
   if (s_fail) return;
   // zero the strict lower triangle (MATLAB chol returns an upper-triangular matrix)
@@ -514,7 +721,7 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
 
 // Launch on stream st: S matrices of order N in dA (N x N x S), pfail S ints, active S flags; Pg = S x 16 x Np doubles of
 // scratch, needed only when chol2_needs_gpanel(N).  Two panels in LDS up to N = 592, one up to N = 1200, global panel beyond
-// (with a right-hand side riding along -- Np more doubles of LDS -- up to N = 576 / 1120).
+// (with a right-hand side riding along -- Np more doubles of LDS -- up to N = 560 / 1104).
 #define CHOL2_NP(N) ((size_t)((((N) + 15) >> 4) << 4))
 #define CHOL2_LDS_BYTES1(N, rhs) ((size_t)(CH2_LDS_FIXED + (16 + ((rhs) ? 1 : 0)) * CHOL2_NP(N)) * sizeof(double))
 #define CHOL2_LDS_BYTES2(N, rhs) ((size_t)(CH2_LDS_FIXED + (32 + ((rhs) ? 1 : 0)) * CHOL2_NP(N)) * sizeof(double))
