@@ -355,7 +355,7 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
       }
     }
   }
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, stream_wait_latency(st));
   if (!gp_factor_ok(f, S)) return VBMC_INTERNAL_RETRY;     // a first try failed: once more with the noise-inflation loop
   if (L && any_inv)
     for (int s = 0; s < S; ++s)
@@ -503,7 +503,7 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz, nout * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
   f.h_pfd = f.pin_out + B;
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, stream_wait_latency(st));
   if (!gp_factor_ok(f, B)) return VBMC_INTERNAL_RETRY;
   memcpy(nlZ, f.pin_out, (size_t)B * 8);
   if (compute_grad) memcpy(dnlZ, f.pin_out + 2 * (size_t)B, (size_t)B * Nhyp * 8);

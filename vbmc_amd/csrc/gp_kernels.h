@@ -99,31 +99,46 @@ __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const 
     // of eight rows in flight, fixed-order butterfly.  (Round 5: the first version walked N / 8 dependent load + divide steps
     // per lane and called exp(h[d]) for every element of the scaled copy -- 18 us of a 0.55 ms gplite_nlZ call.)
     const int wave = tid >> 6, lane = tid & 63;
-    for (int d = wave; d < D; d += 4) {
-      const double ell = exp(h[d]);
-      const double* xd = X + (size_t)N * d;
-      double acc = 0.0;
-      int n = lane;
-      for (; n + 7 * 64 < N; n += 8 * 64) {
-        double v[8];
+    // wave w takes the dimensions w, w + 4, ...: all of them at once, eight rows per lane and dimension in flight (the ragged end
+    // masked: adds + 0), so that the whole reduction is one round trip to memory -- the inputs have just been uploaded
+    double ell[8], acc[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = xd[n + 64 * u];
+    for (int j = 0; j < 8; ++j) { const int d = wave + 4 * j; ell[j] = d < D ? exp(h[d]) : 1.0; acc[j] = 0.0; }
+    for (int n = lane; n < N; n += 8 * 64) {
+      double v[8][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u] / ell;
+      for (int j = 0; j < 8; ++j) {
+        const int d = wave + 4 * j;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[j][u] = (d < D && n + 64 * u < N) ? X[(size_t)N * d + n + 64 * u] : 0.0;
       }
-      for (; n < N; n += 64) acc += xd[n] / ell;
-      acc = wave_sum(acc);
-      if (lane == 0) { mean[d] = acc / N; sell[d] = ell; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[j] += v[j][u] / ell[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = wave + 4 * j;
+      if (d < D) {                       // wave-uniform
+        const double t = wave_sum(acc[j]);
+        if (lane == 0) { mean[d] = t / N; sell[d] = ell[j]; }
+      }
     }
   }
   __syncthreads();
   for (int n = blockIdx.x * blockDim.x + tid; n < N; n += gridDim.x * blockDim.x) {
     double acc = 0.0;
-    for (int d = 0; d < D; ++d) {
-      double v = X[n + (size_t)N * d] / sell[d] - mean[d];
-      Xc[((size_t)s * N + n) * D + d] = v;
-      acc = fma(v, v, acc);
-    }
+    double xv[32];                                        // the point's coordinates: every load in flight at once
+#pragma unroll
+    for (int d = 0; d < 32; ++d) xv[d] = d < D ? X[n + (size_t)N * d] : 0.0;
+#pragma unroll
+    for (int d = 0; d < 32; ++d)
+      if (d < D) {
+        double v = xv[d] / sell[d] - mean[d];
+        Xc[((size_t)s * N + n) * D + d] = v;
+        acc = fma(v, v, acc);
+      }
     aa[(size_t)s * N + n] = acc;
     if (rout) {
       const double* hm = h + moff;
@@ -131,10 +146,12 @@ __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const 
       if (meanfun == 1) m = hm[0];
       else if (meanfun == 4) {
         double z2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-          const double t = (X[n + (size_t)N * d] - hm[1 + d]) / som[d];
-          z2 = fma(t, t, z2);
-        }
+#pragma unroll
+        for (int d = 0; d < 32; ++d)
+          if (d < D) {
+            const double t = (xv[d] - hm[1 + d]) / som[d];
+            z2 = fma(t, t, z2);
+          }
         m = hm[0] - 0.5 * z2;            // gplite_meanfun.m:425-431
       }
       rout[(size_t)s * N + n] = y[n] - m;
@@ -347,12 +364,15 @@ __device__ __forceinline__ void alpha_solve1_body(int N, int s, const double* __
     fetch_fwd(b + 1);
   }
   __syncthreads();
-  // ---- backward: R x = v.  Step b needs R[e][b0 + c] (row e, 16 columns) for e < b0.
-  auto fetch_bwd = [&](int b) {
+  // ---- backward: R x = v.  Step b needs R[e][b0 + c] (row e, 16 columns) for e < b0 -- fetched FOUR steps ahead into a ring
+  // (round 5: a step is ~0.25 us of exchange and two 16-term products, an L2 round trip ~1 us; with one step of look-ahead every
+  // step waited for its row, 1.2 us per step)
+  double prq[4][16];
+  auto fetch_bwd = [&](int b, double (&pr)[16]) {
     const int b0 = b << 4;
     const bool mine = b >= 0 && e < b0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) pre[c] = (mine && b0 + c < N) ? R[(size_t)(b0 + c) * N + e] : 0.0;
+    for (int c = 0; c < 16; ++c) pr[c] = (mine && b0 + c < N) ? R[(size_t)(b0 + c) * N + e] : 0.0;
     if (b >= 1 && myblk == b - 1) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) fi[c] = Fi[(size_t)(b - 1) * 256 + c * 16 + k];      // row k of R_bb^{-1} = column k of (R_bb')^{-1}
@@ -362,31 +382,38 @@ __device__ __forceinline__ void alpha_solve1_body(int N, int s, const double* __
 #pragma unroll
     for (int c = 0; c < 16; ++c) fi[c] = Fi[(size_t)(nblk - 1) * 256 + c * 16 + k];
   }
-  fetch_bwd(nblk - 1);
-  for (int b = nblk - 1; b >= 0; --b) {
-    if (myblk == b) {
-      tb[k] = z;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double a4[4] = {0.0, 0.0, 0.0, 0.0};          // four short chains instead of one of 16 dependent FMAs
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a4[c & 3] = fma(fi[c], tb[c], a4[c & 3]);
-      const double a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-      z = e < N ? a : 0.0;
-      xb[b & 1][k] = z;
+  for (int q = 0; q < 4; ++q) fetch_bwd(nblk - 1 - q, prq[q]);
+  for (int bb = nblk - 1; bb >= 0; bb -= 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = bb - q;
+      if (b >= 0) {                          // uniform
+        if (myblk == b) {
+          tb[k] = z;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          double a4[4] = {0.0, 0.0, 0.0, 0.0};          // four short chains instead of one of 16 dependent FMAs
+#pragma unroll
+          for (int c = 0; c < 16; ++c) a4[c & 3] = fma(fi[c], tb[c], a4[c & 3]);
+          const double a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+          z = e < N ? a : 0.0;
+          xb[b & 1][k] = z;
+        }
+        // LDS-only barrier: __syncthreads() would also wait for the global loads in flight for the next steps (vmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        double p4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) p4[c & 3] = fma(prq[q][c], xb[b & 1][c], p4[c & 3]);
+        z -= (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        fetch_bwd(b - 4, prq[q]);
+      }
     }
-    // LDS-only barrier: __syncthreads() would also wait for the global loads just issued for the next step (vmcnt(0))
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    double p4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < 16; ++c) p4[c & 3] = fma(pre[c], xb[b & 1][c], p4[c & 3]);
-    z -= (p4[0] + p4[1]) + (p4[2] + p4[3]);
-    fetch_bwd(b - 1);
   }
   if (e < N) Xo[(size_t)s * N + e] = scal ? z / scal[s * 4 + 3] : z;
 }
-__global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+__global__ void __launch_bounds__(ASOLVE1_THREADS, 2) k_alpha_solve1(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                                  const unsigned char* __restrict__ on, const double* __restrict__ Zin,
                                                                  double* __restrict__ Xo, int skip_fwd, const double* __restrict__ scal) {
   const int s = blockIdx.x;
@@ -400,14 +427,14 @@ __global__ void __launch_bounds__(ASOLVE1_THREADS) k_alpha_solve1(int N, const d
 // and their idle gaps (~12 us of a 0.46 ms gplite_nlZ call) on top of the longer of the two.
 static_assert(ASOLVE1_THREADS == 64 * TRI2_W, "the combined launch runs both bodies with one block size");
 template <int MAXS>
-__global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2_alpha(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
+__global__ void __launch_bounds__(64 * TRI2_W, 2) k_tri_inverse2_alpha(int N, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                                     const unsigned char* __restrict__ on, double* __restrict__ TT,
                                                                     const double* __restrict__ Zin, double* __restrict__ Xo,
                                                                     const double* __restrict__ scal) {
   const int s = blockIdx.y;
   if (!on[s]) return;
   if ((int)blockIdx.x == (int)gridDim.x - 1) alpha_solve1_body(N, s, Lall, Finv, Zin, Xo, 1, scal);
-  else tri_inverse2_body<MAXS>(N, blockIdx.x, s, Lall, Finv, TT, 1);
+  else tri_inverse2_body<MAXS, (MAXS <= 4 ? 4 : 2)>(N, blockIdx.x, s, Lall, Finv, TT, 1);
 }
 
 // [mstar, vstar] = gplite_pred(gp, xstar, ystar, [], 1, 1) (gplite_post.m:189) from the solves the append needs anyway:

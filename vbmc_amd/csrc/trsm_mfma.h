@@ -321,9 +321,10 @@ __global__ void __launch_bounds__(64) k_tri_inverse(int N, int S, const double* 
 // left-looking update behind every block (4.6 us per step at N = 400: 115 us for the first slab, the critical path of a
 // gplite_nlZ gradient for one hyper-parameter vector).  Up to TRI2_W * MAXS row blocks below the slab's own.
 #define TRI2_W 8
-template <int MAXS>
+template <int MAXS, int DEPTH>
 __device__ __forceinline__ void tri_inverse2_body(int N, int cb, int s, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                   double* __restrict__ T, int transposed) {
+  static_assert(TRI2_W % DEPTH == 0, "the tile ring is indexed by the step modulo DEPTH");
   __shared__ double Vb[2][16 * 17];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,15 +338,18 @@ __device__ __forceinline__ void tri_inverse2_body(int N, int cb, int s, const do
     const int k = e >> 4, c = k0 + (e & 15);
     if (c < N) To[transposed ? (size_t)k * N + c : (size_t)c * N + k] = 0.0;
   }
-  tmf4 acc[MAXS], pre[MAXS];
+  tmf4 acc[MAXS];
+  // Tiles R[b, i] of this wave's row blocks i > b (the A operand of the update, negated at use), fetched DEPTH steps ahead into a
+  // ring: a step is ~0.4 us of dependent MFMAs and one LDS round trip, an L2 round trip ~1 us -- one step of look-ahead left every
+  // step waiting for its tiles (1.3 us per step measured).
+  tmf4 pre[DEPTH][MAXS];
 #pragma unroll
-  for (int sl = 0; sl < MAXS; ++sl) { acc[sl] = (tmf4){0.0, 0.0, 0.0, 0.0}; pre[sl] = (tmf4){0.0, 0.0, 0.0, 0.0}; }
+  for (int sl = 0; sl < MAXS; ++sl) acc[sl] = (tmf4){0.0, 0.0, 0.0, 0.0};
   if (wave == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[0][r] = (4 * r + lg == li) ? 1.0 : 0.0;       // the identity block
   }
-  // tiles R[b, i] of this wave's row blocks i > b (the A operand of the update, negated at use)
-  auto fetch = [&](int b) {
+  auto fetch = [&](int b, tmf4 (&pr)[MAXS]) {
 #pragma unroll
     for (int sl = 0; sl < MAXS; ++sl) {
       const int i = cb + wave + TRI2_W * sl;                     // wave-uniform
@@ -355,7 +359,7 @@ __device__ __forceinline__ void tri_inverse2_body(int N, int cb, int s, const do
         const d4u t = *reinterpret_cast<const d4u*>(R + (size_t)col * N + (b << 4) + 4 * lg);
         v = (tmf4){t[0], t[1], t[2], t[3]};
       }
-      pre[sl] = v;
+      pr[sl] = v;
     }
   };
   double fv[4];      // this wave's next diagonal block inverse: A[i = li][k = 4u + lg] = Finv_b[li][4u + lg]
@@ -364,53 +368,67 @@ __device__ __forceinline__ void tri_inverse2_body(int N, int cb, int s, const do
     for (int u = 0; u < 4; ++u) fv[u] = b < nblk ? Fi[(size_t)b * 256 + li * 16 + 4 * u + lg] : 0.0;
   };
   fetch_fv(cb + wave);
-  fetch(cb);
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) fetch(cb + q, pre[q]);
   bool done = false;
 #pragma unroll
   for (int sb = 0; sb < MAXS; ++sb) {
-    for (int ow = 0; ow < TRI2_W && !done; ++ow) {
-      const int b = cb + sb * TRI2_W + ow, b0 = b << 4;
-      if (b >= nblk) { done = true; break; }
-      double* Vw = Vb[ow & 1];                                   // TRI2_W is even: the parity of the step
-      if (wave == ow) {
-        tmf4 vb = {0.0, 0.0, 0.0, 0.0};
+    for (int ow0 = 0; ow0 < TRI2_W && !done; ow0 += DEPTH) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[u], acc[sb][u], vb, 0, 0, 0);
+      for (int q = 0; q < DEPTH; ++q) {
+        const int ow = ow0 + q;
+        const int b = cb + sb * TRI2_W + ow, b0 = b << 4;
+        if (b >= nblk) { done = true; }
+        if (!done) {
+          double* Vw = Vb[q & 1];                                // DEPTH is even: the parity of the step
+          if (wave == ow) {
+            tmf4 vb = {0.0, 0.0, 0.0, 0.0}, vb2 = {0.0, 0.0, 0.0, 0.0};
+            vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[0], acc[sb][0], vb, 0, 0, 0);
+            vb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[1], acc[sb][1], vb2, 0, 0, 0);
+            vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[2], acc[sb][2], vb, 0, 0, 0);
+            vb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[3], acc[sb][3], vb2, 0, 0, 0);
+            vb += vb2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Vw[(4 * r + lg) * 17 + li] = vb[r];
-        const int c = k0 + li;
+            for (int r = 0; r < 4; ++r) Vw[(4 * r + lg) * 17 + li] = vb[r];
+            const int c = k0 + li;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = b0 + 4 * r + lg;
-          if (k < N && c < N) To[transposed ? (size_t)k * N + c : (size_t)c * N + k] = vb[r];
-        }
-        fetch_fv(b + TRI2_W);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (b + 1 < nblk) {
-        double bv[4];
+            for (int r = 0; r < 4; ++r) {
+              const int k = b0 + 4 * r + lg;
+              if (k < N && c < N) To[transposed ? (size_t)k * N + c : (size_t)c * N + k] = vb[r];
+            }
+            fetch_fv(b + TRI2_W);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (b + 1 < nblk) {
+            double bv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = Vw[(4 * lg + u) * 17 + li];
+            for (int u = 0; u < 4; ++u) bv[u] = Vw[(4 * lg + u) * 17 + li];
 #pragma unroll
-        for (int sl = sb; sl < MAXS; ++sl) {
-          const int i = cb + wave + TRI2_W * sl;
-          if (i > b && i < nblk) {                               // wave-uniform
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[sl][u], bv[u], acc[sl], 0, 0, 0);
+            for (int sl = sb; sl < MAXS; ++sl) {
+              const int i = cb + wave + TRI2_W * sl;
+              if (i > b && i < nblk) {                           // wave-uniform
+                tmf4 a2 = {0.0, 0.0, 0.0, 0.0};
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][0], bv[0], acc[sl], 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][1], bv[1], a2, 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][2], bv[2], acc[sl], 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][3], bv[3], a2, 0, 0, 0);
+                acc[sl] += a2;
+              }
+            }
+            fetch(b + DEPTH, pre[q]);
           }
         }
-        fetch(b + 1);
       }
     }
   }
 }
 
 template <int MAXS>
-__global__ void __launch_bounds__(64 * TRI2_W) k_tri_inverse2(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
+__global__ void __launch_bounds__(64 * TRI2_W, 2) k_tri_inverse2(int N, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
                                                               const unsigned char* __restrict__ lchol, double* __restrict__ T, int transposed) {
   const int cb = blockIdx.x, s = blockIdx.y;
   if (!lchol[s]) return;
-  tri_inverse2_body<MAXS>(N, cb, s, Lall, Finv, T, transposed);
+  tri_inverse2_body<MAXS, (MAXS <= 4 ? 4 : 2)>(N, cb, s, Lall, Finv, T, transposed);
 }
 static inline bool tri_inverse2_fits(int N) { return TRSM_NBLK(N) <= TRI2_W * 8; }
 
