@@ -294,7 +294,11 @@ vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_ar
  * (measured at creation; vbmc_ctx_create raises GPU_MAX_HW_QUEUES to 8 ahead of its own first HIP call so that there are queues to choose
  * from -- unless the environment holds a value, VBMC_HW_QUEUES=0 forbids it, or another HIP user initialised the runtime first: see
  * INTEGRATION.md), and a slot stream is ordered after whatever the context's own stream still holds at submit (a surrogate being
- * uploaded, draws being produced).  While the device works on one batch the host stages the next, so that the device never waits for
+ * uploaded, draws being produced).  COST OF THE FIRST SUBMIT of a context: the placement is MEASURED -- up to six candidate streams
+ * per slot stream, each timed with two probe launches beside every stream it has to share the device with (a 45 us low-occupancy
+ * kernel and a one-wave kernel, twice, with a synchronisation each): 1-6 ms once per context, device otherwise idle, before the
+ * first batch is enqueued; VBMC_PLACE=0 skips the measurement and takes the first candidate (VBMC_DEBUG_PLACE=1 prints the ratios).
+ * Create the context, and submit a first (warm-up) batch, outside a timed region.  While the device works on one batch the host stages the next, so that the device never waits for
  * the host between batches.  Measured at the headline shape: 2.49 ms per blocking call of 64 restarts, 2.39-2.42 ms per pipelined batch;
  * 0.37 / 0.33 ms for 8 restarts, 102 / 65 us for one.  Passes of one slot stream execute in submission order; each
  * slot must be collected before it is submitted again.  Results are bit-identical to vbmc_elbo_batch with the same args.
