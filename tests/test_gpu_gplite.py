@@ -160,10 +160,12 @@ def test_posterior_on_ill_conditioned_kernel_matrices(va, seed, D, N):
         assert relerr(a["L"], b["L"]) < 1e-10
 
 
-@pytest.mark.parametrize("N", [497, 512, 513, 592, 593])
+@pytest.mark.parametrize("N", [497, 512, 513, 560, 561, 592, 593, 1104, 1105])
 def test_posterior_at_the_kernel_switch_points(va, N):
     """N = 512 | 513: the single right-hand-side solve changes kernels (k_alpha_solve1 keeps one vector element per thread of a
-    512-thread workgroup); N = 592 | 593: the Cholesky kernel drops from two panels in LDS to one; 497: a ragged last block."""
+    512-thread workgroup); N = 560 | 561: the Cholesky kernel (with the right-hand side riding along: Np more doubles of LDS) drops
+    from two panels in LDS to one (592 | 593 before round 5); 1104 | 1105: the panel moves to a global scratch block; 497: a ragged
+    last block."""
     p = synth_problem(40 + N, 3, N, 2, 2, meanfun=4, noisy=True)      # condition ~1e3: the tolerances test the kernels, not the problem
     ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4, noisefun=p["noisefun"], s2=p["s2"])
     gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 4, p["noisefun"], p["s2"])
@@ -174,6 +176,23 @@ def test_posterior_at_the_kernel_switch_points(va, N):
     o = va.gplite_pred(gp, Xq, None, None, True)
     r = R.gplite_pred(ref, Xq, ssflag=True)
     assert relerr(o[2], r[2]) < 1e-7 and np.max(np.abs(o[3] - r[3])) < 1e-6 * max(1.0, np.max(np.abs(r[3])))
+
+
+def test_posterior_when_pivots_leave_the_fast_tile_range(va):
+    """The Cholesky kernel's fast diagonal-tile routine (blocked LDL', chol_mfma.h: chol_diag_tile_fast) declines a tile with a pivot
+    outside (2^-200, 2^200) and the careful pivot-by-pivot routine redoes it: a signal variance of e^160 over a noise of e^-6 puts
+    the pivots of K / sn2 + I near 2^240 -- the posterior must still match the oracle (and nothing may be flagged as not positive
+    definite); the same with a tiny signal (pivots stay ~1: the fast path) as the control."""
+    for lnsf in (80.0, -3.0):
+        p = synth_problem(7, 3, 53, 2, 2, meanfun=1, noisy=False)
+        p["hyp"][3, :] = lnsf                       # ln sf
+        p["hyp"][4, :] = -3.0                       # ln sn
+        ref = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=1, noisefun=p["noisefun"], s2=p["s2"])
+        gp = va.gplite_post(p["hyp"], p["X"], p["y"], 1, 1, p["noisefun"], p["s2"])
+        for a, b in zip(gp["post"], ref["post"]):
+            assert a["Lchol"] == b["Lchol"] and a["sn2_mult"] == b["sn2_mult"] == 1.0
+            assert relerr(a["L"], b["L"]) < 1e-10, (lnsf, relerr(a["L"], b["L"]))
+            assert relerr(a["alpha"], b["alpha"]) < 1e-6, (lnsf, relerr(a["alpha"], b["alpha"]))
 
 
 def test_rank1_update_equals_full_posterior(va):

@@ -9,7 +9,7 @@
 //   k_gp_build      A_s = K/(sn2div*mult) + diag(sn2/sn2div)   (Lchol)   or  K + mult*diag(sn2)
 //   k_chol2         (chol_mfma.h) in-place blocked (16) right-looking Cholesky, upper factor, one WG per sample,
 //                   reports MATLAB's p (> 0 = not positive definite) for the jitter retry
-//   k_gp_resid      r = y - m(X)
+//   k_gp_scale      scaled, centred inputs and row norms per hyper-sample; r = y - m(X)
 //   k_pred_prep     ell-scaled, sq_dist-centred training inputs per hyper-sample
 //   k_gp_pred       four waves per 16 test points: cross-kernel slab -> fmu = m* + Ks'alpha, V = inv(L')*(sW.*Ks) as
 //                   MFMA products against the precomputed triangular inverse, fs2 = kss - |V|^2
@@ -84,7 +84,7 @@ __device__ inline double gp_meanfun(int meanfun, int D, const double* hm, const 
 
 // A_s for the Cholesky.  Xc[s] holds the scaled, mean-centred inputs a = (X' ./ ell) - mean  (D x N),
 // aa[s][n] = |a_n|^2.  K = sf2 * exp(-max(aa_i + aa_j - 2 a_i.a_j, 0)/2)   (gplite_core.m:52-56)
-// rout != null: the residual r = y - m(X) of the same hyper-sample as well (gplite_core.m:58-65; what k_gp_resid computes).
+// rout != null: the residual r = y - m(X) of the same hyper-sample as well (gplite_core.m:58-65; round 4 had a kernel of its own for it).
 __global__ void __launch_bounds__(256) k_gp_scale(int N, int D, int Nhyp, const double* __restrict__ X,
                                                   const double* __restrict__ hyp, double* __restrict__ Xc,
                                                   double* __restrict__ aa, int moff, int meanfun, const double* __restrict__ y,
@@ -504,21 +504,6 @@ __global__ void __launch_bounds__(256) k_rank1_assemble(int N, const double* __r
       anew[(size_t)s * N1 + N] = -coef;
     }
   }
-}
-
-// r = y - m(X)  per sample
-__global__ void __launch_bounds__(256) k_gp_resid(int N, int D, int Nhyp, int moff, int meanfun,
-                                                  const double* __restrict__ X, const double* __restrict__ y,
-                                                  const double* __restrict__ hyp, double* __restrict__ rout) {
-  const int s = blockIdx.y;
-  const double* hm = hyp + (size_t)s * Nhyp + moff;
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
-    rout[(size_t)s * N + n] = y[n] - gp_meanfun(meanfun, D, hm, X + n, (size_t)N);
-}
-
-__global__ void k_scale_vec(size_t n, int per, const double* __restrict__ scal, int scol, double* __restrict__ v) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = v[i] / scal[(i / per) * 4 + scol];
 }
 
 __global__ void k_negate_copy(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
