@@ -64,6 +64,38 @@ __global__ void __launch_bounds__(512) k_tile_stream(int N, double* A, int mode,
   if (sum == 1.2345e300) out[0] = sum;
 }
 
+// The same stream with 16-byte accesses: a lane takes rows (2 li, 2 li + 1) of a column of a 32 x 16 tile pair (variant 9, modes 2 / 3).
+template <int G>
+__global__ void __launch_bounds__(512) k_tile_stream_x4(int N, double* A, int mode, int passes, double* out) {
+  typedef double d2a __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4, nti = N >> 5, ntj = N >> 4;        // 32-row pairs x 16-column tiles
+  unsigned lob[4];
+  for (int r = 0; r < 4; ++r) lob[r] = (unsigned)(((lg + 4 * r) * N + 2 * li) * 8);
+  char* Ab = reinterpret_cast<char*>(A);
+  double sum = 0.0;
+  for (int p = 0; p < passes; ++p)
+    for (int t = wave * G; t + G <= nti * ntj; t += 8 * G) {
+      d2a c[G][4];
+      unsigned ob[G][4];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int ti = (t + g) % nti, tj = (t + g) / nti;
+        const unsigned tpb = (unsigned)(((tj << 4) * N + (ti << 5)) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ob[g][r] = tpb + lob[r]; c[g][r] = *reinterpret_cast<const d2a*>(Ab + ob[g][r]); }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (mode) { d2a v = c[g][r]; v[0] += 1.0; v[1] += 1.0; *reinterpret_cast<d2a*>(Ab + ob[g][r]) = v; }
+          else sum += c[g][r][0] + c[g][r][1];
+        }
+    }
+  if (sum == 1.2345e300) out[0] = sum;
+}
+
 static double *g_dFinv = nullptr, *g_dpfd = nullptr, *g_drin = nullptr, *g_dzout = nullptr;   // variant 2: the by-products as well
 static hipError_t launch(int variant, int N, int S, double* dA, int* dpf, unsigned char* dact, double* dPg, hipStream_t st) {
   switch (variant) {
@@ -101,6 +133,24 @@ int main(int argc, char** argv) {
         const double bytes = (double)passes * (N / 16) * (N / 16) * 2048.0 * (mode ? 2 : 1);
         printf("tile stream N=%d WGs=%d (same matrix) G=%d %s: %.3f ms  %.1f GB/s per WG\n", N, S, G, mode ? "load+store" : "load only", best,
                bytes / best * 1e-6);
+      }
+    for (int G = 2; G <= 8; G *= 2)
+      for (int mode = 0; mode < 2; ++mode) {
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+          CHECK(hipEventRecord(e0, 0));
+          if (G == 2) hipLaunchKernelGGL((k_tile_stream_x4<2>), dim3(S), dim3(512), 0, 0, N, dA, mode, passes, dout);
+          else if (G == 4) hipLaunchKernelGGL((k_tile_stream_x4<4>), dim3(S), dim3(512), 0, 0, N, dA, mode, passes, dout);
+          else hipLaunchKernelGGL((k_tile_stream_x4<8>), dim3(S), dim3(512), 0, 0, N, dA, mode, passes, dout);
+          CHECK(hipEventRecord(e1, 0));
+          CHECK(hipDeviceSynchronize());
+          float t;
+          CHECK(hipEventElapsedTime(&t, e0, e1));
+          best = std::min(best, t);
+        }
+        const double bytes = (double)passes * (N / 32) * (N / 16) * 4096.0 * (mode ? 2 : 1);
+        printf("tile-PAIR stream (16-byte accesses) N=%d WGs=%d G=%d pairs %s: %.3f ms  %.1f GB/s per WG\n", N, S, G, mode ? "load+store" : "load only",
+               best, bytes / best * 1e-6);
       }
     return 0;
   }

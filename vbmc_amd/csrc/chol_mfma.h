@@ -35,6 +35,9 @@
 #ifndef CH2_PREF      // the next diagonal tile fetched before the panel phase: measured, wave 0's four extra loads in front of its panel
 #define CH2_PREF 0    // tile cost the whole phase 0.5 us per step and saved 0.15 us of look-ahead (profiles/r05_chol.md) -- off
 #endif
+#ifndef CH2_X4        // the trailing update on 32 x 16 tile PAIRS with 16-byte accesses (0: round 2's 16 x 16 tiles, 8-byte accesses)
+#define CH2_X4 1
+#endif
 #ifndef CH2_DEFER     // the diagonal tile / block inverse stored in the NEXT step's panel phase instead of on the look-ahead's path
 #define CH2_DEFER CH2_FAST
 #endif
@@ -625,8 +628,110 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       // FAST groups lie entirely in full tile columns (16 (tj + 1) <= ntr): no masks -- the entries below the diagonal of a
       // diagonal tile are updated like the rest (they hold whatever the builder left there, nobody reads them, and the
       // strict lower triangle is zeroed at the end).
-      const int STRIDE = CH2_G * UW;
       const int ntf = ntr >> 4;
+      if (CH2_X4) {
+      // Round 5: ONE compute unit streams 16 x 16 tiles through the L2 at 65 GB/s with 8-byte accesses and at 125-135 GB/s with
+      // 16-byte accesses (tools/chol_bench.hip 9: the memory pipe's rate is per instruction) -- and this phase is that stream.  A
+      // lane now takes rows (2 li, 2 li + 1) of a column of a 32 x 16 tile PAIR (tiles ti = 2 p, 2 p + 1 of block column tj) in one
+      // 16-byte access: the even rows are one MFMA tile, the odd rows the other -- the row permutation only changes which panel
+      // column a lane feeds as the B operand (i0 + 2 li, i0 + 2 li + 1).  Block column tj has (tj + 1) / 2 pairs; with tj even its
+      // diagonal tile is left over and goes tile by tile (as does a ragged last column).  Pairs v = 0, 1, ... run down the
+      // columns from column 1 (column 0 is the look-ahead's tile); H(2 m) = m^2, H(2 m + 1) = m (m + 1) pairs lie before a column.
+      typedef double d2x __attribute__((ext_vector_type(2), aligned(8)));
+      const int vfast = (ntf & 1) ? (ntf >> 1) * ((ntf >> 1) + 1) : (ntf >> 1) * (ntf >> 1);     // H(ntf): pairs in the full columns
+      unsigned lob2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lob2[r] = (unsigned)(((lg + 4 * r) * N + 2 * li) * 8);
+      const char* Ab = reinterpret_cast<const char*>(At);
+      const int PSTR = 2 * UW;                                   // two pairs (four tiles' worth of registers) per wave and round
+      int v0 = 2 * uslot, pp, tj;
+      {
+        int m = (int)sqrtf((float)v0);
+        m += ((m + 1) * (m + 1) <= v0) ? 1 : 0;
+        m -= (m * m > v0) ? 1 : 0;
+        if (v0 < m * (m + 1)) { tj = 2 * m; pp = v0 - m * m; } else { tj = 2 * m + 1; pp = v0 - m * (m + 1); }
+      }
+      auto padvance = [&](int by) { pp += by; while (pp >= ((tj + 1) >> 1)) { pp -= (tj + 1) >> 1; ++tj; } };
+      auto pgroup = [&]() {
+        d2x c[2][4];
+        unsigned ob[2][4];
+        int i0_[2], j0_[2];
+        CH2_GSTAMP(0);
+        {
+          int a = pp, b = tj;
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            i0_[g] = a << 5; j0_[g] = b << 4;
+            const unsigned tpb = (unsigned)((j0_[g] * N + i0_[g]) * 8);   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              ob[g][r] = tpb + lob2[r];
+              c[g][r] = *reinterpret_cast<const d2x*>(Ab + ob[g][r]);
+            }
+            const bool wrap = a + 1 >= ((b + 1) >> 1);
+            a = wrap ? 0 : a + 1;
+            b += wrap ? 1 : 0;
+          }
+        }
+        CH2_GSTAMP(1);
+        d4_t ae[2], ao[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { ae[g] = (d4_t){0.0, 0.0, 0.0, 0.0}; ao[g] = (d4_t){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+        for (int pn = 0; pn < (TWO ? 2 : 1); ++pn) {
+          const int buf = TWO ? 1 - pn : 0, sh = (TWO && pn == 1) ? 16 : 0;   // panel B first (its columns start at this step's t0)
+          d4v pj[2], pe[2], po[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            pj[g] = ldP4(buf, lg, sh + j0_[g] + li);
+            pe[g] = ldP4(buf, lg, sh + i0_[g] + 2 * li);
+            po[g] = ldP4(buf, lg, sh + i0_[g] + 2 * li + 1);
+          }
+          if (pn == 0) CH2_GSTAMP(2);
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              ae[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[g][q], pe[g][q], ae[g], 0, 0, 0);
+              ao[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pj[g][q], po[g][q], ao[g], 0, 0, 0);
+            }
+        }
+        CH2_GSTAMP(3);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            d2x v = c[g][r];
+            v[0] -= ae[g][r]; v[1] -= ao[g][r];
+            *reinterpret_cast<d2x*>(const_cast<char*>(Ab) + ob[g][r]) = v;
+          }
+        CH2_GSTAMP(4);
+      };
+      for (; v0 + 2 <= vfast; v0 += PSTR, padvance(PSTR)) pgroup();
+      // left over, tile by tile with masks, dealt round-robin: a last pair of the full columns (vfast odd), the diagonal tiles of the
+      // even full columns (2, 4, ...; column 0's is the look-ahead's), every tile of a ragged last column
+      {
+        int k = 0;
+        if (vfast & 1) {
+          if ((k++ % UW) == uslot) {
+            const int vl = vfast - 1;
+            int m = (int)sqrtf((float)vl);
+            m += ((m + 1) * (m + 1) <= vl) ? 1 : 0;
+            m -= (m * m > vl) ? 1 : 0;
+            int tjl, pl;
+            if (vl < m * (m + 1)) { tjl = 2 * m; pl = vl - m * m; } else { tjl = 2 * m + 1; pl = vl - m * (m + 1); }
+            tile_masked(2 * pl, tjl, true);
+            tile_masked(2 * pl + 1, tjl, true);
+          }
+        }
+        for (int c2 = 2; c2 < ntf; c2 += 2)
+          if ((k++ % UW) == uslot) tile_masked(c2, c2, true);
+        if (ntr & 15)
+          for (int a = 0; a <= ntf; ++a)
+            if ((k++ % UW) == uslot) tile_masked(a, ntf, true);
+      }
+      } else {
+      const int STRIDE = CH2_G * UW;
       const int ufast = ntf * (ntf + 1) / 2;
       unsigned lob[4];                          // byte offset of this lane's element in register r of a tile
 #pragma unroll
@@ -700,6 +805,7 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
           a = wrap ? 0 : a + 1;
           b += wrap ? 1 : 0;
         }
+      }
       }
       }
     }
