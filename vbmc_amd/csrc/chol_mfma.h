@@ -482,6 +482,13 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
         rv[q] = (4 * q + lg <= li) ? Dgc[(4 * q + lg) * 17 + li] : 0.0;    // A operand: Rkk'[t = li][u = 4q + lg] (lower triangular)
       }
       constexpr int PT = CH2_W >= 16 ? 2 : 3;                              // tiles in flight per wave
+      // the row block through a wave-uniform base + one 32-bit byte offset per element (N <= 10208: N^2 * 8 < 2^32): with 64-bit
+      // addresses per element the compiler, short of registers in this kernel, loaded INTO the address registers and waited for
+      // each load in turn (up to four L2 round trips per tile triple, +0.5 us on every panel phase; profiles/r05_chol.md)
+      // (buffer accesses: base and extent in four SGPRs, ONE VGPR of offset per element, an offset past the extent reads 0 /
+      // drops the store -- no masks on the data, no branches around the stores)
+      const __amdgpu_buffer_rsrc_t Arow = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(A + (size_t)kb + (size_t)N * t0), 0, (int)(((size_t)N * N - ((size_t)kb + (size_t)N * t0)) * 8), 0x00020000);
       for (int tb = wave; tb < nt; tb += PT * CH2_W) {
         double bv[PT][4];
 #pragma unroll
@@ -491,8 +498,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
           for (int q = 0; q < 4; ++q) {
             const int u = 4 * q + lg;
             const bool ok = tj < nt && u < nb && j < ntr;
-            const double v = A[ok ? (size_t)(kb + u) + (size_t)N * (t0 + j) : 0];
-            bv[p][q] = ok ? v : 0.0;
+            const unsigned off = ok ? (unsigned)((u + N * j) * 8) : 0xfffffff0u;
+            bv[p][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Arow, (int)off, 0, 0));
           }
         }
 #pragma unroll
@@ -517,7 +524,9 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int t = lg + 4 * r;
-              if (t < nb && j < ntr) A[(size_t)(kb + t) + (size_t)N * (t0 + j)] = acc[r];
+              const unsigned off = (t < nb && j < ntr) ? (unsigned)((t + N * j) * 8) : 0xfffffff0u;
+              typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, (double)acc[r]), Arow, (int)off, 0, 0);
             }
           }
         }
@@ -643,6 +652,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) lob2[r] = (unsigned)(((lg + 4 * r) * N + 2 * li) * 8);
       const char* Ab = reinterpret_cast<const char*>(At);
+      const __amdgpu_buffer_rsrc_t Atr = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)At, 0, (int)(((size_t)N * N - ((size_t)t0 + (size_t)N * t0)) * 8), 0x00020000);
       const int PSTR = 2 * UW;                                   // two pairs (four tiles' worth of registers) per wave and round
       int v0 = 2 * uslot, pp, tj;
       {
@@ -703,7 +714,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
           for (int r = 0; r < 4; ++r) {
             d2x v = c[g][r];
             v[0] -= ae[g][r]; v[1] -= ao[g][r];
-            *reinterpret_cast<d2x*>(const_cast<char*>(Ab) + ob[g][r]) = v;
+            typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), Atr, (int)ob[g][r], 0, 0);   // (SGPR base: no 64-bit address per store)
           }
         CH2_GSTAMP(4);
       };
