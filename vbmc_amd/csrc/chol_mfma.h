@@ -38,6 +38,9 @@
 #ifndef CH2_X4        // the trailing update on 32 x 16 tile PAIRS with 16-byte accesses (0: round 2's 16 x 16 tiles, 8-byte accesses)
 #define CH2_X4 1
 #endif
+#ifndef CH2_JOIN      // the look-ahead wave joins a large update from its third round of groups on
+#define CH2_JOIN 1
+#endif
 #ifndef CH2_DEFER     // the diagonal tile / block inverse stored in the NEXT step's panel phase instead of on the look-ahead's path
 #define CH2_DEFER CH2_FAST
 #endif
@@ -600,7 +603,10 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
     const bool idle4 = CH2_IDLE4 && !((!TWO || pbuf == 1) && npair > 48);
     const int UW = CH2_W - (idle4 ? 2 : 1);                              // waves that update
     const int uslot = (idle4 && wave > 4) ? wave - 2 : wave - 1;         // their index 0 .. UW - 1
-    if (wave > 0 && !(idle4 && wave == 4)) {
+    // Round 5: in a large update the look-ahead wave does not sit out the rest of the phase: from the third round of groups on
+    // (its look-ahead takes about two) wave 0 is one more slot of the deal.
+    const bool joins = CH2_X4 && CH2_JOIN && !idle4 && wave == 0;
+    if ((wave > 0 && !(idle4 && wave == 4)) || joins) {
       // one tile with masks: ragged edges, diagonal tiles of the slow path, the row block of an A step
       auto tile_masked = [&](int a, int b, bool both) {
         const int i0 = a << 4, j0 = b << 4, i = i0 + li, jb = j0 + lg;
@@ -655,7 +661,8 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
       const __amdgpu_buffer_rsrc_t Atr = __builtin_amdgcn_make_buffer_rsrc(
           (void*)At, 0, (int)(((size_t)N * N - ((size_t)t0 + (size_t)N * t0)) * 8), 0x00020000);
       const int PSTR = 2 * UW;                                   // two pairs (four tiles' worth of registers) per wave and round
-      int v0 = 2 * uslot, pp, tj;
+      const bool late = CH2_JOIN && !idle4;                     // rounds 0, 1: UW slots; from round 2 on UW + 1 (wave 0 = slot UW)
+      int v0 = joins ? 2 * 3 * UW : 2 * uslot, pp, tj;
       {
         int m = (int)sqrtf((float)v0);
         m += ((m + 1) * (m + 1) <= v0) ? 1 : 0;
@@ -719,7 +726,11 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
           }
         CH2_GSTAMP(4);
       };
-      for (; v0 + 2 <= vfast; v0 += PSTR, padvance(PSTR)) pgroup();
+      for (int n = joins ? 2 : 0; v0 + 2 <= vfast; ++n) {
+        pgroup();
+        const int by = (late && n >= 2) ? PSTR + 2 : PSTR;
+        v0 += by; padvance(by);
+      }
       // left over, tile by tile with masks, dealt round-robin: a last pair of the full columns (vfast odd), the diagonal tiles of the
       // even full columns (2, 4, ...; column 0's is the look-ahead's), every tile of a ragged last column
       {
