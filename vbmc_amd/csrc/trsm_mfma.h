@@ -437,12 +437,14 @@ static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const 
                                             const unsigned char* lchol, double* T, int transposed) {
   const int cw = trsm_cw_for(N);
   if (cw == 0) return hipErrorInvalidValue;
-  // few slabs (a handful of matrices): the latency-shaped kernel; many: one wave per slab keeps every SIMD busy anyway
+  // the workgroup-per-slab kernel whenever the slab's row blocks fit its accumulator registers (N <= 1024) -- built for the latency
+  // of a handful of matrices, it is also 17 % of a whole gplite_nlZ batch faster at 64 and 256 matrices (78 -> 91 k, 133 -> 157 k
+  // evals/s: the one-wave kernel runs at a tenth of the matrix-pipe rate); VBMC_TRI2=0: the one-wave kernel (A/B)
   {
-    static const int force = getenv("VBMC_TRI2") ? atoi(getenv("VBMC_TRI2")) : -1;    // 0: never, 1: whenever it fits
+    static const int force = getenv("VBMC_TRI2") ? atoi(getenv("VBMC_TRI2")) : -1;
     const int nblk = TRSM_NBLK(N);
     const bool fits = nblk <= TRI2_W * 8;
-    const bool want = force < 0 ? (size_t)S * nblk <= 1024 : force != 0;
+    const bool want = force != 0;
     if (fits && want) {
       if (nblk <= TRI2_W * 4) hipLaunchKernelGGL((k_tri_inverse2<4>), dim3(nblk, S, 1), dim3(64 * TRI2_W), 0, st, N, S, Lall, Finv, lchol, T, transposed);
       else hipLaunchKernelGGL((k_tri_inverse2<8>), dim3(nblk, S, 1), dim3(64 * TRI2_W), 0, st, N, S, Lall, Finv, lchol, T, transposed);
