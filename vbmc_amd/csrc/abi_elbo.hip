@@ -516,7 +516,7 @@ struct ElboPlan {
   double *d_theta = nullptr, *d_fix = nullptr, *d_delta2 = nullptr, *d_bnd = nullptr;
   double *d_ljbar = nullptr;
   double *d_vpd = nullptr, *d_entp = nullptr, *d_lj = nullptr, *d_out = nullptr, *d_part = nullptr, *d_red = nullptr;
-  double *d_Z = nullptr, *d_X = nullptr, *d_J = nullptr, *d_vg = nullptr, *d_var = nullptr;
+  double *d_Z = nullptr, *d_X = nullptr, *d_J = nullptr, *d_vg = nullptr, *d_var = nullptr, *d_vs = nullptr;   // d_vs: per-sample gradient vectors (k_var_sample)
   const double* d_eps = nullptr;
   double* out_direct = nullptr;   // the pinned result block itself: the finalize kernel writes the records there (small pipelined passes)
   long long eps_stride_r = 0;
@@ -797,12 +797,14 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
       }
     }
     P.needX = P.vgrad || P.any_nochol || P.tri_gemm;
-    { vbmc_status s_ = ensure(ctx, ctx->varbuf, ((P.needX ? nz : 0) + nJ + nvg + nvo) * sizeof(double)); if (s_) return s_; }
+    const size_t nvs = P.vgrad ? (size_t)R * S * 2 * (size_t)dm.T : 0;
+    { vbmc_status s_ = ensure(ctx, ctx->varbuf, ((P.needX ? nz : 0) + nJ + nvg + nvo + nvs) * sizeof(double)); if (s_) return s_; }
     P.d_Z = (double*)ctx->zbuf.p;
     P.d_X = (double*)ctx->varbuf.p;
     P.d_J = P.d_X + (P.needX ? nz : 0);
     P.d_vg = P.d_J + nJ;
     P.d_var = P.d_vg + nvg;
+    P.d_vs = P.d_var + nvo;
   }
   return VBMC_OK;
 }
@@ -1104,7 +1106,14 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     va.dm = dm; va.vpd = P.d_vpd; va.gpc = gp->gpc; va.delta2 = P.d_delta2; va.lj = P.d_lj; va.J = P.d_J;
     va.vg = P.vgrad ? P.d_vg : nullptr; va.compute_var = P.compute_var; va.want_grad = P.compute_grad; va.stride = P.var_stride;
     va.out = P.d_var;
-    va.no_jacobian = P.no_jacobian; va.dvs_out = P.d_dvs;
+    va.no_jacobian = P.no_jacobian; va.dvs_out = P.d_dvs; va.vs = P.d_vs;
+    if (P.vgrad) {
+      const size_t slds = VAR_SAMPLE_LDS(K, T);
+      if (slds > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+      hipLaunchKernelGGL(k_var_sample, dim3(S, R), dim3(VARSMP_THREADS), slds, st, va);
+      LAUNCH_CHECK(ctx, "k_var_sample");
+    }
     const size_t vlds = VAR_FINAL_LDS(S, K, P.compute_grad ? T : 0);
     if (vlds > 64 * 1024)
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_var_final, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));

@@ -407,7 +407,102 @@ struct VarFinArgs {
   double* out;
   int no_jacobian;     // 1: the variance gradient with respect to sigma, lambda, w themselves (misc/gplogjoint.m:375-396 skipped)
   double* dvs_out;     // null, or R x S x T: the per-hyper-sample variance gradient dvarF(:, s) (avg_flag = 0: :407-409 skipped)
+  double* vs;          // R x S x 2 x T scratch: per hyper-sample dF(:, s) and dvarF(:, s) after the Jacobians (k_var_sample -> k_var_final)
 };
+
+// k_var_sample (round 5): the per-hyper-sample gradients dF(:, s) and dvarF(:, s) with their Jacobians (misc/gplogjoint.m:286-303,
+// 352-390), one workgroup per (hyper-sample, restart).  They were a loop over s inside k_var_final's single workgroup per restart --
+// seven barriers and half a dozen dependent round trips to memory per sample, S = 20 times in a row: 464 us of a 0.95 ms
+// evaluation at the headline GP shape.  k_var_final now only adds the S vectors up (in sample order).
+#define VARSMP_THREADS 256
+__global__ void __launch_bounds__(VARSMP_THREADS) k_var_sample(VarFinArgs a) {
+  extern __shared__ double lds[];
+  const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+  const ElboDims& dm = a.dm;
+  const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
+  const double EPS = 2.220446049250313e-16;
+  VpLayout L{D, K};
+  const double* v = a.vpd + (size_t)r * L.stride();
+  const double* w = v + L.w();
+  const double* sigma = v + L.sigma();
+  const double* lam = v + L.lambda();
+  double* red = lds;          // nt
+  double* dFs = red + nt;     // T
+  double* dvs = dFs + T;      // T
+  double* tmpK = dvs + T;     // K
+  double* tmpK2 = tmpK + K;   // K
+  const int LJS = 2 * D + 2;
+  const double* lj = a.lj + (size_t)r * S * K * LJS;
+  const double* Js = a.J + ((size_t)r * S + s) * K * K;
+  const bool jac = a.no_jacobian == 0;
+  const double* g = a.gpc + (size_t)s * GPC_STRIDE(D);
+  const double* vg = a.vg + ((size_t)r * S + s) * (size_t)K * (2 * D + 1);
+  for (int i = tid; i < T; i += nt) { dFs[i] = 0.0; dvs[i] = 0.0; }
+  __syncthreads();
+  // per-sample value gradient dF(:,s) after Jacobians (:352-373)
+  if (dm.opt[0]) for (int p = tid; p < D * K; p += nt) dFs[dm.off_mu + p] = lj[((size_t)s * K + p / D) * LJS + 1 + p % D];
+  if (dm.opt[1]) for (int k = tid; k < K; k += nt) dFs[dm.off_sigma + k] = lj[((size_t)s * K + k) * LJS + 1 + D] * (jac ? sigma[k] : 1.0);
+  if (dm.opt[2])
+    for (int d = tid; d < D; d += nt) {
+      double ls = 0.0;
+      for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
+      dFs[dm.off_lambda + d] = ls * (jac ? lam[d] : 1.0);
+    }
+  // variance gradient pieces (:286-303)
+  if (dm.opt[0])
+    for (int p = tid; p < D * K; p += nt) {
+      int d = p % D, k = p / D;
+      dvs[dm.off_mu + p] = -w[k] * w[k] * (2.0 * vg[(size_t)k * (2 * D + 1) + d]);  // :289
+    }
+  // nf_kk and sum_d lambda_d^2 / tau_kk,d^2 once per component (:274-275,293)
+  for (int k = tid; k < K; k += nt) {
+    double slt = 0.0, sl2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
+      slt += log(sqrt(t2));
+      sl2 += lam[d] * lam[d] / t2;
+    }
+    tmpK[k] = exp(g[3 * D] - slt);
+    tmpK2[k] = sl2;
+  }
+  __syncthreads();
+  if (dm.opt[1])
+    for (int k = tid; k < K; k += nt)
+      dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * tmpK[k] * tmpK2[k] + vg[(size_t)k * (2 * D + 1) + D]) * (jac ? sigma[k] : 1.0);  // :293, Jacobian :382
+  if (dm.opt[2])
+    for (int d = tid; d < D; d += nt) {
+      double accd = 0.0;
+      for (int k = 0; k < K; ++k) {
+        double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
+        accd -= 2.0 * w[k] * w[k] * (sigma[k] * sigma[k] * tmpK[k] * lam[d] / t2 + vg[(size_t)k * (2 * D + 1) + D + 1 + d]);  // :297
+      }
+      dvs[dm.off_lambda + d] = accd * (jac ? lam[d] : 1.0);  // Jacobian :386
+    }
+  __syncthreads();
+  if (dm.opt[3]) {
+    // softmax Jacobian on w_grad = I_k and on w_vargrad = 2 w_k max(eps, J_kk)  (:301, :366-372, :390)
+    double p1 = 0.0, p2 = 0.0;
+    for (int k = tid; k < K; k += nt) {
+      double ik = lj[((size_t)s * K + k) * LJS];
+      double wv = 2.0 * w[k] * fmax(EPS, Js[k + (size_t)K * k]);
+      tmpK[k] = wv;
+      p1 += w[k] * ik;
+      p2 += w[k] * wv;
+    }
+    double d1 = block_sum(p1, red);
+    double d2 = block_sum(p2, red);
+    for (int k = tid; k < K; k += nt) {
+      double ik = lj[((size_t)s * K + k) * LJS];
+      dFs[dm.off_eta + k] = jac ? w[k] * ik - w[k] * d1 : ik;
+      dvs[dm.off_eta + k] = jac ? w[k] * tmpK[k] - w[k] * d2 : tmpK[k];
+    }
+  }
+  __syncthreads();
+  double* o = a.vs + ((size_t)r * S + s) * 2 * (size_t)T;
+  for (int i = tid; i < T; i += nt) { o[i] = dFs[i]; o[T + i] = dvs[i]; }
+  if (a.dvs_out) for (int i = tid; i < T; i += nt) a.dvs_out[((size_t)r * S + s) * T + i] = dvs[i];
+}
+#define VAR_SAMPLE_LDS(K, T) ((size_t)(VARSMP_THREADS + 2 * (size_t)(T) + 2 * (size_t)(K)) * sizeof(double))
 
 #define VARFIN_THREADS 1024
 __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
@@ -419,27 +514,18 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
   VpLayout L{D, K};
   const double* v = a.vpd + (size_t)r * L.stride();
   const double* w = v + L.w();
-  const double* sigma = v + L.sigma();
-  const double* lam = v + L.lambda();
   double* red = lds;          // nt
   double* Fs = red + nt;      // S
   double* vFs = Fs + S;       // S
-  const int Tg = a.want_grad ? T : 0;   // the five gradient vectors exist only when a gradient is wanted (host sizing follows)
-  double* dFs = vFs + S;      // T  per-sample gradient (after Jacobians), reused per s
-  double* dvs = dFs + Tg;     // T  per-sample variance gradient
-  double* acc1 = dvs + Tg;    // T  sum_s dvarF(:,s)
+  const int Tg = a.want_grad ? T : 0;   // the gradient vectors exist only when a gradient is wanted (host sizing follows: five T-vectors)
+  double* acc1 = vFs + S;     // T  sum_s dvarF(:,s)
   double* acc2 = acc1 + Tg;   // T  sum_s F(s) dF(:,s)
   double* acc3 = acc2 + Tg;   // T  sum_s dF(:,s)
-  double* tmpK = acc3 + Tg;   // K
-  double* tmpK2 = tmpK + K;   // K
   const int LJS = 2 * D + 2;
   const double* lj = a.lj + (size_t)r * S * K * LJS;
   const double* Jr = a.J + (size_t)r * S * K * K;
   double* o = a.out + (size_t)r * a.stride;
   const bool vgrad = a.want_grad && a.compute_var == 2;
-  const bool jac = a.no_jacobian == 0;
-  for (int i = tid; i < T; i += nt) { acc1[i] = 0.0; acc2[i] = 0.0; acc3[i] = 0.0; }
-  __syncthreads();
   // ---- per-hyper-sample F(s) and varF(s) (:203, :283, :329-332, :350): the S samples are independent, one WAVE each (16 at a
   // time), lanes along the component pairs, fixed-order wave butterfly -- instead of S sequential workgroup-wide reductions
   // (a single full-ELCBO evaluation spent 0.26-0.39 ms of its 0.72 ms here)
@@ -479,79 +565,24 @@ __global__ void __launch_bounds__(VARFIN_THREADS) k_var_final(VarFinArgs a) {
     }
   }
   __syncthreads();
-  for (int s = 0; s < S && vgrad; ++s) {
-    const double* Js = Jr + (size_t)s * K * K;
-    if (vgrad) {
-      const double* g = a.gpc + (size_t)s * GPC_STRIDE(D);
-      const double* vg = a.vg + ((size_t)r * S + s) * (size_t)K * (2 * D + 1);
-      for (int i = tid; i < T; i += nt) { dFs[i] = 0.0; dvs[i] = 0.0; }
-      __syncthreads();
-      // per-sample value gradient dF(:,s) after Jacobians (:352-373)
-      if (dm.opt[0]) for (int p = tid; p < D * K; p += nt) dFs[dm.off_mu + p] = lj[((size_t)s * K + p / D) * LJS + 1 + p % D];
-      if (dm.opt[1]) for (int k = tid; k < K; k += nt) dFs[dm.off_sigma + k] = lj[((size_t)s * K + k) * LJS + 1 + D] * (jac ? sigma[k] : 1.0);
-      if (dm.opt[2])
-        for (int d = tid; d < D; d += nt) {
-          double ls = 0.0;
-          for (int k = 0; k < K; ++k) ls += lj[((size_t)s * K + k) * LJS + 2 + D + d];
-          dFs[dm.off_lambda + d] = ls * (jac ? lam[d] : 1.0);
+  if (vgrad) {
+    // sum_s dvarF(:, s), sum_s F(s) dF(:, s), sum_s dF(:, s) from k_var_sample's vectors, in sample order, eight loads in flight
+    const double* vsr = a.vs + (size_t)r * S * 2 * (size_t)T;
+    for (int i = tid; i < T; i += nt) {
+      double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int s0 = 0; s0 < S; s0 += 4) {
+        double df[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = s0 + u < S;
+          df[u] = ok ? vsr[(size_t)(s0 + u) * 2 * T + i] : 0.0;
+          dv[u] = ok ? vsr[(size_t)(s0 + u) * 2 * T + T + i] : 0.0;
         }
-      // variance gradient pieces (:286-303)
-      if (dm.opt[0])
-        for (int p = tid; p < D * K; p += nt) {
-          int d = p % D, k = p / D;
-          dvs[dm.off_mu + p] = -w[k] * w[k] * (2.0 * vg[(size_t)k * (2 * D + 1) + d]);  // :289
-        }
-      // nf_kk and sum_d lambda_d^2 / tau_kk,d^2 once per component (:274-275,293)
-      for (int k = tid; k < K; k += nt) {
-        double slt = 0.0, sl2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-          double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
-          slt += log(sqrt(t2));
-          sl2 += lam[d] * lam[d] / t2;
-        }
-        tmpK[k] = exp(g[3 * D] - slt);
-        tmpK2[k] = sl2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (s0 + u < S) { a1 += dv[u]; a2 += Fs[s0 + u] * df[u]; a3 += df[u]; }
       }
-      __syncthreads();
-      if (dm.opt[1])
-        for (int k = tid; k < K; k += nt)
-          dvs[dm.off_sigma + k] = -2.0 * w[k] * w[k] * (sigma[k] * tmpK[k] * tmpK2[k] + vg[(size_t)k * (2 * D + 1) + D]) * (jac ? sigma[k] : 1.0);  // :293, Jacobian :382
-      if (dm.opt[2])
-        for (int d = tid; d < D; d += nt) {
-          double accd = 0.0;
-          for (int k = 0; k < K; ++k) {
-            double t2 = 2.0 * sigma[k] * sigma[k] * lam[d] * lam[d] + g[d] + 2.0 * a.delta2[d];
-            accd -= 2.0 * w[k] * w[k] * (sigma[k] * sigma[k] * tmpK[k] * lam[d] / t2 + vg[(size_t)k * (2 * D + 1) + D + 1 + d]);  // :297
-          }
-          dvs[dm.off_lambda + d] = accd * (jac ? lam[d] : 1.0);  // Jacobian :386
-        }
-      __syncthreads();
-      if (dm.opt[3]) {
-        // softmax Jacobian on w_grad = I_k and on w_vargrad = 2 w_k max(eps, J_kk)  (:301, :366-372, :390)
-        double p1 = 0.0, p2 = 0.0;
-        for (int k = tid; k < K; k += nt) {
-          double ik = lj[((size_t)s * K + k) * LJS];
-          double wv = 2.0 * w[k] * fmax(EPS, Js[k + (size_t)K * k]);
-          tmpK[k] = wv;
-          p1 += w[k] * ik;
-          p2 += w[k] * wv;
-        }
-        double d1 = block_sum(p1, red);
-        double d2 = block_sum(p2, red);
-        for (int k = tid; k < K; k += nt) {
-          double ik = lj[((size_t)s * K + k) * LJS];
-          dFs[dm.off_eta + k] = jac ? w[k] * ik - w[k] * d1 : ik;
-          dvs[dm.off_eta + k] = jac ? w[k] * tmpK[k] - w[k] * d2 : tmpK[k];
-        }
-      }
-      __syncthreads();
-      double fsv = Fs[s];
-      if (a.dvs_out) for (int i = tid; i < T; i += nt) a.dvs_out[((size_t)r * S + s) * T + i] = dvs[i];
-      for (int i = tid; i < T; i += nt) {
-        acc1[i] += dvs[i];
-        acc2[i] += fsv * dFs[i];
-        acc3[i] += dFs[i];
-      }
+      acc1[i] = a1; acc2[i] = a2; acc3[i] = a3;
     }
     __syncthreads();
   }
