@@ -248,8 +248,13 @@ __global__ void __launch_bounds__(64) k_trsm_bwd(int N, int K, int S, const doub
 }
 
 // host side: the slab solves with the slab width that fits N (one wave per CW columns, hyper-sample s, restart r)
+template <bool BWD>
+static inline hipError_t trsm2_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
+                                      const unsigned char* lchol, const double* Zin, double* Zout);
+static inline bool trsm2_wanted(int N);
 static inline hipError_t trsm_fwd_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
                                          const unsigned char* lchol, double* Z) {
+  if (trsm2_wanted(N)) return trsm2_launch<false>(st, N, K, S, R, Lall, Finv, lchol, Z, Z);
   const int cw = trsm_cw_for(N);
   if (cw == 0) return hipErrorInvalidValue;
   TRSM_DISPATCH_CW(cw, {
@@ -264,6 +269,7 @@ static inline hipError_t trsm_fwd_launch(hipStream_t st, int N, int K, int S, in
 }
 static inline hipError_t trsm_bwd_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
                                          const unsigned char* lchol, const double* Vin, double* Xo) {
+  if (trsm2_wanted(N)) return trsm2_launch<true>(st, N, K, S, R, Lall, Finv, lchol, Vin, Xo);
   const int cw = trsm_cw_for(N);
   if (cw == 0) return hipErrorInvalidValue;
   TRSM_DISPATCH_CW(cw, {
@@ -431,6 +437,149 @@ __global__ void __launch_bounds__(64 * TRI2_W, 2) k_tri_inverse2(int N, int S, c
   tri_inverse2_body<MAXS, (MAXS <= 4 ? 4 : 2)>(N, cb, s, Lall, Finv, T, transposed);
 }
 static inline bool tri_inverse2_fits(int N) { return TRSM_NBLK(N) <= TRI2_W * 8; }
+
+// The general slab solves in the same shape (round 5): R' V = Z (BWD = false) and R X = V (BWD = true) for 16 right-hand sides per
+// workgroup of TRI2_W waves, the slab's row blocks in accumulator registers, V_b / X_b through a double-buffered 2 KB of LDS, tiles of
+// R fetched DEPTH steps ahead.  Forward: blocks 0, 1, ... (wave w owns blocks w, w + 8, ...), update acc_i -= R[b, i]' V_b with the
+// tile read as one 32-byte vector per lane (rows b0 + 4 lg .. + 3 of column i0 + li: the inner index permuted, the LDS read of V_b
+// permuted to match).  Backward: blocks nblk - 1, nblk - 2, ... (wave w owns nblk - 1 - w, nblk - 9 - w, ...), update
+// acc_i -= R[i, b] X_b with the tile's four columns 4 u + lg per lane (16 consecutive rows across li: one cache line per column),
+// the block inverse transposed (R_bb^-1 = Finv_b').  Z is [r][s][k][N] (column k of the right-hand sides contiguous), in place or
+// into Xo.  One-wave-per-slab kernels k_trsm_fwd / k_trsm_bwd: 144 / 178 us at N = 400 (5.8 / 7.1 us per block step).
+template <int MAXS, int DEPTH, bool BWD>
+__device__ __forceinline__ void trsm2_body(int N, int K, int k0, const double* __restrict__ R, const double* __restrict__ Fi,
+                                           const double* __restrict__ Zin, double* __restrict__ Zout) {
+  static_assert(TRI2_W % DEPTH == 0, "the tile ring is indexed by the step modulo DEPTH");
+  __shared__ double Vb[2][16 * 17];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = (N + 15) >> 4;
+  typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+  const int col = k0 + li;                                      // this lane's right-hand side
+  tmf4 acc[MAXS], pre[DEPTH][MAXS];
+  // step st = 0, 1, ... handles block blk(st) = st (forward) / nblk - 1 - st (backward); wave w owns the steps w, w + 8, ...
+  auto blk = [&](int st) { return BWD ? nblk - 1 - st : st; };
+#pragma unroll
+  for (int sl = 0; sl < MAXS; ++sl) {
+    const int st = wave + TRI2_W * sl, b = blk(st);
+    tmf4 v = {0.0, 0.0, 0.0, 0.0};
+    if (st < nblk && col < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (b << 4) + 4 * r + lg;
+        v[r] = row < N ? Zin[(size_t)col * N + row] : 0.0;
+      }
+    }
+    acc[sl] = v;
+  }
+  // tiles for step st: the A operands of this wave's blocks still to come
+  auto fetch = [&](int st, tmf4 (&pr)[MAXS]) {
+    const int b = blk(st);
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+      const int sti = wave + TRI2_W * sl, i = blk(sti);        // wave-uniform
+      tmf4 v = {0.0, 0.0, 0.0, 0.0};
+      if (sti > st && sti < nblk && st < nblk) {
+        if (!BWD) {
+          const int c = (i << 4) + li;                          // R[b0 + 4 lg + u][i0 + li], u = 0 .. 3 (block b is not the last: its rows exist)
+          if (c < N) {
+            const d4u t = *reinterpret_cast<const d4u*>(R + (size_t)c * N + (b << 4) + 4 * lg);
+            v = (tmf4){t[0], t[1], t[2], t[3]};
+          }
+        } else {
+          const int row = (i << 4) + li;                        // R[i0 + li][b0 + 4 u + lg], u = 0 .. 3 (block i is not the last: its rows exist)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = (b << 4) + 4 * u + lg;
+            v[u] = c < N ? R[(size_t)c * N + row] : 0.0;
+          }
+        }
+      }
+      pr[sl] = v;
+    }
+  };
+  double fv[4];      // block inverse as the A operand: forward Finv_b[li][k], backward Finv_b[k][li]
+  auto fetch_fv = [&](int st) {
+    const int b = blk(st);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fv[u] = st < nblk ? (BWD ? Fi[(size_t)b * 256 + (4 * u + lg) * 16 + li] : Fi[(size_t)b * 256 + li * 16 + 4 * u + lg]) : 0.0;
+  };
+  fetch_fv(wave);
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) fetch(q, pre[q]);
+  bool done = false;
+#pragma unroll
+  for (int sb = 0; sb < MAXS; ++sb) {
+    for (int ow0 = 0; ow0 < TRI2_W && !done; ow0 += DEPTH) {
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q) {
+        const int ow = ow0 + q;
+        const int st = sb * TRI2_W + ow, b = blk(st), b0 = b << 4;
+        if (st >= nblk) { done = true; }
+        if (!done) {
+          double* Vw = Vb[q & 1];                                // DEPTH is even: the parity of the step
+          if (wave == ow) {
+            tmf4 vb = {0.0, 0.0, 0.0, 0.0}, vb2 = {0.0, 0.0, 0.0, 0.0};
+            vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[0], acc[sb][0], vb, 0, 0, 0);
+            vb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[1], acc[sb][1], vb2, 0, 0, 0);
+            vb = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[2], acc[sb][2], vb, 0, 0, 0);
+            vb2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fv[3], acc[sb][3], vb2, 0, 0, 0);
+            vb += vb2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vw[(4 * r + lg) * 17 + li] = vb[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = b0 + 4 * r + lg;
+              if (row < N && col < K) Zout[(size_t)col * N + row] = vb[r];
+            }
+            fetch_fv(st + TRI2_W);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (st + 1 < nblk) {
+            double bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bv[u] = BWD ? Vw[(4 * u + lg) * 17 + li] : Vw[(4 * lg + u) * 17 + li];
+#pragma unroll
+            for (int sl = sb; sl < MAXS; ++sl) {
+              const int sti = wave + TRI2_W * sl;
+              if (sti > st && sti < nblk) {                      // wave-uniform
+                tmf4 a2 = {0.0, 0.0, 0.0, 0.0};
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][0], bv[0], acc[sl], 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][1], bv[1], a2, 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][2], bv[2], acc[sl], 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pre[q][sl][3], bv[3], a2, 0, 0, 0);
+                acc[sl] += a2;
+              }
+            }
+            fetch(st + DEPTH, pre[q]);
+          }
+        }
+      }
+    }
+  }
+}
+template <int MAXS, bool BWD>
+__global__ void __launch_bounds__(64 * TRI2_W, 2) k_trsm2(int N, int K, int S, const double* __restrict__ Lall, const double* __restrict__ Finv,
+                                                         const unsigned char* __restrict__ lchol, const double* __restrict__ Zin,
+                                                         double* __restrict__ Zout) {
+  const int cb = blockIdx.x, s = blockIdx.y, r = blockIdx.z;
+  if (!lchol[s]) return;
+  const size_t off = ((size_t)r * S + s) * (size_t)K * N;
+  trsm2_body<MAXS, (MAXS <= 4 ? 4 : 2), BWD>(N, K, cb * 16, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, Zin + off, Zout + off);
+}
+// the workgroup-per-slab solves when the row blocks fit the accumulator registers (N <= 1024); VBMC_TRSM2=0: the one-wave kernels (A/B)
+static inline bool trsm2_wanted(int N) {
+  static const int force = getenv("VBMC_TRSM2") ? atoi(getenv("VBMC_TRSM2")) : -1;
+  return force != 0 && TRSM_NBLK(N) <= TRI2_W * 8;
+}
+template <bool BWD>
+static inline hipError_t trsm2_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
+                                      const unsigned char* lchol, const double* Zin, double* Zout) {
+  const dim3 grid((K + 15) / 16, S, R);
+  if (TRSM_NBLK(N) <= TRI2_W * 4) hipLaunchKernelGGL((k_trsm2<4, BWD>), grid, dim3(64 * TRI2_W), 0, st, N, K, S, Lall, Finv, lchol, Zin, Zout);
+  else hipLaunchKernelGGL((k_trsm2<8, BWD>), grid, dim3(64 * TRI2_W), 0, st, N, K, S, Lall, Finv, lchol, Zin, Zout);
+  return hipGetLastError();
+}
 
 // T = inv(R') (transposed != 0: its transpose), see k_tri_inverse
 static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const double* Lall, const double* Finv,
