@@ -206,10 +206,10 @@ __device__ __forceinline__ bool chol_diag_tile_fast(double (&X)[4], double* __re
   (void)dbg;
   CH2_TSTAMP(0);
   double rg[4] = {0.0, 0.0, 0.0, 0.0};          // inverse: M[4 kk + lg][c = li] of the blocks done so far
-  double ris_prev = 0.0, m10 = 0.0, m20 = 0.0, m30 = 0.0, m21 = 0.0, m31 = 0.0, m32 = 0.0;   // block b - 1: 1 / sqrt(d), unit-factor entries
+  double m10 = 0.0, m20 = 0.0, m30 = 0.0, m21 = 0.0, m31 = 0.0, m32 = 0.0;   // block b - 1: its unit-factor entries inside the diagonal block
   // rows 4 k .. 4 k + 3 of the inverse: the sums over the earlier blocks split over the four lane groups (u = 4 kk + lg) and added by
-  // permlane swaps, the coupling inside the 4 x 4 diagonal block with the uniform unit-factor entries; Ri[c][t] = M[t][c] / sqrt(d_t)
-  auto inverse_block = [&](int k, double ris, double n10, double n20, double n30, double n21, double n31, double n32) {
+  // permlane swaps, the coupling inside the 4 x 4 diagonal block with the uniform unit-factor entries (rows scaled by 1 / sqrt(d_t) at the end)
+  auto inverse_block = [&](int k, double n10, double n20, double n30, double n21, double n31, double n32) {
     const int q = 4 * k;
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -229,7 +229,6 @@ __device__ __forceinline__ bool chol_diag_tile_fast(double (&X)[4], double* __re
     const double r2 = fma(-n21, r1, fma(-n20, r0, bv[2]));
     const double r3 = fma(-n32, r2, fma(-n31, r1, fma(-n30, r0, bv[3])));
     const double rsel = lg == 0 ? r0 : (lg == 1 ? r1 : (lg == 2 ? r2 : r3));
-    (void)ris;
     return rsel;
   };
 #pragma unroll
@@ -270,7 +269,7 @@ __device__ __forceinline__ bool chol_diag_tile_fast(double (&X)[4], double* __re
       for (int r = b + 1; r < 4; ++r) X[r] -= acc[r];
     }
     // the previous block's rows of the inverse, beside this block's chain
-    if (b > 0) rg[b - 1] = inverse_block(b - 1, ris_prev, m10, m20, m30, m21, m31, m32);
+    if (b > 0) rg[b - 1] = inverse_block(b - 1, m10, m20, m30, m21, m31, m32);
     Lt[li * 17 + c0 + lg] = lsel;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -281,7 +280,7 @@ __device__ __forceinline__ bool chol_diag_tile_fast(double (&X)[4], double* __re
     m10 = l10; m20 = l20; m30 = l30; m21 = l21; m31 = l31; m32 = l32;
     CH2_TSTAMP(1 + b);
   }
-  rg[3] = inverse_block(3, ris_prev, m10, m20, m30, m21, m31, m32);
+  rg[3] = inverse_block(3, m10, m20, m30, m21, m31, m32);
   CH2_TSTAMP(5);
   // Roots: lane t < 16 takes pivot t -- sqrt and 1 / sqrt of all sixteen in one chain (the loop carried none), and the range test
   // with them: anything but a positive normal number of moderate size sends the tile to the careful routine.
