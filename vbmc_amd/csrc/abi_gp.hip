@@ -104,7 +104,7 @@ struct GpFactor {
   size_t extra_in = 0;
   std::function<void(double*)> fill_extra;
   bool defer_alpha = false;     // set by the caller: it launches alpha's backward solve itself (dz -> dal, k_tri_inverse2_alpha)
-  TmpBuf dIn, dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dz, dones, dninv, dal, dfinv, dExtra;   // dIn: the packed inputs (dX .. dninv, dExtra are windows)
+  TmpBuf dIn, dX, dy, dhyp, dXc, daa, dsn2, dscal, dact, dA, dpf, dr, dz, dones, dninv, dlch, dal, dfinv, dExtra;   // dIn: the packed inputs (dX .. dninv, dExtra are windows)
 };
 
 // fail_is_error: vbmc_gp_post refuses a matrix that is still not positive definite after the retries;
@@ -160,7 +160,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   // issued eight hipMemcpyAsync from pageable memory -- each of them staged and waited for by the runtime, ~100 us of host time
   // in a call whose kernels take 0.36 ms.)
   const size_t nX = (size_t)N * D, nH = (size_t)Nhyp * S, nS = (size_t)S * N, nC = (size_t)S * 4;
-  const size_t nB = (3 * (size_t)S + 7) / 8;
+  const size_t nB = (4 * (size_t)S + 7) / 8;             // ones | needinv | active | lchol
   const size_t in_doubles = nX + N + nH + nS + nC + nB + f.extra_in;
   { vbmc_status s_ = ensure_pin(ctx, (in_doubles + pin_extra_doubles) * 8 + 8); if (s_) return s_; }
   double* hin = (double*)ctx->pin;
@@ -171,7 +171,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   memcpy(hin + nX + N + nH, sn2all.data(), nS * 8);
   memcpy(hin + nX + N + nH + nS, scal.data(), nC * 8);
   unsigned char* hb = (unsigned char*)(hin + nX + N + nH + nS + nC);
-  memcpy(hb, ones.data(), S); memcpy(hb + S, needinv.data(), S); memcpy(hb + 2 * S, active.data(), S);
+  memcpy(hb, ones.data(), S); memcpy(hb + S, needinv.data(), S); memcpy(hb + 2 * S, active.data(), S); memcpy(hb + 3 * S, lch.data(), S);
   if (f.extra_in && f.fill_extra) f.fill_extra(hin + nX + N + nH + nS + nC + nB);
   TmpBuf& dIn = f.dIn;
   HIP_TRY(ctx, dIn.alloc(ctx, in_doubles * 8));
@@ -179,7 +179,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
     double* din = dIn.as<double>();
     dX.view(din); dy.view(din + nX); dhyp.view(din + nX + N); dsn2.view(din + nX + N + nH); dscal.view(din + nX + N + nH + nS);
     unsigned char* db = (unsigned char*)(din + nX + N + nH + nS + nC);
-    dones.view(db); dninv.view(db + S); dact.view(db + 2 * S);
+    dones.view(db); dninv.view(db + S); dact.view(db + 2 * S); f.dlch.view(db + 3 * S);
     f.dExtra.view(din + nX + N + nH + nS + nC + nB);
   }
   TmpBuf &dal = f.dal, &dfinv = f.dfinv;
@@ -336,7 +336,19 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   HIP_TRY(ctx, hipMemcpyAsync(alh, dal.p, ((size_t)S * N + S) * 8, hipMemcpyDeviceToHost, st));
   f.h_pfd = alh + (size_t)S * N;
   const bool wantL = L != nullptr || gp_out != nullptr;
-  if (wantL && any_inv) {
+  // Low-noise samples (:84-99): gp.post(s).L = -inv(K + sn2 I) = -T'T with T = inv(R').  Round 5, N <= 1024: the workgroup-per-slab
+  // inverse of the factor and the rank-k product on the matrix cores (k_tri_inverse2 + k_syrk_tt, as in the marginal-likelihood
+  // gradient), the product written NEGATED and in full over the factor it came from -- the factorisation's block then holds
+  // gp.post(s).L for every sample, whichever branch it took (k_spd_inverse, 270 us at N = 400, wrote the inverse elsewhere and left the
+  // sign and one copy per sample to the assembly).  alpha's solve (gp_factorize) read the factor before this point of the stream.
+  const bool inv_in_place = wantL && any_inv && tri_inverse2_fits(N) && trsm2_wanted(N);
+  TmpBuf dTTi;
+  if (inv_in_place) {
+    HIP_TRY(ctx, dTTi.alloc(ctx, (size_t)S * N * N * 8));
+    HIP_TRY(ctx, tri_inverse_launch(st, N, S, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dTTi.as<double>(), 1));
+    syrk_tt_launch(st, N, S, dTTi.as<double>(), dninv.as<unsigned char>(), dA.as<double>(), true);
+    HIP_TRY(ctx, hipGetLastError());
+  } else if (wantL && any_inv) {
     // pL = -L\(L'\eye(N)) for low-noise samples (:98); the sign is applied where the matrix is consumed
     HIP_TRY(ctx, dXi.alloc(ctx, (size_t)S * N * N * 8));
     SPD_INVERSE_LAUNCH(ctx, N, S, st, dA.as<double>(), dfinv.as<double>(), dninv.as<unsigned char>(), dXi.as<double>());
@@ -344,7 +356,7 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   }
   if (L) {
     // the caller's copy of gp.post(s).L (D2H only when asked for)
-    if (!any_inv) {   // every sample on the Cholesky branch: one contiguous block
+    if (!any_inv || inv_in_place) {   // one contiguous block: every sample on the Cholesky branch, or the inverses already in their places
       vbmc_status s_ = d2h_bounced(ctx, L, dA.as<double>(), (size_t)S * N * N * 8);
       if (s_) return s_;
     } else {
@@ -357,7 +369,7 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   }
   HIP_TRY(ctx, stream_wait_latency(st));
   if (!gp_factor_ok(f, S)) return VBMC_INTERNAL_RETRY;     // a first try failed: once more with the noise-inflation loop
-  if (L && any_inv)
+  if (L && any_inv && !inv_in_place)
     for (int s = 0; s < S; ++s)
       if (!lch[s]) for (size_t i = 0; i < (size_t)N * N; ++i) L[(size_t)s * N * N + i] = -L[(size_t)s * N * N + i];
 
@@ -369,16 +381,16 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   if (sW) for (int s = 0; s < S; ++s) for (int n = 0; n < N; ++n) sW[(size_t)s * N + n] = sW1[s];
   if (sn2_mult) memcpy(sn2_mult, mult.data(), S * 8);
   if (Lchol) memcpy(Lchol, lch.data(), S);
-  if (gp_out && resident && !any_inv) {
-    // adopt: the surrogate's device blocks ARE the factorisation's (every sample on the Cholesky branch: d_lchol = the ones)
+  if (gp_out && resident && (!any_inv || inv_in_place)) {
+    // adopt: the surrogate's device blocks ARE the factorisation's (d_lchol = the per-sample branch flags of the packed upload)
     vbmc_gp* gp = new vbmc_gp();
     gp->N = N; gp->D = D; gp->S = S; gp->Nhyp = Nhyp; gp->Ncov = Ncov; gp->Nnoise = Nnoise; gp->meanfun = meanfun;
     gp->hyp_host.assign(hyp, hyp + (size_t)Nhyp * S);
-    gp->sn2_eff.resize(S); gp->Lchol.assign(S, 1);
+    gp->sn2_eff.resize(S); gp->Lchol.assign(lch.begin(), lch.end());
     for (int s = 0; s < S; ++s) gp->sn2_eff[s] = 1.0 / (sW1[s] * sW1[s]);
     gp->pooled = true; gp->in_views = true; gp->hasL = true;
     gp->blk_in = f.dIn.p; f.dIn.p = nullptr;
-    gp->X = f.dX.as<double>(); gp->hyp = f.dhyp.as<double>(); gp->d_lchol = f.dones.as<unsigned char>();
+    gp->X = f.dX.as<double>(); gp->hyp = f.dhyp.as<double>(); gp->d_lchol = f.dlch.as<unsigned char>();
     double* e = f.dExtra.as<double>();
     gp->gpc = e; gp->d_sn2 = e + nG; gp->d_meanX = e + nG + S; gp->d_mult = e + nG + S + D;
     gp->alpha = dal.as<double>(); dal.p = nullptr;

@@ -619,7 +619,9 @@ static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const 
 // NT = 2: 64 x 64 per workgroup as above (throughput: many matrices).  NT = 1: 32 x 32 per workgroup, one 16 x 16 tile per
 // wave -- for a handful of matrices the kernel is a chain of k-groups per workgroup, each an L2 round trip plus its MFMAs, and a
 // quarter of the MFMAs per group on four times the workgroups shortens exactly that chain (30 -> 12 us for one matrix of order 400).
-template <int NT>
+// FULLNEG: the whole symmetric matrix, negated (C = -T'T: gp.post(s).L = -inv(K + sn2 I) of a low-noise posterior, gplite_core.m:98),
+// the tiles above the diagonal 64 x 64 blocks written a second time as their mirror image.
+template <int NT, bool FULLNEG = false>
 __global__ void __launch_bounds__(256) k_syrk_tt(int N, const double* __restrict__ TTall, const unsigned char* __restrict__ on,
                                                  double* __restrict__ Call) {
   constexpr int WT = 16 * NT;                              // rows / columns per wave
@@ -676,14 +678,24 @@ __global__ void __launch_bounds__(256) k_syrk_tt(int N, const double* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + 16 * a + lg + 4 * r, i = i0 + 16 * b + li;
-        if (j < N && i < N && (diag64 || i <= j)) C[(size_t)j * N + i] = acc[a][b][r];
+        if (j < N && i < N && (diag64 || i <= j)) {
+          const double v = FULLNEG ? -acc[a][b][r] : acc[a][b][r];
+          C[(size_t)j * N + i] = v;
+          if (FULLNEG && !diag64) C[(size_t)i * N + j] = v;
+        }
       }
 }
-// C = T'T for S matrices on stream st
-static inline void syrk_tt_launch(hipStream_t st, int N, int S, const double* TT, const unsigned char* on, double* C) {
+// C = T'T for S matrices on stream st (fullneg: C = -T'T, both triangles)
+static inline void syrk_tt_launch(hipStream_t st, int N, int S, const double* TT, const unsigned char* on, double* C, bool fullneg = false) {
   const int t64 = (N + 63) / 64, t32 = (N + 31) / 32;
-  if ((size_t)S * t64 * (t64 + 1) / 2 <= 128) hipLaunchKernelGGL((k_syrk_tt<1>), dim3(t32, t32, S), dim3(256), 0, st, N, TT, on, C);
-  else hipLaunchKernelGGL((k_syrk_tt<2>), dim3(t64, t64, S), dim3(256), 0, st, N, TT, on, C);
+  const bool small = (size_t)S * t64 * (t64 + 1) / 2 <= 128;
+  if (fullneg) {
+    if (small) hipLaunchKernelGGL((k_syrk_tt<1, true>), dim3(t32, t32, S), dim3(256), 0, st, N, TT, on, C);
+    else hipLaunchKernelGGL((k_syrk_tt<2, true>), dim3(t64, t64, S), dim3(256), 0, st, N, TT, on, C);
+  } else {
+    if (small) hipLaunchKernelGGL((k_syrk_tt<1, false>), dim3(t32, t32, S), dim3(256), 0, st, N, TT, on, C);
+    else hipLaunchKernelGGL((k_syrk_tt<2, false>), dim3(t64, t64, S), dim3(256), 0, st, N, TT, on, C);
+  }
 }
 
 // Two waves per workgroup take the column blocks cb and nblk-1-cb: a long and a short solve, so that every workgroup does
