@@ -983,6 +983,13 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
 namespace {
 // Ks = k(X, xstar), v = L' \ Ks, x = L \ v per hyper-sample on the device (gplite_post.m:226-237); for the samples that store
 // -inv(K + sn2 I) instead of a factor, x = L Ks (k_symm) and v is unused.
+// up to six small device-to-device copies in one launch (the per-sample constants a surrogate inherits from the one it extends)
+struct CopySegs { const double* src[6]; double* dst[6]; int n[6]; };
+__global__ void k_copy_segs(CopySegs c) {
+  const int g = blockIdx.x;
+  for (int i = threadIdx.x; i < c.n[g]; i += blockDim.x) c.dst[g][i] = c.src[g][i];
+}
+
 vbmc_status rank1_solves_dev(vbmc_ctx* ctx, const vbmc_gp* gp, const double* xstar, TmpBuf& dKs, TmpBuf& dV, TmpBuf& dXo) {
   const int N = gp->N, D = gp->D, S = gp->S;
   if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
@@ -1058,22 +1065,59 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
   hipLaunchKernelGGL(k_rank1_assemble, dim3(N1, S), dim3(256), 0, st, N, gp->L, gp->alpha, gp->d_lchol, dV.as<double>(), dXo.as<double>(),
                      dsc.as<double>(), dLn.as<double>(), dan.as<double>());
   HIP_TRY(ctx, hipGetLastError());
-  std::vector<double> ah((size_t)S * N1), sW1(S);
-  HIP_TRY(ctx, hipMemcpyAsync(ah.data(), dan.p, ah.size() * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  for (int s = 0; s < S; ++s) sW1[s] = 1.0 / std::sqrt(gp->sn2_eff[s]);   // post.sW(1) is unchanged by the append (:239)
-  vbmc_gp* ng = nullptr;
-  vbmc_status st2 = gp_upload_impl(ctx, N1, D, S, gp->Nhyp, gp->Ncov, gp->Nnoise, gp->meanfun, X_new, gp->hyp_host.data(), ah.data(), nullptr,
-                                   dLn.as<double>(), nullptr, sW1.data(), gp->Lchol.data(), &ng);
-  if (st2 != VBMC_OK) return st2;
+  // The new surrogate ADOPTS the assembled factors and alpha (round 5; before: alpha to the host, a second round of six pageable
+  // uploads, a device-to-device copy of the S factors, two more synchronisations).  Its small blocks are windows of ONE pooled
+  // block [X_new | meanX | hyp | gpc | sn2_eff | mult | lchol]: X_new and its column means come up through the pinned block, the
+  // per-sample constants -- unchanged by an append -- are copied from the surrogate it extends in one launch.
+  const int Nhyp = gp->Nhyp;
+  const size_t nXn = (size_t)N1 * D, nG = (size_t)S * GPC_STRIDE(D), nH = (size_t)Nhyp * S;
+  const size_t nsmall = nXn + D + nH + nG + 2 * (size_t)S + ((size_t)S + 7) / 8;
+  { vbmc_status s_ = ensure_pin(ctx, ((nXn + D) + (size_t)S * N1) * 8 + 8); if (s_) return s_; }
+  double* hin = (double*)ctx->pin;
+  memcpy(hin, X_new, nXn * 8);
+  for (int d = 0; d < D; ++d) {
+    double acc = 0.0;
+    for (int n = 0; n < N1; ++n) acc += X_new[n + (size_t)N1 * d];
+    hin[nXn + d] = acc / N1;
+  }
+  double* ah = hin + nXn + D;              // alpha comes back here
+  vbmc_gp* ng = new vbmc_gp();
+  ng->N = N1; ng->D = D; ng->S = S; ng->Nhyp = Nhyp; ng->Ncov = gp->Ncov; ng->Nnoise = gp->Nnoise; ng->meanfun = gp->meanfun;
+  ng->hyp_host = gp->hyp_host; ng->sn2_eff = gp->sn2_eff; ng->Lchol = gp->Lchol;     // post.sW(1) is unchanged by the append (:239)
+  ng->pooled = true; ng->in_views = true; ng->hasL = true;
+  {
+    hipError_t e = pool_get(ctx, nsmall * 8, &ng->blk_in);
+    if (e == hipSuccess) e = pool_get(ctx, (size_t)S * TRSM_NBLK(N1) * 256 * sizeof(double), (void**)&ng->d_finv);
+    if (e != hipSuccess) { vbmc_gp_free(ctx, ng); return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_rank1_update: %s", hipGetErrorString(e)); }
+  }
+  double* blk = (double*)ng->blk_in;
+  ng->X = blk; ng->d_meanX = blk + nXn; ng->hyp = blk + nXn + D; ng->gpc = ng->hyp + nH; ng->d_sn2 = ng->gpc + nG; ng->d_mult = ng->d_sn2 + S;
+  ng->d_lchol = (unsigned char*)(ng->d_mult + S);
+  ng->L = dLn.as<double>(); dLn.p = nullptr;
+  ng->alpha = dan.as<double>(); dan.p = nullptr;
+  bool ok = hipMemcpyAsync(blk, hin, (nXn + D) * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+  {
+    CopySegs cs{};
+    cs.src[0] = gp->hyp; cs.dst[0] = ng->hyp; cs.n[0] = (int)nH;
+    cs.src[1] = gp->gpc; cs.dst[1] = ng->gpc; cs.n[1] = (int)nG;
+    cs.src[2] = gp->d_sn2; cs.dst[2] = ng->d_sn2; cs.n[2] = S;
+    cs.src[3] = gp->has_noise ? gp->d_mult : gp->d_sn2; cs.dst[3] = ng->d_mult; cs.n[3] = S;     // (without a noise model the slot is just initialised)
+    cs.src[4] = (const double*)gp->d_lchol; cs.dst[4] = (double*)ng->d_lchol; cs.n[4] = 0;
+    hipLaunchKernelGGL(k_copy_segs, dim3(4), dim3(256), 0, st, cs);
+    ok = ok && hipMemcpyAsync(ng->d_lchol, gp->d_lchol, (size_t)S, hipMemcpyDeviceToDevice, st) == hipSuccess;     // bytes: not a whole number of doubles
+  }
+  hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N1), S), dim3(64), 0, st, N1, ng->L, ng->d_lchol, ng->d_finv);
+  ok = ok && hipMemcpyAsync(ah, ng->alpha, (size_t)S * N1 * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+  ok = ok && hipGetLastError() == hipSuccess;
+  {
+    const hipError_t e = stream_wait_latency(st);
+    if (!ok || e != hipSuccess) { vbmc_gp_free(ctx, ng); (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_rank1_update: %s", hipGetErrorString(e)); }
+  }
   if (gp->has_noise) {
     for (int i = 0; i < 3; ++i) ng->noisefun[i] = gp->noisefun[i];
-    hipError_t e = pool_get(ctx, (size_t)S * 8, (void**)&ng->d_mult);
-    if (e == hipSuccess) e = hipMemcpy(ng->d_mult, gp->d_mult, (size_t)S * 8, hipMemcpyDeviceToDevice);
-    if (e != hipSuccess) { vbmc_gp_free(ctx, ng); return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_rank1_update: %s", hipGetErrorString(e)); }
     ng->has_noise = true;
   }
-  if (alpha_new) memcpy(alpha_new, ah.data(), ah.size() * 8);
+  if (alpha_new) memcpy(alpha_new, ah, (size_t)S * N1 * 8);
   if (L_new) { vbmc_status s_ = d2h_bounced(ctx, L_new, ng->L, (size_t)S * N1 * N1 * 8); if (s_) { vbmc_gp_free(ctx, ng); return s_; } }
   *out = ng;
   return VBMC_OK;
