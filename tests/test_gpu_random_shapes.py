@@ -54,7 +54,12 @@ def test_negelcbo_random_shapes(va, shape, seed, flags, ns_half, compute_var, me
         assert relerr(out["dF"][:, 0], ref["dF"]) < 1e-8
     assert relerr(out["G"][0], ref["G"]) < 1e-9 and relerr(out["H"][0], ref["H"]) < 1e-9
     if compute_var:
-        assert relerr(out["varG"][0], ref["varG"]) < 1e-7
+        # varG is a difference (prior integral minus |L' \ z|^2): its error relative to the oracle grows with the condition number of
+        # the kernel matrix -- and so does the oracle's own.  1e-7 up to cond(K) = 1e6, in proportion beyond (the 100x sweep reaches a
+        # noise-free one-dimensional GP of 53 points, cond(K) ~ 3e7, where the product with the explicit inverse is off by 1.3e-7 and
+        # the substitution by 2.4e-7: round 5, `profiles/r05_var.md`)
+        condK = max((np.linalg.cond(q["L"]) ** 2 if q["Lchol"] else np.linalg.cond(q["L"])) for q in gp["post"])
+        assert relerr(out["varG"][0], ref["varG"]) < 1e-7 * max(1.0, condK / 1e6), condK
 
 
 wide = st.tuples(st.integers(1, 32), st.integers(1, 200), st.integers(5, 220), st.integers(1, 3))
@@ -82,7 +87,9 @@ def test_negelcbo_random_shapes_wide(va, shape, seed, ns_half, compute_var, grad
     ref = R.negelcbo_vbmc(theta, 0.0, vp, gp, Ns, grad, compute_var, eps=eps)
     out = va.negelcbo_batch(theta, 0.0, vp, gp, Ns, grad, compute_var, eps=eps)
     assert relerr(out["G"][0], ref["G"]) < 1e-9 and relerr(out["H"][0], ref["H"]) < 1e-9, (shape, Ns, compute_var)
-    assert relerr(out["F"][0], ref["F"]) < 1e-9
+    # F = -(G + H) (beta = 0): 1e-9 of the terms it is made of, which is 1e-9 of F itself unless they cancel (the 100x sweep reaches
+    # D = K = 1, N = 32, where |G| + |H| = 1.3 |F| and F is off by 1.16e-9 with G and H each inside 1e-9)
+    assert abs(out["F"][0] - ref["F"]) < 1e-9 * max(abs(ref["F"]), abs(ref["G"]) + abs(ref["H"]), 1e-300)
     if grad:
         assert relerr(out["dF"][:, 0], ref["dF"]) < 1e-8, (shape, Ns, compute_var)
     if compute_var:
