@@ -193,7 +193,13 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
   HIP_TRY(ctx, dfinv.alloc(ctx, (size_t)S * TRSM_NBLK(N) * 256 * 8));
   f.d_pfd = dal.as<double>() + (size_t)S * N;
   const int moff = Ncov + Nnoise;
-  HIP_TRY(ctx, hipMemcpyAsync(dIn.p, hin, in_doubles * 8, hipMemcpyHostToDevice, st));
+  // (small blocks by a kernel that reads the pinned block over the host link instead of the copy engine: the hand-over from a DMA
+  // copy to the first kernel of the stream is 8-9 us on top of the copy's 6.5 -- abi_elbo.hip: copy_by_kernel)
+  if (copy_by_kernel(in_doubles * 8))
+    hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((in_doubles + 255) / 256, 1024)), dim3(256), 0, st, in_doubles, (const double*)hin,
+                       dIn.as<double>());
+  else
+    HIP_TRY(ctx, hipMemcpyAsync(dIn.p, hin, in_doubles * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_gp_scale, dim3(4, S), dim3(256), 0, st, N, D, Nhyp, dX.as<double>(), dhyp.as<double>(), dXc.as<double>(), daa.as<double>(),
                      moff, meanfun, dy.as<double>(), dr.as<double>());
 
@@ -333,7 +339,11 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
   TmpBuf &dA = f.dA, &dal = f.dal, &dfinv = f.dfinv, &dninv = f.dninv, dXi;
 
   double* alh = f.pin_out;   // pinned: the copy is asynchronous, one synchronisation below; the failure indices ride behind alpha
-  HIP_TRY(ctx, hipMemcpyAsync(alh, dal.p, ((size_t)S * N + S) * 8, hipMemcpyDeviceToHost, st));
+  if (copy_by_kernel(((size_t)S * N + S) * 8))
+    hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>(((size_t)S * N + S + 255) / 256, 1024)), dim3(256), 0, st, (size_t)S * N + S,
+                       (const double*)dal.as<double>(), alh);
+  else
+    HIP_TRY(ctx, hipMemcpyAsync(alh, dal.p, ((size_t)S * N + S) * 8, hipMemcpyDeviceToHost, st));
   f.h_pfd = alh + (size_t)S * N;
   const bool wantL = L != nullptr || gp_out != nullptr;
   // Low-noise samples (:84-99): gp.post(s).L = -inv(K + sn2 I) = -T'T with T = inv(R').  Round 5, N <= 1024: the workgroup-per-slab
@@ -479,8 +489,10 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
   hipStream_t st = ctx->stream;
   const int Nnoise = f.Nnoise, Nmean = f.Nmean;
   TmpBuf dout, dKi, dpart, dTT;
-  HIP_TRY(ctx, dout.alloc(ctx, nout * 8));
-  double* dnlz = dout.as<double>();
+  // the closing kernel writes the (small) block of results straight into the pinned block over the host link: no copy behind it
+  const bool out_direct = copy_by_kernel(nout * 8);
+  if (!out_direct) HIP_TRY(ctx, dout.alloc(ctx, nout * 8));
+  double* dnlz = out_direct ? f.pin_out : dout.as<double>();
   const int nt1 = (N + NLZ_T - 1) / NLZ_T, ntile = nt1 * nt1, P = D + 1 + Nnoise;
   if (compute_grad) {
     // Kinv*sl = L\(L'\eye(N)) for every hyper-parameter vector (:240) as T'T with T = inv(L'): one triangular solve of the
@@ -513,7 +525,7 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
                                       f.dscal.as<double>(), compute_grad ? dpart.as<double>() : (const double*)nullptr,
                                       (const double*)f.d_pfd, dnlz));
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz, nout * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
+  if (!out_direct) HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz, nout * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
   f.h_pfd = f.pin_out + B;
   HIP_TRY(ctx, stream_wait_latency(st));
   if (!gp_factor_ok(f, B)) return VBMC_INTERNAL_RETRY;
