@@ -1107,7 +1107,11 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
   ng->d_lchol = (unsigned char*)(ng->d_mult + S);
   ng->L = dLn.as<double>(); dLn.p = nullptr;
   ng->alpha = dan.as<double>(); dan.p = nullptr;
-  bool ok = hipMemcpyAsync(blk, hin, (nXn + D) * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+  bool ok = true;
+  if (copy_by_kernel((nXn + D) * 8))
+    hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((nXn + D + 255) / 256, 1024)), dim3(256), 0, st, nXn + D, (const double*)hin, blk);
+  else
+    ok = hipMemcpyAsync(blk, hin, (nXn + D) * 8, hipMemcpyHostToDevice, st) == hipSuccess;
   {
     CopySegs cs{};
     cs.src[0] = gp->hyp; cs.dst[0] = ng->hyp; cs.n[0] = (int)nH;
@@ -1119,7 +1123,11 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
     ok = ok && hipMemcpyAsync(ng->d_lchol, gp->d_lchol, (size_t)S, hipMemcpyDeviceToDevice, st) == hipSuccess;     // bytes: not a whole number of doubles
   }
   hipLaunchKernelGGL(k_diag_inv, dim3(TRSM_NBLK(N1), S), dim3(64), 0, st, N1, ng->L, ng->d_lchol, ng->d_finv);
-  ok = ok && hipMemcpyAsync(ah, ng->alpha, (size_t)S * N1 * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (copy_by_kernel((size_t)S * N1 * 8))
+    hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>(((size_t)S * N1 + 255) / 256, 1024)), dim3(256), 0, st, (size_t)S * N1,
+                       (const double*)ng->alpha, ah);
+  else
+    ok = ok && hipMemcpyAsync(ah, ng->alpha, (size_t)S * N1 * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
   ok = ok && hipGetLastError() == hipSuccess;
   {
     const hipError_t e = stream_wait_latency(st);
