@@ -229,8 +229,11 @@ def entropy_kernel_label(D, K):
     from vbmc_amd import _lib
 
     qs, kt, hv, tl = (ctypes.c_int() for _ in range(4))
-    if not _lib.load().vbmc_entropy_plan(int(D), int(K), ctypes.byref(qs), ctypes.byref(kt), ctypes.byref(hv), ctypes.byref(tl)):
+    kind = _lib.load().vbmc_entropy_plan(int(D), int(K), ctypes.byref(qs), ctypes.byref(kt), ctypes.byref(hv), ctypes.byref(tl))
+    if not kind:
         return "k_entropy<D=%d,grad> (VALU)" % D
+    if kind == 2:
+        return "k_entropy_lane<DT=%d,KP=%d,grad> (+ log-joint role)" % (qs.value, kt.value)
     Kh = (K + hv.value - 1) // hv.value
     return "k_entropy_mfma<QS=%d,KT=%d%s,grad%s>" % (qs.value, kt.value, "+tail%d" % (Kh - 16 * kt.value) if tl.value else "",
                                                      "" if hv.value == 1 else ",HV=%d" % hv.value)

@@ -431,8 +431,9 @@ vbmc_status vbmc_rng_dump(vbmc_ctx* ctx, int D, int K, int R, int Ns, uint64_t s
 
 /* Reporting hook: which instantiation of the Monte-Carlo entropy kernel (vbmc_amd/csrc/entropy_mfma.h) a D-dimensional,
  * K-component mixture runs on in dense mode: qs = ceil((D+2)/4), kt = 16-component k-tiles per wave, hv = waves per workgroup,
- * tail = values per lane of the component tail (0: none).  Returns 1, or 0 when the VALU kernel serves the shape.  bench.py
- * labels the kernel it measures with it. */
+ * tail = values per lane of the component tail (0: none).  Returns 1; 2 when the shape is in the small class (K <= 16, D <= 12) and
+ * runs on the lane-per-sample kernel (vbmc_amd/csrc/entropy_lane.h: qs = padded dimension DT, kt = padded component count KP,
+ * hv = waves per workgroup); 0 when the plain VALU kernel serves it.  bench.py labels the kernel it measures with it. */
 int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* tail);
 
 /* Test hook: y = exp(x) evaluated by the hot-loop device implementations (0: polynomial, 1 / 2: 256-entry table with the two- /

@@ -68,6 +68,8 @@ def test_entropy_plan_reporting_hook():
     assert bench.entropy_kernel_label(10, 64) == "k_entropy_mfma<QS=3,KT=4,grad>"
     assert bench.entropy_kernel_label(10, 56) == "k_entropy_mfma<QS=3,KT=3+tail8,grad>"
     assert bench.entropy_kernel_label(20, 56) == "k_entropy_mfma<QS=6,KT=4,grad>"          # two values per lane would spill there
-    assert bench.entropy_kernel_label(6, 10) == "k_entropy_mfma<QS=2,KT=1,grad>"
+    assert bench.entropy_kernel_label(6, 10) == "k_entropy_lane<DT=6,KP=10,grad> (+ log-joint role)"      # the small class (round 6)
+    assert bench.entropy_kernel_label(13, 10) == "k_entropy_mfma<QS=4,KT=1,grad>"
+    assert bench.entropy_kernel_label(6, 17) == "k_entropy_mfma<QS=2,KT=1+tail1,grad>"
     assert bench.entropy_kernel_label(10, 200) == "k_entropy_mfma<QS=3,KT=3+tail2,grad,HV=4>"
     assert bench.entropy_kernel_label(40, 10).startswith("k_entropy<D=40")

@@ -65,6 +65,7 @@ def test_headline_translation_unit_compiles_cold_on_the_target_and_runs(tmp_path
     assert found["vgpr"] == int(re.search(r"vgpr (\d+)", meta_line).group(1)), (found, meta_line)
     # a library with the fresh object in place of the shipped one
     objs = [os.path.join(OBJ, "vbmc_hip.o")] + [obj if q == 3 else os.path.join(OBJ, "ent_mfma_qs%d.o" % q) for q in range(1, 10)]
+    objs += [os.path.join(OBJ, "ent_lane_dt%d.o" % dt) for dt in (2, 4, 6, 8, 10, 12)]
     lib = str(tmp_path / "libvbmc_hip_cold.so")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,7 +1,8 @@
 """Build libvbmc_hip.so (and the microbenchmark) for gfx950 with hipcc, in-tree.
 
 Translation units are compiled in parallel: vbmc_hip.hip (ABI + all kernels but the MFMA entropy
-family) and ent_mfma_inst.hip once per QS = 1..9 (k_entropy_mfma<QS, KT, grad> for every KT).
+family), ent_mfma_inst.hip once per QS = 1..9 (k_entropy_mfma<QS, KT, grad> for every KT) and
+ent_lane_inst.hip once per padded dimension DT = 2, 4, .., 12 (k_entropy_lane<DT, KP, grad>).
 """
 from __future__ import annotations
 
@@ -19,7 +20,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 MAIN_DEPS = ["vbmc_hip.hip", "abi_elbo.hip", "abi_gp.hip", "abi_comm.hip", "common.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "elbo_kernels.h", "logjoint_body.h", "trsm_mfma.h",
              "var_kernels.h", "gp_kernels.h", "chol_mfma.h", os.path.join("..", "..", "include", "vbmc_hip.h")]
 MFMA_DEPS = ["ent_mfma_inst.hip", "entropy_mfma.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "logjoint_body.h"]
+LANE_DEPS = ["ent_lane_inst.hip", "entropy_lane.h", "device_math.h", "exp2_tab1k.h", "elbo_types.h", "logjoint_body.h"]
 QS_RANGE = range(1, 10)
+LANE_DT = (2, 4, 6, 8, 10, 12)
 
 
 def _newer(target, deps):
@@ -49,6 +52,11 @@ def build(force=False, verbose=True):
         objs.append(o)
         if force or _newer(o, [os.path.join(CSRC, d) for d in MFMA_DEPS]):
             jobs.append([hipcc] + FLAGS + ["-DQS_VALUE=%d" % qs, "-c", os.path.join(CSRC, "ent_mfma_inst.hip"), "-o", o])
+    for dt in LANE_DT:
+        o = os.path.join(OBJDIR, "ent_lane_dt%d.o" % dt)
+        objs.append(o)
+        if force or _newer(o, [os.path.join(CSRC, d) for d in LANE_DEPS]):
+            jobs.append([hipcc] + FLAGS + ["-DDT_VALUE=%d" % dt, "-c", os.path.join(CSRC, "ent_lane_inst.hip"), "-o", o])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda c: _run(c, verbose), jobs))

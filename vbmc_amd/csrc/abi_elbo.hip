@@ -364,6 +364,46 @@ int vbmc_occupancy_ent_mfma_qs7(int, int, int, const EntArgs*);
 int vbmc_occupancy_ent_mfma_qs8(int, int, int, const EntArgs*);
 int vbmc_occupancy_ent_mfma_qs9(int, int, int, const EntArgs*);
 }
+// ---- lane-per-sample entropy kernel (entropy_lane.h; round 6): small mixtures, K <= 16 and D <= 12.  One translation unit per padded
+// dimension DT = 2, 4, .., 12 (ent_lane_inst.hip), KP = K rounded up to even.
+extern "C" {
+int vbmc_launch_ent_lane_dt2(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_lane_dt4(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_lane_dt6(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_lane_dt8(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_lane_dt10(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_launch_ent_lane_dt12(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+int vbmc_occupancy_ent_lane_dt2(int, int, const EntArgs*);
+int vbmc_occupancy_ent_lane_dt4(int, int, const EntArgs*);
+int vbmc_occupancy_ent_lane_dt6(int, int, const EntArgs*);
+int vbmc_occupancy_ent_lane_dt8(int, int, const EntArgs*);
+int vbmc_occupancy_ent_lane_dt10(int, int, const EntArgs*);
+int vbmc_occupancy_ent_lane_dt12(int, int, const EntArgs*);
+}
+#define ENT_LANE_WAVES_HOST 4     // = ENT_LANE_WAVES (entropy_lane.h)
+// the role's staged inputs (entropy_lane.h: ent_lane_role_lds) must fit the launch's dynamic LDS; larger training sets keep the separate log-joint kernel
+static bool lane_role_fits(int D, int K, int N, int S) {
+  return ((size_t)((N + 63) & ~63) * (D + ENT_LANE_WAVES_HOST) + (size_t)S * GPC_STRIDE(D) + (size_t)VpLayout{D, K}.stride() + D) * sizeof(double) <= 48 * 1024;
+}
+static bool lane_entropy_fits(int D, int K, double cutoff) { return D >= 1 && D <= 12 && K >= 1 && K <= 16 && !(cutoff > 0.0); }
+static bool launch_entropy_lane(int D, int K, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
+  typedef int (*fn_t)(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
+  static const fn_t fns[6] = {vbmc_launch_ent_lane_dt2, vbmc_launch_ent_lane_dt4, vbmc_launch_ent_lane_dt6,
+                              vbmc_launch_ent_lane_dt8, vbmc_launch_ent_lane_dt10, vbmc_launch_ent_lane_dt12};
+  return fns[(D + 1) / 2 - 1](2 * ((K + 1) / 2), grad ? 1 : 0, g.x, g.y, g.z, (void*)st, &ea) == 0;
+}
+static int entropy_lane_occupancy(int D, int K, bool grad) {
+  typedef int (*fn_t)(int, int, const EntArgs*);
+  static const fn_t fns[6] = {vbmc_occupancy_ent_lane_dt2, vbmc_occupancy_ent_lane_dt4, vbmc_occupancy_ent_lane_dt6,
+                              vbmc_occupancy_ent_lane_dt8, vbmc_occupancy_ent_lane_dt10, vbmc_occupancy_ent_lane_dt12};
+  static int cache[6][9][2];      // 0: not asked yet
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int& c = cache[(D + 1) / 2 - 1][(K + 1) / 2][grad ? 1 : 0];
+  if (c == 0) { EntArgs q{}; const int nb = fns[(D + 1) / 2 - 1](2 * ((K + 1) / 2), grad ? 1 : 0, &q); c = nb > 0 ? nb : -1; }
+  return c;
+}
+
 // Waves per workgroup for 64 < K <= 128 (tools/tune_sweep.py, round 2): two -- four are 10-30 % slower (more exchange and barrier
 // coupling) -- EXCEPT where the two-wave kernel with four k-tiles per wave and a wide operand (D >= 15) spills its way down:
 // there four waves with two k-tiles each fit their registers (D = 24, K = 128: 3.4 vs 5.7 ms; D = 20, K = 128: 3.9 vs 5.0;
@@ -503,7 +543,7 @@ struct ElboPlan {
   ElboDims dm{};
   int compute_grad = 0, compute_var = 0, dt = 0;
   double beta = 0.0;
-  bool mc = false, has_bnd = false, use_mfma = false, vgrad = false, any_nochol = false, needX = false, fin_big = false, tri_gemm = false;
+  bool mc = false, has_bnd = false, use_mfma = false, use_lane = false, vgrad = false, any_nochol = false, needX = false, fin_big = false, tri_gemm = false;
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   int no_jacobian = 0;
@@ -707,7 +747,10 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     const char* force = getenv("VBMC_ENT_KERNEL");  // "valu" (A/B testing); default: the MFMA kernel when it fits
     P.use_mfma = mfma_entropy_fits(D, K, P.cutoff, &P.qs, &P.kt, &P.hv);
     if (force && !strcmp(force, "valu")) P.use_mfma = false;
-    const int tile_sz = P.use_mfma ? 16 : 32;          // base samples per tile
+    // small mixtures: the lane-per-sample kernel (entropy_lane.h).  VBMC_ENT_KERNEL=mfma keeps the matrix-core kernel there (A/B runs, tests)
+    P.use_lane = lane_entropy_fits(D, K, P.cutoff) && !(force && (!strcmp(force, "valu") || !strcmp(force, "mfma")));
+    if (P.use_lane) P.use_mfma = false;
+    const int tile_sz = P.use_lane ? 64 : (P.use_mfma ? 16 : 32);          // base samples per tile
     const int ntile = (Mh + tile_sz - 1) / tile_sz;
     // chunks per (component, restart): minimise  ceil(waves / resident slots) * (setup + tiles per wave),
     // i.e. whole rounds of resident waves, with the per-wave setup worth ~1.5 tiles
@@ -732,9 +775,13 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
       }
       static const bool occ_off = [] { const char* e = getenv("VBMC_ENT_OCC"); return e && !strcmp(e, "0"); }();   // A/B: the old constant
       if (occ_off) waves_per_cu = P.use_mfma ? 8 : 5;
+      if (P.use_lane) {
+        const int nb = entropy_lane_occupancy(D, K, compute_grad != 0);
+        waves_per_cu = ENT_LANE_WAVES_HOST * (nb > 0 ? nb : 2);
+      }
       const long long slots = (long long)ctx->num_cu * waves_per_cu * cw;
       const long long kr = (long long)K * P.Rp * (P.use_mfma ? (P.hv & 15) : 1);   // waves per chunk index (hv + 16 TL: with a component tail); Rp: R, or the undivided batch's (plan_restarts)
-      const double setup = 1.5;   // measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
+      const double setup = P.use_lane ? 1.0 : 1.5;   // (lane kernel: a tile of 64 samples is ~1.5 us, the set-up about that)  measured: C = 7 (45 tiles per wave) beats C = 5 (63) by 1 % at the headline shape once the setup loads are batched
       double best = 1e300;
       int bestC = 1;
       for (int c = 1; c <= ntile; ++c) {
@@ -766,7 +813,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     } else if (a->eps_mode == 2) {
       P.d_eps = a->eps; P.eps_stride_r = a->eps_shared ? 0 : (long long)eps_block;
     }
-    if (!P.use_mfma) {
+    if (!P.use_mfma && !P.use_lane) {
       P.ent_lds = ((size_t)K * (P.dt + ENTP_EXTRA) + WAVE + (compute_grad ? (size_t)K * 65 : 0)) * sizeof(double);
       if (P.ent_lds > 160 * 1024) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d, D = %d needs %zu B of LDS (> 160 KiB)", K, D, P.ent_lds);
     }
@@ -900,7 +947,8 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // ---- expected log joint: enqueued on `ls` -- the context's stream, or the auxiliary one beside the entropy kernel
   // ... and so does a pass on a slot stream: the pass on the other slot stream is what fills in around its entropy kernel, and a log
   // joint forked off there is the last to be let onto the chip (profiles/r04_experiments.md section 11)
-  const bool fork = sh.mode == 0 && P.mc && (long long)S * R >= ctx->num_cu / 2 && !ctx->prof_alone && ctx_aux(ctx);   // a single chain: the fork / join events cost more than they hide
+  const bool lane_role_possible = P.use_lane && P.compute_grad && !P.lj_records && dm.N > 1 && lane_role_fits(D, K, dm.N, S);     // (decided below: co_lane)
+  const bool fork = sh.mode == 0 && P.mc && (long long)S * R >= ctx->num_cu / 2 && !ctx->prof_alone && !lane_role_possible && ctx_aux(ctx);   // a single chain: the fork / join events cost more than they hide
   // value + gradient: moments on the matrix cores (k_logjoint_mfma); value only: the VALU kernel.  VBMC_LJ_KERNEL=valu / mfma forces one of them.
   const char* ljf = getenv("VBMC_LJ_KERNEL");
   // one workgroup per (hyper-sample, restart): needs enough of them to fill the chip, otherwise (a single chain) the finer-grained VALU
@@ -908,7 +956,10 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const bool lj_force = ljf && !strcmp(ljf, "mfma");   // tests: exercise the MFMA kernel on small grids too
   // (round 4: from S R = one workgroup per compute unit on -- below, the finer-grained VALU kernel is the faster one: R = 8 at the headline
   // shape, 160 (hyper-sample, restart) workgroups: 56 us against 34 alone, the step 0.394 -> 0.360 ms; equal at R = 16, 142 against 174 us at R = 64)
-  const bool co_shape = sh.mode == 0 && !fork && !lj_force && lj_co_shape(ctx, P);      // (the role takes precedence over the matrix-core kernel where its limits admit the batch)
+  // (round 6) the lane-per-sample kernel of small mixtures carries the role at every batch width: a pass of that class is ONE chip-wide launch
+  static const bool co_off_env = [] { const char* e = getenv("VBMC_LJ_CO"); return e && !strcmp(e, "0"); }();
+  const bool co_lane = lane_role_possible && sh.mode == 0 && !lj_force && !co_off_env && !(ljf && !strcmp(ljf, "valu"));
+  const bool co_shape = co_lane || (sh.mode == 0 && !fork && !lj_force && lj_co_shape(ctx, P));      // (the role takes precedence over the matrix-core kernel where its limits admit the batch)
   // (round 5) ... and enough WAVES in each: with K <= 16 a workgroup of the matrix-core kernel is a single wave walking the whole training
   // set, and the VALU kernel's four waves per cell group are faster until the batch is several chips wide (BASELINE configs[1], K = 10,
   // S R = 512: 28.3 us against 19.9)
@@ -1006,14 +1057,23 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         // (round 5) a BATCH wide enough that the record buffer holds one record per hyper-sample (elbo_plan: ljrec): one role workgroup per
         // cell group -- the restarts supply the parallelism the splits supply to a single chain
         if ((long long)S * std::min(R, P.Rp) >= ctx->num_cu / 2) lc.nsplit = 1;
+        if (P.use_lane) lc.nsplit = 1;      // (the lane kernel's role walks the LDS-staged training set whole)
       }
       lc.nwg = ((K + 3) / 4) * S * lc.nsplit;
+      if (P.use_lane) {      // the role is dealt over the entropy waves themselves (entropy_lane.h): no rows of its own
+        lc.rows = co_rows = 0;
+      } else
       lc.rows = co_rows = (lc.nwg + nc - 1) / nc;
       lc.want_grad = P.compute_grad;
       lc.dm = dm; lc.X = gp->X; lc.alpha = gp->alpha; lc.gpc = gp->gpc; lc.delta2 = P.d_delta2; lc.lj = P.d_lj;
     }
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     if (sh.mode == 2 || nc <= 0) {
+    } else if (P.use_lane) {
+      ea.nc_launch = nc;
+      const int gx = (K * nc + ENT_LANE_WAVES_HOST - 1) / ENT_LANE_WAVES_HOST;
+      bool ok = launch_entropy_lane(D, K, P.compute_grad != 0, dim3(gx, 1 + co_rows, R), st, ea);
+      if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no lane entropy kernel for D = %d, K = %d", D, K);
     } else if (P.use_mfma) {
       bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(nc, K + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
@@ -1765,6 +1825,13 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
 // qs = ceil((D + 2) / 4), kt = k-tiles per wave, hv = waves per workgroup, tail = tail values per lane (0: none).  Returns 0 when
 // the matrix-core kernel does not serve the shape (the VALU kernel does).
 extern "C" int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* tail) {
+  if (lane_entropy_fits(D, K, 0.0)) {       // small mixtures: k_entropy_lane<DT, KP> (qs: DT, kt: KP, four waves per workgroup)
+    if (qs) *qs = 2 * ((D + 1) / 2);
+    if (kt) *kt = 2 * ((K + 1) / 2);
+    if (hv) *hv = ENT_LANE_WAVES_HOST;
+    if (tail) *tail = 0;
+    return 2;
+  }
   int q = 0, k = 0, h = 0;
   const bool ok = mfma_entropy_fits(D, K, 0.0, &q, &k, &h);
   if (qs) *qs = q;

@@ -45,6 +45,41 @@ __device__ __forceinline__ double wave_sum_valu(double v) {
   return xor_sum32(v);
 }
 
+// Sums over the wave of NV per-lane values at once, as a TREE: lanes ^32 and ^16 by the permlane swaps with TWO values per exchange (the
+// swap of registers X, Y leaves [X low half | Y low half] and [X high half | Y high half]: their sum is X folded into lanes 0-31 and Y
+// into lanes 32-63 -- three instructions for the pair), then every register holds four values, one per row of sixteen lanes, reduced
+// by the row steps of wave_sum_valu.  NV = 24: 126 VALU instructions where 24 wave_sum_valu are 720.  Fixed order: deterministic.
+// On return register m = 0 .. (NV + 3) / 4 - 1 of `out` holds, in EVERY lane of row q = lane >> 4, the total of value 4 m + {0, 2, 1, 3}[q]
+// (values beyond NV: zero).
+__device__ __forceinline__ double swap_sum32(double x, double y) {
+  const auto a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double swap_sum16(double x, double y) {
+  const auto a = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+template <int NV>
+__device__ __forceinline__ void wave_sum_tree(const double (&v)[NV], double (&out)[(NV + 3) / 4]) {
+  constexpr int N4 = (NV + 3) / 4;
+  double h[2 * N4];
+#pragma unroll
+  for (int i = 0; i < 2 * N4; ++i) {
+    const double x = 2 * i < NV ? v[2 * i < NV ? 2 * i : 0] : 0.0, y = 2 * i + 1 < NV ? v[2 * i + 1 < NV ? 2 * i + 1 : 0] : 0.0;
+    h[i] = swap_sum32(x, y);                  // lanes 0-31: value 2 i, lanes 32-63: value 2 i + 1
+  }
+#pragma unroll
+  for (int m = 0; m < N4; ++m) {
+    double t = swap_sum16(h[2 * m], h[2 * m + 1]);   // rows: values 4 m, 4 m + 2, 4 m + 1, 4 m + 3
+    t = dpp_pair_sum<0xB1>(t);
+    t = dpp_pair_sum<0x4E>(t);
+    t = dpp_pair_sum<0x141>(t);
+    out[m] = dpp_pair_sum<0x140>(t);
+  }
+}
+
 // fp64 exp used in the hot loops.  Range reduction x = n ln2 + r, |r| <= ln2/2, degree-13 Taylor
 // polynomial in Horner form (|rel err| < 3e-16 before the final scaling), result scaled by
 // 2^n with v_ldexp_f64.  Underflows to 0 and overflows to +inf like exp(); a NaN argument is
@@ -256,6 +291,26 @@ __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restric
   else { u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96); u = fma(r, u, c); }
   const double Tr = T * r;
   return ldexp(fma(Tr, u, T), ni >> 10);
+}
+// The same exp with the rounding by the magic-number addition: three full-rate adds in place of v_rndne_f64 + v_cvt_i32_f64 (both
+// quarter-rate) + v_sub; the integer sits in the low mantissa bits of t -- table index = low 10 bits, binary exponent = bits 10..41 (one
+// v_alignbit).  Valid for |y| < 2^41: the argument is clamped from below at -2^40 (exp -> 0 there anyway); large positive arguments
+// do not occur (they would mean exp = inf).  For the VALU-only kernels (entropy_lane.h), where the quarter-rate pair is a third of the
+// exp's cycles; the matrix-core kernel keeps vb_exp_tab1k (measured there in round 5: no gain).
+template <bool QUAD = false>
+__device__ __forceinline__ double vb_exp_tab1k_m(double y, const double* __restrict__ tab) {
+  const double c = 0.693147180559945309417232 / 1024;
+  const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
+  asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(y), "v"(-1099511627776.0));
+  const double t = y + MAGIC;
+  const int lo = __double2loint(t), hi = __double2hiint(t);
+  const double r = y - (t - MAGIC);
+  const double T = tab[lo & (VB_EXP_TAB1K_N - 1)];
+  double u;
+  if (QUAD) u = fma(r, c * c / 2, c + c * c * c / 32);
+  else { u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96); u = fma(r, u, c); }
+  const double Tr = T * r;
+  return ldexp(fma(Tr, u, T), (int)__builtin_amdgcn_alignbit((unsigned)hi, (unsigned)lo, 10));
 }
 template <bool QUAD = false>
 __device__ __forceinline__ vb_d4 vb_exp_tab1k4(vb_d4 y, const double* __restrict__ tab) {

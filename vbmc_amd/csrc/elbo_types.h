@@ -62,6 +62,7 @@ struct EntArgs {
   int r0, rstride;       // the device-RNG stream of restart r is keyed by r0 + r * rstride: the restart's index in the WHOLE batch when
                          // the batch is dealt over several devices (vbmc_elbo_batch_multi: r0 = g, rstride = G); 0, 1 otherwise
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
+  int nc_launch;         // k_entropy_lane: chunk slots this launch covers (its items are (j, slot) pairs, four per workgroup)
   LjCo lj;               // CO kernels only: the expected log joint as extra workgroups of this launch (lj.rows = 0: none)
 };
 

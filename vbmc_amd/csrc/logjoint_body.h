@@ -11,10 +11,13 @@
 // lane with ni = d (and d+16) and broadcast inside the 16-lane row; the 2D+1 sums are reduced over the 16 lanes of a row only
 // (4 butterfly steps, each shuffle serving four cells).
 // record layout [2D+2] = I_k, w_k*dmu[D], w_k*dsigma (no Jacobian), w_k*dlambda[D]
+// (round 6: on the VALU -- quad permutes and the row (half-)mirror pair the same groups the xor butterfly 1, 2, 4, 8 does, every lane of a
+// group already holding the group's sum: the same bits as the __shfl_xor form without its eight ds_bpermute round trips per value)
 __device__ __forceinline__ double row16_sum(double v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
+  v = dpp_pair_sum<0xB1>(v);
+  v = dpp_pair_sum<0x4E>(v);
+  v = dpp_pair_sum<0x141>(v);
+  return dpp_pair_sum<0x140>(v);
 }
 
 // The sums of one wave over its share of the training set -> pp[kq][NC] (LDS rows of this wave, NC = 2 DT + 2: I, M[DT], S, L[DT]).
@@ -138,7 +141,7 @@ __device__ __forceinline__ void lj_wave_sums(const ElboDims& dm, const double* _
 // Output record of component k = 4 kgroup + kq from `nrows` rows of wave sums (row stride `rstride` doubles, added in row order),
 // one lane per output column.  with_const: the closed-form mean-function terms of :169-174 / :208-210 / :229-231 / :250-252 that do
 // not depend on the training set are added (exactly one of the records that are later summed carries them).
-template <int DT>
+template <int DT, int ROWS = 2 * DT + 2>
 __device__ __forceinline__ void lj_write_record(const ElboDims& dm, const double* __restrict__ v, const double* __restrict__ g,
                                                 const double* __restrict__ delta2, const double* pp0, int nrows, int rstride,
                                                 int kgroup, int want_grad, bool with_const, double* __restrict__ o_s /* [K][2D+2] of (r, s) */) {
@@ -157,8 +160,8 @@ __device__ __forceinline__ void lj_write_record(const ElboDims& dm, const double
     // column c of the output record <-> slot of the row (padded to DT)
     const int d = (c >= 1 && c <= D) ? c - 1 : (c >= D + 2 ? c - D - 2 : 0);
     const int slot = c == 0 ? 0 : (c <= D ? c : (c == D + 1 ? 1 + DT : 2 + DT + d));
-    double acc = pp0[kq * NC + slot];
-    for (int w2 = 1; w2 < nrows; ++w2) acc += pp0[(size_t)w2 * rstride + kq * NC + slot];
+    double acc = pp0[kq * ROWS + slot];
+    for (int w2 = 1; w2 < nrows; ++w2) acc += pp0[(size_t)w2 * rstride + kq * ROWS + slot];
     if (!with_const) {
       o[c] = c == 0 ? acc : wk * acc;
       continue;
@@ -187,17 +190,17 @@ __device__ __forceinline__ void lj_write_record(const ElboDims& dm, const double
 // kgroup = w mod G4, split sp = (w / G4) mod nsplit of the training set, hyper-sample s = w / (G4 nsplit), and writes ITS OWN record
 // lj[r][s nsplit + sp][k][2D+2] -- the reduction over hyper-samples (k_reduce_both with S nsplit "samples") adds the splits, the
 // record of split 0 carries the closed-form terms.  lds: >= 256 + 4 (2 DT + 2) doubles (exp table, then this wave's rows).
-template <int DT>
-__device__ __forceinline__ void lj_co_role(const LjCo& a, const double* __restrict__ vpd, double* lds) {
-  constexpr int NC = 2 * DT + 2;
-  const int w = blockIdx.y * gridDim.x + blockIdx.x, r = blockIdx.z, lane = threadIdx.x & 63;
-  if (w >= a.nwg) return;
+// lj_role_wave: the role for ONE wave -- cell-group index w of restart r, the 256-entry exp table TAB and the wave's own 4 (2 DT + 2)
+// row doubles pp given by the caller.  share_tab: the table belongs to a workgroup of several role waves, each of which has filled its
+// quarter of it -- the ordering point before the first exponential is then a workgroup barrier (every wave of the workgroup reaches it:
+// callers do not return early), otherwise the wave-level fence.
+template <int DT, bool SHARE_TAB = false>
+__device__ __forceinline__ void lj_role_wave(const LjCo& a, const double* __restrict__ vpd, int w, int r, double* TAB, double* pp) {
   const ElboDims& dm = a.dm;
   const int D = dm.D, K = dm.K, G4 = (K + 3) / 4;
+  const bool live = w < a.nwg;
+  if (!live) w = 0;            // (SHARE_TAB: an idle wave still walks to the barrier; it writes nothing)
   const int kgroup = w % G4, t = w / G4, sp = t % a.nsplit, s = t / a.nsplit;
-  double* TAB = lds;
-  double* pp = lds + VB_EXP_TAB_N;
-  for (int i = lane; i < VB_EXP_TAB_N; i += 64) TAB[i] = c_exp2_tab[i];
   VpLayout L{D, K};
   const double* v = vpd + (size_t)r * L.stride();
   const double* g = a.gpc + (size_t)s * GPC_STRIDE(D);
@@ -206,8 +209,163 @@ __device__ __forceinline__ void lj_co_role(const LjCo& a, const double* __restri
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  lj_wave_sums<DT>(dm, v, a.X, a.alpha + (size_t)s * dm.N, g, a.delta2, TAB, kgroup, sp, a.nsplit, a.want_grad, pp, fence);
+  auto ready = [&] { if (SHARE_TAB) __syncthreads(); else fence(); };
+  if (SHARE_TAB && !live) { __syncthreads(); return; }
+  lj_wave_sums<DT>(dm, v, a.X, a.alpha + (size_t)s * dm.N, g, a.delta2, TAB, kgroup, sp, a.nsplit, a.want_grad, pp, ready);
   fence();
   double* o_s = a.lj + ((size_t)r * dm.S * a.nsplit + (size_t)s * a.nsplit + sp) * K * (2 * D + 2);
   lj_write_record<DT>(dm, v, g, a.delta2, pp, 1, 0, kgroup, a.want_grad, sp == 0, o_s);
+}
+
+template <int DT>
+__device__ __forceinline__ void lj_co_role(const LjCo& a, const double* __restrict__ vpd, double* lds) {
+  const int w = blockIdx.y * gridDim.x + blockIdx.x, r = blockIdx.z, lane = threadIdx.x & 63;
+  if (w >= a.nwg) return;
+  double* TAB = lds;
+  double* pp = lds + VB_EXP_TAB_N;
+  for (int i = lane; i < VB_EXP_TAB_N; i += 64) TAB[i] = c_exp2_tab[i];
+  lj_role_wave<DT>(a, vpd, w, r, TAB, pp);
+}
+
+// The role inside k_entropy_lane (entropy_lane.h): everything the cell group reads is in LDS -- the restart's vp block VL, the
+// per-hyper-sample constants GL (all S), delta^2, the training inputs XL ([D][NP], NP = N rounded up to 64, zero-padded) staged by the
+// workgroup, and this hyper-sample's alpha in the wave's own block AL (zero-padded likewise) -- so the walk over the training set waits
+// for LDS, not for memory.  One split (the wave walks the whole training set), records per hyper-sample.
+// Lane layout: cell c = lane & 3 (component 4 kgroup + c), point lane pl = lane >> 2: the sums over a cell's sixteen point lanes are
+// two row rotations (DPP) and the two permlane swaps, and the swaps carry TWO values each (cell4_sum_tree): 57 VALU instructions for
+// the thirteen sums of D = 6 where the four-step row butterfly per value took 266.  The loop body is cut to what it needs (128 -> ~55
+// VALU instructions per slab of 16 points): the standardised distance as ONE fused multiply-add per dimension (mu / tau carried
+// beside 1 / tau), no select and no bound on the padded dimensions and points (their 1 / tau, their alpha are zero), four slabs per trip
+// as independent chains, the exponential by the entropy kernel's 1024-entry table with the argument scaled in the multiply-add that
+// forms it; the gradient factors (:207, :228, :249) are applied to the per-lane partial sums -- they are linear -- so the tree sums the
+// record's columns directly.    scr: LJ_LANE_SCR(DT) doubles of the wave's own.
+#define LJ_LANE_SCR(DT_) (4 * (3 * (DT_) + 2))
+// sums over the lanes of equal (lane & 3) of NV values: on return register m of `out` holds, in the lanes of row q = lane >> 4, the total of
+// value 4 m + {0, 2, 1, 3}[q] for cell lane & 3 (every point lane of the row holds it)
+template <int NV>
+__device__ __forceinline__ void cell4_sum_tree(const double (&v)[NV], double (&out)[(NV + 3) / 4]) {
+  constexpr int N4 = (NV + 3) / 4;
+  double h[2 * N4];
+#pragma unroll
+  for (int i = 0; i < 2 * N4; ++i) {
+    const double x = 2 * i < NV ? v[2 * i < NV ? 2 * i : 0] : 0.0, y = 2 * i + 1 < NV ? v[2 * i + 1 < NV ? 2 * i + 1 : 0] : 0.0;
+    h[i] = swap_sum32(x, y);
+  }
+#pragma unroll
+  for (int m = 0; m < N4; ++m) {
+    double t = swap_sum16(h[2 * m], h[2 * m + 1]);
+    t = dpp_pair_sum<0x128>(t);        // row_ror:8
+    out[m] = dpp_pair_sum<0x124>(t);   // row_ror:4
+  }
+}
+template <int DT>
+__device__ __forceinline__ void lj_lane_role(const LjCo& a, int w, int r, const double* VL, const double* GL, const double* D2L,
+                                             const double* XL, int NP, const double* AL, const double* TAB1K, double* scr) {
+  constexpr int NC = 2 * DT + 2;
+  constexpr int SR = 3 * DT + 2;            // scratch row per cell: [mu / tau (DT) | 1 / tau (DT) | 2 free | lambda (DT)]; the NC record sums later take the head
+  const ElboDims& dm = a.dm;
+  const int D = dm.D, K = dm.K, G4 = (K + 3) / 4;
+  const int kgroup = w % G4, s = w / G4;
+  const double* g = GL + (size_t)s * GPC_STRIDE(D);
+  const int lane = threadIdx.x & 63, pl = lane >> 2, cq = lane & 3;
+  const int kk = 4 * kgroup + cq;
+  const int k = kk < K ? kk : K - 1;
+  VpLayout L{D, K};
+  auto fence = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const double sig = VL[L.sigma() + k];
+  double* row = scr + cq * SR;
+  // point lane pl owns dimension d = pl (DT <= 12)
+  double my_logtau = 0.0;
+  {
+    double mi = 0.0, it = 0.0, lm = 0.0;
+    if (pl < D) {
+      lm = VL[L.lambda() + pl];
+      const double tau = sqrt(sig * sig * lm * lm + g[pl] + D2L[pl]);  // :164
+      my_logtau = log(tau);
+      it = 1.0 / tau;
+      mi = VL[L.mu() + pl + D * k] * it;
+    }
+    if (pl < DT) { row[pl] = mi; row[DT + pl] = it; row[NC + pl] = lm; }     // (lambda behind the NC slots the sums will take: it is read again at the end)
+  }
+  double sumlogtau = dpp_pair_sum<0x128>(my_logtau);      // over the sixteen point lanes of the cell: rotations inside the row, then the rows
+  sumlogtau = dpp_pair_sum<0x124>(sumlogtau);
+  sumlogtau = xor_sum16(sumlogtau);
+  sumlogtau = xor_sum32(sumlogtau);
+  fence();
+  double mit[DT], itau[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { mit[d] = row[d]; itau[d] = row[DT + d]; }     // zero for padded dimensions: they vanish below
+  const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
+  const double ylnnf = VB_EXP_TAB1K_SCALE * lnnf;
+  double accI = 0.0, accA[DT], accQ[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { accA[d] = 0.0; accQ[d] = 0.0; }
+  const double* xr[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) xr[d] = XL + NP * min(d, D - 1) + pl;
+  const double* ar = AL + pl;
+  // slabs of sixteen points per trip: four while their 4 DT distances fit the registers, two beyond (DT = 10, 12 with four spilled)
+  constexpr int U = DT <= 8 ? 4 : 2;
+  for (int n0 = 0; n0 < NP; n0 += 16 * U) {
+    double dl[U][DT], a2[U], za[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a2[u] = 0.0;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        dl[u][d] = fma(-xr[d][n0 + 16 * u], itau[d], mit[d]);        // delta_k = (mu - x) / tau  :167
+        a2[u] = fma(dl[u][d], dl[u][d], a2[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      za[u] = vb_exp_tab1k_m<false>(fma(a2[u], -0.5 * VB_EXP_TAB1K_SCALE, ylnnf), TAB1K) * ar[n0 + 16 * u];   // z_k alpha  :168
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      accI += za[u];
+      if (a.want_grad) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const double t = dl[u][d] * za[u];
+          accA[d] += t;                                      // A_d = sum delta_d z alpha          (:207-208 without its factor)
+          accQ[d] = fma(dl[u][d], t, accQ[d]);               // sum delta_d^2 z alpha; Q_d = this - I   (:228, :249-250 without theirs)
+        }
+      }
+    }
+  }
+  // the record's columns as per-lane partial sums (the factors are linear), summed over the cell's point lanes
+  double vals[NC];
+  vals[0] = accI;
+  {
+    double accS = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const double qd = accQ[d] - accI, lam_d = row[NC + d];
+      const double li = lam_d * itau[d], si = sig * itau[d];
+      accS = fma(li * li, qd, accS);                         // dz_dsigma factor   (:228)
+      vals[1 + d] = -itau[d] * accA[d];                      // dz_dmu factor      (:207)
+      vals[2 + DT + d] = si * si * lam_d * qd;               // dz_dlambda factor  (:249)
+    }
+    vals[1 + DT] = sig * accS;
+  }
+  constexpr int N4 = (NC + 3) / 4;
+  double tot[N4];
+  cell4_sum_tree<NC>(vals, tot);
+  fence();           // the scratch rows become the rows of sums
+  {
+    const int q = lane >> 4, qv = ((q & 1) << 1) | (q >> 1);
+#pragma unroll
+    for (int m = 0; m < N4; ++m) {
+      const int vi = 4 * m + qv;
+      if ((lane & 12) == 0 && vi < NC) row[vi] = tot[m];      // the first point lane of each cell in the row
+    }
+  }
+  fence();
+  double* o_s = a.lj + ((size_t)r * dm.S + s) * K * (2 * D + 2);
+  lj_write_record<DT, SR>(dm, VL, g, D2L, scr, 1, 0, kgroup, a.want_grad, true, o_s);
+  fence();
 }
