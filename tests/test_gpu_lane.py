@@ -59,7 +59,7 @@ def test_the_plan_hook_names_the_class(va):
 
     lib = _lib.load()
     q = [ctypes.c_int() for _ in range(4)]
-    for D, K, kind in ((6, 10, 2), (1, 1, 2), (12, 16, 2), (13, 16, 1), (12, 17, 1), (6, 50, 1)):
+    for D, K, kind in ((6, 10, 2), (1, 1, 2), (8, 16, 2), (12, 8, 2), (10, 10, 2), (12, 9, 1), (10, 11, 1), (12, 16, 1), (13, 16, 1), (12, 17, 1), (6, 50, 1)):
         assert lib.vbmc_entropy_plan(D, K, *[ctypes.byref(x) for x in q]) == kind, (D, K)
     assert lib.vbmc_entropy_plan(5, 7, *[ctypes.byref(x) for x in q]) == 2 and (q[0].value, q[1].value, q[2].value) == (6, 8, 4)
 
@@ -69,7 +69,9 @@ SHAPES = [
     (6, 200, 10, 8, 1000),      # BASELINE configs[1]
     (1, 20, 1, 1, 10),          # one component: q = its own density, H = its entropy
     (1, 30, 16, 2, 130),
-    (12, 50, 16, 2, 200),       # both limits of the class
+    (8, 50, 16, 2, 200),        # the corners of the class
+    (12, 50, 8, 2, 200),
+    (10, 50, 10, 2, 300),
     (12, 40, 1, 1, 64),
     (2, 30, 2, 1, 100),         # BASELINE configs[0]
     (5, 33, 7, 3, 2),           # one antithetic pair per component
@@ -82,7 +84,8 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("D,N,K,S,Ns", SHAPES)
-def test_lane_kernel_matches_oracle_and_matrix_core_kernel(va, D, N, K, S, Ns):
+def test_lane_kernel_matches_oracle_and_matrix_core_kernel(va, monkeypatch, D, N, K, S, Ns):
+    monkeypatch.setenv("VBMC_ENT_KERNEL", "lane")    # (a single evaluation is below the width the policy gives the lane kernel: ask for it)
     p, gp, vp, theta = problem(100 + D + K, D, N, K, S)
     Mh = (Ns + 1) // 2
     eps = np.random.default_rng(5).standard_normal((K, Mh, D))
@@ -110,9 +113,28 @@ def test_lane_kernel_matches_oracle_and_matrix_core_kernel(va, D, N, K, S, Ns):
     assert relerr(o["G"][0], ld["G"][0]) < RT_VAL and relerr(o["dG"][:, 0], ld["dG"][:, 0]) < RT_GRAD
 
 
-def test_batch_of_restarts_and_restart_keys(va):
+def test_the_policy_gives_wide_batches_to_the_lane_kernel(va):
+    """K R tiles >= 96: the lane kernel; a single chain: the matrix-core kernel (its role splits the training set over more waves) --
+    seen from outside as bit-identity with the forced choice"""
+    D, N, K, S, Ns = 6, 80, 10, 3, 300
+    p, gp, vp, theta = problem(7, D, N, K, S)
+    th = np.asfortranarray(theta[:, None] + 0.05 * np.random.default_rng(3).standard_normal((theta.size, 4)))
+    wide = va.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=21)           # 10 x 4 x 3 = 120 tiles
+    one = va.negelcbo_batch(th[:, 0], 0, vp, gp, Ns, True, 0, seed=21)      # 30 tiles
+    with env(VBMC_ENT_KERNEL="lane"):
+        wl = va.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=21)
+    with env(VBMC_ENT_KERNEL="mfma"):
+        om = va.negelcbo_batch(th[:, 0], 0, vp, gp, Ns, True, 0, seed=21)
+        wm = va.negelcbo_batch(th, 0, vp, gp, Ns, True, 0, seed=21)
+    assert np.array_equal(wide["dF"], wl["dF"]) and np.array_equal(one["dF"], om["dF"])
+    assert not np.array_equal(wide["dH"], wm["dH"])        # (the two kernels sum in different orders: equal to rounding, not to the bit)
+    assert relerr(wide["dH"], wm["dH"]) < 1e-12
+
+
+def test_batch_of_restarts_and_restart_keys(va, monkeypatch):
     """R = 5 restarts in one launch: every column equals the same theta evaluated alone under its restart key, bit for bit (a restart's
     records do not depend on the batch it sits in), and matches the oracle on the dumped device stream"""
+    monkeypatch.setenv("VBMC_ENT_KERNEL", "lane")
     D, N, K, S, Ns, Rn = 6, 80, 10, 3, 300, 5
     p, gp, vp, theta = problem(7, D, N, K, S)
     th = np.asfortranarray(theta[:, None] + 0.05 * np.random.default_rng(3).standard_normal((theta.size, Rn)))
@@ -127,7 +149,8 @@ def test_batch_of_restarts_and_restart_keys(va):
         assert relerr(b["F"][r], ref["F"]) < RT_VAL and relerr(b["dF"][:, r], ref["dF"]) < RT_GRAD
 
 
-def test_chunking_does_not_change_the_sum_beyond_rounding(va):
+def test_chunking_does_not_change_the_sum_beyond_rounding(va, monkeypatch):
+    monkeypatch.setenv("VBMC_ENT_KERNEL", "lane")
     D, N, K, S, Ns = 6, 60, 10, 2, 2000
     p, gp, vp, theta = problem(9, D, N, K, S)
     base = va.negelcbo_batch(theta, 0, vp, gp, Ns, True, 0, seed=4)

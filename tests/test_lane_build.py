@@ -34,4 +34,4 @@ def test_no_lane_kernel_spills(tmp_path):
             vg = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
             assert spill == 0 and priv == 0, (m.group(2), m.group(3), m.group(4), spill, priv, vg)
             seen += 1
-    assert seen == 6 * 8 * 2, seen
+    assert seen == (4 * 8 + 5 + 4) * 2, seen          # DT = 2..8: KP = 2..16; DT = 10: KP <= 10; DT = 12: KP <= 8

@@ -385,7 +385,16 @@ int vbmc_occupancy_ent_lane_dt12(int, int, const EntArgs*);
 static bool lane_role_fits(int D, int K, int N, int S) {
   return ((size_t)((N + 63) & ~63) * (D + ENT_LANE_WAVES_HOST) + (size_t)S * GPC_STRIDE(D) + (size_t)VpLayout{D, K}.stride() + D) * sizeof(double) <= 48 * 1024;
 }
-static bool lane_entropy_fits(int D, int K, double cutoff) { return D >= 1 && D <= 12 && K >= 1 && K <= 16 && !(cutoff > 0.0); }
+// The class: K <= 16, D <= 12, dense -- minus the corner where the two signs' densities and the gradient accumulators of a lane do not
+// fit 256 registers (DT = 12 with KP >= 10, DT = 10 with KP >= 12: built for one wave per SIMD those kernels take 2-3x the matrix-core
+// kernel's time, tools/run_lane_sweep.sh; they are not instantiated).
+static bool lane_entropy_fits(int D, int K, double cutoff) {
+  const int dt = 2 * ((D + 1) / 2), kp = 2 * ((K + 1) / 2);
+  return D >= 1 && D <= 12 && K >= 1 && K <= 16 && !(cutoff > 0.0) && !((dt >= 12 && kp >= 10) || (dt >= 10 && kp >= 12));
+}
+// ... and a batch wide enough to fill the chip with 64-sample tiles: a single chain (K R tiles < ~100) is bound by the launch's own
+// latencies, where the matrix-core kernel's role splits the training set over more waves (6 % to 10 % faster there)
+#define ENT_LANE_MIN_TILES 96
 static bool launch_entropy_lane(int D, int K, bool grad, dim3 g, hipStream_t st, const EntArgs& ea) {
   typedef int (*fn_t)(int, int, unsigned, unsigned, unsigned, void*, const EntArgs*);
   static const fn_t fns[6] = {vbmc_launch_ent_lane_dt2, vbmc_launch_ent_lane_dt4, vbmc_launch_ent_lane_dt6,
@@ -748,7 +757,8 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     P.use_mfma = mfma_entropy_fits(D, K, P.cutoff, &P.qs, &P.kt, &P.hv);
     if (force && !strcmp(force, "valu")) P.use_mfma = false;
     // small mixtures: the lane-per-sample kernel (entropy_lane.h).  VBMC_ENT_KERNEL=mfma keeps the matrix-core kernel there (A/B runs, tests)
-    P.use_lane = lane_entropy_fits(D, K, P.cutoff) && !(force && (!strcmp(force, "valu") || !strcmp(force, "mfma")));
+    P.use_lane = lane_entropy_fits(D, K, P.cutoff) && !(force && (!strcmp(force, "valu") || !strcmp(force, "mfma"))) &&
+                 ((long long)K * P.Rp * ((Mh + 63) / 64) >= ENT_LANE_MIN_TILES || (force && !strcmp(force, "lane")));
     if (P.use_lane) P.use_mfma = false;
     const int tile_sz = P.use_lane ? 64 : (P.use_mfma ? 16 : 32);          // base samples per tile
     const int ntile = (Mh + tile_sz - 1) / tile_sz;
@@ -1071,7 +1081,10 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     if (sh.mode == 2 || nc <= 0) {
     } else if (P.use_lane) {
       ea.nc_launch = nc;
-      const int gx = (K * nc + ENT_LANE_WAVES_HOST - 1) / ENT_LANE_WAVES_HOST;
+      // workgroups per restart: four (component, chunk) items each -- and, where the launch carries the role, at least one wave per cell
+      // group (a single chain has ten entropy waves and twenty-four cell groups: two groups behind each other on a wave were most of its launch)
+      int gx = (K * nc + ENT_LANE_WAVES_HOST - 1) / ENT_LANE_WAVES_HOST;
+      if (co) gx = std::max(gx, (ea.lj.nwg + ENT_LANE_WAVES_HOST - 1) / ENT_LANE_WAVES_HOST);
       bool ok = launch_entropy_lane(D, K, P.compute_grad != 0, dim3(gx, 1 + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no lane entropy kernel for D = %d, K = %d", D, K);
     } else if (P.use_mfma) {

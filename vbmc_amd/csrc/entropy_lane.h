@@ -1,5 +1,5 @@
 // k_entropy_lane: the Monte-Carlo entropy + reparameterisation gradient (ent/entmc_vbmc.m:49-104) for SMALL mixtures (K <= 16,
-// D <= 12) -- the class where the matrix-core kernel (entropy_mfma.h) pads ten components to a sixteen-wide k-tile, D + 2 columns to
+// D <= 12, less the corner that does not fit the registers) -- the class where the matrix-core kernel (entropy_mfma.h) pads ten components to a sixteen-wide k-tile, D + 2 columns to
 // sixteen, spends a wave instruction on sixteen samples, and pays a 4 us set-up per wave for a 19 us life (BASELINE configs[1]).
 //
 //   lane  <-> one BASE sample; the lane evaluates both signs of the antithetic pair (entmc_vbmc.m:53-54), which share the even part of
@@ -39,12 +39,12 @@ static inline size_t ent_lane_role_lds(const EntArgs& ea) {
 #ifdef ENT_LANE_OCC_ALL          // A/B builds (tools/lane_build.py)
 #define ENT_LANE_OCC(DT_, KP_) ENT_LANE_OCC_ALL
 #endif
-// Two, except where the two signs' densities, the weight-gradient accumulators and the 4 DT gradient accumulators do not fit 256
-// registers: those instantiations are built for ONE wave per SIMD (512 registers).  No lane kernel may spill: with 87 spilled
-// registers (DT = 12, KP = 14, four role slabs per trip) the launch returned run-to-run different, wrong sums -- the CPU test
-// tests/test_lane_build.py compiles every instantiation and requires a zero spill count and no private segment.
+// Two.  No lane kernel may spill: with 87 spilled registers (DT = 12, KP = 14, four role slabs per trip) a launch returned run-to-run
+// different, wrong sums -- the instantiations whose two signs' densities, weight-gradient and 4 DT gradient accumulators do not fit
+// 256 registers are outside the class (abi_elbo.hip: lane_entropy_fits), and tests/test_lane_build.py compiles every instantiation
+// and requires a zero spill count and no private segment.
 #ifndef ENT_LANE_OCC
-#define ENT_LANE_OCC(DT_, KP_) ((((DT_) >= 12 && (KP_) >= 10) || ((DT_) >= 10 && (KP_) >= 12)) ? 1 : 2)
+#define ENT_LANE_OCC(DT_, KP_) 2
 #endif
 
 #ifdef VBMC_INSTRUMENT   // per-wave timeline (tools/lane_timeline.py): [entry, staged, role begin, role end, tiles begin, tiles end, exit] on the 100 MHz counter + HW_ID | XCC_ID << 32
