@@ -301,18 +301,22 @@ def main():
     cdev = dev if (backend == "nccl" and ndev_real) else torch.device("cpu")  # where collective buffers live
 
     if args.check_launch:
-        me = torch.tensor([rank, os.getpid(), gpu if ndev_real else -1], dtype=torch.int64, device=cdev)
+        # (restart_offset, restart_stride): the device-RNG keys of this rank's share of the dealt batch -- restart r of the undivided batch
+        # sits on rank r mod world (vbmc_elbo_batch_multi; misc/vpsieve_vbmc.m:74-83 is the loop that is dealt)
+        me = torch.tensor([rank, os.getpid(), gpu if ndev_real else -1, rank % world, world], dtype=torch.int64, device=cdev)
+        NF = 5
         if multi:
-            allr = torch.empty(world * 3, dtype=torch.int64, device=cdev)
+            allr = torch.empty(world * NF, dtype=torch.int64, device=cdev)
             dist.all_gather_into_tensor(allr, me)
             dist.barrier()
         else:
             allr = me
         if rank == 0:
-            rows = allr.cpu().numpy().reshape(world, 3)
-            print(json.dumps({"check_launch": True, "n_gpus": world, "backend": backend if world > 1 else None,
+            rows = allr.cpu().numpy().reshape(world, NF)
+            print(json.dumps({"check_launch": True, "n_gpus": world, "world_size_observed": int(rows.shape[0]), "backend": backend if world > 1 else None,
                               "spawned_by_bench": os.environ.get("VBMC_BENCH_SPAWNED") == "1",
-                              "ranks": [{"rank": int(a), "pid": int(b), "device": int(c)} for a, b, c in rows]}), flush=True)
+                              "ranks": [{"rank": int(a), "pid": int(b), "device": int(c), "restart_offset": int(d), "restart_stride": int(e)}
+                                        for a, b, c, d, e in rows]}), flush=True)
         if multi:
             dist.destroy_process_group()
         return

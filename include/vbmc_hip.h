@@ -44,10 +44,27 @@ typedef struct vbmc_gp vbmc_gp;   /* device-resident gp.post(1..S) (gplite_post.
 
 /* ---- library / context ------------------------------------------------------------- */
 int vbmc_abi_version(void);
-/* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private one.  Side effect, once per process and only
- * while the HIP runtime has not been initialised by anyone: setenv("GPU_MAX_HW_QUEUES", "8", no overwrite) -- the pipelined forms keep
- * five streams busy and the runtime's default of four hardware queues serialises two of them (VBMC_HW_QUEUES=0: leave it alone,
- * VBMC_HW_QUEUES=n: that many). */
+/* The shapes the library accepts -- the numbers its own validation enforces (anything beyond is VBMC_ERR_UNSUPPORTED and falls
+ * through to the reference), so that a binding asks instead of restating them: matlab/vbmc_hip_supported.m reads them through
+ * vbmc_hip_mex('limits').  A pure host function: no device, no context.  Replaces nothing in the reference (it has no limits);
+ * the fall-through edges are listed in INTEGRATION.md section 4. */
+typedef struct vbmc_limits {
+  uint32_t struct_size;      /* sizeof(vbmc_limits) of the caller */
+  int32_t max_D;             /* dimensions (every entry point) */
+  int32_t max_K;             /* mixture components (misc/negelcbo_vbmc.m, ent/entmc_vbmc.m) */
+  int32_t max_N;             /* training points of the surrogate on the factor paths: gplite_post / _pred / _nlZ, the variance of the
+                                expected log joint, the acquisition sweep (the plain expected log joint has no limit) */
+  int32_t max_Na;            /* importance points of acqviqr / acqimiqr */
+  int32_t max_T_vargrad;     /* variational parameters with the gradient of the variance (compute_var = 2) */
+  int32_t delta_ok;          /* 1: vp.delta ~= 0 is accelerated */
+  int32_t meanfun_mask;      /* bit i set: gplite mean function id i is accelerated (0, 1, 4) */
+} vbmc_limits;
+vbmc_status vbmc_get_limits(vbmc_limits* out);
+/* stream: a hipStream_t to launch on (e.g. torch's current stream) or NULL for a private one.  Side effect of the FIRST call in a process (std::call_once;
+ * later contexts do not touch the environment): setenv("GPU_MAX_HW_QUEUES", "8", no overwrite) -- the pipelined forms keep five
+ * streams busy and the runtime's default of four hardware queues serialises two of them (VBMC_HW_QUEUES=0: leave it alone,
+ * VBMC_HW_QUEUES=n: that many).  It takes effect only if no other HIP user (torch, say) initialised the runtime earlier; a host with
+ * threads that read the environment concurrently should set the variable itself and pass VBMC_HW_QUEUES=0. */
 vbmc_status vbmc_ctx_create(int device, void* stream, vbmc_ctx** out);
 void vbmc_ctx_destroy(vbmc_ctx* ctx);
 const char* vbmc_last_error(const vbmc_ctx* ctx);

@@ -6,13 +6,14 @@ function [H,dH] = entmc_vbmc(vp,Ns,grad_flags,jacobian_flag)
 % the flagged groups in the order [mu(:); log sigma; log lambda; eta] with the Jacobians applied
 % (:110-125), or without them for JACOBIAN_FLAG = 0 (gradients with respect to sigma, lambda and w themselves).
 % VBMC_HIP_PARITY=1: the K blocks randn(D,1,Ns/2) are drawn here in the reference's order (:53), and nothing else is drawn.
-% K > 256 (the library's limit) goes to the reference before any draw.
+% A mixture beyond the library's limits (vbmc_hip_supported(): max_K, max_D) goes to the reference before any draw.
 if nargin < 2 || isempty(Ns); Ns = 10; end
 if nargout < 2; grad_flags = false; elseif nargin < 3 || isempty(grad_flags); grad_flags = true; end
 if isscalar(grad_flags); grad_flags = ones(1,4)*grad_flags; end
 if nargin < 4 || isempty(jacobian_flag); jacobian_flag = true; end
 g = any(grad_flags);
-if vp.K > 256 || vp.D > 32
+lim = vbmc_hip_supported();
+if vp.K > lim.max_K || vp.D > lim.max_D
     ref = vbmc_hip_reference('entmc_vbmc');
     if nargout > 1; [H,dH] = ref(vp,Ns,grad_flags,jacobian_flag); else; H = ref(vp,Ns,grad_flags,jacobian_flag); end
     return;

@@ -57,7 +57,7 @@ gp.outwarpfun = [];
 if Nhyp ~= gp.Ncov+gp.Nnoise+gp.Nmean
     error('gplite_post:dimmismatch','Number of hyperparameters mismatched with GP model specification.');
 end
-[alpha,L,sW,mult,lch] = vbmc_hip_mex('gp_post',hyp,X,y,s2,gp.meanfun,gp.noisefun);
+[alpha,L,sW,mult,lch,hdev] = vbmc_hip_mex('gp_post',hyp,X,y,s2,gp.meanfun,gp.noisefun);   % hdev: the posterior the device just built
 for s = 1:Ns
     gp.post(s).hyp = hyp(:,s);
     gp.post(s).alpha = alpha(:,s);
@@ -66,6 +66,10 @@ for s = 1:Ns
     gp.post(s).sn2_mult = mult(s);
     gp.post(s).Lchol = logical(lch(s));
 end
+% the factorisation stays where it was computed: registered for this gp, so that the next negelcbo_vbmc / gplogjoint / gplite_pred on
+% it uploads nothing (through round 5 the gateway freed it here and the first evaluation sent X, alpha and all of L back:
+% 25.6 MB at N = 400, S = 20).  gplite/gplite_post.m:167-172 is where the reference finishes the struct.
+vbmc_hip_gp_handle(gp,hdev);
 end
 
 function ok = rank1_supported(gp)

@@ -23,17 +23,28 @@ if compute_vargrad && compute_var ~= 2
 end
 
 vpflags = [vp.optimize_mu, vp.optimize_sigma, vp.optimize_lambda, vp.optimize_weights];
-supported = any(gp.meanfun == [0 1 4]) ...         % (round 5: dvarF without the Jacobians and per hyper-sample are accelerated too)
+% shapes and model ids through vbmc_hip_supported (D, K, N, covariance, mean function, integrated mean, warping: the library's own
+% limits), the call form here; whatever the library still refuses (vbmc_hip:unsupported) falls through below as well -- this
+% function draws no random numbers, so a second pass on the reference is always exact
+supported = vbmc_hip_supported(gp,vp,compute_var ~= 0) ...         % (round 5: dvarF without the Jacobians and per hyper-sample are accelerated too)
     && (~any(grad_flags) || isequal(logical(grad_flags(:)'),logical(vpflags))) ...
-    && ~(isfield(gp,'intmeanfun') && gp.intmeanfun > 0) && (~vp.optimize_weights || isfield(vp,'eta'));
-if ~supported
-    ref = vbmc_hip_reference('gplogjoint');
-    outs = cell(1,max(nargout,1));
-    [outs{:}] = ref(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K);
-    outs(end+1:7) = {[]};
-    [F,dF,varF,dvarF,varss,I_sk,J_sjk] = outs{:};
-    return;
+    && (~vp.optimize_weights || isfield(vp,'eta'));
+if supported
+    try
+        [F,dF,varF,dvarF,varss,I_sk,J_sjk] = on_device(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K,compute_vargrad);
+        return;
+    catch err
+        if ~strcmp(err.identifier,'vbmc_hip:unsupported'); rethrow(err); end
+    end
 end
+ref = vbmc_hip_reference('gplogjoint');
+outs = cell(1,max(nargout,1));
+[outs{:}] = ref(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K);
+outs(end+1:7) = {[]};
+[F,dF,varF,dvarF,varss,I_sk,J_sjk] = outs{:};
+end
+
+function [F,dF,varF,dvarF,varss,I_sk,J_sjk] = on_device(vp,gp,grad_flags,avg_flag,jacobian_flag,compute_var,separate_K,compute_vargrad)
 [theta,vp] = get_vptheta(vp);                  % misc/get_vptheta.m: the rescaled vp, so that theta and the fixed groups agree
 h = vbmc_hip_gp_handle(gp);
 g = any(grad_flags);

@@ -3,8 +3,9 @@ function [F,dF,G,H,varF,dH,varGss,varG,varH,I_sk,J_sjk] = negelcbo_vbmc(theta,be
 %
 % Same signature, nargin/nargout defaulting and error ids as the reference
 % (misc/negelcbo_vbmc.m:1-24).  Put this directory BEFORE the VBMC folders on the path.  Anything
-% outside the accelerated path (unsupported mean function, weights-only optimisation, K > 256,
-% ...) falls through to the reference implementation found further down the path.
+% outside the accelerated path (unsupported mean function, weights-only optimisation, a mixture or a
+% training set beyond the library's limits -- vbmc_hip_supported asks the library for them -- ...) falls
+% through to the reference implementation found further down the path.
 %
 % Random numbers.  The reference draws K blocks randn(D,1,Ns/2) per call when Ns > 0 (ent/entmc_vbmc.m:53) and nothing
 % when Ns == 0 (entlb_vbmc, misc/negelcbo_vbmc.m:104-110).  VBMC_HIP_PARITY=1: exactly those blocks are drawn here, in

@@ -29,6 +29,9 @@
 //     [acq,fbar,vtot] = vbmc_hip_mex('acq_iqr', h, his, Xs, gplengthscale, X_rescaled, sn2new, var_regularized, TolGPVar)
 //     [nlZ,dnlZ] = vbmc_hip_mex('gp_nlz', Hyp /*Nhyp x B*/, X, y, s2, meanfun, noisefun)   (gplite_nlZ for B vectors)
 //     C = vbmc_hip_mex('sq_dist', a, b)
+//     lim = vbmc_hip_mex('limits')                          -> struct max_D, max_K, max_N, max_Na, max_T_vargrad, delta_ok, meanfun: the shapes the
+//                                                             library accepts (vbmc_get_limits; no device needed) -- matlab/vbmc_hip_supported.m
+//     n3 = vbmc_hip_mex('stats')                            -> [host uploads of a surrogate, device posteriors kept, rank-one appends kept]
 // Every GPU of the node from ONE MATLAB process (the communicator inside the library, include/vbmc_hip.h):
 //     n  = vbmc_hip_mex('comm_open', ndev)                 -> must be the first command of the session: a context and an RCCL rank
 //                                                             per device; the single-device commands then run on device 0.
@@ -56,6 +59,7 @@
 #include "vbmc_hip.h"
 
 static vbmc_ctx* g_ctx = nullptr;
+static long long g_stats[3] = {0, 0, 0};   // 'stats': gp_upload(_all) commands, gp_post handles kept, gp_rank1 appends
 static vbmc_comm* g_comm = nullptr;   // 'comm_open': owns one context per device; g_ctx is then its device-0 context
 
 static void at_exit() {
@@ -181,6 +185,26 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
   char cmd[32];
   mxGetString(prhs[0], cmd, sizeof cmd);
 
+  if (!strcmp(cmd, "limits")) {     // the shapes the library accepts (vbmc_get_limits: a host function, no device): struct for vbmc_hip_supported.m
+    vbmc_limits lim;
+    lim.struct_size = sizeof lim;
+    if (vbmc_get_limits(&lim) != VBMC_OK) return raise("vbmc_hip:abi", "vbmc_get_limits refused the struct (ABI mismatch)");
+    const char* names[] = {"max_D", "max_K", "max_N", "max_Na", "max_T_vargrad", "delta_ok", "meanfun"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 7, names);
+    const double v[6] = {(double)lim.max_D, (double)lim.max_K, (double)lim.max_N, (double)lim.max_Na, (double)lim.max_T_vargrad, (double)lim.delta_ok};
+    for (int i = 0; i < 6; ++i) { mxArray* a = mxCreateDoubleMatrix(1, 1, mxREAL); mxGetDoubles(a)[0] = v[i]; mxSetField(plhs[0], 0, names[i], a); }
+    int nm = 0;
+    for (int i = 0; i < 31; ++i) nm += (lim.meanfun_mask >> i) & 1;
+    mxArray* mf = mxCreateDoubleMatrix(1, nm, mxREAL);
+    for (int i = 0, j = 0; i < 31; ++i) if ((lim.meanfun_mask >> i) & 1) mxGetDoubles(mf)[j++] = i;
+    mxSetField(plhs[0], 0, "meanfun", mf);
+    return 0;
+  }
+  if (!strcmp(cmd, "stats")) {      // [surrogates uploaded from the host, posteriors built on the device, rank-one appends] since the gateway was loaded
+    plhs[0] = mxCreateDoubleMatrix(1, 3, mxREAL);
+    for (int i = 0; i < 3; ++i) mxGetDoubles(plhs[0])[i] = (double)g_stats[i];
+    return 0;
+  }
   if (!strcmp(cmd, "open")) return ensure_ctx(nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0);
   if (!strcmp(cmd, "comm_open")) {
     if (g_comm || g_ctx) return raise("vbmc_hip:usage", "comm_open must be the first command of the session");
@@ -211,6 +235,7 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
                                     g.L.data(), g.sW1.data(), g.lch.data(), &h);
     if (st == VBMC_OK) st = vbmc_gp_set_noise(g_ctx, h, g.nf, g.mult.data());
     if (st != VBMC_OK) return fail(st);
+    ++g_stats[0];
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
     *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
     return 0;
@@ -227,6 +252,7 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     if (st != VBMC_OK) return fail_comm(st);
     for (int i = 0; i < n && st == VBMC_OK; ++i) st = vbmc_gp_set_noise(vbmc_comm_ctx(g_comm, i), hs[i], g.nf, g.mult.data());
     if (st != VBMC_OK) { vbmc_gp_free_all(g_comm, hs.data()); return raise("vbmc_hip:error", "vbmc_gp_set_noise failed on a replica"); }
+    ++g_stats[0];
     plhs[0] = mxCreateNumericMatrix(1, n, mxUINT64_CLASS, mxREAL);
     for (int i = 0; i < n; ++i) ((uint64_t*)mxGetData(plhs[0]))[i] = (uint64_t)(uintptr_t)hs[i];
     return 0;
@@ -407,7 +433,7 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
     if (nlhs > 2) plhs[2] = sW;
     if (nlhs > 3) plhs[3] = mult;
     if (nlhs > 4) plhs[4] = lch;
-    if (nlhs > 5) { plhs[5] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[5]) = (uint64_t)(uintptr_t)h; }
+    if (nlhs > 5) { plhs[5] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[5]) = (uint64_t)(uintptr_t)h; ++g_stats[1]; }
     else vbmc_gp_free(g_ctx, h);
     return 0;
   }
@@ -425,7 +451,7 @@ static int dispatch(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) 
                                           mxGetDoubles(prhs[6]), mxGetDoubles(plhs[0]), nlhs > 1 ? mxGetDoubles(L) : nullptr, &hn);
     if (st != VBMC_OK) return fail(st);
     if (nlhs > 1) plhs[1] = L;
-    if (nlhs > 2) { plhs[2] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[2]) = (uint64_t)(uintptr_t)hn; }
+    if (nlhs > 2) { plhs[2] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[2]) = (uint64_t)(uintptr_t)hn; ++g_stats[2]; }
     else vbmc_gp_free(g_ctx, hn);
     return 0;
   }

@@ -67,6 +67,9 @@ class Mex:
         L.mxGetNumberOfDimensions.restype = sz; L.mxGetNumberOfDimensions.argtypes = [vp]
         L.mxGetDimensions.restype = C.POINTER(sz); L.mxGetDimensions.argtypes = [vp]
         L.mxGetNumberOfElements.restype = sz; L.mxGetNumberOfElements.argtypes = [vp]
+        L.mxGetField.restype = vp; L.mxGetField.argtypes = [vp, sz, C.c_char_p]
+        L.mxGetNumberOfFields.restype = C.c_int; L.mxGetNumberOfFields.argtypes = [vp]
+        L.mxGetFieldNameByNumber.restype = C.c_char_p; L.mxGetFieldNameByNumber.argtypes = [vp, C.c_int]
         L.mock_mex_call.restype = C.c_int
         L.mock_mex_call.argtypes = [C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_char_p, sz, C.c_char_p, sz]
         L.mock_mex_live_arrays.restype = C.c_long
@@ -127,6 +130,13 @@ class Mex:
         nd = L.mxGetNumberOfDimensions(h)
         dims = tuple(L.mxGetDimensions(h)[i] for i in range(nd))
         n = L.mxGetNumberOfElements(h)
+        if cls == mxSTRUCT:        # 1 x 1 struct -> dict (what 'limits' returns)
+            assert n == 1
+            out = {}
+            for i in range(L.mxGetNumberOfFields(h)):
+                name = L.mxGetFieldNameByNumber(h, i).decode()
+                out[name] = self.from_mx(L.mxGetField(h, 0, name.encode()))
+            return out
         dt = _NP[cls]
         out = np.empty(dims, dtype=dt, order="F")
         if n:

@@ -45,6 +45,19 @@ def test_external_launcher_ranks_are_used_as_they_are():
     assert len({r["pid"] for r in line["ranks"]}) == 2
 
 
+@pytest.mark.timeout(400)
+def test_eight_ranks_as_the_driver_launches_them():
+    """BASELINE configs[3] is eight ranks on one node (never available to this build: SCALE skipped in every round).  What can be held
+    without the hardware: `bench.py --gpus 8` under the driver's own launcher creates eight processes, every one joins the group, and
+    the eight shares of the dealt batch carry eight distinct restart offsets with stride 8 (restart r on rank r mod 8,
+    misc/vpsieve_vbmc.m:74-83)."""
+    line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                 "--master-port", "29719", BENCH, "--gpus", "8", "--check-launch"], {"VBMC_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}, 380)
+    assert line["n_gpus"] == 8 and line["world_size_observed"] == 8 and line["backend"] == "gloo"
+    assert len({r["pid"] for r in line["ranks"]}) == 8 and sorted(r["rank"] for r in line["ranks"]) == list(range(8))
+    assert sorted(r["restart_offset"] for r in line["ranks"]) == list(range(8)) and {r["restart_stride"] for r in line["ranks"]} == {8}
+
+
 def test_single_rank_default():
     line = _run([sys.executable, BENCH, "--check-launch"], {}, 120)
     assert line["n_gpus"] == 1 and len(line["ranks"]) == 1

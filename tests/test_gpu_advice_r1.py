@@ -103,3 +103,37 @@ def test_pred_and_acquisition_with_output_dependent_noise(va, noisefun):
     acq = va.acqwrapper_vbmc(Xs, vp, gp, st, False, "acqf_vbmc", None)
     acr = R.acqwrapper_vbmc(Xs, vp, ref, st, "acqf")[0]
     assert relerr(acq, acr) < 1e-7
+
+
+def test_entry_points_refuse_outputs_they_do_not_serve(va):
+    """dvarG_s / dG_s (and the other per-hyper-sample / per-component outputs) are served by vbmc_elbo_batch alone.  The Adam
+    loop and the sharded evaluation run elbo_plan, which validates the fields, and then neither allocate nor read them back: they used
+    to return VBMC_OK with the caller's buffer untouched.  Now: VBMC_ERR_UNSUPPORTED, and the buffer is still untouched."""
+    import ctypes as C
+
+    from vbmc_amd._lib import VbmcUnsupported, ptr
+    from vbmc_amd.elbo import _build_args
+
+    p = synth_problem(4, 3, 30, 4, 2)
+    gp = R.gplite_post(p["hyp"], p["X"], p["y"], meanfun=4)
+    vp = R.make_vp(p["mu"], p["sigma"], p["lam"], eta=p["eta"])
+    vp["w"] = np.exp(p["eta"]) / np.sum(np.exp(p["eta"]))
+    theta = np.concatenate([p["mu"].reshape(-1, order="F"), np.log(p["sigma"]), np.log(p["lam"]), p["eta"]]).reshape(-1, 1)
+    eng = va.default_engine()
+    ctx = eng.ctx
+    T, S = theta.shape[0], 2
+    dgp = eng.device_gp(gp, need_L=True)
+    for field in ("dvarG_s", "dG_s"):
+        cv = 2 if field == "dvarG_s" else 0
+        a, keep, _ = _build_args(np.asfortranarray(theta), 1.0 if cv else 0.0, vp, gp, 20, True, cv, None, False, None, None, False, 3, eng, 0.0)
+        sentinel = np.full((T, S, 1), 12345.0, order="F")
+        setattr(a, field, ptr(sentinel))
+        x = np.zeros((T, 1), order="F"); f = np.zeros(1); it = np.zeros(1, dtype=np.int32)
+        with pytest.raises(VbmcUnsupported):
+            ctx.check(ctx.lib.vbmc_adam_batch(ctx.h, dgp.h, C.byref(a), 1e-3, 5, 1e-3, 0.1, 200.0, ptr(x), ptr(f),
+                                               it.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None))
+        assert np.all(sentinel == 12345.0)
+        if cv == 0:
+            n = C.c_size_t(0)
+            with pytest.raises(VbmcUnsupported):
+                ctx.check(ctx.lib.vbmc_elbo_shard_size(ctx.h, dgp.h, C.byref(a), 2, C.byref(n)))

@@ -70,7 +70,7 @@ def _big_gp(seed, D, N, S, noisy=False, low_noise=False):
 
 
 # Round 5: N = 4500 -- beyond the 3872 of the four-column slab: two right-hand sides per wave (up to N = 6800; one up
-# to 10208), every GP / variance path.
+# to 9696), every GP / variance path.
 @pytest.mark.parametrize("cfg", [(6, 1500, 2, False), (4, 2200, 1, False), (5, 1300, 2, True), (3, 4500, 1, False)])
 def test_gp_post_pred_rank1_beyond_the_wide_slab(va, cfg):
     D, N, S, low = cfg

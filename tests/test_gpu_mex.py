@@ -229,6 +229,36 @@ def test_gp_post_pred_rank1(mex, va, noisy):
     mex.call(0, "gp_free", hh)
 
 
+def test_limits_command_and_a_posterior_that_stays_on_the_device(mex, va):
+    """'limits' hands the shims the library's own numbers (matlab/vbmc_hip_supported.m); 'gp_post' asked for its sixth output leaves the
+    posterior on the device and the objective evaluated on that handle equals the one on an uploaded copy WITHOUT any upload
+    (matlab/gplite_post.m registers the handle with vbmc_hip_gp_handle: the next negelcbo_vbmc sends nothing; 'stats' counts)."""
+    lim = mex.call(1, "limits")[0]
+    assert isinstance(lim, dict) and list(lim) == ["max_D", "max_K", "max_N", "max_Na", "max_T_vargrad", "delta_ok", "meanfun"]
+    assert (lim["max_D"][0, 0], lim["max_K"][0, 0], lim["max_N"][0, 0], lim["max_Na"][0, 0], lim["delta_ok"][0, 0]) == (32, 512, 9696, 256, 1)
+    assert lim["meanfun"].reshape(-1).tolist() == [0, 1, 4]
+    p, gp, vp, theta = make()
+    S = 3
+    n0 = mex.call(1, "stats")[0].reshape(-1)
+    nf = np.array(p["noisefun"], dtype=float).reshape(1, -1)
+    out = mex.call(6, "gp_post", p["hyp"], p["X"], p["y"].reshape(-1, 1), None, p["meanfun"], nf)
+    hd = np.uint64(out[5][0, 0])
+    n1 = mex.call(1, "stats")[0].reshape(-1)
+    assert (n1 - n0).tolist() == [0, 1, 0]
+    a = mex.call(2, "elbo", hd, theta.reshape(-1, 1), vp_struct(vp), 40, 1, 0, 0, 0, None, None, 77, S)
+    n2 = mex.call(1, "stats")[0].reshape(-1)
+    assert (n2 - n0).tolist() == [0, 1, 0]                  # the evaluation uploaded nothing
+    hu = np.uint64(mex.call(1, "gp_upload", gp_struct(gp))[0][0, 0])
+    b = mex.call(2, "elbo", hu, theta.reshape(-1, 1), vp_struct(vp), 40, 1, 0, 0, 0, None, None, 77, S)
+    assert (mex.call(1, "stats")[0].reshape(-1) - n0).tolist() == [1, 1, 0]
+    assert abs(a[0][0, 0] - b[0][0, 0]) <= 1e-12 * abs(b[0][0, 0]) and np.max(np.abs(a[1] - b[1])) <= 1e-11 * np.max(np.abs(b[1]))
+    mex.call(0, "gp_free", hd)
+    mex.call(0, "gp_free", hu)
+    # five outputs: the gateway frees the device posterior itself (the round-5 shim's form: nothing leaks)
+    mex.call(5, "gp_post", p["hyp"], p["X"], p["y"].reshape(-1, 1), None, p["meanfun"], nf)
+    assert (mex.call(1, "stats")[0].reshape(-1) - n0).tolist() == [1, 1, 0]
+
+
 def test_gp_nlz_and_sq_dist(mex, va):
     p = synth_problem(7, 3, 35, 4, 5)
     nf = np.array(p["noisefun"], dtype=float).reshape(1, -1)

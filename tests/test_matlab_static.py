@@ -173,3 +173,17 @@ def test_random_draws_per_branch_match_the_reference():
         ref = open("/root/reference/misc/vpoptimize_vbmc.m").read()
         assert calls(ref) == ["randi"] and "idx(randi(numel(idx)))" in ref
         assert calls(open("/root/reference/misc/negelcbo_vbmc.m").read()) == []
+
+
+def test_gplite_post_keeps_the_device_posterior_and_gplogjoint_falls_through():
+    """matlab/gplite_post.m asks 'gp_post' for its sixth output (the device handle) and registers it for the gp it returns -- the
+    next evaluation uploads nothing (tests/test_gpu_mex.py runs that sequence through the gateway); matlab/gplogjoint.m catches
+    vbmc_hip:unsupported like negelcbo_vbmc.m does and hands the call to the reference."""
+    post = open(os.path.join(ROOT, "matlab", "gplite_post.m")).read()
+    m = re.search(r"\[([^\]]*)\]\s*=\s*vbmc_hip_mex\('gp_post'", post)
+    assert m and len([t for t in m.group(1).split(",") if t.strip()]) == 6
+    hname = m.group(1).split(",")[-1].strip()
+    assert re.search(r"vbmc_hip_gp_handle\(gp,\s*%s\)" % re.escape(hname), post)
+    lj = strip(open(os.path.join(ROOT, "matlab", "gplogjoint.m")).read())
+    assert "try" in lj and "catch err" in lj and "vbmc_hip_supported(gp,vp" in lj
+    assert re.search(r"strcmp\(err\.identifier,\s*''\)", lj) and "vbmc_hip_reference(''" in lj

@@ -329,6 +329,9 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
   if (a->eps_mode != 0 && !(a->eps_mode == 1 && a->eps_shared))
     return comm_err(c, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_batch_multi: device RNG (eps_mode 0) or one shared host block of draws only");
   if (a->restart_offset != 0 || a->restart_stride > 1) return comm_err(c, VBMC_ERR_INVALID, "vbmc_elbo_batch_multi deals the restarts itself");
+  //  per-hyper-sample GRADIENTS are served by vbmc_elbo_batch alone: elbo_plan would accept the fields, this path neither
+  // allocates nor reads them back -- refuse instead of returning OK with the caller's buffers untouched
+  if (a->dG_s || a->dvarG_s) return comm_err(c, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_batch_multi: per-hyper-sample gradients (dG_s, dvarG_s) only through vbmc_elbo_batch");
   const int G = c->world, R = a->R, K = a->K, D = a->D;
   if (R < 1 || K < 1 || D < 1) return comm_err(c, VBMC_ERR_INVALID, "D, K, R must be positive");
   int T = 0;

@@ -28,9 +28,14 @@ static vbmc_status ctx_create_impl(int device, void* stream, vbmc_ctx** out, boo
   // process -- so it is raised HERE, ahead of this function's own first HIP call, for every host alike (the MEX gateway, ctypes, a C
   // caller).  A value already in the environment is kept; it has no effect when another HIP user (torch, say) initialised the runtime
   // first -- the streams are then placed among the queues that exist (stream_beside) -- and VBMC_HW_QUEUES=0 leaves the variable alone.
+  // ONCE per process (it ran on every context creation -- setenv from a library races with getenv in the host's other
+  // threads, the MATLAB JVM's among them -- so the window is the first creation only, before this library has made any HIP call).
   {
-    const char* hq = getenv("VBMC_HW_QUEUES");
-    if (!(hq && !strcmp(hq, "0"))) (void)setenv("GPU_MAX_HW_QUEUES", hq && atoi(hq) > 0 ? hq : "8", 0);
+    static std::once_flag hq_once;
+    std::call_once(hq_once, [] {
+      const char* hq = getenv("VBMC_HW_QUEUES");
+      if (!(hq && !strcmp(hq, "0"))) (void)setenv("GPU_MAX_HW_QUEUES", hq && atoi(hq) > 0 ? hq : "8", 0);
+    });
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VBMC_ERR_NO_DEVICE;
@@ -193,7 +198,7 @@ static vbmc_status gp_upload_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, 
   *out = nullptr;
   if (N <= 0 || D <= 0 || S <= 0 || !X || !hyp || !alpha || !sW1)
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_gp_upload: N, D, S must be positive and X/hyp/alpha/sW1 non-null");
-  if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_gp_upload: D = %d > 32 not accelerated", D);
+  if (D > VBMC_LIM_D) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_gp_upload: D = %d > %d not accelerated", D, VBMC_LIM_D);
   if (!(meanfun == 0 || meanfun == 1 || meanfun == 4))
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "gplogjoint:UnsupportedMeanFun: meanfun %d not accelerated (0,1,4 are)", meanfun);
   if (Ncov != D + 1) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "only the SE-ARD covariance (Ncov = D+1) is accelerated");
@@ -610,7 +615,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   dm.D = a->D; dm.K = a->K; dm.R = a->R; dm.S = gp->S; dm.N = gp->N;
   if (dm.D != gp->D) return set_err(ctx, VBMC_ERR_INVALID, "vp.D = %d but gp has D = %d", dm.D, gp->D);
   if (dm.K <= 0 || dm.R <= 0) return set_err(ctx, VBMC_ERR_INVALID, "K and R must be positive");
-  if (dm.K > 512) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d > 512 not accelerated", dm.K);
+  if (dm.K > VBMC_LIM_K) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "K = %d > %d not accelerated", dm.K, VBMC_LIM_K);
   const int D = dm.D, K = dm.K, R = dm.R, S = dm.S;
   int T = 0;
   for (int g = 0; g < 4; ++g) dm.opt[g] = a->optimize[g] ? 1 : 0;
@@ -639,7 +644,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   if (compute_var != 0 && VAR_FINAL_LDS(S, K, compute_grad ? T : 0) > 160 * 1024)   // k_var_final: five T-vectors in LDS
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance gradient with %d variational parameters (> 4000) not accelerated", T);
   if (compute_var != 0 && trsm_cw_for(dm.N) == 0)
-    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > 10208 not accelerated", dm.N);
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "variance path with N = %d > %d not accelerated", dm.N, trsm_max_n());
   P.beta = (std::isfinite(a->beta)) ? a->beta : 0.0;  // negelcbo_vbmc.m:15: non-finite beta -> 0
   // theta must be finite (the device exp does not propagate NaN)
   for (size_t i = 0; i < (size_t)T * R; ++i)
@@ -1644,7 +1649,7 @@ extern "C" vbmc_status vbmc_elbo_abandon(vbmc_ctx* ctx, int slot) {
 static vbmc_status shard_check(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, int rank, int world) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_shard_*: null gp / args");
   if (world < 1 || rank < 0 || rank >= world) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_shard_*: rank %d of world %d", rank, world);
-  if (a->compute_var != 0 || a->separate_K || a->G_s || a->varG_s)
+  if (a->compute_var != 0 || a->separate_K || a->G_s || a->varG_s || a->dG_s || a->dvarG_s)
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_shard_*: the sharded evaluation covers value + gradient without variance "
                                               "(the optimiser-loop call, misc/vpoptimize_vbmc.m:71)");
   if (a->eps_mode != 0 && a->Ns > 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_elbo_shard_*: device RNG only (eps_mode 0)");
@@ -1744,6 +1749,8 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   if (!a || !a->compute_grad) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_adam_batch needs compute_grad = 1");
   if (MaxIter < 1) return set_err(ctx, VBMC_ERR_INVALID, "MaxIter must be >= 1");
   if (a->eps_mode != 0 && a->Ns > 0) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_adam_batch draws fresh device RNG every iteration (eps_mode 0)");
+  if (a->separate_K || a->I_sk || a->J_sjk || a->G_s || a->varG_s || a->dG_s || a->dvarG_s || a->dvarG)      // (accepted by elbo_plan, never served here)
+    return set_err(ctx, VBMC_ERR_UNSUPPORTED, "vbmc_adam_batch: per-component / per-hyper-sample outputs only through vbmc_elbo_batch");
   ElboPlan P;
   { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
   const int T = P.dm.T, R = P.dm.R;
@@ -1837,6 +1844,24 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
 // test / reporting hook: the instantiation the Monte-Carlo entropy of a D-dimensional K-component mixture runs on (dense mode):
 // qs = ceil((D + 2) / 4), kt = k-tiles per wave, hv = waves per workgroup, tail = tail values per lane (0: none).  Returns 0 when
 // the matrix-core kernel does not serve the shape (the VALU kernel does).
+// largest variational parameter count whose five T-vectors fit k_var_final's LDS (with S = 1, K = 1: the bound elbo_plan applies per call)
+static int limit_T_vargrad() {
+  int T = 1;
+  while (VAR_FINAL_LDS(1, 1, T + 1) <= 160 * 1024) ++T;
+  return T;
+}
+extern "C" vbmc_status vbmc_get_limits(vbmc_limits* out) {
+  if (!out || out->struct_size != sizeof(vbmc_limits)) return VBMC_ERR_INVALID;
+  out->max_D = VBMC_LIM_D;
+  out->max_K = VBMC_LIM_K;
+  out->max_N = trsm_max_n();
+  out->max_Na = VBMC_LIM_NA;
+  out->max_T_vargrad = limit_T_vargrad();
+  out->delta_ok = 1;
+  out->meanfun_mask = VBMC_LIM_MEANFUN_MASK;
+  return VBMC_OK;
+}
+
 extern "C" int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* tail) {
   if (lane_entropy_fits(D, K, 0.0)) {       // small mixtures: k_entropy_lane<DT, KP> (qs: DT, kt: KP, four waves per workgroup)
     if (qs) *qs = 2 * ((D + 1) / 2);

@@ -119,7 +119,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
                          GpFactor& f, size_t pin_extra_doubles = 0, bool optimistic = false, bool alpha_aside = false) {
   if (N <= 0 || D <= 0 || S <= 0 || !X || !y || !hyp || !noisefun)
     return set_err(ctx, VBMC_ERR_INVALID, "%s: bad arguments", who);
-  if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
+  if (D > VBMC_LIM_D) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > %d not accelerated", D, VBMC_LIM_D);
   if (!(meanfun == 0 || meanfun == 1 || meanfun == 4))
     return set_err(ctx, VBMC_ERR_UNSUPPORTED, "gplite mean function %d not accelerated (0,1,4 are)", meanfun);
   const int Ncov = D + 1, Nnoise = noise_nhyp(noisefun);
@@ -130,7 +130,7 @@ vbmc_status gp_factorize(vbmc_ctx* ctx, const char* who, int N, int D, int S, in
                    fail_is_error ? "gplite_post" : "gplite_nlZ");
   // right-hand-side slabs of the triangular solves live in LDS: 16 columns wide up to N = 1136, narrower beyond (trsm_cw_for);
   // the Cholesky panel moves to a global scratch block when it no longer fits
-  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > 10208 not accelerated", N);
+  if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d > %d not accelerated", N, trsm_max_n());
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
@@ -377,7 +377,7 @@ static vbmc_status gp_post_impl(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, in
       }
     }
   }
-  HIP_TRY(ctx, stream_wait_latency(st));
+  HIP_TRY(ctx, stream_wait_latency(st, N > 1024));
   if (!gp_factor_ok(f, S)) return VBMC_INTERNAL_RETRY;     // a first try failed: once more with the noise-inflation loop
   if (L && any_inv && !inv_in_place)
     for (int s = 0; s < S; ++s)
@@ -527,7 +527,7 @@ static vbmc_status gp_nlz_impl(vbmc_ctx* ctx, int N, int D, int B, int Nhyp, int
   HIP_TRY(ctx, hipGetLastError());
   if (!out_direct) HIP_TRY(ctx, hipMemcpyAsync(f.pin_out, dnlz, nout * 8, hipMemcpyDeviceToHost, st));   // pinned: asynchronous
   f.h_pfd = f.pin_out + B;
-  HIP_TRY(ctx, stream_wait_latency(st));
+  HIP_TRY(ctx, stream_wait_latency(st, N > 1024));
   if (!gp_factor_ok(f, B)) return VBMC_INTERNAL_RETRY;
   memcpy(nlZ, f.pin_out, (size_t)B * 8);
   if (compute_grad) memcpy(dnlZ, f.pin_out + 2 * (size_t)B, (size_t)B * Nhyp * 8);
@@ -569,7 +569,7 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   // fmu / fs2 -- all the acquisition functions read (acqwrapper_vbmc.m:17) -- never depend on it
   // an empty s2star counts as zero (gplite_noisefun.m:51): the kernels add nothing when the pointer is null
   const int N = gp->N, D = gp->D, S = gp->S;
-  if (D > 32) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > 32 not accelerated", D);
+  if (D > VBMC_LIM_D) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "D = %d > %d not accelerated", D, VBMC_LIM_D);
   const int Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
   // beyond N = 1248 a 16-row tile of inv(L') no longer fits the LDS: the variance then comes from slab solves (k_pred_slab)
   const bool slab_pred = (size_t)16 * Np * 8 > PRED_LDS_MAX || nblk > PRED_MAXG || trsm_cw_for(N) != 16;
@@ -851,7 +851,7 @@ extern "C" vbmc_status vbmc_acq_is_create(vbmc_ctx* ctx, const vbmc_gp* gp, int 
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_acq_is_create: per-hyper-sample importance points need fs2a from the caller");
   const int N = gp->N, D = gp->D, S = gp->S;
   const int Nap = ((Na + 15) / 16) * 16;
-  if (Nap > 16 * 16) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "Na = %d > 256 importance points not accelerated", Na);
+  if (Nap > VBMC_LIM_NA) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "Na = %d > %d importance points not accelerated", Na, VBMC_LIM_NA);
   if (trsm_cw_for(N) == 0) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "N = %d too large", N);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -1130,7 +1130,7 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
     ok = ok && hipMemcpyAsync(ah, ng->alpha, (size_t)S * N1 * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
   ok = ok && hipGetLastError() == hipSuccess;
   {
-    const hipError_t e = stream_wait_latency(st);
+    const hipError_t e = stream_wait_latency(st, N1 > 1024);
     if (!ok || e != hipSuccess) { vbmc_gp_free(ctx, ng); (void)hipGetLastError(); return set_err(ctx, VBMC_ERR_HIP, "vbmc_gp_rank1_update: %s", hipGetErrorString(e)); }
   }
   if (gp->has_noise) {

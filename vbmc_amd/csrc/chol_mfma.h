@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(CH2_THREADS) k_chol2(int N, double* __restrict
         rv[q] = (4 * q + lg <= li) ? Dgc[(4 * q + lg) * 17 + li] : 0.0;    // A operand: Rkk'[t = li][u = 4q + lg] (lower triangular)
       }
       constexpr int PT = CH2_W >= 16 ? 2 : 3;                              // tiles in flight per wave
-      // the row block through a wave-uniform base + one 32-bit byte offset per element (N <= 10208: N^2 * 8 < 2^32): with 64-bit
+      // the row block through a wave-uniform base + one 32-bit byte offset per element (N <= 9696: N^2 * 8 < 2^32): with 64-bit
       // addresses per element the compiler, short of registers in this kernel, loaded INTO the address registers and waited for
       // each load in turn (up to four L2 round trips per tile triple, +0.5 us on every panel phase; profiles/r05_chol.md)
       // (buffer accesses: base and extent in four SGPRs, ONE VGPR of offset per element, an offset past the extent reads 0 /

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -10,6 +11,12 @@
 #include <vector>
 
 #include "../../include/vbmc_hip.h"
+
+// the shapes the validation accepts (vbmc_get_limits reports them)
+#define VBMC_LIM_D 32
+#define VBMC_LIM_K 512
+#define VBMC_LIM_NA 256
+#define VBMC_LIM_MEANFUN_MASK ((1 << 0) | (1 << 1) | (1 << 4))
 
 struct DevBuf {
   void* p = nullptr;
@@ -214,15 +221,19 @@ static inline vbmc_status d2h_bounced(vbmc_ctx* ctx, void* dst, const void* src,
 }
 
 // Wait for a stream at the end of a latency-bound call (one gplite_nlZ evaluation of a slice-sampling chain, one gplite_post): poll
-// for up to ~2 ms before falling back to the blocking wait -- the blocking wait's wake-up costs 10-20 us of a 0.4 ms call whose
+// for up to 300 us before falling back to the blocking wait -- the blocking wait's wake-up costs 10-20 us of a 0.4 ms call whose
 // caller is about to issue the next one.  VBMC_SPIN_WAIT=0 restores the plain blocking wait.
-static inline hipError_t stream_wait_latency(hipStream_t st) {
+//  The poll is bounded by the CLOCK -- 300 us -- not by a count of queries (4000 of them were a few ms of a host core when the
+// work was long), and a caller that knows its work is long (N in the thousands: the factorisation alone is milliseconds) passes
+// big = true and goes straight to the blocking wait.
+static inline hipError_t stream_wait_latency(hipStream_t st, bool big = false) {
   static const int spin = getenv("VBMC_SPIN_WAIT") ? atoi(getenv("VBMC_SPIN_WAIT")) : 1;
-  if (spin) {
-    for (int i = 0; i < 4000; ++i) {
+  if (spin && !big) {
+    const auto t0 = std::chrono::steady_clock::now();
+    do {
       const hipError_t e = hipStreamQuery(st);
       if (e != hipErrorNotReady) return e;
-    }
+    } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(300));
   }
   return hipStreamSynchronize(st);
 }

@@ -19,7 +19,7 @@ typedef double tmf4 __attribute__((ext_vector_type(4)));
 // Narrow slabs for large N: the slab of a wave holds CW = 16, 8 or 4 right-hand sides (row stride CW + 1), the MFMAs still
 // run 16 columns wide with zeros beyond CW.  16 columns fit the 160 KB of LDS up to N = 1136, 8 up to N = 2144, 4 up to
 // N = 3872 (VBMC's default MaxFunEvals = 50 (2 + D) reaches N = 1700 at D = 32), and -- round 5 -- 2 up to N = 6800, 1 up to
-// N = 10208: a fallback that trades matrix-core utilisation for range, chosen per call by trsm_cw_for(N).
+// N = 9696: a fallback that trades matrix-core utilisation for range, chosen per call by trsm_cw_for(N).
 template <int CW>
 __device__ __forceinline__ double trsm_vld(const double* __restrict__ V, int row, int li) {
   return (CW == 16 || li < CW) ? V[row * (CW + 1) + (CW == 16 ? li : (li < CW ? li : 0))] : 0.0;
@@ -205,8 +205,15 @@ static inline int trsm_cw_for(int N) {
   if (TRSM_LDS_BYTES_CW(N, 8) <= 160 * 1024) return 8;
   if (TRSM_LDS_BYTES_CW(N, 4) <= 160 * 1024) return 4;
   if (TRSM_LDS_BYTES_CW(N, 2) <= 160 * 1024) return 2;      // (round 5) up to N = 6800
-  if (TRSM_LDS_BYTES_CW(N, 1) <= 160 * 1024) return 1;      //           up to N = 10208: one right-hand side per wave
+  if (TRSM_LDS_BYTES_CW(N, 1) <= 160 * 1024) return 1;      //           up to N = 9696: one right-hand side per wave
   return 0;
+}
+// the largest N the solves take (whole 16-row blocks): 9696 -- what vbmc_get_limits reports and the refusals quote.  (Rounds 5's texts
+// said 10208, which forgot the 64 x TR_VS panel buffer beside the one-column slab.)
+static inline int trsm_max_n() {
+  int N = 16;
+  while (trsm_cw_for(N + 16) != 0) N += 16;
+  return N;
 }
 #define TRSM_DISPATCH_CW(cwv_, ...)                                 \
   switch (cwv_) {                                                   \
