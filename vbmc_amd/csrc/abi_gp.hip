@@ -560,8 +560,10 @@ struct PredBufs {
 };
 
 // gplite_pred for every hyper-sample, results left on the device (shared by vbmc_gp_pred and vbmc_acq_eval)
+// want_ks: the caller reads the sW-scaled cross-kernel matrix itself (the IQR acquisition functions); otherwise the variance comes from
+// k_pred_fused and that matrix is never written (round 6).  VBMC_PRED_FUSED=0 keeps the two-kernel form (A/B runs, tests).
 vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, int Nstar, const double* Xstar, const double* ystar,
-                           const double* s2star, PredBufs& pb) {
+                           const double* s2star, PredBufs& pb, bool want_ks = false) {
   if (!gp || Nstar <= 0 || !Xstar) return set_err(ctx, VBMC_ERR_INVALID, "%s: bad arguments", who);
   if (!gp->hasL) return set_err(ctx, VBMC_ERR_INVALID, "%s needs gp.post(s).L on the device", who);
   if (!gp->has_noise) return set_err(ctx, VBMC_ERR_INVALID, "%s: call vbmc_gp_set_noise (noisefun, sn2_mult) first", who);
@@ -648,10 +650,40 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   const int ntile_ = (Nstar + 15) / 16;
   int PZ = std::max(1, ctx->num_cu / std::max(1, maxg * S));
   PZ = std::min(PZ, std::max(1, ntile_ / (PRED_THREADS / 64)));
+  static const bool fused_off = [] { const char* e = getenv("VBMC_PRED_FUSED"); return e && !strcmp(e, "0"); }();
+  // point tiles resident per workgroup: as many N x 16 tiles as the 160 KB hold beside the 2 KB table (three at N = 400)
+  const int fused_pt = (int)std::min<size_t>(PREDF_PT_FOR_QS((D + 3) / 4), ((size_t)160 * 1024 - 2048 - (PREDF_THREADS / 64) * PREDF_MAXPT * 16 * 8 - 256) / ((size_t)Np * 16 * 8));
+  const bool fused = !want_ks && !slab_pred && !fused_off && fused_pt >= 1 && (D + 3) / 4 <= 8;
+  if (fused) {
+    for (int s = 0; s < S; ++s) grp[s] = 1;      // k_pred_final: one block of partial sums per hyper-sample
+    maxg = 1;
+  }
   HIP_TRY(ctx, pb.dgrp.alloc(ctx, grp.size() * sizeof(int)));
   HIP_TRY(ctx, pb.dpV.alloc(ctx, (size_t)maxg * S * Nstar * 8));
   HIP_TRY(ctx, pb.dpF.alloc(ctx, (size_t)S * Nstar * 8));
   HIP_TRY(ctx, hipMemcpyAsync(pb.dgrp.p, grp.data(), grp.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  if (fused) {
+    const size_t fl = (size_t)fused_pt * Np * 16 * 8;
+    const int npass = (ntile_ + fused_pt - 1) / fused_pt;
+    // one workgroup per compute unit (its LDS is full), each walking the (hyper-sample, pass) units b, b + grid, ...; VBMC_PRED_WGS=n: n (A/B runs)
+    static const int wgs_env = [] { const char* e = getenv("VBMC_PRED_WGS"); return e ? atoi(e) : 0; }();
+    const int gxf = std::max(1, std::min(npass * S, wgs_env > 0 ? wgs_env : ctx->num_cu));
+#define PRED_FUSED_PT(QSV, PTV) { \
+      if (fl > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pred_fused<QSV, PTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
+      hipLaunchKernelGGL((k_pred_fused<QSV, PTV>), dim3(gxf), dim3(PREDF_THREADS), fl, st, pa, dXc.as<double>(), daa.as<double>(), \
+                         dmuv.as<double>(), pb.dpV.as<double>(), pb.dpF.as<double>()); }
+#define PRED_FUSED(QSV) case QSV: \
+      if (fused_pt >= 3) { if constexpr (PREDF_PT_FOR_QS(QSV) >= 3) PRED_FUSED_PT(QSV, 3) } \
+      else if (fused_pt == 2) { if constexpr (PREDF_PT_FOR_QS(QSV) >= 2) PRED_FUSED_PT(QSV, 2) } \
+      else PRED_FUSED_PT(QSV, 1) \
+      break;
+    switch ((D + 3) / 4) { PRED_FUSED(1) PRED_FUSED(2) PRED_FUSED(3) PRED_FUSED(4) PRED_FUSED(5) PRED_FUSED(6) PRED_FUSED(7) PRED_FUSED(8) default: break; }
+#undef PRED_FUSED_PT
+#undef PRED_FUSED
+    hipLaunchKernelGGL(k_pred_final, dim3((Nstar + 255) / 256, S), dim3(256), 0, st, pa, pb.dgrp.as<int>(), pb.dpV.as<double>(), pb.dpF.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    return VBMC_OK;
+  }
   HIP_TRY(ctx, pb.dKs.alloc(ctx, (size_t)S * N * (((size_t)Nstar + 15) / 16) * 16 * 8));   // tiled by 16 points
   // inner dimension of the MFMA distance blocks: QS = ceil(D / 4) steps
 #define PRED_KS(QSV) case QSV: hipLaunchKernelGGL((k_pred_ks<QSV>), dim3((Nstar + 15) / 16, S), dim3(64), 0, st, pa, dXc.as<double>(), \
@@ -936,7 +968,7 @@ extern "C" vbmc_status vbmc_acq_iqr_eval(vbmc_ctx* ctx, const vbmc_gp* gp, const
     return VBMC_OK;
   }
   PredBufs pb;
-  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, nullptr, pb); if (s_ != VBMC_OK) return s_; }
+  { vbmc_status s_ = pred_on_device(ctx, "vbmc_acq_iqr_eval", gp, Nstar, Xs, nullptr, nullptr, pb, true); if (s_ != VBMC_OK) return s_; }
   hipStream_t st = ctx->stream;
   const int N = gp->N, D = gp->D, S = gp->S;
   TmpBuf dgl, dXr, dsn, dsx, dacqs, dres;
@@ -1142,3 +1174,4 @@ extern "C" vbmc_status vbmc_gp_rank1_update(vbmc_ctx* ctx, const vbmc_gp* gp, co
   *out = ng;
   return VBMC_OK;
 }
+

@@ -728,6 +728,195 @@ __global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const d
   }
 }
 
+// k_pred_fused (round 6): gplite_pred's variance WITHOUT the cross-kernel matrix in memory (gplite_pred.m:74-104).  k_pred_ks wrote
+// sW .* Ks for every (hyper-sample, training point, test point) -- 524 MB at N* = 8192, S = 20, N = 400 -- and every row group of
+// k_gp_pred streamed its columns of it again (2.2 GB against ~16 MB of inputs and outputs).  Here the roles of the two operands are
+// swapped: a workgroup computes the N x 16 cross-kernel tiles of PT point tiles ONCE, into LDS (each value exactly once on the whole
+// device: the distances as QS MFMAs per 16 x 16 block and the table exponential, as k_pred_ks), and its sixteen waves then walk the
+// row tiles of inv(L') -- 640 KB per hyper-sample at N = 400, read through the L2 (the workgroups in flight share one or two
+// hyper-samples: x fastest in the grid) -- with every A operand loaded once per k-step and used against the PT resident tiles.
+// Row tiles are dealt to the waves in snake order over the four SIMD classes (tile b costs b + 1 k-steps x 4: the sums per SIMD, not
+// per wave, are what the matrix pipe sees).  Low-noise samples (Lchol = false, :103-104) take all columns and accumulate
+// Ks .* (L Ks).  fmu's data term Ks' alpha (:83) is a dot product over the resident tile.  Partial sums: one per hyper-sample and
+// point (block 0 of partV; k_pred_final is told there is one block).
+// dynamic LDS: PT x Np x 16 doubles (beside 2 KB of table and NWV x PT x 16 doubles of per-wave sums).
+#define PREDF_THREADS 768      // twelve waves, three per SIMD (168 registers: sixteen at 128 spilled 37; eight left the matrix pipe half idle behind the L2)
+#define PREDF_MAXPT 3
+// resident point tiles the registers allow at QS dim-blocks (168 registers at three waves per SIMD; beyond: spills -- tests/test_lane_build.py)
+#define PREDF_PT_FOR_QS(QS_) ((QS_) <= 3 ? 3 : ((QS_) <= 5 ? 2 : 1))
+template <int QS, int PT>
+__global__ void __launch_bounds__(PREDF_THREADS, 1) k_pred_fused(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
+                                                                 const double* __restrict__ muv, double* __restrict__ partV,
+                                                                 double* __restrict__ partF) {
+  constexpr int NWV = PREDF_THREADS / 64;
+  extern __shared__ double KsL[];              // [p][n][16], sW-scaled, zero for n >= N and for points beyond Nstar
+  __shared__ double tab[VB_EXP_TAB_N];
+  __shared__ double FMW[NWV][PT][16];          // fmu's data term per wave (its row blocks), added in wave order
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int N = a.N, D = a.D, Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
+  const int ntile = (a.Nstar + 15) >> 4, npass = (ntile + PT - 1) / PT, nunit = npass * a.S;
+  for (int t = tid; t < VB_EXP_TAB_N; t += PREDF_THREADS) tab[t] = c_exp2_tab[t];
+  __syncthreads();
+  // A workgroup's LDS is full -- two never share a compute unit -- so the grid is one workgroup per unit of the chip, each walking the
+  // units (hyper-sample, pass) b, b + gridDim.x, ...: what a workgroup does once (launch, table) is paid once, the test points of the
+  // next unit are in flight behind the current one, and at any moment the workgroups in flight share one or two hyper-samples' factors
+  for (int unit = blockIdx.x; unit < nunit; unit += gridDim.x) {
+    const int s = unit / npass, pass = unit - s * npass;
+    const int pt0 = pass * PT;
+    const int npt = min(PT, ntile - pt0);
+    const double* h = a.hyp + (size_t)s * a.Nhyp;
+    const double* mu = muv + (size_t)s * 2 * D;
+    const double* iell = mu + D;
+    const double lsf2 = 2.0 * h[D];
+    const bool lc = a.lchol[s] != 0;
+    const double sW = lc ? 1.0 / sqrt(a.sn2_eff[s]) : 1.0;
+    const double* xcs = Xc + (size_t)s * N * D;
+    const double* aas = aa + (size_t)s * N;
+    const double* al = a.alpha + (size_t)s * N;
+    const double* Am = (lc ? a.tinv : a.L) + (size_t)s * N * N;   // element (row, col) at col * N + row
+    // ---- the cross-kernel tiles: 16 x 16 blocks (training points n0 .. n0 + 15 x the tile's points).  A wave takes the row blocks
+    // n0 = 16 (wave + NWV i) of EVERY resident point tile; the training-point fragment, |a|^2 and alpha of a row block are loaded once per
+    // block and one block ahead; fmu's data term Ks' alpha (:83) is accumulated on the way
+    {
+      double xb[PT][QS], bb[PT], fmacc[PT];
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const bool cv = p < npt && (pt0 + p) * 16 + li < a.Nstar;
+        bb[p] = 0.0; fmacc[p] = 0.0;
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+          const int d = 4 * q + lg;
+          xb[p][q] = (cv && d < D) ? fma(a.Xs[(pt0 + p) * 16 + li + (size_t)a.Nstar * d], iell[d], -mu[d]) : 0.0;
+          bb[p] = fma(xb[p][q], xb[p][q], bb[p]);
+        }
+        bb[p] = xor_sum16(bb[p]);
+        bb[p] = xor_sum32(bb[p]);
+      }
+      auto ld_a = [&](int nb, double (&av)[QS], double (&an)[4]) {
+        const int n0 = nb * 16, na = min(n0 + li, N - 1);
+#pragma unroll
+        for (int q = 0; q < QS; ++q) { const int d = 4 * q + lg; av[q] = (d < D && nb < nblk) ? xcs[(size_t)na * D + d] : 0.0; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = n0 + lg + 4 * r; an[r] = (n < N && nb < nblk) ? aas[n] : 0.0; }
+      };
+      double av[QS], an[4];
+      ld_a(wave, av, an);
+      for (int nb = wave; nb < nblk; nb += NWV) {
+        double avn[QS], ann[4], ah[4];
+        ld_a(nb + NWV, avn, ann);
+        const int n0 = nb * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = n0 + lg + 4 * r; ah[r] = n < N ? al[n] : 0.0; }     // (alpha: consumed after the exponentials)
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < QS; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], xb[p][q], acc, 0, 0, 0);
+          const bool cv = p < npt && (pt0 + p) * 16 + li < a.Nstar;
+          double* out = KsL + ((size_t)p * Np + n0) * 16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + lg + 4 * r;
+            double v = 0.0;
+            if (n < N && cv) {
+              const double cdist = fmax(an[r] + (bb[p] - 2.0 * acc[r]), 0.0);      // sq_dist.m:45,49
+              v = vb_exp_tab<0>(lsf2 - cdist / 2.0, tab);                          // sf2 exp(-K/2)  (gplite_pred.m:74)
+            }
+            fmacc[p] = fma(v, ah[r], fmacc[p]);
+            out[(lg + 4 * r) * 16 + li] = v * sW;                                  // sW .* Ks  (:99)
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < QS; ++q) av[q] = avn[q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) an[r] = ann[r];
+      }
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        double fm = xor_sum16(fmacc[p]);
+        fm = xor_sum32(fm);
+        if (lg == 0) FMW[wave][p][li] = fm;
+      }
+    }
+    __syncthreads();
+    if (tid < npt * 16) {
+      const int p = tid >> 4, i = tid & 15, jc = (pt0 + p) * 16 + i;
+      double fm = 0.0;
+      for (int w = 0; w < NWV; ++w) fm += FMW[w][p][i];
+      if (jc < a.Nstar) partF[(size_t)s * a.Nstar + jc] = fm;
+    }
+    // ---- the product: this wave's row tiles against the PT resident tiles
+    double part[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) part[p] = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      // unit k (descending cost) -> SIMD class in snake order, wave within the class in turn
+      const int kq = k & 7, cls = kq < 4 ? kq : 7 - kq, wsel = cls + 4 * ((k >> 2) % (NWV / 4));
+      if (wsel != wave) continue;
+      const int rt = nblk - 1 - k;
+      const int ncol = lc ? (rt + 1) * 16 : Np;
+      const int row = rt * 16 + li;
+      const bool rv = row < N;
+      tmf4 acc[PT];
+#pragma unroll
+      for (int p = 0; p < PT; ++p) acc[p] = (tmf4){0.0, 0.0, 0.0, 0.0};
+      // A operands: chunks of four k-steps, loaded one chunk ahead of their MFMAs into two register sets used in turn (no copies between
+      // them: a set rotated by moves makes the wave wait for the loads it has just issued); the other three waves of the SIMD cover the wait
+      const double* arow = Am + (rv ? row : 0);
+      auto lda4 = [&](int c0, double (&d)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 4 * u + lg;
+          d[u] = (rv && c < N && c0 < ncol) ? arow[(size_t)c * N] : 0.0;
+        }
+      };
+      auto mm4 = [&](int c0, const double (&d)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* brow = KsL + (size_t)(c0 + 4 * u + lg) * 16 + li;
+#pragma unroll
+          for (int p = 0; p < PT; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[u], brow[(size_t)p * Np * 16], acc[p], 0, 0, 0);
+        }
+      };
+      double b0[4], b1[4];
+      lda4(0, b0);
+      for (int c0 = 0; c0 < ncol; c0 += 32) {
+        lda4(c0 + 16, b1);
+        mm4(c0, b0);
+        if (c0 + 16 < ncol) { lda4(c0 + 32, b0); mm4(c0 + 16, b1); }
+      }
+      // C layout: lane (col = li = point, row = rt * 16 + lg + 4 q)
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        if (lc) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) part[p] = fma(acc[p][q], acc[p][q], part[p]);     // sum(V .* V)          (:100)
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)                                                   // sum(Ks .* (L * Ks))  (:104)
+            part[p] = fma(KsL[((size_t)p * Np + rt * 16 + lg + 4 * q) * 16 + li], acc[p][q], part[p]);
+        }
+      }
+    }
+    // ---- the waves' partial sums, added in wave order (the tiles' LDS is dead: it holds them)
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      double v = xor_sum16(part[p]);
+      v = xor_sum32(v);
+      if (lg == 0) KsL[(wave * PREDF_MAXPT + p) * 16 + li] = v;
+    }
+    __syncthreads();
+    if (tid < npt * 16) {
+      const int p = tid >> 4, i = tid & 15, jc = (pt0 + p) * 16 + i;
+      double v = 0.0;
+      for (int w = 0; w < NWV; ++w) v += KsL[(w * PREDF_MAXPT + p) * 16 + i];
+      if (jc < a.Nstar) partV[(size_t)s * a.Nstar + jc] = v;
+    }
+    __syncthreads();      // the next unit writes the tiles
+  }
+}
+
 // k_pred_slab: the large-N form of the prediction variance (N beyond what k_gp_pred keeps resident: a 16-row tile of the
 // triangular inverse no longer fits the LDS).  One wave per CW test points: their sW-scaled cross-kernel columns form a slab
 // in LDS, V = L' \ (sW .* Ks) by the blocked substitution of trsm_mfma.h (gplite_pred.m:99), sum(V.^2) per point (:100);
