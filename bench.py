@@ -831,12 +831,12 @@ def main():
             v = leg("aux.config4", lambda: shape_leg(20, 800, 100, 20000, 20, 16, "lumpy", True, 6))
             if v is not None:
                 aux["config4"] = v
-                # configs[4]'s label "fp32 vs fp64 tolerance stress": the device-side A/B (S-step on v_mfma_f32_16x16x4_f32, tools/f32s_eval.py)
+                # configs[4]'s label "fp32 vs fp64 tolerance stress": the device-side A/B (S-step on v_mfma_f32_16x16x4_f32, tools/archive/f32s_eval.py)
                 # is not part of the product build; its measured error and kernel time are read from the committed record
                 try:
                     f32 = json.load(open(os.path.join(ROOT, "profiles", "r05_fp32_exponent.json")))
                     v["fp32_exponent"] = {
-                        "source": "profiles/r05_fp32_exponent.json (tools/f32s_eval.py on the GPU box: full configs[4] shape, both builds against the C port on the dumped device stream)",
+                        "source": "profiles/r05_fp32_exponent.json (tools/archive/f32s_eval.py on the GPU box: full configs[4] shape, both builds against the C port on the dumped device stream)",
                         **{sc: {"kernel_ms_fp64": r_["fp64"]["kernel_ms_R16"], "kernel_ms_fp32_exponent": r_["fp32_exponent"]["kernel_ms_R16"],
                                 "F_relerr": r_["fp32_exponent"]["F_relerr_vs_c_port"], "H_relerr": r_["fp32_exponent"]["H_relerr_vs_c_port"],
                                 "dF_block_relerr": r_["fp32_exponent"]["dF_block_relerr_vs_c_port"],

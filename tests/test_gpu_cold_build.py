@@ -53,7 +53,7 @@ def test_headline_translation_unit_compiles_cold_on_the_target_and_runs(tmp_path
     found = None
     for body in re.split(r"\n  - \.agpr_count", "\n" + meta)[1:]:
         body = ".agpr_count" + body
-        m = re.search(r"\.name:\s+(_Z14k_entropy_mfmaILi3ELi3ELb1ELb0ELi1ELi1ELb0ELi1ELb0EEv7EntArgs)", body)
+        m = re.search(r"\.name:\s+(_Z14k_entropy_mfmaILi3ELi3ELb1ELb0ELi1ELi1ELb0ELb0EEv7EntArgs)", body)
         if m:
             g = lambda k: int(re.search(k + r":\s+(\d+)", body).group(1))  # noqa: E731
             found = {"vgpr": g(r"\.vgpr_count"), "agpr": g(r"\.agpr_count"), "scratch": g(r"\.private_segment_fixed_size"),

@@ -18,15 +18,10 @@ EXP = os.path.join(ROOT, "vbmc_amd", "lib", "exp")
 OBJ = os.path.join(ROOT, "vbmc_amd", "lib", "obj")
 # name -> (compile flags, [environment settings to time it under])
 VARIANTS = {
-    "head": (["@HEAD"], [{}]),            # round 4's kernel
-    "r5": ([], [{}]),                     # the tree: quadratic exp + GP2 + ETZ + C2
-    "noc2": (["-DVBMC_NO_C2"], [{}]),
-    "cubic": (["-DVBMC_EXP_CUBIC"], [{}]),
-    "nogp2": (["-DVBMC_NO_GP2"], [{}]),
-    "evx": (["-DVBMC_EVX"], [{}]),
-    "noetz": (["-DVBMC_NO_ETZ"], [{}]),
-    "tablin": (["-DVBMC_EXP_TABLIN"], [{}]),   # diagnostic: the exp table read without bank conflicts (results meaningless)
-}
+    "head": (["@HEAD"], [{}]),            # the committed kernel
+    "tree": ([], [{}]),                   # the working tree
+}      # (round 5's variants -- -DVBMC_NO_C2, -DVBMC_EXP_CUBIC, -DVBMC_NO_GP2, -DVBMC_EVX, -DVBMC_NO_ETZ, -DVBMC_EXP_TABLIN -- were switches of the
+       #  product header until round 6; their results are profiles/r05_experiments.md, their code is in the history)
 if os.environ.get("ENT_AB"):
     VARIANTS = {}
     for item in os.environ["ENT_AB"].split(";"):

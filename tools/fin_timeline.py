@@ -1,4 +1,4 @@
-"""Phase timeline of k_finalize_ws inside the single-chain Adam loop: a build of the library with -DVBMC_FIN_CLK
+"""Phase timeline of k_finalize_ws inside the single-chain Adam loop: a build of the library with -DVBMC_INSTRUMENT
 stamps the 100 MHz counter at the kernel's phases (restart 0's workgroup; the nine single-wave tasks each stamp their own start / end).
 
     python tools/fin_timeline.py build     (here: vbmc_amd/lib/exp/libvbmc_hip_finclk.so)
@@ -18,7 +18,7 @@ LIB = os.path.join(EXP, "libvbmc_hip_finclk.so")
 def build():
     os.makedirs(EXP, exist_ok=True)
     o = os.path.join(EXP, "vbmc_hip_finclk.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DVBMC_FIN_CLK",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DVBMC_INSTRUMENT",
                            "-c", os.path.join(ROOT, "vbmc_amd", "csrc", "vbmc_hip.hip"), "-o", o])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", o] +
                           [os.path.join(OBJ, "ent_mfma_qs%d.o" % q) for q in range(1, 10)] + ["-ldl", "-o", LIB])

@@ -548,18 +548,15 @@ static vbmc_status multi_submit_impl(vbmc_comm* c, const vbmc_gp* const* gps, co
     // the pick runs on the stream the pass ran on (the result records are that stream's scratch: the next pass queued there overwrites
     // them)
     vbmc_ctx* ps = (n > 0 && ctx->slot_where[slot]) ? ctx->slot_where[slot] : ctx;
-    // VBMC_COMM_XS (A/B): 1 = the exchange stream (default), 2 = at high priority, 0 = no exchange stream: each exchange on the
-    // stream of its pass (the communicator then sees alternating streams)
-    static const int xs_mode = [] { const char* e = getenv("VBMC_COMM_XS"); return e ? atoi(e) : 1; }();
+    // the communicator's own exchange stream (each exchange on the stream of its pass, and the exchange stream at high priority, were
+    // measured equal in round 4)
     hipStream_t xst = ps->stream;
-    if (ps != ctx && xs_mode != 0) {
+    if (ps != ctx) {
       if (!c->xs[i]) {     // beside both slot streams (abi_elbo.hip: stream_beside); they exist and, for the first batch, are idle but for this pass
-        int lo = 0, hi = 0;
-        COMM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
         hipStream_t both[2];
         int nb = 0;
         for (vbmc_ctx* sub : ctx->slot_sub) if (sub) both[nb++] = sub->stream;
-        c->xs[i] = stream_beside(ctx, both, nb, xs_mode == 2 ? hi : 0);     // (none to be had: the exchange stays on the pass's stream)
+        c->xs[i] = stream_beside(ctx, both, nb, 0);     // (none to be had: the exchange stays on the pass's stream)
       }
       if (c->xs[i]) xst = c->xs[i];
     }

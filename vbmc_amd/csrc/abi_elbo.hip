@@ -56,11 +56,8 @@ static vbmc_status ctx_create_impl(int device, void* stream, vbmc_ctx** out, boo
   for (auto& e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return VBMC_ERR_HIP; }
   {
-    const char* ov = getenv("VBMC_LJ_OVERLAP");   // "0": everything on one stream (A/B testing)
-    ctx->overlap = !(ov && !strcmp(ov, "0"));
-    if (!with_aux) ctx->overlap = false;
-    const char* ea = getenv("VBMC_AUX_EAGER");   // "0": on first use (A/B, round 4)
-    if (with_aux && !(ea && !strcmp(ea, "0"))) (void)ctx_aux(ctx);
+    ctx->overlap = with_aux;
+    if (with_aux) (void)ctx_aux(ctx);
     if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
       delete ctx;
@@ -496,7 +493,7 @@ static bool mfma_entropy_fits(int D, int K, double cutoff, int* qs_out, int* kt_
 // (hipHostMalloc: mapped into the device's address space, coherent) is read / written by the kernel directly over the host link.
 // A DMA-engine copy between two kernels of a stream costs 50-100 us of hand-over latency each way (measured: 190-215 us between
 // k_finalize of one batch and k_prep of the next at the headline shape, where the copies themselves are 0.3 MB); a kernel
-// launch costs ~10 us.  VBMC_COPY_ENGINE=1 restores the hipMemcpyAsync path (A/B runs); larger transfers always use it.
+// launch costs ~10 us.  Larger transfers use the copy engines.
 #define COPY_KERNEL_MAX_BYTES ((size_t)4 << 20)
 __global__ void k_copy_f64(size_t n, const double* __restrict__ src, double* __restrict__ dst) {
   VB_SMALL_PRIO();
@@ -527,10 +524,7 @@ __global__ void k_pack_sepk(int R, int S, int K, int LJS, int diag_only, const d
   }
 }
 
-static bool copy_by_kernel(size_t bytes) {
-  static const int engine = [] { const char* e = getenv("VBMC_COPY_ENGINE"); return (e && !strcmp(e, "1")) ? 1 : 0; }();
-  return !engine && bytes <= COPY_KERNEL_MAX_BYTES;
-}
+static bool copy_by_kernel(size_t bytes) { return bytes <= COPY_KERNEL_MAX_BYTES; }
 
 // inv(L') of the Lchol samples, once per surrogate (gplite_pred's triangular product and the full-variance path use it); null when
 // a 16-row tile of it does not fit the prediction kernel's LDS (N > 1248: those paths fall back to substitutions)
@@ -561,7 +555,6 @@ struct ElboPlan {
   double *d_finbig = nullptr, *d_gamma = nullptr;
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   int no_jacobian = 0;
-  const double* h_up = nullptr;   // the staged upload block when the pass's first launch does the upload itself (k_prep_up)
   int Rp = 0;                // the restarts the launch shapes are chosen for: R, or the undivided batch's (vbmc_elbo_args.plan_restarts)
   double* d_dvs = nullptr;   // per-hyper-sample variance gradient block (dvarG_s), pooled for the call
   bool lj_records = false;   // the caller reads per-hyper-sample log-joint records (separate_K, G_s / varG_s, the variance kernels)
@@ -589,9 +582,7 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
   // hyper-sample -- or an entropy-only evaluation, whose surrogate is a one-point stand-in -- can fill the chip by itself and wants the
   // kernels built for occupancy, not these)
   const long long KR = (long long)P.dm.K * (P.Rp > P.dm.R ? P.Rp : (long long)P.dm.R * P.rstride);
-  // VBMC_LJ_CO_SR / VBMC_LJ_CO_KR (A/B, round 5): the two width limits in units of the chip's compute units (defaults 0.5 and 2)
-  static const double lim_sr = [] { const char* e = getenv("VBMC_LJ_CO_SR"); return e ? atof(e) : 0.5; }();
-  static const double lim_kr = [] { const char* e = getenv("VBMC_LJ_CO_KR"); return e ? atof(e) : 2.0; }();
+  const double lim_sr = 0.5, lim_kr = 2.0;     // the two width limits in units of the chip's compute units (other values measured in round 5: profiles/r05_experiments.md section 8)
   return !co_off && !lj_force_mfma && P.mc && P.use_mfma && (P.hv & 15) == 1 && P.qs <= 8 && !(P.cutoff > 0.0) && P.compute_grad &&
          !P.lj_records && SR < lim_sr * ctx->num_cu && (P.Rp > P.dm.R || SR * P.rstride < lim_sr * ctx->num_cu) &&   // (the undivided batch's choice when the restarts are dealt over devices)
          KR < lim_kr * ctx->num_cu && P.dm.N > 1 &&
@@ -605,9 +596,7 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
 #define VAR_FINAL_LDS(S_, K_, Tg_) ((VARFIN_THREADS + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
-// defer_upload: the caller goes straight on to elbo_enqueue with the pass's k_prep (vbmc_elbo_batch, the pipelined submit): the upload
-// is then done by that launch itself (k_prep_up) instead of a copy kernel of its own.
-static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0, bool defer_upload = false) {
+static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
   if (a->struct_size != sizeof(vbmc_elbo_args))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(vbmc_elbo_args));
@@ -716,13 +705,9 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
   P.d_fix = P.d_theta + n_theta;
   P.d_delta2 = P.d_fix + n_fix;
   P.d_bnd = P.has_bnd ? P.d_delta2 + n_delta : nullptr;
-  // (built and measured in round 5, NOT adopted: at BASELINE configs[1] the host's submit falls from 23.6 to 17.1 us with this and the
-  // folded reduction, but the step does not move (49.8 -> 51.2 us): the pass is bound by its two 30 us kernels on the device, and a
-  // workgroup that unpacks its restart from the pinned block pays a trip over the host link.  VBMC_PREP_UP=1 turns it on.)
-  static const bool up_fuse = [] { const char* e = getenv("VBMC_PREP_UP"); return e && !strcmp(e, "1"); }();
-  if (defer_upload && up_fuse && copy_by_kernel(n_up * sizeof(double)) && n_theta > 0) {
-    P.h_up = hp;          // k_prep_up copies and unpacks (elbo_enqueue)
-  } else if (copy_by_kernel(n_up * sizeof(double))) {
+  // (upload + unpacking in one launch and the reductions folded into the finalize kernel were built and measured in round 5: the host's
+  // submit 23.6 -> 17.1 us at BASELINE configs[1], the step unchanged -- docs/history.md)
+  if (copy_by_kernel(n_up * sizeof(double))) {
     hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((n_up + 255) / 256, 1024)), dim3(256), 0, st, n_up, (const double*)hp, P.d_theta);
     HIP_TRY(ctx, hipGetLastError());
   } else {
@@ -788,8 +773,6 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
         // are where the correction pays (D = 28, K = 40: 1.36 -> 1.10 ms): profiles/r03_shape_sweep.md
         if (P.qs >= 5 && waves_per_cu > 8) waves_per_cu = 8;
       }
-      static const bool occ_off = [] { const char* e = getenv("VBMC_ENT_OCC"); return e && !strcmp(e, "0"); }();   // A/B: the old constant
-      if (occ_off) waves_per_cu = P.use_mfma ? 8 : 5;
       if (P.use_lane) {
         const int nb = entropy_lane_occupancy(D, K, compute_grad != 0);
         waves_per_cu = ENT_LANE_WAVES_HOST * (nb > 0 ? nb : 2);
@@ -846,12 +829,11 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
     { vbmc_status s_ = ensure(ctx, ctx->zbuf, nz * sizeof(double)); if (s_) return s_; }
     const size_t nJ = (size_t)R * S * K * K, nvg = (size_t)R * S * K * (2 * D + 1), nvo = (size_t)R * P.var_stride;
     // full variance without its gradient (eval_fullelcbo): V = inv(L') Z as a product with the explicit inverse (k_tri_gemm, out of
-    // place into the X block) instead of the substitution; VBMC_VAR_TRSM=1 keeps the substitution (A/B runs)
+    // place into the X block) instead of the substitution
     {
-      static const bool keep_trsm = [] { const char* e = getenv("VBMC_VAR_TRSM"); return e && !strcmp(e, "1"); }();
       bool any_chol = false;
       for (int s = 0; s < S; ++s) any_chol |= (gp->Lchol[s] != 0);
-      if (compute_var == 1 && any_chol && !keep_trsm) {
+      if (compute_var == 1 && any_chol) {
         bool have = false;
         vbmc_status s_ = ensure_tinv(ctx, gp, &have);
         if (s_) return s_;
@@ -946,14 +928,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   const size_t prep_lds = ((size_t)D * K + 3 * K + D + 8) * sizeof(double);
   if (prep_lds > 64 * 1024)
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
-  if (!skip_prep && P.h_up && !pend) {
-    hipLaunchKernelGGL(k_prep_up, dim3(R), dim3(256), prep_lds, st, dm, P.n_up, P.n_theta, P.h_up, P.d_theta, P.d_vpd, P.d_entp);
-    LAUNCH_CHECK(ctx, "k_prep_up");
-  } else if (!skip_prep) {
-    if (P.h_up) {      // (not reached: a deferred upload belongs to a plain pass)
-      hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)std::min<size_t>((P.n_up + 255) / 256, 1024)), dim3(256), 0, st, P.n_up, P.h_up, P.d_theta);
-      LAUNCH_CHECK(ctx, "k_copy_f64");
-    }
+  if (!skip_prep) {
     hipLaunchKernelGGL(k_prep, dim3(R), dim3(256), prep_lds, st, dm, P.d_theta, P.d_fix, P.d_vpd, P.d_entp, pend ? *pend : AdamState{},
                        pend ? pend_iter : 0, (const double*)P.d_out);
     LAUNCH_CHECK(ctx, "k_prep");
@@ -1021,16 +996,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     LAUNCH_CHECK(ctx, "k_lj_reduce");
     return VBMC_OK;
   };
-  // A/B (round 4): VBMC_LJ_FIRST=1 queues the log joint on the auxiliary stream BEFORE the entropy kernel is queued on the main one
-  static const bool lj_first = [] { const char* e = getenv("VBMC_LJ_FIRST"); return e && !strcmp(e, "1"); }();
   if (fork) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    if (lj_first) {
-      vbmc_status s_ = enqueue_logjoint(ctx->aux);
-      if (s_) return s_;
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
-    }
   } else if (sh.mode != 2) {
     vbmc_status s_ = enqueue_logjoint(st);
     if (s_) return s_;
@@ -1046,7 +1014,6 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
 
   // ---- entropy
   FinArgs fa{};
-  bool fin_fold = false;
   fa.dm = dm;
   if (P.mc) {
     EntArgs ea{};
@@ -1055,10 +1022,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     ea.part = sh.mode == 1 ? sh.send + shard_lj_doubles(P, sh.world) : P.d_part;
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff; ea.r0 = P.r0; ea.rstride = P.rstride;
-    {   // progress-ordered wave priorities (entropy_mfma.h); VBMC_ENT_PRIO=0: without (A/B)
-      static const int prio_env = [] { const char* e = getenv("VBMC_ENT_PRIO"); return e ? atoi(e) : 1; }();
-      ea.prio = prio_env;
-    }
+    ea.prio = 1;   // progress-ordered wave priorities (entropy_mfma.h)
     int co_rows = 0;
     if (co) {
       LjCo& lc = ea.lj;
@@ -1105,23 +1069,8 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     LAUNCH_CHECK(ctx, "the entropy kernel");
     if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     if (sh.mode == 1) return VBMC_OK;   // the records are in the send block; the exchange and the rest follow in mode 2
-    // chunk partials -> one record per (r, j), summed in chunk order.  (Round 5) FEW records -- at most sixteen log-joint records per
-    // component and sixteen sample chunks, a small mixture: BASELINE configs[1] -- and everything of the finalize kernel staged in LDS
-    // (its FAST instantiation): that kernel sums them while it stages, in the same order, and the launch is saved (fin_fold).
-    {
-      static const bool fold_off = [] { const char* e = getenv("VBMC_FIN_FOLD"); return !(e && !strcmp(e, "1")); }();     // (see VBMC_PREP_UP: measured, not adopted; "1" turns it on)
-      static const bool fin_seq0 = [] { const char* e = getenv("VBMC_FIN"); return e && !strcmp(e, "seq"); }();
-      const int Sraw = co ? S * ea.lj.nsplit : S, LJS0 = 2 * D + 2;
-      const int next_mu0 = dm.opt[0] ? D * K : 0;
-      const int Text0 = next_mu0 + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
-      const size_t need = (FIN_THREADS + 3 * (size_t)K + (size_t)D * K + 3 * (size_t)T + 8 + (size_t)VpLayout{D, K}.stride() +
-                           (P.has_bnd ? 3 * (size_t)Text0 : 0) + (size_t)K * LJS0 + (size_t)K * P.ncol) * sizeof(double);
-      fin_fold = !fold_off && !fin_seq0 && !fork && sh.mode == 0 && !P.fin_big && !P.d_finbig && need <= 96 * 1024 && Sraw <= 16 && P.C <= 16 &&
-                 K * LJS0 <= 2048 && K * P.ncol <= 4096 && !fuse && !pend;
-      if (fin_fold) { fa.fold = 1; fa.S_raw = Sraw; fa.C_raw = P.C; fa.lj_raw = P.d_lj; fa.part_raw = P.d_part; }
-    }
-    if (fin_fold) {
-    } else if (fork)
+    // chunk partials -> one record per (r, j), summed in chunk order
+    if (fork)
       hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
                          P.d_part, P.d_red);
     else
@@ -1140,7 +1089,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   }
 
   if (fork) {   // the entropy kernel is already queued on the main stream: the log joint fills in around it
-    if (!lj_first) {
+    {
       vbmc_status s_ = enqueue_logjoint(ctx->aux);
       if (s_) return s_;
       HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
@@ -1164,8 +1113,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     } else {
       HIP_TRY(ctx, trsm_fwd_launch(st, N, K, S, R, gp->L, gp->d_finv, gp->d_lchol, P.d_Z));
     }
-    static const bool gram_valu = [] { const char* e = getenv("VBMC_VAR_GRAM"); return e && !strcmp(e, "valu"); }();   // A/B runs
-    if (P.compute_var == 1 && (!gram_valu || P.tri_gemm))   // full K x K matrix: Gram products on the matrix cores, one workgroup per (s, r)
+    if (P.compute_var == 1)   // full K x K matrix: Gram products on the matrix cores, one workgroup per (s, r)
       hipLaunchKernelGGL(k_var_gram_mfma, dim3(S, R), dim3(1024), 0, st, dm, P.d_vpd, gp->gpc, P.d_delta2, gp->d_sn2, gp->d_lchol,
                          P.d_Z, P.d_X, P.d_J, P.tri_gemm ? 1 : 0);
     else
@@ -1215,19 +1163,16 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     fa.stage = 0;
     if (lds + stage_vp <= 96 * 1024) { fa.stage |= 2; lds += stage_vp; }
     if (lds + stage_rec <= 96 * 1024) { fa.stage |= 1; lds += stage_rec; }
-    // k_finalize_ws: the wave-specialised form (one barrier instead of ~18; round 3); VBMC_FIN=seq keeps the sequential kernel
-    // for A/B runs.  Only the wave-specialised kernel carries the fused Adam update + unpacking of the next iteration.
-    static const bool fin_seq = [] { const char* e = getenv("VBMC_FIN"); return e && !strcmp(e, "seq"); }();
-    if (fuse && !fin_seq) {
+    // k_finalize_ws: the wave-specialised form (one barrier; round 3 -- the sequential kernel with its ~18 barriers is in the history);
+    // it carries the fused Adam update + unpacking of the next iteration
+    if (fuse) {
       fa.next_iter = fuse_iter; fa.next_A = *fuse; fa.next_theta = P.d_theta; fa.next_vpfix = P.d_fix; fa.next_vpd = P.d_vpd; fa.next_entp = P.d_entp;
     }
     if (lds > 64 * 1024) {
-      HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_finalize_ws<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (fin_seq && !P.no_jacobian) hipLaunchKernelGGL(k_finalize, dim3(R), dim3(FIN_THREADS), lds, st, fa);   // (the untransformed gradients exist in k_finalize_ws only)
-    else if (fa.stage == 3 && !fa.big) hipLaunchKernelGGL(k_finalize_ws<true>, dim3(R), dim3(FIN_THREADS), lds, st, fa);
+    if (fa.stage == 3 && !fa.big) hipLaunchKernelGGL(k_finalize_ws<true>, dim3(R), dim3(FIN_THREADS), lds, st, fa);
     else hipLaunchKernelGGL(k_finalize_ws<false>, dim3(R), dim3(FIN_THREADS), lds, st, fa);
     LAUNCH_CHECK(ctx, "k_finalize");
   }
@@ -1398,7 +1343,7 @@ extern "C" vbmc_status vbmc_elbo_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
     if (s_) return s_;
   }
   ElboPlan P;
-  { vbmc_status s_ = elbo_plan(ctx, gp, a, P, 0, true); if (s_) return s_; }
+  { vbmc_status s_ = elbo_plan(ctx, gp, a, P); if (s_) return s_; }
   const size_t ndvs = a->dvarG_s ? (size_t)P.dm.T * P.dm.S * P.dm.R : 0;    // gplogjoint's dvarF with avg_flag = 0: T x S per restart
   if (ndvs) HIP_TRY(ctx, pool_get(ctx, ndvs * sizeof(double), (void**)&P.d_dvs));
   vbmc_status st = elbo_enqueue(ctx, gp, P, a->seed);
@@ -1446,12 +1391,12 @@ static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc
   // the slot's own pinned block stands in for the context's while the inputs are staged and the copies are enqueued
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
-  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P, 0, true);
+  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P);
   // Result blocks of at most 256 KB are written by the finalize kernel straight into the pinned block (no read-back launch: BASELINE
   // configs[1] 52.1 -> 50.0 us per step, nothing elsewhere), only where nothing on the device reads the records afterwards (not under a
-  // communicator: k_comm_pick does).  VBMC_DIRECT_OUT=n: another bound in KB, 0 = never (A/B).  The mirror image -- the staging block read
+  // communicator: k_comm_pick does).  The mirror image -- the staging block read
   // by the pass's first kernel instead of a copy launch -- was built and measured too: no gain (49.8 us), removed.
-  static const size_t direct_kb = [] { const char* e = getenv("VBMC_DIRECT_OUT"); return e ? (size_t)atol(e) : (size_t)256; }();
+  const size_t direct_kb = 256;
   if (!s_) {
     sp->hout = (double*)ctx->pin + sp->P.n_up;
     if (allow_direct && direct_kb && sp->P.compute_var == 0 && sp->P.out_n * sizeof(double) <= direct_kb * 1024) sp->P.out_direct = sp->hout;
@@ -1512,10 +1457,8 @@ static double place_ratio(int device, int num_cu, hipStream_t a, hipStream_t b) 
   if (!ok) (void)hipGetLastError();
   return ok ? best : 2.0;
 }
-// a new stream that dispatches beside every stream of `beside` (up to six candidates; the first one if none does); VBMC_PLACE=0: unchecked
+// a new stream that dispatches beside every stream of `beside` (up to six candidates; the first one if none does)
 static hipStream_t stream_beside(vbmc_ctx* ctx, const hipStream_t* beside, int nb, int priority = 0) {
-  static const bool off = [] { const char* e = getenv("VBMC_PLACE"); return e && !strcmp(e, "0"); }();
-  static const bool dbg = [] { const char* e = getenv("VBMC_DEBUG_PLACE"); return e && !strcmp(e, "1"); }();
   hipStream_t cand[6];
   int nc = 0;
   hipStream_t pick = nullptr;
@@ -1524,11 +1467,7 @@ static hipStream_t stream_beside(vbmc_ctx* ctx, const hipStream_t* beside, int n
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) { (void)hipGetLastError(); break; }
     cand[nc++] = s;
     bool ok = true;
-    for (int i = 0; i < nb && ok && !off; ++i) {
-      const double r = place_ratio(ctx->device, ctx->num_cu, beside[i], s);
-      if (dbg) fprintf(stderr, "[vbmc place] candidate %d beside stream %d: %.2f\n", nc - 1, i, r);
-      ok = r < 0.35;
-    }
+    for (int i = 0; i < nb && ok; ++i) ok = place_ratio(ctx->device, ctx->num_cu, beside[i], s) < 0.35;
     if (ok) pick = s;
   }
   if (!pick && nc) pick = cand[0];
@@ -1552,14 +1491,13 @@ static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vb
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int ch = slot & 1;
   if (!ctx->slot_sub[0] || !ctx->slot_sub[1]) {     // both children at once, before anything runs on either: the second beside the first
-    static const bool sub_fork = [] { const char* e = getenv("VBMC_SUB_FORK"); return e && !strcmp(e, "1"); }();   // A/B (round 4)
     for (int c2 = 0; c2 < 2; ++c2) {
       if (ctx->slot_sub[c2]) continue;
       hipStream_t other = ctx->slot_sub[1 - c2] ? ctx->slot_sub[1 - c2]->stream : nullptr;
       hipStream_t s = stream_beside(ctx, &other, other ? 1 : 0);
       if (!s) return set_err(ctx, VBMC_ERR_HIP, "vbmc_elbo_submit: no stream for slot %d", slot);
       vbmc_ctx* sc = nullptr;
-      vbmc_status st = ctx_create_impl(ctx->device, s, &sc, sub_fork);     // no fork on a slot stream (elbo_enqueue): one stream per child
+      vbmc_status st = ctx_create_impl(ctx->device, s, &sc, false);     // no fork on a slot stream (elbo_enqueue): one stream per child
       if (st != VBMC_OK) { (void)hipStreamDestroy(s); return set_err(ctx, st, "vbmc_elbo_submit: no stream for slot %d", slot); }
       sc->own_stream = true;
       sc->is_sub = true;
@@ -1571,9 +1509,8 @@ static vbmc_status slot_ctx(vbmc_ctx* ctx, const vbmc_elbo_args* a, int slot, vb
   sc->profiling = false;
   // ... when there is anything: an event recorded on an idle stream and waited for on another is still a device-side dependency between
   // two queues, 15-30 us per step where a step is that short (tools/archive/r4_host_cost.py: one restart at VBMC's own sample count 58 -> 27 us
-  // per step, BASELINE configs[1] 89 -> 52).  VBMC_SLOT_XEV=1: always (A/B).
-  static const int xev_mode = [] { const char* e = getenv("VBMC_SLOT_XEV"); return e ? atoi(e) : 2; }();
-  if (xev_mode == 1 || (xev_mode == 2 && hipStreamQuery(ctx->stream) != hipSuccess)) {
+  // per step, BASELINE configs[1] 89 -> 52).
+  if (hipStreamQuery(ctx->stream) != hipSuccess) {
     (void)hipGetLastError();
     HIP_TRY(ctx, hipEventRecord(ctx->slot_xev[slot], ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(sc->stream, ctx->slot_xev[slot], 0));
@@ -1772,26 +1709,16 @@ extern "C" vbmc_status vbmc_adam_batch(vbmc_ctx* ctx, const vbmc_gp* gp, const v
   // Where the NEXT iteration follows without a stopping test in between, this iteration's finalize kernel applies the Adam update
   // and unpacks the new theta itself (k_finalize_ws: fused), and the next pass starts at its log-joint kernel; before a stopping
   // test (every 20 iterations from the 40th, utils/fminadam.m:65) and at the end the update is a launch of its own.
-  static const bool fusable = [] { const char* e = getenv("VBMC_FIN"); return !(e && !strcmp(e, "seq")) && !(getenv("VBMC_ADAM_FUSE") && !strcmp(getenv("VBMC_ADAM_FUSE"), "0")); }();
   bool prepped = false;   // the previous pass has already applied its update and unpacked theta for this one
-  bool pending = false;   // (round-2 schedule) the update of iteration iter - 1 rides on this iteration's k_prep
   for (iter = 1; iter <= MaxIter; ++iter) {
     const bool check = iter % 20 == 0 && iter >= 40;
     const bool last = check || iter == MaxIter;
-    const bool fuse = fusable && !last;
+    const bool fuse = !last;
     adam_set_iter(A, iter);
-    if (fusable) {
-      { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, nullptr, 0, nullptr, fuse ? &A : nullptr, iter, prepped); if (s_) return s_; }
-      prepped = fuse;
-      // the stopping test and the final read-back need this iteration's update now; the next pass unpacks theta itself
-      if (!fuse) hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
-    } else {   // round-2 schedule (A/B runs): the update of iteration iter - 1 rides on this iteration's k_prep
-      AdamState Ap = A;
-      if (pending) adam_set_iter(Ap, iter - 1);
-      { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, pending ? &Ap : nullptr, iter - 1); if (s_) return s_; }
-      pending = true;
-      if (last) { hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out); pending = false; }
-    }
+    { vbmc_status s_ = elbo_enqueue(ctx, gp, P, a->seed + (unsigned long long)iter, nullptr, 0, nullptr, fuse ? &A : nullptr, iter, prepped); if (s_) return s_; }
+    prepped = fuse;
+    // the stopping test and the final read-back need this iteration's update now; the next pass unpacks theta itself
+    if (!fuse) hipLaunchKernelGGL(k_adam_step, dim3(R), dim3(256), 0, st, A, iter, P.d_theta, P.d_out);
     if (check) {
       hipLaunchKernelGGL(k_adam_check, dim3(R), dim3(256), 0, st, A, iter);
       HIP_TRY(ctx, hipMemcpyAsync(done.data(), A.done, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1879,7 +1806,7 @@ extern "C" int vbmc_entropy_plan(int D, int K, int* qs, int* kt, int* hv, int* t
   return ok ? 1 : 0;
 }
 
-#ifdef VBMC_FIN_CLK
+#ifdef VBMC_INSTRUMENT
 extern "C" int vbmc_dbg_fin_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_dbg), 64 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }

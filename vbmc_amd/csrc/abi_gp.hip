@@ -665,9 +665,8 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   if (fused) {
     const size_t fl = (size_t)fused_pt * Np * 16 * 8;
     const int npass = (ntile_ + fused_pt - 1) / fused_pt;
-    // one workgroup per compute unit (its LDS is full), each walking the (hyper-sample, pass) units b, b + grid, ...; VBMC_PRED_WGS=n: n (A/B runs)
-    static const int wgs_env = [] { const char* e = getenv("VBMC_PRED_WGS"); return e ? atoi(e) : 0; }();
-    const int gxf = std::max(1, std::min(npass * S, wgs_env > 0 ? wgs_env : ctx->num_cu));
+    // one workgroup per compute unit (its LDS is full), each walking the (hyper-sample, pass) units b, b + grid, ...
+    const int gxf = std::max(1, std::min(npass * S, ctx->num_cu));
 #define PRED_FUSED_PT(QSV, PTV) { \
       if (fl > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pred_fused<QSV, PTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
       hipLaunchKernelGGL((k_pred_fused<QSV, PTV>), dim3(gxf), dim3(PREDF_THREADS), fl, st, pa, dXc.as<double>(), daa.as<double>(), \

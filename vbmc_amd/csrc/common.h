@@ -222,13 +222,12 @@ static inline vbmc_status d2h_bounced(vbmc_ctx* ctx, void* dst, const void* src,
 
 // Wait for a stream at the end of a latency-bound call (one gplite_nlZ evaluation of a slice-sampling chain, one gplite_post): poll
 // for up to 300 us before falling back to the blocking wait -- the blocking wait's wake-up costs 10-20 us of a 0.4 ms call whose
-// caller is about to issue the next one.  VBMC_SPIN_WAIT=0 restores the plain blocking wait.
+// caller is about to issue the next one.
 //  The poll is bounded by the CLOCK -- 300 us -- not by a count of queries (4000 of them were a few ms of a host core when the
 // work was long), and a caller that knows its work is long (N in the thousands: the factorisation alone is milliseconds) passes
 // big = true and goes straight to the blocking wait.
 static inline hipError_t stream_wait_latency(hipStream_t st, bool big = false) {
-  static const int spin = getenv("VBMC_SPIN_WAIT") ? atoi(getenv("VBMC_SPIN_WAIT")) : 1;
-  if (spin && !big) {
+  if (!big) {
     const auto t0 = std::chrono::steady_clock::now();
     do {
       const hipError_t e = hipStreamQuery(st);

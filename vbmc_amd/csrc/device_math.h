@@ -239,50 +239,25 @@ __device__ __forceinline__ vb_d4 vb_exp_tab4(vb_d4 x, const double* __restrict__
 // Accuracy as vb_exp_tab<1> ("sum" mode): the argument's own rounding, |x| 1e-16, dominates.
 #define VB_EXP_TAB1K_N 1024
 #define VB_EXP_TAB1K_SCALE 1477.3197218702985291365628   // 1024 / ln 2
-// QUAD (round 5: what the entropy kernel runs; -DVBMC_EXP_CUBIC builds it with the cubic for A/B runs): the polynomial behind the table is
+// QUAD (round 5: what the matrix-core entropy kernel runs; the lane kernel and every other user keep the cubic): the polynomial behind the table is
 // the economised QUADRATIC 1 + c r' (1 + c r'/2) -- one fused multiply-add fewer per value (10 VALU operations), relative error
 // (c/2)^3/24 = 1.6e-12 of every term, an odd function of r' to leading order, so that over the terms of a mixture density it averages out:
 // measured on the headline shape, H and dH move by 1.3e-16 and 2.2e-16 (profiles/r04_experiments.md section 2); the 50-digit vectors of
 // tests/golden stay at 1e-11, and the per-value bound is tests/test_gpu_elbo.py::test_device_exp_sum_mode_accuracy.
-#ifdef VBMC_EXP_CUBIC
-#define VB_EXP_TAB1K_QUAD false
-#else
+// The accuracy this trades: a mixture with ONE component, or one that dominates, has no terms to average over -- H and dH
+// then carry the per-value 1.6e-12.  Stated in INTEGRATION.md; tests/test_gpu_elbo.py::test_single_and_dominated_mixtures_against_the_50_digit_vectors
+// bounds it against mpmath vectors (1e-11 holds there too).
 #define VB_EXP_TAB1K_QUAD true
-#endif
 template <bool QUAD = false>
 __device__ __forceinline__ double vb_exp_tab1k(double y, const double* __restrict__ tab) {
   const double c = 0.693147180559945309417232 / 1024;
-#ifdef VBMC_EXP_MAGIC
-  // A/B variant: rint by the magic-number addition (three full-rate adds instead of v_rndne + v_cvt + v_sub, two of them quarter-rate);
-  // the integer sits in the low mantissa bits of t: table index = low 10 bits, binary exponent = bits 10..41 (one v_alignbit).
-  // Valid for |y| < 2^41 only (no saturation).
-  {
-    const double MAGIC = 6755399441055744.0;   // 1.5 * 2^52
-    const double t = y + MAGIC;
-    const int lo = __double2loint(t), hi = __double2hiint(t);
-    const double r = y - (t - MAGIC);
-    const double T = tab[lo & (VB_EXP_TAB1K_N - 1)];
-    double u;
-    if (QUAD) u = fma(r, c * c / 2, c + c * c * c / 32);
-    else { u = fma(r, c * c * c / 6, c * c / 2 + c * c * c * c / 96); u = fma(r, u, c); }
-    const double Tr = T * r;
-    return ldexp(fma(Tr, u, T), (int)__builtin_amdgcn_alignbit((unsigned)hi, (unsigned)lo, 10));
-  }
-#endif
   const double nr = __builtin_rint(y);
   // the conversion must SATURATE for |y| >= 2^31 (that is what makes a clamp unnecessary): the hardware instruction does, a
   // C++ cast of an out-of-range value is undefined -- hence the instruction itself
   int ni;
   asm("v_cvt_i32_f64 %0, %1" : "=v"(ni) : "v"(nr));
   const double r = y - nr;
-#ifdef VBMC_EXP_TABLIN   // diagnostic build (results meaningless): the table read without bank conflicts -- consecutive lanes read consecutive
-                         // entries; same instructions (the mask is a scalar register the compiler cannot see through)
-  int msk_;
-  asm("s_mov_b32 %0, 0" : "=s"(msk_));
-  const double T = (tab + (threadIdx.x & 63))[ni & msk_];
-#else
   const double T = tab[ni & (VB_EXP_TAB1K_N - 1)];
-#endif
   // cubic: the dropped quartic term (c r')^4/24 is economised into the quadratic one (r'^4 ~ r'^2/4 - 1/128 on [-1/2, 1/2]:
   // Chebyshev), which leaves a remainder of c^4/24/64 = 1.4e-16 instead of 5.4e-16 at no cost.  Quadratic: the dropped cubic term
   // (c r')^3/6 is economised into the linear one (r'^3 ~ 3 r'/16): remainder c^3/6/32 = 1.6e-12 instead of 6.5e-12

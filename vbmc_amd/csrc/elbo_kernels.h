@@ -152,19 +152,6 @@ __global__ void __launch_bounds__(256) k_prep(ElboDims dm, double* __restrict__ 
   prep_body(dm, theta, vpfix, vpd, entp, blockIdx.x, sh);
 }
 
-// k_prep_up (round 5): the upload of a pass and its unpacking in ONE launch.  The staged block (theta | fixed vp | delta^2 | bounds, in
-// the pass's pinned host block, mapped into the device's address space) is copied into device memory by all workgroups together -- the
-// kernels that follow read it there -- while each workgroup unpacks ITS restart straight from the pinned source (the device copy is
-// complete only at the end of the launch).  One launch less per pass: where a pass is seven short kernels (BASELINE configs[1]) the
-// launch and its first round trip are a sixth of it, and the host's submit is mostly launches.
-__global__ void __launch_bounds__(256) k_prep_up(ElboDims dm, size_t n_up, size_t n_theta, const double* __restrict__ hsrc,
-                                                 double* __restrict__ ddst, double* __restrict__ vpd, double* __restrict__ entp) {
-  VB_SMALL_PRIO();
-  extern __shared__ double sh[];
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += (size_t)gridDim.x * blockDim.x) ddst[i] = hsrc[i];
-  prep_body(dm, hsrc, hsrc + n_theta, vpd, entp, blockIdx.x, sh);
-}
-
 // ------------------------------------------------------------------------------------------
 // k_logjoint: misc/gplogjoint.m:162-271 (body: logjoint_body.h).  One workgroup = four (component k, hyper-sample s) cells;
 // with LJ_MAXW waves each wave takes every LJ_MAXW-th 16-point slab of the training set.
@@ -702,12 +689,6 @@ struct FinArgs {
   double TolCon, WeightThreshold, WeightPenalty, beta;
   int M, C, ncol, want_grad, has_bnd, var_stride;
   int no_jacobian;        // 1: gradients with respect to sigma, lambda, w themselves (JACOBIAN_FLAG = 0 of the stand-alone forms; k_finalize_ws only)
-  // fold (round 5, FAST instantiation only): the pass has FEW partial records (S' <= 16 log-joint records per component, C <= 16 sample
-  // chunks; small mixtures: BASELINE configs[1]) -- the finalize kernel sums them itself while it stages (same order as k_lj_reduce /
-  // k_ent_reduce: identical bits) and the pass does without the reduction launch
-  int fold, S_raw, C_raw;
-  const double* lj_raw;   // R x S' x K x (2D+2)
-  const double* part_raw; // R x K x C x ncol
   double invS, invM;      // 1 / S and 1 / (2 M) from the host (the same IEEE quotients; a division per thread in k_finalize_ws's preamble otherwise)
   int stage;              // 1: the host sized the LDS so that the log-joint and entropy records of a restart are staged in it
   double* big;            // null, or R x (3T + DK) doubles of global scratch for dG | dH | dP | gsc when they exceed the LDS
@@ -755,257 +736,6 @@ __device__ __forceinline__ void stage_copy4(const StageBlk (&b)[4], int tid, int
   }
 }
 
-__global__ void __launch_bounds__(FIN_THREADS) k_finalize(FinArgs a) {
-  VB_SMALL_PRIO();
-  extern __shared__ double lds[];
-  const int r = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const ElboDims& dm = a.dm;
-  const int D = dm.D, K = dm.K, S = dm.S, T = dm.T;
-  VpLayout L{D, K};
-  const double* v = a.vpd + (size_t)r * L.stride();
-  const double* bnd = a.bnd;
-  double* red = lds;           // nt
-  double* Ibar = red + nt;     // K   mean_s I_sk
-  double* Hj = Ibar + K;       // K   (1/M) sum_i log q' for component j
-  double* wraw = Hj + K;       // K   raw w-gradient of H
-  // the three T-vectors and the D x K soft-bound table: LDS, or for very large D x K the restart's slice of a global scratch
-  // block (workgroup barriers order the accesses either way)
-  double* bigr = a.big ? a.big + (size_t)r * (3 * (size_t)T + (size_t)D * K) : nullptr;
-  double* dG = bigr ? bigr : wraw + K;       // T (packed)
-  double* dH = dG + T;         // T
-  double* dP = dH + T;         // T   penalty gradient
-  double* scal = bigr ? wraw + K : dP + T;   // 8 scalars
-  // w, sigma, lambda are read inside serial loops over the components below: LDS copies keep those loops off the
-  // global-memory latency (a single chain, R = 1, is bound by exactly this kernel's dependent chains)
-  double* gsc = bigr ? dP + T : scal + 8;    // D x K   soft-bound gradient of the lnscale block per (d, k)
-  double* stg = bigr ? scal + 8 : gsc + D * K;   // staging area (a.stage says what fits)
-  // Everything this workgroup reads more than once sits in LDS: the vp record and the bounds (stage & 2), the
-  // log-joint / entropy records of the restart (stage & 1).  A single chain (R = 1) is bound by exactly this kernel's
-  // chains of dependent global loads, so they are issued in a few wide batches up front.
-  if (a.stage & 2) {
-    stage_copy(stg, v, L.stride(), tid, nt);
-    v = stg;
-    stg += L.stride();
-    if (a.has_bnd) {
-      const int next_mu = dm.opt[0] ? D * K : 0;
-      const int Text = next_mu + ((dm.opt[1] || dm.opt[2]) ? D * K : 0) + (dm.opt[3] ? K : 0);
-      stage_copy(stg, a.bnd, 2 * Text, tid, nt);
-      bnd = stg;
-      stg += 2 * Text;
-    }
-  }
-  const double* w = v + L.w();
-  const double* sigma = v + L.sigma();
-  const double* lam = v + L.lambda();
-  double* o = a.out + (size_t)r * (OUT_HDR + 3 * T);
-  const int LJS = 2 * D + 2;
-  const double invS = 1.0 / S;
-
-  for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
-  __syncthreads();
-  // ---- expected log joint from the per-component sums over hyper-samples (k_lj_reduce):
-  // G = (1/S) sum_s sum_k w_k I_sk  (:203,:400)
-  const double* lb = a.ljbar + (size_t)r * K * LJS;
-  const double* pe_src = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;
-  if (a.stage & 1) {
-    // the per-restart records are read in column order by few threads below
-    double* lbL = stg;
-    double* peL = lbL + K * LJS;
-    stage_copy(lbL, lb, K * LJS, tid, nt);
-    if (pe_src) stage_copy(peL, pe_src, K * a.C * a.ncol, tid, nt);
-    lb = lbL;
-    if (pe_src) pe_src = peL;
-    __syncthreads();
-  }
-  for (int k = tid; k < K; k += nt) Ibar[k] = lb[(size_t)k * LJS] * invS;
-  __syncthreads();
-  {
-    double part = 0.0;
-    for (int k = tid; k < K; k += nt) part += w[k] * Ibar[k];
-    double G = block_sum(part, red);
-    if (tid == 0) scal[0] = G;
-    __syncthreads();
-  }
-  if (a.want_grad) {
-    if (dm.opt[0])
-      for (int p = tid; p < D * K; p += nt) dG[dm.off_mu + p] = lb[(size_t)(p / D) * LJS + 1 + p % D] * invS;
-    if (dm.opt[1])
-      for (int k = tid; k < K; k += nt) dG[dm.off_sigma + k] = lb[(size_t)k * LJS + 1 + D] * sigma[k] * invS;  // Jacobian :356
-    if (dm.opt[2])
-      for (int d = tid >> 4; d < D; d += nt >> 4) {   // sums over the components: 16 lanes per output (see row16 note above)
-        double acc = 0.0;
-        for (int k = tid & 15; k < K; k += 16) acc += lb[(size_t)k * LJS + 2 + D + d];   // :250
-        acc = row16_sum(acc);
-        if ((tid & 15) == 0) dG[dm.off_lambda + d] = acc * lam[d] * invS;                // :362
-      }
-    // softmax Jacobian J_w = diag(w) - w w' (gplogjoint.m:366-368) applied to w_grad = I_k; w' I = G
-    if (dm.opt[3])
-      for (int k = tid; k < K; k += nt) dG[dm.off_eta + k] = w[k] * Ibar[k] - w[k] * scal[0];
-  }
-  __syncthreads();
-
-  // ---- entropy
-  const double lognf = v[L.lognf()];
-  if (a.entpart) {
-    const double invM = 1.0 / (2.0 * a.M);  // Ns = 2*Mh samples per component
-    const double* pe = pe_src;
-    for (int j = tid; j < K; j += nt) {
-      double acc = 0.0;
-      for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol];
-      Hj[j] = lognf + acc * invM;  // mean_i log q(x_i), x_i ~ component j
-    }
-    __syncthreads();
-    {
-      double part = 0.0;
-      for (int j = tid; j < K; j += nt) part -= w[j] * Hj[j];  // :67
-      double H = block_sum(part, red);
-      if (tid == 0) scal[1] = H;
-    }
-    if (a.want_grad) {
-      if (dm.opt[0])
-        for (int p = tid; p < D * K; p += nt) {
-          int d = p % D, j = p / D;
-          double acc = 0.0;
-          for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol + 1 + d];
-          dH[dm.off_mu + p] = w[j] * acc * invM / lam[d];  // :82
-        }
-      if (dm.opt[1])
-        for (int j = tid; j < K; j += nt) {
-          double acc = 0.0;
-          for (int c = 0; c < a.C; ++c) acc += pe[((size_t)j * a.C + c) * a.ncol + 1 + D];
-          dH[dm.off_sigma + j] = w[j] * acc * invM * sigma[j];  // :88 and Jacobian :113
-        }
-      if (dm.opt[2])
-        for (int d = tid >> 4; d < D; d += nt >> 4) {
-          double acc = 0.0;
-          for (int j = tid & 15; j < K; j += 16) {
-            double aj = 0.0;
-            for (int c = 0; c < a.C; ++c) aj += pe[((size_t)j * a.C + c) * a.ncol + 2 + D + d];
-            acc += w[j] * sigma[j] * aj * invM;  // :93 (the /lambda of lsum cancels the *lambda of :107)
-          }
-          acc = row16_sum(acc);
-          if ((tid & 15) == 0) dH[dm.off_lambda + d] = acc;
-        }
-      if (dm.opt[3])
-        for (int l = tid >> 4; l < K; l += nt >> 4) {
-          double acc = 0.0;
-          for (int j = tid & 15; j < K; j += 16) {
-            double aj = 0.0;
-            for (int c = 0; c < a.C; ++c) aj += pe[((size_t)j * a.C + c) * a.ncol + 2 + 2 * D + l];
-            acc += w[j] * aj * invM;  // :100
-          }
-          acc = row16_sum(acc);
-          if ((tid & 15) == 0) wraw[l] = -Hj[l] - acc;  // :97
-        }
-    }
-  } else {
-    const double* eb = a.entlb + (size_t)r * (1 + D * K + 2 * K + D);
-    if (tid == 0) scal[1] = eb[0];
-    if (a.want_grad) {
-      if (dm.opt[0]) for (int p = tid; p < D * K; p += nt) dH[dm.off_mu + p] = eb[1 + p];
-      if (dm.opt[1]) for (int k = tid; k < K; k += nt) dH[dm.off_sigma + k] = eb[1 + D * K + k];
-      if (dm.opt[2]) for (int d = tid; d < D; d += nt) dH[dm.off_lambda + d] = eb[1 + D * K + K + d];
-      if (dm.opt[3]) for (int k = tid; k < K; k += nt) wraw[k] = eb[1 + D * K + K + D + k];
-    }
-  }
-  __syncthreads();
-  if (a.want_grad && dm.opt[3]) {
-    double part = 0.0;
-    for (int k = tid; k < K; k += nt) part += w[k] * wraw[k];
-    double dot = block_sum(part, red);
-    for (int k = tid; k < K; k += nt) dH[dm.off_eta + k] = w[k] * wraw[k] - w[k] * dot;  // :121-123
-  }
-  __syncthreads();
-
-  // ---- penalties (negelcbo_vbmc.m:136-164, vpbndloss.m, softbndloss.m)
-  double pen = 0.0;
-  if (a.has_bnd) {
-    const int next_mu = dm.opt[0] ? D * K : 0;
-    const int has_sc = (dm.opt[1] || dm.opt[2]) ? 1 : 0;
-    const int Text = next_mu + has_sc * D * K + (dm.opt[3] ? K : 0);
-    const double* lb = bnd;
-    const double* ub = bnd + Text;
-    double part = 0.0;
-    // mu block
-    if (dm.opt[0])
-      for (int p = tid; p < D * K; p += nt) {
-        double x = v[L.mu() + p], l = lb[p], u = ub[p], ell = (u - l) * a.TolCon;
-        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; dP[dm.off_mu + p] += (x - l) / (ell * ell); }
-        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; dP[dm.off_mu + p] += (x - u) / (ell * ell); }
-      }
-    // lnscale block D x K : lnsigma_k + lnlambda_d (vpbndloss.m:36); gradient summed over d / k
-    if (has_sc) {
-      // pass 1: loss, and the per-(d, k) gradient contributions parked in LDS for the two marginal sums below
-      for (int p = tid; p < D * K; p += nt) {
-        int d = p % D, k = p / D;
-        double x = v[L.lnsigma() + k] + v[L.lnlambda() + d];
-        double l = lb[next_mu + p], u = ub[next_mu + p], ell = (u - l) * a.TolCon;
-        double g = 0.0;
-        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; g += (x - l) / (ell * ell); }
-        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; g += (x - u) / (ell * ell); }
-        gsc[p] = g;
-      }
-      __syncthreads();
-      if (a.want_grad) {
-        if (dm.opt[1])
-          for (int k = tid >> 4; k < K; k += nt >> 4) {
-            double acc = 0.0;
-            for (int d = tid & 15; d < D; d += 16) acc += gsc[d + D * k];
-            acc = row16_sum(acc);
-            if ((tid & 15) == 0) dP[dm.off_sigma + k] += acc;
-          }
-        if (dm.opt[2])
-          for (int d = tid >> 4; d < D; d += nt >> 4) {
-            double acc = 0.0;
-            for (int k = tid & 15; k < K; k += 16) acc += gsc[d + D * k];
-            acc = row16_sum(acc);
-            if ((tid & 15) == 0) dP[dm.off_lambda + d] += acc;
-          }
-      }
-    }
-    if (dm.opt[3]) {
-      const int o3 = next_mu + has_sc * D * K;
-      for (int k = tid; k < K; k += nt) {
-        double x = v[L.eta() + k], l = lb[o3 + k], u = ub[o3 + k], ell = (u - l) * a.TolCon;
-        if (x < l) { double t = (l - x) / ell; part += 0.5 * t * t; dP[dm.off_eta + k] += (x - l) / (ell * ell); }
-        if (x > u) { double t = (x - u) / ell; part += 0.5 * t * t; dP[dm.off_eta + k] += (x - u) / (ell * ell); }
-      }
-      // weight-size penalty :146-162
-      for (int k = tid; k < K; k += nt) part += a.WeightPenalty * ((w[k] < a.WeightThreshold) ? w[k] : a.WeightThreshold);
-      if (a.want_grad) {
-        double pd = 0.0;
-        for (int k = tid; k < K; k += nt) pd += (w[k] < a.WeightThreshold) ? w[k] * a.WeightPenalty : 0.0;
-        double dot = block_sum(pd, red);
-        for (int k = tid; k < K; k += nt) {
-          double gk = (w[k] < a.WeightThreshold) ? a.WeightPenalty : 0.0;
-          dP[dm.off_eta + k] += w[k] * gk - w[k] * dot;
-        }
-      }
-    }
-    pen = block_sum(part, red);   // one sum for every soft-bound and weight term of the restart
-  }
-  __syncthreads();
-  // ---- assemble
-  double varG = 0.0, varGss = 0.0;
-  const double* vr = a.var ? a.var + (size_t)r * a.var_stride : nullptr;
-  if (vr) { varG = vr[0]; varGss = vr[1]; }
-  if (tid == 0) {
-    double G = scal[0], H = scal[1];
-    double F = -G - H;                                  // :116
-    if (a.beta != 0.0) F += a.beta * sqrt(varG);        // :127 (varH = 0)
-    F += pen;
-    o[0] = F; o[1] = G; o[2] = H; o[3] = varG; o[4] = varGss;
-  }
-  if (a.want_grad) {
-    for (int i = tid; i < T; i += nt) {
-      double g = -dG[i] - dH[i];                        // :117
-      if (a.beta != 0.0 && vr) g += 0.5 * a.beta * vr[2 + i] / sqrt(varG);  // :129
-      o[OUT_HDR + i] = g + dP[i];
-      o[OUT_HDR + T + i] = dG[i];
-      o[OUT_HDR + 2 * T + i] = dH[i];
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // k_finalize_ws: the same arithmetic as k_finalize, organised for LATENCY (round 3).  k_finalize runs its sections one after the
@@ -1023,7 +753,7 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#ifdef VBMC_FIN_CLK   // phase timeline of the finalize kernel (tools/fin_timeline.py): restart 0's workgroup stamps the 100 MHz counter
+#ifdef VBMC_INSTRUMENT   // phase timeline of the finalize kernel (tools/fin_timeline.py): restart 0's workgroup stamps the 100 MHz counter
 __device__ unsigned long long g_fin_dbg[64];   // (in-loop iterations only: the Adam tail is part of the picture)
 #define FIN_STAMP(i_) do { if (a.next_iter > 0 && blockIdx.x == 0 && threadIdx.x == 0) g_fin_dbg[i_] = wall_clock64(); } while (0)
 #define FIN_STAMP_W(i_) do { if (a.next_iter > 0 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_fin_dbg[i_] = wall_clock64(); } while (0)
@@ -1080,52 +810,15 @@ __global__ void __launch_bounds__(FIN_THREADS) k_finalize_ws(FinArgs a) {
   const double invS = a.invS;
   const double* lb = a.ljbar + (size_t)r * K * LJS;
   const double* pe = a.entpart ? a.entpart + (size_t)r * K * a.C * a.ncol : nullptr;   // (C = 1: reduced records)
-  const bool fold = FAST && a.fold != 0;
   if (FAST || (a.stage & 1)) {
     double* lbL = stg;
     double* peL = lbL + K * LJS;
-    if (!fold) {
-      sb[2] = StageBlk{lbL, lb, K * LJS};
-      if (pe) sb[3] = StageBlk{peL, pe, K * a.C * a.ncol};
-    }
+    sb[2] = StageBlk{lbL, lb, K * LJS};
+    if (pe) sb[3] = StageBlk{peL, pe, K * a.C * a.ncol};
     lb = lbL;
     if (pe) pe = peL;
   }
   stage_copy4(sb, tid, nt);      // (every load of the four blocks in flight before the first store)
-  if (fold) {
-    // sum_s' lj_raw[r][s'][k][col] and sum_c part_raw[r][k][c][col], eight loads in flight, added in record order
-    double* lbL = const_cast<double*>(lb);
-    const double* src = a.lj_raw + (size_t)r * a.S_raw * K * LJS;
-    const size_t st_ = (size_t)K * LJS;
-    for (int i = tid; i < K * LJS; i += nt) {
-      double acc = 0.0;
-      for (int s0 = 0; s0 < a.S_raw; s0 += 8) {
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = s0 + u < a.S_raw ? src[(size_t)(s0 + u) * st_ + i] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (s0 + u < a.S_raw) acc += t[u];
-      }
-      lbL[i] = acc;
-    }
-    if (pe) {
-      double* peL = const_cast<double*>(pe);
-      const double* ps = a.part_raw + (size_t)r * K * a.C_raw * a.ncol;
-      for (int i = tid; i < K * a.ncol; i += nt) {
-        const int j = i / a.ncol, col = i - j * a.ncol;
-        const double* pj = ps + (size_t)j * a.C_raw * a.ncol + col;
-        double acc = 0.0;
-        for (int c0 = 0; c0 < a.C_raw; c0 += 8) {
-          double t[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = c0 + u < a.C_raw ? pj[(size_t)(c0 + u) * a.ncol] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) if (c0 + u < a.C_raw) acc += t[u];
-        }
-        peL[i] = acc;
-      }
-    }
-  }
   for (int i = tid; i < T; i += nt) { dG[i] = 0.0; dH[i] = 0.0; dP[i] = 0.0; }
   if (tid < 8) scal[tid] = 0.0;
   __syncthreads();

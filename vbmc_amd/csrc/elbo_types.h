@@ -68,10 +68,6 @@ struct EntArgs {
 
 // The short kernels of a pass (copies, k_prep, the log joint, the reductions, the finalize kernel) ask for the highest issue priority: in
 // the pipelined step they share SIMDs with the other pass's entropy kernel, whose waves run at priorities 3 -> 0 (entropy_mfma.h), and
-// they are what the next pass waits for.  -DVBMC_NO_SMALL_PRIO: without (A/B).
-#ifndef VBMC_NO_SMALL_PRIO
+// they are what the next pass waits for.
 #define VB_SMALL_PRIO() __builtin_amdgcn_s_setprio(3)
-#else
-#define VB_SMALL_PRIO() do { } while (0)
-#endif
 

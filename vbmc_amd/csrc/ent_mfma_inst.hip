@@ -6,13 +6,10 @@
 #ifndef QS_VALUE
 #error "compile with -DQS_VALUE=<1..9>"
 #endif
-#ifndef VBMC_ENT_CW
-#define VBMC_ENT_CW 0     // > 1: chunk-wave workgroups (entropy_mfma.h, CW) for the instantiations listed in launch_kt
-#endif
 #define CAT2(a, b) a##b
 #define CAT(a, b) CAT2(a, b)
 
-// mode 0: launch.  mode 2: the chunk waves per workgroup of the kernel that would run.  mode 1: no launch -- returns the number of workgroups of this instantiation one compute unit holds at the launch's
+// mode 0: launch.  mode 1: no launch -- returns the number of workgroups of this instantiation one compute unit holds at the launch's
 // dynamic LDS size (hipOccupancyMaxActiveBlocksPerMultiprocessor: registers AND LDS), for the chunk model of elbo_plan.
 template <int KT, int HV, int TL = 0>
 static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArgs& ea) {
@@ -28,13 +25,9 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
     // the launch carries the log-joint role (gradient kernels, dense): the caller checked the shape
     if (ea.lj.rows > 0) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, true>;
   }
-  int cwv = 1;   // chunk waves per workgroup of the chosen kernel
-  if constexpr (VBMC_ENT_CW > 1 && HV == 1 && KT == 3 && TL == 1) {
-    if (!fn && grad && !(ea.cutoff > 0.0)) { fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, VBMC_ENT_CW>; cwv = VBMC_ENT_CW; }
-  }
   // the device-RNG launch of a kernel that otherwise spends registers on the parity mode's prefetch (entropy_mfma.h: EM, EPF)
   if constexpr (HV == 1 && QS_VALUE <= 4 && KT <= 3) {
-    if (!fn && grad && !ea.eps && !(ea.cutoff > 0.0)) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, 1, false>;
+    if (!fn && grad && !ea.eps && !(ea.cutoff > 0.0)) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, false>;
   }
   if (!fn) {
     if (ea.cutoff > 0.0 && HV == 1 && !TL) {  // opt-in block-sparse variant (single-wave kernels only, no component tail)
@@ -45,15 +38,13 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
     }
   }
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int threads = (ea.cutoff > 0.0 && HV == 1 && !TL) ? WAVE : WAVE * HV * cwv;
-  if (mode == 2) return cwv;
+  const int threads = (ea.cutoff > 0.0 && HV == 1 && !TL) ? WAVE : WAVE * HV;
   if (mode == 1) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return nb * cwv;   // in single-wave-workgroup equivalents
+    return nb;
   }
   EntArgs arg = ea;
-  if (cwv > 1) grid.x = (grid.x + cwv - 1) / cwv;
   void* args[] = {(void*)&arg};
   (void)hipLaunchKernel(fn, grid, dim3(threads), args, lds, st);
   return 0;
@@ -104,12 +95,7 @@ extern "C" int CAT(vbmc_occupancy_ent_mfma_qs, QS_VALUE)(int kt, int grad, int h
   return dispatch(1, kt, grad, hv, dim3(1, 1, 1), nullptr, ea);
 }
 
-// chunk waves per workgroup (entropy_mfma.h, CW) of the instantiation that would run; -1: no such kernel
-extern "C" int CAT(vbmc_cw_ent_mfma_qs, QS_VALUE)(int kt, int grad, int hv, const EntArgs* ea) {
-  return dispatch(2, kt, grad, hv, dim3(1, 1, 1), nullptr, ea);
-}
-
-#ifdef VBMC_EXP_CLK
+#ifdef VBMC_INSTRUMENT
 extern "C" int CAT(vbmc_dbg_ent_read_qs, QS_VALUE)(unsigned long long* out, size_t n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ent_dbg), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }

@@ -40,109 +40,35 @@ struct EntTileAny { static constexpr bool rt = false, val = true; };     // one 
                                                                           // the tile gets if-converted into twice as many)
 struct EntTileFull { static constexpr bool rt = false, val = false; };
 struct EntTilePartial { static constexpr bool rt = false, val = true; };
-#ifdef VBMC_ENT_NOSPLIT          // A/B builds: one body everywhere
-#define VBMC_ENT_SPLIT(KT_, QS_, TL_, HV_, CW_) false
-#endif
-#ifndef VBMC_ENT_SPLIT
-#define VBMC_ENT_SPLIT(KT_, QS_, TL_, HV_, CW_) ((HV_) == 1)
-#endif
+#define VBMC_ENT_SPLIT(KT_, QS_, TL_, HV_) ((HV_) == 1)
 
-#ifdef VBMC_EXP_CLK   // timeline experiment (tools/archive/r4_timeline.py): per wave [entry, loop start, loop end, exit] on the 100 MHz counter + HW_ID + XCC_ID
+#ifdef VBMC_INSTRUMENT   // timeline experiment (tools/archive/r4_timeline.py): per wave [entry, loop start, loop end, exit] on the 100 MHz counter + HW_ID + XCC_ID
 #define VBMC_DBG_WAVES 32768
 __device__ unsigned long long g_ent_dbg[6 * VBMC_DBG_WAVES];
 #endif
 
-// Phase switches for timing experiments (tools/ent_experiments.py builds variants of the library with -DVBMC_EXP_NO...;
-// results are then meaningless -- only the kernel duration is read).  All true in the product build.
-#ifdef VBMC_EXP_NOEXP
-constexpr bool X_EXP = false;
-#else
-constexpr bool X_EXP = true;
-#endif
-#ifdef VBMC_EXP_NOPV
-constexpr bool X_PV = false;
-#else
-constexpr bool X_PV = true;
-#endif
-#ifdef VBMC_EXP_NOEPI
-constexpr bool X_EPI = false;
-#else
-constexpr bool X_EPI = true;
-#endif
-#ifdef VBMC_EXP_NOW
-constexpr bool X_W = false;
-#else
-constexpr bool X_W = true;
-#endif
 // The staggered schedule: both signs in straight-line code, the second sign's exponentials issued inside the first sign's
 // per-sample latency chain.  It pays where the registers are there: one and three k-tiles per wave (K <= 16, 33..48: no spills,
 // 0-6 % faster, tools/tune_sweep.py small); with two k-tiles (168-VGPR budget of three waves per SIMD) and with four (256) it
-// spills and loses 2-12 %, so those keep the sign loop.  -DVBMC_STAG forces it everywhere, -DVBMC_NO_STAG nowhere (A/B builds;
-// with the weight gradient compiled out -- registers to spare -- it gains 2.6 % at four k-tiles too: tools/ent_experiments.py).
+// spills and loses 2-12 %, so those keep the sign loop.
 // At three k-tiles with a component tail and D >= 19 (QS >= 6), and without a tail at D >= 31, the staggered code spills too
 // (37-90 VGPRs) and the loop is 2-10 % faster again.
-#if defined(VBMC_STAG)
-#define VBMC_STAG_FOR(KT_, QS_, TL_) true
-#elif defined(VBMC_NO_STAG)
-#define VBMC_STAG_FOR(KT_, QS_, TL_) false
-#else
 // Round 4 (the in-loop log's twelve constant registers are gone): four k-tiles (-0.6..-2.5 %) and two k-tiles from D = 19 on (-1.8..-3.7 %) too.
 #define VBMC_STAG_FOR(KT_, QS_, TL_) ((KT_) == 1 || (KT_) == 4 || ((KT_) == 2 && (QS_) >= 6) || ((KT_) == 3 && (QS_) <= ((TL_) ? 5 : 8)))
-#endif
-#ifdef VBMC_EXP_NOS
-constexpr bool X_S = false;
-#else
-constexpr bool X_S = true;
-#endif
 
 
-// Round 5 (profiles/r05_experiments.md), each with its A/B switch:
+// Round 5 (profiles/r05_experiments.md; the measured alternatives -- round 4's forms, the and-mask zeroing EVX, the fp32 S-step F32S -- are in
+// the history, docs/history.md):
 //  GP2  the gradient epilogue without shuffles and without branches: the lanes of column 1 hand A'_i over with q'_i (same exec-masked
 //       store), the sample-layout lanes return 1/q'_i AND A'_i/q'_i, and the PV-layout lanes read the pair with one broadcast ds_read2 --
 //       no ds_bpermute (16 per tile), and no `d < D` predicate around the four sample rows (lanes of the padded columns compute values
-//       nobody stores): the compiler had made four basic blocks of them, each an exposed LDS round trip.   -DVBMC_NO_GP2: round 4's form
-//  EVX  (NOT adopted) the padded slots of the sample-side fragment zeroed by v_and_b32 with masks the compiler cannot see through, instead
-//       of the four v_cndmask_b32 it makes of the AND with a compare's 0 / -1 (19 cycles each in tools/valu_rate.hip's isolated chain):
-//       in the kernel the selects are FASTER -- by 0.8 % (minimum of four interleaved runs) to 2 % (median); an exec-masked v_mov_b64
-//       between two scalar writes of exec: +1.6 % (profiles/r05_experiments.md).                           -DVBMC_EVX: the and-form
-//  ETZ  dim-blocks that are all padding are zeroed once per wave, not once per tile (four v_mov_b64 per tile).   -DVBMC_NO_ETZ
-#ifdef VBMC_NO_GP2
-constexpr bool X_GP2 = false;
-#else
-constexpr bool X_GP2 = true;
-#endif
-#ifdef VBMC_EVX          // (A/B only: measured slower than the selects, see above)
-constexpr bool X_EVX = true;
-#else
-constexpr bool X_EVX = false;
-#endif
-#ifdef VBMC_NO_ETZ
-constexpr bool X_ETZ = false;
-#else
-constexpr bool X_ETZ = true;
-#endif
+//       nobody stores): the compiler had made four basic blocks of them, each an exposed LDS round trip.
+//  ETZ  dim-blocks that are all padding are zeroed once per wave, not once per tile (four v_mov_b64 per tile).
 //  C2   the even part of the exponent rides in the linear product: D + 2 <= 4 QS always, so the inner slots D and D + 1 of the last
 //       dim-block(s) are free -- they carry [|u'|^2, 1] against [h_k - h_j, const_k], and E+ = L + C comes out of QS MFMAs per k-tile
 //       instead of QS + 1.  The second sign still needs C by itself (E- = 2C - E+): 2C_ik = 2 c0_k |u'_i|^2 + 2 c1_k, one FMA per
 //       element from a pair table in LDS (one broadcast ds_read_b128 per element, immediate offsets, issued behind the MFMAs).
-//       Per tile -KT MFMA (27 ns each), +4 KT VALU.                                                  -DVBMC_NO_C2: round 4's S-step
-#ifdef VBMC_NO_C2
-constexpr bool X_C2 = false;
-#else
-constexpr bool X_C2 = true;
-#endif
-// F32S (A/B build only, -DVBMC_F32S; BASELINE configs[4]'s label "fp32 vs fp64 tolerance stress" answered on the device):
-// the S-step -- the exponents E = b_k . a_i -- on v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulation: half the matrix-pipe time of
-// the fp64 instruction), everything behind it (table exp, PV step, per-sample scalars, gradients) in fp64 as before.  Where the S-step is
-// round 4's form (no C2: the configs[4] instantiation among them).  The fp32 instruction leaves row 4 g + r in register r of lane group g
-// where the fp64 one leaves row 4 r + g: the component a register holds changes (ent_ci), nothing else.  Never the default: the measured
-// error and time are in profiles/r05_fp32_exponent.md.
-#ifdef VBMC_F32S
-constexpr bool X_F32S = true;
-#else
-constexpr bool X_F32S = false;
-#endif
-typedef float vf4 __attribute__((ext_vector_type(4)));
+//       Per tile -KT MFMA (27 ns each), +4 KT VALU.
 
 // Where C2 and GP2 are used: everywhere except the instantiations where the sweep of every (k-tiles, tail, waves per workgroup) class
 // over D = 2..32 measured them slower than round 4's forms (tools/tune_sweep.py, variants noc2 / nogp2 of tools/tune_build.py against the
@@ -205,30 +131,17 @@ __device__ __forceinline__ void ent_sync_wg() {
 // EM (round 5): the instantiation reads its draws from memory (parity mode / eps_mode 2) -- it spends QS registers per lane on the tile
 // loaded one tile ahead (EPF below).  EM = false: the device-RNG launch of the same shape; those registers hold PV operands instead
 // (VBR).  Only the instantiations that prefetch exist twice (ent_mfma_inst.hip); everywhere else EM = true is the one kernel for both.
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, int CW = 1, bool EM = true>
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, bool EM = true>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
 // tools/ent_experiments.py x_w2 at D = 10), so that one instantiation moved (single-wave workgroups only: the multi-wave ones
 // were not re-measured).
-#ifdef VBMC_ENT_WAVES_ALL      // A/B builds (tools/tune_build.py): every instantiation for this many waves per SIMD
-#define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) VBMC_ENT_WAVES_ALL
-#endif
 // Which workgroup shapes share the even part of the exponent between the antithetic pair (EO: 4 instead of 2 QS S-step MFMAs per k-tile and
 // tile).  Single-wave workgroups since round 2; round 4: two- and four-wave workgroups (64 < K <= 256) too -- the second sign's exponents are
 // parked in LDS (NML) and the PV exchange is single-buffered to pay for that LDS: up to -35 % at D >= 20 (tools/tune_sweep.py, r04_experiments.md
-// section 10), BASELINE configs[4] 9.75 -> 8.5 ms.  -DVBMC_NO_EO2 / -DVBMC_NO_EO4: round 3's plain per-sign S-step there (A/B builds).
-#ifdef VBMC_NO_EO2
-#define VBMC_ENT_EO(HV_) ((HV_) == 1)
-#elif defined(VBMC_NO_EO4)
-#define VBMC_ENT_EO(HV_) ((HV_) == 1 || (HV_) == 2)
-#else
+// section 10), BASELINE configs[4] 9.75 -> 8.5 ms.  (The plain per-sign S-step, !EO, remains as the general form of the sign loop.)
 #define VBMC_ENT_EO(HV_) true
-#endif
-#ifndef VBMC_ENT_CW_WAVES
-#define VBMC_ENT_CW_WAVES 3     // waves per SIMD the chunk-wave kernels (CW > 1) are built for
-#endif
-#ifndef VBMC_ENT_WAVES
 // ONE wave per SIMD (512 registers: nothing spills) where the two-wave build spills so much that losing the second wave's latency
 // hiding is the smaller evil (round 3, tools/tune_build.py w1:-DVBMC_ENT_WAVES_ALL=1 against the policy over 112 shapes,
 // profiles/r03_shape_sweep.md): four k-tiles on one wave from D = 15 on (K = 53..64: 11-23 % faster), three k-tiles from D = 27 on
@@ -240,9 +153,7 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
    ((HV_) == 4 && (KT_) == 3 && (QS_) >= 9))
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) \
   (VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) ? 1 : ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2))
-#endif
-__global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV))) k_entropy_mfma(EntArgs a) {
-  static_assert(CW == 1 || (HV == 1 && !CO && !SPARSE && GRAD), "chunk-wave workgroups exist for the dense single-wave gradient kernels");
+__global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
   static_assert(!CO || (HV == 1 && QS <= 8 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 30");
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4 || HV == 8), "larger mixtures are split over the waves of a workgroup (HV = 2, 4; round 5: 8, K <= 512)");
   static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
@@ -252,9 +163,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   constexpr int NPV = (4 * QS + 15) / 16;  // 16-column blocks of the PV output (D + 2 columns)
   constexpr int QL = QS;                   // MFMAs of the linear part of the S-step (inner index c = 4q + lg < D, zero operands beyond D: for
                                            // D mod 4 in {3, 0} the last one multiplies zeros -- a compile-time count keeps the KT chains branch-free)
-  __shared__ double Et_all[CW][16 * DP];   // eps tile [i][d], staged by wave 0 and shared by the HV waves of the workgroup (one per chunk wave)
-  constexpr bool GP2 = X_GP2 && GRAD && ent_gp2_for(KT, QS, TL, HV);
-  __shared__ double RQ_all[HV * CW][GP2 ? 32 : 16];   // q'_i then 1/q'_i  (GP2: and A'_i then A'_i/q'_i behind them)
+  __shared__ double Et[16 * DP];   // eps tile [i][d], staged by wave 0 and shared by the HV waves of the workgroup
+  constexpr bool GP2 = GRAD && ent_gp2_for(KT, QS, TL, HV);
+  __shared__ double RQ_all[HV][GP2 ? 32 : 16];   // q'_i then 1/q'_i  (GP2: and A'_i then A'_i/q'_i behind them)
   __shared__ double BND_all[HV][SPARSE ? KT * 16 * 3 : 1];  // per component: |m'_k|, cK_k - cK_j, h_k  (block-sparse bound)
   // partial PV outputs of the two halves, double-buffered by sign so that one workgroup barrier per sign is enough
   constexpr int YXN = NPV * 4 * WAVE;      // doubles per (sign, wave) slot of the PV exchange (in the dynamic LDS, see PB)
@@ -268,37 +179,24 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   constexpr bool YXSB = HV > 1 && EO;   // one PV exchange buffer for both signs (a barrier more per tile): the LDS it frees holds the parked exponents
   // US (round 4): the LDS tile holds u' = eps sigma_j, not eps -- every reader wanted the product (S-step operand, tail, gradient
   // epilogue: a multiply per use), the own exponent comes from |u'|^2 as well
-#ifdef VBMC_NO_US
-  constexpr bool US = false;
-#else
   constexpr bool US = EO;
-#endif
   constexpr bool VBL = GRAD && HV == 1 && (KT >= 3 || NPV >= 2);
   __shared__ double VBS_all[HV][VBL ? KT * 4 * NPV * WAVE : 1];
-  constexpr bool C2 = X_C2 && VBMC_ENT_EO(HV) && !SPARSE && ent_c2_for(KT, QS, TL, HV);
-  constexpr bool F32S = X_F32S && VBMC_ENT_EO(HV) && !C2 && !SPARSE && CW == 1;
+  constexpr bool C2 = EO && !SPARSE && ent_c2_for(KT, QS, TL, HV);
   // component (within the wave's share) held by accumulator register rr of this lane group in k-tile kt
-#define ENT_CI(kt_, rr_) (F32S ? 16 * (kt_) + 4 * lg + (rr_) : 16 * (kt_) + 4 * (rr_) + lg)
+#define ENT_CI(kt_, rr_) (16 * (kt_) + 4 * (rr_) + lg)
   __shared__ __attribute__((aligned(16))) double SCP_all[HV][C2 ? KT * 16 * 2 : 2];   // C2: [component 16 kt + c][2 c0, 2 c1] of the even part
   __shared__ double BTL_all[HV][TL ? 4 * TL * DP : 1];  // tail: linear S-step coefficients [t][d] (x 1024/ln2), zero beyond D and for absent components
-  // CW > 1 (chunk waves): the CW waves of a workgroup work on the SAME (component j, restart r) and on CW consecutive sample chunks,
-  // each on its own -- no barrier in the tile loop -- but they share what depends on (j, r) only: the exp table, the PV operands and,
-  // new here, the S-step operands (SAL: read from LDS right before the MFMA that consumes them, 2 KT QL VGPRs less).  The second
-  // sign's exponents wait in a private LDS block instead of registers (NML: 8 KT VGPRs less).  Together that is what the 168-VGPR
-  // budget of THREE waves per SIMD needs, and the shared table is what lets twelve waves' LDS fit a compute unit.
-  constexpr bool SAL = CW > 1, NML = CW > 1 || (HV > 1 && EO);   // (two-wave workgroups with the shared even part park them too: their registers are spoken for)
-  __shared__ double SAS_all[SAL ? KT * QL * WAVE : 1];
-  __shared__ double NMS_all[HV * CW][NML ? KT * 4 * WAVE : 1];
-#ifdef VBMC_EXP_CLK
+  constexpr bool NML = HV > 1 && EO;   // multi-wave workgroups park the second sign's exponents in LDS: their registers are spoken for
+  __shared__ double NMS_all[HV][NML ? KT * 4 * WAVE : 1];
+#ifdef VBMC_INSTRUMENT
   const unsigned long long wckE = wall_clock64();
 #endif
-  const int tid = threadIdx.x, wv = tid >> 6, hv = HV == 1 ? 0 : wv, cwi = CW == 1 ? 0 : wv, lane = tid & 63;
+  const int tid = threadIdx.x, wv = tid >> 6, hv = HV == 1 ? 0 : wv, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
-  const int c = CW == 1 ? (int)blockIdx.x : (int)blockIdx.x * CW + cwi, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = blockIdx.z;
+  const int c = (int)blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = blockIdx.z;
   const int D = a.D, K = a.K;
-  double* Et = Et_all[cwi];
   double* RQ = RQ_all[wv];
-  double* SAS = SAS_all;
   double* NMS = NMS_all[wv];
   double* BND = BND_all[hv];
   double* VBS = VBS_all[hv];
@@ -324,7 +222,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   double* const YX = PB + VB_EXP_TAB1K_N;
   // (round 5) the exp table's global loads and sigma_j leave at the kernel's entry, beside the parameter block's: three round trips to
   // memory one after the other (block, sigma_j behind the barrier, table behind the operand build) were a third of the 9.7 us set-up
-  constexpr int NTH0 = WAVE * HV * CW;
+  constexpr int NTH0 = WAVE * HV;
   constexpr int NTB0 = (VB_EXP_TAB1K_N + NTH0 - 1) / NTH0;
   double tt[NTB0];
 #pragma unroll
@@ -334,7 +232,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
     // single chain) this setup is a quarter of the kernel
     const double* gsrc = a.entp + (size_t)r * K * PSg;
-    constexpr int NT = WAVE * HV * CW;
+    constexpr int NT = WAVE * HV;
     const int n = K * PSg;
     int idx = tid;
     for (; idx + 7 * NT < n; idx += 8 * NT) {
@@ -357,14 +255,14 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   const double* pj = gp + (size_t)j * PSg;
   const double cKj = pj[D + 1];
   const double hj_neg = 0.5 / (sigj * sigj);   // = -h_j bit for bit (k_prep computes h = -0.5/(sigma*sigma))
-  const int nr_last = (TL || F32S) ? 4 : max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
+  const int nr_last = TL ? 4 : max(1, min(4, (Kw - 16 * (KT - 1) + 3) >> 2));  // accumulator registers with a valid component in the last k-tile (1..4)
   constexpr unsigned FULL_MASK = (1u << KT) - 1u;
   const double logwj = SPARSE ? log(pj[D + 2]) : 0.0;
 
   // ---- mixture-side operand fragments (registers, built once).  The S-step operands carry the factor 1024/ln2 of the exp's
   // range reduction (device_math.h: vb_exp_tab1k): the MFMAs deliver E * 1024/ln2
   constexpr double ESC = VB_EXP_TAB1K_SCALE;
-  double SA[SAL ? 1 : KT][QL];  // S-step "A" operand, linear part: comp 16kt + li, inner c = 4q + lg < D   (in LDS when SAL)
+  double SA[KT][QL];  // S-step "A" operand, linear part: comp 16kt + li, inner c = 4q + lg < D
   double SC[KT];              // S-step "A" operand, even part: inner index lg = 0 (coefficient of |u'|^2), 1 (constant), 2, 3 (zero)
   double VB[VBL ? 1 : KT][4][NPV];   // PV "B" operand: comp 16kt + 4r + lg, column 16pv + li      (GRAD; in LDS when VBL)
   double WF[KT][4];           // w_k for comp 16kt + 4r + lg                                  (!GRAD)
@@ -393,8 +291,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
           if (cc == D) sav = kv ? ESC * (h + hj_neg) : 0.0;
           if (cc == D + 1) sav = ESC * (kv ? fma(h, m2, pk[D + 1]) - cKj : -1.0e6);
         }
-        if (SAL) { if (cwi == 0) SAS[(kt * QL + q) * WAVE + lane] = sav; }
-        else SA[SAL ? 0 : kt][q] = sav;
+        SA[kt][q] = sav;
       } else {   // plain S-step: linear and even columns in one (D + 2)-column operand, QS MFMAs per sign
         double v;
         if (!kv) v = (cc == D + 1) ? -1.0e6 : 0.0;
@@ -402,20 +299,19 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
         else if (cc == D) v = h + hj_neg;
         else if (cc == D + 1) v = fma(h, m2, pk[D + 1]) - cKj;
         else v = 0.0;
-        SA[SAL ? 0 : kt][q] = ESC * v;
+        SA[kt][q] = ESC * v;
       }
     }
     // the sample's own exponent -shift_i = -cK_j + |u'_i|^2/(2 sigma_j^2) is folded into the two even columns: accumulators start at 0
     SC[kt] = ESC * (!kv ? (lg == 1 ? -1.0e6 : 0.0)                          // padded component: exp -> 0
                         : (lg == 0 ? h + hj_neg : (lg == 1 ? fma(h, m2, pk[D + 1]) - cKj : 0.0)));
-    if (C2 && lg < 2 && (CW == 1 || cwi == 0)) SCP[(16 * kt + li) * 2 + lg] = 2.0 * SC[kt];
+    if (C2 && lg < 2) SCP[(16 * kt + li) * 2 + lg] = 2.0 * SC[kt];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int k2 = ENT_CI(kt, rr);
       const bool kv2 = k2 < Kw;
       const double* p2 = gp + (size_t)(kv2 ? kbase + k2 : 0) * PSg;
       if (GRAD) {
-        if (CW > 1 && cwi != 0) continue;   // the shared PV operands are written by the first chunk wave
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
           const int col = 16 * pv + li;
@@ -455,8 +351,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       for (int d = 0; d < D; ++d) { double t = pq[d] - pj[d]; m2 = fma(t, t, m2); }
       tC0[u] = kvq ? ESC * (h + hj_neg) : 0.0;
       tC1[u] = ESC * (kvq ? fma(h, m2, pq[D + 1]) - cKj : -1.0e6);            // absent component: exp -> 0
-      if (CW == 1 || cwi == 0)
-        for (int d = li; d < DP; d += 16) BTL[tq * DP + d] = (kvq && d < D) ? ESC * (-2.0 * h * (pq[d] - pj[d])) : 0.0;
+      for (int d = li; d < DP; d += 16) BTL[tq * DP + d] = (kvq && d < D) ? ESC * (-2.0 * h * (pq[d] - pj[d])) : 0.0;
       if (GRAD) {
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {     // PV "B" operand: inner index lg <-> tail component 4u + lg, column 16 pv + li
@@ -482,18 +377,13 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     for (int u = 0; u < NTB0; ++u) if (VB_EXP_TAB1K_N % NTH0 == 0 || tid + u * NTH0 < VB_EXP_TAB1K_N) TAB[tid + u * NTH0] = tt[u];
   }
   __syncthreads();
-  if (CW > 1 && c >= a.C) return;   // a chunk wave beyond the last chunk (C not a multiple of CW): no barrier follows
 
-#define SAV(kt_, q_) (SAL ? SAS[((kt_) * QL + (q_)) * WAVE + lane] : SA[SAL ? 0 : (kt_)][q_])
+#define SAV(kt_, q_) SA[kt_][q_]
   // VBR (round 5): with the registers the gradient epilogue gave back (GP2) and one PV accumulator set (TWO below), PV operands of the
   // three-k-tile kernels stay in registers again -- the LDS reads of the PV step were worth 2-3 % (profiles/r05_experiments.md: all
   // twelve in registers -3.4 %, ten -2.5 %, with the parity-mode prefetch holding its QS registers): all of them in the device-RNG
-  // instantiation (EM = false), ten in the one that prefetches its draws.  -DVBMC_VBR=n (A/B): n for both; 0: all from LDS (round 4)
-#ifdef VBMC_VBR
-  constexpr int VBR = (VBL && NPV == 1 && CW == 1 && HV == 1 && KT == 3) ? (VBMC_VBR) : 0;
-#else
-  constexpr int VBR = (VBL && NPV == 1 && CW == 1 && HV == 1 && KT == 3 && !CO) ? ((EM && QS <= 4) ? (TL == 2 ? 4 : 10) : 12) : 0;
-#endif
+  // instantiation (EM = false), ten in the one that prefetches its draws.
+  constexpr int VBR = (VBL && NPV == 1 && HV == 1 && KT == 3 && !CO) ? ((EM && QS <= 4) ? (TL == 2 ? 4 : 10) : 12) : 0;
   double VBreg[VBR > 0 ? VBR : 1];
 #pragma unroll
   for (int u = 0; u < VBR; ++u) VBreg[u] = VBS[u * WAVE + lane];
@@ -509,7 +399,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = 0.0;
 
-#ifdef VBMC_EXP_CLK   // timing experiment: shader-clock ticks (s_memtime) against the constant 100 MHz counter over one wave's tile loop
+#ifdef VBMC_INSTRUMENT   // timing experiment: shader-clock ticks (s_memtime) against the constant 100 MHz counter over one wave's tile loop
   const unsigned long long wck0 = wall_clock64();
 #endif
   const int ntile = (a.Mh + 15) >> 4;
@@ -523,11 +413,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   // into QS registers per lane (round 4) -- issued right after the current tile went to LDS, waited for at the next tile's start, a whole
   // tile of arithmetic later -- instead of a load-and-wait at the head of every tile.  Where the registers are there (EPF); the same
   // kernel serves the device-RNG mode, so the registers are spent in both.
-#ifdef VBMC_NO_EPF
-  constexpr bool EPF = false;
-#else
   constexpr bool EPF = EM && HV == 1 && QS <= 4 && KT <= 3 && !SPARSE;
-#endif
   double epre[EPF ? QS : 1];
   auto eps_fetch = [&](const int tile) {
 #pragma unroll
@@ -541,11 +427,9 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
   if (EPF && epsr) eps_fetch(t0);
   // (ETZ) the device-RNG path writes only the dim-blocks that hold a dimension: the others are zeroed here, once.  The first ordering point
   // of the tile body lies between this and the first read.
-  if (X_ETZ && !epsr && (HV == 1 || hv == 0))
+  if (!epsr && (HV == 1 || hv == 0))
     for (int idx = lane; idx < 16 * DP; idx += WAVE) Et[idx] = 0.0;
-  // (EVX) lanes whose slot of the last dim-block (and, for D = 4 QS - 5, of the one before) is padding, as wave masks in scalar registers
-  int evm1 = emask, evm2 = emask2;
-  if (X_EVX) { asm volatile("" : "+v"(evm1)); asm volatile("" : "+v"(evm2)); }
+  const int evm1 = emask, evm2 = emask2;
   // (C2) the sample-side values of the even slots: slot D takes |u'_i|^2 (factor c2u), slot D + 1 the constant 1 (c2o); they sit in the last
   // dim-block, or -- D = 4 QS - 5 -- slot D in the last slot of the one before
   const double c2u1 = (4 * (QS - 1) + lg == D) ? 1.0 : 0.0, c2o1 = (4 * (QS - 1) + lg == D + 1) ? 1.0 : 0.0;
@@ -579,25 +463,17 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #pragma unroll
       for (int q = lg; q < QS; q += 4) {
         double z4[4] = {0.0, 0.0, 0.0, 0.0};
-#ifdef VBMC_EXP_NORNG
-        if (q < (D + 3) / 4) { z4[0] = 1e-3 * (double)((b0 + li) & 1023) - 0.5; z4[1] = 0.25 * z4[0]; z4[2] = -z4[0]; z4[3] = 0.5 - z4[1]; }
-#else
         // inlined (round 4: -2.5 % at the headline shape -- no call, no wait for every outstanding memory operation at its entry, scalar key
         // schedule) except in the two instantiations where the inlined body costs registers the kernel does not have (tools/tune_sweep.py:
-        // D = 18, K = 80: +6 %, D = 24, K = 96: +11 %); -DVBMC_RNG_CALL: the out-of-line body everywhere (A/B builds)
-#ifndef VBMC_RNG_CALL
+        // D = 18, K = 80: +6 %, D = 24, K = 96: +11 %)
 #define VBMC_RNG_CALL_FOR(KT_, QS_, TL_, HV_) ((HV_) == 2 && (((KT_) == 2 && (TL_) == 2 && (QS_) == 5) || ((KT_) == 3 && (TL_) == 0 && (QS_) == 7)))
-#else
-#define VBMC_RNG_CALL_FOR(KT_, QS_, TL_, HV_) true
-#endif
         if constexpr (!VBMC_RNG_CALL_FOR(KT, QS, TL, HV)) {
         if (q < (D + 3) / 4) { const vb_d4 zz = vb_normal4i(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q); z4[0] = zz[0]; z4[1] = zz[1]; z4[2] = zz[2]; z4[3] = zz[3]; }
         } else {
         if (q < (D + 3) / 4) vb_normal4(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q, z4);
         }
 #undef VBMC_RNG_CALL_FOR
-#endif
-        if (!X_ETZ || q < (D + 3) / 4) {     // (ETZ: an all-padding dim-block has been zero since the start of the wave)
+        if (q < (D + 3) / 4) {     // (ETZ: an all-padding dim-block has been zero since the start of the wave)
 #pragma unroll
         for (int t = 0; t < 4; ++t) Et[li * DP + 4 * q + t] = US ? sigj * z4[t] : z4[t];
         }
@@ -616,13 +492,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       if (QS >= 2 && q == QS - 2) ev[q] = __hiloint2double(__double2hiint(ev[q]) & evm2, __double2loint(ev[q]) & evm2);
       e2 = fma(ev[q], ev[q], e2);
     }
-#ifdef VBMC_NO_PLS       // A/B: round 4's shuffles through the LDS pipeline
-    e2 += __shfl_xor(e2, 16, 64);
-    e2 += __shfl_xor(e2, 32, 64);
-#else
     e2 = xor_sum16(e2);     // (PLS, round 5: on the VALU -- |u'|^2 heads the last MFMA group of the S-step and the second sign's exponents)
     e2 = xor_sum32(e2);
-#endif
     // US: the sum above is |u'_i|^2 already
     double shift = US ? fma(-e2, hj_neg, cKj) : cKj - 0.5 * e2;              // exponent of the sample's own component: cK_j - |eps_i|^2 / 2
     const double u2 = US ? e2 : sigj * sigj * e2;                            // |u'_i|^2
@@ -681,28 +552,12 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
             nm[(EO && !NML) ? kt : 0] = e2nd;
           }
         } else
-        if (F32S) {
-          const vf4 z4 = {0.f, 0.f, 0.f, 0.f};
-          const vf4 c32 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)SC[kt], (float)sfc, z4, 0, 0, 0);
-          vf4 n32 = c32;
-#pragma unroll
-          for (int q = 0; q < QL; ++q) n32 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)SAV(kt, q), (float)sfl[q], n32, 0, 0, 0);
-          mf4 e2nd;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) { n[kt][rr] = (double)n32[rr]; e2nd[rr] = 2.0 * (double)c32[rr] - n[kt][rr]; }
-          if (NML) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) NMS[(kt * 4 + rr) * WAVE + lane] = e2nd[rr];
-          } else {
-            nm[(EO && !NML) ? kt : 0] = e2nd;
-          }
-        } else
         if (!SP || ((act >> kt) & 1u)) {
-          const mf4 cacc = X_S ? __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0) : (mf4){SC[kt] * sfc, sfl[0], SAV(kt, 0), -1.0};
+          const mf4 cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(SC[kt], sfc, n[kt], 0, 0, 0);
           n[kt] = cacc;
 #pragma unroll
           for (int q = 0; q < QL; ++q)
-            if (X_S) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SAV(kt, q), sfl[q], n[kt], 0, 0, 0);
+            n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SAV(kt, q), sfl[q], n[kt], 0, 0, 0);
           if (NML) {
             const mf4 e2nd = 2.0 * cacc - n[kt];
 #pragma unroll
@@ -734,7 +589,6 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     // ---- the phases of one sign as inlined pieces (x: the sign's exponents, overwritten by their exponentials)
     auto exps = [&](mf4 (&x)[KT], auto k0c, auto k1c) {   // k-tiles k0 .. k1-1: 4 straight-line exps each
       constexpr int k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
-      if (!X_EXP) return;
 #pragma unroll
       for (int kt = k0; kt < k1; ++kt) {
         if (kt < KT - 1) {
@@ -754,7 +608,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       }
     };
     auto texp = [&](double (&t)[TLN]) {
-      if (TL && X_EXP) {
+      if (TL) {
 #pragma unroll
         for (int u = 0; u < TLN; ++u) t[u] = vb_exp_tab1k<VB_EXP_TAB1K_QUAD>(t[u], TAB);
       }
@@ -762,14 +616,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     // PV-step: Y[i][col]; lane (col = li, lg) register rr <-> sample lg + 4 rr.  Two accumulator sets halve the dependent chain.
     // (NPV >= 2: the column blocks are independent chains already, one set is enough -- 16 VGPRs less.)
     auto pvstep = [&](mf4 (&x)[KT], mf4 (&Y)[NPV], int sg, const double (&tn)[TLN]) {
-#if defined(VBMC_TUNE_PV1)
-      constexpr bool TWO = false;     // A/B: one accumulator set even with a single column block
-#elif defined(VBMC_TUNE_PV2)
-      constexpr bool TWO = (VBMC_TUNE_PV2) != 0 || NPV == 1;
-#else
       constexpr bool TWO = NPV == 1 && KT <= 2;     // (round 5: at three k-tiles and more the second set's eight registers are worth more as PV
                                                     //  operands; the dependent MFMAs of one chain issue back to back anyway: 2.138 vs 2.140 ms)
-#endif
       mf4 Y2s[TWO ? NPV : 1];
       mf4 (&Y2)[TWO ? NPV : 1] = Y2s;
 #pragma unroll
@@ -777,7 +625,6 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
 #pragma unroll
       for (int kt = 0; kt < KT - 1; ++kt) {
         if (SP && !((act >> kt) & 1u)) continue;
-        if (!X_PV) { Y[0] += x[kt]; continue; }
 #pragma unroll
         for (int pv = 0; pv < NPV; ++pv) {
           mf4& Yb = TWO ? Y2[TWO ? pv : 0] : Y[pv];
@@ -791,7 +638,6 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       for (int pv = 0; pv < NPV; ++pv) {
         mf4& Yb = TWO ? Y2[TWO ? pv : 0] : Y[pv];
         if (SP && !((act >> (KT - 1)) & 1u)) { if (TWO) Y[pv] += Yb; continue; }
-        if (!X_PV) { Y[pv] += x[KT - 1]; continue; }
         Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][0], VBV(KT - 1, 0, pv), Y[pv], 0, 0, 0);
         if (nr_last > 1) Yb = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][1], VBV(KT - 1, 1, pv), Yb, 0, 0, 0);
         if (nr_last > 2) Y[pv] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[KT - 1][2], VBV(KT - 1, 2, pv), Y[pv], 0, 0, 0);
@@ -831,12 +677,8 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     };
     double arq = 0.0;   // GP2: A'_i / q'_i in the sample layout
     // TQ (round 5): the second sign's gradient epilogue reuses the four u'_id the first sign read (-0.2 %; eight registers across the second
-    // sign's exponentials, so only in the headline class, where they are there).  -DVBMC_NO_TQ: both signs read (A/B)
-#ifndef VBMC_NO_TQ
-    constexpr bool TQ = GP2 && US && NPV == 1 && HV == 1 && CW == 1 && EO && KT == 3 && QS <= 3 && !CO && !EM && VBMC_STAG_FOR(KT, QS, TL);
-#else
-    constexpr bool TQ = false;
-#endif
+    // sign's exponentials, so only in the headline class, where they are there).
+    constexpr bool TQ = GP2 && US && NPV == 1 && HV == 1 && EO && KT == 3 && QS <= 3 && !CO && !EM && VBMC_STAG_FOR(KT, QS, TL);
     double tq[TQ ? 4 : 1];
     auto get_rq = [&]() -> double {
       double qs_ = RQ[li];
@@ -860,7 +702,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       for (int kt = 0; kt < KT; ++kt) {
         if (SP && !((act >> kt) & 1u)) continue;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) if (X_W || (kt == 0 && rr == 0)) Wacc[kt][rr] = fma(x[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
+        for (int rr = 0; rr < 4; ++rr) Wacc[kt][rr] = fma(x[kt][rr], rqs, Wacc[kt][rr]);  // (:100)
       }
     };
     auto put_rq = [&](double rqs) {
@@ -873,7 +715,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       constexpr int SG = decltype(sgc)::value;
       if constexpr (GP2) {
 #pragma unroll
-        for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
+        for (int rr = 0; rr < 4; ++rr) {
           const int i = lg + 4 * rr;
           const double rq = RQ[i], ar = RQ[GP2 ? 16 + i : 0];     // one broadcast read of the pair
 #pragma unroll
@@ -894,7 +736,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       }
       const int base = lane & 48;
 #pragma unroll
-      for (int rr = 0; rr < (X_EPI ? 4 : 1); ++rr) {
+      for (int rr = 0; rr < 4; ++rr) {
         const int i = lg + 4 * rr;
         const double Av = __shfl(Y[0][rr], base | 1, 64);    // A'_i  (column 1)
         const double rq = RQ[i];
@@ -926,7 +768,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
     using IH = std::integral_constant<int, (KT + 1) / 2>;
     using IK = std::integral_constant<int, KT>;
 
-    if constexpr (EO && GRAD && CW == 1 && HV == 1 && VBMC_STAG_FOR(KT, QS, TL)) {
+    if constexpr (EO && GRAD && HV == 1 && VBMC_STAG_FOR(KT, QS, TL)) {
       // Both signs in straight-line code, staggered: the second sign's exponentials (independent of everything the first
       // sign's per-sample chain waits for -- the q' exchange through LDS, the reciprocal, the 1/q' exchange) are issued
       // inside that chain, so this wave keeps the pipe busy across its own latencies instead of leaving them to the one
@@ -965,18 +807,14 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
             const int cc = 4 * q + lg;
             // the sample-side fragment: kept in registers across the sign loop, or re-read from the LDS tile (2 QS registers
             // less) where the kernel is short of them -- tools/tune_sweep.py: four k-tiles per wave or D >= 27
-#ifdef VBMC_TUNE_EVREG
-            constexpr bool EVREG = (VBMC_TUNE_EVREG) != 0;
-#else
             constexpr bool EVREG = KT <= 3 && QS <= 7;
-#endif
             sf[q] = (cc < D) ? ssig * (EVREG ? ev[q] : Et[li * DP + 4 * q + lg]) : ((cc == D) ? u2 : ((cc == D + 1) ? 1.0 : 0.0));
           }
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
             n[kt] = (mf4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[SAL ? 0 : kt][q], sf[q], n[kt], 0, 0, 0);
+            for (int q = 0; q < QS; ++q) n[kt] = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[kt][q], sf[q], n[kt], 0, 0, 0);
           }
         }
         exps(n, I0{}, IK{});
@@ -1035,18 +873,17 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       }
     }
   };
-  if constexpr (VBMC_ENT_SPLIT(KT, QS, TL, HV, CW)) {
+  if constexpr (VBMC_ENT_SPLIT(KT, QS, TL, HV)) {
     const int tf = min(t1, a.Mh >> 4);        // tiles [t0, tf) hold 16 samples each
-#ifndef VBMC_ENT_NOPRIO
     // A wave's issue priority falls as it progresses (s_setprio 3 -> 0 at the quarter points of its tiles): of two waves that share a
     // SIMD the one BEHIND is served first.  At equal priority the arbiter keeps serving the older wave: with a single round of waves
     // (8 restarts per device: 2000 waves on 2048 slots) one wave of each SIMD finished at 240 us, the other at 340, the last 100 us at
     // the single-wave issue rate (tools/archive/r4_timeline.py).  R = 8: 0.337 -> 0.327 ms per step (-3.1 %), R = 16: 0.644 -> 0.633, R = 32:
     // 1.246 -> 1.234, R = 64 (eleven rounds: there is always a younger wave to take over) within 0.2 % either way; the same bits.
-    // Halves instead of quarters: a third of the gain.  EntArgs::prio = 0 (VBMC_ENT_PRIO=0) / -DVBMC_ENT_NOPRIO: without (A/B).
+    // Halves instead of quarters: a third of the gain.  EntArgs::prio = 0 (VBMC_ENT_PRIO=0): without (A/B).
     // Not in the instantiations built for ONE wave per SIMD (nothing to arbitrate; the thresholds only cost scalar registers there: +0.5-1.1 %
     // at D >= 20, K = 56..64 over the 112-shape sweep, against -3.2 % on average for the shapes of 8..64 components).
-    constexpr bool PRIO = CW > 1 || (CO ? QS <= 4 : VBMC_ENT_WAVES(KT, QS, TL, HV) > 1);
+    constexpr bool PRIO = CO ? QS <= 4 : VBMC_ENT_WAVES(KT, QS, TL, HV) > 1;
     const bool pr = PRIO && a.prio != 0;
     const int q1 = pr ? t0 + (t1 - t0 + 3) / 4 : -1, q2 = pr ? t0 + (t1 - t0 + 1) / 2 : -1, q3 = pr ? t0 + (3 * (t1 - t0) + 3) / 4 : -1;
     if (pr) __builtin_amdgcn_s_setprio(3);
@@ -1056,16 +893,13 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       if (tile == q3) __builtin_amdgcn_s_setprio(0);
       tile_body(tile, EntTileFull{});
     }
-#else
-    for (int tile = t0; tile < tf; ++tile) tile_body(tile, EntTileFull{});
-#endif
     if (tf < t1) tile_body(tf, EntTilePartial{});
   } else {
     // (no priorities here: in the multi-wave kernels the three thresholds cost scalar registers these instantiations do not have --
     // BASELINE configs[4]: kernel alone 8.31 -> 8.64 ms with the code in place and switched off, 8.50 switched on)
     for (int tile = t0; tile < t1; ++tile) tile_body(tile, EntTileAny{});
   }
-#ifdef VBMC_EXP_CLK
+#ifdef VBMC_INSTRUMENT
   const unsigned long long wck1 = wall_clock64();
 #endif
   accH += log(pm) + 0.693147180559945309417 * (double)pe;
@@ -1119,7 +953,7 @@ __global__ void __launch_bounds__(WAVE * HV * CW, CW > 1 ? VBMC_ENT_CW_WAVES : (
       }
     }
   }
-#ifdef VBMC_EXP_CLK
+#ifdef VBMC_INSTRUMENT
   if (lane == 0) {
     const size_t w = ((size_t)r * K + j) * a.C + c;
     if (w < VBMC_DBG_WAVES) {

@@ -574,11 +574,8 @@ __global__ void __launch_bounds__(64 * TRI2_W, 2) k_trsm2(int N, int K, int S, c
   const size_t off = ((size_t)r * S + s) * (size_t)K * N;
   trsm2_body<MAXS, (MAXS <= 4 ? 4 : 2), BWD>(N, K, cb * 16, Lall + (size_t)s * N * N, Finv + (size_t)s * TRSM_NBLK(N) * 256, Zin + off, Zout + off);
 }
-// the workgroup-per-slab solves when the row blocks fit the accumulator registers (N <= 1024); VBMC_TRSM2=0: the one-wave kernels (A/B)
-static inline bool trsm2_wanted(int N) {
-  static const int force = getenv("VBMC_TRSM2") ? atoi(getenv("VBMC_TRSM2")) : -1;
-  return force != 0 && TRSM_NBLK(N) <= TRI2_W * 8;
-}
+// the workgroup-per-slab solves when the row blocks fit the accumulator registers (N <= 1024)
+static inline bool trsm2_wanted(int N) { return TRSM_NBLK(N) <= TRI2_W * 8; }
 template <bool BWD>
 static inline hipError_t trsm2_launch(hipStream_t st, int N, int K, int S, int R, const double* Lall, const double* Finv,
                                       const unsigned char* lchol, const double* Zin, double* Zout) {
@@ -595,13 +592,10 @@ static inline hipError_t tri_inverse_launch(hipStream_t st, int N, int S, const 
   if (cw == 0) return hipErrorInvalidValue;
   // the workgroup-per-slab kernel whenever the slab's row blocks fit its accumulator registers (N <= 1024) -- built for the latency
   // of a handful of matrices, it is also 17 % of a whole gplite_nlZ batch faster at 64 and 256 matrices (78 -> 91 k, 133 -> 157 k
-  // evals/s: the one-wave kernel runs at a tenth of the matrix-pipe rate); VBMC_TRI2=0: the one-wave kernel (A/B)
+  // evals/s: the one-wave kernel runs at a tenth of the matrix-pipe rate)
   {
-    static const int force = getenv("VBMC_TRI2") ? atoi(getenv("VBMC_TRI2")) : -1;
     const int nblk = TRSM_NBLK(N);
-    const bool fits = nblk <= TRI2_W * 8;
-    const bool want = force != 0;
-    if (fits && want) {
+    if (nblk <= TRI2_W * 8) {
       if (nblk <= TRI2_W * 4) hipLaunchKernelGGL((k_tri_inverse2<4>), dim3(nblk, S, 1), dim3(64 * TRI2_W), 0, st, N, S, Lall, Finv, lchol, T, transposed);
       else hipLaunchKernelGGL((k_tri_inverse2<8>), dim3(nblk, S, 1), dim3(64 * TRI2_W), 0, st, N, S, Lall, Finv, lchol, T, transposed);
       return hipGetLastError();
