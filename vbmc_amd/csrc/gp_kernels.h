@@ -774,6 +774,7 @@ __global__ void __launch_bounds__(PREDF_THREADS, 1) k_pred_fused(PredArgs a, con
     const double* aas = aa + (size_t)s * N;
     const double* al = a.alpha + (size_t)s * N;
     const double* Am = (lc ? a.tinv : a.L) + (size_t)s * N * N;   // element (row, col) at col * N + row
+    const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)Am, 0, (int)((size_t)N * N * 8), 0x00020000);
     // ---- the cross-kernel tiles: 16 x 16 blocks (training points n0 .. n0 + 15 x the tile's points).  A wave takes the row blocks
     // n0 = 16 (wave + NWV i) of EVERY resident point tile; the training-point fragment, |a|^2 and alpha of a row block are loaded once per
     // block and one block ahead; fmu's data term Ks' alpha (:83) is accumulated on the way
@@ -860,30 +861,47 @@ __global__ void __launch_bounds__(PREDF_THREADS, 1) k_pred_fused(PredArgs a, con
       tmf4 acc[PT];
 #pragma unroll
       for (int p = 0; p < PT; ++p) acc[p] = (tmf4){0.0, 0.0, 0.0, 0.0};
-      // A operands: chunks of four k-steps, loaded one chunk ahead of their MFMAs into two register sets used in turn (no copies between
-      // them: a set rotated by moves makes the wave wait for the loads it has just issued); the other three waves of the SIMD cover the wait
-      const double* arow = Am + (rv ? row : 0);
+      // Operands in chunks of four k-steps, BOTH loaded one chunk ahead of their MFMAs into two register sets used in turn: the A operands
+      // (inv(L'), from the L2) and the B operands (the resident tiles, from LDS).  The scheduling barriers keep the next chunk's loads
+      // ABOVE the current chunk's MFMAs: left to itself the compiler sank half of the global loads and every LDS read down to right in
+      // front of their consumers (s_waitcnt vmcnt / lgkmcnt directly ahead of every second MFMA: half of the waves' cycles were such
+      // waits, SQ_WAIT_INST_ANY in profiles/r06_aux.md).
+      // (A through a buffer descriptor: base and extent in scalar registers, ONE 32-bit offset per lane and a scalar add per load -- the
+      // 64-bit address, the compare and the select per element were 3 VALU instructions per MFMA of this loop, and on this chip every VALU
+      // instruction of a SIMD waits while an fp64 MFMA executes.  Columns beyond N lie past the extent and read 0; the lanes of rows
+      // beyond N start 2 GB up and stay past it)
+      const unsigned vo = rv ? (unsigned)(((size_t)row + (size_t)lg * N) * 8) : 0x80000000u;
+      const double* bl = KsL + (size_t)lg * 16 + li;
       auto lda4 = [&](int c0, double (&d)[4]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = c0 + 4 * u + lg;
-          d[u] = (rv && c < N && c0 < ncol) ? arow[(size_t)c * N] : 0.0;
-        }
+        for (int u = 0; u < 4; ++u)
+          d[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Ar, (int)(vo + (unsigned)((c0 + 4 * u) * N * 8)), 0, 0));
       };
-      auto mm4 = [&](int c0, const double (&d)[4]) {
+      auto ldb4 = [&](int c0, double (&b)[4][PT]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double* brow = KsL + (size_t)(c0 + 4 * u + lg) * 16 + li;
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int p = 0; p < PT; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[u], brow[(size_t)p * Np * 16], acc[p], 0, 0, 0);
-        }
+          for (int p = 0; p < PT; ++p) b[u][p] = bl[(size_t)(c0 + 4 * u) * 16 + (size_t)p * Np * 16];
       };
-      double b0[4], b1[4];
-      lda4(0, b0);
+      auto mm4 = [&](const double (&d)[4], const double (&b)[4][PT]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[u], b[u][p], acc[p], 0, 0, 0);
+      };
+      double a0[4], a1[4], q0[4][PT], q1[4][PT];
+      lda4(0, a0);
+      ldb4(0, q0);
       for (int c0 = 0; c0 < ncol; c0 += 32) {
-        lda4(c0 + 16, b1);
-        mm4(c0, b0);
-        if (c0 + 16 < ncol) { lda4(c0 + 32, b0); mm4(c0 + 16, b1); }
+        const bool two = c0 + 16 < ncol;
+        if (two) { lda4(c0 + 16, a1); ldb4(c0 + 16, q1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mm4(a0, q0);
+        if (two) {
+          if (c0 + 32 < ncol) { lda4(c0 + 32, a0); ldb4(c0 + 32, q0); }
+          __builtin_amdgcn_sched_barrier(0);
+          mm4(a1, q1);
+        }
       }
       // C layout: lane (col = li = point, row = rt * 16 + lg + 4 q)
 #pragma unroll
