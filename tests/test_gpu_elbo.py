@@ -200,6 +200,28 @@ def test_batch_equals_singles_and_is_deterministic(va):
         assert relerr(b1["dF"][:, r], ref["dF"]) < RT_GRAD
 
 
+@pytest.mark.parametrize("D,K,Ns,R_", [(10, 50, 2000, 64), (10, 50, 2010, 64), (6, 20, 200, 400), (3, 40, 1500, 300), (13, 33, 700, 300), (14, 56, 330, 300)])
+def test_walking_entropy_launch_equals_the_chunk_grid(va, D, K, Ns, R_, monkeypatch):
+    """Wide batches (two or more waves per wave slot in the chunk grid) run the WALKING launch of the matrix-core entropy kernel: one wave per
+    slot walks its share of all (restart, component) pairs' tiles, a partial record per (wave, pair), variable record counts per pair in the
+    reduction.  Same draws, same tile body: against the chunk grid (VBMC_ENT_WALK=0) only the order of summation over a pair's records
+    differs.  Shapes: the headline class, a ragged last tile, many pairs per wave, one / two k-tiles, a component tail of eight."""
+    p, gp, vp, theta = problem(40 + D, D, 30, K, 2)
+    thetas = theta[:, None] + 0.05 * np.random.default_rng(D).standard_normal((theta.size, R_))
+    monkeypatch.setenv("VBMC_ENT_KERNEL", "mfma")          # (small mixtures: not the lane kernel)
+    monkeypatch.delenv("VBMC_ENT_WALK", raising=False)
+    w1 = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=77)
+    w2 = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=77)
+    assert np.array_equal(w1["H"], w2["H"]) and np.array_equal(w1["dH"], w2["dH"])      # deterministic
+    monkeypatch.setenv("VBMC_ENT_WALK", "0")
+    c = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=77)
+    assert relerr(w1["H"], c["H"]) < 1e-13
+    for r in range(R_):
+        assert relerr(w1["dH"][:, r], c["dH"][:, r]) < 1e-12
+    assert not np.array_equal(w1["dH"], c["dH"]), "the walking launch did not run (same bits as the chunk grid)"
+    assert np.array_equal(w1["G"], c["G"])      # the log joint is untouched
+
+
 def test_device_rng_stream_is_reproducible_and_standard_normal(va):
     """eps_mode 0: the Philox stream the kernel consumes can be dumped and fed to the oracle."""
     p, gp, vp, theta = problem(6, 5, 40, 4, 2)

@@ -34,6 +34,7 @@ def build(qs=3):
     names = [k for k in VARIANTS if (not only or k in only.split(","))]
     os.makedirs(EXP, exist_ok=True)
     others = [os.path.join(OBJ, "vbmc_hip.o")] + [os.path.join(OBJ, "ent_mfma_qs%d.o" % q) for q in range(1, 10) if q != qs]
+    others += [os.path.join(OBJ, "ent_lane_dt%d.o" % dt) for dt in (2, 4, 6, 8, 10, 12)]
     procs = []
     for name in names:
         flags = [f for f in VARIANTS[name][0] if f != "@HEAD"]

@@ -25,7 +25,7 @@ def main():
            os.path.join(out, "q.o")]
     subprocess.check_call(cmd, cwd=out)
     asm = open(os.path.join(out, "ent_mfma_inst-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-    print("# k_entropy_mfma<QS=%d, KT, GRAD, SPARSE, HV, TL, CO, EM>  (hipcc --save-temps, .amdgpu_metadata; +tail: component tail, +lj: log-joint role, +rng: the device-RNG instantiation, EM = false)" % qs)
+    print("# k_entropy_mfma<QS=%d, KT, GRAD, SPARSE, HV, TL, CO, EM, WALK>  (hipcc --save-temps, .amdgpu_metadata; +tail: component tail, +lj: log-joint role, +rng: the device-RNG instantiation, EM = false, +walk: the walking launch)" % qs)
     meta = asm[asm.index("amdhsa.kernels:"):]
     for body in re.split(r"\n  - \.agpr_count", "\n" + meta)[1:]:
         body = ".agpr_count" + body
@@ -37,15 +37,15 @@ def main():
         def g(k):
             return int(re.search(k + r":\s+(\d+)", body).group(1))
 
-        t = re.match(r"_Z14k_entropy_mfmaILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)ELb(\d)E", name)
+        t = re.match(r"_Z14k_entropy_mfmaILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d+)ELi(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
         v, a = g(r"\.vgpr_count"), g(r"\.agpr_count")
         tot = ((v + a + 7) // 8) * 8
-        print("KT=%s%s%s%s grad=%s sparse=%s HV=%s: vgpr %d agpr %d sgpr %d vgpr_spill %d sgpr_spill %d scratch %d B lds %d B -> %d waves/SIMD"
+        print("KT=%s%s%s%s%s grad=%s sparse=%s HV=%s: vgpr %d agpr %d sgpr %d vgpr_spill %d sgpr_spill %d scratch %d B lds %d B -> %d waves/SIMD"
               % (t.group(2), ("+tail" if t.group(6) == "1" else "+tail8" if t.group(6) == "2" else ""), ("+lj" if t.group(7) == "1" else ""),
-                 ("+rng" if t.group(8) == "0" else ""), t.group(3), t.group(4), t.group(5), v, a, g(r"\.sgpr_count"), g(r"\.vgpr_spill_count"), g(r"\.sgpr_spill_count"),
+                 ("+rng" if t.group(8) == "0" else ""), ("+walk" if t.group(9) == "1" else ""), t.group(3), t.group(4), t.group(5), v, a, g(r"\.sgpr_count"), g(r"\.vgpr_spill_count"), g(r"\.sgpr_spill_count"),
                  g(r"\.private_segment_fixed_size"), g(r"\.group_segment_fixed_size"), min(8, 512 // max(tot, 1))))
     # instruction mix of the dense gradient kernel with three k-tiles + component tail (K = 49..52: the headline instantiation at QS = 3)
-    key = "_Z14k_entropy_mfmaILi%dELi3ELb1ELb0ELi1ELi1ELb0ELb0EEv7EntArgs" % qs      # (... EM = false: the device-RNG instantiation)
+    key = "_Z14k_entropy_mfmaILi%dELi3ELb1ELb0ELi1ELi1ELb0ELb0ELb1EEv7EntArgs" % qs      # (... EM = false, WALK = true: the device-RNG instantiation of the walking launch)
     i = asm.find(key + ":")
     if i >= 0:
         body = asm[i: asm.find(".Lfunc_end", i)]

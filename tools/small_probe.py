@@ -43,4 +43,4 @@ for i in range(50):
 blk = (time.perf_counter() - t1) / 50
 print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("VBMC_")}, "shape": [D, N, K, Ns, S, R],
                   "evals_per_s": R * nsteps / best, "us_per_step": 1e6 * best / nsteps, "ent_kernel_us_med_min": [1e3 * float(np.median(ems)), 1e3 * float(np.min(ems))],
-                  "lj_kernel_us": 1e3 * float(np.median(ljs)), "blocking_us": 1e6 * blk, "F0": float(F_[0])}))
+                  "lj_kernel_us": 1e3 * float(np.median(ljs)), "blocking_us": 1e6 * blk, "F0": float(F_[0]), "F_sum": float(np.sum(F_)), "dF_abs_sum": float(np.sum(np.abs(dF_)))}))

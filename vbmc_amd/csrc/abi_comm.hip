@@ -385,7 +385,7 @@ extern "C" vbmc_status vbmc_elbo_batch_multi(vbmc_comm* c, const vbmc_gp* const*
     L.sub.dF = want(a->dF, L.dF, T); L.sub.dG = want(a->dG, L.dG, T); L.sub.dH = want(a->dH, L.dH, T);
     L.sub.I_sk = want(a->I_sk, L.I, (size_t)L.S * K); L.sub.J_sjk = want(a->J_sjk, L.J, (size_t)L.S * K * K);
     L.sub.G_s = want(a->G_s, L.Gs, L.S); L.sub.varG_s = want(a->varG_s, L.vGs, L.S);
-    vbmc_status st = elbo_plan(ctx, gps[i], &L.sub, L.plan);
+    vbmc_status st = elbo_plan(ctx, gps[i], &L.sub, L.plan, 0, true);
     if (!st) st = elbo_enqueue(ctx, gps[i], L.plan, a->seed);
     if (st) {
       local_fail = comm_err(c, st, "device %d: %s", ctx->device, vbmc_last_error(ctx));

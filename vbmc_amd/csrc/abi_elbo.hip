@@ -556,6 +556,7 @@ struct ElboPlan {
   int Mh = 0, C = 1, tpc = 1, ncol = 1, qs = 0, kt = 0, hv = 1, var_stride = 0;
   int no_jacobian = 0;
   int Rp = 0;                // the restarts the launch shapes are chosen for: R, or the undivided batch's (vbmc_elbo_args.plan_restarts)
+  int walk_tpw = 0, walk_nw = 0;   // > 0: the matrix-core entropy kernel WALKS (entropy_mfma.h): tiles per wave, waves of the launch
   double* d_dvs = nullptr;   // per-hyper-sample variance gradient block (dvarG_s), pooled for the call
   bool lj_records = false;   // the caller reads per-hyper-sample log-joint records (separate_K, G_s / varG_s, the variance kernels)
   int r0 = 0, rstride = 1;   // device-RNG key of restart r: r0 + r * rstride (vbmc_elbo_args.restart_offset / restart_stride)
@@ -596,7 +597,7 @@ static bool lj_co_shape(const vbmc_ctx* ctx, const ElboPlan& P) {
 // dynamic LDS of k_var_final: reduction scratch, two S-vectors, five T-vectors (only with a gradient), two K-vectors
 #define VAR_FINAL_LDS(S_, K_, Tg_) ((VARFIN_THREADS + 2 * (size_t)(S_) + 5 * (size_t)(Tg_) + 2 * (size_t)(K_) + 8) * sizeof(double))
 // Validation (reference error ids), one H2D of theta | fixed vp | delta^2 | bounds, scratch sizing.
-static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0) {
+static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_args* a, ElboPlan& P, int chunk_world = 0, bool pipelined = false) {
   if (!gp || !a) return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_batch: null gp/args");
   if (a->struct_size != sizeof(vbmc_elbo_args))
     return set_err(ctx, VBMC_ERR_INVALID, "vbmc_elbo_args.struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(vbmc_elbo_args));
@@ -797,6 +798,24 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
       if (getenv("VBMC_DEBUG_OCC")) fprintf(stderr, "chunks: D %d K %d R %d qs %d kt %d hv %d waves/CU %d slots %lld kr %lld ntile %d -> C %d\n", D, K, R, P.qs, P.kt, P.hv, waves_per_cu, slots, kr, ntile, bestC);
       P.tpc = (ntile + bestC - 1) / bestC;
       P.C = (ntile + P.tpc - 1) / P.tpc;
+      // The walk (entropy_mfma.h): once the chunk grid would hand every wave slot two or more waves, ONE wave per slot walks its share of
+      // all the (restart, component) pairs' tiles instead -- a set-up per (wave, pair) instead of per chunk.  The device-RNG gradient kernels of
+      // single-wave workgroups at D <= 14, K <= 56 (the instantiations that take the loop without spilling); not where
+      // the bits must be those of another launch shape (sharded evaluation, plan_restarts) or the launch carries the log-joint role.
+      // Not for the passes of a pipeline either (vbmc_elbo_submit): there the short kernels of the NEXT pass take the slots the chunk grid's
+      // waves free as they finish, and the step is the sum of its kernels' work with no gap at all (2.19 ms at the headline shape) -- a launch
+      // whose waves all end together leaves them nothing until it is over (2.24); a blocking call or an optimiser iteration has no next pass
+      // to interleave (2.29 -> 2.25 ms).  VBMC_ENT_WALK=0: the chunk grid (A/B runs, tests).
+      const char* walk_env = getenv("VBMC_ENT_WALK");
+      const bool walk_off = walk_env && !strcmp(walk_env, "0");
+      const long long total = (long long)K * R * ntile;
+      if (P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && P.kt <= 3 && a->eps_mode == 0 && compute_grad && !(P.cutoff > 0.0) && cw == 1 && chunk_world == 0 && !pipelined && P.Rp == R && !walk_off && !getenv("VBMC_ENT_CHUNKS") &&
+          kr * P.C >= 2 * slots && total < (1LL << 31) && !lj_co_shape(ctx, P)) {
+        P.walk_tpw = (int)((total + slots - 1) / slots);
+        P.walk_nw = (int)((total + P.walk_tpw - 1) / P.walk_tpw);
+        P.C = ent_walk_max_slots(ntile, P.walk_tpw);
+        if (getenv("VBMC_DEBUG_OCC")) fprintf(stderr, "walk: %d waves x %d tiles, %d record slots per pair\n", P.walk_nw, P.walk_tpw, P.C);
+      }
     }
     P.ncol = compute_grad ? (2 + 2 * D + K) : 1;
     { vbmc_status s_ = ensure(ctx, ctx->entpart, ((size_t)R * K * P.C * P.ncol + (size_t)R * K * P.ncol) * sizeof(double)); if (s_) return s_; }
@@ -969,7 +988,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       DISPATCH_DT(dt, {
         constexpr int NCT = (2 * DT + 1 + 15) / 16;
         const int nw = (K + 15) / 16;
-        const size_t mom_lds = (size_t)nw * 16 * 16 * NCT * sizeof(double);   // moment exchange; large K x D falls back to the VALU kernel
+        const size_t mom_lds = LJ_MFMA_DYN_LDS(DT, nw);   // feature rows / moment exchange; large K x D falls back to the VALU kernel
         // the kernels reach hyper-sample s only through alpha + s N and gpc + s GPC_STRIDE and use dm.S as the record
         // stride: a slice [s0, s0 + ns) is the same launch with shifted pointers (the variant choice above uses the FULL S,
         // so a sharded evaluation runs the kernel the unsharded one would)
@@ -978,7 +997,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         const double* al = gp->alpha + (size_t)s0 * dm.N;
         const double* gc = gp->gpc + (size_t)s0 * GPC_STRIDE(D);
         if (ns <= 0) {
-        } else if (lj_mfma && mom_lds <= 48 * 1024) {
+        } else if (lj_mfma && mom_lds + LJ_MFMA_STATIC_LDS <= 64 * 1024) {
           hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(ns, R), dim3(WAVE * nw), mom_lds, ls, dml, P.d_vpd,
                              gp->X, gp->d_meanX, al, gc, P.d_delta2, lj_out);
           LAUNCH_CHECK(ctx, "k_logjoint_mfma");
@@ -1023,6 +1042,9 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff; ea.r0 = P.r0; ea.rstride = P.rstride;
     ea.prio = 1;   // progress-ordered wave priorities (entropy_mfma.h)
+    const bool walk = P.walk_tpw > 0;
+    if (walk && (sh.mode != 0 || co)) return set_err(ctx, VBMC_ERR_INVALID, "internal: the walking entropy launch was planned for a sharded / role-carrying pass");
+    if (walk) { ea.walk_tpw = P.walk_tpw; ea.walk_R = R; }
     int co_rows = 0;
     if (co) {
       LjCo& lc = ea.lj;
@@ -1057,7 +1079,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       bool ok = launch_entropy_lane(D, K, P.compute_grad != 0, dim3(gx, 1 + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no lane entropy kernel for D = %d, K = %d", D, K);
     } else if (P.use_mfma) {
-      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, dim3(nc, K + co_rows, R), st, ea);
+      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, walk ? dim3(P.walk_nw, 1, 1) : dim3(nc, K + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
     } else {
       const size_t lds = P.ent_lds;
@@ -1072,10 +1094,10 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     // chunk partials -> one record per (r, j), summed in chunk order
     if (fork)
       hipLaunchKernelGGL(k_ent_reduce, dim3(K, R), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
-                         P.d_part, P.d_red);
+                         P.d_part, P.d_red, P.walk_tpw, (P.Mh + 15) / 16);
     else
       hipLaunchKernelGGL(k_reduce_both, dim3(K, R, 2), dim3(P.ncol >= 192 ? 256 : (P.ncol >= 96 ? 128 : 64)), 0, st, P.C, P.ncol,
-                         P.d_part, P.d_red, co ? S * ea.lj.nsplit : S, 2 * D + 2, P.d_lj, P.d_ljbar);
+                         P.d_part, P.d_red, co ? S * ea.lj.nsplit : S, 2 * D + 2, P.d_lj, P.d_ljbar, P.walk_tpw, (P.Mh + 15) / 16);
     LAUNCH_CHECK(ctx, "k_ent_reduce / k_reduce_both");
     fa.entpart = P.d_red; fa.entlb = nullptr; fa.M = P.Mh; fa.C = 1; fa.ncol = P.ncol;
   } else {
@@ -1391,7 +1413,7 @@ static vbmc_status elbo_submit_core(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc
   // the slot's own pinned block stands in for the context's while the inputs are staged and the copies are enqueued
   std::swap(ctx->pin, ctx->slot_pin[slot]);
   std::swap(ctx->pin_cap, ctx->slot_pin_cap[slot]);
-  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P);
+  vbmc_status s_ = elbo_plan(ctx, gp, a, sp->P, 0, true);
   // Result blocks of at most 256 KB are written by the finalize kernel straight into the pinned block (no read-back launch: BASELINE
   // configs[1] 52.1 -> 50.0 us per step, nothing elsewhere), only where nothing on the device reads the records afterwards (not under a
   // communicator: k_comm_pick does).  The mirror image -- the staging block read

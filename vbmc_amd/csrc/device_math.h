@@ -296,6 +296,30 @@ __device__ __forceinline__ vb_d4 vb_exp_tab1k4(vb_d4 y, const double* __restrict
 }
 
 // 1/q for q > 0 finite: v_rcp_f64 seed + two Newton steps (<= 1 ulp), instead of the IEEE division sequence
+// log(x) = vb_log_pos(x, &e) + ln2 * e for a positive normal x: the classic reduction x = 2^k m, m in [sqrt(1/2), sqrt(2)), f = m - 1,
+// s = f / (2 + f), log(m) = f - (f^2/2 - s (f^2/2 + R(s^2))) with the degree-14 odd minimax R (< 1 ulp).  The coefficients are READ from
+// constant memory through a pointer the compiler cannot see through: the entropy kernel takes one logarithm per (wave, segment), and as
+// literals the library log's twelve polynomial constants were hoisted out of the segment loop and sat in VGPRs across every tile.
+static __constant__ double c_vb_log_coef[7] = {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01,
+                                        1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01};
+__device__ __forceinline__ double vb_log_pos(double x, int* e) {
+  const double* lc = c_vb_log_coef;
+  asm volatile("" : "+s"(lc));
+  int k = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  k -= lo ? 1 : 0;
+  *e += k;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, lc[5], lc[3]), lc[1]);
+  const double t2 = z * fma(w, fma(w, fma(w, lc[6], lc[4]), lc[2]), lc[0]);
+  const double hfsq = 0.5 * f * f;
+  return f - (hfsq - s * (hfsq + (t2 + t1)));
+}
+
 __device__ __forceinline__ double vb_rcp(double q) {
   double r = __builtin_amdgcn_rcp(q);
   double e = fma(-q, r, 1.0);

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "device_math.h"
 #include "elbo_types.h"
+#include "exp2_tab1k.h"
 #include "logjoint_body.h"
 
 // Sum over the workgroup (blockDim.x a multiple of 64; `red` holds at least one double per wave): a fixed-order butterfly
@@ -193,11 +194,16 @@ __global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const 
 // since delta = (mu' - x') / tau:  sum za delta_d = (mu'_d M0 - M1_d)/tau_d,  sum za delta_d^2 = (mu'_d^2 M0 -
 // 2 mu'_d M1_d + M2_d)/tau_d^2.  A workgroup = one (restart, hyper-sample); wave w owns the 16 components 16w + li.
 // Per k-step (4 training points) a lane evaluates ONE z (its component, point 4q + lg: the MFMA A operand) and the
-// 2D + 1 moment columns are NCT = ceil((2D+1)/16) MFMAs against the feature rows [1, x', x'^2] read from the
-// LDS-staged chunk of X.  The exponent itself stays on the VALU in the reference's (mu - x)/tau form (no
-// cancellation); centring keeps the moment recombination at ~1e-14 relative.
+// 2D + 1 moment columns are NCT = ceil((2D+1)/16) MFMAs against the feature rows [x', x'^2, 1] of the LDS-staged
+// chunk of X.  The exponent itself stays on the VALU as a sum of squares of (mu' - x')/tau (no cancellation);
+// centring keeps the moment recombination at ~1e-14 relative.
 // ------------------------------------------------------------------------------------------
 #define LJ_CH 64   // training points staged per chunk
+// dynamic LDS of the kernel: the staged feature rows, and -- in the same bytes, once the loop is over -- the moment exchange of its nw waves
+#define LJ_MFMA_NF(DT_) (16 * ((2 * (DT_) + 1 + 15) / 16))
+#define LJ_MFMA_NFP(DT_) ((LJ_MFMA_NF(DT_) % 32 == 16) ? LJ_MFMA_NF(DT_) : LJ_MFMA_NF(DT_) + 16)
+#define LJ_MFMA_DYN_LDS(DT_, nw_) (std::max<size_t>((size_t)LJ_CH * LJ_MFMA_NFP(DT_), (size_t)(nw_) * 16 * LJ_MFMA_NF(DT_)) * sizeof(double))
+#define LJ_MFMA_STATIC_LDS ((size_t)(VB_EXP_TAB1K_N + LJ_CH) * sizeof(double))
 template <int DT>
 __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const double* __restrict__ vpd,
                                                         const double* __restrict__ X,       // N x D col-major
@@ -208,69 +214,82 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
                                                         double* __restrict__ lj) {
   VB_SMALL_PRIO();
   constexpr int NCT = (2 * DT + 1 + 15) / 16;
-  __shared__ double TAB[VB_EXP_TAB_N];
-  __shared__ double XT[LJ_CH][DT];        // centred chunk of X, [n][d], zero beyond D / N
-  __shared__ double ALC[LJ_CH];
-  extern __shared__ double MOM[];         // nw x 16 x (16 NCT): moments per wave, [cell][column]
+  constexpr int NF = LJ_MFMA_NF(DT);      // feature columns of a staged point: [x'_1..x'_D, x'_1^2..x'_D^2, 1, 0..]  (x' first: 16-byte aligned reads)
+  constexpr int CH = LJ_CH;
+  __shared__ double TAB[VB_EXP_TAB1K_N];
+  // (round 6) the chunk is staged as the FEATURE rows the moment MFMAs multiply by: a lane's B operand is one ds_read_b64 at [point][16 t + li]
+  // (it was a three-way select on the column index per MFMA -- a v_cndmask_b32 costs four fp64 operations on this chip), and the exponent
+  // reads x' from the same row (columns 0..D-1)
+  // (row stride = 16 mod 32 doubles: the two rows a half-wave's ds_read_b64 touches -- points 4 q + lg, lg = 0, 1 or 2, 3 -- then lie in
+  // different halves of the banks, for the B operand's sixteen consecutive columns and for the exponent's broadcast reads alike; with
+  // NF = 32 the four rows sat on the same banks and the kernel was slower than the selects it replaced: 161 against 138 us)
+  constexpr int NFP = LJ_MFMA_NFP(DT);
+  extern __shared__ __attribute__((aligned(16))) double MOM[];         // CH x NFP feature rows; after the loop nw x 16 x NF: moments per wave, [cell][column]
+  double (*PHI)[NFP] = reinterpret_cast<double (*)[NFP]>(MOM);
+  __shared__ double ALC[CH];
   const int s = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int D = dm.D, K = dm.K, N = dm.N;
   const int kk = 16 * wv + li;
   const bool kvalid = kk < K;
   const int k = kvalid ? kk : K - 1;
-  for (int t = tid; t < VB_EXP_TAB_N; t += nthr) TAB[t] = c_exp2_tab[t];
+  for (int t = tid; t < VB_EXP_TAB1K_N; t += nthr) TAB[t] = c_exp2_tab1k[t];
+  for (int idx = tid; idx < CH * NFP; idx += nthr) { const int col = idx % NFP; PHI[idx / NFP][col] = col == 2 * D ? 1.0 : 0.0; }   // the constant column and the padding: once
   VpLayout L{D, K};
   const double* v = vpd + (size_t)r * L.stride();
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);
   const double sig = v[L.sigma() + k];
   const double wk = v[L.w() + k];
-  double mu[DT], itau[DT];
+  // The exponent as the table exp wants it, y = (ln nf - sum_d delta_d^2 / 2) 1024/ln2 = lnf' - sum_d (c_d - x'_d t_d)^2 with
+  // t_d = sqrt(512/ln2) / tau_d and c_d = mu'_d t_d: two operations per dimension where (mu' - x') / tau, squared and summed, took three, and
+  // no scaling of the argument.  (c_d carries one rounding of mu'_d t_d: an absolute error of 1e-16 |mu'_d| / tau_d in delta_d, i.e.
+  // 2e-16 |delta_d mu'_d| / tau_d in the exponent -- the reference's own (mu - x) / tau has the rounding of x - mean(x) against it.)
+  const double SQH = 27.17829760922398;      // sqrt(1024 / (2 ln 2))
+  double tt[DT], cc[DT];
   double sumlogtau = 0.0;
 #pragma unroll
   for (int d = 0; d < DT; ++d) {
+    double it = 0.0, m = 0.0;
     if (d < D) {
       const double lam_d = v[L.lambda() + d];
       const double tau = sqrt(sig * sig * lam_d * lam_d + g[d] + delta2[d]);  // :164
       sumlogtau += log(tau);
-      itau[d] = 1.0 / tau;
-      mu[d] = v[L.mu() + d + D * k] - meanX[d];
-    } else { itau[d] = 0.0; mu[d] = 0.0; }
+      it = 1.0 / tau;
+      m = v[L.mu() + d + D * k] - meanX[d];
+    }
+    tt[d] = SQH * it;
+    cc[d] = m * tt[d];
   }
   const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
+  const double lnf = kvalid ? VB_EXP_TAB1K_SCALE * lnnf : -1.0e300;     // (a padded row: exp -> 0, no select in the loop)
   typedef double lj4 __attribute__((ext_vector_type(4)));
   lj4 acc[NCT];
 #pragma unroll
   for (int t = 0; t < NCT; ++t) acc[t] = (lj4){0.0, 0.0, 0.0, 0.0};
   const double* al = alpha + (size_t)s * N;
-  for (int c0 = 0; c0 < N; c0 += LJ_CH) {
+  for (int c0 = 0; c0 < N; c0 += CH) {
     __syncthreads();
-    for (int idx = tid; idx < LJ_CH * DT; idx += nthr) {
-      const int nl = idx / DT, d = idx - nl * DT, n = c0 + nl;
-      XT[nl][d] = (d < D && n < N) ? X[n + (size_t)N * d] - meanX[d] : 0.0;
+    for (int idx = tid; idx < CH * DT; idx += nthr) {     // (consecutive threads take consecutive points of one dimension: coalesced)
+      const int d = idx / CH, nl = idx - d * CH, n = c0 + nl;
+      const double xv = (d < D && n < N) ? X[n + (size_t)N * d] - meanX[d] : 0.0;
+      if (d < D) { PHI[nl][d] = xv; PHI[nl][D + d] = xv * xv; }
     }
-    for (int nl = tid; nl < LJ_CH; nl += nthr) ALC[nl] = (c0 + nl < N) ? al[c0 + nl] : 0.0;
+    for (int nl = tid; nl < CH; nl += nthr) ALC[nl] = (c0 + nl < N) ? al[c0 + nl] : 0.0;
     __syncthreads();
 #pragma unroll 2
-    for (int q = 0; q < LJ_CH / 4; ++q) {
+    for (int q = 0; q < CH / 4; ++q) {
       const int nl = 4 * q + lg;
-      const double* xr = XT[nl];
+      const double* xr = &PHI[nl][0];
       double a2 = 0.0;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) { const double dl = (mu[d] - xr[d]) * itau[d]; a2 = fma(dl, dl, a2); }   // delta_k :167
-      const double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);                                                    // z_k :168
-      const double za = kvalid ? z * ALC[nl] : 0.0;       // alpha is zero beyond N
+      for (int d = 0; d < DT; ++d) { const double dl = fma(-xr[d], tt[d], cc[d]); a2 = fma(dl, dl, a2); }   // delta_k :167 (scaled)
+      const double z = vb_exp_tab1k(lnf - a2, TAB);                                                         // z_k :168
+      const double za = z * ALC[nl];       // alpha is zero beyond N
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) {
-        const int col = 16 * t + li;
-        double b;
-        if (col == 0) b = 1.0;
-        else if (col <= D) b = xr[col - 1];
-        else if (col <= 2 * D) { const double xv = xr[col - 1 - D]; b = xv * xv; }
-        else b = 0.0;
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, b, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, PHI[nl][16 * t + li], acc[t], 0, 0, 0);
     }
   }
+  __syncthreads();     // (every wave is done with the feature rows: the moments take their place)
   // moments -> LDS: accumulator (row = cell lg + 4 reg, column = 16 t + li)
   double* mw = MOM + (size_t)wv * 16 * (16 * NCT);
 #pragma unroll
@@ -280,7 +299,7 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
   __syncthreads();
   if (lg == 0 && kvalid) {
     const double* m = mw + li * (16 * NCT);
-    const double M0 = m[0];
+    const double M0 = m[2 * D];
     double* o = lj + (((size_t)r * dm.S + s) * K + k) * (2 * D + 2);
     double nu = 0.0, sl2 = 0.0, accS = 0.0;
 #pragma unroll
@@ -288,11 +307,12 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
       if (d < D) {
         const double xm = g[D + d], iom2 = g[2 * D + d];
         const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
-        const double M1 = m[1 + d], M2 = m[1 + D + d];
-        const double S1 = (mu[d] * M0 - M1) * itau[d];                                      // sum za delta_d
-        const double S2 = ((mu[d] * mu[d]) * M0 - 2.0 * mu[d] * M1 + M2) * (itau[d] * itau[d]);   // sum za delta_d^2
-        const double lit = lam_d * itau[d], sit = sig * itau[d];
-        const double accM = -itau[d] * S1;                       // dz_dmu*alpha      :207-208
+        const double M1 = m[d], M2 = m[D + d];
+        const double muc = mu_d - meanX[d], it = 1.0 / sqrt(sig * sig * lam_d * lam_d + g[d] + delta2[d]);   // (as above; not kept across the loop)
+        const double S1 = (muc * M0 - M1) * it;                                      // sum za delta_d
+        const double S2 = ((muc * muc) * M0 - 2.0 * muc * M1 + M2) * (it * it);      // sum za delta_d^2
+        const double lit = lam_d * it, sit = sig * it;
+        const double accM = -it * S1;                            // dz_dmu*alpha      :207-208
         const double accL = (sit * sit * lam_d) * (S2 - M0);     // dz_dlambda*alpha  :249-250
         accS = fma(lit * lit, S2 - M0, accS);                    // :228
         nu += iom2 * (mu_d * mu_d + sig * sig * lam_d * lam_d - 2.0 * mu_d * xm + xm * xm + delta2[d]);
@@ -597,8 +617,9 @@ __global__ void __launch_bounds__(256) k_entlb(ElboDims dm, const double* __rest
 // chunk count (which is large when few restarts must still fill the chip).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ent_reduce_body(int j, int r, int K, int C, int ncol, const double* __restrict__ part,
-                                                double* __restrict__ red) {
+                                                double* __restrict__ red, int walk_tpw, int walk_ntile) {
   const double* p = part + ((size_t)r * K + j) * C * ncol;
+  if (walk_tpw > 0) C = ent_walk_slots((long long)r * K + j, walk_ntile, walk_tpw);   // the walk: the slots this pair's waves filled, of its C
   double* o = red + ((size_t)r * K + j) * ncol;
   for (int col = threadIdx.x; col < ncol; col += blockDim.x) {
     double acc = 0.0;
@@ -625,9 +646,9 @@ __device__ __forceinline__ void ent_reduce_body(int j, int r, int K, int C, int 
 }
 
 __global__ void __launch_bounds__(256) k_ent_reduce(int C, int ncol, const double* __restrict__ part,
-                                                    double* __restrict__ red) {
+                                                    double* __restrict__ red, int walk_tpw, int walk_ntile) {
   VB_SMALL_PRIO();
-  ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red);
+  ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red, walk_tpw, walk_ntile);
 }
 
 // k_lj_reduce: sum the log-joint partials over hyper-samples in sample order, one thread per column:
@@ -666,9 +687,10 @@ __global__ void __launch_bounds__(64) k_lj_reduce(int S, int K, int LJS, const d
 
 // both reductions in one launch (blockIdx.z = 0: entropy chunks, 1: hyper-samples) when they sit on the same stream
 __global__ void __launch_bounds__(256) k_reduce_both(int C, int ncol, const double* __restrict__ part, double* __restrict__ red,
-                                                     int S, int LJS, const double* __restrict__ lj, double* __restrict__ ljbar) {
+                                                     int S, int LJS, const double* __restrict__ lj, double* __restrict__ ljbar,
+                                                     int walk_tpw, int walk_ntile) {
   VB_SMALL_PRIO();
-  if (blockIdx.z == 0) ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red);
+  if (blockIdx.z == 0) ent_reduce_body(blockIdx.x, blockIdx.y, gridDim.x, C, ncol, part, red, walk_tpw, walk_ntile);
   else lj_reduce_body(blockIdx.x, blockIdx.y, S, gridDim.x, LJS, lj, ljbar);
 }
 

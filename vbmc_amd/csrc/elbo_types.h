@@ -63,8 +63,18 @@ struct EntArgs {
                          // the batch is dealt over several devices (vbmc_elbo_batch_multi: r0 = g, rstride = G); 0, 1 otherwise
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
   int nc_launch;         // k_entropy_lane: chunk slots this launch covers (its items are (j, slot) pairs, four per workgroup)
+  int walk_tpw, walk_R;  // k_entropy_mfma, single-wave workgroups: > 0: the WALK -- grid (waves, 1, 1), wave w owns tiles [w tpw, (w + 1) tpw) of the
+                         // sequence of all walk_R x K (restart, component) pairs' tiles; C = record slots per pair (ent_walk_slots)
   LjCo lj;               // CO kernels only: the expected log joint as extra workgroups of this launch (lj.rows = 0: none)
 };
+
+// The walk's record slots (entropy_mfma.h): pair p holds tiles [p ntile, (p + 1) ntile) of the sequence, wave w owns [w tpw, (w + 1) tpw): the
+// pair's records come from waves first .. last, in that order, in slots 0 .. last - first of its C slots.
+__host__ __device__ inline int ent_walk_first(long long p, int ntile, int tpw) { return (int)((p * ntile) / tpw); }
+__host__ __device__ inline int ent_walk_slots(long long p, int ntile, int tpw) {
+  return (int)((p * ntile + ntile - 1) / tpw) - ent_walk_first(p, ntile, tpw) + 1;
+}
+__host__ __device__ inline int ent_walk_max_slots(int ntile, int tpw) { return (ntile - 1) / tpw + 2; }
 
 // The short kernels of a pass (copies, k_prep, the log joint, the reductions, the finalize kernel) ask for the highest issue priority: in
 // the pipelined step they share SIMDs with the other pass's entropy kernel, whose waves run at priorities 3 -> 0 (entropy_mfma.h), and

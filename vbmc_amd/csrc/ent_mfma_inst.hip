@@ -25,9 +25,13 @@ static int launch_kt(int mode, int grad, dim3 grid, hipStream_t st, const EntArg
     // the launch carries the log-joint role (gradient kernels, dense): the caller checked the shape
     if (ea.lj.rows > 0) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, true>;
   }
+  // the walking launch (entropy_mfma.h: WALK; elbo_plan decides): the device-RNG gradient kernels of single-wave workgroups, without the role
+  const bool walk = ea.walk_tpw > 0;
+  if (walk && !(HV == 1 && QS_VALUE <= 4 && KT <= 3 && grad && !fn && !ea.eps && !(ea.cutoff > 0.0))) return mode != 0 ? -1 : 1;
   // the device-RNG launch of a kernel that otherwise spends registers on the parity mode's prefetch (entropy_mfma.h: EM, EPF)
   if constexpr (HV == 1 && QS_VALUE <= 4 && KT <= 3) {
-    if (!fn && grad && !ea.eps && !(ea.cutoff > 0.0)) fn = (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, false>;
+    if (!fn && grad && !ea.eps && !(ea.cutoff > 0.0))
+      fn = walk ? (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, false, true> : (const void*)k_entropy_mfma<QS_VALUE, KT, true, false, 1, TL, false, false>;
   }
   if (!fn) {
     if (ea.cutoff > 0.0 && HV == 1 && !TL) {  // opt-in block-sparse variant (single-wave kernels only, no component tail)

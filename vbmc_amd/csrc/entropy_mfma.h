@@ -131,7 +131,7 @@ __device__ __forceinline__ void ent_sync_wg() {
 // EM (round 5): the instantiation reads its draws from memory (parity mode / eps_mode 2) -- it spends QS registers per lane on the tile
 // loaded one tile ahead (EPF below).  EM = false: the device-RNG launch of the same shape; those registers hold PV operands instead
 // (VBR).  Only the instantiations that prefetch exist twice (ent_mfma_inst.hip); everywhere else EM = true is the one kernel for both.
-template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, bool EM = true>
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, bool EM = true, bool WALK = false>
 // Waves per SIMD the register budget is set for: three (168 VGPRs) for the small kernels, two (256) from three k-tiles on.
 // Two k-tiles + a tail of ONE value per lane (K = 33..36) spills 14 VGPRs at 168 and is still 5-9 % faster than the spill-free
 // two-wave build; with TWO tail values per lane (K = 37..40: 24 spilled) the two-wave build wins by 2-4 % (round 3,
@@ -153,8 +153,13 @@ template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool C
    ((HV_) == 4 && (KT_) == 3 && (QS_) >= 9))
 #define VBMC_ENT_WAVES(KT_, QS_, TL_, HV_) \
   (VBMC_ENT_ONE_WAVE(KT_, QS_, TL_, HV_) ? 1 : ((((KT_) <= 2 && (QS_) <= 4) && !((KT_) == 2 && (TL_) == 2 && (HV_) == 1)) ? 3 : 2))
-__global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+// ent_mfma_segment: the work of one wave (workgroup) on ONE (component j, restart r): tiles [t0, t1) of the component's samples, partial
+// record into slot c.  The kernel below calls it once (the chunk grid) or once per segment of the wave's tile range (the walk, see there);
+// pdone / ptot: the tiles the wave had behind it when it entered the segment / has in all (the progress its issue priority follows).
+__device__ __forceinline__ void ent_mfma_segment(const EntArgs& a, const int c, const int j, const int r, const int t0, const int t1,
+                                                 const int pdone, const int ptot) {
   static_assert(!CO || (HV == 1 && QS <= 8 && !SPARSE), "the log-joint role exists for single-wave dense kernels at D <= 30");
+  static_assert(!WALK || (HV == 1 && !CO), "the walk exists for single-wave workgroups without the log-joint role");
   static_assert(KT <= 4 && (HV == 1 || HV == 2 || HV == 4 || HV == 8), "larger mixtures are split over the waves of a workgroup (HV = 2, 4; round 5: 8, K <= 512)");
   static_assert(TL == 0 || ((TL == 1 || TL == 2) && !SPARSE), "the component tail (one or two values per lane) exists for the dense kernels only");
   constexpr int TLN = TL > 0 ? TL : 1;     // tail values per lane: tail component 4u + lg, u < TL (the layout of a k-tile's register u)
@@ -192,10 +197,18 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
 #ifdef VBMC_INSTRUMENT
   const unsigned long long wckE = wall_clock64();
 #endif
-  const int tid = threadIdx.x, wv = tid >> 6, hv = HV == 1 ? 0 : wv, lane = tid & 63;
+  int tid_ = threadIdx.x;
+  // (the segment loop of the walk: nothing of a segment's set-up may be hoisted out of it and kept alive across the tile loops -- the exp table's
+  // sixteen values per lane, for one.  Every lane-dependent value of the set-up derives from this.)
+  if (WALK) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, wv = tid >> 6, hv = HV == 1 ? 0 : wv, lane = tid & 63;
   const int li = lane & 15, lg = lane >> 4;
-  const int c = (int)blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = blockIdx.z;
-  const int D = a.D, K = a.K;
+  // (the uniform side of the same: the dimensions and the three base pointers the set-up and the epilogue start from)
+  int D_ = a.D, K_ = a.K;
+  const double *entp_ = a.entp, *vpd_ = a.vpd;
+  double* part_ = a.part;
+  if (WALK) asm volatile("" : "+s"(D_), "+s"(K_), "+s"(entp_), "+s"(vpd_), "+s"(part_));
+  const int D = D_, K = K_;
   double* RQ = RQ_all[wv];
   double* NMS = NMS_all[wv];
   double* BND = BND_all[hv];
@@ -209,12 +222,6 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   // stage this restart's packed parameter block [k][m_1..m_D, h, cK, w, wi] in LDS with coalesced loads;
   // the per-lane operand fragments below are gathered from LDS, not from global memory
   extern __shared__ double PB[];
-  if (CO) {   // workgroup-uniform: the first a.lj.rows grid rows are the log-joint role (>= 8 KB of dynamic LDS: table + rows fit)
-    if ((int)blockIdx.y < a.lj.rows) {
-      lj_co_role<4 * QS>(a.lj, a.vpd, PB);
-      return;
-    }
-  }
   // The parameter block is needed only while the operand fragments are built; afterwards its LDS holds the exp table
   // 2^(j/1024) (8 KB) and, behind it, the PV exchange buffers of multi-wave workgroups [sign][wave][YXN] (the launcher sizes the
   // dynamic LDS for the larger of the two uses)
@@ -227,11 +234,11 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   double tt[NTB0];
 #pragma unroll
   for (int u = 0; u < NTB0; ++u) tt[u] = c_exp2_tab1k[min(tid + u * NTH0, VB_EXP_TAB1K_N - 1)];
-  const double sigj = a.vpd[(size_t)r * VpLayout{D, K}.stride() + VpLayout{D, K}.sigma() + j];
+  const double sigj = vpd_[(size_t)r * VpLayout{D, K}.stride() + VpLayout{D, K}.sigma() + j];
   {
     // eight loads in flight per lane: the plain copy loop waits for every load in turn, and with few tiles per wave (a
     // single chain) this setup is a quarter of the kernel
-    const double* gsrc = a.entp + (size_t)r * K * PSg;
+    const double* gsrc = entp_ + (size_t)r * K * PSg;
     constexpr int NT = WAVE * HV;
     const int n = K * PSg;
     int idx = tid;
@@ -406,8 +413,6 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
   const double sfm0 = lg == 0 ? 1.0 : 0.0, sfm1 = lg == 1 ? 1.0 : 0.0;   // sample-side operand of the even S-step product (EO)
   const int emask = (4 * (QS - 1) + lg < D) ? -1 : 0;   // this lane's slot of the last dim-block: a dimension (all ones) or padding (zero)
   const int emask2 = (QS >= 2 && 4 * (QS - 2) + lg < D) ? -1 : 0;   // ... and of the one before
-  const int t0 = (c + a.c0) * a.tiles_per_chunk;
-  const int t1 = min(t0 + a.tiles_per_chunk, ntile);
   const double* epsr = a.eps ? a.eps + (size_t)r * a.eps_stride_r + (size_t)j * a.Mh * D : nullptr;
   // Parity mode (draws from memory: ent/entmc_vbmc.m:53-55 with the caller's randn stream): the tile of draws is loaded ONE TILE AHEAD
   // into QS registers per lane (round 4) -- issued right after the current tile went to LDS, waited for at the next tile's start, a whole
@@ -460,6 +465,10 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
       // land in the padded dimensions and in the samples beyond Mh too; the padded dimensions are masked where they could matter
       // (ev below: one multiply; every other reader has zero coefficients beyond D or checks d < D), the samples beyond Mh by
       // svalid in the per-sample scalars (their densities are those of ordinary draws: finite)
+      // (the Philox key schedule -- fourteen uniform words -- is recomputed from the seed every tile, on the scalar unit beside the vector work:
+      // kept across the tile loop it is fourteen scalar registers this kernel does not have, i.e. v_readlane_b32 reloads on the vector pipe)
+      unsigned long long seed_t = a.seed;
+      if (WALK) asm volatile("" : "+s"(seed_t));
 #pragma unroll
       for (int q = lg; q < QS; q += 4) {
         double z4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -468,9 +477,9 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
         // D = 18, K = 80: +6 %, D = 24, K = 96: +11 %)
 #define VBMC_RNG_CALL_FOR(KT_, QS_, TL_, HV_) ((HV_) == 2 && (((KT_) == 2 && (TL_) == 2 && (QS_) == 5) || ((KT_) == 3 && (TL_) == 0 && (QS_) == 7)))
         if constexpr (!VBMC_RNG_CALL_FOR(KT, QS, TL, HV)) {
-        if (q < (D + 3) / 4) { const vb_d4 zz = vb_normal4i(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q); z4[0] = zz[0]; z4[1] = zz[1]; z4[2] = zz[2]; z4[3] = zz[3]; }
+        if (q < (D + 3) / 4) { const vb_d4 zz = vb_normal4i(seed_t, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q); z4[0] = zz[0]; z4[1] = zz[1]; z4[2] = zz[2]; z4[3] = zz[3]; }
         } else {
-        if (q < (D + 3) / 4) vb_normal4(a.seed, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q, z4);
+        if (q < (D + 3) / 4) vb_normal4(seed_t, (unsigned)(b0 + li), (unsigned)j, (unsigned)(a.r0 + r * a.rstride), (unsigned)q, z4);
         }
 #undef VBMC_RNG_CALL_FOR
         if (q < (D + 3) / 4) {     // (ETZ: an all-padding dim-block has been zero since the start of the wave)
@@ -885,8 +894,10 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
     // at D >= 20, K = 56..64 over the 112-shape sweep, against -3.2 % on average for the shapes of 8..64 components).
     constexpr bool PRIO = CO ? QS <= 4 : VBMC_ENT_WAVES(KT, QS, TL, HV) > 1;
     const bool pr = PRIO && a.prio != 0;
-    const int q1 = pr ? t0 + (t1 - t0 + 3) / 4 : -1, q2 = pr ? t0 + (t1 - t0 + 1) / 2 : -1, q3 = pr ? t0 + (3 * (t1 - t0) + 3) / 4 : -1;
-    if (pr) __builtin_amdgcn_s_setprio(3);
+    // (the quarter points of the WAVE's tiles, as tile indices of this segment: one that lies in an earlier segment was passed there, one at
+    // this segment's first tile fires there)
+    const int q1 = pr ? t0 + (ptot + 3) / 4 - pdone : -1, q2 = pr ? t0 + (ptot + 1) / 2 - pdone : -1, q3 = pr ? t0 + (3 * ptot + 3) / 4 - pdone : -1;
+    if (pr && pdone == 0) __builtin_amdgcn_s_setprio(3);
     for (int tile = t0; tile < tf; ++tile) {
       if (tile == q1) __builtin_amdgcn_s_setprio(2);
       if (tile == q2) __builtin_amdgcn_s_setprio(1);
@@ -902,11 +913,12 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
 #ifdef VBMC_INSTRUMENT
   const unsigned long long wck1 = wall_clock64();
 #endif
-  accH += log(pm) + 0.693147180559945309417 * (double)pe;
+  if (WALK) accH += vb_log_pos(pm, &pe) + 0.693147180559945309417 * (double)pe;     // (no literal constants: device_math.h)
+  else accH += log(pm) + 0.693147180559945309417 * (double)pe;
   if (lg != 0) accH = 0.0;   // the four lanes of a sample hold identical copies: count one
 
   // ---- fixed-order reductions and the partial record
-  double* o = a.part + (((size_t)r * K + j) * a.C + c) * a.ncol;
+  double* o = part_ + (((size_t)r * K + j) * a.C + c) * a.ncol;
   accH = wave_sum(accH);
   if (lane == 0 && hv == 0) o[0] = accH;
   if (GRAD) {
@@ -966,4 +978,49 @@ __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_W
 #undef VBV
 #undef SAV
 #undef ENT_CI
+}
+
+// The kernel.  Chunk grid (WALK = false): workgroup (c, j, r) takes chunk c of component j of restart r -- a.tiles_per_chunk tiles, record
+// slot c.  WALK = true (its own instantiations: gradient kernels of single-wave workgroups; grid (waves, 1, 1); a.walk_tpw tiles per wave): the tiles of all (restart, component) pairs form ONE sequence
+// (pair p = r K + j holds tiles [p ntile, (p + 1) ntile)), wave w owns [w tpw, (w + 1) tpw) of it and walks its pairs one segment after the
+// other; the record of a segment goes to slot (w - first wave of the pair) of the pair's a.C slots, which the reduction counts the same way
+// (ent_walk_slots).  With R K C >> wave slots the chunk grid hands every slot a new wave -- a new set-up (staging the parameter block, building
+// the operand fragments, the exp table: 8-11 us during which the SIMD's other wave issues alone, at 2/3 of the pair's rate) and an epilogue --
+// every chunk; the walk pays them once per (wave, pair): 2.6 instead of 11 per slot at the headline shape, and 4x fewer partial records.
+template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, bool EM = true, bool WALK = false>
+__global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+  if (CO) {   // workgroup-uniform: the first a.lj.rows grid rows are the log-joint role (>= 8 KB of dynamic LDS: table + rows fit)
+    if ((int)blockIdx.y < a.lj.rows) {
+      extern __shared__ double PB[];
+      lj_co_role<4 * QS>(a.lj, a.vpd, PB);
+      return;
+    }
+  }
+  const int ntile = (a.Mh + 15) >> 4;
+  // ONE call site for both forms (the body is ~5000 instructions): the chunk grid is a walk of one segment
+  constexpr bool walk = WALK;
+  int c = (int)blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = (int)blockIdx.z;
+  int tlo = ((int)blockIdx.x + a.c0) * a.tiles_per_chunk, thi = min(tlo + a.tiles_per_chunk, ntile), pdone = 0, rem = 0;
+  if (walk) {   // (the host keeps K R ntile below 2^31)
+    const int g = (int)blockIdx.x * a.walk_tpw;
+    rem = min(a.walk_tpw, a.K * a.walk_R * ntile - g);
+    const int p = g / ntile;
+    tlo = g - p * ntile;
+    r = p / a.K;
+    j = p - r * a.K;
+    c = (int)blockIdx.x - (g - tlo) / a.walk_tpw;     // = w - ent_walk_first(p): a pair that begins inside this wave's range has it as its first
+  }
+  const int ptot = walk ? rem : thi - tlo;
+  for (;;) {
+    if (walk) thi = min(ntile, tlo + rem);
+    ent_mfma_segment<QS, KT, GRAD, SPARSE, HV, TL, CO, EM, WALK>(a, c, j, r, tlo, thi, pdone, ptot);
+    if (!walk) break;
+    pdone += thi - tlo;
+    rem -= thi - tlo;
+    if (rem <= 0) break;
+    if (++j == a.K) { j = 0; ++r; }
+    tlo = 0;
+    c = 0;
+    __syncthreads();      // the next segment's parameter block overwrites the exp table
+  }
 }
