@@ -660,7 +660,7 @@ def main():
         legs = [
             ("gplite_post_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng), 5, warm=6)),
             ("gplite_post_resident_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, need_L=False, engine=eng), 5, warm=6)),
-            ("gplite_pred_8192_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.gplite_pred(gp, Xs, None, None, False, engine=eng), 3)),
+            ("gplite_pred_8192_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.gplite_pred(gp, Xs, None, None, False, engine=eng), 5, warm=3)),
             ("eval_fullelcbo_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta0, 0, vp, gp, 4096, 0, 1, nargout=11, engine=eng), 5)),
             ("diagvar_grad_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_vbmc(theta0, 1.0, vp, gp, 128, 1, 2, nargout=2, engine=eng), 5)),
             ("entlb_sieve_R250_ms", lambda: 1e3 * timeit(lambda: vbmc_amd.negelcbo_batch(np.tile(theta0[:, None], (1, 250)), 0, vp, gp, 0, False, 0, engine=eng), 5)),

@@ -290,7 +290,9 @@ typedef struct vbmc_elbo_args {
   int32_t plan_restarts;     /* 0: launch shapes follow THIS call's R.  P > 0: this call is a share of a batch of P restarts (dealt   */
                              /* over devices: restart_offset / restart_stride): the sample chunking, the log-joint kernel and its     */
                              /* splits are chosen as for a batch of P, so that every restart's results are BIT-IDENTICAL to the ones   */
-                             /* the undivided batch (R = P, plan_restarts 0 or P) computes -- the opt-in exact mode of                 */
+                             /* the undivided batch evaluated with plan_restarts = P computes (a blocking call with plan_restarts 0    */
+                             /* may take the walking entropy launch of wide batches: same draws, another order of summation over a      */
+                             /* component's partial records, 1e-13) -- the opt-in exact mode of                                         */
                              /* vbmc_elbo_batch_multi / vbmc_elbo_multi_submit, which pass the field through.  Costs throughput where   */
                              /* a share is much smaller than the batch (launch shapes of a full chip on an eighth of the work).        */
 } vbmc_elbo_args;

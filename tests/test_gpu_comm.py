@@ -171,7 +171,12 @@ def test_dealt_shares_at_a_shape_where_the_launches_differ(va):
     assert np.array_equal(np.argsort(F_all, kind="stable"), np.argsort(whole["F"], kind="stable"))
     assert worst > 0.0        # (the shape was chosen for this: here the two launches DO differ -- the exact mode below is not vacuous)
     # EXACT MODE (round 5, vbmc_elbo_args.plan_restarts = the undivided R): every share launches the undivided batch's shapes -- sample
-    # chunks, log-joint kernel and its splits -- so every column is bit-identical, for shares of 2, 3 and 8 ranks (64 % 3 != 0: a ragged deal)
+    # chunks, log-joint kernel and its splits -- so every column is bit-identical, for shares of 2, 3 and 8 ranks (64 % 3 != 0: a ragged deal).
+    # (Round 6: the undivided batch itself is evaluated under the same plan_restarts -- a blocking call without it may take the walking
+    # entropy launch, whose records are summed in another order: 1e-13, not the same bits.)
+    plain = whole
+    whole = va.negelcbo_batch(Th, 0, vp, gp, Ns, True, 0, seed=31, plan_restarts=Th.shape[1])
+    assert float(np.max(np.abs(whole["F"] - plain["F"]) / np.maximum(1.0, np.abs(plain["F"])))) < 1e-12
     for G2 in (8, 3, 2):
         for g in range(G2):
             cols = np.arange(Th.shape[1])[g::G2]

@@ -33,7 +33,9 @@ out["gplite_post_resident_ms"] = 1e3 * timeit(lambda: vbmc_amd.gplite_post(inp["
                                                                            need_L=False, engine=eng), 5, warm=6)
 gp = vbmc_amd.gplite_post(inp["hyp"], inp["X"], inp["y"], 1, 4, (1, 0, 0), None, engine=eng)
 Xs = 1.5 * np.random.default_rng(0).standard_normal((8192, D))
-out["gplite_pred_8192_ms"] = 1e3 * timeit(lambda: vbmc_amd.gplite_pred(gp, Xs, None, None, False, engine=eng), 3)
+# (three warm-up calls: the first two after a posterior that downloaded its factor grow the pools and touch the result pages -- 9-10 ms each,
+# profiles/r06_aux.md section 1; with one warm-up the mean of three read 3.8 ms)
+out["gplite_pred_8192_ms"] = 1e3 * timeit(lambda: vbmc_amd.gplite_pred(gp, Xs, None, None, False, engine=eng), 5, warm=3)
 vp = vbmc_amd.make_vp(inp["mu"], inp["sigma"], inp["lam"], eta=inp["eta"])
 vp["w"] = np.exp(inp["eta"]) / np.sum(np.exp(inp["eta"]))
 theta = np.concatenate([inp["mu"].reshape(-1, order="F"), np.log(inp["sigma"]), np.log(inp["lam"]), inp["eta"]])

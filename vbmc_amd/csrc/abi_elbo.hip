@@ -809,7 +809,7 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
       const char* walk_env = getenv("VBMC_ENT_WALK");
       const bool walk_off = walk_env && !strcmp(walk_env, "0");
       const long long total = (long long)K * R * ntile;
-      if (P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && P.kt <= 3 && a->eps_mode == 0 && compute_grad && !(P.cutoff > 0.0) && cw == 1 && chunk_world == 0 && !pipelined && P.Rp == R && !walk_off && !getenv("VBMC_ENT_CHUNKS") &&
+      if (P.use_mfma && (P.hv & 15) == 1 && P.qs <= 4 && P.kt <= 3 && a->eps_mode == 0 && compute_grad && !(P.cutoff > 0.0) && cw == 1 && chunk_world == 0 && !pipelined && a->plan_restarts == 0 && !walk_off && !getenv("VBMC_ENT_CHUNKS") &&
           kr * P.C >= 2 * slots && total < (1LL << 31) && !lj_co_shape(ctx, P)) {
         P.walk_tpw = (int)((total + slots - 1) / slots);
         P.walk_nw = (int)((total + P.walk_tpw - 1) / P.walk_tpw);
@@ -973,7 +973,8 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
   // set, and the VALU kernel's four waves per cell group are faster until the batch is several chips wide (BASELINE configs[1], K = 10,
   // S R = 512: 28.3 us against 19.9)
   const bool lj_wide = K > 16 || (long long)S * P.Rp >= 4LL * ctx->num_cu;
-  const bool lj_mfma = !co_shape && P.compute_grad && K <= 256 && (lj_force || ((long long)S * P.Rp >= ctx->num_cu && lj_wide)) && !(ljf && !strcmp(ljf, "valu"));
+  // (round 6: value-only passes too -- the sieve's 250 candidates -- through the kernel's GRAD = false form, once the batch is four chips wide)
+  const bool lj_mfma = !co_shape && (P.compute_grad || (long long)S * P.Rp >= 4LL * ctx->num_cu) && K <= 256 && (lj_force || ((long long)S * P.Rp >= ctx->num_cu && lj_wide)) && !(ljf && !strcmp(ljf, "valu"));
   // Small grids (a single chain, a handful of restarts): the VALU log joint runs as a ROLE of the entropy launch (single-wave
   // workgroups ahead of the entropy ones, entropy_mfma.h CO = true) -- two dependent-chain-bound kernels side by side instead of
   // one after the other, one launch less.  Its records are per (hyper-sample, split of the training set); the reduction over
@@ -998,8 +999,12 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
         const double* gc = gp->gpc + (size_t)s0 * GPC_STRIDE(D);
         if (ns <= 0) {
         } else if (lj_mfma && mom_lds + LJ_MFMA_STATIC_LDS <= 64 * 1024) {
-          hipLaunchKernelGGL((k_logjoint_mfma<DT>), dim3(ns, R), dim3(WAVE * nw), mom_lds, ls, dml, P.d_vpd,
-                             gp->X, gp->d_meanX, al, gc, P.d_delta2, lj_out);
+          if (P.compute_grad)
+            hipLaunchKernelGGL((k_logjoint_mfma<DT, true>), dim3(ns, R), dim3(WAVE * nw), mom_lds, ls, dml, P.d_vpd,
+                               gp->X, gp->d_meanX, al, gc, P.d_delta2, lj_out);
+          else
+            hipLaunchKernelGGL((k_logjoint_mfma<DT, false>), dim3(ns, R), dim3(WAVE * nw), mom_lds, ls, dml, P.d_vpd,
+                               gp->X, gp->d_meanX, al, gc, P.d_delta2, lj_out);
           LAUNCH_CHECK(ctx, "k_logjoint_mfma");
         } else {
           hipLaunchKernelGGL((k_logjoint<DT>), dim3((K + 3) / 4, ns, R), dim3(lj_split ? WAVE * LJ_MAXW : WAVE), 0, ls, dml, P.d_vpd, gp->X, al, gc,

@@ -204,7 +204,10 @@ __global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const 
 #define LJ_MFMA_NFP(DT_) ((LJ_MFMA_NF(DT_) % 32 == 16) ? LJ_MFMA_NF(DT_) : LJ_MFMA_NF(DT_) + 16)
 #define LJ_MFMA_DYN_LDS(DT_, nw_) (std::max<size_t>((size_t)LJ_CH * LJ_MFMA_NFP(DT_), (size_t)(nw_) * 16 * LJ_MFMA_NF(DT_)) * sizeof(double))
 #define LJ_MFMA_STATIC_LDS ((size_t)(VB_EXP_TAB1K_N + LJ_CH) * sizeof(double))
-template <int DT>
+// GRAD = false (round 6: the sieve's value-only passes, R = 250 candidates x S hyper-samples): the same walk without the moments -- the
+// lane sums its own z alpha over its points, the four point lanes of a component are added at the end; no MFMA, no feature columns
+// beyond x'.  (The VALU kernel's four-cells-per-wave form is built for latency: 575 us for that batch against ~180 here.)
+template <int DT, bool GRAD = true>
 __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const double* __restrict__ vpd,
                                                         const double* __restrict__ X,       // N x D col-major
                                                         const double* __restrict__ meanX,   // D column means of X
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
     for (int idx = tid; idx < CH * DT; idx += nthr) {     // (consecutive threads take consecutive points of one dimension: coalesced)
       const int d = idx / CH, nl = idx - d * CH, n = c0 + nl;
       const double xv = (d < D && n < N) ? X[n + (size_t)N * d] - meanX[d] : 0.0;
-      if (d < D) { PHI[nl][d] = xv; PHI[nl][D + d] = xv * xv; }
+      if (d < D) { PHI[nl][d] = xv; if (GRAD) PHI[nl][D + d] = xv * xv; }
     }
     for (int nl = tid; nl < CH; nl += nthr) ALC[nl] = (c0 + nl < N) ? al[c0 + nl] : 0.0;
     __syncthreads();
@@ -285,9 +288,28 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
       for (int d = 0; d < DT; ++d) { const double dl = fma(-xr[d], tt[d], cc[d]); a2 = fma(dl, dl, a2); }   // delta_k :167 (scaled)
       const double z = vb_exp_tab1k(lnf - a2, TAB);                                                         // z_k :168
       const double za = z * ALC[nl];       // alpha is zero beyond N
+      if (GRAD) {
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, PHI[nl][16 * t + li], acc[t], 0, 0, 0);
+        for (int t = 0; t < NCT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, PHI[nl][16 * t + li], acc[t], 0, 0, 0);
+      } else {
+        acc[0][0] += za;
+      }
     }
+  }
+  if (!GRAD) {      // I_k alone (:169-174): the component's four point lanes, in lane-group order
+    double M0 = acc[0][0];
+    M0 += __shfl_xor(M0, 16, 64);
+    M0 += __shfl_xor(M0, 32, 64);
+    if (lg == 0 && kvalid) {
+      double nu = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double xm = g[D + d], iom2 = g[2 * D + d];
+        const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
+        nu += iom2 * (mu_d * mu_d + sig * sig * lam_d * lam_d - 2.0 * mu_d * xm + xm * xm + delta2[d]);
+      }
+      lj[(((size_t)r * dm.S + s) * K + k) * (2 * D + 2)] = M0 + g[3 * D + 1] + (-0.5 * nu);
+    }
+    return;
   }
   __syncthreads();     // (every wave is done with the feature rows: the moments take their place)
   // moments -> LDS: accumulator (row = cell lg + 4 reg, column = 16 t + li)
