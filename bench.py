@@ -522,20 +522,26 @@ def main():
         expected log joint runs before it on the same stream).  In the timed region the kernel shares the chip with the other
         slot stream's small kernels and log joint, and in a blocking call with the log joint forked beside it: those durations
         overlap each other and do not price the kernel -- the blocking call's is reported next to it."""
-        ent_ms, lj_ms, beside = [], [], []
+        ent_ms, lj_ms, beside, walk_ms = [], [], [], []
+        # (round 6) the launch FORM of the timed region: the steps of a pipeline run the chunk grid; a blocking call of this width would take
+        # the walking launch (entropy_mfma.h: WALK) -- plan_restarts = R keeps the chunk grid (same shapes, same bits as the pipelined steps)
         eng.ctx.set_profiling(1)
         for i in range(10):
-            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=757 + i, engine=eng)
+            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=757 + i, engine=eng, plan_restarts=Rr)
             beside.append(eng.ctx.last_kernel_ms()[0])
         eng.ctx.set_profiling(2)
         for i in range(20):      # twenty launches: one disturbed launch in five moved the average by several per cent
-            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=777 + i, engine=eng)
+            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=777 + i, engine=eng, plan_restarts=Rr)
             a, b = eng.ctx.last_kernel_ms()
             ent_ms.append(a)
             lj_ms.append(b)
+        for i in range(10):      # ... and the walking launch of the blocking call, alone on the device likewise
+            vbmc_amd.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=797 + i, engine=eng)
+            walk_ms.append(eng.ctx.last_kernel_ms()[0])
         eng.ctx.set_profiling(False)
         extra["entropy_kernel_ms_beside_forked_logjoint"] = float(np.mean(beside))
         extra["entropy_kernel_ms_median_min_max"] = [float(np.median(ent_ms)), float(np.min(ent_ms)), float(np.max(ent_ms))]
+        extra["blocking_call_entropy_kernel_ms"] = float(np.mean(walk_ms))     # (the walking launch where the library chose it)
         ent_ms, lj_ms = float(np.mean(ent_ms)), float(np.mean(lj_ms))
         f_ent, f_lj, P = algorithmic_flops(D, K, M, S, N)
         achieved = Rr * f_ent / (ent_ms * 1e-3) / 1e12
@@ -551,6 +557,8 @@ def main():
             with open(os.path.join(pdir, pmc_files[-1])) as f:
                 pmc = json.load(f)
             traffic = pmc["hbm_bytes_per_launch"]
+            if "walk_hbm_bytes_per_launch" in pmc:
+                extra["blocking_call_entropy_kernel_traffic_bytes"] = pmc["walk_hbm_bytes_per_launch"]
             traffic_stale = pmc.get("kernel_source_sha256_16") != kernel_source_hash()
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; taken at commit %s)" % (pmc_files[-1], pmc.get("commit", "?"))
         extra["logjoint_kernel_ms"] = lj_ms

@@ -113,9 +113,8 @@ vbmc_status vbmc_gp_set_noise(vbmc_ctx* ctx, vbmc_gp* gp, const int32_t noisefun
  * Lchol S; *gp_out (optional) receives the device-resident posterior for vbmc_elbo_batch /
  * vbmc_gp_pred without a second upload: it takes over the device blocks the factorisation worked in (no copy of the S
  * N x N factors) and is ready when the call returns -- one upload, one synchronisation per call.
- * This call and vbmc_gp_nlz end with a polling wait on the context's stream (up to ~2 ms of hipStreamQuery before the
- * blocking wait: their callers issue the next evaluation at once); VBMC_SPIN_WAIT=0 in the environment makes it a plain
- * blocking wait.
+ * This call and vbmc_gp_nlz end with a polling wait on the context's stream (at most 300 us of hipStreamQuery before the
+ * blocking wait, none where the enqueued work is known to be large: their callers issue the next evaluation at once).
  */
 vbmc_status vbmc_gp_post(vbmc_ctx* ctx, int N, int D, int S, int Nhyp, int meanfun, const int32_t noisefun[3],
                          const double* X, const double* y, const double* s2, const double* hyp,

@@ -32,16 +32,21 @@ def grab(txt, kern, ctr):
     return float(re.search(r"- %s = ([0-9.e+]+)" % ctr, seg).group(1))
 
 
-kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1, false"   # the headline instantiation: QS 3, three k-tiles + component tail (round 4: one more template argument follows)
+kern = "`void k_entropy_mfma<3, 3, true, false, 1, 1, false, false, false>"   # the headline instantiation: QS 3, three k-tiles + component tail, device RNG, chunk grid
+kern_walk = "`void k_entropy_mfma<3, 3, true, false, 1, 1, false, false, true>"   # ... and its walking launch (round 6: blocking calls)
 fetch, write = grab(pa, kern, "FETCH_SIZE"), grab(pb, kern, "WRITE_SIZE")
 hbm = int(round(fetch * 1024 * 2 + write * 1024))
+walk = {}
+if kern_walk in pa and kern_walk in pb:
+    wf, ww = grab(pa, kern_walk, "FETCH_SIZE"), grab(pb, kern_walk, "WRITE_SIZE")
+    walk = {"walk_FETCH_SIZE_KB_per_launch": wf, "walk_WRITE_SIZE_KB_per_launch": ww, "walk_hbm_bytes_per_launch": int(round(wf * 1024 * 2 + ww * 1024))}
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 json.dump({"profile": "profiles/%s_%s_summary.md" % (RND, tag), "kernel": "k_entropy_mfma<3,3,true,false,1,1>", "commit": commit,
            "kernel_source_sha256_16": kernel_source_hash(),
            "workload": "python bench.py (R=64, C3, device RNG)", "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section); "
                          "WRITE_SIZE as reported (uncalibrated)",
-           "hbm_bytes_per_launch": hbm}, open("profiles/%s_pmc.json" % RND, "w"), indent=1)
+           "hbm_bytes_per_launch": hbm, **walk}, open("profiles/%s_pmc.json" % RND, "w"), indent=1)
 busy, act = grab(pa, kern, "SQ_VALU_MFMA_BUSY_CYCLES"), grab(pa, kern, "SQ_ACTIVE_INST_VALU")
 n_mfma, n_valu = grab(pa, kern, "SQ_INSTS_MFMA"), grab(pa, kern, "SQ_INSTS_VALU")
 TS = 64 * 50 * 313 * 2.0     # tile-signs per launch at the headline shape: R x K x ceil(5000 / 16) tiles x 2 signs
