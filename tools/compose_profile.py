@@ -92,7 +92,7 @@ test suite, `python bench.py --extras`, `tools/bench_aux.py`, `tools/microbench.
 `rocprofv3 --kernel-trace --stats` and two separate `--pmc` passes of
 `python bench.py [--steps 3 --warmup 1] --no-cpu-baseline --no-aux` (the timed region of the default command; the auxiliary legs and the CPU baseline run after it); assembled by `tools/compose_profile.py`.  {changes}
 In a blocking call `k_logjoint_mfma` runs on the context's second, lower-priority stream beside the entropy kernel: its traced duration there
-is the span over which its workgroups were fitted into the entropy kernel's idle slots (alone it takes 0.14 ms); in the pipelined steps it runs
+is the span over which its workgroups were fitted into the entropy kernel's idle slots (alone it takes 0.12 ms); in the pipelined steps it runs
 at the head of its pass on the slot stream, beside the other pass's entropy kernel.
 
 `pytest tests -m gpu`: **{rd('pytest_gpu.txt').splitlines()[-1]}**.
@@ -109,7 +109,7 @@ at the head of its pass on the slot stream, beside the other pass's entropy kern
 {last_json(rd('bench_traced.json'))}
 ```
 
-## Kernel trace (tools/rocpd_summary.py; 82 ELBO launches = 11 warm-up + 20 timed + 21 of the --sync-steps leg + 30 roofline-leg; k_chol / k_gp_* / k_alpha_solve = the one-off gplite_post that builds the synthetic GP posterior, outside the timed region)
+## Kernel trace (tools/rocpd_summary.py; 92 ELBO launches = 11 warm-up + 20 timed (chunk grid) + 21 of the --sync-steps leg (walking launches) + 30 roofline-leg (chunk grid) + 10 walking launches alone; k_chol / k_gp_* / k_alpha_solve = the one-off gplite_post that builds the synthetic GP posterior, outside the timed region)
 
 {rd('kernel_trace.md')}
 

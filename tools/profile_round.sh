@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 if [ "${ONLY_TRACE:-0}" = "1" ]; then
   rocprofv3 --kernel-trace --stats -d $out/t -o p -- python bench.py --no-cpu-baseline --no-aux > $out/bench_traced.json 2> $out/trace_stderr.txt
   python tools/rocpd_summary.py $(find $out/t -name '*.db' | head -1) > $out/kernel_trace.md
-  python tools/rocpd_launches.py $(find $out/t -name '*.db' | head -1) k_entropy_mfma "pipelined steps (8 + 3 warm-up, 20 timed):31" "blocking calls, log joint forked beside it (21 of the --sync-steps leg: walking launches; 10 of the roofline leg: chunk grid):31" "roofline leg, kernel alone, chunk grid as in the pipelined steps (the figure bench.py prices):20" "the blocking call's walking launch, kernel alone:10" > $out/kernel_phases.md
+  python tools/rocpd_launches.py $(find $out/t -name '*.db' | head -1) k_entropy_mfma "pipelined steps (8 + 3 warm-up, 20 timed):31" "blocking calls, log joint forked beside it (21 of the --sync-steps leg, walking launches; 10 of the roofline leg, chunk grid):31" "roofline leg, kernel alone, chunk grid as in the pipelined steps (the figure bench.py prices):20" "the blocking call's walking launch, kernel alone:10" > $out/kernel_phases.md
   rm -rf $out/t
   cat $out/kernel_phases.md
   exit 0
@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --stats -d $out/t -o p -- python bench.py --no-cpu-base
 python tools/rocpd_summary.py $(find $out/t -name '*.db' | head -1) > $out/kernel_trace.md
 # the dominant kernel's launches by phase of the command: 8 + 3 warm-up and 20 timed steps (pipelined: four batches in flight on two streams, the
 # kernels of consecutive batches overlap), then 21 + 10 blocking calls (log joint forked beside the kernel) and 20 with the kernel alone
-python tools/rocpd_launches.py $(find $out/t -name '*.db' | head -1) k_entropy_mfma "pipelined steps (8 + 3 warm-up, 20 timed):31" "blocking calls, log joint forked beside it (21 of the --sync-steps leg: walking launches; 10 of the roofline leg: chunk grid):31" "roofline leg, kernel alone, chunk grid as in the pipelined steps (the figure bench.py prices):20" "the blocking call's walking launch, kernel alone:10" > $out/kernel_phases.md
+python tools/rocpd_launches.py $(find $out/t -name '*.db' | head -1) k_entropy_mfma "pipelined steps (8 + 3 warm-up, 20 timed):31" "blocking calls, log joint forked beside it (21 of the --sync-steps leg, walking launches; 10 of the roofline leg, chunk grid):31" "roofline leg, kernel alone, chunk grid as in the pipelined steps (the figure bench.py prices):20" "the blocking call's walking launch, kernel alone:10" > $out/kernel_phases.md
 rm -rf $out/t
 rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $out/a -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aux > /dev/null 2> $out/pmc_a_stderr.txt
 python tools/pmc_summary.py $(find $out/a -name '*.db' | head -1) > $out/pmc_a.md
