@@ -96,6 +96,24 @@ def test_vpoptimize_improves_elbo(va):
     assert vp2["stats"]["I_sk"].shape == (2, 3) and vp2["stats"]["J_sjk"].shape == (2, 3, 3)
 
 
+def test_device_adam_wide_batch_on_the_walking_launch(va, monkeypatch):
+    """64 chains in lock-step at a sample count where each iteration's entropy pass is several rounds of waves: the on-device loop's passes
+    are blocking-style evaluations and take the walking launch (entropy_mfma.h: WALK).  Against the same loop on the chunk grid
+    (VBMC_ENT_WALK=0) the objective values agree to the order of summation over a component's partial records -- and are not the same bits,
+    i.e. the walk did run."""
+    p, gp, vp, theta = problem(35, 10, 60, 50, 2)
+    opts = dict(TolLength=1e-6, TolWeight=1e-2, TolConLoss=0.01, WeightPenalty=0.1)
+    vpb, tb = R.vpbounds(vp, gp, opts)
+    x0 = theta[:, None] + 0.03 * np.random.default_rng(4).standard_normal((theta.size, 64))
+    monkeypatch.delenv("VBMC_ENT_WALK", raising=False)
+    xw, fw, xtw, ftw, itw = va.fminadam_device(x0, 0, vpb, gp, 2000, tb, 1e-3, 6, seed=9)
+    monkeypatch.setenv("VBMC_ENT_WALK", "0")
+    xc, fc, xtc, ftc, itc = va.fminadam_device(x0, 0, vpb, gp, 2000, tb, 1e-3, 6, seed=9)
+    assert np.array_equal(itw, itc)
+    assert relerr(xw, xc) < 1e-9 and relerr(np.asarray(fw), np.asarray(fc)) < 1e-9
+    assert not np.array_equal(np.asarray(xw), np.asarray(xc))
+
+
 def test_device_adam_equals_host_adam(va):
     """vbmc_adam_batch (whole loop on the device) vs utils/fminadam.m's loop on the host calling the same
     device objective with the same per-iteration seeds: identical stopping iteration, iterates to round-off."""
