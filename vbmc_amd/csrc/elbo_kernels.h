@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(WAVE * LJ_MAXW) k_logjoint(ElboDims dm, const 
 // chunk of X.  The exponent itself stays on the VALU as a sum of squares of (mu' - x')/tau (no cancellation);
 // centring keeps the moment recombination at ~1e-14 relative.
 // ------------------------------------------------------------------------------------------
-#define LJ_CH 64   // training points staged per chunk
+#define LJ_CH 64   // training points staged per chunk (32: 113 against 116 us at the headline shape, twice the barriers for large N; profiles/r06_experiments.md)
 // dynamic LDS of the kernel: the staged feature rows, and -- in the same bytes, once the loop is over -- the moment exchange of its nw waves
 #define LJ_MFMA_NF(DT_) (16 * ((2 * (DT_) + 1 + 15) / 16))
 #define LJ_MFMA_NFP(DT_) ((LJ_MFMA_NF(DT_) % 32 == 16) ? LJ_MFMA_NF(DT_) : LJ_MFMA_NF(DT_) + 16)
