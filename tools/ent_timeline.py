@@ -85,6 +85,18 @@ def main():
     wpc = np.bincount(np.unique(cuk, return_inverse=True)[1])[np.unique(cuk, return_inverse=True)[1]]
     print("loop us by waves on the CU: " + "  ".join("%d: n=%d med %.0f" % (k, (wpc == k).sum(), np.median(dur[wpc == k])) for k in np.unique(wpc)))
     print("entry time us percentiles 1/50/99: " + " ".join("%.1f" % v for v in np.percentile(ent, [1, 50, 99]) / 100.0))
+    print("entry time us percentiles 60/70/80/90/95/98: " + " ".join("%.1f" % v for v in np.percentile(ent, [60, 70, 80, 90, 95, 98]) / 100.0))
+    late = ent > 200        # entered more than 2 us after the first wave
+    if late.any():
+        # is a late wave the successor of an earlier one in the same wave slot (it waited for registers / LDS), or did a free slot wait for it?
+        first_exit = {}
+        for k_, e_ in zip(slot, ex):
+            first_exit[k_] = min(first_exit.get(k_, 1 << 60), e_)
+        wait_for_slot = np.array([first_exit[k_] <= t_ for k_, t_ in zip(slot[late], ent[late])])
+        print("late waves (> 2 us): %d; of them %d entered a wave slot an earlier wave of this launch had left" % (late.sum(), wait_for_slot.sum()))
+        cuk_ = simdk >> 2
+        nres = np.array([np.sum((cuk_ == c_) & (ent <= t_) & (ex > t_)) for c_, t_ in zip(cuk_[late], ent[late])])
+        print("waves resident on the late wave's compute unit at its entry (incl. itself): min %d median %d max %d" % (nres.min(), np.median(nres), nres.max()))
     tiles = (Ns // 2 + 15) // 16
     print("tile-signs per wave-loop: ~%.1f; loop ticks(10ns)/tile-sign median %.2f" % (2.0 * tiles * K * R / len(a), np.median(le - ls) / (2.0 * tiles * K * R / len(a))))
 

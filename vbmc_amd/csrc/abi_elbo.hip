@@ -557,6 +557,7 @@ struct ElboPlan {
   int no_jacobian = 0;
   int Rp = 0;                // the restarts the launch shapes are chosen for: R, or the undivided batch's (vbmc_elbo_args.plan_restarts)
   int walk_tpw = 0, walk_nw = 0;   // > 0: the matrix-core entropy kernel WALKS (entropy_mfma.h): tiles per wave, waves of the launch
+  int co_c1 = 0, co_c2 = 0, co_tpc2 = 0;   // co_c2 > 0: two chunk classes (EntArgs: the role's workgroups take the second, shorter one)
   double* d_dvs = nullptr;   // per-hyper-sample variance gradient block (dvarG_s), pooled for the call
   bool lj_records = false;   // the caller reads per-hyper-sample log-joint records (separate_K, G_s / varG_s, the variance kernels)
   int r0 = 0, rstride = 1;   // device-RNG key of restart r: r0 + r * rstride (vbmc_elbo_args.restart_offset / restart_stride)
@@ -570,6 +571,21 @@ struct ElboPlan {
   long long eps_stride_r = 0;
   double TolCon = 0.0, WeightThreshold = 0.0, WeightPenalty = 0.0, cutoff = 0.0;
 };
+
+// Splits of the training set per cell group of the log-joint role: per-workgroup set-up (exp table, tau / log tau) against the length of the
+// dependent loop over the training set.  Single chain at the headline shape (260 cell groups, 25 slabs of 16 points), us per Adam
+// iteration: 1 split 46.6, 2: 41.1, 3: 41.2, 4: 43.0, 6: 45.4, 8: 52.2 (more workgroups than wave slots) -> about 640 role workgroups per restart
+static int lj_co_nsplit(const vbmc_ctx* ctx, const ElboPlan& P) {
+  const int K = P.dm.K, S = P.dm.S, R = P.dm.R;
+  const long long cells = (long long)((K + 3) / 4) * S;   // per restart: a restart's bits do not depend on the batch it is in
+  const int slabs = (P.dm.N + 15) / 16;
+  int ns = (int)std::max<long long>(1, std::min<long long>(std::min(LJ_CO_SPLIT, slabs), (640 + cells / 2) / cells));
+  // (round 5) a BATCH wide enough that the record buffer holds one record per hyper-sample (elbo_plan: ljrec): one role workgroup per
+  // cell group -- the restarts supply the parallelism the splits supply to a single chain
+  if ((long long)S * std::min(R, P.Rp) >= ctx->num_cu / 2) ns = 1;
+  if (P.use_lane) ns = 1;      // (the lane kernel's role walks the LDS-staged training set whole)
+  return ns;
+}
 
 // Does the expected log joint run as a role of the MFMA entropy launch (entropy_mfma.h CO = true; see elbo_enqueue)?  The part of the
 // answer that elbo_plan needs too (the chunk model asks for the occupancy of the kernel that will run).
@@ -798,6 +814,27 @@ static vbmc_status elbo_plan(vbmc_ctx* ctx, const vbmc_gp* gp, const vbmc_elbo_a
       if (getenv("VBMC_DEBUG_OCC")) fprintf(stderr, "chunks: D %d K %d R %d qs %d kt %d hv %d waves/CU %d slots %lld kr %lld ntile %d -> C %d\n", D, K, R, P.qs, P.kt, P.hv, waves_per_cu, slots, kr, ntile, bestC);
       P.tpc = (ntile + bestC - 1) / bestC;
       P.C = (ntile + P.tpc - 1) / P.tpc;
+      // Two chunk classes where the launch carries the log-joint role (one or two restarts at Ns = 1e4: ~2000 entropy waves + 500-1000 role
+      // waves on 2048 slots -- the role's waves went first and a quarter of the entropy waves entered a role late): the role's workgroups go
+      // on to a chunk of the entropy that is a role's length (~4 tiles: 18 us) shorter, every wave of the launch is resident from the
+      // start and all leave together.  Not where the chunking must be another launch's (sharded, plan_restarts) or is forced.
+      if (P.use_mfma && (P.hv & 15) == 1 && cw == 1 && chunk_world == 0 && a->plan_restarts == 0 && !getenv("VBMC_ENT_CHUNKS") && compute_grad &&
+          lj_co_shape(ctx, P)) {
+        const int role_per_r = ((K + 3) / 4) * S * lj_co_nsplit(ctx, P);
+        const long long waves0 = slots - (long long)role_per_r * R;
+        const int TROLE = 4;                                   // a role in tiles (role + its later set-up against 4.5 us per tile of a wave that shares its SIMD)
+        const int c1 = (int)(waves0 / ((long long)K * R)), c2max = role_per_r / K;
+        if (c1 >= 1 && c2max >= 1 && ntile > TROLE * c1 + c1 + c2max) {
+          const int tpc2 = (ntile - TROLE * c1 + c1 + c2max - 1) / (c1 + c2max);
+          const int tpc1 = (ntile - c2max * tpc2 + c1 - 1) / c1;
+          const int rest = ntile - c1 * tpc1;
+          if (tpc2 >= 1 && tpc1 > tpc2 && rest > 0) {
+            P.co_c1 = c1; P.co_tpc2 = tpc2; P.co_c2 = (rest + tpc2 - 1) / tpc2;
+            P.tpc = tpc1; P.C = P.co_c1 + P.co_c2;
+            if (getenv("VBMC_DEBUG_OCC")) fprintf(stderr, "two chunk classes: %d x %d tiles + %d x %d tiles (role workgroups per restart %d)\n", c1, tpc1, P.co_c2, tpc2, role_per_r);
+          }
+        }
+      }
       // The walk (entropy_mfma.h): once the chunk grid would hand every wave slot two or more waves, ONE wave per slot walks its share of
       // all the (restart, component) pairs' tiles instead -- a set-up per (wave, pair) instead of per chunk.  The device-RNG gradient kernels of
       // single-wave workgroups at D <= 14, K <= 56 (the instantiations that take the loop without spilling); not where
@@ -1047,29 +1084,22 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
     ea.D = D; ea.K = K; ea.Mh = P.Mh; ea.C = sh.mode == 1 ? perC : P.C; ea.c0 = c0; ea.tiles_per_chunk = P.tpc; ea.ncol = P.ncol; ea.seed = seed;
     ea.eps = P.d_eps; ea.eps_stride_r = P.eps_stride_r; ea.cutoff = P.cutoff; ea.r0 = P.r0; ea.rstride = P.rstride;
     ea.prio = 1;   // progress-ordered wave priorities (entropy_mfma.h)
+    ea.co_c1 = P.co_c1; ea.co_c2 = P.co_c2; ea.co_tpc2 = P.co_tpc2;
     const bool walk = P.walk_tpw > 0;
     if (walk && (sh.mode != 0 || co)) return set_err(ctx, VBMC_ERR_INVALID, "internal: the walking entropy launch was planned for a sharded / role-carrying pass");
     if (walk) { ea.walk_tpw = P.walk_tpw; ea.walk_R = R; }
     int co_rows = 0;
     if (co) {
       LjCo& lc = ea.lj;
-      // splits of the training set per cell group: per-workgroup set-up (exp table, tau / log tau) against the length of the dependent
-      // loop over the training set.  Single chain at the headline shape (260 cell groups, 25 slabs of 16 points), us per Adam
-      // iteration: 1 split 46.6, 2: 41.1, 3: 41.2, 4: 43.0, 6: 45.4, 8: 52.2 (more workgroups than wave slots) -> about 640 role workgroups per restart
-      {
-        const long long cells = (long long)((K + 3) / 4) * S;   // per restart: a restart's bits do not depend on the batch it is in
-        const int slabs = (dm.N + 15) / 16;
-        lc.nsplit = (int)std::max<long long>(1, std::min<long long>(std::min(LJ_CO_SPLIT, slabs), (640 + cells / 2) / cells));
-        // (round 5) a BATCH wide enough that the record buffer holds one record per hyper-sample (elbo_plan: ljrec): one role workgroup per
-        // cell group -- the restarts supply the parallelism the splits supply to a single chain
-        if ((long long)S * std::min(R, P.Rp) >= ctx->num_cu / 2) lc.nsplit = 1;
-        if (P.use_lane) lc.nsplit = 1;      // (the lane kernel's role walks the LDS-staged training set whole)
-      }
+      lc.nsplit = lj_co_nsplit(ctx, P);
       lc.nwg = ((K + 3) / 4) * S * lc.nsplit;
       if (P.use_lane) {      // the role is dealt over the entropy waves themselves (entropy_lane.h): no rows of its own
         lc.rows = co_rows = 0;
-      } else
-      lc.rows = co_rows = (lc.nwg + nc - 1) / nc;
+      } else {
+        // (two chunk classes: the grid's x extent is the first class, the role's workgroups -- and as many more as the second class needs -- follow in rows)
+        const int gx = P.co_c2 > 0 ? P.co_c1 : nc;
+        lc.rows = co_rows = (std::max(lc.nwg, P.co_c2 > 0 ? K * P.co_c2 : 0) + gx - 1) / gx;
+      }
       lc.want_grad = P.compute_grad;
       lc.dm = dm; lc.X = gp->X; lc.alpha = gp->alpha; lc.gpc = gp->gpc; lc.delta2 = P.d_delta2; lc.lj = P.d_lj;
     }
@@ -1084,7 +1114,7 @@ static vbmc_status elbo_enqueue(vbmc_ctx* ctx, const vbmc_gp* gp, const ElboPlan
       bool ok = launch_entropy_lane(D, K, P.compute_grad != 0, dim3(gx, 1 + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no lane entropy kernel for D = %d, K = %d", D, K);
     } else if (P.use_mfma) {
-      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, walk ? dim3(P.walk_nw, 1, 1) : dim3(nc, K + co_rows, R), st, ea);
+      bool ok = launch_entropy_mfma(P.qs, P.kt, P.hv, P.compute_grad != 0, walk ? dim3(P.walk_nw, 1, 1) : dim3((co && P.co_c2 > 0) ? P.co_c1 : nc, K + co_rows, R), st, ea);
       if (!ok) return set_err(ctx, VBMC_ERR_UNSUPPORTED, "no MFMA entropy kernel for D = %d", D);
     } else {
       const size_t lds = P.ent_lds;

@@ -63,6 +63,9 @@ struct EntArgs {
                          // the batch is dealt over several devices (vbmc_elbo_batch_multi: r0 = g, rstride = G); 0, 1 otherwise
   double cutoff;         // > 0: skip k-tiles whose terms are provably < exp(-cutoff) relative to q (block-sparse mode)
   int nc_launch;         // k_entropy_lane: chunk slots this launch covers (its items are (j, slot) pairs, four per workgroup)
+  int co_c1, co_c2, co_tpc2;   // k_entropy_mfma: TWO chunk classes per (component, restart) -- slots 0 .. co_c1 - 1 hold tiles_per_chunk tiles each, slots
+                         // co_c1 .. co_c1 + co_c2 - 1 co_tpc2 (fewer) tiles each; in a launch that carries the log-joint role the role's workgroups
+                         // take the second class AFTER their role (they enter the tile loop a role later and leave it with the others).  co_c2 = 0: one class
   int walk_tpw, walk_R;  // k_entropy_mfma, single-wave workgroups: > 0: the WALK -- grid (waves, 1, 1), wave w owns tiles [w tpw, (w + 1) tpw) of the
                          // sequence of all walk_R x K (restart, component) pairs' tiles; C = record slots per pair (ent_walk_slots)
   LjCo lj;               // CO kernels only: the expected log joint as extra workgroups of this launch (lj.rows = 0: none)

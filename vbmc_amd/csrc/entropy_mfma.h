@@ -989,18 +989,32 @@ __device__ __forceinline__ void ent_mfma_segment(const EntArgs& a, const int c, 
 // every chunk; the walk pays them once per (wave, pair): 2.6 instead of 11 per slot at the headline shape, and 4x fewer partial records.
 template <int QS, int KT, bool GRAD, bool SPARSE, int HV = 1, int TL = 0, bool CO = false, bool EM = true, bool WALK = false>
 __global__ void __launch_bounds__(WAVE * HV, CO ? (QS <= 4 ? 2 : 1) : VBMC_ENT_WAVES(KT, QS, TL, HV)) k_entropy_mfma(EntArgs a) {
+  const int ntile = (a.Mh + 15) >> 4;
+  // ONE call site for all forms (the body is ~5000 instructions): the chunk grid is a walk of one segment
+  constexpr bool walk = WALK;
+  int c = (int)blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = (int)blockIdx.z;
+  int tlo = ((int)blockIdx.x + a.c0) * a.tiles_per_chunk, thi = min(tlo + a.tiles_per_chunk, ntile), pdone = 0, rem = 0;
+  if (!WALK && a.co_c2 > 0 && c >= a.co_c1) {      // a chunk of the second class (launched without the role: the grid spans both classes)
+    tlo = a.co_c1 * a.tiles_per_chunk + (c - a.co_c1) * a.co_tpc2;
+    thi = min(tlo + a.co_tpc2, ntile);
+  }
   if (CO) {   // workgroup-uniform: the first a.lj.rows grid rows are the log-joint role (>= 8 KB of dynamic LDS: table + rows fit)
     if ((int)blockIdx.y < a.lj.rows) {
       extern __shared__ double PB[];
       lj_co_role<4 * QS>(a.lj, a.vpd, PB);
-      return;
+      // Round 6: ... and then a SHORT chunk of the entropy.  A launch of one or two restarts at Ns = 1e4 is ~2000 entropy waves plus 500-1000 role
+      // waves on 2048 wave slots: the role waves went first and a quarter of the entropy waves entered 18 us late, on a 45 us life
+      // (tools/ent_timeline.py: 1525 = 6 per compute unit at once, the rest when the role was over).  Now every wave of the launch is
+      // resident from the start: the role's workgroups carry the second chunk class (co_tpc2 tiles: a role's length fewer), all leave together.
+      const int e = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+      if (a.co_c2 <= 0 || e >= a.K * a.co_c2) return;
+      j = e / a.co_c2;
+      c = a.co_c1 + (e - j * a.co_c2);
+      tlo = a.co_c1 * a.tiles_per_chunk + (c - a.co_c1) * a.co_tpc2;
+      thi = min(tlo + a.co_tpc2, ntile);
+      __syncthreads();      // the role's table and rows: the entropy set-up overwrites them
     }
   }
-  const int ntile = (a.Mh + 15) >> 4;
-  // ONE call site for both forms (the body is ~5000 instructions): the chunk grid is a walk of one segment
-  constexpr bool walk = WALK;
-  int c = (int)blockIdx.x, j = CO ? (int)blockIdx.y - a.lj.rows : (int)blockIdx.y, r = (int)blockIdx.z;
-  int tlo = ((int)blockIdx.x + a.c0) * a.tiles_per_chunk, thi = min(tlo + a.tiles_per_chunk, ntile), pdone = 0, rem = 0;
   if (walk) {   // (the host keeps K R ntile below 2^31)
     const int g = (int)blockIdx.x * a.walk_tpw;
     rem = min(a.walk_tpw, a.K * a.walk_R * ntile - g);
