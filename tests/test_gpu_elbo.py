@@ -222,6 +222,25 @@ def test_walking_entropy_launch_equals_the_chunk_grid(va, D, K, Ns, R_, monkeypa
     assert np.array_equal(w1["G"], c["G"])      # the log joint is untouched
 
 
+@pytest.mark.parametrize("R_,Ns", [(1, 10000), (2, 10000), (1, 3000)])
+def test_two_chunk_classes_where_the_launch_carries_the_role(va, R_, Ns, monkeypatch):
+    """One or two restarts at a large sample count: the entropy launch carries the log-joint role, and the role's workgroups go on to a
+    shorter chunk of the entropy (two chunk classes per component, EntArgs::co_c1 / co_c2 / co_tpc2).  Against the one-class chunk grid
+    (VBMC_ENT_CHUNKS forces a uniform chunking) only the order of summation over a component's partial records differs."""
+    p, gp, vp, theta = problem(61, 10, 80, 50, 20)
+    thetas = theta[:, None] + 0.05 * np.random.default_rng(R_).standard_normal((theta.size, R_))
+    monkeypatch.delenv("VBMC_ENT_CHUNKS", raising=False)
+    a = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=5)
+    a2 = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=5)
+    assert np.array_equal(a["F"], a2["F"]) and np.array_equal(a["dF"], a2["dF"])
+    monkeypatch.setenv("VBMC_ENT_CHUNKS", "12")
+    b = va.negelcbo_batch(thetas, 0, vp, gp, Ns, True, 0, seed=5)
+    assert relerr(a["H"], b["H"]) < 1e-13 and relerr(a["G"], b["G"]) < 1e-13
+    for r in range(R_):
+        assert relerr(a["dH"][:, r], b["dH"][:, r]) < 1e-12 and relerr(a["dG"][:, r], b["dG"][:, r]) < 1e-12
+    assert not np.array_equal(a["dH"], b["dH"])
+
+
 def test_device_rng_stream_is_reproducible_and_standard_normal(va):
     """eps_mode 0: the Philox stream the kernel consumes can be dumped and fed to the oracle."""
     p, gp, vp, theta = problem(6, 5, 40, 4, 2)
