@@ -237,7 +237,6 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
   const bool kvalid = kk < K;
   const int k = kvalid ? kk : K - 1;
   for (int t = tid; t < VB_EXP_TAB1K_N; t += nthr) TAB[t] = c_exp2_tab1k[t];
-  for (int idx = tid; idx < CH * NFP; idx += nthr) { const int col = idx % NFP; PHI[idx / NFP][col] = col == 2 * D ? 1.0 : 0.0; }   // the constant column and the padding: once
   VpLayout L{D, K};
   const double* v = vpd + (size_t)r * L.stride();
   const double* g = gpc + (size_t)s * GPC_STRIDE(D);
@@ -250,19 +249,34 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
   const double SQH = 27.17829760922398;      // sqrt(1024 / (2 ln 2))
   double tt[DT], cc[DT];
   double sumlogtau = 0.0;
+  // (the four point lanes of a component share this set-up: lane group lg takes the dimensions d = lg, lg + 4, .. -- a square root, a
+  // logarithm and a division each, ~120 instructions -- and hands t_d, c_d to the other three through the LDS the feature rows will
+  // occupy; all ten dimensions on every lane were a third of the kernel's VALU instructions)
+  {
+    double* ex = MOM + (size_t)(wv * 16 + li) * NF;      // [t_0..t_DT-1 | c_0..c_DT-1] of this component (2 DT <= NF)
 #pragma unroll
-  for (int d = 0; d < DT; ++d) {
-    double it = 0.0, m = 0.0;
-    if (d < D) {
-      const double lam_d = v[L.lambda() + d];
-      const double tau = sqrt(sig * sig * lam_d * lam_d + g[d] + delta2[d]);  // :164
-      sumlogtau += log(tau);
-      it = 1.0 / tau;
-      m = v[L.mu() + d + D * k] - meanX[d];
+    for (int u = 0; u < (DT + 3) / 4; ++u) {
+      const int d = 4 * u + lg;
+      double it = 0.0, m = 0.0;
+      if (d < D) {
+        const double lam_d = v[L.lambda() + d];
+        const double tau = sqrt(sig * sig * lam_d * lam_d + g[d] + delta2[d]);  // :164
+        sumlogtau += log(tau);
+        it = 1.0 / tau;
+        m = v[L.mu() + d + D * k] - meanX[d];
+      }
+      if (d < DT) { ex[d] = SQH * it; ex[DT + d] = m * (SQH * it); }
     }
-    tt[d] = SQH * it;
-    cc[d] = m * tt[d];
+    sumlogtau += __shfl_xor(sumlogtau, 16, 64);
+    sumlogtau += __shfl_xor(sumlogtau, 32, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { tt[d] = ex[d]; cc[d] = ex[DT + d]; }
   }
+  __syncthreads();       // (the feature rows' initialisation follows in the same bytes)
+  for (int idx = tid; idx < CH * NFP; idx += nthr) { const int col = idx % NFP; PHI[idx / NFP][col] = col == 2 * D ? 1.0 : 0.0; }   // the constant column and the padding: once
   const double lnnf = g[3 * D] - sumlogtau;  // ln_sf2 + sum_lnell - sum(log(tau_k))  :165
   const double lnf = kvalid ? VB_EXP_TAB1K_SCALE * lnnf : -1.0e300;     // (a padded row: exp -> 0, no select in the loop)
   typedef double lj4 __attribute__((ext_vector_type(4)));
@@ -272,8 +286,10 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
   const double* al = alpha + (size_t)s * N;
   for (int c0 = 0; c0 < N; c0 += CH) {
     __syncthreads();
-    for (int idx = tid; idx < CH * DT; idx += nthr) {     // (consecutive threads take consecutive points of one dimension: coalesced)
-      const int d = idx / CH, nl = idx - d * CH, n = c0 + nl;
+    // (consecutive threads take consecutive dimensions of one point: consecutive LDS words.  Consecutive POINTS of one dimension -- the
+    // coalesced order for X -- are 384 B apart in the rows: two banks for a wave's store, 1.4e7 conflict cycles per launch; X is 32 KB in the L2)
+    for (int idx = tid; idx < CH * DT; idx += nthr) {
+      const int nl = idx / DT, d = idx - nl * DT, n = c0 + nl;
       const double xv = (d < D && n < N) ? X[n + (size_t)N * d] - meanX[d] : 0.0;
       if (d < D) { PHI[nl][d] = xv; if (GRAD) PHI[nl][D + d] = xv * xv; }
     }
@@ -330,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_logjoint_mfma(ElboDims dm, const doubl
         const double xm = g[D + d], iom2 = g[2 * D + d];
         const double lam_d = v[L.lambda() + d], mu_d = v[L.mu() + d + D * k];
         const double M1 = m[d], M2 = m[D + d];
-        const double muc = mu_d - meanX[d], it = 1.0 / sqrt(sig * sig * lam_d * lam_d + g[d] + delta2[d]);   // (as above; not kept across the loop)
+        const double muc = mu_d - meanX[d], it = tt[d] * (1.0 / SQH);      // 1 / tau_d back from t_d (one rounding: the moments carry 1e-14 already)
         const double S1 = (muc * M0 - M1) * it;                                      // sum za delta_d
         const double S2 = ((muc * muc) * M0 - 2.0 * muc * M1 + M2) * (it * it);      // sum za delta_d^2
         const double lit = lam_d * it, sit = sig * it;
