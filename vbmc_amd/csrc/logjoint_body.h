@@ -68,38 +68,32 @@ __device__ __forceinline__ void lj_wave_sums(const ElboDims& dm, const double* _
   double accA[DT], accQ[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d) { accA[d] = 0.0; accQ[d] = 0.0; }
-  // the loads of the next slab are issued before the arithmetic of the current one (a single chain is bound by this
-  // kernel's memory latency, not its flops)
+  // Slabs are loaded TWO ahead of their arithmetic (a single chain is bound by this kernel's memory latency, not its flops: a slab's ~100
+  // instructions of one wave are shorter than a load's round trip).  Round 6: through buffer descriptors -- X and alpha as byte ranges, one
+  // 32-bit offset per lane and a scalar offset per dimension: no address arithmetic, no bounds test and no branch per load (a dimension or
+  // a point beyond the range reads 0; a point beyond N inside X's range reads a neighbour's value against alpha = 0) -- and the loop
+  // unrolled by its three slab buffers, so that no register is moved: the loop body was 84 fp64 operations among 54 moves, 11 address
+  // computations and 11 exec-masked branches.
+  const __amdgpu_buffer_rsrc_t Xr = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((size_t)N * D * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t Ar = __builtin_amdgcn_make_buffer_rsrc((void*)al, 0, N * 8, 0x00020000);
   const int step = 16 * NW;
   int n = ni + 16 * wv;
-  double xc[DT], ac = 0.0;
+  auto load = [&](const int nidx, double (&x)[DT], double& aa) {
+    const int off = min(nidx, N) * 8;      // (a point beyond N: alpha's range ends at N -- it reads 0 -- and X yields some finite value)
 #pragma unroll
-  for (int d = 0; d < DT; ++d) xc[d] = (d < D && n < N) ? X[n + (size_t)N * d] : 0.0;
-  if (n < N) ac = al[n];
-  // (round 5) TWO slabs ahead: a slab's ~80 instructions of one wave are shorter than a load's round trip, so with one slab in flight the
-  // loop still waited for memory every trip (the role's dozen trips are most of its 14 us)
-  double xn[DT], an = 0.0;
-  {
-    const int n1 = n + step;
-#pragma unroll
-    for (int d = 0; d < DT; ++d) xn[d] = (d < D && n1 < N) ? X[n1 + (size_t)N * d] : 0.0;
-    if (n1 < N) an = al[n1];
-  }
-  while (n < N) {
-    const int nn = n + step, n2 = nn + step;
-    double x2[DT], a2n = 0.0;
-#pragma unroll
-    for (int d = 0; d < DT; ++d) x2[d] = (d < D && n2 < N) ? X[n2 + (size_t)N * d] : 0.0;
-    if (n2 < N) a2n = al[n2];
+    for (int d = 0; d < DT; ++d) x[d] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Xr, off, d * N * 8, 0));
+    aa = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Ar, off, 0, 0));
+  };
+  auto trip = [&](const double (&x)[DT], const double aa) {
     double dl[DT];
     double a2 = 0.0;
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
-      dl[d] = (mu[d] - xc[d]) * itau[d];  // delta_k :167
+      dl[d] = (mu[d] - x[d]) * itau[d];  // delta_k :167  (the reference's form: X is not centred here, mu_d / tau_d - x_d / tau_d would cancel)
       a2 = fma(dl[d], dl[d], a2);
     }
-    double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);  // z_k :168
-    double za = z * ac;
+    const double z = vb_exp_tab(lnnf - 0.5 * a2, TAB);  // z_k :168
+    const double za = z * aa;
     accI += za;
     if (want_grad) {
 #pragma unroll
@@ -108,10 +102,22 @@ __device__ __forceinline__ void lj_wave_sums(const ElboDims& dm, const double* _
         accQ[d] = fma(fma(dl[d], dl[d], -1.0), za, accQ[d]);      // :228, :249-250 without theirs
       }
     }
-#pragma unroll
-    for (int d = 0; d < DT; ++d) { xc[d] = xn[d]; xn[d] = x2[d]; }
-    ac = an; an = a2n;
-    n = nn;
+  };
+  double x0[DT], x1[DT], x2[DT], a0, a1, a2v;
+  load(n, x0, a0);
+  load(n + step, x1, a1);
+  while (n < N) {
+    load(n + 2 * step, x2, a2v);
+    trip(x0, a0);
+    n += step;
+    if (n >= N) break;
+    load(n + 2 * step, x0, a0);
+    trip(x1, a1);
+    n += step;
+    if (n >= N) break;
+    load(n + 2 * step, x1, a1);
+    trip(x2, a2v);
+    n += step;
   }
   accI = row16_sum(accI);
   if (want_grad) {
