@@ -654,9 +654,13 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
   // point tiles resident per workgroup: as many N x 16 tiles as the 160 KB hold beside the 2 KB table (three at N = 400)
   const int fused_pt = (int)std::min<size_t>(PREDF_PT_FOR_QS((D + 3) / 4), ((size_t)160 * 1024 - 2048 - (PREDF_THREADS / 64) * PREDF_MAXPT * 16 * 8 - 256) / ((size_t)Np * 16 * 8));
   const bool fused = !want_ks && !slab_pred && !fused_off && fused_pt >= 1 && (D + 3) / 4 <= 8;
+  // few points (the importance sampler's ~110 per call): RS workgroups per (hyper-sample, pass) unit share its row tiles (k_pred_fused)
+  int fused_rs = 1;
   if (fused) {
-    for (int s = 0; s < S; ++s) grp[s] = 1;      // k_pred_final: one block of partial sums per hyper-sample
-    maxg = 1;
+    const int units = ((ntile_ + fused_pt - 1) / fused_pt) * S;
+    fused_rs = std::max(1, std::min(std::min(4, nblk / 4), ctx->num_cu / std::max(1, units)));
+    for (int s = 0; s < S; ++s) grp[s] = fused_rs;      // k_pred_final: fused_rs blocks of partial sums per hyper-sample
+    maxg = fused_rs;
   }
   HIP_TRY(ctx, pb.dgrp.alloc(ctx, grp.size() * sizeof(int)));
   HIP_TRY(ctx, pb.dpV.alloc(ctx, (size_t)maxg * S * Nstar * 8));
@@ -666,11 +670,11 @@ vbmc_status pred_on_device(vbmc_ctx* ctx, const char* who, const vbmc_gp* gp, in
     const size_t fl = (size_t)fused_pt * Np * 16 * 8;
     const int npass = (ntile_ + fused_pt - 1) / fused_pt;
     // one workgroup per compute unit (its LDS is full), each walking the (hyper-sample, pass) units b, b + grid, ...
-    const int gxf = std::max(1, std::min(npass * S, ctx->num_cu));
+    const int gxf = std::max(1, std::min(npass * S * fused_rs, ctx->num_cu));
 #define PRED_FUSED_PT(QSV, PTV) { \
       if (fl > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_pred_fused<QSV, PTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
       hipLaunchKernelGGL((k_pred_fused<QSV, PTV>), dim3(gxf), dim3(PREDF_THREADS), fl, st, pa, dXc.as<double>(), daa.as<double>(), \
-                         dmuv.as<double>(), pb.dpV.as<double>(), pb.dpF.as<double>()); }
+                         dmuv.as<double>(), pb.dpV.as<double>(), pb.dpF.as<double>(), fused_rs); }
 #define PRED_FUSED(QSV) case QSV: \
       if (fused_pt >= 3) { if constexpr (PREDF_PT_FOR_QS(QSV) >= 3) PRED_FUSED_PT(QSV, 3) } \
       else if (fused_pt == 2) { if constexpr (PREDF_PT_FOR_QS(QSV) >= 2) PRED_FUSED_PT(QSV, 2) } \

@@ -747,21 +747,25 @@ __global__ void __launch_bounds__(PRED_THREADS, 4) k_gp_pred(PredArgs a, const d
 template <int QS, int PT>
 __global__ void __launch_bounds__(PREDF_THREADS, 1) k_pred_fused(PredArgs a, const double* __restrict__ Xc, const double* __restrict__ aa,
                                                                  const double* __restrict__ muv, double* __restrict__ partV,
-                                                                 double* __restrict__ partF) {
+                                                                 double* __restrict__ partF, const int RS) {
+  // RS > 1 (few points: the units do not cover the chip): RS workgroups share a unit -- each computes the unit's tiles (cheap) and takes
+  // every RS-th row tile of inv(L'); their partial sums are blocks rs of partV, which k_pred_final adds in block order.  The importance
+  // sampler's predictions of ~110 points were 60 workgroups walking 25 row tiles each: 74 us a call, 187 dependent calls.
   constexpr int NWV = PREDF_THREADS / 64;
   extern __shared__ double KsL[];              // [p][n][16], sW-scaled, zero for n >= N and for points beyond Nstar
   __shared__ double tab[VB_EXP_TAB_N];
   __shared__ double FMW[NWV][PT][16];          // fmu's data term per wave (its row blocks), added in wave order
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int N = a.N, D = a.D, Np = ((N + 15) >> 4) << 4, nblk = Np >> 4;
-  const int ntile = (a.Nstar + 15) >> 4, npass = (ntile + PT - 1) / PT, nunit = npass * a.S;
+  const int ntile = (a.Nstar + 15) >> 4, npass = (ntile + PT - 1) / PT, nunit = npass * a.S * RS;
   for (int t = tid; t < VB_EXP_TAB_N; t += PREDF_THREADS) tab[t] = c_exp2_tab[t];
   __syncthreads();
   // A workgroup's LDS is full -- two never share a compute unit -- so the grid is one workgroup per unit of the chip, each walking the
   // units (hyper-sample, pass) b, b + gridDim.x, ...: what a workgroup does once (launch, table) is paid once, the test points of the
   // next unit are in flight behind the current one, and at any moment the workgroups in flight share one or two hyper-samples' factors
   for (int unit = blockIdx.x; unit < nunit; unit += gridDim.x) {
-    const int s = unit / npass, pass = unit - s * npass;
+    const int rs = unit % RS, u2 = unit / RS;
+    const int s = u2 / npass, pass = u2 - s * npass;
     const int pt0 = pass * PT;
     const int npt = min(PT, ntile - pt0);
     const double* h = a.hyp + (size_t)s * a.Nhyp;
@@ -844,17 +848,18 @@ __global__ void __launch_bounds__(PREDF_THREADS, 1) k_pred_fused(PredArgs a, con
       const int p = tid >> 4, i = tid & 15, jc = (pt0 + p) * 16 + i;
       double fm = 0.0;
       for (int w = 0; w < NWV; ++w) fm += FMW[w][p][i];
-      if (jc < a.Nstar) partF[(size_t)s * a.Nstar + jc] = fm;
+      if (jc < a.Nstar && rs == 0) partF[(size_t)s * a.Nstar + jc] = fm;
     }
     // ---- the product: this wave's row tiles against the PT resident tiles
     double part[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) part[p] = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-      // unit k (descending cost) -> SIMD class in snake order, wave within the class in turn
+    for (int k0 = rs; k0 < nblk; k0 += RS) {
+      // this workgroup's row tiles k0 = rs, rs + RS, .. (descending cost); the i-th of them -> SIMD class in snake order, wave within the class in turn
+      const int k = k0 / RS;
       const int kq = k & 7, cls = kq < 4 ? kq : 7 - kq, wsel = cls + 4 * ((k >> 2) % (NWV / 4));
       if (wsel != wave) continue;
-      const int rt = nblk - 1 - k;
+      const int rt = nblk - 1 - k0;
       const int ncol = lc ? (rt + 1) * 16 : Np;
       const int row = rt * 16 + li;
       const bool rv = row < N;
@@ -929,7 +934,7 @@ __global__ void __launch_bounds__(PREDF_THREADS, 1) k_pred_fused(PredArgs a, con
       const int p = tid >> 4, i = tid & 15, jc = (pt0 + p) * 16 + i;
       double v = 0.0;
       for (int w = 0; w < NWV; ++w) v += KsL[(w * PREDF_MAXPT + p) * 16 + i];
-      if (jc < a.Nstar) partV[(size_t)s * a.Nstar + jc] = v;
+      if (jc < a.Nstar) partV[((size_t)rs * a.S + s) * a.Nstar + jc] = v;
     }
     __syncthreads();      // the next unit writes the tiles
   }
